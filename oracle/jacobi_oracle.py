@@ -1,0 +1,924 @@
+"""CPU oracle: a plain-Python/numpy restatement of the reference's Jacobi decoding loop.
+
+TEST INFRASTRUCTURE ONLY.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this module; the product package ``jacobiforcing_amd`` never
+does (its HIP path fails loudly when the extension is missing).
+
+Parity status: PINNED.  Every function below is checked bit-for-bit against golden vectors
+produced by running the unmodified reference in the build container
+(``tests/golden/gen_golden.py`` -> ``tests/golden/*.json``; checked by
+``tests/test_oracle_golden.py``).  The reference ships no golden vectors of its own
+(SURVEY.md §4).
+
+Citations use the SURVEY abbreviations (paths relative to the reference root):
+  MB  = modeling/cllm2_qwen2_modeling_kv_terminate_on_eos_improved_multiblock_lookahead_unified.py
+  SB  = modeling/cllm2_qwen2_modeling_kv_terminate_on_eos_improved.py
+  JD  = inference_engine/engine/jacobi_decoding.py
+  JDN = inference_engine/engine/jacobi_decoding_nongreedy.py
+  MR  = inference_engine/engine/model_runner.py
+  BM  = inference_engine/engine/block_manager.py
+"""
+from __future__ import annotations
+
+import math
+from collections import deque
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+Rows = List[List[int]]
+
+
+# ======================================================================================
+# a2 — block-local argmax with torch.argmax semantics (MB:476, SB:197, JD:357/567)
+# ======================================================================================
+def argmax_rows(logits: np.ndarray) -> np.ndarray:
+    """Row-wise argmax of a [R, V] float array with torch semantics: the first index of
+    the maximum; NaN compares greater than everything (first NaN wins); -0.0 == +0.0."""
+    x = np.asarray(logits)
+    if x.dtype != np.float32 and x.dtype != np.float64:
+        x = x.astype(np.float32)
+    R = x.shape[0]
+    out = np.empty((R,), dtype=np.int64)
+    nan = np.isnan(x)
+    has_nan = nan.any(axis=1)
+    with np.errstate(invalid="ignore"):
+        am = np.argmax(np.where(nan, -np.inf, x), axis=1)
+    out[:] = am
+    if has_nan.any():
+        out[has_nan] = np.argmax(nan[has_nan], axis=1)
+    return out
+
+
+def bf16_bits_to_f32(bits: np.ndarray) -> np.ndarray:
+    """uint16 bf16 payloads -> float32 values."""
+    b = np.asarray(bits).astype(np.uint32) << np.uint32(16)
+    return b.view(np.float32)
+
+
+def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    """float32 -> bf16 payload, round-to-nearest-even (torch .to(bfloat16))."""
+    u = np.asarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    nan = np.isnan(np.asarray(x, dtype=np.float32))
+    r = ((u + np.uint64(0x7FFF) + ((u >> np.uint64(16)) & np.uint64(1))) >> np.uint64(16)).astype(np.uint16)
+    r[nan] = np.uint16(0x7FC0)
+    return r
+
+
+# ======================================================================================
+# a3 — token equality + accepted-prefix scan (MB:482-486, SB:199-200, JD:253-293)
+# ======================================================================================
+def accept_lengths(draft: Rows, greedy: Rows) -> List[int]:
+    """accepted[b] = 1 + number of leading positions i with draft[b][i+1] == greedy[b][i].
+    ``draft`` may have one row broadcast against B greedy rows (MB:482)."""
+    B = max(len(draft), len(greedy))
+    if len(draft) not in (1, B) or len(greedy) not in (1, B):
+        raise ValueError(f"cannot broadcast draft rows {len(draft)} against greedy rows {len(greedy)}")
+    acc = []
+    for b in range(B):
+        d = draft[b if len(draft) > 1 else 0]
+        g = greedy[b if len(greedy) > 1 else 0]
+        k = 0
+        L = len(d)
+        while k < L - 1 and d[k + 1] == g[k]:
+            k += 1
+        acc.append(k + 1)
+    return acc
+
+
+def first_max_index(vals: Sequence[int]) -> int:
+    """torch.argmax on an int vector: first index of the maximum (MB:489)."""
+    best, bi = None, 0
+    for i, v in enumerate(vals):
+        if best is None or v > best:
+            best, bi = v, i
+    return bi
+
+
+# ======================================================================================
+# a8 — rejection recycling candidate build (MB:62-91)
+# ======================================================================================
+def build_candidates(pool: Sequence[List[int]], token_val: int, out_row: List[int]) -> Rows:
+    cands: Rows = []
+    L_out = len(out_row)
+    for seq in reversed(list(pool)[:-1]):          # newest entry skipped (MB:74)
+        pos = -1
+        for i, t in enumerate(seq):
+            if t == token_val:
+                pos = i
+                break
+        if pos < 0:
+            continue
+        cand = list(seq[pos:])
+        if len(cand) > L_out:
+            cand = cand[:L_out]
+        elif len(cand) < L_out:
+            cand = cand + out_row[len(cand):L_out]  # pad with the current draft's tail (MB:84-86)
+        cands.append(cand)
+    return cands
+
+
+# ======================================================================================
+# a1 — multiblock Jacobi generation call as an explicit state machine (MB:227-740)
+# ======================================================================================
+class MultiblockOracle:
+    """State machine of one ``jacobi_forward_greedy_multiblock`` generation call.
+
+    Usage::
+
+        st = MultiblockOracle(input_ids, kv_tokens, n=..., K=..., ...)
+        while (step := st.begin_iteration()) is not None:
+            out_rows, spans = step
+            greedy = forward(st.kv_rows_before_forward, out_rows)   # [B][T]
+            st.end_iteration(greedy)
+            if st.done: break
+        st.finalize()
+        st.ret, st.next_token, st.iters, st.kv_tokens
+    """
+
+    def __init__(self, input_ids: List[int], kv_tokens: List[int], *, n: int, K: int = 2, r: float = 0.85,
+                 lookahead_start_ratio: float = 0.0, n_gram_pool_size: int = 4,
+                 eos_token_id: Optional[int] = None, pad_token_id: Optional[int] = None,
+                 max_iteration_count: int = 128):
+        self.n, self.K, self.r = int(n), int(K), r
+        self.lookahead = lookahead_start_ratio
+        self.eos_id, self.pad_id = eos_token_id, pad_token_id
+        self.eos_enabled = eos_token_id is not None
+        self.max_iter = int(max_iteration_count)
+        self.pool: deque = deque(maxlen=n_gram_pool_size)            # MB:238
+        # block state (MB:249-257)
+        self.out_acc: Rows = [[]]
+        self.q_draft: List[Rows] = [[list(input_ids)]]
+        self.need_reverify: List[bool] = [False]
+        self.total_acc: List[int] = [0]
+        self.num_blocks = 1
+        self.active_blocks = 1
+        self.RA = 0
+        self.last_next_token: Optional[int] = None                    # MB:259 (empty tensor)
+        self.kv_rows: Rows = [list(kv_tokens)]                        # cache rows (token content)
+        self.prompt_len = len(kv_tokens)                              # MB:261
+        self.spawn_threshold = math.ceil(r * n)                       # MB:262
+        self.iters = 0
+        self.done = False
+        self.returned_early = False
+        self.ret: List[int] = []
+        self.next_token: Optional[int] = None
+        self.banners: List[str] = []
+        self._spans: List[Tuple[int, int, int]] = []
+        self._out: Rows = []
+
+    # -- helpers -------------------------------------------------------------------
+    def kv_len(self) -> int:
+        return len(self.kv_rows[0])
+
+    def _kv_trim(self, num_false: int) -> None:                        # MB:36-59
+        if num_false <= 0:
+            return
+        new_len = max(0, self.kv_len() - num_false)
+        self.kv_rows = [row[:new_len] for row in self.kv_rows]
+
+    def _kv_resize(self, new_B: int) -> None:                          # MB:93-127
+        cur = len(self.kv_rows)
+        if cur == new_B:
+            return
+        if new_B > cur:
+            if cur == 1:
+                self.kv_rows = [list(self.kv_rows[0]) for _ in range(new_B)]
+            else:
+                reps = (new_B + cur - 1) // cur
+                self.kv_rows = [list(r) for r in (self.kv_rows * reps)[:new_B]]
+        else:
+            self.kv_rows = self.kv_rows[:new_B]
+
+    def _committed_len(self, cur_RA: int) -> int:                      # MB:264-271
+        c = self.prompt_len
+        for b in range(self.num_blocks):
+            if b != cur_RA and not self.need_reverify[b]:
+                c += len(self.out_acc[b])
+        return c + len(self.out_acc[cur_RA])
+
+    @staticmethod
+    def _ensure_batch(rows: Rows, B: int) -> Rows:                     # MB:288-312
+        if not rows or len(rows[0]) == 0:
+            return [[] for _ in range(B)]
+        cur = len(rows)
+        if cur == B:
+            return rows
+        if cur == 1:
+            return [list(rows[0]) for _ in range(B)]
+        reps = (B + cur - 1) // cur
+        return [list(r) for r in (rows * reps)[:B]]
+
+    def _concat_all_blocks_seq(self) -> List[int]:                     # MB:387-411
+        seq: List[int] = []
+        for bb in range(self.num_blocks):
+            seq += self.out_acc[bb]
+            q = self.q_draft[bb]
+            if q and len(q[0]) > 0:
+                seq += q[0]
+        if self.pad_id is not None:
+            seq = [t for t in seq if t != self.pad_id]
+        return seq
+
+    def _final_ret(self) -> List[int]:                                 # MB:533-537 / 602-606 / 725-730
+        ret: List[int] = []
+        for bb in range(self.num_blocks):
+            if bb != self.RA and not self.need_reverify[bb] and len(self.out_acc[bb]) > 0:
+                ret += self.out_acc[bb]
+        return ret + self.out_acc[self.RA]
+
+    def _return(self, next_token: int) -> None:
+        self.ret = self._final_ret()
+        td = self.kv_len() - (self.prompt_len + len(self.ret))         # MB:540-543
+        if td > 0:
+            self._kv_trim(td)
+        self.next_token = next_token
+        self.done = True
+        self.returned_early = True
+
+    # -- iteration -------------------------------------------------------------------
+    def begin_iteration(self):
+        """MB:414-422.  Returns (out rows [B][T], spans) or None when the loop ends."""
+        if self.done or self.iters >= self.max_iter:
+            return None
+        self.iters += 1
+        RA = self.RA
+        ra_rows = self.q_draft[RA]
+        B_ra = len(ra_rows)
+        pieces: List[Rows] = []
+        spans: List[Tuple[int, int, int]] = []
+        cursor = 1
+        L_ra = len(ra_rows[0]) if ra_rows else 0
+        if L_ra > 0:
+            pieces.append(ra_rows)
+            spans.append((RA, cursor, L_ra))
+            cursor += L_ra
+        for b in range(self.num_blocks):
+            if b == RA or not self.need_reverify[b]:
+                continue
+            L_acc = len(self.out_acc[b])
+            if L_acc > 0:
+                pieces.append(self._ensure_batch([self.out_acc[b]], B_ra))
+                cursor += L_acc
+            q = self.q_draft[b]
+            L_tail = len(q[0]) if q else 0
+            if L_tail > 0:
+                pieces.append(self._ensure_batch(q, B_ra))
+                spans.append((b, cursor, L_tail))
+                cursor += L_tail
+        out: Rows = [[] for _ in range(B_ra)]
+        for p in pieces:
+            for i in range(B_ra):
+                out[i] = out[i] + list(p[i])
+        if B_ra == 0 or len(out[0]) == 0:
+            self.iters_break_empty = True
+            return None                                                # MB:418-419 (iters already counted)
+        self._kv_resize(len(out))                                      # MB:421-422
+        self._out, self._spans = out, spans
+        return out, spans
+
+    def end_iteration(self, greedy_all: Rows) -> None:
+        """MB:428-721 after the forward: ``greedy_all[b][t]`` = argmax of logits[b, t]."""
+        n, RA = self.n, self.RA
+        out = self._out
+        B = len(out)
+        assert len(greedy_all) == B and all(len(g) == len(out[0]) for g in greedy_all)
+        # the forward appended every row's tokens to its cache row (DynamicCache.update)
+        self.kv_rows = [self.kv_rows[b] + list(out[b]) for b in range(B)]
+
+        for (b, start, L) in self._spans:
+            greedy = [g[start - 1:start - 1 + L] for g in greedy_all]                   # MB:473-476
+            draft = self.q_draft[b]
+            accepted = accept_lengths(draft, greedy)                                     # MB:482-486
+            best_idx = first_max_index(accepted) if b == self.RA else 0                  # MB:487-491
+            acc_len_raw = accepted[best_idx]
+            draft_row = list(draft[best_idx])                                            # MB:496 (IndexError if rows<=best)
+            g = list(greedy[best_idx])
+            self.kv_rows = [self.kv_rows[best_idx]]                                      # MB:500-502
+            L_eff = len(draft_row)
+            if L_eff == 0:
+                continue
+            acc_len = acc_len_raw
+            eos_reached = False
+            if self.eos_enabled and b == self.RA and acc_len > 0:                        # MB:513-521
+                for i in range(acc_len):
+                    if draft_row[i] == self.eos_id:
+                        acc_len = i + 1
+                        eos_reached = True
+                        break
+            has_rejected = acc_len < L_eff
+            if acc_len > 0:                                                              # MB:526-528
+                self.out_acc[b] = self.out_acc[b] + draft_row[:acc_len]
+                self.total_acc[b] += acc_len
+            if eos_reached and b == self.RA:                                             # MB:531-547
+                self._return(draft_row[acc_len - 1])
+                return
+            if has_rejected:                                                             # MB:550-588
+                nxt = g[max(acc_len - 1, 0)]
+                self.q_draft[b] = [[nxt] + g[acc_len:-1]]
+                if b == self.RA:
+                    concat_seq = self._concat_all_blocks_seq()
+                    if len(concat_seq) > 0:
+                        self.pool.append(concat_seq)
+                    tail = g[acc_len:-1]
+                    if len(tail) > 0:
+                        self.pool.append(list(tail))
+                    if self.total_acc[b] / n >= self.lookahead:                          # MB:577 (float division)
+                        cands = build_candidates(self.pool, nxt, self.q_draft[b][0])
+                        if len(cands) > 1:                                               # MB:579 (Q5)
+                            self.q_draft[b] = [self.q_draft[b][0]] + cands
+                            self._kv_resize(len(self.q_draft[b]))                        # MB:585
+            else:                                                                        # MB:590-593
+                self.q_draft[b] = [[]]
+                nxt = g[-1]
+            if b == self.RA:
+                self.last_next_token = nxt
+            if self.eos_enabled and b == self.RA and self.last_next_token == self.eos_id:  # MB:599-614
+                self.out_acc[b] = self.out_acc[b] + [self.last_next_token]
+                self._return(self.last_next_token)
+                return
+
+        # MB:617-626 keep exactly the committed length
+        self._kv_trim(self.kv_len() - self._committed_len(self.RA))
+
+        # MB:629-653 spawn
+        newest = self.num_blocks - 1
+        if self.total_acc[newest] >= self.spawn_threshold and self.active_blocks < self.K:
+            if self.pad_id is None:
+                raise ValueError("pad_token_id must be provided when spawning pseudo-active blocks.")
+            self.banners.append("spawn")
+            ra_rows = self.q_draft[self.RA]
+            L_ra = len(ra_rows[0]) if ra_rows else 0
+            pad_len = max(0, n - L_ra)
+            self.q_draft.append([list(row) + [self.pad_id] * pad_len for row in ra_rows])
+            self.out_acc.append([])
+            self.total_acc.append(0)
+            self.need_reverify.append(True)
+            self.num_blocks += 1
+            self.active_blocks += 1
+
+        # MB:656-716 promote
+        if self.total_acc[self.RA] >= n:
+            for b in range(self.num_blocks):
+                if self.need_reverify[b] and self.total_acc[b] > 0:
+                    self.banners.append("switch")
+                    acc_pref = self.out_acc[b]
+                    tail_rows = self.q_draft[b]
+                    if len(acc_pref) > 0 and len(tail_rows) != 1:
+                        raise RuntimeError("cat of [1,a] with multi-row tail")            # torch.cat would raise
+                    q_full = acc_pref + list(tail_rows[0]) if len(acc_pref) > 0 else list(tail_rows[0])
+                    assert len(q_full) == n, f"draft size mismatch: draft at {len(q_full)} vs. n_token_seq_len {n}"
+                    self.out_acc[b] = []
+                    self.total_acc[b] = 0
+                    lnt = [] if self.last_next_token is None else [self.last_next_token]
+                    self.q_draft[b] = [lnt + q_full[1:]]
+                    self.need_reverify[b] = False
+                    self.RA = b
+                    self._kv_trim(self.kv_len() - self._committed_len(self.RA))
+                    self.active_blocks -= 1
+                    self.num_blocks -= 1                                                 # Q3: lists keep their entries
+                    break
+                self.active_blocks -= 1                                                  # Q4
+
+        # MB:719-721 early stop
+        if all(self.total_acc[b] >= n for b in range(self.num_blocks)):
+            self.banners.append("early_stop")
+            self.done = True
+
+    def finalize(self) -> None:
+        """MB:723-740 (only when the loop was left without an in-loop return)."""
+        if self.returned_early:
+            return
+        ret: List[int] = []
+        for b in range(self.num_blocks):
+            if b != self.RA and not self.need_reverify[b] and len(self.out_acc[b]) > 0:
+                ret += self.out_acc[b]
+        if len(self.out_acc[self.RA]) > 0:
+            ret += self.out_acc[self.RA]
+        self.ret = ret
+        td = self.kv_len() - (self.prompt_len + len(ret))
+        if td > 0:
+            self._kv_trim(td)
+        self.next_token = self.last_next_token
+        self.done = True
+
+    @property
+    def kv_tokens(self) -> List[int]:
+        return self.kv_rows[0]
+
+
+ForwardFn = Callable[[Rows, Rows], Rows]   # (kv_rows [B][S], out_rows [B][T]) -> greedy [B][T]
+
+
+def mb_generation_call(forward: ForwardFn, input_ids: List[int], kv_tokens: List[int], **kw):
+    """One generation call; returns the state object (ret, next_token, iters, kv_tokens)."""
+    st = MultiblockOracle(input_ids, kv_tokens, **kw)
+    trace = []
+    while True:
+        step = st.begin_iteration()
+        if step is None:
+            break
+        out, spans = step
+        kv_before = [list(r) for r in st.kv_rows]
+        greedy = forward(kv_before, out)
+        trace.append(dict(kv_len=len(kv_before[0]), out=[list(r) for r in out], greedy=[list(g) for g in greedy],
+                          spans=list(spans)))
+        st.end_iteration(greedy)
+        if st.done:
+            break
+    st.finalize()
+    st.trace = trace
+    return st
+
+
+def mb_prefill(forward: ForwardFn, prompt: List[int], draft: List[int]):
+    """MB:175-225: forward prompt ⧺ draft, n-gram = argmax(logits[:, -n-1:-1]), KV cut back to the prompt."""
+    n = len(draft)
+    greedy = forward([[]], [list(prompt) + list(draft)])[0]
+    ngram = greedy[-n - 1:-1] if n > 0 else []
+    return ngram, list(prompt)
+
+
+# ======================================================================================
+# a14 — HF single-block Jacobi generation call (SB:140-276)
+# ======================================================================================
+def sb_generation_call(forward: ForwardFn, input_ids: List[int], kv_tokens: List[int], *, n: int,
+                       eos_token_id: Optional[int] = None):
+    eos_enabled = eos_token_id is not None
+    kv = list(kv_tokens)
+    out = list(input_ids)
+    accepted_n_gram = list(input_ids)          # aliases the input buffer (SB:145); writes past the end are dropped
+    total_accepted = 0
+    itr = 0
+    next_token = None
+    trace = []
+
+    def write(pos, toks):
+        for j, t in enumerate(toks):
+            if pos + j < len(accepted_n_gram):
+                accepted_n_gram[pos + j] = t
+
+    while total_accepted < n:
+        itr += 1
+        greedy_all = forward([kv], [out])[0]
+        trace.append(dict(kv_len=len(kv), out=list(out), greedy=list(greedy_all)))
+        kv = kv + out
+        L = len(out)
+        greedy = greedy_all[:-1]                                                        # SB:197
+        k = 0
+        while k < L - 1 and out[k + 1] == greedy[k]:
+            k += 1
+        num_accepted_raw = k + 1                                                        # SB:199-202
+        num_accepted = num_accepted_raw
+        if eos_enabled:
+            for i in range(num_accepted_raw):
+                if out[i] == eos_token_id:
+                    num_accepted = i + 1
+                    break
+        if num_accepted > 0:
+            write(total_accepted, out[:num_accepted])                                   # SB:215
+        total_accepted += num_accepted
+        if eos_enabled and eos_token_id in out[:num_accepted]:                          # SB:219-227
+            to_delete = max(0, len(kv) - total_accepted)
+            if to_delete > 0:
+                kv = kv[:len(kv) - to_delete]
+            return dict(ret=accepted_n_gram[:total_accepted], next_token=eos_token_id, iters=itr, kv_tokens=kv,
+                        trace=trace)
+        if num_accepted_raw < L:                                                        # SB:231-255
+            kv = kv[:len(kv) - (L - num_accepted_raw)]
+            next_token = greedy_all[num_accepted_raw - 1]
+            if eos_enabled and next_token == eos_token_id:
+                write(total_accepted, [next_token])
+                total_accepted += 1
+                to_delete = max(0, len(kv) - total_accepted)
+                if to_delete > 0:
+                    kv = kv[:len(kv) - to_delete]
+                return dict(ret=accepted_n_gram[:total_accepted], next_token=next_token, iters=itr, kv_tokens=kv,
+                            trace=trace)
+            out = [next_token] + greedy_all[num_accepted_raw:-1]
+        else:                                                                           # SB:258-273
+            next_token = greedy_all[-1]
+            write(total_accepted, [next_token])
+            total_accepted += 1
+            if eos_enabled and next_token == eos_token_id:
+                to_delete = max(0, len(kv) - total_accepted)
+                if to_delete > 0:
+                    kv = kv[:len(kv) - to_delete]
+                return dict(ret=accepted_n_gram[:total_accepted], next_token=next_token, iters=itr, kv_tokens=kv,
+                            trace=trace)
+    return dict(ret=accepted_n_gram[:total_accepted], next_token=next_token, iters=itr, kv_tokens=kv, trace=trace)
+
+
+# ======================================================================================
+# a15/a16/a17 — engine single-block decoder (JD:302-724) with the caller side (MR:1157-1199,
+# 1407-1408) and block-manager bookkeeping (BM:267-276, 534-564) reduced to their integers
+# ======================================================================================
+class OracleSeq:
+    """The integers of ``Sequence`` + block-table length the Jacobi path touches (SEQ:14-156)."""
+
+    def __init__(self, prompt: List[int], block_len: int, max_tokens: int, max_iters: int = 128,
+                 prefill_draft: Optional[List[int]] = None, block_size: int = 256):
+        self.token_ids = list(prompt)
+        self.num_prompt_tokens = len(prompt)
+        self.num_cached_tokens = len(prompt)
+        self.block_len, self.max_tokens, self.max_iters = block_len, max_tokens, max_iters
+        self.prefill_draft = prefill_draft
+        self.block_size = block_size
+        self.num_table_blocks = (len(prompt) + block_size - 1) // block_size     # BlockManager.allocate
+        self.num_permanent_spec_blocks = 0
+
+    def __len__(self):
+        return len(self.token_ids)
+
+    @property
+    def num_completion_tokens(self):
+        return len(self.token_ids) - self.num_prompt_tokens
+
+    def grow_for_draft(self, L: int) -> None:                                   # MR:1166-1198
+        S = len(self)
+        need = (S + L - 1 + self.block_size - 1) // self.block_size
+        committed = (S + self.block_size - 1) // self.block_size
+        self.num_table_blocks = need                                             # truncate or extend
+        self.num_permanent_spec_blocks = max(self.num_permanent_spec_blocks, need - committed)
+
+    def trim_kv_only_fast(self, num_tokens: int) -> None:                       # BM:534-564
+        if num_tokens <= 0:
+            return
+        new_cached = max(len(self), self.num_cached_tokens - num_tokens)
+        self.num_cached_tokens = new_cached
+        blocks_needed = (new_cached + self.block_size - 1) // self.block_size if new_cached > 0 else 0
+        keep = blocks_needed + self.num_permanent_spec_blocks
+        if self.num_table_blocks > keep:
+            self.num_table_blocks = keep
+
+
+EngineForward = Callable[[List[OracleSeq], Rows], List[Rows]]
+# (seqs, draft [B][L]) -> greedy [B][L-1]  (argmax of logits[:, :-1], MR:1413-1416)
+
+
+def _engine_next_draft(seq: OracleSeq, L: int, acc_len: int, greedy: List[int], pads: Callable[[int], List[int]]):
+    """JD:414-436 / JD:673-709."""
+    d = [seq.token_ids[-1]]
+    if acc_len < L:
+        remaining = greedy[1:] if acc_len == 1 else greedy[acc_len - 1:]
+        copy_len = min(len(remaining), L - 1)
+        d += remaining[:copy_len]
+    else:
+        d += [greedy[-1]]
+        copy_len = 1
+    if copy_len < L - 1:
+        d += pads(L - 1 - copy_len)
+    return d
+
+
+def _engine_first_draft(seq: OracleSeq, L: int, pads):
+    """JD:332-347 / JD:529-546 (prefill draft) and JD:142-171 (random init)."""
+    d = [seq.token_ids[-1]]
+    if seq.prefill_draft is not None:
+        pl = min(len(seq.prefill_draft), L - 1)
+        d += list(seq.prefill_draft[:pl])
+        if pl < L - 1:
+            d += pads(L - 1 - pl)
+        seq.prefill_draft = None
+    else:
+        if L > 1:
+            d += pads(L - 1)
+    return d
+
+
+def _engine_commit_row(seq: OracleSeq, L: int, draft: List[int], greedy: List[int], eos_id: Optional[int]):
+    """JD:357-399 / JD:589-649: returns (acc_len, new_tokens, eos_reached)."""
+    k = 0
+    while k < L - 1 and draft[k + 1] == greedy[k]:
+        k += 1
+    acc_len = max(1, min(k + 1, L))
+    eos = False
+    if eos_id is not None and acc_len > 1:
+        for i in range(1, acc_len):
+            if draft[i] == eos_id:
+                acc_len = 1 + (i - 1) + 1
+                eos = True
+                break
+    num_spec = acc_len - 1
+    new: List[int] = []
+    if num_spec > 0:
+        new += draft[1:acc_len]
+        seq.token_ids += draft[1:acc_len]
+    if acc_len == 1:
+        nt = greedy[0]
+        seq.token_ids.append(nt)
+        new.append(nt)
+        num_spec = 1
+        if eos_id is not None and nt == eos_id:
+            eos = True
+    seq.trim_kv_only_fast(L - 1 - num_spec)
+    if len(seq) != seq.num_cached_tokens:
+        raise RuntimeError(f"Invariant violated: len(token_ids)={len(seq)} != num_cached_tokens={seq.num_cached_tokens}")
+    return acc_len, new, eos
+
+
+def engine_generate_single(forward: EngineForward, seq: OracleSeq, eos_id: Optional[int],
+                           pads: Callable[[int], List[int]], stats: Optional[dict] = None) -> List[int]:
+    """JD:302-445."""
+    L = seq.block_len
+    max_tokens = seq.max_tokens - seq.num_completion_tokens
+    if L <= 1:
+        return []
+    accepted: List[int] = []
+    q: Optional[List[int]] = None
+    eos_reached = False
+    iters = 0
+    while not eos_reached and len(accepted) < max_tokens and iters < seq.max_iters:
+        iters += 1
+        if q is None:
+            q = _engine_first_draft(seq, L, pads)
+        else:
+            q[0] = seq.token_ids[-1]                                             # JD:197-199
+        seq.grow_for_draft(L)
+        greedy = forward([seq], [q])[0]
+        seq.num_cached_tokens = len(seq) - 1 + L                                 # MR:1407-1408
+        acc_len, new, eos = _engine_commit_row(seq, L, q, greedy, eos_id)
+        eos_reached = eos_reached or eos
+        accepted += new
+        if eos_reached or len(accepted) >= max_tokens:
+            break
+        q = _engine_next_draft(seq, L, acc_len, greedy, pads)
+    if stats is not None:
+        stats["num_chunk_calls"] += 1
+        stats["num_jacobi_iterations"] += iters
+        stats["tokens_accepted"] += len(accepted)
+        stats["tokens_per_call"].append(len(accepted))
+        stats["iterations_per_call"].append(iters)
+    return accepted
+
+
+def new_stats() -> dict:
+    return dict(num_chunk_calls=0, num_jacobi_iterations=0, tokens_accepted=0, tokens_per_call=[],
+                tokens_per_iteration=[], iterations_per_call=[])
+
+
+def engine_generate_batch(forward: EngineForward, seqs: List[OracleSeq], eos_id: Optional[int],
+                          pads: Callable[[int], List[int]], stats: Optional[dict] = None) -> List[List[int]]:
+    """JD:447-724 (group by L, larger groups first, one stats iteration per batch step)."""
+    if not seqs:
+        return []
+    if len(seqs) == 1:
+        return [engine_generate_single(forward, seqs[0], eos_id, pads, stats)]
+    B = len(seqs)
+    accepted: List[List[int]] = [[] for _ in range(B)]
+    q: List[Optional[List[int]]] = [None] * B
+    eos_reached = [False] * B
+    iters = [0] * B
+    max_tokens = [max(0, s.max_tokens - s.num_completion_tokens) for s in seqs]
+    n_iter_call = 0
+    prev_len = [0] * B
+    while True:
+        active = [i for i in range(B) if not eos_reached[i] and len(accepted[i]) < max_tokens[i]
+                  and iters[i] < seqs[i].max_iters]
+        if not active:
+            break
+        groups: Dict[int, List[int]] = {}
+        for i in active:
+            if seqs[i].block_len > 1:
+                groups.setdefault(seqs[i].block_len, []).append(i)
+        if not groups:
+            break
+        n_iter_call += 1
+        tokens_this_iter = 0
+        for L, idxs in sorted(groups.items(), key=lambda x: len(x[1]), reverse=True):
+            drafts = []
+            for i in idxs:
+                iters[i] += 1
+                if q[i] is None:
+                    q[i] = _engine_first_draft(seqs[i], L, pads)
+                else:
+                    q[i][0] = seqs[i].token_ids[-1]
+                drafts.append(q[i])
+            for i in idxs:
+                seqs[i].grow_for_draft(L)
+            greedy = forward([seqs[i] for i in idxs], drafts)
+            for i in idxs:
+                seqs[i].num_cached_tokens = len(seqs[i]) - 1 + L
+            for row, i in enumerate(idxs):
+                acc_len, new, eos = _engine_commit_row(seqs[i], L, drafts[row], greedy[row], eos_id)
+                if eos:
+                    eos_reached[i] = True
+                accepted[i] += new
+                tokens_this_iter += len(accepted[i]) - prev_len[i]
+                prev_len[i] = len(accepted[i])
+                if eos_reached[i] or len(accepted[i]) >= max_tokens[i]:
+                    q[i] = None
+                    continue
+                q[i] = _engine_next_draft(seqs[i], L, acc_len, greedy[row], pads)
+        if stats is not None:
+            stats["tokens_per_iteration"].append(tokens_this_iter)
+    if stats is not None:
+        tot = sum(len(a) for a in accepted)
+        stats["num_chunk_calls"] += 1
+        stats["num_jacobi_iterations"] += n_iter_call
+        stats["tokens_accepted"] += tot
+        stats["tokens_per_call"].append(tot)
+        stats["iterations_per_call"].append(n_iter_call)
+    return accepted
+
+
+# ======================================================================================
+# a19 — non-greedy rejection-sampling verify (JDN:299-354) with injected randomness
+# ======================================================================================
+def softmax_rows_f32(logits: np.ndarray, temperature: float) -> np.ndarray:
+    """JDN:65-70 in fp32: p = softmax(logits / T) (T<=0 treated as 1)."""
+    x = np.asarray(logits, dtype=np.float32)
+    t = np.float32(1.0 if (temperature is None or temperature <= 0) else temperature)
+    if t != np.float32(1.0):
+        x = x / t
+    m = x.max(axis=-1, keepdims=True)
+    e = np.exp(x - m, dtype=np.float32)
+    return (e / e.sum(axis=-1, keepdims=True, dtype=np.float32)).astype(np.float32)
+
+
+def inverse_cdf_sample(probs: np.ndarray, u: float) -> int:
+    """The injected stand-in for torch.multinomial used on both sides of the parity test:
+    smallest index whose float64 running sum exceeds u * total (clamped to V-1)."""
+    c = np.cumsum(probs.astype(np.float64))
+    idx = int(np.searchsorted(c, u * float(c[-1]), side="right"))
+    return min(idx, probs.shape[0] - 1)
+
+
+def rs_verify_row(draft_row: List[int], probs: np.ndarray, eos_id: Optional[int],
+                  next_uniform: Callable[[], float], next_bonus_uniform: Callable[[], float]):
+    """JDN:315-354.  probs: [L-1, V] target distribution.  Returns (committed, num_keep_for_kv, eos)."""
+    L = len(draft_row)
+    if L <= 1:
+        return [], 0, False
+    committed: List[int] = []
+    eos = False
+    for t in range(L - 1):
+        proposed = int(draft_row[t + 1])
+        p_x = float(probs[t, proposed])
+        u = float(next_uniform())
+        if u < p_x:
+            committed.append(proposed)
+            if eos_id is not None and proposed == eos_id:
+                eos = True
+                break
+            continue
+        bonus = None
+        for _ in range(16):                                                     # JDN:136-146
+            y = inverse_cdf_sample(probs[t], next_bonus_uniform())
+            if y != proposed:
+                bonus = y
+                break
+        if bonus is None:                                                       # JDN:147-153
+            p2 = probs[t].copy()
+            p2[proposed] = 0.0
+            bonus = proposed if float(p2.sum()) <= 0 else int(argmax_rows(p2[None, :])[0])
+        committed.append(int(bonus))
+        if eos_id is not None and int(bonus) == eos_id:
+            eos = True
+        break
+    return committed, len(committed), eos
+
+
+NonGreedyForward = Callable[[List[OracleSeq], Rows], List[np.ndarray]]
+# (seqs, draft [B][L]) -> logits per row, each [L-1, V] float32 (MR:1413-1416)
+
+
+def _ng_next_draft(seq: OracleSeq, L: int, n_committed: int, greedy: List[int], pads):
+    """JDN:444-466 / JDN:619-638 (same shape as the greedy decoder's next draft)."""
+    return _engine_next_draft(seq, L, 1 + n_committed, greedy, pads)
+
+
+def _ng_commit(seq: OracleSeq, L: int, committed: List[int], num_keep: int):
+    """JDN:417-437 / JDN:592-612."""
+    if committed:
+        seq.token_ids += committed
+    seq.trim_kv_only_fast((L - 1) - num_keep)
+    if len(seq) != seq.num_cached_tokens:
+        raise RuntimeError(f"Invariant violated: len(token_ids)={len(seq)} != num_cached_tokens={seq.num_cached_tokens}")
+
+
+def nongreedy_generate_single(forward: NonGreedyForward, seq: OracleSeq, eos_id: Optional[int], temperature: float,
+                              pads, next_uniform, next_bonus_uniform, stats: Optional[dict] = None):
+    """JDN:376-482."""
+    L = seq.block_len
+    max_tokens = seq.max_tokens - seq.num_completion_tokens
+    accepted: List[int] = []
+    q: Optional[List[int]] = None
+    eos_reached = False
+    iters = 0
+    while not eos_reached and len(accepted) < max_tokens and iters < seq.max_iters:
+        iters += 1
+        if L <= 1:
+            break
+        if q is None:
+            q = [seq.token_ids[-1]] + pads(L - 1)
+        else:
+            q[0] = seq.token_ids[-1]
+        seq.grow_for_draft(L)
+        logits = forward([seq], [q])[0]
+        seq.num_cached_tokens = len(seq) - 1 + L
+        probs = softmax_rows_f32(logits, temperature)
+        committed, keep, eos = rs_verify_row(q, probs, eos_id, next_uniform, next_bonus_uniform)
+        eos_reached = eos_reached or eos
+        _ng_commit(seq, L, committed, keep)
+        accepted += committed
+        if eos_reached or len(accepted) >= max_tokens:
+            break
+        greedy = argmax_rows(logits).tolist()
+        q = _ng_next_draft(seq, L, len(committed), greedy, pads)
+    if stats is not None:
+        stats["num_chunk_calls"] += 1
+        stats["num_jacobi_iterations"] += iters
+        stats["tokens_accepted"] += len(accepted)
+        stats["tokens_per_call"].append(len(accepted))
+        stats["iterations_per_call"].append(iters)
+    return accepted
+
+
+def nongreedy_generate_batch(forward: NonGreedyForward, seqs: List[OracleSeq], eos_id: Optional[int],
+                             temperature: float, pads, next_uniform, next_bonus_uniform,
+                             stats: Optional[dict] = None):
+    """JDN:485-667."""
+    if not seqs:
+        return []
+    if len(seqs) == 1:
+        return [nongreedy_generate_single(forward, seqs[0], eos_id, temperature, pads, next_uniform,
+                                          next_bonus_uniform, stats)]
+    B = len(seqs)
+    accepted: List[List[int]] = [[] for _ in range(B)]
+    q: List[Optional[List[int]]] = [None] * B
+    eos_reached = [False] * B
+    iters = [0] * B
+    max_tokens = [max(0, s.max_tokens - s.num_completion_tokens) for s in seqs]
+    n_iter_call = 0
+    while True:
+        active = [i for i in range(B) if not eos_reached[i] and len(accepted[i]) < max_tokens[i]
+                  and iters[i] < seqs[i].max_iters]
+        if not active:
+            break
+        groups: Dict[int, List[int]] = {}
+        for i in active:
+            if seqs[i].block_len > 1:
+                groups.setdefault(seqs[i].block_len, []).append(i)
+        if not groups:
+            break
+        n_iter_call += 1
+        tokens_this_iter = 0
+        for L, idxs in sorted(groups.items(), key=lambda x: len(x[1]), reverse=True):
+            drafts = []
+            for i in idxs:
+                iters[i] += 1
+                if q[i] is None:
+                    q[i] = [seqs[i].token_ids[-1]] + pads(L - 1)
+                else:
+                    q[i][0] = seqs[i].token_ids[-1]
+                drafts.append(q[i])
+            for i in idxs:
+                seqs[i].grow_for_draft(L)
+            logits = forward([seqs[i] for i in idxs], drafts)
+            for i in idxs:
+                seqs[i].num_cached_tokens = len(seqs[i]) - 1 + L
+            for row, i in enumerate(idxs):
+                probs = softmax_rows_f32(logits[row], temperature)
+                committed, keep, eos = rs_verify_row(drafts[row], probs, eos_id, next_uniform, next_bonus_uniform)
+                eos_reached[i] = eos_reached[i] or eos
+                _ng_commit(seqs[i], L, committed, keep)
+                accepted[i] += committed
+                tokens_this_iter += len(committed)
+                if eos_reached[i] or len(accepted[i]) >= max_tokens[i]:
+                    q[i] = None
+                    continue
+                greedy = argmax_rows(logits[row]).tolist()
+                q[i] = _ng_next_draft(seqs[i], L, len(committed), greedy, pads)
+        if stats is not None:
+            stats["tokens_per_iteration"].append(tokens_this_iter)
+    if stats is not None:
+        tot = sum(len(a) for a in accepted)
+        stats["num_chunk_calls"] += 1
+        stats["num_jacobi_iterations"] += n_iter_call
+        stats["tokens_accepted"] += tot
+        stats["tokens_per_call"].append(tot)
+        stats["iterations_per_call"].append(n_iter_call)
+    return accepted
+
+
+class CounterStream:
+    """Counter-based injected randomness shared by the golden generator and the tests:
+    element k = mix32(seed, k)."""
+
+    def __init__(self, seed: int):
+        from oracle.scripted_model import mix32
+        self._mix = mix32
+        self.seed = seed
+        self.k = 0
+
+    def next_u32(self) -> int:
+        v = self._mix(self.seed, self.k)
+        self.k += 1
+        return v
+
+    def pads(self, vocab: int) -> Callable[[int], List[int]]:
+        return lambda count: [self.next_u32() % vocab for _ in range(count)]
+
+    def uniform(self) -> float:
+        return (self.next_u32() >> 8) / float(1 << 24)

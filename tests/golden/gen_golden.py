@@ -1,0 +1,644 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the UNMODIFIED reference in this container.
+
+Run (build container only — /root/reference does not exist on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
+
+What it does
+------------
+* imports the reference's decode functions from /root/reference
+  (modeling/cllm2_qwen2_modeling_kv_terminate_on_eos_improved_multiblock_lookahead_unified.py,
+   modeling/cllm2_qwen2_modeling_kv_terminate_on_eos_improved.py,
+   inference_engine/engine/jacobi_decoding.py, .../jacobi_decoding_nongreedy.py)
+  with two in-process shims (a transformers-4.53-style ``DynamicCache`` stand-in and an
+  empty ``flash_attn`` module) and NO edits to the reference;
+* drives them with the deterministic scripted model of ``oracle/scripted_model.py``
+  through a duck-typed ``self`` (HF path) or ``forward_step[_batch]`` callbacks (engine
+  path), injecting every random draw (draft initialisation, random pads, uniforms,
+  residual samples) from counter-based streams so the run is reproducible anywhere;
+* records inputs and outputs as plain data under tests/golden/*.json.
+
+Only DATA is written (token ids, lengths, counters).  No reference source text is copied.
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import json
+import os
+import random
+import sys
+import types
+from pathlib import Path
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+REF = Path("/root/reference")
+if not REF.is_dir():
+    sys.exit("reference tree not present; golden vectors can only be regenerated in the build container")
+sys.path.insert(0, str(REF))
+
+from oracle.scripted_model import ScriptedModel, mix32  # noqa: E402
+
+OUT_DIR = Path(__file__).resolve().parent
+
+# --------------------------------------------------------------------------------------
+# shims + imports of the reference
+# --------------------------------------------------------------------------------------
+import modeling.cllm2_qwen2_modeling_kv_terminate_on_eos_improved_multiblock_lookahead_unified as mb  # noqa: E402
+import modeling.cllm2_qwen2_modeling_kv_terminate_on_eos_improved as sb  # noqa: E402
+
+
+class FakeCache:
+    """transformers-4.53 DynamicCache surface the reference touches."""
+
+    def __init__(self):
+        self.key_cache = []
+        self.value_cache = []
+
+    def get_seq_length(self):
+        return self.key_cache[0].size(-2) if self.key_cache else 0
+
+
+FakeCache.delete_false_key_value = mb._delete_false_key_value
+mb.DynamicCache = FakeCache
+mb.create_causal_mask = lambda **kw: None
+
+
+class FakeCacheSB(FakeCache):
+    pass
+
+
+FakeCacheSB.delete_false_key_value = sb.delete_false_key_value
+sb.DynamicCache = FakeCacheSB
+sb.create_causal_mask = lambda **kw: None
+
+_fa = types.ModuleType("flash_attn")
+_fa.flash_attn_varlen_func = None
+_fa.flash_attn_with_kvcache = None
+sys.modules["flash_attn"] = _fa
+from inference_engine.engine.jacobi_decoding import JacobiDecoder  # noqa: E402
+from inference_engine.engine.jacobi_decoding_nongreedy import JacobiDecoderNonGreedy  # noqa: E402
+import inference_engine.engine.jacobi_decoding_nongreedy as jdn_mod  # noqa: E402
+from inference_engine.engine.block_manager import BlockManager  # noqa: E402
+from inference_engine.engine.sequence import Sequence  # noqa: E402
+from inference_engine.sampling_params import SamplingParams  # noqa: E402
+
+
+# --------------------------------------------------------------------------------------
+# duck-typed HF "self" around the scripted model
+# --------------------------------------------------------------------------------------
+class _Trace:
+    def __init__(self):
+        self.forwards = []  # dicts: kv_len, out [B][T], greedy [B][T]
+
+
+class FakeLayer:
+    attention_type = "full_attention"
+
+    def __init__(self, owner):
+        self.owner = owner
+
+    def __call__(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None,
+                 use_cache=None, cache_position=None, position_embeddings=None):
+        cache = past_key_value
+        tok = hidden_states[..., 0].long()
+        B, T = tok.shape
+        kv_len = cache.get_seq_length()
+        if cache.key_cache:
+            assert cache.key_cache[0].size(0) == B, (cache.key_cache[0].shape, B)
+            prefix = cache.key_cache[0][:, 0, :, 0]
+        else:
+            prefix = torch.empty((B, 0), dtype=torch.long)
+        model = self.owner.scripted
+        greedy = []
+        for b in range(B):
+            g = model.greedy_rows(prefix[b].tolist(), [tok[b].tolist()])[0]
+            greedy.append(g)
+        k_new = tok.view(B, 1, T, 1).clone()
+        v_new = position_ids.expand(B, T).reshape(B, 1, T, 1).clone()
+        if cache.key_cache:
+            cache.key_cache[0] = torch.cat([cache.key_cache[0], k_new], dim=-2)
+            cache.value_cache[0] = torch.cat([cache.value_cache[0], v_new], dim=-2)
+        else:
+            cache.key_cache.append(k_new)
+            cache.value_cache.append(v_new)
+        self.owner.trace.forwards.append(dict(kv_len=kv_len, out=tok.tolist(), greedy=greedy))
+        g = torch.tensor(greedy, dtype=torch.double)
+        return (torch.stack([tok.double(), g], dim=-1),)
+
+
+class FakeInner:
+    def __init__(self, owner):
+        self.layers = [FakeLayer(owner)]
+        self.has_sliding_layers = False
+        self.config = types.SimpleNamespace(num_hidden_layers=1)
+
+    def embed_tokens(self, ids):
+        return ids.double().unsqueeze(-1)
+
+    def rotary_emb(self, h, pos):
+        return pos
+
+    def norm(self, h):
+        return h
+
+
+class FakeSelf:
+    def __init__(self, scripted: ScriptedModel):
+        self.scripted = scripted
+        self.trace = _Trace()
+        self.model = FakeInner(self)
+        self.config = types.SimpleNamespace()
+
+    def lm_head(self, h):
+        g = h[..., 1].long()
+        B, T = g.shape
+        V = self.scripted.vocab
+        # cheap deterministic noise in (-1,1) + planted max (the reference then calls .float())
+        idx = torch.arange(V).view(1, 1, V)
+        noise = (((idx * 2654435761 + (g.unsqueeze(-1) + 1) * 40503) % 65536).float() / 32768.0) - 1.0
+        noise.scatter_(-1, g.unsqueeze(-1), 8.0)
+        return noise
+
+
+def kv_tokens(cache):
+    if not cache.key_cache:
+        return []
+    assert cache.key_cache[0].size(0) >= 1
+    return cache.key_cache[0][0, 0, :, 0].tolist()
+
+
+BANNERS = {
+    "======New block added": "spawn",
+    "============= SWITCHING REAL ACTIVE BLOCK": "switch",
+    "EARLY STOPPING": "early_stop",
+}
+
+
+def banners_of(text: str):
+    out = []
+    for line in text.splitlines():
+        for k, v in BANNERS.items():
+            if line.startswith(k):
+                out.append(v)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# HF multiblock (MB) cases — driver mirrors DRV-MR:152-240
+# --------------------------------------------------------------------------------------
+def run_mb_case(name, *, vocab, seed, robust, prompt_len, n, K, r, pool, lookahead=0.0,
+                eos_pos=None, period=0, max_iter=128, max_calls=6, max_new_tokens=10 ** 9):
+    eos_id, pad_id = vocab - 1, vocab - 2
+    model = ScriptedModel(vocab, seed, robust, prompt_len, eos_id=eos_id, eos_pos=eos_pos,
+                          reserved=(pad_id,), period=period)
+    fs = FakeSelf(model)
+    rng = random.Random(seed * 7919 + 13)
+    prompt = model.prompt()
+    input_ids = torch.tensor([prompt], dtype=torch.long)
+    generated = list(prompt)
+    calls = []
+
+    # prefill (DRV-MR:174-198)
+    draft0 = [rng.choice(generated) for _ in range(n)]
+    fs.trace = _Trace()
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        cache, first_tok, ngram, it0 = mb.jacobi_forward_greedy_multiblock(
+            fs, input_ids=torch.tensor([prompt + draft0], dtype=torch.long), attention_mask=None,
+            past_key_values=None, use_cache=True, prefill_phase=True, n_token_seq_len=n,
+            K=K, r=r, lookahead_start_ratio=lookahead, n_gram_pool_size=pool,
+            eos_token_id=eos_id, pad_token_id=pad_id, max_iteration_count=max_iter)
+    prefill = dict(draft=draft0, ngram=ngram[0].tolist(), first_correct_token=first_tok.tolist(),
+                   iters=int(it0), kv_len=cache.get_seq_length(), kv_tokens=kv_tokens(cache),
+                   forward=fs.trace.forwards[0] if False else dict(
+                       kv_len=fs.trace.forwards[0]["kv_len"], greedy_tail=fs.trace.forwards[0]["greedy"][0][-n - 1:-1]))
+    first_correct = None
+    ncall = 0
+    stop_reason = None
+    total_new = 0
+    while True:
+        gen_part = generated[prompt_len:]
+        if eos_id in gen_part:
+            stop_reason = "eos"
+            break
+        if total_new >= max_new_tokens:
+            stop_reason = "max_new_tokens"
+            break
+        if ncall >= max_calls:
+            stop_reason = "max_calls"
+            break
+        if ncall == 0:
+            inp = ngram[0].tolist()
+        else:
+            inp = [int(first_correct.view(-1)[0])] + [rng.choice(generated) for _ in range(n - 1)]
+        fs.trace = _Trace()
+        buf = io.StringIO()
+        kv_before = cache.get_seq_length()
+        with contextlib.redirect_stdout(buf):
+            cache, first_correct, acc, iters = mb.jacobi_forward_greedy_multiblock(
+                fs, input_ids=torch.tensor([inp], dtype=torch.long), attention_mask=None,
+                past_key_values=cache, use_cache=True, prefill_phase=False, n_token_seq_len=n,
+                K=K, r=r, lookahead_start_ratio=lookahead, n_gram_pool_size=pool,
+                eos_token_id=eos_id, pad_token_id=pad_id, max_iteration_count=max_iter)
+        ret = acc[0].tolist()
+        generated += ret
+        total_new += len(ret)
+        calls.append(dict(input=inp, kv_len_before=kv_before, ret=ret,
+                          next_token=first_correct.view(-1).tolist(), next_token_shape=list(first_correct.shape),
+                          iters=int(iters), kv_len=cache.get_seq_length(), kv_tokens=kv_tokens(cache),
+                          kv_batch=int(cache.key_cache[0].size(0)),
+                          banners=banners_of(buf.getvalue()), forwards=fs.trace.forwards))
+        ncall += 1
+    new_tokens = total_new - 1  # DRV-MR:243 "subtract prefill"
+    total_iters = sum(c["iters"] for c in calls)
+    return dict(name=name, kind="mb",
+                params=dict(n=n, K=K, r=r, pool=pool, lookahead=lookahead, eos_id=eos_id, pad_id=pad_id,
+                            max_iter=max_iter, max_calls=max_calls),
+                model=model.describe(), prompt=prompt, prefill=prefill, calls=calls,
+                summary=dict(new_tokens=new_tokens, calls=ncall + 1, total_iterations=total_iters,
+                             stop_reason=stop_reason, generated=generated[prompt_len:]))
+
+
+# --------------------------------------------------------------------------------------
+# HF single block (SB) cases
+# --------------------------------------------------------------------------------------
+def run_sb_case(name, *, vocab, seed, robust, prompt_len, n, eos_pos=None, max_calls=5):
+    eos_id = vocab - 1
+    model = ScriptedModel(vocab, seed, robust, prompt_len, eos_id=eos_id, eos_pos=eos_pos)
+    fs = FakeSelf(model)
+    rng = random.Random(seed * 104729 + 7)
+    prompt = model.prompt()
+    generated = list(prompt)
+    draft0 = [rng.choice(generated) for _ in range(n)]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        cache, first_tok, ngram, _ = sb.jacobi_forward_greedy(
+            fs, input_ids=torch.tensor([prompt + draft0], dtype=torch.long), past_key_values=None,
+            use_cache=True, prefill_phase=True, n_token_seq_len=n, eos_token_id=eos_id)
+    prefill = dict(draft=draft0, ngram=ngram[0].tolist(), kv_len=cache.get_seq_length())
+    calls = []
+    ncall = 0
+    first_correct = None
+    while True:
+        if eos_id in generated[prompt_len:] or ncall >= max_calls:
+            break
+        if ncall == 0:
+            inp = ngram[0].tolist()
+        else:
+            inp = [int(first_correct.view(-1)[0])] + [rng.choice(generated) for _ in range(n - 1)]
+        fs.trace = _Trace()
+        kv_before = cache.get_seq_length()
+        with contextlib.redirect_stdout(buf):
+            cache, first_correct, acc, itr = sb.jacobi_forward_greedy(
+                fs, input_ids=torch.tensor([inp], dtype=torch.long), past_key_values=cache,
+                use_cache=True, prefill_phase=False, n_token_seq_len=n, eos_token_id=eos_id)
+        ret = acc[0].tolist()
+        generated += ret
+        calls.append(dict(input=inp, kv_len_before=kv_before, ret=ret, next_token=first_correct.view(-1).tolist(),
+                          iters=int(itr), kv_len=cache.get_seq_length(), kv_tokens=kv_tokens(cache),
+                          forwards=fs.trace.forwards))
+        ncall += 1
+    return dict(name=name, kind="sb", params=dict(n=n, eos_id=eos_id), model=model.describe(), prompt=prompt,
+                prefill=prefill, calls=calls, summary=dict(generated=generated[prompt_len:]))
+
+
+# --------------------------------------------------------------------------------------
+# engine (JD / JDN) cases
+# --------------------------------------------------------------------------------------
+class CounterStream:
+    """Counter-based injected randomness: element k = mix32(seed, k)."""
+
+    def __init__(self, seed):
+        self.seed = seed
+        self.k = 0
+
+    def next_u32(self):
+        v = mix32(self.seed, self.k)
+        self.k += 1
+        return v
+
+    def randint(self, low, high, size, **kw):
+        nel = int(np.prod(size))
+        return torch.tensor([low + self.next_u32() % (high - low) for _ in range(nel)], dtype=torch.long).view(*size)
+
+    def uniform(self):
+        # 24-bit uniform in [0,1): exactly representable in fp32
+        return (self.next_u32() >> 8) / float(1 << 24)
+
+
+@contextlib.contextmanager
+def patched(obj, attr, value):
+    old = getattr(obj, attr)
+    setattr(obj, attr, value)
+    try:
+        yield
+    finally:
+        setattr(obj, attr, old)
+
+
+class EngineHarness:
+    """Caller side of the decoder seam, following MR:1134-1199 and MR:1407-1416
+    (seed check, block-table growth without clearing, num_cached_tokens update)."""
+
+    def __init__(self, vocab, num_blocks=64, block_size=256, logits_dtype=torch.float32):
+        self.vocab = vocab
+        self.block_size = block_size
+        self.bm = BlockManager(num_blocks, block_size)
+        self.models = {}
+        self.trace = []
+        self.logits_dtype = logits_dtype
+
+    def add_seq(self, model: ScriptedModel, sp: SamplingParams, prefill_draft=None):
+        seq = Sequence(model.prompt(), sp)
+        self.bm.allocate(seq)
+        seq.num_cached_tokens = len(seq)  # after prefill (MR:941)
+        seq._prefill_draft = prefill_draft
+        self.models[seq.seq_id] = model
+        return seq
+
+    def forward_step_batch(self, seqs, draft):
+        B, L = draft.shape
+        if L < 2:
+            raise ValueError("Draft must have at least 2 tokens (seed + 1 speculative)")
+        rows = []
+        for i, seq in enumerate(seqs):
+            seq.draft_tokens_gpu = draft[i]
+            if seq.token_ids[-1] != int(draft[i, 0]):
+                raise ValueError("Seed mismatch")
+            S = len(seq)
+            need = (S + L - 1 + self.block_size - 1) // self.block_size
+            committed_blocks = (S + self.block_size - 1) // self.block_size
+            cur = len(seq.block_table)
+            if cur >= need:
+                if cur > need:
+                    seq.block_table = seq.block_table[:need]
+                    seq.block_table_version += 1
+            else:
+                for _ in range(need - cur):
+                    if not self.bm.can_append(seq):
+                        raise RuntimeError("Cannot allocate blocks for draft tokens")
+                    bid = self.bm.free_block_ids[0]
+                    self.bm._allocate_block_no_clear(bid)
+                    seq.block_table.append(bid)
+                    seq.block_table_version += 1
+            seq.num_permanent_spec_blocks = max(seq.num_permanent_spec_blocks, need - committed_blocks)
+            model = self.models[seq.seq_id]
+            lg = model.logits_rows(seq.token_ids[:-1], [draft[i].tolist()])[0]  # [L, V]
+            rows.append(torch.from_numpy(lg))
+        logits = torch.stack(rows, 0).to(self.logits_dtype)
+        for seq in seqs:
+            seq.num_cached_tokens = (len(seq) - 1) + L
+        self.trace.append(dict(seq_ids=[s.seq_id for s in seqs], draft=draft.tolist(),
+                               seq_lens=[len(s) for s in seqs]))
+        return logits[:, :-1, :]
+
+    def forward_step(self, seq, draft):
+        return self.forward_step_batch([seq], draft)
+
+
+def run_jd_case(name, *, vocab, seeds, robust, prompt_lens, block_lens, max_tokens, eos_pos=None,
+                use_prefill_draft=True, pad_seed=99, batch=True, max_iters=128):
+    eos_id, pad_id = vocab - 1, vocab - 2
+    H = EngineHarness(vocab)
+    dec = JacobiDecoder(H.bm, forward_step=H.forward_step, forward_step_batch=H.forward_step_batch,
+                        eos_token_id=eos_id, pad_token_id=pad_id, vocab_size=vocab, device=torch.device("cpu"))
+    seqs, descr = [], []
+    base_id = None
+    for i, (sd, pl, bl) in enumerate(zip(seeds, prompt_lens, block_lens)):
+        ep = None if eos_pos is None else eos_pos[i]
+        m = ScriptedModel(vocab, sd, robust, pl, eos_id=eos_id, eos_pos=ep, reserved=(pad_id,))
+        sp = SamplingParams(temperature=0.0, max_tokens=max_tokens[i], decode_strategy="jacobi",
+                            jacobi_block_len=bl, jacobi_max_iterations=max_iters)
+        pd = None
+        if use_prefill_draft:
+            # what MR:914-918 stores: greedy over the prompt's last position + draft window (random draft)
+            rr = random.Random(sd)
+            d0 = [rr.choice(m.prompt()) for _ in range(bl)]
+            pd = m.greedy_rows(m.prompt()[:-1], [[m.prompt()[-1]] + d0])[0][:bl]
+        s = H.add_seq(m, sp, pd)
+        if base_id is None:
+            base_id = s.seq_id
+        seqs.append(s)
+        descr.append(dict(model=m.describe(), prompt=m.prompt(), block_len=bl, max_tokens=max_tokens[i],
+                          prefill_draft=pd))
+    stream = CounterStream(pad_seed)
+    with patched(torch, "randint", stream.randint):
+        if batch:
+            out = dec.generate_chunk_batch(seqs)
+        else:
+            out = [dec.generate_chunk(s) for s in seqs]
+    for t in H.trace:
+        t["seq_idx"] = [sid - base_id for sid in t.pop("seq_ids")]
+    return dict(name=name, kind="jd", params=dict(vocab=vocab, eos_id=eos_id, pad_id=pad_id, pad_seed=pad_seed,
+                                                  batch=batch, max_iters=max_iters),
+                seqs=descr, outputs=out, stats=dec.stats,
+                final=[dict(token_ids=s.token_ids, num_cached_tokens=s.num_cached_tokens,
+                            num_blocks=len(s.block_table)) for s in seqs],
+                pads_consumed=stream.k, forwards=H.trace)
+
+
+def scripted_multinomial(stream):
+    def _mn(probs, num_samples=1, **kw):
+        assert probs.dim() == 1 and num_samples == 1
+        u = stream.uniform()
+        c = torch.cumsum(probs.double(), 0)
+        thr = u * float(c[-1])
+        idx = int(torch.searchsorted(c, torch.tensor(thr, dtype=torch.double), right=True))
+        idx = min(idx, probs.numel() - 1)
+        return torch.tensor([idx], dtype=torch.long)
+    return _mn
+
+
+def run_jdn_case(name, *, vocab, seeds, robust, prompt_lens, block_len, max_tokens, temperature,
+                 eos_pos=None, rng_seed=5, batch=True):
+    eos_id, pad_id = vocab - 1, vocab - 2
+    H = EngineHarness(vocab)
+    dec = JacobiDecoderNonGreedy(H.bm, forward_step=H.forward_step, forward_step_batch=H.forward_step_batch,
+                                 eos_token_id=eos_id, pad_token_id=pad_id, vocab_size=vocab,
+                                 device=torch.device("cpu"))
+    seqs, descr = [], []
+    for i, (sd, pl) in enumerate(zip(seeds, prompt_lens)):
+        ep = None if eos_pos is None else eos_pos[i]
+        m = ScriptedModel(vocab, sd, robust, pl, eos_id=eos_id, eos_pos=ep, reserved=(pad_id,))
+        sp = SamplingParams(temperature=temperature, max_tokens=max_tokens, decode_strategy="jacobi",
+                            jacobi_block_len=block_len)
+        seqs.append(H.add_seq(m, sp, None))
+        descr.append(dict(model=m.describe(), prompt=m.prompt()))
+    pads = CounterStream(rng_seed * 3 + 1)
+    unis = CounterStream(rng_seed * 3 + 2)
+    bonus = CounterStream(rng_seed * 3 + 3)
+    events = []
+
+    def _rand(size=(), **kw):
+        u = unis.uniform()
+        events.append(("u", u))
+        return torch.tensor(u, dtype=torch.float32)
+
+    mn = scripted_multinomial(bonus)
+
+    def _mn(probs, num_samples=1, **kw):
+        r = mn(probs, num_samples)
+        events.append(("bonus", int(r)))
+        return r
+
+    with patched(torch, "randint", pads.randint), patched(torch, "rand", _rand), patched(torch, "multinomial", _mn):
+        if batch:
+            out = dec.generate_chunk_batch(seqs)
+        else:
+            out = [dec.generate_chunk(s) for s in seqs]
+    return dict(name=name, kind="jdn",
+                params=dict(vocab=vocab, eos_id=eos_id, pad_id=pad_id, rng_seed=rng_seed, batch=batch,
+                            block_len=block_len, max_tokens=max_tokens, temperature=temperature),
+                seqs=descr, outputs=out, stats=dec.stats,
+                final=[dict(token_ids=s.token_ids, num_cached_tokens=s.num_cached_tokens) for s in seqs],
+                draws=dict(pads=pads.k, uniforms=unis.k, bonus=bonus.k), forwards=H.trace)
+
+
+# --------------------------------------------------------------------------------------
+# kernel-level vectors: torch.argmax / accept-length semantics (ties, NaN, -inf, bf16)
+# --------------------------------------------------------------------------------------
+def run_argmax_vectors():
+    g = torch.Generator().manual_seed(1234)
+    cases = []
+    V = 97
+    for dtype in (torch.float32, torch.bfloat16):
+        x = torch.randn(12, V, generator=g).to(dtype)
+        x[1, 5] = x[1, 40] = 9.0                       # exact tie -> first index
+        x[2, 96] = 11.0                                 # max at last index
+        x[3, 0] = 11.0                                  # max at first index
+        x[4, 17] = float("nan")                         # NaN counts as max
+        x[5, 30] = float("nan"); x[5, 9] = float("nan")  # two NaNs -> first NaN
+        x[6, :] = -float("inf")                         # all -inf -> index 0
+        x[7, 20] = float("inf"); x[7, 3] = float("inf")  # +inf tie -> first
+        x[8, :] = 0.0                                   # all equal -> 0
+        x[9, 50] = float("inf"); x[9, 60] = float("nan")  # NaN beats +inf
+        x[10, 10] = -0.0; x[10, :10] = -1.0; x[10, 11:] = -1.0; x[10, 44] = 0.0  # -0.0 == 0.0 tie -> first
+        am = torch.argmax(x, dim=-1).tolist()
+        cases.append(dict(dtype=str(dtype).split(".")[-1],
+                          bits=(x.view(torch.int32) if dtype == torch.float32 else x.view(torch.int16).int()).tolist(),
+                          argmax=am))
+    # accept-length semantics (MB:482-486 / JD:253-293)
+    acc = []
+    rr = random.Random(7)
+    for _ in range(40):
+        L = rr.randint(1, 9)
+        B = rr.randint(1, 4)
+        draft = [[rr.randint(0, 3) for _ in range(L)] for _ in range(B)]
+        greedy = [[rr.randint(0, 3) for _ in range(L)] for _ in range(B)]
+        d, gt = torch.tensor(draft), torch.tensor(greedy)
+        mismatch = d[:, 1:] != gt[:, :-1]
+        a = ((mismatch.cumsum(dim=-1) == 0).sum(dim=-1) + 1).tolist()
+        best = int(torch.argmax(torch.tensor(a)))
+        acc.append(dict(draft=draft, greedy=greedy, accepted=a, best_idx=best))
+    return dict(kind="kernel_vectors", argmax=cases, accept=acc)
+
+
+# --------------------------------------------------------------------------------------
+def main():
+    torch.manual_seed(0)
+    mbs = []
+    add = lambda *a, **k: mbs.append(run_mb_case(*a, **k))
+    # basic sweeps
+    add("n8_K1", vocab=64, seed=1, robust=60, prompt_len=6, n=8, K=1, r=0.85, pool=4)
+    add("n8_K2_r50_trace", vocab=1000, seed=2, robust=70, prompt_len=6, n=8, K=2, r=0.5, pool=4, max_calls=4)
+    add("n16_K2_r85", vocab=1000, seed=3, robust=70, prompt_len=11, n=16, K=2, r=0.85, pool=4)
+    add("n16_K3_r50", vocab=64, seed=4, robust=65, prompt_len=9, n=16, K=3, r=0.5, pool=4)
+    add("n32_K1", vocab=1000, seed=5, robust=70, prompt_len=20, n=32, K=1, r=0.85, pool=4)
+    add("n32_K2_r85_default", vocab=1000, seed=6, robust=70, prompt_len=24, n=32, K=2, r=0.85, pool=4)
+    add("n32_K2_r50_pool8", vocab=64, seed=7, robust=70, prompt_len=17, n=32, K=2, r=0.5, pool=8)
+    add("n32_K3_r50_pool4_small_vocab", vocab=32, seed=8, robust=55, prompt_len=13, n=32, K=3, r=0.5, pool=4)
+    add("n16_pool1", vocab=64, seed=9, robust=60, prompt_len=7, n=16, K=2, r=0.5, pool=1)
+    add("n16_period_candidates", vocab=64, seed=10, robust=45, prompt_len=10, n=16, K=2, r=0.6, pool=4, period=5)
+    add("n32_period_candidates_pool8", vocab=48, seed=11, robust=40, prompt_len=12, n=32, K=2, r=0.6, pool=8, period=7)
+    add("n16_period3_K3", vocab=40, seed=12, robust=35, prompt_len=8, n=16, K=3, r=0.4, pool=4, period=3)
+    add("n16_lookahead_half", vocab=48, seed=13, robust=45, prompt_len=9, n=16, K=2, r=0.6, pool=4, period=5, lookahead=0.5)
+    add("n8_low_robust_acc1", vocab=64, seed=14, robust=0, prompt_len=5, n=8, K=2, r=0.85, pool=4)
+    add("n8_full_robust_all_accept", vocab=64, seed=15, robust=100, prompt_len=5, n=8, K=2, r=0.5, pool=4)
+    add("n16_max_iter3", vocab=64, seed=16, robust=30, prompt_len=6, n=16, K=2, r=0.85, pool=4, max_iter=3)
+    add("n64_K2", vocab=1000, seed=17, robust=75, prompt_len=30, n=64, K=2, r=0.85, pool=4, max_calls=3)
+    add("n16_K4_r25", vocab=64, seed=18, robust=60, prompt_len=9, n=16, K=4, r=0.25, pool=4, period=6)
+    # EOS placements: inside accepted prefix, as first token, as "next token", at block boundary (Q13)
+    add("n8_eos_mid", vocab=64, seed=20, robust=70, prompt_len=6, n=8, K=2, r=0.5, pool=4, eos_pos=6 + 11)
+    add("n8_eos_first_token", vocab=64, seed=21, robust=70, prompt_len=6, n=8, K=2, r=0.5, pool=4, eos_pos=6)
+    add("n8_eos_at_block_end_Q13", vocab=64, seed=22, robust=100, prompt_len=6, n=8, K=1, r=0.5, pool=4, eos_pos=6 + 8)
+    add("n8_eos_second_block_start", vocab=64, seed=23, robust=80, prompt_len=6, n=8, K=2, r=0.5, pool=4, eos_pos=6 + 8 + 1)
+    add("n16_eos_in_pseudo", vocab=64, seed=24, robust=85, prompt_len=7, n=16, K=2, r=0.3, pool=4, eos_pos=7 + 20)
+    add("n16_eos_next_token", vocab=64, seed=25, robust=50, prompt_len=7, n=16, K=2, r=0.85, pool=4, eos_pos=7 + 5)
+    for sd in range(30, 42):
+        rr = random.Random(sd)
+        n = rr.choice([8, 16, 32])
+        add(f"rand_{sd}", vocab=rr.choice([24, 48, 200]), seed=sd, robust=rr.choice([30, 50, 70, 90]),
+            prompt_len=rr.randint(4, 20), n=n, K=rr.choice([1, 2, 2, 3]), r=rr.choice([0.3, 0.5, 0.85]),
+            pool=rr.choice([2, 4, 8]), period=rr.choice([0, 0, 4, 9]),
+            eos_pos=rr.choice([None, None, rr.randint(4, 20) + rr.randint(0, 3 * n)]), max_calls=4)
+    sbs = [
+        run_sb_case("sb_n16", vocab=1000, seed=50, robust=70, prompt_len=12, n=16),
+        run_sb_case("sb_n8_all_accept", vocab=64, seed=51, robust=100, prompt_len=5, n=8),
+        run_sb_case("sb_n8_eos_mid", vocab=64, seed=52, robust=70, prompt_len=5, n=8, eos_pos=5 + 10),
+        run_sb_case("sb_n8_eos_next", vocab=64, seed=53, robust=40, prompt_len=5, n=8, eos_pos=5 + 3),
+        run_sb_case("sb_n8_eos_bonus", vocab=64, seed=54, robust=100, prompt_len=5, n=8, eos_pos=5 + 8),
+        run_sb_case("sb_n32", vocab=200, seed=55, robust=60, prompt_len=21, n=32),
+    ]
+    jds = [
+        run_jd_case("jd_single_L8", vocab=64, seeds=[60], robust=70, prompt_lens=[9], block_lens=[8],
+                    max_tokens=[40], batch=False),
+        run_jd_case("jd_single_L16_noprefill", vocab=200, seeds=[61], robust=60, prompt_lens=[14], block_lens=[16],
+                    max_tokens=[48], batch=False, use_prefill_draft=False),
+        run_jd_case("jd_single_eos", vocab=64, seeds=[62], robust=80, prompt_lens=[7], block_lens=[8],
+                    max_tokens=[64], eos_pos=[7 + 13], batch=False),
+        run_jd_case("jd_batch3_mixedL", vocab=64, seeds=[63, 64, 65], robust=70, prompt_lens=[9, 12, 6],
+                    block_lens=[8, 16, 8], max_tokens=[24, 30, 40]),
+        run_jd_case("jd_batch4_eos_overshoot", vocab=100, seeds=[66, 67, 68, 69], robust=75,
+                    prompt_lens=[5, 8, 250, 255], block_lens=[16, 16, 16, 16], max_tokens=[24, 24, 40, 40],
+                    eos_pos=[5 + 9, None, None, 255 + 30]),
+        run_jd_case("jd_batch2_robust0_ar_fallback", vocab=64, seeds=[70, 71], robust=0, prompt_lens=[6, 6],
+                    block_lens=[8, 8], max_tokens=[12, 12]),
+        run_jd_case("jd_batch2_robust100", vocab=64, seeds=[72, 73], robust=100, prompt_lens=[6, 9],
+                    block_lens=[8, 8], max_tokens=[30, 30]),
+        run_jd_case("jd_batch2_maxiters", vocab=64, seeds=[74, 75], robust=20, prompt_lens=[6, 9],
+                    block_lens=[8, 8], max_tokens=[100, 100], max_iters=5),
+    ]
+    jdns = [
+        run_jdn_case("jdn_single_T1", vocab=64, seeds=[80], robust=70, prompt_lens=[8], block_len=8,
+                     max_tokens=32, temperature=1.0, batch=False),
+        run_jdn_case("jdn_batch3_T07", vocab=64, seeds=[81, 82, 83], robust=70, prompt_lens=[8, 5, 11], block_len=8,
+                     max_tokens=24, temperature=0.7),
+        run_jdn_case("jdn_batch2_eos", vocab=64, seeds=[84, 85], robust=90, prompt_lens=[8, 5], block_len=16,
+                     max_tokens=48, temperature=0.5, eos_pos=[8 + 6, 5 + 20]),
+    ]
+    kv = run_argmax_vectors()
+
+    def dump(fname, obj):
+        p = OUT_DIR / fname
+        with open(p, "w") as f:
+            json.dump(obj, f, separators=(",", ":"))
+        print(f"wrote {p} ({p.stat().st_size / 1024:.1f} KiB)")
+
+    dump("mb_cases.json", mbs)
+    dump("sb_cases.json", sbs)
+    dump("jd_cases.json", jds)
+    dump("jdn_cases.json", jdns)
+    dump("kernel_vectors.json", kv)
+    # quick human summary
+    for c in mbs:
+        fw = [f for cl in c["calls"] for f in cl["forwards"]]
+        maxB = max((len(f["out"]) for f in fw), default=0)
+        maxT = max((len(f["out"][0]) for f in fw), default=0)
+        s = c["summary"]
+        tpf = (s["new_tokens"] / s["total_iterations"]) if s["total_iterations"] else 0
+        ban = sum((cl["banners"] for cl in c["calls"]), [])
+        print(f"{c['name']:34s} calls={s['calls']} new={s['new_tokens']} iters={s['total_iterations']} tpf={tpf:.2f} "
+              f"maxB={maxB} maxT={maxT} stop={s['stop_reason']} spawn={ban.count('spawn')} switch={ban.count('switch')}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,179 @@
+"""Pin the CPU oracle (oracle/jacobi_oracle.py) against golden vectors recorded from the
+unmodified reference (tests/golden/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import jacobi_oracle as O
+from oracle.scripted_model import ScriptedModel
+
+from .conftest import load_golden
+
+MB = load_golden("mb_cases.json")
+SB = load_golden("sb_cases.json")
+JD = load_golden("jd_cases.json")
+JDN = load_golden("jdn_cases.json")
+
+
+def scripted_forward(model):
+    def fwd(kv_rows, out_rows):
+        return [model.greedy_rows(kv_rows[b], [out_rows[b]])[0] for b in range(len(out_rows))]
+    return fwd
+
+
+# ----------------------------------------------------------------------------- kernel-level
+def test_argmax_semantics(kernel_vectors):
+    for case in kernel_vectors["argmax"]:
+        bits = np.array(case["bits"], dtype=np.int64)
+        if case["dtype"] == "float32":
+            x = bits.astype(np.uint32).view(np.float32) if False else (bits & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
+        else:
+            x = O.bf16_bits_to_f32((bits & 0xFFFF).astype(np.uint16))
+        assert O.argmax_rows(x).tolist() == case["argmax"]
+
+
+def test_accept_lengths(kernel_vectors):
+    for c in kernel_vectors["accept"]:
+        acc = O.accept_lengths(c["draft"], c["greedy"])
+        assert acc == c["accepted"]
+        assert O.first_max_index(acc) == c["best_idx"]
+
+
+def test_bf16_roundtrip():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(4096).astype(np.float32)
+    b = O.f32_to_bf16_bits(x)
+    import torch
+    ref = torch.from_numpy(x).to(torch.bfloat16).view(torch.int16).numpy().astype(np.uint16)
+    assert (b == ref).all()
+    assert (O.bf16_bits_to_f32(b) == torch.from_numpy(x).to(torch.bfloat16).float().numpy()).all()
+
+
+# ----------------------------------------------------------------------------- multiblock
+@pytest.mark.parametrize("case", MB, ids=[c["name"] for c in MB])
+def test_multiblock_calls(case):
+    p = case["params"]
+    model = ScriptedModel.from_dict(case["model"])
+    assert model.prompt() == case["prompt"]
+    fwd = scripted_forward(model)
+    # prefill (MB:175-225)
+    ngram, kv = O.mb_prefill(fwd, case["prompt"], case["prefill"]["draft"])
+    assert ngram == case["prefill"]["ngram"]
+    assert kv == case["prefill"]["kv_tokens"]
+    for ci, call in enumerate(case["calls"]):
+        assert len(kv) == call["kv_len_before"]
+        st = O.mb_generation_call(fwd, call["input"], kv, n=p["n"], K=p["K"], r=p["r"],
+                                  lookahead_start_ratio=p["lookahead"], n_gram_pool_size=p["pool"],
+                                  eos_token_id=p["eos_id"], pad_token_id=p["pad_id"],
+                                  max_iteration_count=p["max_iter"])
+        ctx = f"{case['name']} call {ci}"
+        assert st.ret == call["ret"], ctx
+        assert [st.next_token] == call["next_token"], ctx
+        assert st.iters == call["iters"], ctx
+        assert st.kv_tokens == call["kv_tokens"], ctx
+        assert len(st.kv_rows) == call["kv_batch"], ctx
+        assert st.banners == call["banners"], ctx
+        # per-iteration forward inputs/outputs
+        assert len(st.trace) == len(call["forwards"]), ctx
+        for it, (a, b) in enumerate(zip(st.trace, call["forwards"])):
+            assert a["out"] == b["out"], f"{ctx} iter {it}"
+            assert a["greedy"] == b["greedy"], f"{ctx} iter {it}"
+            assert a["kv_len"] == b["kv_len"], f"{ctx} iter {it}"
+        kv = st.kv_tokens
+
+
+def test_multiblock_greedy_equals_ar(mb_cases):
+    """The reference's own correctness criterion (test_jacobi_decoding_greedy.py:180-206): greedy Jacobi
+    output == greedy AR output.  Holds up to the EOS token for every recorded case."""
+    for case in mb_cases:
+        model = ScriptedModel.from_dict(case["model"])
+        gen = case["summary"]["generated"]
+        ar = model.ar_continuation(len(case["prompt"]), len(gen))
+        assert gen == ar, case["name"]
+
+
+# ----------------------------------------------------------------------------- single block (HF)
+@pytest.mark.parametrize("case", SB, ids=[c["name"] for c in SB])
+def test_singleblock_calls(case):
+    model = ScriptedModel.from_dict(case["model"])
+    fwd = scripted_forward(model)
+    n, eos = case["params"]["n"], case["params"]["eos_id"]
+    ngram, kv = O.mb_prefill(fwd, case["prompt"], case["prefill"]["draft"])
+    assert ngram == case["prefill"]["ngram"]
+    for ci, call in enumerate(case["calls"]):
+        r = O.sb_generation_call(fwd, call["input"], kv, n=n, eos_token_id=eos)
+        assert r["ret"] == call["ret"], (case["name"], ci)
+        assert [r["next_token"]] == call["next_token"]
+        assert r["iters"] == call["iters"]
+        assert r["kv_tokens"] == call["kv_tokens"]
+        for a, b in zip(r["trace"], call["forwards"]):
+            assert a["out"] == b["out"][0] and a["greedy"] == b["greedy"][0]
+        kv = r["kv_tokens"]
+
+
+# ----------------------------------------------------------------------------- engine greedy
+def _mk_seqs(case, max_iters=128):
+    seqs, models = [], []
+    for d in case["seqs"]:
+        m = ScriptedModel.from_dict(d["model"])
+        assert m.prompt() == d["prompt"]
+        models.append(m)
+        seqs.append(O.OracleSeq(d["prompt"], d.get("block_len", case["params"].get("block_len")),
+                                d.get("max_tokens", case["params"].get("max_tokens")), max_iters=max_iters,
+                                prefill_draft=d.get("prefill_draft")))
+    return seqs, models
+
+
+@pytest.mark.parametrize("case", JD, ids=[c["name"] for c in JD])
+def test_engine_greedy(case):
+    p = case["params"]
+    seqs, models = _mk_seqs(case, p["max_iters"])
+    by_id = {id(s): m for s, m in zip(seqs, models)}
+    trace = []
+
+    def fwd(ss, drafts):
+        trace.append(dict(seq_idx=[seqs.index(s) for s in ss], draft=[list(d) for d in drafts],
+                          seq_lens=[len(s) for s in ss]))
+        return [by_id[id(s)].greedy_rows(s.token_ids[:-1], [d])[0][:-1] for s, d in zip(ss, drafts)]
+
+    stream = O.CounterStream(p["pad_seed"])
+    stats = O.new_stats()
+    pads = stream.pads(p["vocab"])
+    if p["batch"]:
+        out = O.engine_generate_batch(fwd, seqs, p["eos_id"], pads, stats)
+    else:
+        out = [O.engine_generate_single(fwd, s, p["eos_id"], pads, stats) for s in seqs]
+    assert out == case["outputs"]
+    assert stats == case["stats"]
+    assert stream.k == case["pads_consumed"]
+    for s, f in zip(seqs, case["final"]):
+        assert s.token_ids == f["token_ids"]
+        assert s.num_cached_tokens == f["num_cached_tokens"]
+        assert s.num_table_blocks == f["num_blocks"]
+    assert trace == case["forwards"]
+
+
+# ----------------------------------------------------------------------------- engine non-greedy
+@pytest.mark.parametrize("case", JDN, ids=[c["name"] for c in JDN])
+def test_engine_nongreedy(case):
+    p = case["params"]
+    seqs, models = _mk_seqs(case)
+    by_id = {id(s): m for s, m in zip(seqs, models)}
+
+    def fwd(ss, drafts):
+        return [by_id[id(s)].logits_rows(s.token_ids[:-1], [d])[0][:-1] for s, d in zip(ss, drafts)]
+
+    pads = O.CounterStream(p["rng_seed"] * 3 + 1)
+    unis = O.CounterStream(p["rng_seed"] * 3 + 2)
+    bonus = O.CounterStream(p["rng_seed"] * 3 + 3)
+    stats = O.new_stats()
+    args = (p["eos_id"], p["temperature"], pads.pads(p["vocab"]), unis.uniform, bonus.uniform, stats)
+    if p["batch"]:
+        out = O.nongreedy_generate_batch(fwd, seqs, *args)
+    else:
+        out = [O.nongreedy_generate_single(fwd, s, *args) for s in seqs]
+    assert out == case["outputs"]
+    assert stats == case["stats"]
+    assert dict(pads=pads.k, uniforms=unis.k, bonus=bonus.k) == case["draws"]
+    for s, f in zip(seqs, case["final"]):
+        assert s.token_ids == f["token_ids"]
+        assert s.num_cached_tokens == f["num_cached_tokens"]
