@@ -1,0 +1,212 @@
+/*
+ * jacobiforcing.h — C ABI of the MI355X-native Jacobi-decoding hot path.
+ *
+ * The reference (hao-ai-lab/JacobiForcing) is pure Python; it has no FFI of its own.  The entry
+ * points below are what a ctypes binding on the reference side would bind for its loop body
+ * (INTEGRATION.md shows the stub).  Each entry cites the reference code it replaces; citations use
+ *   MB  = modeling/cllm2_qwen2_modeling_kv_terminate_on_eos_improved_multiblock_lookahead_unified.py
+ *   SB  = modeling/cllm2_qwen2_modeling_kv_terminate_on_eos_improved.py
+ *   JD  = inference_engine/engine/jacobi_decoding.py
+ *   JDN = inference_engine/engine/jacobi_decoding_nongreedy.py
+ *   MR  = inference_engine/engine/model_runner.py
+ *   ATT = inference_engine/layers/attention.py
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch) unless marked "host";
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - return value 0 = ok, negative = JF_E_* (message via jf_last_error()); nothing throws;
+ *   - no allocation happens inside any call; workspaces are sized by the *_bytes() helpers;
+ *   - thread-compatible (one caller thread per GPU/process), not thread-safe.
+ */
+#ifndef JACOBIFORCING_H
+#define JACOBIFORCING_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JF_VERSION 100
+
+enum {
+    JF_OK = 0,
+    JF_E_INVALID = -1,   /* bad argument (shape / alignment / null) -> ValueError on the Python side */
+    JF_E_CAPACITY = -2,  /* a fixed capacity would be exceeded       -> RuntimeError                  */
+    JF_E_LAUNCH = -3     /* HIP launch / runtime failure             -> RuntimeError                  */
+};
+
+enum { JF_F32 = 0, JF_BF16 = 1 };
+
+int jf_version(void);
+const char *jf_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * (a2) block-local logits argmax.  Replaces torch.argmax(block_logits, dim=-1) at MB:476, SB:197,
+ * JD:357, JD:567, MR:917.  torch semantics: first index of the maximum, NaN is the maximum,
+ * -0.0 == +0.0.
+ *
+ * logits      [R, V] row-major, row stride `row_stride` elements (>= V), dtype JF_F32 or JF_BF16
+ * packed      [R] uint64 workspace; MUST be all-zero on entry.  On exit packed[r] =
+ *             (order_key(max) << 32) | ~argmax.  Consumers (jf_argmax_decode, jf_mb_step,
+ *             jf_engine_step, ...) re-zero it after reading, so one torch.zeros() at start-up
+ *             is enough.
+ * Algorithmic bytes: R*V*esize read (+ 8*R written).
+ */
+int jf_argmax_partial(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride,
+                      uint64_t *packed, void *stream);
+
+/* packed -> int64 token ids (and re-zero packed).  greedy [R] int64. */
+int jf_argmax_decode(uint64_t *packed, int64_t R, int64_t *greedy, void *stream);
+
+/* convenience: partial + decode.  */
+int jf_argmax_rows(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride,
+                   uint64_t *packed, int64_t *greedy, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (a3) token equality + accepted-prefix scan.  Replaces MB:482-486 / SB:199-200 / JD:253-293:
+ *   accepted[b] = 1 + #leading i with draft[b, i+1] == greedy[b, i],  i in [0, L-2].
+ * draft  [draft_rows, L] int64 (draft_rows == 1 broadcasts, MB:482), greedy [B, >=L-1] int64 with
+ * row stride greedy_stride.  accepted [B] int32, best_idx [1] int32 = first index of max (MB:489).
+ */
+int jf_accept_lengths(const int64_t *draft, int draft_rows, const int64_t *greedy, int64_t greedy_stride,
+                      int B, int L, int32_t *accepted, int32_t *best_idx, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multiblock Jacobi state machine (a1, a3-a12): one generation call of
+ * jacobi_forward_greedy_multiblock (MB:227-740) per prompt, P prompts side by side.
+ *
+ * The per-prompt state is an opaque int32 block in device memory, sized by jf_mb_state_ints().
+ * Per iteration the caller runs:   forward(out) -> jf_argmax_partial -> jf_mb_step -> read desc.
+ */
+typedef struct jf_mb_params {
+    int32_t n;               /* n_token_seq_len (MB:149)                                  */
+    int32_t K;               /* max concurrent blocks (MB:151)                            */
+    int32_t spawn_threshold; /* ceil(r * n), computed by the caller in double (MB:262)    */
+    int32_t pool_size;       /* n_gram_pool_size (MB:155); 0/1 disables recycling         */
+    int32_t eos_id;          /* -1 = EOS handling off (MB:234)                            */
+    int32_t pad_id;          /* -1 = none (spawn then fails like MB:631-632)              */
+    int32_t max_iter;        /* max_iteration_count (MB:166)                              */
+    int32_t max_blocks;      /* capacity of the block lists (>= K; Q3 can exceed K)       */
+    double lookahead_start_ratio; /* MB:154, compared as total_acc / n >= ratio (MB:577)  */
+} jf_mb_params;
+
+/* one per prompt, written by jf_mb_begin / jf_mb_step (device memory or mapped pinned host memory) */
+typedef struct jf_mb_desc {
+    int32_t B;          /* rows of the next forward (0 when done)                              */
+    int32_t T;          /* tokens per row of the next forward                                  */
+    int32_t done;       /* 1: call finished; ret/next_token/iters valid                        */
+    int32_t error;      /* 0 or JF_E_* raised inside the state machine                         */
+    int32_t iters;      /* Jacobi iterations so far (MB:413-415)                               */
+    int32_t kv_len;     /* committed KV length after this step (MB:617-626, 733-736)           */
+    int32_t ret_len;    /* tokens in ret (valid when done)                                     */
+    int32_t next_token; /* MB:547/614/739 (valid when done; -1 if never set)                   */
+    int32_t kv_src_row; /* candidate row whose K/V for [kv_copy_dst, +kv_copy_len) must be     */
+    int32_t kv_copy_dst;/*   copied onto row 0 (0 when nothing to copy, MB:500-502)            */
+    int32_t kv_copy_len;
+    int32_t events;     /* bit0 spawn, bit1 switch, bit2 early-stop (banners MB:634/660/720)   */
+    int32_t accepted;   /* tokens the real-active block accepted in this step                  */
+    int32_t nspans;
+    int32_t rsv0, rsv1;
+} jf_mb_desc;
+
+int64_t jf_mb_state_ints(const jf_mb_params *p); /* int32 elements per prompt state */
+int32_t jf_mb_max_rows(const jf_mb_params *p);   /* max B (candidate rows)          */
+int32_t jf_mb_max_tokens(const jf_mb_params *p); /* max T per row                   */
+
+/* Start a generation call for P prompts (MB:230-262, then the first build_out_and_spans MB:317-377).
+ * states      [P, state_ints] int32
+ * input_ids   [P, n] int64 — token 0 is the correct next token, not yet cached (MB:243)
+ * kv_len      [P] int32 — committed KV length == prompt_len for this call (MB:261)
+ * desc        [P] jf_mb_desc
+ */
+int jf_mb_begin(int32_t *states, int64_t state_ints, int P, const jf_mb_params *params,
+                const int64_t *input_ids, const int32_t *kv_len, jf_mb_desc *desc, void *stream);
+
+/* Emit the forward inputs for the current iteration (MB:417-436) in a row-padded layout:
+ *   rows of prompt p start at row_base[p] = sum_{q<p} B_q (computed on the device),
+ *   input_ids [Rtot, Tpad] int64 (padding = pad_fill), positions [Rtot, Tpad] int32 (kv_len + t),
+ *   row_prompt [Rtot] int32, row_len [Rtot] int32 (T of that row).
+ * Also records (row_base, Tpad) in each state so jf_mb_step can find its greedy tokens.
+ */
+int jf_mb_pack(int32_t *states, int64_t state_ints, int P, int32_t Tpad, int64_t pad_fill,
+               int64_t *input_ids, int32_t *positions, int32_t *row_prompt, int32_t *row_len,
+               void *stream);
+
+/* One loop body after the forward (MB:467-721, and MB:723-740 when the call ends):
+ * verify every span against the packed argmax results, pick the best candidate row, EOS cap,
+ * accept, re-draft, pool + candidate build, KV bookkeeping, spawn, promote, early stop, then the
+ * next build_out_and_spans.  packed is indexed (row_base[p] + b) * Tpad + t and is re-zeroed.
+ */
+int jf_mb_step(int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len,
+               jf_mb_desc *desc, void *stream);
+
+/* Copy results of finished calls: ret [P, ret_cap] int64 (ret_len in desc). */
+int jf_mb_read_ret(const int32_t *states, int64_t state_ints, int P, int64_t *ret, int32_t ret_cap,
+                   void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * KV cache (a9/a10/a18).  Layout per layer: kv [2, rows, H_kv, S_max, D] (K then V), any 2-byte
+ * or 4-byte element; a "token row" is D elements.  Replaces the Triton store_kvcache_kernel
+ * (ATT:10-40), DynamicCache narrow/expand/contiguous (MB:93-127, 500-502) and trims (MB:36-59).
+ */
+/* scatter freshly computed K/V [N, H_kv, D] into cache slots: dst token index slot[i] (-1 = skip) */
+int jf_kv_append(void *k_cache, void *v_cache, const void *k_new, const void *v_new,
+                 const int64_t *slot, int64_t N, int32_t H_kv, int32_t D, int64_t S_max,
+                 int32_t elem_bytes, void *stream);
+
+/* commit accepted candidate rows: for prompt p copy desc[p].kv_copy_len token rows from the
+ * candidate scratch cand[(p*cand_rows + kv_src_row-1), :, 0:len] to main[p, :, kv_copy_dst: +len],
+ * for K and V of `layers` layers (pointer arrays live in device memory). */
+int jf_kv_commit(void *const *main_k, void *const *main_v, void *const *cand_k, void *const *cand_v,
+                 int32_t layers, const jf_mb_desc *desc, int P, int32_t cand_rows, int32_t H_kv,
+                 int32_t D, int64_t S_max, int64_t T_max, int32_t elem_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Engine single-block decoder step (a15): JD:567-710 for a batch of rows with a common L.
+ * draft [B, L] int64 (draft[:,0] = seed), packed argmax of logits [B, L-1, V] at
+ * packed[(b*(L-1)) + i].  Per row: acc_len (JD:572,589-590), EOS cap (JD:597-602), committed tokens
+ * (JD:609-631 incl. the AR fallback), next draft (JD:680-709) with pads taken from pad_stream in
+ * row order starting at *pad_cursor.
+ */
+typedef struct jf_engine_row {
+    int32_t acc_len;     /* after EOS cap                                   */
+    int32_t n_new;       /* tokens committed this step (>=1)                */
+    int32_t eos;         /* EOS committed                                   */
+    int32_t active_next; /* row keeps decoding (not eos, below max_tokens)  */
+    int32_t n_pads;      /* pads consumed for the next draft                */
+    int32_t rsv[3];
+} jf_engine_row;
+
+int jf_engine_step(const int64_t *draft, int B, int L, uint64_t *packed, int32_t eos_id,
+                   const int32_t *remaining_tokens /* [B] max_tokens - accepted so far */,
+                   int64_t *new_tokens /* [B, L] */, int64_t *next_draft /* [B, L] */,
+                   const int64_t *pad_stream, int64_t pad_stream_len, int64_t *pad_cursor,
+                   jf_engine_row *rows, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Non-greedy verify (a19): fused softmax-gather + argmax over logits [R, V] read once.
+ * For row r: p_draft[r] = softmax(logits[r] / T)[draft_next[r]] in fp32 (JDN:65-70, 328),
+ * row max / sum-exp (for residual sampling) and the packed argmax (JDN:446, 619).
+ */
+int jf_rs_probs(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride,
+                const int64_t *draft_next, float temperature, float *p_draft, float *row_max,
+                float *row_sumexp, uint64_t *packed, void *workspace, size_t workspace_bytes,
+                void *stream);
+size_t jf_rs_workspace_bytes(int64_t R, int64_t V);
+
+/* sequential accept/reject of one block (JDN:326-348) with injected uniforms u[L-1]; on the
+ * first rejection position the bonus token is drawn by inverse CDF from softmax(logits[row]/T)
+ * with bonus_u[16] retries != proposed (JDN:135-153).  result [4] int32: n_committed, eos,
+ * reject_pos (-1 none), n_bonus_draws; committed [L-1] int64.
+ */
+int jf_rs_accept(const void *logits, int dtype, int64_t V, int64_t row_stride, const int64_t *draft,
+                 int L, const float *p_draft, const float *row_max, const float *row_sumexp,
+                 float temperature, const float *u, const float *bonus_u, int32_t eos_id,
+                 int64_t *committed, int32_t *result, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JACOBIFORCING_H */

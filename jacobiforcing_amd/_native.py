@@ -1,0 +1,122 @@
+"""ctypes binding of the C-ABI library (include/jacobiforcing.h).
+
+The HIP library is the only implementation of the hot path this package has.  If it cannot be
+loaded the package fails loudly — there is no CPU or eager-PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "lib" / "libjacobiforcing.so"
+SRC_PATH = _PKG / "csrc" / "jf_kernels.hip"
+INCLUDE_DIR = _PKG.parent / "include"
+
+JF_OK, JF_E_INVALID, JF_E_CAPACITY, JF_E_LAUNCH = 0, -1, -2, -3
+JF_F32, JF_BF16 = 0, 1
+
+
+class MbParams(C.Structure):
+    _fields_ = [("n", C.c_int32), ("K", C.c_int32), ("spawn_threshold", C.c_int32), ("pool_size", C.c_int32),
+                ("eos_id", C.c_int32), ("pad_id", C.c_int32), ("max_iter", C.c_int32), ("max_blocks", C.c_int32),
+                ("lookahead_start_ratio", C.c_double)]
+
+
+class MbDesc(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in
+                ("B", "T", "done", "error", "iters", "kv_len", "ret_len", "next_token", "kv_src_row", "kv_copy_dst",
+                 "kv_copy_len", "events", "accepted", "nspans", "rsv0", "rsv1")]
+
+
+DESC_INTS = C.sizeof(MbDesc) // 4
+DESC_FIELDS = [f[0] for f in MbDesc._fields_]
+
+
+class EngineRow(C.Structure):
+    _fields_ = [("acc_len", C.c_int32), ("n_new", C.c_int32), ("eos", C.c_int32), ("active_next", C.c_int32),
+                ("n_pads", C.c_int32), ("rsv", C.c_int32 * 3)]
+
+
+ENGINE_ROW_INTS = C.sizeof(EngineRow) // 4
+
+_vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+
+_SIGNATURES = {
+    "jf_version": (C.c_int, []),
+    "jf_last_error": (C.c_char_p, []),
+    "jf_argmax_partial": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _vp, _vp]),
+    "jf_argmax_decode": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "jf_argmax_rows": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "jf_accept_lengths": (C.c_int, [_vp, C.c_int, _vp, _i64, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "jf_mb_state_ints": (_i64, [C.POINTER(MbParams)]),
+    "jf_mb_max_rows": (_i32, [C.POINTER(MbParams)]),
+    "jf_mb_max_tokens": (_i32, [C.POINTER(MbParams)]),
+    "jf_mb_begin": (C.c_int, [_vp, _i64, C.c_int, C.POINTER(MbParams), _vp, _vp, _vp, _vp]),
+    "jf_mb_pack": (C.c_int, [_vp, _i64, C.c_int, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "jf_mb_step": (C.c_int, [_vp, _i64, C.c_int, _vp, _i64, _vp, _vp]),
+    "jf_mb_read_ret": (C.c_int, [_vp, _i64, C.c_int, _vp, _i32, _vp]),
+    "jf_kv_append": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i32, _vp]),
+    "jf_kv_commit": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, C.c_int, _i32, _i32, _i32, _i64, _i64, _i32, _vp]),
+    "jf_engine_step": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "jf_rs_probs": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "jf_rs_workspace_bytes": (_sz, [_i64, _i64]),
+    "jf_rs_accept": (C.c_int, [_vp, C.c_int, _i64, _i64, _vp, C.c_int, _vp, _vp, _vp, _f32, _vp, _vp, _i32, _vp, _vp, _vp]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_LIB = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def load(path: os.PathLike | None = None):
+    """dlopen the library and attach signatures.  Raises NativeLibraryError when it is missing."""
+    p = Path(path) if path is not None else LIB_PATH
+    if not p.exists():
+        raise NativeLibraryError(
+            f"{p} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "jacobiforcing_amd has no CPU / eager fallback for the Jacobi loop body.")
+    try:
+        lib = C.CDLL(str(p))
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise NativeLibraryError(f"cannot load {p}: {e}") from e
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise NativeLibraryError(f"{p} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = load()
+    return _LIB
+
+
+def check(rc: int, what: str = ""):
+    """Map C-ABI return codes onto the exception types the reference raises."""
+    if rc == JF_OK:
+        return
+    msg = lib().jf_last_error()
+    msg = msg.decode() if isinstance(msg, (bytes, bytearray)) else str(msg)
+    text = f"{what}: {msg}" if what else msg
+    if rc == JF_E_INVALID:
+        raise ValueError(text)
+    raise RuntimeError(text)
+
+
+def raise_state_error(code: int, what: str):
+    if code == JF_E_INVALID:
+        raise ValueError(f"{what}: invalid state inside the Jacobi state machine (shape/assert; see MB:482, MB:631, MB:667)")
+    if code == JF_E_CAPACITY:
+        raise RuntimeError(f"{what}: fixed capacity exceeded inside the Jacobi state machine (raise max_blocks)")
+    if code:
+        raise RuntimeError(f"{what}: state machine error {code}")

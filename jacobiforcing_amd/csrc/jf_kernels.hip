@@ -1,0 +1,663 @@
+// jf_kernels.hip — gfx950 (MI355X / CDNA4) kernels and the C ABI of include/jacobiforcing.h.
+//
+// Everything here is HBM/latency-bound integer and compare work: no MFMA.  The only kernel that
+// moves real bytes is argmax_partial (R*V*esize per launch); it streams 16 B per lane with four
+// loads in flight, reduces with wave shuffles + one LDS hop and publishes one 64-bit atomicMax per
+// (row, chunk).  The Jacobi state machine runs one 64-lane wavefront per prompt (jf_mb_core.h).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "jacobiforcing.h"
+#include "jf_mb_core.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(JF_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return JF_OK;
+}
+
+extern "C" int jf_version(void) { return JF_VERSION; }
+extern "C" const char *jf_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------------
+// wave-level helpers (wavefront = 64 lanes)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        uint64_t o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        int o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// one wavefront per workgroup
+struct DevLanes {
+    __device__ __forceinline__ int lane() const { return threadIdx.x; }
+    __device__ __forceinline__ int count() const { return 64; }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+    __device__ __forceinline__ int reduce_min(int v) const { return wave_min_i32(v); }
+    __device__ __forceinline__ int reduce_sum(int v) const { return wave_sum_i32(v); }
+    __device__ __forceinline__ int prefix_count(bool pred) const {
+        const unsigned long long m = __ballot(pred);
+        return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// (a2) argmax over the vocabulary — the convergence kernel's HBM stream
+// ------------------------------------------------------------------------------------------------
+// order-preserving key of an fp32 payload with torch.argmax semantics:
+//   NaN -> greatest, -0.0 == +0.0, otherwise numeric order.
+__device__ __forceinline__ uint32_t order_key(uint32_t u) {
+    u = (u == 0x80000000u) ? 0u : u;
+    const uint32_t k = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((u & 0x7fffffffu) > 0x7f800000u) ? 0xFFFFFFFFu : k;
+}
+
+constexpr int AM_TPB = 256;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int DT> struct Elem;
+template <> struct Elem<JF_F32> { using T = uint32_t; static constexpr int EPV = 4; };
+template <> struct Elem<JF_BF16> { using T = uint16_t; static constexpr int EPV = 8; };
+
+template <int DT>
+__device__ __forceinline__ void consume_vec(const u32x4 v, uint32_t idx0, uint32_t &best, uint32_t &bidx) {
+    if constexpr (DT == JF_F32) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t k = order_key(w[j]);
+            if (k > best) { best = k; bidx = idx0 + j; }
+        }
+    } else {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t k0 = order_key(w[j] << 16);          // low half = element 2j
+            if (k0 > best) { best = k0; bidx = idx0 + 2 * j; }
+            const uint32_t k1 = order_key(w[j] & 0xFFFF0000u);  // high half = element 2j+1
+            if (k1 > best) { best = k1; bidx = idx0 + 2 * j + 1; }
+        }
+    }
+}
+
+template <int DT>
+__device__ __forceinline__ uint32_t load_key(const void *row, int64_t i) {
+    if constexpr (DT == JF_F32) return order_key(((const uint32_t *)row)[i]);
+    else return order_key(((uint32_t)((const uint16_t *)row)[i]) << 16);
+}
+
+// VEC: rows are 16-byte aligned -> 16 B per lane per load, 4 loads in flight.
+template <int DT, bool VEC>
+__global__ __launch_bounds__(AM_TPB) void argmax_partial_kernel(const void *__restrict__ logits, int64_t R, int64_t V,
+                                                                 int64_t row_stride, unsigned long long *__restrict__ packed,
+                                                                 int chunks_per_row, int64_t chunk_elems) {
+    using E = Elem<DT>;
+    constexpr int EPV = E::EPV;
+    const int64_t item = blockIdx.x;
+    const int64_t row = item / chunks_per_row;
+    const int c = (int)(item - row * chunks_per_row);
+    const int64_t begin = (int64_t)c * chunk_elems;
+    int64_t end = begin + chunk_elems;
+    if (end > V) end = V;
+    const typename E::T *p = (const typename E::T *)logits + row * row_stride;
+    const int tid = threadIdx.x;
+
+    uint32_t best = 0u, bidx = 0xFFFFFFFFu;   // every real key is >= 0x007FFFFF > 0
+    if constexpr (VEC) {
+        const u32x4 *pv = (const u32x4 *)p;
+        int64_t i = begin + (int64_t)tid * EPV;
+        constexpr int64_t STEP = (int64_t)AM_TPB * EPV;
+        for (; i + 3 * STEP + EPV <= end; i += 4 * STEP) {
+            const u32x4 v0 = __builtin_nontemporal_load(pv + (i) / EPV);
+            const u32x4 v1 = __builtin_nontemporal_load(pv + (i + STEP) / EPV);
+            const u32x4 v2 = __builtin_nontemporal_load(pv + (i + 2 * STEP) / EPV);
+            const u32x4 v3 = __builtin_nontemporal_load(pv + (i + 3 * STEP) / EPV);
+            consume_vec<DT>(v0, (uint32_t)i, best, bidx);
+            consume_vec<DT>(v1, (uint32_t)(i + STEP), best, bidx);
+            consume_vec<DT>(v2, (uint32_t)(i + 2 * STEP), best, bidx);
+            consume_vec<DT>(v3, (uint32_t)(i + 3 * STEP), best, bidx);
+        }
+        for (; i + EPV <= end; i += STEP) {
+            const u32x4 v0 = __builtin_nontemporal_load(pv + i / EPV);
+            consume_vec<DT>(v0, (uint32_t)i, best, bidx);
+        }
+        // ragged tail of the row (V not a multiple of EPV): the last <EPV elements
+        const int64_t vec_end = begin + ((end - begin) / EPV) * EPV;
+        for (int64_t j = vec_end + tid; j < end; j += AM_TPB) {
+            const uint32_t k = load_key<DT>(p, j);
+            if (k > best) { best = k; bidx = (uint32_t)j; }
+        }
+    } else {
+        for (int64_t j = begin + tid; j < end; j += AM_TPB) {
+            const uint32_t k = load_key<DT>(p, j);
+            if (k > best) { best = k; bidx = (uint32_t)j; }
+        }
+    }
+    // (key, first index) -> one u64 whose max is the answer: larger key wins, then smaller index
+    uint64_t pk = ((uint64_t)best << 32) | (uint64_t)(~bidx);
+    pk = wave_max_u64(pk);
+    __shared__ uint64_t s_part[AM_TPB / 64];
+    if ((tid & 63) == 0) s_part[tid >> 6] = pk;
+    __syncthreads();
+    if (tid == 0) {
+        uint64_t m = s_part[0];
+#pragma unroll
+        for (int w = 1; w < AM_TPB / 64; ++w) m = s_part[w] > m ? s_part[w] : m;
+        atomicMax(packed + row, (unsigned long long)m);
+    }
+}
+
+__global__ void argmax_decode_kernel(unsigned long long *packed, int64_t R, int64_t *greedy) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < R) {
+        greedy[r] = (int64_t)jfmb::decode_packed(packed[r]);
+        packed[r] = 0ull;
+    }
+}
+
+static int64_t pick_chunk(int dtype, int64_t R, int64_t V) {
+    const int64_t gran = (int64_t)AM_TPB * (dtype == JF_F32 ? 4 : 8);
+    const char *env = getenv("JF_ARGMAX_CHUNK");
+    if (env && atoll(env) > 0) {
+        int64_t c = atoll(env);
+        return ((c + gran - 1) / gran) * gran;
+    }
+    // aim for >= ~2048 workgroups (8 per CU) while keeping >= one full 4-deep unrolled pass per WG
+    const int64_t target_items = 2048;
+    int64_t per_row = (target_items + R - 1) / R;
+    if (per_row < 1) per_row = 1;
+    int64_t chunk = (V + per_row - 1) / per_row;
+    chunk = ((chunk + gran - 1) / gran) * gran;
+    const int64_t lo = 4 * gran, hi = 16 * gran;
+    if (chunk < lo) chunk = lo;
+    if (chunk > hi) chunk = hi;
+    return chunk;
+}
+
+extern "C" int jf_argmax_partial(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride,
+                                 uint64_t *packed, void *stream) {
+    if (R == 0) return JF_OK;
+    if (!logits || !packed) return fail(JF_E_INVALID, "jf_argmax_partial: null pointer");
+    if (dtype != JF_F32 && dtype != JF_BF16) return fail(JF_E_INVALID, "jf_argmax_partial: dtype %d", dtype);
+    if (R < 0 || V <= 0 || row_stride < V || V > 0x7FFFFFFFll)
+        return fail(JF_E_INVALID, "jf_argmax_partial: bad shape R=%lld V=%lld stride=%lld", (long long)R, (long long)V,
+                    (long long)row_stride);
+    const int esz = dtype == JF_F32 ? 4 : 2;
+    const bool vec = (((uintptr_t)logits) % 16 == 0) && ((row_stride * esz) % 16 == 0);
+    const int64_t chunk = pick_chunk(dtype, R, V);
+    const int64_t cpr = (V + chunk - 1) / chunk;
+    const int64_t items = R * cpr;
+    if (items > 0x7FFFFFFFll) return fail(JF_E_CAPACITY, "jf_argmax_partial: grid too large");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)items), block(AM_TPB);
+    unsigned long long *pk = (unsigned long long *)packed;
+    if (dtype == JF_F32) {
+        if (vec) argmax_partial_kernel<JF_F32, true><<<grid, block, 0, s>>>(logits, R, V, row_stride, pk, (int)cpr, chunk);
+        else argmax_partial_kernel<JF_F32, false><<<grid, block, 0, s>>>(logits, R, V, row_stride, pk, (int)cpr, chunk);
+    } else {
+        if (vec) argmax_partial_kernel<JF_BF16, true><<<grid, block, 0, s>>>(logits, R, V, row_stride, pk, (int)cpr, chunk);
+        else argmax_partial_kernel<JF_BF16, false><<<grid, block, 0, s>>>(logits, R, V, row_stride, pk, (int)cpr, chunk);
+    }
+    return check_launch("argmax_partial_kernel");
+}
+
+extern "C" int jf_argmax_decode(uint64_t *packed, int64_t R, int64_t *greedy, void *stream) {
+    if (R == 0) return JF_OK;
+    if (!packed || !greedy || R < 0) return fail(JF_E_INVALID, "jf_argmax_decode: bad argument");
+    argmax_decode_kernel<<<dim3((unsigned)((R + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        (unsigned long long *)packed, R, greedy);
+    return check_launch("argmax_decode_kernel");
+}
+
+extern "C" int jf_argmax_rows(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, uint64_t *packed,
+                              int64_t *greedy, void *stream) {
+    int rc = jf_argmax_partial(logits, dtype, R, V, row_stride, packed, stream);
+    if (rc) return rc;
+    return jf_argmax_decode(packed, R, greedy, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// (a3) accepted-prefix scan
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void accept_lengths_kernel(const int64_t *draft, int draft_rows, const int64_t *greedy,
+                                                              int64_t greedy_stride, int B, int L, int32_t *accepted,
+                                                              int32_t *best_idx) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int b = wave; b < B; b += 4) {
+        const int64_t *d = draft + (int64_t)(draft_rows == 1 ? 0 : b) * L;
+        const int64_t *g = greedy + (int64_t)b * greedy_stride;
+        int m = L - 1;
+        for (int i0 = 0; i0 < L - 1; i0 += 64) {   // ballot + first-set-bit per 64 tokens
+            const int i = i0 + lane;
+            const bool mis = (i < L - 1) && (d[i + 1] != g[i]);
+            const unsigned long long bal = __ballot(mis);
+            if (bal) { m = i0 + __ffsll((long long)bal) - 1; break; }
+        }
+        if (lane == 0) accepted[b] = (L == 0) ? 0 : m + 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && best_idx) {
+        int best = -1, bi = 0;
+        for (int b = 0; b < B; ++b)
+            if (accepted[b] > best) { best = accepted[b]; bi = b; }
+        *best_idx = bi;
+    }
+}
+
+extern "C" int jf_accept_lengths(const int64_t *draft, int draft_rows, const int64_t *greedy, int64_t greedy_stride, int B,
+                                 int L, int32_t *accepted, int32_t *best_idx, void *stream) {
+    if (B <= 0) return JF_OK;
+    if (!draft || !greedy || !accepted) return fail(JF_E_INVALID, "jf_accept_lengths: null pointer");
+    if (draft_rows != 1 && draft_rows != B)
+        return fail(JF_E_INVALID, "jf_accept_lengths: draft rows %d do not broadcast against %d", draft_rows, B);
+    if (L < 0 || greedy_stride < L - 1) return fail(JF_E_INVALID, "jf_accept_lengths: bad L/stride");
+    accept_lengths_kernel<<<1, 256, 0, (hipStream_t)stream>>>(draft, draft_rows, greedy, greedy_stride, B, L, accepted, best_idx);
+    return check_launch("accept_lengths_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// multiblock state machine: one wavefront per prompt
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void mb_begin_kernel(int32_t *states, int64_t state_ints, jf_mb_params prm,
+                                                       const int64_t *input_ids, const int32_t *kv_len, jf_mb_desc *desc) {
+    jfmb::mb_begin_body(DevLanes{}, blockIdx.x, states, state_ints, prm, input_ids, kv_len, desc);
+}
+__global__ __launch_bounds__(64) void mb_pack_kernel(int32_t *states, int64_t state_ints, int32_t Tpad, int64_t pad_fill,
+                                                      int64_t *input_ids, int32_t *positions, int32_t *row_prompt,
+                                                      int32_t *row_len) {
+    jfmb::mb_pack_body(DevLanes{}, blockIdx.x, states, state_ints, Tpad, pad_fill, input_ids, positions, row_prompt, row_len);
+}
+__global__ __launch_bounds__(64) void mb_step_kernel(int32_t *states, int64_t state_ints, unsigned long long *packed,
+                                                      int64_t packed_len, jf_mb_desc *desc) {
+    jfmb::mb_step_body(DevLanes{}, blockIdx.x, states, state_ints, (uint64_t *)packed, packed_len, desc);
+}
+__global__ __launch_bounds__(64) void mb_read_ret_kernel(const int32_t *states, int64_t state_ints, int64_t *ret,
+                                                          int32_t ret_cap) {
+    jfmb::mb_read_ret_body(DevLanes{}, blockIdx.x, states, state_ints, ret, ret_cap);
+}
+
+static int check_params(const jf_mb_params *p, const char *who) {
+    if (!p) return fail(JF_E_INVALID, "%s: null params", who);
+    if (p->n < 1 || p->n > 1024) return fail(JF_E_INVALID, "%s: n=%d out of range [1,1024]", who, p->n);
+    if (p->K < 1) return fail(JF_E_INVALID, "%s: K=%d", who, p->K);
+    if (p->pool_size < 0 || p->pool_size > 64) return fail(JF_E_INVALID, "%s: pool_size=%d out of range [0,64]", who, p->pool_size);
+    if (p->max_iter < 0) return fail(JF_E_INVALID, "%s: max_iter=%d", who, p->max_iter);
+    return JF_OK;
+}
+
+extern "C" int64_t jf_mb_state_ints(const jf_mb_params *p) {
+    if (check_params(p, "jf_mb_state_ints")) return -1;
+    return jfmb::make_layout(p->n, p->K, p->pool_size, p->max_blocks).total;
+}
+extern "C" int32_t jf_mb_max_rows(const jf_mb_params *p) {
+    if (check_params(p, "jf_mb_max_rows")) return -1;
+    return jfmb::make_layout(p->n, p->K, p->pool_size, p->max_blocks).RMAX;
+}
+extern "C" int32_t jf_mb_max_tokens(const jf_mb_params *p) {
+    if (check_params(p, "jf_mb_max_tokens")) return -1;
+    return jfmb::make_layout(p->n, p->K, p->pool_size, p->max_blocks).TMAX;
+}
+
+extern "C" int jf_mb_begin(int32_t *states, int64_t state_ints, int P, const jf_mb_params *params, const int64_t *input_ids,
+                           const int32_t *kv_len, jf_mb_desc *desc, void *stream) {
+    if (P <= 0) return JF_OK;
+    int rc = check_params(params, "jf_mb_begin");
+    if (rc) return rc;
+    if (!states || !input_ids || !kv_len) return fail(JF_E_INVALID, "jf_mb_begin: null pointer");
+    if (state_ints < jf_mb_state_ints(params)) return fail(JF_E_INVALID, "jf_mb_begin: state block too small");
+    mb_begin_kernel<<<P, 64, 0, (hipStream_t)stream>>>(states, state_ints, *params, input_ids, kv_len, desc);
+    return check_launch("mb_begin_kernel");
+}
+
+extern "C" int jf_mb_pack(int32_t *states, int64_t state_ints, int P, int32_t Tpad, int64_t pad_fill, int64_t *input_ids,
+                          int32_t *positions, int32_t *row_prompt, int32_t *row_len, void *stream) {
+    if (P <= 0) return JF_OK;
+    if (!states || !input_ids || !positions || !row_prompt || !row_len) return fail(JF_E_INVALID, "jf_mb_pack: null pointer");
+    if (Tpad <= 0) return fail(JF_E_INVALID, "jf_mb_pack: Tpad=%d", Tpad);
+    mb_pack_kernel<<<P, 64, 0, (hipStream_t)stream>>>(states, state_ints, Tpad, pad_fill, input_ids, positions, row_prompt, row_len);
+    return check_launch("mb_pack_kernel");
+}
+
+extern "C" int jf_mb_step(int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len, jf_mb_desc *desc,
+                          void *stream) {
+    if (P <= 0) return JF_OK;
+    if (!states || !packed) return fail(JF_E_INVALID, "jf_mb_step: null pointer");
+    mb_step_kernel<<<P, 64, 0, (hipStream_t)stream>>>(states, state_ints, (unsigned long long *)packed, packed_len, desc);
+    return check_launch("mb_step_kernel");
+}
+
+extern "C" int jf_mb_read_ret(const int32_t *states, int64_t state_ints, int P, int64_t *ret, int32_t ret_cap, void *stream) {
+    if (P <= 0) return JF_OK;
+    if (!states || !ret || ret_cap <= 0) return fail(JF_E_INVALID, "jf_mb_read_ret: bad argument");
+    mb_read_ret_kernel<<<P, 64, 0, (hipStream_t)stream>>>(states, state_ints, ret, ret_cap);
+    return check_launch("mb_read_ret_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// KV cache: append (scatter) and candidate-row commit.  A token row is D elements = D*esz bytes
+// (256 B for bf16 / D=128): 16 lanes x 16 B, four token rows per wavefront instruction.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kv_append_kernel(uint4 *__restrict__ k_cache, uint4 *__restrict__ v_cache,
+                                                         const uint4 *__restrict__ k_new, const uint4 *__restrict__ v_new,
+                                                         const int64_t *__restrict__ slot, int64_t N, int H_kv,
+                                                         int vec_per_row, int64_t S_max) {
+    // one (token, head) row per vec_per_row lanes
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t rowid = gid / vec_per_row;
+    const int lane = (int)(gid - rowid * vec_per_row);
+    if (rowid >= N * H_kv) return;
+    const int64_t tok = rowid / H_kv;
+    const int h = (int)(rowid - tok * H_kv);
+    const int64_t sl = slot[tok];
+    if (sl < 0) return;                                   // ATT:24 (slot == -1 skipped)
+    const int64_t brow = sl / S_max, pos = sl - brow * S_max;
+    const int64_t dst = ((brow * H_kv + h) * S_max + pos) * vec_per_row + lane;
+    const int64_t src = rowid * vec_per_row + lane;
+    k_cache[dst] = k_new[src];
+    v_cache[dst] = v_new[src];
+}
+
+extern "C" int jf_kv_append(void *k_cache, void *v_cache, const void *k_new, const void *v_new, const int64_t *slot, int64_t N,
+                            int32_t H_kv, int32_t D, int64_t S_max, int32_t elem_bytes, void *stream) {
+    if (N <= 0) return JF_OK;
+    if (!k_cache || !v_cache || !k_new || !v_new || !slot) return fail(JF_E_INVALID, "jf_kv_append: null pointer");
+    const int64_t row_bytes = (int64_t)D * elem_bytes;
+    if (row_bytes % 16 != 0 || H_kv <= 0 || S_max <= 0) return fail(JF_E_INVALID, "jf_kv_append: row bytes %lld not /16", (long long)row_bytes);
+    const int vpr = (int)(row_bytes / 16);
+    const int64_t threads = N * H_kv * vpr;
+    kv_append_kernel<<<dim3((unsigned)((threads + 255) / 256)), 256, 0, (hipStream_t)stream>>>(
+        (uint4 *)k_cache, (uint4 *)v_cache, (const uint4 *)k_new, (const uint4 *)v_new, slot, N, H_kv, vpr, S_max);
+    return check_launch("kv_append_kernel");
+}
+
+__global__ __launch_bounds__(256) void kv_commit_kernel(void *const *main_k, void *const *main_v, void *const *cand_k,
+                                                         void *const *cand_v, const jf_mb_desc *desc, int cand_rows, int H_kv,
+                                                         int vec_per_row, int64_t S_max, int64_t T_max) {
+    const int p = blockIdx.x;
+    const int layer = blockIdx.y >> 1, which = blockIdx.y & 1;
+    const jf_mb_desc d = desc[p];
+    if (d.kv_copy_len <= 0 || d.kv_src_row <= 0) return;
+    const uint4 *src = (const uint4 *)(which ? cand_v[layer] : cand_k[layer]);
+    uint4 *dst = (uint4 *)(which ? main_v[layer] : main_k[layer]);
+    const int64_t crow = (int64_t)p * cand_rows + (d.kv_src_row - 1);
+    const int64_t total = (int64_t)H_kv * d.kv_copy_len * vec_per_row;
+    for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
+        const int lane = (int)(i % vec_per_row);
+        const int64_t r = i / vec_per_row;
+        const int t = (int)(r % d.kv_copy_len);
+        const int h = (int)(r / d.kv_copy_len);
+        const int64_t s_off = ((crow * H_kv + h) * T_max + t) * vec_per_row + lane;
+        const int64_t d_off = (((int64_t)p * H_kv + h) * S_max + d.kv_copy_dst + t) * vec_per_row + lane;
+        dst[d_off] = src[s_off];
+    }
+}
+
+extern "C" int jf_kv_commit(void *const *main_k, void *const *main_v, void *const *cand_k, void *const *cand_v, int32_t layers,
+                            const jf_mb_desc *desc, int P, int32_t cand_rows, int32_t H_kv, int32_t D, int64_t S_max,
+                            int64_t T_max, int32_t elem_bytes, void *stream) {
+    if (P <= 0 || layers <= 0 || cand_rows <= 0) return JF_OK;
+    if (!main_k || !main_v || !cand_k || !cand_v || !desc) return fail(JF_E_INVALID, "jf_kv_commit: null pointer");
+    const int64_t row_bytes = (int64_t)D * elem_bytes;
+    if (row_bytes % 16 != 0) return fail(JF_E_INVALID, "jf_kv_commit: row bytes %lld not /16", (long long)row_bytes);
+    kv_commit_kernel<<<dim3(P, layers * 2), 256, 0, (hipStream_t)stream>>>(main_k, main_v, cand_k, cand_v, desc, cand_rows, H_kv,
+                                                                         (int)(row_bytes / 16), S_max, T_max);
+    return check_launch("kv_commit_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// engine single-block step: 4 wavefronts take the rows round-robin, then one pass hands out pads
+// ------------------------------------------------------------------------------------------------
+struct WaveLanes {   // one wavefront inside a 256-thread workgroup; no workgroup barrier inside a row
+    __device__ __forceinline__ int lane() const { return threadIdx.x & 63; }
+    __device__ __forceinline__ int count() const { return 64; }
+    __device__ __forceinline__ void sync() const {}
+    __device__ __forceinline__ int reduce_min(int v) const { return wave_min_i32(v); }
+    __device__ __forceinline__ int reduce_sum(int v) const { return wave_sum_i32(v); }
+};
+
+__global__ __launch_bounds__(256) void engine_step_kernel(const int64_t *draft, int B, int L, unsigned long long *packed,
+                                                           int eos_id, const int32_t *remaining, int64_t *new_tokens,
+                                                           int64_t *next_draft, const int64_t *pad_stream, int64_t pad_len,
+                                                           int64_t *pad_cursor, jf_engine_row *rows) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int b = wave; b < B; b += 4) {
+        const unsigned long long *pk = packed + (int64_t)b * (L - 1);
+        auto G = [pk](int i) { return jfmb::decode_packed(pk[i]); };
+        jfmb::EngineRowOut o = jfmb::engine_row_body(WaveLanes{}, draft + (int64_t)b * L, L, G, eos_id, remaining[b],
+                                                     new_tokens + (int64_t)b * L, next_draft + (int64_t)b * L);
+        if (lane == 0) {
+            rows[b].acc_len = o.acc_len; rows[b].n_new = o.n_new; rows[b].eos = o.eos; rows[b].active_next = o.active_next;
+            rows[b].n_pads = o.active_next ? (L - 1 - o.copy_len) : 0;
+            rows[b].rsv[0] = o.copy_len;
+        }
+    }
+    __syncthreads();
+    // pads in row order (JD:705-707 consumes torch.randint sequentially): exclusive scan over rows
+    __shared__ int64_t s_base;
+    if (threadIdx.x == 0) s_base = *pad_cursor;
+    __syncthreads();
+    int64_t run = s_base;
+    for (int b = 0; b < B; ++b) {
+        const int np = rows[b].n_pads, cl = rows[b].rsv[0];
+        for (int i = threadIdx.x; i < np; i += blockDim.x) {
+            const int64_t k = run + i;
+            next_draft[(int64_t)b * L + 1 + cl + i] = pad_stream[pad_len > 0 ? (k % pad_len) : 0];
+        }
+        run += np;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *pad_cursor = run;
+    for (int64_t i = threadIdx.x; i < (int64_t)B * (L - 1); i += blockDim.x) packed[i] = 0ull;
+}
+
+extern "C" int jf_engine_step(const int64_t *draft, int B, int L, uint64_t *packed, int32_t eos_id, const int32_t *remaining_tokens,
+                              int64_t *new_tokens, int64_t *next_draft, const int64_t *pad_stream, int64_t pad_stream_len,
+                              int64_t *pad_cursor, jf_engine_row *rows, void *stream) {
+    if (B <= 0) return JF_OK;
+    if (L < 2) return fail(JF_E_INVALID, "Draft must have at least 2 tokens (seed + 1 speculative)");   // MR:1144-1145
+    if (!draft || !packed || !remaining_tokens || !new_tokens || !next_draft || !pad_cursor || !rows || (!pad_stream && pad_stream_len > 0))
+        return fail(JF_E_INVALID, "jf_engine_step: null pointer");
+    engine_step_kernel<<<1, 256, 0, (hipStream_t)stream>>>(draft, B, L, (unsigned long long *)packed, eos_id, remaining_tokens,
+                                                        new_tokens, next_draft, pad_stream, pad_stream_len, pad_cursor, rows);
+    return check_launch("engine_step_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// (a19) non-greedy verify: fused online-softmax gather + argmax, logits read once
+// ------------------------------------------------------------------------------------------------
+template <int DT>
+__device__ __forceinline__ float load_f(const void *row, int64_t i) {
+    if constexpr (DT == JF_F32) return ((const float *)row)[i];
+    else return __uint_as_float(((uint32_t)((const uint16_t *)row)[i]) << 16);
+}
+
+// one workgroup per row: running (max, sum exp((x-max)/T)) per lane, merged by shuffles.
+template <int DT>
+__global__ __launch_bounds__(256) void rs_probs_kernel(const void *logits, int64_t R, int64_t V, int64_t row_stride,
+                                                        const int64_t *draft_next, float inv_temp, float *p_draft,
+                                                        float *row_max, float *row_sumexp, unsigned long long *packed) {
+    using E = Elem<DT>;
+    const int64_t row = blockIdx.x;
+    const typename E::T *p = (const typename E::T *)logits + row * row_stride;
+    const int tid = threadIdx.x;
+    float m = -INFINITY, s = 0.f;
+    uint32_t best = 0u, bidx = 0xFFFFFFFFu;
+    for (int64_t i = tid; i < V; i += 256) {
+        const float x = load_f<DT>(p, i) * inv_temp;
+        uint32_t k;
+        if constexpr (DT == JF_F32) k = order_key(((const uint32_t *)p)[i]);
+        else k = order_key(((uint32_t)((const uint16_t *)p)[i]) << 16);
+        if (k > best) { best = k; bidx = (uint32_t)i; }
+        if (x > m) { s = s * expf(m - x) + 1.f; m = x; }
+        else s += expf(x - m);
+    }
+    // merge (m, s) across the workgroup
+    __shared__ float sm[256], ss[256];
+    __shared__ uint64_t sp[4];
+    sm[tid] = m; ss[tid] = s;
+    uint64_t pk = wave_max_u64(((uint64_t)best << 32) | (uint64_t)(~bidx));
+    if ((tid & 63) == 0) sp[tid >> 6] = pk;
+    __syncthreads();
+    if (tid == 0) {
+        float M = -INFINITY;
+        for (int i = 0; i < 256; ++i) M = sm[i] > M ? sm[i] : M;
+        float Ssum = 0.f;
+        for (int i = 0; i < 256; ++i) Ssum += (sm[i] == -INFINITY) ? 0.f : ss[i] * expf(sm[i] - M);
+        row_max[row] = M;
+        row_sumexp[row] = Ssum;
+        const int64_t tok = draft_next[row];
+        float pd = 0.f;
+        if (tok >= 0 && tok < V) pd = expf(load_f<DT>(p, tok) * inv_temp - M) / Ssum;
+        p_draft[row] = pd;
+        uint64_t mm = sp[0];
+        for (int w = 1; w < 4; ++w) mm = sp[w] > mm ? sp[w] : mm;
+        packed[row] = mm;
+    }
+}
+
+extern "C" size_t jf_rs_workspace_bytes(int64_t R, int64_t V) { (void)R; (void)V; return 0; }
+
+extern "C" int jf_rs_probs(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, const int64_t *draft_next,
+                           float temperature, float *p_draft, float *row_max, float *row_sumexp, uint64_t *packed,
+                           void *workspace, size_t workspace_bytes, void *stream) {
+    (void)workspace; (void)workspace_bytes;
+    if (R <= 0) return JF_OK;
+    if (!logits || !draft_next || !p_draft || !row_max || !row_sumexp || !packed) return fail(JF_E_INVALID, "jf_rs_probs: null pointer");
+    if (dtype != JF_F32 && dtype != JF_BF16) return fail(JF_E_INVALID, "jf_rs_probs: dtype %d", dtype);
+    const float t = (temperature <= 0.f) ? 1.f : temperature;    // JDN:66-67
+    const float inv = 1.f / t;
+    if (dtype == JF_F32)
+        rs_probs_kernel<JF_F32><<<dim3((unsigned)R), 256, 0, (hipStream_t)stream>>>(logits, R, V, row_stride, draft_next, inv, p_draft, row_max, row_sumexp, (unsigned long long *)packed);
+    else
+        rs_probs_kernel<JF_BF16><<<dim3((unsigned)R), 256, 0, (hipStream_t)stream>>>(logits, R, V, row_stride, draft_next, inv, p_draft, row_max, row_sumexp, (unsigned long long *)packed);
+    return check_launch("rs_probs_kernel");
+}
+
+// sequential accept/reject of one block + inverse-CDF bonus draw on the rejected row
+template <int DT>
+__global__ __launch_bounds__(256) void rs_accept_kernel(const void *logits, int64_t V, int64_t row_stride, const int64_t *draft,
+                                                         int L, const float *p_draft, const float *row_max,
+                                                         const float *row_sumexp, float inv_temp, const float *u,
+                                                         const float *bonus_u, int eos_id, int64_t *committed, int32_t *result) {
+    __shared__ int s_n, s_eos, s_rej, s_pick;
+    __shared__ double s_sum[256], s_pre[256];
+    __shared__ double s_total;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        int n = 0, eos = 0, rej = -1;
+        for (int t = 0; t < L - 1; ++t) {                          // JDN:326-348
+            const int64_t proposed = draft[t + 1];
+            if (u[t] < p_draft[t]) {
+                committed[n++] = proposed;
+                if (eos_id >= 0 && proposed == eos_id) { eos = 1; break; }
+                continue;
+            }
+            rej = t;
+            break;
+        }
+        s_n = n; s_eos = eos; s_rej = rej;
+    }
+    __syncthreads();
+    const int rej = s_rej;
+    int draws = 0;
+    if (rej >= 0) {
+        // residual sampling (JDN:135-153): inverse CDF over p = exp(x/T - M)/S in vocabulary order with a
+        // float64 running sum; each thread owns a contiguous slice, so the scan is two-level.
+        const void *row = (const char *)logits + (int64_t)rej * row_stride * (DT == JF_F32 ? 4 : 2);
+        const float M = row_max[rej], Sx = row_sumexp[rej];
+        const int64_t per = (V + 255) / 256;
+        const int64_t lo = (int64_t)tid * per < V ? (int64_t)tid * per : V;
+        const int64_t hi = (lo + per < V) ? lo + per : V;
+        double acc = 0.0;
+        for (int64_t i = lo; i < hi; ++i) acc += (double)(expf(load_f<DT>(row, i) * inv_temp - M) / Sx);
+        s_sum[tid] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            double run = 0.0;
+            for (int i = 0; i < 256; ++i) { s_pre[i] = run; run += s_sum[i]; }
+            s_total = run;
+        }
+        __syncthreads();
+        const int64_t proposed = draft[rej + 1];
+        int bonus = -1;
+        for (int tr = 0; tr < 16 && bonus < 0; ++tr) {
+            const double thr = (double)bonus_u[tr] * s_total;
+            if (tid == 0) s_pick = (int)(V - 1);                   // clamp when thr >= total
+            __syncthreads();
+            const double pre = s_pre[tid];
+            if (hi > lo && thr >= pre && thr < pre + acc) {        // exactly one slice owns thr
+                double run = pre;
+                int64_t pick = hi - 1;
+                for (int64_t i = lo; i < hi; ++i) {
+                    run += (double)(expf(load_f<DT>(row, i) * inv_temp - M) / Sx);
+                    if (run > thr) { pick = i; break; }
+                }
+                s_pick = (int)pick;
+            }
+            __syncthreads();
+            draws++;
+            if ((int64_t)s_pick != proposed) bonus = s_pick;
+            __syncthreads();
+        }
+        if (tid == 0) {
+            // after 16 collisions the reference takes argmax of p with the proposed id masked (JDN:147-153);
+            // the wrapper resolves that rare case from result[3] == 16 && committed == proposed.
+            if (bonus < 0) bonus = (int)proposed;
+            committed[s_n] = bonus;
+            s_n = s_n + 1;
+            if (eos_id >= 0 && bonus == eos_id) s_eos = 1;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { result[0] = s_n; result[1] = s_eos; result[2] = rej; result[3] = draws; }
+}
+
+extern "C" int jf_rs_accept(const void *logits, int dtype, int64_t V, int64_t row_stride, const int64_t *draft, int L,
+                            const float *p_draft, const float *row_max, const float *row_sumexp, float temperature,
+                            const float *u, const float *bonus_u, int32_t eos_id, int64_t *committed, int32_t *result,
+                            void *stream) {
+    if (L <= 1) return JF_OK;
+    if (!logits || !draft || !p_draft || !row_max || !row_sumexp || !u || !bonus_u || !committed || !result)
+        return fail(JF_E_INVALID, "jf_rs_accept: null pointer");
+    const float t = (temperature <= 0.f) ? 1.f : temperature;
+    const float inv = 1.f / t;
+    if (dtype == JF_F32)
+        rs_accept_kernel<JF_F32><<<1, 256, 0, (hipStream_t)stream>>>(logits, V, row_stride, draft, L, p_draft, row_max, row_sumexp, inv, u, bonus_u, eos_id, committed, result);
+    else if (dtype == JF_BF16)
+        rs_accept_kernel<JF_BF16><<<1, 256, 0, (hipStream_t)stream>>>(logits, V, row_stride, draft, L, p_draft, row_max, row_sumexp, inv, u, bonus_u, eos_id, committed, result);
+    else return fail(JF_E_INVALID, "jf_rs_accept: dtype %d", dtype);
+    return check_launch("rs_accept_kernel");
+}

@@ -1,0 +1,613 @@
+// jf_mb_core.h — the multiblock Jacobi state machine (one generation call of the reference's
+// jacobi_forward_greedy_multiblock, MB:227-740), written once against a small "lanes" policy:
+//
+//   * DevLanes  (jf_kernels.hip): one 64-lane wavefront per prompt; token rows are compared,
+//     searched and copied 64 tokens per instruction, reductions are wave shuffles.
+//   * a single-lane policy used ONLY by tests/hostsim (CPU CI of this logic; never shipped).
+//
+// Control flow is wave-uniform: every lane holds the same scalars in registers; token arrays live
+// in the state block (LDS-staged or global) and phases that exchange data through it are separated
+// by lanes.sync().
+//
+// MB = modeling/cllm2_qwen2_modeling_kv_terminate_on_eos_improved_multiblock_lookahead_unified.py
+#pragma once
+#include <stdint.h>
+
+#include "jacobiforcing.h"
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define JF_HD __host__ __device__ __forceinline__
+#else
+#define JF_HD inline
+#endif
+
+#define JF_FAIL(code) do { err = (code); err_line = __LINE__; } while (0)
+
+namespace jfmb {
+
+// ---- header slots (int32 indices into the state block) ---------------------------------------
+enum : int {
+    H_N = 0, H_K, H_SPAWN_THR, H_POOL_SIZE, H_EOS, H_PAD, H_MAX_ITER, H_NB,      // params
+    H_RMAX, H_TMAX, H_LPOOL, H_LOOK_LO, H_LOOK_HI,
+    H_NUM_BLOCKS, H_ACTIVE, H_RA, H_LEN_LISTS, H_LNT, H_HAS_LNT, H_ITERS, H_DONE, // MB:249-262
+    H_RET_EARLY, H_ERR, H_PROMPT_LEN, H_KV_LEN, H_POOL_COUNT, H_POOL_HEAD,
+    H_RET_LEN, H_NEXT_TOK, H_B, H_T, H_NSPANS, H_ROW_BASE, H_TPAD,
+    H_SPANS = 40,            // 3 ints per span (block, start, L), up to NB spans
+    H_END = 40 + 3 * 16
+};
+constexpr int MAX_NB = 16;
+
+enum : int { EVT_SPAWN = 1, EVT_SWITCH = 2, EVT_EARLY = 4 };
+
+struct Layout {
+    int n, NB, RMAX, TMAX, LPOOL, pool_size;
+    int blk_stride;   // per block: [need_reverify, total_acc, acc_len, draft_rows, draft_len, rsv*3] + out_acc[n+1] + draft[RMAX][n]
+    int off_blocks, off_pool, off_out, off_ret, total;
+};
+
+JF_HD int imax(int a, int b) { return a > b ? a : b; }
+JF_HD int imin(int a, int b) { return a < b ? a : b; }
+
+JF_HD Layout make_layout(int n, int K, int pool_size, int max_blocks) {
+    Layout L;
+    L.n = n;
+    L.NB = imin(imax(max_blocks, K), MAX_NB);
+    L.RMAX = imax(1, pool_size);          // 1 + (pool_size-1) recycled candidates (MB:74, 579-582)
+    L.TMAX = L.NB * n;                    // RA draft + (acc ⧺ tail) of every pseudo block (MB:317-377)
+    L.LPOOL = L.NB * n;                   // concat of all blocks (MB:387-411)
+    L.pool_size = pool_size;
+    L.blk_stride = 8 + (n + 1) + L.RMAX * n;
+    L.off_blocks = H_END;
+    L.off_pool = L.off_blocks + L.NB * L.blk_stride;
+    L.off_out = L.off_pool + imax(pool_size, 0) * (1 + L.LPOOL);
+    L.off_ret = L.off_out + L.RMAX * L.TMAX;
+    L.total = L.off_ret + L.TMAX + 2;
+    L.total = (L.total + 3) & ~3;         // keep 16-byte multiples
+    return L;
+}
+
+JF_HD Layout layout_of(const int32_t *S) {
+    return make_layout(S[H_N], S[H_K], S[H_POOL_SIZE], S[H_NB]);
+}
+
+enum : int { B_NEED = 0, B_TOTAL, B_ACCLEN, B_DROWS, B_DLEN, B_HDR = 8 };
+
+// ---- the machine -----------------------------------------------------------------------------
+// GreedyFn: int operator()(int row, int t)  -> argmax token of logits[row, t] of this prompt.
+template <class Lanes>
+struct Machine {
+    int32_t *S;
+    Layout L;
+    Lanes lanes;
+
+    // scalar state mirrored in registers (uniform across lanes)
+    int n, K, eos, pad, num_blocks, active, RA, len_lists, lnt, has_lnt, iters, done, ret_early, err;
+    int prompt_len, kv_len, pool_count, pool_head;
+    int events, ra_accepted, kv_src_row, kv_copy_dst, kv_copy_len, err_line;
+
+    JF_HD Machine(int32_t *s, Lanes l, const Layout &lay) : S(s), L(lay), lanes(l) {}
+
+    JF_HD int32_t *blk(int b) const { return S + L.off_blocks + b * L.blk_stride; }
+    JF_HD int32_t *acc(int b) const { return blk(b) + B_HDR; }
+    JF_HD int32_t *draft(int b, int r) const { return blk(b) + B_HDR + (L.n + 1) + r * L.n; }
+    JF_HD int32_t *pool_entry(int i) const {   // i-th oldest, 0 <= i < pool_count
+        int slot = (pool_head + i) % L.pool_size;
+        return S + L.off_pool + slot * (1 + L.LPOOL);
+    }
+    JF_HD int32_t *out_row(int r) const { return S + L.off_out + r * L.TMAX; }
+    JF_HD int32_t *ret() const { return S + L.off_ret; }
+
+    JF_HD void load_scalars() {
+        n = S[H_N]; K = S[H_K]; eos = S[H_EOS]; pad = S[H_PAD];
+        num_blocks = S[H_NUM_BLOCKS]; active = S[H_ACTIVE]; RA = S[H_RA]; len_lists = S[H_LEN_LISTS];
+        lnt = S[H_LNT]; has_lnt = S[H_HAS_LNT]; iters = S[H_ITERS]; done = S[H_DONE];
+        ret_early = S[H_RET_EARLY]; err = S[H_ERR]; prompt_len = S[H_PROMPT_LEN]; kv_len = S[H_KV_LEN];
+        pool_count = S[H_POOL_COUNT]; pool_head = S[H_POOL_HEAD];
+        events = 0; ra_accepted = 0; kv_src_row = 0; kv_copy_dst = 0; kv_copy_len = 0; err_line = 0;
+    }
+    JF_HD void store_scalars() {
+        lanes.sync();
+        if (lanes.lane() == 0) {
+            S[H_NUM_BLOCKS] = num_blocks; S[H_ACTIVE] = active; S[H_RA] = RA; S[H_LEN_LISTS] = len_lists;
+            S[H_LNT] = lnt; S[H_HAS_LNT] = has_lnt; S[H_ITERS] = iters; S[H_DONE] = done;
+            S[H_RET_EARLY] = ret_early; S[H_ERR] = err; S[H_KV_LEN] = kv_len;
+            S[H_POOL_COUNT] = pool_count; S[H_POOL_HEAD] = pool_head;
+        }
+        lanes.sync();
+    }
+
+    // ---- lane-parallel primitives -------------------------------------------------------------
+    JF_HD void copy(int32_t *dst, const int32_t *src, int len) const {
+        for (int i = lanes.lane(); i < len; i += lanes.count()) dst[i] = src[i];
+    }
+    JF_HD void fill(int32_t *dst, int v, int len) const {
+        for (int i = lanes.lane(); i < len; i += lanes.count()) dst[i] = v;
+    }
+    JF_HD int find_first_eq(const int32_t *a, int len, int tok) const {
+        int m = len;
+        for (int i = lanes.lane(); i < len; i += lanes.count())
+            if (a[i] == tok) { m = i; break; }
+        return lanes.reduce_min(m);
+    }
+
+    // ---- MB:264-271 ---------------------------------------------------------------------------
+    JF_HD int committed_len(int cur_RA) const {
+        int c = prompt_len;
+        for (int b = 0; b < num_blocks; ++b)
+            if (b != cur_RA && !blk(b)[B_NEED]) c += blk(b)[B_ACCLEN];
+        return c + blk(cur_RA)[B_ACCLEN];
+    }
+
+    // ---- pool (deque(maxlen=pool_size), MB:238) -------------------------------------------------
+    // reserve the slot for a new newest entry; returns its storage (caller fills tokens, then sync)
+    JF_HD int32_t *pool_push_slot(int len) {
+        if (L.pool_size <= 0) return nullptr;
+        if (pool_count == L.pool_size) { pool_head = (pool_head + 1) % L.pool_size; pool_count--; }
+        int slot = (pool_head + pool_count) % L.pool_size;
+        pool_count++;
+        int32_t *e = S + L.off_pool + slot * (1 + L.LPOOL);
+        if (lanes.lane() == 0) e[0] = len;
+        return e;
+    }
+
+    // ---- MB:317-377 build_out_and_spans; returns T (0 = empty) ----------------------------------
+    JF_HD int build_out(int &B_out, int &nspans_out) {
+        lanes.sync();
+        int32_t *ra = blk(RA);
+        int B_ra = ra[B_DROWS];
+        int L_ra = ra[B_DLEN];
+        int cursor = 1, nsp = 0;
+        int tpos = 0;   // write position in out rows
+        if (L_ra > 0) {
+            for (int r = 0; r < B_ra; ++r) copy(out_row(r), draft(RA, r), L_ra);
+            if (lanes.lane() == 0) { S[H_SPANS + 0] = RA; S[H_SPANS + 1] = cursor; S[H_SPANS + 2] = L_ra; }
+            nsp = 1; cursor += L_ra; tpos += L_ra;
+        }
+        for (int b = 0; b < num_blocks; ++b) {
+            int32_t *bb = blk(b);
+            if (b == RA || !bb[B_NEED]) continue;
+            int L_acc = bb[B_ACCLEN];
+            if (L_acc > 0) {
+                if (tpos + L_acc > L.TMAX) { JF_FAIL(JF_E_CAPACITY); break; }
+                for (int r = 0; r < B_ra; ++r) copy(out_row(r) + tpos, acc(b), L_acc);   // broadcast (MB:357)
+                cursor += L_acc; tpos += L_acc;
+            }
+            int L_tail = bb[B_DLEN];
+            if (L_tail > 0) {
+                if (tpos + L_tail > L.TMAX || nsp >= L.NB) { JF_FAIL(JF_E_CAPACITY); break; }
+                int rows_b = bb[B_DROWS];
+                for (int r = 0; r < B_ra; ++r) {                                         // MB:288-312
+                    int sr = (rows_b == B_ra) ? r : (rows_b == 1 ? 0 : (r % rows_b));
+                    copy(out_row(r) + tpos, draft(b, sr), L_tail);
+                }
+                if (lanes.lane() == 0) {
+                    S[H_SPANS + 3 * nsp + 0] = b; S[H_SPANS + 3 * nsp + 1] = cursor; S[H_SPANS + 3 * nsp + 2] = L_tail;
+                }
+                nsp++; cursor += L_tail; tpos += L_tail;
+            }
+        }
+        lanes.sync();
+        B_out = B_ra; nspans_out = nsp;
+        return tpos;
+    }
+
+    // ---- MB:533-547 / 602-614 in-loop return, MB:723-740 finalize -----------------------------------
+    JF_HD void collect_ret(bool in_loop, int kv_cur, int next_tok) {
+        lanes.sync();
+        int pos = 0;
+        for (int b = 0; b < num_blocks; ++b) {
+            int32_t *bb = blk(b);
+            if (b != RA && !bb[B_NEED] && bb[B_ACCLEN] > 0) { copy(ret() + pos, acc(b), bb[B_ACCLEN]); pos += bb[B_ACCLEN]; }
+        }
+        if (blk(RA)[B_ACCLEN] > 0) { copy(ret() + pos, acc(RA), blk(RA)[B_ACCLEN]); pos += blk(RA)[B_ACCLEN]; }
+        int final_committed = prompt_len + pos;
+        kv_len = kv_cur > final_committed ? final_committed : kv_cur;      // trim only when td > 0
+        done = 1;
+        if (in_loop) ret_early = 1;
+        lanes.sync();
+        if (lanes.lane() == 0) { S[H_RET_LEN] = pos; S[H_NEXT_TOK] = next_tok; }
+    }
+
+    // ---- start of a call: MB:230-262 ------------------------------------------------------------
+    template <class TokFn>
+    JF_HD void begin(const jf_mb_params &p, TokFn input_tok, int kv0, jf_mb_desc *d) {
+        if (lanes.lane() == 0) {
+            for (int i = 0; i < H_END; ++i) S[i] = 0;
+            S[H_N] = p.n; S[H_K] = p.K; S[H_SPAWN_THR] = p.spawn_threshold; S[H_POOL_SIZE] = p.pool_size;
+            S[H_EOS] = p.eos_id; S[H_PAD] = p.pad_id; S[H_MAX_ITER] = p.max_iter; S[H_NB] = L.NB;
+            S[H_RMAX] = L.RMAX; S[H_TMAX] = L.TMAX; S[H_LPOOL] = L.LPOOL;
+            union { double d; int32_t i[2]; } u; u.d = p.lookahead_start_ratio;
+            S[H_LOOK_LO] = u.i[0]; S[H_LOOK_HI] = u.i[1];
+            S[H_NUM_BLOCKS] = 1; S[H_ACTIVE] = 1; S[H_RA] = 0; S[H_LEN_LISTS] = 1;
+            S[H_LNT] = -1; S[H_HAS_LNT] = 0; S[H_PROMPT_LEN] = kv0; S[H_KV_LEN] = kv0; S[H_NEXT_TOK] = -1;
+            int32_t *b0 = blk(0);
+            b0[B_NEED] = 0; b0[B_TOTAL] = 0; b0[B_ACCLEN] = 0; b0[B_DROWS] = 1; b0[B_DLEN] = p.n;
+        }
+        lanes.sync();
+        for (int i = lanes.lane(); i < p.n; i += lanes.count()) draft(0, 0)[i] = (int32_t)input_tok(i);
+        lanes.sync();
+        load_scalars();
+        next_iteration(d);
+    }
+
+    // ---- MB:414-419 loop head + the descriptor --------------------------------------------------
+    JF_HD void next_iteration(jf_mb_desc *d) {
+        int B = 0, T = 0, nsp = 0;
+        if (!done && !err) {
+            if (iters >= S[H_MAX_ITER]) {
+                collect_ret(false, kv_len, has_lnt ? lnt : -1);
+            } else {
+                iters++;
+                T = build_out(B, nsp);
+                if (err) { done = 1; T = 0; B = 0; }
+                else if (T == 0) { collect_ret(false, kv_len, has_lnt ? lnt : -1); B = 0; }
+            }
+        }
+        store_scalars();
+        if (lanes.lane() == 0) {
+            S[H_B] = done ? 0 : B; S[H_T] = done ? 0 : T; S[H_NSPANS] = done ? 0 : nsp;
+            if (d) {
+                d->B = done ? 0 : B; d->T = done ? 0 : T; d->done = done; d->error = err; d->iters = iters;
+                d->kv_len = kv_len; d->ret_len = S[H_RET_LEN]; d->next_token = S[H_NEXT_TOK];
+                d->kv_src_row = kv_src_row; d->kv_copy_dst = kv_copy_dst; d->kv_copy_len = kv_copy_len;
+                d->events = events; d->accepted = ra_accepted; d->nspans = done ? 0 : nsp; d->rsv0 = err_line; d->rsv1 = 0;
+            }
+        }
+        lanes.sync();
+    }
+
+    // ---- MB:467-721 ------------------------------------------------------------------------------
+    template <class GreedyFn>
+    JF_HD void step(GreedyFn G, jf_mb_desc *d) {
+        load_scalars();
+        if (done || err) { next_iteration(d); return; }
+        const int B = S[H_B], T = S[H_T], nspans = S[H_NSPANS];
+        const int kv_before = kv_len;
+        int kv_cur = kv_before + T;          // DynamicCache.update appended every forwarded token
+        int best_row = 0;                    // physical candidate row the logical cache was narrowed to
+        bool returned = false;
+        union { double dd; int32_t i[2]; } lk; lk.i[0] = S[H_LOOK_LO]; lk.i[1] = S[H_LOOK_HI];
+
+        for (int s = 0; s < nspans && !returned; ++s) {
+            const int b = S[H_SPANS + 3 * s], start = S[H_SPANS + 3 * s + 1], Ls = S[H_SPANS + 3 * s + 2];
+            int32_t *bb = blk(b);
+            const int rows_d = bb[B_DROWS];
+            // accepted[r] (MB:482-486); RA: best = first max (MB:489), pseudo: row 0 (MB:491)
+            int best_idx = 0, acc_raw = 0;
+            const int nrows = (b == RA) ? B : 1;
+            for (int r = 0; r < nrows; ++r) {
+                const int32_t *drow = draft(b, rows_d == 1 ? 0 : r);
+                int m = Ls - 1;
+                for (int i = lanes.lane(); i < Ls - 1; i += lanes.count())
+                    if (drow[i + 1] != G(r, start - 1 + i)) { m = i; break; }
+                m = lanes.reduce_min(m);
+                if (m + 1 > acc_raw) { acc_raw = m + 1; best_idx = r; }
+            }
+            if (rows_d != 1 && B != 1 && rows_d != B) { JF_FAIL(JF_E_INVALID); break; }   // torch broadcast would raise
+            const int32_t *drow = draft(b, rows_d == 1 ? 0 : best_idx);
+            if (s == 0 || b == RA) best_row = (b == RA) ? best_idx : best_row;   // MB:500-502
+            if (Ls == 0) continue;
+            int acc_len = acc_raw;
+            bool eos_reached = false;
+            if (eos >= 0 && b == RA && acc_len > 0) {                          // MB:513-521
+                int e = find_first_eq(drow, acc_len, eos);
+                if (e < acc_len) { acc_len = e + 1; eos_reached = true; }
+            }
+            const bool has_rejected = acc_len < Ls;
+            // MB:526-528
+            if (bb[B_ACCLEN] + acc_len > n + 1) { JF_FAIL(JF_E_CAPACITY); break; }
+            copy(acc(b) + bb[B_ACCLEN], drow, acc_len);
+            const int last_acc_tok = drow[acc_len - 1];
+            lanes.sync();
+            const int new_acclen = bb[B_ACCLEN] + acc_len, new_total = bb[B_TOTAL] + acc_len;
+            lanes.sync();
+            if (lanes.lane() == 0) { bb[B_ACCLEN] = new_acclen; bb[B_TOTAL] = new_total; }
+            lanes.sync();
+            if (b == RA) ra_accepted += acc_len;
+            if (eos_reached && b == RA) {                                       // MB:531-547
+                collect_ret(true, kv_cur, last_acc_tok);
+                returned = true;
+                break;
+            }
+            int nxt;
+            if (has_rejected) {                                                 // MB:550-558
+                nxt = G(best_idx, start - 1 + (acc_len - 1 > 0 ? acc_len - 1 : 0));
+                const int newL = Ls - acc_len;                                  // [nxt] + greedy[acc_len:-1]
+                lanes.sync();
+                int32_t *d0 = draft(b, 0);
+                for (int i = lanes.lane(); i < newL; i += lanes.count())
+                    d0[i] = (i == 0) ? nxt : G(best_idx, start - 1 + acc_len + i - 1);
+                lanes.sync();
+                if (lanes.lane() == 0) { bb[B_DROWS] = 1; bb[B_DLEN] = newL; }
+                lanes.sync();
+                if (b == RA) {
+                    // MB:564-573: pool.append(concat of all blocks), pool.append(rejected greedy tail)
+                    {
+                        // length first (PAD stripped, MB:405-407), then fill
+                        int clen = 0;
+                        for (int q = 0; q < num_blocks; ++q) {
+                            int32_t *qb = blk(q);
+                            const int la = qb[B_ACCLEN], ld = qb[B_DLEN];
+                            int cnt = 0;
+                            for (int i = lanes.lane(); i < la + ld; i += lanes.count()) {
+                                int tok = i < la ? acc(q)[i] : draft(q, 0)[i - la];
+                                if (!(pad >= 0 && tok == pad)) cnt++;
+                            }
+                            clen += lanes.reduce_sum(cnt);
+                        }
+                        if (clen > L.LPOOL) { JF_FAIL(JF_E_CAPACITY); break; }
+                        if (clen > 0) {
+                            int32_t *e = pool_push_slot(clen);
+                            if (e) {
+                                int base = 0;
+                                for (int q = 0; q < num_blocks; ++q) {
+                                    int32_t *qb = blk(q);
+                                    const int la = qb[B_ACCLEN], ld = qb[B_DLEN];
+                                    // order-preserving compaction, 64 tokens per pass
+                                    for (int i0 = 0; i0 < la + ld; i0 += lanes.count()) {
+                                        int i = i0 + lanes.lane();
+                                        int tok = 0; bool keep = false;
+                                        if (i < la + ld) {
+                                            tok = i < la ? acc(q)[i] : draft(q, 0)[i - la];
+                                            keep = !(pad >= 0 && tok == pad);
+                                        }
+                                        int before = lanes.prefix_count(keep);      // # kept lanes below me
+                                        if (keep) e[1 + base + before] = tok;
+                                        base += lanes.reduce_sum(keep ? 1 : 0);
+                                    }
+                                }
+                            }
+                        }
+                        lanes.sync();
+                        const int tlen = newL - 1;                                // greedy[acc_len:-1]
+                        if (tlen > 0) {
+                            int32_t *e = pool_push_slot(tlen);
+                            if (e) for (int i = lanes.lane(); i < tlen; i += lanes.count()) e[1 + i] = d0[1 + i];
+                        }
+                        lanes.sync();
+                    }
+                    // MB:577-585 candidates
+                    if ((double)new_total / (double)n >= lk.dd) {
+                        int C = 0;
+                        for (int i = pool_count - 2; i >= 0; --i) {               // reversed(list(pool)[:-1])
+                            int32_t *e = pool_entry(i);
+                            const int elen = e[0];
+                            const int pos = find_first_eq(e + 1, elen, nxt);
+                            if (pos >= elen) continue;
+                            if (1 + C >= L.RMAX) { JF_FAIL(JF_E_CAPACITY); break; }
+                            int32_t *c = draft(b, 1 + C);
+                            const int avail = elen - pos;
+                            for (int j = lanes.lane(); j < newL; j += lanes.count())
+                                c[j] = j < avail ? e[1 + pos + j] : d0[j];        // MB:82-86
+                            C++;
+                        }
+                        if (err) break;
+                        lanes.sync();
+                        if (C > 1 && lanes.lane() == 0) bb[B_DROWS] = 1 + C;        // MB:579-582 (Q5)
+                        lanes.sync();
+                    }
+                }
+            } else {                                                            // MB:590-593
+                nxt = G(best_idx, start - 1 + Ls - 1);
+                lanes.sync();
+                if (lanes.lane() == 0) { bb[B_DROWS] = 1; bb[B_DLEN] = 0; }
+                lanes.sync();
+            }
+            if (b == RA) { lnt = nxt; has_lnt = 1; }
+            if (eos >= 0 && b == RA && lnt == eos) {                             // MB:599-614
+                if (bb[B_ACCLEN] + 1 > n + 1) { JF_FAIL(JF_E_CAPACITY); break; }
+                const int al = bb[B_ACCLEN];
+                lanes.sync();
+                if (lanes.lane() == 0) { acc(b)[al] = lnt; bb[B_ACCLEN] = al + 1; }
+                lanes.sync();
+                collect_ret(true, kv_cur, lnt);
+                returned = true;
+                break;
+            }
+        }
+
+        if (!returned && !err) {
+            // MB:617-626
+            { int c = committed_len(RA); if (kv_cur > c) kv_cur = c; }
+            kv_len = kv_cur;
+            // MB:629-653 spawn
+            {
+                const int newest = num_blocks - 1;
+                if (blk(newest)[B_TOTAL] >= S[H_SPAWN_THR] && active < K) {
+                    if (pad < 0) { JF_FAIL(JF_E_INVALID); }
+                    else if (len_lists >= L.NB) { JF_FAIL(JF_E_CAPACITY); }
+                    else {
+                        events |= EVT_SPAWN;
+                        int32_t *ra = blk(RA), *nb = blk(len_lists);
+                        const int rows = ra[B_DROWS], L_ra = ra[B_DLEN];
+                        for (int r = 0; r < rows; ++r) {
+                            int32_t *dst = draft(len_lists, r);
+                            const int32_t *src = draft(RA, r);
+                            for (int i = lanes.lane(); i < n; i += lanes.count()) dst[i] = i < L_ra ? src[i] : pad;
+                        }
+                        lanes.sync();
+                        if (lanes.lane() == 0) {
+                            nb[B_NEED] = 1; nb[B_TOTAL] = 0; nb[B_ACCLEN] = 0; nb[B_DROWS] = rows;
+                            nb[B_DLEN] = L_ra > n ? L_ra : n;
+                        }
+                        lanes.sync();
+                        len_lists++; num_blocks++; active++;
+                    }
+                }
+            }
+            // MB:656-716 promote
+            if (!err && blk(RA)[B_TOTAL] >= n) {
+                for (int b = 0; b < num_blocks; ++b) {
+                    int32_t *bb = blk(b);
+                    if (bb[B_NEED] && bb[B_TOTAL] > 0) {
+                        events |= EVT_SWITCH;
+                        const int a = bb[B_ACCLEN], t = bb[B_DLEN];
+                        if (a + t != n || bb[B_DROWS] != 1 || !has_lnt) { JF_FAIL(JF_E_INVALID); break; }  // MB:667 assert
+                        // q_full = acc ⧺ tail ; new draft = [last_next_token] ⧺ q_full[1:]
+                        lanes.sync();
+                        int32_t *d0 = draft(b, 0);
+                        // shift tail right by a (backwards-safe: stage through the out buffer)
+                        int32_t *tmp = out_row(0);
+                        copy(tmp, d0, t);
+                        lanes.sync();
+                        for (int i = lanes.lane(); i < n; i += lanes.count()) {
+                            int v = i < a ? acc(b)[i] : tmp[i - a];
+                            if (i == 0) v = lnt;
+                            d0[i] = v;
+                        }
+                        lanes.sync();
+                        if (lanes.lane() == 0) {
+                            bb[B_ACCLEN] = 0; bb[B_TOTAL] = 0; bb[B_NEED] = 0; bb[B_DROWS] = 1;
+                            bb[B_DLEN] = n;
+                        }
+                        lanes.sync();
+                        RA = b;
+                        { int c = committed_len(RA); if (kv_cur > c) kv_cur = c; kv_len = kv_cur; }
+                        active--; num_blocks--;                                   // Q3
+                        break;
+                    }
+                    active--;                                                     // Q4
+                }
+            }
+            // MB:719-721 early stop
+            if (!err) {
+                bool all_full = true;
+                for (int b = 0; b < num_blocks; ++b) if (blk(b)[B_TOTAL] < n) all_full = false;
+                if (all_full) {
+                    events |= EVT_EARLY;
+                    collect_ret(false, kv_len, has_lnt ? lnt : -1);
+                }
+            }
+        }
+        if (err) done = 1;
+        // physical KV: everything kept from this forward came from candidate row best_row
+        if (best_row != 0 && kv_len > kv_before) { kv_src_row = best_row; kv_copy_dst = kv_before; kv_copy_len = kv_len - kv_before; }
+        next_iteration(d);
+    }
+};
+
+}  // namespace jfmb
+
+// ---------------------------------------------------------------------------------------------
+// Kernel bodies shared by the HIP kernels (DevLanes) and tests/hostsim (single lane).
+// ---------------------------------------------------------------------------------------------
+namespace jfmb {
+
+JF_HD int decode_packed(uint64_t v) { return (int)(~(uint32_t)(v & 0xFFFFFFFFull)); }
+
+template <class Lanes>
+JF_HD void mb_begin_body(Lanes lanes, int p, int32_t *states, int64_t state_ints, const jf_mb_params &prm,
+                         const int64_t *input_ids, const int32_t *kv_len, jf_mb_desc *desc) {
+    int32_t *S = states + (int64_t)p * state_ints;
+    Layout lay = make_layout(prm.n, prm.K, prm.pool_size, prm.max_blocks);
+    Machine<Lanes> m(S, lanes, lay);
+    const int64_t *in = input_ids + (int64_t)p * prm.n;
+    m.begin(prm, [in](int i) { return in[i]; }, kv_len[p], desc ? desc + p : nullptr);
+}
+
+template <class Lanes>
+JF_HD void mb_pack_body(Lanes lanes, int p, int32_t *states, int64_t state_ints, int32_t Tpad, int64_t pad_fill,
+                        int64_t *input_ids, int32_t *positions, int32_t *row_prompt, int32_t *row_len) {
+    int32_t *S = states + (int64_t)p * state_ints;
+    int row_base = 0;
+    for (int q = 0; q < p; ++q) row_base += states[(int64_t)q * state_ints + H_B];
+    Layout lay = layout_of(S);
+    const int B = S[H_B], T = S[H_T], kv = S[H_KV_LEN];
+    lanes.sync();
+    if (lanes.lane() == 0) { S[H_ROW_BASE] = row_base; S[H_TPAD] = Tpad; }
+    for (int r = 0; r < B; ++r) {
+        const int32_t *src = S + lay.off_out + r * lay.TMAX;
+        const int64_t o = (int64_t)(row_base + r) * Tpad;
+        for (int t = lanes.lane(); t < Tpad; t += lanes.count()) {
+            input_ids[o + t] = t < T ? (int64_t)src[t] : pad_fill;
+            positions[o + t] = kv + t;
+        }
+        if (lanes.lane() == 0) { row_prompt[row_base + r] = p; row_len[row_base + r] = T; }
+    }
+    lanes.sync();
+}
+
+template <class Lanes>
+JF_HD void mb_step_body(Lanes lanes, int p, int32_t *states, int64_t state_ints, uint64_t *packed,
+                        int64_t packed_len, jf_mb_desc *desc) {
+    int32_t *S = states + (int64_t)p * state_ints;
+    Layout lay = layout_of(S);
+    Machine<Lanes> m(S, lanes, lay);
+    const int64_t base = S[H_ROW_BASE];
+    const int64_t tpad = S[H_TPAD];
+    const int B = S[H_B];
+    const uint64_t *pk = packed;
+    auto G = [pk, base, tpad, packed_len](int r, int t) -> int {
+        const int64_t idx = (base + r) * tpad + t;
+        return (idx >= 0 && idx < packed_len) ? decode_packed(pk[idx]) : -1;
+    };
+    m.step(G, desc ? desc + p : nullptr);
+    // re-zero this prompt's slice of the argmax workspace for the next jf_argmax_partial
+    lanes.sync();
+    const int64_t lo = base * tpad, hi = (base + B) * tpad;
+    for (int64_t i = lo + lanes.lane(); i < hi && i < packed_len; i += lanes.count()) packed[i] = 0;
+}
+
+template <class Lanes>
+JF_HD void mb_read_ret_body(Lanes lanes, int p, const int32_t *states, int64_t state_ints, int64_t *ret, int32_t ret_cap) {
+    const int32_t *S = states + (int64_t)p * state_ints;
+    Layout lay = layout_of(S);
+    const int len = S[H_RET_LEN];
+    for (int i = lanes.lane(); i < ret_cap; i += lanes.count())
+        ret[(int64_t)p * ret_cap + i] = i < len ? (int64_t)S[lay.off_ret + i] : -1;
+}
+
+// ---- engine single-block step (JD:567-710) for one row; pads handled by the caller ----------------
+struct EngineRowOut { int acc_len, n_new, eos, active_next, copy_len, seed; };
+
+// greedy(i) for i in [0, L-1); draft row d[0..L)
+template <class Lanes, class GreedyFn>
+JF_HD EngineRowOut engine_row_body(Lanes lanes, const int64_t *d, int L, GreedyFn greedy, int eos_id, int remaining,
+                                   int64_t *new_tokens, int64_t *next_draft) {
+    EngineRowOut o;
+    int m = L - 1;
+    for (int i = lanes.lane(); i < L - 1; i += lanes.count())
+        if (d[i + 1] != (int64_t)greedy(i)) { m = i; break; }
+    m = lanes.reduce_min(m);
+    int acc_len = m + 1;                                   // JD:572 / 589-590
+    if (acc_len < 1) acc_len = 1;
+    if (acc_len > L) acc_len = L;
+    int eos = 0;
+    if (eos_id >= 0 && acc_len > 1) {                      // JD:597-602
+        int e = acc_len;
+        for (int i = 1 + lanes.lane(); i < acc_len; i += lanes.count())
+            if (d[i] == (int64_t)eos_id) { e = i; break; }
+        e = lanes.reduce_min(e);
+        if (e < acc_len) { acc_len = e + 1; eos = 1; }
+    }
+    int n_new = acc_len - 1;
+    int seed;
+    if (n_new > 0) {                                       // JD:609-614
+        for (int i = lanes.lane(); i < n_new; i += lanes.count()) new_tokens[i] = d[1 + i];
+        seed = (int)d[acc_len - 1];
+    } else {                                               // JD:619-631 autoregressive fallback
+        const int nt = greedy(0);
+        if (lanes.lane() == 0) new_tokens[0] = nt;
+        n_new = 1;
+        seed = nt;
+        if (eos_id >= 0 && nt == eos_id) eos = 1;
+    }
+    const int active_next = (!eos && n_new < remaining) ? 1 : 0;   // JD:659-669
+    int copy_len = 0;
+    if (active_next) {                                     // JD:680-709
+        if (lanes.lane() == 0) next_draft[0] = seed;
+        if (acc_len < L) {
+            const int off = acc_len == 1 ? 1 : acc_len - 1;
+            int rem = (L - 1) - off;
+            copy_len = rem < L - 1 ? rem : L - 1;
+            for (int i = lanes.lane(); i < copy_len; i += lanes.count()) next_draft[1 + i] = greedy(off + i);
+        } else {
+            if (lanes.lane() == 0) next_draft[1] = greedy(L - 2);
+            copy_len = 1;
+        }
+    }
+    o.acc_len = acc_len; o.n_new = n_new; o.eos = eos; o.active_next = active_next; o.copy_len = copy_len; o.seed = seed;
+    return o;
+}
+
+}  // namespace jfmb

@@ -1,0 +1,328 @@
+"""Thin torch-facing wrappers over the C ABI (include/jacobiforcing.h).
+
+torch is used for device memory and streams only; every operation below runs in the HIP
+library (``jacobiforcing_amd/lib/libjacobiforcing.so``).  Reference citations follow the
+header.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+EVT_SPAWN, EVT_SWITCH, EVT_EARLY = 1, 2, 4
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(device: torch.device):
+    if device.type == "cuda":
+        return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return None
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return N.JF_F32
+    if t.dtype == torch.bfloat16:
+        return N.JF_BF16
+    raise ValueError(f"logits dtype must be float32 or bfloat16, got {t.dtype}")
+
+
+# --------------------------------------------------------------------------------------------
+# (a2) argmax
+# --------------------------------------------------------------------------------------------
+def new_packed(rows: int, device) -> torch.Tensor:
+    """Zeroed argmax workspace (uint64 payloads held in an int64 tensor)."""
+    return torch.zeros((max(int(rows), 1),), dtype=torch.int64, device=device)
+
+
+def argmax_partial(logits: torch.Tensor, packed: torch.Tensor) -> None:
+    """logits [R, V] (last dim contiguous) -> packed[r] = (key << 32) | ~argmax.  packed must be zero."""
+    if logits.dim() != 2 or logits.stride(1) != 1:
+        raise ValueError(f"logits must be [R, V] with a contiguous vocabulary axis, got {tuple(logits.shape)} strides {logits.stride()}")
+    R, V = logits.shape
+    if packed.numel() < R:
+        raise ValueError("argmax workspace too small")
+    N.check(N.lib().jf_argmax_partial(_ptr(logits), _dtype_code(logits), R, V, logits.stride(0) if R > 1 else V,
+                                      _ptr(packed), _stream(logits.device)), "jf_argmax_partial")
+
+
+def argmax_rows(logits: torch.Tensor, packed: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """torch.argmax(logits, dim=-1) semantics (MB:476, SB:197, JD:357/567) for [..., V] logits."""
+    shape = logits.shape[:-1]
+    V = logits.shape[-1]
+    flat = logits.reshape(-1, V)
+    R = flat.shape[0]
+    if packed is None:
+        packed = new_packed(R, logits.device)
+    greedy = torch.empty((R,), dtype=torch.int64, device=logits.device)
+    if R:
+        argmax_partial(flat, packed)
+        N.check(N.lib().jf_argmax_decode(_ptr(packed), R, _ptr(greedy), _stream(logits.device)), "jf_argmax_decode")
+    return greedy.view(shape)
+
+
+# --------------------------------------------------------------------------------------------
+# (a3) accepted-prefix scan
+# --------------------------------------------------------------------------------------------
+def accept_lengths(draft: torch.Tensor, greedy: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """accepted[b] = 1 + #leading matches of draft[b,1:] vs greedy[b,:L-1]; best = first argmax (MB:482-489)."""
+    if draft.dim() != 2 or greedy.dim() != 2:
+        raise ValueError("draft and greedy must be 2-D")
+    draft = draft.contiguous()
+    B, L = greedy.shape[0], draft.shape[1]
+    if greedy.stride(1) != 1:
+        greedy = greedy.contiguous()
+    accepted = torch.empty((B,), dtype=torch.int32, device=draft.device)
+    best = torch.zeros((1,), dtype=torch.int32, device=draft.device)
+    N.check(N.lib().jf_accept_lengths(_ptr(draft), draft.shape[0], _ptr(greedy), greedy.stride(0), B, L, _ptr(accepted),
+                                      _ptr(best), _stream(draft.device)), "jf_accept_lengths")
+    return accepted, best
+
+
+# --------------------------------------------------------------------------------------------
+# multiblock state machine
+# --------------------------------------------------------------------------------------------
+@dataclass
+class MultiblockParams:
+    n: int = 32
+    K: int = 2
+    r: float = 0.85
+    lookahead_start_ratio: float = 0.0
+    n_gram_pool_size: int = 4
+    eos_token_id: Optional[int] = None
+    pad_token_id: Optional[int] = None
+    max_iteration_count: int = 128
+    max_blocks: int = 8
+
+    def to_c(self) -> N.MbParams:
+        return N.MbParams(n=int(self.n), K=int(self.K), spawn_threshold=int(math.ceil(self.r * self.n)),  # MB:262
+                          pool_size=int(self.n_gram_pool_size),
+                          eos_id=-1 if self.eos_token_id is None else int(self.eos_token_id),
+                          pad_id=-1 if self.pad_token_id is None else int(self.pad_token_id),
+                          max_iter=int(self.max_iteration_count), max_blocks=int(max(self.max_blocks, self.K)),
+                          lookahead_start_ratio=float(self.lookahead_start_ratio))
+
+
+class MultiblockBatch:
+    """P side-by-side multiblock Jacobi calls (one wavefront each) sharing one forward per iteration."""
+
+    def __init__(self, P: int, params: MultiblockParams, device):
+        self.P = int(P)
+        self.params = params
+        self.device = torch.device(device)
+        self.c_params = params.to_c()
+        lib = N.lib()
+        self.state_ints = int(lib.jf_mb_state_ints(C.byref(self.c_params)))
+        if self.state_ints <= 0:
+            N.check(N.JF_E_INVALID, "jf_mb_state_ints")
+        self.max_rows = int(lib.jf_mb_max_rows(C.byref(self.c_params)))
+        self.max_tokens = int(lib.jf_mb_max_tokens(C.byref(self.c_params)))
+        dev = self.device
+        self.states = torch.zeros((self.P, self.state_ints), dtype=torch.int32, device=dev)
+        self.desc_dev = torch.zeros((self.P, N.DESC_INTS), dtype=torch.int32, device=dev)
+        pin = dev.type == "cuda"
+        self.desc_host = torch.zeros((self.P, N.DESC_INTS), dtype=torch.int32, pin_memory=pin)
+        rows = self.P * self.max_rows
+        self.packed = new_packed(rows * self.max_tokens, dev)
+        self.input_ids = torch.zeros((rows * self.max_tokens,), dtype=torch.int64, device=dev)
+        self.positions = torch.zeros((rows * self.max_tokens,), dtype=torch.int32, device=dev)
+        self.row_prompt = torch.zeros((rows,), dtype=torch.int32, device=dev)
+        self.row_len = torch.zeros((rows,), dtype=torch.int32, device=dev)
+        self.ret_cap = self.max_tokens + 2
+        self.ret_buf = torch.zeros((self.P, self.ret_cap), dtype=torch.int64, device=dev)
+        self.Rtot = 0
+        self.Tpad = 0
+
+    # -- descriptor readback: the one host sync of an iteration ---------------------------------
+    def _read_desc(self) -> np.ndarray:
+        self.desc_host.copy_(self.desc_dev, non_blocking=True)
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
+        d = self.desc_host.numpy()
+        err = d[:, N.DESC_FIELDS.index("error")]
+        if err.any():
+            p = int(np.nonzero(err)[0][0])
+            N.raise_state_error(int(err[p]), f"multiblock prompt {p} (state-machine line {int(d[p, N.DESC_FIELDS.index('rsv0')])})")
+        return d
+
+    def desc_field(self, d: np.ndarray, name: str) -> np.ndarray:
+        return d[:, N.DESC_FIELDS.index(name)]
+
+    def begin(self, input_ids: torch.Tensor, kv_len: torch.Tensor) -> np.ndarray:
+        """MB:230-262 for every prompt: input_ids [P, n] int64, kv_len [P] int32."""
+        n = self.params.n
+        if tuple(input_ids.shape) != (self.P, n):
+            raise ValueError(f"input_ids must be [{self.P}, {n}], got {tuple(input_ids.shape)}")
+        input_ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
+        kv_len = kv_len.to(device=self.device, dtype=torch.int32).contiguous()
+        N.check(N.lib().jf_mb_begin(_ptr(self.states), self.state_ints, self.P, C.byref(self.c_params), _ptr(input_ids),
+                                    _ptr(kv_len), _ptr(self.desc_dev), _stream(self.device)), "jf_mb_begin")
+        return self._read_desc()
+
+    def pack(self, d: np.ndarray):
+        """Forward inputs of the current iteration (MB:417-436): returns (input_ids [R,Tpad], positions [R,Tpad],
+        row_prompt [R], row_len [R])."""
+        B = self.desc_field(d, "B")
+        T = self.desc_field(d, "T")
+        self.Rtot = int(B.sum())
+        self.Tpad = int(T.max()) if self.Rtot else 0
+        if self.Rtot == 0:
+            return None
+        fill = self.params.pad_token_id if self.params.pad_token_id is not None else 0
+        N.check(N.lib().jf_mb_pack(_ptr(self.states), self.state_ints, self.P, self.Tpad, int(fill), _ptr(self.input_ids),
+                                   _ptr(self.positions), _ptr(self.row_prompt), _ptr(self.row_len), _stream(self.device)),
+                "jf_mb_pack")
+        R, Tp = self.Rtot, self.Tpad
+        return (self.input_ids[:R * Tp].view(R, Tp), self.positions[:R * Tp].view(R, Tp), self.row_prompt[:R],
+                self.row_len[:R])
+
+    def verify(self, logits: torch.Tensor) -> np.ndarray:
+        """argmax over the vocabulary + the whole loop body (MB:467-721): logits [Rtot, Tpad, V] or [Rtot*Tpad, V]."""
+        V = logits.shape[-1]
+        flat = logits.reshape(-1, V)
+        if flat.shape[0] != self.Rtot * self.Tpad:
+            raise ValueError(f"expected logits for {self.Rtot}x{self.Tpad} positions, got {tuple(logits.shape)}")
+        argmax_partial(flat, self.packed)
+        return self.step()
+
+    def step(self) -> np.ndarray:
+        N.check(N.lib().jf_mb_step(_ptr(self.states), self.state_ints, self.P, _ptr(self.packed),
+                                   self.Rtot * self.Tpad, _ptr(self.desc_dev), _stream(self.device)), "jf_mb_step")
+        return self._read_desc()
+
+    def results(self, d: np.ndarray) -> List[dict]:
+        N.check(N.lib().jf_mb_read_ret(_ptr(self.states), self.state_ints, self.P, _ptr(self.ret_buf), self.ret_cap,
+                                       _stream(self.device)), "jf_mb_read_ret")
+        ret = self.ret_buf.cpu().numpy()
+        out = []
+        for p in range(self.P):
+            ln = int(self.desc_field(d, "ret_len")[p])
+            out.append(dict(ret=ret[p, :ln].tolist(), next_token=int(self.desc_field(d, "next_token")[p]),
+                            iters=int(self.desc_field(d, "iters")[p]), kv_len=int(self.desc_field(d, "kv_len")[p])))
+        return out
+
+
+# --------------------------------------------------------------------------------------------
+# KV cache
+# --------------------------------------------------------------------------------------------
+def kv_append(k_cache: torch.Tensor, v_cache: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor,
+              slot: torch.Tensor) -> None:
+    """cache [rows, H_kv, S_max, D]; new [N, H_kv, D]; slot[i] = row * S_max + position (-1 skips) (ATT:10-40)."""
+    rows, H, S_max, D = k_cache.shape
+    Ntok = k_new.shape[0]
+    if not (k_cache.is_contiguous() and v_cache.is_contiguous() and k_new.is_contiguous() and v_new.is_contiguous()):
+        raise ValueError("kv_append expects contiguous tensors")
+    if tuple(k_new.shape) != (Ntok, H, D) or slot.numel() != Ntok or slot.dtype != torch.int64:
+        raise ValueError("kv_append: shape/dtype mismatch")
+    N.check(N.lib().jf_kv_append(_ptr(k_cache), _ptr(v_cache), _ptr(k_new), _ptr(v_new), _ptr(slot), Ntok, H, D, S_max,
+                                 k_cache.element_size(), _stream(k_cache.device)), "jf_kv_append")
+
+
+class KVCommitter:
+    """Holds the per-layer pointer tables for jf_kv_commit (candidate row -> committed row, MB:500-502)."""
+
+    def __init__(self, main_k: Sequence[torch.Tensor], main_v: Sequence[torch.Tensor], cand_k: Sequence[torch.Tensor],
+                 cand_v: Sequence[torch.Tensor], cand_rows: int):
+        dev = main_k[0].device
+        self.layers = len(main_k)
+        self.P, self.H, self.S_max, self.D = main_k[0].shape
+        self.T_max = cand_k[0].shape[2]
+        self.cand_rows = int(cand_rows)
+        self.esz = main_k[0].element_size()
+        self._keep = (list(main_k), list(main_v), list(cand_k), list(cand_v))
+        mk = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device=dev)
+        self.tabs = [mk(main_k), mk(main_v), mk(cand_k), mk(cand_v)]
+        self.device = dev
+
+    def commit(self, desc_dev: torch.Tensor) -> None:
+        N.check(N.lib().jf_kv_commit(_ptr(self.tabs[0]), _ptr(self.tabs[1]), _ptr(self.tabs[2]), _ptr(self.tabs[3]),
+                                     self.layers, _ptr(desc_dev), self.P, self.cand_rows, self.H, self.D, self.S_max,
+                                     self.T_max, self.esz, _stream(self.device)), "jf_kv_commit")
+
+
+# --------------------------------------------------------------------------------------------
+# engine single-block step (JD:567-710)
+# --------------------------------------------------------------------------------------------
+class EngineStepper:
+    def __init__(self, max_rows: int, max_L: int, device, pad_stream: torch.Tensor):
+        dev = torch.device(device)
+        self.device = dev
+        self.max_rows, self.max_L = int(max_rows), int(max_L)
+        self.packed = new_packed(self.max_rows * self.max_L, dev)
+        self.new_tokens = torch.zeros((self.max_rows, self.max_L), dtype=torch.int64, device=dev)
+        self.next_draft = torch.zeros((self.max_rows, self.max_L), dtype=torch.int64, device=dev)
+        self.rows_dev = torch.zeros((self.max_rows, N.ENGINE_ROW_INTS), dtype=torch.int32, device=dev)
+        self.rows_host = torch.zeros((self.max_rows, N.ENGINE_ROW_INTS), dtype=torch.int32, pin_memory=dev.type == "cuda")
+        self.tok_host = torch.zeros((self.max_rows, self.max_L), dtype=torch.int64, pin_memory=dev.type == "cuda")
+        self.pad_stream = pad_stream.to(device=dev, dtype=torch.int64).contiguous()
+        self.pad_cursor = torch.zeros((1,), dtype=torch.int64, device=dev)
+        self.remaining = torch.zeros((self.max_rows,), dtype=torch.int32, device=dev)
+
+    def step(self, draft: torch.Tensor, logits: torch.Tensor, eos_id: Optional[int], remaining: Sequence[int]):
+        """draft [B, L] int64, logits [B, L-1, V] -> (rows ndarray [B, 8], new_tokens ndarray [B, L], next_draft tensor)."""
+        B, L = draft.shape
+        if L < 2:
+            raise ValueError("Draft must have at least 2 tokens (seed + 1 speculative)")      # MR:1144-1145
+        if logits.ndim != 3 or logits.size(0) != B or logits.size(1) != L - 1:                 # JD:244-248
+            raise ValueError(f"forward must return logits [B, L-1, vocab] for verifying speculative tokens, "
+                             f"expected [{B}, {L - 1}, *], got {tuple(logits.shape)}")
+        if B > self.max_rows or L > self.max_L:
+            raise RuntimeError("EngineStepper capacity exceeded")
+        draft = draft.to(device=self.device, dtype=torch.int64).contiguous()
+        flat = logits.reshape(B * (L - 1), logits.shape[-1])
+        argmax_partial(flat, self.packed)
+        rem = torch.tensor(list(remaining), dtype=torch.int32)
+        self.remaining[:B].copy_(rem, non_blocking=True)
+        nt = self.new_tokens[:B * L].view(-1)[:B * L].view(B, L) if False else self.new_tokens.view(-1)[:B * L].view(B, L)
+        nd = self.next_draft.view(-1)[:B * L].view(B, L)
+        N.check(N.lib().jf_engine_step(_ptr(draft), B, L, _ptr(self.packed), -1 if eos_id is None else int(eos_id),
+                                       _ptr(self.remaining), _ptr(nt), _ptr(nd), _ptr(self.pad_stream),
+                                       self.pad_stream.numel(), _ptr(self.pad_cursor), _ptr(self.rows_dev),
+                                       _stream(self.device)), "jf_engine_step")
+        self.rows_host[:B].copy_(self.rows_dev[:B], non_blocking=True)
+        th = self.tok_host.view(-1)[:B * L].view(B, L)
+        th.copy_(nt, non_blocking=True)
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
+        return self.rows_host[:B].numpy(), th.numpy(), nd
+
+
+# --------------------------------------------------------------------------------------------
+# non-greedy verify (JDN:299-354)
+# --------------------------------------------------------------------------------------------
+def rs_probs(logits: torch.Tensor, draft_next: torch.Tensor, temperature: float, packed: torch.Tensor):
+    """logits [R, V]; draft_next [R] int64 -> (p_draft, row_max, row_sumexp) fp32 [R]; packed gets the argmax."""
+    R, V = logits.shape
+    dev = logits.device
+    p = torch.empty((R,), dtype=torch.float32, device=dev)
+    m = torch.empty((R,), dtype=torch.float32, device=dev)
+    s = torch.empty((R,), dtype=torch.float32, device=dev)
+    N.check(N.lib().jf_rs_probs(_ptr(logits), _dtype_code(logits), R, V, logits.stride(0), _ptr(draft_next.contiguous()),
+                                float(temperature), _ptr(p), _ptr(m), _ptr(s), _ptr(packed), None, 0, _stream(dev)),
+            "jf_rs_probs")
+    return p, m, s
+
+
+def rs_accept(logits: torch.Tensor, draft: torch.Tensor, p_draft, row_max, row_sumexp, temperature: float,
+              u: torch.Tensor, bonus_u: torch.Tensor, eos_id: Optional[int]):
+    """One block's sequential accept/reject (JDN:326-348).  Returns (committed list, eos, reject_pos, draws)."""
+    L = draft.numel()
+    dev = logits.device
+    committed = torch.zeros((max(L, 1),), dtype=torch.int64, device=dev)
+    result = torch.zeros((4,), dtype=torch.int32, device=dev)
+    N.check(N.lib().jf_rs_accept(_ptr(logits), _dtype_code(logits), logits.shape[-1], logits.stride(0), _ptr(draft.contiguous()),
+                                 L, _ptr(p_draft), _ptr(row_max), _ptr(row_sumexp), float(temperature), _ptr(u.contiguous()),
+                                 _ptr(bonus_u.contiguous()), -1 if eos_id is None else int(eos_id), _ptr(committed),
+                                 _ptr(result), _stream(dev)), "jf_rs_accept")
+    r = result.cpu().tolist()
+    return committed[:r[0]].cpu().tolist(), bool(r[1]), r[2], r[3]

@@ -1,0 +1,71 @@
+// tests/hostsim/hostsim.cpp — TEST INFRASTRUCTURE ONLY (never loaded by jacobiforcing_amd).
+//
+// Compiles the device state-machine source (jacobiforcing_amd/csrc/jf_mb_core.h) with a
+// single-lane policy so its control logic can be checked against the golden vectors on a
+// machine without a GPU.  On the GPU box the same source runs as one wavefront per prompt
+// (jf_kernels.hip) and is checked again through the C ABI by the `-m gpu` tests.
+#include <stdint.h>
+#include <string.h>
+
+#include "jacobiforcing.h"
+#include "jf_mb_core.h"
+
+struct HostLanes {
+    int lane() const { return 0; }
+    int count() const { return 1; }
+    void sync() const {}
+    int reduce_min(int v) const { return v; }
+    int reduce_sum(int v) const { return v; }
+    int prefix_count(bool) const { return 0; }
+};
+
+extern "C" {
+
+int64_t hs_mb_state_ints(const jf_mb_params *p) { return jfmb::make_layout(p->n, p->K, p->pool_size, p->max_blocks).total; }
+int32_t hs_mb_max_rows(const jf_mb_params *p) { return jfmb::make_layout(p->n, p->K, p->pool_size, p->max_blocks).RMAX; }
+int32_t hs_mb_max_tokens(const jf_mb_params *p) { return jfmb::make_layout(p->n, p->K, p->pool_size, p->max_blocks).TMAX; }
+
+int hs_mb_begin(int32_t *states, int64_t state_ints, int P, const jf_mb_params *params, const int64_t *input_ids,
+                const int32_t *kv_len, jf_mb_desc *desc) {
+    for (int p = 0; p < P; ++p) jfmb::mb_begin_body(HostLanes{}, p, states, state_ints, *params, input_ids, kv_len, desc);
+    return 0;
+}
+int hs_mb_pack(int32_t *states, int64_t state_ints, int P, int32_t Tpad, int64_t pad_fill, int64_t *input_ids,
+               int32_t *positions, int32_t *row_prompt, int32_t *row_len) {
+    for (int p = 0; p < P; ++p)
+        jfmb::mb_pack_body(HostLanes{}, p, states, state_ints, Tpad, pad_fill, input_ids, positions, row_prompt, row_len);
+    return 0;
+}
+int hs_mb_step(int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len, jf_mb_desc *desc) {
+    for (int p = 0; p < P; ++p) jfmb::mb_step_body(HostLanes{}, p, states, state_ints, packed, packed_len, desc);
+    return 0;
+}
+int hs_mb_read_ret(const int32_t *states, int64_t state_ints, int P, int64_t *ret, int32_t ret_cap) {
+    for (int p = 0; p < P; ++p) jfmb::mb_read_ret_body(HostLanes{}, p, states, state_ints, ret, ret_cap);
+    return 0;
+}
+
+// engine step for a batch of rows, same contract as jf_engine_step
+int hs_engine_step(const int64_t *draft, int B, int L, uint64_t *packed, int32_t eos_id, const int32_t *remaining,
+                   int64_t *new_tokens, int64_t *next_draft, const int64_t *pad_stream, int64_t pad_len,
+                   int64_t *pad_cursor, jf_engine_row *rows) {
+    for (int b = 0; b < B; ++b) {
+        const uint64_t *pk = packed + (int64_t)b * (L - 1);
+        auto G = [pk](int i) { return jfmb::decode_packed(pk[i]); };
+        jfmb::EngineRowOut o = jfmb::engine_row_body(HostLanes{}, draft + (int64_t)b * L, L, G, eos_id, remaining[b],
+                                                     new_tokens + (int64_t)b * L, next_draft + (int64_t)b * L);
+        rows[b].acc_len = o.acc_len; rows[b].n_new = o.n_new; rows[b].eos = o.eos; rows[b].active_next = o.active_next;
+        rows[b].n_pads = o.active_next ? (L - 1 - o.copy_len) : 0;
+        rows[b].rsv[0] = o.copy_len;
+    }
+    int64_t run = *pad_cursor;
+    for (int b = 0; b < B; ++b) {
+        for (int i = 0; i < rows[b].n_pads; ++i)
+            next_draft[(int64_t)b * L + 1 + rows[b].rsv[0] + i] = pad_stream[pad_len > 0 ? ((run + i) % pad_len) : 0];
+        run += rows[b].n_pads;
+    }
+    *pad_cursor = run;
+    for (int64_t i = 0; i < (int64_t)B * (L - 1); ++i) packed[i] = 0;
+    return 0;
+}
+}

@@ -1,0 +1,181 @@
+"""Multiblock Jacobi state machine (jf_mb_* through jacobiforcing_amd.ops.MultiblockBatch) against
+the golden vectors recorded from the reference and against the CPU oracle.
+
+The same test body runs on two backends:
+  * hostsim (CPU): the device source compiled single-lane — checks the logic without a GPU;
+  * hip (marked gpu): the real kernels through the C ABI on an MI355X.
+"""
+import numpy as np
+import pytest
+import torch
+
+from jacobiforcing_amd import ops
+from oracle import jacobi_oracle as O
+from oracle.scripted_model import ScriptedModel
+
+from .backends import device_for, use_backend
+from .conftest import load_golden
+
+MB = load_golden("mb_cases.json")
+
+BACKENDS = [pytest.param("hostsim", id="hostsim"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+
+
+def _params(p, max_blocks=8):
+    return ops.MultiblockParams(n=p["n"], K=p["K"], r=p["r"], lookahead_start_ratio=p["lookahead"],
+                                n_gram_pool_size=p["pool"], eos_token_id=p["eos_id"], pad_token_id=p["pad_id"],
+                                max_iteration_count=p["max_iter"], max_blocks=max_blocks)
+
+
+def run_calls(batch, models, kvs, inputs, dev, dtype=torch.float32, traces=None):
+    """Drive one generation call for P prompts side by side with the scripted models as the 'forward'."""
+    P = batch.P
+    d = batch.begin(torch.tensor(inputs, dtype=torch.int64), torch.tensor([len(k) for k in kvs], dtype=torch.int32))
+    kvs = [list(k) for k in kvs]
+    events = [[] for _ in range(P)]
+    while True:
+        packed_in = batch.pack(d)
+        if packed_in is None:
+            break
+        ids, pos, row_prompt, row_len = packed_in
+        ids_h, pos_h = ids.cpu().numpy(), pos.cpu().numpy()
+        rp, rl = row_prompt.cpu().numpy(), row_len.cpu().numpy()
+        B, T = batch.desc_field(d, "B").copy(), batch.desc_field(d, "T").copy()
+        R, Tpad = ids_h.shape
+        V = models[0].vocab
+        logits = np.zeros((R, Tpad, V), dtype=np.float32)
+        r0 = 0
+        rows_of = []
+        for p in range(P):
+            rows = [ids_h[r0 + b, :T[p]].tolist() for b in range(B[p])]
+            rows_of.append(rows)
+            if B[p]:
+                assert (rp[r0:r0 + B[p]] == p).all() and (rl[r0:r0 + B[p]] == T[p]).all()
+                assert (pos_h[r0:r0 + B[p], :T[p]] == len(kvs[p]) + np.arange(T[p])).all()
+                lg = models[p].logits_rows(kvs[p], rows)
+                logits[r0:r0 + B[p], :T[p]] = lg
+                if traces is not None:
+                    traces[p].append(dict(kv_len=len(kvs[p]), out=rows, greedy=models[p].greedy_rows(kvs[p], rows)))
+            r0 += B[p]
+        d = batch.verify(torch.from_numpy(logits).to(dtype).to(dev))
+        for p in range(P):
+            if B[p] == 0:
+                continue
+            new_kv = int(batch.desc_field(d, "kv_len")[p])
+            src = int(batch.desc_field(d, "kv_src_row")[p]) if batch.desc_field(d, "kv_copy_len")[p] > 0 else 0
+            if batch.desc_field(d, "kv_copy_len")[p] > 0:
+                assert batch.desc_field(d, "kv_copy_dst")[p] == len(kvs[p])
+                assert batch.desc_field(d, "kv_copy_len")[p] == new_kv - len(kvs[p])
+            keep = new_kv - len(kvs[p])
+            assert 0 <= keep <= T[p]
+            kvs[p] = kvs[p] + rows_of[p][src][:keep]
+            ev = int(batch.desc_field(d, "events")[p])
+            events[p] += [nm for bit, nm in ((1, "spawn"), (2, "switch"), (4, "early_stop")) if ev & bit]
+        if batch.desc_field(d, "done").all():
+            break
+    res = batch.results(d)
+    for p in range(P):
+        res[p]["kv_tokens"] = kvs[p]
+        res[p]["banners"] = events[p]
+    return res
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", MB, ids=[c["name"] for c in MB])
+def test_golden_calls(case, backend):
+    with use_backend(backend):
+        dev = device_for(backend)
+        p = case["params"]
+        model = ScriptedModel.from_dict(case["model"])
+        batch = ops.MultiblockBatch(1, _params(p), dev)
+        kv = case["prefill"]["kv_tokens"]
+        for ci, call in enumerate(case["calls"]):
+            traces = [[]]
+            r = run_calls(batch, [model], [kv], [call["input"]], dev, traces=traces)[0]
+            ctx = f"{case['name']} call {ci}"
+            assert r["ret"] == call["ret"], ctx
+            assert [r["next_token"]] == call["next_token"], ctx
+            assert r["iters"] == call["iters"], ctx
+            assert r["kv_len"] == call["kv_len"], ctx
+            assert r["kv_tokens"] == call["kv_tokens"], ctx
+            assert r["banners"] == call["banners"], ctx
+            assert len(traces[0]) == len(call["forwards"]), ctx
+            for it, (a, b) in enumerate(zip(traces[0], call["forwards"])):
+                assert a["out"] == b["out"], f"{ctx} iter {it}"
+                assert a["kv_len"] == b["kv_len"], f"{ctx} iter {it}"
+            kv = r["kv_tokens"]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("cfg", [dict(n=16, K=2, r=0.5, pool=4, vocab=64, period=5, robust=50),
+                                 dict(n=32, K=2, r=0.85, pool=4, vocab=300, period=0, robust=70),
+                                 dict(n=32, K=3, r=0.4, pool=8, vocab=48, period=7, robust=40),
+                                 dict(n=64, K=2, r=0.85, pool=4, vocab=1000, period=0, robust=75)],
+                         ids=lambda c: f"n{c['n']}K{c['K']}p{c['pool']}")
+def test_batch_vs_oracle(cfg, dtype, backend):
+    """P prompts side by side (BASELINE config 4 shape: independent state machines, one forward) vs the
+    oracle run prompt by prompt, several consecutive calls, EOS for some prompts."""
+    with use_backend(backend):
+        dev = device_for(backend)
+        P, n = 6, cfg["n"]
+        V = cfg["vocab"]
+        eos_id, pad_id = V - 1, V - 2
+        rng = np.random.default_rng(1234 + n)
+        models, kvs = [], []
+        for p in range(P):
+            pl = int(rng.integers(4, 40))
+            eos_pos = None if p % 3 else pl + int(rng.integers(n // 2, 3 * n))
+            m = ScriptedModel(V, 1000 + 17 * p + n, cfg["robust"], pl, eos_id=eos_id, eos_pos=eos_pos,
+                              reserved=(pad_id,), period=cfg["period"])
+            models.append(m)
+            kvs.append(m.prompt())
+        prm = ops.MultiblockParams(n=n, K=cfg["K"], r=cfg["r"], n_gram_pool_size=cfg["pool"], eos_token_id=eos_id,
+                                   pad_token_id=pad_id)
+        batch = ops.MultiblockBatch(P, prm, dev)
+        fwd = [(lambda m: (lambda kv_rows, rows: [m.greedy_rows(kv_rows[b], [rows[b]])[0] for b in range(len(rows))]))(m)
+               for m in models]
+        inputs = []
+        for p in range(P):
+            draft = [int(x) for x in rng.choice(kvs[p], size=n)]
+            ngram, _ = O.mb_prefill(fwd[p], kvs[p], draft)
+            inputs.append(ngram)
+        okvs = [list(k) for k in kvs]
+        for call in range(3):
+            res = run_calls(batch, models, kvs, inputs, dev, dtype=dtype)
+            nxt_inputs = []
+            for p in range(P):
+                st = O.mb_generation_call(fwd[p], inputs[p], okvs[p], n=n, K=cfg["K"], r=cfg["r"],
+                                          n_gram_pool_size=cfg["pool"], eos_token_id=eos_id, pad_token_id=pad_id)
+                ctx = f"call {call} prompt {p}"
+                assert res[p]["ret"] == st.ret, ctx
+                assert res[p]["next_token"] == (st.next_token if st.next_token is not None else -1), ctx
+                assert res[p]["iters"] == st.iters, ctx
+                assert res[p]["kv_tokens"] == st.kv_tokens, ctx
+                assert res[p]["banners"] == st.banners, ctx
+                okvs[p] = st.kv_tokens
+                kvs[p] = res[p]["kv_tokens"]
+                nt = st.next_token if st.next_token is not None else 0
+                nxt_inputs.append([nt] + [int(x) for x in rng.choice(kvs[p], size=n - 1)])
+            inputs = nxt_inputs
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_spawn_without_pad_raises(backend):
+    """MB:631-632: spawning without pad_token_id is a ValueError."""
+    with use_backend(backend):
+        dev = device_for(backend)
+        m = ScriptedModel(64, 3, 100, 5)
+        prm = ops.MultiblockParams(n=8, K=2, r=0.25, eos_token_id=None, pad_token_id=None)
+        batch = ops.MultiblockBatch(1, prm, dev)
+        with pytest.raises(ValueError):
+            run_calls(batch, [m], [m.prompt()], [m.ar_continuation(5, 8)], dev)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_bad_shapes(backend):
+    with use_backend(backend):
+        dev = device_for(backend)
+        batch = ops.MultiblockBatch(2, ops.MultiblockParams(n=8, pad_token_id=0), dev)
+        with pytest.raises(ValueError):
+            batch.begin(torch.zeros((2, 7), dtype=torch.int64), torch.zeros((2,), dtype=torch.int32))
