@@ -119,7 +119,102 @@ __device__ __forceinline__ uint32_t load_key(const void *row, int64_t i) {
     else return order_key(((uint32_t)((const uint16_t *)row)[i]) << 16);
 }
 
-// VEC: rows are 16-byte aligned -> 16 B per lane per load, 4 loads in flight.
+// ---- exact scalar-order scan of [begin, end) of one row (any alignment): used for unaligned rows, ragged
+// tails and the rare chunks that contain a NaN.
+template <int DT>
+__device__ __forceinline__ void scan_exact(const void *p, int64_t begin, int64_t end, int tid, uint32_t &best, uint32_t &bidx) {
+    for (int64_t j = begin + tid; j < end; j += AM_TPB) {
+        const uint32_t k = load_key<DT>(p, j);
+        if (k > best) { best = k; bidx = (uint32_t)j; }
+    }
+}
+
+// ---- lean per-vector keys --------------------------------------------------------------------
+// Signed "two's-complement-like" key of an IEEE payload: k = w ^ ((w >> 31) & 0x7FFFFFFF).  Numeric order as a
+// signed integer; +NaN sorts above +inf, -NaN below -inf (both are detected and sent to the exact path);
+// key(-0.0) == -1 and key(+0.0) == 0, so -1 is bumped to 0 to make the two zeros tie (torch semantics).
+typedef int16_t i16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int32_t skey32(uint32_t w) { return (int32_t)(w ^ (((uint32_t)((int32_t)w >> 31)) & 0x7FFFFFFFu)); }
+__device__ __forceinline__ uint32_t skey16x2(uint32_t w) {      // both halves at once
+    const i16x2 v = __builtin_bit_cast(i16x2, w);
+    const i16x2 sh = v >> (int16_t)15;                           // v_pk_ashrrev_i16
+    return w ^ (__builtin_bit_cast(uint32_t, sh) & 0x7FFF7FFFu);
+}
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+    const i16x2 x = __builtin_bit_cast(i16x2, a), y = __builtin_bit_cast(i16x2, b);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(x, y));
+}
+__device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) {
+    const i16x2 x = __builtin_bit_cast(i16x2, a), y = __builtin_bit_cast(i16x2, b);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(x, y));
+}
+__device__ __forceinline__ int32_t hmax_i16x2(uint32_t a) {
+    const int32_t lo = (int32_t)(int16_t)(a & 0xFFFFu), hi = (int32_t)a >> 16;
+    return lo > hi ? lo : hi;
+}
+__device__ __forceinline__ int32_t hmin_i16x2(uint32_t a) {
+    const int32_t lo = (int32_t)(int16_t)(a & 0xFFFFu), hi = (int32_t)a >> 16;
+    return lo < hi ? lo : hi;
+}
+
+template <int DT> struct FastTrack;
+template <> struct FastTrack<JF_F32> {
+    int32_t best = INT32_MIN, mn = INT32_MAX;
+    uint32_t bvec = 0xFFFFFFFFu;
+    __device__ __forceinline__ void consume(const u32x4 v, uint32_t i) {
+        const int32_t k0 = skey32(v.x), k1 = skey32(v.y), k2 = skey32(v.z), k3 = skey32(v.w);
+        int32_t m = max(max(k0, k1), max(k2, k3));
+        mn = min(mn, min(min(k0, k1), min(k2, k3)));
+        m = (m == -1) ? 0 : m;
+        if (m > best) { best = m; bvec = i; }
+    }
+    __device__ __forceinline__ bool saw_nan() const { return best > (int32_t)0x7F800000 || mn < (int32_t)0x807FFFFF; }
+    // first element of the vector at bvec whose canonical key equals best
+    __device__ __forceinline__ uint32_t resolve(const void *p) const {
+        const u32x4 v = *(const u32x4 *)((const uint32_t *)p + bvec);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t j = 3;
+#pragma unroll
+        for (int q = 3; q >= 0; --q) { int32_t k = skey32(w[q]); k = (k == -1) ? 0 : k; if (k == best) j = q; }
+        return bvec + j;
+    }
+    __device__ __forceinline__ uint32_t ukey() const { return (uint32_t)best ^ 0x80000000u; }   // == order_key()
+};
+template <> struct FastTrack<JF_BF16> {
+    int32_t best = INT32_MIN;
+    uint32_t mnp = 0x7FFF7FFFu;     // packed running min
+    uint32_t bvec = 0xFFFFFFFFu;
+    __device__ __forceinline__ void consume(const u32x4 v, uint32_t i) {
+        const uint32_t k0 = skey16x2(v.x), k1 = skey16x2(v.y), k2 = skey16x2(v.z), k3 = skey16x2(v.w);
+        const uint32_t pm = pk_max_i16(pk_max_i16(k0, k1), pk_max_i16(k2, k3));
+        mnp = pk_min_i16(mnp, pk_min_i16(pk_min_i16(k0, k1), pk_min_i16(k2, k3)));
+        int32_t m = hmax_i16x2(pm);
+        m = (m == -1) ? 0 : m;
+        if (m > best) { best = m; bvec = i; }
+    }
+    __device__ __forceinline__ bool saw_nan() const { return best > 0x7F80 || hmin_i16x2(mnp) < (int32_t)(int16_t)0x807F; }
+    __device__ __forceinline__ uint32_t resolve(const void *p) const {
+        const u32x4 v = *(const u32x4 *)((const uint16_t *)p + bvec);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t j = 7;
+#pragma unroll
+        for (int q = 7; q >= 0; --q) {
+            const uint32_t h = (q & 1) ? (w[q >> 1] >> 16) : (w[q >> 1] & 0xFFFFu);
+            int32_t k = (int32_t)(int16_t)(h ^ ((h & 0x8000u) ? 0x7FFFu : 0u));
+            k = (k == -1) ? 0 : k;
+            if (k == best) j = q;
+        }
+        return bvec + j;
+    }
+    // same value order_key(w16 << 16) gives for non-NaN payloads
+    __device__ __forceinline__ uint32_t ukey() const {
+        const uint32_t k16 = (uint32_t)best & 0xFFFFu;
+        return best >= 0 ? ((k16 | 0x8000u) << 16) : (((k16 ^ 0x8000u) << 16) | 0xFFFFu);
+    }
+};
+
+// VEC: rows are 16-byte aligned -> 16 B per lane per load, 4 loads in flight, one compare chain per vector.
 template <int DT, bool VEC>
 __global__ __launch_bounds__(AM_TPB) void argmax_partial_kernel(const void *__restrict__ logits, int64_t R, int64_t V,
                                                                  int64_t row_stride, unsigned long long *__restrict__ packed,
@@ -138,6 +233,7 @@ __global__ __launch_bounds__(AM_TPB) void argmax_partial_kernel(const void *__re
     uint32_t best = 0u, bidx = 0xFFFFFFFFu;   // every real key is >= 0x007FFFFF > 0
     if constexpr (VEC) {
         const u32x4 *pv = (const u32x4 *)p;
+        FastTrack<DT> ft;
         int64_t i = begin + (int64_t)tid * EPV;
         constexpr int64_t STEP = (int64_t)AM_TPB * EPV;
         for (; i + 3 * STEP + EPV <= end; i += 4 * STEP) {
@@ -145,26 +241,25 @@ __global__ __launch_bounds__(AM_TPB) void argmax_partial_kernel(const void *__re
             const u32x4 v1 = __builtin_nontemporal_load(pv + (i + STEP) / EPV);
             const u32x4 v2 = __builtin_nontemporal_load(pv + (i + 2 * STEP) / EPV);
             const u32x4 v3 = __builtin_nontemporal_load(pv + (i + 3 * STEP) / EPV);
-            consume_vec<DT>(v0, (uint32_t)i, best, bidx);
-            consume_vec<DT>(v1, (uint32_t)(i + STEP), best, bidx);
-            consume_vec<DT>(v2, (uint32_t)(i + 2 * STEP), best, bidx);
-            consume_vec<DT>(v3, (uint32_t)(i + 3 * STEP), best, bidx);
+            ft.consume(v0, (uint32_t)i);
+            ft.consume(v1, (uint32_t)(i + STEP));
+            ft.consume(v2, (uint32_t)(i + 2 * STEP));
+            ft.consume(v3, (uint32_t)(i + 3 * STEP));
         }
         for (; i + EPV <= end; i += STEP) {
             const u32x4 v0 = __builtin_nontemporal_load(pv + i / EPV);
-            consume_vec<DT>(v0, (uint32_t)i, best, bidx);
+            ft.consume(v0, (uint32_t)i);
         }
-        // ragged tail of the row (V not a multiple of EPV): the last <EPV elements
         const int64_t vec_end = begin + ((end - begin) / EPV) * EPV;
-        for (int64_t j = vec_end + tid; j < end; j += AM_TPB) {
-            const uint32_t k = load_key<DT>(p, j);
-            if (k > best) { best = k; bidx = (uint32_t)j; }
+        if (__syncthreads_or(ft.saw_nan() ? 1 : 0)) {
+            scan_exact<DT>(p, begin, vec_end, tid, best, bidx);          // NaN somewhere in this chunk: exact rescan
+        } else if (ft.bvec != 0xFFFFFFFFu) {
+            best = ft.ukey();
+            bidx = ft.resolve(p);
         }
+        scan_exact<DT>(p, vec_end, end, tid, best, bidx);                 // ragged tail (V % EPV), indices above all vectors
     } else {
-        for (int64_t j = begin + tid; j < end; j += AM_TPB) {
-            const uint32_t k = load_key<DT>(p, j);
-            if (k > best) { best = k; bidx = (uint32_t)j; }
-        }
+        scan_exact<DT>(p, begin, end, tid, best, bidx);
     }
     // (key, first index) -> one u64 whose max is the answer: larger key wins, then smaller index
     uint64_t pk = ((uint64_t)best << 32) | (uint64_t)(~bidx);

@@ -194,3 +194,44 @@ def test_kv_commit_copies_candidate_rows():
     ops.KVCommitter(mk, mv, ck, cv, CR).commit(desc.cuda())
     for l in range(layers):
         assert torch.equal(mk[l], ref_k[l]) and torch.equal(mv[l], ref_v[l])
+
+
+@GPU
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_argmax_special_values_vector_path(dtype):
+    """-NaN / +NaN with payloads, -0.0 vs +0.0 ties, all-negative and all -inf rows on the 16-byte vector path
+    (V multiple of 8, several chunks) against torch.argmax on the CPU."""
+    V = 40960
+    g = torch.Generator().manual_seed(9)
+    rows = []
+
+    def base(neg=False):
+        x = torch.randn(V, generator=g)
+        return -x.abs() - 0.5 if neg else x
+
+    def bits(x):
+        return x.view(torch.int32) if dtype == torch.float32 else x.view(torch.int16)
+
+    def set_bits(x, pos, payload32):
+        b = bits(x)
+        b[pos] = payload32 if dtype == torch.float32 else (payload32 >> 16) - (0x10000 if (payload32 >> 16) >= 0x8000 else 0)
+    cases = []
+    x = base().to(dtype); set_bits(x, 20000, 0xFFC00000 - (1 << 32)); cases.append(x)                 # -NaN only
+    x = base().to(dtype); set_bits(x, 30001, 0xFFC00000 - (1 << 32)); set_bits(x, 111, 0x7FC10000); cases.append(x)   # +NaN first
+    x = base().to(dtype); set_bits(x, 5, 0xFFC00000 - (1 << 32)); set_bits(x, 4000, 0x7FFF0000); cases.append(x)      # -NaN first
+    x = base(True).to(dtype); x[777] = -0.0; x[20000] = 0.0; cases.append(x)                          # -0 before +0
+    x = base(True).to(dtype); x[20000] = -0.0; x[777] = 0.0; cases.append(x)                          # +0 before -0
+    x = base(True).to(dtype); x[12345] = -0.0; cases.append(x)                                        # only -0
+    x = base(True).to(dtype); cases.append(x)                                                         # all negative
+    x = torch.full((V,), -float("inf")).to(dtype); cases.append(x)                                    # all -inf -> 0
+    x = torch.full((V,), -float("inf")).to(dtype); x[V - 1] = -3.0e38; cases.append(x)                # last element
+    x = base().to(dtype); x[8191] = 50.0; x[8192] = 50.0; cases.append(x)                             # tie across chunk edge
+    x = base().to(dtype); x[3] = float("inf"); x[V - 3] = float("inf"); cases.append(x)
+    X = torch.stack(cases)
+    ref = torch.argmax(X.float(), dim=-1)
+    got = ops.argmax_rows(X.cuda()).cpu()
+    assert got.tolist() == ref.tolist()
+    # a non-contiguous row stride keeps rows 16-byte aligned as well
+    Y = torch.zeros(X.shape[0], V + 64, dtype=dtype)
+    Y[:, :V] = X
+    assert ops.argmax_rows(Y.cuda()[:, :V]).cpu().tolist() == ref.tolist()

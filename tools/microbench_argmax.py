@@ -12,7 +12,20 @@ from jacobiforcing_amd import ops  # noqa: E402
 V = 152064
 
 
-def bench(R, dtype, iters=50, chunk=None):
+import ctypes
+_PROBE = None
+
+
+def probe_lib():
+    global _PROBE
+    if _PROBE is None:
+        _PROBE = ctypes.CDLL(str(Path(__file__).resolve().parent / "libprobe_stream.so"))
+        _PROBE.probe_stream.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                        ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    return _PROBE
+
+
+def bench(R, dtype, iters=50, chunk=None, probe=False, batch=1):
     if chunk:
         os.environ["JF_ARGMAX_CHUNK"] = str(chunk)
     else:
@@ -25,13 +38,21 @@ def bench(R, dtype, iters=50, chunk=None):
         packed.zero_()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    esz = 4 if dtype == torch.float32 else 2
+    pchunk = chunk or (8192 if esz == 4 else 16384)
+    st = torch.cuda.current_stream().cuda_stream
     for i in range(iters):
         packed.zero_()
         ev[i][0].record()
-        ops.argmax_partial(xs[i % nbuf], packed)
+        for j in range(batch):
+            x = xs[(i * batch + j) % nbuf]
+            if probe:
+                probe_lib().probe_stream(x.data_ptr(), esz, R, V, V, packed.data_ptr(), pchunk, st)
+            else:
+                ops.argmax_partial(x, packed)
         ev[i][1].record()
     torch.cuda.synchronize()
-    ts = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
+    ts = sorted(a.elapsed_time(b) * 1e3 / batch for a, b in ev)
     med, mn = ts[len(ts) // 2], ts[0]
     byts = R * V * (4 if dtype == torch.float32 else 2)
     return med, mn, byts / med / 1e3, byts / mn / 1e3
@@ -40,9 +61,13 @@ def bench(R, dtype, iters=50, chunk=None):
 if __name__ == "__main__":
     chunks = [None] + [int(c) for c in sys.argv[1:]]
     print(f"{'R':>5} {'dtype':>6} {'chunk':>7} {'MB':>8} {'med_us':>8} {'min_us':>8} {'GB/s(med)':>10} {'GB/s(min)':>10}")
+    batch = int(os.environ.get("MB_BATCH", "8"))
+    Rs = [int(r) for r in os.environ.get("MB_ROWS", "16,32,64,256,512,2048").split(",")]
     for dtype in (torch.float32, torch.bfloat16):
-        for R in (16, 32, 64, 256, 512, 2048):
+        for R in Rs:
             for c in chunks:
-                med, mn, g1, g2 = bench(R, dtype, chunk=c)
-                print(f"{R:5d} {str(dtype)[6:]:>6} {str(c):>7} {R * V * (4 if dtype == torch.float32 else 2) / 1e6:8.1f} "
-                      f"{med:8.1f} {mn:8.1f} {g1:10.0f} {g2:10.0f}", flush=True)
+                for probe in (False, True):
+                    med, mn, g1, g2 = bench(R, dtype, chunk=c, probe=probe, batch=batch)
+                    tag = "probe" if probe else "argmx"
+                    print(f"{R:5d} {str(dtype)[6:]:>6} {str(c):>7} {R * V * (4 if dtype == torch.float32 else 2) / 1e6:8.1f} "
+                          f"{med:8.1f} {mn:8.1f} {g1:10.0f} {g2:10.0f} {tag} x{batch}", flush=True)
