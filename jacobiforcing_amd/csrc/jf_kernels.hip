@@ -214,8 +214,9 @@ template <> struct FastTrack<JF_BF16> {
     }
 };
 
-// VEC: rows are 16-byte aligned -> 16 B per lane per load, 4 loads in flight, one compare chain per vector.
-template <int DT, bool VEC>
+// VEC: rows are 16-byte aligned -> 16 B per lane per load, UNROLL independent loads in flight per lane
+// (4 or 8 KB per wavefront), one compare chain per 16-byte vector.  All loop arithmetic is 32-bit.
+template <int DT, bool VEC, int UNROLL>
 __global__ __launch_bounds__(AM_TPB) void argmax_partial_kernel(const void *__restrict__ logits, int64_t R, int64_t V,
                                                                  int64_t row_stride, unsigned long long *__restrict__ packed,
                                                                  int chunks_per_row, int64_t chunk_elems) {
@@ -232,23 +233,21 @@ __global__ __launch_bounds__(AM_TPB) void argmax_partial_kernel(const void *__re
 
     uint32_t best = 0u, bidx = 0xFFFFFFFFu;   // every real key is >= 0x007FFFFF > 0
     if constexpr (VEC) {
-        const u32x4 *pv = (const u32x4 *)p;
         FastTrack<DT> ft;
-        int64_t i = begin + (int64_t)tid * EPV;
-        constexpr int64_t STEP = (int64_t)AM_TPB * EPV;
-        for (; i + 3 * STEP + EPV <= end; i += 4 * STEP) {
-            const u32x4 v0 = __builtin_nontemporal_load(pv + (i) / EPV);
-            const u32x4 v1 = __builtin_nontemporal_load(pv + (i + STEP) / EPV);
-            const u32x4 v2 = __builtin_nontemporal_load(pv + (i + 2 * STEP) / EPV);
-            const u32x4 v3 = __builtin_nontemporal_load(pv + (i + 3 * STEP) / EPV);
-            ft.consume(v0, (uint32_t)i);
-            ft.consume(v1, (uint32_t)(i + STEP));
-            ft.consume(v2, (uint32_t)(i + 2 * STEP));
-            ft.consume(v3, (uint32_t)(i + 3 * STEP));
+        const uint32_t ebase = (uint32_t)begin;                       // element index of the chunk start (V < 2^31)
+        const int nvec = (int)((end - begin) / EPV);                  // full 16-byte vectors in this chunk
+        const u32x4 *q = (const u32x4 *)p + (begin / EPV) + tid;
+        int k = tid;
+        for (; k + (UNROLL - 1) * AM_TPB < nvec; k += UNROLL * AM_TPB, q += UNROLL * AM_TPB) {
+            u32x4 v[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(q + u * AM_TPB);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) ft.consume(v[u], ebase + (uint32_t)(k + u * AM_TPB) * EPV);
         }
-        for (; i + EPV <= end; i += STEP) {
-            const u32x4 v0 = __builtin_nontemporal_load(pv + i / EPV);
-            ft.consume(v0, (uint32_t)i);
+        for (; k < nvec; k += AM_TPB, q += AM_TPB) {
+            const u32x4 v0 = __builtin_nontemporal_load(q);
+            ft.consume(v0, ebase + (uint32_t)k * EPV);
         }
         const int64_t vec_end = begin + ((end - begin) / EPV) * EPV;
         if (__syncthreads_or(ft.saw_nan() ? 1 : 0)) {
@@ -283,20 +282,22 @@ __global__ void argmax_decode_kernel(unsigned long long *packed, int64_t R, int6
     }
 }
 
+static int64_t env_i64(const char *name, int64_t dflt) {
+    const char *e = getenv(name);
+    return (e && *e) ? atoll(e) : dflt;
+}
+
 static int64_t pick_chunk(int dtype, int64_t R, int64_t V) {
-    const int64_t gran = (int64_t)AM_TPB * (dtype == JF_F32 ? 4 : 8);
-    const char *env = getenv("JF_ARGMAX_CHUNK");
-    if (env && atoll(env) > 0) {
-        int64_t c = atoll(env);
-        return ((c + gran - 1) / gran) * gran;
-    }
-    // aim for >= ~2048 workgroups (8 per CU) while keeping >= one full 4-deep unrolled pass per WG
-    const int64_t target_items = 2048;
+    const int64_t gran = (int64_t)AM_TPB * (dtype == JF_F32 ? 4 : 8);   // elements one workgroup covers per load round
+    int64_t c = env_i64("JF_ARGMAX_CHUNK", 0);
+    if (c > 0) return ((c + gran - 1) / gran) * gran;
+    // ~8 workgroups per CU (2048) when the problem is big enough, never less than one 4-deep round per workgroup
+    const int64_t target_items = env_i64("JF_ARGMAX_ITEMS", 2048);
     int64_t per_row = (target_items + R - 1) / R;
     if (per_row < 1) per_row = 1;
     int64_t chunk = (V + per_row - 1) / per_row;
-    chunk = ((chunk + gran - 1) / gran) * gran;
-    const int64_t lo = 4 * gran, hi = 16 * gran;
+    chunk = ((chunk + 4 * gran - 1) / (4 * gran)) * (4 * gran);
+    const int64_t lo = 4 * gran, hi = 64 * gran;
     if (chunk < lo) chunk = lo;
     if (chunk > hi) chunk = hi;
     return chunk;
@@ -319,13 +320,18 @@ extern "C" int jf_argmax_partial(const void *logits, int dtype, int64_t R, int64
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)items), block(AM_TPB);
     unsigned long long *pk = (unsigned long long *)packed;
+    const bool deep = env_i64("JF_ARGMAX_UNROLL", 8) >= 8 && chunk >= 8 * (int64_t)AM_TPB * (dtype == JF_F32 ? 4 : 8);
+#define JF_LAUNCH(DT, VECF, UNR) argmax_partial_kernel<DT, VECF, UNR><<<grid, block, 0, s>>>(logits, R, V, row_stride, pk, (int)cpr, chunk)
     if (dtype == JF_F32) {
-        if (vec) argmax_partial_kernel<JF_F32, true><<<grid, block, 0, s>>>(logits, R, V, row_stride, pk, (int)cpr, chunk);
-        else argmax_partial_kernel<JF_F32, false><<<grid, block, 0, s>>>(logits, R, V, row_stride, pk, (int)cpr, chunk);
+        if (!vec) JF_LAUNCH(JF_F32, false, 4);
+        else if (deep) JF_LAUNCH(JF_F32, true, 8);
+        else JF_LAUNCH(JF_F32, true, 4);
     } else {
-        if (vec) argmax_partial_kernel<JF_BF16, true><<<grid, block, 0, s>>>(logits, R, V, row_stride, pk, (int)cpr, chunk);
-        else argmax_partial_kernel<JF_BF16, false><<<grid, block, 0, s>>>(logits, R, V, row_stride, pk, (int)cpr, chunk);
+        if (!vec) JF_LAUNCH(JF_BF16, false, 4);
+        else if (deep) JF_LAUNCH(JF_BF16, true, 8);
+        else JF_LAUNCH(JF_BF16, true, 4);
     }
+#undef JF_LAUNCH
     return check_launch("argmax_partial_kernel");
 }
 
