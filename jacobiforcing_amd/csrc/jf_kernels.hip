@@ -274,6 +274,59 @@ __global__ __launch_bounds__(AM_TPB) void argmax_partial_kernel(const void *__re
     }
 }
 
+// Wave-independent variant: every wavefront owns one (row, chunk) item end to end — no LDS, no workgroup
+// barrier; the NaN vote is a ballot, the reduction six shuffles, the publish one atomicMax per wavefront.
+template <int DT, int UNROLL>
+__global__ __launch_bounds__(AM_TPB) void argmax_wave_kernel(const void *__restrict__ logits, int64_t R, int64_t V,
+                                                              int64_t row_stride, unsigned long long *__restrict__ packed,
+                                                              int chunks_per_row, int64_t chunk_elems) {
+    using E = Elem<DT>;
+    constexpr int EPV = E::EPV;
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * (AM_TPB / 64) + (threadIdx.x >> 6);
+    if (item >= R * chunks_per_row) return;
+    const int64_t row = item / chunks_per_row;
+    const int c = (int)(item - row * chunks_per_row);
+    const int64_t begin = (int64_t)c * chunk_elems;
+    int64_t end = begin + chunk_elems;
+    if (end > V) end = V;
+    const typename E::T *p = (const typename E::T *)logits + row * row_stride;
+
+    FastTrack<DT> ft;
+    const uint32_t ebase = (uint32_t)begin;
+    const int nvec = (int)((end - begin) / EPV);
+    const u32x4 *q = (const u32x4 *)p + (begin / EPV) + lane;
+    int k = lane;
+    for (; k + (UNROLL - 1) * 64 < nvec; k += UNROLL * 64, q += UNROLL * 64) {
+        u32x4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(q + u * 64);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) ft.consume(v[u], ebase + (uint32_t)(k + u * 64) * EPV);
+    }
+    for (; k < nvec; k += 64, q += 64) {
+        const u32x4 v0 = __builtin_nontemporal_load(q);
+        ft.consume(v0, ebase + (uint32_t)k * EPV);
+    }
+    uint32_t best = 0u, bidx = 0xFFFFFFFFu;
+    const int64_t vec_end = begin + (int64_t)nvec * EPV;
+    if (__ballot(ft.saw_nan()) != 0ull) {
+        for (int64_t j = begin + lane; j < vec_end; j += 64) {
+            const uint32_t kk = load_key<DT>(p, j);
+            if (kk > best) { best = kk; bidx = (uint32_t)j; }
+        }
+    } else if (ft.bvec != 0xFFFFFFFFu) {
+        best = ft.ukey();
+        bidx = ft.resolve(p);
+    }
+    for (int64_t j = vec_end + lane; j < end; j += 64) {
+        const uint32_t kk = load_key<DT>(p, j);
+        if (kk > best) { best = kk; bidx = (uint32_t)j; }
+    }
+    uint64_t pk = wave_max_u64(((uint64_t)best << 32) | (uint64_t)(~bidx));
+    if (lane == 0) atomicMax(packed + row, (unsigned long long)pk);
+}
+
 __global__ void argmax_decode_kernel(unsigned long long *packed, int64_t R, int64_t *greedy) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r < R) {
@@ -287,20 +340,16 @@ static int64_t env_i64(const char *name, int64_t dflt) {
     return (e && *e) ? atoll(e) : dflt;
 }
 
-static int64_t pick_chunk(int dtype, int64_t R, int64_t V) {
-    const int64_t gran = (int64_t)AM_TPB * (dtype == JF_F32 ? 4 : 8);   // elements one workgroup covers per load round
+// Balanced chunking: cpr chunks per row of equal size (rounded up to `gran` elements).
+static int64_t pick_chunk(int64_t gran, int64_t R, int64_t V, int64_t target_items) {
     int64_t c = env_i64("JF_ARGMAX_CHUNK", 0);
     if (c > 0) return ((c + gran - 1) / gran) * gran;
-    // ~8 workgroups per CU (2048) when the problem is big enough, never less than one 4-deep round per workgroup
-    const int64_t target_items = env_i64("JF_ARGMAX_ITEMS", 2048);
     int64_t per_row = (target_items + R - 1) / R;
     if (per_row < 1) per_row = 1;
+    const int64_t max_per_row = (V + gran - 1) / gran;
+    if (per_row > max_per_row) per_row = max_per_row;
     int64_t chunk = (V + per_row - 1) / per_row;
-    chunk = ((chunk + 4 * gran - 1) / (4 * gran)) * (4 * gran);
-    const int64_t lo = 4 * gran, hi = 64 * gran;
-    if (chunk < lo) chunk = lo;
-    if (chunk > hi) chunk = hi;
-    return chunk;
+    return ((chunk + gran - 1) / gran) * gran;
 }
 
 extern "C" int jf_argmax_partial(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride,
@@ -312,15 +361,31 @@ extern "C" int jf_argmax_partial(const void *logits, int dtype, int64_t R, int64
         return fail(JF_E_INVALID, "jf_argmax_partial: bad shape R=%lld V=%lld stride=%lld", (long long)R, (long long)V,
                     (long long)row_stride);
     const int esz = dtype == JF_F32 ? 4 : 2;
+    const int epv = 16 / esz;
     const bool vec = (((uintptr_t)logits) % 16 == 0) && ((row_stride * esz) % 16 == 0);
-    const int64_t chunk = pick_chunk(dtype, R, V);
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long *pk = (unsigned long long *)packed;
+    const bool wave_mode = vec && env_i64("JF_ARGMAX_WAVE", 1) != 0;
+    const bool deep = env_i64("JF_ARGMAX_UNROLL", 8) >= 8;
+    if (wave_mode) {
+        // one item per wavefront: aim for ~3 wavefronts per SIMD (256 CUs x 4 SIMDs x 3)
+        const int64_t chunk = pick_chunk(64 * epv, R, V, env_i64("JF_ARGMAX_ITEMS", 3072));
+        const int64_t cpr = (V + chunk - 1) / chunk;
+        const int64_t items = R * cpr;
+        const int64_t blocks = (items + (AM_TPB / 64) - 1) / (AM_TPB / 64);
+        if (blocks > 0x7FFFFFFFll) return fail(JF_E_CAPACITY, "jf_argmax_partial: grid too large");
+        dim3 grid((unsigned)blocks), block(AM_TPB);
+#define JF_LAUNCHW(DT, UNR) argmax_wave_kernel<DT, UNR><<<grid, block, 0, s>>>(logits, R, V, row_stride, pk, (int)cpr, chunk)
+        if (dtype == JF_F32) { if (deep) JF_LAUNCHW(JF_F32, 8); else JF_LAUNCHW(JF_F32, 4); }
+        else { if (deep) JF_LAUNCHW(JF_BF16, 8); else JF_LAUNCHW(JF_BF16, 4); }
+#undef JF_LAUNCHW
+        return check_launch("argmax_wave_kernel");
+    }
+    const int64_t chunk = pick_chunk((int64_t)AM_TPB * epv, R, V, env_i64("JF_ARGMAX_ITEMS", 1024));
     const int64_t cpr = (V + chunk - 1) / chunk;
     const int64_t items = R * cpr;
     if (items > 0x7FFFFFFFll) return fail(JF_E_CAPACITY, "jf_argmax_partial: grid too large");
-    hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)items), block(AM_TPB);
-    unsigned long long *pk = (unsigned long long *)packed;
-    const bool deep = env_i64("JF_ARGMAX_UNROLL", 8) >= 8 && chunk >= 8 * (int64_t)AM_TPB * (dtype == JF_F32 ? 4 : 8);
 #define JF_LAUNCH(DT, VECF, UNR) argmax_partial_kernel<DT, VECF, UNR><<<grid, block, 0, s>>>(logits, R, V, row_stride, pk, (int)cpr, chunk)
     if (dtype == JF_F32) {
         if (!vec) JF_LAUNCH(JF_F32, false, 4);
