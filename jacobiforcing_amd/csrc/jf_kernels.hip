@@ -365,11 +365,15 @@ extern "C" int jf_argmax_partial(const void *logits, int dtype, int64_t R, int64
     const bool vec = (((uintptr_t)logits) % 16 == 0) && ((row_stride * esz) % 16 == 0);
     hipStream_t s = (hipStream_t)stream;
     unsigned long long *pk = (unsigned long long *)packed;
-    const bool wave_mode = vec && env_i64("JF_ARGMAX_WAVE", 1) != 0;
+    // Measured on MI355X (profiles/argmax_microbench_r01.txt): big problems stream best as ~1 wavefront per SIMD
+    // (1024 items, each a long contiguous range with 8 x 16 B per lane in flight: 6.8 TB/s fp32 at R>=512);
+    // small ones (< 48 MB) are launch/ramp bound and prefer 4-wave workgroups sharing a chunk.
+    const int64_t bytes = R * V * esz;
+    const bool wave_mode = vec && env_i64("JF_ARGMAX_WAVE", bytes >= (48ll << 20) ? 1 : 0) != 0;
     const bool deep = env_i64("JF_ARGMAX_UNROLL", 8) >= 8;
     if (wave_mode) {
-        // one item per wavefront: aim for ~3 wavefronts per SIMD (256 CUs x 4 SIMDs x 3)
-        const int64_t chunk = pick_chunk(64 * epv, R, V, env_i64("JF_ARGMAX_ITEMS", 3072));
+        // one item per wavefront, one wavefront per SIMD (256 CUs x 4 SIMDs)
+        const int64_t chunk = pick_chunk(64 * epv, R, V, env_i64("JF_ARGMAX_ITEMS", 1024));
         const int64_t cpr = (V + chunk - 1) / chunk;
         const int64_t items = R * cpr;
         const int64_t blocks = (items + (AM_TPB / 64) - 1) / (AM_TPB / 64);
@@ -381,7 +385,7 @@ extern "C" int jf_argmax_partial(const void *logits, int dtype, int64_t R, int64
 #undef JF_LAUNCHW
         return check_launch("argmax_wave_kernel");
     }
-    const int64_t chunk = pick_chunk((int64_t)AM_TPB * epv, R, V, env_i64("JF_ARGMAX_ITEMS", 1024));
+    const int64_t chunk = pick_chunk((int64_t)AM_TPB * epv, R, V, env_i64("JF_ARGMAX_ITEMS", 512));
     const int64_t cpr = (V + chunk - 1) / chunk;
     const int64_t items = R * cpr;
     if (items > 0x7FFFFFFFll) return fail(JF_E_CAPACITY, "jf_argmax_partial: grid too large");
