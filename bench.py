@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py — tokens/sec + mean tokens/forward of multiblock Jacobi decoding (n=32, K=2, r=0.85, pool=4) on a
+Qwen2.5-Coder-7B-shaped model, synthetic HumanEval-shaped prompts, random-init bf16 weights.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" is one Jacobi iteration over the rank's batch of prompts: one PyTorch forward over every prompt's rows,
+then the HIP loop body (jf_argmax_partial -> jf_mb_step -> jf_kv_commit) and one descriptor read-back.  The timed
+region is exactly K steps between barrier+synchronize fences; every rank runs the same per-GPU workload (weak
+scaling, prompts shard over ranks, no data-path collective) and rank 0 prints ONE JSON line whose `value` is the
+whole-job accepted tokens per second.
+
+Extra objects on the line:
+  roofline      — jf_argmax_partial (the convergence kernel's HBM stream): algorithmic bytes R*V*2 per launch
+                  over the average launch duration measured with HIP events on the launch stream.
+  cpu_baseline  — the CPU oracle (the reference's HF loop + DynamicCache handling restated) with a torch-CPU
+                  forward of the same weights, timed on the host cores for a bounded sample.
+  scripted_acceptance — the same K-step measurement with the synthetic acceptance model switched on (the random
+                  weights accept ~1 token per forward; a Jacobi-Forcing checkpoint accepts ~4).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import random
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+from jacobiforcing_amd import _native, ops  # noqa: E402
+from jacobiforcing_amd import distributed as jd  # noqa: E402
+from jacobiforcing_amd.engine.multiblock_decoder import MultiblockJacobiDecoder  # noqa: E402
+from jacobiforcing_amd.modeling.qwen2 import Qwen2Config, Qwen2Model, Qwen2Weights  # noqa: E402
+from jacobiforcing_amd.synthetic import ScriptedAcceptance, humaneval_shaped_prompts  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+class ArgmaxTimer:
+    """HIP events around every jf_argmax_partial launch (recorded on the launch stream = torch's current stream)."""
+
+    def __init__(self):
+        self.events = []
+        self.bytes = 0
+        self.rows = 0
+        self._orig = ops.argmax_partial
+
+    def __enter__(self):
+        def timed(logits, packed):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            self._orig(logits, packed)
+            b.record()
+            self.events.append((a, b))
+            self.bytes += logits.shape[0] * logits.shape[1] * logits.element_size()
+            self.rows += logits.shape[0]
+        ops.argmax_partial = timed
+        return self
+
+    def __exit__(self, *exc):
+        ops.argmax_partial = self._orig
+
+    def summary(self):
+        if not self.events:
+            return None
+        us = [a.elapsed_time(b) * 1e3 for a, b in self.events]
+        avg_us = sum(us) / len(us)
+        avg_bytes = self.bytes / len(us)
+        return dict(launches=len(us), avg_us=avg_us, avg_bytes=avg_bytes, avg_rows=self.rows / len(us),
+                    gbs=avg_bytes / avg_us / 1e3)
+
+
+def run_steps(dec: MultiblockJacobiDecoder, prompts, warmup: int, steps: int, seed: int, timer=None):
+    """Prefill (untimed), W warm-up iterations, then exactly K timed iterations.  Returns (tokens, seconds, ...)."""
+    dev = dec.device
+    state = dict(i=0, tokens=0, t0=None, t1=None, acc_at_start=0)
+    total = warmup + steps
+    acc_idx = _native.DESC_FIELDS.index("accepted")
+
+    def on_iter(i, d):
+        state["tokens_all"] = state.get("tokens_all", 0) + int(d[:, acc_idx].sum())
+        if i == warmup and warmup > 0:
+            jd.barrier(dev)
+            state["acc_at_start"] = state["tokens_all"]
+            if timer is not None:
+                timer.events.clear(); timer.bytes = 0; timer.rows = 0
+            state["t0"] = time.perf_counter()
+        if i == total:
+            jd.barrier(dev)
+            state["t1"] = time.perf_counter()
+
+    def on_start():
+        if warmup == 0:
+            jd.barrier(dev)
+            if timer is not None:
+                timer.events.clear(); timer.bytes = 0; timer.rows = 0
+            state["t0"] = time.perf_counter()
+
+    stats, gen_s, iters = dec.generate(prompts, max_new_tokens=1 << 30, max_calls=1 << 30, seed=seed,
+                                       on_iteration=on_iter, max_iterations=total, on_generation_start=on_start)
+    if state["t1"] is None:          # every prompt finished early (EOS): close the window
+        jd.barrier(dev)
+        state["t1"] = time.perf_counter()
+    tokens = state.get("tokens_all", 0) - state["acc_at_start"]
+    return dict(tokens=tokens, seconds=state["t1"] - state["t0"], iterations=min(iters, total) - warmup, stats=stats)
+
+
+def cpu_baseline(model, prompt, prm, budget_s: float):
+    """The reference's HF path restated for the CPU (oracle state machine + DynamicCache-style torch-CPU forward of the
+    same weights), timed on the host cores for a bounded sample.  Only this leg imports oracle/."""
+    from oracle import cpu_reference as CR
+    t0 = time.perf_counter()
+    cpu = CR.CpuQwen2(model.cfg, model.w, dtype=torch.bfloat16)
+    load_s = time.perf_counter() - t0
+    r = CR.timed_tokens_per_second(cpu, prompt, random.Random(1234), n=prm.n, K=prm.K, r=prm.r,
+                                   pool=prm.n_gram_pool_size, eos=prm.eos_token_id, pad=prm.pad_token_id, budget_s=budget_s)
+    return dict(value=r["tokens_per_sec"], unit="tokens/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"1 prompt ({len(prompt)} tokens), {r['calls']} generation calls, {r['iterations']} Jacobi "
+                       f"iterations, {r['tokens']} tokens in {r['seconds']:.1f}s; oracle loop + torch-CPU bf16 forward "
+                       f"with DynamicCache-style cat/expand/narrow (weights copied from the GPU in {load_s:.1f}s, untimed)",
+                tokens_per_forward=(r["tokens"] / r["iterations"]) if r["iterations"] else 0.0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=96)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--prompts-per-gpu", type=int, default=8)
+    ap.add_argument("--model", default=os.environ.get("JF_MODEL", "qwen2.5-coder-7b"), help="qwen2.5-coder-7b | tiny | <hf dir>")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=float(os.environ.get("JF_CPU_BASELINE_S", "20")))
+    ap.add_argument("--no-scripted", action="store_true")
+    ap.add_argument("--robust", type=int, default=75)
+    args = ap.parse_args()
+
+    info = jd.init_from_env("nccl")
+    if info.world_size != args.gpus and info.world_size > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={info.world_size}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the Jacobi loop body has no CPU path")
+    torch.cuda.set_device(info.local_rank)
+    dev = torch.device("cuda", info.local_rank)
+    _native.lib()                                   # fail loudly if the HIP extension is missing
+
+    if args.model == "tiny":
+        cfg = Qwen2Config.tiny(vocab_size=4096, hidden_size=256, layers=4, heads=8, kv_heads=2, head_dim=32, inter=512)
+        name = "tiny-qwen2"
+    elif args.model == "qwen2.5-coder-7b":
+        cfg, name = Qwen2Config.qwen2_5_coder_7b(), "Qwen2.5-Coder-7B (random-init)"
+    else:
+        cfg, name = Qwen2Config.from_json(Path(args.model) / "config.json"), f"{Path(args.model).name} (checkpoint)"
+    weights = Qwen2Weights(cfg, dev, dtype=torch.bfloat16, seed=0)
+    if args.model not in ("tiny", "qwen2.5-coder-7b"):
+        weights.load_safetensors(args.model, cfg)
+    model = Qwen2Model(cfg, weights)
+
+    prm = ops.MultiblockParams(n=32, K=2, r=0.85, lookahead_start_ratio=0.0, n_gram_pool_size=4,
+                               eos_token_id=cfg.eos_token_id, pad_token_id=cfg.pad_token_id)
+    P = args.prompts_per_gpu
+    vocab_hi = min(151643, cfg.vocab_size - 2)
+    all_prompts = humaneval_shaped_prompts(P * info.world_size, seed=1234, vocab_hi=vocab_hi)
+    prompts = jd.shard_prompts(all_prompts, info)
+    dec = MultiblockJacobiDecoder(model, P, prm, max_seq_len=4096)
+
+    # ---- headline: unmodified random-init model ------------------------------------------------
+    with ArgmaxTimer() as tm:
+        r = run_steps(dec, prompts, args.warmup, args.steps, seed=1234 + info.rank, timer=tm)
+        roof = tm.summary()
+    agg = jd.gather_throughput(r["tokens"], r["iterations"] * 1.0, r["seconds"], dev)
+    # ---- same measurement with the synthetic acceptance model -------------------------------------
+    scripted = None
+    if not args.no_scripted:
+        dec.logits_hook = ScriptedAcceptance(cfg.vocab_size, robust_pct=args.robust, vocab_hi=vocab_hi)
+        r2 = run_steps(dec, prompts, args.warmup, args.steps, seed=4321 + info.rank)
+        a2 = jd.gather_throughput(r2["tokens"], r2["iterations"] * 1.0, r2["seconds"], dev)
+        dec.logits_hook = None
+        scripted = dict(value=a2["tokens"] / a2["seconds"], unit="tokens/s",
+                        tokens_per_forward=a2["tokens"] / max(a2["iterations"] * P, 1),
+                        ms_per_step=a2["seconds"] / args.steps * 1e3, robust_pct=args.robust,
+                        note="logits get a planted context-robust prediction (jacobiforcing_amd/synthetic.py) — extra "
+                             "work inside the forward; emulates a Jacobi-Forcing checkpoint's acceptance")
+    out = None
+    if info.rank == 0:
+        steps_done = max(int(round(agg["iterations"] / info.world_size)), 1)
+        value = agg["tokens"] / agg["seconds"]
+        tpf = agg["tokens"] / (agg["iterations"] * P) if agg["iterations"] else 0.0   # per prompt, per forward
+        out = {
+            "metric": "tokens/sec (+ mean tokens/forward), multiblock Jacobi n=32 K=2 r=0.85 pool=4, Qwen2.5-Coder-7B",
+            "value": value, "unit": "tokens/s", "n_gpus": info.world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": agg["seconds"] / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "tokens_per_forward": tpf,
+            "config": {"workload": f"{P} HumanEval-shaped synthetic prompts per GPU (BASELINE config 3 semantics batched "
+                                   f"as in config 4: {P * info.world_size} prompts sharded {info.world_size}-way), "
+                                   "multiblock lookahead + rejection recycling, greedy",
+                       "model": name, "n": 32, "K": 2, "r": 0.85, "pool": 4, "prompts_per_gpu": P,
+                       "steps_measured": steps_done, "logits_dtype": "bf16",
+                       "weights": "random-init (no network for checkpoints); acceptance is what these weights give"},
+        }
+        if roof is not None:
+            out["roofline"] = {"bound": "hbm", "achieved": roof["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": roof["gbs"] / HBM_PEAK_GBS, "traffic": _pmc_traffic(roof),
+                               "kernel": "jf_argmax_partial (argmax_wave_kernel / argmax_partial_kernel)",
+                               "bytes_per_launch": roof["avg_bytes"], "us_per_launch": roof["avg_us"],
+                               "rows_per_launch": roof["avg_rows"], "launches": roof["launches"]}
+        if scripted is not None:
+            out["scripted_acceptance"] = scripted
+    if info.rank == 0 and info.world_size == 1 and args.cpu_baseline_seconds > 0:
+        try:
+            out["cpu_baseline"] = cpu_baseline(model, prompts[0], prm, args.cpu_baseline_seconds)
+        except Exception as e:  # the baseline must not kill the GPU measurement
+            out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": f"failed: {type(e).__name__}: {e}"}
+    if out is not None:
+        print(json.dumps(out), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+def _pmc_traffic(roof):
+    """HBM bytes per launch from the committed PMC pass (profiles/), when one exists for this shape; else null."""
+    f = ROOT / "profiles" / "pmc_argmax_latest.json"
+    try:
+        d = json.loads(f.read_text())
+        return d.get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+if __name__ == "__main__":
+    main()

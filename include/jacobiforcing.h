@@ -34,7 +34,8 @@ enum {
     JF_OK = 0,
     JF_E_INVALID = -1,   /* bad argument (shape / alignment / null) -> ValueError on the Python side */
     JF_E_CAPACITY = -2,  /* a fixed capacity would be exceeded       -> RuntimeError                  */
-    JF_E_LAUNCH = -3     /* HIP launch / runtime failure             -> RuntimeError                  */
+    JF_E_LAUNCH = -3,    /* HIP launch / runtime failure             -> RuntimeError                  */
+    JF_E_SHAPE = -4      /* rows that torch could not broadcast (MB:482, reachable with K >= 3) -> RuntimeError */
 };
 
 enum { JF_F32 = 0, JF_BF16 = 1 };
@@ -118,9 +119,13 @@ int32_t jf_mb_max_tokens(const jf_mb_params *p); /* max T per row               
 /* Start a generation call for P prompts (MB:230-262, then the first build_out_and_spans MB:317-377).
  * states      [P, state_ints] int32
  * input_ids   [P, n] int64 — token 0 is the correct next token, not yet cached (MB:243)
- * kv_len      [P] int32 — committed KV length == prompt_len for this call (MB:261)
+ * kv_len      [P] int32 — committed KV length == prompt_len for this call (MB:261), or
+ *             JF_MB_INACTIVE: the prompt is finished and rides along with B = 0, or
+ *             JF_MB_KEEP: leave this prompt's running call untouched (rolling restarts in a batch)
  * desc        [P] jf_mb_desc
  */
+#define JF_MB_INACTIVE (-1)
+#define JF_MB_KEEP (-2)
 int jf_mb_begin(int32_t *states, int64_t state_ints, int P, const jf_mb_params *params,
                 const int64_t *input_ids, const int32_t *kv_len, jf_mb_desc *desc, void *stream);
 

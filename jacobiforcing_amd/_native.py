@@ -14,8 +14,9 @@ LIB_PATH = _PKG / "lib" / "libjacobiforcing.so"
 SRC_PATH = _PKG / "csrc" / "jf_kernels.hip"
 INCLUDE_DIR = _PKG.parent / "include"
 
-JF_OK, JF_E_INVALID, JF_E_CAPACITY, JF_E_LAUNCH = 0, -1, -2, -3
+JF_OK, JF_E_INVALID, JF_E_CAPACITY, JF_E_LAUNCH, JF_E_SHAPE = 0, -1, -2, -3, -4
 JF_F32, JF_BF16 = 0, 1
+JF_MB_INACTIVE, JF_MB_KEEP = -1, -2
 
 
 class MbParams(C.Structure):
@@ -116,6 +117,10 @@ def check(rc: int, what: str = ""):
 def raise_state_error(code: int, what: str):
     if code == JF_E_INVALID:
         raise ValueError(f"{what}: invalid state inside the Jacobi state machine (shape/assert; see MB:482, MB:631, MB:667)")
+    if code == JF_E_SHAPE:
+        # what torch raises at MB:482 when a re-surfaced pseudo block (Q3, K >= 3) has k rows and the RA draft has B
+        raise RuntimeError(f"{what}: The size of tensor a must match the size of tensor b at non-singleton dimension 0 "
+                           "(draft rows vs candidate rows, MB:482)")
     if code == JF_E_CAPACITY:
         raise RuntimeError(f"{what}: fixed capacity exceeded inside the Jacobi state machine (raise max_blocks)")
     if code:

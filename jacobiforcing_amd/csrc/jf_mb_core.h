@@ -227,6 +227,7 @@ struct Machine {
         for (int i = lanes.lane(); i < p.n; i += lanes.count()) draft(0, 0)[i] = (int32_t)input_tok(i);
         lanes.sync();
         load_scalars();
+        if (kv0 < 0) { done = 1; kv_len = 0; }               // JF_MB_INACTIVE: a finished prompt rides along with B = 0
         next_iteration(d);
     }
 
@@ -283,7 +284,7 @@ struct Machine {
                 m = lanes.reduce_min(m);
                 if (m + 1 > acc_raw) { acc_raw = m + 1; best_idx = r; }
             }
-            if (rows_d != 1 && B != 1 && rows_d != B) { JF_FAIL(JF_E_INVALID); break; }   // torch broadcast would raise
+            if (rows_d != 1 && B != 1 && rows_d != B) { JF_FAIL(JF_E_SHAPE); break; }   // torch broadcast raises (MB:482)
             const int32_t *drow = draft(b, rows_d == 1 ? 0 : best_idx);
             if (s == 0 || b == RA) best_row = (b == RA) ? best_idx : best_row;   // MB:500-502
             if (Ls == 0) continue;
@@ -502,6 +503,7 @@ JF_HD void mb_begin_body(Lanes lanes, int p, int32_t *states, int64_t state_ints
     Layout lay = make_layout(prm.n, prm.K, prm.pool_size, prm.max_blocks);
     Machine<Lanes> m(S, lanes, lay);
     const int64_t *in = input_ids + (int64_t)p * prm.n;
+    if (kv_len[p] == JF_MB_KEEP) return;                      // prompt keeps running its current call
     m.begin(prm, [in](int i) { return in[i]; }, kv_len[p], desc ? desc + p : nullptr);
 }
 

@@ -1,0 +1,209 @@
+"""Multiblock Jacobi decoding with rejection recycling for a batch of prompts.
+
+Host orchestration of the hot path the north star names: per Jacobi iteration one PyTorch forward
+over every prompt's rows, then ``jf_argmax_partial`` + ``jf_mb_step`` (verify, accept, re-draft,
+pool/candidates, spawn/promote) + ``jf_kv_commit`` in HIP, and ONE small descriptor read-back.
+
+The per-prompt semantics are those of the reference's ``jacobi_forward_greedy_multiblock``
+(MB:140-740) and its driver loop (JacobiForcing/jacobi_forcing_inference_MR_humaneval.py:152-273 =
+"DRV"): prefill with a random draft, first call seeded with the prefill n-gram, later calls with
+``[first_correct_token] + n-1 tokens drawn from the text so far``; stop on EOS / max_new_tokens /
+max_calls; tokens-per-second excludes the prefill and counts ``new_tokens - 1`` (DRV:243).
+The reference runs one prompt at a time; here P prompts share a forward, each with its own state
+machine and rolling call restarts (BASELINE config 4).
+"""
+from __future__ import annotations
+
+import random
+import time
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .. import _native as N
+from .. import ops
+from ..modeling.qwen2 import Qwen2Model, StaticKVCache
+
+
+@dataclass
+class PromptStats:
+    """One row of the reference driver's CSV (DRV:259-273)."""
+    prompt_tokens: int = 0
+    new_tokens: int = 0
+    calls: int = 0
+    total_iterations: int = 0
+    time_sec: float = 0.0
+    stop_reason: Optional[str] = None
+    token_ids: List[int] = field(default_factory=list)
+
+    @property
+    def avg_iter_per_call(self):
+        return self.total_iterations / self.calls if self.calls else 0.0
+
+    @property
+    def avg_iter_per_token(self):
+        return self.total_iterations / self.new_tokens if self.new_tokens else 0.0
+
+    def row(self, gen_time: float) -> dict:
+        return dict(prompt_tokens=self.prompt_tokens, new_tokens=self.new_tokens, calls=self.calls,
+                    total_iterations=self.total_iterations, avg_iter_per_call=self.avg_iter_per_call,
+                    avg_iter_per_token=self.avg_iter_per_token, time_sec=self.time_sec,
+                    toks_per_sec=(self.new_tokens / gen_time) if gen_time > 0 else 0.0, stop_reason=self.stop_reason)
+
+
+LogitsHook = Callable[[torch.Tensor, "MultiblockJacobiDecoder"], torch.Tensor]
+
+
+class MultiblockJacobiDecoder:
+    def __init__(self, model: Qwen2Model, num_prompts: int, params: ops.MultiblockParams, max_seq_len: int = 4096,
+                 logits_hook: Optional[LogitsHook] = None):
+        self.model = model
+        self.P = int(num_prompts)
+        self.params = params
+        self.device = model.device
+        self.batch = ops.MultiblockBatch(self.P, params, self.device)
+        self.cand_rows = self.batch.max_rows - 1
+        self.cache = StaticKVCache(model.cfg, self.P, max_seq_len, self.cand_rows, self.batch.max_tokens, self.device,
+                                   dtype=model.dtype)
+        self.max_seq_len = max_seq_len
+        self.logits_hook = logits_hook
+        self.kv_len_host = np.zeros(self.P, dtype=np.int64)
+        self.forwards = 0
+        self.last_logits_rows = 0
+        self._f = {k: N.DESC_FIELDS.index(k) for k in N.DESC_FIELDS}
+
+    # ------------------------------------------------------------------------------ prefill (MB:175-225)
+    @torch.inference_mode()
+    def prefill(self, prompts: Sequence[Sequence[int]], drafts: Sequence[Sequence[int]]) -> List[List[int]]:
+        """Forward prompt ⧺ draft per prompt, first n-gram = argmax(logits[-n-1:-1]); KV is cut back to the prompt.
+        lm_head runs on the last n+1 positions only (the reference computes all S+n rows, MB:216)."""
+        n = self.params.n
+        dev = self.device
+        ngrams = []
+        for p, (prompt, draft) in enumerate(zip(prompts, drafts)):
+            ids = torch.tensor([list(prompt) + list(draft)], dtype=torch.int64, device=dev)
+            T = ids.shape[1]
+            if T > self.max_seq_len:
+                raise RuntimeError(f"prompt {p}: {T} tokens exceed max_seq_len={self.max_seq_len}")
+            pos = torch.arange(T, dtype=torch.int32, device=dev).view(1, T)
+            z = torch.zeros(1, dtype=torch.int32, device=dev)
+            logits = self.model.forward(ids, pos, self.cache, row_prompt=torch.full((1,), p, dtype=torch.int32, device=dev),
+                                        row_cand=torch.full((1,), -1, dtype=torch.int32, device=dev),
+                                        row_len=torch.full((1,), T, dtype=torch.int32, device=dev), kv_len_rows=z,
+                                        any_candidates=False, logits_rows=slice(T - n - 1, T - 1))
+            if self.logits_hook is not None:
+                logits = self.logits_hook(logits, self, prefill=(p, len(prompt)))
+            ngrams.append(ops.argmax_rows(logits).cpu().tolist())
+            self.kv_len_host[p] = len(prompt)
+        self.cache.kv_len.copy_(torch.from_numpy(self.kv_len_host.astype(np.int32)))
+        return ngrams
+
+    # ------------------------------------------------------------------------------ one Jacobi iteration
+    @torch.inference_mode()
+    def iteration(self, d: np.ndarray) -> np.ndarray:
+        """forward -> verify/accept/re-draft (HIP) -> KV commit.  ``d`` is the current descriptor table."""
+        packed_in = self.batch.pack(d)
+        if packed_in is None:
+            return d
+        ids, pos, row_prompt, row_len = packed_in
+        B = d[:, self._f["B"]]
+        any_cand = bool((B > 1).any())
+        dev = self.device
+        R = ids.shape[0]
+        if any_cand:
+            # candidate index inside a prompt -> scratch row p*cand_rows + (b-1); row 0 writes the main cache
+            bidx = np.concatenate([np.arange(b) for b in B if b > 0])
+            pidx = np.repeat(np.arange(self.P), B)
+            rc = np.where(bidx > 0, pidx * max(self.cand_rows, 1) + bidx - 1, -1).astype(np.int32)
+            row_cand = torch.from_numpy(rc).to(dev, non_blocking=True)
+        else:
+            row_cand = torch.full((R,), -1, dtype=torch.int32, device=dev)
+        kv_rows = self.cache.kv_len[row_prompt.long()]
+        logits = self.model.forward(ids, pos, self.cache, row_prompt=row_prompt, row_cand=row_cand, row_len=row_len,
+                                    kv_len_rows=kv_rows, any_candidates=any_cand)
+        if self.logits_hook is not None:
+            logits = self.logits_hook(logits, self, prefill=None)
+        self.forwards += 1
+        self.last_logits_rows = logits.shape[0]
+        d = self.batch.verify(logits)
+        if self.cache.committer is not None and any_cand:
+            self.cache.committer.commit(self.batch.desc_dev)
+        act = B > 0
+        self.kv_len_host[act] = d[act, self._f["kv_len"]]
+        self.cache.kv_len.copy_(torch.from_numpy(self.kv_len_host.astype(np.int32)), non_blocking=True)
+        return d
+
+    # ------------------------------------------------------------------------------ driver (DRV:152-273)
+    @torch.inference_mode()
+    def generate(self, prompts: Sequence[Sequence[int]], max_new_tokens: int = 1024, max_calls: int = 1024,
+                 seed: int = 1234, on_iteration: Optional[Callable[[int, np.ndarray], None]] = None,
+                 max_iterations: Optional[int] = None, on_generation_start: Optional[Callable[[], None]] = None):
+        """Decode every prompt to EOS / max_new_tokens / max_calls.  Returns (stats per prompt, gen_seconds,
+        iterations).  ``gen_seconds`` covers the generation phase only (prefill excluded, DRV:217-230)."""
+        assert len(prompts) == self.P
+        n, eos = self.params.n, self.params.eos_token_id
+        rngs = [random.Random(seed + p) for p in range(self.P)]          # one stream per prompt (order-independent)
+        stats = [PromptStats(prompt_tokens=len(p)) for p in prompts]
+        text = [list(p) for p in prompts]                              # generated_ids incl. the prompt (DRV:150)
+        t0 = time.perf_counter()
+        drafts = [[rngs[p].choice(text[p]) for _ in range(n)] for p in range(self.P)]      # DRV:176-180
+        ngrams = self.prefill(prompts, drafts)
+        for s in stats:
+            s.calls = 1                                                # the prefill call counts (DRV:234)
+        active = np.ones(self.P, dtype=bool)
+        inputs = np.array(ngrams, dtype=np.int64)                      # call 1 reuses the prefill n-gram (DRV:206-208)
+        begin_kv = self.kv_len_host.astype(np.int32).copy()
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        t_gen = time.perf_counter()
+        d = self.batch.begin(torch.from_numpy(inputs), torch.from_numpy(begin_kv))
+        if on_generation_start is not None:
+            on_generation_start()
+        iters_total = 0
+        while active.any():
+            d = self.iteration(d)
+            iters_total += 1
+            if on_iteration is not None:
+                on_iteration(iters_total, d)
+            done = (d[:, self._f["done"]] == 1) & active
+            if done.any():
+                res = self.batch.results(d)
+                restart = np.full(self.P, N.JF_MB_KEEP, dtype=np.int32)
+                for p in np.nonzero(done)[0]:
+                    r = res[p]
+                    st = stats[p]
+                    text[p] += r["ret"]
+                    st.token_ids += r["ret"]
+                    st.calls += 1
+                    st.total_iterations += r["iters"]
+                    new_total = len(st.token_ids)
+                    self.kv_len_host[p] = r["kv_len"]
+                    if eos is not None and eos in st.token_ids:                      # DRV:154-160
+                        st.stop_reason = "eos"
+                    elif new_total >= max_new_tokens:
+                        st.stop_reason = "max_new_tokens"
+                    elif st.calls >= max_calls:
+                        st.stop_reason = "max_calls"
+                    if st.stop_reason is not None:
+                        active[p] = False
+                        restart[p] = N.JF_MB_INACTIVE
+                    else:
+                        nt = r["next_token"]
+                        inputs[p] = [nt] + [rngs[p].choice(text[p]) for _ in range(n - 1)]   # DRV:209-215
+                        restart[p] = r["kv_len"]
+                if active.any():
+                    d = self.batch.begin(torch.from_numpy(inputs), torch.from_numpy(restart))
+                    self.cache.kv_len.copy_(torch.from_numpy(self.kv_len_host.astype(np.int32)), non_blocking=True)
+            if max_iterations is not None and iters_total >= max_iterations:
+                break
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        gen_seconds = time.perf_counter() - t_gen
+        for st in stats:
+            st.new_tokens = max(len(st.token_ids) - 1, 0)              # DRV:243 "subtract prefill"
+            st.time_sec = time.perf_counter() - t0
+            if st.stop_reason is None:
+                st.stop_reason = "interrupted"
+        return stats, gen_seconds, iters_total

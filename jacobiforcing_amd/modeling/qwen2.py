@@ -1,0 +1,239 @@
+"""Minimal Qwen2 forward in stock PyTorch-ROCm over a static, preallocated KV cache.
+
+The north star keeps the transformer forward in PyTorch; this module is that forward, written
+so the Jacobi loop body never has to copy the cache:
+
+* committed K/V of prompt ``p`` live once in ``k_main[layer][p, :, :kv_len[p]]`` — "trim" is a
+  length decrement, "append" of an accepted row-0 token is free (its K/V is already in place);
+* recycled candidate rows (MB:575-588) write their speculative K/V into a small scratch
+  ``k_cand`` and are attended over the shared prefix; the winner's accepted rows are copied to
+  the main cache by ``jf_kv_commit`` (replacing MB:93-127 / MB:500-502's full-cache copies).
+
+It mirrors what the reference's forward computes (HF Qwen2: embed -> N x [RMSNorm, QKV+bias,
+RoPE, GQA attention, o_proj, RMSNorm, SwiGLU] -> RMSNorm -> lm_head, cf. MB:428-463 and
+inference_engine/models/qwen3.py:185-215) but shares no code with it.
+"""
+from __future__ import annotations
+
+import json
+import math
+from dataclasses import dataclass
+from pathlib import Path
+from typing import List, Optional
+
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+
+
+@dataclass
+class Qwen2Config:
+    vocab_size: int = 152064
+    hidden_size: int = 3584
+    intermediate_size: int = 18944
+    num_hidden_layers: int = 28
+    num_attention_heads: int = 28
+    num_key_value_heads: int = 4
+    head_dim: int = 128
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 1000000.0
+    max_position_embeddings: int = 32768
+    tie_word_embeddings: bool = False
+    eos_token_id: int = 151645
+    pad_token_id: int = 151643
+
+    @classmethod
+    def qwen2_5_coder_7b(cls) -> "Qwen2Config":
+        """Qwen2.5-Coder-7B-Instruct (public HF config; the checkpoint family README.md:114 names)."""
+        return cls()
+
+    @classmethod
+    def tiny(cls, vocab_size=512, hidden_size=128, layers=2, heads=4, kv_heads=2, head_dim=32, inter=256) -> "Qwen2Config":
+        return cls(vocab_size=vocab_size, hidden_size=hidden_size, intermediate_size=inter, num_hidden_layers=layers,
+                   num_attention_heads=heads, num_key_value_heads=kv_heads, head_dim=head_dim,
+                   max_position_embeddings=4096, eos_token_id=vocab_size - 1, pad_token_id=vocab_size - 2)
+
+    @classmethod
+    def from_json(cls, path) -> "Qwen2Config":
+        d = json.loads(Path(path).read_text())
+        hd = d.get("head_dim") or d["hidden_size"] // d["num_attention_heads"]
+        eos = d.get("eos_token_id", 151645)
+        if isinstance(eos, list):
+            eos = eos[0]
+        return cls(vocab_size=d["vocab_size"], hidden_size=d["hidden_size"], intermediate_size=d["intermediate_size"],
+                   num_hidden_layers=d["num_hidden_layers"], num_attention_heads=d["num_attention_heads"],
+                   num_key_value_heads=d.get("num_key_value_heads", d["num_attention_heads"]), head_dim=hd,
+                   rms_norm_eps=d.get("rms_norm_eps", 1e-6), rope_theta=d.get("rope_theta", 1e6),
+                   max_position_embeddings=d.get("max_position_embeddings", 32768),
+                   tie_word_embeddings=d.get("tie_word_embeddings", False), eos_token_id=eos,
+                   pad_token_id=d.get("pad_token_id") or 151643)
+
+
+def _rms_norm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    xf = x.float()
+    xf = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+    return (xf.to(x.dtype)) * w
+
+
+class Qwen2Weights:
+    """Flat weight container (fused QKV and gate/up so each layer is 4 GEMMs)."""
+
+    def __init__(self, cfg: Qwen2Config, device, dtype=torch.bfloat16, seed: int = 0, init_std: float = 0.02):
+        g = torch.Generator(device=device).manual_seed(seed)
+        H, I = cfg.hidden_size, cfg.intermediate_size
+        nq, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+
+        def rnd(*shape, std=init_std):
+            return (torch.randn(*shape, generator=g, device=device, dtype=torch.float32) * std).to(dtype)
+
+        self.embed = rnd(cfg.vocab_size, H)
+        self.layers = []
+        for _ in range(cfg.num_hidden_layers):
+            self.layers.append(dict(
+                ln1=torch.ones(H, device=device, dtype=dtype),
+                wqkv=rnd((nq + 2 * nkv) * hd, H), bqkv=rnd((nq + 2 * nkv) * hd, std=0.01),
+                wo=rnd(H, nq * hd),
+                ln2=torch.ones(H, device=device, dtype=dtype),
+                wgu=rnd(2 * I, H), wd=rnd(H, I)))
+        self.norm = torch.ones(H, device=device, dtype=dtype)
+        self.lm_head = self.embed if cfg.tie_word_embeddings else rnd(cfg.vocab_size, H)
+
+    def load_safetensors(self, model_dir, cfg: Qwen2Config) -> None:
+        """Load a HF Qwen2 checkpoint directory (*.safetensors) when one is available."""
+        from safetensors import safe_open
+        nq, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        tensors = {}
+        for f in sorted(Path(model_dir).glob("*.safetensors")):
+            with safe_open(str(f), "pt", "cpu") as sf:
+                for k in sf.keys():
+                    tensors[k] = sf.get_tensor(k)
+        dev, dt = self.embed.device, self.embed.dtype
+        get = lambda k: tensors[k].to(device=dev, dtype=dt)
+        self.embed = get("model.embed_tokens.weight")
+        for i, L in enumerate(self.layers):
+            pre = f"model.layers.{i}."
+            L["ln1"] = get(pre + "input_layernorm.weight")
+            L["ln2"] = get(pre + "post_attention_layernorm.weight")
+            L["wqkv"] = torch.cat([get(pre + f"self_attn.{n}_proj.weight") for n in "qkv"], 0)
+            L["bqkv"] = torch.cat([get(pre + f"self_attn.{n}_proj.bias") for n in "qkv"], 0)
+            L["wo"] = get(pre + "self_attn.o_proj.weight")
+            L["wgu"] = torch.cat([get(pre + "mlp.gate_proj.weight"), get(pre + "mlp.up_proj.weight")], 0)
+            L["wd"] = get(pre + "mlp.down_proj.weight")
+        self.norm = get("model.norm.weight")
+        self.lm_head = self.embed if cfg.tie_word_embeddings else get("lm_head.weight")
+
+
+class StaticKVCache:
+    """Preallocated K/V: main [P, H_kv, S_max, D] per layer (+ candidate scratch [P*cand_rows, H_kv, T_max, D])."""
+
+    def __init__(self, cfg: Qwen2Config, P: int, S_max: int, cand_rows: int, T_max: int, device, dtype=torch.bfloat16):
+        nkv, hd, NL = cfg.num_key_value_heads, cfg.head_dim, cfg.num_hidden_layers
+        self.P, self.S_max, self.cand_rows, self.T_max = P, S_max, max(cand_rows, 0), T_max
+        z = lambda *s: torch.zeros(*s, device=device, dtype=dtype)
+        self.k = [z(P, nkv, S_max, hd) for _ in range(NL)]
+        self.v = [z(P, nkv, S_max, hd) for _ in range(NL)]
+        cr = max(self.cand_rows, 1)
+        self.ck = [z(P * cr, nkv, T_max, hd) for _ in range(NL)]
+        self.cv = [z(P * cr, nkv, T_max, hd) for _ in range(NL)]
+        self.kv_len = torch.zeros(P, dtype=torch.int32, device=device)     # committed length per prompt
+        self.committer = ops.KVCommitter(self.k, self.v, self.ck, self.cv, cr) if self.cand_rows > 0 else None
+
+    def get_seq_length(self, p: int = 0) -> int:
+        return int(self.kv_len[p])
+
+
+class Qwen2Model:
+    def __init__(self, cfg: Qwen2Config, weights: Qwen2Weights):
+        self.cfg = cfg
+        self.w = weights
+        self.device = weights.embed.device
+        self.dtype = weights.embed.dtype
+        hd = cfg.head_dim
+        inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, hd, 2, device=self.device, dtype=torch.float32) / hd))
+        t = torch.arange(cfg.max_position_embeddings, device=self.device, dtype=torch.float32)
+        fr = torch.outer(t, inv)
+        self.cos = fr.cos()     # [max_pos, hd/2] fp32
+        self.sin = fr.sin()
+
+    # -- pieces -----------------------------------------------------------------------------
+    def _rope(self, x: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
+        """x [R, T, heads, hd]; pos [R, T] -> rotate-half RoPE (HF convention)."""
+        cos = self.cos[pos].unsqueeze(2)
+        sin = self.sin[pos].unsqueeze(2)
+        x1, x2 = x[..., : x.shape[-1] // 2].float(), x[..., x.shape[-1] // 2:].float()
+        return torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], dim=-1).to(x.dtype)
+
+    def _mlp(self, L, x):
+        gu = F.linear(x, L["wgu"])
+        g, u = gu.chunk(2, dim=-1)
+        return F.linear(F.silu(g) * u, L["wd"])
+
+    # -- forward over a static cache -------------------------------------------------------------
+    @torch.inference_mode()
+    def forward(self, input_ids: torch.Tensor, positions: torch.Tensor, cache: StaticKVCache,
+                row_prompt: torch.Tensor, row_cand: torch.Tensor, row_len: torch.Tensor,
+                kv_len_rows: torch.Tensor, any_candidates: bool, logits_rows: Optional[slice] = None) -> torch.Tensor:
+        """One forward over R rows of (padded) length T.
+
+        input_ids [R,T] int64, positions [R,T] int32 (= kv_len + t), row_prompt [R] (cache row of the prefix),
+        row_cand [R] (-1: the row writes into the main cache, else index into the candidate scratch),
+        row_len [R] valid tokens per row, kv_len_rows [R] committed prefix length per row.
+        Returns logits [R, T, V] in the weight dtype (or only ``logits_rows`` of the flattened [R*T])."""
+        cfg, w = self.cfg, self.w
+        R, T = input_ids.shape
+        nq, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        G = nq // nkv
+        dev = self.device
+        pos = positions.long()
+        S_cur = int(kv_len_rows.max().item()) + T if R else T     # one host read per forward (shape of the key axis)
+        S_cur = min(S_cur, cache.S_max)
+        ar_t = torch.arange(T, device=dev)
+        ar_s = torch.arange(S_cur, device=dev)
+        kvl = kv_len_rows.long()
+        rel = ar_s.view(1, 1, S_cur) - kvl.view(R, 1, 1)                            # key index relative to the new block
+        mask = (rel < 0) | ((rel <= ar_t.view(1, T, 1)) & (rel < row_len.long().view(R, 1, 1)))
+        mask = mask.view(R, 1, 1, T, S_cur).expand(R, 1, G, T, S_cur).reshape(R, 1, G * T, S_cur)
+        # slots of the freshly computed K/V rows
+        valid = ar_t.view(1, T) < row_len.long().view(R, 1)
+        main_rows = row_cand < 0
+        slot_main = torch.where(valid & main_rows.view(R, 1), row_prompt.long().view(R, 1) * cache.S_max + pos,
+                                torch.full_like(pos, -1)).reshape(-1)
+        slot_cand = torch.where(valid & (~main_rows).view(R, 1), row_cand.long().view(R, 1) * cache.T_max + ar_t.view(1, T),
+                                torch.full_like(pos, -1)).reshape(-1) if any_candidates else None
+        rp = row_prompt.long()
+
+        x = w.embed[input_ids]                                                        # [R,T,H]
+        for li, L in enumerate(w.layers):
+            h = _rms_norm(x, L["ln1"], cfg.rms_norm_eps)
+            qkv = F.linear(h, L["wqkv"], L["bqkv"]).view(R, T, nq + 2 * nkv, hd)
+            q = self._rope(qkv[:, :, :nq], pos)
+            k = self._rope(qkv[:, :, nq:nq + nkv], pos).reshape(R * T, nkv, hd).contiguous()
+            v = qkv[:, :, nq + nkv:].reshape(R * T, nkv, hd).contiguous()
+            ops.kv_append(cache.k[li], cache.v[li], k, v, slot_main)                  # a18: append (row 0 of each prompt)
+            if any_candidates:
+                ops.kv_append(cache.ck[li], cache.cv[li], k, v, slot_cand)
+                Kf = cache.k[li][rp, :, :S_cur].clone()                               # [R,nkv,S,hd] prefix (+ row-0 tail)
+                Vf = cache.v[li][rp, :, :S_cur].clone()
+                cr = (~main_rows).nonzero(as_tuple=True)[0]
+                if cr.numel():
+                    # candidate rows see their own speculative tail instead of row 0's
+                    tail_idx = (kvl[cr].view(-1, 1) + ar_t.view(1, T)).clamp_(max=S_cur - 1)   # [C,T]
+                    ck = cache.ck[li][row_cand[cr].long(), :, :T]                      # [C,nkv,T,hd]
+                    cv = cache.cv[li][row_cand[cr].long(), :, :T]
+                    idx = tail_idx.view(-1, 1, T, 1).expand(-1, nkv, T, hd)
+                    Kf[cr] = Kf[cr].scatter(2, idx, ck)
+                    Vf[cr] = Vf[cr].scatter(2, idx, cv)
+            else:
+                Kf = cache.k[li][:, :, :S_cur] if R == cache.P else cache.k[li][rp, :, :S_cur]
+                Vf = cache.v[li][:, :, :S_cur] if R == cache.P else cache.v[li][rp, :, :S_cur]
+            qh = q.view(R, T, nkv, G, hd).permute(0, 2, 3, 1, 4).reshape(R, nkv, G * T, hd)
+            o = F.scaled_dot_product_attention(qh, Kf, Vf, attn_mask=mask)
+            o = o.view(R, nkv, G, T, hd).permute(0, 3, 1, 2, 4).reshape(R, T, nq * hd)
+            x = x + F.linear(o, L["wo"])
+            x = x + self._mlp(L, _rms_norm(x, L["ln2"], cfg.rms_norm_eps))
+        x = _rms_norm(x, w.norm, cfg.rms_norm_eps)
+        flat = x.reshape(R * T, cfg.hidden_size)
+        if logits_rows is not None:
+            flat = flat[logits_rows]
+        return F.linear(flat, w.lm_head)

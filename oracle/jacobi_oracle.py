@@ -73,7 +73,7 @@ def accept_lengths(draft: Rows, greedy: Rows) -> List[int]:
     ``draft`` may have one row broadcast against B greedy rows (MB:482)."""
     B = max(len(draft), len(greedy))
     if len(draft) not in (1, B) or len(greedy) not in (1, B):
-        raise ValueError(f"cannot broadcast draft rows {len(draft)} against greedy rows {len(greedy)}")
+        raise RuntimeError(f"The size of tensor a ({len(draft)}) must match the size of tensor b ({len(greedy)}) at non-singleton dimension 0")
     acc = []
     for b in range(B):
         d = draft[b if len(draft) > 1 else 0]
@@ -176,6 +176,9 @@ class MultiblockOracle:
             return
         new_len = max(0, self.kv_len() - num_false)
         self.kv_rows = [row[:new_len] for row in self.kv_rows]
+
+    def _kv_narrow(self, best_idx: int) -> None:                       # MB:500-502
+        self.kv_rows = [self.kv_rows[best_idx]]
 
     def _kv_resize(self, new_B: int) -> None:                          # MB:93-127
         cur = len(self.kv_rows)
@@ -294,7 +297,7 @@ class MultiblockOracle:
             acc_len_raw = accepted[best_idx]
             draft_row = list(draft[best_idx])                                            # MB:496 (IndexError if rows<=best)
             g = list(greedy[best_idx])
-            self.kv_rows = [self.kv_rows[best_idx]]                                      # MB:500-502
+            self._kv_narrow(best_idx)                                                    # MB:500-502
             L_eff = len(draft_row)
             if L_eff == 0:
                 continue

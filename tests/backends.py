@@ -131,6 +131,38 @@ class HostSimLib:
         return 0
 
 
+    # -- KV cache stand-ins (byte moves; same contracts as jf_kv_append / jf_kv_commit)
+    def jf_kv_append(self, k_cache, v_cache, k_new, v_new, slot, Ntok, H, D, S_max, esz, stream):
+        rowb = D * esz
+        sl = _view(slot, Ntok, np.int64)
+        for dst0, src0 in ((_addr(k_cache), _addr(k_new)), (_addr(v_cache), _addr(v_new))):
+            for i in range(Ntok):
+                s_ = int(sl[i])
+                if s_ < 0:
+                    continue
+                brow, pos = divmod(s_, S_max)
+                for h in range(H):
+                    C.memmove(dst0 + ((brow * H + h) * S_max + pos) * rowb, src0 + (i * H + h) * rowb, rowb)
+        return 0
+
+    def jf_kv_commit(self, main_k, main_v, cand_k, cand_v, layers, desc, P, cand_rows, H, D, S_max, T_max, esz, stream):
+        rowb = D * esz
+        tabs = [_view(t, layers, np.int64) for t in (main_k, main_v, cand_k, cand_v)]
+        d = _view(desc, P * N.DESC_INTS, np.int32).reshape(P, N.DESC_INTS)
+        f = N.DESC_FIELDS.index
+        for p in range(P):
+            ln, src, dst = int(d[p, f("kv_copy_len")]), int(d[p, f("kv_src_row")]), int(d[p, f("kv_copy_dst")])
+            if ln <= 0 or src <= 0:
+                continue
+            crow = p * cand_rows + src - 1
+            for l in range(layers):
+                for mi, ci in ((0, 2), (1, 3)):
+                    for h in range(H):
+                        C.memmove(int(tabs[mi][l]) + ((p * H + h) * S_max + dst) * rowb,
+                                  int(tabs[ci][l]) + ((crow * H + h) * T_max) * rowb, ln * rowb)
+        return 0
+
+
 @contextlib.contextmanager
 def use_backend(name: str):
     """Temporarily install a backend as the library jacobiforcing_amd.ops talks to."""

@@ -1,0 +1,94 @@
+"""bench.py plumbing on the CPU (hostsim backend, tiny model) and the N>1 aggregation path over gloo."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from jacobiforcing_amd import ops
+from jacobiforcing_amd.engine.multiblock_decoder import MultiblockJacobiDecoder
+from jacobiforcing_amd.synthetic import ScriptedAcceptance, humaneval_shaped_prompts
+
+from .backends import use_backend
+from .test_decoder_e2e import tiny_model
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_prompt_shapes():
+    ps = humaneval_shaped_prompts(164, seed=1234)
+    lens = np.array([len(p) for p in ps])
+    assert lens.min() >= 110 and lens.max() <= 620 and 150 < np.median(lens) < 260
+    assert max(max(p) for p in ps) < 151643
+
+
+def test_run_steps_counts_exactly_k_steps():
+    import bench
+    with use_backend("hostsim"):
+        model = tiny_model("cpu", seed=4)
+        V = model.cfg.vocab_size
+        prm = ops.MultiblockParams(n=8, K=2, r=0.85, n_gram_pool_size=4, eos_token_id=None, pad_token_id=V - 2)
+        prompts = [[1, 2, 3, 4, 5, 6, 7], [9, 8, 7, 6, 5]]
+        dec = MultiblockJacobiDecoder(model, 2, prm, max_seq_len=512)
+        r = bench.run_steps(dec, prompts, warmup=3, steps=7, seed=1)
+        assert r["iterations"] == 7 and r["tokens"] >= 7 and r["seconds"] > 0
+        r0 = bench.run_steps(dec, prompts, warmup=0, steps=5, seed=1)
+        assert r0["iterations"] == 5 and r0["tokens"] >= 5
+
+
+def test_scripted_acceptance_raises_tokens_per_forward():
+    """With the synthetic acceptance model the loop accepts several tokens per forward and the output is the
+    scripted target sequence (greedy Jacobi == greedy AR of the hooked model)."""
+    import bench
+    with use_backend("hostsim"):
+        model = tiny_model("cpu", seed=4)
+        V = model.cfg.vocab_size
+        prm = ops.MultiblockParams(n=16, K=2, r=0.85, n_gram_pool_size=4, eos_token_id=None, pad_token_id=V - 2)
+        prompts = [[1, 2, 3, 4, 5, 6, 7], [9, 8, 7, 6, 5], [4, 4, 4]]
+        hook = ScriptedAcceptance(V, robust_pct=80, vocab_hi=V - 2)
+        dec = MultiblockJacobiDecoder(model, 3, prm, max_seq_len=512, logits_hook=hook)
+        stats, _, iters = dec.generate(prompts, max_new_tokens=48, max_calls=8, seed=3)
+        for p, st in enumerate(stats):
+            pos = torch.arange(len(prompts[p]), len(prompts[p]) + len(st.token_ids))
+            tgt = hook.target(pos, torch.full_like(pos, p)).tolist()
+            assert st.token_ids == tgt
+        tpf = sum(len(s.token_ids) for s in stats) / sum(s.total_iterations for s in stats)
+        assert tpf > 2.0
+
+
+_WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, {root!r})
+    import torch
+    from jacobiforcing_amd import distributed as jd
+    info = jd.init_from_env("gloo")
+    prompts = list(range(10))
+    mine = jd.shard_prompts(prompts, info)
+    jd.barrier()
+    agg = jd.gather_throughput(tokens=100.0 * (info.rank + 1), iterations=10.0, seconds=1.0 + info.rank)
+    if info.rank == 0:
+        print(json.dumps(dict(agg=agg, mine=mine, ws=info.world_size)))
+    torch.distributed.destroy_process_group()
+""")
+
+
+def test_two_rank_gloo_aggregation(tmp_path):
+    """world_size-2 over gloo: prompts shard i mod world, tokens/iterations sum, wall time is the max over ranks."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=str(ROOT)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True))
+    outs = [p.communicate(timeout=180) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    d = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert d["ws"] == 2 and d["mine"] == [0, 2, 4, 6, 8]
+    assert d["agg"] == dict(tokens=300.0, iterations=20.0, seconds=2.0, world_size=2)
