@@ -156,10 +156,12 @@ int jf_mb_read_ret(const int32_t *states, int64_t state_ints, int P, int64_t *re
  * or 4-byte element; a "token row" is D elements.  Replaces the Triton store_kvcache_kernel
  * (ATT:10-40), DynamicCache narrow/expand/contiguous (MB:93-127, 500-502) and trims (MB:36-59).
  */
-/* scatter freshly computed K/V [N, H_kv, D] into cache slots: dst token index slot[i] (-1 = skip) */
+/* scatter freshly computed K/V rows into cache slots: token i goes to slot[i] = row * S_max + position
+ * (-1 = skip).  Sources are [N, H_kv, D] views whose token stride is k_tok_stride / v_tok_stride ELEMENTS (heads
+ * and D contiguous), so K and V can be read straight out of a fused QKV projection without a copy. */
 int jf_kv_append(void *k_cache, void *v_cache, const void *k_new, const void *v_new,
                  const int64_t *slot, int64_t N, int32_t H_kv, int32_t D, int64_t S_max,
-                 int32_t elem_bytes, void *stream);
+                 int64_t k_tok_stride, int64_t v_tok_stride, int32_t elem_bytes, void *stream);
 
 /* commit accepted candidate rows: for prompt p copy desc[p].kv_copy_len token rows from the
  * candidate scratch cand[(p*cand_rows + kv_src_row-1), :, 0:len] to main[p, :, kv_copy_dst: +len],

@@ -543,7 +543,8 @@ extern "C" int jf_mb_read_ret(const int32_t *states, int64_t state_ints, int P, 
 __global__ __launch_bounds__(256) void kv_append_kernel(uint4 *__restrict__ k_cache, uint4 *__restrict__ v_cache,
                                                          const uint4 *__restrict__ k_new, const uint4 *__restrict__ v_new,
                                                          const int64_t *__restrict__ slot, int64_t N, int H_kv,
-                                                         int vec_per_row, int64_t S_max) {
+                                                         int vec_per_row, int64_t S_max, int64_t k_tok_vecs,
+                                                         int64_t v_tok_vecs) {
     // one (token, head) row per vec_per_row lanes
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t rowid = gid / vec_per_row;
@@ -555,21 +556,26 @@ __global__ __launch_bounds__(256) void kv_append_kernel(uint4 *__restrict__ k_ca
     if (sl < 0) return;                                   // ATT:24 (slot == -1 skipped)
     const int64_t brow = sl / S_max, pos = sl - brow * S_max;
     const int64_t dst = ((brow * H_kv + h) * S_max + pos) * vec_per_row + lane;
-    const int64_t src = rowid * vec_per_row + lane;
-    k_cache[dst] = k_new[src];
-    v_cache[dst] = v_new[src];
+    const int64_t hoff = (int64_t)h * vec_per_row + lane;
+    k_cache[dst] = k_new[tok * k_tok_vecs + hoff];
+    v_cache[dst] = v_new[tok * v_tok_vecs + hoff];
 }
 
 extern "C" int jf_kv_append(void *k_cache, void *v_cache, const void *k_new, const void *v_new, const int64_t *slot, int64_t N,
-                            int32_t H_kv, int32_t D, int64_t S_max, int32_t elem_bytes, void *stream) {
+                            int32_t H_kv, int32_t D, int64_t S_max, int64_t k_tok_stride, int64_t v_tok_stride,
+                            int32_t elem_bytes, void *stream) {
     if (N <= 0) return JF_OK;
     if (!k_cache || !v_cache || !k_new || !v_new || !slot) return fail(JF_E_INVALID, "jf_kv_append: null pointer");
     const int64_t row_bytes = (int64_t)D * elem_bytes;
     if (row_bytes % 16 != 0 || H_kv <= 0 || S_max <= 0) return fail(JF_E_INVALID, "jf_kv_append: row bytes %lld not /16", (long long)row_bytes);
+    if ((k_tok_stride * elem_bytes) % 16 != 0 || (v_tok_stride * elem_bytes) % 16 != 0 || k_tok_stride < (int64_t)H_kv * D ||
+        v_tok_stride < (int64_t)H_kv * D || ((uintptr_t)k_new) % 16 != 0 || ((uintptr_t)v_new) % 16 != 0)
+        return fail(JF_E_INVALID, "jf_kv_append: source strides/pointers must be 16-byte aligned and >= H_kv*D");
     const int vpr = (int)(row_bytes / 16);
     const int64_t threads = N * H_kv * vpr;
     kv_append_kernel<<<dim3((unsigned)((threads + 255) / 256)), 256, 0, (hipStream_t)stream>>>(
-        (uint4 *)k_cache, (uint4 *)v_cache, (const uint4 *)k_new, (const uint4 *)v_new, slot, N, H_kv, vpr, S_max);
+        (uint4 *)k_cache, (uint4 *)v_cache, (const uint4 *)k_new, (const uint4 *)v_new, slot, N, H_kv, vpr, S_max,
+        k_tok_stride * elem_bytes / 16, v_tok_stride * elem_bytes / 16);
     return check_launch("kv_append_kernel");
 }
 

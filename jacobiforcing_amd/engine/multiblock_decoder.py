@@ -121,8 +121,9 @@ class MultiblockJacobiDecoder:
         else:
             row_cand = torch.full((R,), -1, dtype=torch.int32, device=dev)
         kv_rows = self.cache.kv_len[row_prompt.long()]
+        s_cur = int(self.kv_len_host[B > 0].max()) + ids.shape[1]
         logits = self.model.forward(ids, pos, self.cache, row_prompt=row_prompt, row_cand=row_cand, row_len=row_len,
-                                    kv_len_rows=kv_rows, any_candidates=any_cand)
+                                    kv_len_rows=kv_rows, any_candidates=any_cand, s_cur=s_cur)
         if self.logits_hook is not None:
             logits = self.logits_hook(logits, self, prefill=None)
         self.forwards += 1

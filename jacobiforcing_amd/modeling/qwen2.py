@@ -70,12 +70,6 @@ class Qwen2Config:
                    pad_token_id=d.get("pad_token_id") or 151643)
 
 
-def _rms_norm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
-    xf = x.float()
-    xf = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
-    return (xf.to(x.dtype)) * w
-
-
 class Qwen2Weights:
     """Flat weight container (fused QKV and gate/up so each layer is 4 GEMMs)."""
 
@@ -157,82 +151,91 @@ class Qwen2Model:
         self.sin = fr.sin()
 
     # -- pieces -----------------------------------------------------------------------------
-    def _rope(self, x: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
-        """x [R, T, heads, hd]; pos [R, T] -> rotate-half RoPE (HF convention)."""
-        cos = self.cos[pos].unsqueeze(2)
-        sin = self.sin[pos].unsqueeze(2)
-        x1, x2 = x[..., : x.shape[-1] // 2].float(), x[..., x.shape[-1] // 2:].float()
-        return torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], dim=-1).to(x.dtype)
+    def _norm(self, x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+        return F.rms_norm(x, (x.shape[-1],), w, self.cfg.rms_norm_eps)
+
+    @staticmethod
+    def _rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+        """x [R, T, heads, hd]; cos/sin [R, T, 1, hd/2] in x's dtype -> rotate-half RoPE (HF convention)."""
+        h = x.shape[-1] // 2
+        x1, x2 = x[..., :h], x[..., h:]
+        return torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], dim=-1)
 
     def _mlp(self, L, x):
-        gu = F.linear(x, L["wgu"])
-        g, u = gu.chunk(2, dim=-1)
+        g, u = F.linear(x, L["wgu"]).chunk(2, dim=-1)
         return F.linear(F.silu(g) * u, L["wd"])
 
     # -- forward over a static cache -------------------------------------------------------------
     @torch.inference_mode()
     def forward(self, input_ids: torch.Tensor, positions: torch.Tensor, cache: StaticKVCache,
                 row_prompt: torch.Tensor, row_cand: torch.Tensor, row_len: torch.Tensor,
-                kv_len_rows: torch.Tensor, any_candidates: bool, logits_rows: Optional[slice] = None) -> torch.Tensor:
+                kv_len_rows: torch.Tensor, any_candidates: bool, logits_rows: Optional[slice] = None,
+                s_cur: Optional[int] = None) -> torch.Tensor:
         """One forward over R rows of (padded) length T.
 
         input_ids [R,T] int64, positions [R,T] int32 (= kv_len + t), row_prompt [R] (cache row of the prefix),
         row_cand [R] (-1: the row writes into the main cache, else index into the candidate scratch),
-        row_len [R] valid tokens per row, kv_len_rows [R] committed prefix length per row.
-        Returns logits [R, T, V] in the weight dtype (or only ``logits_rows`` of the flattened [R*T])."""
+        row_len [R] valid tokens per row, kv_len_rows [R] committed prefix length per row, s_cur = max(kv_len)+T when the
+        caller knows it (saves a device read).  Returns logits [R*T, V] in the weight dtype (or ``logits_rows`` of it)."""
         cfg, w = self.cfg, self.w
         R, T = input_ids.shape
         nq, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         G = nq // nkv
         dev = self.device
         pos = positions.long()
-        S_cur = int(kv_len_rows.max().item()) + T if R else T     # one host read per forward (shape of the key axis)
-        S_cur = min(S_cur, cache.S_max)
+        if s_cur is None:
+            s_cur = (int(kv_len_rows.max().item()) + T) if R else T
+        S_cur = min(int(s_cur), cache.S_max)
         ar_t = torch.arange(T, device=dev)
         ar_s = torch.arange(S_cur, device=dev)
         kvl = kv_len_rows.long()
+        rlen = row_len.long()
         rel = ar_s.view(1, 1, S_cur) - kvl.view(R, 1, 1)                            # key index relative to the new block
-        mask = (rel < 0) | ((rel <= ar_t.view(1, T, 1)) & (rel < row_len.long().view(R, 1, 1)))
+        mask = (rel < 0) | ((rel <= ar_t.view(1, T, 1)) & (rel < rlen.view(R, 1, 1)))
         mask = mask.view(R, 1, 1, T, S_cur).expand(R, 1, G, T, S_cur).reshape(R, 1, G * T, S_cur)
         # slots of the freshly computed K/V rows
-        valid = ar_t.view(1, T) < row_len.long().view(R, 1)
+        valid = ar_t.view(1, T) < rlen.view(R, 1)
         main_rows = row_cand < 0
-        slot_main = torch.where(valid & main_rows.view(R, 1), row_prompt.long().view(R, 1) * cache.S_max + pos,
-                                torch.full_like(pos, -1)).reshape(-1)
-        slot_cand = torch.where(valid & (~main_rows).view(R, 1), row_cand.long().view(R, 1) * cache.T_max + ar_t.view(1, T),
-                                torch.full_like(pos, -1)).reshape(-1) if any_candidates else None
+        neg = torch.full_like(pos, -1)
+        slot_main = torch.where(valid & main_rows.view(R, 1), row_prompt.long().view(R, 1) * cache.S_max + pos, neg).reshape(-1)
         rp = row_prompt.long()
+        if any_candidates:
+            slot_cand = torch.where(valid & (~main_rows).view(R, 1), row_cand.long().view(R, 1) * cache.T_max + ar_t.view(1, T),
+                                    neg).reshape(-1)
+            cr = (~main_rows).nonzero(as_tuple=True)[0]
+            if cr.numel():
+                tail_idx = (kvl[cr].view(-1, 1) + ar_t.view(1, T)).clamp_(max=S_cur - 1)          # [C,T]
+                tail_idx = tail_idx.view(-1, 1, T, 1).expand(-1, nkv, T, hd)
+                crc = row_cand[cr].long()
+        cos = self.cos[pos].to(self.dtype).unsqueeze(2)                               # [R,T,1,hd/2], shared by all layers
+        sin = self.sin[pos].to(self.dtype).unsqueeze(2)
+        direct = (not any_candidates) and R == cache.P                               # row r is prompt r: attend in place
 
         x = w.embed[input_ids]                                                        # [R,T,H]
         for li, L in enumerate(w.layers):
-            h = _rms_norm(x, L["ln1"], cfg.rms_norm_eps)
-            qkv = F.linear(h, L["wqkv"], L["bqkv"]).view(R, T, nq + 2 * nkv, hd)
-            q = self._rope(qkv[:, :, :nq], pos)
-            k = self._rope(qkv[:, :, nq:nq + nkv], pos).reshape(R * T, nkv, hd).contiguous()
-            v = qkv[:, :, nq + nkv:].reshape(R * T, nkv, hd).contiguous()
+            qkv = F.linear(self._norm(x, L["ln1"]), L["wqkv"], L["bqkv"]).view(R, T, nq + 2 * nkv, hd)
+            qk = self._rope(qkv[:, :, :nq + nkv], cos, sin)                           # q and k in one pass
+            k = qk.view(R * T, nq + nkv, hd)[:, nq:]
+            v = qkv.view(R * T, nq + 2 * nkv, hd)[:, nq + nkv:]
             ops.kv_append(cache.k[li], cache.v[li], k, v, slot_main)                  # a18: append (row 0 of each prompt)
             if any_candidates:
                 ops.kv_append(cache.ck[li], cache.cv[li], k, v, slot_cand)
-                Kf = cache.k[li][rp, :, :S_cur].clone()                               # [R,nkv,S,hd] prefix (+ row-0 tail)
-                Vf = cache.v[li][rp, :, :S_cur].clone()
-                cr = (~main_rows).nonzero(as_tuple=True)[0]
+                Kf = cache.k[li][rp, :, :S_cur]                                       # [R,nkv,S,hd] gathered prefix (+ row-0 tail)
+                Vf = cache.v[li][rp, :, :S_cur]
                 if cr.numel():
                     # candidate rows see their own speculative tail instead of row 0's
-                    tail_idx = (kvl[cr].view(-1, 1) + ar_t.view(1, T)).clamp_(max=S_cur - 1)   # [C,T]
-                    ck = cache.ck[li][row_cand[cr].long(), :, :T]                      # [C,nkv,T,hd]
-                    cv = cache.cv[li][row_cand[cr].long(), :, :T]
-                    idx = tail_idx.view(-1, 1, T, 1).expand(-1, nkv, T, hd)
-                    Kf[cr] = Kf[cr].scatter(2, idx, ck)
-                    Vf[cr] = Vf[cr].scatter(2, idx, cv)
+                    Kf[cr] = Kf[cr].scatter(2, tail_idx, cache.ck[li][crc, :, :T])
+                    Vf[cr] = Vf[cr].scatter(2, tail_idx, cache.cv[li][crc, :, :T])
+            elif direct:
+                Kf, Vf = cache.k[li][:, :, :S_cur], cache.v[li][:, :, :S_cur]
             else:
-                Kf = cache.k[li][:, :, :S_cur] if R == cache.P else cache.k[li][rp, :, :S_cur]
-                Vf = cache.v[li][:, :, :S_cur] if R == cache.P else cache.v[li][rp, :, :S_cur]
-            qh = q.view(R, T, nkv, G, hd).permute(0, 2, 3, 1, 4).reshape(R, nkv, G * T, hd)
+                Kf, Vf = cache.k[li][rp, :, :S_cur], cache.v[li][rp, :, :S_cur]
+            qh = qk[:, :, :nq].view(R, T, nkv, G, hd).permute(0, 2, 3, 1, 4).reshape(R, nkv, G * T, hd)
             o = F.scaled_dot_product_attention(qh, Kf, Vf, attn_mask=mask)
             o = o.view(R, nkv, G, T, hd).permute(0, 3, 1, 2, 4).reshape(R, T, nq * hd)
             x = x + F.linear(o, L["wo"])
-            x = x + self._mlp(L, _rms_norm(x, L["ln2"], cfg.rms_norm_eps))
-        x = _rms_norm(x, w.norm, cfg.rms_norm_eps)
+            x = x + self._mlp(L, self._norm(x, L["ln2"]))
+        x = self._norm(x, w.norm)
         flat = x.reshape(R * T, cfg.hidden_size)
         if logits_rows is not None:
             flat = flat[logits_rows]

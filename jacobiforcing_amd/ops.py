@@ -217,15 +217,21 @@ class MultiblockBatch:
 # --------------------------------------------------------------------------------------------
 def kv_append(k_cache: torch.Tensor, v_cache: torch.Tensor, k_new: torch.Tensor, v_new: torch.Tensor,
               slot: torch.Tensor) -> None:
-    """cache [rows, H_kv, S_max, D]; new [N, H_kv, D]; slot[i] = row * S_max + position (-1 skips) (ATT:10-40)."""
+    """cache [rows, H_kv, S_max, D]; new [N, H_kv, D] (token stride free, heads/D contiguous); slot[i] = row * S_max +
+    position (-1 skips) (ATT:10-40)."""
     rows, H, S_max, D = k_cache.shape
     Ntok = k_new.shape[0]
-    if not (k_cache.is_contiguous() and v_cache.is_contiguous() and k_new.is_contiguous() and v_new.is_contiguous()):
-        raise ValueError("kv_append expects contiguous tensors")
-    if tuple(k_new.shape) != (Ntok, H, D) or slot.numel() != Ntok or slot.dtype != torch.int64:
-        raise ValueError("kv_append: shape/dtype mismatch")
+    if not (k_cache.is_contiguous() and v_cache.is_contiguous()):
+        raise ValueError("kv_append expects contiguous caches")
+    for t in (k_new, v_new):
+        if tuple(t.shape) != (Ntok, H, D) or t.stride(2) != 1 or t.stride(1) != D:
+            raise ValueError("kv_append: sources must be [N, H_kv, D] with contiguous heads")
+    if slot.numel() != Ntok or slot.dtype != torch.int64:
+        raise ValueError("kv_append: slot must be int64 [N]")
+    ks = k_new.stride(0) if Ntok > 1 else H * D
+    vs = v_new.stride(0) if Ntok > 1 else H * D
     N.check(N.lib().jf_kv_append(_ptr(k_cache), _ptr(v_cache), _ptr(k_new), _ptr(v_new), _ptr(slot), Ntok, H, D, S_max,
-                                 k_cache.element_size(), _stream(k_cache.device)), "jf_kv_append")
+                                 ks, vs, k_cache.element_size(), _stream(k_cache.device)), "jf_kv_append")
 
 
 class KVCommitter:

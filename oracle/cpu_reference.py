@@ -137,10 +137,16 @@ class _Hooked(O.MultiblockOracle):
         self.cache.narrow_row(best_idx)
 
 
-def cpu_multiblock_call(model: CpuQwen2, cache: CpuCache, input_ids, kv_tokens, **kw):
-    """One generation call (MB:227-740) on the CPU.  Returns the oracle state (ret, next_token, iters)."""
+def cpu_multiblock_call(model: CpuQwen2, cache: CpuCache, input_ids, kv_tokens, deadline: Optional[float] = None, **kw):
+    """One generation call (MB:227-740) on the CPU.  Returns the oracle state (ret, next_token, iters).  With a
+    ``deadline`` (perf_counter seconds) the call is abandoned between iterations once it is passed; ``st.partial``
+    then holds the tokens the real-active block had accepted so far (bounded CPU sample for bench.py)."""
     st = _Hooked(input_ids, kv_tokens, cache=cache, **kw)
+    st.partial = None
     while True:
+        if deadline is not None and time.perf_counter() > deadline:
+            st.partial = sum(len(a) for b, a in enumerate(st.out_acc) if not st.need_reverify[b])
+            return st
         step = st.begin_iteration()
         if step is None:
             break
@@ -174,8 +180,13 @@ def timed_tokens_per_second(model: CpuQwen2, prompt: List[int], rng, *, n, K, r,
     t0 = time.perf_counter()
     tokens = iters = calls = 0
     while time.perf_counter() - t0 < budget_s and calls < max_calls:
-        st = cpu_multiblock_call(model, cache, inp, kv, n=n, K=K, r=r, n_gram_pool_size=pool, eos_token_id=eos,
-                                 pad_token_id=pad)
+        st = cpu_multiblock_call(model, cache, inp, kv, deadline=t0 + budget_s, n=n, K=K, r=r, n_gram_pool_size=pool,
+                                 eos_token_id=eos, pad_token_id=pad)
+        if st.partial is not None:                 # budget hit inside a call: count what was accepted so far
+            tokens += st.partial
+            iters += st.iters
+            calls += 1
+            break
         kv = st.kv_tokens
         text += st.ret
         tokens += len(st.ret)

@@ -132,17 +132,17 @@ class HostSimLib:
 
 
     # -- KV cache stand-ins (byte moves; same contracts as jf_kv_append / jf_kv_commit)
-    def jf_kv_append(self, k_cache, v_cache, k_new, v_new, slot, Ntok, H, D, S_max, esz, stream):
+    def jf_kv_append(self, k_cache, v_cache, k_new, v_new, slot, Ntok, H, D, S_max, ks, vs, esz, stream):
         rowb = D * esz
         sl = _view(slot, Ntok, np.int64)
-        for dst0, src0 in ((_addr(k_cache), _addr(k_new)), (_addr(v_cache), _addr(v_new))):
+        for dst0, src0, tstride in ((_addr(k_cache), _addr(k_new), ks), (_addr(v_cache), _addr(v_new), vs)):
             for i in range(Ntok):
                 s_ = int(sl[i])
                 if s_ < 0:
                     continue
                 brow, pos = divmod(s_, S_max)
                 for h in range(H):
-                    C.memmove(dst0 + ((brow * H + h) * S_max + pos) * rowb, src0 + (i * H + h) * rowb, rowb)
+                    C.memmove(dst0 + ((brow * H + h) * S_max + pos) * rowb, src0 + (i * tstride + h * D) * esz, rowb)
         return 0
 
     def jf_kv_commit(self, main_k, main_v, cand_k, cand_v, layers, desc, P, cand_rows, H, D, S_max, T_max, esz, stream):
