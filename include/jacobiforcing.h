@@ -193,25 +193,43 @@ int jf_engine_step(const int64_t *draft, int B, int L, uint64_t *packed, int32_t
                    jf_engine_row *rows, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Non-greedy verify (a19): fused softmax-gather + argmax over logits [R, V] read once.
- * For row r: p_draft[r] = softmax(logits[r] / T)[draft_next[r]] in fp32 (JDN:65-70, 328),
- * row max / sum-exp (for residual sampling) and the packed argmax (JDN:446, 619).
+ * Non-greedy verify (a19), JDN = inference_engine/engine/jacobi_decoding_nongreedy.py.
+ *
+ * jf_rs_probs: fused softmax-gather + argmax over logits [R, V] read once.  For row r:
+ *   p_draft[r] = softmax(logits[r] / T)[draft_next[r]] in fp32 (JDN:65-70, 328), row max and sum-exp (for the
+ *   residual sampling) and the packed argmax (next draft, JDN:446/619).  packed must be zero on entry.
  */
 int jf_rs_probs(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride,
                 const int64_t *draft_next, float temperature, float *p_draft, float *row_max,
-                float *row_sumexp, uint64_t *packed, void *workspace, size_t workspace_bytes,
-                void *stream);
-size_t jf_rs_workspace_bytes(int64_t R, int64_t V);
+                float *row_sumexp, uint64_t *packed, void *stream);
 
-/* sequential accept/reject of one block (JDN:326-348) with injected uniforms u[L-1]; on the
- * first rejection position the bonus token is drawn by inverse CDF from softmax(logits[row]/T)
- * with bonus_u[16] retries != proposed (JDN:135-153).  result [4] int32: n_committed, eos,
- * reject_pos (-1 none), n_bonus_draws; committed [L-1] int64.
+typedef struct jf_rs_row {
+    int32_t n_committed;   /* tokens committed (accepted drafts + bonus), >= 1          */
+    int32_t eos;           /* EOS committed                                              */
+    int32_t reject_pos;    /* first rejected position, -1 = whole block accepted         */
+    int32_t n_bonus_draws; /* residual-sampling draws used (<= 16)                        */
+    int32_t n_uniforms;    /* accept/reject uniforms consumed                             */
+    int32_t n_pads;        /* random pads consumed by the next draft                      */
+    int32_t active_next;   /* row keeps decoding                                          */
+    int32_t rsv;
+} jf_rs_row;
+
+/* jf_rs_step: the sequential accept/reject of every row of a batch (JDN:581-639) in one launch.
+ *   draft [B, L]; logits [B*(L-1), V]; p_draft/row_max/row_sumexp/packed [B*(L-1)] from jf_rs_probs.
+ *   Position t of row b is accepted iff u < p_draft (JDN:328-340); on the first rejection a bonus token != proposed is
+ *   drawn by inverse CDF of softmax(logits/T) (float64 running sum in vocabulary order) with up to 16 draws
+ *   (JDN:135-146), then argmax of the masked distribution (JDN:147-153).  Randomness is injected: u_stream /
+ *   bonus_stream (floats in [0,1)) and pad_stream (token ids) are consumed cyclically from *cursor in row order,
+ *   exactly where the reference calls torch.rand / torch.multinomial / torch.randint.
+ *   committed [B, L], next_draft [B, L] (JDN:444-466), rows [B].  packed is re-zeroed.
  */
-int jf_rs_accept(const void *logits, int dtype, int64_t V, int64_t row_stride, const int64_t *draft,
-                 int L, const float *p_draft, const float *row_max, const float *row_sumexp,
-                 float temperature, const float *u, const float *bonus_u, int32_t eos_id,
-                 int64_t *committed, int32_t *result, void *stream);
+int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_stride, const int64_t *draft, int B, int L,
+               const float *p_draft, const float *row_max, const float *row_sumexp, uint64_t *packed,
+               float temperature, int32_t eos_id, const int32_t *remaining_tokens,
+               const float *u_stream, int64_t u_len, int64_t *u_cursor,
+               const float *bonus_stream, int64_t bonus_len, int64_t *bonus_cursor,
+               const int64_t *pad_stream, int64_t pad_len, int64_t *pad_cursor,
+               int64_t *committed, int64_t *next_draft, jf_rs_row *rows, void *stream);
 
 #ifdef __cplusplus
 }

@@ -42,6 +42,15 @@ class EngineRow(C.Structure):
 
 ENGINE_ROW_INTS = C.sizeof(EngineRow) // 4
 
+
+class RsRow(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("n_committed", "eos", "reject_pos", "n_bonus_draws", "n_uniforms", "n_pads",
+                                         "active_next", "rsv")]
+
+
+RS_ROW_INTS = C.sizeof(RsRow) // 4
+RS_FIELDS = [f[0] for f in RsRow._fields_]
+
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
 _SIGNATURES = {
@@ -61,9 +70,9 @@ _SIGNATURES = {
     "jf_kv_append": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i32, _vp]),
     "jf_kv_commit": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, C.c_int, _i32, _i32, _i32, _i64, _i64, _i32, _vp]),
     "jf_engine_step": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
-    "jf_rs_probs": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "jf_rs_workspace_bytes": (_sz, [_i64, _i64]),
-    "jf_rs_accept": (C.c_int, [_vp, C.c_int, _i64, _i64, _vp, C.c_int, _vp, _vp, _vp, _f32, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "jf_rs_probs": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _vp, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "jf_rs_step": (C.c_int, [_vp, C.c_int, _i64, _i64, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _f32, _i32, _vp,
+                             _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

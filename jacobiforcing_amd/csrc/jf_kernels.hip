@@ -680,10 +680,10 @@ __device__ __forceinline__ float load_f(const void *row, int64_t i) {
     else return __uint_as_float(((uint32_t)((const uint16_t *)row)[i]) << 16);
 }
 
-// one workgroup per row: running (max, sum exp((x-max)/T)) per lane, merged by shuffles.
+// one workgroup per row: running (max, sum exp(x/T - max)) per lane, merged through LDS.
 template <int DT>
 __global__ __launch_bounds__(256) void rs_probs_kernel(const void *logits, int64_t R, int64_t V, int64_t row_stride,
-                                                        const int64_t *draft_next, float inv_temp, float *p_draft,
+                                                        const int64_t *draft_next, float temp, float *p_draft,
                                                         float *row_max, float *row_sumexp, unsigned long long *packed) {
     using E = Elem<DT>;
     const int64_t row = blockIdx.x;
@@ -692,15 +692,12 @@ __global__ __launch_bounds__(256) void rs_probs_kernel(const void *logits, int64
     float m = -INFINITY, s = 0.f;
     uint32_t best = 0u, bidx = 0xFFFFFFFFu;
     for (int64_t i = tid; i < V; i += 256) {
-        const float x = load_f<DT>(p, i) * inv_temp;
-        uint32_t k;
-        if constexpr (DT == JF_F32) k = order_key(((const uint32_t *)p)[i]);
-        else k = order_key(((uint32_t)((const uint16_t *)p)[i]) << 16);
+        const float x = load_f<DT>(p, i) / temp;
+        const uint32_t k = load_key<DT>(p, i);
         if (k > best) { best = k; bidx = (uint32_t)i; }
         if (x > m) { s = s * expf(m - x) + 1.f; m = x; }
         else s += expf(x - m);
     }
-    // merge (m, s) across the workgroup
     __shared__ float sm[256], ss[256];
     __shared__ uint64_t sp[4];
     sm[tid] = m; ss[tid] = s;
@@ -716,124 +713,186 @@ __global__ __launch_bounds__(256) void rs_probs_kernel(const void *logits, int64
         row_sumexp[row] = Ssum;
         const int64_t tok = draft_next[row];
         float pd = 0.f;
-        if (tok >= 0 && tok < V) pd = expf(load_f<DT>(p, tok) * inv_temp - M) / Ssum;
+        if (tok >= 0 && tok < V) pd = expf(load_f<DT>(p, tok) / temp - M) / Ssum;
         p_draft[row] = pd;
         uint64_t mm = sp[0];
         for (int w = 1; w < 4; ++w) mm = sp[w] > mm ? sp[w] : mm;
-        packed[row] = mm;
+        atomicMax(packed + row, (unsigned long long)mm);
     }
 }
 
-extern "C" size_t jf_rs_workspace_bytes(int64_t R, int64_t V) { (void)R; (void)V; return 0; }
-
 extern "C" int jf_rs_probs(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, const int64_t *draft_next,
                            float temperature, float *p_draft, float *row_max, float *row_sumexp, uint64_t *packed,
-                           void *workspace, size_t workspace_bytes, void *stream) {
-    (void)workspace; (void)workspace_bytes;
+                           void *stream) {
     if (R <= 0) return JF_OK;
     if (!logits || !draft_next || !p_draft || !row_max || !row_sumexp || !packed) return fail(JF_E_INVALID, "jf_rs_probs: null pointer");
     if (dtype != JF_F32 && dtype != JF_BF16) return fail(JF_E_INVALID, "jf_rs_probs: dtype %d", dtype);
     const float t = (temperature <= 0.f) ? 1.f : temperature;    // JDN:66-67
-    const float inv = 1.f / t;
     if (dtype == JF_F32)
-        rs_probs_kernel<JF_F32><<<dim3((unsigned)R), 256, 0, (hipStream_t)stream>>>(logits, R, V, row_stride, draft_next, inv, p_draft, row_max, row_sumexp, (unsigned long long *)packed);
+        rs_probs_kernel<JF_F32><<<dim3((unsigned)R), 256, 0, (hipStream_t)stream>>>(logits, R, V, row_stride, draft_next, t, p_draft, row_max, row_sumexp, (unsigned long long *)packed);
     else
-        rs_probs_kernel<JF_BF16><<<dim3((unsigned)R), 256, 0, (hipStream_t)stream>>>(logits, R, V, row_stride, draft_next, inv, p_draft, row_max, row_sumexp, (unsigned long long *)packed);
+        rs_probs_kernel<JF_BF16><<<dim3((unsigned)R), 256, 0, (hipStream_t)stream>>>(logits, R, V, row_stride, draft_next, t, p_draft, row_max, row_sumexp, (unsigned long long *)packed);
     return check_launch("rs_probs_kernel");
 }
 
-// sequential accept/reject of one block + inverse-CDF bonus draw on the rejected row
+// Sequential accept/reject over the rows of a batch (JDN:581-639) in ONE launch: rows are visited in order so the
+// injected uniform / bonus / pad streams are consumed exactly like the reference consumes torch.rand / multinomial /
+// randint; the only wide work — inverse-CDF sampling of the bonus token on a rejected position — uses all 256 threads.
 template <int DT>
-__global__ __launch_bounds__(256) void rs_accept_kernel(const void *logits, int64_t V, int64_t row_stride, const int64_t *draft,
-                                                         int L, const float *p_draft, const float *row_max,
-                                                         const float *row_sumexp, float inv_temp, const float *u,
-                                                         const float *bonus_u, int eos_id, int64_t *committed, int32_t *result) {
-    __shared__ int s_n, s_eos, s_rej, s_pick;
+__global__ __launch_bounds__(256) void rs_step_kernel(const void *logits, int64_t V, int64_t row_stride, const int64_t *draft,
+                                                       int B, int L, const float *p_draft, const float *row_max,
+                                                       const float *row_sumexp, unsigned long long *packed, float temp,
+                                                       int eos_id, const int32_t *remaining, const float *u_stream,
+                                                       int64_t u_len, int64_t *u_cursor, const float *b_stream, int64_t b_len,
+                                                       int64_t *b_cursor, const int64_t *pad_stream, int64_t pad_len,
+                                                       int64_t *pad_cursor, int64_t *committed, int64_t *next_draft,
+                                                       jf_rs_row *rows) {
+    __shared__ int s_n, s_eos, s_rej, s_pick, s_used;
     __shared__ double s_sum[256], s_pre[256];
     __shared__ double s_total;
+    __shared__ uint64_t s_best[4];
+    __shared__ int64_t s_uc, s_bc, s_pc;
     const int tid = threadIdx.x;
-    if (tid == 0) {
-        int n = 0, eos = 0, rej = -1;
-        for (int t = 0; t < L - 1; ++t) {                          // JDN:326-348
-            const int64_t proposed = draft[t + 1];
-            if (u[t] < p_draft[t]) {
-                committed[n++] = proposed;
-                if (eos_id >= 0 && proposed == eos_id) { eos = 1; break; }
-                continue;
-            }
-            rej = t;
-            break;
-        }
-        s_n = n; s_eos = eos; s_rej = rej;
-    }
+    if (tid == 0) { s_uc = *u_cursor; s_bc = *b_cursor; s_pc = *pad_cursor; }
     __syncthreads();
-    const int rej = s_rej;
-    int draws = 0;
-    if (rej >= 0) {
-        // residual sampling (JDN:135-153): inverse CDF over p = exp(x/T - M)/S in vocabulary order with a
-        // float64 running sum; each thread owns a contiguous slice, so the scan is two-level.
-        const void *row = (const char *)logits + (int64_t)rej * row_stride * (DT == JF_F32 ? 4 : 2);
-        const float M = row_max[rej], Sx = row_sumexp[rej];
-        const int64_t per = (V + 255) / 256;
-        const int64_t lo = (int64_t)tid * per < V ? (int64_t)tid * per : V;
-        const int64_t hi = (lo + per < V) ? lo + per : V;
-        double acc = 0.0;
-        for (int64_t i = lo; i < hi; ++i) acc += (double)(expf(load_f<DT>(row, i) * inv_temp - M) / Sx);
-        s_sum[tid] = acc;
-        __syncthreads();
+    for (int b = 0; b < B; ++b) {
+        const int64_t *d = draft + (int64_t)b * L;
+        int64_t *cm = committed + (int64_t)b * L;
+        const int64_t r0 = (int64_t)b * (L - 1);
         if (tid == 0) {
-            double run = 0.0;
-            for (int i = 0; i < 256; ++i) { s_pre[i] = run; run += s_sum[i]; }
-            s_total = run;
+            int n = 0, eos = 0, rej = -1, used = 0;
+            for (int t = 0; t < L - 1; ++t) {                      // JDN:326-348
+                const int64_t proposed = d[t + 1];
+                const float u = u_stream[(s_uc + used) % u_len];
+                used++;
+                if (u < p_draft[r0 + t]) {
+                    cm[n++] = proposed;
+                    if (eos_id >= 0 && proposed == eos_id) { eos = 1; break; }
+                    continue;
+                }
+                rej = t;
+                break;
+            }
+            s_n = n; s_eos = eos; s_rej = rej; s_used = used;
+            s_uc += used;
         }
         __syncthreads();
-        const int64_t proposed = draft[rej + 1];
-        int bonus = -1;
-        for (int tr = 0; tr < 16 && bonus < 0; ++tr) {
-            const double thr = (double)bonus_u[tr] * s_total;
-            if (tid == 0) s_pick = (int)(V - 1);                   // clamp when thr >= total
+        const int rej = s_rej;
+        int draws = 0;
+        if (rej >= 0) {
+            // residual sampling (JDN:135-153): inverse CDF over p = exp(x/T - M)/S in vocabulary order with a float64
+            // running sum; each thread owns a contiguous slice, so the scan is two-level.
+            const void *row = (const char *)logits + (r0 + rej) * row_stride * (DT == JF_F32 ? 4 : 2);
+            const float M = row_max[r0 + rej], Sx = row_sumexp[r0 + rej];
+            const int64_t per = (V + 255) / 256;
+            const int64_t lo = (int64_t)tid * per < V ? (int64_t)tid * per : V;
+            const int64_t hi = (lo + per < V) ? lo + per : V;
+            double acc = 0.0;
+            for (int64_t i = lo; i < hi; ++i) acc += (double)(expf(load_f<DT>(row, i) / temp - M) / Sx);
+            s_sum[tid] = acc;
             __syncthreads();
-            const double pre = s_pre[tid];
-            if (hi > lo && thr >= pre && thr < pre + acc) {        // exactly one slice owns thr
-                double run = pre;
-                int64_t pick = hi - 1;
-                for (int64_t i = lo; i < hi; ++i) {
-                    run += (double)(expf(load_f<DT>(row, i) * inv_temp - M) / Sx);
-                    if (run > thr) { pick = i; break; }
-                }
-                s_pick = (int)pick;
+            if (tid == 0) {
+                double run = 0.0;
+                for (int i = 0; i < 256; ++i) { s_pre[i] = run; run += s_sum[i]; }
+                s_total = run;
             }
             __syncthreads();
-            draws++;
-            if ((int64_t)s_pick != proposed) bonus = s_pick;
+            const int64_t proposed = d[rej + 1];
+            int bonus = -1;
+            for (int tr = 0; tr < 16 && bonus < 0; ++tr) {
+                const double thr = (double)b_stream[(s_bc + tr) % b_len] * s_total;
+                if (tid == 0) s_pick = (int)(V - 1);               // clamp when thr >= total
+                __syncthreads();
+                const double pre = s_pre[tid];
+                if (hi > lo && thr >= pre && thr < pre + acc) {    // exactly one slice owns thr
+                    double run = pre;
+                    int64_t pick = hi - 1;
+                    for (int64_t i = lo; i < hi; ++i) {
+                        run += (double)(expf(load_f<DT>(row, i) / temp - M) / Sx);
+                        if (run > thr) { pick = i; break; }
+                    }
+                    s_pick = (int)pick;
+                }
+                __syncthreads();
+                draws++;
+                if ((int64_t)s_pick != proposed) bonus = s_pick;
+                __syncthreads();
+            }
+            if (bonus < 0) {
+                // 16 collisions: argmax of p with the proposed id masked (JDN:147-153); all mass on it -> keep it
+                uint32_t best = 0u, bidx = 0xFFFFFFFFu;
+                for (int64_t i = tid; i < V; i += 256) {
+                    if (i == proposed) continue;
+                    const uint32_t k = load_key<DT>(row, i);
+                    if (k > best) { best = k; bidx = (uint32_t)i; }
+                }
+                uint64_t pk = wave_max_u64(((uint64_t)best << 32) | (uint64_t)(~bidx));
+                if ((tid & 63) == 0) s_best[tid >> 6] = pk;
+                __syncthreads();
+                uint64_t mm = s_best[0];
+                for (int w = 1; w < 4; ++w) mm = s_best[w] > mm ? s_best[w] : mm;
+                const int alt = jfmb::decode_packed(mm);
+                const float palt = (alt >= 0 && alt < V) ? expf(load_f<DT>(row, alt) / temp - M) / Sx : 0.f;
+                bonus = (palt > 0.f) ? alt : (int)proposed;
+                __syncthreads();
+            }
+            if (tid == 0) {
+                cm[s_n] = bonus;
+                s_n = s_n + 1;
+                if (eos_id >= 0 && bonus == eos_id) s_eos = 1;
+                s_bc += draws;
+            }
             __syncthreads();
         }
-        if (tid == 0) {
-            // after 16 collisions the reference takes argmax of p with the proposed id masked (JDN:147-153);
-            // the wrapper resolves that rare case from result[3] == 16 && committed == proposed.
-            if (bonus < 0) bonus = (int)proposed;
-            committed[s_n] = bonus;
-            s_n = s_n + 1;
-            if (eos_id >= 0 && bonus == eos_id) s_eos = 1;
+        // next draft (JDN:444-466 / 619-638): seed + greedy fill from this forward + random pads
+        const int n_committed = s_n;
+        const int active_next = (!s_eos && n_committed < remaining[b]) ? 1 : 0;
+        int copy_len = 0, n_pads = 0;
+        if (active_next) {
+            int64_t *nd = next_draft + (int64_t)b * L;
+            const int acc_len = 1 + n_committed;
+            if (tid == 0) nd[0] = cm[n_committed - 1];
+            if (acc_len < L) {
+                const int off = acc_len > 1 ? acc_len - 1 : 1;
+                const int rem = (L - 1) - off;
+                copy_len = rem < L - 1 ? rem : L - 1;
+                for (int i = tid; i < copy_len; i += 256) nd[1 + i] = jfmb::decode_packed(packed[r0 + off + i]);
+            } else {
+                if (tid == 0) nd[1] = jfmb::decode_packed(packed[r0 + L - 2]);
+                copy_len = 1;
+            }
+            n_pads = L - 1 - copy_len;
+            for (int i = tid; i < n_pads; i += 256) nd[1 + copy_len + i] = pad_stream[(s_pc + i) % pad_len];
         }
         __syncthreads();
+        if (tid == 0) {
+            rows[b].n_committed = n_committed; rows[b].eos = s_eos; rows[b].reject_pos = rej; rows[b].n_bonus_draws = draws;
+            rows[b].n_uniforms = s_used; rows[b].n_pads = n_pads; rows[b].active_next = active_next; rows[b].rsv = 0;
+            s_pc += n_pads;
+        }
+        for (int64_t i = tid; i < L - 1; i += 256) packed[r0 + i] = 0ull;
+        __syncthreads();
     }
-    if (tid == 0) { result[0] = s_n; result[1] = s_eos; result[2] = rej; result[3] = draws; }
+    if (tid == 0) { *u_cursor = s_uc; *b_cursor = s_bc; *pad_cursor = s_pc; }
 }
 
-extern "C" int jf_rs_accept(const void *logits, int dtype, int64_t V, int64_t row_stride, const int64_t *draft, int L,
-                            const float *p_draft, const float *row_max, const float *row_sumexp, float temperature,
-                            const float *u, const float *bonus_u, int32_t eos_id, int64_t *committed, int32_t *result,
-                            void *stream) {
-    if (L <= 1) return JF_OK;
-    if (!logits || !draft || !p_draft || !row_max || !row_sumexp || !u || !bonus_u || !committed || !result)
-        return fail(JF_E_INVALID, "jf_rs_accept: null pointer");
+extern "C" int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_stride, const int64_t *draft, int B, int L,
+                          const float *p_draft, const float *row_max, const float *row_sumexp, uint64_t *packed,
+                          float temperature, int32_t eos_id, const int32_t *remaining, const float *u_stream, int64_t u_len,
+                          int64_t *u_cursor, const float *bonus_stream, int64_t bonus_len, int64_t *bonus_cursor,
+                          const int64_t *pad_stream, int64_t pad_len, int64_t *pad_cursor, int64_t *committed,
+                          int64_t *next_draft, jf_rs_row *rows, void *stream) {
+    if (B <= 0) return JF_OK;
+    if (L < 2) return fail(JF_E_INVALID, "Draft must have at least 2 tokens (seed + 1 speculative)");
+    if (!logits || !draft || !p_draft || !row_max || !row_sumexp || !packed || !remaining || !u_stream || !u_cursor ||
+        !bonus_stream || !bonus_cursor || !pad_stream || !pad_cursor || !committed || !next_draft || !rows)
+        return fail(JF_E_INVALID, "jf_rs_step: null pointer");
+    if (u_len <= 0 || bonus_len <= 0 || pad_len <= 0) return fail(JF_E_INVALID, "jf_rs_step: empty random stream");
     const float t = (temperature <= 0.f) ? 1.f : temperature;
-    const float inv = 1.f / t;
     if (dtype == JF_F32)
-        rs_accept_kernel<JF_F32><<<1, 256, 0, (hipStream_t)stream>>>(logits, V, row_stride, draft, L, p_draft, row_max, row_sumexp, inv, u, bonus_u, eos_id, committed, result);
+        rs_step_kernel<JF_F32><<<1, 256, 0, (hipStream_t)stream>>>(logits, V, row_stride, draft, B, L, p_draft, row_max, row_sumexp, (unsigned long long *)packed, t, eos_id, remaining, u_stream, u_len, u_cursor, bonus_stream, bonus_len, bonus_cursor, pad_stream, pad_len, pad_cursor, committed, next_draft, rows);
     else if (dtype == JF_BF16)
-        rs_accept_kernel<JF_BF16><<<1, 256, 0, (hipStream_t)stream>>>(logits, V, row_stride, draft, L, p_draft, row_max, row_sumexp, inv, u, bonus_u, eos_id, committed, result);
-    else return fail(JF_E_INVALID, "jf_rs_accept: dtype %d", dtype);
-    return check_launch("rs_accept_kernel");
+        rs_step_kernel<JF_BF16><<<1, 256, 0, (hipStream_t)stream>>>(logits, V, row_stride, draft, B, L, p_draft, row_max, row_sumexp, (unsigned long long *)packed, t, eos_id, remaining, u_stream, u_len, u_cursor, bonus_stream, bonus_len, bonus_cursor, pad_stream, pad_len, pad_cursor, committed, next_draft, rows);
+    else return fail(JF_E_INVALID, "jf_rs_step: dtype %d", dtype);
+    return check_launch("rs_step_kernel");
 }

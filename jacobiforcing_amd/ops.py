@@ -304,31 +304,69 @@ class EngineStepper:
 
 
 # --------------------------------------------------------------------------------------------
-# non-greedy verify (JDN:299-354)
+# non-greedy verify (JDN:299-354, 581-639)
 # --------------------------------------------------------------------------------------------
-def rs_probs(logits: torch.Tensor, draft_next: torch.Tensor, temperature: float, packed: torch.Tensor):
-    """logits [R, V]; draft_next [R] int64 -> (p_draft, row_max, row_sumexp) fp32 [R]; packed gets the argmax."""
-    R, V = logits.shape
-    dev = logits.device
-    p = torch.empty((R,), dtype=torch.float32, device=dev)
-    m = torch.empty((R,), dtype=torch.float32, device=dev)
-    s = torch.empty((R,), dtype=torch.float32, device=dev)
-    N.check(N.lib().jf_rs_probs(_ptr(logits), _dtype_code(logits), R, V, logits.stride(0), _ptr(draft_next.contiguous()),
-                                float(temperature), _ptr(p), _ptr(m), _ptr(s), _ptr(packed), None, 0, _stream(dev)),
-            "jf_rs_probs")
-    return p, m, s
+class RsStepper:
+    """Rejection-sampling verify of a batch of rows: jf_rs_probs (softmax-gather + argmax, logits read once) followed by
+    jf_rs_step (sequential accept/reject, bonus draw, next draft) — two launches and one read-back per iteration."""
 
+    def __init__(self, max_rows: int, max_L: int, device, pad_stream, u_stream, bonus_stream):
+        dev = torch.device(device)
+        self.device = dev
+        self.max_rows, self.max_L = int(max_rows), int(max_L)
+        n = self.max_rows * self.max_L
+        self.packed = new_packed(n, dev)
+        f32 = lambda k: torch.zeros((k,), dtype=torch.float32, device=dev)
+        self.p_draft, self.row_max, self.row_sumexp = f32(n), f32(n), f32(n)
+        self.committed = torch.zeros((self.max_rows, self.max_L), dtype=torch.int64, device=dev)
+        self.next_draft = torch.zeros((self.max_rows, self.max_L), dtype=torch.int64, device=dev)
+        self.rows_dev = torch.zeros((self.max_rows, N.RS_ROW_INTS), dtype=torch.int32, device=dev)
+        pin = dev.type == "cuda"
+        self.rows_host = torch.zeros((self.max_rows, N.RS_ROW_INTS), dtype=torch.int32, pin_memory=pin)
+        self.tok_host = torch.zeros((self.max_rows, self.max_L), dtype=torch.int64, pin_memory=pin)
+        self.pad_stream = torch.as_tensor(pad_stream).to(device=dev, dtype=torch.int64).contiguous()
+        self.u_stream = torch.as_tensor(u_stream).to(device=dev, dtype=torch.float32).contiguous()
+        self.bonus_stream = torch.as_tensor(bonus_stream).to(device=dev, dtype=torch.float32).contiguous()
+        self.cursors = torch.zeros((3,), dtype=torch.int64, device=dev)          # uniforms, bonus, pads
+        self.remaining = torch.zeros((self.max_rows,), dtype=torch.int32, device=dev)
 
-def rs_accept(logits: torch.Tensor, draft: torch.Tensor, p_draft, row_max, row_sumexp, temperature: float,
-              u: torch.Tensor, bonus_u: torch.Tensor, eos_id: Optional[int]):
-    """One block's sequential accept/reject (JDN:326-348).  Returns (committed list, eos, reject_pos, draws)."""
-    L = draft.numel()
-    dev = logits.device
-    committed = torch.zeros((max(L, 1),), dtype=torch.int64, device=dev)
-    result = torch.zeros((4,), dtype=torch.int32, device=dev)
-    N.check(N.lib().jf_rs_accept(_ptr(logits), _dtype_code(logits), logits.shape[-1], logits.stride(0), _ptr(draft.contiguous()),
-                                 L, _ptr(p_draft), _ptr(row_max), _ptr(row_sumexp), float(temperature), _ptr(u.contiguous()),
-                                 _ptr(bonus_u.contiguous()), -1 if eos_id is None else int(eos_id), _ptr(committed),
-                                 _ptr(result), _stream(dev)), "jf_rs_accept")
-    r = result.cpu().tolist()
-    return committed[:r[0]].cpu().tolist(), bool(r[1]), r[2], r[3]
+    def step(self, draft: torch.Tensor, logits: torch.Tensor, temperature: float, eos_id: Optional[int],
+             remaining: Sequence[int], cursors: Sequence[int]):
+        B, L = draft.shape
+        if L < 2:
+            raise ValueError("Draft must have at least 2 tokens (seed + 1 speculative)")
+        if logits.ndim != 3 or logits.size(0) != B or logits.size(1) != L - 1:
+            raise ValueError(f"forward must return logits [B, L-1, vocab], expected [{B}, {L - 1}, *], got {tuple(logits.shape)}")
+        if B > self.max_rows or L > self.max_L:
+            raise RuntimeError("RsStepper capacity exceeded")
+        dev = self.device
+        draft = draft.to(device=dev, dtype=torch.int64).contiguous()
+        V = logits.shape[-1]
+        flat = logits.reshape(B * (L - 1), V)
+        if flat.stride(1) != 1:
+            flat = flat.contiguous()
+        R = B * (L - 1)
+        draft_next = draft[:, 1:].reshape(-1).contiguous()
+        lib = N.lib()
+        N.check(lib.jf_rs_probs(_ptr(flat), _dtype_code(flat), R, V, flat.stride(0), _ptr(draft_next), float(temperature),
+                                _ptr(self.p_draft), _ptr(self.row_max), _ptr(self.row_sumexp), _ptr(self.packed),
+                                _stream(dev)), "jf_rs_probs")
+        self.remaining[:B].copy_(torch.tensor(list(remaining), dtype=torch.int32), non_blocking=True)
+        self.cursors.copy_(torch.tensor(list(cursors), dtype=torch.int64), non_blocking=True)
+        cm = self.committed.view(-1)[:B * L].view(B, L)
+        nd = self.next_draft.view(-1)[:B * L].view(B, L)
+        cur = self.cursors
+        c_ptr = lambda i: C.c_void_p(cur.data_ptr() + 8 * i)
+        N.check(lib.jf_rs_step(_ptr(flat), _dtype_code(flat), V, flat.stride(0), _ptr(draft), B, L, _ptr(self.p_draft),
+                               _ptr(self.row_max), _ptr(self.row_sumexp), _ptr(self.packed), float(temperature),
+                               -1 if eos_id is None else int(eos_id), _ptr(self.remaining),
+                               _ptr(self.u_stream), self.u_stream.numel(), c_ptr(0),
+                               _ptr(self.bonus_stream), self.bonus_stream.numel(), c_ptr(1),
+                               _ptr(self.pad_stream), self.pad_stream.numel(), c_ptr(2),
+                               _ptr(cm), _ptr(nd), _ptr(self.rows_dev), _stream(dev)), "jf_rs_step")
+        self.rows_host[:B].copy_(self.rows_dev[:B], non_blocking=True)
+        th = self.tok_host.view(-1)[:B * L].view(B, L)
+        th.copy_(cm, non_blocking=True)
+        if dev.type == "cuda":
+            torch.cuda.current_stream(dev).synchronize()
+        return self.rows_host[:B].numpy(), th.numpy(), nd

@@ -163,6 +163,79 @@ class HostSimLib:
         return 0
 
 
+    # -- non-greedy stand-ins (oracle arithmetic with the kernel's stream/cursor contract)
+    def _rows_f32(self, logits, dtype, R, V, stride):
+        if dtype == N.JF_F32:
+            x = _view(logits, (R - 1) * stride + V, np.float32)
+            return np.stack([x[r * stride:r * stride + V] for r in range(R)])
+        b = _view(logits, (R - 1) * stride + V, np.uint16)
+        return O.bf16_bits_to_f32(np.stack([b[r * stride:r * stride + V] for r in range(R)]))
+
+    def jf_rs_probs(self, logits, dtype, R, V, stride, draft_next, temperature, p_draft, row_max, row_sumexp, packed, stream):
+        rows = self._rows_f32(logits, dtype, R, V, stride)
+        t = np.float32(1.0 if temperature <= 0 else temperature)
+        x = rows / t
+        m = x.max(axis=1)
+        e = np.exp(x - m[:, None], dtype=np.float32)
+        ssum = e.sum(axis=1, dtype=np.float32)
+        dn = _view(draft_next, R, np.int64)
+        _view(row_max, R, np.float32)[:] = m
+        _view(row_sumexp, R, np.float32)[:] = ssum
+        _view(p_draft, R, np.float32)[:] = e[np.arange(R), dn] / ssum
+        am = O.argmax_rows(rows).astype(np.uint64)
+        pk = _view(packed, R, np.uint64)
+        pk[:] = np.maximum(pk, (np.uint64(1) << np.uint64(32)) | ((~am) & np.uint64(0xFFFFFFFF)))
+        return 0
+
+    def jf_rs_step(self, logits, dtype, V, stride, draft, B, L, p_draft, row_max, row_sumexp, packed, temperature, eos_id,
+                   remaining, u_stream, u_len, u_cursor, b_stream, b_len, b_cursor, pad_stream, pad_len, pad_cursor,
+                   committed, next_draft, rows, stream):
+        R = B * (L - 1)
+        lg = self._rows_f32(logits, dtype, R, V, stride)
+        probs = O.softmax_rows_f32(lg, temperature)
+        d = _view(draft, B * L, np.int64).reshape(B, L)
+        us, bs, ps = _view(u_stream, u_len, np.float32), _view(b_stream, b_len, np.float32), _view(pad_stream, pad_len, np.int64)
+        uc, bc, pc = _view(u_cursor, 1, np.int64), _view(b_cursor, 1, np.int64), _view(pad_cursor, 1, np.int64)
+        rem = _view(remaining, B, np.int32)
+        cm = _view(committed, B * L, np.int64).reshape(B, L)
+        nd = _view(next_draft, B * L, np.int64).reshape(B, L)
+        rw = _view(rows, B * N.RS_ROW_INTS, np.int32).reshape(B, N.RS_ROW_INTS)
+        pk = _view(packed, R, np.uint64)
+        greedy = ((~pk) & np.uint64(0xFFFFFFFF)).astype(np.int64).reshape(B, L - 1)
+        eos = None if eos_id < 0 else int(eos_id)
+        for b in range(B):
+            used = {"u": 0, "b": 0}
+
+            def nu():
+                v = float(us[(uc[0] + used["u"]) % u_len]); used["u"] += 1; return v
+
+            def nb():
+                v = float(bs[(bc[0] + used["b"]) % b_len]); used["b"] += 1; return v
+            toks, keep, e = O.rs_verify_row(d[b].tolist(), probs[b * (L - 1):(b + 1) * (L - 1)], eos, nu, nb)
+            uc[0] += used["u"]; bc[0] += used["b"]
+            cm[b, :len(toks)] = toks
+            rej = used["u"] - 1 if (len(toks) == used["u"] and used["b"] > 0) or (used["b"] > 0) else -1
+            active = (not e) and len(toks) < int(rem[b])
+            npads = 0
+            if active:
+                acc_len = 1 + len(toks)
+                row = [toks[-1]]
+                if acc_len < L:
+                    r_ = greedy[b, acc_len - 1:].tolist()
+                    copy_len = min(len(r_), L - 1)
+                    row += r_[:copy_len]
+                else:
+                    row += [int(greedy[b, -1])]
+                    copy_len = 1
+                npads = L - 1 - copy_len
+                row += [int(ps[(pc[0] + i) % pad_len]) for i in range(npads)]
+                nd[b] = row
+                pc[0] += npads
+            rw[b] = [len(toks), int(e), rej, used["b"], used["u"], npads, int(active), 0]
+        pk[:] = 0
+        return 0
+
+
 @contextlib.contextmanager
 def use_backend(name: str):
     """Temporarily install a backend as the library jacobiforcing_amd.ops talks to."""

@@ -1,0 +1,144 @@
+"""Engine single-block greedy decoder (jacobiforcing_amd.engine.jacobi_decoding.JacobiDecoder, HIP jf_engine_step)
+against golden vectors recorded from the reference's JacobiDecoder (tests/golden/jd_cases.json)."""
+import numpy as np
+import pytest
+import torch
+
+from jacobiforcing_amd.engine.block_manager import BlockManager
+from jacobiforcing_amd.engine.jacobi_decoding import JacobiDecoder
+from jacobiforcing_amd.engine.sequence import Sequence
+from jacobiforcing_amd.sampling_params import SamplingParams
+from oracle.jacobi_oracle import CounterStream
+from oracle.scripted_model import ScriptedModel
+
+from .backends import device_for, use_backend
+from .conftest import load_golden
+
+JD = load_golden("jd_cases.json")
+BACKENDS = [pytest.param("hostsim", id="hostsim"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+
+
+class Harness:
+    """Caller side of the decoder seam (what MR:1134-1199 / 1407-1416 do around the model forward)."""
+
+    def __init__(self, vocab, dev, dtype=torch.float32, block_size=256):
+        self.bm = BlockManager(64, block_size)
+        self.block_size = block_size
+        self.models = {}
+        self.trace = []
+        self.dev, self.dtype = dev, dtype
+        self.order = []
+
+    def add(self, model, sp, prefill_draft):
+        seq = Sequence(model.prompt(), sp)
+        self.bm.allocate(seq)
+        seq.num_cached_tokens = len(seq)
+        seq._prefill_draft = prefill_draft
+        self.models[seq.seq_id] = model
+        self.order.append(seq.seq_id)
+        return seq
+
+    def forward_step_batch(self, seqs, draft):
+        B, L = draft.shape
+        if L < 2:
+            raise ValueError("Draft must have at least 2 tokens (seed + 1 speculative)")
+        d = draft.cpu()
+        rows = []
+        for i, seq in enumerate(seqs):
+            seq.draft_tokens_gpu = draft[i]
+            if seq.token_ids[-1] != int(d[i, 0]):
+                raise ValueError("Seed mismatch")
+            S = len(seq)
+            need = (S + L - 1 + self.block_size - 1) // self.block_size
+            committed = (S + self.block_size - 1) // self.block_size
+            cur = len(seq.block_table)
+            if cur > need:
+                seq.block_table = seq.block_table[:need]
+            for _ in range(max(0, need - cur)):
+                bid = self.bm.free_block_ids[0]
+                self.bm._allocate_block_no_clear(bid)
+                seq.block_table.append(bid)
+            seq.num_permanent_spec_blocks = max(seq.num_permanent_spec_blocks, need - committed)
+            rows.append(torch.from_numpy(self.models[seq.seq_id].logits_rows(seq.token_ids[:-1], [d[i].tolist()])[0]))
+        logits = torch.stack(rows, 0).to(self.dtype).to(self.dev)
+        for seq in seqs:
+            seq.num_cached_tokens = (len(seq) - 1) + L
+        self.trace.append(dict(seq_idx=[self.order.index(s.seq_id) for s in seqs], draft=d.tolist(),
+                               seq_lens=[len(s) for s in seqs]))
+        return logits[:, :-1, :]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", JD, ids=[c["name"] for c in JD])
+def test_engine_greedy_golden(case, dtype, backend):
+    with use_backend(backend):
+        dev = device_for(backend)
+        p = case["params"]
+        H = Harness(p["vocab"], dev, dtype)
+        dec = JacobiDecoder(H.bm, forward_step=lambda s, d: H.forward_step_batch([s], d),
+                            forward_step_batch=H.forward_step_batch, eos_token_id=p["eos_id"], pad_token_id=p["pad_id"],
+                            vocab_size=p["vocab"], device=torch.device(dev))
+        stream = CounterStream(p["pad_seed"])
+        dec.set_pad_stream([stream.next_u32() % p["vocab"] for _ in range(max(case["pads_consumed"], 1) + 64)])
+        seqs = []
+        for d in case["seqs"]:
+            m = ScriptedModel.from_dict(d["model"])
+            sp = SamplingParams(temperature=0.0, max_tokens=d["max_tokens"], decode_strategy="jacobi",
+                                jacobi_block_len=d["block_len"], jacobi_max_iterations=p["max_iters"])
+            seqs.append(H.add(m, sp, d["prefill_draft"]))
+        out = dec.generate_chunk_batch(seqs) if p["batch"] else [dec.generate_chunk(s) for s in seqs]
+        assert out == case["outputs"]
+        assert dec.stats == case["stats"]
+        assert dec._pad_cursor == case["pads_consumed"]
+        for s, f in zip(seqs, case["final"]):
+            assert s.token_ids == f["token_ids"]
+            assert s.num_cached_tokens == f["num_cached_tokens"]
+            assert len(s.block_table) == f["num_blocks"]
+        assert H.trace == case["forwards"]
+
+
+def test_constructor_errors():
+    with use_backend("hostsim"):
+        with pytest.raises(ValueError):
+            JacobiDecoder(None, vocab_size=10)
+        with pytest.raises(ValueError):
+            JacobiDecoder(None, forward_step=lambda s, d: None)
+
+
+# ----------------------------------------------------------------------------- non-greedy (rejection sampling)
+from jacobiforcing_amd.engine.jacobi_decoding_nongreedy import JacobiDecoderNonGreedy  # noqa: E402
+
+JDN = load_golden("jdn_cases.json")
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", JDN, ids=[c["name"] for c in JDN])
+def test_engine_nongreedy_golden(case, backend):
+    """Rejection-sampling verify with injected uniforms / residual draws / pads against the reference's
+    JacobiDecoderNonGreedy.  Floating point enters through softmax only (fp32 exp on the GPU vs torch CPU); the committed
+    token ids must still agree for these seeds (24-bit uniforms leave ~1e-6 chance of a flip per comparison)."""
+    with use_backend(backend):
+        dev = device_for(backend)
+        p = case["params"]
+        H = Harness(p["vocab"], dev, torch.float32)
+        dec = JacobiDecoderNonGreedy(H.bm, forward_step=lambda s, d: H.forward_step_batch([s], d),
+                                     forward_step_batch=H.forward_step_batch, eos_token_id=p["eos_id"],
+                                     pad_token_id=p["pad_id"], vocab_size=p["vocab"], device=torch.device(dev))
+        pads, unis, bonus = (CounterStream(p["rng_seed"] * 3 + k) for k in (1, 2, 3))
+        dr = case["draws"]
+        dec.set_streams([pads.next_u32() % p["vocab"] for _ in range(dr["pads"] + 64)],
+                        [unis.uniform() for _ in range(dr["uniforms"] + 64)],
+                        [bonus.uniform() for _ in range(dr["bonus"] + 64)])
+        seqs = []
+        for d in case["seqs"]:
+            m = ScriptedModel.from_dict(d["model"])
+            sp = SamplingParams(temperature=p["temperature"], max_tokens=p["max_tokens"], decode_strategy="jacobi",
+                                jacobi_block_len=p["block_len"])
+            seqs.append(H.add(m, sp, None))
+        out = dec.generate_chunk_batch(seqs) if p["batch"] else [dec.generate_chunk(s) for s in seqs]
+        assert out == case["outputs"]
+        assert dec.stats == case["stats"]
+        assert dict(pads=dec._cur[2], uniforms=dec._cur[0], bonus=dec._cur[1]) == case["draws"]
+        for s, f in zip(seqs, case["final"]):
+            assert s.token_ids == f["token_ids"] and s.num_cached_tokens == f["num_cached_tokens"]
