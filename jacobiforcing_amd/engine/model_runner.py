@@ -1,0 +1,276 @@
+"""Per-GPU runner: owns the PyTorch-ROCm Qwen2 forward + static KV cache and routes a scheduled batch to the decode
+strategy — the role of the reference's ``ModelRunner`` (inference_engine/engine/model_runner.py = "MR") for the Jacobi
+path: ``run`` (MR:1464-1550), ``_jacobi_prefill_with_drafting`` (MR:777-963), ``_jacobi_forward_step_batch``
+(MR:1134-1418), decoder selection by temperature (MR:293-373).  Tensor parallelism, CUDA-graph capture tables and the
+shared-memory RPC are out of scope: prompts replicate across GPUs instead.
+
+New relative to the reference: ``decode_strategy="jacobi_multiblock_rejection_recycling"`` is implemented (the reference
+raises NotImplementedError at MR:1468-1473) via ``MultiblockJacobiDecoder``.
+"""
+from __future__ import annotations
+
+import os
+import random
+import time
+from pathlib import Path
+from typing import List, Optional
+
+import torch
+
+from .. import _native, ops
+from ..config import Config
+from ..modeling.qwen2 import Qwen2Model, Qwen2Weights, StaticKVCache
+from .jacobi_decoding import JacobiDecoder
+from .jacobi_decoding_nongreedy import JacobiDecoderNonGreedy
+from .multiblock_decoder import MultiblockJacobiDecoder
+from .sequence import Sequence
+
+
+class ProfileTimer:
+    """PROFILE=1 section timer with the reference's section names (MR:29-144) so reports are comparable."""
+
+    def __init__(self, device):
+        self.enabled = os.environ.get("PROFILE", "0") == "1"
+        self.device = device
+        self.timings, self.counts, self._t0 = {}, {}, {}
+        self.tokens = self.iterations = 0
+
+    def _sync(self):
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+
+    def start(self, name):
+        if self.enabled:
+            self._sync()
+            self._t0[name] = time.perf_counter()
+
+    def stop(self, name):
+        if self.enabled and name in self._t0:
+            self._sync()
+            dt = (time.perf_counter() - self._t0.pop(name)) * 1e3
+            self.timings[name] = self.timings.get(name, 0.0) + dt
+            self.counts[name] = self.counts.get(name, 0) + 1
+
+    def report(self) -> str:
+        tot = sum(self.timings.values()) or 1.0
+        lines = [f"{k:<32}{v:10.2f} ms {self.counts[k]:6d} calls {100 * v / tot:5.1f}%" for k, v in sorted(self.timings.items())]
+        fwd = self.timings.get("jacobi.forward", 0.0) + self.timings.get("jacobi.lm_head", 0.0)
+        if fwd and self.tokens:
+            lines.append(f"overhead vs forward-only: {100 * (1 - fwd / tot):.1f}%  TPF={self.tokens / max(self.iterations, 1):.2f}")
+        return "\n".join(lines)
+
+
+class ModelRunner:
+    def __init__(self, config: Config, rank: int = 0, event=None, device: Optional[str] = None):
+        self.config = config
+        self.rank, self.world_size = 0, 1
+        dev = device or os.environ.get("JF_DEVICE") or ("cuda" if torch.cuda.is_available() else "cpu")
+        self.device = torch.device(dev)
+        if self.device.type == "cuda":
+            _native.lib()                                     # fail loudly when the HIP extension is missing
+        hf = config.hf_config
+        dtype = torch.bfloat16 if self.device.type == "cuda" else torch.float32
+        self.weights = Qwen2Weights(hf, self.device, dtype=dtype, seed=int(os.environ.get("JF_WEIGHT_SEED", "0")),
+                                    init_std=float(os.environ.get("JF_INIT_STD", "0.02")))
+        if list(Path(config.model_path).glob("*.safetensors")):
+            self.weights.load_safetensors(config.model_path, hf)
+        else:
+            print(f"[ModelRunner] no *.safetensors under {config.model_path}: using random-init weights", flush=True)
+        self.model = Qwen2Model(hf, self.weights)
+        self.block_size = config.kvcache_block_size
+        self.max_rows = int(min(config.max_num_seqs, int(os.environ.get("JF_MAX_ROWS", "64"))))
+        self.kv_cache = StaticKVCache(hf, self.max_rows, config.max_model_len, 0, 1, self.device, dtype=dtype)
+        self.free_rows = list(range(self.max_rows))
+        if config.num_kvcache_blocks <= 0:
+            config.num_kvcache_blocks = self.max_rows * ((config.max_model_len + self.block_size - 1) // self.block_size + 4)
+        self.block_manager = None
+        self.jacobi_decoder = None
+        self._mb_decoders = {}
+        self.profiler = ProfileTimer(self.device)
+        self._kv_host = [0] * self.max_rows
+
+    # ------------------------------------------------------------------------------------------
+    def call(self, method_name, *args):
+        return getattr(self, method_name)(*args)
+
+    def exit(self):
+        if self.profiler.enabled:
+            print(self.profiler.report(), flush=True)
+
+    def _row(self, seq: Sequence) -> int:
+        if seq.cache_row < 0:
+            if not self.free_rows:
+                raise RuntimeError("no free KV cache row (raise max_num_seqs / JF_MAX_ROWS)")
+            seq.cache_row = self.free_rows.pop(0)
+        return seq.cache_row
+
+    def release(self, seq: Sequence) -> None:
+        if seq.cache_row >= 0:
+            self.free_rows.append(seq.cache_row)
+            seq.cache_row = -1
+
+    def _forward_rows(self, seqs: List[Sequence], ids: torch.Tensor, starts: List[int], lens: List[int],
+                      logits_rows=None) -> torch.Tensor:
+        """Forward ``ids`` [B, T] where row b continues cache row seqs[b].cache_row from position starts[b]."""
+        dev = self.device
+        B, T = ids.shape
+        st = torch.tensor(starts, dtype=torch.int32, device=dev)
+        pos = st.view(B, 1) + torch.arange(T, dtype=torch.int32, device=dev).view(1, T)
+        rp = torch.tensor([self._row(s) for s in seqs], dtype=torch.int32, device=dev)
+        return self.model.forward(ids.to(dev), pos, self.kv_cache, row_prompt=rp, row_cand=torch.full((B,), -1, dtype=torch.int32, device=dev),
+                                  row_len=torch.tensor(lens, dtype=torch.int32, device=dev), kv_len_rows=st,
+                                  any_candidates=False, logits_rows=logits_rows, s_cur=max(starts) + T)
+
+    # ------------------------------------------------------------------------------------------ MR:777-963
+    @torch.inference_mode()
+    def _jacobi_prefill_with_drafting(self, seqs: List[Sequence]):
+        V = self.config.hf_config.vocab_size
+        for seq in seqs:
+            sp = getattr(seq, "sampling_params", None)
+            block_len = getattr(sp, "jacobi_block_len", 64) if sp else 64
+            prompt_len = len(seq)
+            draft = [random.choice(seq.token_ids) for _ in range(block_len)]                  # MR:797
+            ids = torch.tensor([seq.token_ids + draft], dtype=torch.int64)
+            T = ids.shape[1]
+            if T > self.config.max_model_len:
+                raise RuntimeError(f"prompt + draft ({T}) exceeds max_model_len={self.config.max_model_len}")
+            logits = self._forward_rows([seq], ids, [0], [T], logits_rows=slice(prompt_len - 1, prompt_len + block_len - 1))
+            seq._prefill_draft = ops.argmax_rows(logits).cpu().tolist()                        # MR:914-918
+            seq.num_cached_tokens = prompt_len                                                 # MR:929-947 (roll back)
+            seq.draft_tokens = None
+        return [[] for _ in seqs]
+
+    # ------------------------------------------------------------------------------------------ MR:1134-1418
+    @torch.inference_mode()
+    def _jacobi_forward_step_batch(self, seqs: List[Sequence], draft_tokens_batch: torch.Tensor) -> torch.Tensor:
+        B, L = len(seqs), draft_tokens_batch.size(1)
+        if L < 2:
+            raise ValueError("Draft must have at least 2 tokens (seed + 1 speculative)")
+        seeds = draft_tokens_batch[:, 0].cpu().tolist()
+        for i, seq in enumerate(seqs):
+            seq.draft_tokens_gpu = draft_tokens_batch[i]
+            if seq.token_ids[-1] != seeds[i]:                                                  # MR:1157-1162
+                raise ValueError(f"Seed mismatch: seq[-1]={seq.token_ids[-1]}, draft[0]={seeds[i]}")
+        prof = self.profiler
+        prof.start("jacobi.block_alloc")
+        bm = self.block_manager
+        for seq in seqs:                                                                        # MR:1166-1199
+            S = len(seq)
+            if S + L - 1 > self.config.max_model_len:
+                raise RuntimeError(f"Sequence needs {S + L - 1} positions but max_model_len={self.config.max_model_len}")
+            need = (S + L - 1 + self.block_size - 1) // self.block_size
+            committed = (S + self.block_size - 1) // self.block_size
+            cur = len(seq.block_table)
+            if cur > need:
+                seq.block_table = seq.block_table[:need]
+                seq.block_table_version += 1
+            elif bm is not None:
+                for _ in range(need - cur):
+                    if not bm.can_append(seq) or not bm.free_block_ids:
+                        raise RuntimeError("Cannot allocate blocks for draft tokens")
+                    bid = bm.free_block_ids[0]
+                    bm._allocate_block_no_clear(bid)
+                    seq.block_table.append(bid)
+                    seq.block_table_version += 1
+            seq.num_permanent_spec_blocks = max(seq.num_permanent_spec_blocks, need - committed)
+        prof.stop("jacobi.block_alloc")
+        prof.start("jacobi.forward")
+        logits = self._forward_rows(seqs, draft_tokens_batch, [len(s) - 1 for s in seqs], [L] * B)   # seed re-forwarded at S-1
+        prof.stop("jacobi.forward")
+        for seq in seqs:
+            seq.num_cached_tokens = (len(seq) - 1) + L                                         # MR:1407-1408
+        V = logits.shape[-1]
+        return logits.view(B, L, V)[:, :-1, :]                                                  # MR:1413-1416
+
+    def _jacobi_forward_step(self, seq: Sequence, draft_tokens: torch.Tensor) -> torch.Tensor:
+        return self._jacobi_forward_step_batch([seq], draft_tokens)
+
+    def _ensure_jacobi_decoder_initialized(self, seqs):                                         # MR:293-373
+        jac = [s for s in seqs if s.decode_strategy == "jacobi"]
+        if not jac:
+            return
+        if any(getattr(s, "jacobi_on_policy", False) for s in jac):
+            raise NotImplementedError("jacobi_on_policy (rollout-record production for training) is out of scope for the "
+                                      "decode-throughput path (SURVEY §2 row 5)")
+        temps = [float(getattr(s, "temperature", 0.0)) for s in jac]
+        all_greedy, all_ng = all(t == 0.0 for t in temps), all(t > 0.0 for t in temps)
+        if not (all_greedy or all_ng):
+            raise NotImplementedError("Mixed temperature modes in Jacobi batch not supported. Got some sequences with "
+                                      f"temperature=0 (greedy) and some with temperature>0 (non-greedy). Temperatures: {temps}")
+        want = JacobiDecoder if all_greedy else JacobiDecoderNonGreedy
+        if not isinstance(self.jacobi_decoder, want):
+            self.jacobi_decoder = want(block_manager=self.block_manager, forward_step=self._jacobi_forward_step,
+                                       forward_step_batch=self._jacobi_forward_step_batch, eos_token_id=self.config.eos,
+                                       pad_token_id=self.config.pad, vocab_size=self.config.hf_config.vocab_size,
+                                       device=self.device)
+
+    # ------------------------------------------------------------------------------------------ multiblock (new)
+    @torch.inference_mode()
+    def _run_multiblock(self, seqs: List[Sequence]):
+        sp0 = seqs[0].sampling_params
+        key = (len(seqs), sp0.jacobi_block_len, sp0.jacobi_max_blocks, sp0.jacobi_spawn_ratio, sp0.jacobi_lookahead_start_ratio,
+               sp0.jacobi_n_gram_pool_size, sp0.jacobi_max_iterations, sp0.ignore_eos)
+        for s in seqs[1:]:
+            sp = s.sampling_params
+            if (sp.jacobi_block_len, sp.jacobi_max_blocks, sp.jacobi_spawn_ratio, sp.jacobi_lookahead_start_ratio,
+                    sp.jacobi_n_gram_pool_size, sp.jacobi_max_iterations, sp.ignore_eos) != key[1:]:
+                raise NotImplementedError("multiblock requests in one batch must share their jacobi_* parameters")
+        dec = self._mb_decoders.get(key)
+        if dec is None:
+            prm = ops.MultiblockParams(n=sp0.jacobi_block_len, K=sp0.jacobi_max_blocks, r=sp0.jacobi_spawn_ratio,
+                                       lookahead_start_ratio=sp0.jacobi_lookahead_start_ratio,
+                                       n_gram_pool_size=sp0.jacobi_n_gram_pool_size,
+                                       eos_token_id=None if sp0.ignore_eos else self.config.eos, pad_token_id=self.config.pad,
+                                       max_iteration_count=sp0.jacobi_max_iterations)
+            dec = MultiblockJacobiDecoder(self.model, len(seqs), prm, max_seq_len=self.config.max_model_len)
+            self._mb_decoders = {key: dec}                      # one live decoder (its KV cache is the big allocation)
+        max_new = max(s.max_tokens - s.num_completion_tokens for s in seqs)
+        stats, gen_s, iters = dec.generate([s.token_ids for s in seqs], max_new_tokens=max_new, max_calls=1 << 30,
+                                           seed=int(os.environ.get("JF_DRAFT_SEED", "1234")))
+        self.last_multiblock = dict(stats=stats, gen_seconds=gen_s, iterations=iters)
+        out = []
+        for s, st in zip(seqs, stats):
+            toks = st.token_ids
+            s.extend_tokens(toks)
+            s.num_cached_tokens = len(s)
+            out.append(toks)
+        return out
+
+    # ------------------------------------------------------------------------------------------ autoregressive
+    @torch.inference_mode()
+    def _run_autoregressive(self, seqs: List[Sequence], is_prefill: bool):
+        toks = []
+        for seq in seqs:
+            if is_prefill:
+                ids = torch.tensor([seq.token_ids], dtype=torch.int64)
+                logits = self._forward_rows([seq], ids, [0], [len(seq)], logits_rows=slice(len(seq) - 1, len(seq)))
+            else:
+                ids = torch.tensor([[seq.last_token]], dtype=torch.int64)
+                logits = self._forward_rows([seq], ids, [len(seq) - 1], [1])
+            seq.num_cached_tokens = len(seq)
+            if seq.temperature == 0.0:
+                toks.append(int(ops.argmax_rows(logits)[0]))
+            else:                                               # Gumbel-max sampling like layers/sampler.py:10-24
+                p = torch.softmax(logits.float() / seq.temperature, dim=-1)
+                toks.append(int(torch.argmax(p / torch.empty_like(p).exponential_(1).clamp_min_(1e-10), dim=-1)[0]))
+        return toks
+
+    # ------------------------------------------------------------------------------------------ MR:1464-1550
+    def run(self, seqs: List[Sequence], is_prefill: bool):
+        mb = [s for s in seqs if s.decode_strategy == "jacobi_multiblock_rejection_recycling"]
+        jac = [s for s in seqs if s.decode_strategy == "jacobi"]
+        if mb and len(mb) != len(seqs) or jac and len(jac) != len(seqs):
+            raise NotImplementedError("Mixed decode strategies in same batch not supported. "
+                                      f"Got {len(jac)} Jacobi, {len(mb)} multiblock and {len(seqs) - len(jac) - len(mb)} autoregressive sequences.")
+        if mb:
+            if is_prefill:
+                for s in seqs:
+                    s.num_cached_tokens = len(s)
+                return [[] for _ in seqs]
+            return self._run_multiblock(seqs)
+        if jac:
+            self._ensure_jacobi_decoder_initialized(seqs)
+            if is_prefill:
+                return self._jacobi_prefill_with_drafting(seqs)
+            return self.jacobi_decoder.generate_chunk_batch(seqs)
+        return self._run_autoregressive(seqs, is_prefill)

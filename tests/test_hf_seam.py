@@ -1,0 +1,121 @@
+"""HF-style seam functions (jacobiforcing_amd.hf_seam) against the golden call records of the reference's
+jacobi_forward_greedy_multiblock (mb_cases.json) and jacobi_forward_greedy (sb_cases.json), and end to end on the
+PyTorch Qwen2 backend."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from jacobiforcing_amd import hf_seam
+from oracle.scripted_model import ScriptedModel
+
+from .backends import device_for, use_backend
+from .conftest import load_golden
+from .test_decoder_e2e import scratch_forward, tiny_model
+
+MB = load_golden("mb_cases.json")
+SB = load_golden("sb_cases.json")
+BACKENDS = [pytest.param("hostsim", id="hostsim"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+
+
+class ScriptedBackend:
+    def __init__(self, model: ScriptedModel, dev):
+        self.model, self.device = model, torch.device(dev)
+
+    def new_cache(self):
+        c = types.SimpleNamespace(tokens=[], spec=None, best=0)
+        c.get_seq_length = lambda: len(c.tokens)
+        return c
+
+    def forward(self, rows, cache):
+        r = rows.cpu().tolist()
+        lg = self.model.logits_rows(cache.tokens, r)
+        cache.spec = [cache.tokens + row for row in r]
+        cache.best = 0
+        return torch.from_numpy(lg.reshape(-1, lg.shape[-1])).to(self.device)
+
+    def commit(self, cache, src_row, dst, length):
+        assert dst == len(cache.tokens)
+        cache.best = src_row
+
+    def set_length(self, cache, n):
+        src = cache.spec[cache.best] if cache.spec is not None else cache.tokens
+        cache.tokens = src[:n]
+        cache.spec = None
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", MB[:12] + MB[18:24], ids=[c["name"] for c in MB[:12] + MB[18:24]])
+def test_multiblock_seam_golden(case, backend):
+    with use_backend(backend):
+        dev = device_for(backend)
+        p = case["params"]
+        me = types.SimpleNamespace(jf_backend=ScriptedBackend(ScriptedModel.from_dict(case["model"]), dev))
+        kw = dict(n_token_seq_len=p["n"], K=p["K"], r=p["r"], lookahead_start_ratio=p["lookahead"], n_gram_pool_size=p["pool"],
+                  eos_token_id=p["eos_id"], pad_token_id=p["pad_id"], max_iteration_count=p["max_iter"], use_cache=True)
+        ids = torch.tensor([case["prompt"] + case["prefill"]["draft"]], dtype=torch.int64, device=dev)
+        cache, first, ngram, it = hf_seam.jacobi_forward_greedy_multiblock(me, ids, past_key_values=None, prefill_phase=True, **kw)
+        assert ngram.cpu().tolist() == [case["prefill"]["ngram"]] and first.cpu().tolist() == case["prefill"]["first_correct_token"]
+        assert it == 0 and cache.get_seq_length() == case["prefill"]["kv_len"]
+        for call in case["calls"]:
+            ids = torch.tensor([call["input"]], dtype=torch.int64, device=dev)
+            cache, nxt, ret, iters = hf_seam.jacobi_forward_greedy_multiblock(me, ids, past_key_values=cache, prefill_phase=False, **kw)
+            assert ret.cpu().tolist() == [call["ret"]]
+            assert list(nxt.shape) == call["next_token_shape"] and nxt.view(-1).cpu().tolist() == call["next_token"]
+            assert iters == call["iters"]
+            assert cache.tokens == call["kv_tokens"]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", SB, ids=[c["name"] for c in SB])
+def test_singleblock_seam_golden(case, backend, capsys):
+    with use_backend(backend):
+        dev = device_for(backend)
+        n, eos = case["params"]["n"], case["params"]["eos_id"]
+        me = types.SimpleNamespace(jf_backend=ScriptedBackend(ScriptedModel.from_dict(case["model"]), dev))
+        ids = torch.tensor([case["prompt"] + case["prefill"]["draft"]], dtype=torch.int64, device=dev)
+        cache, _, ngram, _ = hf_seam.jacobi_forward_greedy(me, ids, past_key_values=None, prefill_phase=True, n_token_seq_len=n,
+                                                           eos_token_id=eos, use_cache=True)
+        assert ngram.cpu().tolist() == [case["prefill"]["ngram"]]
+        for call in case["calls"]:
+            ids = torch.tensor([call["input"]], dtype=torch.int64, device=dev)
+            cache, nxt, ret, itr = hf_seam.jacobi_forward_greedy(me, ids, past_key_values=cache, prefill_phase=False,
+                                                                 n_token_seq_len=n, eos_token_id=eos)
+            assert ret.cpu().tolist() == [call["ret"]]
+            assert nxt.view(-1).cpu().tolist() == call["next_token"]
+            assert itr == call["iters"]
+            assert cache.tokens == call["kv_tokens"]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_seam_on_qwen2_backend_equals_autoregressive(backend):
+    """Driver loop of JacobiForcing/jacobi_forcing_inference_MR_humaneval.py:152-240 over the real (tiny) Qwen2 backend:
+    the concatenated accepted n-grams equal greedy AR decoding."""
+    import random
+    with use_backend(backend):
+        dev = device_for(backend)
+        model = tiny_model(dev, seed=17)
+        V = model.cfg.vocab_size
+        me = types.SimpleNamespace(jf_backend=hf_seam.Qwen2Backend(model, max_seq_len=256, max_rows=4, max_tokens=128))
+        me.jacobi_forward_greedy_multiblock = types.MethodType(hf_seam.jacobi_forward_greedy_multiblock, me)
+        n, rng = 16, random.Random(3)
+        prompt = [int(t) for t in np.random.default_rng(2).integers(0, V - 2, size=11)]
+        text = list(prompt)
+        draft = [rng.choice(text) for _ in range(n)]
+        kw = dict(n_token_seq_len=n, K=2, r=0.5, n_gram_pool_size=4, eos_token_id=None, pad_token_id=V - 2, use_cache=True)
+        cache, _, ngram, _ = me.jacobi_forward_greedy_multiblock(torch.tensor([prompt + draft], device=dev), past_key_values=None,
+                                                                 prefill_phase=True, **kw)
+        inp, gen = ngram, []
+        for _ in range(3):
+            cache, first, acc, iters = me.jacobi_forward_greedy_multiblock(inp, past_key_values=cache, prefill_phase=False, **kw)
+            gen += acc[0].cpu().tolist()
+            text += acc[0].cpu().tolist()
+            assert cache.get_seq_length() == len(prompt) + len(gen)
+            inp = torch.cat([first.view(1, 1), torch.tensor([[rng.choice(text) for _ in range(n - 1)]], device=dev)], dim=-1)
+        fwd = scratch_forward(model)
+        toks, ar = list(prompt), []
+        for _ in range(len(gen)):
+            nxt = fwd([toks[:-1]], [[toks[-1]]])[0][0]
+            ar.append(nxt); toks.append(nxt)
+        assert gen == ar

@@ -235,3 +235,30 @@ def test_argmax_special_values_vector_path(dtype):
     Y = torch.zeros(X.shape[0], V + 64, dtype=dtype)
     Y[:, :V] = X
     assert ops.argmax_rows(Y.cuda()[:, :V]).cpu().tolist() == ref.tolist()
+
+
+# ------------------------------------------------------------------------------------- non-greedy softmax-gather
+@GPU
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("temperature", [1.0, 0.7])
+def test_rs_probs_vs_torch_softmax(dtype, temperature):
+    """p_draft = softmax(logits / T)[draft] (JDN:65-70, 328) in fp32: tolerance 2e-5 relative (fp32 exp/sum order),
+    argmax bit-exact."""
+    R, V = 31, 152064
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn(R, V, generator=g) * 3).to(dtype)
+    dn = torch.randint(0, V, (R,), generator=g)
+    dn[0] = int(torch.argmax(x[0].float()))
+    st = ops.RsStepper(4, 16, "cuda", [0], [0.5], [0.5])
+    lib = N.lib()
+    xd = x.cuda()
+    p = torch.zeros(R, device="cuda"); m = torch.zeros(R, device="cuda"); s = torch.zeros(R, device="cuda")
+    packed = ops.new_packed(R, "cuda")
+    N.check(lib.jf_rs_probs(ops._ptr(xd), ops._dtype_code(xd), R, V, V, ops._ptr(dn.cuda()), temperature, ops._ptr(p), ops._ptr(m),
+                            ops._ptr(s), ops._ptr(packed), ops._stream(xd.device)))
+    ref = torch.softmax(x.float() / temperature, dim=-1)
+    want = ref[torch.arange(R), dn]
+    got = p.cpu()
+    assert torch.allclose(got, want, rtol=2e-5, atol=1e-12), float(((got - want).abs() / want).max())
+    am = (~packed.cpu()) & 0xFFFFFFFF
+    assert am.tolist() == torch.argmax(x.float(), dim=-1).tolist()

@@ -1,0 +1,99 @@
+"""Drop-in surface: ``from jacobiforcing_amd import LLM, SamplingParams`` behaves like the reference's
+``inference_engine`` on the Jacobi path.  The correctness criterion is the reference's own
+(inference_engine/tests/test_jacobi_decoding_greedy.py:180-206): greedy Jacobi output == greedy AR output."""
+import dataclasses
+import json
+
+import pytest
+import torch
+
+from jacobiforcing_amd import LLM, SamplingParams
+from jacobiforcing_amd.config import Config
+
+from .backends import device_for, use_backend
+
+BACKENDS = [pytest.param("hostsim", id="hostsim"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture()
+def model_dir(tmp_path):
+    cfg = dict(vocab_size=320, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+               num_key_value_heads=2, max_position_embeddings=1024, rms_norm_eps=1e-6, rope_theta=10000.0,
+               tie_word_embeddings=False, eos_token_id=319, pad_token_id=318, model_type="qwen2")
+    (tmp_path / "config.json").write_text(json.dumps(cfg))
+    return str(tmp_path)
+
+
+def test_sampling_params_surface():
+    """Field names and defaults of inference_engine/sampling_params.py:4-38."""
+    want = dict(temperature=1.0, max_tokens=64, ignore_eos=False, decode_strategy="autoregressive", jacobi_block_len=64,
+                jacobi_max_iterations=128, jacobi_max_blocks=2, jacobi_spawn_ratio=0.85, jacobi_lookahead_start_ratio=0.0,
+                jacobi_n_gram_pool_size=4, jacobi_on_policy=False)
+    assert {f.name: f.default for f in dataclasses.fields(SamplingParams)} == want
+    assert SamplingParams().use_jacobi
+    with pytest.raises(AssertionError):
+        SamplingParams(temperature=-1.0)
+    with pytest.raises(ValueError):
+        SamplingParams(temperature=0.0, jacobi_on_policy=True)
+
+
+def test_config_checks(model_dir, tmp_path):
+    c = Config(model_dir, max_model_len=512)
+    assert c.hf_config.vocab_size == 320 and c.max_model_len == 512
+    with pytest.raises(AssertionError):
+        Config(model_dir, kvcache_block_size=100)
+    with pytest.raises(AssertionError):
+        Config(str(tmp_path / "missing"))
+    with pytest.raises(NotImplementedError):
+        Config(model_dir, tensor_parallel_size=2)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_jacobi_matches_autoregressive(model_dir, backend, monkeypatch):
+    monkeypatch.setenv("JF_INIT_STD", "0.3")
+    with use_backend(backend):
+        dev = device_for(backend)
+        llm = LLM(model_dir, tokenizer_path="none", device=dev, max_model_len=512, max_num_batched_tokens=512, max_num_seqs=4)
+        prompts = [[5, 9, 200, 31, 7], [100, 101, 102, 103, 104, 105, 106, 107, 108], [250, 3]]
+        N = 40
+        ar = llm.generate(prompts, SamplingParams(temperature=0.0, max_tokens=N, ignore_eos=True), use_tqdm=False)
+        jac = llm.generate(prompts, SamplingParams(temperature=0.0, max_tokens=N, ignore_eos=True, decode_strategy="jacobi",
+                                                   jacobi_block_len=16), use_tqdm=False)
+        mb = llm.generate(prompts, SamplingParams(temperature=0.0, max_tokens=N, ignore_eos=True,
+                                                  decode_strategy="jacobi_multiblock_rejection_recycling",
+                                                  jacobi_block_len=16, jacobi_max_blocks=2, jacobi_spawn_ratio=0.5),
+                          use_tqdm=False)
+        assert [len(o["token_ids"]) for o in ar] == [N] * 3
+        for a, j, m in zip(ar, jac, mb):
+            assert len(j["token_ids"]) >= N and len(m["token_ids"]) >= N     # E3: the last iteration may overshoot
+            assert j["token_ids"][:N] == a["token_ids"]
+            assert m["token_ids"][:N] == a["token_ids"]
+            assert j["text"] == ""
+        tpf = llm.model_runner.jacobi_decoder.stats
+        assert tpf["tokens_accepted"] >= 3 * N and tpf["num_jacobi_iterations"] >= 1
+        # kwargs of LLM.generate (llm.py:22-37); the names the reference breaks on are mapped
+        kw = llm.generate(prompts[:1], SamplingParams(temperature=0.0, max_tokens=20, ignore_eos=True), use_tqdm=False,
+                          greedy=True, jacobi_block_len=8, jacobi_num_blocks=2, jacobi_ngram_pool_size=4, jacobi_spawn_ratio=0.5)
+        assert kw[0]["token_ids"][:20] == ar[0]["token_ids"][:20]
+        llm.exit()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_nongreedy_and_errors(model_dir, backend, monkeypatch):
+    monkeypatch.setenv("JF_INIT_STD", "0.3")
+    with use_backend(backend):
+        dev = device_for(backend)
+        llm = LLM(model_dir, tokenizer_path="none", device=dev, max_model_len=512, max_num_batched_tokens=512, max_num_seqs=4)
+        torch.manual_seed(0)
+        out = llm.generate([[1, 2, 3, 4], [9, 8, 7]], SamplingParams(temperature=0.8, max_tokens=24, ignore_eos=True,
+                                                                     decode_strategy="jacobi", jacobi_block_len=8), use_tqdm=False)
+        assert all(len(o["token_ids"]) >= 24 for o in out)
+        with pytest.raises(NotImplementedError):        # MR:1538-1542 mixed strategies
+            llm.generate([[1, 2, 3], [4, 5, 6]], [SamplingParams(temperature=0.0, max_tokens=4, decode_strategy="jacobi"),
+                                                 SamplingParams(temperature=0.0, max_tokens=4)], use_tqdm=False)
+        llm2 = LLM(model_dir, tokenizer_path="none", device=dev, max_model_len=512, max_num_batched_tokens=512, max_num_seqs=4)
+        with pytest.raises(NotImplementedError):        # MR:367-373 mixed temperatures
+            llm2.generate([[1, 2, 3], [4, 5, 6]], [SamplingParams(temperature=0.0, max_tokens=4, decode_strategy="jacobi"),
+                                                  SamplingParams(temperature=1.0, max_tokens=4, decode_strategy="jacobi")], use_tqdm=False)
+        with pytest.raises(ValueError):
+            llm2.generate(["text prompt"], SamplingParams(max_tokens=4), use_tqdm=False)
