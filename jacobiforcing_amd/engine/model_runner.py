@@ -70,6 +70,8 @@ class ModelRunner:
             _native.lib()                                     # fail loudly when the HIP extension is missing
         hf = config.hf_config
         dtype = torch.bfloat16 if self.device.type == "cuda" else torch.float32
+        if os.environ.get("JF_DTYPE"):
+            dtype = getattr(torch, os.environ["JF_DTYPE"])
         self.weights = Qwen2Weights(hf, self.device, dtype=dtype, seed=int(os.environ.get("JF_WEIGHT_SEED", "0")),
                                     init_std=float(os.environ.get("JF_INIT_STD", "0.02")))
         if list(Path(config.model_path).glob("*.safetensors")):

@@ -51,6 +51,7 @@ def test_config_checks(model_dir, tmp_path):
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_jacobi_matches_autoregressive(model_dir, backend, monkeypatch):
     monkeypatch.setenv("JF_INIT_STD", "0.3")
+    monkeypatch.setenv("JF_DTYPE", "float32")     # bf16 GEMV-vs-GEMM rounding flips near-tie argmaxes of a random model
     with use_backend(backend):
         dev = device_for(backend)
         llm = LLM(model_dir, tokenizer_path="none", device=dev, max_model_len=512, max_num_batched_tokens=512, max_num_seqs=4)
