@@ -50,6 +50,7 @@ class ArgmaxTimer:
         self.events = []
         self.bytes = 0
         self.rows = 0
+        self.all_rows = []          # every launch since construction (for matching PMC passes to shapes)
         self._orig = ops.argmax_partial
 
     def __enter__(self):
@@ -61,6 +62,7 @@ class ArgmaxTimer:
             self.events.append((a, b))
             self.bytes += logits.shape[0] * logits.shape[1] * logits.element_size()
             self.rows += logits.shape[0]
+            self.all_rows.append(int(logits.shape[0]))
         ops.argmax_partial = timed
         return self
 
@@ -161,8 +163,10 @@ def main():
         weights.load_safetensors(args.model, cfg)
     model = Qwen2Model(cfg, weights)
 
+    # EOS handling is switched off for the measurement so that every rank keeps all of its prompts decoding for the
+    # whole timed window (random weights can emit any id; a finished prompt would shrink that rank's per-step work)
     prm = ops.MultiblockParams(n=32, K=2, r=0.85, lookahead_start_ratio=0.0, n_gram_pool_size=4,
-                               eos_token_id=cfg.eos_token_id, pad_token_id=cfg.pad_token_id)
+                               eos_token_id=None, pad_token_id=cfg.pad_token_id)
     P = args.prompts_per_gpu
     vocab_hi = min(151643, cfg.vocab_size - 2)
     all_prompts = humaneval_shaped_prompts(P * info.world_size, seed=1234, vocab_hi=vocab_hi)
@@ -174,6 +178,8 @@ def main():
         r = run_steps(dec, prompts, args.warmup, args.steps, seed=1234 + info.rank, timer=tm)
         roof = tm.summary()
     agg = jd.gather_throughput(r["tokens"], r["iterations"] * 1.0, r["seconds"], dev)
+    if os.environ.get("JF_DUMP_LAUNCHES") and info.rank == 0:
+        Path(os.environ["JF_DUMP_LAUNCHES"]).write_text(json.dumps(dict(rows=tm.all_rows, V=cfg.vocab_size, esz=2)))
     # ---- same measurement with the synthetic acceptance model -------------------------------------
     scripted = None
     if not args.no_scripted:
@@ -225,11 +231,13 @@ def main():
 
 
 def _pmc_traffic(roof):
-    """HBM bytes per launch from the committed PMC pass (profiles/), when one exists for this shape; else null."""
+    """HBM bytes per launch = algorithmic bytes x the traffic ratio measured in the committed rocprofv3 PMC passes of
+    this same command (profiles/pmc_argmax_latest.json: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch over algorithmic
+    bytes, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction); null when no pass is committed."""
     f = ROOT / "profiles" / "pmc_argmax_latest.json"
     try:
         d = json.loads(f.read_text())
-        return d.get("hbm_bytes_per_launch")
+        return float(d["traffic_over_algorithmic"]) * roof["avg_bytes"]
     except Exception:
         return None
 
