@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=float(os.environ.get("JF_CPU_BASELINE_S", "20")))
     ap.add_argument("--no-scripted", action="store_true")
     ap.add_argument("--robust", type=int, default=75)
+    ap.add_argument("--no-tuned-gemms", action="store_true")
     args = ap.parse_args()
 
     info = jd.init_from_env("nccl")
@@ -150,6 +151,8 @@ def main():
     torch.cuda.set_device(info.local_rank)
     dev = torch.device("cuda", info.local_rank)
     _native.lib()                                   # fail loudly if the HIP extension is missing
+    from jacobiforcing_amd.tuning import enable_tuned_gemms
+    tuned = (not args.no_tuned_gemms) and enable_tuned_gemms()
 
     if args.model == "tiny":
         cfg = Qwen2Config.tiny(vocab_size=4096, hidden_size=256, layers=4, heads=8, kv_heads=2, head_dim=32, inter=512)
@@ -171,7 +174,7 @@ def main():
     vocab_hi = min(151643, cfg.vocab_size - 2)
     all_prompts = humaneval_shaped_prompts(P * info.world_size, seed=1234, vocab_hi=vocab_hi)
     prompts = jd.shard_prompts(all_prompts, info)
-    dec = MultiblockJacobiDecoder(model, P, prm, max_seq_len=4096)
+    dec = MultiblockJacobiDecoder(model, P, prm, max_seq_len=4096, t_align=8 if tuned else 1)
 
     # ---- headline: unmodified random-init model ------------------------------------------------
     with ArgmaxTimer() as tm:
@@ -208,7 +211,9 @@ def main():
                                    "multiblock lookahead + rejection recycling, greedy",
                        "model": name, "n": 32, "K": 2, "r": 0.85, "pool": 4, "prompts_per_gpu": P,
                        "steps_measured": steps_done, "logits_dtype": "bf16",
-                       "weights": "random-init (no network for checkpoints); acceptance is what these weights give"},
+                       "weights": "random-init (no network for checkpoints); acceptance is what these weights give",
+                       "gemm_selection": "TunableOp table jacobiforcing_amd/tunableop_mi355x.csv (hipBLASLt/rocBLAS picks for "
+                                         "M=64..512; row length padded to a multiple of 8)" if tuned else "library default"},
         }
         if roof is not None:
             out["roofline"] = {"bound": "hbm", "achieved": roof["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -367,9 +367,9 @@ extern "C" int jf_argmax_partial(const void *logits, int dtype, int64_t R, int64
     unsigned long long *pk = (unsigned long long *)packed;
     // Measured on MI355X (profiles/argmax_microbench_r01.txt): big problems stream best as ~1 wavefront per SIMD
     // (1024 items, each a long contiguous range with 8 x 16 B per lane in flight: 6.8 TB/s fp32 at R>=512);
-    // small ones (< 48 MB) are launch/ramp bound and prefer 4-wave workgroups sharing a chunk.
+    // small ones (< 72 MB) are launch/ramp bound and prefer 4-wave workgroups sharing a chunk.
     const int64_t bytes = R * V * esz;
-    const bool wave_mode = vec && env_i64("JF_ARGMAX_WAVE", bytes >= (48ll << 20) ? 1 : 0) != 0;
+    const bool wave_mode = vec && env_i64("JF_ARGMAX_WAVE", bytes >= (72ll << 20) ? 1 : 0) != 0;
     const bool deep = env_i64("JF_ARGMAX_UNROLL", 8) >= 8;
     if (wave_mode) {
         // one item per wavefront, one wavefront per SIMD (256 CUs x 4 SIMDs)

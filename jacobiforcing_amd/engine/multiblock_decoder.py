@@ -58,7 +58,7 @@ LogitsHook = Callable[[torch.Tensor, "MultiblockJacobiDecoder"], torch.Tensor]
 
 class MultiblockJacobiDecoder:
     def __init__(self, model: Qwen2Model, num_prompts: int, params: ops.MultiblockParams, max_seq_len: int = 4096,
-                 logits_hook: Optional[LogitsHook] = None):
+                 logits_hook: Optional[LogitsHook] = None, t_align: int = 1):
         self.model = model
         self.P = int(num_prompts)
         self.params = params
@@ -69,6 +69,7 @@ class MultiblockJacobiDecoder:
                                    dtype=model.dtype)
         self.max_seq_len = max_seq_len
         self.logits_hook = logits_hook
+        self.t_align = int(t_align)          # pad the per-iteration row length to a multiple (tuned-GEMM shape grid)
         self.kv_len_host = np.zeros(self.P, dtype=np.int64)
         self.forwards = 0
         self.last_logits_rows = 0
@@ -104,7 +105,7 @@ class MultiblockJacobiDecoder:
     @torch.inference_mode()
     def iteration(self, d: np.ndarray) -> np.ndarray:
         """forward -> verify/accept/re-draft (HIP) -> KV commit.  ``d`` is the current descriptor table."""
-        packed_in = self.batch.pack(d)
+        packed_in = self.batch.pack(d, self.t_align)
         if packed_in is None:
             return d
         ids, pos, row_prompt, row_len = packed_in

@@ -169,13 +169,15 @@ class MultiblockBatch:
                                     _ptr(kv_len), _ptr(self.desc_dev), _stream(self.device)), "jf_mb_begin")
         return self._read_desc()
 
-    def pack(self, d: np.ndarray):
+    def pack(self, d: np.ndarray, t_align: int = 1):
         """Forward inputs of the current iteration (MB:417-436): returns (input_ids [R,Tpad], positions [R,Tpad],
-        row_prompt [R], row_len [R])."""
+        row_prompt [R], row_len [R]).  ``t_align`` rounds the padded row length up (keeps GEMM shapes on a small grid)."""
         B = self.desc_field(d, "B")
         T = self.desc_field(d, "T")
         self.Rtot = int(B.sum())
         self.Tpad = int(T.max()) if self.Rtot else 0
+        if t_align > 1 and self.Tpad:
+            self.Tpad = min(((self.Tpad + t_align - 1) // t_align) * t_align, self.max_tokens)
         if self.Rtot == 0:
             return None
         fill = self.params.pad_token_id if self.params.pad_token_id is not None else 0
