@@ -163,6 +163,19 @@ int jf_kv_append(void *k_cache, void *v_cache, const void *k_new, const void *v_
                  const int64_t *slot, int64_t N, int32_t H_kv, int32_t D, int64_t S_max,
                  int64_t k_tok_stride, int64_t v_tok_stride, int32_t elem_bytes, void *stream);
 
+/* Fused RoPE + Q re-layout + KV append for one layer (what the reference's forward does in three steps:
+ * apply_rotary_pos_emb, the Triton store_kvcache_kernel ATT:10-40, and the attention input transpose).
+ *   qkv        [N, (nq + 2*nkv) * D] the fused projection output, token-major (N = R*T tokens, token i = r*T + t)
+ *   positions  [N] int32 absolute positions; cos/sin [max_pos, D/2] float32 tables (rotate-half convention)
+ *   q_out      [R, nkv, (nq/nkv)*T, D]: rotated queries grouped by KV head (query row = g*T + t)
+ *   K (rotated) and V rows are written to the main cache at slot_main[i] and, when cand caches are given, to the
+ *   candidate scratch at slot_cand[i] (slot = row * S_max|T_max + position; -1 skips).
+ * dtype JF_F32 or JF_BF16 for qkv / q_out / caches. */
+int jf_rope_kv_append(const void *qkv, int dtype, int64_t N, int32_t T, int32_t nq, int32_t nkv, int32_t D,
+                      const int32_t *positions, const float *cos_table, const float *sin_table, void *q_out,
+                      void *k_cache, void *v_cache, const int64_t *slot_main, int64_t S_max,
+                      void *k_cand, void *v_cand, const int64_t *slot_cand, int64_t T_max, void *stream);
+
 /* commit accepted candidate rows: for prompt p copy desc[p].kv_copy_len token rows from the
  * candidate scratch cand[(p*cand_rows + kv_src_row-1), :, 0:len] to main[p, :, kv_copy_dst: +len],
  * for K and V of `layers` layers (pointer arrays live in device memory). */

@@ -579,6 +579,99 @@ extern "C" int jf_kv_append(void *k_cache, void *v_cache, const void *k_new, con
     return check_launch("kv_append_kernel");
 }
 
+// ---- fused RoPE + Q re-layout + KV append (one launch per layer instead of ~10 elementwise launches) -------------
+template <typename T> __device__ __forceinline__ float ld_f(const T *p);
+template <> __device__ __forceinline__ float ld_f<float>(const float *p) { return *p; }
+template <> __device__ __forceinline__ float ld_f<uint16_t>(const uint16_t *p) { return __uint_as_float(((uint32_t)*p) << 16); }
+template <typename T> __device__ __forceinline__ void st_f(T *p, float v);
+template <> __device__ __forceinline__ void st_f<float>(float *p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st_f<uint16_t>(uint16_t *p, float v) {      // round-to-nearest-even like torch
+    uint32_t u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) { *p = 0x7FC0; return; }
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    *p = (uint16_t)(u >> 16);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rope_kv_append_kernel(const T *__restrict__ qkv, int64_t N, int Tlen, int nq, int nkv, int D,
+                                                              const int32_t *__restrict__ positions, const float *__restrict__ cos_t,
+                                                              const float *__restrict__ sin_t, T *__restrict__ q_out,
+                                                              T *__restrict__ k_cache, T *__restrict__ v_cache,
+                                                              const int64_t *__restrict__ slot_main, int64_t S_max,
+                                                              T *__restrict__ k_cand, T *__restrict__ v_cand,
+                                                              const int64_t *__restrict__ slot_cand, int64_t T_max) {
+    const int half = D >> 1;
+    const int heads = nq + 2 * nkv;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = N * heads * half;
+    if (gid >= total) return;
+    const int i = (int)(gid % half);
+    const int64_t th = gid / half;
+    const int h = (int)(th % heads);
+    const int64_t tok = th / heads;
+    const T *src = qkv + (tok * heads + h) * D;
+    const float x1 = ld_f(src + i), x2 = ld_f(src + half + i);
+    float o1 = x1, o2 = x2;
+    if (h < nq + nkv) {                                   // rotate q and k heads, v passes through
+        const int64_t pos = positions[tok];
+        const float c = cos_t[pos * half + i], sn = sin_t[pos * half + i];
+        o1 = x1 * c - x2 * sn;
+        o2 = x2 * c + x1 * sn;
+    }
+    if (h < nq) {
+        const int G = nq / nkv;
+        const int kvh = h / G, g = h - kvh * G;
+        const int64_t r = tok / Tlen, t = tok - r * Tlen;
+        T *dst = q_out + (((r * nkv + kvh) * (int64_t)G * Tlen) + (int64_t)g * Tlen + t) * D;
+        st_f(dst + i, o1);
+        st_f(dst + half + i, o2);
+        return;
+    }
+    const bool is_v = h >= nq + nkv;
+    const int kvh = is_v ? h - nq - nkv : h - nq;
+    const int64_t sm = slot_main[tok];
+    if (sm >= 0) {
+        const int64_t brow = sm / S_max, pos = sm - brow * S_max;
+        T *dst = (is_v ? v_cache : k_cache) + ((brow * nkv + kvh) * S_max + pos) * D;
+        st_f(dst + i, o1);
+        st_f(dst + half + i, o2);
+    }
+    if (slot_cand) {
+        const int64_t sc = slot_cand[tok];
+        if (sc >= 0) {
+            const int64_t brow = sc / T_max, pos = sc - brow * T_max;
+            T *dst = (is_v ? v_cand : k_cand) + ((brow * nkv + kvh) * T_max + pos) * D;
+            st_f(dst + i, o1);
+            st_f(dst + half + i, o2);
+        }
+    }
+}
+
+extern "C" int jf_rope_kv_append(const void *qkv, int dtype, int64_t N, int32_t T, int32_t nq, int32_t nkv, int32_t D,
+                                 const int32_t *positions, const float *cos_table, const float *sin_table, void *q_out,
+                                 void *k_cache, void *v_cache, const int64_t *slot_main, int64_t S_max, void *k_cand,
+                                 void *v_cand, const int64_t *slot_cand, int64_t T_max, void *stream) {
+    if (N <= 0) return JF_OK;
+    if (!qkv || !positions || !cos_table || !sin_table || !q_out || !k_cache || !v_cache || !slot_main)
+        return fail(JF_E_INVALID, "jf_rope_kv_append: null pointer");
+    if (T <= 0 || N % T != 0 || nq <= 0 || nkv <= 0 || nq % nkv != 0 || D <= 0 || (D & 1) || S_max <= 0)
+        return fail(JF_E_INVALID, "jf_rope_kv_append: bad shape N=%lld T=%d nq=%d nkv=%d D=%d", (long long)N, T, nq, nkv, D);
+    if (slot_cand && (!k_cand || !v_cand || T_max <= 0)) return fail(JF_E_INVALID, "jf_rope_kv_append: candidate cache missing");
+    const int64_t total = N * (nq + 2 * nkv) * (D / 2);
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == JF_F32)
+        rope_kv_append_kernel<float><<<grid, block, 0, s>>>((const float *)qkv, N, T, nq, nkv, D, positions, cos_table, sin_table,
+                                                         (float *)q_out, (float *)k_cache, (float *)v_cache, slot_main, S_max,
+                                                         (float *)k_cand, (float *)v_cand, slot_cand, T_max);
+    else if (dtype == JF_BF16)
+        rope_kv_append_kernel<uint16_t><<<grid, block, 0, s>>>((const uint16_t *)qkv, N, T, nq, nkv, D, positions, cos_table, sin_table,
+                                                            (uint16_t *)q_out, (uint16_t *)k_cache, (uint16_t *)v_cache, slot_main,
+                                                            S_max, (uint16_t *)k_cand, (uint16_t *)v_cand, slot_cand, T_max);
+    else return fail(JF_E_INVALID, "jf_rope_kv_append: dtype %d", dtype);
+    return check_launch("rope_kv_append_kernel");
+}
+
 __global__ __launch_bounds__(256) void kv_commit_kernel(void *const *main_k, void *const *main_v, void *const *cand_k,
                                                          void *const *cand_v, const jf_mb_desc *desc, int cand_rows, int H_kv,
                                                          int vec_per_row, int64_t S_max, int64_t T_max) {

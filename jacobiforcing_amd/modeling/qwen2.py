@@ -207,19 +207,17 @@ class Qwen2Model:
                 tail_idx = (kvl[cr].view(-1, 1) + ar_t.view(1, T)).clamp_(max=S_cur - 1)          # [C,T]
                 tail_idx = tail_idx.view(-1, 1, T, 1).expand(-1, nkv, T, hd)
                 crc = row_cand[cr].long()
-        cos = self.cos[pos].to(self.dtype).unsqueeze(2)                               # [R,T,1,hd/2], shared by all layers
-        sin = self.sin[pos].to(self.dtype).unsqueeze(2)
+        pos32 = positions.to(torch.int32).reshape(-1).contiguous()
         direct = (not any_candidates) and R == cache.P                               # row r is prompt r: attend in place
 
         x = w.embed[input_ids]                                                        # [R,T,H]
         for li, L in enumerate(w.layers):
-            qkv = F.linear(self._norm(x, L["ln1"]), L["wqkv"], L["bqkv"]).view(R, T, nq + 2 * nkv, hd)
-            qk = self._rope(qkv[:, :, :nq + nkv], cos, sin)                           # q and k in one pass
-            k = qk.view(R * T, nq + nkv, hd)[:, nq:]
-            v = qkv.view(R * T, nq + 2 * nkv, hd)[:, nq + nkv:]
-            ops.kv_append(cache.k[li], cache.v[li], k, v, slot_main)                  # a18: append (row 0 of each prompt)
+            qkv = F.linear(self._norm(x, L["ln1"]), L["wqkv"], L["bqkv"]).view(R * T, (nq + 2 * nkv) * hd)
+            # one HIP launch: RoPE on q/k, queries re-laid out per KV head, K/V rows appended to the cache(s) (a18)
+            qh = ops.rope_kv_append(qkv, T, nq, nkv, hd, pos32, self.cos, self.sin, cache.k[li], cache.v[li], slot_main,
+                                    cache.ck[li] if any_candidates else None, cache.cv[li] if any_candidates else None,
+                                    slot_cand if any_candidates else None)
             if any_candidates:
-                ops.kv_append(cache.ck[li], cache.cv[li], k, v, slot_cand)
                 Kf = cache.k[li][rp, :, :S_cur]                                       # [R,nkv,S,hd] gathered prefix (+ row-0 tail)
                 Vf = cache.v[li][rp, :, :S_cur]
                 if cr.numel():
@@ -230,7 +228,6 @@ class Qwen2Model:
                 Kf, Vf = cache.k[li][:, :, :S_cur], cache.v[li][:, :, :S_cur]
             else:
                 Kf, Vf = cache.k[li][rp, :, :S_cur], cache.v[li][rp, :, :S_cur]
-            qh = qk[:, :, :nq].view(R, T, nkv, G, hd).permute(0, 2, 3, 1, 4).reshape(R, nkv, G * T, hd)
             o = F.scaled_dot_product_attention(qh, Kf, Vf, attn_mask=mask)
             o = o.view(R, nkv, G, T, hd).permute(0, 3, 1, 2, 4).reshape(R, T, nq * hd)
             x = x + F.linear(o, L["wo"])

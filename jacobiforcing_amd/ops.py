@@ -236,6 +236,29 @@ def kv_append(k_cache: torch.Tensor, v_cache: torch.Tensor, k_new: torch.Tensor,
                                  ks, vs, k_cache.element_size(), _stream(k_cache.device)), "jf_kv_append")
 
 
+def rope_kv_append(qkv: torch.Tensor, T: int, nq: int, nkv: int, D: int, positions: torch.Tensor, cos: torch.Tensor,
+                   sin: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, slot_main: torch.Tensor,
+                   k_cand: Optional[torch.Tensor] = None, v_cand: Optional[torch.Tensor] = None,
+                   slot_cand: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Fused RoPE + query re-layout + KV append of one layer.  qkv [N, (nq+2nkv)*D] contiguous; returns q [R, nkv, G*T, D]."""
+    Ntok = qkv.shape[0]
+    if not qkv.is_contiguous() or qkv.shape[1] != (nq + 2 * nkv) * D:
+        raise ValueError("rope_kv_append: qkv must be contiguous [N, (nq+2nkv)*D]")
+    if positions.dtype != torch.int32 or positions.numel() != Ntok or not positions.is_contiguous():
+        raise ValueError("rope_kv_append: positions must be contiguous int32 [N]")
+    R = Ntok // T
+    G = nq // nkv
+    q = torch.empty((R, nkv, G * T, D), dtype=qkv.dtype, device=qkv.device)
+    S_max = k_cache.shape[2]
+    T_max = k_cand.shape[2] if k_cand is not None else 0
+    N.check(N.lib().jf_rope_kv_append(_ptr(qkv), _dtype_code(qkv), Ntok, T, nq, nkv, D, _ptr(positions), _ptr(cos), _ptr(sin), _ptr(q),
+                                      _ptr(k_cache), _ptr(v_cache), _ptr(slot_main), S_max,
+                                      _ptr(k_cand) if slot_cand is not None else None,
+                                      _ptr(v_cand) if slot_cand is not None else None, _ptr(slot_cand), T_max,
+                                      _stream(qkv.device)), "jf_rope_kv_append")
+    return q
+
+
 class KVCommitter:
     """Holds the per-layer pointer tables for jf_kv_commit (candidate row -> committed row, MB:500-502)."""
 

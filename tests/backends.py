@@ -145,6 +145,45 @@ class HostSimLib:
                     C.memmove(dst0 + ((brow * H + h) * S_max + pos) * rowb, src0 + (i * tstride + h * D) * esz, rowb)
         return 0
 
+    def jf_rope_kv_append(self, qkv, dtype, Ntok, T, nq, nkv, D, positions, cos_t, sin_t, q_out, k_cache, v_cache, slot_main,
+                          S_max, k_cand, v_cand, slot_cand, T_max, stream):
+        heads, half = nq + 2 * nkv, D // 2
+        if dtype == N.JF_F32:
+            x = _view(qkv, Ntok * heads * D, np.float32).reshape(Ntok, heads, D).astype(np.float32)
+        else:
+            x = O.bf16_bits_to_f32(_view(qkv, Ntok * heads * D, np.uint16)).reshape(Ntok, heads, D)
+        pos = _view(positions, Ntok, np.int32).astype(np.int64)
+        mp = int(pos.max()) + 1
+        cos = _view(cos_t, mp * half, np.float32).reshape(mp, half)[pos][:, None, :]
+        sin = _view(sin_t, mp * half, np.float32).reshape(mp, half)[pos][:, None, :]
+        x1, x2 = x[..., :half], x[..., half:]
+        rot = np.concatenate([x1 * cos - x2 * sin, x2 * cos + x1 * sin], axis=-1).astype(np.float32)
+        out = np.where((np.arange(heads) < nq + nkv)[None, :, None], rot, x).astype(np.float32)
+        esz = 4 if dtype == N.JF_F32 else 2
+
+        def enc(a):
+            return a.astype(np.float32) if dtype == N.JF_F32 else O.f32_to_bf16_bits(a.astype(np.float32))
+        R, G = Ntok // T, nq // nkv
+        q = out[:, :nq].reshape(R, T, nkv, G, D).transpose(0, 2, 3, 1, 4).reshape(-1)
+        _view(q_out, q.size, np.float32 if dtype == N.JF_F32 else np.uint16)[:] = enc(q)
+        rowb = D * esz
+
+        def scatter(kc, vc, slots, cap):
+            sl = _view(slots, Ntok, np.int64)
+            for i in range(Ntok):
+                s_ = int(sl[i])
+                if s_ < 0:
+                    continue
+                brow, p_ = divmod(s_, cap)
+                for h in range(nkv):
+                    for base, src in ((_addr(kc), out[i, nq + h]), (_addr(vc), out[i, nq + nkv + h])):
+                        buf = np.ascontiguousarray(enc(src))
+                        C.memmove(base + ((brow * nkv + h) * cap + p_) * rowb, buf.ctypes.data, rowb)
+        scatter(k_cache, v_cache, slot_main, S_max)
+        if _addr(slot_cand):
+            scatter(k_cand, v_cand, slot_cand, T_max)
+        return 0
+
     def jf_kv_commit(self, main_k, main_v, cand_k, cand_v, layers, desc, P, cand_rows, H, D, S_max, T_max, esz, stream):
         rowb = D * esz
         tabs = [_view(t, layers, np.int64) for t in (main_k, main_v, cand_k, cand_v)]

@@ -262,3 +262,37 @@ def test_rs_probs_vs_torch_softmax(dtype, temperature):
     assert torch.allclose(got, want, rtol=2e-5, atol=1e-12), float(((got - want).abs() / want).max())
     am = (~packed.cpu()) & 0xFFFFFFFF
     assert am.tolist() == torch.argmax(x.float(), dim=-1).tolist()
+
+
+# ------------------------------------------------------------------------------------- fused RoPE + Q layout + KV append
+@GPU
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_rope_kv_append_matches_torch(dtype):
+    R, T, nq, nkv, D, S_max, T_max = 3, 5, 8, 2, 32, 40, 8
+    g = torch.Generator().manual_seed(6)
+    qkv = torch.randn(R * T, (nq + 2 * nkv) * D, generator=g).to(dtype).cuda()
+    pos = torch.randint(0, 30, (R * T,), generator=g, dtype=torch.int32)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
+    fr = torch.outer(torch.arange(64, dtype=torch.float32), inv)
+    cos, sin = fr.cos().cuda(), fr.sin().cuda()
+    kc = torch.zeros(2, nkv, S_max, D, dtype=dtype, device="cuda"); vc = torch.zeros_like(kc)
+    ck = torch.zeros(3, nkv, T_max, D, dtype=dtype, device="cuda"); cv = torch.zeros_like(ck)
+    slot_main = torch.full((R * T,), -1, dtype=torch.int64); slot_cand = torch.full((R * T,), -1, dtype=torch.int64)
+    slot_main[:T] = 1 * S_max + 7 + torch.arange(T)                 # row 0 of "prompt 1" appends at 7..
+    slot_cand[T:2 * T] = 2 * T_max + torch.arange(T)                # a candidate row writes the scratch
+    q = ops.rope_kv_append(qkv, T, nq, nkv, D, pos.cuda(), cos, sin, kc, vc, slot_main.cuda(), ck, cv, slot_cand.cuda())
+    x = qkv.float().cpu().view(R * T, nq + 2 * nkv, D)
+    c, s_ = fr.cos()[pos.long()][:, None, :], fr.sin()[pos.long()][:, None, :]
+    x1, x2 = x[..., :D // 2], x[..., D // 2:]
+    rot = torch.cat([x1 * c - x2 * s_, x2 * c + x1 * s_], -1)
+    G = nq // nkv
+    q_ref = rot[:, :nq].view(R, T, nkv, G, D).permute(0, 2, 3, 1, 4).reshape(R, nkv, G * T, D).to(dtype)
+    tol = dict(atol=0, rtol=0) if dtype == torch.float32 else dict(atol=1e-2, rtol=1e-2)
+    assert torch.allclose(q.cpu().float(), q_ref.float(), **tol)
+    k_ref, v_ref = rot[:, nq:nq + nkv].to(dtype), x[:, nq + nkv:].to(dtype)
+    for t in range(T):
+        assert torch.allclose(kc[1, :, 7 + t].cpu().float(), k_ref[t].float(), **tol)
+        assert torch.equal(vc[1, :, 7 + t].cpu(), v_ref[t])
+        assert torch.allclose(ck[2, :, t].cpu().float(), k_ref[T + t].float(), **tol)
+        assert torch.equal(cv[2, :, t].cpu(), v_ref[T + t])
+    assert float(kc[0].abs().sum()) == 0 and float(ck[:2].abs().sum()) == 0
