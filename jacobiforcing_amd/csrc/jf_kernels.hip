@@ -485,6 +485,7 @@ static int check_params(const jf_mb_params *p, const char *who) {
     if (p->K < 1) return fail(JF_E_INVALID, "%s: K=%d", who, p->K);
     if (p->pool_size < 0 || p->pool_size > 64) return fail(JF_E_INVALID, "%s: pool_size=%d out of range [0,64]", who, p->pool_size);
     if (p->max_iter < 0) return fail(JF_E_INVALID, "%s: max_iter=%d", who, p->max_iter);
+    if (p->max_blocks > jfmb::MAX_NB || p->K > jfmb::MAX_NB) return fail(JF_E_INVALID, "%s: max_blocks=%d too large", who, p->max_blocks);
     return JF_OK;
 }
 

@@ -32,15 +32,15 @@ enum : int {
     H_NUM_BLOCKS, H_ACTIVE, H_RA, H_LEN_LISTS, H_LNT, H_HAS_LNT, H_ITERS, H_DONE, // MB:249-262
     H_RET_EARLY, H_ERR, H_PROMPT_LEN, H_KV_LEN, H_POOL_COUNT, H_POOL_HEAD,
     H_RET_LEN, H_NEXT_TOK, H_B, H_T, H_NSPANS, H_ROW_BASE, H_TPAD,
-    H_SPANS = 40,            // 3 ints per span (block, start, L), up to NB spans
-    H_END = 40 + 3 * 16
+    H_SPANS = 40             // 3 ints per span (block, start, L), NB spans follow the fixed header
 };
-constexpr int MAX_NB = 16;
+constexpr int MAX_NB = 4096; // sanity bound only; the block lists can grow by one entry per iteration (Q3/Q4 with K >= 3)
 
 enum : int { EVT_SPAWN = 1, EVT_SWITCH = 2, EVT_EARLY = 4 };
 
 struct Layout {
     int n, NB, RMAX, TMAX, LPOOL, pool_size;
+    int hdr_ints;     // fixed header + 3 * NB span slots
     int blk_stride;   // per block: [need_reverify, total_acc, acc_len, draft_rows, draft_len, rsv*3] + out_acc[n+1] + draft[RMAX][n]
     int off_blocks, off_pool, off_out, off_ret, total;
 };
@@ -57,7 +57,8 @@ JF_HD Layout make_layout(int n, int K, int pool_size, int max_blocks) {
     L.LPOOL = L.NB * n;                   // concat of all blocks (MB:387-411)
     L.pool_size = pool_size;
     L.blk_stride = 8 + (n + 1) + L.RMAX * n;
-    L.off_blocks = H_END;
+    L.hdr_ints = H_SPANS + 3 * L.NB;
+    L.off_blocks = L.hdr_ints;
     L.off_pool = L.off_blocks + L.NB * L.blk_stride;
     L.off_out = L.off_pool + imax(pool_size, 0) * (1 + L.LPOOL);
     L.off_ret = L.off_out + L.RMAX * L.TMAX;
@@ -212,7 +213,7 @@ struct Machine {
     template <class TokFn>
     JF_HD void begin(const jf_mb_params &p, TokFn input_tok, int kv0, jf_mb_desc *d) {
         if (lanes.lane() == 0) {
-            for (int i = 0; i < H_END; ++i) S[i] = 0;
+            for (int i = 0; i < L.hdr_ints; ++i) S[i] = 0;
             S[H_N] = p.n; S[H_K] = p.K; S[H_SPAWN_THR] = p.spawn_threshold; S[H_POOL_SIZE] = p.pool_size;
             S[H_EOS] = p.eos_id; S[H_PAD] = p.pad_id; S[H_MAX_ITER] = p.max_iter; S[H_NB] = L.NB;
             S[H_RMAX] = L.RMAX; S[H_TMAX] = L.TMAX; S[H_LPOOL] = L.LPOOL;

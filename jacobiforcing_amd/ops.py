@@ -102,14 +102,22 @@ class MultiblockParams:
     eos_token_id: Optional[int] = None
     pad_token_id: Optional[int] = None
     max_iteration_count: int = 128
-    max_blocks: int = 8
+    # Capacity of the block lists.  K <= 2 never needs more than a handful (a promotion ends the call, Q3).  With
+    # K >= 3 the reference's counters run away (active_blocks goes negative, Q4) and it spawns one block per iteration,
+    # so exact parity needs 1 + max_iteration_count entries; None picks that automatically.
+    max_blocks: Optional[int] = None
+
+    def _blocks(self) -> int:
+        if self.max_blocks is not None:
+            return int(self.max_blocks)
+        return 8 if self.K <= 2 else 1 + int(self.max_iteration_count)
 
     def to_c(self) -> N.MbParams:
         return N.MbParams(n=int(self.n), K=int(self.K), spawn_threshold=int(math.ceil(self.r * self.n)),  # MB:262
                           pool_size=int(self.n_gram_pool_size),
                           eos_id=-1 if self.eos_token_id is None else int(self.eos_token_id),
                           pad_id=-1 if self.pad_token_id is None else int(self.pad_token_id),
-                          max_iter=int(self.max_iteration_count), max_blocks=int(max(self.max_blocks, self.K)),
+                          max_iter=int(self.max_iteration_count), max_blocks=int(max(self._blocks(), self.K)),
                           lookahead_start_ratio=float(self.lookahead_start_ratio))
 
 

@@ -21,7 +21,7 @@ MB = load_golden("mb_cases.json")
 BACKENDS = [pytest.param("hostsim", id="hostsim"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
 
 
-def _params(p, max_blocks=8):
+def _params(p, max_blocks=None):
     return ops.MultiblockParams(n=p["n"], K=p["K"], r=p["r"], lookahead_start_ratio=p["lookahead"],
                                 n_gram_pool_size=p["pool"], eos_token_id=p["eos_id"], pad_token_id=p["pad_id"],
                                 max_iteration_count=p["max_iter"], max_blocks=max_blocks)
