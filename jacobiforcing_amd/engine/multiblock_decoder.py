@@ -65,8 +65,10 @@ class MultiblockJacobiDecoder:
         self.device = model.device
         self.batch = ops.MultiblockBatch(self.P, params, self.device)
         self.cand_rows = self.batch.max_rows - 1
-        self.cache = StaticKVCache(model.cfg, self.P, max_seq_len, self.cand_rows, self.batch.max_tokens, self.device,
-                                   dtype=model.dtype)
+        # rows longer than (K+2)*n only occur when the reference's block counters run away; the forward buffers are sized
+        # for the realistic case and a longer row is a capacity error rather than gigabytes of idle scratch
+        self.t_cap = min(self.batch.max_tokens, max(128, (params.K + 2) * params.n))
+        self.cache = StaticKVCache(model.cfg, self.P, max_seq_len, self.cand_rows, self.t_cap, self.device, dtype=model.dtype)
         self.max_seq_len = max_seq_len
         self.logits_hook = logits_hook
         self.t_align = int(t_align)          # pad the per-iteration row length to a multiple (tuned-GEMM shape grid)
@@ -109,6 +111,9 @@ class MultiblockJacobiDecoder:
         if packed_in is None:
             return d
         ids, pos, row_prompt, row_len = packed_in
+        if ids.shape[1] > self.t_cap:
+            raise RuntimeError(f"a row of {ids.shape[1]} tokens exceeds the forward capacity {self.t_cap} "
+                               "(the block counters ran away, see DESIGN.md §3.2)")
         B = d[:, self._f["B"]]
         any_cand = bool((B > 1).any())
         dev = self.device

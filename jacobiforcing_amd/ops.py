@@ -102,15 +102,16 @@ class MultiblockParams:
     eos_token_id: Optional[int] = None
     pad_token_id: Optional[int] = None
     max_iteration_count: int = 128
-    # Capacity of the block lists.  K <= 2 never needs more than a handful (a promotion ends the call, Q3).  With
-    # K >= 3 the reference's counters run away (active_blocks goes negative, Q4) and it spawns one block per iteration,
-    # so exact parity needs 1 + max_iteration_count entries; None picks that automatically.
+    # Capacity of the block lists.  The reference's counters can run away (active_blocks goes negative, Q4: K >= 3, or
+    # K = 2 with a pseudo block that made no progress when the RA block filled) and it then spawns one block per
+    # iteration, so exact parity needs 1 + max_iteration_count entries; None picks that (~240 KB of state per prompt
+    # at n = 32).  A smaller value turns such runs into a capacity RuntimeError.
     max_blocks: Optional[int] = None
 
     def _blocks(self) -> int:
         if self.max_blocks is not None:
             return int(self.max_blocks)
-        return 8 if self.K <= 2 else 1 + int(self.max_iteration_count)
+        return 1 + int(self.max_iteration_count)
 
     def to_c(self) -> N.MbParams:
         return N.MbParams(n=int(self.n), K=int(self.K), spawn_threshold=int(math.ceil(self.r * self.n)),  # MB:262
