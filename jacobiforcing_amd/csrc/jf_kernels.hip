@@ -214,6 +214,59 @@ template <> struct FastTrack<JF_BF16> {
     }
 };
 
+// Software-pipelined scan of `nvec` 16-byte vectors starting at q (lane-strided by STR vectors): two register sets of
+// eight vectors; the loads of set B are issued before set A is consumed and vice versa, so a wavefront keeps 8-16 KB in
+// flight at all times instead of draining between batches.  The last pair is peeled so every load in the loop body is
+// unconditional (a conditional load would make the compiler wait for vmcnt(0)).
+template <int DT, int STR>
+__device__ __forceinline__ void scan_pipelined(FastTrack<DT> &ft, const u32x4 *q, int k, int nvec, uint32_t ebase) {
+    constexpr int EPV = Elem<DT>::EPV;
+    constexpr int BATCH = 8 * STR;
+    const int nfull = (nvec > k + 7 * STR) ? ((nvec - k - 7 * STR - 1) / BATCH + 1) : 0;
+    const int npairs = nfull >> 1;
+    u32x4 A[8], B[8];
+    if (npairs >= 1) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) A[u] = __builtin_nontemporal_load(q + u * STR);
+        for (int p = 0; p < npairs - 1; ++p) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) B[u] = __builtin_nontemporal_load(q + BATCH + u * STR);
+            __builtin_amdgcn_sched_barrier(0);          // keep the loads of the next set ABOVE the compare chain
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ft.consume(A[u], ebase + (uint32_t)(k + u * STR) * EPV);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) A[u] = __builtin_nontemporal_load(q + 2 * BATCH + u * STR);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ft.consume(B[u], ebase + (uint32_t)(k + BATCH + u * STR) * EPV);
+            __builtin_amdgcn_sched_barrier(0);
+            q += 2 * BATCH;
+            k += 2 * BATCH;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) B[u] = __builtin_nontemporal_load(q + BATCH + u * STR);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ft.consume(A[u], ebase + (uint32_t)(k + u * STR) * EPV);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ft.consume(B[u], ebase + (uint32_t)(k + BATCH + u * STR) * EPV);
+        q += 2 * BATCH;
+        k += 2 * BATCH;
+    }
+    if (nfull & 1) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) A[u] = __builtin_nontemporal_load(q + u * STR);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ft.consume(A[u], ebase + (uint32_t)(k + u * STR) * EPV);
+        q += BATCH;
+        k += BATCH;
+    }
+    for (; k < nvec; k += STR, q += STR) {
+        const u32x4 v0 = __builtin_nontemporal_load(q);
+        ft.consume(v0, ebase + (uint32_t)k * EPV);
+    }
+}
+
 // VEC: rows are 16-byte aligned -> 16 B per lane per load, UNROLL independent loads in flight per lane
 // (4 or 8 KB per wavefront), one compare chain per 16-byte vector.  All loop arithmetic is 32-bit.
 template <int DT, bool VEC, int UNROLL>
@@ -238,16 +291,20 @@ __global__ __launch_bounds__(AM_TPB) void argmax_partial_kernel(const void *__re
         const int nvec = (int)((end - begin) / EPV);                  // full 16-byte vectors in this chunk
         const u32x4 *q = (const u32x4 *)p + (begin / EPV) + tid;
         int k = tid;
-        for (; k + (UNROLL - 1) * AM_TPB < nvec; k += UNROLL * AM_TPB, q += UNROLL * AM_TPB) {
-            u32x4 v[UNROLL];
+        if constexpr (UNROLL == 16) {
+            scan_pipelined<DT, AM_TPB>(ft, q, k, nvec, ebase);
+        } else {
+            for (; k + (UNROLL - 1) * AM_TPB < nvec; k += UNROLL * AM_TPB, q += UNROLL * AM_TPB) {
+                u32x4 v[UNROLL];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(q + u * AM_TPB);
+                for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(q + u * AM_TPB);
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) ft.consume(v[u], ebase + (uint32_t)(k + u * AM_TPB) * EPV);
-        }
-        for (; k < nvec; k += AM_TPB, q += AM_TPB) {
-            const u32x4 v0 = __builtin_nontemporal_load(q);
-            ft.consume(v0, ebase + (uint32_t)k * EPV);
+                for (int u = 0; u < UNROLL; ++u) ft.consume(v[u], ebase + (uint32_t)(k + u * AM_TPB) * EPV);
+            }
+            for (; k < nvec; k += AM_TPB, q += AM_TPB) {
+                const u32x4 v0 = __builtin_nontemporal_load(q);
+                ft.consume(v0, ebase + (uint32_t)k * EPV);
+            }
         }
         const int64_t vec_end = begin + ((end - begin) / EPV) * EPV;
         if (__syncthreads_or(ft.saw_nan() ? 1 : 0)) {
@@ -297,16 +354,20 @@ __global__ __launch_bounds__(AM_TPB) void argmax_wave_kernel(const void *__restr
     const int nvec = (int)((end - begin) / EPV);
     const u32x4 *q = (const u32x4 *)p + (begin / EPV) + lane;
     int k = lane;
-    for (; k + (UNROLL - 1) * 64 < nvec; k += UNROLL * 64, q += UNROLL * 64) {
-        u32x4 v[UNROLL];
+    if constexpr (UNROLL == 16) {
+        scan_pipelined<DT, 64>(ft, q, k, nvec, ebase);
+    } else {
+        for (; k + (UNROLL - 1) * 64 < nvec; k += UNROLL * 64, q += UNROLL * 64) {
+            u32x4 v[UNROLL];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(q + u * 64);
+            for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(q + u * 64);
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) ft.consume(v[u], ebase + (uint32_t)(k + u * 64) * EPV);
-    }
-    for (; k < nvec; k += 64, q += 64) {
-        const u32x4 v0 = __builtin_nontemporal_load(q);
-        ft.consume(v0, ebase + (uint32_t)k * EPV);
+            for (int u = 0; u < UNROLL; ++u) ft.consume(v[u], ebase + (uint32_t)(k + u * 64) * EPV);
+        }
+        for (; k < nvec; k += 64, q += 64) {
+            const u32x4 v0 = __builtin_nontemporal_load(q);
+            ft.consume(v0, ebase + (uint32_t)k * EPV);
+        }
     }
     uint32_t best = 0u, bidx = 0xFFFFFFFFu;
     const int64_t vec_end = begin + (int64_t)nvec * EPV;
@@ -370,7 +431,9 @@ extern "C" int jf_argmax_partial(const void *logits, int dtype, int64_t R, int64
     // small ones (< 72 MB) are launch/ramp bound and prefer 4-wave workgroups sharing a chunk.
     const int64_t bytes = R * V * esz;
     const bool wave_mode = vec && env_i64("JF_ARGMAX_WAVE", bytes >= (72ll << 20) ? 1 : 0) != 0;
-    const bool deep = env_i64("JF_ARGMAX_UNROLL", 8) >= 8;
+    const int64_t unroll = env_i64("JF_ARGMAX_UNROLL", 8);       // 4, 8, or 16 (= two pipelined sets of 8)
+    const bool deep = unroll >= 8;
+    const bool pipe = unroll >= 16;
     if (wave_mode) {
         // one item per wavefront, one wavefront per SIMD (256 CUs x 4 SIMDs)
         const int64_t chunk = pick_chunk(64 * epv, R, V, env_i64("JF_ARGMAX_ITEMS", 1024));
@@ -380,8 +443,8 @@ extern "C" int jf_argmax_partial(const void *logits, int dtype, int64_t R, int64
         if (blocks > 0x7FFFFFFFll) return fail(JF_E_CAPACITY, "jf_argmax_partial: grid too large");
         dim3 grid((unsigned)blocks), block(AM_TPB);
 #define JF_LAUNCHW(DT, UNR) argmax_wave_kernel<DT, UNR><<<grid, block, 0, s>>>(logits, R, V, row_stride, pk, (int)cpr, chunk)
-        if (dtype == JF_F32) { if (deep) JF_LAUNCHW(JF_F32, 8); else JF_LAUNCHW(JF_F32, 4); }
-        else { if (deep) JF_LAUNCHW(JF_BF16, 8); else JF_LAUNCHW(JF_BF16, 4); }
+        if (dtype == JF_F32) { if (pipe) JF_LAUNCHW(JF_F32, 16); else if (deep) JF_LAUNCHW(JF_F32, 8); else JF_LAUNCHW(JF_F32, 4); }
+        else { if (pipe) JF_LAUNCHW(JF_BF16, 16); else if (deep) JF_LAUNCHW(JF_BF16, 8); else JF_LAUNCHW(JF_BF16, 4); }
 #undef JF_LAUNCHW
         return check_launch("argmax_wave_kernel");
     }
@@ -393,10 +456,12 @@ extern "C" int jf_argmax_partial(const void *logits, int dtype, int64_t R, int64
 #define JF_LAUNCH(DT, VECF, UNR) argmax_partial_kernel<DT, VECF, UNR><<<grid, block, 0, s>>>(logits, R, V, row_stride, pk, (int)cpr, chunk)
     if (dtype == JF_F32) {
         if (!vec) JF_LAUNCH(JF_F32, false, 4);
+        else if (pipe) JF_LAUNCH(JF_F32, true, 16);
         else if (deep) JF_LAUNCH(JF_F32, true, 8);
         else JF_LAUNCH(JF_F32, true, 4);
     } else {
         if (!vec) JF_LAUNCH(JF_BF16, false, 4);
+        else if (pipe) JF_LAUNCH(JF_BF16, true, 16);
         else if (deep) JF_LAUNCH(JF_BF16, true, 8);
         else JF_LAUNCH(JF_BF16, true, 4);
     }
