@@ -87,7 +87,7 @@ class NativeLibraryError(RuntimeError):
 
 def load(path: os.PathLike | None = None):
     """dlopen the library and attach signatures.  Raises NativeLibraryError when it is missing."""
-    p = Path(path) if path is not None else LIB_PATH
+    p = Path(path) if path is not None else Path(os.environ.get("JF_LIB", LIB_PATH))   # JF_LIB: kernel A/B builds (tools/)
     if not p.exists():
         raise NativeLibraryError(
             f"{p} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "

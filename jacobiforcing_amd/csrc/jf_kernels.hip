@@ -86,6 +86,11 @@ __device__ __forceinline__ uint32_t order_key(uint32_t u) {
 }
 
 constexpr int AM_TPB = 256;
+#ifdef JF_EXP_NO_NT
+#define JF_LOAD(p) (*(p))
+#else
+#define JF_LOAD(p) __builtin_nontemporal_load(p)
+#endif
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <int DT> struct Elem;
@@ -158,21 +163,24 @@ __device__ __forceinline__ int32_t hmin_i16x2(uint32_t a) {
     return lo < hi ? lo : hi;
 }
 
-template <int DT> struct FastTrack;
-template <> struct FastTrack<JF_F32> {
+template <int DT, bool KEEPV> struct FastTrack;
+template <bool KEEPV> struct FastTrack<JF_F32, KEEPV> {
     int32_t best = INT32_MIN, mn = INT32_MAX;
     uint32_t bvec = 0xFFFFFFFFu;
+    u32x4 bv = {0u, 0u, 0u, 0u};     // KEEPV: the best vector itself (saves the end-of-item reload, costs 4 selects per vector)
     __device__ __forceinline__ void consume(const u32x4 v, uint32_t i) {
         const int32_t k0 = skey32(v.x), k1 = skey32(v.y), k2 = skey32(v.z), k3 = skey32(v.w);
         int32_t m = max(max(k0, k1), max(k2, k3));
         mn = min(mn, min(min(k0, k1), min(k2, k3)));
         m = (m == -1) ? 0 : m;
-        if (m > best) { best = m; bvec = i; }
+        if constexpr (KEEPV) { if (m > best) { best = m; bvec = i; bv = v; } }
+        else { if (m > best) { best = m; bvec = i; } }
     }
     __device__ __forceinline__ bool saw_nan() const { return best > (int32_t)0x7F800000 || mn < (int32_t)0x807FFFFF; }
     // first element of the vector at bvec whose canonical key equals best
     __device__ __forceinline__ uint32_t resolve(const void *p) const {
-        const u32x4 v = *(const u32x4 *)((const uint32_t *)p + bvec);
+        u32x4 v;
+        if constexpr (KEEPV) v = bv; else v = *(const u32x4 *)((const uint32_t *)p + bvec);
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         uint32_t j = 3;
 #pragma unroll
@@ -181,21 +189,24 @@ template <> struct FastTrack<JF_F32> {
     }
     __device__ __forceinline__ uint32_t ukey() const { return (uint32_t)best ^ 0x80000000u; }   // == order_key()
 };
-template <> struct FastTrack<JF_BF16> {
+template <bool KEEPV> struct FastTrack<JF_BF16, KEEPV> {
     int32_t best = INT32_MIN;
     uint32_t mnp = 0x7FFF7FFFu;     // packed running min
     uint32_t bvec = 0xFFFFFFFFu;
+    u32x4 bv = {0u, 0u, 0u, 0u};     // KEEPV: the best vector itself (saves the end-of-item reload, costs 4 selects per vector)
     __device__ __forceinline__ void consume(const u32x4 v, uint32_t i) {
         const uint32_t k0 = skey16x2(v.x), k1 = skey16x2(v.y), k2 = skey16x2(v.z), k3 = skey16x2(v.w);
         const uint32_t pm = pk_max_i16(pk_max_i16(k0, k1), pk_max_i16(k2, k3));
         mnp = pk_min_i16(mnp, pk_min_i16(pk_min_i16(k0, k1), pk_min_i16(k2, k3)));
         int32_t m = hmax_i16x2(pm);
         m = (m == -1) ? 0 : m;
-        if (m > best) { best = m; bvec = i; }
+        if constexpr (KEEPV) { if (m > best) { best = m; bvec = i; bv = v; } }
+        else { if (m > best) { best = m; bvec = i; } }
     }
     __device__ __forceinline__ bool saw_nan() const { return best > 0x7F80 || hmin_i16x2(mnp) < (int32_t)(int16_t)0x807F; }
     __device__ __forceinline__ uint32_t resolve(const void *p) const {
-        const u32x4 v = *(const u32x4 *)((const uint16_t *)p + bvec);
+        u32x4 v;
+        if constexpr (KEEPV) v = bv; else v = *(const u32x4 *)((const uint16_t *)p + bvec);
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         uint32_t j = 7;
 #pragma unroll
@@ -218,8 +229,8 @@ template <> struct FastTrack<JF_BF16> {
 // eight vectors; the loads of set B are issued before set A is consumed and vice versa, so a wavefront keeps 8-16 KB in
 // flight at all times instead of draining between batches.  The last pair is peeled so every load in the loop body is
 // unconditional (a conditional load would make the compiler wait for vmcnt(0)).
-template <int DT, int STR>
-__device__ __forceinline__ void scan_pipelined(FastTrack<DT> &ft, const u32x4 *q, int k, int nvec, uint32_t ebase) {
+template <int DT, int STR, class FT>
+__device__ __forceinline__ void scan_pipelined(FT &ft, const u32x4 *q, int k, int nvec, uint32_t ebase) {
     constexpr int EPV = Elem<DT>::EPV;
     constexpr int BATCH = 8 * STR;
     const int nfull = (nvec > k + 7 * STR) ? ((nvec - k - 7 * STR - 1) / BATCH + 1) : 0;
@@ -227,16 +238,16 @@ __device__ __forceinline__ void scan_pipelined(FastTrack<DT> &ft, const u32x4 *q
     u32x4 A[8], B[8];
     if (npairs >= 1) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) A[u] = __builtin_nontemporal_load(q + u * STR);
+        for (int u = 0; u < 8; ++u) A[u] = JF_LOAD(q + u * STR);
         for (int p = 0; p < npairs - 1; ++p) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) B[u] = __builtin_nontemporal_load(q + BATCH + u * STR);
+            for (int u = 0; u < 8; ++u) B[u] = JF_LOAD(q + BATCH + u * STR);
             __builtin_amdgcn_sched_barrier(0);          // keep the loads of the next set ABOVE the compare chain
 #pragma unroll
             for (int u = 0; u < 8; ++u) ft.consume(A[u], ebase + (uint32_t)(k + u * STR) * EPV);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) A[u] = __builtin_nontemporal_load(q + 2 * BATCH + u * STR);
+            for (int u = 0; u < 8; ++u) A[u] = JF_LOAD(q + 2 * BATCH + u * STR);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 8; ++u) ft.consume(B[u], ebase + (uint32_t)(k + BATCH + u * STR) * EPV);
@@ -245,7 +256,7 @@ __device__ __forceinline__ void scan_pipelined(FastTrack<DT> &ft, const u32x4 *q
             k += 2 * BATCH;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) B[u] = __builtin_nontemporal_load(q + BATCH + u * STR);
+        for (int u = 0; u < 8; ++u) B[u] = JF_LOAD(q + BATCH + u * STR);
 #pragma unroll
         for (int u = 0; u < 8; ++u) ft.consume(A[u], ebase + (uint32_t)(k + u * STR) * EPV);
 #pragma unroll
@@ -255,14 +266,14 @@ __device__ __forceinline__ void scan_pipelined(FastTrack<DT> &ft, const u32x4 *q
     }
     if (nfull & 1) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) A[u] = __builtin_nontemporal_load(q + u * STR);
+        for (int u = 0; u < 8; ++u) A[u] = JF_LOAD(q + u * STR);
 #pragma unroll
         for (int u = 0; u < 8; ++u) ft.consume(A[u], ebase + (uint32_t)(k + u * STR) * EPV);
         q += BATCH;
         k += BATCH;
     }
     for (; k < nvec; k += STR, q += STR) {
-        const u32x4 v0 = __builtin_nontemporal_load(q);
+        const u32x4 v0 = JF_LOAD(q);
         ft.consume(v0, ebase + (uint32_t)k * EPV);
     }
 }
@@ -286,7 +297,7 @@ __global__ __launch_bounds__(AM_TPB) void argmax_partial_kernel(const void *__re
 
     uint32_t best = 0u, bidx = 0xFFFFFFFFu;   // every real key is >= 0x007FFFFF > 0
     if constexpr (VEC) {
-        FastTrack<DT> ft;
+        FastTrack<DT, true> ft;                                       // small problems: skip the end-of-item reload
         const uint32_t ebase = (uint32_t)begin;                       // element index of the chunk start (V < 2^31)
         const int nvec = (int)((end - begin) / EPV);                  // full 16-byte vectors in this chunk
         const u32x4 *q = (const u32x4 *)p + (begin / EPV) + tid;
@@ -297,12 +308,12 @@ __global__ __launch_bounds__(AM_TPB) void argmax_partial_kernel(const void *__re
             for (; k + (UNROLL - 1) * AM_TPB < nvec; k += UNROLL * AM_TPB, q += UNROLL * AM_TPB) {
                 u32x4 v[UNROLL];
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(q + u * AM_TPB);
+                for (int u = 0; u < UNROLL; ++u) v[u] = JF_LOAD(q + u * AM_TPB);
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) ft.consume(v[u], ebase + (uint32_t)(k + u * AM_TPB) * EPV);
             }
             for (; k < nvec; k += AM_TPB, q += AM_TPB) {
-                const u32x4 v0 = __builtin_nontemporal_load(q);
+                const u32x4 v0 = JF_LOAD(q);
                 ft.consume(v0, ebase + (uint32_t)k * EPV);
             }
         }
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(AM_TPB) void argmax_wave_kernel(const void *__restr
     if (end > V) end = V;
     const typename E::T *p = (const typename E::T *)logits + row * row_stride;
 
-    FastTrack<DT> ft;
+    FastTrack<DT, false> ft;                                          // one wave per SIMD: VALU latency is exposed, keep it lean
     const uint32_t ebase = (uint32_t)begin;
     const int nvec = (int)((end - begin) / EPV);
     const u32x4 *q = (const u32x4 *)p + (begin / EPV) + lane;
@@ -360,12 +371,12 @@ __global__ __launch_bounds__(AM_TPB) void argmax_wave_kernel(const void *__restr
         for (; k + (UNROLL - 1) * 64 < nvec; k += UNROLL * 64, q += UNROLL * 64) {
             u32x4 v[UNROLL];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(q + u * 64);
+            for (int u = 0; u < UNROLL; ++u) v[u] = JF_LOAD(q + u * 64);
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) ft.consume(v[u], ebase + (uint32_t)(k + u * 64) * EPV);
         }
         for (; k < nvec; k += 64, q += 64) {
-            const u32x4 v0 = __builtin_nontemporal_load(q);
+            const u32x4 v0 = JF_LOAD(q);
             ft.consume(v0, ebase + (uint32_t)k * EPV);
         }
     }
