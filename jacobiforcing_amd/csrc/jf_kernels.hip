@@ -437,11 +437,12 @@ extern "C" int jf_argmax_partial(const void *logits, int dtype, int64_t R, int64
     const bool vec = (((uintptr_t)logits) % 16 == 0) && ((row_stride * esz) % 16 == 0);
     hipStream_t s = (hipStream_t)stream;
     unsigned long long *pk = (unsigned long long *)packed;
-    // Measured on MI355X (profiles/argmax_microbench_r01.txt): big problems stream best as ~1 wavefront per SIMD
+    // Measured on MI355X (profiles/argmax_microbench_r01*.txt): big problems stream best as ~1 wavefront per SIMD
     // (1024 items, each a long contiguous range with 8 x 16 B per lane in flight: 6.8 TB/s fp32 at R>=512);
-    // small ones (< 72 MB) are launch/ramp bound and prefer 4-wave workgroups sharing a chunk.
+    // below ~140 MB the kernel is launch/ramp bound and 4-wave workgroups sharing a chunk (best vector kept in
+    // registers, one item per ~64 KB, 256..1024 items) are 5-20 % faster.
     const int64_t bytes = R * V * esz;
-    const bool wave_mode = vec && env_i64("JF_ARGMAX_WAVE", bytes >= (72ll << 20) ? 1 : 0) != 0;
+    const bool wave_mode = vec && env_i64("JF_ARGMAX_WAVE", bytes >= (140ll << 20) ? 1 : 0) != 0;
     const int64_t unroll = env_i64("JF_ARGMAX_UNROLL", 8);       // 4, 8, or 16 (= two pipelined sets of 8)
     const bool deep = unroll >= 8;
     const bool pipe = unroll >= 16;
@@ -459,7 +460,10 @@ extern "C" int jf_argmax_partial(const void *logits, int dtype, int64_t R, int64
 #undef JF_LAUNCHW
         return check_launch("argmax_wave_kernel");
     }
-    const int64_t chunk = pick_chunk((int64_t)AM_TPB * epv, R, V, env_i64("JF_ARGMAX_ITEMS", 512));
+    int64_t wg_items = bytes >> 16;
+    if (wg_items < 256) wg_items = 256;
+    if (wg_items > 1024) wg_items = 1024;
+    const int64_t chunk = pick_chunk((int64_t)AM_TPB * epv, R, V, env_i64("JF_ARGMAX_ITEMS", wg_items));
     const int64_t cpr = (V + chunk - 1) / chunk;
     const int64_t items = R * cpr;
     if (items > 0x7FFFFFFFll) return fail(JF_E_CAPACITY, "jf_argmax_partial: grid too large");
