@@ -447,8 +447,26 @@ extern "C" int jf_argmax_partial(const void *logits, int dtype, int64_t R, int64
     const bool deep = unroll >= 8;
     const bool pipe = unroll >= 16;
     if (wave_mode) {
-        // one item per wavefront, one wavefront per SIMD (256 CUs x 4 SIMDs)
-        const int64_t chunk = pick_chunk(64 * epv, R, V, env_i64("JF_ARGMAX_ITEMS", 1024));
+        // one item per wavefront, ~one wavefront per SIMD (256 CUs x 4 SIMDs = 1024 slots).  Split each row into the
+        // smallest number of chunks whose makespan ceil(items / 1024) * (V / per_row) is within 10 % of the best
+        // split of up to 4 wavefronts per SIMD: e.g. R = 384 -> 5 chunks per row (1920 items, two rounds of V/5) instead
+        // of 3 (1152 items: a second round for only 128 of them).
+        int64_t items_target = env_i64("JF_ARGMAX_ITEMS", 0);
+        if (items_target <= 0) {
+            const int64_t slots = 1024, max_pr = (4 * slots + R - 1) / R;
+            double best = 1e30;
+            for (int64_t pr = 1; pr <= max_pr; ++pr) {
+                const double ms = (double)((R * pr + slots - 1) / slots) / (double)pr;
+                if (ms < best) best = ms;
+            }
+            int64_t pick = 1;
+            for (int64_t pr = 1; pr <= max_pr; ++pr) {
+                const double ms = (double)((R * pr + slots - 1) / slots) / (double)pr;
+                if (ms <= best * 1.10) { pick = pr; break; }
+            }
+            items_target = R * pick;
+        }
+        const int64_t chunk = pick_chunk(64 * epv, R, V, items_target);
         const int64_t cpr = (V + chunk - 1) / chunk;
         const int64_t items = R * cpr;
         const int64_t blocks = (items + (AM_TPB / 64) - 1) / (AM_TPB / 64);
