@@ -51,6 +51,8 @@ class ArgmaxTimer:
         self.bytes = 0
         self.rows = 0
         self.all_rows = []          # every launch since construction (for matching PMC passes to shapes)
+        self.launched_rows = 0
+        self.valid_rows = None      # callable -> algorithmic rows of the launch in flight
         self._orig = ops.argmax_partial
 
     def __enter__(self):
@@ -60,8 +62,13 @@ class ArgmaxTimer:
             self._orig(logits, packed)
             b.record()
             self.events.append((a, b))
-            self.bytes += logits.shape[0] * logits.shape[1] * logits.element_size()
-            self.rows += logits.shape[0]
+            # algorithmic rows: the positions that carry a draft token (sum_p B_p*T_p); the launch also streams the few
+            # padding rows that keep the forward rectangular, those are NOT counted as useful bytes
+            valid = self.valid_rows() if self.valid_rows is not None else logits.shape[0]
+            valid = min(int(valid), int(logits.shape[0])) or int(logits.shape[0])
+            self.bytes += valid * logits.shape[1] * logits.element_size()
+            self.rows += valid
+            self.launched_rows += int(logits.shape[0])
             self.all_rows.append(int(logits.shape[0]))
         ops.argmax_partial = timed
         return self
@@ -76,7 +83,7 @@ class ArgmaxTimer:
         avg_us = sum(us) / len(us)
         avg_bytes = self.bytes / len(us)
         return dict(launches=len(us), avg_us=avg_us, avg_bytes=avg_bytes, avg_rows=self.rows / len(us),
-                    gbs=avg_bytes / avg_us / 1e3)
+                    avg_launched_rows=self.launched_rows / len(us), gbs=avg_bytes / avg_us / 1e3)
 
 
 def run_steps(dec: MultiblockJacobiDecoder, prompts, warmup: int, steps: int, seed: int, timer=None):
@@ -92,7 +99,7 @@ def run_steps(dec: MultiblockJacobiDecoder, prompts, warmup: int, steps: int, se
             jd.barrier(dev)
             state["acc_at_start"] = state["tokens_all"]
             if timer is not None:
-                timer.events.clear(); timer.bytes = 0; timer.rows = 0
+                timer.events.clear(); timer.bytes = 0; timer.rows = 0; timer.launched_rows = 0
             state["t0"] = time.perf_counter()
         if i == total:
             jd.barrier(dev)
@@ -102,7 +109,7 @@ def run_steps(dec: MultiblockJacobiDecoder, prompts, warmup: int, steps: int, se
         if warmup == 0:
             jd.barrier(dev)
             if timer is not None:
-                timer.events.clear(); timer.bytes = 0; timer.rows = 0
+                timer.events.clear(); timer.bytes = 0; timer.rows = 0; timer.launched_rows = 0
             state["t0"] = time.perf_counter()
 
     stats, gen_s, iters = dec.generate(prompts, max_new_tokens=1 << 30, max_calls=1 << 30, seed=seed,
@@ -178,6 +185,7 @@ def main():
 
     # ---- headline: unmodified random-init model ------------------------------------------------
     with ArgmaxTimer() as tm:
+        tm.valid_rows = lambda: dec.last_valid_rows
         r = run_steps(dec, prompts, args.warmup, args.steps, seed=1234 + info.rank, timer=tm)
         roof = tm.summary()
     agg = jd.gather_throughput(r["tokens"], r["iterations"] * 1.0, r["seconds"], dev)
@@ -220,7 +228,8 @@ def main():
                                "frac": roof["gbs"] / HBM_PEAK_GBS, "traffic": _pmc_traffic(roof),
                                "kernel": "jf_argmax_partial (argmax_wave_kernel / argmax_partial_kernel)",
                                "bytes_per_launch": roof["avg_bytes"], "us_per_launch": roof["avg_us"],
-                               "rows_per_launch": roof["avg_rows"], "launches": roof["launches"]}
+                               "rows_per_launch": roof["avg_rows"], "rows_streamed_per_launch": roof["avg_launched_rows"],
+                               "launches": roof["launches"]}
         if scripted is not None:
             out["scripted_acceptance"] = scripted
     if info.rank == 0 and info.world_size == 1 and args.cpu_baseline_seconds > 0:

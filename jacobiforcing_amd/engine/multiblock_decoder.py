@@ -75,6 +75,8 @@ class MultiblockJacobiDecoder:
         self.kv_len_host = np.zeros(self.P, dtype=np.int64)
         self.forwards = 0
         self.last_logits_rows = 0
+        self.last_valid_rows = 0             # sum_p B_p * T_p of the last forward (algorithmic rows, without padding)
+        self.profiler = None                 # optional ProfileTimer (PROFILE=1 sections, reference names MR:116-134)
         self._f = {k: N.DESC_FIELDS.index(k) for k in N.DESC_FIELDS}
 
     # ------------------------------------------------------------------------------ prefill (MB:175-225)
@@ -126,29 +128,55 @@ class MultiblockJacobiDecoder:
             row_cand = torch.from_numpy(rc).to(dev, non_blocking=True)
         else:
             row_cand = torch.full((R,), -1, dtype=torch.int32, device=dev)
+        self.last_valid_rows = int((B * d[:, self._f["T"]]).sum())
+        prof = self.profiler
         kv_rows = self.cache.kv_len[row_prompt.long()]
         s_cur = int(self.kv_len_host[B > 0].max()) + ids.shape[1]
+        if prof: prof.start("jacobi.forward")
         logits = self.model.forward(ids, pos, self.cache, row_prompt=row_prompt, row_cand=row_cand, row_len=row_len,
                                     kv_len_rows=kv_rows, any_candidates=any_cand, s_cur=s_cur)
         if self.logits_hook is not None:
             logits = self.logits_hook(logits, self, prefill=None)
+        if prof: prof.stop("jacobi.forward")
         self.forwards += 1
         self.last_logits_rows = logits.shape[0]
+        if prof: prof.start("jacobi.verify")          # argmax + accept + re-draft + pool + spawn/promote in two launches
         d = self.batch.verify(logits)
+        if prof: prof.stop("jacobi.verify")
         if self.cache.committer is not None and any_cand:
+            if prof: prof.start("jacobi.commit")
             self.cache.committer.commit(self.batch.desc_dev)
+            if prof: prof.stop("jacobi.commit")
+        if prof:
+            prof.iterations += 1
+            prof.tokens += int(d[:, self._f["accepted"]].sum())
         act = B > 0
         self.kv_len_host[act] = d[act, self._f["kv_len"]]
         self.cache.kv_len.copy_(torch.from_numpy(self.kv_len_host.astype(np.int32)), non_blocking=True)
         return d
 
+    # ------------------------------------------------------------------------------ streaming (applications/)
+    def generate_stream(self, prompts, **kw):
+        """Generator counterpart of the reference's streaming driver (applications/jacobi_streaming_driver.py:7-193):
+        yields ``(prompt_index, new_token_ids)`` the moment a prompt finishes a block-level call; the generator's return
+        value (``StopIteration.value``) is ``generate``'s result."""
+        return self._generate_events(prompts, **kw)
+
+    def generate(self, prompts, **kw):
+        """Decode every prompt to EOS / max_new_tokens / max_calls.  Returns (stats per prompt, gen_seconds, iterations);
+        ``gen_seconds`` covers the generation phase only (prefill excluded, DRV:217-230)."""
+        it = self._generate_events(prompts, **kw)
+        while True:
+            try:
+                next(it)
+            except StopIteration as stop:
+                return stop.value
+
     # ------------------------------------------------------------------------------ driver (DRV:152-273)
-    @torch.inference_mode()
-    def generate(self, prompts: Sequence[Sequence[int]], max_new_tokens: int = 1024, max_calls: int = 1024,
+    def _generate_events(self, prompts: Sequence[Sequence[int]], max_new_tokens: int = 1024, max_calls: int = 1024,
                  seed: int = 1234, on_iteration: Optional[Callable[[int, np.ndarray], None]] = None,
-                 max_iterations: Optional[int] = None, on_generation_start: Optional[Callable[[], None]] = None):
-        """Decode every prompt to EOS / max_new_tokens / max_calls.  Returns (stats per prompt, gen_seconds,
-        iterations).  ``gen_seconds`` covers the generation phase only (prefill excluded, DRV:217-230)."""
+                 max_iterations: Optional[int] = None, on_generation_start: Optional[Callable[[], None]] = None,
+                 on_call_done: Optional[Callable[[int, List[int]], None]] = None):
         assert len(prompts) == self.P
         n, eos = self.params.n, self.params.eos_token_id
         rngs = [random.Random(seed + p) for p in range(self.P)]          # one stream per prompt (order-independent)
@@ -183,6 +211,9 @@ class MultiblockJacobiDecoder:
                     st = stats[p]
                     text[p] += r["ret"]
                     st.token_ids += r["ret"]
+                    if on_call_done is not None:
+                        on_call_done(int(p), r["ret"])
+                    yield int(p), list(r["ret"])
                     st.calls += 1
                     st.total_iterations += r["iters"]
                     new_total = len(st.token_ids)

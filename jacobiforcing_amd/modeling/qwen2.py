@@ -93,6 +93,23 @@ class Qwen2Weights:
         self.norm = torch.ones(H, device=device, dtype=dtype)
         self.lm_head = self.embed if cfg.tie_word_embeddings else rnd(cfg.vocab_size, H)
 
+    def load_state_dict(self, sd, cfg: Qwen2Config) -> None:
+        """Adopt the tensors of a HF ``Qwen2ForCausalLM.state_dict()`` (fuses q/k/v and gate/up; casts to this dtype)."""
+        dev, dt = self.embed.device, self.embed.dtype
+        get = lambda k: sd[k].detach().to(device=dev, dtype=dt)
+        self.embed = get("model.embed_tokens.weight")
+        for i, L in enumerate(self.layers):
+            pre = f"model.layers.{i}."
+            L["ln1"] = get(pre + "input_layernorm.weight")
+            L["ln2"] = get(pre + "post_attention_layernorm.weight")
+            L["wqkv"] = torch.cat([get(pre + f"self_attn.{n}_proj.weight") for n in "qkv"], 0)
+            L["bqkv"] = torch.cat([get(pre + f"self_attn.{n}_proj.bias") for n in "qkv"], 0)
+            L["wo"] = get(pre + "self_attn.o_proj.weight")
+            L["wgu"] = torch.cat([get(pre + "mlp.gate_proj.weight"), get(pre + "mlp.up_proj.weight")], 0)
+            L["wd"] = get(pre + "mlp.down_proj.weight")
+        self.norm = get("model.norm.weight")
+        self.lm_head = self.embed if cfg.tie_word_embeddings else get("lm_head.weight")
+
     def load_safetensors(self, model_dir, cfg: Qwen2Config) -> None:
         """Load a HF Qwen2 checkpoint directory (*.safetensors) when one is available."""
         from safetensors import safe_open
@@ -138,6 +155,25 @@ class StaticKVCache:
 
 
 class Qwen2Model:
+    @classmethod
+    def from_hf(cls, hf_model, device=None, dtype=None) -> "Qwen2Model":
+        """Build the forward from a loaded ``transformers`` Qwen2ForCausalLM (route 2)."""
+        c = hf_model.config
+        cfg = Qwen2Config(vocab_size=c.vocab_size, hidden_size=c.hidden_size, intermediate_size=c.intermediate_size,
+                          num_hidden_layers=c.num_hidden_layers, num_attention_heads=c.num_attention_heads,
+                          num_key_value_heads=c.num_key_value_heads,
+                          head_dim=getattr(c, "head_dim", None) or c.hidden_size // c.num_attention_heads,
+                          rms_norm_eps=c.rms_norm_eps, rope_theta=getattr(c, "rope_theta", None) or 1e6,
+                          max_position_embeddings=c.max_position_embeddings, tie_word_embeddings=c.tie_word_embeddings,
+                          eos_token_id=c.eos_token_id if isinstance(c.eos_token_id, int) else 151645,
+                          pad_token_id=c.pad_token_id or 151643)
+        p0 = next(hf_model.parameters())
+        w = Qwen2Weights.__new__(Qwen2Weights)
+        w.embed = torch.empty(0, device=device or p0.device, dtype=dtype or p0.dtype)
+        w.layers = [dict() for _ in range(cfg.num_hidden_layers)]
+        w.load_state_dict(hf_model.state_dict(), cfg)
+        return cls(cfg, w)
+
     def __init__(self, cfg: Qwen2Config, weights: Qwen2Weights):
         self.cfg = cfg
         self.w = weights

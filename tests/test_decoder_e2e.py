@@ -171,3 +171,47 @@ def test_decoder_equals_autoregressive(backend):
                 ar.append(nxt)
                 toks.append(nxt)
             assert stats[p].token_ids == ar
+
+
+def test_generate_stream_yields_calls_in_order():
+    """Streaming counterpart (applications/jacobi_streaming_driver.py): chunks arrive per finished call and concatenate
+    to exactly what generate() returns."""
+    with use_backend("hostsim"):
+        model = tiny_model("cpu", seed=8)
+        V = model.cfg.vocab_size
+        prm = ops.MultiblockParams(n=8, K=2, r=0.85, n_gram_pool_size=4, eos_token_id=None, pad_token_id=V - 2)
+        prompts = [[3, 1, 4, 1, 5, 9, 2, 6], [2, 7, 1, 8]]
+        dec = MultiblockJacobiDecoder(model, 2, prm, max_seq_len=256)
+        it = dec.generate_stream(prompts, max_new_tokens=24, max_calls=8, seed=2)
+        got = {0: [], 1: []}
+        nchunks = 0
+        while True:
+            try:
+                p, toks = next(it)
+                got[p] += toks
+                nchunks += 1
+            except StopIteration as stop:
+                stats, gen_s, iters = stop.value
+                break
+        assert nchunks >= 4
+        assert got[0] == stats[0].token_ids and got[1] == stats[1].token_ids
+        dec2 = MultiblockJacobiDecoder(model, 2, prm, max_seq_len=256)
+        stats2, _, _ = dec2.generate(prompts, max_new_tokens=24, max_calls=8, seed=2)
+        assert [s.token_ids for s in stats2] == [s.token_ids for s in stats]
+
+
+def test_from_hf_builds_equivalent_forward():
+    tr = pytest.importorskip("transformers")
+    with use_backend("hostsim"):
+        hf_cfg = tr.Qwen2Config(vocab_size=97, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                                num_key_value_heads=2, max_position_embeddings=512, tie_word_embeddings=False, use_sliding_window=False)
+        torch.manual_seed(1)
+        hf = tr.Qwen2ForCausalLM(hf_cfg).eval().float()
+        model = Qwen2Model.from_hf(hf)
+        ids = torch.randint(0, 97, (1, 12))
+        cache = StaticKVCache(model.cfg, 1, 32, 0, 1, "cpu", dtype=torch.float32)
+        z = torch.zeros(1, dtype=torch.int32)
+        got = model.forward(ids, torch.arange(12, dtype=torch.int32).view(1, 12), cache, z, z - 1, z + 12, z, False)
+        with torch.no_grad():
+            ref = hf(input_ids=ids).logits[0]
+        assert torch.allclose(got, ref, atol=2e-4, rtol=2e-4)
