@@ -64,7 +64,8 @@ class Qwen2Config:
         return cls(vocab_size=d["vocab_size"], hidden_size=d["hidden_size"], intermediate_size=d["intermediate_size"],
                    num_hidden_layers=d["num_hidden_layers"], num_attention_heads=d["num_attention_heads"],
                    num_key_value_heads=d.get("num_key_value_heads", d["num_attention_heads"]), head_dim=hd,
-                   rms_norm_eps=d.get("rms_norm_eps", 1e-6), rope_theta=d.get("rope_theta", 1e6),
+                   rms_norm_eps=d.get("rms_norm_eps", 1e-6),
+                   rope_theta=d.get("rope_theta") or (d.get("rope_parameters") or {}).get("rope_theta") or 1e6,
                    max_position_embeddings=d.get("max_position_embeddings", 32768),
                    tie_word_embeddings=d.get("tie_word_embeddings", False), eos_token_id=eos,
                    pad_token_id=d.get("pad_token_id") or 151643)
@@ -163,7 +164,8 @@ class Qwen2Model:
                           num_hidden_layers=c.num_hidden_layers, num_attention_heads=c.num_attention_heads,
                           num_key_value_heads=c.num_key_value_heads,
                           head_dim=getattr(c, "head_dim", None) or c.hidden_size // c.num_attention_heads,
-                          rms_norm_eps=c.rms_norm_eps, rope_theta=getattr(c, "rope_theta", None) or 1e6,
+                          rms_norm_eps=c.rms_norm_eps,
+                          rope_theta=(getattr(c, "rope_theta", None) or (getattr(c, "rope_parameters", None) or {}).get("rope_theta") or 1e6),
                           max_position_embeddings=c.max_position_embeddings, tie_word_embeddings=c.tie_word_embeddings,
                           eos_token_id=c.eos_token_id if isinstance(c.eos_token_id, int) else 151645,
                           pad_token_id=c.pad_token_id or 151643)
