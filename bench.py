@@ -146,7 +146,7 @@ def main():
     ap.add_argument("--model", default=os.environ.get("JF_MODEL", "qwen2.5-coder-7b"), help="qwen2.5-coder-7b | tiny | <hf dir>")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=float(os.environ.get("JF_CPU_BASELINE_S", "20")))
     ap.add_argument("--no-scripted", action="store_true")
-    ap.add_argument("--robust", type=int, default=75)
+    ap.add_argument("--robust", type=int, default=82)
     ap.add_argument("--no-tuned-gemms", action="store_true")
     args = ap.parse_args()
 
