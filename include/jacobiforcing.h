@@ -176,6 +176,10 @@ int jf_rope_kv_append(const void *qkv, int dtype, int64_t N, int32_t T, int32_t 
                       void *k_cache, void *v_cache, const int64_t *slot_main, int64_t S_max,
                       void *k_cand, void *v_cand, const int64_t *slot_cand, int64_t T_max, void *stream);
 
+/* SwiGLU gate of the MLP in one pass: out[m, i] = silu(gu[m, i]) * gu[m, I + i] for the fused gate/up projection output
+ * gu [M, 2*I] (row-major), out [M, I].  fp32 arithmetic, one rounding; dtype JF_F32 or JF_BF16. */
+int jf_swiglu(const void *gu, int dtype, int64_t M, int64_t I, void *out, void *stream);
+
 /* commit accepted candidate rows: for prompt p copy desc[p].kv_copy_len token rows from the
  * candidate scratch cand[(p*cand_rows + kv_src_row-1), :, 0:len] to main[p, :, kv_copy_dst: +len],
  * for K and V of `layers` layers (pointer arrays live in device memory). */

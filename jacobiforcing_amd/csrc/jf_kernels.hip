@@ -771,6 +771,40 @@ extern "C" int jf_rope_kv_append(const void *qkv, int dtype, int64_t N, int32_t 
     return check_launch("rope_kv_append_kernel");
 }
 
+// ---- SwiGLU gate: 8 bf16 (or 4 fp32) per lane per load on both halves -------------------------------------------
+template <typename T, int EPV>
+__global__ __launch_bounds__(256) void swiglu_kernel(const T *__restrict__ gu, int64_t M, int64_t I, T *__restrict__ out) {
+    const int64_t vec_per_row = I / EPV;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= M * vec_per_row) return;
+    const int64_t m = gid / vec_per_row, v = gid - m * vec_per_row;
+    const T *g = gu + m * 2 * I + v * EPV;
+    const T *u = g + I;
+    T *o = out + m * I + v * EPV;
+    T gv[EPV], uv[EPV], ov[EPV];
+    *reinterpret_cast<uint4 *>(gv) = *reinterpret_cast<const uint4 *>(g);
+    *reinterpret_cast<uint4 *>(uv) = *reinterpret_cast<const uint4 *>(u);
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+        const float x = ld_f(gv + j), y = ld_f(uv + j);
+        st_f(ov + j, (x / (1.f + expf(-x))) * y);
+    }
+    *reinterpret_cast<uint4 *>(o) = *reinterpret_cast<const uint4 *>(ov);
+}
+
+extern "C" int jf_swiglu(const void *gu, int dtype, int64_t M, int64_t I, void *out, void *stream) {
+    if (M <= 0 || I <= 0) return JF_OK;
+    if (!gu || !out) return fail(JF_E_INVALID, "jf_swiglu: null pointer");
+    const int epv = dtype == JF_F32 ? 4 : 8;
+    if ((dtype != JF_F32 && dtype != JF_BF16) || I % epv != 0 || ((uintptr_t)gu) % 16 || ((uintptr_t)out) % 16)
+        return fail(JF_E_INVALID, "jf_swiglu: dtype/alignment (I must be a multiple of %d)", epv);
+    const int64_t total = M * (I / epv);
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (dtype == JF_F32) swiglu_kernel<float, 4><<<grid, block, 0, (hipStream_t)stream>>>((const float *)gu, M, I, (float *)out);
+    else swiglu_kernel<uint16_t, 8><<<grid, block, 0, (hipStream_t)stream>>>((const uint16_t *)gu, M, I, (uint16_t *)out);
+    return check_launch("swiglu_kernel");
+}
+
 __global__ __launch_bounds__(256) void kv_commit_kernel(void *const *main_k, void *const *main_v, void *const *cand_k,
                                                          void *const *cand_v, const jf_mb_desc *desc, int cand_rows, int H_kv,
                                                          int vec_per_row, int64_t S_max, int64_t T_max) {

@@ -199,9 +199,9 @@ class Qwen2Model:
         x1, x2 = x[..., :h], x[..., h:]
         return torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], dim=-1)
 
-    def _mlp(self, L, x):
-        g, u = F.linear(x, L["wgu"]).chunk(2, dim=-1)
-        return F.linear(F.silu(g) * u, L["wd"])
+    def _mlp_residual(self, L, x2d, h2d):
+        """x + down(silu(gate(h)) * up(h)) with the gate in one HIP launch and the residual in the GEMM epilogue."""
+        return torch.addmm(x2d, ops.swiglu(F.linear(h2d, L["wgu"])), L["wd"].t())
 
     # -- forward over a static cache -------------------------------------------------------------
     @torch.inference_mode()
@@ -231,6 +231,8 @@ class Qwen2Model:
         rel = ar_s.view(1, 1, S_cur) - kvl.view(R, 1, 1)                            # key index relative to the new block
         mask = (rel < 0) | ((rel <= ar_t.view(1, T, 1)) & (rel < rlen.view(R, 1, 1)))
         mask = mask.view(R, 1, 1, T, S_cur).expand(R, 1, G, T, S_cur).reshape(R, 1, G * T, S_cur)
+        # additive mask built once per forward (a bool mask is converted inside every SDPA call otherwise)
+        bias = torch.zeros(mask.shape, dtype=self.dtype, device=dev).masked_fill_(~mask, float("-inf"))
         # slots of the freshly computed K/V rows
         valid = ar_t.view(1, T) < rlen.view(R, 1)
         main_rows = row_cand < 0
@@ -248,9 +250,9 @@ class Qwen2Model:
         pos32 = positions.to(torch.int32).reshape(-1).contiguous()
         direct = (not any_candidates) and R == cache.P                               # row r is prompt r: attend in place
 
-        x = w.embed[input_ids]                                                        # [R,T,H]
+        x = w.embed[input_ids].view(R * T, cfg.hidden_size)                           # [R*T, H]
         for li, L in enumerate(w.layers):
-            qkv = F.linear(self._norm(x, L["ln1"]), L["wqkv"], L["bqkv"]).view(R * T, (nq + 2 * nkv) * hd)
+            qkv = F.linear(self._norm(x, L["ln1"]), L["wqkv"], L["bqkv"])                 # [R*T, (nq+2nkv)*hd]
             # one HIP launch: RoPE on q/k, queries re-laid out per KV head, K/V rows appended to the cache(s) (a18)
             qh = ops.rope_kv_append(qkv, T, nq, nkv, hd, pos32, self.cos, self.sin, cache.k[li], cache.v[li], slot_main,
                                     cache.ck[li] if any_candidates else None, cache.cv[li] if any_candidates else None,
@@ -266,12 +268,11 @@ class Qwen2Model:
                 Kf, Vf = cache.k[li][:, :, :S_cur], cache.v[li][:, :, :S_cur]
             else:
                 Kf, Vf = cache.k[li][rp, :, :S_cur], cache.v[li][rp, :, :S_cur]
-            o = F.scaled_dot_product_attention(qh, Kf, Vf, attn_mask=mask)
-            o = o.view(R, nkv, G, T, hd).permute(0, 3, 1, 2, 4).reshape(R, T, nq * hd)
-            x = x + F.linear(o, L["wo"])
-            x = x + self._mlp(L, self._norm(x, L["ln2"]))
-        x = self._norm(x, w.norm)
-        flat = x.reshape(R * T, cfg.hidden_size)
+            o = F.scaled_dot_product_attention(qh, Kf, Vf, attn_mask=bias)
+            o = o.view(R, nkv, G, T, hd).permute(0, 3, 1, 2, 4).reshape(R * T, nq * hd)
+            x = torch.addmm(x, o, L["wo"].t())                                        # residual in the GEMM epilogue
+            x = self._mlp_residual(L, x, self._norm(x, L["ln2"]))
+        flat = self._norm(x, w.norm)
         if logits_rows is not None:
             flat = flat[logits_rows]
         return F.linear(flat, w.lm_head)

@@ -268,6 +268,16 @@ def rope_kv_append(qkv: torch.Tensor, T: int, nq: int, nkv: int, D: int, positio
     return q
 
 
+def swiglu(gu: torch.Tensor) -> torch.Tensor:
+    """silu(gate) * up for the fused [M, 2I] projection output -> [M, I] (one HIP launch)."""
+    if gu.dim() != 2 or not gu.is_contiguous() or gu.shape[1] % 2:
+        raise ValueError("swiglu expects a contiguous [M, 2*I] tensor")
+    M, I2 = gu.shape
+    out = torch.empty((M, I2 // 2), dtype=gu.dtype, device=gu.device)
+    N.check(N.lib().jf_swiglu(_ptr(gu), _dtype_code(gu), M, I2 // 2, _ptr(out), _stream(gu.device)), "jf_swiglu")
+    return out
+
+
 class KVCommitter:
     """Holds the per-layer pointer tables for jf_kv_commit (candidate row -> committed row, MB:500-502)."""
 

@@ -184,6 +184,19 @@ class HostSimLib:
             scatter(k_cand, v_cand, slot_cand, T_max)
         return 0
 
+    def jf_swiglu(self, gu, dtype, M, I, out, stream):
+        if dtype == N.JF_F32:
+            x = _view(gu, M * 2 * I, np.float32).reshape(M, 2 * I).astype(np.float32)
+        else:
+            x = O.bf16_bits_to_f32(_view(gu, M * 2 * I, np.uint16)).reshape(M, 2 * I)
+        g, u = x[:, :I], x[:, I:]
+        r = ((g / (np.float32(1) + np.exp(-g, dtype=np.float32))) * u).astype(np.float32)
+        if dtype == N.JF_F32:
+            _view(out, M * I, np.float32)[:] = r.reshape(-1)
+        else:
+            _view(out, M * I, np.uint16)[:] = O.f32_to_bf16_bits(r.reshape(-1))
+        return 0
+
     def jf_kv_commit(self, main_k, main_v, cand_k, cand_v, layers, desc, P, cand_rows, H, D, S_max, T_max, esz, stream):
         rowb = D * esz
         tabs = [_view(t, layers, np.int64) for t in (main_k, main_v, cand_k, cand_v)]

@@ -296,3 +296,15 @@ def test_rope_kv_append_matches_torch(dtype):
         assert torch.allclose(ck[2, :, t].cpu().float(), k_ref[T + t].float(), **tol)
         assert torch.equal(cv[2, :, t].cpu(), v_ref[T + t])
     assert float(kc[0].abs().sum()) == 0 and float(ck[:2].abs().sum()) == 0
+
+
+@GPU
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_swiglu_matches_torch(dtype):
+    g = torch.Generator().manual_seed(8)
+    gu = (torch.randn(37, 2 * 1024, generator=g) * 2).to(dtype).cuda()
+    out = ops.swiglu(gu)
+    a, b = gu.float().chunk(2, dim=-1)
+    ref = (torch.nn.functional.silu(a) * b)
+    tol = dict(atol=1e-5, rtol=1e-5) if dtype == torch.float32 else dict(atol=2e-2, rtol=2e-2)
+    assert torch.allclose(out.float(), ref, **tol)
