@@ -906,23 +906,60 @@ __device__ __forceinline__ float load_f(const void *row, int64_t i) {
     else return __uint_as_float(((uint32_t)((const uint16_t *)row)[i]) << 16);
 }
 
-// one workgroup per row: running (max, sum exp(x/T - max)) per lane, merged through LDS.
+// one workgroup per row: 16 B per lane per load (four in flight), per-lane online softmax (running max m, sum of
+// exp(x/T - m)) next to the vector-granular argmax tracker, merged through LDS.  Logits are read exactly once.
 template <int DT>
+__device__ __forceinline__ void softmax_acc(float x, float &m, float &s) {
+    if (x > m) { s = s * expf(m - x) + 1.f; m = x; }
+    else s += expf(x - m);
+}
+
+template <int DT, bool VEC>
 __global__ __launch_bounds__(256) void rs_probs_kernel(const void *logits, int64_t R, int64_t V, int64_t row_stride,
                                                         const int64_t *draft_next, float temp, float *p_draft,
                                                         float *row_max, float *row_sumexp, unsigned long long *packed) {
     using E = Elem<DT>;
+    constexpr int EPV = E::EPV;
     const int64_t row = blockIdx.x;
     const typename E::T *p = (const typename E::T *)logits + row * row_stride;
     const int tid = threadIdx.x;
+    const float inv_t = 1.f / temp;
     float m = -INFINITY, s = 0.f;
     uint32_t best = 0u, bidx = 0xFFFFFFFFu;
-    for (int64_t i = tid; i < V; i += 256) {
-        const float x = load_f<DT>(p, i) / temp;
-        const uint32_t k = load_key<DT>(p, i);
-        if (k > best) { best = k; bidx = (uint32_t)i; }
-        if (x > m) { s = s * expf(m - x) + 1.f; m = x; }
-        else s += expf(x - m);
+    int64_t done = 0;
+    if constexpr (VEC) {
+        const int nvec = (int)(V / EPV);
+        const u32x4 *q = (const u32x4 *)p + tid;
+        auto eat = [&](const u32x4 v, int k) {
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (DT == JF_F32) {
+                    const uint32_t kk = order_key(w[j]);
+                    if (kk > best) { best = kk; bidx = (uint32_t)(k * EPV + j); }
+                    softmax_acc<DT>(__uint_as_float(w[j]) * inv_t, m, s);
+                } else {
+                    const uint32_t lo = w[j] << 16, hi = w[j] & 0xFFFF0000u;
+                    const uint32_t k0 = order_key(lo), k1 = order_key(hi);
+                    if (k0 > best) { best = k0; bidx = (uint32_t)(k * EPV + 2 * j); }
+                    if (k1 > best) { best = k1; bidx = (uint32_t)(k * EPV + 2 * j + 1); }
+                    softmax_acc<DT>(__uint_as_float(lo) * inv_t, m, s);
+                    softmax_acc<DT>(__uint_as_float(hi) * inv_t, m, s);
+                }
+            }
+        };
+        int k = tid;
+        for (; k + 3 * 256 < nvec; k += 4 * 256, q += 4 * 256) {
+            const u32x4 v0 = JF_LOAD(q), v1 = JF_LOAD(q + 256), v2 = JF_LOAD(q + 512), v3 = JF_LOAD(q + 768);
+            eat(v0, k); eat(v1, k + 256); eat(v2, k + 512); eat(v3, k + 768);
+        }
+        for (; k < nvec; k += 256, q += 256) eat(JF_LOAD(q), k);
+        done = (int64_t)nvec * EPV;
+    }
+    for (int64_t i = done + tid; i < V; i += 256) {            // unaligned rows / ragged tail
+        const uint32_t kk = load_key<DT>(p, i);
+        if (kk > best) { best = kk; bidx = (uint32_t)i; }
+        softmax_acc<DT>(load_f<DT>(p, i) * inv_t, m, s);
     }
     __shared__ float sm[256], ss[256];
     __shared__ uint64_t sp[4];
@@ -939,7 +976,7 @@ __global__ __launch_bounds__(256) void rs_probs_kernel(const void *logits, int64
         row_sumexp[row] = Ssum;
         const int64_t tok = draft_next[row];
         float pd = 0.f;
-        if (tok >= 0 && tok < V) pd = expf(load_f<DT>(p, tok) / temp - M) / Ssum;
+        if (tok >= 0 && tok < V) pd = expf(load_f<DT>(p, tok) * inv_t - M) / Ssum;
         p_draft[row] = pd;
         uint64_t mm = sp[0];
         for (int w = 1; w < 4; ++w) mm = sp[w] > mm ? sp[w] : mm;
@@ -954,10 +991,18 @@ extern "C" int jf_rs_probs(const void *logits, int dtype, int64_t R, int64_t V, 
     if (!logits || !draft_next || !p_draft || !row_max || !row_sumexp || !packed) return fail(JF_E_INVALID, "jf_rs_probs: null pointer");
     if (dtype != JF_F32 && dtype != JF_BF16) return fail(JF_E_INVALID, "jf_rs_probs: dtype %d", dtype);
     const float t = (temperature <= 0.f) ? 1.f : temperature;    // JDN:66-67
-    if (dtype == JF_F32)
-        rs_probs_kernel<JF_F32><<<dim3((unsigned)R), 256, 0, (hipStream_t)stream>>>(logits, R, V, row_stride, draft_next, t, p_draft, row_max, row_sumexp, (unsigned long long *)packed);
-    else
-        rs_probs_kernel<JF_BF16><<<dim3((unsigned)R), 256, 0, (hipStream_t)stream>>>(logits, R, V, row_stride, draft_next, t, p_draft, row_max, row_sumexp, (unsigned long long *)packed);
+    const int esz = dtype == JF_F32 ? 4 : 2;
+    const bool vec = (((uintptr_t)logits) % 16 == 0) && ((row_stride * esz) % 16 == 0);
+    const dim3 grid((unsigned)R), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long *pk = (unsigned long long *)packed;
+    if (dtype == JF_F32) {
+        if (vec) rs_probs_kernel<JF_F32, true><<<grid, block, 0, s>>>(logits, R, V, row_stride, draft_next, t, p_draft, row_max, row_sumexp, pk);
+        else rs_probs_kernel<JF_F32, false><<<grid, block, 0, s>>>(logits, R, V, row_stride, draft_next, t, p_draft, row_max, row_sumexp, pk);
+    } else {
+        if (vec) rs_probs_kernel<JF_BF16, true><<<grid, block, 0, s>>>(logits, R, V, row_stride, draft_next, t, p_draft, row_max, row_sumexp, pk);
+        else rs_probs_kernel<JF_BF16, false><<<grid, block, 0, s>>>(logits, R, V, row_stride, draft_next, t, p_draft, row_max, row_sumexp, pk);
+    }
     return check_launch("rs_probs_kernel");
 }
 
@@ -979,6 +1024,7 @@ __global__ __launch_bounds__(256) void rs_step_kernel(const void *logits, int64_
     __shared__ uint64_t s_best[4];
     __shared__ int64_t s_uc, s_bc, s_pc;
     const int tid = threadIdx.x;
+    const float inv_t = 1.f / temp;      // same scaling as rs_probs_kernel (row_max / row_sumexp were computed with it)
     if (tid == 0) { s_uc = *u_cursor; s_bc = *b_cursor; s_pc = *pad_cursor; }
     __syncthreads();
     for (int b = 0; b < B; ++b) {
@@ -1014,7 +1060,7 @@ __global__ __launch_bounds__(256) void rs_step_kernel(const void *logits, int64_
             const int64_t lo = (int64_t)tid * per < V ? (int64_t)tid * per : V;
             const int64_t hi = (lo + per < V) ? lo + per : V;
             double acc = 0.0;
-            for (int64_t i = lo; i < hi; ++i) acc += (double)(expf(load_f<DT>(row, i) / temp - M) / Sx);
+            for (int64_t i = lo; i < hi; ++i) acc += (double)(expf(load_f<DT>(row, i) * inv_t - M) / Sx);
             s_sum[tid] = acc;
             __syncthreads();
             if (tid == 0) {
@@ -1034,7 +1080,7 @@ __global__ __launch_bounds__(256) void rs_step_kernel(const void *logits, int64_
                     double run = pre;
                     int64_t pick = hi - 1;
                     for (int64_t i = lo; i < hi; ++i) {
-                        run += (double)(expf(load_f<DT>(row, i) / temp - M) / Sx);
+                        run += (double)(expf(load_f<DT>(row, i) * inv_t - M) / Sx);
                         if (run > thr) { pick = i; break; }
                     }
                     s_pick = (int)pick;
@@ -1058,7 +1104,7 @@ __global__ __launch_bounds__(256) void rs_step_kernel(const void *logits, int64_
                 uint64_t mm = s_best[0];
                 for (int w = 1; w < 4; ++w) mm = s_best[w] > mm ? s_best[w] : mm;
                 const int alt = jfmb::decode_packed(mm);
-                const float palt = (alt >= 0 && alt < V) ? expf(load_f<DT>(row, alt) / temp - M) / Sx : 0.f;
+                const float palt = (alt >= 0 && alt < V) ? expf(load_f<DT>(row, alt) * inv_t - M) / Sx : 0.f;
                 bonus = (palt > 0.f) ? alt : (int)proposed;
                 __syncthreads();
             }
