@@ -218,7 +218,8 @@ int jf_engine_step(const int64_t *draft, int B, int L, uint64_t *packed, int32_t
  */
 int jf_rs_probs(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride,
                 const int64_t *draft_next, float temperature, float *p_draft, float *row_max,
-                float *row_sumexp, uint64_t *packed, void *stream);
+                float *row_sumexp, uint64_t *packed, void *workspace, size_t workspace_bytes, void *stream);
+size_t jf_rs_workspace_bytes(int64_t R, int64_t V);   /* per-chunk (max, sum-exp) partials */
 
 typedef struct jf_rs_row {
     int32_t n_committed;   /* tokens committed (accepted drafts + bonus), >= 1          */

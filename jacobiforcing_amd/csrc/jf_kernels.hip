@@ -906,60 +906,88 @@ __device__ __forceinline__ float load_f(const void *row, int64_t i) {
     else return __uint_as_float(((uint32_t)((const uint16_t *)row)[i]) << 16);
 }
 
-// one workgroup per row: 16 B per lane per load (four in flight), per-lane online softmax (running max m, sum of
-// exp(x/T - m)) next to the vector-granular argmax tracker, merged through LDS.  Logits are read exactly once.
-template <int DT>
-__device__ __forceinline__ void softmax_acc(float x, float &m, float &s) {
-    if (x > m) { s = s * expf(m - x) + 1.f; m = x; }
-    else s += expf(x - m);
+// Stage 1 — one workgroup per (row, chunk): 16 B per lane per load, four vectors (16/32 elements) per lane per round.
+// Per round the lane first raises its running max over the whole round (register-resident values), rescales its sum once,
+// then adds exp(x - m) for every element: one exp per element plus one per round, branch-free.  The argmax tracker runs on
+// the same registers.  Partials (m, s) go to the workspace, the argmax to `packed` by atomicMax.
+template <int DT, int NV>
+__device__ __forceinline__ void rs_round(const u32x4 (&vv)[NV], const uint32_t (&e0)[NV], float inv_t, float &m, float &s,
+                                         uint32_t &best, uint32_t &bidx) {
+    constexpr int EPV = Elem<DT>::EPV;
+    constexpr int NE = NV * EPV;
+    float x[NE];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const uint32_t w[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (DT == JF_F32) {
+                const uint32_t kk = order_key(w[j]);
+                if (kk > best) { best = kk; bidx = e0[u] + j; }
+                x[u * 4 + j] = __uint_as_float(w[j]) * inv_t;
+            } else {
+                const uint32_t lo = w[j] << 16, hi = w[j] & 0xFFFF0000u;
+                const uint32_t k0 = order_key(lo), k1 = order_key(hi);
+                if (k0 > best) { best = k0; bidx = e0[u] + 2 * j; }
+                if (k1 > best) { best = k1; bidx = e0[u] + 2 * j + 1; }
+                x[u * 8 + 2 * j] = __uint_as_float(lo) * inv_t;
+                x[u * 8 + 2 * j + 1] = __uint_as_float(hi) * inv_t;
+            }
+        }
+    }
+    float mx = x[0];
+#pragma unroll
+    for (int j = 1; j < NE; ++j) mx = fmaxf(mx, x[j]);
+    const float mn = fmaxf(m, mx);
+    if (mn == -INFINITY) return;                        // nothing finite yet: keep (m, s) = (-inf, 0), never form inf - inf
+    float acc = (m == -INFINITY) ? 0.f : s * expf(m - mn);
+#pragma unroll
+    for (int j = 0; j < NE; ++j) acc += expf(x[j] - mn);
+    s = acc;
+    m = mn;
 }
 
 template <int DT, bool VEC>
-__global__ __launch_bounds__(256) void rs_probs_kernel(const void *logits, int64_t R, int64_t V, int64_t row_stride,
-                                                        const int64_t *draft_next, float temp, float *p_draft,
-                                                        float *row_max, float *row_sumexp, unsigned long long *packed) {
+__global__ __launch_bounds__(256) void rs_probs_partial_kernel(const void *logits, int64_t R, int64_t V, int64_t row_stride,
+                                                                float inv_t, float2 *__restrict__ partial,
+                                                                unsigned long long *packed, int cpr, int64_t chunk_elems) {
     using E = Elem<DT>;
     constexpr int EPV = E::EPV;
-    const int64_t row = blockIdx.x;
+    const int64_t item = blockIdx.x;
+    const int64_t row = item / cpr;
+    const int c = (int)(item - row * cpr);
+    const int64_t begin = (int64_t)c * chunk_elems;
+    int64_t end = begin + chunk_elems;
+    if (end > V) end = V;
     const typename E::T *p = (const typename E::T *)logits + row * row_stride;
     const int tid = threadIdx.x;
-    const float inv_t = 1.f / temp;
     float m = -INFINITY, s = 0.f;
     uint32_t best = 0u, bidx = 0xFFFFFFFFu;
-    int64_t done = 0;
+    int64_t done = begin;
     if constexpr (VEC) {
-        const int nvec = (int)(V / EPV);
-        const u32x4 *q = (const u32x4 *)p + tid;
-        auto eat = [&](const u32x4 v, int k) {
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if constexpr (DT == JF_F32) {
-                    const uint32_t kk = order_key(w[j]);
-                    if (kk > best) { best = kk; bidx = (uint32_t)(k * EPV + j); }
-                    softmax_acc<DT>(__uint_as_float(w[j]) * inv_t, m, s);
-                } else {
-                    const uint32_t lo = w[j] << 16, hi = w[j] & 0xFFFF0000u;
-                    const uint32_t k0 = order_key(lo), k1 = order_key(hi);
-                    if (k0 > best) { best = k0; bidx = (uint32_t)(k * EPV + 2 * j); }
-                    if (k1 > best) { best = k1; bidx = (uint32_t)(k * EPV + 2 * j + 1); }
-                    softmax_acc<DT>(__uint_as_float(lo) * inv_t, m, s);
-                    softmax_acc<DT>(__uint_as_float(hi) * inv_t, m, s);
-                }
-            }
-        };
+        const int nvec = (int)((end - begin) / EPV);
+        const u32x4 *q = (const u32x4 *)p + (begin / EPV) + tid;
+        const uint32_t ebase = (uint32_t)begin;
         int k = tid;
         for (; k + 3 * 256 < nvec; k += 4 * 256, q += 4 * 256) {
-            const u32x4 v0 = JF_LOAD(q), v1 = JF_LOAD(q + 256), v2 = JF_LOAD(q + 512), v3 = JF_LOAD(q + 768);
-            eat(v0, k); eat(v1, k + 256); eat(v2, k + 512); eat(v3, k + 768);
+            const u32x4 vv[4] = {JF_LOAD(q), JF_LOAD(q + 256), JF_LOAD(q + 512), JF_LOAD(q + 768)};
+            const uint32_t e0[4] = {ebase + (uint32_t)k * EPV, ebase + (uint32_t)(k + 256) * EPV, ebase + (uint32_t)(k + 512) * EPV,
+                                    ebase + (uint32_t)(k + 768) * EPV};
+            rs_round<DT, 4>(vv, e0, inv_t, m, s, best, bidx);
         }
-        for (; k < nvec; k += 256, q += 256) eat(JF_LOAD(q), k);
-        done = (int64_t)nvec * EPV;
+        for (; k < nvec; k += 256, q += 256) {          // this lane's remaining vectors, one at a time
+            const u32x4 vv[1] = {JF_LOAD(q)};
+            const uint32_t e0[1] = {ebase + (uint32_t)k * EPV};
+            rs_round<DT, 1>(vv, e0, inv_t, m, s, best, bidx);
+        }
+        done = begin + (int64_t)nvec * EPV;
     }
-    for (int64_t i = done + tid; i < V; i += 256) {            // unaligned rows / ragged tail
+    for (int64_t i = done + tid; i < end; i += 256) {    // unaligned rows / ragged tail (V % EPV)
         const uint32_t kk = load_key<DT>(p, i);
         if (kk > best) { best = kk; bidx = (uint32_t)i; }
-        softmax_acc<DT>(load_f<DT>(p, i) * inv_t, m, s);
+        const float xv = load_f<DT>(p, i) * inv_t;
+        if (xv > m) { s = (m == -INFINITY ? 0.f : s * expf(m - xv)) + 1.f; m = xv; }
+        else if (xv != -INFINITY) s += expf(xv - m);
     }
     __shared__ float sm[256], ss[256];
     __shared__ uint64_t sp[4];
@@ -972,38 +1000,78 @@ __global__ __launch_bounds__(256) void rs_probs_kernel(const void *logits, int64
         for (int i = 0; i < 256; ++i) M = sm[i] > M ? sm[i] : M;
         float Ssum = 0.f;
         for (int i = 0; i < 256; ++i) Ssum += (sm[i] == -INFINITY) ? 0.f : ss[i] * expf(sm[i] - M);
-        row_max[row] = M;
-        row_sumexp[row] = Ssum;
-        const int64_t tok = draft_next[row];
-        float pd = 0.f;
-        if (tok >= 0 && tok < V) pd = expf(load_f<DT>(p, tok) * inv_t - M) / Ssum;
-        p_draft[row] = pd;
+        partial[item] = make_float2(M, Ssum);
         uint64_t mm = sp[0];
         for (int w = 1; w < 4; ++w) mm = sp[w] > mm ? sp[w] : mm;
         atomicMax(packed + row, (unsigned long long)mm);
     }
 }
 
+// Stage 2 — one thread per row: merge the chunk partials, then the gathered probability of the drafted id.
+template <int DT>
+__global__ __launch_bounds__(256) void rs_probs_finish_kernel(const void *logits, int64_t R, int64_t V, int64_t row_stride,
+                                                               const int64_t *draft_next, float inv_t, const float2 *partial,
+                                                               int cpr, float *p_draft, float *row_max, float *row_sumexp) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= R) return;
+    float M = -INFINITY;
+    for (int c = 0; c < cpr; ++c) M = fmaxf(M, partial[row * cpr + c].x);
+    float S = 0.f;
+    for (int c = 0; c < cpr; ++c) {
+        const float2 ps = partial[row * cpr + c];
+        S += (ps.x == -INFINITY) ? 0.f : ps.y * expf(ps.x - M);
+    }
+    row_max[row] = M;
+    row_sumexp[row] = S;
+    const int64_t tok = draft_next[row];
+    const void *p = (const char *)logits + row * row_stride * (DT == JF_F32 ? 4 : 2);
+    p_draft[row] = (tok >= 0 && tok < V) ? expf(load_f<DT>(p, tok) * inv_t - M) / S : 0.f;
+}
+
+static int64_t rs_chunk(int dtype, int64_t R, int64_t V, int64_t *cpr_out) {
+    const int64_t gran = 4 * (int64_t)256 * (dtype == JF_F32 ? 4 : 8);     // one full round per workgroup
+    int64_t per_row = (2048 + R - 1) / R;
+    if (per_row < 1) per_row = 1;
+    if (per_row > 64) per_row = 64;
+    int64_t chunk = (V + per_row - 1) / per_row;
+    chunk = ((chunk + gran - 1) / gran) * gran;
+    *cpr_out = (V + chunk - 1) / chunk;
+    return chunk;
+}
+
+extern "C" size_t jf_rs_workspace_bytes(int64_t R, int64_t V) {
+    (void)V;
+    return (size_t)(R > 0 ? R : 0) * 64 * sizeof(float2);
+}
+
 extern "C" int jf_rs_probs(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, const int64_t *draft_next,
                            float temperature, float *p_draft, float *row_max, float *row_sumexp, uint64_t *packed,
-                           void *stream) {
+                           void *workspace, size_t workspace_bytes, void *stream) {
     if (R <= 0) return JF_OK;
-    if (!logits || !draft_next || !p_draft || !row_max || !row_sumexp || !packed) return fail(JF_E_INVALID, "jf_rs_probs: null pointer");
+    if (!logits || !draft_next || !p_draft || !row_max || !row_sumexp || !packed || !workspace)
+        return fail(JF_E_INVALID, "jf_rs_probs: null pointer");
     if (dtype != JF_F32 && dtype != JF_BF16) return fail(JF_E_INVALID, "jf_rs_probs: dtype %d", dtype);
+    if (workspace_bytes < jf_rs_workspace_bytes(R, V)) return fail(JF_E_INVALID, "jf_rs_probs: workspace too small");
     const float t = (temperature <= 0.f) ? 1.f : temperature;    // JDN:66-67
+    const float inv_t = 1.f / t;
     const int esz = dtype == JF_F32 ? 4 : 2;
     const bool vec = (((uintptr_t)logits) % 16 == 0) && ((row_stride * esz) % 16 == 0);
-    const dim3 grid((unsigned)R), block(256);
+    int64_t cpr = 1;
+    const int64_t chunk = rs_chunk(dtype, R, V, &cpr);
+    const dim3 grid((unsigned)(R * cpr)), block(256);
     hipStream_t s = (hipStream_t)stream;
     unsigned long long *pk = (unsigned long long *)packed;
+    float2 *part = (float2 *)workspace;
     if (dtype == JF_F32) {
-        if (vec) rs_probs_kernel<JF_F32, true><<<grid, block, 0, s>>>(logits, R, V, row_stride, draft_next, t, p_draft, row_max, row_sumexp, pk);
-        else rs_probs_kernel<JF_F32, false><<<grid, block, 0, s>>>(logits, R, V, row_stride, draft_next, t, p_draft, row_max, row_sumexp, pk);
+        if (vec) rs_probs_partial_kernel<JF_F32, true><<<grid, block, 0, s>>>(logits, R, V, row_stride, inv_t, part, pk, (int)cpr, chunk);
+        else rs_probs_partial_kernel<JF_F32, false><<<grid, block, 0, s>>>(logits, R, V, row_stride, inv_t, part, pk, (int)cpr, chunk);
+        rs_probs_finish_kernel<JF_F32><<<dim3((unsigned)((R + 255) / 256)), 256, 0, s>>>(logits, R, V, row_stride, draft_next, inv_t, part, (int)cpr, p_draft, row_max, row_sumexp);
     } else {
-        if (vec) rs_probs_kernel<JF_BF16, true><<<grid, block, 0, s>>>(logits, R, V, row_stride, draft_next, t, p_draft, row_max, row_sumexp, pk);
-        else rs_probs_kernel<JF_BF16, false><<<grid, block, 0, s>>>(logits, R, V, row_stride, draft_next, t, p_draft, row_max, row_sumexp, pk);
+        if (vec) rs_probs_partial_kernel<JF_BF16, true><<<grid, block, 0, s>>>(logits, R, V, row_stride, inv_t, part, pk, (int)cpr, chunk);
+        else rs_probs_partial_kernel<JF_BF16, false><<<grid, block, 0, s>>>(logits, R, V, row_stride, inv_t, part, pk, (int)cpr, chunk);
+        rs_probs_finish_kernel<JF_BF16><<<dim3((unsigned)((R + 255) / 256)), 256, 0, s>>>(logits, R, V, row_stride, draft_next, inv_t, part, (int)cpr, p_draft, row_max, row_sumexp);
     }
-    return check_launch("rs_probs_kernel");
+    return check_launch("rs_probs kernels");
 }
 
 // Sequential accept/reject over the rows of a batch (JDN:581-639) in ONE launch: rows are visited in order so the

@@ -362,6 +362,7 @@ class RsStepper:
         self.packed = new_packed(n, dev)
         f32 = lambda k: torch.zeros((k,), dtype=torch.float32, device=dev)
         self.p_draft, self.row_max, self.row_sumexp = f32(n), f32(n), f32(n)
+        self.ws = torch.zeros((n * 64 * 2,), dtype=torch.float32, device=dev)     # jf_rs_workspace_bytes(n, V)
         self.committed = torch.zeros((self.max_rows, self.max_L), dtype=torch.int64, device=dev)
         self.next_draft = torch.zeros((self.max_rows, self.max_L), dtype=torch.int64, device=dev)
         self.rows_dev = torch.zeros((self.max_rows, N.RS_ROW_INTS), dtype=torch.int32, device=dev)
@@ -394,7 +395,7 @@ class RsStepper:
         lib = N.lib()
         N.check(lib.jf_rs_probs(_ptr(flat), _dtype_code(flat), R, V, flat.stride(0), _ptr(draft_next), float(temperature),
                                 _ptr(self.p_draft), _ptr(self.row_max), _ptr(self.row_sumexp), _ptr(self.packed),
-                                _stream(dev)), "jf_rs_probs")
+                                _ptr(self.ws), self.ws.numel() * 4, _stream(dev)), "jf_rs_probs")
         self.remaining[:B].copy_(torch.tensor(list(remaining), dtype=torch.int32), non_blocking=True)
         self.cursors.copy_(torch.tensor(list(cursors), dtype=torch.int64), non_blocking=True)
         cm = self.committed.view(-1)[:B * L].view(B, L)

@@ -223,7 +223,7 @@ class HostSimLib:
         b = _view(logits, (R - 1) * stride + V, np.uint16)
         return O.bf16_bits_to_f32(np.stack([b[r * stride:r * stride + V] for r in range(R)]))
 
-    def jf_rs_probs(self, logits, dtype, R, V, stride, draft_next, temperature, p_draft, row_max, row_sumexp, packed, stream):
+    def jf_rs_probs(self, logits, dtype, R, V, stride, draft_next, temperature, p_draft, row_max, row_sumexp, packed, ws, ws_bytes, stream):
         rows = self._rows_f32(logits, dtype, R, V, stride)
         t = np.float32(1.0 if temperature <= 0 else temperature)
         x = rows / t

@@ -255,7 +255,7 @@ def test_rs_probs_vs_torch_softmax(dtype, temperature):
     p = torch.zeros(R, device="cuda"); m = torch.zeros(R, device="cuda"); s = torch.zeros(R, device="cuda")
     packed = ops.new_packed(R, "cuda")
     N.check(lib.jf_rs_probs(ops._ptr(xd), ops._dtype_code(xd), R, V, V, ops._ptr(dn.cuda()), temperature, ops._ptr(p), ops._ptr(m),
-                            ops._ptr(s), ops._ptr(packed), ops._stream(xd.device)))
+                            ops._ptr(s), ops._ptr(packed), ops._ptr(st.ws), st.ws.numel() * 4, ops._stream(xd.device)))
     ref = torch.softmax(x.float() / temperature, dim=-1)
     want = ref[torch.arange(R), dn]
     got = p.cpu()

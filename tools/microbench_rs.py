@@ -15,8 +15,9 @@ for dtype in (torch.bfloat16, torch.float32):
         dn = torch.randint(0, V, (R,), device="cuda")
         p = torch.zeros(R, device="cuda"); m = torch.zeros(R, device="cuda"); s = torch.zeros(R, device="cuda")
         packed = ops.new_packed(R, "cuda")
+        ws = torch.zeros(R * 128, device="cuda")
         f = lambda: N.check(N.lib().jf_rs_probs(ops._ptr(x), ops._dtype_code(x), R, V, V, ops._ptr(dn), 0.8, ops._ptr(p), ops._ptr(m),
-                                                ops._ptr(s), ops._ptr(packed), ops._stream(x.device)))
+                                                ops._ptr(s), ops._ptr(packed), ops._ptr(ws), ws.numel() * 4, ops._stream(x.device)))
         for _ in range(3):
             f()
         torch.cuda.synchronize()
