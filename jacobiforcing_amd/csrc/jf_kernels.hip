@@ -989,17 +989,24 @@ __global__ __launch_bounds__(256) void rs_probs_partial_kernel(const void *logit
         if (xv > m) { s = (m == -INFINITY ? 0.f : s * expf(m - xv)) + 1.f; m = xv; }
         else if (xv != -INFINITY) s += expf(xv - m);
     }
-    __shared__ float sm[256], ss[256];
+    // merge (m, s) pairs: six shuffle steps inside the wavefront, then one LDS hop across the four wavefronts
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float m2 = __shfl_xor(m, off, 64), s2 = __shfl_xor(s, off, 64);
+        const float M = fmaxf(m, m2);
+        s = (M == -INFINITY) ? 0.f : ((m == -INFINITY ? 0.f : s * expf(m - M)) + (m2 == -INFINITY ? 0.f : s2 * expf(m2 - M)));
+        m = M;
+    }
+    __shared__ float sm[4], ss[4];
     __shared__ uint64_t sp[4];
-    sm[tid] = m; ss[tid] = s;
     uint64_t pk = wave_max_u64(((uint64_t)best << 32) | (uint64_t)(~bidx));
-    if ((tid & 63) == 0) sp[tid >> 6] = pk;
+    if ((tid & 63) == 0) { sp[tid >> 6] = pk; sm[tid >> 6] = m; ss[tid >> 6] = s; }
     __syncthreads();
     if (tid == 0) {
         float M = -INFINITY;
-        for (int i = 0; i < 256; ++i) M = sm[i] > M ? sm[i] : M;
+        for (int i = 0; i < 4; ++i) M = sm[i] > M ? sm[i] : M;
         float Ssum = 0.f;
-        for (int i = 0; i < 256; ++i) Ssum += (sm[i] == -INFINITY) ? 0.f : ss[i] * expf(sm[i] - M);
+        for (int i = 0; i < 4; ++i) Ssum += (sm[i] == -INFINITY) ? 0.f : ss[i] * expf(sm[i] - M);
         partial[item] = make_float2(M, Ssum);
         uint64_t mm = sp[0];
         for (int w = 1; w < 4; ++w) mm = sp[w] > mm ? sp[w] : mm;
