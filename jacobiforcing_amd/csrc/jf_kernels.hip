@@ -907,6 +907,7 @@ __device__ __forceinline__ float load_f(const void *row, int64_t i) {
 }
 
 // Stage 1 — one workgroup per (row, chunk): 16 B per lane per load, four vectors (16/32 elements) per lane per round.
+// (hot loop: hardware v_exp_f32 via __expf, ~1e-6 relative; the verify tolerance is 2e-5)
 // Per round the lane first raises its running max over the whole round (register-resident values), rescales its sum once,
 // then adds exp(x - m) for every element: one exp per element plus one per round, branch-free.  The argmax tracker runs on
 // the same registers.  Partials (m, s) go to the workspace, the argmax to `packed` by atomicMax.
@@ -940,9 +941,9 @@ __device__ __forceinline__ void rs_round(const u32x4 (&vv)[NV], const uint32_t (
     for (int j = 1; j < NE; ++j) mx = fmaxf(mx, x[j]);
     const float mn = fmaxf(m, mx);
     if (mn == -INFINITY) return;                        // nothing finite yet: keep (m, s) = (-inf, 0), never form inf - inf
-    float acc = (m == -INFINITY) ? 0.f : s * expf(m - mn);
+    float acc = (m == -INFINITY) ? 0.f : s * __expf(m - mn);
 #pragma unroll
-    for (int j = 0; j < NE; ++j) acc += expf(x[j] - mn);
+    for (int j = 0; j < NE; ++j) acc += __expf(x[j] - mn);
     s = acc;
     m = mn;
 }
