@@ -912,8 +912,7 @@ __device__ __forceinline__ float load_f(const void *row, int64_t i) {
 // then adds exp(x - m) for every element: one exp per element plus one per round, branch-free.  The argmax tracker runs on
 // the same registers.  Partials (m, s) go to the workspace, the argmax to `packed` by atomicMax.
 template <int DT, int NV>
-__device__ __forceinline__ void rs_round(const u32x4 (&vv)[NV], const uint32_t (&e0)[NV], float inv_t, float &m, float &s,
-                                         uint32_t &best, uint32_t &bidx) {
+__device__ __forceinline__ void rs_round(const u32x4 (&vv)[NV], float inv_t, float &m, float &s) {
     constexpr int EPV = Elem<DT>::EPV;
     constexpr int NE = NV * EPV;
     float x[NE];
@@ -923,16 +922,10 @@ __device__ __forceinline__ void rs_round(const u32x4 (&vv)[NV], const uint32_t (
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if constexpr (DT == JF_F32) {
-                const uint32_t kk = order_key(w[j]);
-                if (kk > best) { best = kk; bidx = e0[u] + j; }
                 x[u * 4 + j] = __uint_as_float(w[j]) * inv_t;
             } else {
-                const uint32_t lo = w[j] << 16, hi = w[j] & 0xFFFF0000u;
-                const uint32_t k0 = order_key(lo), k1 = order_key(hi);
-                if (k0 > best) { best = k0; bidx = e0[u] + 2 * j; }
-                if (k1 > best) { best = k1; bidx = e0[u] + 2 * j + 1; }
-                x[u * 8 + 2 * j] = __uint_as_float(lo) * inv_t;
-                x[u * 8 + 2 * j + 1] = __uint_as_float(hi) * inv_t;
+                x[u * 8 + 2 * j] = __uint_as_float(w[j] << 16) * inv_t;
+                x[u * 8 + 2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u) * inv_t;
             }
         }
     }
@@ -969,26 +962,33 @@ __global__ __launch_bounds__(256) void rs_probs_partial_kernel(const void *logit
         const int nvec = (int)((end - begin) / EPV);
         const u32x4 *q = (const u32x4 *)p + (begin / EPV) + tid;
         const uint32_t ebase = (uint32_t)begin;
+        FastTrack<DT, true> ft;                          // same vector-granular argmax tracker as the greedy kernel
         int k = tid;
         for (; k + 3 * 256 < nvec; k += 4 * 256, q += 4 * 256) {
             const u32x4 vv[4] = {JF_LOAD(q), JF_LOAD(q + 256), JF_LOAD(q + 512), JF_LOAD(q + 768)};
-            const uint32_t e0[4] = {ebase + (uint32_t)k * EPV, ebase + (uint32_t)(k + 256) * EPV, ebase + (uint32_t)(k + 512) * EPV,
-                                    ebase + (uint32_t)(k + 768) * EPV};
-            rs_round<DT, 4>(vv, e0, inv_t, m, s, best, bidx);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ft.consume(vv[u], ebase + (uint32_t)(k + u * 256) * EPV);
+            rs_round<DT, 4>(vv, inv_t, m, s);
         }
         for (; k < nvec; k += 256, q += 256) {          // this lane's remaining vectors, one at a time
             const u32x4 vv[1] = {JF_LOAD(q)};
-            const uint32_t e0[1] = {ebase + (uint32_t)k * EPV};
-            rs_round<DT, 1>(vv, e0, inv_t, m, s, best, bidx);
+            ft.consume(vv[0], ebase + (uint32_t)k * EPV);
+            rs_round<DT, 1>(vv, inv_t, m, s);
         }
         done = begin + (int64_t)nvec * EPV;
+        if (__syncthreads_or(ft.saw_nan() ? 1 : 0)) {
+            scan_exact<DT>(p, begin, done, tid, best, bidx);               // NaN in the chunk: exact key rescan
+        } else if (ft.bvec != 0xFFFFFFFFu) {
+            best = ft.ukey();
+            bidx = ft.resolve(p);
+        }
     }
     for (int64_t i = done + tid; i < end; i += 256) {    // unaligned rows / ragged tail (V % EPV)
         const uint32_t kk = load_key<DT>(p, i);
         if (kk > best) { best = kk; bidx = (uint32_t)i; }
         const float xv = load_f<DT>(p, i) * inv_t;
-        if (xv > m) { s = (m == -INFINITY ? 0.f : s * expf(m - xv)) + 1.f; m = xv; }
-        else if (xv != -INFINITY) s += expf(xv - m);
+        if (xv > m) { s = (m == -INFINITY ? 0.f : s * __expf(m - xv)) + 1.f; m = xv; }
+        else if (xv != -INFINITY) s += __expf(xv - m);
     }
     // merge (m, s) pairs: six shuffle steps inside the wavefront, then one LDS hop across the four wavefronts
 #pragma unroll
