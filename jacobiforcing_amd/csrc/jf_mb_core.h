@@ -532,7 +532,7 @@ JF_HD void mb_pack_body(Lanes lanes, int p, int32_t *states, int64_t state_ints,
 
 template <class Lanes>
 JF_HD void mb_step_body(Lanes lanes, int p, int32_t *states, int64_t state_ints, uint64_t *packed,
-                        int64_t packed_len, jf_mb_desc *desc) {
+                        int64_t packed_len, jf_mb_desc *desc, int32_t *stage = nullptr, int stage_ints = 0) {
     int32_t *S = states + (int64_t)p * state_ints;
     Layout lay = layout_of(S);
     Machine<Lanes> m(S, lanes, lay);
@@ -540,11 +540,29 @@ JF_HD void mb_step_body(Lanes lanes, int p, int32_t *states, int64_t state_ints,
     const int64_t tpad = S[H_TPAD];
     const int B = S[H_B];
     const uint64_t *pk = packed;
-    auto G = [pk, base, tpad, packed_len](int r, int t) -> int {
-        const int64_t idx = (base + r) * tpad + t;
-        return (idx >= 0 && idx < packed_len) ? decode_packed(pk[idx]) : -1;
-    };
-    m.step(G, desc ? desc + p : nullptr);
+    const int ntok = B * (int)tpad;
+    if (stage && ntok > 0 && ntok <= stage_ints) {
+        // stage this prompt's greedy token rows (decoded argmax results) in LDS once: every accept scan, re-draft and
+        // next-token pick below then reads LDS instead of making dependent trips to global memory
+        for (int i = lanes.lane(); i < ntok; i += lanes.count()) {
+            const int64_t idx = base * tpad + i;
+            stage[i] = (idx >= 0 && idx < packed_len) ? decode_packed(pk[idx]) : -1;
+        }
+        lanes.sync();
+        const int32_t *sg = stage;
+        const int tp = (int)tpad;
+        auto G = [sg, tp, ntok](int r, int t) -> int {
+            const int i = r * tp + t;
+            return (i >= 0 && i < ntok) ? sg[i] : -1;
+        };
+        m.step(G, desc ? desc + p : nullptr);
+    } else {
+        auto G = [pk, base, tpad, packed_len](int r, int t) -> int {
+            const int64_t idx = (base + r) * tpad + t;
+            return (idx >= 0 && idx < packed_len) ? decode_packed(pk[idx]) : -1;
+        };
+        m.step(G, desc ? desc + p : nullptr);
+    }
     // re-zero this prompt's slice of the argmax workspace for the next jf_argmax_partial
     lanes.sync();
     const int64_t lo = base * tpad, hi = (base + B) * tpad;

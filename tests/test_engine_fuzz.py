@@ -1,0 +1,128 @@
+"""Randomised engine-path sweep: JacobiDecoder / JacobiDecoderNonGreedy (HIP jf_engine_step / jf_rs_*) against the oracle's
+restatement of JD / JDN over random batch sizes, block lengths, max_tokens, EOS positions and robustness."""
+import numpy as np
+import pytest
+import torch
+
+from jacobiforcing_amd.engine.jacobi_decoding import JacobiDecoder
+from jacobiforcing_amd.engine.jacobi_decoding_nongreedy import JacobiDecoderNonGreedy
+from jacobiforcing_amd.sampling_params import SamplingParams
+from oracle import jacobi_oracle as O
+from oracle.scripted_model import ScriptedModel
+
+from .backends import device_for, use_backend
+from .test_engine_decoder import Harness
+
+BACKENDS = [pytest.param("hostsim", id="hostsim"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+
+
+def _setup(seed):
+    rng = np.random.default_rng(777 + seed)
+    V = int(rng.choice([16, 64, 200]))
+    B = int(rng.integers(1, 6))
+    robust = int(rng.choice([0, 30, 60, 80, 100]))
+    max_iters = int(rng.choice([128, 128, 4]))
+    same_L = rng.random() < 0.5
+    L0 = int(rng.choice([2, 3, 5, 8, 16, 33]))
+    items = []
+    for i in range(B):
+        pl = int(rng.integers(1, 40)) if rng.random() < 0.8 else int(rng.integers(250, 262))
+        L = L0 if same_L else int(rng.choice([2, 4, 8, 16]))
+        mt = int(rng.integers(1, 60))
+        eos_pos = None if rng.random() < 0.5 else pl + int(rng.integers(0, 40))
+        use_pd = rng.random() < 0.6
+        items.append(dict(seed=9000 + 13 * seed + i, pl=pl, L=L, mt=mt, eos_pos=eos_pos, use_pd=use_pd))
+    return rng, V, robust, max_iters, items
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("seed", range(40))
+def test_engine_greedy_fuzz(seed, backend):
+    rng, V, robust, max_iters, items = _setup(seed)
+    eos, pad = V - 1, V - 2
+    pads = [int(x) for x in rng.integers(0, V, size=4096)]
+    with use_backend(backend):
+        dev = device_for(backend)
+        H = Harness(V, dev, torch.float32)
+        dec = JacobiDecoder(H.bm, forward_step=lambda s, d: H.forward_step_batch([s], d), forward_step_batch=H.forward_step_batch,
+                            eos_token_id=eos, pad_token_id=pad, vocab_size=V, device=torch.device(dev))
+        dec.set_pad_stream(pads)
+        seqs, oseqs, models = [], [], []
+        for it in items:
+            m = ScriptedModel(V, it["seed"], robust, it["pl"], eos_id=eos, eos_pos=it["eos_pos"], reserved=(pad,))
+            pd = m.greedy_rows(m.prompt()[:-1], [[m.prompt()[-1]] + [1] * it["L"]])[0][:it["L"]] if it["use_pd"] else None
+            sp = SamplingParams(temperature=0.0, max_tokens=it["mt"], decode_strategy="jacobi", jacobi_block_len=it["L"],
+                                jacobi_max_iterations=max_iters)
+            seqs.append(H.add(m, sp, list(pd) if pd is not None else None))
+            oseqs.append(O.OracleSeq(m.prompt(), it["L"], it["mt"], max_iters=max_iters, prefill_draft=list(pd) if pd is not None else None))
+            models.append(m)
+        by = {id(s): m for s, m in zip(oseqs, models)}
+        cur = [0]
+
+        def opads(k):
+            out = [pads[(cur[0] + i) % len(pads)] for i in range(k)]
+            cur[0] += k
+            return out
+
+        def ofwd(ss, drafts):
+            return [by[id(s)].greedy_rows(s.token_ids[:-1], [d])[0][:-1] for s, d in zip(ss, drafts)]
+        stats = O.new_stats()
+        want = O.engine_generate_batch(ofwd, oseqs, eos, opads, stats)
+        got = dec.generate_chunk_batch(seqs)
+        assert got == want
+        assert dec.stats == stats
+        assert dec._pad_cursor == cur[0]
+        for s, o in zip(seqs, oseqs):
+            assert s.token_ids == o.token_ids and s.num_cached_tokens == o.num_cached_tokens
+            assert len(s.block_table) == o.num_table_blocks
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("seed", range(24))
+def test_engine_nongreedy_fuzz(seed, backend):
+    """Same sweep for rejection sampling.  The oracle and the kernels share the injected streams; probabilities differ only
+    in fp32 rounding, so a decision can flip only when a uniform lands within ~1e-6 of p — none does for these seeds."""
+    rng, V, robust, max_iters, items = _setup(1000 + seed)
+    eos, pad = V - 1, V - 2
+    temperature = float(rng.choice([1.0, 0.7, 0.4]))
+    pads = [int(x) for x in rng.integers(0, V, size=4096)]
+    unis = [float(x) for x in (rng.integers(0, 1 << 24, size=8192) / float(1 << 24))]
+    bonus = [float(x) for x in (rng.integers(0, 1 << 24, size=8192) / float(1 << 24))]
+    L = items[0]["L"]
+    with use_backend(backend):
+        dev = device_for(backend)
+        H = Harness(V, dev, torch.float32)
+        dec = JacobiDecoderNonGreedy(H.bm, forward_step=lambda s, d: H.forward_step_batch([s], d),
+                                     forward_step_batch=H.forward_step_batch, eos_token_id=eos, pad_token_id=pad, vocab_size=V,
+                                     device=torch.device(dev))
+        dec.set_streams(pads, unis, bonus)
+        seqs, oseqs, models = [], [], []
+        for it in items:
+            m = ScriptedModel(V, it["seed"], robust, it["pl"], eos_id=eos, eos_pos=it["eos_pos"], reserved=(pad,))
+            sp = SamplingParams(temperature=temperature, max_tokens=it["mt"], decode_strategy="jacobi", jacobi_block_len=it["L"],
+                                jacobi_max_iterations=max_iters)
+            seqs.append(H.add(m, sp, None))
+            oseqs.append(O.OracleSeq(m.prompt(), it["L"], it["mt"], max_iters=max_iters))
+            models.append(m)
+        by = {id(s): m for s, m in zip(oseqs, models)}
+        cur = {"p": 0, "u": 0, "b": 0}
+
+        def take(name, arr):
+            def f(k=None):
+                if k is None:
+                    v = arr[cur[name] % len(arr)]
+                    cur[name] += 1
+                    return v
+                out = [arr[(cur[name] + i) % len(arr)] for i in range(k)]
+                cur[name] += k
+                return out
+            return f
+
+        def ofwd(ss, drafts):
+            return [by[id(s)].logits_rows(s.token_ids[:-1], [d])[0][:-1] for s, d in zip(ss, drafts)]
+        stats = O.new_stats()
+        want = O.nongreedy_generate_batch(ofwd, oseqs, eos, temperature, take("p", pads), take("u", unis), take("b", bonus), stats)
+        got = dec.generate_chunk_batch(seqs)
+        assert got == want
+        assert dec.stats == stats
+        assert dec._cur == [cur["u"], cur["b"], cur["p"]]
