@@ -568,11 +568,11 @@ __global__ __launch_bounds__(64) void mb_pack_kernel(int32_t *states, int64_t st
                                                       int32_t *row_len) {
     jfmb::mb_pack_body(DevLanes{}, blockIdx.x, states, state_ints, Tpad, pad_fill, input_ids, positions, row_prompt, row_len);
 }
-constexpr int MB_STAGE_INTS = 8192;   // 32 KB of LDS: greedy rows of one prompt (B x Tpad tokens); larger shapes read global
+constexpr int MB_STAGE_INTS = 12288;  // 48 KB of LDS: compact image of the live state + the prompt's greedy rows; else global
 __global__ __launch_bounds__(64) void mb_step_kernel(int32_t *states, int64_t state_ints, unsigned long long *packed,
                                                       int64_t packed_len, jf_mb_desc *desc) {
-    __shared__ int32_t s_greedy[MB_STAGE_INTS];
-    jfmb::mb_step_body(DevLanes{}, blockIdx.x, states, state_ints, (uint64_t *)packed, packed_len, desc, s_greedy, MB_STAGE_INTS);
+    __shared__ int32_t s_stage[MB_STAGE_INTS];
+    jfmb::mb_step_body(DevLanes{}, blockIdx.x, states, state_ints, (uint64_t *)packed, packed_len, desc, s_stage, MB_STAGE_INTS);
 }
 __global__ __launch_bounds__(64) void mb_read_ret_kernel(const int32_t *states, int64_t state_ints, int64_t *ret,
                                                           int32_t ret_cap) {

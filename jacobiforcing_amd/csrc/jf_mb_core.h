@@ -67,6 +67,26 @@ JF_HD Layout make_layout(int n, int K, int pool_size, int max_blocks) {
     return L;
 }
 
+// same arrangement with explicit token capacities (the compact LDS image of a live state uses smaller ones)
+JF_HD Layout make_layout_caps(int n, int NB, int RMAX, int cap_tokens, int pool_size) {
+    Layout L;
+    L.n = n;
+    L.NB = NB;
+    L.RMAX = RMAX;
+    L.TMAX = cap_tokens;
+    L.LPOOL = cap_tokens;
+    L.pool_size = pool_size;
+    L.blk_stride = 8 + (n + 1) + L.RMAX * n;
+    L.hdr_ints = H_SPANS + 3 * L.NB;
+    L.off_blocks = L.hdr_ints;
+    L.off_pool = L.off_blocks + L.NB * L.blk_stride;
+    L.off_out = L.off_pool + imax(pool_size, 0) * (1 + L.LPOOL);
+    L.off_ret = L.off_out + L.RMAX * L.TMAX;
+    L.total = L.off_ret + L.TMAX + 2;
+    L.total = (L.total + 3) & ~3;
+    return L;
+}
+
 JF_HD Layout layout_of(const int32_t *S) {
     return make_layout(S[H_N], S[H_K], S[H_POOL_SIZE], S[H_NB]);
 }
@@ -534,29 +554,61 @@ template <class Lanes>
 JF_HD void mb_step_body(Lanes lanes, int p, int32_t *states, int64_t state_ints, uint64_t *packed,
                         int64_t packed_len, jf_mb_desc *desc, int32_t *stage = nullptr, int stage_ints = 0) {
     int32_t *S = states + (int64_t)p * state_ints;
-    Layout lay = layout_of(S);
-    Machine<Lanes> m(S, lanes, lay);
+    const Layout Lg = layout_of(S);
     const int64_t base = S[H_ROW_BASE];
     const int64_t tpad = S[H_TPAD];
     const int B = S[H_B];
     const uint64_t *pk = packed;
     const int ntok = B * (int)tpad;
-    if (stage && ntok > 0 && ntok <= stage_ints) {
-        // stage this prompt's greedy token rows (decoded argmax results) in LDS once: every accept scan, re-draft and
-        // next-token pick below then reads LDS instead of making dependent trips to global memory
+    const int live = S[H_LEN_LISTS];
+    // Compact LDS image of the LIVE state: the block lists are sized for the worst case (1 + max_iter entries) but a step
+    // touches `live` blocks (+1 if it spawns) and token rows no longer than (visible blocks + 1) * n.
+    const int nbc = imin(Lg.NB, live + 1);
+    const int cap = imin(Lg.TMAX, (imax(S[H_NUM_BLOCKS], live) + 1) * Lg.n);
+    const Layout Lc = make_layout_caps(Lg.n, nbc, Lg.RMAX, cap, Lg.pool_size);
+    const bool fits = stage && !S[H_DONE] && !S[H_ERR] && ntok > 0 && (Lc.total + ntok) <= stage_ints;
+    if (fits) {
+        int32_t *W = stage;                  // working image
+        int32_t *sg = stage + Lc.total;      // greedy rows of this prompt
+        for (int i = lanes.lane(); i < H_SPANS + 3 * imin(S[H_NSPANS], nbc); i += lanes.count()) W[i] = S[i];
+        for (int i = lanes.lane(); i < live * Lg.blk_stride; i += lanes.count()) W[Lc.off_blocks + i] = S[Lg.off_blocks + i];
+        for (int e = 0; e < Lg.pool_size; ++e) {
+            const int32_t *src = S + Lg.off_pool + e * (1 + Lg.LPOOL);
+            int32_t *dst = W + Lc.off_pool + e * (1 + Lc.LPOOL);
+            const int len = imin(src[0], Lc.LPOOL);
+            for (int i = lanes.lane(); i < 1 + len; i += lanes.count()) dst[i] = src[i];
+        }
         for (int i = lanes.lane(); i < ntok; i += lanes.count()) {
             const int64_t idx = base * tpad + i;
-            stage[i] = (idx >= 0 && idx < packed_len) ? decode_packed(pk[idx]) : -1;
+            sg[i] = (idx >= 0 && idx < packed_len) ? decode_packed(pk[idx]) : -1;
         }
         lanes.sync();
-        const int32_t *sg = stage;
         const int tp = (int)tpad;
         auto G = [sg, tp, ntok](int r, int t) -> int {
             const int i = r * tp + t;
             return (i >= 0 && i < ntok) ? sg[i] : -1;
         };
+        Machine<Lanes> m(W, lanes, Lc);
         m.step(G, desc ? desc + p : nullptr);
+        lanes.sync();
+        // write the image back (header without the capacity slots, live blocks, pool entries, next `out`, `ret`)
+        const int live2 = W[H_LEN_LISTS];
+        for (int i = lanes.lane(); i < H_SPANS + 3 * imin(W[H_NSPANS], nbc); i += lanes.count())
+            if (i != H_NB && i != H_RMAX && i != H_TMAX && i != H_LPOOL) S[i] = W[i];
+        for (int i = lanes.lane(); i < live2 * Lg.blk_stride; i += lanes.count()) S[Lg.off_blocks + i] = W[Lc.off_blocks + i];
+        for (int e = 0; e < Lg.pool_size; ++e) {
+            const int32_t *src = W + Lc.off_pool + e * (1 + Lc.LPOOL);
+            int32_t *dst = S + Lg.off_pool + e * (1 + Lg.LPOOL);
+            const int len = imin(src[0], Lc.LPOOL);
+            for (int i = lanes.lane(); i < 1 + len; i += lanes.count()) dst[i] = src[i];
+        }
+        const int B2 = W[H_B], T2 = W[H_T];
+        for (int r = 0; r < B2; ++r)
+            for (int i = lanes.lane(); i < T2; i += lanes.count()) S[Lg.off_out + r * Lg.TMAX + i] = W[Lc.off_out + r * Lc.TMAX + i];
+        if (W[H_DONE])
+            for (int i = lanes.lane(); i < W[H_RET_LEN]; i += lanes.count()) S[Lg.off_ret + i] = W[Lc.off_ret + i];
     } else {
+        Machine<Lanes> m(S, lanes, Lg);
         auto G = [pk, base, tpad, packed_len](int r, int t) -> int {
             const int64_t idx = (base + r) * tpad + t;
             return (idx >= 0 && idx < packed_len) ? decode_packed(pk[idx]) : -1;

@@ -37,7 +37,9 @@ int hs_mb_pack(int32_t *states, int64_t state_ints, int P, int32_t Tpad, int64_t
     return 0;
 }
 int hs_mb_step(int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len, jf_mb_desc *desc) {
-    for (int p = 0; p < P; ++p) jfmb::mb_step_body(HostLanes{}, p, states, state_ints, packed, packed_len, desc);
+    // same staging buffer size as the kernel's LDS array, so the compact-image path (and its fall-back) run on the CPU too
+    static int32_t stage[12288];
+    for (int p = 0; p < P; ++p) jfmb::mb_step_body(HostLanes{}, p, states, state_ints, packed, packed_len, desc, stage, 12288);
     return 0;
 }
 int hs_mb_read_ret(const int32_t *states, int64_t state_ints, int P, int64_t *ret, int32_t ret_cap) {
