@@ -12,6 +12,11 @@
 #include <string.h>
 
 #include "jacobiforcing.h"
+#ifdef JF_EXP_MB_TRACE
+// experiment build only (tools/mb_step_trace.py): shader-clock stamps of prompt 0's step, read back by jf_exp_read_trace
+__device__ unsigned long long g_mb_trace[32];
+#define JF_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_mb_trace[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#endif
 #include "jf_mb_core.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -68,6 +73,11 @@ struct DevLanes {
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     __device__ __forceinline__ int reduce_min(int v) const { return wave_min_i32(v); }
     __device__ __forceinline__ int reduce_sum(int v) const { return wave_sum_i32(v); }
+    __device__ __forceinline__ int first_true(bool pred) const {      // lowest lane with pred, 64 if none
+        const unsigned long long m = __ballot(pred);
+        return m ? __builtin_ctzll(m) : 64;
+    }
+    __device__ __forceinline__ int count_true(bool pred) const { return __popcll(__ballot(pred)); }
     __device__ __forceinline__ int prefix_count(bool pred) const {
         const unsigned long long m = __ballot(pred);
         return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -568,12 +578,17 @@ __global__ __launch_bounds__(64) void mb_pack_kernel(int32_t *states, int64_t st
                                                       int32_t *row_len) {
     jfmb::mb_pack_body(DevLanes{}, blockIdx.x, states, state_ints, Tpad, pad_fill, input_ids, positions, row_prompt, row_len);
 }
-constexpr int MB_STAGE_INTS = 12288;  // 48 KB of LDS: compact image of the live state + the prompt's greedy rows; else global
 __global__ __launch_bounds__(64) void mb_step_kernel(int32_t *states, int64_t state_ints, unsigned long long *packed,
                                                       int64_t packed_len, jf_mb_desc *desc) {
-    __shared__ int32_t s_stage[MB_STAGE_INTS];
-    jfmb::mb_step_body(DevLanes{}, blockIdx.x, states, state_ints, (uint64_t *)packed, packed_len, desc, s_stage, MB_STAGE_INTS);
+    JF_STAMP(0);
+    jfmb::mb_step_body(DevLanes{}, blockIdx.x, states, state_ints, (uint64_t *)packed, packed_len, desc);
+    JF_STAMP(12);
 }
+#ifdef JF_EXP_MB_TRACE
+extern "C" int jf_exp_read_trace(unsigned long long *out32) {
+    return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_mb_trace), sizeof(unsigned long long) * 32);
+}
+#endif
 __global__ __launch_bounds__(64) void mb_read_ret_kernel(const int32_t *states, int64_t state_ints, int64_t *ret,
                                                           int32_t ret_cap) {
     jfmb::mb_read_ret_body(DevLanes{}, blockIdx.x, states, state_ints, ret, ret_cap);

@@ -6,7 +6,7 @@
 //   * a single-lane policy used ONLY by tests/hostsim (CPU CI of this logic; never shipped).
 //
 // Control flow is wave-uniform: every lane holds the same scalars in registers; token arrays live
-// in the state block (LDS-staged or global) and phases that exchange data through it are separated
+// in the state block and phases that exchange data through it are separated
 // by lanes.sync().
 //
 // MB = modeling/cllm2_qwen2_modeling_kv_terminate_on_eos_improved_multiblock_lookahead_unified.py
@@ -17,10 +17,15 @@
 
 #if defined(__HIPCC__) || defined(__CUDACC__)
 #define JF_HD __host__ __device__ __forceinline__
+#define JF_UNROLL _Pragma("unroll")
 #else
 #define JF_HD inline
+#define JF_UNROLL
 #endif
 
+#ifndef JF_STAMP
+#define JF_STAMP(k) do { } while (0)   // experiment builds define it to record a clock at phase k
+#endif
 #define JF_FAIL(code) do { err = (code); err_line = __LINE__; } while (0)
 
 namespace jfmb {
@@ -64,26 +69,6 @@ JF_HD Layout make_layout(int n, int K, int pool_size, int max_blocks) {
     L.off_ret = L.off_out + L.RMAX * L.TMAX;
     L.total = L.off_ret + L.TMAX + 2;
     L.total = (L.total + 3) & ~3;         // keep 16-byte multiples
-    return L;
-}
-
-// same arrangement with explicit token capacities (the compact LDS image of a live state uses smaller ones)
-JF_HD Layout make_layout_caps(int n, int NB, int RMAX, int cap_tokens, int pool_size) {
-    Layout L;
-    L.n = n;
-    L.NB = NB;
-    L.RMAX = RMAX;
-    L.TMAX = cap_tokens;
-    L.LPOOL = cap_tokens;
-    L.pool_size = pool_size;
-    L.blk_stride = 8 + (n + 1) + L.RMAX * n;
-    L.hdr_ints = H_SPANS + 3 * L.NB;
-    L.off_blocks = L.hdr_ints;
-    L.off_pool = L.off_blocks + L.NB * L.blk_stride;
-    L.off_out = L.off_pool + imax(pool_size, 0) * (1 + L.LPOOL);
-    L.off_ret = L.off_out + L.RMAX * L.TMAX;
-    L.total = L.off_ret + L.TMAX + 2;
-    L.total = (L.total + 3) & ~3;
     return L;
 }
 
@@ -145,10 +130,12 @@ struct Machine {
         for (int i = lanes.lane(); i < len; i += lanes.count()) dst[i] = v;
     }
     JF_HD int find_first_eq(const int32_t *a, int len, int tok) const {
-        int m = len;
-        for (int i = lanes.lane(); i < len; i += lanes.count())
-            if (a[i] == tok) { m = i; break; }
-        return lanes.reduce_min(m);
+        for (int i0 = 0; i0 < len; i0 += lanes.count()) {
+            const int i = i0 + lanes.lane();
+            const int f = lanes.first_true(i < len && a[i] == tok);
+            if (f < lanes.count()) return i0 + f;
+        }
+        return len;
     }
 
     // ---- MB:264-271 ---------------------------------------------------------------------------
@@ -261,12 +248,14 @@ struct Machine {
             } else {
                 iters++;
                 T = build_out(B, nsp);
+                JF_STAMP(10);
                 if (err) { done = 1; T = 0; B = 0; }
                 else if (T == 0) { collect_ret(false, kv_len, has_lnt ? lnt : -1); B = 0; }
             }
         }
         store_scalars();
         if (lanes.lane() == 0) {
+            JF_STAMP(11);
             S[H_B] = done ? 0 : B; S[H_T] = done ? 0 : T; S[H_NSPANS] = done ? 0 : nsp;
             if (d) {
                 d->B = done ? 0 : B; d->T = done ? 0 : T; d->done = done; d->error = err; d->iters = iters;
@@ -283,6 +272,7 @@ struct Machine {
     JF_HD void step(GreedyFn G, jf_mb_desc *d) {
         load_scalars();
         if (done || err) { next_iteration(d); return; }
+        JF_STAMP(1);
         const int B = S[H_B], T = S[H_T], nspans = S[H_NSPANS];
         const int kv_before = kv_len;
         int kv_cur = kv_before + T;          // DynamicCache.update appended every forwarded token
@@ -297,14 +287,34 @@ struct Machine {
             // accepted[r] (MB:482-486); RA: best = first max (MB:489), pseudo: row 0 (MB:491)
             int best_idx = 0, acc_raw = 0;
             const int nrows = (b == RA) ? B : 1;
-            for (int r = 0; r < nrows; ++r) {
-                const int32_t *drow = draft(b, rows_d == 1 ? 0 : r);
-                int m = Ls - 1;
-                for (int i = lanes.lane(); i < Ls - 1; i += lanes.count())
-                    if (drow[i + 1] != G(r, start - 1 + i)) { m = i; break; }
-                m = lanes.reduce_min(m);
-                if (m + 1 > acc_raw) { acc_raw = m + 1; best_idx = r; }
+            const int cmp = Ls - 1;          // comparisons per row; m == cmp <=> no mismatch found (yet)
+            // four rows per pass: their loads are independent and issue together, then one ballot per row
+            for (int r0 = 0; r0 < nrows; r0 += 4) {
+                int m[4] = {cmp, cmp, cmp, cmp};
+                for (int i0 = 0; i0 < cmp; i0 += lanes.count()) {
+                    const int i = i0 + lanes.lane();
+                    bool mm[4];
+JF_UNROLL
+                    for (int k = 0; k < 4; ++k) {
+                        const int r = r0 + k;
+                        mm[k] = (r < nrows && i < cmp && m[k] == cmp)
+                                    ? draft(b, rows_d == 1 ? 0 : r)[i + 1] != G(r, start - 1 + i) : false;
+                    }
+                    bool open = false;
+JF_UNROLL
+                    for (int k = 0; k < 4; ++k) {
+                        if (r0 + k < nrows && m[k] == cmp) {
+                            const int f = lanes.first_true(mm[k]);
+                            if (f < lanes.count()) m[k] = i0 + f; else open = true;
+                        }
+                    }
+                    if (!open) break;
+                }
+JF_UNROLL
+                for (int k = 0; k < 4; ++k)
+                    if (r0 + k < nrows && m[k] + 1 > acc_raw) { acc_raw = m[k] + 1; best_idx = r0 + k; }
             }
+            JF_STAMP(2);
             if (rows_d != 1 && B != 1 && rows_d != B) { JF_FAIL(JF_E_SHAPE); break; }   // torch broadcast raises (MB:482)
             const int32_t *drow = draft(b, rows_d == 1 ? 0 : best_idx);
             if (s == 0 || b == RA) best_row = (b == RA) ? best_idx : best_row;   // MB:500-502
@@ -325,6 +335,7 @@ struct Machine {
             lanes.sync();
             if (lanes.lane() == 0) { bb[B_ACCLEN] = new_acclen; bb[B_TOTAL] = new_total; }
             lanes.sync();
+            JF_STAMP(3);
             if (b == RA) ra_accepted += acc_len;
             if (eos_reached && b == RA) {                                       // MB:531-547
                 collect_ret(true, kv_cur, last_acc_tok);
@@ -342,43 +353,35 @@ struct Machine {
                 lanes.sync();
                 if (lanes.lane() == 0) { bb[B_DROWS] = 1; bb[B_DLEN] = newL; }
                 lanes.sync();
+                JF_STAMP(4);
                 if (b == RA) {
                     // MB:564-573: pool.append(concat of all blocks), pool.append(rejected greedy tail)
                     {
-                        // length first (PAD stripped, MB:405-407), then fill
-                        int clen = 0;
-                        for (int q = 0; q < num_blocks; ++q) {
-                            int32_t *qb = blk(q);
-                            const int la = qb[B_ACCLEN], ld = qb[B_DLEN];
-                            int cnt = 0;
-                            for (int i = lanes.lane(); i < la + ld; i += lanes.count()) {
-                                int tok = i < la ? acc(q)[i] : draft(q, 0)[i - la];
-                                if (!(pad >= 0 && tok == pad)) cnt++;
-                            }
-                            clen += lanes.reduce_sum(cnt);
-                        }
-                        if (clen > L.LPOOL) { JF_FAIL(JF_E_CAPACITY); break; }
-                        if (clen > 0) {
-                            int32_t *e = pool_push_slot(clen);
-                            if (e) {
-                                int base = 0;
-                                for (int q = 0; q < num_blocks; ++q) {
-                                    int32_t *qb = blk(q);
-                                    const int la = qb[B_ACCLEN], ld = qb[B_DLEN];
-                                    // order-preserving compaction, 64 tokens per pass
-                                    for (int i0 = 0; i0 < la + ld; i0 += lanes.count()) {
-                                        int i = i0 + lanes.lane();
-                                        int tok = 0; bool keep = false;
-                                        if (i < la + ld) {
-                                            tok = i < la ? acc(q)[i] : draft(q, 0)[i - la];
-                                            keep = !(pad >= 0 && tok == pad);
-                                        }
-                                        int before = lanes.prefix_count(keep);      // # kept lanes below me
-                                        if (keep) e[1 + base + before] = tok;
-                                        base += lanes.reduce_sum(keep ? 1 : 0);
+                        // PAD-stripped concat (MB:405-407) compacted straight into the slot the push will take (the oldest
+                        // entry's storage when the deque is full); the push is committed only if something was kept
+                        if (L.pool_size > 0) {
+                            const int slot = (pool_count == L.pool_size) ? pool_head : (pool_head + pool_count) % L.pool_size;
+                            int32_t *e = S + L.off_pool + slot * (1 + L.LPOOL);
+                            int clen = 0;
+                            for (int q = 0; q < num_blocks && !err; ++q) {
+                                int32_t *qb = blk(q);
+                                const int la = qb[B_ACCLEN], ld = qb[B_DLEN];
+                                for (int i0 = 0; i0 < la + ld; i0 += lanes.count()) {   // order-preserving, 64 tokens per pass
+                                    const int i = i0 + lanes.lane();
+                                    int tok = 0; bool keep = false;
+                                    if (i < la + ld) {
+                                        tok = i < la ? acc(q)[i] : draft(q, 0)[i - la];
+                                        keep = !(pad >= 0 && tok == pad);
                                     }
+                                    const int before = lanes.prefix_count(keep);      // # kept lanes below me
+                                    const int cnt = lanes.count_true(keep);
+                                    if (clen + cnt > L.LPOOL) { JF_FAIL(JF_E_CAPACITY); break; }
+                                    if (keep) e[1 + clen + before] = tok;
+                                    clen += cnt;
                                 }
                             }
+                            if (err) break;
+                            if (clen > 0) pool_push_slot(clen);
                         }
                         lanes.sync();
                         const int tlen = newL - 1;                                // greedy[acc_len:-1]
@@ -387,26 +390,52 @@ struct Machine {
                             if (e) for (int i = lanes.lane(); i < tlen; i += lanes.count()) e[1 + i] = d0[1 + i];
                         }
                         lanes.sync();
+                        JF_STAMP(5);
                     }
                     // MB:577-585 candidates
                     if ((double)new_total / (double)n >= lk.dd) {
                         int C = 0;
-                        for (int i = pool_count - 2; i >= 0; --i) {               // reversed(list(pool)[:-1])
-                            int32_t *e = pool_entry(i);
-                            const int elen = e[0];
-                            const int pos = find_first_eq(e + 1, elen, nxt);
-                            if (pos >= elen) continue;
-                            if (1 + C >= L.RMAX) { JF_FAIL(JF_E_CAPACITY); break; }
-                            int32_t *c = draft(b, 1 + C);
-                            const int avail = elen - pos;
-                            for (int j = lanes.lane(); j < newL; j += lanes.count())
-                                c[j] = j < avail ? e[1 + pos + j] : d0[j];        // MB:82-86
-                            C++;
+                        // reversed(list(pool)[:-1]), four entries per pass so that their length reads, then their token
+                        // reads, are independent round trips instead of a chain
+                        for (int i1 = pool_count - 2; i1 >= 0 && !err; i1 -= 4) {
+                            const int32_t *e[4];
+                            int elen[4], pos[4];
+JF_UNROLL
+                            for (int k = 0; k < 4; ++k) e[k] = (i1 - k >= 0) ? pool_entry(i1 - k) : nullptr;
+                            int maxlen = 0;
+JF_UNROLL
+                            for (int k = 0; k < 4; ++k) { elen[k] = e[k] ? e[k][0] : 0; pos[k] = elen[k]; maxlen = imax(maxlen, elen[k]); }
+                            for (int i0 = 0; i0 < maxlen; i0 += lanes.count()) {
+                                const int i = i0 + lanes.lane();
+                                bool hit[4];
+JF_UNROLL
+                                for (int k = 0; k < 4; ++k) hit[k] = (pos[k] == elen[k] && i < elen[k]) ? e[k][1 + i] == nxt : false;
+                                bool open = false;
+JF_UNROLL
+                                for (int k = 0; k < 4; ++k) {
+                                    if (pos[k] == elen[k] && i0 < elen[k]) {
+                                        const int f = lanes.first_true(hit[k]);
+                                        if (f < lanes.count()) pos[k] = i0 + f; else if (i0 + lanes.count() < elen[k]) open = true;
+                                    }
+                                }
+                                if (!open) break;
+                            }
+JF_UNROLL
+                            for (int k = 0; k < 4; ++k) {
+                                if (!e[k] || pos[k] >= elen[k] || err) continue;
+                                if (1 + C >= L.RMAX) { JF_FAIL(JF_E_CAPACITY); continue; }
+                                int32_t *c = draft(b, 1 + C);
+                                const int avail = elen[k] - pos[k];
+                                for (int j = lanes.lane(); j < newL; j += lanes.count())
+                                    c[j] = j < avail ? e[k][1 + pos[k] + j] : d0[j];   // MB:82-86
+                                C++;
+                            }
                         }
                         if (err) break;
                         lanes.sync();
                         if (C > 1 && lanes.lane() == 0) bb[B_DROWS] = 1 + C;        // MB:579-582 (Q5)
                         lanes.sync();
+                        JF_STAMP(6);
                     }
                 }
             } else {                                                            // MB:590-593
@@ -430,6 +459,7 @@ struct Machine {
 
         if (!returned && !err) {
             // MB:617-626
+            JF_STAMP(7);
             { int c = committed_len(RA); if (kv_cur > c) kv_cur = c; }
             kv_len = kv_cur;
             // MB:629-653 spawn
@@ -492,6 +522,7 @@ struct Machine {
                 }
             }
             // MB:719-721 early stop
+            JF_STAMP(8);
             if (!err) {
                 bool all_full = true;
                 for (int b = 0; b < num_blocks; ++b) if (blk(b)[B_TOTAL] < n) all_full = false;
@@ -502,6 +533,7 @@ struct Machine {
             }
         }
         if (err) done = 1;
+        JF_STAMP(9);
         // physical KV: everything kept from this forward came from candidate row best_row
         if (best_row != 0 && kv_len > kv_before) { kv_src_row = best_row; kv_copy_dst = kv_before; kv_copy_len = kv_len - kv_before; }
         next_iteration(d);
@@ -552,69 +584,19 @@ JF_HD void mb_pack_body(Lanes lanes, int p, int32_t *states, int64_t state_ints,
 
 template <class Lanes>
 JF_HD void mb_step_body(Lanes lanes, int p, int32_t *states, int64_t state_ints, uint64_t *packed,
-                        int64_t packed_len, jf_mb_desc *desc, int32_t *stage = nullptr, int stage_ints = 0) {
+                        int64_t packed_len, jf_mb_desc *desc) {
     int32_t *S = states + (int64_t)p * state_ints;
-    const Layout Lg = layout_of(S);
+    Layout lay = layout_of(S);
+    Machine<Lanes> m(S, lanes, lay);
     const int64_t base = S[H_ROW_BASE];
     const int64_t tpad = S[H_TPAD];
     const int B = S[H_B];
     const uint64_t *pk = packed;
-    const int ntok = B * (int)tpad;
-    const int live = S[H_LEN_LISTS];
-    // Compact LDS image of the LIVE state: the block lists are sized for the worst case (1 + max_iter entries) but a step
-    // touches `live` blocks (+1 if it spawns) and token rows no longer than (visible blocks + 1) * n.
-    const int nbc = imin(Lg.NB, live + 1);
-    const int cap = imin(Lg.TMAX, (imax(S[H_NUM_BLOCKS], live) + 1) * Lg.n);
-    const Layout Lc = make_layout_caps(Lg.n, nbc, Lg.RMAX, cap, Lg.pool_size);
-    const bool fits = stage && !S[H_DONE] && !S[H_ERR] && ntok > 0 && (Lc.total + ntok) <= stage_ints;
-    if (fits) {
-        int32_t *W = stage;                  // working image
-        int32_t *sg = stage + Lc.total;      // greedy rows of this prompt
-        for (int i = lanes.lane(); i < H_SPANS + 3 * imin(S[H_NSPANS], nbc); i += lanes.count()) W[i] = S[i];
-        for (int i = lanes.lane(); i < live * Lg.blk_stride; i += lanes.count()) W[Lc.off_blocks + i] = S[Lg.off_blocks + i];
-        for (int e = 0; e < Lg.pool_size; ++e) {
-            const int32_t *src = S + Lg.off_pool + e * (1 + Lg.LPOOL);
-            int32_t *dst = W + Lc.off_pool + e * (1 + Lc.LPOOL);
-            const int len = imin(src[0], Lc.LPOOL);
-            for (int i = lanes.lane(); i < 1 + len; i += lanes.count()) dst[i] = src[i];
-        }
-        for (int i = lanes.lane(); i < ntok; i += lanes.count()) {
-            const int64_t idx = base * tpad + i;
-            sg[i] = (idx >= 0 && idx < packed_len) ? decode_packed(pk[idx]) : -1;
-        }
-        lanes.sync();
-        const int tp = (int)tpad;
-        auto G = [sg, tp, ntok](int r, int t) -> int {
-            const int i = r * tp + t;
-            return (i >= 0 && i < ntok) ? sg[i] : -1;
-        };
-        Machine<Lanes> m(W, lanes, Lc);
-        m.step(G, desc ? desc + p : nullptr);
-        lanes.sync();
-        // write the image back (header without the capacity slots, live blocks, pool entries, next `out`, `ret`)
-        const int live2 = W[H_LEN_LISTS];
-        for (int i = lanes.lane(); i < H_SPANS + 3 * imin(W[H_NSPANS], nbc); i += lanes.count())
-            if (i != H_NB && i != H_RMAX && i != H_TMAX && i != H_LPOOL) S[i] = W[i];
-        for (int i = lanes.lane(); i < live2 * Lg.blk_stride; i += lanes.count()) S[Lg.off_blocks + i] = W[Lc.off_blocks + i];
-        for (int e = 0; e < Lg.pool_size; ++e) {
-            const int32_t *src = W + Lc.off_pool + e * (1 + Lc.LPOOL);
-            int32_t *dst = S + Lg.off_pool + e * (1 + Lg.LPOOL);
-            const int len = imin(src[0], Lc.LPOOL);
-            for (int i = lanes.lane(); i < 1 + len; i += lanes.count()) dst[i] = src[i];
-        }
-        const int B2 = W[H_B], T2 = W[H_T];
-        for (int r = 0; r < B2; ++r)
-            for (int i = lanes.lane(); i < T2; i += lanes.count()) S[Lg.off_out + r * Lg.TMAX + i] = W[Lc.off_out + r * Lc.TMAX + i];
-        if (W[H_DONE])
-            for (int i = lanes.lane(); i < W[H_RET_LEN]; i += lanes.count()) S[Lg.off_ret + i] = W[Lc.off_ret + i];
-    } else {
-        Machine<Lanes> m(S, lanes, Lg);
-        auto G = [pk, base, tpad, packed_len](int r, int t) -> int {
-            const int64_t idx = (base + r) * tpad + t;
-            return (idx >= 0 && idx < packed_len) ? decode_packed(pk[idx]) : -1;
-        };
-        m.step(G, desc ? desc + p : nullptr);
-    }
+    auto G = [pk, base, tpad, packed_len](int r, int t) -> int {
+        const int64_t idx = (base + r) * tpad + t;
+        return (idx >= 0 && idx < packed_len) ? decode_packed(pk[idx]) : -1;
+    };
+    m.step(G, desc ? desc + p : nullptr);
     // re-zero this prompt's slice of the argmax workspace for the next jf_argmax_partial
     lanes.sync();
     const int64_t lo = base * tpad, hi = (base + B) * tpad;

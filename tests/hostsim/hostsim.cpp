@@ -16,6 +16,8 @@ struct HostLanes {
     void sync() const {}
     int reduce_min(int v) const { return v; }
     int reduce_sum(int v) const { return v; }
+    int first_true(bool pred) const { return pred ? 0 : 1; }
+    int count_true(bool pred) const { return pred ? 1 : 0; }
     int prefix_count(bool) const { return 0; }
 };
 
@@ -37,9 +39,7 @@ int hs_mb_pack(int32_t *states, int64_t state_ints, int P, int32_t Tpad, int64_t
     return 0;
 }
 int hs_mb_step(int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len, jf_mb_desc *desc) {
-    // same staging buffer size as the kernel's LDS array, so the compact-image path (and its fall-back) run on the CPU too
-    static int32_t stage[12288];
-    for (int p = 0; p < P; ++p) jfmb::mb_step_body(HostLanes{}, p, states, state_ints, packed, packed_len, desc, stage, 12288);
+    for (int p = 0; p < P; ++p) jfmb::mb_step_body(HostLanes{}, p, states, state_ints, packed, packed_len, desc);
     return 0;
 }
 int hs_mb_read_ret(const int32_t *states, int64_t state_ints, int P, int64_t *ret, int32_t ret_cap) {
