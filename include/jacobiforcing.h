@@ -58,6 +58,15 @@ const char *jf_last_error(void);
 int jf_argmax_partial(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride,
                       uint64_t *packed, void *stream);
 
+/* Same, for logits computed on a compacted list of positions: row i's result goes to
+ * packed[out_index[i]]; rows with out_index[i] < 0 (list padding) are not read at all.
+ * The reference runs lm_head + argmax over every position of the padded [B, T] rectangle
+ * (MB:463-476); with jf_mb_pack's valid_index only positions that carry a draft token are
+ * computed, and jf_mb_step still finds them at (row_base + b) * Tpad + t.
+ */
+int jf_argmax_scatter(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride,
+                      const int32_t *out_index, uint64_t *packed, void *stream);
+
 /* packed -> int64 token ids (and re-zero packed).  greedy [R] int64. */
 int jf_argmax_decode(uint64_t *packed, int64_t R, int64_t *greedy, void *stream);
 
@@ -134,10 +143,14 @@ int jf_mb_begin(int32_t *states, int64_t state_ints, int P, const jf_mb_params *
  *   input_ids [Rtot, Tpad] int64 (padding = pad_fill), positions [Rtot, Tpad] int32 (kv_len + t),
  *   row_prompt [Rtot] int32, row_len [Rtot] int32 (T of that row).
  * Also records (row_base, Tpad) in each state so jf_mb_step can find its greedy tokens.
+ * valid_index (nullable) [>= roundup(sum_p B_p*T_p, valid_align)] int32: flat index row*Tpad + t of
+ *   every position that carries a draft token, prompt by prompt, row by row; the list is rounded
+ *   up to a multiple of valid_align (>= 1) with -1 entries.  Its length is known on the host from
+ *   the descriptors (sum of B*T).  Feed it to the lm_head gather and to jf_argmax_scatter.
  */
 int jf_mb_pack(int32_t *states, int64_t state_ints, int P, int32_t Tpad, int64_t pad_fill,
                int64_t *input_ids, int32_t *positions, int32_t *row_prompt, int32_t *row_len,
-               void *stream);
+               int32_t *valid_index, int32_t valid_align, void *stream);
 
 /* One loop body after the forward (MB:467-721, and MB:723-740 when the call ends):
  * verify every span against the packed argmax results, pick the best candidate row, EOS cap,

@@ -57,6 +57,7 @@ _SIGNATURES = {
     "jf_version": (C.c_int, []),
     "jf_last_error": (C.c_char_p, []),
     "jf_argmax_partial": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _vp, _vp]),
+    "jf_argmax_scatter": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _vp, _vp, _vp]),
     "jf_argmax_decode": (C.c_int, [_vp, _i64, _vp, _vp]),
     "jf_argmax_rows": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _vp, _vp, _vp]),
     "jf_accept_lengths": (C.c_int, [_vp, C.c_int, _vp, _i64, C.c_int, C.c_int, _vp, _vp, _vp]),
@@ -64,7 +65,7 @@ _SIGNATURES = {
     "jf_mb_max_rows": (_i32, [C.POINTER(MbParams)]),
     "jf_mb_max_tokens": (_i32, [C.POINTER(MbParams)]),
     "jf_mb_begin": (C.c_int, [_vp, _i64, C.c_int, C.POINTER(MbParams), _vp, _vp, _vp, _vp]),
-    "jf_mb_pack": (C.c_int, [_vp, _i64, C.c_int, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "jf_mb_pack": (C.c_int, [_vp, _i64, C.c_int, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "jf_mb_step": (C.c_int, [_vp, _i64, C.c_int, _vp, _i64, _vp, _vp]),
     "jf_mb_read_ret": (C.c_int, [_vp, _i64, C.c_int, _vp, _i32, _vp]),
     "jf_kv_append": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i32, _vp]),

@@ -293,11 +293,15 @@ __device__ __forceinline__ void scan_pipelined(FT &ft, const u32x4 *q, int k, in
 template <int DT, bool VEC, int UNROLL>
 __global__ __launch_bounds__(AM_TPB) void argmax_partial_kernel(const void *__restrict__ logits, int64_t R, int64_t V,
                                                                  int64_t row_stride, unsigned long long *__restrict__ packed,
-                                                                 int chunks_per_row, int64_t chunk_elems) {
+                                                                 int chunks_per_row, int64_t chunk_elems,
+                                                                 const int32_t *__restrict__ out_index) {
     using E = Elem<DT>;
     constexpr int EPV = E::EPV;
     const int64_t item = blockIdx.x;
     const int64_t row = item / chunks_per_row;
+    // slot of this row's result (jf_argmax_scatter): read up front so its latency hides behind the stream; < 0 = padding row
+    const int64_t orow = out_index ? (int64_t)out_index[row] : row;
+    if (orow < 0) return;
     const int c = (int)(item - row * chunks_per_row);
     const int64_t begin = (int64_t)c * chunk_elems;
     int64_t end = begin + chunk_elems;
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(AM_TPB) void argmax_partial_kernel(const void *__re
         uint64_t m = s_part[0];
 #pragma unroll
         for (int w = 1; w < AM_TPB / 64; ++w) m = s_part[w] > m ? s_part[w] : m;
-        atomicMax(packed + row, (unsigned long long)m);
+        atomicMax(packed + orow, (unsigned long long)m);
     }
 }
 
@@ -357,13 +361,16 @@ __global__ __launch_bounds__(AM_TPB) void argmax_partial_kernel(const void *__re
 template <int DT, int UNROLL>
 __global__ __launch_bounds__(AM_TPB) void argmax_wave_kernel(const void *__restrict__ logits, int64_t R, int64_t V,
                                                               int64_t row_stride, unsigned long long *__restrict__ packed,
-                                                              int chunks_per_row, int64_t chunk_elems) {
+                                                              int chunks_per_row, int64_t chunk_elems,
+                                                              const int32_t *__restrict__ out_index) {
     using E = Elem<DT>;
     constexpr int EPV = E::EPV;
     const int lane = threadIdx.x & 63;
     const int64_t item = (int64_t)blockIdx.x * (AM_TPB / 64) + (threadIdx.x >> 6);
     if (item >= R * chunks_per_row) return;
     const int64_t row = item / chunks_per_row;
+    const int64_t orow = out_index ? (int64_t)out_index[row] : row;
+    if (orow < 0) return;
     const int c = (int)(item - row * chunks_per_row);
     const int64_t begin = (int64_t)c * chunk_elems;
     int64_t end = begin + chunk_elems;
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(AM_TPB) void argmax_wave_kernel(const void *__restr
         if (kk > best) { best = kk; bidx = (uint32_t)j; }
     }
     uint64_t pk = wave_max_u64(((uint64_t)best << 32) | (uint64_t)(~bidx));
-    if (lane == 0) atomicMax(packed + row, (unsigned long long)pk);
+    if (lane == 0) atomicMax(packed + orow, (unsigned long long)pk);
 }
 
 __global__ void argmax_decode_kernel(unsigned long long *packed, int64_t R, int64_t *greedy) {
@@ -434,8 +441,8 @@ static int64_t pick_chunk(int64_t gran, int64_t R, int64_t V, int64_t target_ite
     return ((chunk + gran - 1) / gran) * gran;
 }
 
-extern "C" int jf_argmax_partial(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride,
-                                 uint64_t *packed, void *stream) {
+static int argmax_launch(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, const int32_t *out_index,
+                         uint64_t *packed, void *stream) {
     if (R == 0) return JF_OK;
     if (!logits || !packed) return fail(JF_E_INVALID, "jf_argmax_partial: null pointer");
     if (dtype != JF_F32 && dtype != JF_BF16) return fail(JF_E_INVALID, "jf_argmax_partial: dtype %d", dtype);
@@ -482,7 +489,7 @@ extern "C" int jf_argmax_partial(const void *logits, int dtype, int64_t R, int64
         const int64_t blocks = (items + (AM_TPB / 64) - 1) / (AM_TPB / 64);
         if (blocks > 0x7FFFFFFFll) return fail(JF_E_CAPACITY, "jf_argmax_partial: grid too large");
         dim3 grid((unsigned)blocks), block(AM_TPB);
-#define JF_LAUNCHW(DT, UNR) argmax_wave_kernel<DT, UNR><<<grid, block, 0, s>>>(logits, R, V, row_stride, pk, (int)cpr, chunk)
+#define JF_LAUNCHW(DT, UNR) argmax_wave_kernel<DT, UNR><<<grid, block, 0, s>>>(logits, R, V, row_stride, pk, (int)cpr, chunk, out_index)
         if (dtype == JF_F32) { if (pipe) JF_LAUNCHW(JF_F32, 16); else if (deep) JF_LAUNCHW(JF_F32, 8); else JF_LAUNCHW(JF_F32, 4); }
         else { if (pipe) JF_LAUNCHW(JF_BF16, 16); else if (deep) JF_LAUNCHW(JF_BF16, 8); else JF_LAUNCHW(JF_BF16, 4); }
 #undef JF_LAUNCHW
@@ -496,7 +503,7 @@ extern "C" int jf_argmax_partial(const void *logits, int dtype, int64_t R, int64
     const int64_t items = R * cpr;
     if (items > 0x7FFFFFFFll) return fail(JF_E_CAPACITY, "jf_argmax_partial: grid too large");
     dim3 grid((unsigned)items), block(AM_TPB);
-#define JF_LAUNCH(DT, VECF, UNR) argmax_partial_kernel<DT, VECF, UNR><<<grid, block, 0, s>>>(logits, R, V, row_stride, pk, (int)cpr, chunk)
+#define JF_LAUNCH(DT, VECF, UNR) argmax_partial_kernel<DT, VECF, UNR><<<grid, block, 0, s>>>(logits, R, V, row_stride, pk, (int)cpr, chunk, out_index)
     if (dtype == JF_F32) {
         if (!vec) JF_LAUNCH(JF_F32, false, 4);
         else if (pipe) JF_LAUNCH(JF_F32, true, 16);
@@ -510,6 +517,17 @@ extern "C" int jf_argmax_partial(const void *logits, int dtype, int64_t R, int64
     }
 #undef JF_LAUNCH
     return check_launch("argmax_partial_kernel");
+}
+
+extern "C" int jf_argmax_partial(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride,
+                                 uint64_t *packed, void *stream) {
+    return argmax_launch(logits, dtype, R, V, row_stride, nullptr, packed, stream);
+}
+
+extern "C" int jf_argmax_scatter(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride,
+                                 const int32_t *out_index, uint64_t *packed, void *stream) {
+    if (R > 0 && !out_index) return fail(JF_E_INVALID, "jf_argmax_scatter: null out_index");
+    return argmax_launch(logits, dtype, R, V, row_stride, out_index, packed, stream);
 }
 
 extern "C" int jf_argmax_decode(uint64_t *packed, int64_t R, int64_t *greedy, void *stream) {
@@ -575,8 +593,9 @@ __global__ __launch_bounds__(64) void mb_begin_kernel(int32_t *states, int64_t s
 }
 __global__ __launch_bounds__(64) void mb_pack_kernel(int32_t *states, int64_t state_ints, int32_t Tpad, int64_t pad_fill,
                                                       int64_t *input_ids, int32_t *positions, int32_t *row_prompt,
-                                                      int32_t *row_len) {
-    jfmb::mb_pack_body(DevLanes{}, blockIdx.x, states, state_ints, Tpad, pad_fill, input_ids, positions, row_prompt, row_len);
+                                                      int32_t *row_len, int32_t *valid_index, int32_t valid_align) {
+    jfmb::mb_pack_body(DevLanes{}, blockIdx.x, gridDim.x, states, state_ints, Tpad, pad_fill, input_ids, positions, row_prompt,
+                       row_len, valid_index, valid_align);
 }
 __global__ __launch_bounds__(64) void mb_step_kernel(int32_t *states, int64_t state_ints, unsigned long long *packed,
                                                       int64_t packed_len, jf_mb_desc *desc) {
@@ -629,11 +648,13 @@ extern "C" int jf_mb_begin(int32_t *states, int64_t state_ints, int P, const jf_
 }
 
 extern "C" int jf_mb_pack(int32_t *states, int64_t state_ints, int P, int32_t Tpad, int64_t pad_fill, int64_t *input_ids,
-                          int32_t *positions, int32_t *row_prompt, int32_t *row_len, void *stream) {
+                          int32_t *positions, int32_t *row_prompt, int32_t *row_len, int32_t *valid_index,
+                          int32_t valid_align, void *stream) {
     if (P <= 0) return JF_OK;
     if (!states || !input_ids || !positions || !row_prompt || !row_len) return fail(JF_E_INVALID, "jf_mb_pack: null pointer");
     if (Tpad <= 0) return fail(JF_E_INVALID, "jf_mb_pack: Tpad=%d", Tpad);
-    mb_pack_kernel<<<P, 64, 0, (hipStream_t)stream>>>(states, state_ints, Tpad, pad_fill, input_ids, positions, row_prompt, row_len);
+    mb_pack_kernel<<<P, 64, 0, (hipStream_t)stream>>>(states, state_ints, Tpad, pad_fill, input_ids, positions, row_prompt, row_len,
+                                                      valid_index, valid_align < 1 ? 1 : valid_align);
     return check_launch("mb_pack_kernel");
 }
 

@@ -561,11 +561,16 @@ JF_HD void mb_begin_body(Lanes lanes, int p, int32_t *states, int64_t state_ints
 }
 
 template <class Lanes>
-JF_HD void mb_pack_body(Lanes lanes, int p, int32_t *states, int64_t state_ints, int32_t Tpad, int64_t pad_fill,
-                        int64_t *input_ids, int32_t *positions, int32_t *row_prompt, int32_t *row_len) {
+JF_HD void mb_pack_body(Lanes lanes, int p, int P, int32_t *states, int64_t state_ints, int32_t Tpad, int64_t pad_fill,
+                        int64_t *input_ids, int32_t *positions, int32_t *row_prompt, int32_t *row_len,
+                        int32_t *valid_index, int32_t valid_align) {
     int32_t *S = states + (int64_t)p * state_ints;
-    int row_base = 0;
-    for (int q = 0; q < p; ++q) row_base += states[(int64_t)q * state_ints + H_B];
+    int row_base = 0, valid_base = 0;
+    for (int q = 0; q < p; ++q) {
+        const int32_t *Q = states + (int64_t)q * state_ints;
+        row_base += Q[H_B];
+        valid_base += Q[H_B] * Q[H_T];
+    }
     Layout lay = layout_of(S);
     const int B = S[H_B], T = S[H_T], kv = S[H_KV_LEN];
     lanes.sync();
@@ -578,6 +583,14 @@ JF_HD void mb_pack_body(Lanes lanes, int p, int32_t *states, int64_t state_ints,
             positions[o + t] = kv + t;
         }
         if (lanes.lane() == 0) { row_prompt[row_base + r] = p; row_len[row_base + r] = T; }
+        // flat position of every token that carries a draft (lm_head / argmax run on these only)
+        if (valid_index)
+            for (int t = lanes.lane(); t < T; t += lanes.count()) valid_index[valid_base + r * T + t] = (int32_t)(o + t);
+    }
+    if (valid_index && p == P - 1 && valid_align > 1) {            // round the list up with "no position" entries
+        const int nv = valid_base + B * T;
+        const int nvp = (nv + valid_align - 1) / valid_align * valid_align;
+        for (int i = nv + lanes.lane(); i < nvp; i += lanes.count()) valid_index[i] = -1;
     }
     lanes.sync();
 }

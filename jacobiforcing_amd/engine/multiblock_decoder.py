@@ -58,7 +58,8 @@ LogitsHook = Callable[[torch.Tensor, "MultiblockJacobiDecoder"], torch.Tensor]
 
 class MultiblockJacobiDecoder:
     def __init__(self, model: Qwen2Model, num_prompts: int, params: ops.MultiblockParams, max_seq_len: int = 4096,
-                 logits_hook: Optional[LogitsHook] = None, t_align: int = 1):
+                 logits_hook: Optional[LogitsHook] = None, t_align: int = 1, compact_logits: bool = True,
+                 logit_align: Optional[int] = None):
         self.model = model
         self.P = int(num_prompts)
         self.params = params
@@ -72,6 +73,8 @@ class MultiblockJacobiDecoder:
         self.max_seq_len = max_seq_len
         self.logits_hook = logits_hook
         self.t_align = int(t_align)          # pad the per-iteration row length to a multiple (tuned-GEMM shape grid)
+        self.compact_logits = bool(compact_logits)   # lm_head + argmax on draft-carrying positions only (no padding rows)
+        self.logit_align = int(logit_align) if logit_align else self.t_align   # lm_head M rounded up to this multiple
         self.kv_len_host = np.zeros(self.P, dtype=np.int64)
         self.forwards = 0
         self.last_logits_rows = 0
@@ -109,7 +112,7 @@ class MultiblockJacobiDecoder:
     @torch.inference_mode()
     def iteration(self, d: np.ndarray) -> np.ndarray:
         """forward -> verify/accept/re-draft (HIP) -> KV commit.  ``d`` is the current descriptor table."""
-        packed_in = self.batch.pack(d, self.t_align)
+        packed_in = self.batch.pack(d, self.t_align, compact=self.compact_logits, valid_align=self.logit_align)
         if packed_in is None:
             return d
         ids, pos, row_prompt, row_len = packed_in
@@ -134,7 +137,8 @@ class MultiblockJacobiDecoder:
         s_cur = int(self.kv_len_host[B > 0].max()) + ids.shape[1]
         if prof: prof.start("jacobi.forward")
         logits = self.model.forward(ids, pos, self.cache, row_prompt=row_prompt, row_cand=row_cand, row_len=row_len,
-                                    kv_len_rows=kv_rows, any_candidates=any_cand, s_cur=s_cur)
+                                    kv_len_rows=kv_rows, any_candidates=any_cand, s_cur=s_cur,
+                                    logit_index=self.batch.valid_index)
         if self.logits_hook is not None:
             logits = self.logits_hook(logits, self, prefill=None)
         if prof: prof.stop("jacobi.forward")

@@ -208,13 +208,14 @@ class Qwen2Model:
     def forward(self, input_ids: torch.Tensor, positions: torch.Tensor, cache: StaticKVCache,
                 row_prompt: torch.Tensor, row_cand: torch.Tensor, row_len: torch.Tensor,
                 kv_len_rows: torch.Tensor, any_candidates: bool, logits_rows: Optional[slice] = None,
-                s_cur: Optional[int] = None) -> torch.Tensor:
+                s_cur: Optional[int] = None, logit_index: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One forward over R rows of (padded) length T.
 
         input_ids [R,T] int64, positions [R,T] int32 (= kv_len + t), row_prompt [R] (cache row of the prefix),
         row_cand [R] (-1: the row writes into the main cache, else index into the candidate scratch),
         row_len [R] valid tokens per row, kv_len_rows [R] committed prefix length per row, s_cur = max(kv_len)+T when the
-        caller knows it (saves a device read).  Returns logits [R*T, V] in the weight dtype (or ``logits_rows`` of it)."""
+        caller knows it (saves a device read).  Returns logits [R*T, V] in the weight dtype (or ``logits_rows`` of it, or
+        the rows listed in ``logit_index`` — flat positions, negative entries are list padding and yield a junk row)."""
         cfg, w = self.cfg, self.w
         R, T = input_ids.shape
         nq, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
@@ -275,4 +276,6 @@ class Qwen2Model:
         flat = self._norm(x, w.norm)
         if logits_rows is not None:
             flat = flat[logits_rows]
+        if logit_index is not None:
+            flat = flat.index_select(0, logit_index.clamp(min=0).long())
         return F.linear(flat, w.lm_head)

@@ -56,6 +56,18 @@ def argmax_partial(logits: torch.Tensor, packed: torch.Tensor) -> None:
                                       _ptr(packed), _stream(logits.device)), "jf_argmax_partial")
 
 
+def argmax_scatter(logits: torch.Tensor, out_index: torch.Tensor, packed: torch.Tensor) -> None:
+    """As ``argmax_partial`` for logits of a compacted position list: row i -> packed[out_index[i]]; rows whose index is
+    negative (list padding) are skipped without being read."""
+    if logits.dim() != 2 or logits.stride(1) != 1:
+        raise ValueError(f"logits must be [R, V] with a contiguous vocabulary axis, got {tuple(logits.shape)} strides {logits.stride()}")
+    R, V = logits.shape
+    if out_index.dtype != torch.int32 or out_index.numel() < R or not out_index.is_contiguous():
+        raise ValueError("out_index must be a contiguous int32 tensor with one entry per logits row")
+    N.check(N.lib().jf_argmax_scatter(_ptr(logits), _dtype_code(logits), R, V, logits.stride(0) if R > 1 else V,
+                                      _ptr(out_index), _ptr(packed), _stream(logits.device)), "jf_argmax_scatter")
+
+
 def argmax_rows(logits: torch.Tensor, packed: Optional[torch.Tensor] = None) -> torch.Tensor:
     """torch.argmax(logits, dim=-1) semantics (MB:476, SB:197, JD:357/567) for [..., V] logits."""
     shape = logits.shape[:-1]
@@ -147,6 +159,9 @@ class MultiblockBatch:
         self.positions = torch.zeros((rows * self.max_tokens,), dtype=torch.int32, device=dev)
         self.row_prompt = torch.zeros((rows,), dtype=torch.int32, device=dev)
         self.row_len = torch.zeros((rows,), dtype=torch.int32, device=dev)
+        self.valid_index_buf = torch.zeros((rows * self.max_tokens + 64,), dtype=torch.int32, device=dev)
+        self.valid_index: Optional[torch.Tensor] = None     # set by pack(compact=True)
+        self.Nvalid = 0
         self.ret_cap = self.max_tokens + 2
         self.ret_buf = torch.zeros((self.P, self.ret_cap), dtype=torch.int64, device=dev)
         self.Rtot = 0
@@ -178,9 +193,11 @@ class MultiblockBatch:
                                     _ptr(kv_len), _ptr(self.desc_dev), _stream(self.device)), "jf_mb_begin")
         return self._read_desc()
 
-    def pack(self, d: np.ndarray, t_align: int = 1):
+    def pack(self, d: np.ndarray, t_align: int = 1, compact: bool = False, valid_align: int = 1):
         """Forward inputs of the current iteration (MB:417-436): returns (input_ids [R,Tpad], positions [R,Tpad],
-        row_prompt [R], row_len [R]).  ``t_align`` rounds the padded row length up (keeps GEMM shapes on a small grid)."""
+        row_prompt [R], row_len [R]).  ``t_align`` rounds the padded row length up (keeps GEMM shapes on a small grid).
+        ``compact=True`` also fills ``self.valid_index`` (flat positions that carry a draft token, rounded up to a
+        multiple of ``valid_align`` with -1): lm_head and the argmax then run on those positions only."""
         B = self.desc_field(d, "B")
         T = self.desc_field(d, "T")
         self.Rtot = int(B.sum())
@@ -190,17 +207,35 @@ class MultiblockBatch:
         if self.Rtot == 0:
             return None
         fill = self.params.pad_token_id if self.params.pad_token_id is not None else 0
+        valid_align = max(int(valid_align), 1)
+        self.Nvalid = int((B.astype(np.int64) * T).sum())
+        nvp = (self.Nvalid + valid_align - 1) // valid_align * valid_align
+        if compact and nvp > self.valid_index_buf.numel():
+            raise RuntimeError("valid-position list exceeds its buffer")
         N.check(N.lib().jf_mb_pack(_ptr(self.states), self.state_ints, self.P, self.Tpad, int(fill), _ptr(self.input_ids),
-                                   _ptr(self.positions), _ptr(self.row_prompt), _ptr(self.row_len), _stream(self.device)),
+                                   _ptr(self.positions), _ptr(self.row_prompt), _ptr(self.row_len),
+                                   _ptr(self.valid_index_buf) if compact else None, valid_align, _stream(self.device)),
                 "jf_mb_pack")
+        self.valid_index = self.valid_index_buf[:nvp] if compact else None
         R, Tp = self.Rtot, self.Tpad
         return (self.input_ids[:R * Tp].view(R, Tp), self.positions[:R * Tp].view(R, Tp), self.row_prompt[:R],
                 self.row_len[:R])
 
-    def verify(self, logits: torch.Tensor) -> np.ndarray:
-        """argmax over the vocabulary + the whole loop body (MB:467-721): logits [Rtot, Tpad, V] or [Rtot*Tpad, V]."""
+    def verify(self, logits: torch.Tensor, compacted: Optional[bool] = None) -> np.ndarray:
+        """argmax over the vocabulary + the whole loop body (MB:467-721).  logits: [Rtot, Tpad, V] / [Rtot*Tpad, V], or —
+        after ``pack(compact=True)`` — one row per entry of ``self.valid_index``.  ``compacted=None`` decides by the
+        row count, preferring the compacted reading when ``pack`` was asked for the list (pass it explicitly if the
+        rectangular tensor happens to have as many rows as the rounded-up list)."""
         V = logits.shape[-1]
         flat = logits.reshape(-1, V)
+        if compacted is None:
+            compacted = self.valid_index is not None and flat.shape[0] == self.valid_index.numel()
+        if compacted:
+            if self.valid_index is None or flat.shape[0] != self.valid_index.numel():
+                raise ValueError(f"expected logits for the {0 if self.valid_index is None else self.valid_index.numel()} "
+                                 f"listed positions, got {tuple(logits.shape)}")
+            argmax_scatter(flat, self.valid_index, self.packed)
+            return self.step()
         if flat.shape[0] != self.Rtot * self.Tpad:
             raise ValueError(f"expected logits for {self.Rtot}x{self.Tpad} positions, got {tuple(logits.shape)}")
         argmax_partial(flat, self.packed)

@@ -66,5 +66,10 @@ class ScriptedAcceptance:
         ok = torch.cumprod(match.to(torch.int32), dim=1).bool()          # committed prefix is always on-target
         rob = (_hash(ids, pos, 0x51ED) % 100) < self.robust
         nxt = torch.where(ok | rob, self.target(pos + 1, pr), _hash(ids, pos + pr, 0x7777) % self.vocab_hi)
-        logits.view(R * T, -1)[torch.arange(R * T, device=dev), nxt.reshape(-1)] = self.boost
+        nxt = nxt.reshape(-1)
+        vi = getattr(b, "valid_index", None)
+        if vi is not None and logits.reshape(-1, logits.shape[-1]).shape[0] == vi.numel():
+            nxt = nxt[vi.clamp(min=0).long()]               # logits of the compacted position list
+        flat = logits.view(-1, logits.shape[-1])
+        flat[torch.arange(flat.shape[0], device=dev), nxt] = self.boost
         return logits

@@ -57,7 +57,7 @@ class HostSimLib:
         sig = {
             "hs_mb_state_ints": (i64, [P]), "hs_mb_max_rows": (i32, [P]), "hs_mb_max_tokens": (i32, [P]),
             "hs_mb_begin": (C.c_int, [vp, i64, C.c_int, P, vp, vp, vp]),
-            "hs_mb_pack": (C.c_int, [vp, i64, C.c_int, i32, i64, vp, vp, vp, vp]),
+            "hs_mb_pack": (C.c_int, [vp, i64, C.c_int, i32, i64, vp, vp, vp, vp, vp, i32]),
             "hs_mb_step": (C.c_int, [vp, i64, C.c_int, vp, i64, vp]),
             "hs_mb_read_ret": (C.c_int, [vp, i64, C.c_int, vp, i32]),
             "hs_engine_step": (C.c_int, [vp, C.c_int, C.c_int, vp, i32, vp, vp, vp, vp, i64, vp, vp]),
@@ -111,6 +111,22 @@ class HostSimLib:
         pk = _view(packed, R, np.uint64)
         new = (np.uint64(1) << np.uint64(32)) | ((~am) & np.uint64(0xFFFFFFFF))
         pk[:] = np.maximum(pk, new)
+        return 0
+
+    def jf_argmax_scatter(self, logits, dtype, R, V, stride, out_index, packed, stream):
+        oi = _view(out_index, R, np.int32)
+        keep = np.nonzero(oi >= 0)[0]
+        if dtype == N.JF_F32:
+            x = _view(logits, (R - 1) * stride + V, np.float32)
+            rows = np.stack([x[r * stride:r * stride + V] for r in keep]) if len(keep) else np.zeros((0, V), np.float32)
+        else:
+            b = _view(logits, (R - 1) * stride + V, np.uint16)
+            rows = O.bf16_bits_to_f32(np.stack([b[r * stride:r * stride + V] for r in keep])) if len(keep) else np.zeros((0, V), np.float32)
+        if len(keep):
+            am = O.argmax_rows(rows).astype(np.uint64)
+            pk = _view(packed, int(oi.max()) + 1, np.uint64)
+            new = (np.uint64(1) << np.uint64(32)) | ((~am) & np.uint64(0xFFFFFFFF))
+            pk[oi[keep]] = np.maximum(pk[oi[keep]], new)
         return 0
 
     def jf_argmax_decode(self, packed, R, greedy, stream):

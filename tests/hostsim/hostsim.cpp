@@ -33,9 +33,10 @@ int hs_mb_begin(int32_t *states, int64_t state_ints, int P, const jf_mb_params *
     return 0;
 }
 int hs_mb_pack(int32_t *states, int64_t state_ints, int P, int32_t Tpad, int64_t pad_fill, int64_t *input_ids,
-               int32_t *positions, int32_t *row_prompt, int32_t *row_len) {
+               int32_t *positions, int32_t *row_prompt, int32_t *row_len, int32_t *valid_index, int32_t valid_align) {
     for (int p = 0; p < P; ++p)
-        jfmb::mb_pack_body(HostLanes{}, p, states, state_ints, Tpad, pad_fill, input_ids, positions, row_prompt, row_len);
+        jfmb::mb_pack_body(HostLanes{}, p, P, states, state_ints, Tpad, pad_fill, input_ids, positions, row_prompt, row_len,
+                           valid_index, valid_align < 1 ? 1 : valid_align);
     return 0;
 }
 int hs_mb_step(int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len, jf_mb_desc *desc) {

@@ -151,6 +151,31 @@ def test_decoder_matches_oracle(cfg, backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+def test_compacted_logits_equal_rectangular(backend):
+    """lm_head + argmax on the draft-carrying positions only (jf_mb_pack's valid_index -> jf_argmax_scatter) gives the
+    same tokens, calls and iteration counts as the padded [R, Tpad] rectangle, with fewer logits rows."""
+    with use_backend(backend):
+        dev = device_for(backend)
+        model = tiny_model(dev, seed=21)
+        V = model.cfg.vocab_size
+        prm = ops.MultiblockParams(n=16, K=2, r=0.5, n_gram_pool_size=4, eos_token_id=V - 1, pad_token_id=V - 2)
+        rng = np.random.default_rng(11)
+        prompts = [[int(t) for t in rng.integers(0, V - 2, size=int(L))] for L in (6, 23, 11, 40, 3)]
+        out = {}
+        for compact in (False, True):
+            dec = MultiblockJacobiDecoder(model, len(prompts), prm, max_seq_len=256, t_align=8, compact_logits=compact)
+            rows = []
+            stats, _, iters = dec.generate(prompts, max_new_tokens=40, max_calls=5, seed=5,
+                                           on_iteration=lambda i, d: rows.append((dec.last_logits_rows, dec.last_valid_rows)))
+            out[compact] = ([(s.token_ids, s.calls, s.total_iterations, s.stop_reason) for s in stats], iters, rows)
+        assert out[True][0] == out[False][0] and out[True][1] == out[False][1]
+        for (lr_c, valid_c), (lr_r, valid_r) in zip(out[True][2], out[False][2]):
+            assert valid_c == valid_r
+            assert lr_c == (valid_c + 7) // 8 * 8 and lr_c <= lr_r
+        assert sum(r[0] for r in out[True][2]) < sum(r[0] for r in out[False][2])
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_decoder_equals_autoregressive(backend):
     """The reference's greedy criterion (inference_engine/tests/test_jacobi_decoding_greedy.py:180-206): the Jacobi
     output equals plain greedy AR decoding of the same model."""

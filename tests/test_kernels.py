@@ -117,6 +117,34 @@ def test_argmax_full_size_property():
     assert (got == torch.argmax(x.float(), dim=-1)).all()
 
 
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("R,V,slots", [(37, 4096, 64), (9, 1001, 9), (200, 32000, 512), (168, 152064, 192)])
+def test_argmax_scatter_matches_torch(R, V, slots, dtype, backend):
+    """jf_argmax_scatter: row i of the compacted logits lands in packed[out_index[i]]; rows with a negative index
+    (list padding) are skipped, untouched slots stay zero."""
+    if backend == "hostsim" and R * V > 4_000_000:
+        pytest.skip("GPU-size case")
+    with use_backend(backend):
+        dev = device_for(backend)
+        g = torch.Generator().manual_seed(R + V)
+        x = torch.randn(R, V, generator=g).to(dtype)
+        x[1, 5] = x[1, 900] = 9.0                              # tie: first index wins
+        perm = torch.randperm(slots, generator=g)[:R].to(torch.int32)
+        perm[R // 2] = -1
+        perm[R - 1] = -1
+        packed = ops.new_packed(slots, dev)
+        ops.argmax_scatter(x.to(dev), perm.to(dev), packed)
+        got = packed.cpu().numpy().astype(np.uint64)
+        ref = torch.argmax(x.float(), dim=-1).numpy()
+        used = np.zeros(slots, dtype=bool)
+        for i in range(R):
+            if perm[i] >= 0:
+                assert int((~got[perm[i]]) & np.uint64(0xFFFFFFFF)) == ref[i], i
+                used[int(perm[i])] = True
+        assert (got[~used] == 0).all()
+
+
 def test_argmax_rejects_bad_input():
     with use_backend("hostsim"):
         with pytest.raises(ValueError):

@@ -179,3 +179,66 @@ def test_bad_shapes(backend):
         batch = ops.MultiblockBatch(2, ops.MultiblockParams(n=8, pad_token_id=0), dev)
         with pytest.raises(ValueError):
             batch.begin(torch.zeros((2, 7), dtype=torch.int64), torch.zeros((2,), dtype=torch.int32))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_pack_valid_index(backend):
+    """jf_mb_pack's compacted position list: flat index row*Tpad + t of every draft-carrying position, prompt by prompt
+    and row by row, rounded up to the requested multiple with -1."""
+    with use_backend(backend):
+        dev = device_for(backend)
+        P, n = 3, 8
+        prm = ops.MultiblockParams(n=n, K=2, r=0.5, n_gram_pool_size=4, eos_token_id=None, pad_token_id=0)
+        batch = ops.MultiblockBatch(P, prm, dev)
+        models = [ScriptedModel(64, 40 + p, 60, 5 + p, reserved=(0,), period=3) for p in range(P)]
+        kvs = [m.prompt() for m in models]
+        rng = np.random.default_rng(0)
+        inputs = [[int(x) for x in rng.choice(kvs[p], size=n)] for p in range(P)]
+        d = batch.begin(torch.tensor(inputs, dtype=torch.int64), torch.tensor([len(k) for k in kvs], dtype=torch.int32))
+        seen_ragged = False
+        for _ in range(12):
+            packed_in = batch.pack(d, t_align=4, compact=True, valid_align=8)
+            if packed_in is None:
+                break
+            ids = packed_in[0].cpu().numpy()
+            B, T = batch.desc_field(d, "B").copy(), batch.desc_field(d, "T").copy()
+            Tpad = ids.shape[1]
+            exp, r0 = [], 0
+            for p in range(P):
+                for b in range(B[p]):
+                    exp += [(r0 + b) * Tpad + t for t in range(T[p])]
+                r0 += B[p]
+            nv = len(exp)
+            exp += [-1] * ((nv + 7) // 8 * 8 - nv)
+            assert batch.Nvalid == nv
+            assert batch.valid_index.cpu().tolist() == exp
+            seen_ragged |= nv < ids.size
+            V = models[0].vocab
+            logits = np.zeros((ids.shape[0], Tpad, V), dtype=np.float32)
+            r0 = 0
+            for p in range(P):
+                rows = [ids[r0 + b, :T[p]].tolist() for b in range(B[p])]
+                if B[p]:
+                    logits[r0:r0 + B[p], :T[p]] = models[p].logits_rows(kvs[p], rows)
+                r0 += B[p]
+            flat = torch.from_numpy(logits).reshape(-1, V)
+            vi = batch.valid_index.cpu().long().clamp(min=0)
+            before = [list(k) for k in kvs]
+            d = batch.verify(flat[vi].contiguous().to(dev))          # compacted logits -> jf_argmax_scatter
+            r0 = 0
+            for p in range(P):
+                if B[p]:
+                    keep = int(batch.desc_field(d, "kv_len")[p]) - len(before[p])
+                    src = int(batch.desc_field(d, "kv_src_row")[p]) if batch.desc_field(d, "kv_copy_len")[p] > 0 else 0
+                    kvs[p] = before[p] + ids[r0 + src, :keep].tolist()
+                r0 += B[p]
+            if batch.desc_field(d, "done").all():
+                break
+        assert seen_ragged
+        res = batch.results(d)
+        for p in range(P):
+            st = O.mb_generation_call((lambda m: (lambda kv_rows, rows: [m.greedy_rows(kv_rows[b], [rows[b]])[0]
+                                                                        for b in range(len(rows))]))(models[p]),
+                                      inputs[p], models[p].prompt(), n=n, K=2, r=0.5, n_gram_pool_size=4, eos_token_id=None,
+                                      pad_token_id=0)
+            assert res[p]["ret"] == st.ret and res[p]["iters"] == st.iters
