@@ -222,6 +222,21 @@ int jf_engine_step(const int64_t *draft, int B, int L, uint64_t *packed, int32_t
                    const int64_t *pad_stream, int64_t pad_stream_len, int64_t *pad_cursor,
                    jf_engine_row *rows, void *stream);
 
+/* Caller side of the batched forward when the KV cache is PAGED as in the reference
+ * (MR:1204-1265 "jacobi.buffer_fill" + _get_slot_mapping_pattern MR:965-986): for B sequences of
+ * committed length S_i (seq_len, >= 1) and a draft [B, L] (column 0 = the cached seed), fill
+ *   input_ids [B*L] int64, positions [B*L] int64 (S_i - 1 + j),
+ *   slot_mapping [B*L] int32 = block_tables[i, (S_i-1+j) / block_size] * block_size + (S_i-1+j) % block_size,
+ *   cu_seqlens_q [B+1] (i*L), cu_seqlens_k [B+1] (prefix sums of S_i - 1 + L), cache_seqlens [B] (S_i - 1)
+ * in one launch (the reference: a Python loop over the batch with ~8 launches per sequence).
+ * block_tables [B, max_cols] int32, -1 = no block.  err (nullable, zero it first): first row + 1
+ * with S < 1 or a position without a block (the reference raises ValueError / RuntimeError there).
+ */
+int jf_engine_fill(const int64_t *draft, int B, int L, const int32_t *seq_len,
+                   const int32_t *block_tables, int max_cols, int block_size, int64_t *input_ids,
+                   int64_t *positions, int32_t *slot_mapping, int32_t *cu_seqlens_q,
+                   int32_t *cu_seqlens_k, int32_t *cache_seqlens, int32_t *err, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Non-greedy verify (a19), JDN = inference_engine/engine/jacobi_decoding_nongreedy.py.
  *

@@ -383,6 +383,61 @@ class EngineStepper:
 
 
 # --------------------------------------------------------------------------------------------
+# paged-KV index buffers of one batched Jacobi forward (MR:1204-1265, 965-986)
+# --------------------------------------------------------------------------------------------
+class PagedFill:
+    """The reference's ``jacobi_buffers`` (MR:650-686) and their per-forward fill, as one launch.  For callers that keep
+    the reference's paged KV cache + varlen attention; this package's own forward uses a static cache row per request."""
+
+    def __init__(self, max_batch: int, max_block_len: int, max_blocks_per_seq: int, block_size: int, device):
+        dev = torch.device(device)
+        self.device, self.block_size = dev, int(block_size)
+        self.max_batch, self.max_L, self.max_cols = int(max_batch), int(max_block_len), int(max_blocks_per_seq)
+        n = self.max_batch * self.max_L
+        self.input_ids = torch.zeros((n,), dtype=torch.int64, device=dev)
+        self.positions = torch.zeros((n,), dtype=torch.int64, device=dev)
+        self.slot_mapping = torch.zeros((n,), dtype=torch.int32, device=dev)
+        self.cu_seqlens_q = torch.zeros((self.max_batch + 1,), dtype=torch.int32, device=dev)
+        self.cu_seqlens_k = torch.zeros((self.max_batch + 1,), dtype=torch.int32, device=dev)
+        self.cache_seqlens = torch.zeros((self.max_batch,), dtype=torch.int32, device=dev)
+        self.block_tables = torch.full((self.max_batch, self.max_cols), -1, dtype=torch.int32, device=dev)
+        self.seq_len = torch.zeros((self.max_batch,), dtype=torch.int32, device=dev)
+        self.err = torch.zeros((1,), dtype=torch.int32, device=dev)
+
+    def fill(self, draft: torch.Tensor, seq_lens: Sequence[int], block_tables: Sequence[Sequence[int]], check: bool = True):
+        """draft [B, L] int64; seq_lens = len(seq) per row; block_tables = seq.block_table per row.  Returns the views
+        (input_ids, positions, slot_mapping, cu_seqlens_q, cu_seqlens_k, cache_seqlens, block_tables, max_seqlen_k)."""
+        B, L = draft.shape
+        if L < 2:
+            raise ValueError("Draft must have at least 2 tokens (seed + 1 speculative)")              # MR:1144-1145
+        if B > self.max_batch or L > self.max_L:
+            raise RuntimeError("PagedFill capacity exceeded")
+        for i, S in enumerate(seq_lens):
+            if S < 1:
+                raise ValueError(f"Sequence {i} has invalid length S={S}. Must be >= 1.")               # MR:1222-1223
+            if len(block_tables[i]) > self.max_cols:                                                     # MR:1240-1247
+                raise RuntimeError(f"Sequence {i} needs {len(block_tables[i])} blocks but buffer only has {self.max_cols}.")
+        bt = np.full((B, self.max_cols), -1, dtype=np.int32)
+        for i, t in enumerate(block_tables):
+            bt[i, :len(t)] = t
+        self.block_tables[:B].copy_(torch.from_numpy(bt), non_blocking=True)
+        self.seq_len[:B].copy_(torch.tensor(list(seq_lens), dtype=torch.int32), non_blocking=True)
+        draft = draft.to(device=self.device, dtype=torch.int64).contiguous()
+        self.err.zero_()
+        N.check(N.lib().jf_engine_fill(_ptr(draft), B, L, _ptr(self.seq_len), _ptr(self.block_tables), self.max_cols,
+                                       self.block_size, _ptr(self.input_ids), _ptr(self.positions), _ptr(self.slot_mapping),
+                                       _ptr(self.cu_seqlens_q), _ptr(self.cu_seqlens_k), _ptr(self.cache_seqlens),
+                                       _ptr(self.err), _stream(self.device)), "jf_engine_fill")
+        if check and int(self.err.item()):
+            raise RuntimeError(f"Sequence {int(self.err.item()) - 1}: a draft position has no KV block "
+                               "(Cannot allocate blocks for draft tokens)")                            # MR:1190-1191
+        n = B * L
+        return (self.input_ids[:n], self.positions[:n], self.slot_mapping[:n], self.cu_seqlens_q[:B + 1],
+                self.cu_seqlens_k[:B + 1], self.cache_seqlens[:B], self.block_tables[:B],
+                max(int(S) - 1 + L for S in seq_lens))
+
+
+# --------------------------------------------------------------------------------------------
 # non-greedy verify (JDN:299-354, 581-639)
 # --------------------------------------------------------------------------------------------
 class RsStepper:

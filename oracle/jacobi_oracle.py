@@ -925,3 +925,218 @@ class CounterStream:
 
     def uniform(self) -> float:
         return (self.next_u32() >> 8) / float(1 << 24)
+
+
+# ------------------------------------------------------------------------------------------------
+# On-policy rollout records — restates inference_engine/engine/jacobi_decoding_nongreedy_on_policy.py
+# ("JDO").  Randomness is injected in the reference's call order: ``rnd`` (random.choice / randrange,
+# JDO:254-266, 474), ``next_uniform`` (torch.rand, JDO:306), ``next_multinomial_uniform`` (every
+# torch.multinomial: bonus draws JDO:157-163 and the re-draft samples JDO:476).
+# ------------------------------------------------------------------------------------------------
+def trim_left_padding(ids: List[int], pad: Optional[int]) -> List[int]:          # JDO:77-87
+    if not ids:
+        return []
+    if pad is None:
+        return list(ids)
+    for i, t in enumerate(ids):
+        if int(t) != int(pad):
+            return list(ids[i:])
+    return []
+
+
+def truncate_after_stop(ids: List[int], start_idx: int, stop_ids) -> List[int]:  # JDO:170-182
+    stop = set(int(x) for x in stop_ids)
+    for i in range(max(0, int(start_idx)), len(ids)):
+        if int(ids[i]) in stop:
+            return list(ids[:i + 1])
+    return list(ids)
+
+
+def onpolicy_verify(proposed: List[int], probs: np.ndarray, stop_ids, next_uniform, next_multinomial_uniform):
+    """JDO:270-327.  Returns (committed, stop_hit)."""
+    committed: List[int] = []
+    stop = set(int(x) for x in stop_ids)
+    stop_hit = False
+    for t, x in enumerate(proposed):
+        x = int(x)
+        if x < 0 or x >= probs.shape[-1]:
+            raise ValueError(f"Token index {x} out of bounds for vocab size {probs.shape[-1]}.")
+        p_x = float(probs[t, x])
+        u = float(next_uniform())
+        if u < p_x:
+            committed.append(x)
+        else:
+            bonus = None
+            for _ in range(16):                                                  # JDO:157-163
+                y = inverse_cdf_sample(probs[t], next_multinomial_uniform())
+                if y != x:
+                    bonus = y
+                    break
+            if bonus is None:                                                    # JDO:164-168
+                p2 = probs[t].copy()
+                p2[x] = 0.0
+                bonus = x if float(p2.sum()) <= 0.0 else int(argmax_rows(p2[None, :])[0])
+            committed.append(int(bonus))
+            break
+        if committed[-1] in stop:
+            stop_hit = True
+            break
+    if committed and committed[-1] in stop:
+        stop_hit = True
+    return committed, stop_hit
+
+
+def onpolicy_run_one_block(forward: NonGreedyForward, seq: OracleSeq, block_len: int, budget: int, completion_start: int,
+                           temperature: float, stop_ids, pad_id: int, vocab: int, rnd, next_uniform,
+                           next_multinomial_uniform):
+    """JDO:331-488.  Returns (trajectory, appended_total, forwards_used, stopped)."""
+    full_len = int(block_len)
+    if full_len <= 0 or budget <= 0:
+        return [], 0, 0, True
+    gen_len = min(full_len, int(budget))
+    choices = [int(t) for t in seq.token_ids if int(t) != int(pad_id)]           # JDO:254-266
+    init = [rnd.choice(choices) if choices else rnd.randrange(vocab) for _ in range(gen_len)]
+    block = list(init) + [pad_id] * (full_len - gen_len)
+    accepted, stopped, fwd_used, appended = 0, False, 0, 0
+    traj = [list(block)]
+    stop = set(int(x) for x in stop_ids)
+    while accepted < gen_len and not stopped:
+        remaining = gen_len - accepted
+        if not seq.token_ids:
+            seq.token_ids = [pad_id]
+        proposed = [int(t) for t in block[accepted:gen_len]]
+        draft = [int(seq.token_ids[-1])] + proposed
+        seq.grow_for_draft(remaining + 1)
+        logits = forward([seq], [draft])[0]                                      # [remaining, V]
+        seq.num_cached_tokens = len(seq) - 1 + (remaining + 1)
+        fwd_used += 1
+        probs = softmax_rows_f32(logits, temperature)
+        committed, stop_hit = onpolicy_verify(proposed, probs, stop_ids, next_uniform, next_multinomial_uniform)
+        if not committed:
+            committed = [proposed[0]]
+            stop_hit = committed[0] in stop
+        seq.token_ids += committed                                               # JDO:412-416
+        appended += len(committed)
+        seq.trim_kv_only_fast(remaining - len(committed))                        # JDO:420-426
+        if len(seq) != seq.num_cached_tokens:
+            raise RuntimeError(f"Invariant violated: len(token_ids)={len(seq)} != num_cached_tokens={seq.num_cached_tokens}")
+        prev = accepted
+        accepted = min(gen_len, accepted + len(committed))
+        block[prev:accepted] = committed[:accepted - prev]
+        if stop_hit:                                                             # JDO:439-463
+            full = list(seq.token_ids)
+            trunc = truncate_after_stop(full, completion_start, stop_ids)
+            if len(trunc) != len(full):
+                seq.token_ids = trunc
+                seq.trim_kv_only_fast(len(full) - len(trunc))
+            stopped = True
+            pos = next((j for j in range(prev, accepted) if int(block[j]) in stop), None)
+            if pos is not None:
+                for k in range(pos + 1, full_len):
+                    block[k] = pad_id
+                accepted = min(accepted, pos + 1)
+        if not stopped and accepted < gen_len:                                   # JDO:465-477
+            local_start = len(committed)
+            new = []
+            for jj in range(gen_len - accepted):
+                li = local_start + jj
+                new.append(rnd.randrange(vocab) if li >= probs.shape[0]
+                           else inverse_cdf_sample(probs[li], next_multinomial_uniform()))
+            block[accepted:gen_len] = new
+        for k in range(gen_len, full_len):
+            block[k] = pad_id
+        traj.append(list(block))
+    return traj, appended, fwd_used, stopped
+
+
+def onpolicy_rollout_records_batch(forward: NonGreedyForward, seqs: List[OracleSeq], temperature: float, stop_ids,
+                                   pad_id: int, vocab: int, rnd, next_uniform, next_multinomial_uniform,
+                                   n_token_seq_len: Optional[int] = None, data_ids: Optional[List[str]] = None):
+    """JDO:494-614: (records per sequence {block index -> record}, metrics per sequence).
+    ``seq.max_iters`` is the maximum number of BLOCKS (JDO:232-233)."""
+    B = len(seqs)
+    if B == 0:
+        return [], []
+    starts = [len(s.token_ids) for s in seqs]
+    block_lens = [int(n_token_seq_len) if n_token_seq_len is not None else int(s.block_len) for s in seqs]
+    budgets = [max(0, s.max_tokens - s.num_completion_tokens) for s in seqs]
+    stopped = [False] * B
+    done_blocks, forwards, generated = [0] * B, [0] * B, [0] * B
+    ids = data_ids if data_ids is not None else [f"data_{i}" for i in range(B)]
+    out: List[Dict[int, dict]] = [dict() for _ in range(B)]
+    while True:
+        active = [i for i in range(B) if not stopped[i] and done_blocks[i] < seqs[i].max_iters and budgets[i] > 0]
+        if not active:
+            break
+        for i in active:
+            seq, k = seqs[i], done_blocks[i]
+            if block_lens[i] <= 0:
+                stopped[i] = True
+                continue
+            prompt_trim = trim_left_padding(list(seq.token_ids), pad_id)
+            traj, app, fw, hit = onpolicy_run_one_block(forward, seq, block_lens[i], budgets[i], starts[i], temperature,
+                                                        stop_ids, pad_id, vocab, rnd, next_uniform, next_multinomial_uniform)
+            done_blocks[i] += 1
+            forwards[i] += fw
+            generated[i] += app
+            budgets[i] = max(0, budgets[i] - app)
+            stopped[i] = bool(hit)
+            teacher = trim_left_padding(truncate_after_stop(list(seq.token_ids), starts[i], stop_ids), pad_id)
+            out[i][k] = dict(diffusion_itr_id=f"itr_{k}", data_id=str(ids[i]), prompt_ids=prompt_trim,
+                             answer_trajectory_ids=traj, teacher_output_ids=teacher,
+                             tokens_per_iter=float(generated[i]) / float(max(1, done_blocks[i])),
+                             tokens_per_forward=float(generated[i]) / float(max(1, forwards[i])),
+                             num_iters=done_blocks[i], num_forwards=forwards[i])
+    final = {}
+    for i in range(B):
+        final[str(ids[i])] = trim_left_padding(truncate_after_stop(list(seqs[i].token_ids), starts[i], stop_ids), pad_id)
+    for i in range(B):
+        for k in out[i]:
+            out[i][k]["teacher_output_ids"] = final.get(str(ids[i]), [])
+    metrics = [dict(total_tokens=float(generated[i]), num_iters=float(done_blocks[i]), num_forwards=float(forwards[i]),
+                    tokens_per_iter=float(generated[i]) / float(max(1, done_blocks[i])),
+                    tokens_per_forward=float(generated[i]) / float(max(1, forwards[i]))) for i in range(B)]
+    return out, metrics
+
+
+class ScriptedRandom:
+    """``random.choice`` / ``random.randrange`` over a CounterStream (the golden generator patches the same in)."""
+
+    def __init__(self, stream: "CounterStream"):
+        self.stream = stream
+
+    def choice(self, seq):
+        return seq[self.stream.next_u32() % len(seq)]
+
+    def randrange(self, n):
+        return self.stream.next_u32() % n
+
+
+# ------------------------------------------------------------------------------------------------
+# paged-KV index buffers of one batched Jacobi forward — restates MR:1204-1265 ("jacobi.buffer_fill")
+# and MR:965-986 (_get_slot_mapping_pattern).  Test infrastructure only.
+# ------------------------------------------------------------------------------------------------
+def engine_fill_ref(draft, seq_lens, block_tables, block_size, max_cols):
+    """draft [B][L]; seq_lens[i] = len(seq_i) (>= 1); block_tables[i] = list of block ids.
+    Returns dict(input_ids, positions, slot_mapping, cu_seqlens_q, cu_seqlens_k, cache_seqlens, block_tables, max_seqlen_k)."""
+    B, L = len(draft), len(draft[0])
+    input_ids, positions, slots = [], [], []
+    cu_q, cu_k, cache = [0], [0], []
+    bt = np.full((B, max_cols), -1, dtype=np.int32)                                  # MR:678, 1248-1249
+    for i in range(B):
+        S = seq_lens[i]
+        if S < 1:
+            raise ValueError(f"Sequence {i} has invalid length S={S}. Must be >= 1.")    # MR:1222-1223
+        if len(block_tables[i]) > max_cols:
+            raise RuntimeError(f"Sequence {i} needs {len(block_tables[i])} blocks but buffer only has {max_cols}.")  # MR:1240-1247
+        bt[i, :len(block_tables[i])] = block_tables[i]
+        input_ids += [int(t) for t in draft[i]]                                      # MR:1227
+        for j in range(L):
+            pos = S - 1 + j                                                          # MR:1229, 979
+            positions.append(pos)
+            slots.append(int(bt[i, pos // block_size]) * block_size + pos % block_size)   # MR:981-982, 1252-1254
+        cu_q.append(cu_q[-1] + L)                                                    # MR:1256
+        cu_k.append(cu_k[-1] + (S - 1) + L)                                          # MR:1257
+        cache.append(S - 1)                                                          # MR:1260-1263
+    return dict(input_ids=input_ids, positions=positions, slot_mapping=slots, cu_seqlens_q=cu_q, cu_seqlens_k=cu_k,
+                cache_seqlens=cache, block_tables=bt, max_seqlen_k=max(S - 1 + L for S in seq_lens))   # MR:1273

@@ -99,6 +99,28 @@ class HostSimLib:
     def jf_engine_step(self, *a):
         return self.hs.hs_engine_step(*a[:-1])
 
+    def jf_engine_fill(self, draft, B, L, seq_len, block_tables, max_cols, block_size, input_ids, positions, slot_mapping,
+                       cu_q, cu_k, cache_seqlens, err, stream):
+        d = _view(draft, B * L, np.int64).reshape(B, L)
+        S = _view(seq_len, B, np.int32)
+        bt = _view(block_tables, B * max_cols, np.int32).reshape(B, max_cols)
+        ii, pp, sm = _view(input_ids, B * L, np.int64), _view(positions, B * L, np.int64), _view(slot_mapping, B * L, np.int32)
+        q, k, cs = _view(cu_q, B + 1, np.int32), _view(cu_k, B + 1, np.int32), _view(cache_seqlens, B, np.int32)
+        q[0] = k[0] = 0
+        for i in range(B):
+            for j in range(L):
+                pos = int(S[i]) - 1 + j
+                ii[i * L + j], pp[i * L + j] = d[i, j], pos
+                blk = pos // block_size
+                ok = pos >= 0 and blk < max_cols and bt[i, blk] >= 0
+                sm[i * L + j] = bt[i, blk] * block_size + pos % block_size if ok else -1
+                if not ok and err:
+                    e = _view(err, 1, np.int32)
+                    if e[0] == 0:
+                        e[0] = i + 1
+            q[i + 1], k[i + 1], cs[i] = q[i] + L, k[i] + int(S[i]) - 1 + L, int(S[i]) - 1
+        return 0
+
     # -- numpy stand-ins for the streaming kernels (oracle arithmetic)
     def jf_argmax_partial(self, logits, dtype, R, V, stride, packed, stream):
         if dtype == N.JF_F32:

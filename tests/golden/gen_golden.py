@@ -87,6 +87,7 @@ sys.modules["flash_attn"] = _fa
 from inference_engine.engine.jacobi_decoding import JacobiDecoder  # noqa: E402
 from inference_engine.engine.jacobi_decoding_nongreedy import JacobiDecoderNonGreedy  # noqa: E402
 import inference_engine.engine.jacobi_decoding_nongreedy as jdn_mod  # noqa: E402
+import inference_engine.engine.jacobi_decoding_nongreedy_on_policy as jdo_mod  # noqa: E402
 from inference_engine.engine.block_manager import BlockManager  # noqa: E402
 from inference_engine.engine.sequence import Sequence  # noqa: E402
 from inference_engine.sampling_params import SamplingParams  # noqa: E402
@@ -503,6 +504,56 @@ def run_jdn_case(name, *, vocab, seeds, robust, prompt_lens, block_len, max_toke
                 draws=dict(pads=pads.k, uniforms=unis.k, bonus=bonus.k), forwards=H.trace)
 
 
+class ScriptedRandom:
+    """Stand-in for the ``random`` module inside the on-policy decoder (draft initialisation, JDO:254-266, 474)."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def choice(self, seq):
+        return seq[self.stream.next_u32() % len(seq)]
+
+    def randrange(self, n):
+        return self.stream.next_u32() % n
+
+
+def run_jdo_case(name, *, vocab, seeds, robust, prompt_lens, block_len, max_tokens, temperature, max_blocks=128,
+                 eos_pos=None, extra_stop=None, rng_seed=9, left_pad=0):
+    """JacobiDecoderNonGreedyOnPolicy.generate_rollout_records_batch (JDO:494-614) with every random draw injected."""
+    eos_id, pad_id = vocab - 1, vocab - 2
+    stop_ids = [eos_id] + ([extra_stop] if extra_stop is not None else [])
+    H = EngineHarness(vocab)
+    dec = jdo_mod.JacobiDecoderNonGreedyOnPolicy(H.bm, forward_step=H.forward_step, forward_step_batch=H.forward_step_batch,
+                                                 eos_token_id=stop_ids if len(stop_ids) > 1 else eos_id,
+                                                 pad_token_id=pad_id, vocab_size=vocab, device=torch.device("cpu"))
+    seqs, descr = [], []
+    for i, (sd, pl) in enumerate(zip(seeds, prompt_lens)):
+        ep = None if eos_pos is None else eos_pos[i]
+        reserved = (pad_id,) + ((extra_stop,) if extra_stop is not None else ())
+        m = ScriptedModel(vocab, sd, robust, pl, eos_id=eos_id, eos_pos=ep, reserved=reserved)
+        sp = SamplingParams(temperature=temperature, max_tokens=max_tokens, decode_strategy="jacobi",
+                            jacobi_block_len=block_len, jacobi_max_iterations=max_blocks, jacobi_on_policy=True)
+        seq = H.add_seq(m, sp, None)
+        seqs.append(seq)
+        descr.append(dict(model=m.describe(), prompt=m.prompt()))
+    inits = CounterStream(rng_seed * 5 + 1)
+    unis = CounterStream(rng_seed * 5 + 2)
+    multi = CounterStream(rng_seed * 5 + 3)
+
+    def _rand(size=(), **kw):
+        return torch.tensor(unis.uniform(), dtype=torch.float32)
+
+    with patched(jdo_mod, "random", ScriptedRandom(inits)), patched(torch, "rand", _rand), \
+            patched(torch, "multinomial", scripted_multinomial(multi)):
+        records, metrics = dec.generate_rollout_records_batch(seqs, n_token_seq_len=None, return_metrics=True)
+    return dict(name=name, kind="jdo",
+                params=dict(vocab=vocab, eos_id=eos_id, pad_id=pad_id, stop_ids=stop_ids, rng_seed=rng_seed,
+                            block_len=block_len, max_tokens=max_tokens, temperature=temperature, max_blocks=max_blocks),
+                seqs=descr, records=[{str(k): v for k, v in r.items()} for r in records], metrics=metrics,
+                final=[dict(token_ids=s.token_ids, num_cached_tokens=s.num_cached_tokens) for s in seqs],
+                draws=dict(inits=inits.k, uniforms=unis.k, multinomial=multi.k), forwards=H.trace)
+
+
 # --------------------------------------------------------------------------------------
 # kernel-level vectors: torch.argmax / accept-length semantics (ties, NaN, -inf, bf16)
 # --------------------------------------------------------------------------------------
@@ -615,6 +666,20 @@ def main():
         run_jdn_case("jdn_batch2_eos", vocab=64, seeds=[84, 85], robust=90, prompt_lens=[8, 5], block_len=16,
                      max_tokens=48, temperature=0.5, eos_pos=[8 + 6, 5 + 20]),
     ]
+    jdos = [
+        run_jdo_case("jdo_single_T1", vocab=64, seeds=[90], robust=70, prompt_lens=[8], block_len=8, max_tokens=24,
+                     temperature=1.0),
+        run_jdo_case("jdo_batch2_stop_T07", vocab=64, seeds=[91, 92], robust=90, prompt_lens=[8, 5], block_len=8,
+                     max_tokens=40, temperature=0.7, eos_pos=[8 + 11, 5 + 3]),
+        run_jdo_case("jdo_budget_padfill", vocab=64, seeds=[93, 94], robust=80, prompt_lens=[6, 9], block_len=16,
+                     max_tokens=21, temperature=0.5),
+        run_jdo_case("jdo_maxblocks2", vocab=64, seeds=[95], robust=60, prompt_lens=[7], block_len=8, max_tokens=64,
+                     temperature=1.0, max_blocks=2),
+        run_jdo_case("jdo_two_stop_ids", vocab=100, seeds=[96, 97, 98], robust=85, prompt_lens=[5, 12, 7], block_len=8,
+                     max_tokens=48, temperature=0.8, eos_pos=[None, 12 + 9, 7 + 30], extra_stop=41),
+        run_jdo_case("jdo_hot_T2", vocab=48, seeds=[99], robust=100, prompt_lens=[6], block_len=8, max_tokens=16,
+                     temperature=2.0),
+    ]
     kv = run_argmax_vectors()
 
     def dump(fname, obj):
@@ -627,6 +692,7 @@ def main():
     dump("sb_cases.json", sbs)
     dump("jd_cases.json", jds)
     dump("jdn_cases.json", jdns)
+    dump("jdo_cases.json", jdos)
     dump("kernel_vectors.json", kv)
     # quick human summary
     for c in mbs:

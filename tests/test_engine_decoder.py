@@ -4,10 +4,12 @@ import numpy as np
 import pytest
 import torch
 
+from jacobiforcing_amd import ops
 from jacobiforcing_amd.engine.block_manager import BlockManager
 from jacobiforcing_amd.engine.jacobi_decoding import JacobiDecoder
 from jacobiforcing_amd.engine.sequence import Sequence
 from jacobiforcing_amd.sampling_params import SamplingParams
+from oracle import jacobi_oracle as O
 from oracle.jacobi_oracle import CounterStream
 from oracle.scripted_model import ScriptedModel
 
@@ -142,3 +144,40 @@ def test_engine_nongreedy_golden(case, backend):
         assert dict(pads=dec._cur[2], uniforms=dec._cur[0], bonus=dec._cur[1]) == case["draws"]
         for s, f in zip(seqs, case["final"]):
             assert s.token_ids == f["token_ids"] and s.num_cached_tokens == f["num_cached_tokens"]
+
+
+# ------------------------------------------------------------------------------------- paged-KV index buffers (a16)
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_paged_fill_matches_reference_arithmetic(backend):
+    """jf_engine_fill vs the restatement of MR:1204-1265 / 965-986: positions, slot mapping through the block tables,
+    cu_seqlens, cache_seqlens — including sequences that start a new block inside the draft and S = 1."""
+    with use_backend(backend):
+        dev = device_for(backend)
+        bs, max_cols = 256, 12
+        rng = np.random.default_rng(3)
+        fill = ops.PagedFill(max_batch=16, max_block_len=64, max_blocks_per_seq=max_cols, block_size=bs, device=dev)
+        for B, L in [(1, 2), (3, 16), (7, 33), (16, 64)]:
+            seq_lens = [int(x) for x in rng.integers(1, 2000, size=B)]
+            seq_lens[0] = 1
+            if B > 2:
+                seq_lens[1] = 256                               # seed is the last slot of block 0, draft starts block 1
+                seq_lens[2] = 255 + 256
+            tables = []
+            for S in seq_lens:
+                need = (S + L - 1 + bs - 1) // bs
+                tables.append([int(x) for x in rng.choice(4096, size=need, replace=False)])
+            draft = torch.from_numpy(rng.integers(0, 1000, size=(B, L))).to(torch.int64)
+            out = fill.fill(draft.to(dev), seq_lens, tables)
+            ref = O.engine_fill_ref(draft.tolist(), seq_lens, tables, bs, max_cols)
+            names = ["input_ids", "positions", "slot_mapping", "cu_seqlens_q", "cu_seqlens_k", "cache_seqlens"]
+            for name, got in zip(names, out[:6]):
+                assert got.cpu().tolist() == list(ref[name]), (B, L, name)
+            assert (out[6].cpu().numpy() == ref["block_tables"]).all()
+            assert out[7] == ref["max_seqlen_k"]
+        # a draft position without a block is an error, as in the reference (MR:1190-1191)
+        with pytest.raises(RuntimeError):
+            fill.fill(torch.zeros((1, 8), dtype=torch.int64, device=dev), [250], [[5]])
+        with pytest.raises(ValueError):
+            fill.fill(torch.zeros((1, 8), dtype=torch.int64, device=dev), [0], [[5]])
+        with pytest.raises(ValueError):
+            fill.fill(torch.zeros((1, 1), dtype=torch.int64, device=dev), [4], [[5]])

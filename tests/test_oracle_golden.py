@@ -12,6 +12,7 @@ MB = load_golden("mb_cases.json")
 SB = load_golden("sb_cases.json")
 JD = load_golden("jd_cases.json")
 JDN = load_golden("jdn_cases.json")
+JDO = load_golden("jdo_cases.json")
 
 
 def scripted_forward(model):
@@ -177,3 +178,40 @@ def test_engine_nongreedy(case):
     for s, f in zip(seqs, case["final"]):
         assert s.token_ids == f["token_ids"]
         assert s.num_cached_tokens == f["num_cached_tokens"]
+
+
+# ----------------------------------------------------------------------------- on-policy rollout records (JDO)
+def run_oracle_jdo(case):
+    p = case["params"]
+    seqs, models = _mk_seqs(case, max_iters=p["max_blocks"])
+    by_id = {id(s): m for s, m in zip(seqs, models)}
+    trace = []
+
+    def fwd(ss, drafts):
+        trace.append(dict(seq_idx=[seqs.index(s) for s in ss], draft=[list(d) for d in drafts], seq_lens=[len(s) for s in ss]))
+        return [by_id[id(s)].logits_rows(s.token_ids[:-1], [d])[0][:-1] for s, d in zip(ss, drafts)]
+
+    inits = O.CounterStream(p["rng_seed"] * 5 + 1)
+    unis = O.CounterStream(p["rng_seed"] * 5 + 2)
+    multi = O.CounterStream(p["rng_seed"] * 5 + 3)
+    records, metrics = O.onpolicy_rollout_records_batch(fwd, seqs, p["temperature"], p["stop_ids"], p["pad_id"], p["vocab"],
+                                                        O.ScriptedRandom(inits), unis.uniform, multi.uniform)
+    return seqs, records, metrics, dict(inits=inits.k, uniforms=unis.k, multinomial=multi.k), trace
+
+
+def check_jdo(case, seqs, records, metrics, draws, trace=None):
+    assert [{str(k): v for k, v in r.items()} for r in records] == case["records"]
+    assert metrics == case["metrics"]
+    assert draws == case["draws"]
+    for s, f in zip(seqs, case["final"]):
+        assert list(s.token_ids) == f["token_ids"]
+        assert s.num_cached_tokens == f["num_cached_tokens"]
+    if trace is not None:
+        assert [dict(draft=t["draft"], seq_lens=t["seq_lens"]) for t in trace] == \
+               [dict(draft=t["draft"], seq_lens=t["seq_lens"]) for t in case["forwards"]]
+
+
+@pytest.mark.parametrize("case", JDO, ids=[c["name"] for c in JDO])
+def test_engine_onpolicy_records(case):
+    seqs, records, metrics, draws, trace = run_oracle_jdo(case)
+    check_jdo(case, seqs, records, metrics, draws, trace)
