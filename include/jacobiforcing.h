@@ -277,6 +277,36 @@ int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_stride, con
                const int64_t *pad_stream, int64_t pad_len, int64_t *pad_cursor,
                int64_t *committed, int64_t *next_draft, jf_rs_row *rows, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * On-policy rollout step, JDO = inference_engine/engine/jacobi_decoding_nongreedy_on_policy.py.
+ * One sequence, R = proposed tokens of the current block that are not accepted yet; logits [R, V] and
+ * p_draft / row_max / row_sumexp / packed [R] from jf_rs_probs(draft_next = proposed).
+ *   verify  (JDO:270-327): accept proposed[t] iff u < p_draft[t]; first rejection -> bonus != proposed[t]
+ *           (inverse CDF, <= 16 draws, then masked argmax: JDO:157-168) and stop; a committed token in
+ *           stop_ids[n_stop] ends the block (stop_hit).
+ *   redraft (JDO:465-477): if not stopped and n_committed < R, rows n_committed..R-1 each draw one sample
+ *           from softmax(logits[row] / T) -> redraft[row] (the block's new guesses).
+ * u_stream feeds the accept tests (torch.rand), m_stream every multinomial draw (bonus draws first, then
+ * the re-draft rows in order), both consumed cyclically from *cursor, which is advanced.  packed is re-zeroed.
+ */
+typedef struct jf_op_row {
+    int32_t n_committed;     /* accepted proposals + bonus, >= 1                     */
+    int32_t stop_hit;        /* a stop token was committed                           */
+    int32_t reject_pos;      /* first rejected position, -1 = all accepted           */
+    int32_t n_bonus_draws;   /* multinomial draws used by the bonus (<= 16)          */
+    int32_t n_uniforms;      /* accept/reject uniforms consumed                      */
+    int32_t n_redraft;       /* rows re-drafted = R - n_committed, or 0              */
+    int32_t redraft_base_lo; /* m_stream index of the first re-draft draw (64 bit)   */
+    int32_t redraft_base_hi;
+} jf_op_row;
+
+int jf_rs_onpolicy_step(const void *logits, int dtype, int64_t V, int64_t row_stride, const int64_t *proposed, int R,
+                        const float *p_draft, const float *row_max, const float *row_sumexp, uint64_t *packed,
+                        float temperature, const int32_t *stop_ids, int n_stop,
+                        const float *u_stream, int64_t u_len, int64_t *u_cursor,
+                        const float *m_stream, int64_t m_len, int64_t *m_cursor,
+                        int64_t *committed /* [R] */, int64_t *redraft /* [R] */, jf_op_row *row, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,15 @@ class RsRow(C.Structure):
 RS_ROW_INTS = C.sizeof(RsRow) // 4
 RS_FIELDS = [f[0] for f in RsRow._fields_]
 
+
+class OpRow(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("n_committed", "stop_hit", "reject_pos", "n_bonus_draws", "n_uniforms", "n_redraft",
+                                         "redraft_base_lo", "redraft_base_hi")]
+
+
+OP_ROW_INTS = C.sizeof(OpRow) // 4
+OP_FIELDS = [f[0] for f in OpRow._fields_]
+
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
 _SIGNATURES = {
@@ -79,6 +88,8 @@ _SIGNATURES = {
     "jf_rs_workspace_bytes": (_sz, [_i64, _i64]),
     "jf_rs_step": (C.c_int, [_vp, C.c_int, _i64, _i64, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _f32, _i32, _vp,
                              _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "jf_rs_onpolicy_step": (C.c_int, [_vp, C.c_int, _i64, _i64, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_float, _vp, C.c_int,
+                                      _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

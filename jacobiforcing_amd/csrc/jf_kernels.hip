@@ -1318,6 +1318,187 @@ __global__ __launch_bounds__(256) void rs_step_kernel(const void *logits, int64_
     if (tid == 0) { *u_cursor = s_uc; *b_cursor = s_bc; *pad_cursor = s_pc; }
 }
 
+// ------------------------------------------------------------------------------------------------
+// On-policy rollout step (JDO = inference_engine/engine/jacobi_decoding_nongreedy_on_policy.py): sequential accept /
+// reject of ONE sequence's proposed tokens with a stop-token SET (JDO:270-327), then a fresh sample of every not yet
+// accepted position from this forward's distribution (JDO:465-477) — one workgroup per re-drafted row.
+// ------------------------------------------------------------------------------------------------
+template <int DT>
+__device__ __forceinline__ double rs_slice_sum(const void *row, int64_t lo, int64_t hi, float inv_t, float M, float Sx) {
+    double acc = 0.0;
+    for (int64_t i = lo; i < hi; ++i) acc += (double)(expf(load_f<DT>(row, i) * inv_t - M) / Sx);
+    return acc;
+}
+template <int DT>
+__device__ __forceinline__ int64_t rs_slice_pick(const void *row, int64_t lo, int64_t hi, float inv_t, float M, float Sx,
+                                                 double pre, double thr) {
+    double run = pre;
+    for (int64_t i = lo; i < hi; ++i) {
+        run += (double)(expf(load_f<DT>(row, i) * inv_t - M) / Sx);
+        if (run > thr) return i;
+    }
+    return hi - 1;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void rs_onpolicy_verify_kernel(const void *logits, int64_t V, int64_t row_stride,
+                                                                  const int64_t *proposed, int R, const float *p_draft,
+                                                                  const float *row_max, const float *row_sumexp, float temp,
+                                                                  const int32_t *stop_ids, int n_stop, const float *u_stream,
+                                                                  int64_t u_len, int64_t *u_cursor, const float *m_stream,
+                                                                  int64_t m_len, int64_t *m_cursor, int64_t *committed,
+                                                                  jf_op_row *out) {
+    __shared__ int s_n, s_stop, s_rej, s_pick, s_used;
+    __shared__ double s_sum[256], s_pre[256];
+    __shared__ double s_total;
+    __shared__ uint64_t s_best[4];
+    const int tid = threadIdx.x;
+    const float inv_t = 1.f / temp;
+    const int64_t uc = *u_cursor, mc = *m_cursor;
+    auto is_stop = [&](int64_t tok) { for (int k = 0; k < n_stop; ++k) if (tok == (int64_t)stop_ids[k]) return true; return false; };
+    if (tid == 0) {
+        int n = 0, stop = 0, rej = -1, used = 0;
+        for (int t = 0; t < R; ++t) {                                  // JDO:293-320
+            const int64_t x = proposed[t];
+            const float u = u_stream[(uc + used) % u_len];
+            used++;
+            if (u < p_draft[t]) {
+                committed[n++] = x;
+                if (is_stop(x)) { stop = 1; break; }
+                continue;
+            }
+            rej = t;
+            break;
+        }
+        s_n = n; s_stop = stop; s_rej = rej; s_used = used;
+    }
+    __syncthreads();
+    const int rej = s_rej;
+    int draws = 0;
+    if (rej >= 0) {                                                    // JDO:157-168 (bonus != proposed)
+        const void *row = (const char *)logits + (int64_t)rej * row_stride * (DT == JF_F32 ? 4 : 2);
+        const float M = row_max[rej], Sx = row_sumexp[rej];
+        const int64_t per = (V + 255) / 256;
+        const int64_t lo = (int64_t)tid * per < V ? (int64_t)tid * per : V;
+        const int64_t hi = (lo + per < V) ? lo + per : V;
+        const double acc = rs_slice_sum<DT>(row, lo, hi, inv_t, M, Sx);
+        s_sum[tid] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            double run = 0.0;
+            for (int i = 0; i < 256; ++i) { s_pre[i] = run; run += s_sum[i]; }
+            s_total = run;
+        }
+        __syncthreads();
+        const int64_t x = proposed[rej];
+        int bonus = -1;
+        for (int tr = 0; tr < 16 && bonus < 0; ++tr) {
+            const double thr = (double)m_stream[(mc + tr) % m_len] * s_total;
+            if (tid == 0) s_pick = (int)(V - 1);
+            __syncthreads();
+            const double pre = s_pre[tid];
+            if (hi > lo && thr >= pre && thr < pre + acc) s_pick = (int)rs_slice_pick<DT>(row, lo, hi, inv_t, M, Sx, pre, thr);
+            __syncthreads();
+            draws++;
+            if ((int64_t)s_pick != x) bonus = s_pick;
+            __syncthreads();
+        }
+        if (bonus < 0) {
+            uint32_t best = 0u, bidx = 0xFFFFFFFFu;
+            for (int64_t i = tid; i < V; i += 256) {
+                if (i == x) continue;
+                const uint32_t k = load_key<DT>(row, i);
+                if (k > best) { best = k; bidx = (uint32_t)i; }
+            }
+            uint64_t pk = wave_max_u64(((uint64_t)best << 32) | (uint64_t)(~bidx));
+            if ((tid & 63) == 0) s_best[tid >> 6] = pk;
+            __syncthreads();
+            uint64_t mm = s_best[0];
+            for (int w = 1; w < 4; ++w) mm = s_best[w] > mm ? s_best[w] : mm;
+            const int alt = jfmb::decode_packed(mm);
+            const float palt = (alt >= 0 && alt < V) ? expf(load_f<DT>(row, alt) * inv_t - M) / Sx : 0.f;
+            bonus = (palt > 0.f) ? alt : (int)x;
+            __syncthreads();
+        }
+        if (tid == 0) {
+            committed[s_n] = bonus;
+            s_n = s_n + 1;
+            if (is_stop(bonus)) s_stop = 1;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int n = s_n;
+        const int n_redraft = (!s_stop && n < R) ? R - n : 0;          // JDO:465: not stopped and accepted < gen_len
+        const int64_t base = mc + draws;
+        out->n_committed = n; out->stop_hit = s_stop; out->reject_pos = rej; out->n_bonus_draws = draws;
+        out->n_uniforms = s_used; out->n_redraft = n_redraft;
+        out->redraft_base_lo = (int32_t)(base & 0xFFFFFFFFll); out->redraft_base_hi = (int32_t)(base >> 32);
+        *u_cursor = uc + s_used;
+        *m_cursor = base + n_redraft;
+    }
+}
+
+// one workgroup per logits row: rows >= n_committed draw one sample each (inverse CDF, float64 running sum in vocabulary
+// order, the same arithmetic as the bonus draw); every row's argmax slot is re-zeroed.
+template <int DT>
+__global__ __launch_bounds__(256) void rs_sample_rows_kernel(const void *logits, int64_t V, int64_t row_stride, int R,
+                                                              const float *row_max, const float *row_sumexp, float temp,
+                                                              const float *m_stream, int64_t m_len, const jf_op_row *res,
+                                                              int64_t *redraft, unsigned long long *packed) {
+    __shared__ double s_sum[256], s_pre[256];
+    __shared__ double s_total;
+    __shared__ int s_pick;
+    const int li = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) packed[li] = 0ull;
+    const int n = res->n_committed;
+    if (res->n_redraft <= 0 || li < n) return;
+    const int64_t base = ((int64_t)res->redraft_base_hi << 32) | (int64_t)(uint32_t)res->redraft_base_lo;
+    const float inv_t = 1.f / temp;
+    const void *row = (const char *)logits + (int64_t)li * row_stride * (DT == JF_F32 ? 4 : 2);
+    const float M = row_max[li], Sx = row_sumexp[li];
+    const int64_t per = (V + 255) / 256;
+    const int64_t lo = (int64_t)tid * per < V ? (int64_t)tid * per : V;
+    const int64_t hi = (lo + per < V) ? lo + per : V;
+    const double acc = rs_slice_sum<DT>(row, lo, hi, inv_t, M, Sx);
+    s_sum[tid] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double run = 0.0;
+        for (int i = 0; i < 256; ++i) { s_pre[i] = run; run += s_sum[i]; }
+        s_total = run;
+        s_pick = (int)(V - 1);
+    }
+    __syncthreads();
+    const double thr = (double)m_stream[(base + (li - n)) % m_len] * s_total;
+    const double pre = s_pre[tid];
+    if (hi > lo && thr >= pre && thr < pre + acc) s_pick = (int)rs_slice_pick<DT>(row, lo, hi, inv_t, M, Sx, pre, thr);
+    __syncthreads();
+    if (tid == 0) redraft[li] = s_pick;
+}
+
+extern "C" int jf_rs_onpolicy_step(const void *logits, int dtype, int64_t V, int64_t row_stride, const int64_t *proposed, int R,
+                                   const float *p_draft, const float *row_max, const float *row_sumexp, uint64_t *packed,
+                                   float temperature, const int32_t *stop_ids, int n_stop, const float *u_stream, int64_t u_len,
+                                   int64_t *u_cursor, const float *m_stream, int64_t m_len, int64_t *m_cursor,
+                                   int64_t *committed, int64_t *redraft, jf_op_row *row, void *stream) {
+    if (R <= 0) return JF_OK;
+    if (!logits || !proposed || !p_draft || !row_max || !row_sumexp || !packed || !u_stream || !u_cursor || !m_stream ||
+        !m_cursor || !committed || !redraft || !row || (n_stop > 0 && !stop_ids))
+        return fail(JF_E_INVALID, "jf_rs_onpolicy_step: null pointer");
+    if (u_len <= 0 || m_len <= 0 || n_stop < 0) return fail(JF_E_INVALID, "jf_rs_onpolicy_step: empty random stream");
+    const float t = (temperature <= 0.f) ? 1.f : temperature;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == JF_F32) {
+        rs_onpolicy_verify_kernel<JF_F32><<<1, 256, 0, s>>>(logits, V, row_stride, proposed, R, p_draft, row_max, row_sumexp, t, stop_ids, n_stop, u_stream, u_len, u_cursor, m_stream, m_len, m_cursor, committed, row);
+        rs_sample_rows_kernel<JF_F32><<<R, 256, 0, s>>>(logits, V, row_stride, R, row_max, row_sumexp, t, m_stream, m_len, row, redraft, (unsigned long long *)packed);
+    } else if (dtype == JF_BF16) {
+        rs_onpolicy_verify_kernel<JF_BF16><<<1, 256, 0, s>>>(logits, V, row_stride, proposed, R, p_draft, row_max, row_sumexp, t, stop_ids, n_stop, u_stream, u_len, u_cursor, m_stream, m_len, m_cursor, committed, row);
+        rs_sample_rows_kernel<JF_BF16><<<R, 256, 0, s>>>(logits, V, row_stride, R, row_max, row_sumexp, t, m_stream, m_len, row, redraft, (unsigned long long *)packed);
+    } else return fail(JF_E_INVALID, "jf_rs_onpolicy_step: dtype %d", dtype);
+    return check_launch("rs_onpolicy kernels");
+}
+
 extern "C" int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_stride, const int64_t *draft, int B, int L,
                           const float *p_draft, const float *row_max, const float *row_sumexp, uint64_t *packed,
                           float temperature, int32_t eos_id, const int32_t *remaining, const float *u_stream, int64_t u_len,

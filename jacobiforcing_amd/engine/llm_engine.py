@@ -59,6 +59,16 @@ class LLMEngine:
         result = self.model_runner.call("run", seqs, is_prefill)
         if result is None or (is_prefill and len(result) > 0 and result[0] == []):              # ENG:90-93
             return [], sum(len(seq) for seq in seqs)
+        if len(result) > 0 and isinstance(result[0], dict):                                     # on-policy, ENG:95-116
+            # every sequence of the batch finishes and carries the WHOLE list of per-sequence records, as in the reference
+            num_new = 0 if is_prefill else sum(seq.num_completion_tokens for seq in seqs)
+            for seq in seqs:
+                seq.status = SequenceStatus.FINISHED
+                seq._rollout_records = result
+                if seq in self.scheduler.running:
+                    self.scheduler.running.remove(seq)
+                self.model_runner.release(seq)
+            return [(seq.seq_id, seq._rollout_records) for seq in seqs], (-num_new if num_new > 0 else 0)
         token_ids = result
         is_jacobi = len(token_ids) > 0 and isinstance(token_ids[0], (list, tuple))
         if is_jacobi:
@@ -104,6 +114,12 @@ class LLMEngine:
                     pbar.update(1)
         if pbar is not None:
             pbar.close()
+        ordered = [outputs[seq_id] for seq_id in sorted(outputs)]
+        if ordered and isinstance(ordered[0], list) and ordered[0] and isinstance(ordered[0][0], dict):   # ENG:176-185
+            records = []
+            for seq_output in ordered:          # one copy of the batch's record list per sequence (reference behaviour)
+                records.extend(seq_output) if isinstance(seq_output, list) else records.append(seq_output)
+            return records
         res = []
         for seq_id in sorted(outputs):
             toks = [int(t) for t in outputs[seq_id]]

@@ -22,6 +22,7 @@ from ..config import Config
 from ..modeling.qwen2 import Qwen2Model, Qwen2Weights, StaticKVCache
 from .jacobi_decoding import JacobiDecoder
 from .jacobi_decoding_nongreedy import JacobiDecoderNonGreedy
+from .jacobi_decoding_nongreedy_on_policy import JacobiDecoderNonGreedyOnPolicy
 from .multiblock_decoder import MultiblockJacobiDecoder
 from .sequence import Sequence
 
@@ -191,9 +192,13 @@ class ModelRunner:
         jac = [s for s in seqs if s.decode_strategy == "jacobi"]
         if not jac:
             return
-        if any(getattr(s, "jacobi_on_policy", False) for s in jac):
-            raise NotImplementedError("jacobi_on_policy (rollout-record production for training) is out of scope for the "
-                                      "decode-throughput path (SURVEY §2 row 5)")
+        if any(getattr(s, "jacobi_on_policy", False) for s in jac):                              # MR:317, 334-343
+            if not isinstance(self.jacobi_decoder, JacobiDecoderNonGreedyOnPolicy):
+                self.jacobi_decoder = JacobiDecoderNonGreedyOnPolicy(
+                    block_manager=self.block_manager, forward_step=self._jacobi_forward_step,
+                    forward_step_batch=self._jacobi_forward_step_batch, eos_token_id=self.config.eos,
+                    pad_token_id=self.config.pad, vocab_size=self.config.hf_config.vocab_size, device=self.device)
+            return
         temps = [float(getattr(s, "temperature", 0.0)) for s in jac]
         all_greedy, all_ng = all(t == 0.0 for t in temps), all(t > 0.0 for t in temps)
         if not (all_greedy or all_ng):
@@ -274,5 +279,11 @@ class ModelRunner:
             self._ensure_jacobi_decoder_initialized(seqs)
             if is_prefill:
                 return self._jacobi_prefill_with_drafting(seqs)
+            if any(getattr(s, "jacobi_on_policy", False) for s in seqs):                         # MR:1483-1510
+                if not isinstance(self.jacobi_decoder, JacobiDecoderNonGreedyOnPolicy):
+                    raise RuntimeError("On-policy decoder not initialized correctly. Expected JacobiDecoderNonGreedyOnPolicy "
+                                       f"but got {type(self.jacobi_decoder)}")
+                return self.jacobi_decoder.generate_rollout_records_batch(
+                    seqs, n_token_seq_len=getattr(seqs[0], "jacobi_block_len", 64), return_metrics=False)
             return self.jacobi_decoder.generate_chunk_batch(seqs)
         return self._run_autoregressive(seqs, is_prefill)

@@ -505,3 +505,61 @@ class RsStepper:
         if dev.type == "cuda":
             torch.cuda.current_stream(dev).synchronize()
         return self.rows_host[:B].numpy(), th.numpy(), nd
+
+
+# --------------------------------------------------------------------------------------------
+# on-policy rollout step (JDO:270-327 verify + JDO:465-477 re-draft)
+# --------------------------------------------------------------------------------------------
+class OnPolicyStepper:
+    """jf_rs_probs + jf_rs_onpolicy_step for one sequence per call: three launches, one read-back."""
+
+    def __init__(self, max_L: int, device, u_stream, m_stream, stop_ids: Sequence[int]):
+        dev = torch.device(device)
+        self.device, self.max_L = dev, int(max_L)
+        n = self.max_L
+        self.packed = new_packed(n, dev)
+        f32 = lambda k: torch.zeros((k,), dtype=torch.float32, device=dev)
+        self.p_draft, self.row_max, self.row_sumexp = f32(n), f32(n), f32(n)
+        self.ws = torch.zeros((n * 64 * 2,), dtype=torch.float32, device=dev)
+        self.out = torch.zeros((2, n), dtype=torch.int64, device=dev)              # committed, redraft
+        self.row_dev = torch.zeros((N.OP_ROW_INTS,), dtype=torch.int32, device=dev)
+        pin = dev.type == "cuda"
+        self.row_host = torch.zeros((N.OP_ROW_INTS,), dtype=torch.int32, pin_memory=pin)
+        self.out_host = torch.zeros((2, n), dtype=torch.int64, pin_memory=pin)
+        self.u_stream = torch.as_tensor(u_stream).to(device=dev, dtype=torch.float32).contiguous()
+        self.m_stream = torch.as_tensor(m_stream).to(device=dev, dtype=torch.float32).contiguous()
+        self.stop_ids = torch.tensor([int(x) for x in stop_ids], dtype=torch.int32, device=dev)
+        self.cursors = torch.zeros((2,), dtype=torch.int64, device=dev)             # uniforms, multinomial
+
+    def step(self, proposed: torch.Tensor, logits: torch.Tensor, temperature: float, cursors: Sequence[int]):
+        """proposed [R] int64, logits [R, V] -> (row dict, committed list, redraft list [R] (valid from n_committed))."""
+        R = int(proposed.numel())
+        if logits.dim() != 2 or logits.shape[0] != R:
+            raise ValueError(f"forward must return logits [1, {R}, vocab], got {tuple(logits.shape)}")     # JDO:392-393
+        if R > self.max_L:
+            raise RuntimeError("OnPolicyStepper capacity exceeded")
+        dev = self.device
+        V = logits.shape[-1]
+        flat = logits if logits.stride(1) == 1 else logits.contiguous()
+        prop = proposed.to(device=dev, dtype=torch.int64).contiguous()
+        lib = N.lib()
+        N.check(lib.jf_rs_probs(_ptr(flat), _dtype_code(flat), R, V, flat.stride(0) if R > 1 else V, _ptr(prop),
+                                float(temperature), _ptr(self.p_draft), _ptr(self.row_max), _ptr(self.row_sumexp),
+                                _ptr(self.packed), _ptr(self.ws), self.ws.numel() * 4, _stream(dev)), "jf_rs_probs")
+        self.cursors.copy_(torch.tensor(list(cursors), dtype=torch.int64), non_blocking=True)
+        cur = self.cursors
+        c_ptr = lambda i: C.c_void_p(cur.data_ptr() + 8 * i)
+        cm, rd = self.out[0], self.out[1]
+        N.check(lib.jf_rs_onpolicy_step(_ptr(flat), _dtype_code(flat), V, flat.stride(0) if R > 1 else V, _ptr(prop), R,
+                                        _ptr(self.p_draft), _ptr(self.row_max), _ptr(self.row_sumexp), _ptr(self.packed),
+                                        float(temperature), _ptr(self.stop_ids), int(self.stop_ids.numel()),
+                                        _ptr(self.u_stream), self.u_stream.numel(), c_ptr(0),
+                                        _ptr(self.m_stream), self.m_stream.numel(), c_ptr(1),
+                                        _ptr(cm), _ptr(rd), _ptr(self.row_dev), _stream(dev)), "jf_rs_onpolicy_step")
+        self.row_host.copy_(self.row_dev, non_blocking=True)
+        self.out_host[:, :R].copy_(self.out[:, :R], non_blocking=True)
+        if dev.type == "cuda":
+            torch.cuda.current_stream(dev).synchronize()
+        row = dict(zip(N.OP_FIELDS, self.row_host.tolist()))
+        n = row["n_committed"]
+        return row, self.out_host[0, :n].tolist(), self.out_host[1, :R].tolist()

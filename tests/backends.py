@@ -325,6 +325,38 @@ class HostSimLib:
         pk[:] = 0
         return 0
 
+    def jf_rs_onpolicy_step(self, logits, dtype, V, stride, proposed, R, p_draft, row_max, row_sumexp, packed, temperature,
+                            stop_ids, n_stop, u_stream, u_len, u_cursor, m_stream, m_len, m_cursor, committed, redraft, row,
+                            stream):
+        lg = self._rows_f32(logits, dtype, R, V, stride)
+        probs = O.softmax_rows_f32(lg, temperature)
+        prop = _view(proposed, R, np.int64).tolist()
+        stops = _view(stop_ids, n_stop, np.int32).tolist() if n_stop else []
+        us, ms = _view(u_stream, u_len, np.float32), _view(m_stream, m_len, np.float32)
+        uc, mc = _view(u_cursor, 1, np.int64), _view(m_cursor, 1, np.int64)
+        used = {"u": 0, "m": 0}
+
+        def nu():
+            v = float(us[(uc[0] + used["u"]) % u_len]); used["u"] += 1; return v
+
+        def nm():
+            v = float(ms[(mc[0] + used["m"]) % m_len]); used["m"] += 1; return v
+        toks, stop_hit = O.onpolicy_verify(prop, probs, stops, nu, nm)
+        draws = used["m"]
+        rej = used["u"] - 1 if draws > 0 else -1
+        cm, rd = _view(committed, R, np.int64), _view(redraft, R, np.int64)
+        cm[:len(toks)] = toks
+        n_re = (R - len(toks)) if (not stop_hit and len(toks) < R) else 0
+        base = int(mc[0]) + draws
+        for li in range(len(toks), len(toks) + n_re):
+            rd[li] = O.inverse_cdf_sample(probs[li], nm())
+        rw = _view(row, N.OP_ROW_INTS, np.int32)
+        rw[:6] = [len(toks), int(stop_hit), rej, draws, used["u"], n_re]
+        rw[6:8] = np.array([base], dtype=np.int64).view(np.int32)
+        uc[0] += used["u"]; mc[0] += used["m"]
+        _view(packed, R, np.uint64)[:] = 0
+        return 0
+
 
 @contextlib.contextmanager
 def use_backend(name: str):

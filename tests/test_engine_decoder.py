@@ -112,6 +112,7 @@ def test_constructor_errors():
 from jacobiforcing_amd.engine.jacobi_decoding_nongreedy import JacobiDecoderNonGreedy  # noqa: E402
 
 JDN = load_golden("jdn_cases.json")
+JDO = load_golden("jdo_cases.json")
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -144,6 +145,56 @@ def test_engine_nongreedy_golden(case, backend):
         assert dict(pads=dec._cur[2], uniforms=dec._cur[0], bonus=dec._cur[1]) == case["draws"]
         for s, f in zip(seqs, case["final"]):
             assert s.token_ids == f["token_ids"] and s.num_cached_tokens == f["num_cached_tokens"]
+
+
+# ------------------------------------------------------------------------------------- on-policy rollout records
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", JDO, ids=[c["name"] for c in JDO])
+def test_engine_onpolicy_records_golden(case, backend):
+    """generate_rollout_records_batch against the records the reference's JacobiDecoderNonGreedyOnPolicy produced with the
+    same injected draws: block trajectories, prompts, teacher outputs, metrics, draw counts, forward inputs."""
+    from jacobiforcing_amd.engine.jacobi_decoding_nongreedy_on_policy import JacobiDecoderNonGreedyOnPolicy
+    with use_backend(backend):
+        dev = device_for(backend)
+        p = case["params"]
+        H = Harness(p["vocab"], dev, torch.float32)
+        stop = p["stop_ids"] if len(p["stop_ids"]) > 1 else p["eos_id"]
+        dec = JacobiDecoderNonGreedyOnPolicy(H.bm, forward_step=lambda s, d: H.forward_step_batch([s], d),
+                                             forward_step_batch=H.forward_step_batch, eos_token_id=stop,
+                                             pad_token_id=p["pad_id"], vocab_size=p["vocab"], device=torch.device(dev))
+        inits, unis, multi = (CounterStream(p["rng_seed"] * 5 + k) for k in (1, 2, 3))
+        dr = case["draws"]
+        dec.set_streams(O.ScriptedRandom(inits), [unis.uniform() for _ in range(dr["uniforms"] + 64)],
+                        [multi.uniform() for _ in range(dr["multinomial"] + 64)])
+        seqs = []
+        for d in case["seqs"]:
+            m = ScriptedModel.from_dict(d["model"])
+            sp = SamplingParams(temperature=p["temperature"], max_tokens=p["max_tokens"], decode_strategy="jacobi",
+                                jacobi_block_len=p["block_len"], jacobi_max_iterations=p["max_blocks"], jacobi_on_policy=True)
+            seqs.append(H.add(m, sp, None))
+        records, metrics = dec.generate_rollout_records_batch(seqs, return_metrics=True)
+        assert [{str(k): v for k, v in r.items()} for r in records] == case["records"]
+        assert metrics == case["metrics"]
+        assert dict(inits=inits.k, uniforms=dec._cur[0], multinomial=dec._cur[1]) == case["draws"]
+        for s, f in zip(seqs, case["final"]):
+            assert s.token_ids == f["token_ids"] and s.num_cached_tokens == f["num_cached_tokens"]
+        assert [(t["draft"], t["seq_lens"]) for t in H.trace] == [(t["draft"], t["seq_lens"]) for t in case["forwards"]]
+        if all(len(s.token_ids) - len(d["prompt"]) >= p["max_tokens"] for s, d in zip(seqs, case["seqs"])):
+            assert dec.generate_rollout_records(seqs[0]) == {}            # budget is spent: no further blocks
+
+
+def test_onpolicy_constructor_errors():
+    from jacobiforcing_amd.engine.jacobi_decoding_nongreedy_on_policy import JacobiDecoderNonGreedyOnPolicy as D
+    with pytest.raises(ValueError):
+        D(None, eos_token_id=1, pad_token_id=0, vocab_size=8)
+    f = lambda s, d: None
+    with pytest.raises(ValueError):
+        D(None, forward_step=f, pad_token_id=0, vocab_size=8)
+    with pytest.raises(ValueError):
+        D(None, forward_step=f, eos_token_id=1, vocab_size=8)
+    with pytest.raises(ValueError):
+        D(None, forward_step=f, eos_token_id=1, pad_token_id=0)
+    assert D(None, forward_step=f, eos_token_id=[3, 4], pad_token_id=0, vocab_size=8, device="cpu").stop_token_ids == (3, 4)
 
 
 # ------------------------------------------------------------------------------------- paged-KV index buffers (a16)

@@ -98,3 +98,37 @@ def test_nongreedy_and_errors(model_dir, backend, monkeypatch):
                                                   SamplingParams(temperature=1.0, max_tokens=4, decode_strategy="jacobi")], use_tqdm=False)
         with pytest.raises(ValueError):
             llm2.generate(["text prompt"], SamplingParams(max_tokens=4), use_tqdm=False)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_on_policy_rollout_records(model_dir, backend, monkeypatch):
+    """SamplingParams(jacobi_on_policy=True): generate() returns rollout records (JDO:7-28) instead of texts — one
+    {block index -> record} dict per sequence, the batch's list repeated once per sequence exactly as the reference's
+    LLMEngine does (ENG:99-116, 176-185)."""
+    monkeypatch.setenv("JF_INIT_STD", "0.3")
+    with use_backend(backend):
+        dev = device_for(backend)
+        llm = LLM(model_dir, tokenizer_path="none", device=dev, max_model_len=512, max_num_batched_tokens=512, max_num_seqs=4)
+        torch.manual_seed(0)
+        prompts = [[1, 2, 3, 4, 5], [9, 8, 7]]
+        sp = SamplingParams(temperature=0.9, max_tokens=20, ignore_eos=True, decode_strategy="jacobi", jacobi_block_len=8,
+                            jacobi_on_policy=True)
+        recs = llm.generate(prompts, sp, use_tqdm=False)
+        assert len(recs) == len(prompts) ** 2 and recs[:2] == recs[2:]
+        for i, r in enumerate(recs[:2]):
+            assert sorted(r) == list(range(len(r))) and len(r) >= 1
+            total = 0
+            for k in sorted(r):
+                b = r[k]
+                assert b["diffusion_itr_id"] == f"itr_{k}" and b["data_id"] == f"data_{i}"
+                assert all(len(v) == 8 for v in b["answer_trajectory_ids"]) and len(b["answer_trajectory_ids"]) >= 2
+                assert b["prompt_ids"][:len(prompts[i])] == prompts[i]
+                assert b["teacher_output_ids"][:len(b["prompt_ids"])] == b["prompt_ids"]
+                assert b["num_iters"] == k + 1 and b["num_forwards"] >= b["num_iters"]
+                total = len(b["teacher_output_ids"]) - len(prompts[i])
+            stop = {319}
+            done = b["teacher_output_ids"]
+            assert total >= 20 or done[-1] in stop            # budget reached, or a stop token ended the rollout
+            # the last vector of block k is what was committed for that block
+            first = r[0]
+            assert first["answer_trajectory_ids"][-1][:min(8, total)] == done[len(prompts[i]):len(prompts[i]) + min(8, total)]
