@@ -119,3 +119,47 @@ def test_seam_on_qwen2_backend_equals_autoregressive(backend):
             nxt = fwd([toks[:-1]], [[toks[-1]]])[0][0]
             ar.append(nxt); toks.append(nxt)
         assert gen == ar
+
+
+# ------------------------------------------------------------------------------------- streaming driver (applications/)
+class _StubTokenizer:
+    """Token ids <-> "<id>" pieces; enough of the HF tokenizer surface for jacobi_stream_chat."""
+
+    def __init__(self, prompt_ids, eos, pad):
+        self.prompt_ids, self.eos_token_id, self.pad_token_id = prompt_ids, eos, pad
+
+    def apply_chat_template(self, messages, tokenize=False, add_generation_prompt=True):
+        return "PROMPT"
+
+    def __call__(self, text, return_tensors="pt", add_special_tokens=True):
+        if isinstance(text, list):
+            return {"input_ids": torch.tensor([self.prompt_ids], dtype=torch.int64)}
+        ids = [int(x) for x in text.replace(">", " ").replace("<", " ").split()]
+        return types.SimpleNamespace(input_ids=torch.tensor([ids], dtype=torch.int64))
+
+    def decode(self, ids, skip_special_tokens=True, clean_up_tokenization_spaces=False):
+        return "".join(f"<{t}>" for t in ids)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("per_token", [True, False], ids=["per_token", "per_chunk"])
+def test_stream_chat_driver(per_token, backend):
+    """jacobi_stream_chat (applications/jacobi_streaming_driver.py:7-193 surface): the streamed text is the model's greedy
+    continuation up to EOS, on_text sees a growing prefix of it, per-token and per-chunk streaming agree."""
+    from jacobiforcing_amd.drivers.stream_chat import jacobi_stream_chat
+    with use_backend(backend):
+        dev = device_for(backend)
+        V, eos, pad = 200, 199, 198
+        m = ScriptedModel(V, 77, 80, 12, eos_id=eos, eos_pos=12 + 41, reserved=(pad,))
+        me = types.SimpleNamespace(jf_backend=ScriptedBackend(m, dev))
+        tok = _StubTokenizer(m.prompt(), eos, pad)
+        seen = []
+        torch.manual_seed(3)
+        text, final_ids, n_new, gen_time = jacobi_stream_chat(me, tok, [{"role": "user", "content": "hi"}], n_token_seq_len=16,
+                                                              max_new_tokens=200, K=2, r=0.8, n_gram_pool_size=4,
+                                                              on_text=seen.append, stream_per_token=per_token)
+        want = m.ar_continuation(12, 41)                                  # tokens before the EOS at position 53
+        assert final_ids[0].tolist() == want and n_new == len(want) and gen_time > 0
+        assert text == "".join(f"<{t}>" for t in want)
+        assert seen and seen[-1] == text and all(b.startswith(a) for a, b in zip(seen, seen[1:]))
+        assert len(seen) == len(want) if per_token else len(seen) < len(want)
