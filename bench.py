@@ -155,13 +155,15 @@ def main():
     ap.add_argument("--no-tuned-gemms", action="store_true")
     args = ap.parse_args()
 
-    info = jd.init_from_env("nccl")
+    # JF_DIST_BACKEND=gloo + JF_FORCE_DEVICE=0 lets N ranks share one GPU (plumbing check of the N>1 path on a 1-GPU box)
+    info = jd.init_from_env(os.environ.get("JF_DIST_BACKEND", "nccl"))
     if info.world_size != args.gpus and info.world_size > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={info.world_size}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the Jacobi loop body has no CPU path")
-    torch.cuda.set_device(info.local_rank)
-    dev = torch.device("cuda", info.local_rank)
+    dev_index = int(os.environ.get("JF_FORCE_DEVICE", info.local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     _native.lib()                                   # fail loudly if the HIP extension is missing
     from jacobiforcing_amd.tuning import enable_tuned_gemms
     tuned = (not args.no_tuned_gemms) and enable_tuned_gemms()

@@ -27,14 +27,17 @@ def init_from_env(backend: Optional[str] = None) -> RankInfo:
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(int(os.environ.get("JF_FORCE_DEVICE", local)))
         dist.init_process_group(backend=backend, rank=rank, world_size=ws)
     return RankInfo(rank, ws, local)
 
 
 def barrier(device: Optional[torch.device] = None) -> None:
     if dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
     if device is not None and device.type == "cuda":
         torch.cuda.synchronize(device)
 
