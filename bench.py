@@ -5,14 +5,14 @@ Qwen2.5-Coder-7B-shaped model, synthetic HumanEval-shaped prompts, random-init b
   python bench.py --gpus N --steps K --warmup W
 
 A "step" is one Jacobi iteration over the rank's batch of prompts: one PyTorch forward over every prompt's rows,
-then the HIP loop body (jf_argmax_partial -> jf_mb_step -> jf_kv_commit) and one descriptor read-back.  The timed
+then the HIP loop body (jf_argmax_scatter -> jf_mb_step -> jf_kv_commit) and one descriptor read-back.  The timed
 region is exactly K steps between barrier+synchronize fences; every rank runs the same per-GPU workload (weak
 scaling, prompts shard over ranks, no data-path collective) and rank 0 prints ONE JSON line whose `value` is the
 whole-job accepted tokens per second.
 
 Extra objects on the line:
-  roofline      — jf_argmax_partial (the convergence kernel's HBM stream): algorithmic bytes R*V*2 per launch
-                  over the average launch duration measured with HIP events on the launch stream.
+  roofline      — the argmax launch (the convergence kernel's HBM stream): algorithmic bytes = draft-carrying rows * V * 2
+                  per launch over the average launch duration measured with HIP events on the launch stream.
   cpu_baseline  — the CPU oracle (the reference's HF loop + DynamicCache handling restated) with a torch-CPU
                   forward of the same weights, timed on the host cores for a bounded sample.
   scripted_acceptance — the same K-step measurement with the synthetic acceptance model switched on (the random
@@ -147,7 +147,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--prompts-per-gpu", type=int, default=8)
+    ap.add_argument("--prompts-per-gpu", type=int, default=64)
     ap.add_argument("--model", default=os.environ.get("JF_MODEL", "qwen2.5-coder-7b"), help="qwen2.5-coder-7b | tiny | <hf dir>")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=float(os.environ.get("JF_CPU_BASELINE_S", "20")))
     ap.add_argument("--no-scripted", action="store_true")
@@ -203,12 +203,20 @@ def main():
     scripted = None
     if not args.no_scripted:
         dec.logits_hook = ScriptedAcceptance(cfg.vocab_size, robust_pct=args.robust, vocab_hi=vocab_hi)
-        r2 = run_steps(dec, prompts, args.warmup, args.steps, seed=4321 + info.rank)
+        with ArgmaxTimer() as tm2:
+            tm2.valid_rows = lambda: dec.last_valid_rows
+            r2 = run_steps(dec, prompts, args.warmup, args.steps, seed=4321 + info.rank, timer=tm2)
+            roof2 = tm2.summary()
         a2 = jd.gather_throughput(r2["tokens"], r2["iterations"] * 1.0, r2["seconds"], dev)
         dec.logits_hook = None
         scripted = dict(value=a2["tokens"] / a2["seconds"], unit="tokens/s",
                         tokens_per_forward=a2["tokens"] / max(a2["iterations"] * P, 1),
                         ms_per_step=a2["seconds"] / args.steps * 1e3, robust_pct=args.robust,
+                        roofline=None if roof2 is None else {
+                            "bound": "hbm", "achieved": roof2["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": roof2["gbs"] / HBM_PEAK_GBS, "bytes_per_launch": roof2["avg_bytes"],
+                            "us_per_launch": roof2["avg_us"], "rows_per_launch": roof2["avg_rows"],
+                            "logits_rows_per_launch": roof2["avg_launched_rows"], "launches": roof2["launches"]},
                         note="logits get a planted context-robust prediction (jacobiforcing_amd/synthetic.py) — extra "
                              "work inside the forward; emulates a Jacobi-Forcing checkpoint's acceptance")
     out = None
@@ -222,14 +230,14 @@ def main():
             "ms_per_step": agg["seconds"] / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "tokens_per_forward": tpf,
-            "config": {"workload": f"{P} HumanEval-shaped synthetic prompts per GPU (BASELINE config 3 semantics batched "
-                                   f"as in config 4: {P * info.world_size} prompts sharded {info.world_size}-way), "
-                                   "multiblock lookahead + rejection recycling, greedy",
+            "config": {"workload": f"BASELINE config 3 decoding (multiblock lookahead + rejection recycling, greedy) over "
+                                   f"HumanEval-shaped synthetic prompts, a batch of {P} per GPU replica (config 4's batch), "
+                                   f"{P * info.world_size} prompts sharded {info.world_size}-way, no data-path collective",
                        "model": name, "n": 32, "K": 2, "r": 0.85, "pool": 4, "prompts_per_gpu": P,
                        "steps_measured": steps_done, "logits_dtype": "bf16",
                        "weights": "random-init (no network for checkpoints); acceptance is what these weights give",
                        "gemm_selection": "TunableOp table jacobiforcing_amd/tunableop_mi355x.csv (hipBLASLt/rocBLAS picks for "
-                                         "M=64..512; row length padded to a multiple of 8)" if tuned else "library default"},
+                                         "M=64..4096; row length padded to a multiple of 8)" if tuned else "library default"},
         }
         if roof is not None:
             out["roofline"] = {"bound": "hbm", "achieved": roof["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """One-off GEMM selection for the decode shapes of Qwen2.5-7B on MI355X with PyTorch's TunableOp (picks among the
 hipBLASLt / rocBLAS solutions; stock PyTorch-ROCm, nothing custom).  Rows M = prompts x padded block length are kept on a
-grid of multiples of 64 by the decoder (t_align=8 with 8 prompts), so eight M values x five GEMMs cover a decode step.
+grid by the decoder (t_align=8: multiples of 64 with 8 prompts per GPU, of 512 with 64), so a handful of M values x five
+GEMMs cover a decode step.  TUNE_M=512,1024,... adds rows to an existing table (TUNE_OUT = where to write).
 
     python tools/tune_gemms.py            # writes jacobiforcing_amd/tunableop_mi355x.csv
 """
@@ -10,7 +11,7 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
-OUT = ROOT / "jacobiforcing_amd" / "tunableop_mi355x.csv"
+OUT = Path(os.environ.get("TUNE_OUT", ROOT / "jacobiforcing_amd" / "tunableop_mi355x.csv"))   # existing rows are kept
 os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"
 os.environ["PYTORCH_TUNABLEOP_TUNING"] = "1"
 os.environ["PYTORCH_TUNABLEOP_VERBOSE"] = "0"
@@ -42,5 +43,8 @@ for M in Ms:
         F.linear(x, w["qkv"], w["bqkv"]); F.linear(xa, w["o"]); F.linear(x, w["gu"]); F.linear(xi, w["d"]); F.linear(x, w["lm"])
     torch.cuda.synchronize()
     print("tuned M =", M, flush=True)
-torch.cuda.tunable.write_file(str(OUT))
+try:
+    torch.cuda.tunable.write_file(str(OUT))
+except Exception as e:      # some builds only write at exit (to <name>0.csv)
+    print("write_file:", type(e).__name__, e)
 print("wrote", OUT)
