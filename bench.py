@@ -189,7 +189,7 @@ def main():
     all_prompts = humaneval_shaped_prompts(P * info.world_size, seed=1234, vocab_hi=vocab_hi)
     prompts = jd.shard_prompts(all_prompts, info)
     dec = MultiblockJacobiDecoder(model, P, prm, max_seq_len=4096, t_align=8 if tuned else 1,
-                                  logit_align=8 * P if tuned else 1)     # lm_head M stays on the tuned grid (multiples of 8*P)
+                                  logit_align=(64 if P <= 8 else 128) if tuned else 1)   # lm_head M stays on its tuned grid
 
     # ---- headline: unmodified random-init model ------------------------------------------------
     with ArgmaxTimer() as tm:

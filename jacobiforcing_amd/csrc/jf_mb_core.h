@@ -565,12 +565,14 @@ JF_HD void mb_pack_body(Lanes lanes, int p, int P, int32_t *states, int64_t stat
                         int64_t *input_ids, int32_t *positions, int32_t *row_prompt, int32_t *row_len,
                         int32_t *valid_index, int32_t valid_align) {
     int32_t *S = states + (int64_t)p * state_ints;
-    int row_base = 0, valid_base = 0;
-    for (int q = 0; q < p; ++q) {
+    int row_base = 0, valid_base = 0;                 // exclusive prefix over the prompts before this one, lanes in parallel
+    for (int q = lanes.lane(); q < p; q += lanes.count()) {
         const int32_t *Q = states + (int64_t)q * state_ints;
         row_base += Q[H_B];
         valid_base += Q[H_B] * Q[H_T];
     }
+    row_base = lanes.reduce_sum(row_base);
+    valid_base = lanes.reduce_sum(valid_base);
     Layout lay = layout_of(S);
     const int B = S[H_B], T = S[H_T], kv = S[H_KV_LEN];
     lanes.sync();

@@ -39,8 +39,11 @@ for M in Ms:
     x = torch.randn(M, H, device=dev, dtype=torch.bfloat16)
     xi = torch.randn(M, I, device=dev, dtype=torch.bfloat16)
     xa = torch.randn(M, nq * hd, device=dev, dtype=torch.bfloat16)
+    only = os.environ.get("TUNE_ONLY", "")          # "lm": lm_head only (its M is the compacted position count, a finer grid)
     for _ in range(2):
-        F.linear(x, w["qkv"], w["bqkv"]); F.linear(xa, w["o"]); F.linear(x, w["gu"]); F.linear(xi, w["d"]); F.linear(x, w["lm"])
+        if only != "lm":
+            F.linear(x, w["qkv"], w["bqkv"]); F.linear(xa, w["o"]); F.linear(x, w["gu"]); F.linear(xi, w["d"])
+        F.linear(x, w["lm"])
     torch.cuda.synchronize()
     print("tuned M =", M, flush=True)
 try:
