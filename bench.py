@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--no-scripted", action="store_true")
     ap.add_argument("--robust", type=int, default=82)
     ap.add_argument("--no-tuned-gemms", action="store_true")
+    ap.add_argument("--logit-align", type=int, default=0, help="lm_head row count rounded up to this multiple (0 = default)")
     args = ap.parse_args()
 
     # JF_DIST_BACKEND=gloo + JF_FORCE_DEVICE=0 lets N ranks share one GPU (plumbing check of the N>1 path on a 1-GPU box)
@@ -189,7 +190,7 @@ def main():
     all_prompts = humaneval_shaped_prompts(P * info.world_size, seed=1234, vocab_hi=vocab_hi)
     prompts = jd.shard_prompts(all_prompts, info)
     dec = MultiblockJacobiDecoder(model, P, prm, max_seq_len=4096, t_align=8 if tuned else 1,
-                                  logit_align=(64 if P <= 8 else 128) if tuned else 1)   # lm_head M stays on its tuned grid
+                                  logit_align=args.logit_align or (8 * P if tuned else 1))   # lm_head M stays on the tuned grid (multiples of 8*P)
 
     # ---- headline: unmodified random-init model ------------------------------------------------
     with ArgmaxTimer() as tm:
