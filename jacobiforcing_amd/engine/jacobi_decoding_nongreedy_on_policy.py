@@ -59,6 +59,51 @@ def _truncate_after_stop(ids: List[int], start_idx: int, stop_ids: PySeq[int]) -
     return list(ids)
 
 
+class _BlockState:
+    """The fixed-length vector of one block while it is being decoded: accepted prefix ⧺ current guesses ⧺ PAD beyond the
+    token budget, and the trajectory of its snapshots (one per forward, plus the initial guess)."""
+
+    def __init__(self, full_len: int, gen_len: int, pad: int, stop_ids):
+        self.full_len, self.gen_len, self.pad, self.stop = full_len, gen_len, int(pad), set(int(x) for x in stop_ids)
+        self.tokens: List[int] = []
+        self.accepted = 0
+        self.stopped = False
+        self.trajectory: List[List[int]] = []
+
+    def start(self, init: List[int]) -> None:
+        self.tokens = list(init) + [self.pad] * (self.full_len - self.gen_len)
+        self.snapshot()
+
+    def open(self) -> bool:
+        return self.accepted < self.gen_len and not self.stopped
+
+    def pending(self) -> List[int]:
+        return [int(t) for t in self.tokens[self.accepted:self.gen_len]]
+
+    def accept(self, committed: List[int]) -> int:
+        """Write the committed tokens over the guesses; returns the first position they went to (JDO:433-436)."""
+        first = self.accepted
+        self.accepted = min(self.gen_len, first + len(committed))
+        self.tokens[first:self.accepted] = committed[:self.accepted - first]
+        return first
+
+    def close_at_stop(self, first_new: int) -> None:
+        """A stop token was committed: PAD everything after it (JDO:452-463)."""
+        self.stopped = True
+        pos = next((j for j in range(first_new, self.accepted) if int(self.tokens[j]) in self.stop), None)
+        if pos is not None:
+            self.tokens[pos + 1:] = [self.pad] * (self.full_len - pos - 1)
+            self.accepted = min(self.accepted, pos + 1)
+
+    def refill(self, samples: List[int]) -> None:
+        need = self.gen_len - self.accepted
+        self.tokens[self.accepted:self.gen_len] = [int(t) for t in samples[:need]]
+
+    def snapshot(self) -> None:
+        self.tokens[self.gen_len:] = [self.pad] * (self.full_len - self.gen_len)
+        self.trajectory.append(list(self.tokens))
+
+
 class JacobiDecoderNonGreedyOnPolicy:
     def __init__(self, block_manager: BlockManager, forward_step: Optional[LogitsForwardFn] = None,
                  forward_step_batch: Optional[LogitsForwardFnBatch] = None,
@@ -140,78 +185,68 @@ class JacobiDecoderNonGreedyOnPolicy:
     @torch.inference_mode()
     def _run_one_block(self, seq: Sequence, block_len: int, token_budget_remaining: int, completion_start_len: int,
                        profiler=None) -> Tuple[List[List[int]], int, int, bool]:
-        full_len = int(block_len)
-        if full_len <= 0 or token_budget_remaining <= 0:
+        """Returns (trajectory, tokens appended, forwards used, stopped)."""
+        if int(block_len) <= 0 or token_budget_remaining <= 0:
             return [], 0, 0, True
-        gen_len = min(full_len, int(token_budget_remaining))
-        pad = self.pad_token_id
-        block_tokens = self._init_block_draft_from_prompt(list(seq.token_ids), gen_len) + [pad] * (full_len - gen_len)
-        accepted, stopped, fwd_used, appended_total = 0, False, 0, 0
-        trajectory: List[List[int]] = [list(block_tokens)]
-        stop_set = set(self.stop_token_ids)
+        blk = _BlockState(int(block_len), min(int(block_len), int(token_budget_remaining)), self.pad_token_id,
+                          self.stop_token_ids)
+        blk.start(self._init_block_draft_from_prompt(list(seq.token_ids), blk.gen_len))
         sp = getattr(seq, "sampling_params", None)
         temperature = float(getattr(sp, "temperature", 1.0)) if sp is not None else 1.0
-        st = self._ensure(full_len + 1)
-        while accepted < gen_len and not stopped:
-            remaining = gen_len - accepted
+        st = self._ensure(blk.full_len + 1)
+        bm = self.block_manager
+        tick = (lambda name, on: (profiler.start(name) if on else profiler.stop(name))) if profiler else (lambda name, on: None)
+        fwd_used = appended_total = 0
+        while blk.open():
             if not seq.token_ids:
-                seq.token_ids = [pad]
-            proposed = [int(t) for t in block_tokens[accepted:gen_len]]
+                seq.token_ids = [self.pad_token_id]
+            proposed = blk.pending()
+            remaining = len(proposed)
             draft = torch.tensor([[int(seq.token_ids[-1])] + proposed], dtype=torch.long, device=self.device)
             seq.draft_tokens = draft[0].tolist()
-            if profiler: profiler.start("jacobi.forward")
+            tick("jacobi.forward", True)
             logits = self._forward_single(seq, draft)                               # [1, remaining, V]
             fwd_used += 1
-            if profiler: profiler.stop("jacobi.forward")
+            tick("jacobi.forward", False)
             if logits.ndim != 3 or int(logits.size(0)) != 1 or int(logits.size(1)) != remaining:
                 raise ValueError(f"forward must return logits [1, {remaining}, vocab], got {tuple(logits.shape)}")
-            for x in proposed:                                                       # JDO:298-301
-                if x < 0 or x >= int(logits.size(-1)):
-                    raise ValueError(f"Token index {x} out of bounds for vocab size {int(logits.size(-1))}. "
-                                     "This may indicate a mismatch between model vocab and tokenizer vocab.")
-            if profiler: profiler.start("jacobi.verify")
+            V = int(logits.size(-1))
+            bad = next((x for x in proposed if not 0 <= x < V), None)                # JDO:298-301
+            if bad is not None:
+                raise ValueError(f"Token index {bad} out of bounds for vocab size {V}. "
+                                 "This may indicate a mismatch between model vocab and tokenizer vocab.")
+            tick("jacobi.verify", True)
             row, committed, redraft = st.step(draft[0, 1:], logits[0], temperature, self._cur)
             self._cur[0] += row["n_uniforms"]
             self._cur[1] += row["n_bonus_draws"] + row["n_redraft"]
-            stop_hit_local = bool(row["stop_hit"])
-            if profiler: profiler.stop("jacobi.verify")
+            stop_hit = bool(row["stop_hit"])
+            tick("jacobi.verify", False)
             if not committed:
-                committed = [proposed[0]]
-                stop_hit_local = committed[0] in stop_set
-            if profiler: profiler.start("jacobi.commit")
+                committed, stop_hit = [proposed[0]], proposed[0] in blk.stop
+            tick("jacobi.commit", True)
             seq.extend_tokens(committed)                                            # JDO:412-416
-            if self.block_manager is not None:
-                self.block_manager.may_append_batch(seq, len(committed))
-            if profiler: profiler.stop("jacobi.commit")
+            if bm is not None:
+                bm.may_append_batch(seq, len(committed))
+                if remaining > len(committed):
+                    bm.trim_kv_only_fast(seq, remaining - len(committed))           # JDO:420-426
+            tick("jacobi.commit", False)
             appended_total += len(committed)
-            num_to_trim = remaining - len(committed)
-            if num_to_trim > 0 and self.block_manager is not None:
-                self.block_manager.trim_kv_only_fast(seq, num_to_trim)
             seq.clear_draft()
             if len(seq) != seq.num_cached_tokens:
                 raise RuntimeError(f"Invariant violated: len(token_ids)={len(seq)} != num_cached_tokens={seq.num_cached_tokens}")
-            prev = accepted
-            accepted = min(gen_len, accepted + len(committed))
-            block_tokens[prev:accepted] = committed[:accepted - prev]
-            if stop_hit_local:                                                       # JDO:439-463
-                full_ids = list(seq.token_ids)
-                truncated = _truncate_after_stop(full_ids, completion_start_len, self.stop_token_ids)
-                if len(truncated) != len(full_ids):
-                    seq.token_ids = truncated
-                    if self.block_manager is not None:
-                        self.block_manager.trim_kv_only_fast(seq, len(full_ids) - len(truncated))
-                stopped = True
-                pos = next((j for j in range(prev, accepted) if int(block_tokens[j]) in stop_set), None)
-                if pos is not None:
-                    for k in range(pos + 1, full_len):
-                        block_tokens[k] = pad
-                    accepted = min(accepted, pos + 1)
-            if not stopped and accepted < gen_len:                                   # JDO:465-477 (samples drawn on the GPU)
-                block_tokens[accepted:gen_len] = [int(t) for t in redraft[len(committed):len(committed) + gen_len - accepted]]
-            for k in range(gen_len, full_len):
-                block_tokens[k] = pad
-            trajectory.append(list(block_tokens))
-        return trajectory, appended_total, fwd_used, stopped
+            first_new = blk.accept(committed)
+            if stop_hit:                                                             # JDO:439-463
+                kept = _truncate_after_stop(list(seq.token_ids), completion_start_len, self.stop_token_ids)
+                dropped = len(seq.token_ids) - len(kept)
+                if dropped:
+                    seq.token_ids = kept
+                    if bm is not None:
+                        bm.trim_kv_only_fast(seq, dropped)
+                blk.close_at_stop(first_new)
+            elif blk.accepted < blk.gen_len:                                         # JDO:465-477 (samples drawn on the GPU)
+                blk.refill(redraft[len(committed):])
+            blk.snapshot()
+        return blk.trajectory, appended_total, fwd_used, blk.stopped
 
     # ------------------------------------------------------------------------------- records (JDO:494-614)
     @torch.inference_mode()
