@@ -118,7 +118,7 @@ typedef struct jf_mb_desc {
     int32_t events;     /* bit0 spawn, bit1 switch, bit2 early-stop (banners MB:634/660/720)   */
     int32_t accepted;   /* tokens the real-active block accepted in this step                  */
     int32_t nspans;
-    int32_t rsv0, rsv1;
+    int32_t rsv0, rsv1;   /* on error: rsv0 = state-machine source line, rsv1 = (draft rows << 16) | candidate rows for JF_E_SHAPE */
 } jf_mb_desc;
 
 int64_t jf_mb_state_ints(const jf_mb_params *p); /* int32 elements per prompt state */

@@ -140,13 +140,13 @@ def check(rc: int, what: str = ""):
     raise RuntimeError(text)
 
 
-def raise_state_error(code: int, what: str):
+def raise_state_error(code: int, what: str, aux: int = 0):
     if code == JF_E_INVALID:
         raise ValueError(f"{what}: invalid state inside the Jacobi state machine (shape/assert; see MB:482, MB:631, MB:667)")
     if code == JF_E_SHAPE:
         # what torch raises at MB:482 when a re-surfaced pseudo block (Q3, K >= 3) has k rows and the RA draft has B
-        raise RuntimeError(f"{what}: The size of tensor a must match the size of tensor b at non-singleton dimension 0 "
-                           "(draft rows vs candidate rows, MB:482)")
+        raise RuntimeError(f"{what}: The size of tensor a ({aux >> 16}) must match the size of tensor b ({aux & 0xFFFF}) at "
+                           "non-singleton dimension 0 (draft rows vs candidate rows, MB:482)")
     if code == JF_E_CAPACITY:
         raise RuntimeError(f"{what}: fixed capacity exceeded inside the Jacobi state machine (raise max_blocks)")
     if code:

@@ -89,7 +89,7 @@ struct Machine {
     // scalar state mirrored in registers (uniform across lanes)
     int n, K, eos, pad, num_blocks, active, RA, len_lists, lnt, has_lnt, iters, done, ret_early, err;
     int prompt_len, kv_len, pool_count, pool_head;
-    int events, ra_accepted, kv_src_row, kv_copy_dst, kv_copy_len, err_line;
+    int events, ra_accepted, kv_src_row, kv_copy_dst, kv_copy_len, err_line, err_aux;
 
     JF_HD Machine(int32_t *s, Lanes l, const Layout &lay) : S(s), L(lay), lanes(l) {}
 
@@ -109,7 +109,7 @@ struct Machine {
         lnt = S[H_LNT]; has_lnt = S[H_HAS_LNT]; iters = S[H_ITERS]; done = S[H_DONE];
         ret_early = S[H_RET_EARLY]; err = S[H_ERR]; prompt_len = S[H_PROMPT_LEN]; kv_len = S[H_KV_LEN];
         pool_count = S[H_POOL_COUNT]; pool_head = S[H_POOL_HEAD];
-        events = 0; ra_accepted = 0; kv_src_row = 0; kv_copy_dst = 0; kv_copy_len = 0; err_line = 0;
+        events = 0; ra_accepted = 0; kv_src_row = 0; kv_copy_dst = 0; kv_copy_len = 0; err_line = 0; err_aux = 0;
     }
     JF_HD void store_scalars() {
         lanes.sync();
@@ -261,7 +261,7 @@ struct Machine {
                 d->B = done ? 0 : B; d->T = done ? 0 : T; d->done = done; d->error = err; d->iters = iters;
                 d->kv_len = kv_len; d->ret_len = S[H_RET_LEN]; d->next_token = S[H_NEXT_TOK];
                 d->kv_src_row = kv_src_row; d->kv_copy_dst = kv_copy_dst; d->kv_copy_len = kv_copy_len;
-                d->events = events; d->accepted = ra_accepted; d->nspans = done ? 0 : nsp; d->rsv0 = err_line; d->rsv1 = 0;
+                d->events = events; d->accepted = ra_accepted; d->nspans = done ? 0 : nsp; d->rsv0 = err_line; d->rsv1 = err_aux;
             }
         }
         lanes.sync();
@@ -315,7 +315,11 @@ JF_UNROLL
                     if (r0 + k < nrows && m[k] + 1 > acc_raw) { acc_raw = m[k] + 1; best_idx = r0 + k; }
             }
             JF_STAMP(2);
-            if (rows_d != 1 && B != 1 && rows_d != B) { JF_FAIL(JF_E_SHAPE); break; }   // torch broadcast raises (MB:482)
+            if (rows_d != 1 && B != 1 && rows_d != B) {                                   // torch broadcast raises (MB:482)
+                JF_FAIL(JF_E_SHAPE);
+                err_aux = (rows_d << 16) | (B & 0xFFFF);                                  // the two sizes of its message
+                break;
+            }
             const int32_t *drow = draft(b, rows_d == 1 ? 0 : best_idx);
             if (s == 0 || b == RA) best_row = (b == RA) ? best_idx : best_row;   // MB:500-502
             if (Ls == 0) continue;

@@ -176,7 +176,8 @@ class MultiblockBatch:
         err = d[:, N.DESC_FIELDS.index("error")]
         if err.any():
             p = int(np.nonzero(err)[0][0])
-            N.raise_state_error(int(err[p]), f"multiblock prompt {p} (state-machine line {int(d[p, N.DESC_FIELDS.index('rsv0')])})")
+            N.raise_state_error(int(err[p]), f"multiblock prompt {p} (state-machine line {int(d[p, N.DESC_FIELDS.index('rsv0')])})",
+                                aux=int(d[p, N.DESC_FIELDS.index("rsv1")]))
         return d
 
     def desc_field(self, d: np.ndarray, name: str) -> np.ndarray:

@@ -426,7 +426,11 @@ def mb_generation_call(forward: ForwardFn, input_ids: List[int], kv_tokens: List
         greedy = forward(kv_before, out)
         trace.append(dict(kv_len=len(kv_before[0]), out=[list(r) for r in out], greedy=[list(g) for g in greedy],
                           spans=list(spans)))
-        st.end_iteration(greedy)
+        try:
+            st.end_iteration(greedy)
+        except RuntimeError as e:          # MB:482 broadcast failure (the reference dies too): keep the forwards made so far
+            e.trace = trace
+            raise
         if st.done:
             break
     st.finalize()

@@ -197,7 +197,7 @@ def banners_of(text: str):
 # HF multiblock (MB) cases — driver mirrors DRV-MR:152-240
 # --------------------------------------------------------------------------------------
 def run_mb_case(name, *, vocab, seed, robust, prompt_len, n, K, r, pool, lookahead=0.0,
-                eos_pos=None, period=0, max_iter=128, max_calls=6, max_new_tokens=10 ** 9):
+                eos_pos=None, period=0, max_iter=128, max_calls=6, max_new_tokens=10 ** 9, allow_raise=False):
     eos_id, pad_id = vocab - 1, vocab - 2
     model = ScriptedModel(vocab, seed, robust, prompt_len, eos_id=eos_id, eos_pos=eos_pos,
                           reserved=(pad_id,), period=period)
@@ -244,12 +244,21 @@ def run_mb_case(name, *, vocab, seed, robust, prompt_len, n, K, r, pool, lookahe
         fs.trace = _Trace()
         buf = io.StringIO()
         kv_before = cache.get_seq_length()
-        with contextlib.redirect_stdout(buf):
-            cache, first_correct, acc, iters = mb.jacobi_forward_greedy_multiblock(
-                fs, input_ids=torch.tensor([inp], dtype=torch.long), attention_mask=None,
-                past_key_values=cache, use_cache=True, prefill_phase=False, n_token_seq_len=n,
-                K=K, r=r, lookahead_start_ratio=lookahead, n_gram_pool_size=pool,
-                eos_token_id=eos_id, pad_token_id=pad_id, max_iteration_count=max_iter)
+        try:
+            with contextlib.redirect_stdout(buf):
+                cache, first_correct, acc, iters = mb.jacobi_forward_greedy_multiblock(
+                    fs, input_ids=torch.tensor([inp], dtype=torch.long), attention_mask=None,
+                    past_key_values=cache, use_cache=True, prefill_phase=False, n_token_seq_len=n,
+                    K=K, r=r, lookahead_start_ratio=lookahead, n_gram_pool_size=pool,
+                    eos_token_id=eos_id, pad_token_id=pad_id, max_iteration_count=max_iter)
+        except RuntimeError as e:
+            if not allow_raise:
+                raise
+            # the reference itself dies here (torch cannot broadcast the rows at MB:482): record where and how
+            calls.append(dict(input=inp, kv_len_before=kv_before, error=str(e), banners=banners_of(buf.getvalue()),
+                              forwards=fs.trace.forwards))
+            stop_reason = "reference_raised"
+            break
         ret = acc[0].tolist()
         generated += ret
         total_new += len(ret)
@@ -260,7 +269,7 @@ def run_mb_case(name, *, vocab, seed, robust, prompt_len, n, K, r, pool, lookahe
                           banners=banners_of(buf.getvalue()), forwards=fs.trace.forwards))
         ncall += 1
     new_tokens = total_new - 1  # DRV-MR:243 "subtract prefill"
-    total_iters = sum(c["iters"] for c in calls)
+    total_iters = sum(c.get("iters", 0) for c in calls)
     return dict(name=name, kind="mb",
                 params=dict(n=n, K=K, r=r, pool=pool, lookahead=lookahead, eos_id=eos_id, pad_id=pad_id,
                             max_iter=max_iter, max_calls=max_calls),
@@ -631,6 +640,25 @@ def main():
             prompt_len=rr.randint(4, 20), n=n, K=rr.choice([1, 2, 2, 3]), r=rr.choice([0.3, 0.5, 0.85]),
             pool=rr.choice([2, 4, 8]), period=rr.choice([0, 0, 4, 9]),
             eos_pos=rr.choice([None, None, rr.randint(4, 20) + rr.randint(0, 3 * n)]), max_calls=4)
+    # edge knobs (appended after the sweeps so earlier cases keep their indices)
+    add("n16_pool0_no_recycling", vocab=64, seed=43, robust=45, prompt_len=9, n=16, K=2, r=0.6, pool=0, period=5)
+    add("n64_K2_pool4_candidates", vocab=48, seed=44, robust=45, prompt_len=14, n=64, K=2, r=0.85, pool=4, period=7, max_calls=3)
+    add("n4_K2_tiny_block", vocab=64, seed=45, robust=60, prompt_len=5, n=4, K=2, r=0.5, pool=4, period=3)
+    add("n16_r100_spawn_when_full", vocab=64, seed=46, robust=70, prompt_len=8, n=16, K=2, r=1.0, pool=4)
+    add("n16_r005_spawn_at_once", vocab=64, seed=47, robust=70, prompt_len=8, n=16, K=2, r=0.05, pool=4, period=4)
+    add("n32_lookahead_one", vocab=48, seed=48, robust=40, prompt_len=10, n=32, K=2, r=0.6, pool=8, period=6, lookahead=1.0)
+    # configurations on which the reference itself raises (K >= 3: a pseudo block comes back with k candidate rows while the
+    # real-active draft has B not in {1, k} rows, MB:482)
+    raises = [run_mb_case("raise_n16_K3_r005", vocab=64, seed=47, robust=70, prompt_len=8, n=16, K=3, r=0.05, pool=4,
+                          period=4, allow_raise=True)]
+    for sd in range(60, 90):
+        if len(raises) >= 4:
+            break
+        c = run_mb_case(f"raise_scan_{sd}", vocab=48, seed=sd, robust=45, prompt_len=9, n=16, K=3, r=0.3, pool=8, period=5,
+                        allow_raise=True)
+        if c["summary"]["stop_reason"] == "reference_raised":
+            raises.append(c)
+    assert all(c["summary"]["stop_reason"] == "reference_raised" for c in raises)
     sbs = [
         run_sb_case("sb_n16", vocab=1000, seed=50, robust=70, prompt_len=12, n=16),
         run_sb_case("sb_n8_all_accept", vocab=64, seed=51, robust=100, prompt_len=5, n=8),
@@ -689,6 +717,7 @@ def main():
         print(f"wrote {p} ({p.stat().st_size / 1024:.1f} KiB)")
 
     dump("mb_cases.json", mbs)
+    dump("mb_raises.json", raises)
     dump("sb_cases.json", sbs)
     dump("jd_cases.json", jds)
     dump("jdn_cases.json", jdns)

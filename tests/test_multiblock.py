@@ -17,6 +17,7 @@ from .backends import device_for, use_backend
 from .conftest import load_golden
 
 MB = load_golden("mb_cases.json")
+MBR = load_golden("mb_raises.json")
 
 BACKENDS = [pytest.param("hostsim", id="hostsim"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
 
@@ -242,3 +243,27 @@ def test_pack_valid_index(backend):
                                       inputs[p], models[p].prompt(), n=n, K=2, r=0.5, n_gram_pool_size=4, eos_token_id=None,
                                       pad_token_id=0)
             assert res[p]["ret"] == st.ret and res[p]["iters"] == st.iters
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", MBR, ids=[c["name"] for c in MBR])
+def test_reference_crash_is_reproduced(case, backend):
+    """Where the reference itself raises (MB:482 cannot broadcast k candidate rows against B not in {1, k} draft rows), the
+    state machine reports JF_E_SHAPE -> RuntimeError with torch's message, in the same call and after the same forwards."""
+    with use_backend(backend):
+        dev = device_for(backend)
+        p = case["params"]
+        model = ScriptedModel.from_dict(case["model"])
+        batch = ops.MultiblockBatch(1, _params(p), dev)
+        kv = case["prefill"]["kv_tokens"]
+        for call in case["calls"]:
+            traces = [[]]
+            if "error" not in call:
+                r = run_calls(batch, [model], [kv], [call["input"]], dev, traces=traces)[0]
+                assert r["ret"] == call["ret"]
+                kv = r["kv_tokens"]
+                continue
+            with pytest.raises(RuntimeError) as ei:
+                run_calls(batch, [model], [kv], [call["input"]], dev, traces=traces)
+            assert call["error"] in str(ei.value)
+            assert [t["out"] for t in traces[0]] == [f["out"] for f in call["forwards"]]

@@ -12,6 +12,7 @@ MB = load_golden("mb_cases.json")
 SB = load_golden("sb_cases.json")
 JD = load_golden("jd_cases.json")
 JDN = load_golden("jdn_cases.json")
+MBR = load_golden("mb_raises.json")
 JDO = load_golden("jdo_cases.json")
 
 
@@ -109,6 +110,27 @@ def test_singleblock_calls(case):
         for a, b in zip(r["trace"], call["forwards"]):
             assert a["out"] == b["out"][0] and a["greedy"] == b["greedy"][0]
         kv = r["kv_tokens"]
+
+
+@pytest.mark.parametrize("case", MBR, ids=[c["name"] for c in MBR])
+def test_multiblock_reference_crash_is_restated(case):
+    """Configurations on which the reference raises (torch cannot broadcast the draft rows against the candidate rows at
+    MB:482): the oracle fails in the same call, after the same forwards, with torch's message."""
+    p = case["params"]
+    fwd = scripted_forward(ScriptedModel.from_dict(case["model"]))
+    ngram, kv = O.mb_prefill(fwd, case["prompt"], case["prefill"]["draft"])
+    kw = dict(n=p["n"], K=p["K"], r=p["r"], lookahead_start_ratio=p["lookahead"], n_gram_pool_size=p["pool"],
+              eos_token_id=p["eos_id"], pad_token_id=p["pad_id"], max_iteration_count=p["max_iter"])
+    for call in case["calls"]:
+        if "error" not in call:
+            st = O.mb_generation_call(fwd, call["input"], kv, **kw)
+            assert st.ret == call["ret"] and st.kv_tokens == call["kv_tokens"]
+            kv = st.kv_tokens
+            continue
+        with pytest.raises(RuntimeError) as ei:
+            O.mb_generation_call(fwd, call["input"], kv, **kw)
+        assert str(ei.value) == call["error"]
+        assert [t["out"] for t in ei.value.trace] == [f["out"] for f in call["forwards"]]
 
 
 # ----------------------------------------------------------------------------- engine greedy
