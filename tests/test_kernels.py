@@ -89,6 +89,32 @@ def test_argmax_vs_oracle(R, V, dtype):
 
 
 @GPU
+@pytest.mark.parametrize("seed", range(24))
+def test_argmax_randomized_shapes(seed):
+    """Random row counts, vocabulary sizes (aligned and not), row strides, dtypes and special values (NaN, +-inf, -0.0,
+    ties) against torch.argmax — covers the vector path, the scalar path, the NaN re-scan and both launch shapes."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    R = [1, 2, 3, 17, 64, 130, 257][ri(0, 6)]
+    V = [8, 1001, 4096, 32000, 50257, 151936, 152064][ri(0, 6)]
+    if R * V > 40_000_000:
+        R = max(1, 40_000_000 // V)
+    pad = [0, 0, 8, 3][ri(0, 3)]                              # row stride > V, possibly misaligned (scalar path)
+    dtype = [torch.float32, torch.bfloat16][seed % 2]
+    x = torch.randn(R, V + pad, generator=g)
+    if seed % 3 == 0:
+        x[:, :] = x[:, :].round()                              # many exact ties
+    for _ in range(ri(0, 6)):
+        r, c = ri(0, R - 1), ri(0, V - 1)
+        x[r, c] = [float("nan"), float("inf"), float("-inf"), -0.0, 0.0, 1e30][ri(0, 5)]
+    xd = x.to(dtype).cuda()
+    view = xd[:, :V]
+    got = ops.argmax_rows(view).cpu()
+    ref = torch.argmax(view.float().cpu(), dim=-1)
+    assert (got == ref).all(), (R, V, pad, dtype)
+
+
+@GPU
 def test_argmax_strided_rows_and_reuse_of_workspace():
     """logits[:, :-1] style views (row stride > V) and back-to-back launches on one workspace."""
     g = torch.Generator().manual_seed(5)

@@ -267,3 +267,33 @@ def test_reference_crash_is_reproduced(case, backend):
                 run_calls(batch, [model], [kv], [call["input"]], dev, traces=traces)
             assert call["error"] in str(ei.value)
             assert [t["out"] for t in traces[0]] == [f["out"] for f in call["forwards"]]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_block_list_capacity_is_an_error_not_a_corruption(backend):
+    """max_blocks caps the block LISTS (the reference's lists only grow, Q3/Q4): hitting the cap is JF_E_CAPACITY ->
+    RuntimeError reported through the descriptor; with the default capacity (1 + max_iteration_count entries) the same call
+    completes and matches the oracle."""
+    with use_backend(backend):
+        dev = device_for(backend)
+        V, n, K, r = 64, 8, 4, 0.25
+        m = ScriptedModel(V, 23, 80, 6, reserved=(V - 2,))
+        fwd = lambda kv_rows, rows: [m.greedy_rows(kv_rows[b], [rows[b]])[0] for b in range(len(rows))]
+        # try first-block guesses until one makes the block lists outgrow K = 4 (most do at r = 0.25)
+        found = None
+        for s in range(40):
+            g = np.random.default_rng(s)
+            inp = O.mb_prefill(fwd, m.prompt(), [int(x) for x in g.choice(m.prompt(), size=n)])[0]
+            kw = dict(n=n, K=K, r=r, n_gram_pool_size=4, eos_token_id=None, pad_token_id=V - 2)
+            st = O.mb_generation_call(fwd, inp, m.prompt(), **kw)
+            tight = ops.MultiblockParams(max_blocks=K, **kw)
+            try:
+                run_calls(ops.MultiblockBatch(1, tight, dev), [m], [m.prompt()], [inp], dev)
+            except RuntimeError as e:
+                assert "capacity" in str(e)
+                found = (inp, st)
+                break
+        assert found is not None, "no guess outgrew max_blocks = K"
+        inp, st = found
+        res = run_calls(ops.MultiblockBatch(1, ops.MultiblockParams(**kw), dev), [m], [m.prompt()], [inp], dev)[0]
+        assert res["ret"] == st.ret and res["iters"] == st.iters and res["kv_tokens"] == st.kv_tokens
