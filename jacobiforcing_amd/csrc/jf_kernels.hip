@@ -1,9 +1,11 @@
 // jf_kernels.hip — gfx950 (MI355X / CDNA4) kernels and the C ABI of include/jacobiforcing.h.
 //
-// Everything here is HBM/latency-bound integer and compare work: no MFMA.  The only kernel that
-// moves real bytes is argmax_partial (R*V*esize per launch); it streams 16 B per lane with four
-// loads in flight, reduces with wave shuffles + one LDS hop and publishes one 64-bit atomicMax per
-// (row, chunk).  The Jacobi state machine runs one 64-lane wavefront per prompt (jf_mb_core.h).
+// Everything here is HBM/latency-bound integer and compare work: no MFMA.  The kernels that move real bytes are the
+// vocabulary streams — argmax (jf_argmax_partial / jf_argmax_scatter: R*V*esize per launch, 16 B per lane per load, eight
+// loads in flight, one compare chain per 16-byte vector, wave shuffles, one 64-bit atomicMax per (row, chunk)) and its
+// softmax-gather sibling for the non-greedy verify (jf_rs_probs).  The Jacobi state machine runs one 64-lane wavefront per
+// prompt (jf_mb_core.h).  Sections: (a2) argmax, (a3) accept scan, (a1, a4-a12) multiblock state machine, (a18) KV
+// append / RoPE / SwiGLU, (a9/a10) KV commit, (a15) engine step, (a16) paged index fill, (a19) non-greedy + on-policy.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdarg.h>
