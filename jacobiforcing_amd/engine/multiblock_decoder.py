@@ -132,6 +132,9 @@ class MultiblockJacobiDecoder:
         else:
             row_cand = torch.full((R,), -1, dtype=torch.int32, device=dev)
         self.last_valid_rows = int((B * d[:, self._f["T"]]).sum())
+        if int(self.kv_len_host[B > 0].max()) + ids.shape[1] > self.max_seq_len:
+            raise RuntimeError(f"KV cache rows hold {self.max_seq_len} positions; a prompt at "
+                               f"{int(self.kv_len_host[B > 0].max())} cannot take {ids.shape[1]} more (raise max_seq_len)")
         prof = self.profiler
         kv_rows = self.cache.kv_len[row_prompt.long()]
         s_cur = int(self.kv_len_host[B > 0].max()) + ids.shape[1]
@@ -228,6 +231,8 @@ class MultiblockJacobiDecoder:
                         st.stop_reason = "max_new_tokens"
                     elif st.calls >= max_calls:
                         st.stop_reason = "max_calls"
+                    elif r["kv_len"] + self.params.n * (self.params.K + 1) + self.t_cap > self.max_seq_len:
+                        st.stop_reason = "max_seq_len"         # the next call could outgrow this prompt's cache row
                     if st.stop_reason is not None:
                         active[p] = False
                         restart[p] = N.JF_MB_INACTIVE

@@ -43,6 +43,9 @@ class Qwen2Backend:
         B, T = rows.shape
         dev = self.device
         kv = cache.length
+        if kv + T > self.max_seq_len or B > self.max_rows or T > self.max_tokens:
+            raise RuntimeError(f"forward of {B}x{T} tokens at position {kv} exceeds the static cache "
+                               f"(max_seq_len={self.max_seq_len}, max_rows={self.max_rows}, max_tokens={self.max_tokens})")
         pos = (kv + torch.arange(T, dtype=torch.int32, device=dev)).view(1, T).expand(B, T).contiguous()
         z = torch.zeros(B, dtype=torch.int32, device=dev)
         cand = torch.arange(-1, B - 1, dtype=torch.int32, device=dev)

@@ -198,6 +198,19 @@ def test_decoder_equals_autoregressive(backend):
             assert stats[p].token_ids == ar
 
 
+def test_stops_before_the_cache_row_is_full():
+    """A prompt whose next call could outgrow its static KV row stops with stop_reason "max_seq_len" (no write past the row)."""
+    with use_backend("hostsim"):
+        model = tiny_model("cpu", seed=2)
+        V = model.cfg.vocab_size
+        prm = ops.MultiblockParams(n=8, K=2, r=0.5, n_gram_pool_size=4, eos_token_id=None, pad_token_id=V - 2)
+        dec = MultiblockJacobiDecoder(model, 2, prm, max_seq_len=220)
+        stats, _, _ = dec.generate([[1, 2, 3, 4, 5], [7, 8, 9]], max_new_tokens=10_000, max_calls=10_000, seed=1)
+        assert [s.stop_reason for s in stats] == ["max_seq_len", "max_seq_len"]
+        assert all(int(k) + dec.t_cap <= 220 for k in dec.kv_len_host)
+        assert all(len(s.token_ids) > 20 for s in stats)
+
+
 def test_generate_stream_yields_calls_in_order():
     """Streaming counterpart (applications/jacobi_streaming_driver.py): chunks arrive per finished call and concatenate
     to exactly what generate() returns."""
