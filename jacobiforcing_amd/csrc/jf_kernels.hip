@@ -1178,152 +1178,17 @@ extern "C" int jf_rs_probs(const void *logits, int dtype, int64_t R, int64_t V, 
     return check_launch("rs_probs kernels");
 }
 
-// Sequential accept/reject over the rows of a batch (JDN:581-639) in ONE launch: rows are visited in order so the
-// injected uniform / bonus / pad streams are consumed exactly like the reference consumes torch.rand / multinomial /
-// randint; the only wide work — inverse-CDF sampling of the bonus token on a rejected position — uses all 256 threads.
-template <int DT>
-__global__ __launch_bounds__(256) void rs_step_kernel(const void *logits, int64_t V, int64_t row_stride, const int64_t *draft,
-                                                       int B, int L, const float *p_draft, const float *row_max,
-                                                       const float *row_sumexp, unsigned long long *packed, float temp,
-                                                       int eos_id, const int32_t *remaining, const float *u_stream,
-                                                       int64_t u_len, int64_t *u_cursor, const float *b_stream, int64_t b_len,
-                                                       int64_t *b_cursor, const int64_t *pad_stream, int64_t pad_len,
-                                                       int64_t *pad_cursor, int64_t *committed, int64_t *next_draft,
-                                                       jf_rs_row *rows) {
-    __shared__ int s_n, s_eos, s_rej, s_pick, s_used;
-    __shared__ double s_sum[256], s_pre[256];
-    __shared__ double s_total;
-    __shared__ uint64_t s_best[4];
-    __shared__ int64_t s_uc, s_bc, s_pc;
-    const int tid = threadIdx.x;
-    const float inv_t = 1.f / temp;      // same scaling as rs_probs_kernel (row_max / row_sumexp were computed with it)
-    if (tid == 0) { s_uc = *u_cursor; s_bc = *b_cursor; s_pc = *pad_cursor; }
-    __syncthreads();
-    for (int b = 0; b < B; ++b) {
-        const int64_t *d = draft + (int64_t)b * L;
-        int64_t *cm = committed + (int64_t)b * L;
-        const int64_t r0 = (int64_t)b * (L - 1);
-        if (tid == 0) {
-            int n = 0, eos = 0, rej = -1, used = 0;
-            for (int t = 0; t < L - 1; ++t) {                      // JDN:326-348
-                const int64_t proposed = d[t + 1];
-                const float u = u_stream[(s_uc + used) % u_len];
-                used++;
-                if (u < p_draft[r0 + t]) {
-                    cm[n++] = proposed;
-                    if (eos_id >= 0 && proposed == eos_id) { eos = 1; break; }
-                    continue;
-                }
-                rej = t;
-                break;
-            }
-            s_n = n; s_eos = eos; s_rej = rej; s_used = used;
-            s_uc += used;
-        }
-        __syncthreads();
-        const int rej = s_rej;
-        int draws = 0;
-        if (rej >= 0) {
-            // residual sampling (JDN:135-153): inverse CDF over p = exp(x/T - M)/S in vocabulary order with a float64
-            // running sum; each thread owns a contiguous slice, so the scan is two-level.
-            const void *row = (const char *)logits + (r0 + rej) * row_stride * (DT == JF_F32 ? 4 : 2);
-            const float M = row_max[r0 + rej], Sx = row_sumexp[r0 + rej];
-            const int64_t per = (V + 255) / 256;
-            const int64_t lo = (int64_t)tid * per < V ? (int64_t)tid * per : V;
-            const int64_t hi = (lo + per < V) ? lo + per : V;
-            double acc = 0.0;
-            for (int64_t i = lo; i < hi; ++i) acc += (double)(expf(load_f<DT>(row, i) * inv_t - M) / Sx);
-            s_sum[tid] = acc;
-            __syncthreads();
-            if (tid == 0) {
-                double run = 0.0;
-                for (int i = 0; i < 256; ++i) { s_pre[i] = run; run += s_sum[i]; }
-                s_total = run;
-            }
-            __syncthreads();
-            const int64_t proposed = d[rej + 1];
-            int bonus = -1;
-            for (int tr = 0; tr < 16 && bonus < 0; ++tr) {
-                const double thr = (double)b_stream[(s_bc + tr) % b_len] * s_total;
-                if (tid == 0) s_pick = (int)(V - 1);               // clamp when thr >= total
-                __syncthreads();
-                const double pre = s_pre[tid];
-                if (hi > lo && thr >= pre && thr < pre + acc) {    // exactly one slice owns thr
-                    double run = pre;
-                    int64_t pick = hi - 1;
-                    for (int64_t i = lo; i < hi; ++i) {
-                        run += (double)(expf(load_f<DT>(row, i) * inv_t - M) / Sx);
-                        if (run > thr) { pick = i; break; }
-                    }
-                    s_pick = (int)pick;
-                }
-                __syncthreads();
-                draws++;
-                if ((int64_t)s_pick != proposed) bonus = s_pick;
-                __syncthreads();
-            }
-            if (bonus < 0) {
-                // 16 collisions: argmax of p with the proposed id masked (JDN:147-153); all mass on it -> keep it
-                uint32_t best = 0u, bidx = 0xFFFFFFFFu;
-                for (int64_t i = tid; i < V; i += 256) {
-                    if (i == proposed) continue;
-                    const uint32_t k = load_key<DT>(row, i);
-                    if (k > best) { best = k; bidx = (uint32_t)i; }
-                }
-                uint64_t pk = wave_max_u64(((uint64_t)best << 32) | (uint64_t)(~bidx));
-                if ((tid & 63) == 0) s_best[tid >> 6] = pk;
-                __syncthreads();
-                uint64_t mm = s_best[0];
-                for (int w = 1; w < 4; ++w) mm = s_best[w] > mm ? s_best[w] : mm;
-                const int alt = jfmb::decode_packed(mm);
-                const float palt = (alt >= 0 && alt < V) ? expf(load_f<DT>(row, alt) * inv_t - M) / Sx : 0.f;
-                bonus = (palt > 0.f) ? alt : (int)proposed;
-                __syncthreads();
-            }
-            if (tid == 0) {
-                cm[s_n] = bonus;
-                s_n = s_n + 1;
-                if (eos_id >= 0 && bonus == eos_id) s_eos = 1;
-                s_bc += draws;
-            }
-            __syncthreads();
-        }
-        // next draft (JDN:444-466 / 619-638): seed + greedy fill from this forward + random pads
-        const int n_committed = s_n;
-        const int active_next = (!s_eos && n_committed < remaining[b]) ? 1 : 0;
-        int copy_len = 0, n_pads = 0;
-        if (active_next) {
-            int64_t *nd = next_draft + (int64_t)b * L;
-            const int acc_len = 1 + n_committed;
-            if (tid == 0) nd[0] = cm[n_committed - 1];
-            if (acc_len < L) {
-                const int off = acc_len > 1 ? acc_len - 1 : 1;
-                const int rem = (L - 1) - off;
-                copy_len = rem < L - 1 ? rem : L - 1;
-                for (int i = tid; i < copy_len; i += 256) nd[1 + i] = jfmb::decode_packed(packed[r0 + off + i]);
-            } else {
-                if (tid == 0) nd[1] = jfmb::decode_packed(packed[r0 + L - 2]);
-                copy_len = 1;
-            }
-            n_pads = L - 1 - copy_len;
-            for (int i = tid; i < n_pads; i += 256) nd[1 + copy_len + i] = pad_stream[(s_pc + i) % pad_len];
-        }
-        __syncthreads();
-        if (tid == 0) {
-            rows[b].n_committed = n_committed; rows[b].eos = s_eos; rows[b].reject_pos = rej; rows[b].n_bonus_draws = draws;
-            rows[b].n_uniforms = s_used; rows[b].n_pads = n_pads; rows[b].active_next = active_next; rows[b].rsv = 0;
-            s_pc += n_pads;
-        }
-        for (int64_t i = tid; i < L - 1; i += 256) packed[r0 + i] = 0ull;
-        __syncthreads();
-    }
-    if (tid == 0) { *u_cursor = s_uc; *b_cursor = s_bc; *pad_cursor = s_pc; }
-}
-
 // ------------------------------------------------------------------------------------------------
-// On-policy rollout step (JDO = inference_engine/engine/jacobi_decoding_nongreedy_on_policy.py): sequential accept /
-// reject of ONE sequence's proposed tokens with a stop-token SET (JDO:270-327), then a fresh sample of every not yet
-// accepted position from this forward's distribution (JDO:465-477) — one workgroup per re-drafted row.
+// Accept/reject of every row of a batch (JDN:581-639).  The reference visits the rows in order and draws torch.rand /
+// torch.multinomial / torch.randint as it goes, so the position of every draw in the injected streams depends on the rows
+// before it.  Three launches keep that order exact while the only wide work — the inverse-CDF draw of the bonus token on a
+// rejected position, two passes over V — runs one workgroup per row in parallel:
+//   rs_accept_kernel  (1 workgroup)  sequential accept scans from LDS-staged p_draft / uniforms: per row accepted count,
+//                                    rejected position, uniforms used; bonus draws are ASSUMED to take one draw per row
+//   rs_bonus_kernel   (B workgroups) the bonus draw of each rejected row at its assumed stream position
+//   rs_finish_kernel  (1 workgroup)  if some row needed more than one draw (its sample hit the proposed token) the rows
+//                                    after it are redone in order with the true positions (rare); EOS, next drafts, pads,
+//                                    cursors, packed re-zeroed
 // ------------------------------------------------------------------------------------------------
 template <int DT>
 __device__ __forceinline__ double rs_slice_sum(const void *row, int64_t lo, int64_t hi, float inv_t, float M, float Sx) {
@@ -1342,6 +1207,232 @@ __device__ __forceinline__ int64_t rs_slice_pick(const void *row, int64_t lo, in
     return hi - 1;
 }
 
+struct RsShared {
+    double sum[256], pre[256];
+    double total;
+    uint64_t best[4];
+    int pick;
+};
+
+// Residual sampling of one row by the whole workgroup (JDN:135-153 / JDO:157-168): inverse CDF over p = exp(x/T - M)/S in
+// vocabulary order with a float64 running sum (two-level: each thread owns a contiguous slice), up to 16 draws from
+// stream[(base + tr) % len] until the sample differs from `proposed`, then the argmax of the masked distribution.
+// Uniform control flow; returns the token, *draws = stream entries consumed.
+template <int DT>
+__device__ int rs_bonus_row(const void *row, int64_t V, float inv_t, float M, float Sx, int64_t proposed, const float *stream,
+                            int64_t stream_len, int64_t base, RsShared &sh, int *draws_out) {
+    const int tid = threadIdx.x;
+    const int64_t per = (V + 255) / 256;
+    const int64_t lo = (int64_t)tid * per < V ? (int64_t)tid * per : V;
+    const int64_t hi = (lo + per < V) ? lo + per : V;
+    const double acc = rs_slice_sum<DT>(row, lo, hi, inv_t, M, Sx);
+    sh.sum[tid] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double run = 0.0;
+        for (int i = 0; i < 256; ++i) { sh.pre[i] = run; run += sh.sum[i]; }
+        sh.total = run;
+    }
+    __syncthreads();
+    int bonus = -1, draws = 0;
+    for (int tr = 0; tr < 16 && bonus < 0; ++tr) {
+        const double thr = (double)stream[(base + tr) % stream_len] * sh.total;
+        if (tid == 0) sh.pick = (int)(V - 1);               // clamp when thr >= total
+        __syncthreads();
+        const double pre = sh.pre[tid];
+        if (hi > lo && thr >= pre && thr < pre + acc) sh.pick = (int)rs_slice_pick<DT>(row, lo, hi, inv_t, M, Sx, pre, thr);
+        __syncthreads();
+        draws++;
+        if ((int64_t)sh.pick != proposed) bonus = sh.pick;
+        __syncthreads();
+    }
+    if (bonus < 0) {
+        // 16 collisions: argmax of p with the proposed id masked (JDN:147-153); all mass on it -> keep it
+        uint32_t best = 0u, bidx = 0xFFFFFFFFu;
+        for (int64_t i = tid; i < V; i += 256) {
+            if (i == proposed) continue;
+            const uint32_t k = load_key<DT>(row, i);
+            if (k > best) { best = k; bidx = (uint32_t)i; }
+        }
+        const uint64_t pk = wave_max_u64(((uint64_t)best << 32) | (uint64_t)(~bidx));
+        if ((tid & 63) == 0) sh.best[tid >> 6] = pk;
+        __syncthreads();
+        uint64_t mm = sh.best[0];
+        for (int w = 1; w < 4; ++w) mm = sh.best[w] > mm ? sh.best[w] : mm;
+        const int alt = jfmb::decode_packed(mm);
+        const float palt = (alt >= 0 && alt < V) ? expf(load_f<DT>(row, alt) * inv_t - M) / Sx : 0.f;
+        bonus = (palt > 0.f) ? alt : (int)proposed;
+        __syncthreads();
+    }
+    *draws_out = draws;
+    return bonus;
+}
+
+constexpr int RS_STAGE = 8192;      // floats of p_draft / uniforms staged in LDS by the accept scan (B * (L-1) <= this, else global)
+
+__global__ __launch_bounds__(256) void rs_accept_kernel(const int64_t *draft, int B, int L, const float *p_draft, int eos_id,
+                                                         const float *u_stream, int64_t u_len, const int64_t *u_cursor,
+                                                         int64_t *committed, jf_rs_row *rows) {
+    __shared__ float s_p[RS_STAGE], s_u[RS_STAGE];
+    const int tid = threadIdx.x;
+    const int n = B * (L - 1);
+    const int64_t uc0 = *u_cursor;
+    const bool staged = n <= RS_STAGE;
+    if (staged) {
+        for (int i = tid; i < n; i += 256) { s_p[i] = p_draft[i]; s_u[i] = u_stream[(uc0 + i) % u_len]; }   // at most n uniforms are used
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    int used_total = 0, n_rej = 0;
+    for (int b = 0; b < B; ++b) {                                   // JDN:326-348, rows in order
+        const int64_t *d = draft + (int64_t)b * L;
+        int64_t *cm = committed + (int64_t)b * L;
+        const int r0 = b * (L - 1);
+        int nacc = 0, eos = 0, rej = -1, used = 0;
+        for (int t = 0; t < L - 1; ++t) {
+            const int64_t proposed = d[t + 1];
+            const float u = staged ? s_u[used_total + used] : u_stream[(uc0 + used_total + used) % u_len];
+            const float pd = staged ? s_p[r0 + t] : p_draft[r0 + t];
+            used++;
+            if (u < pd) {
+                cm[nacc++] = proposed;
+                if (eos_id >= 0 && proposed == eos_id) { eos = 1; break; }
+                continue;
+            }
+            rej = t;
+            break;
+        }
+        rows[b].n_committed = nacc; rows[b].eos = eos; rows[b].reject_pos = rej; rows[b].n_uniforms = used;
+        rows[b].n_bonus_draws = 0; rows[b].n_pads = 0; rows[b].active_next = 0;
+        rows[b].rsv = n_rej;                                        // bonus draws before this row if every draw is a single one
+        used_total += used;
+        if (rej >= 0) n_rej++;
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void rs_bonus_kernel(const void *logits, int64_t V, int64_t row_stride, const int64_t *draft, int L,
+                                                        const float *row_max, const float *row_sumexp, float temp,
+                                                        const float *b_stream, int64_t b_len, const int64_t *b_cursor,
+                                                        int64_t *committed, jf_rs_row *rows) {
+    __shared__ RsShared sh;
+    const int b = blockIdx.x;
+    const int rej = rows[b].reject_pos;
+    if (rej < 0) return;
+    const int64_t r = (int64_t)b * (L - 1) + rej;
+    const void *row = (const char *)logits + r * row_stride * (DT == JF_F32 ? 4 : 2);
+    int draws = 0;
+    const int bonus = rs_bonus_row<DT>(row, V, 1.f / temp, row_max[r], row_sumexp[r], draft[(int64_t)b * L + rej + 1], b_stream, b_len,
+                                       *b_cursor + rows[b].rsv, sh, &draws);
+    if (threadIdx.x == 0) {
+        committed[(int64_t)b * L + rows[b].n_committed] = bonus;
+        rows[b].n_bonus_draws = draws;
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void rs_finish_kernel(const void *logits, int64_t V, int64_t row_stride, const int64_t *draft,
+                                                         int B, int L, const float *row_max, const float *row_sumexp,
+                                                         unsigned long long *packed, float temp, int eos_id,
+                                                         const int32_t *remaining, int64_t *u_cursor, const float *b_stream,
+                                                         int64_t b_len, int64_t *b_cursor, const int64_t *pad_stream,
+                                                         int64_t pad_len, int64_t *pad_cursor, int64_t *committed,
+                                                         int64_t *next_draft, jf_rs_row *rows) {
+    __shared__ RsShared sh;
+    __shared__ int s_first_bad;
+    __shared__ int64_t s_bc, s_pc;
+    const int tid = threadIdx.x;
+    const int64_t bc0 = *b_cursor;
+    if (tid == 0) {
+        int fb = -1;
+        for (int b = 0; b < B && fb < 0; ++b)
+            if (rows[b].reject_pos >= 0 && rows[b].n_bonus_draws != 1) fb = b;
+        s_first_bad = fb;
+    }
+    __syncthreads();
+    // rows after the first one that needed more than one draw sampled at the wrong stream positions: redo them in order
+    if (s_first_bad >= 0) {
+        int64_t base = bc0 + rows[s_first_bad].rsv + rows[s_first_bad].n_bonus_draws;
+        for (int b = s_first_bad + 1; b < B; ++b) {
+            const int rej = rows[b].reject_pos;
+            if (rej < 0) continue;
+            const int64_t r = (int64_t)b * (L - 1) + rej;
+            const void *row = (const char *)logits + r * row_stride * (DT == JF_F32 ? 4 : 2);
+            int draws = 0;
+            const int bonus = rs_bonus_row<DT>(row, V, 1.f / temp, row_max[r], row_sumexp[r], draft[(int64_t)b * L + rej + 1], b_stream,
+                                               b_len, base, sh, &draws);
+            if (tid == 0) { committed[(int64_t)b * L + rows[b].n_committed] = bonus; rows[b].n_bonus_draws = draws; }
+            base += draws;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    // finalize: bonus joins the committed tokens, EOS, next draft (JDN:444-466 / 619-638), stream cursors
+    if (tid == 0) {
+        int64_t uc = *u_cursor, bc = bc0, pc = *pad_cursor;
+        for (int b = 0; b < B; ++b) {
+            jf_rs_row &rw = rows[b];
+            uc += rw.n_uniforms;
+            int n = rw.n_committed;
+            if (rw.reject_pos >= 0) {
+                bc += rw.n_bonus_draws;
+                if (eos_id >= 0 && committed[(int64_t)b * L + n] == eos_id) rw.eos = 1;
+                n += 1;
+            }
+            rw.n_committed = n;
+            rw.active_next = (!rw.eos && n < remaining[b]) ? 1 : 0;
+            int n_pads = 0;
+            if (rw.active_next) {
+                const int acc_len = 1 + n;
+                int copy_len = 1;
+                if (acc_len < L) {
+                    const int off = acc_len > 1 ? acc_len - 1 : 1;
+                    const int rem = (L - 1) - off;
+                    copy_len = rem < L - 1 ? rem : L - 1;
+                }
+                n_pads = L - 1 - copy_len;
+            }
+            rw.n_pads = n_pads;
+            rw.rsv = (int32_t)(pc - *pad_cursor);                    // this row's offset into the pad stream
+            pc += n_pads;
+        }
+        s_bc = bc; s_pc = pc;
+        *u_cursor = uc; *b_cursor = bc;
+    }
+    __syncthreads();
+    const int64_t pc0 = *pad_cursor;
+    for (int b = 0; b < B; ++b) {
+        const jf_rs_row rw = rows[b];
+        if (!rw.active_next) continue;
+        const int64_t r0 = (int64_t)b * (L - 1);
+        int64_t *nd = next_draft + (int64_t)b * L;
+        const int n = rw.n_committed, acc_len = 1 + n;
+        int copy_len;
+        if (tid == 0) nd[0] = committed[(int64_t)b * L + n - 1];
+        if (acc_len < L) {
+            const int off = acc_len > 1 ? acc_len - 1 : 1;
+            const int rem = (L - 1) - off;
+            copy_len = rem < L - 1 ? rem : L - 1;
+            for (int i = tid; i < copy_len; i += 256) nd[1 + i] = jfmb::decode_packed(packed[r0 + off + i]);
+        } else {
+            if (tid == 0) nd[1] = jfmb::decode_packed(packed[r0 + L - 2]);
+            copy_len = 1;
+        }
+        for (int i = tid; i < rw.n_pads; i += 256) nd[1 + copy_len + i] = pad_stream[(pc0 + rw.rsv + i) % pad_len];
+    }
+    __syncthreads();
+    for (int64_t i = tid; i < (int64_t)B * (L - 1); i += 256) packed[i] = 0ull;
+    if (tid == 0) {
+        *pad_cursor = s_pc;
+        for (int b = 0; b < B; ++b) rows[b].rsv = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// On-policy rollout step (JDO = inference_engine/engine/jacobi_decoding_nongreedy_on_policy.py): sequential accept /
+// reject of ONE sequence's proposed tokens with a stop-token SET (JDO:270-327), then a fresh sample of every not yet
+// accepted position from this forward's distribution (JDO:465-477) — one workgroup per re-drafted row.
+// ------------------------------------------------------------------------------------------------
 template <int DT>
 __global__ __launch_bounds__(256) void rs_onpolicy_verify_kernel(const void *logits, int64_t V, int64_t row_stride,
                                                                   const int64_t *proposed, int R, const float *p_draft,
@@ -1514,10 +1605,16 @@ extern "C" int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_
         return fail(JF_E_INVALID, "jf_rs_step: null pointer");
     if (u_len <= 0 || bonus_len <= 0 || pad_len <= 0) return fail(JF_E_INVALID, "jf_rs_step: empty random stream");
     const float t = (temperature <= 0.f) ? 1.f : temperature;
-    if (dtype == JF_F32)
-        rs_step_kernel<JF_F32><<<1, 256, 0, (hipStream_t)stream>>>(logits, V, row_stride, draft, B, L, p_draft, row_max, row_sumexp, (unsigned long long *)packed, t, eos_id, remaining, u_stream, u_len, u_cursor, bonus_stream, bonus_len, bonus_cursor, pad_stream, pad_len, pad_cursor, committed, next_draft, rows);
-    else if (dtype == JF_BF16)
-        rs_step_kernel<JF_BF16><<<1, 256, 0, (hipStream_t)stream>>>(logits, V, row_stride, draft, B, L, p_draft, row_max, row_sumexp, (unsigned long long *)packed, t, eos_id, remaining, u_stream, u_len, u_cursor, bonus_stream, bonus_len, bonus_cursor, pad_stream, pad_len, pad_cursor, committed, next_draft, rows);
-    else return fail(JF_E_INVALID, "jf_rs_step: dtype %d", dtype);
-    return check_launch("rs_step_kernel");
+    if (dtype != JF_F32 && dtype != JF_BF16) return fail(JF_E_INVALID, "jf_rs_step: dtype %d", dtype);
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long *pk = (unsigned long long *)packed;
+    rs_accept_kernel<<<1, 256, 0, s>>>(draft, B, L, p_draft, eos_id, u_stream, u_len, u_cursor, committed, rows);
+    if (dtype == JF_F32) {
+        rs_bonus_kernel<JF_F32><<<B, 256, 0, s>>>(logits, V, row_stride, draft, L, row_max, row_sumexp, t, bonus_stream, bonus_len, bonus_cursor, committed, rows);
+        rs_finish_kernel<JF_F32><<<1, 256, 0, s>>>(logits, V, row_stride, draft, B, L, row_max, row_sumexp, pk, t, eos_id, remaining, u_cursor, bonus_stream, bonus_len, bonus_cursor, pad_stream, pad_len, pad_cursor, committed, next_draft, rows);
+    } else {
+        rs_bonus_kernel<JF_BF16><<<B, 256, 0, s>>>(logits, V, row_stride, draft, L, row_max, row_sumexp, t, bonus_stream, bonus_len, bonus_cursor, committed, rows);
+        rs_finish_kernel<JF_BF16><<<1, 256, 0, s>>>(logits, V, row_stride, draft, B, L, row_max, row_sumexp, pk, t, eos_id, remaining, u_cursor, bonus_stream, bonus_len, bonus_cursor, pad_stream, pad_len, pad_cursor, committed, next_draft, rows);
+    }
+    return check_launch("rs_step kernels");
 }

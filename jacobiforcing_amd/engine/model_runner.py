@@ -113,7 +113,7 @@ class ModelRunner:
             seq.cache_row = -1
 
     def _forward_rows(self, seqs: List[Sequence], ids: torch.Tensor, starts: List[int], lens: List[int],
-                      logits_rows=None) -> torch.Tensor:
+                      logits_rows=None, logit_index=None) -> torch.Tensor:
         """Forward ``ids`` [B, T] where row b continues cache row seqs[b].cache_row from position starts[b]."""
         dev = self.device
         B, T = ids.shape
@@ -122,24 +122,47 @@ class ModelRunner:
         rp = torch.tensor([self._row(s) for s in seqs], dtype=torch.int32, device=dev)
         return self.model.forward(ids.to(dev), pos, self.kv_cache, row_prompt=rp, row_cand=torch.full((B,), -1, dtype=torch.int32, device=dev),
                                   row_len=torch.tensor(lens, dtype=torch.int32, device=dev), kv_len_rows=st,
-                                  any_candidates=False, logits_rows=logits_rows, s_cur=max(starts) + T)
+                                  any_candidates=False, logits_rows=logits_rows, s_cur=max(starts) + T, logit_index=logit_index)
+
+    def _prompt_forward(self, seqs: List[Sequence], rows: List[List[int]], want: List[range]) -> List[torch.Tensor]:
+        """Forward whole token rows from position 0 (prefill), several ragged rows per launch: rows are padded to the longest
+        of their group (a group holds at most JF_PREFILL_TOKENS padded tokens) and lm_head runs only on the positions in
+        ``want[i]``.  Returns the logits of those positions per row."""
+        budget = int(os.environ.get("JF_PREFILL_TOKENS", "16384"))
+        out: List[torch.Tensor] = [None] * len(rows)
+        i = 0
+        while i < len(rows):
+            j, tmax = i, 0
+            while j < len(rows) and (j == i or (j - i + 1) * max(tmax, len(rows[j])) <= budget):
+                tmax = max(tmax, len(rows[j]))
+                j += 1
+            if tmax > self.config.max_model_len:
+                raise RuntimeError(f"prompt + draft ({tmax}) exceeds max_model_len={self.config.max_model_len}")
+            ids = torch.zeros((j - i, tmax), dtype=torch.int64)
+            for r in range(i, j):
+                ids[r - i, :len(rows[r])] = torch.tensor(rows[r], dtype=torch.int64)
+            idx = torch.tensor([(r - i) * tmax + t for r in range(i, j) for t in want[r]], dtype=torch.int32, device=self.device)
+            logits = self._forward_rows(seqs[i:j], ids, [0] * (j - i), [len(rows[r]) for r in range(i, j)], logit_index=idx)
+            o = 0
+            for r in range(i, j):
+                out[r] = logits[o:o + len(want[r])]
+                o += len(want[r])
+            i = j
+        return out
 
     # ------------------------------------------------------------------------------------------ MR:777-963
     @torch.inference_mode()
     def _jacobi_prefill_with_drafting(self, seqs: List[Sequence]):
-        V = self.config.hf_config.vocab_size
+        rows, want = [], []
         for seq in seqs:
             sp = getattr(seq, "sampling_params", None)
             block_len = getattr(sp, "jacobi_block_len", 64) if sp else 64
-            prompt_len = len(seq)
             draft = [random.choice(seq.token_ids) for _ in range(block_len)]                  # MR:797
-            ids = torch.tensor([seq.token_ids + draft], dtype=torch.int64)
-            T = ids.shape[1]
-            if T > self.config.max_model_len:
-                raise RuntimeError(f"prompt + draft ({T}) exceeds max_model_len={self.config.max_model_len}")
-            logits = self._forward_rows([seq], ids, [0], [T], logits_rows=slice(prompt_len - 1, prompt_len + block_len - 1))
+            rows.append(seq.token_ids + draft)
+            want.append(range(len(seq) - 1, len(seq) + block_len - 1))
+        for seq, logits in zip(seqs, self._prompt_forward(seqs, rows, want)):
             seq._prefill_draft = ops.argmax_rows(logits).cpu().tolist()                        # MR:914-918
-            seq.num_cached_tokens = prompt_len                                                 # MR:929-947 (roll back)
+            seq.num_cached_tokens = len(seq)                                                   # MR:929-947 (roll back)
             seq.draft_tokens = None
         return [[] for _ in seqs]
 
@@ -246,19 +269,23 @@ class ModelRunner:
     # ------------------------------------------------------------------------------------------ autoregressive
     @torch.inference_mode()
     def _run_autoregressive(self, seqs: List[Sequence], is_prefill: bool):
-        toks = []
+        if is_prefill:                                          # ragged prompts, padded per group; last position's logits
+            logits = torch.cat(self._prompt_forward(seqs, [s.token_ids for s in seqs],
+                                                    [range(len(s) - 1, len(s)) for s in seqs]), 0)
+        else:                                                   # decode: the whole batch in one forward (one token per row)
+            ids = torch.tensor([[seq.last_token] for seq in seqs], dtype=torch.int64)
+            logits = self._forward_rows(seqs, ids, [len(seq) - 1 for seq in seqs], [1] * len(seqs))
         for seq in seqs:
-            if is_prefill:
-                ids = torch.tensor([seq.token_ids], dtype=torch.int64)
-                logits = self._forward_rows([seq], ids, [0], [len(seq)], logits_rows=slice(len(seq) - 1, len(seq)))
-            else:
-                ids = torch.tensor([[seq.last_token]], dtype=torch.int64)
-                logits = self._forward_rows([seq], ids, [len(seq) - 1], [1])
             seq.num_cached_tokens = len(seq)
-            if seq.temperature == 0.0:
-                toks.append(int(ops.argmax_rows(logits)[0]))
+        temps = [float(seq.temperature) for seq in seqs]
+        if all(t == 0.0 for t in temps):
+            return [int(t) for t in ops.argmax_rows(logits).cpu().tolist()]
+        toks = []
+        for i, t in enumerate(temps):
+            if t == 0.0:
+                toks.append(int(ops.argmax_rows(logits[i:i + 1])[0]))
             else:                                               # Gumbel-max sampling like layers/sampler.py:10-24
-                p = torch.softmax(logits.float() / seq.temperature, dim=-1)
+                p = torch.softmax(logits[i:i + 1].float() / t, dim=-1)
                 toks.append(int(torch.argmax(p / torch.empty_like(p).exponential_(1).clamp_min_(1e-10), dim=-1)[0]))
         return toks
 

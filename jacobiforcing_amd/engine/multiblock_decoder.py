@@ -14,6 +14,8 @@ machine and rolling call restarts (BASELINE config 4).
 """
 from __future__ import annotations
 
+import os
+
 import random
 import time
 from dataclasses import dataclass, field
@@ -89,22 +91,37 @@ class MultiblockJacobiDecoder:
         lm_head runs on the last n+1 positions only (the reference computes all S+n rows, MB:216)."""
         n = self.params.n
         dev = self.device
-        ngrams = []
-        for p, (prompt, draft) in enumerate(zip(prompts, drafts)):
-            ids = torch.tensor([list(prompt) + list(draft)], dtype=torch.int64, device=dev)
-            T = ids.shape[1]
-            if T > self.max_seq_len:
-                raise RuntimeError(f"prompt {p}: {T} tokens exceed max_seq_len={self.max_seq_len}")
-            pos = torch.arange(T, dtype=torch.int32, device=dev).view(1, T)
-            z = torch.zeros(1, dtype=torch.int32, device=dev)
-            logits = self.model.forward(ids, pos, self.cache, row_prompt=torch.full((1,), p, dtype=torch.int32, device=dev),
-                                        row_cand=torch.full((1,), -1, dtype=torch.int32, device=dev),
-                                        row_len=torch.full((1,), T, dtype=torch.int32, device=dev), kv_len_rows=z,
-                                        any_candidates=False, logits_rows=slice(T - n - 1, T - 1))
-            if self.logits_hook is not None:
-                logits = self.logits_hook(logits, self, prefill=(p, len(prompt)))
-            ngrams.append(ops.argmax_rows(logits).cpu().tolist())
-            self.kv_len_host[p] = len(prompt)
+        rows = [list(prompt) + list(draft) for prompt, draft in zip(prompts, drafts)]
+        for p, row in enumerate(rows):
+            if len(row) > self.max_seq_len:
+                raise RuntimeError(f"prompt {p}: {len(row)} tokens exceed max_seq_len={self.max_seq_len}")
+        ngrams: List[List[int]] = [None] * len(rows)
+        budget = int(os.environ.get("JF_PREFILL_TOKENS", "16384"))       # padded tokens per prefill forward
+        i = 0
+        while i < len(rows):                                             # ragged prompts, several per forward
+            j, tmax = i, 0
+            while j < len(rows) and (j == i or (j - i + 1) * max(tmax, len(rows[j])) <= budget):
+                tmax = max(tmax, len(rows[j]))
+                j += 1
+            G = j - i
+            ids = torch.zeros((G, tmax), dtype=torch.int64)
+            for r in range(i, j):
+                ids[r - i, :len(rows[r])] = torch.tensor(rows[r], dtype=torch.int64)
+            lens = torch.tensor([len(rows[r]) for r in range(i, j)], dtype=torch.int32, device=dev)
+            pos = torch.arange(tmax, dtype=torch.int32, device=dev).view(1, tmax).expand(G, tmax).contiguous()
+            idx = torch.tensor([(r - i) * tmax + t for r in range(i, j) for t in range(len(rows[r]) - n - 1, len(rows[r]) - 1)],
+                               dtype=torch.int32, device=dev)
+            logits = self.model.forward(ids.to(dev), pos, self.cache, row_prompt=torch.arange(i, j, dtype=torch.int32, device=dev),
+                                        row_cand=torch.full((G,), -1, dtype=torch.int32, device=dev), row_len=lens,
+                                        kv_len_rows=torch.zeros(G, dtype=torch.int32, device=dev), any_candidates=False,
+                                        logit_index=idx, s_cur=tmax)
+            for r in range(i, j):
+                lg = logits[(r - i) * n:(r - i + 1) * n]
+                if self.logits_hook is not None:
+                    lg = self.logits_hook(lg, self, prefill=(r, len(prompts[r])))
+                ngrams[r] = ops.argmax_rows(lg).cpu().tolist()
+                self.kv_len_host[r] = len(prompts[r])
+            i = j
         self.cache.kv_len.copy_(torch.from_numpy(self.kv_len_host.astype(np.int32)))
         return ngrams
 

@@ -362,3 +362,50 @@ def test_swiglu_matches_torch(dtype):
     ref = (torch.nn.functional.silu(a) * b)
     tol = dict(atol=1e-5, rtol=1e-5) if dtype == torch.float32 else dict(atol=2e-2, rtol=2e-2)
     assert torch.allclose(out.float(), ref, **tol)
+
+
+# ------------------------------------------------------------------------------------- non-greedy step at batch scale
+def _rs_case(B, L, V, seed, p_hit, u_value):
+    """Logits whose softmax puts ~p_hit on the proposed token of every position; uniforms pinned to u_value."""
+    g = torch.Generator().manual_seed(seed)
+    draft = torch.randint(0, V, (B, L), generator=g)
+    logits = torch.randn(B, L - 1, V, generator=g) * 0.3
+    boost = float(np.log(p_hit / (1 - p_hit) * (V - 1)))                 # logit gap that gives the proposed id mass ~p_hit
+    logits.scatter_(2, draft[:, 1:].unsqueeze(-1), boost)
+    n = 4 * B * L
+    unis = torch.full((n,), u_value)
+    bonus = torch.rand(n, generator=g)
+    pads = torch.randint(0, V, (n,), generator=g)
+    return draft, logits, unis, bonus, pads
+
+
+def _run_rs(backend, B, L, V, seed, p_hit, u_value, dtype):
+    with use_backend(backend):
+        dev = device_for(backend)
+        draft, logits, unis, bonus, pads = _rs_case(B, L, V, seed, p_hit, u_value)
+        st = ops.RsStepper(B, L, dev, pads, unis, bonus)
+        rows, toks, nd = st.step(draft.to(dev), logits.to(dtype).to(dev), 1.0, None, [L] * B, [3, 5, 7])
+        return rows.copy(), toks.copy(), nd.cpu().numpy().copy(), st.cursors.cpu().tolist()
+
+
+@GPU
+@pytest.mark.parametrize("p_hit,u_value", [(0.6, 0.95), (0.9, 0.95), (0.5, 0.3)], ids=["collisions", "many_collisions", "mixed"])
+def test_rs_step_batch_matches_sequential_reference(p_hit, u_value):
+    """jf_rs_step draws the bonus tokens of all rejected rows in parallel at ASSUMED stream positions and repairs the rows
+    behind a row that needed several draws (its sample hit the proposed id).  Forced rejections with a heavy proposed id make
+    such collisions frequent; results must equal the row-by-row restatement (JDN:581-639) incl. every stream cursor."""
+    B, L, V = 48, 9, 2000
+    a = _run_rs("hip", B, L, V, 11, p_hit, u_value, torch.float32)
+    b = _run_rs("hostsim", B, L, V, 11, p_hit, u_value, torch.float32)
+    f = N.RS_FIELDS.index
+    assert (a[0][:, f("reject_pos")] == b[0][:, f("reject_pos")]).all()
+    assert (a[0][:, f("n_bonus_draws")] == b[0][:, f("n_bonus_draws")]).all()
+    if p_hit >= 0.6:
+        assert (b[0][:, f("n_bonus_draws")] > 1).sum() >= 5          # the repair path really ran
+    assert (a[0] == b[0]).all()
+    for r in range(B):
+        n = int(b[0][r, f("n_committed")])
+        assert (a[1][r, :n] == b[1][r, :n]).all(), r
+        if b[0][r, f("active_next")]:
+            assert (a[2][r] == b[2][r]).all(), r
+    assert a[3] == b[3]
