@@ -1441,12 +1441,9 @@ __global__ __launch_bounds__(256) void rs_onpolicy_verify_kernel(const void *log
                                                                   int64_t u_len, int64_t *u_cursor, const float *m_stream,
                                                                   int64_t m_len, int64_t *m_cursor, int64_t *committed,
                                                                   jf_op_row *out) {
-    __shared__ int s_n, s_stop, s_rej, s_pick, s_used;
-    __shared__ double s_sum[256], s_pre[256];
-    __shared__ double s_total;
-    __shared__ uint64_t s_best[4];
+    __shared__ RsShared sh;
+    __shared__ int s_n, s_stop, s_rej, s_used;
     const int tid = threadIdx.x;
-    const float inv_t = 1.f / temp;
     const int64_t uc = *u_cursor, mc = *m_cursor;
     auto is_stop = [&](int64_t tok) { for (int k = 0; k < n_stop; ++k) if (tok == (int64_t)stop_ids[k]) return true; return false; };
     if (tid == 0) {
@@ -1470,49 +1467,8 @@ __global__ __launch_bounds__(256) void rs_onpolicy_verify_kernel(const void *log
     int draws = 0;
     if (rej >= 0) {                                                    // JDO:157-168 (bonus != proposed)
         const void *row = (const char *)logits + (int64_t)rej * row_stride * (DT == JF_F32 ? 4 : 2);
-        const float M = row_max[rej], Sx = row_sumexp[rej];
-        const int64_t per = (V + 255) / 256;
-        const int64_t lo = (int64_t)tid * per < V ? (int64_t)tid * per : V;
-        const int64_t hi = (lo + per < V) ? lo + per : V;
-        const double acc = rs_slice_sum<DT>(row, lo, hi, inv_t, M, Sx);
-        s_sum[tid] = acc;
-        __syncthreads();
-        if (tid == 0) {
-            double run = 0.0;
-            for (int i = 0; i < 256; ++i) { s_pre[i] = run; run += s_sum[i]; }
-            s_total = run;
-        }
-        __syncthreads();
-        const int64_t x = proposed[rej];
-        int bonus = -1;
-        for (int tr = 0; tr < 16 && bonus < 0; ++tr) {
-            const double thr = (double)m_stream[(mc + tr) % m_len] * s_total;
-            if (tid == 0) s_pick = (int)(V - 1);
-            __syncthreads();
-            const double pre = s_pre[tid];
-            if (hi > lo && thr >= pre && thr < pre + acc) s_pick = (int)rs_slice_pick<DT>(row, lo, hi, inv_t, M, Sx, pre, thr);
-            __syncthreads();
-            draws++;
-            if ((int64_t)s_pick != x) bonus = s_pick;
-            __syncthreads();
-        }
-        if (bonus < 0) {
-            uint32_t best = 0u, bidx = 0xFFFFFFFFu;
-            for (int64_t i = tid; i < V; i += 256) {
-                if (i == x) continue;
-                const uint32_t k = load_key<DT>(row, i);
-                if (k > best) { best = k; bidx = (uint32_t)i; }
-            }
-            uint64_t pk = wave_max_u64(((uint64_t)best << 32) | (uint64_t)(~bidx));
-            if ((tid & 63) == 0) s_best[tid >> 6] = pk;
-            __syncthreads();
-            uint64_t mm = s_best[0];
-            for (int w = 1; w < 4; ++w) mm = s_best[w] > mm ? s_best[w] : mm;
-            const int alt = jfmb::decode_packed(mm);
-            const float palt = (alt >= 0 && alt < V) ? expf(load_f<DT>(row, alt) * inv_t - M) / Sx : 0.f;
-            bonus = (palt > 0.f) ? alt : (int)x;
-            __syncthreads();
-        }
+        const int bonus = rs_bonus_row<DT>(row, V, 1.f / temp, row_max[rej], row_sumexp[rej], proposed[rej], m_stream, m_len, mc, sh,
+                                           &draws);
         if (tid == 0) {
             committed[s_n] = bonus;
             s_n = s_n + 1;
