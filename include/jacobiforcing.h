@@ -24,6 +24,9 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* the only symbols the shared library exports (it is built with -fvisibility=hidden) */
+#define JF_API __attribute__((visibility("default")))
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -40,8 +43,8 @@ enum {
 
 enum { JF_F32 = 0, JF_BF16 = 1 };
 
-int jf_version(void);
-const char *jf_last_error(void);
+JF_API int jf_version(void);
+JF_API const char *jf_last_error(void);
 
 /* ---------------------------------------------------------------------------------------------
  * (a2) block-local logits argmax.  Replaces torch.argmax(block_logits, dim=-1) at MB:476, SB:197,
@@ -55,7 +58,7 @@ const char *jf_last_error(void);
  *             is enough.
  * Algorithmic bytes: R*V*esize read (+ 8*R written).
  */
-int jf_argmax_partial(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride,
+JF_API int jf_argmax_partial(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride,
                       uint64_t *packed, void *stream);
 
 /* Same, for logits computed on a compacted list of positions: row i's result goes to
@@ -64,14 +67,14 @@ int jf_argmax_partial(const void *logits, int dtype, int64_t R, int64_t V, int64
  * (MB:463-476); with jf_mb_pack's valid_index only positions that carry a draft token are
  * computed, and jf_mb_step still finds them at (row_base + b) * Tpad + t.
  */
-int jf_argmax_scatter(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride,
+JF_API int jf_argmax_scatter(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride,
                       const int32_t *out_index, uint64_t *packed, void *stream);
 
 /* packed -> int64 token ids (and re-zero packed).  greedy [R] int64. */
-int jf_argmax_decode(uint64_t *packed, int64_t R, int64_t *greedy, void *stream);
+JF_API int jf_argmax_decode(uint64_t *packed, int64_t R, int64_t *greedy, void *stream);
 
 /* convenience: partial + decode.  */
-int jf_argmax_rows(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride,
+JF_API int jf_argmax_rows(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride,
                    uint64_t *packed, int64_t *greedy, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -80,7 +83,7 @@ int jf_argmax_rows(const void *logits, int dtype, int64_t R, int64_t V, int64_t 
  * draft  [draft_rows, L] int64 (draft_rows == 1 broadcasts, MB:482), greedy [B, >=L-1] int64 with
  * row stride greedy_stride.  accepted [B] int32, best_idx [1] int32 = first index of max (MB:489).
  */
-int jf_accept_lengths(const int64_t *draft, int draft_rows, const int64_t *greedy, int64_t greedy_stride,
+JF_API int jf_accept_lengths(const int64_t *draft, int draft_rows, const int64_t *greedy, int64_t greedy_stride,
                       int B, int L, int32_t *accepted, int32_t *best_idx, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -121,9 +124,9 @@ typedef struct jf_mb_desc {
     int32_t rsv0, rsv1;   /* on error: rsv0 = state-machine source line, rsv1 = (draft rows << 16) | candidate rows for JF_E_SHAPE */
 } jf_mb_desc;
 
-int64_t jf_mb_state_ints(const jf_mb_params *p); /* int32 elements per prompt state */
-int32_t jf_mb_max_rows(const jf_mb_params *p);   /* max B (candidate rows)          */
-int32_t jf_mb_max_tokens(const jf_mb_params *p); /* max T per row                   */
+JF_API int64_t jf_mb_state_ints(const jf_mb_params *p); /* int32 elements per prompt state */
+JF_API int32_t jf_mb_max_rows(const jf_mb_params *p);   /* max B (candidate rows)          */
+JF_API int32_t jf_mb_max_tokens(const jf_mb_params *p); /* max T per row                   */
 
 /* Start a generation call for P prompts (MB:230-262, then the first build_out_and_spans MB:317-377).
  * states      [P, state_ints] int32
@@ -135,7 +138,7 @@ int32_t jf_mb_max_tokens(const jf_mb_params *p); /* max T per row               
  */
 #define JF_MB_INACTIVE (-1)
 #define JF_MB_KEEP (-2)
-int jf_mb_begin(int32_t *states, int64_t state_ints, int P, const jf_mb_params *params,
+JF_API int jf_mb_begin(int32_t *states, int64_t state_ints, int P, const jf_mb_params *params,
                 const int64_t *input_ids, const int32_t *kv_len, jf_mb_desc *desc, void *stream);
 
 /* Emit the forward inputs for the current iteration (MB:417-436) in a row-padded layout:
@@ -148,7 +151,7 @@ int jf_mb_begin(int32_t *states, int64_t state_ints, int P, const jf_mb_params *
  *   up to a multiple of valid_align (>= 1) with -1 entries.  Its length is known on the host from
  *   the descriptors (sum of B*T).  Feed it to the lm_head gather and to jf_argmax_scatter.
  */
-int jf_mb_pack(int32_t *states, int64_t state_ints, int P, int32_t Tpad, int64_t pad_fill,
+JF_API int jf_mb_pack(int32_t *states, int64_t state_ints, int P, int32_t Tpad, int64_t pad_fill,
                int64_t *input_ids, int32_t *positions, int32_t *row_prompt, int32_t *row_len,
                int32_t *valid_index, int32_t valid_align, void *stream);
 
@@ -157,11 +160,11 @@ int jf_mb_pack(int32_t *states, int64_t state_ints, int P, int32_t Tpad, int64_t
  * accept, re-draft, pool + candidate build, KV bookkeeping, spawn, promote, early stop, then the
  * next build_out_and_spans.  packed is indexed (row_base[p] + b) * Tpad + t and is re-zeroed.
  */
-int jf_mb_step(int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len,
+JF_API int jf_mb_step(int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len,
                jf_mb_desc *desc, void *stream);
 
 /* Copy results of finished calls: ret [P, ret_cap] int64 (ret_len in desc). */
-int jf_mb_read_ret(const int32_t *states, int64_t state_ints, int P, int64_t *ret, int32_t ret_cap,
+JF_API int jf_mb_read_ret(const int32_t *states, int64_t state_ints, int P, int64_t *ret, int32_t ret_cap,
                    void *stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -172,7 +175,7 @@ int jf_mb_read_ret(const int32_t *states, int64_t state_ints, int P, int64_t *re
 /* scatter freshly computed K/V rows into cache slots: token i goes to slot[i] = row * S_max + position
  * (-1 = skip).  Sources are [N, H_kv, D] views whose token stride is k_tok_stride / v_tok_stride ELEMENTS (heads
  * and D contiguous), so K and V can be read straight out of a fused QKV projection without a copy. */
-int jf_kv_append(void *k_cache, void *v_cache, const void *k_new, const void *v_new,
+JF_API int jf_kv_append(void *k_cache, void *v_cache, const void *k_new, const void *v_new,
                  const int64_t *slot, int64_t N, int32_t H_kv, int32_t D, int64_t S_max,
                  int64_t k_tok_stride, int64_t v_tok_stride, int32_t elem_bytes, void *stream);
 
@@ -184,19 +187,19 @@ int jf_kv_append(void *k_cache, void *v_cache, const void *k_new, const void *v_
  *   K (rotated) and V rows are written to the main cache at slot_main[i] and, when cand caches are given, to the
  *   candidate scratch at slot_cand[i] (slot = row * S_max|T_max + position; -1 skips).
  * dtype JF_F32 or JF_BF16 for qkv / q_out / caches. */
-int jf_rope_kv_append(const void *qkv, int dtype, int64_t N, int32_t T, int32_t nq, int32_t nkv, int32_t D,
+JF_API int jf_rope_kv_append(const void *qkv, int dtype, int64_t N, int32_t T, int32_t nq, int32_t nkv, int32_t D,
                       const int32_t *positions, const float *cos_table, const float *sin_table, void *q_out,
                       void *k_cache, void *v_cache, const int64_t *slot_main, int64_t S_max,
                       void *k_cand, void *v_cand, const int64_t *slot_cand, int64_t T_max, void *stream);
 
 /* SwiGLU gate of the MLP in one pass: out[m, i] = silu(gu[m, i]) * gu[m, I + i] for the fused gate/up projection output
  * gu [M, 2*I] (row-major), out [M, I].  fp32 arithmetic, one rounding; dtype JF_F32 or JF_BF16. */
-int jf_swiglu(const void *gu, int dtype, int64_t M, int64_t I, void *out, void *stream);
+JF_API int jf_swiglu(const void *gu, int dtype, int64_t M, int64_t I, void *out, void *stream);
 
 /* commit accepted candidate rows: for prompt p copy desc[p].kv_copy_len token rows from the
  * candidate scratch cand[(p*cand_rows + kv_src_row-1), :, 0:len] to main[p, :, kv_copy_dst: +len],
  * for K and V of `layers` layers (pointer arrays live in device memory). */
-int jf_kv_commit(void *const *main_k, void *const *main_v, void *const *cand_k, void *const *cand_v,
+JF_API int jf_kv_commit(void *const *main_k, void *const *main_v, void *const *cand_k, void *const *cand_v,
                  int32_t layers, const jf_mb_desc *desc, int P, int32_t cand_rows, int32_t H_kv,
                  int32_t D, int64_t S_max, int64_t T_max, int32_t elem_bytes, void *stream);
 
@@ -216,7 +219,7 @@ typedef struct jf_engine_row {
     int32_t rsv[3];
 } jf_engine_row;
 
-int jf_engine_step(const int64_t *draft, int B, int L, uint64_t *packed, int32_t eos_id,
+JF_API int jf_engine_step(const int64_t *draft, int B, int L, uint64_t *packed, int32_t eos_id,
                    const int32_t *remaining_tokens /* [B] max_tokens - accepted so far */,
                    int64_t *new_tokens /* [B, L] */, int64_t *next_draft /* [B, L] */,
                    const int64_t *pad_stream, int64_t pad_stream_len, int64_t *pad_cursor,
@@ -232,7 +235,7 @@ int jf_engine_step(const int64_t *draft, int B, int L, uint64_t *packed, int32_t
  * block_tables [B, max_cols] int32, -1 = no block.  err (nullable, zero it first): first row + 1
  * with S < 1 or a position without a block (the reference raises ValueError / RuntimeError there).
  */
-int jf_engine_fill(const int64_t *draft, int B, int L, const int32_t *seq_len,
+JF_API int jf_engine_fill(const int64_t *draft, int B, int L, const int32_t *seq_len,
                    const int32_t *block_tables, int max_cols, int block_size, int64_t *input_ids,
                    int64_t *positions, int32_t *slot_mapping, int32_t *cu_seqlens_q,
                    int32_t *cu_seqlens_k, int32_t *cache_seqlens, int32_t *err, void *stream);
@@ -244,10 +247,10 @@ int jf_engine_fill(const int64_t *draft, int B, int L, const int32_t *seq_len,
  *   p_draft[r] = softmax(logits[r] / T)[draft_next[r]] in fp32 (JDN:65-70, 328), row max and sum-exp (for the
  *   residual sampling) and the packed argmax (next draft, JDN:446/619).  packed must be zero on entry.
  */
-int jf_rs_probs(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride,
+JF_API int jf_rs_probs(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride,
                 const int64_t *draft_next, float temperature, float *p_draft, float *row_max,
                 float *row_sumexp, uint64_t *packed, void *workspace, size_t workspace_bytes, void *stream);
-size_t jf_rs_workspace_bytes(int64_t R, int64_t V);   /* per-chunk (max, sum-exp) partials */
+JF_API size_t jf_rs_workspace_bytes(int64_t R, int64_t V);   /* per-chunk (max, sum-exp) partials */
 
 typedef struct jf_rs_row {
     int32_t n_committed;   /* tokens committed (accepted drafts + bonus), >= 1          */
@@ -269,7 +272,7 @@ typedef struct jf_rs_row {
  *   exactly where the reference calls torch.rand / torch.multinomial / torch.randint.
  *   committed [B, L], next_draft [B, L] (JDN:444-466), rows [B].  packed is re-zeroed.
  */
-int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_stride, const int64_t *draft, int B, int L,
+JF_API int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_stride, const int64_t *draft, int B, int L,
                const float *p_draft, const float *row_max, const float *row_sumexp, uint64_t *packed,
                float temperature, int32_t eos_id, const int32_t *remaining_tokens,
                const float *u_stream, int64_t u_len, int64_t *u_cursor,
@@ -300,7 +303,7 @@ typedef struct jf_op_row {
     int32_t redraft_base_hi;
 } jf_op_row;
 
-int jf_rs_onpolicy_step(const void *logits, int dtype, int64_t V, int64_t row_stride, const int64_t *proposed, int R,
+JF_API int jf_rs_onpolicy_step(const void *logits, int dtype, int64_t V, int64_t row_stride, const int64_t *proposed, int R,
                         const float *p_draft, const float *row_max, const float *row_sumexp, uint64_t *packed,
                         float temperature, const int32_t *stop_ids, int n_stop,
                         const float *u_stream, int64_t u_len, int64_t *u_cursor,

@@ -31,6 +31,7 @@ def test_library_exports_every_declared_symbol():
     out = subprocess.check_output(["nm", "-D", "--defined-only", str(lib_path)], text=True)
     exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
     assert declared <= exported, declared - exported
+    assert all(sym.startswith("jf_") for sym in exported), sorted(e for e in exported if not e.startswith("jf_"))[:5]
     raw = ctypes.CDLL(str(lib_path))   # loads without a GPU (no compute call here)
     for name in declared:
         assert hasattr(raw, name)
