@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 import torch
 
+from jacobiforcing_amd import _native as N
 from jacobiforcing_amd import ops
 from jacobiforcing_amd.engine.multiblock_decoder import MultiblockJacobiDecoder
 from jacobiforcing_amd.modeling.qwen2 import Qwen2Config, Qwen2Model, Qwen2Weights, StaticKVCache
@@ -164,10 +165,18 @@ def test_compacted_logits_equal_rectangular(backend):
         out = {}
         for compact in (False, True):
             dec = MultiblockJacobiDecoder(model, len(prompts), prm, max_seq_len=256, t_align=8, compact_logits=compact)
-            rows = []
-            stats, _, iters = dec.generate(prompts, max_new_tokens=40, max_calls=5, seed=5,
-                                           on_iteration=lambda i, d: rows.append((dec.last_logits_rows, dec.last_valid_rows)))
+            rows, accepted = [], np.zeros(len(prompts), dtype=np.int64)
+            acc_col = N.DESC_FIELDS.index("accepted")
+
+            def on_it(i, d):
+                rows.append((dec.last_logits_rows, dec.last_valid_rows))
+                accepted[:] += d[:, acc_col]
+            stats, _, iters = dec.generate(prompts, max_new_tokens=40, max_calls=5, seed=5, on_iteration=on_it)
             out[compact] = ([(s.token_ids, s.calls, s.total_iterations, s.stop_reason) for s in stats], iters, rows)
+            # the per-iteration `accepted` counter bench.py sums is the number of generated tokens (DRV-MR new_tokens); only an
+            # EOS that arrives as the "next token" is appended to ret without having been an accepted draft position (MB:599-614)
+            for a, s in zip(accepted.tolist(), stats):
+                assert a == len(s.token_ids) or (s.stop_reason == "eos" and a == len(s.token_ids) - 1)
         assert out[True][0] == out[False][0] and out[True][1] == out[False][1]
         for (lr_c, valid_c), (lr_r, valid_r) in zip(out[True][2], out[False][2]):
             assert valid_c == valid_r
