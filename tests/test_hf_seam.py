@@ -163,3 +163,25 @@ def test_stream_chat_driver(per_token, backend):
         assert text == "".join(f"<{t}>" for t in want)
         assert seen and seen[-1] == text and all(b.startswith(a) for a, b in zip(seen, seen[1:]))
         assert len(seen) == len(want) if per_token else len(seen) < len(want)
+
+
+# ------------------------------------------------------------------------------------- DRV-SB / AR baseline counterparts
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_single_block_driver_matches_ar_baseline(backend):
+    """drivers/sb_math500.decode_one (the reference MATH500 driver's loop over jacobi_forward_greedy) produces exactly the
+    greedy AR continuation that drivers/ar_baseline.generate_greedy decodes token by token from the same weights — the
+    reference's own correctness criterion — and its row follows the driver's conventions."""
+    from jacobiforcing_amd.drivers import ar_baseline, sb_math500
+    import random
+    with use_backend(backend):
+        dev = device_for(backend)
+        model = tiny_model(dev, seed=9)
+        prompt = [5, 17, 33, 2, 9, 41, 7]
+        me = types.SimpleNamespace(jf_backend=hf_seam.Qwen2Backend(model, max_seq_len=256, max_rows=1, max_tokens=64))
+        row, toks = sb_math500.decode_one(me, prompt, n=8, eos_id=None, alt_eos_id=None, max_new_tokens=40, max_calls=64,
+                                          rng=random.Random(0))
+        ar, _ = ar_baseline.generate_greedy(model, prompt, max_new_tokens=len(toks))
+        assert toks == ar
+        assert row["stop_reason"] == "max_new_tokens" and row["new_tokens"] == len(toks) - 1 and row["calls"] >= 2
+        assert row["total_iterations"] >= row["calls"] - 1 and row["prompt_tokens"] == len(prompt)
+        assert abs(row["avg_iter_per_token"] - row["total_iterations"] / row["new_tokens"]) < 1e-12
