@@ -369,7 +369,7 @@ class EngineStepper:
         argmax_partial(flat, self.packed)
         rem = torch.tensor(list(remaining), dtype=torch.int32)
         self.remaining[:B].copy_(rem, non_blocking=True)
-        nt = self.new_tokens[:B * L].view(-1)[:B * L].view(B, L) if False else self.new_tokens.view(-1)[:B * L].view(B, L)
+        nt = self.new_tokens.view(-1)[:B * L].view(B, L)
         nd = self.next_draft.view(-1)[:B * L].view(B, L)
         N.check(N.lib().jf_engine_step(_ptr(draft), B, L, _ptr(self.packed), -1 if eos_id is None else int(eos_id),
                                        _ptr(self.remaining), _ptr(nt), _ptr(nd), _ptr(self.pad_stream),

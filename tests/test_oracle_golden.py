@@ -27,7 +27,7 @@ def test_argmax_semantics(kernel_vectors):
     for case in kernel_vectors["argmax"]:
         bits = np.array(case["bits"], dtype=np.int64)
         if case["dtype"] == "float32":
-            x = bits.astype(np.uint32).view(np.float32) if False else (bits & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
+            x = (bits & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
         else:
             x = O.bf16_bits_to_f32((bits & 0xFFFF).astype(np.uint16))
         assert O.argmax_rows(x).tolist() == case["argmax"]
