@@ -12,8 +12,6 @@ from __future__ import annotations
 import argparse
 import csv
 import json
-import os
-import sys
 from pathlib import Path
 
 import torch

@@ -16,10 +16,9 @@ inference_engine/models/qwen3.py:185-215) but shares no code with it.
 from __future__ import annotations
 
 import json
-import math
 from dataclasses import dataclass
 from pathlib import Path
-from typing import List, Optional
+from typing import Optional
 
 import torch
 import torch.nn.functional as F
