@@ -11,7 +11,7 @@ from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "lib" / "libjacobiforcing.so"
-SRC_PATH = _PKG / "csrc" / "jf_kernels.hip"
+SRC_DIR = _PKG / "csrc"
 INCLUDE_DIR = _PKG.parent / "include"
 
 JF_OK, JF_E_INVALID, JF_E_CAPACITY, JF_E_LAUNCH, JF_E_SHAPE = 0, -1, -2, -3, -4

@@ -1,0 +1,117 @@
+// jf_engine.hip — (a15) the engine decoder's single-block step and (a16) the paged-KV index fill of its caller.
+#include "jf_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// engine single-block step: 4 wavefronts take the rows round-robin, then one pass hands out pads
+// ------------------------------------------------------------------------------------------------
+struct WaveLanes {   // one wavefront inside a 256-thread workgroup; no workgroup barrier inside a row
+    __device__ __forceinline__ int lane() const { return threadIdx.x & 63; }
+    __device__ __forceinline__ int count() const { return 64; }
+    __device__ __forceinline__ void sync() const {}
+    __device__ __forceinline__ int reduce_min(int v) const { return wave_min_i32(v); }
+    __device__ __forceinline__ int reduce_sum(int v) const { return wave_sum_i32(v); }
+};
+
+__global__ __launch_bounds__(256) void engine_step_kernel(const int64_t *draft, int B, int L, unsigned long long *packed,
+                                                           int eos_id, const int32_t *remaining, int64_t *new_tokens,
+                                                           int64_t *next_draft, const int64_t *pad_stream, int64_t pad_len,
+                                                           int64_t *pad_cursor, jf_engine_row *rows) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int b = wave; b < B; b += 4) {
+        const unsigned long long *pk = packed + (int64_t)b * (L - 1);
+        auto G = [pk](int i) { return jfmb::decode_packed(pk[i]); };
+        jfmb::EngineRowOut o = jfmb::engine_row_body(WaveLanes{}, draft + (int64_t)b * L, L, G, eos_id, remaining[b],
+                                                     new_tokens + (int64_t)b * L, next_draft + (int64_t)b * L);
+        if (lane == 0) {
+            rows[b].acc_len = o.acc_len; rows[b].n_new = o.n_new; rows[b].eos = o.eos; rows[b].active_next = o.active_next;
+            rows[b].n_pads = o.active_next ? (L - 1 - o.copy_len) : 0;
+            rows[b].rsv[0] = o.copy_len;
+        }
+    }
+    __syncthreads();
+    // pads in row order (JD:705-707 consumes torch.randint sequentially): exclusive scan over rows
+    __shared__ int64_t s_base;
+    if (threadIdx.x == 0) s_base = *pad_cursor;
+    __syncthreads();
+    int64_t run = s_base;
+    for (int b = 0; b < B; ++b) {
+        const int np = rows[b].n_pads, cl = rows[b].rsv[0];
+        for (int i = threadIdx.x; i < np; i += blockDim.x) {
+            const int64_t k = run + i;
+            next_draft[(int64_t)b * L + 1 + cl + i] = pad_stream[pad_len > 0 ? (k % pad_len) : 0];
+        }
+        run += np;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *pad_cursor = run;
+    for (int64_t i = threadIdx.x; i < (int64_t)B * (L - 1); i += blockDim.x) packed[i] = 0ull;
+}
+
+extern "C" int jf_engine_step(const int64_t *draft, int B, int L, uint64_t *packed, int32_t eos_id, const int32_t *remaining_tokens,
+                              int64_t *new_tokens, int64_t *next_draft, const int64_t *pad_stream, int64_t pad_stream_len,
+                              int64_t *pad_cursor, jf_engine_row *rows, void *stream) {
+    if (B <= 0) return JF_OK;
+    if (L < 2) return fail(JF_E_INVALID, "Draft must have at least 2 tokens (seed + 1 speculative)");   // MR:1144-1145
+    if (!draft || !packed || !remaining_tokens || !new_tokens || !next_draft || !pad_cursor || !rows || (!pad_stream && pad_stream_len > 0))
+        return fail(JF_E_INVALID, "jf_engine_step: null pointer");
+    engine_step_kernel<<<1, 256, 0, (hipStream_t)stream>>>(draft, B, L, (unsigned long long *)packed, eos_id, remaining_tokens,
+                                                        new_tokens, next_draft, pad_stream, pad_stream_len, pad_cursor, rows);
+    return check_launch("engine_step_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// (a16) paged-KV caller side: every index buffer of one batched Jacobi forward in one launch (MR:1204-1265)
+// ------------------------------------------------------------------------------------------------
+// One wavefront per sequence.  err (nullable) gets the first failing row + 1: S < 1 (MR:1222-1223) or a position whose
+// block is beyond the table / unallocated (MR:1240-1247).
+__global__ __launch_bounds__(64) void engine_fill_kernel(const int64_t *__restrict__ draft, int B, int L,
+                                                          const int32_t *__restrict__ seq_len,
+                                                          const int32_t *__restrict__ block_tables, int max_cols, int block_size,
+                                                          int64_t *__restrict__ input_ids, int64_t *__restrict__ positions,
+                                                          int32_t *__restrict__ slot_mapping, int32_t *__restrict__ cu_q,
+                                                          int32_t *__restrict__ cu_k, int32_t *__restrict__ cache_seqlens,
+                                                          int32_t *__restrict__ err) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const int S = seq_len[i];
+    // cu_seqlens_k[i+1] = sum_{q<=i} (S_q - 1 + L)
+    int part = 0;
+    for (int q = lane; q <= i; q += 64) part += seq_len[q] - 1 + L;
+    part = wave_sum_i32(part);
+    if (lane == 0) {
+        if (i == 0) { cu_q[0] = 0; cu_k[0] = 0; }
+        cu_q[i + 1] = (i + 1) * L;
+        cu_k[i + 1] = part;
+        cache_seqlens[i] = S - 1;
+    }
+    bool bad = S < 1;
+    const int32_t *bt = block_tables + (int64_t)i * max_cols;
+    for (int j = lane; j < L; j += 64) {
+        const int64_t o = (int64_t)i * L + j;
+        const int pos = S - 1 + j;
+        input_ids[o] = draft[o];
+        positions[o] = pos;
+        int slot = -1;
+        if (pos >= 0) {
+            const int blk = pos / block_size, off = pos - blk * block_size;
+            const int id = blk < max_cols ? bt[blk] : -1;
+            if (id >= 0) slot = id * block_size + off; else bad = true;
+        }
+        slot_mapping[o] = slot;
+    }
+    if (err && __ballot(bad) != 0ull && lane == 0) atomicCAS(err, 0, i + 1);
+}
+
+extern "C" int jf_engine_fill(const int64_t *draft, int B, int L, const int32_t *seq_len, const int32_t *block_tables,
+                              int max_cols, int block_size, int64_t *input_ids, int64_t *positions, int32_t *slot_mapping,
+                              int32_t *cu_seqlens_q, int32_t *cu_seqlens_k, int32_t *cache_seqlens, int32_t *err, void *stream) {
+    if (B <= 0) return JF_OK;
+    if (L < 2) return fail(JF_E_INVALID, "Draft must have at least 2 tokens (seed + 1 speculative)");   // MR:1144-1145
+    if (!draft || !seq_len || !block_tables || !input_ids || !positions || !slot_mapping || !cu_seqlens_q || !cu_seqlens_k ||
+        !cache_seqlens)
+        return fail(JF_E_INVALID, "jf_engine_fill: null pointer");
+    if (max_cols <= 0 || block_size <= 0) return fail(JF_E_INVALID, "jf_engine_fill: max_cols=%d block_size=%d", max_cols, block_size);
+    engine_fill_kernel<<<B, 64, 0, (hipStream_t)stream>>>(draft, B, L, seq_len, block_tables, max_cols, block_size, input_ids,
+                                                         positions, slot_mapping, cu_seqlens_q, cu_seqlens_k, cache_seqlens, err);
+    return check_launch("engine_fill_kernel");
+}
+

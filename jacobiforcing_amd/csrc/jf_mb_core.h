@@ -1,7 +1,7 @@
 // jf_mb_core.h — the multiblock Jacobi state machine (one generation call of the reference's
 // jacobi_forward_greedy_multiblock, MB:227-740), written once against a small "lanes" policy:
 //
-//   * DevLanes  (jf_kernels.hip): one 64-lane wavefront per prompt; token rows are compared,
+//   * DevLanes  (jf_common.h): one 64-lane wavefront per prompt; token rows are compared,
 //     searched and copied 64 tokens per instruction, reductions are wave shuffles.
 //   * a single-lane policy used ONLY by tests/hostsim (CPU CI of this logic; never shipped).
 //

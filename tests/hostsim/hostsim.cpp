@@ -3,7 +3,7 @@
 // Compiles the device state-machine source (jacobiforcing_amd/csrc/jf_mb_core.h) with a
 // single-lane policy so its control logic can be checked against the golden vectors on a
 // machine without a GPU.  On the GPU box the same source runs as one wavefront per prompt
-// (jf_kernels.hip) and is checked again through the C ABI by the `-m gpu` tests.
+// (jf_multiblock.hip) and is checked again through the C ABI by the `-m gpu` tests.
 #include <stdint.h>
 #include <string.h>
 

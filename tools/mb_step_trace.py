@@ -2,7 +2,8 @@
 
 Runs the bench workload (random-init Qwen2.5-Coder-7B shape, 8 prompts) for a few iterations and after each one reads
 prompt 0's shader-clock stamps (100 MHz s_memrealtime) back, printing the mean time between consecutive phases.
-    hipcc ... -DJF_EXP_MB_TRACE -o jacobiforcing_amd/lib/libjf_exp_trace.so
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DJF_EXP_MB_TRACE -Iinclude -Ijacobiforcing_amd/csrc \
+          jacobiforcing_amd/csrc/*.hip -o jacobiforcing_amd/lib/libjf_exp_trace.so
     JF_LIB=$PWD/jacobiforcing_amd/lib/libjf_exp_trace.so python tools/mb_step_trace.py
 """
 import ctypes
