@@ -39,6 +39,19 @@ def test_library_exports_every_declared_symbol():
     assert raw.jf_version() == 100
 
 
+def test_plain_c_client(tmp_path):
+    """The boundary is a C ABI: a C99 program including include/jacobiforcing.h compiles with gcc, links against the shared
+    library and gets answers (sizes, argument validation with jf_last_error) without a GPU."""
+    import __graft_entry__ as G
+    lib = G.build_hip()
+    exe = tmp_path / "abi_client"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(ROOT / "tests" / "abi" / "abi_client.c"),
+                           f"-L{lib.parent}", "-ljacobiforcing", f"-Wl,-rpath,{lib.parent}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True)
+    assert "version=100" in out and "desc=64" in out and "params=40" in out
+    assert "rc=-1" in out and "null pointer" in out
+
+
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(N.NativeLibraryError):
         N.load(tmp_path / "nope.so")
