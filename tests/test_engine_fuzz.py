@@ -35,8 +35,13 @@ def _setup(seed):
     return rng, V, robust, max_iters, items
 
 
-@pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("seed", range(40))
+def _cases(n_both, n_total):
+    """seeds below n_both run on both backends; the rest only through the real kernels (the CPU suite stays short)"""
+    return [pytest.param(seed, b, id=f"{b}-{seed}", marks=[pytest.mark.gpu] if b == "hip" else [])
+            for seed in range(n_total) for b in (("hostsim", "hip") if seed < n_both else ("hip",))]
+
+
+@pytest.mark.parametrize("seed,backend", _cases(40, 120))
 def test_engine_greedy_fuzz(seed, backend):
     rng, V, robust, max_iters, items = _setup(seed)
     eos, pad = V - 1, V - 2
@@ -77,8 +82,7 @@ def test_engine_greedy_fuzz(seed, backend):
             assert len(s.block_table) == o.num_table_blocks
 
 
-@pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed,backend", _cases(24, 72))
 def test_engine_nongreedy_fuzz(seed, backend):
     """Same sweep for rejection sampling.  The oracle and the kernels share the injected streams; probabilities differ only
     in fp32 rounding, so a decision can flip only when a uniform lands within ~1e-6 of p — none does for these seeds."""

@@ -14,8 +14,12 @@ from .test_multiblock import run_calls
 BACKENDS = [pytest.param("hostsim", id="hostsim"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
 
 
-@pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("seed", range(120))
+# seeds 0..119 run on both backends; 120..359 only through the real kernels (the CPU suite stays short)
+CASES = [pytest.param(seed, b, id=f"{b}-{seed}", marks=[pytest.mark.gpu] if b == "hip" else [])
+         for seed in range(360) for b in (("hostsim", "hip") if seed < 120 else ("hip",))]
+
+
+@pytest.mark.parametrize("seed,backend", CASES)
 def test_fuzz_vs_oracle(seed, backend):
     rng = np.random.default_rng(10_000 + seed)
     n = int(rng.choice([4, 8, 12, 16, 24, 32, 48, 64]))

@@ -12,7 +12,7 @@ from jacobiforcing_amd.modeling.qwen2 import Qwen2Config, Qwen2Model, Qwen2Weigh
 dev = torch.device("cuda")
 cfg = Qwen2Config.qwen2_5_coder_7b()
 model = Qwen2Model(cfg, Qwen2Weights(cfg, dev, seed=0))
-P = 8
+P = int(__import__("os").environ.get("PROBE_P", "8"))
 cache = StaticKVCache(cfg, P, 4096, 0, 1, dev)
 
 
