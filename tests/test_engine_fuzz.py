@@ -6,6 +6,7 @@ import torch
 
 from jacobiforcing_amd.engine.jacobi_decoding import JacobiDecoder
 from jacobiforcing_amd.engine.jacobi_decoding_nongreedy import JacobiDecoderNonGreedy
+from jacobiforcing_amd.engine.jacobi_decoding_nongreedy_on_policy import JacobiDecoderNonGreedyOnPolicy
 from jacobiforcing_amd.sampling_params import SamplingParams
 from oracle import jacobi_oracle as O
 from oracle.scripted_model import ScriptedModel
@@ -130,3 +131,54 @@ def test_engine_nongreedy_fuzz(seed, backend):
         assert got == want
         assert dec.stats == stats
         assert dec._cur == [cur["u"], cur["b"], cur["p"]]
+
+
+@pytest.mark.parametrize("seed,backend", _cases(16, 64))
+def test_engine_onpolicy_fuzz(seed, backend):
+    """Rollout records (JDO) over random batch sizes, block lengths, budgets, stop positions, one or two stop ids and
+    temperatures: the HIP decoder vs the oracle's restatement with the same injected draws — records, metrics, final token
+    lists and the number of draws consumed from every stream."""
+    rng, V, robust, _, items = _setup(2000 + seed)
+    eos, pad = V - 1, V - 2
+    stop_ids = [eos] if rng.random() < 0.6 else [eos, int(rng.integers(0, V - 2))]
+    temperature = float(rng.choice([1.0, 0.7, 0.4, 1.5]))
+    max_blocks = int(rng.choice([128, 128, 2, 1]))
+    unis = [float(x) for x in (rng.integers(0, 1 << 24, size=8192) / float(1 << 24))]
+    multi = [float(x) for x in (rng.integers(0, 1 << 24, size=8192) / float(1 << 24))]
+    L = max(items[0]["L"], 2)
+    with use_backend(backend):
+        dev = device_for(backend)
+        H = Harness(V, dev, torch.float32)
+        dec = JacobiDecoderNonGreedyOnPolicy(H.bm, forward_step=lambda s, d: H.forward_step_batch([s], d),
+                                             eos_token_id=stop_ids if len(stop_ids) > 1 else eos, pad_token_id=pad, vocab_size=V,
+                                             device=torch.device(dev))
+        a, b = O.CounterStream(5000 + seed), O.CounterStream(5000 + seed)
+        dec.set_streams(O.ScriptedRandom(a), unis, multi)
+        seqs, oseqs, models = [], [], []
+        for it in items:
+            m = ScriptedModel(V, it["seed"], robust, it["pl"], eos_id=eos, eos_pos=it["eos_pos"], reserved=(pad,))
+            sp = SamplingParams(temperature=temperature, max_tokens=it["mt"], decode_strategy="jacobi", jacobi_block_len=L,
+                                jacobi_max_iterations=max_blocks, jacobi_on_policy=True)
+            seqs.append(H.add(m, sp, None))
+            oseqs.append(O.OracleSeq(m.prompt(), L, it["mt"], max_iters=max_blocks))
+            models.append(m)
+        by = {id(s): m for s, m in zip(oseqs, models)}
+        cur = {"u": 0, "m": 0}
+
+        def take(name, arr):
+            def f():
+                v = arr[cur[name] % len(arr)]
+                cur[name] += 1
+                return v
+            return f
+
+        def ofwd(ss, drafts):
+            return [by[id(s)].logits_rows(s.token_ids[:-1], [d])[0][:-1] for s, d in zip(ss, drafts)]
+        want, wmet = O.onpolicy_rollout_records_batch(ofwd, oseqs, temperature, stop_ids, pad, V, O.ScriptedRandom(b),
+                                                      take("u", unis), take("m", multi))
+        got, gmet = dec.generate_rollout_records_batch(seqs, return_metrics=True)
+        assert got == want
+        assert gmet == wmet
+        assert dec._cur == [cur["u"], cur["m"]] and a.k == b.k
+        for s, o in zip(seqs, oseqs):
+            assert s.token_ids == o.token_ids and s.num_cached_tokens == o.num_cached_tokens
