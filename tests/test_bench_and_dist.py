@@ -61,6 +61,32 @@ def test_scripted_acceptance_raises_tokens_per_forward():
         assert tpf > 2.0
 
 
+@pytest.mark.gpu
+def test_full_vocabulary_batch_decodes_the_planted_sequence():
+    """BASELINE sizes end to end through the real kernels: 16 prompts side by side, n=32 K=2 r=0.85 pool=4, the full
+    152 064-entry vocabulary in bf16 (hundreds of logits rows per launch: the wavefront launch shape of the argmax), candidate
+    rows, KV commits.  Size-independent property instead of a CPU pass: with the planted acceptance model the decoded tokens
+    of every prompt ARE the planted target sequence (greedy Jacobi == greedy AR of the same logits) and several tokens are
+    accepted per forward."""
+    from jacobiforcing_amd.modeling.qwen2 import Qwen2Config, Qwen2Model, Qwen2Weights
+    dev = torch.device("cuda")
+    V = 152064
+    cfg = Qwen2Config.tiny(vocab_size=V, hidden_size=128, layers=2, heads=4, kv_heads=2, head_dim=32, inter=256)
+    model = Qwen2Model(cfg, Qwen2Weights(cfg, dev, dtype=torch.bfloat16, seed=1, init_std=0.05))
+    prm = ops.MultiblockParams(n=32, K=2, r=0.85, n_gram_pool_size=4, eos_token_id=None, pad_token_id=151643)
+    prompts = humaneval_shaped_prompts(16, seed=77, vocab_hi=151643)
+    hook = ScriptedAcceptance(V, robust_pct=82, vocab_hi=151643)
+    dec = MultiblockJacobiDecoder(model, len(prompts), prm, max_seq_len=1024, logits_hook=hook, t_align=8, logit_align=64)
+    rows = []
+    stats, _, iters = dec.generate(prompts, max_new_tokens=96, max_calls=8, seed=5,
+                                   on_iteration=lambda i, d: rows.append(dec.last_logits_rows))
+    for p, st in enumerate(stats):
+        pos = torch.arange(len(prompts[p]), len(prompts[p]) + len(st.token_ids))
+        assert st.token_ids == hook.target(pos, torch.full_like(pos, p)).tolist(), p
+    tpf = sum(len(s.token_ids) for s in stats) / sum(s.total_iterations for s in stats)
+    assert tpf > 2.5 and max(rows) * V * 2 >= (140 << 20)            # at least one launch took the wavefront shape
+
+
 _WORKER = textwrap.dedent("""
     import os, sys, json
     sys.path.insert(0, {root!r})
