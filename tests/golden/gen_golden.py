@@ -603,6 +603,28 @@ def run_argmax_vectors():
 
 
 # --------------------------------------------------------------------------------------
+# paged-KV slot mapping pattern of the batched Jacobi forward (MR:965-986), run from the reference's ModelRunner method
+# --------------------------------------------------------------------------------------
+def run_slot_pattern_vectors():
+    from inference_engine.engine.model_runner import ModelRunner
+    real_arange = torch.arange
+
+    def cpu_arange(*a, **k):
+        k.pop("device", None)                      # the method asks for device='cuda'
+        return real_arange(*a, **k)
+
+    out = []
+    for block_size in (256, 512):
+        me = types.SimpleNamespace(block_size=block_size, slot_mapping_lut={}, slot_mapping_cache={})
+        for S, L in [(1, 2), (1, 64), (5, 8), (255, 2), (256, 2), (256, 16), (257, 33), (511, 64), (512, 64), (513, 3), (1000, 32),
+                     (2047, 64), (4096, 17)]:
+            with patched(torch, "arange", cpu_arange):
+                blk, off = ModelRunner._get_slot_mapping_pattern(me, S, L)
+            out.append(dict(block_size=block_size, seq_len=S, draft_len=L, block_indices=blk.tolist(), offsets=off.tolist()))
+    return out
+
+
+# --------------------------------------------------------------------------------------
 def main():
     torch.manual_seed(0)
     mbs = []
@@ -709,6 +731,7 @@ def main():
                      temperature=2.0),
     ]
     kv = run_argmax_vectors()
+    slots = run_slot_pattern_vectors()
 
     def dump(fname, obj):
         p = OUT_DIR / fname
@@ -723,6 +746,7 @@ def main():
     dump("jdn_cases.json", jdns)
     dump("jdo_cases.json", jdos)
     dump("kernel_vectors.json", kv)
+    dump("slot_cases.json", slots)
     # quick human summary
     for c in mbs:
         fw = [f for cl in c["calls"] for f in cl["forwards"]]

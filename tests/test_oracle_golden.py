@@ -13,6 +13,7 @@ SB = load_golden("sb_cases.json")
 JD = load_golden("jd_cases.json")
 JDN = load_golden("jdn_cases.json")
 MBR = load_golden("mb_raises.json")
+SLOTS = load_golden("slot_cases.json")
 JDO = load_golden("jdo_cases.json")
 
 
@@ -237,3 +238,19 @@ def check_jdo(case, seqs, records, metrics, draws, trace=None):
 def test_engine_onpolicy_records(case):
     seqs, records, metrics, draws, trace = run_oracle_jdo(case)
     check_jdo(case, seqs, records, metrics, draws, trace)
+
+
+# ----------------------------------------------------------------------------- paged-KV slot mapping (MR:965-986, 1252-1254)
+def test_engine_fill_matches_reference_slot_pattern():
+    """The (block index, offset) pattern the reference's ModelRunner._get_slot_mapping_pattern returned for (seq_len, draft_len)
+    pairs — first token in the last slot of a block, drafts crossing one and two block boundaries — fixes the oracle's
+    slot_mapping = block_table[block] * block_size + offset, positions and cu_seqlens."""
+    rng = np.random.default_rng(1)
+    for c in SLOTS:
+        bs, S, L = c["block_size"], c["seq_len"], c["draft_len"]
+        table = [int(x) for x in rng.choice(10_000, size=max(c["block_indices"]) + 1, replace=False)]
+        ref = O.engine_fill_ref([list(range(L))], [S], [table], bs, max_cols=len(table) + 2)
+        want = [table[b] * bs + o for b, o in zip(c["block_indices"], c["offsets"])]
+        assert ref["slot_mapping"] == want, c
+        assert ref["positions"] == [S - 1 + j for j in range(L)]
+        assert ref["cu_seqlens_q"] == [0, L] and ref["cu_seqlens_k"] == [0, S - 1 + L] and ref["cache_seqlens"] == [S - 1]
