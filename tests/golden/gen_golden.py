@@ -603,6 +603,66 @@ def run_argmax_vectors():
 
 
 # --------------------------------------------------------------------------------------
+# block bookkeeping the Jacobi decoders drive (BM:114-121, 195-276, 534-564): scripted op sequences on the reference's
+# BlockManager + Sequence, state recorded after every op
+# --------------------------------------------------------------------------------------
+def run_bm_case(seed, num_blocks=48, block_size=256):
+    rr = random.Random(seed)
+    bm = BlockManager(num_blocks, block_size)
+    ops_log = []
+    seqs = []
+    for _ in range(rr.randint(1, 3)):
+        plen = rr.choice([1, 5, 200, 255, 256, 257, 511, 600])
+        seq = Sequence([rr.randrange(50) for _ in range(plen)], SamplingParams(temperature=0.0, max_tokens=4096))
+        bm.allocate(seq)
+        seq.num_cached_tokens = len(seq)
+        seqs.append(seq)
+        ops_log.append(dict(op="allocate", seq=len(seqs) - 1, prompt_len=plen))
+
+    def snap():
+        return dict(tables=[len(s.block_table) for s in seqs], cached=[s.num_cached_tokens for s in seqs],
+                    lens=[len(s) for s in seqs], spec=[s.num_permanent_spec_blocks for s in seqs], free=len(bm.free_block_ids))
+    ops_log[-1]["after"] = snap()
+    for _ in range(40):
+        i = rr.randrange(len(seqs))
+        seq = seqs[i]
+        kind = rr.choice(["jacobi", "jacobi", "jacobi", "ar"])
+        if kind == "ar":
+            seq.append_token(rr.randrange(50))
+            bm.may_append(seq)
+            seq.num_cached_tokens = len(seq)
+            ops_log.append(dict(op="ar", seq=i, after=snap()))
+            continue
+        L = rr.choice([2, 4, 16, 33, 64, 300])
+        S = len(seq)
+        need = (S + L - 1 + block_size - 1) // block_size                      # MR:1166-1198 (the forward's table growth)
+        committed = (S + block_size - 1) // block_size
+        cur = len(seq.block_table)
+        if cur > need:
+            seq.block_table = seq.block_table[:need]
+        for _k in range(max(0, need - cur)):
+            bid = bm.free_block_ids[0]
+            bm._allocate_block_no_clear(bid)
+            seq.block_table.append(bid)
+        seq.num_permanent_spec_blocks = max(seq.num_permanent_spec_blocks, need - committed)
+        seq.num_cached_tokens = S - 1 + L
+        acc = rr.randint(1, L)                                                    # acc_len incl. the seed (JD:609-646)
+        if acc > 1:
+            seq.extend_tokens([rr.randrange(50) for _ in range(acc - 1)])
+            bm.may_append_batch(seq, acc - 1)
+            spec = acc - 1
+        else:
+            seq.append_token(rr.randrange(50))
+            bm.may_append(seq)
+            spec = 1
+        trim = L - 1 - spec
+        if trim > 0:
+            bm.trim_kv_only_fast(seq, trim)
+        ops_log.append(dict(op="jacobi", seq=i, L=L, acc=acc, after=snap()))
+    return dict(seed=seed, num_blocks=num_blocks, block_size=block_size, ops=ops_log)
+
+
+# --------------------------------------------------------------------------------------
 # paged-KV slot mapping pattern of the batched Jacobi forward (MR:965-986), run from the reference's ModelRunner method
 # --------------------------------------------------------------------------------------
 def run_slot_pattern_vectors():
@@ -732,6 +792,7 @@ def main():
     ]
     kv = run_argmax_vectors()
     slots = run_slot_pattern_vectors()
+    bms = [run_bm_case(sd) for sd in range(12)]
 
     def dump(fname, obj):
         p = OUT_DIR / fname
@@ -747,6 +808,7 @@ def main():
     dump("jdo_cases.json", jdos)
     dump("kernel_vectors.json", kv)
     dump("slot_cases.json", slots)
+    dump("bm_cases.json", bms)
     # quick human summary
     for c in mbs:
         fw = [f for cl in c["calls"] for f in cl["forwards"]]

@@ -113,6 +113,7 @@ from jacobiforcing_amd.engine.jacobi_decoding_nongreedy import JacobiDecoderNonG
 
 JDN = load_golden("jdn_cases.json")
 JDO = load_golden("jdo_cases.json")
+BMC = load_golden("bm_cases.json")
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -232,3 +233,68 @@ def test_paged_fill_matches_reference_arithmetic(backend):
             fill.fill(torch.zeros((1, 8), dtype=torch.int64, device=dev), [0], [[5]])
         with pytest.raises(ValueError):
             fill.fill(torch.zeros((1, 1), dtype=torch.int64, device=dev), [4], [[5]])
+
+
+# ------------------------------------------------------------------------------------- block bookkeeping (a17)
+@pytest.mark.parametrize("case", BMC, ids=[f"seed{c['seed']}" for c in BMC])
+def test_block_manager_matches_reference_traces(case):
+    """Scripted sequences of the block operations the decoders drive (forward-side table growth MR:1166-1198,
+    may_append_batch BM:267-276, may_append BM:195-265, trim_kv_only_fast BM:534-564) were run on the reference's BlockManager +
+    Sequence; this package's classes must go through the same states op by op: table lengths, num_cached_tokens, sequence
+    lengths, permanent speculative blocks, free-block count."""
+    import random
+    rr = random.Random(case["seed"])
+    bs = case["block_size"]
+    bm = BlockManager(case["num_blocks"], bs)
+    seqs = []
+
+    def snap():
+        return dict(tables=[len(s.block_table) for s in seqs], cached=[s.num_cached_tokens for s in seqs],
+                    lens=[len(s) for s in seqs], spec=[s.num_permanent_spec_blocks for s in seqs], free=len(bm.free_block_ids))
+    ops_iter = iter(case["ops"])
+    for _ in range(rr.randint(1, 3)):                        # same draws as tests/golden/gen_golden.py::run_bm_case
+        plen = rr.choice([1, 5, 200, 255, 256, 257, 511, 600])
+        seq = Sequence([rr.randrange(50) for _ in range(plen)], SamplingParams(temperature=0.0, max_tokens=4096))
+        bm.allocate(seq)
+        seq.num_cached_tokens = len(seq)
+        seqs.append(seq)
+        op = next(ops_iter)
+        assert op["op"] == "allocate" and op["prompt_len"] == plen
+    assert snap() == op["after"]
+    for step in range(40):
+        i = rr.randrange(len(seqs))
+        seq = seqs[i]
+        kind = rr.choice(["jacobi", "jacobi", "jacobi", "ar"])
+        op = next(ops_iter)
+        assert op["op"] == kind and op["seq"] == i
+        if kind == "ar":
+            seq.append_token(rr.randrange(50))
+            bm.may_append(seq)
+            seq.num_cached_tokens = len(seq)
+        else:
+            L = rr.choice([2, 4, 16, 33, 64, 300])
+            S = len(seq)
+            need = (S + L - 1 + bs - 1) // bs
+            committed = (S + bs - 1) // bs
+            cur = len(seq.block_table)
+            if cur > need:
+                seq.block_table = seq.block_table[:need]
+            for _k in range(max(0, need - cur)):
+                bid = bm.free_block_ids[0]
+                bm._allocate_block_no_clear(bid)
+                seq.block_table.append(bid)
+            seq.num_permanent_spec_blocks = max(seq.num_permanent_spec_blocks, need - committed)
+            seq.num_cached_tokens = S - 1 + L
+            acc = rr.randint(1, L)
+            assert (L, acc) == (op["L"], op["acc"])
+            if acc > 1:
+                seq.extend_tokens([rr.randrange(50) for _ in range(acc - 1)])
+                bm.may_append_batch(seq, acc - 1)
+                spec = acc - 1
+            else:
+                seq.append_token(rr.randrange(50))
+                bm.may_append(seq)
+                spec = 1
+            if L - 1 - spec > 0:
+                bm.trim_kv_only_fast(seq, L - 1 - spec)
+        assert snap() == op["after"], (step, kind)
