@@ -298,3 +298,40 @@ def test_block_manager_matches_reference_traces(case):
             if L - 1 - spec > 0:
                 bm.trim_kv_only_fast(seq, L - 1 - spec)
         assert snap() == op["after"], (step, kind)
+
+
+# ------------------------------------------------------------------------------------- statistical criterion of the reference
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_nongreedy_first_token_follows_the_target_distribution(backend):
+    """The reference's own acceptance test for the non-greedy decoder is statistical: mean Jensen-Shannon divergence < 0.1
+    between Jacobi and autoregressive sampling (inference_engine/tests/test_jacobi_decoding_nongreedy.py).  Rejection
+    sampling with a delta proposal is distribution-preserving, so over many independent draws the FIRST committed token must
+    follow softmax(logits / T) of its position, whatever the draft was."""
+    from jacobiforcing_amd.engine.jacobi_decoding_nongreedy import JacobiDecoderNonGreedy
+    with use_backend(backend):
+        dev = device_for(backend)
+        V, T = 12, 3.0                                   # scripted logits peak at 8.0: T = 3 spreads them (max p ~ 0.55)
+        eos, pad = V - 1, V - 2
+        model = ScriptedModel(V, 4242, 55, 6, eos_id=eos, eos_pos=None, reserved=(pad,))
+        trials = 3000 if backend == "hostsim" else 1500
+        rng = np.random.default_rng(0)
+        counts = np.zeros(V)
+        H = Harness(V, dev, torch.float32)
+        dec = JacobiDecoderNonGreedy(H.bm, forward_step=lambda s, d: H.forward_step_batch([s], d), forward_step_batch=H.forward_step_batch,
+                                     eos_token_id=eos, pad_token_id=pad, vocab_size=V, device=torch.device(dev))
+        for _ in range(trials):
+            dec.set_streams(rng.integers(0, V, size=64), rng.random(64), rng.random(64))
+            sp = SamplingParams(temperature=T, max_tokens=1, decode_strategy="jacobi", jacobi_block_len=4)
+            seq = H.add(model, sp, None)
+            out = dec.generate_chunk(seq)
+            counts[out[0]] += 1
+            H.bm.deallocate(seq)
+        # the target: softmax of the logits that follow the prompt (the draft row's position 0 sees only the prompt)
+        lg = model.logits_rows(model.prompt()[:-1], [[model.prompt()[-1], 0, 0, 0]])[0][0]
+        p = O.softmax_rows_f32(lg[None, :], T)[0].astype(np.float64)
+        q = counts / counts.sum()
+        mid = 0.5 * (p + q)
+        kl = lambda a, b: float(np.sum(np.where(a > 0, a * np.log(a / b), 0.0)))
+        js = 0.5 * kl(p, mid) + 0.5 * kl(q, mid)
+        assert js < 0.01, (js, p.round(3), q.round(3))
+        assert q.max() < 0.95                                  # the distribution is not degenerate (a real test)
