@@ -70,6 +70,13 @@ def test_jacobi_matches_autoregressive(model_dir, backend, monkeypatch):
             assert j["token_ids"][:N] == a["token_ids"]
             assert m["token_ids"][:N] == a["token_ids"]
             assert j["text"] == ""
+        # cross-mode (test_jacobi_decoding_greedy.py:314-491): one request at a time == the same request inside a batch
+        for i, pr in enumerate(prompts):
+            one_ar = llm.generate([pr], SamplingParams(temperature=0.0, max_tokens=N, ignore_eos=True), use_tqdm=False)
+            one_j = llm.generate([pr], SamplingParams(temperature=0.0, max_tokens=N, ignore_eos=True, decode_strategy="jacobi",
+                                                      jacobi_block_len=16), use_tqdm=False)
+            assert one_ar[0]["token_ids"] == ar[i]["token_ids"]
+            assert one_j[0]["token_ids"][:N] == ar[i]["token_ids"]
         tpf = llm.model_runner.jacobi_decoder.stats
         assert tpf["tokens_accepted"] >= 3 * N and tpf["num_jacobi_iterations"] >= 1
         # kwargs of LLM.generate (llm.py:22-37); the names the reference breaks on are mapped
