@@ -130,13 +130,15 @@ def cpu_baseline(model, prompt, prm, budget_s: float):
     same weights), timed on the host cores for a bounded sample.  Only this leg imports oracle/."""
     from oracle import cpu_reference as CR
     t0 = time.perf_counter()
-    cpu = CR.CpuQwen2(model.cfg, model.w, dtype=torch.bfloat16)
+    # bf16 like the GPU path by default; JF_CPU_DTYPE=float32 uses fp32 weights (twice the memory, often the faster CPU GEMM)
+    cpu_dtype = getattr(torch, os.environ.get("JF_CPU_DTYPE", "bfloat16"))
+    cpu = CR.CpuQwen2(model.cfg, model.w, dtype=cpu_dtype)
     load_s = time.perf_counter() - t0
     r = CR.timed_tokens_per_second(cpu, prompt, random.Random(1234), n=prm.n, K=prm.K, r=prm.r,
                                    pool=prm.n_gram_pool_size, eos=prm.eos_token_id, pad=prm.pad_token_id, budget_s=budget_s)
     return dict(value=r["tokens_per_sec"], unit="tokens/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"1 prompt ({len(prompt)} tokens), {r['calls']} generation calls, {r['iterations']} Jacobi "
-                       f"iterations, {r['tokens']} tokens in {r['seconds']:.1f}s; oracle loop + torch-CPU bf16 forward "
+                       f"iterations, {r['tokens']} tokens in {r['seconds']:.1f}s; oracle loop + torch-CPU {str(cpu_dtype)[6:]} forward "
                        f"with DynamicCache-style cat/expand/narrow (weights copied from the GPU in {load_s:.1f}s, untimed)",
                 tokens_per_forward=(r["tokens"] / r["iterations"]) if r["iterations"] else 0.0)
 
