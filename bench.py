@@ -143,6 +143,28 @@ def cpu_baseline(model, prompt, prm, budget_s: float):
                 tokens_per_forward=(r["tokens"] / r["iterations"]) if r["iterations"] else 0.0)
 
 
+def cpu_verify_kernel(rows: int, V: int, budget_s: float = 3.0):
+    """Kernel-level CPU figure beside the roofline: the C/OpenMP restatement of the verify body's HBM-heavy op (argmax over the
+    vocabulary, oracle/verify_ref.c) over a logits tensor of the bench's launch shape, on all host cores."""
+    import ctypes as C
+    lib_path = ROOT / "oracle" / "_build" / "libjf_oracle.so"
+    if not lib_path.exists():
+        return None
+    lib = C.CDLL(str(lib_path))
+    lib.ref_argmax_rows.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]
+    lib.ref_num_threads.restype = C.c_int
+    x = torch.randn(rows, V).to(torch.bfloat16)
+    out = torch.zeros(rows, dtype=torch.int64)
+    lib.ref_argmax_rows(x.data_ptr(), 1, rows, V, V, out.data_ptr())          # warm-up
+    reps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        lib.ref_argmax_rows(x.data_ptr(), 1, rows, V, V, out.data_ptr())
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    return dict(us_per_call=dt * 1e6, gbs=rows * V * 2 / dt / 1e9, rows=rows, threads=int(lib.ref_num_threads()), reps=reps,
+                what="oracle/verify_ref.c ref_argmax_rows (C + OpenMP) over bf16 logits of the bench's launch shape")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -255,6 +277,8 @@ def main():
     if info.rank == 0 and info.world_size == 1 and args.cpu_baseline_seconds > 0:
         try:
             out["cpu_baseline"] = cpu_baseline(model, prompts[0], prm, args.cpu_baseline_seconds)
+            if roof is not None:
+                out["cpu_baseline"]["verify_kernel"] = cpu_verify_kernel(max(int(roof["avg_rows"]), 1), cfg.vocab_size)
         except Exception as e:  # the baseline must not kill the GPU measurement
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
                                    "sample": f"failed: {type(e).__name__}: {e}"}

@@ -14,40 +14,53 @@
 #include <omp.h>
 #endif
 
-static inline float bf16_to_f32(uint16_t b) {
-    uint32_t u = ((uint32_t)b) << 16;
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
+/* Order-preserving key of an fp32 bit pattern: -0.0 folds onto +0.0, NaN is flagged separately.  Integer max over the keys
+ * vectorises (vpmaxud); the first index holding the winning key is found in a second, short pass over one block. */
+static inline uint32_t key_of(uint32_t u) {
+    u = (u == 0x80000000u) ? 0u : u;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+static inline int is_nan_bits(uint32_t u) { return (u & 0x7fffffffu) > 0x7f800000u; }
+
+#define BLK 4096
+#define ARGMAX_BODY(LOAD)                                                                              \
+    uint32_t best = 0;                                                                                 \
+    int64_t best_blk = 0, nan_blk = -1;                                                                \
+    for (int64_t b0 = 0; b0 < V; b0 += BLK) {                                                          \
+        const int64_t e = b0 + BLK < V ? b0 + BLK : V;                                                 \
+        uint32_t m = 0;                                                                                \
+        int nan = 0;                                                                                   \
+        _Pragma("omp simd reduction(max : m) reduction(| : nan)")                                      \
+        for (int64_t i = b0; i < e; ++i) {                                                             \
+            const uint32_t u = LOAD(i);                                                                \
+            nan |= is_nan_bits(u);                                                                     \
+            const uint32_t k = key_of(u);                                                              \
+            m = k > m ? k : m;                                                                         \
+        }                                                                                              \
+        if (nan) { nan_blk = b0; break; }      /* first NaN wins; no earlier block holds one */         \
+        if (m > best) { best = m; best_blk = b0; }                                                     \
+    }                                                                                                  \
+    if (nan_blk >= 0) {                                                                                \
+        for (int64_t i = nan_blk;; ++i) if (is_nan_bits(LOAD(i))) return i;                            \
+    }                                                                                                  \
+    const int64_t e = best_blk + BLK < V ? best_blk + BLK : V;                                         \
+    for (int64_t i = best_blk; i < e; ++i) if (key_of(LOAD(i)) == best) return i;   /* first index on ties */ \
+    return 0;
 
 static int64_t argmax_f32(const float *x, int64_t V) {
-    int64_t bi = 0;
-    float bv = x[0];
-    if (isnan(bv)) return 0;
-    for (int64_t i = 1; i < V; ++i) {
-        const float v = x[i];
-        if (isnan(v)) return i;          /* first NaN wins */
-        if (v > bv) { bv = v; bi = i; }  /* strict: first index on ties, -0.0 == +0.0 */
-    }
-    return bi;
+    const uint32_t *w = (const uint32_t *)x;
+#define LOAD_F32(i) (w[i])
+    ARGMAX_BODY(LOAD_F32)
 }
 
 static int64_t argmax_bf16(const uint16_t *x, int64_t V) {
-    int64_t bi = 0;
-    float bv = bf16_to_f32(x[0]);
-    if (isnan(bv)) return 0;
-    for (int64_t i = 1; i < V; ++i) {
-        const float v = bf16_to_f32(x[i]);
-        if (isnan(v)) return i;
-        if (v > bv) { bv = v; bi = i; }
-    }
-    return bi;
+#define LOAD_BF16(i) (((uint32_t)x[i]) << 16)
+    ARGMAX_BODY(LOAD_BF16)
 }
 
 /* dtype: 0 = f32, 1 = bf16; logits [R, V] with row stride in elements */
 void ref_argmax_rows(const void *logits, int dtype, int64_t R, int64_t V, int64_t stride, int64_t *greedy) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 1)
     for (int64_t r = 0; r < R; ++r) {
         greedy[r] = dtype == 0 ? argmax_f32((const float *)logits + r * stride, V)
                                : argmax_bf16((const uint16_t *)logits + r * stride, V);
