@@ -153,7 +153,9 @@ def cpu_verify_kernel(rows: int, V: int, budget_s: float = 3.0):
     lib = C.CDLL(str(lib_path))
     lib.ref_argmax_rows.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]
     lib.ref_num_threads.restype = C.c_int
-    x = torch.randn(rows, V).to(torch.bfloat16)
+    lib.ref_fill_rows_bf16.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_uint32]
+    x = torch.empty(rows, V, dtype=torch.bfloat16)                             # pages placed by the threads that will scan them
+    lib.ref_fill_rows_bf16(x.data_ptr(), rows, V, V, 1234)
     out = torch.zeros(rows, dtype=torch.int64)
     lib.ref_argmax_rows(x.data_ptr(), 1, rows, V, V, out.data_ptr())          # warm-up
     reps, t0 = 0, time.perf_counter()

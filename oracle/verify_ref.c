@@ -60,10 +60,24 @@ static int64_t argmax_bf16(const uint16_t *x, int64_t V) {
 
 /* dtype: 0 = f32, 1 = bf16; logits [R, V] with row stride in elements */
 void ref_argmax_rows(const void *logits, int dtype, int64_t R, int64_t V, int64_t stride, int64_t *greedy) {
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(static)
     for (int64_t r = 0; r < R; ++r) {
         greedy[r] = dtype == 0 ? argmax_f32((const float *)logits + r * stride, V)
                                : argmax_bf16((const uint16_t *)logits + r * stride, V);
+    }
+}
+
+/* Fill bf16 logits [R, V] with a cheap hash pattern using the SAME static row partition as ref_argmax_rows, so that on a
+ * multi-socket host every row's pages are first touched (and therefore placed) on the NUMA node of the thread that scans it. */
+void ref_fill_rows_bf16(uint16_t *x, int64_t R, int64_t V, int64_t stride, uint32_t seed) {
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < R; ++r) {
+        uint32_t h = seed ^ (uint32_t)(r * 2654435761u);
+        uint16_t *row = x + r * stride;
+        for (int64_t i = 0; i < V; ++i) {
+            h = h * 1664525u + 1013904223u;
+            row[i] = (uint16_t)(0x3C00u + ((h >> 20) & 0x3FFu));      /* finite values around 0.01 .. 2 */
+        }
     }
 }
 
