@@ -137,7 +137,9 @@ __global__ __launch_bounds__(256) void rs_probs_finish_kernel(const void *logits
 
 static int64_t rs_chunk(int dtype, int64_t R, int64_t V, int64_t *cpr_out) {
     const int64_t gran = 4 * (int64_t)256 * (dtype == JF_F32 ? 4 : 8);     // one full round per workgroup
-    int64_t per_row = (2048 + R - 1) / R;
+    const char *e = getenv("JF_RS_ITEMS");                                  // workgroups to aim for (sweeps in tools/)
+    const int64_t target = (e && *e) ? atoll(e) : 1024;                 // measured: fewer, longer items win (profiles/rs_probs_microbench_r01.txt)
+    int64_t per_row = (target + R - 1) / R;
     if (per_row < 1) per_row = 1;
     if (per_row > 64) per_row = 64;
     int64_t chunk = (V + per_row - 1) / per_row;
