@@ -278,9 +278,10 @@ def main():
             out["scripted_acceptance"] = scripted
     if info.rank == 0 and info.world_size == 1 and args.cpu_baseline_seconds > 0:
         try:
+            # the kernel-level figure first: torch's CPU thread pool keeps spinning after the forward below and would compete
+            vk = cpu_verify_kernel(max(int(roof["avg_rows"]), 1), cfg.vocab_size) if roof is not None else None
             out["cpu_baseline"] = cpu_baseline(model, prompts[0], prm, args.cpu_baseline_seconds)
-            if roof is not None:
-                out["cpu_baseline"]["verify_kernel"] = cpu_verify_kernel(max(int(roof["avg_rows"]), 1), cfg.vocab_size)
+            out["cpu_baseline"]["verify_kernel"] = vk
         except Exception as e:  # the baseline must not kill the GPU measurement
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
                                    "sample": f"failed: {type(e).__name__}: {e}"}
