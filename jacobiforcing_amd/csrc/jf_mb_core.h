@@ -219,8 +219,9 @@ struct Machine {
     // ---- start of a call: MB:230-262 ------------------------------------------------------------
     template <class TokFn>
     JF_HD void begin(const jf_mb_params &p, TokFn input_tok, int kv0, jf_mb_desc *d) {
+        fill(S, 0, L.hdr_ints);                              // header + span table (3 ints per possible block), lanes in parallel
+        lanes.sync();
         if (lanes.lane() == 0) {
-            for (int i = 0; i < L.hdr_ints; ++i) S[i] = 0;
             S[H_N] = p.n; S[H_K] = p.K; S[H_SPAWN_THR] = p.spawn_threshold; S[H_POOL_SIZE] = p.pool_size;
             S[H_EOS] = p.eos_id; S[H_PAD] = p.pad_id; S[H_MAX_ITER] = p.max_iter; S[H_NB] = L.NB;
             S[H_RMAX] = L.RMAX; S[H_TMAX] = L.TMAX; S[H_LPOOL] = L.LPOOL;
