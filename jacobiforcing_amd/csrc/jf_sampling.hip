@@ -11,7 +11,9 @@
 // then adds exp(x - m) for every element: one exp per element plus one per round, branch-free.  The argmax tracker runs on
 // the same registers.  Partials (m, s) go to the workspace, the argmax to `packed` by atomicMax.
 template <int DT, int NV>
-__device__ __forceinline__ void rs_round(const u32x4 (&vv)[NV], float inv_t, float &m, float &s) {
+__device__ __forceinline__ void rs_round(const u32x4 (&vv)[NV], float cs, float &m, float &s) {
+    // (m, s) live in the scaled log2 domain: x' = w * cs with cs = log2(e) / T, s = sum of 2^(x' - m); one multiply and one
+    // v_exp_f32 per element (exp(x/T - M) == 2^(x' - m) up to the rounding of the product)
     constexpr int EPV = Elem<DT>::EPV;
     constexpr int NE = NV * EPV;
     float x[NE];
@@ -21,10 +23,10 @@ __device__ __forceinline__ void rs_round(const u32x4 (&vv)[NV], float inv_t, flo
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if constexpr (DT == JF_F32) {
-                x[u * 4 + j] = __uint_as_float(w[j]) * inv_t;
+                x[u * 4 + j] = __uint_as_float(w[j]) * cs;
             } else {
-                x[u * 8 + 2 * j] = __uint_as_float(w[j] << 16) * inv_t;
-                x[u * 8 + 2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u) * inv_t;
+                x[u * 8 + 2 * j] = __uint_as_float(w[j] << 16) * cs;
+                x[u * 8 + 2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u) * cs;
             }
         }
     }
@@ -33,11 +35,16 @@ __device__ __forceinline__ void rs_round(const u32x4 (&vv)[NV], float inv_t, flo
     for (int j = 1; j < NE; ++j) mx = fmaxf(mx, x[j]);
     const float mn = fmaxf(m, mx);
     if (mn == -INFINITY) return;                        // nothing finite yet: keep (m, s) = (-inf, 0), never form inf - inf
-    float acc = (m == -INFINITY) ? 0.f : s * __expf(m - mn);
+    float acc = (m == -INFINITY) ? 0.f : s * __builtin_amdgcn_exp2f(m - mn);
 #pragma unroll
-    for (int j = 0; j < NE; ++j) acc += __expf(x[j] - mn);
+    for (int j = 0; j < NE; ++j) acc += __builtin_amdgcn_exp2f(x[j] - mn);
     s = acc;
     m = mn;
+}
+
+// raw fp32 value behind an order key (inverse of order_key for non-NaN values)
+__device__ __forceinline__ float key_to_float(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
 template <int DT, bool VEC>
@@ -54,6 +61,7 @@ __global__ __launch_bounds__(256) void rs_probs_partial_kernel(const void *logit
     if (end > V) end = V;
     const typename E::T *p = (const typename E::T *)logits + row * row_stride;
     const int tid = threadIdx.x;
+    const float cs = inv_t * 1.44269504088896340736f;     // log2(e) / T
     float m = -INFINITY, s = 0.f;
     uint32_t best = 0u, bidx = 0xFFFFFFFFu;
     int64_t done = begin;
@@ -67,12 +75,12 @@ __global__ __launch_bounds__(256) void rs_probs_partial_kernel(const void *logit
             const u32x4 vv[4] = {JF_LOAD(q), JF_LOAD(q + 256), JF_LOAD(q + 512), JF_LOAD(q + 768)};
 #pragma unroll
             for (int u = 0; u < 4; ++u) ft.consume(vv[u], ebase + (uint32_t)(k + u * 256) * EPV);
-            rs_round<DT, 4>(vv, inv_t, m, s);
+            rs_round<DT, 4>(vv, cs, m, s);
         }
         for (; k < nvec; k += 256, q += 256) {          // this lane's remaining vectors, one at a time
             const u32x4 vv[1] = {JF_LOAD(q)};
             ft.consume(vv[0], ebase + (uint32_t)k * EPV);
-            rs_round<DT, 1>(vv, inv_t, m, s);
+            rs_round<DT, 1>(vv, cs, m, s);
         }
         done = begin + (int64_t)nvec * EPV;
         if (__syncthreads_or(ft.saw_nan() ? 1 : 0)) {
@@ -85,16 +93,16 @@ __global__ __launch_bounds__(256) void rs_probs_partial_kernel(const void *logit
     for (int64_t i = done + tid; i < end; i += 256) {    // unaligned rows / ragged tail (V % EPV)
         const uint32_t kk = load_key<DT>(p, i);
         if (kk > best) { best = kk; bidx = (uint32_t)i; }
-        const float xv = load_f<DT>(p, i) * inv_t;
-        if (xv > m) { s = (m == -INFINITY ? 0.f : s * __expf(m - xv)) + 1.f; m = xv; }
-        else if (xv != -INFINITY) s += __expf(xv - m);
+        const float xv = load_f<DT>(p, i) * cs;
+        if (xv > m) { s = (m == -INFINITY ? 0.f : s * __builtin_amdgcn_exp2f(m - xv)) + 1.f; m = xv; }
+        else if (xv != -INFINITY) s += __builtin_amdgcn_exp2f(xv - m);
     }
     // merge (m, s) pairs: six shuffle steps inside the wavefront, then one LDS hop across the four wavefronts
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const float m2 = __shfl_xor(m, off, 64), s2 = __shfl_xor(s, off, 64);
         const float M = fmaxf(m, m2);
-        s = (M == -INFINITY) ? 0.f : ((m == -INFINITY ? 0.f : s * expf(m - M)) + (m2 == -INFINITY ? 0.f : s2 * expf(m2 - M)));
+        s = (M == -INFINITY) ? 0.f : ((m == -INFINITY ? 0.f : s * exp2f(m - M)) + (m2 == -INFINITY ? 0.f : s2 * exp2f(m2 - M)));
         m = M;
     }
     __shared__ float sm[4], ss[4];
@@ -106,10 +114,12 @@ __global__ __launch_bounds__(256) void rs_probs_partial_kernel(const void *logit
         float M = -INFINITY;
         for (int i = 0; i < 4; ++i) M = sm[i] > M ? sm[i] : M;
         float Ssum = 0.f;
-        for (int i = 0; i < 4; ++i) Ssum += (sm[i] == -INFINITY) ? 0.f : ss[i] * expf(sm[i] - M);
-        partial[item] = make_float2(M, Ssum);
+        for (int i = 0; i < 4; ++i) Ssum += (sm[i] == -INFINITY) ? 0.f : ss[i] * exp2f(sm[i] - M);
         uint64_t mm = sp[0];
         for (int w = 1; w < 4; ++w) mm = sp[w] > mm ? sp[w] : mm;
+        // the chunk's RAW maximum (from the argmax key) and its sum relative to fl(raw max * cs) == M: multiplying by a
+        // positive constant is monotone, so the largest scaled value belongs to the largest raw value
+        partial[item] = make_float2(M == -INFINITY ? -INFINITY : key_to_float((uint32_t)(mm >> 32)), Ssum);
         atomicMax(packed + row, (unsigned long long)mm);
     }
 }
@@ -121,13 +131,15 @@ __global__ __launch_bounds__(256) void rs_probs_finish_kernel(const void *logits
                                                                int cpr, float *p_draft, float *row_max, float *row_sumexp) {
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= R) return;
-    float M = -INFINITY;
-    for (int c = 0; c < cpr; ++c) M = fmaxf(M, partial[row * cpr + c].x);
+    const float cs = inv_t * 1.44269504088896340736f;
+    float Mraw = -INFINITY;
+    for (int c = 0; c < cpr; ++c) Mraw = fmaxf(Mraw, partial[row * cpr + c].x);
     float S = 0.f;
     for (int c = 0; c < cpr; ++c) {
         const float2 ps = partial[row * cpr + c];
-        S += (ps.x == -INFINITY) ? 0.f : ps.y * expf(ps.x - M);
+        S += (ps.x == -INFINITY) ? 0.f : ps.y * exp2f(ps.x * cs - Mraw * cs);
     }
+    const float M = Mraw * inv_t;                         // consumers form exp(x * inv_t - M): exactly 1 at the maximum
     row_max[row] = M;
     row_sumexp[row] = S;
     const int64_t tok = draft_next[row];
