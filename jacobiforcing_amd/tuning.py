@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import os
 import shutil
+import sys
 import tempfile
 from pathlib import Path
 
@@ -29,7 +30,7 @@ def enable_tuned_gemms(csv: Path = CSV) -> bool:
         torch.cuda.tunable.set_filename(str(tmp), insert_device_ordinal=False)
         return bool(torch.cuda.tunable.read_file(str(tmp)))
     except Exception as e:  # older torch / validator mismatch: fall back to the default heuristics
-        print(f"[tuning] tuned GEMM table not loaded: {type(e).__name__}: {e}", flush=True)
+        print(f"[tuning] tuned GEMM table not loaded: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
         try:
             torch.cuda.tunable.enable(False)
         except Exception:
