@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define JF_VERSION 100
+#define JF_VERSION 200
 
 enum {
     JF_OK = 0,
@@ -243,9 +243,17 @@ JF_API int jf_engine_fill(const int64_t *draft, int B, int L, const int32_t *seq
 /* ---------------------------------------------------------------------------------------------
  * Non-greedy verify (a19), JDN = inference_engine/engine/jacobi_decoding_nongreedy.py.
  *
+ * The reference builds its target distribution IN THE DTYPE OF THE LOGITS (JDN:64-70 has no .float(); the engine's
+ * logits are bf16, MR:1382), so dtype selects the arithmetic of every jf_rs_* call:
+ *   JF_F32   p = softmax(logits / T) in float32.
+ *   JF_BF16  xs = bf16(float(x) / float(T)) (one rounding of the float32 quotient; T == 1 leaves x as it is),
+ *            p = bf16(exp(xs - max xs) / sum exp(xs - max xs)) with float32 inside: torch's rounding points.
+ *            `u < p`, the inverse-CDF draws and the masked argmax all use the ROUNDED p.
+ *
  * jf_rs_probs: fused softmax-gather + argmax over logits [R, V] read once.  For row r:
- *   p_draft[r] = softmax(logits[r] / T)[draft_next[r]] in fp32 (JDN:65-70, 328), row max and sum-exp (for the
- *   residual sampling) and the packed argmax (next draft, JDN:446/619).  packed must be zero on entry.
+ *   p_draft[r] = p[draft_next[r]] (JDN:65-70, 328; a float holding a bf16 value for JF_BF16), row_max[r] = max xs,
+ *   row_sumexp[r] = sum exp(xs - max) (both for the residual sampling) and the packed argmax of the RAW logits (next
+ *   draft, JDN:446/619).  packed must be zero on entry.
  */
 JF_API int jf_rs_probs(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride,
                 const int64_t *draft_next, float temperature, float *p_draft, float *row_max,
@@ -263,22 +271,26 @@ typedef struct jf_rs_row {
     int32_t rsv;
 } jf_rs_row;
 
-/* jf_rs_step: the sequential accept/reject of every row of a batch (JDN:581-639) in one launch.
+/* jf_rs_step: the sequential accept/reject of every row of a batch (JDN:581-639).
  *   draft [B, L]; logits [B*(L-1), V]; p_draft/row_max/row_sumexp/packed [B*(L-1)] from jf_rs_probs.
  *   Position t of row b is accepted iff u < p_draft (JDN:328-340); on the first rejection a bonus token != proposed is
- *   drawn by inverse CDF of softmax(logits/T) (float64 running sum in vocabulary order) with up to 16 draws
- *   (JDN:135-146), then argmax of the masked distribution (JDN:147-153).  Randomness is injected: u_stream /
- *   bonus_stream (floats in [0,1)) and pad_stream (token ids) are consumed cyclically from *cursor in row order,
- *   exactly where the reference calls torch.rand / torch.multinomial / torch.randint.
+ *   drawn by inverse CDF of p (float64 running sum in vocabulary order: smallest index whose sum exceeds u * total) with
+ *   up to 16 draws (JDN:135-146), then argmax of the masked distribution (JDN:147-153).  Randomness is injected:
+ *   u_stream / bonus_stream (floats in [0,1)) and pad_stream (token ids) are consumed cyclically from *cursor in row
+ *   order, exactly where the reference calls torch.rand / torch.multinomial / torch.randint.
  *   committed [B, L], next_draft [B, L] (JDN:444-466), rows [B].  packed is re-zeroed.
+ *   workspace: jf_rs_step_workspace_bytes(B) bytes (float64 segment sums of the rejected rows + a row list), 16-byte
+ *   aligned; contents need not be preserved between calls.
  */
+JF_API size_t jf_rs_step_workspace_bytes(int64_t rows);   /* rows = B (jf_rs_step) or R (jf_rs_onpolicy_step) */
 JF_API int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_stride, const int64_t *draft, int B, int L,
                const float *p_draft, const float *row_max, const float *row_sumexp, uint64_t *packed,
                float temperature, int32_t eos_id, const int32_t *remaining_tokens,
                const float *u_stream, int64_t u_len, int64_t *u_cursor,
                const float *bonus_stream, int64_t bonus_len, int64_t *bonus_cursor,
                const int64_t *pad_stream, int64_t pad_len, int64_t *pad_cursor,
-               int64_t *committed, int64_t *next_draft, jf_rs_row *rows, void *stream);
+               int64_t *committed, int64_t *next_draft, jf_rs_row *rows,
+               void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * On-policy rollout step, JDO = inference_engine/engine/jacobi_decoding_nongreedy_on_policy.py.
@@ -288,7 +300,7 @@ JF_API int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_stri
  *           (inverse CDF, <= 16 draws, then masked argmax: JDO:157-168) and stop; a committed token in
  *           stop_ids[n_stop] ends the block (stop_hit).
  *   redraft (JDO:465-477): if not stopped and n_committed < R, rows n_committed..R-1 each draw one sample
- *           from softmax(logits[row] / T) -> redraft[row] (the block's new guesses).
+ *           from p[row] (inverse CDF as above) -> redraft[row] (the block's new guesses).
  * u_stream feeds the accept tests (torch.rand), m_stream every multinomial draw (bonus draws first, then
  * the re-draft rows in order), both consumed cyclically from *cursor, which is advanced.  packed is re-zeroed.
  */
@@ -308,7 +320,8 @@ JF_API int jf_rs_onpolicy_step(const void *logits, int dtype, int64_t V, int64_t
                         float temperature, const int32_t *stop_ids, int n_stop,
                         const float *u_stream, int64_t u_len, int64_t *u_cursor,
                         const float *m_stream, int64_t m_len, int64_t *m_cursor,
-                        int64_t *committed /* [R] */, int64_t *redraft /* [R] */, jf_op_row *row, void *stream);
+                        int64_t *committed /* [R] */, int64_t *redraft /* [R] */, jf_op_row *row,
+                        void *workspace /* jf_rs_step_workspace_bytes(R) */, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

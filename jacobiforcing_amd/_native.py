@@ -87,9 +87,10 @@ _SIGNATURES = {
     "jf_rs_probs": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "jf_rs_workspace_bytes": (_sz, [_i64, _i64]),
     "jf_rs_step": (C.c_int, [_vp, C.c_int, _i64, _i64, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _f32, _i32, _vp,
-                             _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+                             _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "jf_rs_step_workspace_bytes": (_sz, [_i64]),
     "jf_rs_onpolicy_step": (C.c_int, [_vp, C.c_int, _i64, _i64, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_float, _vp, C.c_int,
-                                      _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+                                      _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

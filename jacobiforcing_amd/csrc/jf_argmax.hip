@@ -263,28 +263,35 @@ extern "C" int jf_argmax_rows(const void *logits, int dtype, int64_t R, int64_t 
 // ------------------------------------------------------------------------------------------------
 // (a3) accepted-prefix scan
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void accept_lengths_kernel(const int64_t *draft, int draft_rows, const int64_t *greedy,
-                                                              int64_t greedy_stride, int B, int L, int32_t *accepted,
-                                                              int32_t *best_idx) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int b = wave; b < B; b += 4) {
+__global__ __launch_bounds__(1024) void accept_lengths_kernel(const int64_t *draft, int draft_rows, const int64_t *greedy,
+                                                               int64_t greedy_stride, int B, int L, int32_t *accepted,
+                                                               int32_t *best_idx) {
+    // one wavefront per row (16 rows in flight), first mismatch = ballot + first set bit per 64 tokens; the best row
+    // (largest accepted, then lowest index: torch.argmax, MB:489) is one packed-u64 max over the rows
+    __shared__ unsigned long long s_best[16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    unsigned long long best = 0ull;
+    for (int b = wave; b < B; b += nw) {
         const int64_t *d = draft + (int64_t)(draft_rows == 1 ? 0 : b) * L;
         const int64_t *g = greedy + (int64_t)b * greedy_stride;
         int m = L - 1;
-        for (int i0 = 0; i0 < L - 1; i0 += 64) {   // ballot + first-set-bit per 64 tokens
+        for (int i0 = 0; i0 < L - 1; i0 += 64) {
             const int i = i0 + lane;
             const bool mis = (i < L - 1) && (d[i + 1] != g[i]);
             const unsigned long long bal = __ballot(mis);
             if (bal) { m = i0 + __ffsll((long long)bal) - 1; break; }
         }
-        if (lane == 0) accepted[b] = (L == 0) ? 0 : m + 1;
+        const int acc = (L == 0) ? 0 : m + 1;
+        if (lane == 0) accepted[b] = acc;
+        const unsigned long long k = ((unsigned long long)(uint32_t)(acc + 1) << 32) | (unsigned long long)(~(uint32_t)b);
+        best = k > best ? k : best;
     }
+    if (lane == 0) s_best[wave] = best;
     __syncthreads();
     if (threadIdx.x == 0 && best_idx) {
-        int best = -1, bi = 0;
-        for (int b = 0; b < B; ++b)
-            if (accepted[b] > best) { best = accepted[b]; bi = b; }
-        *best_idx = bi;
+        unsigned long long mm = 0ull;
+        for (int w = 0; w < nw; ++w) mm = s_best[w] > mm ? s_best[w] : mm;
+        *best_idx = mm ? (int32_t)(~(uint32_t)(mm & 0xFFFFFFFFull)) : 0;
     }
 }
 
@@ -295,7 +302,8 @@ extern "C" int jf_accept_lengths(const int64_t *draft, int draft_rows, const int
     if (draft_rows != 1 && draft_rows != B)
         return fail(JF_E_INVALID, "jf_accept_lengths: draft rows %d do not broadcast against %d", draft_rows, B);
     if (L < 0 || greedy_stride < L - 1) return fail(JF_E_INVALID, "jf_accept_lengths: bad L/stride");
-    accept_lengths_kernel<<<1, 256, 0, (hipStream_t)stream>>>(draft, draft_rows, greedy, greedy_stride, B, L, accepted, best_idx);
+    const int threads = B >= 16 ? 1024 : 64 * (B < 1 ? 1 : B);
+    accept_lengths_kernel<<<1, threads, 0, (hipStream_t)stream>>>(draft, draft_rows, greedy, greedy_stride, B, L, accepted, best_idx);
     return check_launch("accept_lengths_kernel");
 }
 

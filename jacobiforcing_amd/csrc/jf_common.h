@@ -161,14 +161,17 @@ template <bool KEEPV> struct FastTrack<JF_F32, KEEPV> {
     int32_t best = INT32_MIN, mn = INT32_MAX;
     uint32_t bvec = 0xFFFFFFFFu;
     u32x4 bv = {0u, 0u, 0u, 0u};     // KEEPV: the best vector itself (saves the end-of-item reload, costs 4 selects per vector)
-    __device__ __forceinline__ void consume(const u32x4 v, uint32_t i) {
+    // returns the vector's largest key (the softmax kernels derive their running maximum from it)
+    __device__ __forceinline__ int32_t consume_ret(const u32x4 v, uint32_t i) {
         const int32_t k0 = skey32(v.x), k1 = skey32(v.y), k2 = skey32(v.z), k3 = skey32(v.w);
         int32_t m = max(max(k0, k1), max(k2, k3));
         mn = min(mn, min(min(k0, k1), min(k2, k3)));
         m = (m == -1) ? 0 : m;
         if constexpr (KEEPV) { if (m > best) { best = m; bvec = i; bv = v; } }
         else { if (m > best) { best = m; bvec = i; } }
+        return m;
     }
+    __device__ __forceinline__ void consume(const u32x4 v, uint32_t i) { (void)consume_ret(v, i); }
     __device__ __forceinline__ bool saw_nan() const { return best > (int32_t)0x7F800000 || mn < (int32_t)0x807FFFFF; }
     // first element of the vector at bvec whose canonical key equals best
     __device__ __forceinline__ uint32_t resolve(const void *p) const {
@@ -187,7 +190,7 @@ template <bool KEEPV> struct FastTrack<JF_BF16, KEEPV> {
     uint32_t mnp = 0x7FFF7FFFu;     // packed running min
     uint32_t bvec = 0xFFFFFFFFu;
     u32x4 bv = {0u, 0u, 0u, 0u};     // KEEPV: the best vector itself (saves the end-of-item reload, costs 4 selects per vector)
-    __device__ __forceinline__ void consume(const u32x4 v, uint32_t i) {
+    __device__ __forceinline__ int32_t consume_ret(const u32x4 v, uint32_t i) {
         const uint32_t k0 = skey16x2(v.x), k1 = skey16x2(v.y), k2 = skey16x2(v.z), k3 = skey16x2(v.w);
         const uint32_t pm = pk_max_i16(pk_max_i16(k0, k1), pk_max_i16(k2, k3));
         mnp = pk_min_i16(mnp, pk_min_i16(pk_min_i16(k0, k1), pk_min_i16(k2, k3)));
@@ -195,7 +198,9 @@ template <bool KEEPV> struct FastTrack<JF_BF16, KEEPV> {
         m = (m == -1) ? 0 : m;
         if constexpr (KEEPV) { if (m > best) { best = m; bvec = i; bv = v; } }
         else { if (m > best) { best = m; bvec = i; } }
+        return m;
     }
+    __device__ __forceinline__ void consume(const u32x4 v, uint32_t i) { (void)consume_ret(v, i); }
     __device__ __forceinline__ bool saw_nan() const { return best > 0x7F80 || hmin_i16x2(mnp) < (int32_t)(int16_t)0x807F; }
     __device__ __forceinline__ uint32_t resolve(const void *p) const {
         u32x4 v;

@@ -2,49 +2,62 @@
 #include "jf_common.h"
 
 // ------------------------------------------------------------------------------------------------
-// engine single-block step: 4 wavefronts take the rows round-robin, then one pass hands out pads
+// engine single-block step (JD:567-710): one wavefront per row, then one small launch hands out the pads
 // ------------------------------------------------------------------------------------------------
-struct WaveLanes {   // one wavefront inside a 256-thread workgroup; no workgroup barrier inside a row
-    __device__ __forceinline__ int lane() const { return threadIdx.x & 63; }
-    __device__ __forceinline__ int count() const { return 64; }
-    __device__ __forceinline__ void sync() const {}
-    __device__ __forceinline__ int reduce_min(int v) const { return wave_min_i32(v); }
-    __device__ __forceinline__ int reduce_sum(int v) const { return wave_sum_i32(v); }
-};
+// Rows are independent except for the pad stream, which the reference consumes in row order (JD:705-707 calls
+// torch.randint per row): launch 1 runs every row on its own wavefront (accept scan = one ballot per 64 tokens), launch 2
+// turns the rows' pad counts into stream offsets with a wavefront scan and fills all pads in parallel.  A dependent
+// launch boundary (~1.5 us) is cheaper than an in-kernel agent-scope fence + arrival counter (~3.5 us per workgroup).
+__global__ __launch_bounds__(64) void engine_rows_kernel(const int64_t *draft, int L, const unsigned long long *packed, int eos_id,
+                                                          const int32_t *remaining, int64_t *new_tokens, int64_t *next_draft,
+                                                          jf_engine_row *rows) {
+    const int b = blockIdx.x;
+    const unsigned long long *pk = packed + (int64_t)b * (L - 1);
+    auto G = [pk](int i) { return jfmb::decode_packed(pk[i]); };
+    jfmb::EngineRowOut o = jfmb::engine_row_body(DevLanes{}, draft + (int64_t)b * L, L, G, eos_id, remaining[b],
+                                                 new_tokens + (int64_t)b * L, next_draft + (int64_t)b * L);
+    if (threadIdx.x == 0) {
+        rows[b].acc_len = o.acc_len; rows[b].n_new = o.n_new; rows[b].eos = o.eos; rows[b].active_next = o.active_next;
+        rows[b].n_pads = o.active_next ? (L - 1 - o.copy_len) : 0;
+        rows[b].rsv[0] = o.copy_len; rows[b].rsv[1] = 0; rows[b].rsv[2] = 0;
+    }
+}
 
-__global__ __launch_bounds__(256) void engine_step_kernel(const int64_t *draft, int B, int L, unsigned long long *packed,
-                                                           int eos_id, const int32_t *remaining, int64_t *new_tokens,
-                                                           int64_t *next_draft, const int64_t *pad_stream, int64_t pad_len,
-                                                           int64_t *pad_cursor, jf_engine_row *rows) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int b = wave; b < B; b += 4) {
-        const unsigned long long *pk = packed + (int64_t)b * (L - 1);
-        auto G = [pk](int i) { return jfmb::decode_packed(pk[i]); };
-        jfmb::EngineRowOut o = jfmb::engine_row_body(WaveLanes{}, draft + (int64_t)b * L, L, G, eos_id, remaining[b],
-                                                     new_tokens + (int64_t)b * L, next_draft + (int64_t)b * L);
-        if (lane == 0) {
-            rows[b].acc_len = o.acc_len; rows[b].n_new = o.n_new; rows[b].eos = o.eos; rows[b].active_next = o.active_next;
-            rows[b].n_pads = o.active_next ? (L - 1 - o.copy_len) : 0;
-            rows[b].rsv[0] = o.copy_len;
+__global__ __launch_bounds__(256) void engine_pads_kernel(int B, int L, unsigned long long *packed, int64_t *next_draft,
+                                                           const int64_t *pad_stream, int64_t pad_len, int64_t *pad_cursor,
+                                                           jf_engine_row *rows) {
+    __shared__ int s_total;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < 64) {                                         // exclusive scan of n_pads in row order, 64 rows per pass
+        int run = 0;
+        for (int b0 = 0; b0 < B; b0 += 64) {
+            const int b = b0 + lane;
+            const int np = b < B ? rows[b].n_pads : 0;
+            int x = np;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(x, off, 64);
+                if (lane >= off) x += o;
+            }
+            if (b < B) rows[b].rsv[1] = run + x - np;
+            run += __shfl(x, 63, 64);
         }
+        if (lane == 0) s_total = run;
     }
     __syncthreads();
-    // pads in row order (JD:705-707 consumes torch.randint sequentially): exclusive scan over rows
-    __shared__ int64_t s_base;
-    if (threadIdx.x == 0) s_base = *pad_cursor;
-    __syncthreads();
-    int64_t run = s_base;
-    for (int b = 0; b < B; ++b) {
+    const int64_t base = *pad_cursor;
+    for (int64_t idx = tid; idx < (int64_t)B * (L - 1); idx += 256) {
+        const int b = (int)(idx / (L - 1)), i = (int)(idx - (int64_t)b * (L - 1));
         const int np = rows[b].n_pads, cl = rows[b].rsv[0];
-        for (int i = threadIdx.x; i < np; i += blockDim.x) {
-            const int64_t k = run + i;
+        if (i < np) {
+            const int64_t k = base + rows[b].rsv[1] + i;
             next_draft[(int64_t)b * L + 1 + cl + i] = pad_stream[pad_len > 0 ? (k % pad_len) : 0];
         }
-        run += np;
+        packed[idx] = 0ull;                                  // consumed by engine_rows_kernel: ready for the next argmax
     }
     __syncthreads();
-    if (threadIdx.x == 0) *pad_cursor = run;
-    for (int64_t i = threadIdx.x; i < (int64_t)B * (L - 1); i += blockDim.x) packed[i] = 0ull;
+    for (int b = tid; b < B; b += 256) rows[b].rsv[1] = 0;
+    if (tid == 0) *pad_cursor = base + s_total;
 }
 
 extern "C" int jf_engine_step(const int64_t *draft, int B, int L, uint64_t *packed, int32_t eos_id, const int32_t *remaining_tokens,
@@ -54,9 +67,10 @@ extern "C" int jf_engine_step(const int64_t *draft, int B, int L, uint64_t *pack
     if (L < 2) return fail(JF_E_INVALID, "Draft must have at least 2 tokens (seed + 1 speculative)");   // MR:1144-1145
     if (!draft || !packed || !remaining_tokens || !new_tokens || !next_draft || !pad_cursor || !rows || (!pad_stream && pad_stream_len > 0))
         return fail(JF_E_INVALID, "jf_engine_step: null pointer");
-    engine_step_kernel<<<1, 256, 0, (hipStream_t)stream>>>(draft, B, L, (unsigned long long *)packed, eos_id, remaining_tokens,
-                                                        new_tokens, next_draft, pad_stream, pad_stream_len, pad_cursor, rows);
-    return check_launch("engine_step_kernel");
+    hipStream_t s = (hipStream_t)stream;
+    engine_rows_kernel<<<B, 64, 0, s>>>(draft, L, (const unsigned long long *)packed, eos_id, remaining_tokens, new_tokens, next_draft, rows);
+    engine_pads_kernel<<<1, 256, 0, s>>>(B, L, (unsigned long long *)packed, next_draft, pad_stream, pad_stream_len, pad_cursor, rows);
+    return check_launch("engine_step kernels");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,43 +1,137 @@
 // jf_sampling.hip — (a19) non-greedy verify: fused softmax-gather + argmax (jf_rs_probs), the batch accept / bonus / finish
 // step (jf_rs_step) and the on-policy rollout step (jf_rs_onpolicy_step).
+//
+// dtype is part of the semantics (JDN = inference_engine/engine/jacobi_decoding_nongreedy.py):
+//   JF_F32   probabilities are a float32 softmax of logits * (1/T): p = expf(x/T - M) / S.
+//   JF_BF16  the reference never widens the engine's bf16 logits (MR:1382, JDN:64-70), so torch rounds after every op:
+//            xs = bf16(float(x) / float(T))  (skipped when T == 1, JDN:68; ATen div_true_kernel: correctly rounded
+//            float32 quotient, then one rounding to bf16), p = bf16(expf(xs - M) / S) with M = max xs, S = sum expf(xs - M)
+//            in float32.  `u < p`, the inverse-CDF walk of the bonus / re-draft draws and the masked argmax all work on the
+//            ROUNDED probabilities, exactly like the reference's `probs` tensor.
 #include "jf_common.h"
 
 // ------------------------------------------------------------------------------------------------
-// (a19) non-greedy verify: fused online-softmax gather + argmax, logits read once
+// numeric helpers
 // ------------------------------------------------------------------------------------------------
-// Stage 1 — one workgroup per (row, chunk): 16 B per lane per load, four vectors (16/32 elements) per lane per round.
-// (hot loop: hardware v_exp_f32 via __expf, ~1e-6 relative; the verify tolerance is 2e-5)
-// Per round the lane first raises its running max over the whole round (register-resident values), rescales its sum once,
-// then adds exp(x - m) for every element: one exp per element plus one per round, branch-free.  The argmax tracker runs on
-// the same registers.  Partials (m, s) go to the workspace, the argmax to `packed` by atomicMax.
-template <int DT, int NV>
-__device__ __forceinline__ void rs_round(const u32x4 (&vv)[NV], float cs, float &m, float &s) {
-    // (m, s) live in the scaled log2 domain: x' = w * cs with cs = log2(e) / T, s = sum of 2^(x' - m); one multiply and one
-    // v_exp_f32 per element (exp(x/T - M) == 2^(x' - m) up to the rounding of the product)
+__device__ __forceinline__ float bf16_rne(float x) {         // nearest bfloat16 (ties to even), as a float
+    uint32_t u = __float_as_uint(x);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return x;          // NaN stays NaN
+    u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+    return __uint_as_float(u);
+}
+
+// temperature-scaled logit, exactly as torch forms it for this dtype
+template <int DT>
+__device__ __forceinline__ float rs_scaled(float x, float t, float inv_t, bool unit_t) {
+    if constexpr (DT == JF_F32) return x * inv_t;
+    else return unit_t ? x : bf16_rne(__fdiv_rn(x, t));
+}
+// probability of one element given the row statistics
+template <int DT>
+__device__ __forceinline__ float rs_prob(float xs, float M, float S) {
+    const float p = expf(xs - M) / S;
+    if constexpr (DT == JF_BF16) return bf16_rne(p);
+    else return p;
+}
+
+struct RsRow {                 // one logits row + what is needed to turn an element into its probability
+    const void *p;
+    int64_t V;
+    float t, inv_t, M, S;
+    bool unit_t, vec;          // vec: 16-byte aligned row -> vector loads
+};
+template <int DT>
+__device__ __forceinline__ float rs_prob_at(const RsRow &r, int64_t i) {
+    return rs_prob<DT>(rs_scaled<DT>(load_f<DT>(r.p, i), r.t, r.inv_t, r.unit_t), r.M, r.S);
+}
+template <int DT>
+__device__ __forceinline__ void rs_unpack(const u32x4 v, float (&x)[Elem<DT>::EPV]) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if constexpr (DT == JF_F32) x[j] = __uint_as_float(w[j]);
+        else { x[2 * j] = __uint_as_float(w[j] << 16); x[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u); }
+    }
+}
+// probabilities of the EPV elements starting at element e0 (a multiple of EPV); elements >= V give 0
+template <int DT>
+__device__ __forceinline__ void rs_probs_of_vec(const RsRow &r, int64_t e0, float (&p)[Elem<DT>::EPV]) {
+    constexpr int EPV = Elem<DT>::EPV;
+    if (r.vec && e0 + EPV <= r.V) {
+        float x[EPV];
+        rs_unpack<DT>(*((const u32x4 *)r.p + e0 / EPV), x);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) p[j] = rs_prob<DT>(rs_scaled<DT>(x[j], r.t, r.inv_t, r.unit_t), r.M, r.S);
+    } else {
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) p[j] = (e0 + j < r.V) ? rs_prob_at<DT>(r, e0 + j) : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// (a19) stage 1 — fused online-softmax + argmax, logits read once
+// ------------------------------------------------------------------------------------------------
+// One workgroup per (row, chunk): 16 B per lane per load, eight loads in flight, processed as two rounds of four vectors
+// (32 bf16 / 16 fp32 elements per lane per round).  Per round the lane's maximum comes out of the argmax tracker's packed
+// integer keys (no float compare per element), the running sum is rescaled once, and every element costs an unpack, one
+// fma and one v_exp_f32:  2^(x*cs - m)  with cs = log2(e) [/ T].  (m, s) live in that scaled log2 domain; partials
+// (raw chunk max, s) go to the workspace, the argmax to `packed` by atomicMax.
+//   SCALE 0: T == 1 (either dtype)           cs = log2 e
+//   SCALE 1: JF_F32, T != 1                  cs = log2 e / T  (x * (1/T), today's fp32 behaviour)
+//   SCALE 2: JF_BF16, T != 1                 xs = bf16(x / T) formed exactly: x * (1/T) decides the rounding unless it lies
+//                                            within 3 ulp of a bf16 tie, then the correctly rounded quotient does.
+__device__ __forceinline__ float scale_bf16_fast(float x, float inv_t, bool &amb) {
+    const uint32_t q = __float_as_uint(x * inv_t);
+    amb = amb || (((q + 0x8003u) & 0xFFFFu) <= 6u);          // low half within [0x7FFD, 0x8003]
+    return __uint_as_float((q + 0x8000u) & 0xFFFF0000u);     // nearest; exact whenever not flagged (no tie possible there)
+}
+
+template <int DT> __device__ __forceinline__ float key_max_to_float(int32_t k);
+template <> __device__ __forceinline__ float key_max_to_float<JF_F32>(int32_t k) {
+    return __uint_as_float((uint32_t)k ^ (((uint32_t)(k >> 31)) & 0x7FFFFFFFu));
+}
+template <> __device__ __forceinline__ float key_max_to_float<JF_BF16>(int32_t k) {
+    const uint32_t h = ((uint32_t)k ^ (((uint32_t)(k >> 15)) & 0x7FFFu)) & 0xFFFFu;
+    return __uint_as_float(h << 16);
+}
+
+template <int DT, int SCALE, int NV, class FT>
+__device__ __forceinline__ void rs_round(const u32x4 (&vv)[NV], FT &ft, uint32_t idx0, uint32_t idx_step, float cs, float t,
+                                         float inv_t, float &m, float &s) {
     constexpr int EPV = Elem<DT>::EPV;
     constexpr int NE = NV * EPV;
+    int32_t kmax = INT32_MIN;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) { const int32_t k = ft.consume_ret(vv[u], idx0 + u * idx_step); kmax = k > kmax ? k : kmax; }
     float x[NE];
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
-        const uint32_t w[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+        float xv[EPV];
+        rs_unpack<DT>(vv[u], xv);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if constexpr (DT == JF_F32) {
-                x[u * 4 + j] = __uint_as_float(w[j]) * cs;
-            } else {
-                x[u * 8 + 2 * j] = __uint_as_float(w[j] << 16) * cs;
-                x[u * 8 + 2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u) * cs;
-            }
-        }
+        for (int j = 0; j < EPV; ++j) x[u * EPV + j] = xv[j];
     }
-    float mx = x[0];
+    float xmax = key_max_to_float<DT>(kmax);                 // the round's largest raw value (NaN if the round holds one)
+    if constexpr (SCALE == 2) {
+        bool amb = false;
+        float xs[NE];
 #pragma unroll
-    for (int j = 1; j < NE; ++j) mx = fmaxf(mx, x[j]);
-    const float mn = fmaxf(m, mx);
-    if (mn == -INFINITY) return;                        // nothing finite yet: keep (m, s) = (-inf, 0), never form inf - inf
+        for (int j = 0; j < NE; ++j) xs[j] = scale_bf16_fast(x[j], inv_t, amb);
+        if (amb) {                                           // ~1e-4 of the elements: settle the whole round exactly
+#pragma unroll
+            for (int j = 0; j < NE; ++j) xs[j] = bf16_rne(__fdiv_rn(x[j], t));
+        }
+#pragma unroll
+        for (int j = 0; j < NE; ++j) x[j] = xs[j];
+        xmax = bf16_rne(__fdiv_rn(xmax, t));
+    }
+    const float mr = xmax * cs;                              // monotone: the round's largest scaled value
+    const float mn = fmaxf(m, mr);
+    if (mn == -INFINITY) return;                             // nothing finite yet: keep (m, s) = (-inf, 0), never form inf - inf
     float acc = (m == -INFINITY) ? 0.f : s * __builtin_amdgcn_exp2f(m - mn);
+    const float nm = -mn;
 #pragma unroll
-    for (int j = 0; j < NE; ++j) acc += __builtin_amdgcn_exp2f(x[j] - mn);
+    for (int j = 0; j < NE; ++j) acc += __builtin_amdgcn_exp2f(fmaf(x[j], cs, nm));
     s = acc;
     m = mn;
 }
@@ -47,9 +141,9 @@ __device__ __forceinline__ float key_to_float(uint32_t k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
-template <int DT, bool VEC>
+template <int DT, bool VEC, int SCALE>
 __global__ __launch_bounds__(256) void rs_probs_partial_kernel(const void *logits, int64_t R, int64_t V, int64_t row_stride,
-                                                                float inv_t, float2 *__restrict__ partial,
+                                                                float t, float inv_t, float2 *__restrict__ partial,
                                                                 unsigned long long *packed, int cpr, int64_t chunk_elems) {
     using E = Elem<DT>;
     constexpr int EPV = E::EPV;
@@ -61,7 +155,7 @@ __global__ __launch_bounds__(256) void rs_probs_partial_kernel(const void *logit
     if (end > V) end = V;
     const typename E::T *p = (const typename E::T *)logits + row * row_stride;
     const int tid = threadIdx.x;
-    const float cs = inv_t * 1.44269504088896340736f;     // log2(e) / T
+    const float cs = (SCALE == 1 ? inv_t : 1.f) * 1.44269504088896340736f;
     float m = -INFINITY, s = 0.f;
     uint32_t best = 0u, bidx = 0xFFFFFFFFu;
     int64_t done = begin;
@@ -71,16 +165,15 @@ __global__ __launch_bounds__(256) void rs_probs_partial_kernel(const void *logit
         const uint32_t ebase = (uint32_t)begin;
         FastTrack<DT, true> ft;                          // same vector-granular argmax tracker as the greedy kernel
         int k = tid;
-        for (; k + 3 * 256 < nvec; k += 4 * 256, q += 4 * 256) {
-            const u32x4 vv[4] = {JF_LOAD(q), JF_LOAD(q + 256), JF_LOAD(q + 512), JF_LOAD(q + 768)};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) ft.consume(vv[u], ebase + (uint32_t)(k + u * 256) * EPV);
-            rs_round<DT, 4>(vv, cs, m, s);
+        for (; k + 7 * 256 < nvec; k += 8 * 256, q += 8 * 256) {
+            const u32x4 va[4] = {JF_LOAD(q), JF_LOAD(q + 256), JF_LOAD(q + 512), JF_LOAD(q + 768)};
+            const u32x4 vb[4] = {JF_LOAD(q + 1024), JF_LOAD(q + 1280), JF_LOAD(q + 1536), JF_LOAD(q + 1792)};
+            rs_round<DT, SCALE, 4>(va, ft, ebase + (uint32_t)k * EPV, 256u * EPV, cs, t, inv_t, m, s);
+            rs_round<DT, SCALE, 4>(vb, ft, ebase + (uint32_t)(k + 1024) * EPV, 256u * EPV, cs, t, inv_t, m, s);
         }
         for (; k < nvec; k += 256, q += 256) {          // this lane's remaining vectors, one at a time
             const u32x4 vv[1] = {JF_LOAD(q)};
-            ft.consume(vv[0], ebase + (uint32_t)k * EPV);
-            rs_round<DT, 1>(vv, cs, m, s);
+            rs_round<DT, SCALE, 1>(vv, ft, ebase + (uint32_t)k * EPV, 0u, cs, t, inv_t, m, s);
         }
         done = begin + (int64_t)nvec * EPV;
         if (__syncthreads_or(ft.saw_nan() ? 1 : 0)) {
@@ -93,7 +186,9 @@ __global__ __launch_bounds__(256) void rs_probs_partial_kernel(const void *logit
     for (int64_t i = done + tid; i < end; i += 256) {    // unaligned rows / ragged tail (V % EPV)
         const uint32_t kk = load_key<DT>(p, i);
         if (kk > best) { best = kk; bidx = (uint32_t)i; }
-        const float xv = load_f<DT>(p, i) * cs;
+        float xv = load_f<DT>(p, i);
+        if constexpr (SCALE == 2) xv = bf16_rne(__fdiv_rn(xv, t));
+        xv *= cs;
         if (xv > m) { s = (m == -INFINITY ? 0.f : s * __builtin_amdgcn_exp2f(m - xv)) + 1.f; m = xv; }
         else if (xv != -INFINITY) s += __builtin_amdgcn_exp2f(xv - m);
     }
@@ -117,8 +212,8 @@ __global__ __launch_bounds__(256) void rs_probs_partial_kernel(const void *logit
         for (int i = 0; i < 4; ++i) Ssum += (sm[i] == -INFINITY) ? 0.f : ss[i] * exp2f(sm[i] - M);
         uint64_t mm = sp[0];
         for (int w = 1; w < 4; ++w) mm = sp[w] > mm ? sp[w] : mm;
-        // the chunk's RAW maximum (from the argmax key) and its sum relative to fl(raw max * cs) == M: multiplying by a
-        // positive constant is monotone, so the largest scaled value belongs to the largest raw value
+        // the chunk's RAW maximum (from the argmax key) and its sum relative to M == fl(scaled(raw max) * cs): scaling and
+        // the multiply are monotone, so the largest scaled value belongs to the largest raw value
         partial[item] = make_float2(M == -INFINITY ? -INFINITY : key_to_float((uint32_t)(mm >> 32)), Ssum);
         atomicMax(packed + row, (unsigned long long)mm);
     }
@@ -127,31 +222,44 @@ __global__ __launch_bounds__(256) void rs_probs_partial_kernel(const void *logit
 // Stage 2 — one thread per row: merge the chunk partials, then the gathered probability of the drafted id.
 template <int DT>
 __global__ __launch_bounds__(256) void rs_probs_finish_kernel(const void *logits, int64_t R, int64_t V, int64_t row_stride,
-                                                               const int64_t *draft_next, float inv_t, const float2 *partial,
+                                                               const int64_t *draft_next, float t, float inv_t, const float2 *partial,
                                                                int cpr, float *p_draft, float *row_max, float *row_sumexp) {
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= R) return;
-    const float cs = inv_t * 1.44269504088896340736f;
+    const bool unit_t = (t == 1.f);
+    const float cs = ((DT == JF_F32 && !unit_t) ? inv_t : 1.f) * 1.44269504088896340736f;
+    // the same (scale, * cs) composition stage 1 applied to its running maxima
+    auto mdom = [&](float raw) { return ((DT == JF_BF16 && !unit_t) ? bf16_rne(__fdiv_rn(raw, t)) : raw) * cs; };
     float Mraw = -INFINITY;
     for (int c = 0; c < cpr; ++c) Mraw = fmaxf(Mraw, partial[row * cpr + c].x);
+    const float mM = mdom(Mraw);
     float S = 0.f;
     for (int c = 0; c < cpr; ++c) {
         const float2 ps = partial[row * cpr + c];
-        S += (ps.x == -INFINITY) ? 0.f : ps.y * exp2f(ps.x * cs - Mraw * cs);
+        S += (ps.x == -INFINITY) ? 0.f : ps.y * exp2f(mdom(ps.x) - mM);
     }
-    const float M = Mraw * inv_t;                         // consumers form exp(x * inv_t - M): exactly 1 at the maximum
+    const float M = rs_scaled<DT>(Mraw, t, inv_t, unit_t);    // consumers form expf(xs - M): exactly 1 at the maximum
     row_max[row] = M;
     row_sumexp[row] = S;
     const int64_t tok = draft_next[row];
     const void *p = (const char *)logits + row * row_stride * (DT == JF_F32 ? 4 : 2);
-    p_draft[row] = (tok >= 0 && tok < V) ? expf(load_f<DT>(p, tok) * inv_t - M) / S : 0.f;
+    p_draft[row] = (tok >= 0 && tok < V) ? rs_prob<DT>(rs_scaled<DT>(load_f<DT>(p, tok), t, inv_t, unit_t), M, S) : 0.f;
+}
+
+struct RsTune { int64_t items; };
+static const RsTune &rs_tune() {                            // read once: sweeps in tools/ set it before the first call
+    static const RsTune t = [] {
+        RsTune r{1024};                                     // measured: fewer, longer items win (profiles/rs_probs_microbench_*.txt)
+        const char *e = getenv("JF_RS_ITEMS");
+        if (e && *e) { const long long v = atoll(e); if (v >= 1 && v <= (1 << 20)) r.items = v; }
+        return r;
+    }();
+    return t;
 }
 
 static int64_t rs_chunk(int dtype, int64_t R, int64_t V, int64_t *cpr_out) {
-    const int64_t gran = 4 * (int64_t)256 * (dtype == JF_F32 ? 4 : 8);     // one full round per workgroup
-    const char *e = getenv("JF_RS_ITEMS");                                  // workgroups to aim for (sweeps in tools/)
-    const int64_t target = (e && *e) ? atoll(e) : 1024;                 // measured: fewer, longer items win (profiles/rs_probs_microbench_r01.txt)
-    int64_t per_row = (target + R - 1) / R;
+    const int64_t gran = 8 * (int64_t)256 * (dtype == JF_F32 ? 4 : 8);     // one full eight-vector batch per workgroup
+    int64_t per_row = (rs_tune().items + R - 1) / R;
     if (per_row < 1) per_row = 1;
     if (per_row > 64) per_row = 64;
     int64_t chunk = (V + per_row - 1) / per_row;
@@ -172,6 +280,7 @@ extern "C" int jf_rs_probs(const void *logits, int dtype, int64_t R, int64_t V, 
     if (!logits || !draft_next || !p_draft || !row_max || !row_sumexp || !packed || !workspace)
         return fail(JF_E_INVALID, "jf_rs_probs: null pointer");
     if (dtype != JF_F32 && dtype != JF_BF16) return fail(JF_E_INVALID, "jf_rs_probs: dtype %d", dtype);
+    if (V <= 0 || V > 0x7FFFFFFFll || row_stride < V) return fail(JF_E_INVALID, "jf_rs_probs: bad shape V=%lld stride=%lld", (long long)V, (long long)row_stride);
     if (workspace_bytes < jf_rs_workspace_bytes(R, V)) return fail(JF_E_INVALID, "jf_rs_probs: workspace too small");
     const float t = (temperature <= 0.f) ? 1.f : temperature;    // JDN:66-67
     const float inv_t = 1.f / t;
@@ -183,147 +292,328 @@ extern "C" int jf_rs_probs(const void *logits, int dtype, int64_t R, int64_t V, 
     hipStream_t s = (hipStream_t)stream;
     unsigned long long *pk = (unsigned long long *)packed;
     float2 *part = (float2 *)workspace;
+    const bool unit = (t == 1.f);
+#define JF_RS_P(DT, VECF, SC) rs_probs_partial_kernel<DT, VECF, SC><<<grid, block, 0, s>>>(logits, R, V, row_stride, t, inv_t, part, pk, (int)cpr, chunk)
     if (dtype == JF_F32) {
-        if (vec) rs_probs_partial_kernel<JF_F32, true><<<grid, block, 0, s>>>(logits, R, V, row_stride, inv_t, part, pk, (int)cpr, chunk);
-        else rs_probs_partial_kernel<JF_F32, false><<<grid, block, 0, s>>>(logits, R, V, row_stride, inv_t, part, pk, (int)cpr, chunk);
-        rs_probs_finish_kernel<JF_F32><<<dim3((unsigned)((R + 255) / 256)), 256, 0, s>>>(logits, R, V, row_stride, draft_next, inv_t, part, (int)cpr, p_draft, row_max, row_sumexp);
+        if (vec) { if (unit) JF_RS_P(JF_F32, true, 0); else JF_RS_P(JF_F32, true, 1); }
+        else { if (unit) JF_RS_P(JF_F32, false, 0); else JF_RS_P(JF_F32, false, 1); }
+        rs_probs_finish_kernel<JF_F32><<<dim3((unsigned)((R + 255) / 256)), 256, 0, s>>>(logits, R, V, row_stride, draft_next, t, inv_t, part, (int)cpr, p_draft, row_max, row_sumexp);
     } else {
-        if (vec) rs_probs_partial_kernel<JF_BF16, true><<<grid, block, 0, s>>>(logits, R, V, row_stride, inv_t, part, pk, (int)cpr, chunk);
-        else rs_probs_partial_kernel<JF_BF16, false><<<grid, block, 0, s>>>(logits, R, V, row_stride, inv_t, part, pk, (int)cpr, chunk);
-        rs_probs_finish_kernel<JF_BF16><<<dim3((unsigned)((R + 255) / 256)), 256, 0, s>>>(logits, R, V, row_stride, draft_next, inv_t, part, (int)cpr, p_draft, row_max, row_sumexp);
+        if (vec) { if (unit) JF_RS_P(JF_BF16, true, 0); else JF_RS_P(JF_BF16, true, 2); }
+        else { if (unit) JF_RS_P(JF_BF16, false, 0); else JF_RS_P(JF_BF16, false, 2); }
+        rs_probs_finish_kernel<JF_BF16><<<dim3((unsigned)((R + 255) / 256)), 256, 0, s>>>(logits, R, V, row_stride, draft_next, t, inv_t, part, (int)cpr, p_draft, row_max, row_sumexp);
     }
+#undef JF_RS_P
     return check_launch("rs_probs kernels");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Inverse-CDF draws (the injected stand-in for torch.multinomial, JDN:126-153 / JDO:150-168): the smallest index whose
+// float64 running sum of probabilities, in vocabulary order, exceeds u * total.
+//
+// Two levels, both streaming the row with lane-contiguous 16-byte loads:
+//   rs_rowsum_kernel   RS_SEG workgroups per selected row; each sums one contiguous vocabulary segment in float64
+//                      (per-lane partials, one tree) -> segsum[row][seg].  The row is read ONCE however many draws follow.
+//   rs_pick (device)   one workgroup per draw: prefix over the RS_SEG segment sums -> the segment the threshold falls
+//                      into -> re-read that one segment (V / RS_SEG elements, L2-resident) with a wavefront scan per
+//                      2048/1024-element tile -> the crossing lane resolves inside its 8/4 elements.
+// ------------------------------------------------------------------------------------------------
+constexpr int RS_SEG = 16;
+constexpr int RS_TILES = 8;                       // tiles of a segment whose per-lane sums are kept in registers
+
+__host__ __device__ inline int64_t rs_seg_elems(int64_t V, int epv) {
+    const int64_t tile = 256 * (int64_t)epv;
+    const int64_t per = (V + RS_SEG - 1) / RS_SEG;
+    return ((per + tile - 1) / tile) * tile;
+}
+
+struct RsWs {                                     // carve-up of the step workspace for `rows` items
+    double *segsum;                               // [rows, RS_SEG]
+    int32_t *sel_row;                             // [rows] logits row to sum for item i, -1 = none
+};
+static inline size_t rs_ws_bytes(int64_t rows) { return (size_t)rows * RS_SEG * sizeof(double) + (((size_t)rows * 4 + 15) / 16) * 16; }
+__host__ __device__ inline RsWs rs_ws(void *ws, int64_t rows) {
+    RsWs w;
+    w.segsum = (double *)ws;
+    w.sel_row = (int32_t *)((char *)ws + (size_t)rows * RS_SEG * sizeof(double));
+    return w;
+}
+extern "C" size_t jf_rs_step_workspace_bytes(int64_t rows) { return rows > 0 ? rs_ws_bytes(rows) : 0; }
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_incl_scan_f64(double v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+template <int DT>
+__device__ __forceinline__ RsRow rs_make_row(const void *logits, int64_t r, int64_t V, int64_t row_stride, float t, float M, float S) {
+    RsRow rr;
+    const int esz = DT == JF_F32 ? 4 : 2;
+    rr.p = (const char *)logits + r * row_stride * esz;
+    rr.V = V; rr.t = t; rr.inv_t = 1.f / t; rr.M = M; rr.S = S;
+    rr.unit_t = (t == 1.f);
+    rr.vec = (((uintptr_t)rr.p) % 16) == 0;
+    return rr;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void rs_rowsum_kernel(const void *logits, int64_t V, int64_t row_stride, const float *row_max,
+                                                         const float *row_sumexp, float t, const int32_t *sel_row, double *segsum) {
+    constexpr int EPV = Elem<DT>::EPV;
+    const int item = blockIdx.x / RS_SEG, seg = blockIdx.x % RS_SEG;
+    const int r = sel_row[item];
+    if (r < 0) return;
+    const RsRow row = rs_make_row<DT>(logits, r, V, row_stride, t, row_max[r], row_sumexp[r]);
+    const int64_t segE = rs_seg_elems(V, EPV);
+    const int64_t lo = (int64_t)seg * segE;
+    int64_t hi = lo + segE;
+    if (hi > V) hi = V;
+    double acc = 0.0;
+    for (int64_t e0 = lo + (int64_t)threadIdx.x * EPV; e0 < hi; e0 += 256 * EPV) {
+        float p[EPV];
+        rs_probs_of_vec<DT>(row, e0, p);
+        double a = 0.0;
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) a += (double)p[j];
+        acc += a;
+    }
+    acc = wave_sum_f64(acc);
+    __shared__ double sw[4];
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) segsum[(int64_t)item * RS_SEG + seg] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+
+struct RsPickShared {
+    double seg[RS_SEG];
+    double wt[RS_TILES][4];
+    double wtx[4];
+    unsigned long long best[4];
+    int pick;
+};
+
+// One inverse-CDF draw by the whole workgroup (uniform control flow).  Returns the index for every thread.
+template <int DT>
+__device__ int rs_pick(const RsRow &row, const double *segsum /* global, RS_SEG */, float u, RsPickShared &sh) {
+    constexpr int EPV = Elem<DT>::EPV;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __syncthreads();                                        // sh may still be read by a previous draw
+    if (tid < RS_SEG) sh.seg[tid] = segsum[tid];
+    if (tid == 0) sh.pick = 0x7FFFFFFF;
+    __syncthreads();
+    double total = 0.0;
+#pragma unroll
+    for (int s = 0; s < RS_SEG; ++s) total += sh.seg[s];
+    const double thr = (double)u * total;
+    int sstar = -1;
+    double excl = 0.0, run = 0.0;
+#pragma unroll
+    for (int s = 0; s < RS_SEG; ++s) {
+        const double nx = run + sh.seg[s];
+        if (sstar < 0 && nx > thr) { sstar = s; excl = run; }
+        run = nx;
+    }
+    if (sstar < 0) return (int)(row.V - 1);                 // thr >= total: clamp like min(idx, V - 1)
+    const double thr_s = thr - excl;                        // threshold inside the segment
+    const int64_t segE = rs_seg_elems(row.V, EPV);
+    const int64_t lo = (int64_t)sstar * segE;
+    int64_t hi = lo + segE;
+    if (hi > row.V) hi = row.V;
+    const int ntiles = (int)((hi - lo + 256 * EPV - 1) / (256 * EPV));
+    // per-lane sums of the first RS_TILES tiles (independent loads), wavefront inclusive scans, wave totals to LDS
+    double incl[RS_TILES], lex[RS_TILES];                    // inclusive / exclusive running sums inside the wavefront
+#pragma unroll
+    for (int k = 0; k < RS_TILES; ++k) {
+        double a = 0.0;
+        if (k < ntiles) {
+            float p[EPV];
+            rs_probs_of_vec<DT>(row, lo + ((int64_t)k * 256 + tid) * EPV, p);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) a += (double)p[j];
+        }
+        incl[k] = wave_incl_scan_f64(a, lane);
+        const double up = __shfl_up(incl[k], 1, 64);        // all lanes active here: never shuffle under the crossing test
+        lex[k] = lane == 0 ? 0.0 : up;
+        if (lane == 63) sh.wt[k][wave] = incl[k];
+    }
+    __syncthreads();
+    double base = 0.0;                                      // running sum of everything before tile k
+    bool found = false;
+    int cand = 0x7FFFFFFF;
+    auto resolve = [&](int k, double ex) {                  // first element of this lane's vector in tile k whose running sum crosses
+        float p[EPV];
+        const int64_t e0 = lo + ((int64_t)k * 256 + tid) * EPV;
+        rs_probs_of_vec<DT>(row, e0, p);
+        double rr = ex;
+        int lastpos = -1, hit = -1;
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+            rr += (double)p[j];
+            if (p[j] > 0.f) lastpos = j;
+            if (hit < 0 && rr > thr_s) hit = j;
+        }
+        if (hit < 0) hit = lastpos >= 0 ? lastpos : EPV - 1;   // rounding only: the scan said this lane crosses
+        int64_t e = e0 + hit;
+        if (e >= row.V) e = row.V - 1;
+        return (int)e;
+    };
+#pragma unroll
+    for (int k = 0; k < RS_TILES; ++k) {
+        if (k < ntiles) {
+            double wb = base;
+            for (int w = 0; w < wave; ++w) wb += sh.wt[k][w];
+            if (!found && wb + incl[k] > thr_s) { cand = resolve(k, wb + lex[k]); found = true; }
+            base += (sh.wt[k][0] + sh.wt[k][1]) + (sh.wt[k][2] + sh.wt[k][3]);
+        }
+    }
+    // segments longer than RS_TILES tiles (V > 16 * 8 * 2048 bf16 elements): remaining tiles one at a time
+    for (int k = RS_TILES; k < ntiles; ++k) {
+        float p[EPV];
+        rs_probs_of_vec<DT>(row, lo + ((int64_t)k * 256 + tid) * EPV, p);
+        double a = 0.0;
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) a += (double)p[j];
+        const double in = wave_incl_scan_f64(a, lane);
+        const double up = __shfl_up(in, 1, 64);
+        __syncthreads();
+        if (lane == 63) sh.wtx[wave] = in;
+        __syncthreads();
+        double wb = base;
+        for (int w = 0; w < wave; ++w) wb += sh.wtx[w];
+        if (!found && wb + in > thr_s) { cand = resolve(k, wb + (lane == 0 ? 0.0 : up)); found = true; }
+        base += (sh.wtx[0] + sh.wtx[1]) + (sh.wtx[2] + sh.wtx[3]);
+    }
+    if (found) atomicMin(&sh.pick, cand);
+    __syncthreads();
+    int pick = sh.pick;
+    if (pick == 0x7FFFFFFF) pick = (int)(hi - 1);           // rounding only: the segment sum said it crosses here
+    return pick;
+}
+
+// argmax of the distribution with `proposed` masked (JDN:147-153 / JDO:164-168): first index of the largest probability —
+// for bf16 logits that is a tie among every id whose ROUNDED probability equals the maximum; all mass on it -> keep it.
+template <int DT>
+__device__ int rs_masked_argmax(const RsRow &row, int64_t proposed, RsPickShared &sh) {
+    constexpr int EPV = Elem<DT>::EPV;
+    const int tid = threadIdx.x;
+    unsigned long long best = 0ull;
+    for (int64_t e0 = (int64_t)tid * EPV; e0 < row.V; e0 += 256 * EPV) {
+        float p[EPV];
+        rs_probs_of_vec<DT>(row, e0, p);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+            const int64_t i = e0 + j;
+            if (i >= row.V || i == proposed || !(p[j] > 0.f)) continue;
+            const unsigned long long k = ((unsigned long long)__float_as_uint(p[j]) << 32) | (unsigned long long)(~(uint32_t)i);
+            best = k > best ? k : best;
+        }
+    }
+    best = wave_max_u64(best);
+    __syncthreads();
+    if ((tid & 63) == 0) sh.best[tid >> 6] = best;
+    __syncthreads();
+    unsigned long long mm = sh.best[0];
+    for (int w = 1; w < 4; ++w) mm = sh.best[w] > mm ? sh.best[w] : mm;
+    __syncthreads();
+    return mm ? jfmb::decode_packed(mm) : (int)proposed;
+}
+
+// Residual sampling of one row (JDN:135-153 / JDO:157-168): up to 16 draws from stream[(base + tr) % len] until the sample
+// differs from `proposed`, then the masked argmax.  Returns the token, *draws = stream entries consumed.
+template <int DT>
+__device__ int rs_bonus_row(const RsRow &row, const double *segsum, int64_t proposed, const float *stream, int64_t stream_len,
+                            int64_t base, RsPickShared &sh, int *draws_out) {
+    int bonus = -1, draws = 0;
+    for (int tr = 0; tr < 16 && bonus < 0; ++tr) {
+        const int y = rs_pick<DT>(row, segsum, stream[(base + tr) % stream_len], sh);
+        draws++;
+        if ((int64_t)y != proposed) bonus = y;
+    }
+    if (bonus < 0) bonus = rs_masked_argmax<DT>(row, proposed, sh);
+    *draws_out = draws;
+    return bonus;
 }
 
 // ------------------------------------------------------------------------------------------------
 // Accept/reject of every row of a batch (JDN:581-639).  The reference visits the rows in order and draws torch.rand /
 // torch.multinomial / torch.randint as it goes, so the position of every draw in the injected streams depends on the rows
-// before it.  Three launches keep that order exact while the only wide work — the inverse-CDF draw of the bonus token on a
-// rejected position, two passes over V — runs one workgroup per row in parallel:
-//   rs_accept_kernel  (1 workgroup)  sequential accept scans from LDS-staged p_draft / uniforms: per row accepted count,
-//                                    rejected position, uniforms used; bonus draws are ASSUMED to take one draw per row
-//   rs_bonus_kernel   (B workgroups) the bonus draw of each rejected row at its assumed stream position
-//   rs_finish_kernel  (1 workgroup)  if some row needed more than one draw (its sample hit the proposed token) the rows
-//                                    after it are redone in order with the true positions (rare); EOS, next drafts, pads,
-//                                    cursors, packed re-zeroed
+// before it.  Four launches keep that order exact:
+//   rs_accept_kernel  (1 workgroup)   p_draft / uniforms staged in LDS by 256 threads, then ONE wavefront walks the rows:
+//                                     a row's L-1 accept tests are one ballot, so the serial chain is B steps, not B*(L-1);
+//                                     bonus draws are ASSUMED to take one stream entry per rejected row
+//   rs_rowsum_kernel  (B * RS_SEG)    float64 segment sums of every rejected row
+//   rs_bonus_kernel   (B workgroups)  the bonus draw of each rejected row at its assumed stream position
+//   rs_finish_kernel  (1 workgroup)   if some row needed more than one draw (its sample hit the proposed token) the rows
+//                                     after it are re-drawn in order with the true positions (segment sums are reused);
+//                                     EOS, next drafts, pads, cursors by parallel scans; packed re-zeroed
 // ------------------------------------------------------------------------------------------------
-template <int DT>
-__device__ __forceinline__ double rs_slice_sum(const void *row, int64_t lo, int64_t hi, float inv_t, float M, float Sx) {
-    double acc = 0.0;
-    for (int64_t i = lo; i < hi; ++i) acc += (double)(expf(load_f<DT>(row, i) * inv_t - M) / Sx);
-    return acc;
-}
-template <int DT>
-__device__ __forceinline__ int64_t rs_slice_pick(const void *row, int64_t lo, int64_t hi, float inv_t, float M, float Sx,
-                                                 double pre, double thr) {
-    double run = pre;
-    for (int64_t i = lo; i < hi; ++i) {
-        run += (double)(expf(load_f<DT>(row, i) * inv_t - M) / Sx);
-        if (run > thr) return i;
-    }
-    return hi - 1;
-}
-
-struct RsShared {
-    double sum[256], pre[256];
-    double total;
-    uint64_t best[4];
-    int pick;
-};
-
-// Residual sampling of one row by the whole workgroup (JDN:135-153 / JDO:157-168): inverse CDF over p = exp(x/T - M)/S in
-// vocabulary order with a float64 running sum (two-level: each thread owns a contiguous slice), up to 16 draws from
-// stream[(base + tr) % len] until the sample differs from `proposed`, then the argmax of the masked distribution.
-// Uniform control flow; returns the token, *draws = stream entries consumed.
-template <int DT>
-__device__ int rs_bonus_row(const void *row, int64_t V, float inv_t, float M, float Sx, int64_t proposed, const float *stream,
-                            int64_t stream_len, int64_t base, RsShared &sh, int *draws_out) {
-    const int tid = threadIdx.x;
-    const int64_t per = (V + 255) / 256;
-    const int64_t lo = (int64_t)tid * per < V ? (int64_t)tid * per : V;
-    const int64_t hi = (lo + per < V) ? lo + per : V;
-    const double acc = rs_slice_sum<DT>(row, lo, hi, inv_t, M, Sx);
-    sh.sum[tid] = acc;
-    __syncthreads();
-    if (tid == 0) {
-        double run = 0.0;
-        for (int i = 0; i < 256; ++i) { sh.pre[i] = run; run += sh.sum[i]; }
-        sh.total = run;
-    }
-    __syncthreads();
-    int bonus = -1, draws = 0;
-    for (int tr = 0; tr < 16 && bonus < 0; ++tr) {
-        const double thr = (double)stream[(base + tr) % stream_len] * sh.total;
-        if (tid == 0) sh.pick = (int)(V - 1);               // clamp when thr >= total
-        __syncthreads();
-        const double pre = sh.pre[tid];
-        if (hi > lo && thr >= pre && thr < pre + acc) sh.pick = (int)rs_slice_pick<DT>(row, lo, hi, inv_t, M, Sx, pre, thr);
-        __syncthreads();
-        draws++;
-        if ((int64_t)sh.pick != proposed) bonus = sh.pick;
-        __syncthreads();
-    }
-    if (bonus < 0) {
-        // 16 collisions: argmax of p with the proposed id masked (JDN:147-153); all mass on it -> keep it
-        uint32_t best = 0u, bidx = 0xFFFFFFFFu;
-        for (int64_t i = tid; i < V; i += 256) {
-            if (i == proposed) continue;
-            const uint32_t k = load_key<DT>(row, i);
-            if (k > best) { best = k; bidx = (uint32_t)i; }
-        }
-        const uint64_t pk = wave_max_u64(((uint64_t)best << 32) | (uint64_t)(~bidx));
-        if ((tid & 63) == 0) sh.best[tid >> 6] = pk;
-        __syncthreads();
-        uint64_t mm = sh.best[0];
-        for (int w = 1; w < 4; ++w) mm = sh.best[w] > mm ? sh.best[w] : mm;
-        const int alt = jfmb::decode_packed(mm);
-        const float palt = (alt >= 0 && alt < V) ? expf(load_f<DT>(row, alt) * inv_t - M) / Sx : 0.f;
-        bonus = (palt > 0.f) ? alt : (int)proposed;
-        __syncthreads();
-    }
-    *draws_out = draws;
-    return bonus;
-}
-
 constexpr int RS_STAGE = 8192;      // floats of p_draft / uniforms staged in LDS by the accept scan (B * (L-1) <= this, else global)
 
 __global__ __launch_bounds__(256) void rs_accept_kernel(const int64_t *draft, int B, int L, const float *p_draft, int eos_id,
                                                          const float *u_stream, int64_t u_len, const int64_t *u_cursor,
-                                                         int64_t *committed, jf_rs_row *rows) {
-    __shared__ float s_p[RS_STAGE], s_u[RS_STAGE];
+                                                         int64_t *committed, jf_rs_row *rows, int32_t *sel_row) {
+    __shared__ float s_p[RS_STAGE], s_u[RS_STAGE];          // s_p carries "proposed == EOS" in its sign bit (p >= 0)
     const int tid = threadIdx.x;
-    const int n = B * (L - 1);
+    const int W = L - 1;
+    const int n = B * W;
     const int64_t uc0 = *u_cursor;
     const bool staged = n <= RS_STAGE;
-    if (staged) {
-        for (int i = tid; i < n; i += 256) { s_p[i] = p_draft[i]; s_u[i] = u_stream[(uc0 + i) % u_len]; }   // at most n uniforms are used
-    }
+    auto p_eos = [&](int i) {
+        const int b = i / W, tt = i - b * W;
+        const uint32_t pb = __float_as_uint(p_draft[i]) & 0x7FFFFFFFu;
+        const bool is_eos = eos_id >= 0 && draft[(int64_t)b * L + tt + 1] == (int64_t)eos_id;
+        return __uint_as_float(pb | (is_eos ? 0x80000000u : 0u));
+    };
+    if (staged)
+        for (int i = tid; i < n; i += 256) { s_p[i] = p_eos(i); s_u[i] = u_stream[(uc0 + i) % u_len]; }   // at most n uniforms are used
     __syncthreads();
-    if (tid != 0) return;
-    int used_total = 0, n_rej = 0;
-    for (int b = 0; b < B; ++b) {                                   // JDN:326-348, rows in order
-        const int64_t *d = draft + (int64_t)b * L;
-        int64_t *cm = committed + (int64_t)b * L;
-        const int r0 = b * (L - 1);
-        int nacc = 0, eos = 0, rej = -1, used = 0;
-        for (int t = 0; t < L - 1; ++t) {
-            const int64_t proposed = d[t + 1];
-            const float u = staged ? s_u[used_total + used] : u_stream[(uc0 + used_total + used) % u_len];
-            const float pd = staged ? s_p[r0 + t] : p_draft[r0 + t];
-            used++;
-            if (u < pd) {
-                cm[nacc++] = proposed;
-                if (eos_id >= 0 && proposed == eos_id) { eos = 1; break; }
-                continue;
+    if (tid < 64) {
+        const int lane = tid;
+        int used_total = 0, n_rej = 0;
+        for (int b = 0; b < B; ++b) {                               // JDN:326-348, rows in order
+            int nacc = 0, eos = 0, rej = -1, used = 0;
+            for (int t0 = 0; t0 < W; t0 += 64) {
+                const int tt = t0 + lane;
+                bool stop = false, rejb = false;
+                if (tt < W) {
+                    const int i = b * W + tt;
+                    const float pe = staged ? s_p[i] : p_eos(i);
+                    const float uu = staged ? s_u[used_total + tt] : u_stream[(uc0 + used_total + tt) % u_len];
+                    const bool acc = uu < __uint_as_float(__float_as_uint(pe) & 0x7FFFFFFFu);
+                    rejb = !acc;
+                    stop = rejb || (__float_as_uint(pe) >> 31);     // rejected, or accepted EOS
+                }
+                const unsigned long long bal = __ballot(stop);
+                if (bal) {
+                    const int f = __builtin_ctzll(bal);
+                    const bool is_rej = (__ballot(rejb) >> f) & 1ull;
+                    if (is_rej) { rej = t0 + f; nacc = t0 + f; } else { eos = 1; nacc = t0 + f + 1; }
+                    used = t0 + f + 1;
+                    break;
+                }
+                const int w = (W - t0) < 64 ? (W - t0) : 64;
+                nacc = t0 + w; used = t0 + w;
             }
-            rej = t;
-            break;
+            if (lane == 0) {
+                jf_rs_row &rw = rows[b];
+                rw.n_committed = nacc; rw.eos = eos; rw.reject_pos = rej; rw.n_uniforms = used;
+                rw.n_bonus_draws = 0; rw.n_pads = 0; rw.active_next = 0;
+                rw.rsv = n_rej;                                     // bonus draws before this row if every draw is a single one
+                sel_row[b] = rej >= 0 ? b * W + rej : -1;
+            }
+            for (int i = lane; i < nacc; i += 64) committed[(int64_t)b * L + i] = draft[(int64_t)b * L + i + 1];
+            used_total += used;
+            if (rej >= 0) n_rej++;
         }
-        rows[b].n_committed = nacc; rows[b].eos = eos; rows[b].reject_pos = rej; rows[b].n_uniforms = used;
-        rows[b].n_bonus_draws = 0; rows[b].n_pads = 0; rows[b].active_next = 0;
-        rows[b].rsv = n_rej;                                        // bonus draws before this row if every draw is a single one
-        used_total += used;
-        if (rej >= 0) n_rej++;
     }
 }
 
@@ -331,20 +621,32 @@ template <int DT>
 __global__ __launch_bounds__(256) void rs_bonus_kernel(const void *logits, int64_t V, int64_t row_stride, const int64_t *draft, int L,
                                                         const float *row_max, const float *row_sumexp, float temp,
                                                         const float *b_stream, int64_t b_len, const int64_t *b_cursor,
-                                                        int64_t *committed, jf_rs_row *rows) {
-    __shared__ RsShared sh;
+                                                        const double *segsum, int64_t *committed, jf_rs_row *rows) {
+    __shared__ RsPickShared sh;
     const int b = blockIdx.x;
     const int rej = rows[b].reject_pos;
     if (rej < 0) return;
     const int64_t r = (int64_t)b * (L - 1) + rej;
-    const void *row = (const char *)logits + r * row_stride * (DT == JF_F32 ? 4 : 2);
+    const RsRow row = rs_make_row<DT>(logits, r, V, row_stride, temp, row_max[r], row_sumexp[r]);
     int draws = 0;
-    const int bonus = rs_bonus_row<DT>(row, V, 1.f / temp, row_max[r], row_sumexp[r], draft[(int64_t)b * L + rej + 1], b_stream, b_len,
+    const int bonus = rs_bonus_row<DT>(row, segsum + (int64_t)b * RS_SEG, draft[(int64_t)b * L + rej + 1], b_stream, b_len,
                                        *b_cursor + rows[b].rsv, sh, &draws);
     if (threadIdx.x == 0) {
         committed[(int64_t)b * L + rows[b].n_committed] = bonus;
         rows[b].n_bonus_draws = draws;
     }
+}
+
+// exclusive prefix sum over consecutive lanes of one wavefront; *total = sum over all 64 lanes
+__device__ __forceinline__ int wave_excl_scan_i32(int v, int lane, int *total) {
+    int x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(x, off, 64);
+        if (lane >= off) x += o;
+    }
+    *total = __shfl(x, 63, 64);
+    return x - v;
 }
 
 template <int DT>
@@ -353,215 +655,227 @@ __global__ __launch_bounds__(256) void rs_finish_kernel(const void *logits, int6
                                                          unsigned long long *packed, float temp, int eos_id,
                                                          const int32_t *remaining, int64_t *u_cursor, const float *b_stream,
                                                          int64_t b_len, int64_t *b_cursor, const int64_t *pad_stream,
-                                                         int64_t pad_len, int64_t *pad_cursor, int64_t *committed,
-                                                         int64_t *next_draft, jf_rs_row *rows) {
-    __shared__ RsShared sh;
+                                                         int64_t pad_len, int64_t *pad_cursor, const double *segsum,
+                                                         int64_t *committed, int64_t *next_draft, jf_rs_row *rows) {
+    __shared__ RsPickShared sh;
     __shared__ int s_first_bad;
-    __shared__ int64_t s_bc, s_pc;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int64_t bc0 = *b_cursor;
-    if (tid == 0) {
-        int fb = -1;
-        for (int b = 0; b < B && fb < 0; ++b)
-            if (rows[b].reject_pos >= 0 && rows[b].n_bonus_draws != 1) fb = b;
-        s_first_bad = fb;
-    }
+    if (tid == 0) s_first_bad = 0x7FFFFFFF;
+    __syncthreads();
+    for (int b = tid; b < B; b += 256)
+        if (rows[b].reject_pos >= 0 && rows[b].n_bonus_draws != 1) atomicMin(&s_first_bad, b);
     __syncthreads();
     // rows after the first one that needed more than one draw sampled at the wrong stream positions: redo them in order
-    if (s_first_bad >= 0) {
-        int64_t base = bc0 + rows[s_first_bad].rsv + rows[s_first_bad].n_bonus_draws;
-        for (int b = s_first_bad + 1; b < B; ++b) {
+    if (s_first_bad < B) {
+        const int fb = s_first_bad;
+        int64_t base = bc0 + rows[fb].rsv + rows[fb].n_bonus_draws;
+        for (int b = fb + 1; b < B; ++b) {
             const int rej = rows[b].reject_pos;
             if (rej < 0) continue;
             const int64_t r = (int64_t)b * (L - 1) + rej;
-            const void *row = (const char *)logits + r * row_stride * (DT == JF_F32 ? 4 : 2);
+            const RsRow row = rs_make_row<DT>(logits, r, V, row_stride, temp, row_max[r], row_sumexp[r]);
             int draws = 0;
-            const int bonus = rs_bonus_row<DT>(row, V, 1.f / temp, row_max[r], row_sumexp[r], draft[(int64_t)b * L + rej + 1], b_stream,
-                                               b_len, base, sh, &draws);
+            const int bonus = rs_bonus_row<DT>(row, segsum + (int64_t)b * RS_SEG, draft[(int64_t)b * L + rej + 1], b_stream, b_len,
+                                               base, sh, &draws);
             if (tid == 0) { committed[(int64_t)b * L + rows[b].n_committed] = bonus; rows[b].n_bonus_draws = draws; }
             base += draws;
-            __syncthreads();
         }
     }
+    __threadfence_block();
     __syncthreads();
-    // finalize: bonus joins the committed tokens, EOS, next draft (JDN:444-466 / 619-638), stream cursors
-    if (tid == 0) {
-        int64_t uc = *u_cursor, bc = bc0, pc = *pad_cursor;
-        for (int b = 0; b < B; ++b) {
-            jf_rs_row &rw = rows[b];
-            uc += rw.n_uniforms;
-            int n = rw.n_committed;
-            if (rw.reject_pos >= 0) {
-                bc += rw.n_bonus_draws;
-                if (eos_id >= 0 && committed[(int64_t)b * L + n] == eos_id) rw.eos = 1;
-                n += 1;
-            }
-            rw.n_committed = n;
-            rw.active_next = (!rw.eos && n < remaining[b]) ? 1 : 0;
-            int n_pads = 0;
-            if (rw.active_next) {
-                const int acc_len = 1 + n;
-                int copy_len = 1;
-                if (acc_len < L) {
-                    const int off = acc_len > 1 ? acc_len - 1 : 1;
-                    const int rem = (L - 1) - off;
-                    copy_len = rem < L - 1 ? rem : L - 1;
-                }
-                n_pads = L - 1 - copy_len;
-            }
-            rw.n_pads = n_pads;
-            rw.rsv = (int32_t)(pc - *pad_cursor);                    // this row's offset into the pad stream
-            pc += n_pads;
+    // finalize, rows in parallel: bonus joins the committed tokens, EOS, next-draft shape (JDN:444-466 / 619-638)
+    for (int b = tid; b < B; b += 256) {
+        jf_rs_row &rw = rows[b];
+        int n = rw.n_committed;
+        if (rw.reject_pos >= 0) {
+            if (eos_id >= 0 && committed[(int64_t)b * L + n] == eos_id) rw.eos = 1;
+            n += 1;
         }
-        s_bc = bc; s_pc = pc;
-        *u_cursor = uc; *b_cursor = bc;
+        rw.n_committed = n;
+        rw.active_next = (!rw.eos && n < remaining[b]) ? 1 : 0;
+        int n_pads = 0;
+        if (rw.active_next) {
+            const int acc_len = 1 + n;
+            int copy_len = 1;
+            if (acc_len < L) {
+                const int off = acc_len > 1 ? acc_len - 1 : 1;
+                const int rem = (L - 1) - off;
+                copy_len = rem < L - 1 ? rem : L - 1;
+            }
+            n_pads = L - 1 - copy_len;
+        }
+        rw.n_pads = n_pads;
     }
+    __threadfence_block();
+    __syncthreads();
+    // stream cursors and every row's offset into the pad stream: exclusive scans in row order by one wavefront
+    if (tid < 64) {
+        int uc = 0, bc = 0, pc = 0;
+        for (int b0 = 0; b0 < B; b0 += 64) {
+            const int b = b0 + lane;
+            const int nu = b < B ? rows[b].n_uniforms : 0;
+            const int nb = (b < B && rows[b].reject_pos >= 0) ? rows[b].n_bonus_draws : 0;
+            const int np = b < B ? rows[b].n_pads : 0;
+            int tu, tb, tp;
+            (void)wave_excl_scan_i32(nu, lane, &tu);
+            (void)wave_excl_scan_i32(nb, lane, &tb);
+            const int ep = wave_excl_scan_i32(np, lane, &tp);
+            if (b < B) rows[b].rsv = pc + ep;                          // this row's offset into the pad stream
+            uc += tu; bc += tb; pc += tp;
+        }
+        if (lane == 0) { *u_cursor += uc; *b_cursor = bc0 + bc; sh.pick = pc; }
+    }
+    __threadfence_block();
     __syncthreads();
     const int64_t pc0 = *pad_cursor;
-    for (int b = 0; b < B; ++b) {
+    const int total_pads = sh.pick;
+    for (int64_t idx = tid; idx < (int64_t)B * L; idx += 256) {        // every next-draft element independently
+        const int b = (int)(idx / L), i = (int)(idx - (int64_t)b * L);
         const jf_rs_row rw = rows[b];
         if (!rw.active_next) continue;
         const int64_t r0 = (int64_t)b * (L - 1);
-        int64_t *nd = next_draft + (int64_t)b * L;
         const int n = rw.n_committed, acc_len = 1 + n;
-        int copy_len;
-        if (tid == 0) nd[0] = committed[(int64_t)b * L + n - 1];
+        int off = 0, copy_len = 1;
         if (acc_len < L) {
-            const int off = acc_len > 1 ? acc_len - 1 : 1;
+            off = acc_len > 1 ? acc_len - 1 : 1;
             const int rem = (L - 1) - off;
             copy_len = rem < L - 1 ? rem : L - 1;
-            for (int i = tid; i < copy_len; i += 256) nd[1 + i] = jfmb::decode_packed(packed[r0 + off + i]);
         } else {
-            if (tid == 0) nd[1] = jfmb::decode_packed(packed[r0 + L - 2]);
-            copy_len = 1;
+            off = L - 2;
         }
-        for (int i = tid; i < rw.n_pads; i += 256) nd[1 + copy_len + i] = pad_stream[(pc0 + rw.rsv + i) % pad_len];
+        int64_t v;
+        if (i == 0) v = committed[(int64_t)b * L + n - 1];
+        else if (i - 1 < copy_len) v = jfmb::decode_packed(packed[r0 + off + (i - 1)]);
+        else v = pad_stream[(pc0 + rw.rsv + (i - 1 - copy_len)) % pad_len];
+        next_draft[idx] = v;
     }
     __syncthreads();
     for (int64_t i = tid; i < (int64_t)B * (L - 1); i += 256) packed[i] = 0ull;
-    if (tid == 0) {
-        *pad_cursor = s_pc;
-        for (int b = 0; b < B; ++b) rows[b].rsv = 0;
-    }
+    for (int b = tid; b < B; b += 256) rows[b].rsv = 0;
+    if (tid == 0) *pad_cursor = pc0 + total_pads;
 }
 
 // ------------------------------------------------------------------------------------------------
 // On-policy rollout step (JDO = inference_engine/engine/jacobi_decoding_nongreedy_on_policy.py): sequential accept /
 // reject of ONE sequence's proposed tokens with a stop-token SET (JDO:270-327), then a fresh sample of every not yet
-// accepted position from this forward's distribution (JDO:465-477) — one workgroup per re-drafted row.
+// accepted position from this forward's distribution (JDO:465-477).
+//   rs_op_accept_kernel   one wavefront: the R accept tests are one ballot
+//   rs_rowsum_kernel      float64 segment sums of the rejected row and of every row after it (the re-draft candidates)
+//   rs_op_bonus_kernel    one workgroup: the bonus draw(s), stop flag, stream cursors
+//   rs_op_redraft_kernel  one workgroup per re-drafted row: one draw each; re-zeroes packed
 // ------------------------------------------------------------------------------------------------
-template <int DT>
-__global__ __launch_bounds__(256) void rs_onpolicy_verify_kernel(const void *logits, int64_t V, int64_t row_stride,
-                                                                  const int64_t *proposed, int R, const float *p_draft,
-                                                                  const float *row_max, const float *row_sumexp, float temp,
-                                                                  const int32_t *stop_ids, int n_stop, const float *u_stream,
-                                                                  int64_t u_len, int64_t *u_cursor, const float *m_stream,
-                                                                  int64_t m_len, int64_t *m_cursor, int64_t *committed,
-                                                                  jf_op_row *out) {
-    __shared__ RsShared sh;
-    __shared__ int s_n, s_stop, s_rej, s_used;
-    const int tid = threadIdx.x;
-    const int64_t uc = *u_cursor, mc = *m_cursor;
-    auto is_stop = [&](int64_t tok) { for (int k = 0; k < n_stop; ++k) if (tok == (int64_t)stop_ids[k]) return true; return false; };
-    if (tid == 0) {
-        int n = 0, stop = 0, rej = -1, used = 0;
-        for (int t = 0; t < R; ++t) {                                  // JDO:293-320
-            const int64_t x = proposed[t];
-            const float u = u_stream[(uc + used) % u_len];
-            used++;
-            if (u < p_draft[t]) {
-                committed[n++] = x;
-                if (is_stop(x)) { stop = 1; break; }
-                continue;
-            }
-            rej = t;
+__device__ __forceinline__ bool op_is_stop(const int32_t *stop_ids, int n_stop, int64_t tok) {
+    for (int k = 0; k < n_stop; ++k) if (tok == (int64_t)stop_ids[k]) return true;
+    return false;
+}
+
+__global__ __launch_bounds__(64) void rs_op_accept_kernel(const int64_t *proposed, int R, const float *p_draft,
+                                                           const int32_t *stop_ids, int n_stop, const float *u_stream,
+                                                           int64_t u_len, const int64_t *u_cursor, int64_t *committed,
+                                                           jf_op_row *out, int32_t *sel_row) {
+    const int lane = threadIdx.x;
+    const int64_t uc = *u_cursor;
+    int n = 0, stop = 0, rej = -1, used = 0;
+    for (int t0 = 0; t0 < R; t0 += 64) {                              // JDO:293-320
+        const int t = t0 + lane;
+        bool st = false, rejb = false;
+        if (t < R) {
+            const bool acc = u_stream[(uc + t) % u_len] < p_draft[t];
+            rejb = !acc;
+            st = rejb || op_is_stop(stop_ids, n_stop, proposed[t]);
+        }
+        const unsigned long long bal = __ballot(st);
+        if (bal) {
+            const int f = __builtin_ctzll(bal);
+            const bool is_rej = (__ballot(rejb) >> f) & 1ull;
+            if (is_rej) { rej = t0 + f; n = t0 + f; } else { stop = 1; n = t0 + f + 1; }
+            used = t0 + f + 1;
             break;
         }
-        s_n = n; s_stop = stop; s_rej = rej; s_used = used;
+        const int w = (R - t0) < 64 ? (R - t0) : 64;
+        n = t0 + w; used = t0 + w;
     }
-    __syncthreads();
-    const int rej = s_rej;
-    int draws = 0;
+    for (int i = lane; i < n; i += 64) committed[i] = proposed[i];
+    for (int i = lane; i < R; i += 64) sel_row[i] = (rej >= 0 && i >= rej) ? i : -1;
+    if (lane == 0) {
+        out->n_committed = n; out->stop_hit = stop; out->reject_pos = rej; out->n_bonus_draws = 0;
+        out->n_uniforms = used; out->n_redraft = 0; out->redraft_base_lo = 0; out->redraft_base_hi = 0;
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void rs_op_bonus_kernel(const void *logits, int64_t V, int64_t row_stride, const int64_t *proposed,
+                                                           int R, const float *row_max, const float *row_sumexp, float temp,
+                                                           const int32_t *stop_ids, int n_stop, int64_t *u_cursor,
+                                                           const float *m_stream, int64_t m_len, int64_t *m_cursor,
+                                                           const double *segsum, int64_t *committed, jf_op_row *out) {
+    __shared__ RsPickShared sh;
+    const int tid = threadIdx.x;
+    const int rej = out->reject_pos;
+    const int64_t mc = *m_cursor;
+    int n = out->n_committed, stop = out->stop_hit, draws = 0;
     if (rej >= 0) {                                                    // JDO:157-168 (bonus != proposed)
-        const void *row = (const char *)logits + (int64_t)rej * row_stride * (DT == JF_F32 ? 4 : 2);
-        const int bonus = rs_bonus_row<DT>(row, V, 1.f / temp, row_max[rej], row_sumexp[rej], proposed[rej], m_stream, m_len, mc, sh,
-                                           &draws);
-        if (tid == 0) {
-            committed[s_n] = bonus;
-            s_n = s_n + 1;
-            if (is_stop(bonus)) s_stop = 1;
-        }
-        __syncthreads();
+        const RsRow row = rs_make_row<DT>(logits, rej, V, row_stride, temp, row_max[rej], row_sumexp[rej]);
+        const int bonus = rs_bonus_row<DT>(row, segsum + (int64_t)rej * RS_SEG, proposed[rej], m_stream, m_len, mc, sh, &draws);
+        if (tid == 0) committed[n] = bonus;
+        n += 1;
+        if (op_is_stop(stop_ids, n_stop, bonus)) stop = 1;
     }
     if (tid == 0) {
-        const int n = s_n;
-        const int n_redraft = (!s_stop && n < R) ? R - n : 0;          // JDO:465: not stopped and accepted < gen_len
+        const int n_redraft = (!stop && n < R) ? R - n : 0;            // JDO:465: not stopped and accepted < gen_len
         const int64_t base = mc + draws;
-        out->n_committed = n; out->stop_hit = s_stop; out->reject_pos = rej; out->n_bonus_draws = draws;
-        out->n_uniforms = s_used; out->n_redraft = n_redraft;
+        out->n_committed = n; out->stop_hit = stop; out->n_bonus_draws = draws; out->n_redraft = n_redraft;
         out->redraft_base_lo = (int32_t)(base & 0xFFFFFFFFll); out->redraft_base_hi = (int32_t)(base >> 32);
-        *u_cursor = uc + s_used;
+        *u_cursor += out->n_uniforms;
         *m_cursor = base + n_redraft;
     }
 }
 
-// one workgroup per logits row: rows >= n_committed draw one sample each (inverse CDF, float64 running sum in vocabulary
-// order, the same arithmetic as the bonus draw); every row's argmax slot is re-zeroed.
+// one workgroup per logits row: rows >= n_committed draw one sample each; every row's argmax slot is re-zeroed.
 template <int DT>
-__global__ __launch_bounds__(256) void rs_sample_rows_kernel(const void *logits, int64_t V, int64_t row_stride, int R,
-                                                              const float *row_max, const float *row_sumexp, float temp,
-                                                              const float *m_stream, int64_t m_len, const jf_op_row *res,
-                                                              int64_t *redraft, unsigned long long *packed) {
-    __shared__ double s_sum[256], s_pre[256];
-    __shared__ double s_total;
-    __shared__ int s_pick;
+__global__ __launch_bounds__(256) void rs_op_redraft_kernel(const void *logits, int64_t V, int64_t row_stride, int R,
+                                                             const float *row_max, const float *row_sumexp, float temp,
+                                                             const float *m_stream, int64_t m_len, const jf_op_row *res,
+                                                             const double *segsum, int64_t *redraft, unsigned long long *packed) {
+    __shared__ RsPickShared sh;
     const int li = blockIdx.x, tid = threadIdx.x;
     if (tid == 0) packed[li] = 0ull;
     const int n = res->n_committed;
     if (res->n_redraft <= 0 || li < n) return;
     const int64_t base = ((int64_t)res->redraft_base_hi << 32) | (int64_t)(uint32_t)res->redraft_base_lo;
-    const float inv_t = 1.f / temp;
-    const void *row = (const char *)logits + (int64_t)li * row_stride * (DT == JF_F32 ? 4 : 2);
-    const float M = row_max[li], Sx = row_sumexp[li];
-    const int64_t per = (V + 255) / 256;
-    const int64_t lo = (int64_t)tid * per < V ? (int64_t)tid * per : V;
-    const int64_t hi = (lo + per < V) ? lo + per : V;
-    const double acc = rs_slice_sum<DT>(row, lo, hi, inv_t, M, Sx);
-    s_sum[tid] = acc;
-    __syncthreads();
-    if (tid == 0) {
-        double run = 0.0;
-        for (int i = 0; i < 256; ++i) { s_pre[i] = run; run += s_sum[i]; }
-        s_total = run;
-        s_pick = (int)(V - 1);
-    }
-    __syncthreads();
-    const double thr = (double)m_stream[(base + (li - n)) % m_len] * s_total;
-    const double pre = s_pre[tid];
-    if (hi > lo && thr >= pre && thr < pre + acc) s_pick = (int)rs_slice_pick<DT>(row, lo, hi, inv_t, M, Sx, pre, thr);
-    __syncthreads();
-    if (tid == 0) redraft[li] = s_pick;
+    const RsRow row = rs_make_row<DT>(logits, li, V, row_stride, temp, row_max[li], row_sumexp[li]);
+    const int y = rs_pick<DT>(row, segsum + (int64_t)li * RS_SEG, m_stream[(base + (li - n)) % m_len], sh);
+    if (tid == 0) redraft[li] = y;
 }
 
 extern "C" int jf_rs_onpolicy_step(const void *logits, int dtype, int64_t V, int64_t row_stride, const int64_t *proposed, int R,
                                    const float *p_draft, const float *row_max, const float *row_sumexp, uint64_t *packed,
                                    float temperature, const int32_t *stop_ids, int n_stop, const float *u_stream, int64_t u_len,
                                    int64_t *u_cursor, const float *m_stream, int64_t m_len, int64_t *m_cursor,
-                                   int64_t *committed, int64_t *redraft, jf_op_row *row, void *stream) {
+                                   int64_t *committed, int64_t *redraft, jf_op_row *row, void *workspace,
+                                   size_t workspace_bytes, void *stream) {
     if (R <= 0) return JF_OK;
     if (!logits || !proposed || !p_draft || !row_max || !row_sumexp || !packed || !u_stream || !u_cursor || !m_stream ||
-        !m_cursor || !committed || !redraft || !row || (n_stop > 0 && !stop_ids))
+        !m_cursor || !committed || !redraft || !row || !workspace || (n_stop > 0 && !stop_ids))
         return fail(JF_E_INVALID, "jf_rs_onpolicy_step: null pointer");
     if (u_len <= 0 || m_len <= 0 || n_stop < 0) return fail(JF_E_INVALID, "jf_rs_onpolicy_step: empty random stream");
+    if (workspace_bytes < rs_ws_bytes(R)) return fail(JF_E_INVALID, "jf_rs_onpolicy_step: workspace too small");
+    if (dtype != JF_F32 && dtype != JF_BF16) return fail(JF_E_INVALID, "jf_rs_onpolicy_step: dtype %d", dtype);
     const float t = (temperature <= 0.f) ? 1.f : temperature;
     hipStream_t s = (hipStream_t)stream;
+    const RsWs w = rs_ws(workspace, R);
+    unsigned long long *pk = (unsigned long long *)packed;
+    rs_op_accept_kernel<<<1, 64, 0, s>>>(proposed, R, p_draft, stop_ids, n_stop, u_stream, u_len, u_cursor, committed, row, w.sel_row);
     if (dtype == JF_F32) {
-        rs_onpolicy_verify_kernel<JF_F32><<<1, 256, 0, s>>>(logits, V, row_stride, proposed, R, p_draft, row_max, row_sumexp, t, stop_ids, n_stop, u_stream, u_len, u_cursor, m_stream, m_len, m_cursor, committed, row);
-        rs_sample_rows_kernel<JF_F32><<<R, 256, 0, s>>>(logits, V, row_stride, R, row_max, row_sumexp, t, m_stream, m_len, row, redraft, (unsigned long long *)packed);
-    } else if (dtype == JF_BF16) {
-        rs_onpolicy_verify_kernel<JF_BF16><<<1, 256, 0, s>>>(logits, V, row_stride, proposed, R, p_draft, row_max, row_sumexp, t, stop_ids, n_stop, u_stream, u_len, u_cursor, m_stream, m_len, m_cursor, committed, row);
-        rs_sample_rows_kernel<JF_BF16><<<R, 256, 0, s>>>(logits, V, row_stride, R, row_max, row_sumexp, t, m_stream, m_len, row, redraft, (unsigned long long *)packed);
-    } else return fail(JF_E_INVALID, "jf_rs_onpolicy_step: dtype %d", dtype);
+        rs_rowsum_kernel<JF_F32><<<R * RS_SEG, 256, 0, s>>>(logits, V, row_stride, row_max, row_sumexp, t, w.sel_row, w.segsum);
+        rs_op_bonus_kernel<JF_F32><<<1, 256, 0, s>>>(logits, V, row_stride, proposed, R, row_max, row_sumexp, t, stop_ids, n_stop, u_cursor, m_stream, m_len, m_cursor, w.segsum, committed, row);
+        rs_op_redraft_kernel<JF_F32><<<R, 256, 0, s>>>(logits, V, row_stride, R, row_max, row_sumexp, t, m_stream, m_len, row, w.segsum, redraft, pk);
+    } else {
+        rs_rowsum_kernel<JF_BF16><<<R * RS_SEG, 256, 0, s>>>(logits, V, row_stride, row_max, row_sumexp, t, w.sel_row, w.segsum);
+        rs_op_bonus_kernel<JF_BF16><<<1, 256, 0, s>>>(logits, V, row_stride, proposed, R, row_max, row_sumexp, t, stop_ids, n_stop, u_cursor, m_stream, m_len, m_cursor, w.segsum, committed, row);
+        rs_op_redraft_kernel<JF_BF16><<<R, 256, 0, s>>>(logits, V, row_stride, R, row_max, row_sumexp, t, m_stream, m_len, row, w.segsum, redraft, pk);
+    }
     return check_launch("rs_onpolicy kernels");
 }
 
@@ -570,25 +884,28 @@ extern "C" int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_
                           float temperature, int32_t eos_id, const int32_t *remaining, const float *u_stream, int64_t u_len,
                           int64_t *u_cursor, const float *bonus_stream, int64_t bonus_len, int64_t *bonus_cursor,
                           const int64_t *pad_stream, int64_t pad_len, int64_t *pad_cursor, int64_t *committed,
-                          int64_t *next_draft, jf_rs_row *rows, void *stream) {
+                          int64_t *next_draft, jf_rs_row *rows, void *workspace, size_t workspace_bytes, void *stream) {
     if (B <= 0) return JF_OK;
     if (L < 2) return fail(JF_E_INVALID, "Draft must have at least 2 tokens (seed + 1 speculative)");
     if (!logits || !draft || !p_draft || !row_max || !row_sumexp || !packed || !remaining || !u_stream || !u_cursor ||
-        !bonus_stream || !bonus_cursor || !pad_stream || !pad_cursor || !committed || !next_draft || !rows)
+        !bonus_stream || !bonus_cursor || !pad_stream || !pad_cursor || !committed || !next_draft || !rows || !workspace)
         return fail(JF_E_INVALID, "jf_rs_step: null pointer");
     if (u_len <= 0 || bonus_len <= 0 || pad_len <= 0) return fail(JF_E_INVALID, "jf_rs_step: empty random stream");
+    if (workspace_bytes < rs_ws_bytes(B)) return fail(JF_E_INVALID, "jf_rs_step: workspace too small");
     const float t = (temperature <= 0.f) ? 1.f : temperature;
     if (dtype != JF_F32 && dtype != JF_BF16) return fail(JF_E_INVALID, "jf_rs_step: dtype %d", dtype);
     hipStream_t s = (hipStream_t)stream;
     unsigned long long *pk = (unsigned long long *)packed;
-    rs_accept_kernel<<<1, 256, 0, s>>>(draft, B, L, p_draft, eos_id, u_stream, u_len, u_cursor, committed, rows);
+    const RsWs w = rs_ws(workspace, B);
+    rs_accept_kernel<<<1, 256, 0, s>>>(draft, B, L, p_draft, eos_id, u_stream, u_len, u_cursor, committed, rows, w.sel_row);
     if (dtype == JF_F32) {
-        rs_bonus_kernel<JF_F32><<<B, 256, 0, s>>>(logits, V, row_stride, draft, L, row_max, row_sumexp, t, bonus_stream, bonus_len, bonus_cursor, committed, rows);
-        rs_finish_kernel<JF_F32><<<1, 256, 0, s>>>(logits, V, row_stride, draft, B, L, row_max, row_sumexp, pk, t, eos_id, remaining, u_cursor, bonus_stream, bonus_len, bonus_cursor, pad_stream, pad_len, pad_cursor, committed, next_draft, rows);
+        rs_rowsum_kernel<JF_F32><<<B * RS_SEG, 256, 0, s>>>(logits, V, row_stride, row_max, row_sumexp, t, w.sel_row, w.segsum);
+        rs_bonus_kernel<JF_F32><<<B, 256, 0, s>>>(logits, V, row_stride, draft, L, row_max, row_sumexp, t, bonus_stream, bonus_len, bonus_cursor, w.segsum, committed, rows);
+        rs_finish_kernel<JF_F32><<<1, 256, 0, s>>>(logits, V, row_stride, draft, B, L, row_max, row_sumexp, pk, t, eos_id, remaining, u_cursor, bonus_stream, bonus_len, bonus_cursor, pad_stream, pad_len, pad_cursor, w.segsum, committed, next_draft, rows);
     } else {
-        rs_bonus_kernel<JF_BF16><<<B, 256, 0, s>>>(logits, V, row_stride, draft, L, row_max, row_sumexp, t, bonus_stream, bonus_len, bonus_cursor, committed, rows);
-        rs_finish_kernel<JF_BF16><<<1, 256, 0, s>>>(logits, V, row_stride, draft, B, L, row_max, row_sumexp, pk, t, eos_id, remaining, u_cursor, bonus_stream, bonus_len, bonus_cursor, pad_stream, pad_len, pad_cursor, committed, next_draft, rows);
+        rs_rowsum_kernel<JF_BF16><<<B * RS_SEG, 256, 0, s>>>(logits, V, row_stride, row_max, row_sumexp, t, w.sel_row, w.segsum);
+        rs_bonus_kernel<JF_BF16><<<B, 256, 0, s>>>(logits, V, row_stride, draft, L, row_max, row_sumexp, t, bonus_stream, bonus_len, bonus_cursor, w.segsum, committed, rows);
+        rs_finish_kernel<JF_BF16><<<1, 256, 0, s>>>(logits, V, row_stride, draft, B, L, row_max, row_sumexp, pk, t, eos_id, remaining, u_cursor, bonus_stream, bonus_len, bonus_cursor, pad_stream, pad_len, pad_cursor, w.segsum, committed, next_draft, rows);
     }
     return check_launch("rs_step kernels");
 }
-

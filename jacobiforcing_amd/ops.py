@@ -443,7 +443,8 @@ class PagedFill:
 # --------------------------------------------------------------------------------------------
 class RsStepper:
     """Rejection-sampling verify of a batch of rows: jf_rs_probs (softmax-gather + argmax, logits read once) followed by
-    jf_rs_step (sequential accept/reject, bonus draw, next draft) — two launches and one read-back per iteration."""
+    jf_rs_step (accept/reject in stream order, bonus draws, next drafts) and one read-back per iteration.  The logits
+    dtype selects the arithmetic: bf16 logits get torch's bf16 rounding points (JDN:64-70 never widens them)."""
 
     def __init__(self, max_rows: int, max_L: int, device, pad_stream, u_stream, bonus_stream):
         dev = torch.device(device)
@@ -454,6 +455,7 @@ class RsStepper:
         f32 = lambda k: torch.zeros((k,), dtype=torch.float32, device=dev)
         self.p_draft, self.row_max, self.row_sumexp = f32(n), f32(n), f32(n)
         self.ws = torch.zeros((n * 64 * 2,), dtype=torch.float32, device=dev)     # jf_rs_workspace_bytes(n, V)
+        self.step_ws = torch.zeros((int(N.lib().jf_rs_step_workspace_bytes(self.max_rows)) // 8 + 2,), dtype=torch.float64, device=dev)
         self.committed = torch.zeros((self.max_rows, self.max_L), dtype=torch.int64, device=dev)
         self.next_draft = torch.zeros((self.max_rows, self.max_L), dtype=torch.int64, device=dev)
         self.rows_dev = torch.zeros((self.max_rows, N.RS_ROW_INTS), dtype=torch.int32, device=dev)
@@ -499,7 +501,8 @@ class RsStepper:
                                _ptr(self.u_stream), self.u_stream.numel(), c_ptr(0),
                                _ptr(self.bonus_stream), self.bonus_stream.numel(), c_ptr(1),
                                _ptr(self.pad_stream), self.pad_stream.numel(), c_ptr(2),
-                               _ptr(cm), _ptr(nd), _ptr(self.rows_dev), _stream(dev)), "jf_rs_step")
+                               _ptr(cm), _ptr(nd), _ptr(self.rows_dev), _ptr(self.step_ws), self.step_ws.numel() * 8,
+                               _stream(dev)), "jf_rs_step")
         self.rows_host[:B].copy_(self.rows_dev[:B], non_blocking=True)
         th = self.tok_host.view(-1)[:B * L].view(B, L)
         th.copy_(cm, non_blocking=True)
@@ -522,6 +525,7 @@ class OnPolicyStepper:
         f32 = lambda k: torch.zeros((k,), dtype=torch.float32, device=dev)
         self.p_draft, self.row_max, self.row_sumexp = f32(n), f32(n), f32(n)
         self.ws = torch.zeros((n * 64 * 2,), dtype=torch.float32, device=dev)
+        self.step_ws = torch.zeros((int(N.lib().jf_rs_step_workspace_bytes(n)) // 8 + 2,), dtype=torch.float64, device=dev)
         self.out = torch.zeros((2, n), dtype=torch.int64, device=dev)              # committed, redraft
         self.row_dev = torch.zeros((N.OP_ROW_INTS,), dtype=torch.int32, device=dev)
         pin = dev.type == "cuda"
@@ -556,7 +560,8 @@ class OnPolicyStepper:
                                         float(temperature), _ptr(self.stop_ids), int(self.stop_ids.numel()),
                                         _ptr(self.u_stream), self.u_stream.numel(), c_ptr(0),
                                         _ptr(self.m_stream), self.m_stream.numel(), c_ptr(1),
-                                        _ptr(cm), _ptr(rd), _ptr(self.row_dev), _stream(dev)), "jf_rs_onpolicy_step")
+                                        _ptr(cm), _ptr(rd), _ptr(self.row_dev), _ptr(self.step_ws),
+                                        self.step_ws.numel() * 8, _stream(dev)), "jf_rs_onpolicy_step")
         self.row_host.copy_(self.row_dev, non_blocking=True)
         self.out_host[:, :R].copy_(self.out[:, :R], non_blocking=True)
         if dev.type == "cuda":

@@ -743,6 +743,43 @@ def softmax_rows_f32(logits: np.ndarray, temperature: float) -> np.ndarray:
     return (e / e.sum(axis=-1, keepdims=True, dtype=np.float32)).astype(np.float32)
 
 
+def bf16_round(x: np.ndarray) -> np.ndarray:
+    """float32 -> nearest bfloat16 (ties to even), returned as float32 values (torch ``.to(torch.bfloat16)``)."""
+    return bf16_bits_to_f32(f32_to_bf16_bits(np.asarray(x, dtype=np.float32)))
+
+
+def softmax_rows_bf16(logits: np.ndarray, temperature: float) -> np.ndarray:
+    """JDN:64-70 on a bfloat16 logits tensor, which is what the engine hands the verifier (MR:1382 has no cast and
+    JDN never calls ``.float()``).  torch keeps the tensor dtype through both ops and rounds after each one:
+      * ``logits / float(T)``: float32 quotient of the widened operand by float32(T), rounded to bf16
+        (ATen div_true_kernel for reduced floating types; skipped when T == 1, JDN:68);
+      * ``torch.softmax``: max / exp(x - max) / sum in float32, result rounded to bf16.
+    Returned as float32 values that are exactly bf16-representable.  The float32 internals of torch's CPU softmax
+    (vectorised exp, summation order) are not reproduced bit for bit - torch's own result differs from an exactly
+    rounded softmax in ~0.1 % of the entries by one bf16 ulp - so entries may differ from torch by one bf16 ulp at
+    that rate; every consumer of the result (``u < p``, the float64 inverse-CDF walk, the masked argmax) works on
+    the rounded values, as the reference does."""
+    x = np.asarray(logits, dtype=np.float32)
+    if not np.array_equal(bf16_round(x), x, equal_nan=True):
+        raise ValueError("softmax_rows_bf16 expects bf16-representable logits")
+    t = np.float32(1.0 if (temperature is None or temperature <= 0) else temperature)
+    if t != np.float32(1.0):
+        x = bf16_round((x / t).astype(np.float32))
+    m = x.max(axis=-1, keepdims=True)
+    e = np.exp(x - m, dtype=np.float32)
+    return bf16_round((e / e.sum(axis=-1, keepdims=True, dtype=np.float32)).astype(np.float32))
+
+
+def target_probs(logits: np.ndarray, temperature: float, logits_dtype: str = "f32") -> np.ndarray:
+    """_build_target_probs (JDN:110-123 / JDO:128-136) for the dtype the forward callback returned.  top_k / top_p are
+    not SamplingParams fields (sampling_params.py:4-38), so the getattr defaults (None) always apply."""
+    if logits_dtype == "bf16":
+        return softmax_rows_bf16(logits, temperature)
+    if logits_dtype != "f32":
+        raise ValueError(f"logits_dtype must be 'f32' or 'bf16', got {logits_dtype!r}")
+    return softmax_rows_f32(logits, temperature)
+
+
 def inverse_cdf_sample(probs: np.ndarray, u: float) -> int:
     """The injected stand-in for torch.multinomial used on both sides of the parity test:
     smallest index whose float64 running sum exceeds u * total (clamped to V-1)."""
@@ -805,7 +842,8 @@ def _ng_commit(seq: OracleSeq, L: int, committed: List[int], num_keep: int):
 
 
 def nongreedy_generate_single(forward: NonGreedyForward, seq: OracleSeq, eos_id: Optional[int], temperature: float,
-                              pads, next_uniform, next_bonus_uniform, stats: Optional[dict] = None):
+                              pads, next_uniform, next_bonus_uniform, stats: Optional[dict] = None,
+                              logits_dtype: str = "f32"):
     """JDN:376-482."""
     L = seq.block_len
     max_tokens = seq.max_tokens - seq.num_completion_tokens
@@ -824,7 +862,7 @@ def nongreedy_generate_single(forward: NonGreedyForward, seq: OracleSeq, eos_id:
         seq.grow_for_draft(L)
         logits = forward([seq], [q])[0]
         seq.num_cached_tokens = len(seq) - 1 + L
-        probs = softmax_rows_f32(logits, temperature)
+        probs = target_probs(logits, temperature, logits_dtype)
         committed, keep, eos = rs_verify_row(q, probs, eos_id, next_uniform, next_bonus_uniform)
         eos_reached = eos_reached or eos
         _ng_commit(seq, L, committed, keep)
@@ -844,13 +882,13 @@ def nongreedy_generate_single(forward: NonGreedyForward, seq: OracleSeq, eos_id:
 
 def nongreedy_generate_batch(forward: NonGreedyForward, seqs: List[OracleSeq], eos_id: Optional[int],
                              temperature: float, pads, next_uniform, next_bonus_uniform,
-                             stats: Optional[dict] = None):
+                             stats: Optional[dict] = None, logits_dtype: str = "f32"):
     """JDN:485-667."""
     if not seqs:
         return []
     if len(seqs) == 1:
         return [nongreedy_generate_single(forward, seqs[0], eos_id, temperature, pads, next_uniform,
-                                          next_bonus_uniform, stats)]
+                                          next_bonus_uniform, stats, logits_dtype)]
     B = len(seqs)
     accepted: List[List[int]] = [[] for _ in range(B)]
     q: List[Optional[List[int]]] = [None] * B
@@ -886,7 +924,7 @@ def nongreedy_generate_batch(forward: NonGreedyForward, seqs: List[OracleSeq], e
             for i in idxs:
                 seqs[i].num_cached_tokens = len(seqs[i]) - 1 + L
             for row, i in enumerate(idxs):
-                probs = softmax_rows_f32(logits[row], temperature)
+                probs = target_probs(logits[row], temperature, logits_dtype)
                 committed, keep, eos = rs_verify_row(drafts[row], probs, eos_id, next_uniform, next_bonus_uniform)
                 eos_reached[i] = eos_reached[i] or eos
                 _ng_commit(seqs[i], L, committed, keep)
@@ -992,7 +1030,7 @@ def onpolicy_verify(proposed: List[int], probs: np.ndarray, stop_ids, next_unifo
 
 def onpolicy_run_one_block(forward: NonGreedyForward, seq: OracleSeq, block_len: int, budget: int, completion_start: int,
                            temperature: float, stop_ids, pad_id: int, vocab: int, rnd, next_uniform,
-                           next_multinomial_uniform):
+                           next_multinomial_uniform, logits_dtype: str = "f32"):
     """JDO:331-488.  Returns (trajectory, appended_total, forwards_used, stopped)."""
     full_len = int(block_len)
     if full_len <= 0 or budget <= 0:
@@ -1014,7 +1052,7 @@ def onpolicy_run_one_block(forward: NonGreedyForward, seq: OracleSeq, block_len:
         logits = forward([seq], [draft])[0]                                      # [remaining, V]
         seq.num_cached_tokens = len(seq) - 1 + (remaining + 1)
         fwd_used += 1
-        probs = softmax_rows_f32(logits, temperature)
+        probs = target_probs(logits, temperature, logits_dtype)
         committed, stop_hit = onpolicy_verify(proposed, probs, stop_ids, next_uniform, next_multinomial_uniform)
         if not committed:
             committed = [proposed[0]]
@@ -1055,7 +1093,8 @@ def onpolicy_run_one_block(forward: NonGreedyForward, seq: OracleSeq, block_len:
 
 def onpolicy_rollout_records_batch(forward: NonGreedyForward, seqs: List[OracleSeq], temperature: float, stop_ids,
                                    pad_id: int, vocab: int, rnd, next_uniform, next_multinomial_uniform,
-                                   n_token_seq_len: Optional[int] = None, data_ids: Optional[List[str]] = None):
+                                   n_token_seq_len: Optional[int] = None, data_ids: Optional[List[str]] = None,
+                                   logits_dtype: str = "f32"):
     """JDO:494-614: (records per sequence {block index -> record}, metrics per sequence).
     ``seq.max_iters`` is the maximum number of BLOCKS (JDO:232-233)."""
     B = len(seqs)
@@ -1079,7 +1118,8 @@ def onpolicy_rollout_records_batch(forward: NonGreedyForward, seqs: List[OracleS
                 continue
             prompt_trim = trim_left_padding(list(seq.token_ids), pad_id)
             traj, app, fw, hit = onpolicy_run_one_block(forward, seq, block_lens[i], budgets[i], starts[i], temperature,
-                                                        stop_ids, pad_id, vocab, rnd, next_uniform, next_multinomial_uniform)
+                                                        stop_ids, pad_id, vocab, rnd, next_uniform, next_multinomial_uniform,
+                                                        logits_dtype)
             done_blocks[i] += 1
             forwards[i] += fw
             generated[i] += app

@@ -54,11 +54,13 @@ class ScriptedModel:
     reserved:    ids never produced by target()/junk (e.g. pad id, eos id)
     period:      when > 0 the target sequence repeats with this period (forces
                  n-gram-pool hits for rejection recycling)
+    peak:        logit planted at the greedy id by logits_rows() (noise is in (-1, 1)); 8.0 makes the
+                 softmax nearly one-hot, smaller values spread the mass (non-greedy verify cases)
     """
 
     def __init__(self, vocab: int, seed: int, robust_pct: int, prompt_len: int,
                  eos_id: Optional[int] = None, eos_pos: Optional[int] = None,
-                 reserved: Sequence[int] = (), period: int = 0):
+                 reserved: Sequence[int] = (), period: int = 0, peak: float = 8.0):
         self.vocab = int(vocab)
         self.seed = int(seed)
         self.robust_pct = int(robust_pct)
@@ -69,6 +71,7 @@ class ScriptedModel:
         if eos_id is not None:
             self.reserved.add(int(eos_id))
         self.period = int(period)
+        self.peak = float(peak)
         self._free = [t for t in range(self.vocab) if t not in self.reserved]
         assert len(self._free) >= 2
 
@@ -125,7 +128,7 @@ class ScriptedModel:
 
     def logits_rows(self, committed: Sequence[int], rows: Sequence[Sequence[int]],
                     dtype=np.float32) -> np.ndarray:
-        """Dense logits [B, T, V]: hash noise in (-1, 1) plus +8 at the greedy id."""
+        """Dense logits [B, T, V]: hash noise in (-1, 1) plus ``peak`` (8.0) at the greedy id."""
         g = self.greedy_rows(committed, rows)
         B, T = len(rows), (len(rows[0]) if rows else 0)
         lg = np.empty((B, T, self.vocab), dtype=np.float32)
@@ -136,17 +139,20 @@ class ScriptedModel:
                 s = np.uint64(mix32(self.seed + 17 * b, base + t))
                 x = (v * np.uint64(2654435761) + s * np.uint64(40503)) & np.uint64(0xFFFF)
                 lg[b, t] = x.astype(np.float32) / np.float32(32768.0) - np.float32(1.0)
-                lg[b, t, g[b][t]] = np.float32(8.0)
+                lg[b, t, g[b][t]] = np.float32(self.peak)
         return lg.astype(dtype)
 
     def ar_continuation(self, start: int, count: int) -> List[int]:
         return [self.target(p) for p in range(start, start + count)]
 
     def describe(self) -> dict:
-        return dict(vocab=self.vocab, seed=self.seed, robust_pct=self.robust_pct,
-                    prompt_len=self.prompt_len, eos_id=self.eos_id, eos_pos=self.eos_pos,
-                    reserved=sorted(self.reserved - ({self.eos_id} if self.eos_id is not None else set())),
-                    period=self.period)
+        d = dict(vocab=self.vocab, seed=self.seed, robust_pct=self.robust_pct,
+                 prompt_len=self.prompt_len, eos_id=self.eos_id, eos_pos=self.eos_pos,
+                 reserved=sorted(self.reserved - ({self.eos_id} if self.eos_id is not None else set())),
+                 period=self.period)
+        if self.peak != 8.0:          # recorded only when it differs, so older fixtures keep their descriptors
+            d["peak"] = self.peak
+        return d
 
     @classmethod
     def from_dict(cls, d: dict) -> "ScriptedModel":

@@ -69,7 +69,7 @@ class HostSimLib:
 
     # -- plumbing
     def jf_version(self):
-        return 100
+        return 200
 
     def jf_last_error(self):
         return self._err
@@ -261,17 +261,24 @@ class HostSimLib:
         b = _view(logits, (R - 1) * stride + V, np.uint16)
         return O.bf16_bits_to_f32(np.stack([b[r * stride:r * stride + V] for r in range(R)]))
 
+    @staticmethod
+    def _ldt(dtype):
+        return "bf16" if dtype == N.JF_BF16 else "f32"
+
+    def jf_rs_step_workspace_bytes(self, rows):
+        return max(int(rows), 0) * (16 * 8 + 16)
+
     def jf_rs_probs(self, logits, dtype, R, V, stride, draft_next, temperature, p_draft, row_max, row_sumexp, packed, ws, ws_bytes, stream):
         rows = self._rows_f32(logits, dtype, R, V, stride)
         t = np.float32(1.0 if temperature <= 0 else temperature)
-        x = rows / t
+        x = rows if t == np.float32(1.0) else (O.bf16_round(rows / t) if dtype == N.JF_BF16 else rows / t)
         m = x.max(axis=1)
         e = np.exp(x - m[:, None], dtype=np.float32)
         ssum = e.sum(axis=1, dtype=np.float32)
         dn = _view(draft_next, R, np.int64)
         _view(row_max, R, np.float32)[:] = m
         _view(row_sumexp, R, np.float32)[:] = ssum
-        _view(p_draft, R, np.float32)[:] = e[np.arange(R), dn] / ssum
+        _view(p_draft, R, np.float32)[:] = O.target_probs(rows, float(temperature), self._ldt(dtype))[np.arange(R), dn]
         am = O.argmax_rows(rows).astype(np.uint64)
         pk = _view(packed, R, np.uint64)
         pk[:] = np.maximum(pk, (np.uint64(1) << np.uint64(32)) | ((~am) & np.uint64(0xFFFFFFFF)))
@@ -279,10 +286,10 @@ class HostSimLib:
 
     def jf_rs_step(self, logits, dtype, V, stride, draft, B, L, p_draft, row_max, row_sumexp, packed, temperature, eos_id,
                    remaining, u_stream, u_len, u_cursor, b_stream, b_len, b_cursor, pad_stream, pad_len, pad_cursor,
-                   committed, next_draft, rows, stream):
+                   committed, next_draft, rows, ws, ws_bytes, stream):
         R = B * (L - 1)
         lg = self._rows_f32(logits, dtype, R, V, stride)
-        probs = O.softmax_rows_f32(lg, temperature)
+        probs = O.target_probs(lg, temperature, self._ldt(dtype))
         d = _view(draft, B * L, np.int64).reshape(B, L)
         us, bs, ps = _view(u_stream, u_len, np.float32), _view(b_stream, b_len, np.float32), _view(pad_stream, pad_len, np.int64)
         uc, bc, pc = _view(u_cursor, 1, np.int64), _view(b_cursor, 1, np.int64), _view(pad_cursor, 1, np.int64)
@@ -327,9 +334,9 @@ class HostSimLib:
 
     def jf_rs_onpolicy_step(self, logits, dtype, V, stride, proposed, R, p_draft, row_max, row_sumexp, packed, temperature,
                             stop_ids, n_stop, u_stream, u_len, u_cursor, m_stream, m_len, m_cursor, committed, redraft, row,
-                            stream):
+                            ws, ws_bytes, stream):
         lg = self._rows_f32(logits, dtype, R, V, stride)
-        probs = O.softmax_rows_f32(lg, temperature)
+        probs = O.target_probs(lg, temperature, self._ldt(dtype))
         prop = _view(proposed, R, np.int64).tolist()
         stops = _view(stop_ids, n_stop, np.int32).tolist() if n_stop else []
         us, ms = _view(u_stream, u_len, np.float32), _view(m_stream, m_len, np.float32)

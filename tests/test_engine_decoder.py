@@ -111,21 +111,23 @@ def test_constructor_errors():
 # ----------------------------------------------------------------------------- non-greedy (rejection sampling)
 from jacobiforcing_amd.engine.jacobi_decoding_nongreedy import JacobiDecoderNonGreedy  # noqa: E402
 
-JDN = load_golden("jdn_cases.json")
-JDO = load_golden("jdo_cases.json")
+JDN = load_golden("jdn_cases.json") + load_golden("jdn_cases_v2.json")
+JDO = load_golden("jdo_cases.json") + load_golden("jdo_cases_v2.json")
 BMC = load_golden("bm_cases.json")
+TORCH_DTYPES = {"f32": torch.float32, "bf16": torch.bfloat16}
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("case", JDN, ids=[c["name"] for c in JDN])
 def test_engine_nongreedy_golden(case, backend):
     """Rejection-sampling verify with injected uniforms / residual draws / pads against the reference's
-    JacobiDecoderNonGreedy.  Floating point enters through softmax only (fp32 exp on the GPU vs torch CPU); the committed
-    token ids must still agree for these seeds (24-bit uniforms leave ~1e-6 chance of a flip per comparison)."""
+    JacobiDecoderNonGreedy, for float32 AND bfloat16 logits (``params.logits_dtype``; the reference keeps the logits dtype
+    through softmax, JDN:64-70, so bf16 logits mean bf16-rounded probabilities).  Floating point enters through the
+    float32 exp / sum inside softmax only; the committed token ids must still agree for these seeds."""
     with use_backend(backend):
         dev = device_for(backend)
         p = case["params"]
-        H = Harness(p["vocab"], dev, torch.float32)
+        H = Harness(p["vocab"], dev, TORCH_DTYPES[p.get("logits_dtype", "f32")])
         dec = JacobiDecoderNonGreedy(H.bm, forward_step=lambda s, d: H.forward_step_batch([s], d),
                                      forward_step_batch=H.forward_step_batch, eos_token_id=p["eos_id"],
                                      pad_token_id=p["pad_id"], vocab_size=p["vocab"], device=torch.device(dev))
@@ -158,7 +160,7 @@ def test_engine_onpolicy_records_golden(case, backend):
     with use_backend(backend):
         dev = device_for(backend)
         p = case["params"]
-        H = Harness(p["vocab"], dev, torch.float32)
+        H = Harness(p["vocab"], dev, TORCH_DTYPES[p.get("logits_dtype", "f32")])
         stop = p["stop_ids"] if len(p["stop_ids"]) > 1 else p["eos_id"]
         dec = JacobiDecoderNonGreedyOnPolicy(H.bm, forward_step=lambda s, d: H.forward_step_batch([s], d),
                                              forward_step_batch=H.forward_step_batch, eos_token_id=stop,

@@ -36,6 +36,20 @@ def _setup(seed):
     return rng, V, robust, max_iters, items
 
 
+TORCH_DTYPES = {"f32": torch.float32, "bf16": torch.bfloat16}
+
+
+def _dtype_and_peak(seed, rng):
+    """odd seeds: bfloat16 logits with a flatter scripted distribution; even seeds: the round-1 float32 / peak 8 sweep"""
+    if seed % 2 == 0:
+        return "f32", 8.0
+    return "bf16", float(rng.choice([3.0, 4.5, 6.0, 8.0]))
+
+
+def _as_dtype(logits, ldt):
+    return O.bf16_round(logits) if ldt == "bf16" else logits
+
+
 def _cases(n_both, n_total):
     """seeds below n_both run on both backends; the rest only through the real kernels (the CPU suite stays short)"""
     return [pytest.param(seed, b, id=f"{b}-{seed}", marks=[pytest.mark.gpu] if b == "hip" else [])
@@ -86,24 +100,27 @@ def test_engine_greedy_fuzz(seed, backend):
 @pytest.mark.parametrize("seed,backend", _cases(24, 72))
 def test_engine_nongreedy_fuzz(seed, backend):
     """Same sweep for rejection sampling.  The oracle and the kernels share the injected streams; probabilities differ only
-    in fp32 rounding, so a decision can flip only when a uniform lands within ~1e-6 of p — none does for these seeds."""
+    in fp32 rounding, so a decision can flip only when a uniform lands within ~1e-6 of p — none does for these seeds.
+    Odd seeds run on bfloat16 logits (the engine's dtype, MR:1382): torch's bf16 rounding points on both sides, and a flatter
+    distribution (peak < 8) so that accept tests, bonus draws and collisions all see non-trivial rounded probabilities."""
     rng, V, robust, max_iters, items = _setup(1000 + seed)
     eos, pad = V - 1, V - 2
     temperature = float(rng.choice([1.0, 0.7, 0.4]))
+    ldt, peak = _dtype_and_peak(seed, rng)
     pads = [int(x) for x in rng.integers(0, V, size=4096)]
     unis = [float(x) for x in (rng.integers(0, 1 << 24, size=8192) / float(1 << 24))]
     bonus = [float(x) for x in (rng.integers(0, 1 << 24, size=8192) / float(1 << 24))]
     L = items[0]["L"]
     with use_backend(backend):
         dev = device_for(backend)
-        H = Harness(V, dev, torch.float32)
+        H = Harness(V, dev, TORCH_DTYPES[ldt])
         dec = JacobiDecoderNonGreedy(H.bm, forward_step=lambda s, d: H.forward_step_batch([s], d),
                                      forward_step_batch=H.forward_step_batch, eos_token_id=eos, pad_token_id=pad, vocab_size=V,
                                      device=torch.device(dev))
         dec.set_streams(pads, unis, bonus)
         seqs, oseqs, models = [], [], []
         for it in items:
-            m = ScriptedModel(V, it["seed"], robust, it["pl"], eos_id=eos, eos_pos=it["eos_pos"], reserved=(pad,))
+            m = ScriptedModel(V, it["seed"], robust, it["pl"], eos_id=eos, eos_pos=it["eos_pos"], reserved=(pad,), peak=peak)
             sp = SamplingParams(temperature=temperature, max_tokens=it["mt"], decode_strategy="jacobi", jacobi_block_len=it["L"],
                                 jacobi_max_iterations=max_iters)
             seqs.append(H.add(m, sp, None))
@@ -124,9 +141,10 @@ def test_engine_nongreedy_fuzz(seed, backend):
             return f
 
         def ofwd(ss, drafts):
-            return [by[id(s)].logits_rows(s.token_ids[:-1], [d])[0][:-1] for s, d in zip(ss, drafts)]
+            return [_as_dtype(by[id(s)].logits_rows(s.token_ids[:-1], [d])[0][:-1], ldt) for s, d in zip(ss, drafts)]
         stats = O.new_stats()
-        want = O.nongreedy_generate_batch(ofwd, oseqs, eos, temperature, take("p", pads), take("u", unis), take("b", bonus), stats)
+        want = O.nongreedy_generate_batch(ofwd, oseqs, eos, temperature, take("p", pads), take("u", unis), take("b", bonus), stats,
+                                          logits_dtype=ldt)
         got = dec.generate_chunk_batch(seqs)
         assert got == want
         assert dec.stats == stats
@@ -143,12 +161,13 @@ def test_engine_onpolicy_fuzz(seed, backend):
     stop_ids = [eos] if rng.random() < 0.6 else [eos, int(rng.integers(0, V - 2))]
     temperature = float(rng.choice([1.0, 0.7, 0.4, 1.5]))
     max_blocks = int(rng.choice([128, 128, 2, 1]))
+    ldt, peak = _dtype_and_peak(seed, rng)
     unis = [float(x) for x in (rng.integers(0, 1 << 24, size=8192) / float(1 << 24))]
     multi = [float(x) for x in (rng.integers(0, 1 << 24, size=8192) / float(1 << 24))]
     L = max(items[0]["L"], 2)
     with use_backend(backend):
         dev = device_for(backend)
-        H = Harness(V, dev, torch.float32)
+        H = Harness(V, dev, TORCH_DTYPES[ldt])
         dec = JacobiDecoderNonGreedyOnPolicy(H.bm, forward_step=lambda s, d: H.forward_step_batch([s], d),
                                              eos_token_id=stop_ids if len(stop_ids) > 1 else eos, pad_token_id=pad, vocab_size=V,
                                              device=torch.device(dev))
@@ -156,7 +175,7 @@ def test_engine_onpolicy_fuzz(seed, backend):
         dec.set_streams(O.ScriptedRandom(a), unis, multi)
         seqs, oseqs, models = [], [], []
         for it in items:
-            m = ScriptedModel(V, it["seed"], robust, it["pl"], eos_id=eos, eos_pos=it["eos_pos"], reserved=(pad,))
+            m = ScriptedModel(V, it["seed"], robust, it["pl"], eos_id=eos, eos_pos=it["eos_pos"], reserved=(pad,), peak=peak)
             sp = SamplingParams(temperature=temperature, max_tokens=it["mt"], decode_strategy="jacobi", jacobi_block_len=L,
                                 jacobi_max_iterations=max_blocks, jacobi_on_policy=True)
             seqs.append(H.add(m, sp, None))
@@ -173,9 +192,9 @@ def test_engine_onpolicy_fuzz(seed, backend):
             return f
 
         def ofwd(ss, drafts):
-            return [by[id(s)].logits_rows(s.token_ids[:-1], [d])[0][:-1] for s, d in zip(ss, drafts)]
+            return [_as_dtype(by[id(s)].logits_rows(s.token_ids[:-1], [d])[0][:-1], ldt) for s, d in zip(ss, drafts)]
         want, wmet = O.onpolicy_rollout_records_batch(ofwd, oseqs, temperature, stop_ids, pad, V, O.ScriptedRandom(b),
-                                                      take("u", unis), take("m", multi))
+                                                      take("u", unis), take("m", multi), logits_dtype=ldt)
         got, gmet = dec.generate_rollout_records_batch(seqs, return_metrics=True)
         assert got == want
         assert gmet == wmet

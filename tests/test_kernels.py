@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(raw, name)
     raw.jf_version.restype = ctypes.c_int
-    assert raw.jf_version() == 100
+    assert raw.jf_version() == 200
 
 
 def test_plain_c_client(tmp_path):
@@ -48,7 +48,7 @@ def test_plain_c_client(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(ROOT / "tests" / "abi" / "abi_client.c"),
                            f"-L{lib.parent}", "-ljacobiforcing", f"-Wl,-rpath,{lib.parent}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
     out = subprocess.check_output([str(exe)], text=True)
-    assert "version=100" in out and "desc=64" in out and "params=40" in out
+    assert "version=200" in out and "desc=64" in out and "params=40" in out
     assert "rc=-1" in out and "null pointer" in out
 
 
@@ -306,30 +306,65 @@ def test_argmax_special_values_vector_path(dtype):
 
 
 # ------------------------------------------------------------------------------------- non-greedy softmax-gather
-@GPU
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-@pytest.mark.parametrize("temperature", [1.0, 0.7])
-def test_rs_probs_vs_torch_softmax(dtype, temperature):
-    """p_draft = softmax(logits / T)[draft] (JDN:65-70, 328) in fp32: tolerance 2e-5 relative (fp32 exp/sum order),
-    argmax bit-exact."""
-    R, V = 31, 152064
-    g = torch.Generator().manual_seed(4)
-    x = (torch.randn(R, V, generator=g) * 3).to(dtype)
-    dn = torch.randint(0, V, (R,), generator=g)
-    dn[0] = int(torch.argmax(x[0].float()))
+def _run_rs_probs(x, dn, temperature):
+    R, V = x.shape
     st = ops.RsStepper(4, 16, "cuda", [0], [0.5], [0.5])
-    lib = N.lib()
+    ws = torch.zeros((int(N.lib().jf_rs_workspace_bytes(R, V)) // 4 + 4,), dtype=torch.float32, device="cuda")
     xd = x.cuda()
     p = torch.zeros(R, device="cuda"); m = torch.zeros(R, device="cuda"); s = torch.zeros(R, device="cuda")
     packed = ops.new_packed(R, "cuda")
-    N.check(lib.jf_rs_probs(ops._ptr(xd), ops._dtype_code(xd), R, V, V, ops._ptr(dn.cuda()), temperature, ops._ptr(p), ops._ptr(m),
-                            ops._ptr(s), ops._ptr(packed), ops._ptr(st.ws), st.ws.numel() * 4, ops._stream(xd.device)))
-    ref = torch.softmax(x.float() / temperature, dim=-1)
-    want = ref[torch.arange(R), dn]
-    got = p.cpu()
+    N.check(N.lib().jf_rs_probs(ops._ptr(xd), ops._dtype_code(xd), R, V, xd.stride(0), ops._ptr(dn.cuda()), temperature, ops._ptr(p),
+                                ops._ptr(m), ops._ptr(s), ops._ptr(packed), ops._ptr(ws), ws.numel() * 4, ops._stream(xd.device)))
+    del st
+    return p.cpu(), m.cpu(), s.cpu(), (~packed.cpu()) & 0xFFFFFFFF
+
+
+@GPU
+@pytest.mark.parametrize("temperature", [1.0, 0.7])
+def test_rs_probs_vs_torch_softmax(temperature):
+    """float32 logits: p_draft = softmax(logits / T)[draft] (JDN:65-70, 328) in fp32: tolerance 2e-5 relative (fp32 exp / sum
+    order), argmax bit-exact."""
+    R, V = 31, 152064
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(R, V, generator=g) * 3
+    dn = torch.randint(0, V, (R,), generator=g)
+    dn[0] = int(torch.argmax(x[0]))
+    got, _, _, am = _run_rs_probs(x, dn, temperature)
+    want = torch.softmax(x / temperature, dim=-1)[torch.arange(R), dn]
     assert torch.allclose(got, want, rtol=2e-5, atol=1e-12), float(((got - want).abs() / want).max())
-    am = (~packed.cpu()) & 0xFFFFFFFF
-    assert am.tolist() == torch.argmax(x.float(), dim=-1).tolist()
+    assert am.tolist() == torch.argmax(x, dim=-1).tolist()
+
+
+def _bf16_bits(t):
+    return t.to(torch.bfloat16).view(torch.int16).to(torch.int32) & 0xFFFF
+
+
+@GPU
+@pytest.mark.parametrize("temperature", [1.0, 0.7, 1.3, 0.25])
+def test_rs_probs_bf16_follows_torch_rounding_points(temperature):
+    """bfloat16 logits: the reference's probs tensor is torch.softmax(logits / T) IN bf16 (JDN:64-70 on MR:1382's logits).
+    torch (CPU, in this test) is the reference: the scaled row maximum must agree bit for bit (one rounding of a float32
+    quotient), p_draft must be a bf16 value within one bf16 ulp of torch's, and equal to it for all but a few rows (float32
+    softmax internals differ in the last place between any two implementations, torch's own CPU kernels included)."""
+    R, V = 248, 152064
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(R, V, generator=g) * 3).to(torch.bfloat16)
+    dn = torch.randint(0, V, (R,), generator=g)
+    am_ref = torch.argmax(x.float(), dim=-1)
+    dn[: R // 2] = am_ref[: R // 2]                                     # half the rows ask for the heaviest token
+    got, m, s, am = _run_rs_probs(x, dn, temperature)
+    scaled = x if temperature == 1.0 else x / float(temperature)        # bf16 tensor, JDN:66-69
+    want = torch.softmax(scaled, dim=-1)[torch.arange(R), dn]
+    assert want.dtype == torch.bfloat16
+    assert torch.equal(m, scaled.float().max(dim=-1).values)             # exact scaling, exact max
+    assert torch.equal(got.to(torch.bfloat16).float(), got)              # a bf16 value held in a float
+    d = (_bf16_bits(got) - _bf16_bits(want.float())).abs()
+    assert int(d.max()) <= 1
+    assert float((d != 0).float().mean()) < 0.03, d.nonzero().flatten().tolist()
+    assert am.tolist() == am_ref.tolist()                                # next-draft argmax is over the RAW logits
+    # the float32 row sum against an exact (float64) one
+    sx = torch.exp(scaled.double() - scaled.double().max(dim=-1, keepdim=True).values).sum(-1)
+    assert torch.allclose(s.double(), sx, rtol=2e-5)
 
 
 # ------------------------------------------------------------------------------------- fused RoPE + Q layout + KV append
@@ -380,26 +415,38 @@ def test_swiglu_matches_torch(dtype):
 
 # ------------------------------------------------------------------------------------- non-greedy step at batch scale
 def _rs_case(B, L, V, seed, p_hit, u_value):
-    """Logits whose softmax puts ~p_hit on the proposed token of every position; uniforms pinned to u_value."""
+    """Logits whose softmax puts ~p_hit on the proposed token of every position; uniforms pinned to u_value (None: random
+    24-bit uniforms)."""
     g = torch.Generator().manual_seed(seed)
     draft = torch.randint(0, V, (B, L), generator=g)
     logits = torch.randn(B, L - 1, V, generator=g) * 0.3
     boost = float(np.log(p_hit / (1 - p_hit) * (V - 1)))                 # logit gap that gives the proposed id mass ~p_hit
     logits.scatter_(2, draft[:, 1:].unsqueeze(-1), boost)
     n = 4 * B * L
-    unis = torch.full((n,), u_value)
-    bonus = torch.rand(n, generator=g)
+    unis = torch.full((n,), u_value) if u_value is not None else torch.randint(0, 1 << 24, (n,), generator=g).float() / float(1 << 24)
+    bonus = torch.randint(0, 1 << 24, (n,), generator=g).float() / float(1 << 24)
     pads = torch.randint(0, V, (n,), generator=g)
     return draft, logits, unis, bonus, pads
 
 
-def _run_rs(backend, B, L, V, seed, p_hit, u_value, dtype):
+def _run_rs(backend, B, L, V, seed, p_hit, u_value, dtype, temperature=1.0, eos=None):
     with use_backend(backend):
         dev = device_for(backend)
         draft, logits, unis, bonus, pads = _rs_case(B, L, V, seed, p_hit, u_value)
         st = ops.RsStepper(B, L, dev, pads, unis, bonus)
-        rows, toks, nd = st.step(draft.to(dev), logits.to(dtype).to(dev), 1.0, None, [L] * B, [3, 5, 7])
+        rows, toks, nd = st.step(draft.to(dev), logits.to(dtype).to(dev), temperature, eos, [L] * B, [3, 5, 7])
         return rows.copy(), toks.copy(), nd.cpu().numpy().copy(), st.cursors.cpu().tolist()
+
+
+def _assert_rs_equal(a, b, B):
+    f = N.RS_FIELDS.index
+    assert (a[0] == b[0]).all(), (a[0].tolist(), b[0].tolist())
+    for r in range(B):
+        n = int(b[0][r, f("n_committed")])
+        assert (a[1][r, :n] == b[1][r, :n]).all(), r
+        if b[0][r, f("active_next")]:
+            assert (a[2][r] == b[2][r]).all(), r
+    assert a[3] == b[3]
 
 
 @GPU
@@ -416,10 +463,86 @@ def test_rs_step_batch_matches_sequential_reference(p_hit, u_value):
     assert (a[0][:, f("n_bonus_draws")] == b[0][:, f("n_bonus_draws")]).all()
     if p_hit >= 0.6:
         assert (b[0][:, f("n_bonus_draws")] > 1).sum() >= 5          # the repair path really ran
-    assert (a[0] == b[0]).all()
-    for r in range(B):
-        n = int(b[0][r, f("n_committed")])
-        assert (a[1][r, :n] == b[1][r, :n]).all(), r
-        if b[0][r, f("active_next")]:
-            assert (a[2][r] == b[2][r]).all(), r
-    assert a[3] == b[3]
+    _assert_rs_equal(a, b, B)
+
+
+@GPU
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("temperature,p_hit,u_value", [(1.0, 0.6, None), (0.8, 0.5, None), (1.3, 0.7, 0.9)],
+                         ids=["T1", "T08", "T13_collisions"])
+def test_rs_step_at_the_real_vocabulary(dtype, temperature, p_hit, u_value):
+    """jf_rs_probs + jf_rs_step at V = 152064 (Qwen2.5's lm_head rows) against the row-by-row oracle restatement
+    (JDN:299-354, 581-639; tests/backends.py) in both dtypes: accepted counts, rejected positions, bonus tokens of the
+    two-level float64 inverse-CDF walk, draws, next drafts, every stream cursor.  bf16 runs torch's rounding points."""
+    B, L, V = 10, 9, 152064
+    a = _run_rs("hip", B, L, V, 21, p_hit, u_value, dtype, temperature, eos=7)
+    b = _run_rs("hostsim", B, L, V, 21, p_hit, u_value, dtype, temperature, eos=7)
+    f = N.RS_FIELDS.index
+    assert (b[0][:, f("reject_pos")] >= 0).sum() >= B // 2               # rejections (bonus draws) really happen
+    _assert_rs_equal(a, b, B)
+
+
+@GPU
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("temperature", [1.0, 0.7])
+def test_rs_onpolicy_step_at_the_real_vocabulary(dtype, temperature):
+    """jf_rs_probs + jf_rs_onpolicy_step at V = 152064 against the oracle restatement (JDO:270-327, 465-477): committed
+    tokens, bonus draws, the re-drafted rows (one inverse-CDF draw each) and both cursors."""
+    R, V = 12, 152064
+    g = torch.Generator().manual_seed(31)
+    proposed = torch.randint(0, V, (R,), generator=g)
+    logits = torch.randn(R, V, generator=g) * 0.5
+    boost = float(np.log(0.8 / 0.2 * (V - 1)))
+    logits[torch.arange(R), proposed] = boost
+    logits[4, proposed[4]] = 0.0                                         # position 4 is (almost surely) rejected
+    unis = torch.randint(0, 1 << 24, (64,), generator=g).float() / float(1 << 24)
+    unis[:4] = 0.01                                                      # positions 0..3 are accepted
+    multi = torch.randint(0, 1 << 24, (64,), generator=g).float() / float(1 << 24)
+    out = {}
+    for backend in ("hip", "hostsim"):
+        with use_backend(backend):
+            dev = device_for(backend)
+            st = ops.OnPolicyStepper(16, dev, unis, multi, [3])
+            out[backend] = st.step(proposed.to(dev), logits.to(dtype).to(dev), temperature, [2, 5]) + (st.cursors.cpu().tolist(),)
+    row_h, cm_h, rd_h, cur_h = out["hip"]
+    row_o, cm_o, rd_o, cur_o = out["hostsim"]
+    assert row_o["reject_pos"] == 4 and row_o["n_redraft"] == R - 5
+    assert row_h == row_o and cm_h == cm_o and cur_h == cur_o
+    n = row_o["n_committed"]
+    assert rd_h[n:] == rd_o[n:]
+
+
+@GPU
+def test_rs_step_batch64_block32_planted_mass():
+    """BASELINE config 5's shape: 64 rows x block 32 x V = 152064, bf16 logits.  Two ids per position carry ~all the mass
+    (the proposed one ~0.5, a planted alternative ~0.5), the uniform is pinned above 0.5: every row rejects at position 0 and
+    the residual draw must return the planted id (collisions with the proposed id are re-drawn, JDN:135-146; the rows behind
+    a collision are repaired).  Size-independent properties: one committed token per row, cursors add up."""
+    B, L, V = 64, 32, 152064
+    g = torch.Generator(device="cuda").manual_seed(3)
+    logits = torch.randn(B, L - 1, V, generator=g, device="cuda").to(torch.bfloat16)
+    draft = torch.randint(0, V, (B, L), generator=g, device="cuda")
+    alt = (draft[:, 1:] + 1 + torch.randint(0, V - 2, (B, L - 1), generator=g, device="cuda")) % V
+    assert bool((alt != draft[:, 1:]).all())
+    logits.scatter_(2, draft[:, 1:].unsqueeze(-1), 22.0)
+    logits.scatter_(2, alt.unsqueeze(-1), 22.0)
+    n = 4 * B
+    unis = torch.full((n,), 0.75)
+    bonus = torch.rand(n, generator=torch.Generator().manual_seed(9))
+    pads = torch.randint(0, V, (4 * B * L,))
+    st = ops.RsStepper(B, L, "cuda", pads, unis, bonus)
+    rows, toks, nd = st.step(draft, logits, 1.0, None, [L] * B, [0, 0, 0])
+    f = N.RS_FIELDS.index
+    assert (rows[:, f("reject_pos")] == 0).all() and (rows[:, f("n_committed")] == 1).all()
+    assert (rows[:, f("n_uniforms")] == 1).all()
+    want = alt[:, 0].cpu().numpy()
+    assert (toks[:, 0] == want).mean() >= 0.98                            # the rest of the vocabulary holds ~1e-3 of the mass
+    assert (toks[:, 0] != draft[:, 1].cpu().numpy()).all()                # a bonus never equals the rejected proposal
+    draws = rows[:, f("n_bonus_draws")]
+    assert draws.min() >= 1 and draws.max() <= 16 and 1.3 < draws.mean() < 3.0   # geometric with p ~ 0.5
+    assert st.cursors.cpu().tolist() == [B, int(draws.sum()), int(rows[:, f("n_pads")].sum())]
+    # next draft: seed = the bonus, then the greedy tail (argmax of rows 1.. = proposed or alt: a tie -> lower id), then pads
+    lo = torch.minimum(draft[:, 1:], alt).cpu().numpy()
+    ndc = nd.cpu().numpy()
+    assert (ndc[:, 0] == toks[:, 0]).all()
+    assert (ndc[:, 1:L - 1] == lo[:, 1:]).all()

@@ -11,10 +11,11 @@ from .conftest import load_golden
 MB = load_golden("mb_cases.json")
 SB = load_golden("sb_cases.json")
 JD = load_golden("jd_cases.json")
-JDN = load_golden("jdn_cases.json")
+JDN = load_golden("jdn_cases.json") + load_golden("jdn_cases_v2.json")
 MBR = load_golden("mb_raises.json")
 SLOTS = load_golden("slot_cases.json")
-JDO = load_golden("jdo_cases.json")
+JDO = load_golden("jdo_cases.json") + load_golden("jdo_cases_v2.json")
+SMX = load_golden("softmax_vectors.json")
 
 
 def scripted_forward(model):
@@ -177,14 +178,44 @@ def test_engine_greedy(case):
 
 
 # ----------------------------------------------------------------------------- engine non-greedy
+def _as_dtype(logits, logits_dtype):
+    """What ``.to(torch.bfloat16)`` does to the scripted model's float32 logits (values kept as float32)."""
+    return O.bf16_round(logits) if logits_dtype == "bf16" else logits
+
+
+@pytest.mark.parametrize("case", SMX, ids=[f"V{c['V']}_T{c['temperature']}" for c in SMX])
+def test_target_probs_follow_torch_rounding_points(case):
+    """_build_target_probs (JDN:110-123) recorded from torch on bf16 logits: the temperature-scaled logits are one rounding of
+    a float32 quotient and must agree bit for bit; the probabilities are a float32 softmax rounded to bf16 — float32 softmax
+    implementations differ in the last place, so entries may sit one bf16 ulp apart, in well under 1 % of the positions."""
+    V, T = case["V"], case["temperature"]
+    lb = np.array(case["logits_bf16"], dtype=np.uint16).reshape(-1, V)
+    x = O.bf16_bits_to_f32(lb)
+    t = np.float32(T)
+    scaled = x if T == 1.0 else O.bf16_round((x / t).astype(np.float32))
+    assert np.array_equal(O.f32_to_bf16_bits(scaled), np.array(case["scaled_bf16"], dtype=np.uint16).reshape(-1, V))
+    p = O.target_probs(x, T, "bf16")
+    got = O.f32_to_bf16_bits(p).astype(np.int64)
+    want = np.array(case["probs_bf16"], dtype=np.uint16).reshape(-1, V).astype(np.int64)
+    assert np.abs(got - want).max() <= 1                     # positive bf16 payloads are ordered like the values
+    assert (got != want).mean() < 0.01
+    # float32 logits keep a float32 softmax (no rounding point): 1e-5 relative against torch
+    pf = O.target_probs(x, T, "f32")
+    wf = np.array(case["probs_f32_of_f32_logits"], dtype=np.uint32).reshape(-1, V).view(np.float32)
+    assert np.allclose(pf, wf, rtol=2e-5, atol=0)
+    assert np.allclose(p.astype(np.float64).sum(-1), 1.0, atol=5e-3)
+
+
 @pytest.mark.parametrize("case", JDN, ids=[c["name"] for c in JDN])
 def test_engine_nongreedy(case):
     p = case["params"]
     seqs, models = _mk_seqs(case)
     by_id = {id(s): m for s, m in zip(seqs, models)}
 
+    ldt = p.get("logits_dtype", "f32")
+
     def fwd(ss, drafts):
-        return [by_id[id(s)].logits_rows(s.token_ids[:-1], [d])[0][:-1] for s, d in zip(ss, drafts)]
+        return [_as_dtype(by_id[id(s)].logits_rows(s.token_ids[:-1], [d])[0][:-1], ldt) for s, d in zip(ss, drafts)]
 
     pads = O.CounterStream(p["rng_seed"] * 3 + 1)
     unis = O.CounterStream(p["rng_seed"] * 3 + 2)
@@ -192,9 +223,9 @@ def test_engine_nongreedy(case):
     stats = O.new_stats()
     args = (p["eos_id"], p["temperature"], pads.pads(p["vocab"]), unis.uniform, bonus.uniform, stats)
     if p["batch"]:
-        out = O.nongreedy_generate_batch(fwd, seqs, *args)
+        out = O.nongreedy_generate_batch(fwd, seqs, *args, logits_dtype=ldt)
     else:
-        out = [O.nongreedy_generate_single(fwd, s, *args) for s in seqs]
+        out = [O.nongreedy_generate_single(fwd, s, *args, logits_dtype=ldt) for s in seqs]
     assert out == case["outputs"]
     assert stats == case["stats"]
     assert dict(pads=pads.k, uniforms=unis.k, bonus=bonus.k) == case["draws"]
@@ -209,16 +240,18 @@ def run_oracle_jdo(case):
     seqs, models = _mk_seqs(case, max_iters=p["max_blocks"])
     by_id = {id(s): m for s, m in zip(seqs, models)}
     trace = []
+    ldt = p.get("logits_dtype", "f32")
 
     def fwd(ss, drafts):
         trace.append(dict(seq_idx=[seqs.index(s) for s in ss], draft=[list(d) for d in drafts], seq_lens=[len(s) for s in ss]))
-        return [by_id[id(s)].logits_rows(s.token_ids[:-1], [d])[0][:-1] for s, d in zip(ss, drafts)]
+        return [_as_dtype(by_id[id(s)].logits_rows(s.token_ids[:-1], [d])[0][:-1], ldt) for s, d in zip(ss, drafts)]
 
     inits = O.CounterStream(p["rng_seed"] * 5 + 1)
     unis = O.CounterStream(p["rng_seed"] * 5 + 2)
     multi = O.CounterStream(p["rng_seed"] * 5 + 3)
     records, metrics = O.onpolicy_rollout_records_batch(fwd, seqs, p["temperature"], p["stop_ids"], p["pad_id"], p["vocab"],
-                                                        O.ScriptedRandom(inits), unis.uniform, multi.uniform)
+                                                        O.ScriptedRandom(inits), unis.uniform, multi.uniform,
+                                                        logits_dtype=ldt)
     return seqs, records, metrics, dict(inits=inits.k, uniforms=unis.k, multinomial=multi.k), trace
 
 
