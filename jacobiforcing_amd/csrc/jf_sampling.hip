@@ -53,19 +53,38 @@ __device__ __forceinline__ void rs_unpack(const u32x4 v, float (&x)[Elem<DT>::EP
         else { x[2 * j] = __uint_as_float(w[j] << 16); x[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u); }
     }
 }
+// the EPV raw values starting at element e0 (a multiple of EPV) as one 16-byte vector; slots at or beyond V hold -inf
+// (probability 0).  Split from the arithmetic so that callers can put several independent loads in flight first.
+template <int DT>
+__device__ __forceinline__ u32x4 rs_load_vec(const RsRow &r, int64_t e0) {
+    constexpr int EPV = Elem<DT>::EPV;
+    if (r.vec && e0 + EPV <= r.V) return *((const u32x4 *)r.p + e0 / EPV);
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if constexpr (DT == JF_F32) {
+            w[j] = (e0 + j < r.V) ? ((const uint32_t *)r.p)[e0 + j] : 0xFF800000u;
+        } else {
+            const uint32_t a = (e0 + 2 * j < r.V) ? ((const uint16_t *)r.p)[e0 + 2 * j] : 0xFF80u;
+            const uint32_t b = (e0 + 2 * j + 1 < r.V) ? ((const uint16_t *)r.p)[e0 + 2 * j + 1] : 0xFF80u;
+            w[j] = a | (b << 16);
+        }
+    }
+    u32x4 v = {w[0], w[1], w[2], w[3]};
+    return v;
+}
+template <int DT>
+__device__ __forceinline__ void rs_probs_from_vec(const RsRow &r, const u32x4 v, float (&p)[Elem<DT>::EPV]) {
+    constexpr int EPV = Elem<DT>::EPV;
+    float x[EPV];
+    rs_unpack<DT>(v, x);
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) p[j] = rs_prob<DT>(rs_scaled<DT>(x[j], r.t, r.inv_t, r.unit_t), r.M, r.S);
+}
 // probabilities of the EPV elements starting at element e0 (a multiple of EPV); elements >= V give 0
 template <int DT>
 __device__ __forceinline__ void rs_probs_of_vec(const RsRow &r, int64_t e0, float (&p)[Elem<DT>::EPV]) {
-    constexpr int EPV = Elem<DT>::EPV;
-    if (r.vec && e0 + EPV <= r.V) {
-        float x[EPV];
-        rs_unpack<DT>(*((const u32x4 *)r.p + e0 / EPV), x);
-#pragma unroll
-        for (int j = 0; j < EPV; ++j) p[j] = rs_prob<DT>(rs_scaled<DT>(x[j], r.t, r.inv_t, r.unit_t), r.M, r.S);
-    } else {
-#pragma unroll
-        for (int j = 0; j < EPV; ++j) p[j] = (e0 + j < r.V) ? rs_prob_at<DT>(r, e0 + j) : 0.f;
-    }
+    rs_probs_from_vec<DT>(r, rs_load_vec<DT>(r, e0), p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -78,12 +97,16 @@ __device__ __forceinline__ void rs_probs_of_vec(const RsRow &r, int64_t e0, floa
 // (raw chunk max, s) go to the workspace, the argmax to `packed` by atomicMax.
 //   SCALE 0: T == 1 (either dtype)           cs = log2 e
 //   SCALE 1: JF_F32, T != 1                  cs = log2 e / T  (x * (1/T), today's fp32 behaviour)
-//   SCALE 2: JF_BF16, T != 1                 xs = bf16(x / T) formed exactly: x * (1/T) decides the rounding unless it lies
-//                                            within 3 ulp of a bf16 tie, then the correctly rounded quotient does.
-__device__ __forceinline__ float scale_bf16_fast(float x, float inv_t, bool &amb) {
+//   SCALE 2: JF_BF16, T != 1                 xs = bf16(x * (1/T)): four integer/float ops.  A bf16 x is +-m * 2^e with an
+//                                            8-bit m, and both roundings commute with the power of two, so
+//                                            bf16(fl32(x / T)) is a function of m alone: the HOST checks the 128
+//                                            mantissas for this T (rs_scale_is_exact) and picks this variant only when
+//                                            the product reproduces torch's quotient for every one of them ...
+//   SCALE 3: JF_BF16, T != 1                 ... otherwise (a bf16 midpoint lies between product and quotient for some
+//                                            mantissa, ~0.2 % of temperatures) the correctly rounded quotient per element.
+__device__ __forceinline__ float scale_bf16_fast(float x, float inv_t) {
     const uint32_t q = __float_as_uint(x * inv_t);
-    amb = amb || (((q + 0x8003u) & 0xFFFFu) <= 6u);          // low half within [0x7FFD, 0x8003]
-    return __uint_as_float((q + 0x8000u) & 0xFFFF0000u);     // nearest; exact whenever not flagged (no tie possible there)
+    return __uint_as_float((q + 0x7FFFu + ((q >> 16) & 1u)) & 0xFFFF0000u);   // RNE (inf stays inf; NaN stays NaN-ish)
 }
 
 template <int DT> __device__ __forceinline__ float key_max_to_float(int32_t k);
@@ -113,16 +136,12 @@ __device__ __forceinline__ void rs_round(const u32x4 (&vv)[NV], FT &ft, uint32_t
     }
     float xmax = key_max_to_float<DT>(kmax);                 // the round's largest raw value (NaN if the round holds one)
     if constexpr (SCALE == 2) {
-        bool amb = false;
-        float xs[NE];
 #pragma unroll
-        for (int j = 0; j < NE; ++j) xs[j] = scale_bf16_fast(x[j], inv_t, amb);
-        if (amb) {                                           // ~1e-4 of the elements: settle the whole round exactly
+        for (int j = 0; j < NE; ++j) x[j] = scale_bf16_fast(x[j], inv_t);
+        xmax = scale_bf16_fast(xmax, inv_t);
+    } else if constexpr (SCALE == 3) {
 #pragma unroll
-            for (int j = 0; j < NE; ++j) xs[j] = bf16_rne(__fdiv_rn(x[j], t));
-        }
-#pragma unroll
-        for (int j = 0; j < NE; ++j) x[j] = xs[j];
+        for (int j = 0; j < NE; ++j) x[j] = bf16_rne(__fdiv_rn(x[j], t));
         xmax = bf16_rne(__fdiv_rn(xmax, t));
     }
     const float mr = xmax * cs;                              // monotone: the round's largest scaled value
@@ -171,6 +190,11 @@ __global__ __launch_bounds__(256) void rs_probs_partial_kernel(const void *logit
             rs_round<DT, SCALE, 4>(va, ft, ebase + (uint32_t)k * EPV, 256u * EPV, cs, t, inv_t, m, s);
             rs_round<DT, SCALE, 4>(vb, ft, ebase + (uint32_t)(k + 1024) * EPV, 256u * EPV, cs, t, inv_t, m, s);
         }
+        if (k + 3 * 256 < nvec) {                        // a remaining half batch
+            const u32x4 va[4] = {JF_LOAD(q), JF_LOAD(q + 256), JF_LOAD(q + 512), JF_LOAD(q + 768)};
+            rs_round<DT, SCALE, 4>(va, ft, ebase + (uint32_t)k * EPV, 256u * EPV, cs, t, inv_t, m, s);
+            k += 4 * 256; q += 4 * 256;
+        }
         for (; k < nvec; k += 256, q += 256) {          // this lane's remaining vectors, one at a time
             const u32x4 vv[1] = {JF_LOAD(q)};
             rs_round<DT, SCALE, 1>(vv, ft, ebase + (uint32_t)k * EPV, 0u, cs, t, inv_t, m, s);
@@ -187,7 +211,7 @@ __global__ __launch_bounds__(256) void rs_probs_partial_kernel(const void *logit
         const uint32_t kk = load_key<DT>(p, i);
         if (kk > best) { best = kk; bidx = (uint32_t)i; }
         float xv = load_f<DT>(p, i);
-        if constexpr (SCALE == 2) xv = bf16_rne(__fdiv_rn(xv, t));
+        if constexpr (SCALE >= 2) xv = bf16_rne(__fdiv_rn(xv, t));
         xv *= cs;
         if (xv > m) { s = (m == -INFINITY ? 0.f : s * __builtin_amdgcn_exp2f(m - xv)) + 1.f; m = xv; }
         else if (xv != -INFINITY) s += __builtin_amdgcn_exp2f(xv - m);
@@ -257,8 +281,21 @@ static const RsTune &rs_tune() {                            // read once: sweeps
     return t;
 }
 
+// Does bf16(x * fl(1/T)) equal torch's bf16(fl32(x / T)) for EVERY normal bf16 x?  Both roundings commute with powers of
+// two, so the 128 mantissas decide (host float division is correctly rounded, like ATen's div_true_kernel).
+static bool rs_scale_is_exact(float t) {
+    const float inv_t = 1.f / t;
+    auto rne = [](float v) { uint32_t u; memcpy(&u, &v, 4); u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u; return u; };
+    for (int m = 128; m < 256; ++m) {
+        const volatile float x = (float)m;
+        const volatile float q = x * inv_t, r = x / t;
+        if (rne(q) != rne(r)) return false;
+    }
+    return true;
+}
+
 static int64_t rs_chunk(int dtype, int64_t R, int64_t V, int64_t *cpr_out) {
-    const int64_t gran = 8 * (int64_t)256 * (dtype == JF_F32 ? 4 : 8);     // one full eight-vector batch per workgroup
+    const int64_t gran = (int64_t)256 * (dtype == JF_F32 ? 4 : 8);         // one vector per lane: equal chunks, balanced items
     int64_t per_row = (rs_tune().items + R - 1) / R;
     if (per_row < 1) per_row = 1;
     if (per_row > 64) per_row = 64;
@@ -299,8 +336,9 @@ extern "C" int jf_rs_probs(const void *logits, int dtype, int64_t R, int64_t V, 
         else { if (unit) JF_RS_P(JF_F32, false, 0); else JF_RS_P(JF_F32, false, 1); }
         rs_probs_finish_kernel<JF_F32><<<dim3((unsigned)((R + 255) / 256)), 256, 0, s>>>(logits, R, V, row_stride, draft_next, t, inv_t, part, (int)cpr, p_draft, row_max, row_sumexp);
     } else {
-        if (vec) { if (unit) JF_RS_P(JF_BF16, true, 0); else JF_RS_P(JF_BF16, true, 2); }
-        else { if (unit) JF_RS_P(JF_BF16, false, 0); else JF_RS_P(JF_BF16, false, 2); }
+        const bool fast = !unit && rs_scale_is_exact(t);
+        if (vec) { if (unit) JF_RS_P(JF_BF16, true, 0); else if (fast) JF_RS_P(JF_BF16, true, 2); else JF_RS_P(JF_BF16, true, 3); }
+        else { if (unit) JF_RS_P(JF_BF16, false, 0); else JF_RS_P(JF_BF16, false, 3); }
         rs_probs_finish_kernel<JF_BF16><<<dim3((unsigned)((R + 255) / 256)), 256, 0, s>>>(logits, R, V, row_stride, draft_next, t, inv_t, part, (int)cpr, p_draft, row_max, row_sumexp);
     }
 #undef JF_RS_P
@@ -314,12 +352,18 @@ extern "C" int jf_rs_probs(const void *logits, int dtype, int64_t R, int64_t V, 
 // Two levels, both streaming the row with lane-contiguous 16-byte loads:
 //   rs_rowsum_kernel   RS_SEG workgroups per selected row; each sums one contiguous vocabulary segment in float64
 //                      (per-lane partials, one tree) -> segsum[row][seg].  The row is read ONCE however many draws follow.
+//                      The workgroup whose segment holds the row's PROPOSED token also records the mass in front of it
+//                      inside the segment and its own probability: with the segment sums that is the token's interval
+//                      [c_lo, c_hi) of the CDF, so "this draw returns the proposed token again" (JDN:140-146: draw until
+//                      the sample differs, at most 16 times) is a comparison of u * total with two numbers — the serial
+//                      part of the reference's draw order costs a few cycles per draw and every row needs ONE real pick.
 //   rs_pick (device)   one workgroup per draw: prefix over the RS_SEG segment sums -> the segment the threshold falls
 //                      into -> re-read that one segment (V / RS_SEG elements, L2-resident) with a wavefront scan per
 //                      2048/1024-element tile -> the crossing lane resolves inside its 8/4 elements.
 // ------------------------------------------------------------------------------------------------
 constexpr int RS_SEG = 16;
 constexpr int RS_TILES = 8;                       // tiles of a segment whose per-lane sums are kept in registers
+constexpr int RS_MAX_TRIES = 16;                  // JDN:135 max_tries
 
 __host__ __device__ inline int64_t rs_seg_elems(int64_t V, int epv) {
     const int64_t tile = 256 * (int64_t)epv;
@@ -328,14 +372,26 @@ __host__ __device__ inline int64_t rs_seg_elems(int64_t V, int epv) {
 }
 
 struct RsWs {                                     // carve-up of the step workspace for `rows` items
-    double *segsum;                               // [rows, RS_SEG]
+    double *segsum;                               // [rows, RS_SEG] float64 mass of each vocabulary segment
+    double *lo_part;                              // [rows] mass in front of the avoided token inside its segment
+    double *p_avoid;                              // [rows] probability of the avoided token
     int32_t *sel_row;                             // [rows] logits row to sum for item i, -1 = none
+    int32_t *avoid;                               // [rows] token a draw must not return (the rejected proposal), -1 = none
+    float *pick_u;                                // [rows] the uniform of the draw that counts; < 0: masked argmax instead
 };
-static inline size_t rs_ws_bytes(int64_t rows) { return (size_t)rows * RS_SEG * sizeof(double) + (((size_t)rows * 4 + 15) / 16) * 16; }
+static inline size_t rs_ws_bytes(int64_t rows) {
+    const size_t r = (size_t)((rows + 3) / 4 * 4);
+    return r * RS_SEG * sizeof(double) + 2 * r * sizeof(double) + 3 * r * sizeof(int32_t);
+}
 __host__ __device__ inline RsWs rs_ws(void *ws, int64_t rows) {
+    const size_t r = (size_t)((rows + 3) / 4 * 4);
     RsWs w;
     w.segsum = (double *)ws;
-    w.sel_row = (int32_t *)((char *)ws + (size_t)rows * RS_SEG * sizeof(double));
+    w.lo_part = w.segsum + r * RS_SEG;
+    w.p_avoid = w.lo_part + r;
+    w.sel_row = (int32_t *)(w.p_avoid + r);
+    w.avoid = w.sel_row + r;
+    w.pick_u = (float *)(w.avoid + r);
     return w;
 }
 extern "C" size_t jf_rs_step_workspace_bytes(int64_t rows) { return rows > 0 ? rs_ws_bytes(rows) : 0; }
@@ -367,30 +423,89 @@ __device__ __forceinline__ RsRow rs_make_row(const void *logits, int64_t r, int6
 
 template <int DT>
 __global__ __launch_bounds__(256) void rs_rowsum_kernel(const void *logits, int64_t V, int64_t row_stride, const float *row_max,
-                                                         const float *row_sumexp, float t, const int32_t *sel_row, double *segsum) {
+                                                         const float *row_sumexp, float t, RsWs w) {
     constexpr int EPV = Elem<DT>::EPV;
     const int item = blockIdx.x / RS_SEG, seg = blockIdx.x % RS_SEG;
-    const int r = sel_row[item];
+    const int r = w.sel_row[item];
     if (r < 0) return;
     const RsRow row = rs_make_row<DT>(logits, r, V, row_stride, t, row_max[r], row_sumexp[r]);
     const int64_t segE = rs_seg_elems(V, EPV);
     const int64_t lo = (int64_t)seg * segE;
     int64_t hi = lo + segE;
     if (hi > V) hi = V;
-    double acc = 0.0;
-    for (int64_t e0 = lo + (int64_t)threadIdx.x * EPV; e0 < hi; e0 += 256 * EPV) {
-        float p[EPV];
-        rs_probs_of_vec<DT>(row, e0, p);
-        double a = 0.0;
+    const int64_t av = w.avoid[item];
+    const bool mine = av >= lo && av < hi;                   // workgroup-uniform: this segment holds the avoided token
+    double acc = 0.0, front = 0.0, pav = 0.0;
+    for (int64_t b0 = lo + (int64_t)threadIdx.x * EPV; b0 < hi; b0 += (int64_t)RS_TILES * 256 * EPV) {
+        u32x4 v[RS_TILES];                                   // up to RS_TILES independent 16-byte loads in flight per lane
 #pragma unroll
-        for (int j = 0; j < EPV; ++j) a += (double)p[j];
-        acc += a;
+        for (int k = 0; k < RS_TILES; ++k) {
+            const int64_t e0 = b0 + (int64_t)k * 256 * EPV;
+            if (e0 < hi) v[k] = rs_load_vec<DT>(row, e0);
+        }
+#pragma unroll
+        for (int k = 0; k < RS_TILES; ++k) {
+            const int64_t e0 = b0 + (int64_t)k * 256 * EPV;
+            if (e0 >= hi) continue;
+            float p[EPV];
+            rs_probs_from_vec<DT>(row, v[k], p);
+            double a = 0.0;
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) a += (double)p[j];
+            acc += a;
+            if (mine) {
+                if (e0 + EPV <= av) front += a;
+                else if (e0 <= av) {
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j) {
+                        if (e0 + j < av) front += (double)p[j];
+                        if (e0 + j == av) pav = (double)p[j];
+                    }
+                }
+            }
+        }
     }
     acc = wave_sum_f64(acc);
-    __shared__ double sw[4];
-    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
+    __shared__ double sw[4], sf[4], sp[4];
+    if (mine) { front = wave_sum_f64(front); pav = wave_sum_f64(pav); }
+    if ((threadIdx.x & 63) == 0) { sw[threadIdx.x >> 6] = acc; sf[threadIdx.x >> 6] = front; sp[threadIdx.x >> 6] = pav; }
     __syncthreads();
-    if (threadIdx.x == 0) segsum[(int64_t)item * RS_SEG + seg] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+    if (threadIdx.x == 0) {
+        w.segsum[(int64_t)item * RS_SEG + seg] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+        if (mine) { w.lo_part[item] = (sf[0] + sf[1]) + (sf[2] + sf[3]); w.p_avoid[item] = (sp[0] + sp[1]) + (sp[2] + sp[3]); }
+    }
+}
+
+// total mass of a row and the CDF interval [c_lo, c_hi) of its avoided token, from the segment sums.  `total` is formed
+// exactly as rs_pick forms it (segments in order), so both compare u * total with the same number.
+__device__ __forceinline__ void rs_interval(const RsWs &w, int item, int64_t V, int epv, double &total, double &c_lo, double &c_hi) {
+    const double *sg = w.segsum + (int64_t)item * RS_SEG;
+    const int64_t av = w.avoid[item];
+    const int sstar = (av >= 0 && av < V) ? (int)(av / rs_seg_elems(V, epv)) : -1;   // an id outside the vocabulary is never drawn
+    double run = 0.0, before = 0.0;
+#pragma unroll
+    for (int s = 0; s < RS_SEG; ++s) {
+        if (s == sstar) before = run;
+        run += sg[s];
+    }
+    total = run;
+    c_lo = sstar >= 0 ? before + w.lo_part[item] : 0.0;
+    c_hi = sstar >= 0 ? c_lo + w.p_avoid[item] : 0.0;
+}
+
+// Up to RS_MAX_TRIES draws from stream[(pos + tr) % len] by lanes 0..15 of one wavefront: the first one that does not
+// fall into [c_lo, c_hi) counts (JDN:136-146).  Returns the number of stream entries consumed; *u_final = the uniform that
+// counts, or -1 when all RS_MAX_TRIES samples were the avoided token (then JDN:147-153's masked argmax decides).
+template <class UFn>
+__device__ __forceinline__ int rs_count_draws(UFn u_at, double total, double c_lo, double c_hi, int lane, float *u_final) {
+    const float u = lane < RS_MAX_TRIES ? u_at(lane) : 0.f;
+    const double thr = (double)u * total;
+    const bool coll = lane < RS_MAX_TRIES && thr >= c_lo && thr < c_hi;
+    const unsigned free_mask = (unsigned)(~__ballot(coll)) & ((1u << RS_MAX_TRIES) - 1u);
+    if (free_mask == 0u) { *u_final = -1.f; return RS_MAX_TRIES; }
+    const int f = __builtin_ctz(free_mask);
+    *u_final = __shfl(u, f, 64);
+    return f + 1;
 }
 
 struct RsPickShared {
@@ -431,12 +546,16 @@ __device__ int rs_pick(const RsRow &row, const double *segsum /* global, RS_SEG 
     const int ntiles = (int)((hi - lo + 256 * EPV - 1) / (256 * EPV));
     // per-lane sums of the first RS_TILES tiles (independent loads), wavefront inclusive scans, wave totals to LDS
     double incl[RS_TILES], lex[RS_TILES];                    // inclusive / exclusive running sums inside the wavefront
+    u32x4 tv[RS_TILES];
+#pragma unroll
+    for (int k = 0; k < RS_TILES; ++k)
+        if (k < ntiles) tv[k] = rs_load_vec<DT>(row, lo + ((int64_t)k * 256 + tid) * EPV);   // independent loads first
 #pragma unroll
     for (int k = 0; k < RS_TILES; ++k) {
         double a = 0.0;
         if (k < ntiles) {
             float p[EPV];
-            rs_probs_of_vec<DT>(row, lo + ((int64_t)k * 256 + tid) * EPV, p);
+            rs_probs_from_vec<DT>(row, tv[k], p);
 #pragma unroll
             for (int j = 0; j < EPV; ++j) a += (double)p[j];
         }
@@ -527,54 +646,54 @@ __device__ int rs_masked_argmax(const RsRow &row, int64_t proposed, RsPickShared
     return mm ? jfmb::decode_packed(mm) : (int)proposed;
 }
 
-// Residual sampling of one row (JDN:135-153 / JDO:157-168): up to 16 draws from stream[(base + tr) % len] until the sample
-// differs from `proposed`, then the masked argmax.  Returns the token, *draws = stream entries consumed.
+// the draw that counts for one row: the pick at u (u >= 0), or the masked argmax after RS_MAX_TRIES collisions (u < 0).
+// The interval test and the walk agree except when u * total lies within float64 rounding of the proposed token's CDF
+// boundary; should the walk return the proposed token after all, the masked argmax is the answer (never the proposal).
 template <int DT>
-__device__ int rs_bonus_row(const RsRow &row, const double *segsum, int64_t proposed, const float *stream, int64_t stream_len,
-                            int64_t base, RsPickShared &sh, int *draws_out) {
-    int bonus = -1, draws = 0;
-    for (int tr = 0; tr < 16 && bonus < 0; ++tr) {
-        const int y = rs_pick<DT>(row, segsum, stream[(base + tr) % stream_len], sh);
-        draws++;
-        if ((int64_t)y != proposed) bonus = y;
-    }
-    if (bonus < 0) bonus = rs_masked_argmax<DT>(row, proposed, sh);
-    *draws_out = draws;
-    return bonus;
+__device__ int rs_final_pick(const RsRow &row, const double *segsum, int64_t proposed, float u, RsPickShared &sh) {
+    int y = -1;
+    if (u >= 0.f) y = rs_pick<DT>(row, segsum, u, sh);
+    if (y < 0 || (int64_t)y == proposed) y = rs_masked_argmax<DT>(row, proposed, sh);
+    return y;
 }
 
 // ------------------------------------------------------------------------------------------------
 // Accept/reject of every row of a batch (JDN:581-639).  The reference visits the rows in order and draws torch.rand /
 // torch.multinomial / torch.randint as it goes, so the position of every draw in the injected streams depends on the rows
-// before it.  Four launches keep that order exact:
+// before it.  Five launches keep that order exact while everything wide runs in parallel:
 //   rs_accept_kernel  (1 workgroup)   p_draft / uniforms staged in LDS by 256 threads, then ONE wavefront walks the rows:
-//                                     a row's L-1 accept tests are one ballot, so the serial chain is B steps, not B*(L-1);
-//                                     bonus draws are ASSUMED to take one stream entry per rejected row
-//   rs_rowsum_kernel  (B * RS_SEG)    float64 segment sums of every rejected row
-//   rs_bonus_kernel   (B workgroups)  the bonus draw of each rejected row at its assumed stream position
-//   rs_finish_kernel  (1 workgroup)   if some row needed more than one draw (its sample hit the proposed token) the rows
-//                                     after it are re-drawn in order with the true positions (segment sums are reused);
-//                                     EOS, next drafts, pads, cursors by parallel scans; packed re-zeroed
+//                                     a row's L-1 accept tests are one ballot, so the serial chain is B steps of LDS
+//                                     latency, not B*(L-1); results are written out by all threads afterwards
+//   rs_rowsum_kernel  (B * RS_SEG)    float64 segment sums of every rejected row + the proposed token's CDF interval
+//   rs_chain_kernel   (1 workgroup)   bonus-stream positions in row order: per rejected row one ballot over <= 16 staged
+//                                     uniforms against the interval gives its number of draws and the uniform that counts
+//   rs_bonus_kernel   (B workgroups)  ONE inverse-CDF walk per rejected row (or the masked argmax)
+//   rs_finish_kernel  (1 workgroup)   EOS, next drafts, pads, cursors by parallel scans; packed re-zeroed
 // ------------------------------------------------------------------------------------------------
-constexpr int RS_STAGE = 8192;      // floats of p_draft / uniforms staged in LDS by the accept scan (B * (L-1) <= this, else global)
+constexpr int RS_STAGE = 6144;      // floats of p_draft / uniforms staged in LDS by the accept scan (B * (L-1) <= this, else global)
+constexpr int RS_ROWS_LDS = 2048;   // rows whose scan results are kept in LDS
 
 __global__ __launch_bounds__(256) void rs_accept_kernel(const int64_t *draft, int B, int L, const float *p_draft, int eos_id,
                                                          const float *u_stream, int64_t u_len, const int64_t *u_cursor,
-                                                         int64_t *committed, jf_rs_row *rows, int32_t *sel_row) {
+                                                         int64_t *committed, jf_rs_row *rows, RsWs w) {
     __shared__ float s_p[RS_STAGE], s_u[RS_STAGE];          // s_p carries "proposed == EOS" in its sign bit (p >= 0)
+    __shared__ int s_res[RS_ROWS_LDS];                       // nacc | eos << 15 | (rej + 1) << 16 per row
     const int tid = threadIdx.x;
     const int W = L - 1;
     const int n = B * W;
     const int64_t uc0 = *u_cursor;
-    const bool staged = n <= RS_STAGE;
+    const int ub = (int)(uc0 % u_len);
+    const bool staged = n <= RS_STAGE && u_len < 0x7FFFFFFFll, in_lds = B <= RS_ROWS_LDS;
     auto p_eos = [&](int i) {
         const int b = i / W, tt = i - b * W;
         const uint32_t pb = __float_as_uint(p_draft[i]) & 0x7FFFFFFFu;
         const bool is_eos = eos_id >= 0 && draft[(int64_t)b * L + tt + 1] == (int64_t)eos_id;
         return __uint_as_float(pb | (is_eos ? 0x80000000u : 0u));
     };
-    if (staged)
-        for (int i = tid; i < n; i += 256) { s_p[i] = p_eos(i); s_u[i] = u_stream[(uc0 + i) % u_len]; }   // at most n uniforms are used
+    if (staged) {
+        const int ul = (int)u_len;
+        for (int i = tid; i < n; i += 256) { s_p[i] = p_eos(i); s_u[i] = u_stream[(ub + i) % ul]; }   // at most n uniforms are used
+    }
     __syncthreads();
     if (tid < 64) {
         const int lane = tid;
@@ -600,41 +719,91 @@ __global__ __launch_bounds__(256) void rs_accept_kernel(const int64_t *draft, in
                     used = t0 + f + 1;
                     break;
                 }
-                const int w = (W - t0) < 64 ? (W - t0) : 64;
-                nacc = t0 + w; used = t0 + w;
+                const int wd = (W - t0) < 64 ? (W - t0) : 64;
+                nacc = t0 + wd; used = t0 + wd;
             }
             if (lane == 0) {
-                jf_rs_row &rw = rows[b];
-                rw.n_committed = nacc; rw.eos = eos; rw.reject_pos = rej; rw.n_uniforms = used;
-                rw.n_bonus_draws = 0; rw.n_pads = 0; rw.active_next = 0;
-                rw.rsv = n_rej;                                     // bonus draws before this row if every draw is a single one
-                sel_row[b] = rej >= 0 ? b * W + rej : -1;
+                if (in_lds) s_res[b] = nacc | (eos << 15) | ((rej + 1) << 16);
+                else { rows[b].n_committed = nacc; rows[b].eos = eos; rows[b].reject_pos = rej; }
+                rows[b].n_uniforms = used;
+                rows[b].rsv = n_rej;                                // rejected rows before this one
             }
-            for (int i = lane; i < nacc; i += 64) committed[(int64_t)b * L + i] = draft[(int64_t)b * L + i + 1];
             used_total += used;
             if (rej >= 0) n_rej++;
         }
+    }
+    __syncthreads();
+    __threadfence_block();
+    // everything else about a row in parallel: row record, the rejected row's work item, the accepted tokens
+    for (int b = tid; b < B; b += 256) {
+        int nacc, eos, rej;
+        if (in_lds) { const int r = s_res[b]; nacc = r & 0x7FFF; eos = (r >> 15) & 1; rej = (r >> 16) - 1; }
+        else { nacc = rows[b].n_committed; eos = rows[b].eos; rej = rows[b].reject_pos; }
+        jf_rs_row &rw = rows[b];
+        rw.n_committed = nacc; rw.eos = eos; rw.reject_pos = rej;
+        rw.n_bonus_draws = 0; rw.n_pads = 0; rw.active_next = 0;
+        w.sel_row[b] = rej >= 0 ? b * W + rej : -1;
+        w.avoid[b] = rej >= 0 ? (int32_t)draft[(int64_t)b * L + rej + 1] : -1;
+        w.pick_u[b] = -1.f;
+    }
+    for (int64_t idx = tid; idx < (int64_t)B * W; idx += 256) {
+        const int b = (int)(idx / W), i = (int)(idx - (int64_t)b * W);
+        const int nacc = in_lds ? (s_res[b] & 0x7FFF) : rows[b].n_committed;
+        if (i < nacc) committed[(int64_t)b * L + i] = draft[(int64_t)b * L + i + 1];
+    }
+}
+
+// bonus-stream bookkeeping in row order (one workgroup): intervals in parallel, then one wavefront walks the rejected rows
+constexpr int RS_CHAIN_STAGE = 4096;
+__global__ __launch_bounds__(256) void rs_chain_kernel(int B, int64_t V, int epv, const float *b_stream, int64_t b_len,
+                                                        const int64_t *b_cursor, jf_rs_row *rows, RsWs w) {
+    __shared__ double s_tot[RS_ROWS_LDS / 2], s_lo[RS_ROWS_LDS / 2], s_hi[RS_ROWS_LDS / 2];
+    __shared__ float s_u[RS_CHAIN_STAGE];
+    __shared__ int s_nrej;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool in_lds = B <= RS_ROWS_LDS / 2;
+    const int64_t bc0 = *b_cursor;
+    if (tid == 0) s_nrej = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int b = tid; b < B; b += 256) {
+        if (rows[b].reject_pos < 0) continue;
+        mine++;
+        if (in_lds) { double t_, lo_, hi_; rs_interval(w, b, V, epv, t_, lo_, hi_); s_tot[b] = t_; s_lo[b] = lo_; s_hi[b] = hi_; }
+    }
+    if (mine) atomicAdd(&s_nrej, mine);
+    __syncthreads();
+    const int nrej = s_nrej;
+    if (nrej == 0) return;
+    const int win = (RS_MAX_TRIES * nrej < RS_CHAIN_STAGE && b_len < 0x7FFFFFFFll) ? RS_MAX_TRIES * nrej : 0;   // uniforms that can be touched
+    if (win) { const int bl = (int)b_len, bb = (int)(bc0 % b_len); for (int i = tid; i < win; i += 256) s_u[i] = b_stream[(bb + i) % bl]; }
+    __syncthreads();
+    if (tid >= 64) return;
+    int off = 0;                                            // stream entries consumed by the rows before
+    for (int b = 0; b < B; ++b) {
+        if (rows[b].reject_pos < 0) continue;
+        double t_, lo_, hi_;
+        if (in_lds) { t_ = s_tot[b]; lo_ = s_lo[b]; hi_ = s_hi[b]; } else rs_interval(w, b, V, epv, t_, lo_, hi_);
+        float uf;
+        const int o = off;
+        const int draws = rs_count_draws([&](int tr) { return win ? s_u[o + tr] : b_stream[(bc0 + o + tr) % b_len]; }, t_, lo_, hi_, lane, &uf);
+        if (lane == 0) { rows[b].n_bonus_draws = draws; w.pick_u[b] = uf; }
+        off += draws;
     }
 }
 
 template <int DT>
 __global__ __launch_bounds__(256) void rs_bonus_kernel(const void *logits, int64_t V, int64_t row_stride, const int64_t *draft, int L,
                                                         const float *row_max, const float *row_sumexp, float temp,
-                                                        const float *b_stream, int64_t b_len, const int64_t *b_cursor,
-                                                        const double *segsum, int64_t *committed, jf_rs_row *rows) {
+                                                        int64_t *committed, jf_rs_row *rows, RsWs w) {
     __shared__ RsPickShared sh;
     const int b = blockIdx.x;
     const int rej = rows[b].reject_pos;
     if (rej < 0) return;
     const int64_t r = (int64_t)b * (L - 1) + rej;
     const RsRow row = rs_make_row<DT>(logits, r, V, row_stride, temp, row_max[r], row_sumexp[r]);
-    int draws = 0;
-    const int bonus = rs_bonus_row<DT>(row, segsum + (int64_t)b * RS_SEG, draft[(int64_t)b * L + rej + 1], b_stream, b_len,
-                                       *b_cursor + rows[b].rsv, sh, &draws);
-    if (threadIdx.x == 0) {
-        committed[(int64_t)b * L + rows[b].n_committed] = bonus;
-        rows[b].n_bonus_draws = draws;
-    }
+    const int bonus = rs_final_pick<DT>(row, w.segsum + (int64_t)b * RS_SEG, draft[(int64_t)b * L + rej + 1], w.pick_u[b], sh);
+    if (threadIdx.x == 0) committed[(int64_t)b * L + rows[b].n_committed] = bonus;
 }
 
 // exclusive prefix sum over consecutive lanes of one wavefront; *total = sum over all 64 lanes
@@ -649,42 +818,13 @@ __device__ __forceinline__ int wave_excl_scan_i32(int v, int lane, int *total) {
     return x - v;
 }
 
-template <int DT>
-__global__ __launch_bounds__(256) void rs_finish_kernel(const void *logits, int64_t V, int64_t row_stride, const int64_t *draft,
-                                                         int B, int L, const float *row_max, const float *row_sumexp,
-                                                         unsigned long long *packed, float temp, int eos_id,
-                                                         const int32_t *remaining, int64_t *u_cursor, const float *b_stream,
-                                                         int64_t b_len, int64_t *b_cursor, const int64_t *pad_stream,
-                                                         int64_t pad_len, int64_t *pad_cursor, const double *segsum,
+__global__ __launch_bounds__(256) void rs_finish_kernel(int B, int L, unsigned long long *packed, int eos_id,
+                                                         const int32_t *remaining, int64_t *u_cursor, int64_t *b_cursor,
+                                                         const int64_t *pad_stream, int64_t pad_len, int64_t *pad_cursor,
                                                          int64_t *committed, int64_t *next_draft, jf_rs_row *rows) {
-    __shared__ RsPickShared sh;
-    __shared__ int s_first_bad;
+    __shared__ int s_total_pads;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int64_t bc0 = *b_cursor;
-    if (tid == 0) s_first_bad = 0x7FFFFFFF;
-    __syncthreads();
-    for (int b = tid; b < B; b += 256)
-        if (rows[b].reject_pos >= 0 && rows[b].n_bonus_draws != 1) atomicMin(&s_first_bad, b);
-    __syncthreads();
-    // rows after the first one that needed more than one draw sampled at the wrong stream positions: redo them in order
-    if (s_first_bad < B) {
-        const int fb = s_first_bad;
-        int64_t base = bc0 + rows[fb].rsv + rows[fb].n_bonus_draws;
-        for (int b = fb + 1; b < B; ++b) {
-            const int rej = rows[b].reject_pos;
-            if (rej < 0) continue;
-            const int64_t r = (int64_t)b * (L - 1) + rej;
-            const RsRow row = rs_make_row<DT>(logits, r, V, row_stride, temp, row_max[r], row_sumexp[r]);
-            int draws = 0;
-            const int bonus = rs_bonus_row<DT>(row, segsum + (int64_t)b * RS_SEG, draft[(int64_t)b * L + rej + 1], b_stream, b_len,
-                                               base, sh, &draws);
-            if (tid == 0) { committed[(int64_t)b * L + rows[b].n_committed] = bonus; rows[b].n_bonus_draws = draws; }
-            base += draws;
-        }
-    }
-    __threadfence_block();
-    __syncthreads();
-    // finalize, rows in parallel: bonus joins the committed tokens, EOS, next-draft shape (JDN:444-466 / 619-638)
+    // rows in parallel: bonus joins the committed tokens, EOS, next-draft shape (JDN:444-466 / 619-638)
     for (int b = tid; b < B; b += 256) {
         jf_rs_row &rw = rows[b];
         int n = rw.n_committed;
@@ -724,12 +864,11 @@ __global__ __launch_bounds__(256) void rs_finish_kernel(const void *logits, int6
             if (b < B) rows[b].rsv = pc + ep;                          // this row's offset into the pad stream
             uc += tu; bc += tb; pc += tp;
         }
-        if (lane == 0) { *u_cursor += uc; *b_cursor = bc0 + bc; sh.pick = pc; }
+        if (lane == 0) { *u_cursor += uc; *b_cursor += bc; s_total_pads = pc; }
     }
     __threadfence_block();
     __syncthreads();
     const int64_t pc0 = *pad_cursor;
-    const int total_pads = sh.pick;
     for (int64_t idx = tid; idx < (int64_t)B * L; idx += 256) {        // every next-draft element independently
         const int b = (int)(idx / L), i = (int)(idx - (int64_t)b * L);
         const jf_rs_row rw = rows[b];
@@ -753,7 +892,7 @@ __global__ __launch_bounds__(256) void rs_finish_kernel(const void *logits, int6
     __syncthreads();
     for (int64_t i = tid; i < (int64_t)B * (L - 1); i += 256) packed[i] = 0ull;
     for (int b = tid; b < B; b += 256) rows[b].rsv = 0;
-    if (tid == 0) *pad_cursor = pc0 + total_pads;
+    if (tid == 0) *pad_cursor = pc0 + s_total_pads;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -761,8 +900,9 @@ __global__ __launch_bounds__(256) void rs_finish_kernel(const void *logits, int6
 // reject of ONE sequence's proposed tokens with a stop-token SET (JDO:270-327), then a fresh sample of every not yet
 // accepted position from this forward's distribution (JDO:465-477).
 //   rs_op_accept_kernel   one wavefront: the R accept tests are one ballot
-//   rs_rowsum_kernel      float64 segment sums of the rejected row and of every row after it (the re-draft candidates)
-//   rs_op_bonus_kernel    one workgroup: the bonus draw(s), stop flag, stream cursors
+//   rs_rowsum_kernel      float64 segment sums of the rejected row (+ its proposed token's CDF interval) and of every
+//                         row after it (the re-draft candidates)
+//   rs_op_bonus_kernel    one workgroup: draws counted against the interval, ONE walk, stop flag, stream cursors
 //   rs_op_redraft_kernel  one workgroup per re-drafted row: one draw each; re-zeroes packed
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool op_is_stop(const int32_t *stop_ids, int n_stop, int64_t tok) {
@@ -773,7 +913,7 @@ __device__ __forceinline__ bool op_is_stop(const int32_t *stop_ids, int n_stop, 
 __global__ __launch_bounds__(64) void rs_op_accept_kernel(const int64_t *proposed, int R, const float *p_draft,
                                                            const int32_t *stop_ids, int n_stop, const float *u_stream,
                                                            int64_t u_len, const int64_t *u_cursor, int64_t *committed,
-                                                           jf_op_row *out, int32_t *sel_row) {
+                                                           jf_op_row *out, RsWs w) {
     const int lane = threadIdx.x;
     const int64_t uc = *u_cursor;
     int n = 0, stop = 0, rej = -1, used = 0;
@@ -793,11 +933,14 @@ __global__ __launch_bounds__(64) void rs_op_accept_kernel(const int64_t *propose
             used = t0 + f + 1;
             break;
         }
-        const int w = (R - t0) < 64 ? (R - t0) : 64;
-        n = t0 + w; used = t0 + w;
+        const int wd = (R - t0) < 64 ? (R - t0) : 64;
+        n = t0 + wd; used = t0 + wd;
     }
     for (int i = lane; i < n; i += 64) committed[i] = proposed[i];
-    for (int i = lane; i < R; i += 64) sel_row[i] = (rej >= 0 && i >= rej) ? i : -1;
+    for (int i = lane; i < R; i += 64) {
+        w.sel_row[i] = (rej >= 0 && i >= rej) ? i : -1;
+        w.avoid[i] = (i == rej) ? (int32_t)proposed[i] : -1;
+    }
     if (lane == 0) {
         out->n_committed = n; out->stop_hit = stop; out->reject_pos = rej; out->n_bonus_draws = 0;
         out->n_uniforms = used; out->n_redraft = 0; out->redraft_base_lo = 0; out->redraft_base_hi = 0;
@@ -809,15 +952,26 @@ __global__ __launch_bounds__(256) void rs_op_bonus_kernel(const void *logits, in
                                                            int R, const float *row_max, const float *row_sumexp, float temp,
                                                            const int32_t *stop_ids, int n_stop, int64_t *u_cursor,
                                                            const float *m_stream, int64_t m_len, int64_t *m_cursor,
-                                                           const double *segsum, int64_t *committed, jf_op_row *out) {
+                                                           int64_t *committed, jf_op_row *out, RsWs w) {
     __shared__ RsPickShared sh;
+    __shared__ float s_uf;
+    __shared__ int s_draws;
     const int tid = threadIdx.x;
     const int rej = out->reject_pos;
     const int64_t mc = *m_cursor;
     int n = out->n_committed, stop = out->stop_hit, draws = 0;
     if (rej >= 0) {                                                    // JDO:157-168 (bonus != proposed)
+        if (tid < 64) {
+            double t_, lo_, hi_;
+            rs_interval(w, rej, V, Elem<DT>::EPV, t_, lo_, hi_);
+            float uf;
+            const int d = rs_count_draws([&](int tr) { return m_stream[(mc + tr) % m_len]; }, t_, lo_, hi_, tid, &uf);
+            if (tid == 0) { s_uf = uf; s_draws = d; }
+        }
+        __syncthreads();
+        draws = s_draws;
         const RsRow row = rs_make_row<DT>(logits, rej, V, row_stride, temp, row_max[rej], row_sumexp[rej]);
-        const int bonus = rs_bonus_row<DT>(row, segsum + (int64_t)rej * RS_SEG, proposed[rej], m_stream, m_len, mc, sh, &draws);
+        const int bonus = rs_final_pick<DT>(row, w.segsum + (int64_t)rej * RS_SEG, proposed[rej], s_uf, sh);
         if (tid == 0) committed[n] = bonus;
         n += 1;
         if (op_is_stop(stop_ids, n_stop, bonus)) stop = 1;
@@ -860,20 +1014,21 @@ extern "C" int jf_rs_onpolicy_step(const void *logits, int dtype, int64_t V, int
         !m_cursor || !committed || !redraft || !row || !workspace || (n_stop > 0 && !stop_ids))
         return fail(JF_E_INVALID, "jf_rs_onpolicy_step: null pointer");
     if (u_len <= 0 || m_len <= 0 || n_stop < 0) return fail(JF_E_INVALID, "jf_rs_onpolicy_step: empty random stream");
-    if (workspace_bytes < rs_ws_bytes(R)) return fail(JF_E_INVALID, "jf_rs_onpolicy_step: workspace too small");
+    if (workspace_bytes < rs_ws_bytes(R) || ((uintptr_t)workspace % 8) != 0) return fail(JF_E_INVALID, "jf_rs_onpolicy_step: workspace too small or misaligned");
     if (dtype != JF_F32 && dtype != JF_BF16) return fail(JF_E_INVALID, "jf_rs_onpolicy_step: dtype %d", dtype);
+    if (V <= 0 || V > 0x7FFFFFFFll) return fail(JF_E_INVALID, "jf_rs_onpolicy_step: V=%lld", (long long)V);
     const float t = (temperature <= 0.f) ? 1.f : temperature;
     hipStream_t s = (hipStream_t)stream;
     const RsWs w = rs_ws(workspace, R);
     unsigned long long *pk = (unsigned long long *)packed;
-    rs_op_accept_kernel<<<1, 64, 0, s>>>(proposed, R, p_draft, stop_ids, n_stop, u_stream, u_len, u_cursor, committed, row, w.sel_row);
+    rs_op_accept_kernel<<<1, 64, 0, s>>>(proposed, R, p_draft, stop_ids, n_stop, u_stream, u_len, u_cursor, committed, row, w);
     if (dtype == JF_F32) {
-        rs_rowsum_kernel<JF_F32><<<R * RS_SEG, 256, 0, s>>>(logits, V, row_stride, row_max, row_sumexp, t, w.sel_row, w.segsum);
-        rs_op_bonus_kernel<JF_F32><<<1, 256, 0, s>>>(logits, V, row_stride, proposed, R, row_max, row_sumexp, t, stop_ids, n_stop, u_cursor, m_stream, m_len, m_cursor, w.segsum, committed, row);
+        rs_rowsum_kernel<JF_F32><<<R * RS_SEG, 256, 0, s>>>(logits, V, row_stride, row_max, row_sumexp, t, w);
+        rs_op_bonus_kernel<JF_F32><<<1, 256, 0, s>>>(logits, V, row_stride, proposed, R, row_max, row_sumexp, t, stop_ids, n_stop, u_cursor, m_stream, m_len, m_cursor, committed, row, w);
         rs_op_redraft_kernel<JF_F32><<<R, 256, 0, s>>>(logits, V, row_stride, R, row_max, row_sumexp, t, m_stream, m_len, row, w.segsum, redraft, pk);
     } else {
-        rs_rowsum_kernel<JF_BF16><<<R * RS_SEG, 256, 0, s>>>(logits, V, row_stride, row_max, row_sumexp, t, w.sel_row, w.segsum);
-        rs_op_bonus_kernel<JF_BF16><<<1, 256, 0, s>>>(logits, V, row_stride, proposed, R, row_max, row_sumexp, t, stop_ids, n_stop, u_cursor, m_stream, m_len, m_cursor, w.segsum, committed, row);
+        rs_rowsum_kernel<JF_BF16><<<R * RS_SEG, 256, 0, s>>>(logits, V, row_stride, row_max, row_sumexp, t, w);
+        rs_op_bonus_kernel<JF_BF16><<<1, 256, 0, s>>>(logits, V, row_stride, proposed, R, row_max, row_sumexp, t, stop_ids, n_stop, u_cursor, m_stream, m_len, m_cursor, committed, row, w);
         rs_op_redraft_kernel<JF_BF16><<<R, 256, 0, s>>>(logits, V, row_stride, R, row_max, row_sumexp, t, m_stream, m_len, row, w.segsum, redraft, pk);
     }
     return check_launch("rs_onpolicy kernels");
@@ -887,25 +1042,28 @@ extern "C" int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_
                           int64_t *next_draft, jf_rs_row *rows, void *workspace, size_t workspace_bytes, void *stream) {
     if (B <= 0) return JF_OK;
     if (L < 2) return fail(JF_E_INVALID, "Draft must have at least 2 tokens (seed + 1 speculative)");
+    if (L > 0x7FFF) return fail(JF_E_INVALID, "jf_rs_step: L=%d too large", L);
     if (!logits || !draft || !p_draft || !row_max || !row_sumexp || !packed || !remaining || !u_stream || !u_cursor ||
         !bonus_stream || !bonus_cursor || !pad_stream || !pad_cursor || !committed || !next_draft || !rows || !workspace)
         return fail(JF_E_INVALID, "jf_rs_step: null pointer");
     if (u_len <= 0 || bonus_len <= 0 || pad_len <= 0) return fail(JF_E_INVALID, "jf_rs_step: empty random stream");
-    if (workspace_bytes < rs_ws_bytes(B)) return fail(JF_E_INVALID, "jf_rs_step: workspace too small");
+    if (workspace_bytes < rs_ws_bytes(B) || ((uintptr_t)workspace % 8) != 0) return fail(JF_E_INVALID, "jf_rs_step: workspace too small or misaligned");
+    if (V <= 0 || V > 0x7FFFFFFFll) return fail(JF_E_INVALID, "jf_rs_step: V=%lld", (long long)V);
     const float t = (temperature <= 0.f) ? 1.f : temperature;
     if (dtype != JF_F32 && dtype != JF_BF16) return fail(JF_E_INVALID, "jf_rs_step: dtype %d", dtype);
     hipStream_t s = (hipStream_t)stream;
     unsigned long long *pk = (unsigned long long *)packed;
     const RsWs w = rs_ws(workspace, B);
-    rs_accept_kernel<<<1, 256, 0, s>>>(draft, B, L, p_draft, eos_id, u_stream, u_len, u_cursor, committed, rows, w.sel_row);
+    rs_accept_kernel<<<1, 256, 0, s>>>(draft, B, L, p_draft, eos_id, u_stream, u_len, u_cursor, committed, rows, w);
     if (dtype == JF_F32) {
-        rs_rowsum_kernel<JF_F32><<<B * RS_SEG, 256, 0, s>>>(logits, V, row_stride, row_max, row_sumexp, t, w.sel_row, w.segsum);
-        rs_bonus_kernel<JF_F32><<<B, 256, 0, s>>>(logits, V, row_stride, draft, L, row_max, row_sumexp, t, bonus_stream, bonus_len, bonus_cursor, w.segsum, committed, rows);
-        rs_finish_kernel<JF_F32><<<1, 256, 0, s>>>(logits, V, row_stride, draft, B, L, row_max, row_sumexp, pk, t, eos_id, remaining, u_cursor, bonus_stream, bonus_len, bonus_cursor, pad_stream, pad_len, pad_cursor, w.segsum, committed, next_draft, rows);
+        rs_rowsum_kernel<JF_F32><<<B * RS_SEG, 256, 0, s>>>(logits, V, row_stride, row_max, row_sumexp, t, w);
+        rs_chain_kernel<<<1, 256, 0, s>>>(B, V, 4, bonus_stream, bonus_len, bonus_cursor, rows, w);
+        rs_bonus_kernel<JF_F32><<<B, 256, 0, s>>>(logits, V, row_stride, draft, L, row_max, row_sumexp, t, committed, rows, w);
     } else {
-        rs_rowsum_kernel<JF_BF16><<<B * RS_SEG, 256, 0, s>>>(logits, V, row_stride, row_max, row_sumexp, t, w.sel_row, w.segsum);
-        rs_bonus_kernel<JF_BF16><<<B, 256, 0, s>>>(logits, V, row_stride, draft, L, row_max, row_sumexp, t, bonus_stream, bonus_len, bonus_cursor, w.segsum, committed, rows);
-        rs_finish_kernel<JF_BF16><<<1, 256, 0, s>>>(logits, V, row_stride, draft, B, L, row_max, row_sumexp, pk, t, eos_id, remaining, u_cursor, bonus_stream, bonus_len, bonus_cursor, pad_stream, pad_len, pad_cursor, w.segsum, committed, next_draft, rows);
+        rs_rowsum_kernel<JF_BF16><<<B * RS_SEG, 256, 0, s>>>(logits, V, row_stride, row_max, row_sumexp, t, w);
+        rs_chain_kernel<<<1, 256, 0, s>>>(B, V, 8, bonus_stream, bonus_len, bonus_cursor, rows, w);
+        rs_bonus_kernel<JF_BF16><<<B, 256, 0, s>>>(logits, V, row_stride, draft, L, row_max, row_sumexp, t, committed, rows, w);
     }
+    rs_finish_kernel<<<1, 256, 0, s>>>(B, L, pk, eos_id, remaining, u_cursor, bonus_cursor, pad_stream, pad_len, pad_cursor, committed, next_draft, rows);
     return check_launch("rs_step kernels");
 }

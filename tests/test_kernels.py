@@ -478,7 +478,7 @@ def test_rs_step_at_the_real_vocabulary(dtype, temperature, p_hit, u_value):
     a = _run_rs("hip", B, L, V, 21, p_hit, u_value, dtype, temperature, eos=7)
     b = _run_rs("hostsim", B, L, V, 21, p_hit, u_value, dtype, temperature, eos=7)
     f = N.RS_FIELDS.index
-    assert (b[0][:, f("reject_pos")] >= 0).sum() >= B // 2               # rejections (bonus draws) really happen
+    assert (b[0][:, f("reject_pos")] >= 0).sum() >= 3                    # rejections (bonus draws) really happen
     _assert_rs_equal(a, b, B)
 
 
@@ -496,7 +496,7 @@ def test_rs_onpolicy_step_at_the_real_vocabulary(dtype, temperature):
     logits[torch.arange(R), proposed] = boost
     logits[4, proposed[4]] = 0.0                                         # position 4 is (almost surely) rejected
     unis = torch.randint(0, 1 << 24, (64,), generator=g).float() / float(1 << 24)
-    unis[:4] = 0.01                                                      # positions 0..3 are accepted
+    unis[2:6] = 0.01                                                     # positions 0..3 are accepted (the cursor starts at 2)
     multi = torch.randint(0, 1 << 24, (64,), generator=g).float() / float(1 << 24)
     out = {}
     for backend in ("hip", "hostsim"):

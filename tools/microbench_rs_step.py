@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""jf_rs_probs + jf_rs_step at BASELINE config 5's shape (batch 64, block 32, V = 152064): every row rejects somewhere, so
+the bonus path (segment sums + inverse-CDF pick + repair) runs for all 64 rows.  Prints the HIP-event time of the step
+(all launches of jf_rs_step) and of jf_rs_probs; run it under `rocprofv3 --kernel-trace --stats` for the per-kernel split.
+
+    python tools/microbench_rs_step.py [--dtype bf16|f32] [--temperature 1.0] [--batch 64] [--block 32]
+"""
+import argparse
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from jacobiforcing_amd import ops  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--temperature", type=float, default=1.0)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--block", type=int, default=32)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--p-hit", type=float, default=0.6)
+    a = ap.parse_args()
+    B, L, V = a.batch, a.block, 152064
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    g = torch.Generator(device="cuda").manual_seed(1)
+    logits = (torch.randn(B, L - 1, V, generator=g, device="cuda") * 2).to(dt)
+    draft = torch.randint(0, V, (B, L), generator=g, device="cuda")
+    # the proposed id of every position holds ~p_hit of the mass at this temperature; uniforms are random -> most rows
+    # reject within a few positions and the residual draw collides with the proposed id with probability ~p_hit
+    import math
+    others = V * math.exp(0.5 * (2.0 / a.temperature) ** 2)            # E[sum exp(x / T)] for x ~ N(0, 2^2)
+    logits.scatter_(2, draft[:, 1:].unsqueeze(-1), a.temperature * math.log(a.p_hit / (1 - a.p_hit) * others))
+    n = 1 << 16
+    st = ops.RsStepper(B, L, "cuda", torch.randint(0, V, (n,)), torch.rand(n), torch.rand(n))
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for _ in range(3):
+        rows, toks, nd = st.step(draft, logits, a.temperature, None, [L] * B, [0, 0, 0])
+    torch.cuda.synchronize()
+    ev[0].record()
+    for i in range(a.iters):
+        st.step(draft, logits, a.temperature, None, [L] * B, [i * 7, i * 3, 0])
+    ev[1].record()
+    torch.cuda.synchronize()
+    import numpy as np
+    from jacobiforcing_amd import _native as N
+    f = N.RS_FIELDS.index
+    rej = int((rows[:, f("reject_pos")] >= 0).sum())
+    print(f"B={B} L={L} V={V} {a.dtype} T={a.temperature}: {ev[0].elapsed_time(ev[1]) / a.iters * 1e3:.1f} us per probs+step+readback "
+          f"({rej} of {B} rows rejected, mean committed {rows[:, f('n_committed')].mean():.2f}, mean draws "
+          f"{rows[:, f('n_bonus_draws')][rows[:, f('reject_pos')] >= 0].mean():.2f})", flush=True)
+    print(f"algorithmic bytes: probs {B * (L - 1) * V * logits.element_size() / 1e6:.1f} MB, bonus rows {rej * V * logits.element_size() / 1e6:.1f} MB "
+          f"(segment sums, read once) + {rej * V * logits.element_size() / 16 / 1e6:.2f} MB (one segment per draw)")
+
+
+if __name__ == "__main__":
+    main()
