@@ -2,19 +2,31 @@
 """bench.py — tokens/sec + mean tokens/forward of multiblock Jacobi decoding (n=32, K=2, r=0.85, pool=4) on a
 Qwen2.5-Coder-7B-shaped model, synthetic HumanEval-shaped prompts, random-init bf16 weights.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--total-prompts M]
 
 A "step" is one Jacobi iteration over the rank's batch of prompts: one PyTorch forward over every prompt's rows,
 then the HIP loop body (jf_argmax_scatter -> jf_mb_step -> jf_kv_commit) and one descriptor read-back.  The timed
-region is exactly K steps between barrier+synchronize fences; every rank runs the same per-GPU workload (weak
-scaling, prompts shard over ranks, no data-path collective) and rank 0 prints ONE JSON line whose `value` is the
-whole-job accepted tokens per second.
+region is exactly K steps between barrier+synchronize fences; prompts shard over ranks with no data-path collective and
+rank 0 prints ONE JSON line whose `value` is the whole-job accepted tokens per second.
+
+Ranks: one process per GPU.  Under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the
+ranks are already there (RANK / LOCAL_RANK / WORLD_SIZE in the environment); started as a plain command with
+--gpus N > 1, bench.py starts the N ranks itself through the same launcher (the reference's only data-parallel precedent
+is process-per-GPU too: JacobiForcing/scripts/inference/scanning_hyperparameter_jacobi_decoding_mr.sh:30-84).  Fewer
+visible GPUs than ranks is an error, never a silent single-GPU run.
+
+Scaling modes: default WEAK (every rank decodes --prompts-per-gpu prompts, 64 = BASELINE config 4's batch per replica);
+--total-prompts M is STRONG scaling (M prompts sharded over the ranks: M = 64 is config 4 as BASELINE states it, 8 per
+GPU at N = 8).
 
 Extra objects on the line:
   roofline      — the argmax launch (the convergence kernel's HBM stream): algorithmic bytes = draft-carrying rows * V * 2
                   per launch over the average launch duration measured with HIP events on the launch stream.
   cpu_baseline  — the CPU oracle (the reference's HF loop + DynamicCache handling restated) with a torch-CPU
                   forward of the same weights, timed on the host cores for a bounded sample.
+  roofline_by_shape — the same launch (and the state-machine step behind it) at 1, 8 and 64 prompts per GPU: rows, bytes,
+                  microseconds, fraction of 8 TB/s — the latency regime of the literal config 3 / config 4 shapes, measured
+                  in this run with short extra windows on rank 0.
   scripted_acceptance — the same K-step measurement with the synthetic acceptance model switched on (the random
                   weights accept ~1 token per forward; a Jacobi-Forcing checkpoint accepts ~4).
 """
@@ -24,6 +36,8 @@ import argparse
 import json
 import os
 import random
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -167,12 +181,35 @@ def cpu_verify_kernel(rows: int, V: int, budget_s: float = 3.0):
                 what="oracle/verify_ref.c ref_argmax_rows (C + OpenMP) over bf16 logits of the bench's launch shape")
 
 
+def launch_command(n_gpus: int, argv, port: int):
+    """The launcher line bench.py runs itself under when it is started as a plain command with --gpus N > 1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+
+
+def spawn_ranks(n_gpus: int, argv) -> int:
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if "JF_FORCE_DEVICE" not in os.environ and visible < n_gpus:
+        raise SystemExit(f"bench.py --gpus {n_gpus}: only {visible} GPU(s) visible; refusing to measure fewer GPUs than asked "
+                         "(JF_FORCE_DEVICE=<i> + JF_DIST_BACKEND=gloo puts every rank on one GPU for a plumbing check)")
+    with socket.socket() as sk:                      # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n_gpus)))
+    return subprocess.call(launch_command(n_gpus, argv, port), env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--prompts-per-gpu", type=int, default=64)
+    ap.add_argument("--prompts-per-gpu", type=int, default=64, help="weak scaling: prompts decoded by every rank")
+    ap.add_argument("--total-prompts", type=int, default=0,
+                    help="strong scaling: this many prompts sharded over the ranks (64 = BASELINE config 4 as stated)")
+    ap.add_argument("--no-shapes", action="store_true", help="skip the roofline_by_shape windows (1 / 8 / 64 prompts per GPU)")
     ap.add_argument("--model", default=os.environ.get("JF_MODEL", "qwen2.5-coder-7b"), help="qwen2.5-coder-7b | tiny | <hf dir>")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=float(os.environ.get("JF_CPU_BASELINE_S", "20")))
     ap.add_argument("--no-scripted", action="store_true")
@@ -181,12 +218,18 @@ def main():
     ap.add_argument("--logit-align", type=int, default=0, help="lm_head row count rounded up to this multiple (0 = default)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))          # plain command: start the N ranks, relay their exit code
     # JF_DIST_BACKEND=gloo + JF_FORCE_DEVICE=0 lets N ranks share one GPU (plumbing check of the N>1 path on a 1-GPU box)
     info = jd.init_from_env(os.environ.get("JF_DIST_BACKEND", "nccl"))
-    if info.world_size != args.gpus and info.world_size > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={info.world_size}")
+    if info.world_size != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={info.world_size}: one rank per GPU")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the Jacobi loop body has no CPU path")
+    if "JF_FORCE_DEVICE" not in os.environ and torch.cuda.device_count() < min(info.world_size, info.local_rank + 1):
+        raise SystemExit(f"rank {info.rank}: local rank {info.local_rank} has no GPU ({torch.cuda.device_count()} visible)")
     dev_index = int(os.environ.get("JF_FORCE_DEVICE", info.local_rank))
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -210,7 +253,10 @@ def main():
     # whole timed window (random weights can emit any id; a finished prompt would shrink that rank's per-step work)
     prm = ops.MultiblockParams(n=32, K=2, r=0.85, lookahead_start_ratio=0.0, n_gram_pool_size=4,
                                eos_token_id=None, pad_token_id=cfg.pad_token_id)
-    P = args.prompts_per_gpu
+    strong = args.total_prompts > 0
+    if strong and args.total_prompts % info.world_size:
+        raise SystemExit(f"--total-prompts {args.total_prompts} does not split over {info.world_size} ranks")
+    P = args.total_prompts // info.world_size if strong else args.prompts_per_gpu
     vocab_hi = min(151643, cfg.vocab_size - 2)
     all_prompts = humaneval_shaped_prompts(P * info.world_size, seed=1234, vocab_hi=vocab_hi)
     prompts = jd.shard_prompts(all_prompts, info)
@@ -253,12 +299,16 @@ def main():
         out = {
             "metric": "tokens/sec (+ mean tokens/forward), multiblock Jacobi n=32 K=2 r=0.85 pool=4, Qwen2.5-Coder-7B",
             "value": value, "unit": "tokens/s", "n_gpus": info.world_size, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": agg["seconds"] / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": agg["seconds"] / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "tokens_per_forward": tpf,
-            "config": {"workload": f"BASELINE config 3 decoding (multiblock lookahead + rejection recycling, greedy) over "
-                                   f"HumanEval-shaped synthetic prompts, a batch of {P} per GPU replica (config 4's batch), "
-                                   f"{P * info.world_size} prompts sharded {info.world_size}-way, no data-path collective",
+            "config": {"workload": (f"BASELINE config 4 as stated (STRONG scaling): {P * info.world_size} HumanEval-shaped synthetic "
+                                    f"prompts sharded {info.world_size}-way = {P} per GPU, " if strong else
+                                    f"WEAK scaling: a batch of {P} HumanEval-shaped synthetic prompts per GPU replica (config 4's "
+                                    f"batch), {P * info.world_size} prompts sharded {info.world_size}-way, ") +
+                                   "BASELINE config 3 decoding (multiblock lookahead + rejection recycling, greedy), "
+                                   "no data-path collective",
+                       "scaling_mode": "strong" if strong else "weak", "total_prompts": P * info.world_size,
                        "model": name, "n": 32, "K": 2, "r": 0.85, "pool": 4, "prompts_per_gpu": P,
                        "steps_measured": steps_done, "logits_dtype": "bf16",
                        "weights": "random-init (no network for checkpoints); acceptance is what these weights give",

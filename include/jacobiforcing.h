@@ -163,6 +163,21 @@ JF_API int jf_mb_pack(int32_t *states, int64_t state_ints, int P, int32_t Tpad, 
 JF_API int jf_mb_step(int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len,
                jf_mb_desc *desc, void *stream);
 
+/* jf_argmax_scatter / jf_argmax_partial + jf_mb_step as ONE launch: the argmax items of the whole forward and one
+ * "stepper" workgroup per prompt that pre-loads the prompt's live state into LDS while the logits stream, waits for its
+ * own rows only (per-prompt arrival counter) and runs the loop body on LDS — a prompt's state machine overlaps the
+ * other prompts' streaming and there is no dependent launch.  Same results as the two calls.
+ *   logits [R, V] (rows follow valid_index when out_index is given, else the Rtot x Tpad rectangle of jf_mb_pack),
+ *   row_prompt [Rtot] as written by jf_mb_pack, Tpad as passed to jf_mb_pack,
+ *   arrive [P] int32: zero on entry (one torch.zeros at start-up); the call leaves it zero,
+ *   params: the jf_mb_params the states were begun with.
+ * Rows that are not 16-byte aligned fall back to the two launches.  A stepper that waits longer than 2 s for its rows
+ * reports JF_E_LAUNCH in its descriptor instead of hanging the GPU. */
+JF_API int jf_mb_verify(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, const int32_t *out_index,
+                 int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len, int32_t Tpad,
+                 const int32_t *row_prompt, int32_t *arrive, jf_mb_desc *desc, const jf_mb_params *params,
+                 void *stream);
+
 /* Copy results of finished calls: ret [P, ret_cap] int64 (ret_len in desc). */
 JF_API int jf_mb_read_ret(const int32_t *states, int64_t state_ints, int P, int64_t *ret, int32_t ret_cap,
                    void *stream);

@@ -76,6 +76,8 @@ _SIGNATURES = {
     "jf_mb_begin": (C.c_int, [_vp, _i64, C.c_int, C.POINTER(MbParams), _vp, _vp, _vp, _vp]),
     "jf_mb_pack": (C.c_int, [_vp, _i64, C.c_int, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "jf_mb_step": (C.c_int, [_vp, _i64, C.c_int, _vp, _i64, _vp, _vp]),
+    "jf_mb_verify": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _vp, _vp, _i64, C.c_int, _vp, _i64, _i32, _vp, _vp, _vp,
+                               C.POINTER(MbParams), _vp]),
     "jf_mb_read_ret": (C.c_int, [_vp, _i64, C.c_int, _vp, _i32, _vp]),
     "jf_kv_append": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i32, _vp]),
     "jf_rope_kv_append": (C.c_int, [_vp, C.c_int, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,

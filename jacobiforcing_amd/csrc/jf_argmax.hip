@@ -1,134 +1,15 @@
 // jf_argmax.hip — (a2) block-local argmax over the vocabulary, the convergence kernel's HBM stream, and (a3) the
-// accepted-prefix scan.  16 B per lane per load, eight loads in flight, one compare chain per 16-byte vector, wave shuffles,
-// one 64-bit atomicMax per (row, chunk); helpers (order keys, FastTrack) live in jf_common.h.
-#include "jf_common.h"
+// accepted-prefix scan.  Device bodies live in jf_argmax_dev.h (shared with the fused verify launch of jf_multiblock.hip).
+#include "jf_argmax_dev.h"
 
-// VEC: rows are 16-byte aligned -> 16 B per lane per load, UNROLL independent loads in flight per lane
-// (4 or 8 KB per wavefront), one compare chain per 16-byte vector.  All loop arithmetic is 32-bit.
-template <int DT, bool VEC, int UNROLL>
-__global__ __launch_bounds__(AM_TPB) void argmax_partial_kernel(const void *__restrict__ logits, int64_t R, int64_t V,
-                                                                 int64_t row_stride, unsigned long long *__restrict__ packed,
-                                                                 int chunks_per_row, int64_t chunk_elems,
-                                                                 const int32_t *__restrict__ out_index) {
-    using E = Elem<DT>;
-    constexpr int EPV = E::EPV;
-    const int64_t item = blockIdx.x;
-    const int64_t row = item / chunks_per_row;
-    // slot of this row's result (jf_argmax_scatter): read up front so its latency hides behind the stream; < 0 = padding row
-    const int64_t orow = out_index ? (int64_t)out_index[row] : row;
-    if (orow < 0) return;
-    const int c = (int)(item - row * chunks_per_row);
-    const int64_t begin = (int64_t)c * chunk_elems;
-    int64_t end = begin + chunk_elems;
-    if (end > V) end = V;
-    const typename E::T *p = (const typename E::T *)logits + row * row_stride;
-    const int tid = threadIdx.x;
-
-    uint32_t best = 0u, bidx = 0xFFFFFFFFu;   // every real key is >= 0x007FFFFF > 0
-    if constexpr (VEC) {
-        FastTrack<DT, true> ft;                                       // small problems: skip the end-of-item reload
-        const uint32_t ebase = (uint32_t)begin;                       // element index of the chunk start (V < 2^31)
-        const int nvec = (int)((end - begin) / EPV);                  // full 16-byte vectors in this chunk
-        const u32x4 *q = (const u32x4 *)p + (begin / EPV) + tid;
-        int k = tid;
-        if constexpr (UNROLL == 16) {
-            scan_pipelined<DT, AM_TPB>(ft, q, k, nvec, ebase);
-        } else {
-            for (; k + (UNROLL - 1) * AM_TPB < nvec; k += UNROLL * AM_TPB, q += UNROLL * AM_TPB) {
-                u32x4 v[UNROLL];
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) v[u] = JF_LOAD(q + u * AM_TPB);
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) ft.consume(v[u], ebase + (uint32_t)(k + u * AM_TPB) * EPV);
-            }
-            for (; k < nvec; k += AM_TPB, q += AM_TPB) {
-                const u32x4 v0 = JF_LOAD(q);
-                ft.consume(v0, ebase + (uint32_t)k * EPV);
-            }
-        }
-        const int64_t vec_end = begin + ((end - begin) / EPV) * EPV;
-        if (__syncthreads_or(ft.saw_nan() ? 1 : 0)) {
-            scan_exact<DT>(p, begin, vec_end, tid, best, bidx);          // NaN somewhere in this chunk: exact rescan
-        } else if (ft.bvec != 0xFFFFFFFFu) {
-            best = ft.ukey();
-            bidx = ft.resolve(p);
-        }
-        scan_exact<DT>(p, vec_end, end, tid, best, bidx);                 // ragged tail (V % EPV), indices above all vectors
-    } else {
-        scan_exact<DT>(p, begin, end, tid, best, bidx);
-    }
-    // (key, first index) -> one u64 whose max is the answer: larger key wins, then smaller index
-    uint64_t pk = ((uint64_t)best << 32) | (uint64_t)(~bidx);
-    pk = wave_max_u64(pk);
-    __shared__ uint64_t s_part[AM_TPB / 64];
-    if ((tid & 63) == 0) s_part[tid >> 6] = pk;
-    __syncthreads();
-    if (tid == 0) {
-        uint64_t m = s_part[0];
-#pragma unroll
-        for (int w = 1; w < AM_TPB / 64; ++w) m = s_part[w] > m ? s_part[w] : m;
-        atomicMax(packed + orow, (unsigned long long)m);
-    }
+template <int DT, bool VEC, bool NT>
+__global__ __launch_bounds__(AM_TPB) void argmax_partial_kernel(ArgmaxArgs a) {
+    (void)argmax_wg_item<DT, VEC, NT>(a, blockIdx.x);
 }
 
-// Wave-independent variant: every wavefront owns one (row, chunk) item end to end — no LDS, no workgroup
-// barrier; the NaN vote is a ballot, the reduction six shuffles, the publish one atomicMax per wavefront.
-template <int DT, int UNROLL>
-__global__ __launch_bounds__(AM_TPB) void argmax_wave_kernel(const void *__restrict__ logits, int64_t R, int64_t V,
-                                                              int64_t row_stride, unsigned long long *__restrict__ packed,
-                                                              int chunks_per_row, int64_t chunk_elems,
-                                                              const int32_t *__restrict__ out_index) {
-    using E = Elem<DT>;
-    constexpr int EPV = E::EPV;
-    const int lane = threadIdx.x & 63;
-    const int64_t item = (int64_t)blockIdx.x * (AM_TPB / 64) + (threadIdx.x >> 6);
-    if (item >= R * chunks_per_row) return;
-    const int64_t row = item / chunks_per_row;
-    const int64_t orow = out_index ? (int64_t)out_index[row] : row;
-    if (orow < 0) return;
-    const int c = (int)(item - row * chunks_per_row);
-    const int64_t begin = (int64_t)c * chunk_elems;
-    int64_t end = begin + chunk_elems;
-    if (end > V) end = V;
-    const typename E::T *p = (const typename E::T *)logits + row * row_stride;
-
-    FastTrack<DT, false> ft;                                          // one wave per SIMD: VALU latency is exposed, keep it lean
-    const uint32_t ebase = (uint32_t)begin;
-    const int nvec = (int)((end - begin) / EPV);
-    const u32x4 *q = (const u32x4 *)p + (begin / EPV) + lane;
-    int k = lane;
-    if constexpr (UNROLL == 16) {
-        scan_pipelined<DT, 64>(ft, q, k, nvec, ebase);
-    } else {
-        for (; k + (UNROLL - 1) * 64 < nvec; k += UNROLL * 64, q += UNROLL * 64) {
-            u32x4 v[UNROLL];
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) v[u] = JF_LOAD(q + u * 64);
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) ft.consume(v[u], ebase + (uint32_t)(k + u * 64) * EPV);
-        }
-        for (; k < nvec; k += 64, q += 64) {
-            const u32x4 v0 = JF_LOAD(q);
-            ft.consume(v0, ebase + (uint32_t)k * EPV);
-        }
-    }
-    uint32_t best = 0u, bidx = 0xFFFFFFFFu;
-    const int64_t vec_end = begin + (int64_t)nvec * EPV;
-    if (__ballot(ft.saw_nan()) != 0ull) {
-        for (int64_t j = begin + lane; j < vec_end; j += 64) {
-            const uint32_t kk = load_key<DT>(p, j);
-            if (kk > best) { best = kk; bidx = (uint32_t)j; }
-        }
-    } else if (ft.bvec != 0xFFFFFFFFu) {
-        best = ft.ukey();
-        bidx = ft.resolve(p);
-    }
-    for (int64_t j = vec_end + lane; j < end; j += 64) {
-        const uint32_t kk = load_key<DT>(p, j);
-        if (kk > best) { best = kk; bidx = (uint32_t)j; }
-    }
-    uint64_t pk = wave_max_u64(((uint64_t)best << 32) | (uint64_t)(~bidx));
-    if (lane == 0) atomicMax(packed + orow, (unsigned long long)pk);
+template <int DT, bool NT>
+__global__ __launch_bounds__(AM_TPB) void argmax_wave_kernel(ArgmaxArgs a) {
+    (void)argmax_wave_item<DT, NT>(a, (int64_t)blockIdx.x * (AM_TPB / 64) + (threadIdx.x >> 6));
 }
 
 __global__ void argmax_decode_kernel(unsigned long long *packed, int64_t R, int64_t *greedy) {
@@ -139,14 +20,29 @@ __global__ void argmax_decode_kernel(unsigned long long *packed, int64_t R, int6
     }
 }
 
-static int64_t env_i64(const char *name, int64_t dflt) {
-    const char *e = getenv(name);
-    return (e && *e) ? atoll(e) : dflt;
+// Tuning overrides for the sweeps in tools/: read and validated ONCE (no environment scans on the hot path).
+struct ArgmaxTune { int64_t chunk, items; int wave, nt; };
+static const ArgmaxTune &argmax_tune() {
+    static const ArgmaxTune t = [] {
+        auto rd = [](const char *name, int64_t lo, int64_t hi, int64_t dflt) {
+            const char *e = getenv(name);
+            if (!e || !*e) return dflt;
+            const long long v = atoll(e);
+            return (v >= lo && v <= hi) ? (int64_t)v : dflt;
+        };
+        ArgmaxTune r;
+        r.chunk = rd("JF_ARGMAX_CHUNK", 1, 1ll << 31, 0);
+        r.items = rd("JF_ARGMAX_ITEMS", 1, 1ll << 24, 0);
+        r.wave = (int)rd("JF_ARGMAX_WAVE", 0, 1, -1);
+        r.nt = (int)rd("JF_ARGMAX_NT", 0, 1, -1);
+        return r;
+    }();
+    return t;
 }
 
 // Balanced chunking: cpr chunks per row of equal size (rounded up to `gran` elements).
 static int64_t pick_chunk(int64_t gran, int64_t R, int64_t V, int64_t target_items) {
-    int64_t c = env_i64("JF_ARGMAX_CHUNK", 0);
+    const int64_t c = argmax_tune().chunk;
     if (c > 0) return ((c + gran - 1) / gran) * gran;
     int64_t per_row = (target_items + R - 1) / R;
     if (per_row < 1) per_row = 1;
@@ -156,34 +52,24 @@ static int64_t pick_chunk(int64_t gran, int64_t R, int64_t V, int64_t target_ite
     return ((chunk + gran - 1) / gran) * gran;
 }
 
-static int argmax_launch(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, const int32_t *out_index,
-                         uint64_t *packed, void *stream) {
-    if (R == 0) return JF_OK;
-    if (!logits || !packed) return fail(JF_E_INVALID, "jf_argmax_partial: null pointer");
-    if (dtype != JF_F32 && dtype != JF_BF16) return fail(JF_E_INVALID, "jf_argmax_partial: dtype %d", dtype);
-    if (R < 0 || V <= 0 || row_stride < V || V > 0x7FFFFFFFll)
-        return fail(JF_E_INVALID, "jf_argmax_partial: bad shape R=%lld V=%lld stride=%lld", (long long)R, (long long)V,
-                    (long long)row_stride);
+// Launch shape, measured on MI355X (profiles/argmax_microbench_r01*.txt): big problems stream best as ~1 wavefront per SIMD
+// (1024 items, each a long contiguous range with 8 x 16 B per lane in flight: 6.8 TB/s fp32 at R>=512); below ~140 MB the
+// kernel is launch/ramp bound and 4-wave workgroups sharing a chunk (best vector kept in registers, one item per ~64 KB,
+// 256..1024 items) are 5-20 % faster.  Non-temporal loads from 60 MB up, plain loads below.
+int argmax_plan(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, ArgmaxPlan *pl) {
     const int esz = dtype == JF_F32 ? 4 : 2;
     const int epv = 16 / esz;
-    const bool vec = (((uintptr_t)logits) % 16 == 0) && ((row_stride * esz) % 16 == 0);
-    hipStream_t s = (hipStream_t)stream;
-    unsigned long long *pk = (unsigned long long *)packed;
-    // Measured on MI355X (profiles/argmax_microbench_r01*.txt): big problems stream best as ~1 wavefront per SIMD
-    // (1024 items, each a long contiguous range with 8 x 16 B per lane in flight: 6.8 TB/s fp32 at R>=512);
-    // below ~140 MB the kernel is launch/ramp bound and 4-wave workgroups sharing a chunk (best vector kept in
-    // registers, one item per ~64 KB, 256..1024 items) are 5-20 % faster.
+    const ArgmaxTune &tn = argmax_tune();
+    pl->vec = (((uintptr_t)logits) % 16 == 0) && ((row_stride * esz) % 16 == 0);
     const int64_t bytes = R * V * esz;
-    const bool wave_mode = vec && env_i64("JF_ARGMAX_WAVE", bytes >= (140ll << 20) ? 1 : 0) != 0;
-    const int64_t unroll = env_i64("JF_ARGMAX_UNROLL", 8);       // 4, 8, or 16 (= two pipelined sets of 8)
-    const bool deep = unroll >= 8;
-    const bool pipe = unroll >= 16;
-    if (wave_mode) {
+    pl->wave_mode = pl->vec && (tn.wave >= 0 ? tn.wave != 0 : bytes >= (140ll << 20));
+    pl->nt = tn.nt >= 0 ? tn.nt != 0 : bytes >= (60ll << 20);
+    if (pl->wave_mode) {
         // one item per wavefront, ~one wavefront per SIMD (256 CUs x 4 SIMDs = 1024 slots).  Split each row into the
         // smallest number of chunks whose makespan ceil(items / 1024) * (V / per_row) is within 10 % of the best
         // split of up to 4 wavefronts per SIMD: e.g. R = 384 -> 5 chunks per row (1920 items, two rounds of V/5) instead
         // of 3 (1152 items: a second round for only 128 of them).
-        int64_t items_target = env_i64("JF_ARGMAX_ITEMS", 0);
+        int64_t items_target = tn.items;
         if (items_target <= 0) {
             const int64_t slots = 1024, max_pr = (4 * slots + R - 1) / R;
             double best = 1e30;
@@ -198,37 +84,51 @@ static int argmax_launch(const void *logits, int dtype, int64_t R, int64_t V, in
             }
             items_target = R * pick;
         }
-        const int64_t chunk = pick_chunk(64 * epv, R, V, items_target);
-        const int64_t cpr = (V + chunk - 1) / chunk;
-        const int64_t items = R * cpr;
-        const int64_t blocks = (items + (AM_TPB / 64) - 1) / (AM_TPB / 64);
-        if (blocks > 0x7FFFFFFFll) return fail(JF_E_CAPACITY, "jf_argmax_partial: grid too large");
-        dim3 grid((unsigned)blocks), block(AM_TPB);
-#define JF_LAUNCHW(DT, UNR) argmax_wave_kernel<DT, UNR><<<grid, block, 0, s>>>(logits, R, V, row_stride, pk, (int)cpr, chunk, out_index)
-        if (dtype == JF_F32) { if (pipe) JF_LAUNCHW(JF_F32, 16); else if (deep) JF_LAUNCHW(JF_F32, 8); else JF_LAUNCHW(JF_F32, 4); }
-        else { if (pipe) JF_LAUNCHW(JF_BF16, 16); else if (deep) JF_LAUNCHW(JF_BF16, 8); else JF_LAUNCHW(JF_BF16, 4); }
-#undef JF_LAUNCHW
+        pl->chunk = pick_chunk(64 * epv, R, V, items_target);
+        pl->cpr = (V + pl->chunk - 1) / pl->chunk;
+        pl->items = R * pl->cpr;
+        pl->blocks = (pl->items + (AM_TPB / 64) - 1) / (AM_TPB / 64);
+    } else {
+        int64_t wg_items = bytes >> 16;
+        if (wg_items < 256) wg_items = 256;
+        if (wg_items > 1024) wg_items = 1024;
+        pl->chunk = pick_chunk((int64_t)AM_TPB * epv, R, V, tn.items > 0 ? tn.items : wg_items);
+        pl->cpr = (V + pl->chunk - 1) / pl->chunk;
+        pl->items = R * pl->cpr;
+        pl->blocks = pl->items;
+    }
+    if (pl->blocks > 0x7FFFFFFFll) return fail(JF_E_CAPACITY, "jf_argmax: grid too large");
+    return JF_OK;
+}
+
+static int argmax_launch(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, const int32_t *out_index,
+                         uint64_t *packed, void *stream) {
+    if (R == 0) return JF_OK;
+    if (!logits || !packed) return fail(JF_E_INVALID, "jf_argmax_partial: null pointer");
+    if (dtype != JF_F32 && dtype != JF_BF16) return fail(JF_E_INVALID, "jf_argmax_partial: dtype %d", dtype);
+    if (R < 0 || V <= 0 || row_stride < V || V > 0x7FFFFFFFll)
+        return fail(JF_E_INVALID, "jf_argmax_partial: bad shape R=%lld V=%lld stride=%lld", (long long)R, (long long)V,
+                    (long long)row_stride);
+    ArgmaxPlan pl;
+    const int rc = argmax_plan(logits, dtype, R, V, row_stride, &pl);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const ArgmaxArgs a{logits, R, V, row_stride, (unsigned long long *)packed, (int)pl.cpr, pl.chunk, out_index};
+    const dim3 grid((unsigned)pl.blocks), block(AM_TPB);
+    if (pl.wave_mode) {
+        if (dtype == JF_F32) { if (pl.nt) argmax_wave_kernel<JF_F32, true><<<grid, block, 0, s>>>(a); else argmax_wave_kernel<JF_F32, false><<<grid, block, 0, s>>>(a); }
+        else { if (pl.nt) argmax_wave_kernel<JF_BF16, true><<<grid, block, 0, s>>>(a); else argmax_wave_kernel<JF_BF16, false><<<grid, block, 0, s>>>(a); }
         return check_launch("argmax_wave_kernel");
     }
-    int64_t wg_items = bytes >> 16;
-    if (wg_items < 256) wg_items = 256;
-    if (wg_items > 1024) wg_items = 1024;
-    const int64_t chunk = pick_chunk((int64_t)AM_TPB * epv, R, V, env_i64("JF_ARGMAX_ITEMS", wg_items));
-    const int64_t cpr = (V + chunk - 1) / chunk;
-    const int64_t items = R * cpr;
-    if (items > 0x7FFFFFFFll) return fail(JF_E_CAPACITY, "jf_argmax_partial: grid too large");
-    dim3 grid((unsigned)items), block(AM_TPB);
-#define JF_LAUNCH(DT, VECF, UNR) argmax_partial_kernel<DT, VECF, UNR><<<grid, block, 0, s>>>(logits, R, V, row_stride, pk, (int)cpr, chunk, out_index)
+#define JF_LAUNCH(DT, VECF, NTF) argmax_partial_kernel<DT, VECF, NTF><<<grid, block, 0, s>>>(a)
     if (dtype == JF_F32) {
-        if (!vec) JF_LAUNCH(JF_F32, false, 4);
-        else if (pipe) JF_LAUNCH(JF_F32, true, 16);
-        else if (deep) JF_LAUNCH(JF_F32, true, 8);
-        else JF_LAUNCH(JF_F32, true, 4);
+        if (!pl.vec) JF_LAUNCH(JF_F32, false, false);
+        else if (pl.nt) JF_LAUNCH(JF_F32, true, true);
+        else JF_LAUNCH(JF_F32, true, false);
     } else {
-        if (!vec) JF_LAUNCH(JF_BF16, false, 4);
-        else if (pipe) JF_LAUNCH(JF_BF16, true, 16);
-        else if (deep) JF_LAUNCH(JF_BF16, true, 8);
-        else JF_LAUNCH(JF_BF16, true, 4);
+        if (!pl.vec) JF_LAUNCH(JF_BF16, false, false);
+        else if (pl.nt) JF_LAUNCH(JF_BF16, true, true);
+        else JF_LAUNCH(JF_BF16, true, false);
     }
 #undef JF_LAUNCH
     return check_launch("argmax_partial_kernel");

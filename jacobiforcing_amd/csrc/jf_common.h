@@ -3,7 +3,9 @@
 // Everything on this path is HBM/latency-bound integer and compare work: no MFMA.  Translation units:
 //   jf_api.hip        error plumbing, jf_version / jf_last_error
 //   jf_argmax.hip     (a2) vocabulary argmax (jf_argmax_partial / _scatter / _decode / _rows), (a3) accept scan
-//   jf_multiblock.hip (a1, a4-a12) the multiblock Jacobi state machine kernels (jf_mb_*), one wavefront per prompt
+//   jf_argmax_dev.h   device bodies of the argmax items, shared with the fused verify launch
+//   jf_multiblock.hip (a1, a4-a12) the multiblock Jacobi state machine kernels (jf_mb_*), one wavefront per prompt, and
+//                     jf_mb_verify: argmax items + per-prompt state-machine steps in ONE launch
 //   jf_kv.hip         (a18) KV append, fused RoPE + append, SwiGLU; (a9/a10) KV commit
 //   jf_engine.hip     (a15) engine single-block step, (a16) paged-KV index fill
 //   jf_sampling.hip   (a19) non-greedy verify (jf_rs_probs, jf_rs_step) and the on-policy rollout step
@@ -79,11 +81,7 @@ __device__ __forceinline__ uint32_t order_key(uint32_t u) {
 }
 
 constexpr int AM_TPB = 256;
-#ifdef JF_EXP_NO_NT
-#define JF_LOAD(p) (*(p))
-#else
-#define JF_LOAD(p) __builtin_nontemporal_load(p)
-#endif
+#define JF_LOAD(p) __builtin_nontemporal_load(p)      // streams read once (the softmax kernels; the argmax picks per launch)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <int DT> struct Elem;
@@ -222,60 +220,6 @@ template <bool KEEPV> struct FastTrack<JF_BF16, KEEPV> {
         return best >= 0 ? ((k16 | 0x8000u) << 16) : (((k16 ^ 0x8000u) << 16) | 0xFFFFu);
     }
 };
-
-// Software-pipelined scan of `nvec` 16-byte vectors starting at q (lane-strided by STR vectors): two register sets of
-// eight vectors; the loads of set B are issued before set A is consumed and vice versa, so a wavefront keeps 8-16 KB in
-// flight at all times instead of draining between batches.  The last pair is peeled so every load in the loop body is
-// unconditional (a conditional load would make the compiler wait for vmcnt(0)).
-template <int DT, int STR, class FT>
-__device__ __forceinline__ void scan_pipelined(FT &ft, const u32x4 *q, int k, int nvec, uint32_t ebase) {
-    constexpr int EPV = Elem<DT>::EPV;
-    constexpr int BATCH = 8 * STR;
-    const int nfull = (nvec > k + 7 * STR) ? ((nvec - k - 7 * STR - 1) / BATCH + 1) : 0;
-    const int npairs = nfull >> 1;
-    u32x4 A[8], B[8];
-    if (npairs >= 1) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) A[u] = JF_LOAD(q + u * STR);
-        for (int p = 0; p < npairs - 1; ++p) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) B[u] = JF_LOAD(q + BATCH + u * STR);
-            __builtin_amdgcn_sched_barrier(0);          // keep the loads of the next set ABOVE the compare chain
-#pragma unroll
-            for (int u = 0; u < 8; ++u) ft.consume(A[u], ebase + (uint32_t)(k + u * STR) * EPV);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) A[u] = JF_LOAD(q + 2 * BATCH + u * STR);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) ft.consume(B[u], ebase + (uint32_t)(k + BATCH + u * STR) * EPV);
-            __builtin_amdgcn_sched_barrier(0);
-            q += 2 * BATCH;
-            k += 2 * BATCH;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) B[u] = JF_LOAD(q + BATCH + u * STR);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) ft.consume(A[u], ebase + (uint32_t)(k + u * STR) * EPV);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) ft.consume(B[u], ebase + (uint32_t)(k + BATCH + u * STR) * EPV);
-        q += 2 * BATCH;
-        k += 2 * BATCH;
-    }
-    if (nfull & 1) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) A[u] = JF_LOAD(q + u * STR);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) ft.consume(A[u], ebase + (uint32_t)(k + u * STR) * EPV);
-        q += BATCH;
-        k += BATCH;
-    }
-    for (; k < nvec; k += STR, q += STR) {
-        const u32x4 v0 = JF_LOAD(q);
-        ft.consume(v0, ebase + (uint32_t)k * EPV);
-    }
-}
-
 
 template <int DT>
 __device__ __forceinline__ float load_f(const void *row, int64_t i) {

@@ -15,7 +15,7 @@
 
 #include "jacobiforcing.h"
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define JF_HD __host__ __device__ __forceinline__
 #define JF_UNROLL _Pragma("unroll")
 #else
@@ -53,13 +53,16 @@ struct Layout {
 JF_HD int imax(int a, int b) { return a > b ? a : b; }
 JF_HD int imin(int a, int b) { return a < b ? a : b; }
 
-JF_HD Layout make_layout(int n, int K, int pool_size, int max_blocks) {
+// every offset follows from (n, NB, RMAX, TMAX, LPOOL, pool_size): the state block in HBM uses the capacities the
+// parameters ask for (make_layout); the fused verify launch runs the SAME machine on a compact image in LDS
+// (compact_layout) and falls back to the HBM block when a step does not fit it
+JF_HD Layout make_layout_dims(int n, int NB, int RMAX, int TMAX, int LPOOL, int pool_size) {
     Layout L;
     L.n = n;
-    L.NB = imin(imax(max_blocks, K), MAX_NB);
-    L.RMAX = imax(1, pool_size);          // 1 + (pool_size-1) recycled candidates (MB:74, 579-582)
-    L.TMAX = L.NB * n;                    // RA draft + (acc ⧺ tail) of every pseudo block (MB:317-377)
-    L.LPOOL = L.NB * n;                   // concat of all blocks (MB:387-411)
+    L.NB = NB;
+    L.RMAX = RMAX;
+    L.TMAX = TMAX;
+    L.LPOOL = LPOOL;
     L.pool_size = pool_size;
     L.blk_stride = 8 + (n + 1) + L.RMAX * n;
     L.hdr_ints = H_SPANS + 3 * L.NB;
@@ -70,6 +73,20 @@ JF_HD Layout make_layout(int n, int K, int pool_size, int max_blocks) {
     L.total = L.off_ret + L.TMAX + 2;
     L.total = (L.total + 3) & ~3;         // keep 16-byte multiples
     return L;
+}
+
+JF_HD Layout make_layout(int n, int K, int pool_size, int max_blocks) {
+    const int NB = imin(imax(max_blocks, K), MAX_NB);
+    // RMAX: 1 + (pool_size-1) recycled candidates (MB:74, 579-582); TMAX: RA draft + (acc ⧺ tail) of every pseudo block
+    // (MB:317-377); LPOOL: concat of all blocks (MB:387-411)
+    return make_layout_dims(n, NB, imax(1, pool_size), NB * n, NB * n, pool_size);
+}
+
+// What a step touches when the block counters behave (K blocks in flight, Q3's stale list entries included): K + 2 list
+// entries, rows of (K + 2) * n tokens, pool entries of 2 * (K + 2) * n tokens.
+JF_HD Layout compact_layout(const Layout &g, int K) {
+    const int NB = imin(g.NB, K + 2);
+    return make_layout_dims(g.n, NB, g.RMAX, imin(g.TMAX, NB * g.n), imin(g.LPOOL, 2 * NB * g.n), g.pool_size);
 }
 
 JF_HD Layout layout_of(const int32_t *S) {
@@ -203,11 +220,18 @@ struct Machine {
     JF_HD void collect_ret(bool in_loop, int kv_cur, int next_tok) {
         lanes.sync();
         int pos = 0;
+        const int cap = L.TMAX + 2;                             // the ret region (a compact image has a smaller one)
         for (int b = 0; b < num_blocks; ++b) {
             int32_t *bb = blk(b);
-            if (b != RA && !bb[B_NEED] && bb[B_ACCLEN] > 0) { copy(ret() + pos, acc(b), bb[B_ACCLEN]); pos += bb[B_ACCLEN]; }
+            if (b != RA && !bb[B_NEED] && bb[B_ACCLEN] > 0) {
+                if (pos + bb[B_ACCLEN] > cap) { JF_FAIL(JF_E_CAPACITY); break; }
+                copy(ret() + pos, acc(b), bb[B_ACCLEN]); pos += bb[B_ACCLEN];
+            }
         }
-        if (blk(RA)[B_ACCLEN] > 0) { copy(ret() + pos, acc(RA), blk(RA)[B_ACCLEN]); pos += blk(RA)[B_ACCLEN]; }
+        if (!err && blk(RA)[B_ACCLEN] > 0) {
+            if (pos + blk(RA)[B_ACCLEN] > cap) JF_FAIL(JF_E_CAPACITY);
+            else { copy(ret() + pos, acc(RA), blk(RA)[B_ACCLEN]); pos += blk(RA)[B_ACCLEN]; }
+        }
         int final_committed = prompt_len + pos;
         kv_len = kv_cur > final_committed ? final_committed : kv_cur;      // trim only when td > 0
         done = 1;
@@ -630,6 +654,54 @@ JF_HD void mb_read_ret_body(Lanes lanes, int p, const int32_t *states, int64_t s
     const int len = S[H_RET_LEN];
     for (int i = lanes.lane(); i < ret_cap; i += lanes.count())
         ret[(int64_t)p * ret_cap + i] = i < len ? (int64_t)S[lay.off_ret + i] : -1;
+}
+
+// ---- compact image of one prompt's state (fused verify launch) -------------------------------------
+// Copy the parts of the HBM state block G (layout LG) a step can touch into the compact image C (layout LC).  Returns false
+// when the current state does not fit the compact capacities (the caller then steps on G itself).  Any number of lanes.
+template <class Lanes>
+JF_HD bool state_to_compact(Lanes lanes, const int32_t *G, const Layout &LG, int32_t *C, const Layout &LC) {
+    const int len_lists = G[H_LEN_LISTS], nsp = G[H_NSPANS], pool_count = G[H_POOL_COUNT], pool_head = G[H_POOL_HEAD];
+    if (len_lists >= LC.NB || nsp > LC.NB || G[H_T] > LC.TMAX || G[H_B] > LC.RMAX) return false;   // a spawn needs one free entry
+    bool fits = true;
+    for (int i = 0; i < pool_count; ++i) {
+        const int slot = (pool_head + i) % LG.pool_size;
+        if (G[LG.off_pool + slot * (1 + LG.LPOOL)] > LC.LPOOL) fits = false;
+    }
+    if (!fits) return false;
+    for (int i = lanes.lane(); i < H_SPANS + 3 * nsp; i += lanes.count()) C[i] = G[i];
+    for (int i = lanes.lane(); i < len_lists * LG.blk_stride; i += lanes.count()) C[LC.off_blocks + i] = G[LG.off_blocks + i];
+    for (int k = 0; k < pool_count; ++k) {
+        const int slot = (pool_head + k) % LG.pool_size;
+        const int32_t *e = G + LG.off_pool + slot * (1 + LG.LPOOL);
+        int32_t *c = C + LC.off_pool + slot * (1 + LC.LPOOL);
+        const int len = e[0];
+        for (int i = lanes.lane(); i < 1 + len; i += lanes.count()) c[i] = e[i];
+    }
+    return true;
+}
+
+// Write a stepped compact image back: header + spans, every listed block, the live pool entries, the next forward's rows,
+// and ret when the call ended.
+template <class Lanes>
+JF_HD void compact_to_state(Lanes lanes, const int32_t *C, const Layout &LC, int32_t *G, const Layout &LG) {
+    const int len_lists = C[H_LEN_LISTS], nsp = C[H_NSPANS], pool_count = C[H_POOL_COUNT], pool_head = C[H_POOL_HEAD];
+    const int B = C[H_B], T = C[H_T];
+    for (int i = lanes.lane(); i < H_SPANS + 3 * nsp; i += lanes.count()) G[i] = C[i];
+    for (int i = lanes.lane(); i < len_lists * LG.blk_stride; i += lanes.count()) G[LG.off_blocks + i] = C[LC.off_blocks + i];
+    for (int k = 0; k < pool_count; ++k) {
+        const int slot = (pool_head + k) % LG.pool_size;
+        const int32_t *c = C + LC.off_pool + slot * (1 + LC.LPOOL);
+        int32_t *e = G + LG.off_pool + slot * (1 + LG.LPOOL);
+        const int len = c[0];
+        for (int i = lanes.lane(); i < 1 + len; i += lanes.count()) e[i] = c[i];
+    }
+    for (int r = 0; r < B; ++r)
+        for (int i = lanes.lane(); i < T; i += lanes.count()) G[LG.off_out + r * LG.TMAX + i] = C[LC.off_out + r * LC.TMAX + i];
+    if (C[H_DONE]) {
+        const int rl = C[H_RET_LEN];
+        for (int i = lanes.lane(); i < rl; i += lanes.count()) G[LG.off_ret + i] = C[LC.off_ret + i];
+    }
 }
 
 // ---- engine single-block step (JD:567-710) for one row; pads handled by the caller ----------------

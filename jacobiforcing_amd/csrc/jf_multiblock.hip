@@ -6,7 +6,7 @@
 __device__ unsigned long long g_mb_trace[32];
 #define JF_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_mb_trace[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #endif
-#include "jf_common.h"
+#include "jf_argmax_dev.h"
 
 // ------------------------------------------------------------------------------------------------
 // multiblock state machine: one wavefront per prompt
@@ -97,3 +97,185 @@ extern "C" int jf_mb_read_ret(const int32_t *states, int64_t state_ints, int P, 
     return check_launch("mb_read_ret_kernel");
 }
 
+// ------------------------------------------------------------------------------------------------
+// jf_mb_verify — the whole convergence check of one iteration in ONE launch (MB:473-486 + MB:487-721):
+//
+//   workgroups [0, P)        one STEPPER per prompt.  While the logits stream, its 256 threads copy the live part of the
+//                            prompt's state block into a compact LDS image (same Machine, smaller Layout); then wavefront 0
+//                            waits for the prompt's arrival count, pulls the prompt's argmax results (8-byte agent-scope
+//                            loads) into LDS, runs Machine::step entirely on LDS, and writes the image + descriptor back.
+//                            A step that does not fit the compact capacities (runaway block lists, Q3/Q4) is redone on
+//                            the HBM block: nothing was written before that, so the result is the same.
+//   workgroups [P, ...)      the argmax items of jf_argmax_scatter / _partial (jf_argmax_dev.h).  After its atomicMax a
+//                            publishing lane drains its memory counter and adds 1 to arrive[prompt of the row].
+//
+// Hand-off (cdna_hip_programming.md, Guideline 16, "8-byte agent atomics both sides"): payload = device-scope atomicMax
+// on packed[], s_waitcnt vmcnt(0), relaxed agent-scope add on the counter; the stepper polls the counter with relaxed
+// agent-scope loads (s_sleep between polls, bounded by a wall-clock limit) and reads packed[] with agent-scope loads.
+// arrive[] must be zero on entry; every stepper resets its word, so the call leaves it zero.
+// Steppers only WAIT for item workgroups and never the other way round, and they are the lowest block ids (dispatched
+// first), so an item workgroup can always be scheduled: no residency assumption, no deadlock.
+// ------------------------------------------------------------------------------------------------
+struct VerifyArgs {
+    ArgmaxArgs am;
+    int32_t *states;
+    int64_t state_ints;
+    int P;
+    int64_t packed_len;
+    const int32_t *row_prompt;     // [Rtot] prompt of every forward row (jf_mb_pack)
+    int32_t *arrive;               // [P]
+    jf_mb_desc *desc;
+    int32_t Tpad;
+    int32_t compacted;             // 1: logits rows follow valid_index (B*T per prompt); 0: the Rtot x Tpad rectangle
+    int32_t lds_ints;              // ints of dynamic LDS available for (compact image + greedy tokens); 0 = step on HBM
+};
+
+struct Lanes256 {                  // all four wavefronts of a stepper workgroup (copy-in only)
+    __device__ __forceinline__ int lane() const { return threadIdx.x; }
+    __device__ __forceinline__ int count() const { return 256; }
+};
+
+__device__ __forceinline__ unsigned long long ld_agent_u64(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr int VERIFY_LDS_HDR = 32;                               // ints in front of the compact image (descriptor + flags)
+constexpr unsigned long long VERIFY_WAIT_TICKS = 200000000ull;   // 2 s of the 100 MHz constant clock: never hang the GPU
+
+__device__ void verify_arrive(const VerifyArgs &a, int64_t orow) {
+    const int p = a.row_prompt[orow / a.Tpad];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the atomicMax above is performed before the count moves
+    __hip_atomic_fetch_add(a.arrive + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ void verify_stepper(const VerifyArgs &a, int p, int32_t *smem) {
+    using namespace jfmb;
+    int32_t *G = a.states + (int64_t)p * a.state_ints;
+    const Layout LG = layout_of(G);
+    const Layout LC = compact_layout(LG, G[H_K]);
+    const int B = G[H_B], T = G[H_T];
+    const int64_t base = G[H_ROW_BASE];
+    const int64_t tpad = G[H_TPAD];
+    const int ng = B * T;                                        // greedy tokens this prompt consumes
+    // dynamic LDS: [0,16) descriptor, [16,32) flags, then the compact image, then the greedy tokens
+    jf_mb_desc *s_desc = (jf_mb_desc *)smem;
+    int32_t *img = smem + VERIFY_LDS_HDR;
+    // ---- while the logits stream: compact image of the live state ---------------------------------
+    bool use_lds = a.lds_ints >= VERIFY_LDS_HDR + LC.total + ng && !G[H_DONE] && !G[H_ERR];
+    if (use_lds) {
+        const bool ok = state_to_compact(Lanes256{}, G, LG, img, LC);
+        if (threadIdx.x == 0) smem[16] = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (use_lds) use_lds = smem[16] != 0;
+    if (threadIdx.x >= 64) return;                               // wavefront 0 is this prompt's state machine
+    const int lane = threadIdx.x;
+    int32_t *gtok = img + LC.total;                              // [B, T] greedy tokens (LDS) when use_lds
+    // ---- wait for this prompt's rows ---------------------------------------------------------------
+    const int expected = (a.compacted ? ng : B * (int)tpad) * a.am.chunks_per_row;
+    bool timed_out = false;
+    if (expected > 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned spins = 0;
+        while (__hip_atomic_load(a.arrive + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
+            __builtin_amdgcn_s_sleep(4);
+            if ((++spins & 1023u) == 0u && __builtin_amdgcn_s_memrealtime() - t0 > VERIFY_WAIT_TICKS) { timed_out = true; break; }
+        }
+        if (lane == 0) __hip_atomic_store(a.arrive + p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    jf_mb_desc *dg = a.desc ? a.desc + p : nullptr;
+    if (timed_out) {                                             // item workgroups never arrived: report, do not step
+        if (lane == 0) { G[H_ERR] = JF_E_LAUNCH; G[H_DONE] = 1; if (dg) { dg->error = JF_E_LAUNCH; dg->done = 1; dg->B = 0; dg->T = 0; } }
+        return;
+    }
+    const unsigned long long *pk = a.am.packed;
+    const int64_t plen = a.packed_len;
+    auto Gglobal = [pk, base, tpad, plen](int r, int t) -> int {
+        const int64_t idx = (base + r) * tpad + t;
+        return (idx >= 0 && idx < plen) ? decode_packed(ld_agent_u64(pk + idx)) : -1;
+    };
+    bool stepped = false;
+    if (use_lds) {
+        for (int i = lane; i < ng; i += 64) gtok[i] = Gglobal(i / T, i - (i / T) * T);
+        __syncthreads();
+        Machine<DevLanes> m(img, DevLanes{}, LC);
+        const int32_t *gt = gtok;
+        m.step([gt, T](int r, int t) -> int { return gt[r * T + t]; }, s_desc);
+        __syncthreads();
+        if (!s_desc->error) {
+            compact_to_state(DevLanes{}, img, LC, G, LG);
+            if (dg && lane < (int)(sizeof(jf_mb_desc) / 4)) ((int32_t *)dg)[lane] = ((const int32_t *)s_desc)[lane];
+            stepped = true;
+        }
+    }
+    if (!stepped) {                                              // step on the HBM block (capacities the parameters ask for)
+        Machine<DevLanes> m(G, DevLanes{}, LG);
+        m.step(Gglobal, dg);
+    }
+    // re-zero this prompt's slice of the argmax workspace for the next launch
+    __syncthreads();
+    const int64_t lo = base * tpad, hi = (base + B) * tpad;
+    for (int64_t i = lo + lane; i < hi && i < plen; i += 64) a.am.packed[i] = 0ull;
+}
+
+template <int DT, bool WAVE, bool NT>
+__global__ __launch_bounds__(AM_TPB) void mb_verify_kernel(VerifyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    if ((int)blockIdx.x < a.P) { verify_stepper(a, blockIdx.x, smem); return; }
+    const int64_t blk = (int64_t)blockIdx.x - a.P;
+    if constexpr (WAVE) {
+        const int64_t orow = argmax_wave_item<DT, NT>(a.am, blk * (AM_TPB / 64) + (threadIdx.x >> 6));
+        if ((threadIdx.x & 63) == 0 && orow >= 0) verify_arrive(a, orow);
+    } else {
+        const int64_t orow = argmax_wg_item<DT, true, NT>(a.am, blk);
+        if (threadIdx.x == 0 && orow >= 0) verify_arrive(a, orow);
+    }
+}
+
+extern "C" int jf_mb_verify(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, const int32_t *out_index,
+                            int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len, int32_t Tpad,
+                            const int32_t *row_prompt, int32_t *arrive, jf_mb_desc *desc, const jf_mb_params *params,
+                            void *stream) {
+    if (P <= 0) return JF_OK;
+    int rc = check_params(params, "jf_mb_verify");
+    if (rc) return rc;
+    if (!logits || !states || !packed || !row_prompt || !arrive || R <= 0 || Tpad <= 0)
+        return fail(JF_E_INVALID, "jf_mb_verify: null pointer or empty forward");
+    if (dtype != JF_F32 && dtype != JF_BF16) return fail(JF_E_INVALID, "jf_mb_verify: dtype %d", dtype);
+    if (V <= 0 || row_stride < V || V > 0x7FFFFFFFll) return fail(JF_E_INVALID, "jf_mb_verify: bad shape V=%lld stride=%lld", (long long)V, (long long)row_stride);
+    ArgmaxPlan pl;
+    rc = argmax_plan(logits, dtype, R, V, row_stride, &pl);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (!pl.vec) {                                               // unaligned logits: the two-launch path
+        rc = out_index ? jf_argmax_scatter(logits, dtype, R, V, row_stride, out_index, packed, stream)
+                       : jf_argmax_partial(logits, dtype, R, V, row_stride, packed, stream);
+        if (rc) return rc;
+        return jf_mb_step(states, state_ints, P, packed, packed_len, desc, stream);
+    }
+    // compact image + greedy tokens of one prompt in LDS; a configuration that needs more than 20 KB steps on HBM instead
+    // (the LDS request applies to every workgroup of the launch and must not cut the streaming workgroups' residency)
+    const jfmb::Layout LG = jfmb::make_layout(params->n, params->K, params->pool_size, params->max_blocks);
+    const jfmb::Layout LC = jfmb::compact_layout(LG, params->K);
+    int64_t lds_ints = VERIFY_LDS_HDR + (int64_t)LC.total + (int64_t)LC.RMAX * LC.TMAX;
+    lds_ints = (lds_ints + 3) & ~3ll;
+    if (lds_ints * 4 > 16 * 1024) lds_ints = 0;
+    VerifyArgs a;
+    a.am = ArgmaxArgs{logits, R, V, row_stride, (unsigned long long *)packed, (int)pl.cpr, pl.chunk, out_index};
+    a.states = states; a.state_ints = state_ints; a.P = P; a.packed_len = packed_len; a.row_prompt = row_prompt;
+    a.arrive = arrive; a.desc = desc; a.Tpad = Tpad; a.compacted = out_index ? 1 : 0; a.lds_ints = (int32_t)lds_ints;
+    const int64_t blocks = pl.blocks + P;
+    if (blocks > 0x7FFFFFFFll) return fail(JF_E_CAPACITY, "jf_mb_verify: grid too large");
+    const dim3 grid((unsigned)blocks), block(AM_TPB);
+    const size_t shm = (size_t)lds_ints * 4;
+#define JF_V(DT, WV, NTF) mb_verify_kernel<DT, WV, NTF><<<grid, block, shm, s>>>(a)
+    if (dtype == JF_F32) {
+        if (pl.wave_mode) { if (pl.nt) JF_V(JF_F32, true, true); else JF_V(JF_F32, true, false); }
+        else { if (pl.nt) JF_V(JF_F32, false, true); else JF_V(JF_F32, false, false); }
+    } else {
+        if (pl.wave_mode) { if (pl.nt) JF_V(JF_BF16, true, true); else JF_V(JF_BF16, true, false); }
+        else { if (pl.nt) JF_V(JF_BF16, false, true); else JF_V(JF_BF16, false, false); }
+    }
+#undef JF_V
+    return check_launch("mb_verify_kernel");
+}

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -17,6 +18,7 @@ import torch
 from . import _native as N
 
 EVT_SPAWN, EVT_SWITCH, EVT_EARLY = 1, 2, 4
+VERIFY_HOOK = None      # bench.py: (before, after) callables around the verify launch (HIP events on the launch stream)
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -166,6 +168,9 @@ class MultiblockBatch:
         self.ret_buf = torch.zeros((self.P, self.ret_cap), dtype=torch.int64, device=dev)
         self.Rtot = 0
         self.Tpad = 0
+        self.arrive = torch.zeros((self.P,), dtype=torch.int32, device=dev)   # jf_mb_verify's per-prompt arrival counters
+        # JF_FUSED_VERIFY=0: argmax and state machine as two launches (A/B measurements in tools/)
+        self.fused = os.environ.get("JF_FUSED_VERIFY", "1") != "0"
 
     # -- descriptor readback: the one host sync of an iteration ---------------------------------
     def _read_desc(self) -> np.ndarray:
@@ -235,12 +240,28 @@ class MultiblockBatch:
             if self.valid_index is None or flat.shape[0] != self.valid_index.numel():
                 raise ValueError(f"expected logits for the {0 if self.valid_index is None else self.valid_index.numel()} "
                                  f"listed positions, got {tuple(logits.shape)}")
-            argmax_scatter(flat, self.valid_index, self.packed)
-            return self.step()
-        if flat.shape[0] != self.Rtot * self.Tpad:
+        elif flat.shape[0] != self.Rtot * self.Tpad:
             raise ValueError(f"expected logits for {self.Rtot}x{self.Tpad} positions, got {tuple(logits.shape)}")
-        argmax_partial(flat, self.packed)
+        if self.fused:
+            return self.verify_fused(flat, self.valid_index if compacted else None)
+        if compacted:
+            argmax_scatter(flat, self.valid_index, self.packed)
+        else:
+            argmax_partial(flat, self.packed)
         return self.step()
+
+    def verify_fused(self, flat: torch.Tensor, out_index: Optional[torch.Tensor]) -> np.ndarray:
+        """jf_mb_verify: argmax items + one stepper workgroup per prompt in one launch (MB:473-721)."""
+        if flat.dim() != 2 or flat.stride(1) != 1:
+            raise ValueError(f"logits must be [R, V] with a contiguous vocabulary axis, got {tuple(flat.shape)} strides {flat.stride()}")
+        R, V = flat.shape
+        VERIFY_HOOK and VERIFY_HOOK[0](self, flat)
+        N.check(N.lib().jf_mb_verify(_ptr(flat), _dtype_code(flat), R, V, flat.stride(0) if R > 1 else V, _ptr(out_index),
+                                     _ptr(self.states), self.state_ints, self.P, _ptr(self.packed), self.Rtot * self.Tpad,
+                                     self.Tpad, _ptr(self.row_prompt), _ptr(self.arrive), _ptr(self.desc_dev),
+                                     C.byref(self.c_params), _stream(self.device)), "jf_mb_verify")
+        VERIFY_HOOK and VERIFY_HOOK[1](self, flat)
+        return self._read_desc()
 
     def step(self) -> np.ndarray:
         N.check(N.lib().jf_mb_step(_ptr(self.states), self.state_ints, self.P, _ptr(self.packed),
