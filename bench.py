@@ -54,10 +54,16 @@ from jacobiforcing_amd.modeling.qwen2 import Qwen2Config, Qwen2Model, Qwen2Weigh
 from jacobiforcing_amd.synthetic import ScriptedAcceptance, humaneval_shaped_prompts  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FUSED = os.environ.get("JF_FUSED_VERIFY", "1") != "0"
+VERIFY_KERNEL = ("mb_verify_kernel (jf_mb_verify: the convergence check in one launch — block-local argmax over the compacted "
+                 "logits, then equality / accepted-prefix scan / re-draft / pool / spawn per prompt on LDS)" if FUSED else
+                 "jf_argmax_scatter + jf_mb_step (two launches, JF_FUSED_VERIFY=0), first event to last")
 
 
-class ArgmaxTimer:
-    """HIP events around every jf_argmax_partial launch (recorded on the launch stream = torch's current stream)."""
+class VerifyTimer:
+    """HIP events around every verify launch of the decoder — jf_mb_verify (argmax items + per-prompt state-machine steps in
+    one launch) or, with JF_FUSED_VERIFY=0, jf_argmax_scatter + jf_mb_step — recorded on the launch stream (torch's
+    current stream) through ops.VERIFY_HOOK."""
 
     def __init__(self):
         self.events = []
@@ -67,16 +73,17 @@ class ArgmaxTimer:
         self.all_valid = []
         self.launched_rows = 0
         self.valid_rows = None      # callable -> algorithmic rows of the launch in flight
-        self._orig = ops.argmax_partial
-        self._orig_scatter = ops.argmax_scatter
+        self._a = None
 
     def __enter__(self):
-        def timed(logits, *rest):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            (self._orig if len(rest) == 1 else self._orig_scatter)(logits, *rest)
+        def before(batch, logits):
+            self._a = torch.cuda.Event(enable_timing=True)
+            self._a.record()
+
+        def after(batch, logits):
+            b = torch.cuda.Event(enable_timing=True)
             b.record()
-            self.events.append((a, b))
+            self.events.append((self._a, b))
             # algorithmic rows: the positions that carry a draft token (sum_p B_p*T_p); list-padding rows (at most 7,
             # skipped by the kernel) are NOT counted as useful bytes
             valid = self.valid_rows() if self.valid_rows is not None else logits.shape[0]
@@ -86,13 +93,14 @@ class ArgmaxTimer:
             self.launched_rows += int(logits.shape[0])
             self.all_rows.append(int(logits.shape[0]))
             self.all_valid.append(valid)
-        ops.argmax_partial = timed
-        ops.argmax_scatter = timed
+        ops.VERIFY_HOOK = (before, after)
         return self
 
     def __exit__(self, *exc):
-        ops.argmax_partial = self._orig
-        ops.argmax_scatter = self._orig_scatter
+        ops.VERIFY_HOOK = None
+
+    def reset(self):
+        self.events.clear(); self.bytes = 0; self.rows = 0; self.launched_rows = 0
 
     def summary(self):
         if not self.events:
@@ -117,7 +125,7 @@ def run_steps(dec: MultiblockJacobiDecoder, prompts, warmup: int, steps: int, se
             jd.barrier(dev)
             state["acc_at_start"] = state["tokens_all"]
             if timer is not None:
-                timer.events.clear(); timer.bytes = 0; timer.rows = 0; timer.launched_rows = 0
+                timer.reset()
             state["t0"] = time.perf_counter()
         if i == total:
             jd.barrier(dev)
@@ -127,7 +135,7 @@ def run_steps(dec: MultiblockJacobiDecoder, prompts, warmup: int, steps: int, se
         if warmup == 0:
             jd.barrier(dev)
             if timer is not None:
-                timer.events.clear(); timer.bytes = 0; timer.rows = 0; timer.launched_rows = 0
+                timer.reset()
             state["t0"] = time.perf_counter()
 
     stats, gen_s, iters = dec.generate(prompts, max_new_tokens=1 << 30, max_calls=1 << 30, seed=seed,
@@ -264,7 +272,7 @@ def main():
                                   logit_align=args.logit_align or (8 * P if tuned else 1))   # lm_head M stays on the tuned grid (multiples of 8*P)
 
     # ---- headline: unmodified random-init model ------------------------------------------------
-    with ArgmaxTimer() as tm:
+    with VerifyTimer() as tm:
         tm.valid_rows = lambda: dec.last_valid_rows
         r = run_steps(dec, prompts, args.warmup, args.steps, seed=1234 + info.rank, timer=tm)
         roof = tm.summary()
@@ -275,7 +283,7 @@ def main():
     scripted = None
     if not args.no_scripted:
         dec.logits_hook = ScriptedAcceptance(cfg.vocab_size, robust_pct=args.robust, vocab_hi=vocab_hi)
-        with ArgmaxTimer() as tm2:
+        with VerifyTimer() as tm2:
             tm2.valid_rows = lambda: dec.last_valid_rows
             r2 = run_steps(dec, prompts, args.warmup, args.steps, seed=4321 + info.rank, timer=tm2)
             roof2 = tm2.summary()
@@ -291,6 +299,27 @@ def main():
                             "logits_rows_per_launch": roof2["avg_launched_rows"], "launches": roof2["launches"]},
                         note="logits get a planted context-robust prediction (jacobiforcing_amd/synthetic.py) — extra "
                              "work inside the forward; emulates a Jacobi-Forcing checkpoint's acceptance")
+    # ---- the same launch at the literal config-3 / config-4 shapes (1 and 8 prompts per GPU) and at 64 ------------------
+    shapes = None
+    if info.world_size == 1 and not args.no_shapes and roof is not None:
+        shapes = []
+        for Ps in (1, 8, 64):
+            if Ps == P:
+                rs = roof
+            else:
+                torch.cuda.empty_cache()
+                ds = MultiblockJacobiDecoder(model, Ps, prm, max_seq_len=4096, t_align=8 if tuned else 1,
+                                             logit_align=(8 * Ps if tuned else 1))
+                with VerifyTimer() as tms:
+                    tms.valid_rows = lambda: ds.last_valid_rows
+                    run_steps(ds, all_prompts[:Ps] if len(all_prompts) >= Ps else humaneval_shaped_prompts(Ps, seed=1234, vocab_hi=vocab_hi),
+                              6, 24, seed=99, timer=tms)
+                    rs = tms.summary()
+                del ds
+            if rs is not None:
+                shapes.append(dict(prompts_per_gpu=Ps, rows_per_launch=rs["avg_rows"], bytes_per_launch=rs["avg_bytes"],
+                                   us_per_launch=rs["avg_us"], achieved=rs["gbs"], frac=rs["gbs"] / HBM_PEAK_GBS,
+                                   launches=rs["launches"]))
     out = None
     if info.rank == 0:
         steps_done = max(int(round(agg["iterations"] / info.world_size)), 1)
@@ -318,12 +347,17 @@ def main():
         if roof is not None:
             out["roofline"] = {"bound": "hbm", "achieved": roof["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": roof["gbs"] / HBM_PEAK_GBS, "traffic": _pmc_traffic(roof),
-                               "kernel": "jf_argmax_scatter (argmax_partial_kernel / argmax_wave_kernel) on the compacted logits",
+                               "kernel": VERIFY_KERNEL,
                                "bytes_per_launch": roof["avg_bytes"], "us_per_launch": roof["avg_us"],
                                "rows_per_launch": roof["avg_rows"], "logits_rows_per_launch": roof["avg_launched_rows"],
                                "note": "logits rows beyond rows_per_launch are list padding (lm_head M on the tuned grid); the "
                                        "kernel skips them unread",
                                "launches": roof["launches"]}
+        if shapes:
+            out["roofline_by_shape"] = {"unit": "GB/s", "peak": HBM_PEAK_GBS, "kernel": VERIFY_KERNEL,
+                                        "note": "HIP events around the verify launch inside short decode windows (6 warm-up + 24 "
+                                                "iterations) of the same model; bytes = draft-carrying rows x V x 2",
+                                        "shapes": shapes}
         if scripted is not None:
             out["scripted_acceptance"] = scripted
     if info.rank == 0 and info.world_size == 1 and args.cpu_baseline_seconds > 0:

@@ -169,7 +169,8 @@ JF_API int jf_mb_step(int32_t *states, int64_t state_ints, int P, uint64_t *pack
  * other prompts' streaming and there is no dependent launch.  Same results as the two calls.
  *   logits [R, V] (rows follow valid_index when out_index is given, else the Rtot x Tpad rectangle of jf_mb_pack),
  *   row_prompt [Rtot] as written by jf_mb_pack, Tpad as passed to jf_mb_pack,
- *   arrive [P] int32: zero on entry (one torch.zeros at start-up); the call leaves it zero,
+ *   arrive [P * 64] int32 (one 256-byte line per prompt): zero on entry (one torch.zeros at start-up); the call
+ *   leaves it zero,
  *   params: the jf_mb_params the states were begun with.
  * Rows that are not 16-byte aligned fall back to the two launches.  A stepper that waits longer than 2 s for its rows
  * reports JF_E_LAUNCH in its descriptor instead of hanging the GPU. */
@@ -239,6 +240,29 @@ JF_API int jf_engine_step(const int64_t *draft, int B, int L, uint64_t *packed, 
                    int64_t *new_tokens /* [B, L] */, int64_t *next_draft /* [B, L] */,
                    const int64_t *pad_stream, int64_t pad_stream_len, int64_t *pad_cursor,
                    jf_engine_row *rows, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * HF single-block step (a14): one iteration body of jacobi_forward_greedy (SB:197-273) after the forward, one launch.
+ *   out [L] int64 (in/out): the forwarded draft; on a rejection it is overwritten with the next draft
+ *       [greedy@mismatch] + greedy[raw : L-1] (SB:231-255), next_len = L - raw tokens;
+ *   packed [L]: jf_argmax_partial of logits [L, V] (greedy[i] verifies out[i+1]; greedy[L-1] is the bonus, SB:258-264);
+ *   total / cap / acc_buf: tokens accepted so far in this call, capacity and storage of accepted_n_gram (SB:145: the
+ *       reference writes into the preallocated input tensor; writes past its end are dropped);
+ *   kv_before: cache length before the forward.  desc->kv_len is the length the reference trims the cache to, including
+ *       its EOS quirk (desired_len = total_accepted without the prompt, SB:221-225).  packed is re-zeroed.
+ */
+typedef struct jf_sb_desc {
+    int32_t raw;         /* accepted incl. position 0, before the EOS cap (SB:199-202)  */
+    int32_t num;         /* after the EOS cap (SB:204-211)                               */
+    int32_t total;       /* total_accepted after this iteration                          */
+    int32_t done;        /* the call returns here (EOS)                                  */
+    int32_t next_token;  /* SB:235 / 260 / the EOS id                                    */
+    int32_t kv_len;      /* committed cache length after the trims                       */
+    int32_t next_len;    /* length of the next draft in `out` (0 when the call ends)     */
+    int32_t eos;         /* EOS was inside the accepted prefix                           */
+} jf_sb_desc;
+JF_API int jf_sb_step(int64_t *out, int L, uint64_t *packed, int32_t eos_id, int32_t total, int32_t cap, int64_t *acc_buf,
+               int32_t kv_before, jf_sb_desc *desc, void *stream);
 
 /* Caller side of the batched forward when the KV cache is PAGED as in the reference
  * (MR:1204-1265 "jacobi.buffer_fill" + _get_slot_mapping_pattern MR:965-986): for B sequences of

@@ -57,6 +57,11 @@ class OpRow(C.Structure):
                                          "redraft_base_lo", "redraft_base_hi")]
 
 
+class SbDesc(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("raw", "num", "total", "done", "next_token", "kv_len", "next_len", "eos")]
+
+
+SB_FIELDS = [f[0] for f in SbDesc._fields_]
 OP_ROW_INTS = C.sizeof(OpRow) // 4
 OP_FIELDS = [f[0] for f in OpRow._fields_]
 
@@ -85,6 +90,7 @@ _SIGNATURES = {
     "jf_swiglu": (C.c_int, [_vp, C.c_int, _i64, _i64, _vp, _vp]),
     "jf_kv_commit": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, C.c_int, _i32, _i32, _i32, _i64, _i64, _i32, _vp]),
     "jf_engine_step": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "jf_sb_step": (C.c_int, [_vp, C.c_int, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "jf_engine_fill": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "jf_rs_probs": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "jf_rs_workspace_bytes": (_sz, [_i64, _i64]),

@@ -26,7 +26,8 @@ struct ArgmaxArgs {
 // One (row, chunk) item by a 256-thread workgroup sharing the chunk.  Returns the result slot (orow, -1 = skipped row) to
 // every thread; thread 0 has published the item with atomicMax when the function returns.
 template <int DT, bool VEC, bool NT>
-__device__ __forceinline__ int64_t argmax_wg_item(const ArgmaxArgs &a, int64_t item) {
+__device__ __forceinline__ int64_t argmax_wg_item(const ArgmaxArgs &a, int64_t item, const int32_t *row_owner = nullptr,
+                                                  int32_t owner_div = 1, int *owner = nullptr) {
     using E = Elem<DT>;
     constexpr int EPV = E::EPV;
     constexpr int UNROLL = 8;
@@ -34,6 +35,7 @@ __device__ __forceinline__ int64_t argmax_wg_item(const ArgmaxArgs &a, int64_t i
     // slot of this row's result (jf_argmax_scatter): read up front so its latency hides behind the stream; < 0 = padding row
     const int64_t orow = a.out_index ? (int64_t)a.out_index[row] : row;
     if (orow < 0) return -1;
+    if (row_owner) *owner = row_owner[(int)orow / owner_div];      // fused launch: whose row this is (latency hides behind the stream)
     const int c = (int)(item - row * a.chunks_per_row);
     const int64_t begin = (int64_t)c * a.chunk_elems;
     int64_t end = begin + a.chunk_elems;
@@ -88,7 +90,8 @@ __device__ __forceinline__ int64_t argmax_wg_item(const ArgmaxArgs &a, int64_t i
 // Wave-independent variant: every wavefront owns one (row, chunk) item end to end — no LDS, no workgroup barrier; the NaN
 // vote is a ballot, the reduction six shuffles, the publish one atomicMax per wavefront (lane 0).  Returns orow or -1.
 template <int DT, bool NT>
-__device__ __forceinline__ int64_t argmax_wave_item(const ArgmaxArgs &a, int64_t item) {
+__device__ __forceinline__ int64_t argmax_wave_item(const ArgmaxArgs &a, int64_t item, const int32_t *row_owner = nullptr,
+                                                    int32_t owner_div = 1, int *owner = nullptr) {
     using E = Elem<DT>;
     constexpr int EPV = E::EPV;
     constexpr int UNROLL = 8;
@@ -97,6 +100,7 @@ __device__ __forceinline__ int64_t argmax_wave_item(const ArgmaxArgs &a, int64_t
     const int64_t row = item / a.chunks_per_row;
     const int64_t orow = a.out_index ? (int64_t)a.out_index[row] : row;
     if (orow < 0) return -1;
+    if (row_owner) *owner = row_owner[(int)orow / owner_div];
     const int c = (int)(item - row * a.chunks_per_row);
     const int64_t begin = (int64_t)c * a.chunk_elems;
     int64_t end = begin + a.chunk_elems;

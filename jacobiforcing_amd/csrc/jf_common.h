@@ -69,6 +69,13 @@ struct DevLanes {
     }
 };
 
+// one wavefront that is the only live wavefront of a larger workgroup (the steppers of jf_mb_verify): a phase boundary is a
+// memory fence (s_waitcnt vmcnt(0) lgkmcnt(0)), not an s_barrier — nobody else is there to wait for, and the ~80
+// barriers of a step cost ~3 us
+struct SoloWaveLanes : DevLanes {
+    __device__ __forceinline__ void sync() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+};
+
 // ------------------------------------------------------------------------------------------------
 // vocabulary-stream helpers shared by the argmax and the softmax-gather kernels
 // ------------------------------------------------------------------------------------------------

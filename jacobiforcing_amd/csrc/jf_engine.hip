@@ -74,6 +74,23 @@ extern "C" int jf_engine_step(const int64_t *draft, int B, int L, uint64_t *pack
 }
 
 // ------------------------------------------------------------------------------------------------
+// (a14) HF single-block step (SB = modeling/cllm2_qwen2_modeling_kv_terminate_on_eos_improved.py:197-273): everything
+// between two forwards of jacobi_forward_greedy in one launch, one descriptor for the host to read.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void sb_step_kernel(int64_t *out, int L, unsigned long long *packed, int eos_id, int total,
+                                                      int cap, int64_t *acc_buf, int kv_before, jf_sb_desc *desc) {
+    jfmb::sb_step_body(DevLanes{}, out, L, (uint64_t *)packed, eos_id, total, cap, acc_buf, kv_before, desc);
+}
+
+extern "C" int jf_sb_step(int64_t *out, int L, uint64_t *packed, int32_t eos_id, int32_t total, int32_t cap, int64_t *acc_buf,
+                          int32_t kv_before, jf_sb_desc *desc, void *stream) {
+    if (L < 1) return fail(JF_E_INVALID, "jf_sb_step: L=%d", L);
+    if (!out || !packed || !acc_buf || !desc || total < 0 || cap < 0 || kv_before < 0) return fail(JF_E_INVALID, "jf_sb_step: bad argument");
+    sb_step_kernel<<<1, 64, 0, (hipStream_t)stream>>>(out, L, (unsigned long long *)packed, eos_id, total, cap, acc_buf, kv_before, desc);
+    return check_launch("sb_step_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
 // (a16) paged-KV caller side: every index buffer of one batched Jacobi forward in one launch (MR:1204-1265)
 // ------------------------------------------------------------------------------------------------
 // One wavefront per sequence.  err (nullable) gets the first failing row + 1: S < 1 (MR:1222-1223) or a position whose

@@ -757,4 +757,60 @@ JF_HD EngineRowOut engine_row_body(Lanes lanes, const int64_t *d, int L, GreedyF
     return o;
 }
 
+// ---- HF single-block step (SB = modeling/cllm2_qwen2_modeling_kv_terminate_on_eos_improved.py:197-273) -------------
+// Everything between two forwards of jacobi_forward_greedy for one call; greedy[i] = decode(packed[i]) verifies out[i+1].
+template <class Lanes>
+JF_HD void sb_step_body(Lanes lanes, int64_t *out, int L, uint64_t *packed, int eos_id, int total, int cap, int64_t *acc_buf,
+                        int kv_before, jf_sb_desc *desc) {
+    auto G = [packed](int i) { return decode_packed(packed[i]); };
+    const int kv_after = kv_before + L;
+    int m = L - 1;                                           // SB:197-200: accepted = 1 + leading matches
+    for (int i0 = 0; i0 < L - 1; i0 += lanes.count()) {
+        const int i = i0 + lanes.lane();
+        const int f = lanes.first_true((i < L - 1) && (out[i + 1] != (int64_t)G(i)));
+        if (f < lanes.count()) { m = i0 + f; break; }
+    }
+    const int raw = m + 1;
+    int num = raw, eos_hit = 0;
+    if (eos_id >= 0) {                                       // SB:204-211: EOS inside the accepted prefix caps it
+        for (int i0 = 0; i0 < raw; i0 += lanes.count()) {
+            const int i = i0 + lanes.lane();
+            const int f = lanes.first_true(i < raw && out[i] == (int64_t)eos_id);
+            if (f < lanes.count()) { num = i0 + f + 1; eos_hit = 1; break; }
+        }
+    }
+    for (int i = lanes.lane(); i < num; i += lanes.count())   // SB:214-215 (writes past the preallocated tensor are dropped)
+        if (total + i < cap) acc_buf[total + i] = out[i];
+    total += num;
+    int done = 0, kv = kv_after, next = -1, next_len = 0;
+    if (eos_hit) {                                           // SB:219-227: desired_len = total_accepted (no prompt length, as written)
+        kv = kv_after < total ? kv_after : total;
+        next = eos_id; done = 1;
+    } else if (raw < L) {                                    // SB:231-255
+        kv = kv_after - (L - raw);
+        next = G(raw - 1);
+        if (eos_id >= 0 && next == eos_id) {
+            if (lanes.lane() == 0 && total < cap) acc_buf[total] = next;
+            total += 1;
+            kv = kv < total ? kv : total;
+            done = 1;
+        } else {
+            next_len = L - raw;                              // [next] + greedy[raw : L-1]
+            lanes.sync();                                    // acc_buf reads of `out` are done
+            for (int j = lanes.lane(); j < next_len; j += lanes.count()) out[j] = (j == 0) ? (int64_t)next : (int64_t)G(raw + j - 1);
+        }
+    } else {                                                 // SB:258-273: bonus token on a full accept
+        next = G(L - 1);
+        if (lanes.lane() == 0 && total < cap) acc_buf[total] = next;
+        total += 1;
+        if (eos_id >= 0 && next == eos_id) { kv = kv < total ? kv : total; done = 1; }
+    }
+    lanes.sync();
+    for (int i = lanes.lane(); i < L; i += lanes.count()) packed[i] = 0;
+    if (lanes.lane() == 0) {
+        desc->raw = raw; desc->num = num; desc->total = total; desc->done = done; desc->next_token = next;
+        desc->kv_len = kv; desc->next_len = next_len; desc->eos = eos_hit;
+    }
+}
+
 }  // namespace jfmb

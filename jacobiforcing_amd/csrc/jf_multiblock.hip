@@ -130,6 +130,24 @@ struct VerifyArgs {
     int32_t lds_ints;              // ints of dynamic LDS available for (compact image + greedy tokens); 0 = step on HBM
 };
 
+#ifdef JF_EXP_VERIFY_TRACE
+// experiment build only (tools/verify_trace.py): wall-clock stamps (100 MHz) of the launch — [0] first item start, [1] last
+// item end, then 8 per stepper: start, image copied, rows arrived, tokens gathered, stepped, written back, end
+__device__ unsigned long long g_vtrace[2 + 8 * 256];
+#define JF_VSTAMP(p, k) do { if (threadIdx.x == 0 && (p) < 256) g_vtrace[2 + 8 * (p) + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" __attribute__((visibility("default"))) int jf_exp_read_vtrace(unsigned long long *out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vtrace), sizeof(unsigned long long) * (size_t)n);
+}
+extern "C" __attribute__((visibility("default"))) int jf_exp_reset_vtrace(void) {
+    static unsigned long long init[2 + 8 * 256];
+    for (int i = 0; i < 2 + 8 * 256; ++i) init[i] = 0ull;
+    init[0] = ~0ull;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_vtrace), init, sizeof(init));
+}
+#else
+#define JF_VSTAMP(p, k) do { } while (0)
+#endif
+
 struct Lanes256 {                  // all four wavefronts of a stepper workgroup (copy-in only)
     __device__ __forceinline__ int lane() const { return threadIdx.x; }
     __device__ __forceinline__ int count() const { return 256; }
@@ -139,13 +157,14 @@ __device__ __forceinline__ unsigned long long ld_agent_u64(const unsigned long l
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+constexpr int VERIFY_ARRIVE_STRIDE = 64;                         // ints between two prompts' arrival words: one 256-byte line each,
+                                                                 // so polls and arrivals of different prompts use different channels
 constexpr int VERIFY_LDS_HDR = 32;                               // ints in front of the compact image (descriptor + flags)
 constexpr unsigned long long VERIFY_WAIT_TICKS = 200000000ull;   // 2 s of the 100 MHz constant clock: never hang the GPU
 
-__device__ void verify_arrive(const VerifyArgs &a, int64_t orow) {
-    const int p = a.row_prompt[orow / a.Tpad];
+__device__ __forceinline__ void verify_arrive(const VerifyArgs &a, int owner) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the atomicMax above is performed before the count moves
-    __hip_atomic_fetch_add(a.arrive + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(a.arrive + (int64_t)owner * VERIFY_ARRIVE_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ void verify_stepper(const VerifyArgs &a, int p, int32_t *smem) {
@@ -157,6 +176,7 @@ __device__ void verify_stepper(const VerifyArgs &a, int p, int32_t *smem) {
     const int64_t base = G[H_ROW_BASE];
     const int64_t tpad = G[H_TPAD];
     const int ng = B * T;                                        // greedy tokens this prompt consumes
+    JF_VSTAMP(p, 0);
     // dynamic LDS: [0,16) descriptor, [16,32) flags, then the compact image, then the greedy tokens
     jf_mb_desc *s_desc = (jf_mb_desc *)smem;
     int32_t *img = smem + VERIFY_LDS_HDR;
@@ -169,6 +189,7 @@ __device__ void verify_stepper(const VerifyArgs &a, int p, int32_t *smem) {
     __syncthreads();
     if (use_lds) use_lds = smem[16] != 0;
     if (threadIdx.x >= 64) return;                               // wavefront 0 is this prompt's state machine
+    JF_VSTAMP(p, 1);
     const int lane = threadIdx.x;
     int32_t *gtok = img + LC.total;                              // [B, T] greedy tokens (LDS) when use_lds
     // ---- wait for this prompt's rows ---------------------------------------------------------------
@@ -177,12 +198,14 @@ __device__ void verify_stepper(const VerifyArgs &a, int p, int32_t *smem) {
     if (expected > 0) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         unsigned spins = 0;
-        while (__hip_atomic_load(a.arrive + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
-            __builtin_amdgcn_s_sleep(4);
-            if ((++spins & 1023u) == 0u && __builtin_amdgcn_s_memrealtime() - t0 > VERIFY_WAIT_TICKS) { timed_out = true; break; }
+        int32_t *word = a.arrive + (int64_t)p * VERIFY_ARRIVE_STRIDE;
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
+            __builtin_amdgcn_s_sleep(20);                        // ~0.6 us between polls: pollers must not load the memory system
+            if ((++spins & 255u) == 0u && __builtin_amdgcn_s_memrealtime() - t0 > VERIFY_WAIT_TICKS) { timed_out = true; break; }
         }
-        if (lane == 0) __hip_atomic_store(a.arrive + p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        if (lane == 0) __hip_atomic_store(word, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
+    JF_VSTAMP(p, 2);
     jf_mb_desc *dg = a.desc ? a.desc + p : nullptr;
     if (timed_out) {                                             // item workgroups never arrived: report, do not step
         if (lane == 0) { G[H_ERR] = JF_E_LAUNCH; G[H_DONE] = 1; if (dg) { dg->error = JF_E_LAUNCH; dg->done = 1; dg->B = 0; dg->T = 0; } }
@@ -197,25 +220,29 @@ __device__ void verify_stepper(const VerifyArgs &a, int p, int32_t *smem) {
     bool stepped = false;
     if (use_lds) {
         for (int i = lane; i < ng; i += 64) gtok[i] = Gglobal(i / T, i - (i / T) * T);
-        __syncthreads();
-        Machine<DevLanes> m(img, DevLanes{}, LC);
+        SoloWaveLanes{}.sync();
+        JF_VSTAMP(p, 3);
+        Machine<SoloWaveLanes> m(img, SoloWaveLanes{}, LC);
         const int32_t *gt = gtok;
         m.step([gt, T](int r, int t) -> int { return gt[r * T + t]; }, s_desc);
-        __syncthreads();
+        SoloWaveLanes{}.sync();
+        JF_VSTAMP(p, 4);
         if (!s_desc->error) {
-            compact_to_state(DevLanes{}, img, LC, G, LG);
+            compact_to_state(SoloWaveLanes{}, img, LC, G, LG);
             if (dg && lane < (int)(sizeof(jf_mb_desc) / 4)) ((int32_t *)dg)[lane] = ((const int32_t *)s_desc)[lane];
             stepped = true;
         }
+        JF_VSTAMP(p, 5);
     }
     if (!stepped) {                                              // step on the HBM block (capacities the parameters ask for)
-        Machine<DevLanes> m(G, DevLanes{}, LG);
+        Machine<SoloWaveLanes> m(G, SoloWaveLanes{}, LG);
         m.step(Gglobal, dg);
     }
     // re-zero this prompt's slice of the argmax workspace for the next launch
-    __syncthreads();
+    SoloWaveLanes{}.sync();
     const int64_t lo = base * tpad, hi = (base + B) * tpad;
     for (int64_t i = lo + lane; i < hi && i < plen; i += 64) a.am.packed[i] = 0ull;
+    JF_VSTAMP(p, 6);
 }
 
 template <int DT, bool WAVE, bool NT>
@@ -223,13 +250,20 @@ __global__ __launch_bounds__(AM_TPB) void mb_verify_kernel(VerifyArgs a) {
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     if ((int)blockIdx.x < a.P) { verify_stepper(a, blockIdx.x, smem); return; }
     const int64_t blk = (int64_t)blockIdx.x - a.P;
+#ifdef JF_EXP_VERIFY_TRACE
+    if ((threadIdx.x & 63) == 0) atomicMin(&g_vtrace[0], __builtin_amdgcn_s_memrealtime());
+#endif
+    int owner = -1;                                              // prompt of this item's row: looked up while the row streams
     if constexpr (WAVE) {
-        const int64_t orow = argmax_wave_item<DT, NT>(a.am, blk * (AM_TPB / 64) + (threadIdx.x >> 6));
-        if ((threadIdx.x & 63) == 0 && orow >= 0) verify_arrive(a, orow);
+        const int64_t orow = argmax_wave_item<DT, NT>(a.am, blk * (AM_TPB / 64) + (threadIdx.x >> 6), a.row_prompt, a.Tpad, &owner);
+        if ((threadIdx.x & 63) == 0 && orow >= 0) verify_arrive(a, owner);
     } else {
-        const int64_t orow = argmax_wg_item<DT, true, NT>(a.am, blk);
-        if (threadIdx.x == 0 && orow >= 0) verify_arrive(a, orow);
+        const int64_t orow = argmax_wg_item<DT, true, NT>(a.am, blk, a.row_prompt, a.Tpad, &owner);
+        if (threadIdx.x == 0 && orow >= 0) verify_arrive(a, owner);
     }
+#ifdef JF_EXP_VERIFY_TRACE
+    if ((threadIdx.x & 63) == 0) atomicMax(&g_vtrace[1], __builtin_amdgcn_s_memrealtime());
+#endif
 }
 
 extern "C" int jf_mb_verify(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, const int32_t *out_index,

@@ -300,6 +300,7 @@ static int64_t rs_chunk(int dtype, int64_t R, int64_t V, int64_t *cpr_out) {
     if (per_row < 1) per_row = 1;
     if (per_row > 64) per_row = 64;
     int64_t chunk = (V + per_row - 1) / per_row;
+    if (chunk < 8 * gran) chunk = 8 * gran;          // at least one eight-vector batch per lane: shorter items are all overhead
     chunk = ((chunk + gran - 1) / gran) * gran;
     *cpr_out = (V + chunk - 1) / chunk;
     return chunk;

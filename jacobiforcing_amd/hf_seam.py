@@ -12,7 +12,8 @@ with the reference's signatures and return tuples (MB:141-167, 219-225, 547/614/
     set_length(cache, n)                -> committed length := n                                          (MB:36-59)
 
 ``Qwen2Backend`` implements it over the PyTorch-ROCm forward + static KV cache; tests use a scripted backend.  The loop
-body is the HIP path (jf_argmax_partial / jf_mb_step / jf_accept_lengths); no ``.item()`` per span or per pool entry.
+body is the HIP path (jf_mb_verify for the multiblock function, jf_argmax_partial + jf_sb_step for the single-block one):
+one descriptor read-back per iteration, no ``.item()`` per span, per pool entry or per accepted prefix.
 """
 from __future__ import annotations
 
@@ -42,7 +43,9 @@ class Qwen2Backend:
         B, T = rows.shape
         dev = self.device
         kv = cache.length
-        if kv + T > self.max_seq_len or B > self.max_rows or T > self.max_tokens:
+        # max_tokens sizes the candidate scratch rows only: a single row (prefill of prompt + draft, any B == 1 forward)
+        # writes the main cache and may be as long as the cache itself
+        if kv + T > self.max_seq_len or B > self.max_rows or (B > 1 and T > self.max_tokens):
             raise RuntimeError(f"forward of {B}x{T} tokens at position {kv} exceeds the static cache "
                                f"(max_seq_len={self.max_seq_len}, max_rows={self.max_rows}, max_tokens={self.max_tokens})")
         pos = (kv + torch.arange(T, dtype=torch.int32, device=dev)).view(1, T).expand(B, T).contiguous()
@@ -141,53 +144,16 @@ def jacobi_forward_greedy(self, input_ids=None, attention_mask=None, position_id
     be = _backend(self)
     cache = past_key_values
     dev = input_ids.device
-    out = input_ids.clone()
-    acc_buf = input_ids.clone()                       # SB:145 aliases the input; writes past its end are dropped
-    cap = acc_buf.shape[1]
-    total, itr = 0, 0
-    next_token = None
-
-    def write(pos, toks):
-        k = max(0, min(toks.shape[1], cap - pos))
-        if k > 0:
-            acc_buf[:, pos:pos + k] = toks[:, :k]
-
-    while total < n:
+    st = ops.SingleBlockStepper(input_ids, getattr(be, "device", dev))
+    itr = 0
+    d = None
+    while st.total < n:                                                                                  # SB:150
         itr += 1
-        L = out.shape[1]
-        logits = be.forward(out, cache)                                                                  # [L, V]
-        kv_after = cache.get_seq_length() + L
-        greedy = ops.argmax_rows(logits).view(1, L)
-        acc, _ = ops.accept_lengths(out, greedy)                                                        # SB:197-202
-        gh = greedy.cpu()
-        oh = out.cpu()
-        raw = int(acc.cpu()[0])
-        num = raw
-        if eos_enabled:                                                                                  # SB:206-211
-            hit = (oh[0, :raw] == eos_token_id).nonzero()
-            if hit.numel():
-                num = int(hit[0]) + 1
-        if num > 0:
-            write(total, out[:, :num])
-        total += num
-        if eos_enabled and bool((oh[0, :num] == eos_token_id).any()):                                    # SB:219-227
-            be.set_length(cache, min(kv_after, total))
-            return cache, torch.full((1, 1), eos_token_id, device=dev, dtype=out.dtype), acc_buf[:, :total], itr
-        if raw < L:                                                                                      # SB:231-255
-            be.set_length(cache, kv_after - (L - raw))
-            next_token = greedy[:, raw - 1:raw]
-            if eos_enabled and int(gh[0, raw - 1]) == eos_token_id:
-                write(total, next_token)
-                total += 1
-                be.set_length(cache, min(cache.get_seq_length(), total))
-                return cache, next_token, acc_buf[:, :total], itr
-            out = torch.cat([next_token, greedy[:, raw:L - 1]], dim=-1)
-        else:                                                                                            # SB:258-273
-            be.set_length(cache, kv_after)
-            next_token = greedy[:, L - 1:L]
-            write(total, next_token)
-            total += 1
-            if eos_enabled and int(gh[0, L - 1]) == eos_token_id:
-                be.set_length(cache, min(cache.get_seq_length(), total))
-                return cache, next_token, acc_buf[:, :total], itr
-    return cache, next_token, acc_buf[:, :total], itr
+        logits = be.forward(st.draft(), cache)                                                           # [L, V]
+        d = st.step(logits, eos_token_id if eos_enabled else None, cache.get_seq_length())               # SB:197-273 on the device
+        be.set_length(cache, d["kv_len"])
+        if d["done"]:
+            break
+    acc = st.acc[:min(st.total, st.cap)].view(1, -1).to(device=dev, dtype=input_ids.dtype)
+    nxt = None if d is None else torch.full((1, 1), d["next_token"], device=dev, dtype=input_ids.dtype)
+    return cache, nxt, acc, itr

@@ -168,7 +168,7 @@ class MultiblockBatch:
         self.ret_buf = torch.zeros((self.P, self.ret_cap), dtype=torch.int64, device=dev)
         self.Rtot = 0
         self.Tpad = 0
-        self.arrive = torch.zeros((self.P,), dtype=torch.int32, device=dev)   # jf_mb_verify's per-prompt arrival counters
+        self.arrive = torch.zeros((self.P * 64,), dtype=torch.int32, device=dev)   # jf_mb_verify: one 256-byte counter line per prompt
         # JF_FUSED_VERIFY=0: argmax and state machine as two launches (A/B measurements in tools/)
         self.fused = os.environ.get("JF_FUSED_VERIFY", "1") != "0"
 
@@ -244,11 +244,14 @@ class MultiblockBatch:
             raise ValueError(f"expected logits for {self.Rtot}x{self.Tpad} positions, got {tuple(logits.shape)}")
         if self.fused:
             return self.verify_fused(flat, self.valid_index if compacted else None)
+        VERIFY_HOOK and VERIFY_HOOK[0](self, flat)
         if compacted:
             argmax_scatter(flat, self.valid_index, self.packed)
         else:
             argmax_partial(flat, self.packed)
-        return self.step()
+        self._launch_step()
+        VERIFY_HOOK and VERIFY_HOOK[1](self, flat)
+        return self._read_desc()
 
     def verify_fused(self, flat: torch.Tensor, out_index: Optional[torch.Tensor]) -> np.ndarray:
         """jf_mb_verify: argmax items + one stepper workgroup per prompt in one launch (MB:473-721)."""
@@ -263,9 +266,12 @@ class MultiblockBatch:
         VERIFY_HOOK and VERIFY_HOOK[1](self, flat)
         return self._read_desc()
 
-    def step(self) -> np.ndarray:
+    def _launch_step(self) -> None:
         N.check(N.lib().jf_mb_step(_ptr(self.states), self.state_ints, self.P, _ptr(self.packed),
                                    self.Rtot * self.Tpad, _ptr(self.desc_dev), _stream(self.device)), "jf_mb_step")
+
+    def step(self) -> np.ndarray:
+        self._launch_step()
         return self._read_desc()
 
     def results(self, d: np.ndarray) -> List[dict]:
@@ -402,6 +408,48 @@ class EngineStepper:
         if self.device.type == "cuda":
             torch.cuda.current_stream(self.device).synchronize()
         return self.rows_host[:B].numpy(), th.numpy(), nd
+
+
+# --------------------------------------------------------------------------------------------
+# HF single-block step (SB:197-273)
+# --------------------------------------------------------------------------------------------
+class SingleBlockStepper:
+    """State of one jacobi_forward_greedy call on the device: the draft row, accepted_n_gram and the argmax workspace.
+    Per iteration: jf_argmax_partial + jf_sb_step and ONE descriptor read-back (the reference: ~12 small launches and three
+    host syncs, SB:199-235)."""
+
+    def __init__(self, input_ids: torch.Tensor, device):
+        dev = torch.device(device)
+        self.device = dev
+        n = int(input_ids.shape[-1])
+        self.cap = n
+        self.out = input_ids.reshape(-1).to(device=dev, dtype=torch.int64).clone()
+        self.acc = input_ids.reshape(-1).to(device=dev, dtype=torch.int64).clone()      # SB:145: accepted_n_gram aliases the input
+        self.packed = new_packed(n, dev)
+        self.desc_dev = torch.zeros((len(N.SB_FIELDS),), dtype=torch.int32, device=dev)
+        self.desc_host = torch.zeros((len(N.SB_FIELDS),), dtype=torch.int32, pin_memory=dev.type == "cuda")
+        self.L = n
+        self.total = 0
+
+    def draft(self) -> torch.Tensor:
+        return self.out[:self.L].view(1, self.L)
+
+    def step(self, logits: torch.Tensor, eos_id: Optional[int], kv_before: int) -> dict:
+        """logits [L, V] of the forwarded draft -> the iteration's descriptor (dict of N.SB_FIELDS)."""
+        L = self.L
+        flat = logits.reshape(-1, logits.shape[-1])
+        if flat.shape[0] != L:
+            raise ValueError(f"expected logits for {L} positions, got {tuple(logits.shape)}")
+        argmax_partial(flat, self.packed)
+        N.check(N.lib().jf_sb_step(_ptr(self.out), L, _ptr(self.packed), -1 if eos_id is None else int(eos_id), self.total,
+                                   self.cap, _ptr(self.acc), int(kv_before), _ptr(self.desc_dev), _stream(self.device)),
+                "jf_sb_step")
+        self.desc_host.copy_(self.desc_dev, non_blocking=True)
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
+        d = dict(zip(N.SB_FIELDS, self.desc_host.tolist()))
+        self.total, self.L = d["total"], d["next_len"]
+        return d
 
 
 # --------------------------------------------------------------------------------------------

@@ -61,6 +61,7 @@ class HostSimLib:
             "hs_mb_step": (C.c_int, [vp, i64, C.c_int, vp, i64, vp]),
             "hs_mb_read_ret": (C.c_int, [vp, i64, C.c_int, vp, i32]),
             "hs_engine_step": (C.c_int, [vp, C.c_int, C.c_int, vp, i32, vp, vp, vp, vp, i64, vp, vp]),
+            "hs_sb_step": (C.c_int, [vp, C.c_int, vp, i32, i32, i32, vp, i32, vp]),
         }
         for k, (r, a) in sig.items():
             f = getattr(self.hs, k)
@@ -107,6 +108,9 @@ class HostSimLib:
 
     def jf_engine_step(self, *a):
         return self.hs.hs_engine_step(*a[:-1])
+
+    def jf_sb_step(self, *a):
+        return self.hs.hs_sb_step(*a[:-1])
 
     def jf_engine_fill(self, draft, B, L, seq_len, block_tables, max_cols, block_size, input_ids, positions, slot_mapping,
                        cu_q, cu_k, cache_seqlens, err, stream):

@@ -48,6 +48,12 @@ int hs_mb_read_ret(const int32_t *states, int64_t state_ints, int P, int64_t *re
     return 0;
 }
 
+int hs_sb_step(int64_t *out, int L, uint64_t *packed, int32_t eos_id, int32_t total, int32_t cap, int64_t *acc_buf,
+               int32_t kv_before, jf_sb_desc *desc) {
+    jfmb::sb_step_body(HostLanes{}, out, L, packed, eos_id, total, cap, acc_buf, kv_before, desc);
+    return 0;
+}
+
 // engine step for a batch of rows, same contract as jf_engine_step
 int hs_engine_step(const int64_t *draft, int B, int L, uint64_t *packed, int32_t eos_id, const int32_t *remaining,
                    int64_t *new_tokens, int64_t *next_draft, const int64_t *pad_stream, int64_t pad_len,

@@ -118,3 +118,44 @@ def test_two_rank_gloo_aggregation(tmp_path):
     d = json.loads(outs[0][0].strip().splitlines()[-1])
     assert d["ws"] == 2 and d["mine"] == [0, 2, 4, 6, 8]
     assert d["agg"] == dict(tokens=300.0, iterations=20.0, seconds=2.0, world_size=2)
+
+
+def test_bench_launch_command_is_one_rank_per_gpu():
+    """Started as a plain command with --gpus N > 1, bench.py re-runs itself under torch.distributed.run with N ranks on the
+    loopback rendezvous (never a silent single-GPU run)."""
+    import bench
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "3"], 29999)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """No GPU here: `bench.py --gpus 2` must fail loudly instead of measuring fewer GPUs than asked."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "JF_FORCE_DEVICE")}
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--model", "tiny"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)
+    assert '"n_gpus"' not in r.stdout
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` (no launcher, no WORLD_SIZE) starts two ranks itself.  On the one-GPU box both ranks share
+    the GPU (JF_FORCE_DEVICE=0) and the throughput gather runs over gloo — everything but RCCL itself is exercised; the line
+    must say n_gpus = 2 and carry the tokens of both ranks, in both scaling modes."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(JF_DIST_BACKEND="gloo", JF_FORCE_DEVICE="0")
+    for extra, mode, per_gpu in ((["--prompts-per-gpu", "4"], "weak", 4), (["--total-prompts", "6"], "strong", 3)):
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--model", "tiny",
+                            "--no-scripted", "--cpu-baseline-seconds", "0", *extra], env=env, capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["scaling"] == mode and d["config"]["prompts_per_gpu"] == per_gpu
+        assert d["config"]["total_prompts"] == 2 * per_gpu and d["value"] > 0 and d["steps"] == 3
+        assert d["tokens_per_forward"] >= 1.0

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Timeline of the fused verify launch (jf_mb_verify) at 1 / 8 / 64 prompts: synthetic bf16 logits at V = 152064, the state
+machines advance with whatever those logits accept.  Prints HIP-event microseconds of the fused launch and of the two
+launches it replaces; with the experiment build (-DJF_EXP_VERIFY_TRACE, JF_LIB=tools/libjf_exp_vtrace.so) also the
+in-kernel stamps: when the items ran and what each stepper did after its rows arrived.
+
+    python tools/verify_trace.py [--prompts 1 8 64] [--iters 12]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from jacobiforcing_amd import _native as N, ops  # noqa: E402
+
+V = 152064
+
+
+def run(P, iters, fused, trace_lib=None):
+    prm = ops.MultiblockParams(n=32, K=2, r=0.85, n_gram_pool_size=4, eos_token_id=None, pad_token_id=151643)
+    batch = ops.MultiblockBatch(P, prm, "cuda")
+    batch.fused = fused
+    g = torch.Generator(device="cuda").manual_seed(7)
+    ids = torch.randint(0, 151000, (P, 32), generator=g, device="cuda")
+    d = batch.begin(ids, torch.full((P,), 200, dtype=torch.int32))
+    times, rows_l = [], []
+    stamps = None
+    for it in range(iters):
+        pk = batch.pack(d, t_align=8, compact=True, valid_align=8 * P)
+        if pk is None:
+            break
+        nv = batch.valid_index.numel()
+        logits = torch.randn(nv, V, generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+        _ = torch.zeros(64 << 20, device="cuda").sum()          # push the fresh logits out of the caches a little
+        torch.cuda.synchronize()
+        if trace_lib is not None and it == iters - 1:
+            trace_lib.jf_exp_reset_vtrace()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ops.VERIFY_HOOK = (lambda *_: a.record(), lambda *_: b.record())
+        d = batch.verify(logits, compacted=True)
+        ops.VERIFY_HOOK = None
+        torch.cuda.synchronize()
+        times.append(a.elapsed_time(b) * 1e3)
+        rows_l.append(batch.Nvalid)
+        if trace_lib is not None and it == iters - 1:
+            buf = (C.c_ulonglong * (2 + 8 * 256))()
+            trace_lib.jf_exp_read_vtrace(buf, 2 + 8 * 256)
+            stamps = np.array(buf[:], dtype=np.uint64)
+        done = batch.desc_field(d, "done")
+        if done.any():                                            # restart finished calls (rolling, like the decoder)
+            kv = np.where(done == 1, batch.desc_field(d, "kv_len"), N.JF_MB_KEEP).astype(np.int32)
+            d = batch.begin(ids, torch.from_numpy(kv))
+    t = np.array(times[2:])
+    r = np.array(rows_l[2:])
+    mb = r.mean() * V * 2 / 1e6
+    print(f"P={P:3d} {'fused  ' if fused else 'unfused'} rows/launch {r.mean():7.1f} ({mb:6.1f} MB)  {t.mean():6.1f} us (min {t.min():6.1f})  "
+          f"{mb / t.mean() * 1e3 / 1e3:6.2f} TB/s = {mb / t.mean() / 8:5.3f} of 8 TB/s", flush=True)
+    if stamps is not None:
+        t0 = int(stamps[0])
+        rel = lambda x: (int(x) - t0) / 100.0                     # 100 MHz ticks -> us
+        print(f"      items: first start 0.0 us, last end {rel(stamps[1]):.1f} us")
+        for p in list(range(min(P, 3))) + ([P - 1] if P > 3 else []):
+            s = stamps[2 + 8 * p: 2 + 8 * p + 7]
+            print(f"      stepper {p:3d}: start {rel(s[0]):6.1f}  image {rel(s[1]):6.1f}  arrived {rel(s[2]):6.1f}  gathered {rel(s[3]):6.1f}  "
+                  f"stepped {rel(s[4]):6.1f}  written {rel(s[5]):6.1f}  end {rel(s[6]):6.1f}")
+        ends = np.array([rel(stamps[2 + 8 * p + 6]) for p in range(P)])
+        arr = np.array([rel(stamps[2 + 8 * p + 2]) for p in range(P)])
+        print(f"      all steppers: arrived {arr.min():.1f}..{arr.max():.1f} us, end {ends.min():.1f}..{ends.max():.1f} us")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--prompts", type=int, nargs="+", default=[1, 8, 64])
+    ap.add_argument("--iters", type=int, default=12)
+    a = ap.parse_args()
+    trace_lib = None
+    lib = N.lib()
+    if hasattr(lib, "jf_exp_read_vtrace"):
+        trace_lib = lib
+        lib.jf_exp_read_vtrace.argtypes = [C.c_void_p, C.c_int]
+    for P in a.prompts:
+        run(P, a.iters, False)
+        run(P, a.iters, True, trace_lib)
+
+
+if __name__ == "__main__":
+    main()
