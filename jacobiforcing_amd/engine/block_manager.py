@@ -27,6 +27,13 @@ class Block:
 
 
 class BlockManager:
+    """Free / used block ids and per-sequence block tables, with the reference's Jacobi entry points.
+
+    No prefix cache: blocks are never hashed or shared between sequences, so the hash bookkeeping the reference does on
+    append (BM:195-265 un-finalises / re-finalises the last block's hash) has nothing to maintain here and
+    ``may_append_batch`` — called by the decoders after every commit, as in the reference — only has to exist.  Block
+    tables still grow and shrink exactly as the reference's do (pinned by tests/golden/bm_cases.json)."""
+
     def __init__(self, num_blocks: int, block_size: int, kv_cache=None):
         self.block_size = block_size
         self.blocks = [Block(i) for i in range(num_blocks)]

@@ -124,6 +124,8 @@ class JacobiDecoderNonGreedy:
             else:
                 max_tokens.append(2048)
         temperature = float(getattr(getattr(seqs[0], "sampling_params", None), "temperature", 1.0))
+        for seq in seqs:
+            ops.reject_unsupported_filters(getattr(seq, "sampling_params", None), self.vocab_size)
         n_iter_call = 0
         dev = self.device
         while True:

@@ -31,32 +31,37 @@ from .sequence import Sequence
 _STREAM_LEN = 1 << 16
 
 
-def _infer_data_id(seq, fallback: str) -> str:                                     # JDO:69-74
-    for attr in ("data_id", "request_id", "req_id", "uid", "id"):
-        v = getattr(seq, attr, None)
-        if v is not None:
-            return str(v)
-    return fallback
+_DATA_ID_ATTRS = ("data_id", "request_id", "req_id", "uid", "id")        # the request attributes JDO:69-74 looks at, in order
 
 
-def _trim_left_padding(ids: List[int], pad_token_id: Optional[int]) -> List[int]:    # JDO:77-87
-    if not ids:
-        return []
+def _infer_data_id(seq, fallback: str) -> str:
+    """First request attribute of _DATA_ID_ATTRS that is set, as a string; else ``fallback``."""
+    found = next((getattr(seq, a) for a in _DATA_ID_ATTRS if getattr(seq, a, None) is not None), None)
+    return fallback if found is None else str(found)
+
+
+def _trim_left_padding(ids: List[int], pad_token_id: Optional[int]) -> List[int]:
+    """Drop the run of pad tokens a left-padded prompt starts with (JDO:77-87); an all-pad list becomes empty."""
+    ids = list(ids)
     if pad_token_id is None:
-        return list(ids)
-    pad = int(pad_token_id)
-    for i, t in enumerate(ids):
-        if int(t) != pad:
-            return list(ids[i:])
-    return []
+        return ids
+    keep = next((k for k, tok in enumerate(ids) if int(tok) != int(pad_token_id)), len(ids))
+    return ids[keep:]
 
 
-def _truncate_after_stop(ids: List[int], start_idx: int, stop_ids: PySeq[int]) -> List[int]:   # JDO:170-182
-    stop = set(int(x) for x in stop_ids)
-    for i in range(max(0, int(start_idx)), len(ids)):
-        if int(ids[i]) in stop:
-            return list(ids[:i + 1])
-    return list(ids)
+def _truncate_after_stop(ids: List[int], start_idx: int, stop_ids: PySeq[int]) -> List[int]:
+    """Cut after the first stop token at or behind ``start_idx`` (the prompt itself may contain stop ids, JDO:170-182)."""
+    ids, stop = list(ids), frozenset(int(x) for x in stop_ids)
+    first = max(0, int(start_idx))
+    hit = next((k for k in range(first, len(ids)) if int(ids[k]) in stop), None)
+    return ids if hit is None else ids[:hit + 1]
+
+
+def _require(value, what: str):
+    """The constructor's contract (JDO:205-221): ids and sizes come from the model config, never from defaults."""
+    if value is None:
+        raise ValueError(f"{what} must be provided from model config. Do not use hard-coded values.")
+    return value
 
 
 class _BlockState:
@@ -115,18 +120,11 @@ class JacobiDecoderNonGreedyOnPolicy:
         self.block_manager = block_manager
         self.forward_step = forward_step
         self.forward_step_batch = forward_step_batch
-        if eos_token_id is None:                                                                  # JDO:205-210
-            raise ValueError("eos_token_id must be provided from model config. Do not use hard-coded values.")
-        elif isinstance(eos_token_id, (list, tuple, set)):
-            self.stop_token_ids = tuple(int(x) for x in eos_token_id)
-        else:
-            self.stop_token_ids = (int(eos_token_id),)
-        if pad_token_id is None:
-            raise ValueError("pad_token_id must be provided from model config. Do not use hard-coded values.")
-        self.pad_token_id = int(pad_token_id)
-        if vocab_size is None:
-            raise ValueError("vocab_size must be provided from model config. Do not use hard-coded values.")
-        self.vocab_size = int(vocab_size)
+        eos = _require(eos_token_id, "eos_token_id")                                              # JDO:205-210
+        many = isinstance(eos, (list, tuple, set))
+        self.stop_token_ids = tuple(int(t) for t in (eos if many else (eos,)))
+        self.pad_token_id = int(_require(pad_token_id, "pad_token_id"))
+        self.vocab_size = int(_require(vocab_size, "vocab_size"))
         self.debug = os.environ.get("JACOBI_DEBUG", "0") == "1"
         if device is None:
             device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
@@ -193,6 +191,7 @@ class JacobiDecoderNonGreedyOnPolicy:
         blk.start(self._init_block_draft_from_prompt(list(seq.token_ids), blk.gen_len))
         sp = getattr(seq, "sampling_params", None)
         temperature = float(getattr(sp, "temperature", 1.0)) if sp is not None else 1.0
+        ops.reject_unsupported_filters(sp, self.vocab_size)
         st = self._ensure(blk.full_len + 1)
         bm = self.block_manager
         tick = (lambda name, on: (profiler.start(name) if on else profiler.stop(name))) if profiler else (lambda name, on: None)

@@ -254,8 +254,10 @@ class ModelRunner:
                                        max_iteration_count=sp0.jacobi_max_iterations)
             dec = MultiblockJacobiDecoder(self.model, len(seqs), prm, max_seq_len=self.config.max_model_len)
             self._mb_decoders = {key: dec}                      # one live decoder (its KV cache is the big allocation)
-        max_new = max(s.max_tokens - s.num_completion_tokens for s in seqs)
-        stats, gen_s, iters = dec.generate([s.token_ids for s in seqs], max_new_tokens=max_new, max_calls=1 << 30,
+        # every request decodes to ITS OWN budget (whole blocks are appended, so the last call may overshoot it by less than
+        # a block, like the reference's accepts, JD E3); a request that outgrew its cache row is finished, not re-queued
+        budgets = [max(s.max_tokens - s.num_completion_tokens, 0) for s in seqs]
+        stats, gen_s, iters = dec.generate([s.token_ids for s in seqs], max_new_tokens=budgets, max_calls=1 << 30,
                                            seed=int(os.environ.get("JF_DRAFT_SEED", "1234")))
         self.last_multiblock = dict(stats=stats, gen_seconds=gen_s, iterations=iters)
         out = []
@@ -263,6 +265,8 @@ class ModelRunner:
             toks = st.token_ids
             s.extend_tokens(toks)
             s.num_cached_tokens = len(s)
+            if st.stop_reason == "max_seq_len":
+                s.max_tokens = min(s.max_tokens, s.num_completion_tokens)      # postprocess_jacobi then finishes it
             out.append(toks)
         return out
 

@@ -202,6 +202,9 @@ class MultiblockJacobiDecoder:
                  max_iterations: Optional[int] = None, on_generation_start: Optional[Callable[[], None]] = None,
                  on_call_done: Optional[Callable[[int, List[int]], None]] = None):
         assert len(prompts) == self.P
+        # one budget per prompt (a scalar applies to all): a prompt stops its calls once it holds that many new tokens
+        budgets = ([int(max_new_tokens)] * self.P if np.isscalar(max_new_tokens) else [int(x) for x in max_new_tokens])
+        assert len(budgets) == self.P
         n, eos = self.params.n, self.params.eos_token_id
         rngs = [random.Random(seed + p) for p in range(self.P)]          # one stream per prompt (order-independent)
         stats = [PromptStats(prompt_tokens=len(p)) for p in prompts]
@@ -244,7 +247,7 @@ class MultiblockJacobiDecoder:
                     self.kv_len_host[p] = r["kv_len"]
                     if eos is not None and eos in st.token_ids:                      # DRV:154-160
                         st.stop_reason = "eos"
-                    elif new_total >= max_new_tokens:
+                    elif new_total >= budgets[p]:
                         st.stop_reason = "max_new_tokens"
                     elif st.calls >= max_calls:
                         st.stop_reason = "max_calls"

@@ -180,11 +180,15 @@ class Qwen2Model:
         self.w = weights
         self.device = weights.embed.device
         self.dtype = weights.embed.dtype
-        hd = cfg.head_dim
-        inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, hd, 2, device=self.device, dtype=torch.float32) / hd))
-        t = torch.arange(cfg.max_position_embeddings, device=self.device, dtype=torch.float32)
-        fr = torch.outer(t, inv)
-        self.cos = fr.cos()     # [max_pos, hd/2] fp32
+        self._rope_tables(cfg.max_position_embeddings)
+
+    def _rope_tables(self, n_pos: int) -> None:
+        """cos / sin [n_pos, hd/2] fp32.  The fused RoPE + KV-append launch indexes them with raw positions, so they always
+        cover every position a cache row can hold: forward() grows them to cache.S_max before the first launch."""
+        hd = self.cfg.head_dim
+        inv = 1.0 / (self.cfg.rope_theta ** (torch.arange(0, hd, 2, device=self.device, dtype=torch.float32) / hd))
+        fr = torch.outer(torch.arange(int(n_pos), device=self.device, dtype=torch.float32), inv)
+        self.cos = fr.cos()
         self.sin = fr.sin()
 
     # -- pieces -----------------------------------------------------------------------------
@@ -224,6 +228,8 @@ class Qwen2Model:
         if s_cur is None:
             s_cur = (int(kv_len_rows.max().item()) + T) if R else T
         S_cur = min(int(s_cur), cache.S_max)
+        if self.cos.shape[0] < cache.S_max:                  # a cache longer than max_position_embeddings: never read past the table
+            self._rope_tables(cache.S_max)
         ar_t = torch.arange(T, device=dev)
         ar_s = torch.arange(S_cur, device=dev)
         kvl = kv_len_rows.long()

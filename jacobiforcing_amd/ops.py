@@ -510,6 +510,21 @@ class PagedFill:
 # --------------------------------------------------------------------------------------------
 # non-greedy verify (JDN:299-354, 581-639)
 # --------------------------------------------------------------------------------------------
+def reject_unsupported_filters(sp, vocab_size: int) -> None:
+    """The reference's _build_target_probs (JDN:110-123) applies top_k / top_p when the request object carries such
+    attributes (SamplingParams has no such fields, sampling_params.py:4-38, so this only happens when a caller attaches them).
+    The HIP verify samples from the unfiltered softmax: an ACTIVE filter is refused loudly instead of being ignored."""
+    if sp is None:
+        return
+    top_k, top_p = getattr(sp, "top_k", None), getattr(sp, "top_p", None)
+    k_active = top_k is not None and 0 < int(top_k) < int(vocab_size)                           # JDN:73-74
+    p_active = top_p is not None and 0.0 < float(top_p) < 1.0                                   # JDN:91-95
+    if k_active or p_active:
+        raise NotImplementedError(f"top_k={top_k!r} / top_p={top_p!r} filtering of the target distribution is not implemented "
+                                  "by the HIP rejection-sampling verify (DESIGN.md §7); remove the attribute or use temperature only")
+
+
+
 class RsStepper:
     """Rejection-sampling verify of a batch of rows: jf_rs_probs (softmax-gather + argmax, logits read once) followed by
     jf_rs_step (accept/reject in stream order, bonus draws, next drafts) and one read-back per iteration.  The logits

@@ -337,3 +337,17 @@ def test_nongreedy_first_token_follows_the_target_distribution(backend):
         js = 0.5 * kl(p, mid) + 0.5 * kl(q, mid)
         assert js < 0.01, (js, p.round(3), q.round(3))
         assert q.max() < 0.95                                  # the distribution is not degenerate (a real test)
+
+
+def test_active_top_k_or_top_p_is_refused():
+    """SamplingParams has no top_k / top_p (sampling_params.py:4-38); the reference honours such attributes when a caller
+    attaches them (JDN:110-123).  The HIP verify samples the unfiltered softmax, so an ACTIVE filter must fail loudly."""
+    import types
+    ops.reject_unsupported_filters(None, 100)
+    ops.reject_unsupported_filters(types.SimpleNamespace(temperature=1.0), 100)
+    ops.reject_unsupported_filters(types.SimpleNamespace(top_k=None, top_p=None), 100)
+    ops.reject_unsupported_filters(types.SimpleNamespace(top_k=0, top_p=1.0), 100)          # inactive values (JDN:73, 94)
+    ops.reject_unsupported_filters(types.SimpleNamespace(top_k=100, top_p=0.0), 100)
+    for bad in (dict(top_k=5), dict(top_p=0.9)):
+        with pytest.raises(NotImplementedError):
+            ops.reject_unsupported_filters(types.SimpleNamespace(**bad), 100)

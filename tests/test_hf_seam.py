@@ -121,6 +121,32 @@ def test_seam_on_qwen2_backend_equals_autoregressive(backend):
         assert gen == ar
 
 
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_seam_prefill_longer_than_the_candidate_scratch(backend):
+    """max_tokens sizes the candidate scratch rows only: a one-row forward (the prefill of prompt + draft, every single-block
+    forward) may be as long as the cache row.  A 70-token prompt with max_tokens = 32 must prefill and decode."""
+    with use_backend(backend):
+        dev = device_for(backend)
+        model = tiny_model(dev, seed=19)
+        V = model.cfg.vocab_size
+        me = types.SimpleNamespace(jf_backend=hf_seam.Qwen2Backend(model, max_seq_len=256, max_rows=4, max_tokens=32))
+        n = 8
+        prompt = [int(t) for t in np.random.default_rng(5).integers(0, V - 2, size=70)]
+        kw = dict(n_token_seq_len=n, K=2, r=0.5, n_gram_pool_size=4, eos_token_id=None, pad_token_id=V - 2, use_cache=True)
+        cache, _, ngram, _ = hf_seam.jacobi_forward_greedy_multiblock(me, torch.tensor([prompt + prompt[:n]], device=dev),
+                                                                       past_key_values=None, prefill_phase=True, **kw)
+        assert cache.get_seq_length() == len(prompt)
+        cache, first, acc, iters = hf_seam.jacobi_forward_greedy_multiblock(me, ngram, past_key_values=cache, prefill_phase=False, **kw)
+        fwd = scratch_forward(model)
+        toks, ar = list(prompt), []
+        for _ in range(acc.shape[1]):
+            nxt = fwd([toks[:-1]], [[toks[-1]]])[0][0]
+            ar.append(nxt); toks.append(nxt)
+        assert acc[0].cpu().tolist() == ar
+        with pytest.raises(RuntimeError):                       # candidates (B > 1) longer than the scratch are still refused
+            me.jf_backend.forward(torch.zeros((2, 40), dtype=torch.int64, device=dev), cache)
+
+
 # ------------------------------------------------------------------------------------- streaming driver (applications/)
 class _StubTokenizer:
     """Token ids <-> "<id>" pieces; enough of the HF tokenizer surface for jacobi_stream_chat."""

@@ -87,6 +87,27 @@ def test_jacobi_matches_autoregressive(model_dir, backend, monkeypatch):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+def test_multiblock_requests_keep_their_own_budgets(model_dir, backend, monkeypatch):
+    """Requests of one multiblock batch with different max_tokens: each stops at ITS budget (whole blocks are appended, so at
+    most one block of overshoot), and a request that ran out of cache row is finished instead of being re-prefilled."""
+    monkeypatch.setenv("JF_INIT_STD", "0.3")
+    monkeypatch.setenv("JF_DTYPE", "float32")
+    with use_backend(backend):
+        dev = device_for(backend)
+        llm = LLM(model_dir, tokenizer_path="none", device=dev, max_model_len=512, max_num_batched_tokens=512, max_num_seqs=4)
+        prompts = [[5, 9, 200, 31, 7], [100, 101, 102, 103, 104, 105, 106, 107, 108]]
+        mk = lambda n: SamplingParams(temperature=0.0, max_tokens=n, ignore_eos=True,
+                                      decode_strategy="jacobi_multiblock_rejection_recycling", jacobi_block_len=8,
+                                      jacobi_max_blocks=2, jacobi_spawn_ratio=0.5)
+        out = llm.generate(prompts, [mk(10), mk(60)], use_tqdm=False)
+        ar = llm.generate(prompts, SamplingParams(temperature=0.0, max_tokens=60, ignore_eos=True), use_tqdm=False)
+        n0, n1 = len(out[0]["token_ids"]), len(out[1]["token_ids"])
+        assert 10 <= n0 < 10 + 2 * 8 + 2 and n1 >= 60
+        assert out[0]["token_ids"] == ar[0]["token_ids"][:n0] and out[1]["token_ids"][:60] == ar[1]["token_ids"]
+        llm.exit()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_nongreedy_and_errors(model_dir, backend, monkeypatch):
     monkeypatch.setenv("JF_INIT_STD", "0.3")
     with use_backend(backend):
