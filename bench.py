@@ -377,9 +377,9 @@ def main():
 
 def _pmc_traffic(roof):
     """HBM bytes per launch = algorithmic bytes x the traffic ratio measured in the committed rocprofv3 PMC passes of
-    this same command (profiles/pmc_argmax_latest.json: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch over algorithmic
+    this same command (profiles/pmc_verify_latest.json: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch over algorithmic
     bytes, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction); null when no pass is committed."""
-    f = ROOT / "profiles" / "pmc_argmax_latest.json"
+    f = ROOT / "profiles" / "pmc_verify_latest.json"
     try:
         d = json.loads(f.read_text())
         return float(d["traffic_over_algorithmic"]) * roof["avg_bytes"]

@@ -658,27 +658,31 @@ JF_HD void mb_read_ret_body(Lanes lanes, int p, const int32_t *states, int64_t s
 
 // ---- compact image of one prompt's state (fused verify launch) -------------------------------------
 // Copy the parts of the HBM state block G (layout LG) a step can touch into the compact image C (layout LC).  Returns false
-// when the current state does not fit the compact capacities (the caller then steps on G itself).  Any number of lanes.
+// when the current state does not fit the compact capacities (the caller then steps on G itself).  Any number of lanes
+// (lanes.sync() must cover all of them).  Two global round trips: the header, then everything else — block entries, span
+// table and a fixed-size prefix of EVERY pool slot (the entry lengths are checked afterwards, from the image).
 template <class Lanes>
 JF_HD bool state_to_compact(Lanes lanes, const int32_t *G, const Layout &LG, int32_t *C, const Layout &LC) {
-    const int len_lists = G[H_LEN_LISTS], nsp = G[H_NSPANS], pool_count = G[H_POOL_COUNT], pool_head = G[H_POOL_HEAD];
-    if (len_lists >= LC.NB || nsp > LC.NB || G[H_T] > LC.TMAX || G[H_B] > LC.RMAX) return false;   // a spawn needs one free entry
+    for (int i = lanes.lane(); i < H_SPANS; i += lanes.count()) C[i] = G[i];
+    lanes.sync();
+    const int len_lists = C[H_LEN_LISTS], nsp = C[H_NSPANS], pool_count = C[H_POOL_COUNT], pool_head = C[H_POOL_HEAD];
+    if (len_lists >= LC.NB || nsp > LC.NB || C[H_T] > LC.TMAX || C[H_B] > LC.RMAX) return false;   // a spawn needs one free entry
+    const int n_sp = 3 * nsp, n_blk = len_lists * LG.blk_stride, per_slot = 1 + LC.LPOOL, n_pool = imax(LG.pool_size, 0) * per_slot;
+    for (int i = lanes.lane(); i < n_sp + n_blk + n_pool; i += lanes.count()) {
+        if (i < n_sp) C[H_SPANS + i] = G[H_SPANS + i];
+        else if (i < n_sp + n_blk) C[LC.off_blocks + (i - n_sp)] = G[LG.off_blocks + (i - n_sp)];
+        else {
+            const int k = i - n_sp - n_blk, slot = k / per_slot, j = k - slot * per_slot;
+            C[LC.off_pool + slot * per_slot + j] = G[LG.off_pool + slot * (1 + LG.LPOOL) + j];
+        }
+    }
+    lanes.sync();
     bool fits = true;
     for (int i = 0; i < pool_count; ++i) {
         const int slot = (pool_head + i) % LG.pool_size;
-        if (G[LG.off_pool + slot * (1 + LG.LPOOL)] > LC.LPOOL) fits = false;
+        if (C[LC.off_pool + slot * per_slot] > LC.LPOOL) fits = false;
     }
-    if (!fits) return false;
-    for (int i = lanes.lane(); i < H_SPANS + 3 * nsp; i += lanes.count()) C[i] = G[i];
-    for (int i = lanes.lane(); i < len_lists * LG.blk_stride; i += lanes.count()) C[LC.off_blocks + i] = G[LG.off_blocks + i];
-    for (int k = 0; k < pool_count; ++k) {
-        const int slot = (pool_head + k) % LG.pool_size;
-        const int32_t *e = G + LG.off_pool + slot * (1 + LG.LPOOL);
-        int32_t *c = C + LC.off_pool + slot * (1 + LC.LPOOL);
-        const int len = e[0];
-        for (int i = lanes.lane(); i < 1 + len; i += lanes.count()) c[i] = e[i];
-    }
-    return true;
+    return fits;
 }
 
 // Write a stepped compact image back: header + spans, every listed block, the live pool entries, the next forward's rows,

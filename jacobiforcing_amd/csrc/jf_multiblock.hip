@@ -151,6 +151,7 @@ extern "C" __attribute__((visibility("default"))) int jf_exp_reset_vtrace(void) 
 struct Lanes256 {                  // all four wavefronts of a stepper workgroup (copy-in only)
     __device__ __forceinline__ int lane() const { return threadIdx.x; }
     __device__ __forceinline__ int count() const { return 256; }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
 };
 
 __device__ __forceinline__ unsigned long long ld_agent_u64(const unsigned long long *p) {

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void rs_probs_finish_kernel(const void *logits
 struct RsTune { int64_t items; };
 static const RsTune &rs_tune() {                            // read once: sweeps in tools/ set it before the first call
     static const RsTune t = [] {
-        RsTune r{1024};                                     // measured: fewer, longer items win (profiles/rs_probs_microbench_*.txt)
+        RsTune r{1024};                                     // resident workgroups per round: 256 CUs x 4 (122 VGPRs per lane)
         const char *e = getenv("JF_RS_ITEMS");
         if (e && *e) { const long long v = atoll(e); if (v >= 1 && v <= (1 << 20)) r.items = v; }
         return r;
@@ -296,11 +296,20 @@ static bool rs_scale_is_exact(float t) {
 
 static int64_t rs_chunk(int dtype, int64_t R, int64_t V, int64_t *cpr_out) {
     const int64_t gran = (int64_t)256 * (dtype == JF_F32 ? 4 : 8);         // one vector per lane: equal chunks, balanced items
-    int64_t per_row = (rs_tune().items + R - 1) / R;
-    if (per_row < 1) per_row = 1;
-    if (per_row > 64) per_row = 64;
+    // Chunks per row: the workgroups of one launch run in rounds of ~`slots` (4 resident workgroups per CU at this kernel's
+    // register count), so pick the split whose makespan  ceil(R * pr / slots) / pr  is smallest — fewest chunks on ties
+    // (fewer, longer items win: profiles/rs_probs_microbench_*.txt) — with at least one eight-vector batch per lane.
+    const int64_t slots = rs_tune().items;
+    int64_t max_pr = V / (8 * gran);
+    if (max_pr < 1) max_pr = 1;
+    if (max_pr > 64) max_pr = 64;
+    int64_t per_row = 1;
+    double best = 1e30;
+    for (int64_t pr = 1; pr <= max_pr; ++pr) {
+        const double ms = (double)((R * pr + slots - 1) / slots) / (double)pr;
+        if (ms < best * 0.97) { best = ms; per_row = pr; }
+    }
     int64_t chunk = (V + per_row - 1) / per_row;
-    if (chunk < 8 * gran) chunk = 8 * gran;          // at least one eight-vector batch per lane: shorter items are all overhead
     chunk = ((chunk + gran - 1) / gran) * gran;
     *cpr_out = (V + chunk - 1) / chunk;
     return chunk;
@@ -671,34 +680,52 @@ __device__ int rs_final_pick(const RsRow &row, const double *segsum, int64_t pro
 //   rs_bonus_kernel   (B workgroups)  ONE inverse-CDF walk per rejected row (or the masked argmax)
 //   rs_finish_kernel  (1 workgroup)   EOS, next drafts, pads, cursors by parallel scans; packed re-zeroed
 // ------------------------------------------------------------------------------------------------
-constexpr int RS_STAGE = 6144;      // floats of p_draft / uniforms staged in LDS by the accept scan (B * (L-1) <= this, else global)
-constexpr int RS_ROWS_LDS = 2048;   // rows whose scan results are kept in LDS
+// strided loop whose loads are issued UNR at a time before the first value is used: the small single-workgroup kernels of
+// the step are chains of global round trips, and a plain `for` pays one round trip per iteration
+template <int UNR, class T, class LoadFn, class StoreFn>
+__device__ __forceinline__ void batched_for(int64_t n, int tid, int nthreads, LoadFn ld, StoreFn st) {
+    for (int64_t i0 = tid; i0 < n; i0 += (int64_t)UNR * nthreads) {
+        T v[UNR];
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) { const int64_t i = i0 + (int64_t)k * nthreads; if (i < n) v[k] = ld(i); }
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) { const int64_t i = i0 + (int64_t)k * nthreads; if (i < n) st(i, v[k]); }
+    }
+}
 
+constexpr int RS_STAGE = 6144;      // floats of p_draft / uniforms staged in LDS by the accept scan (B * (L-1) <= this, else global)
+constexpr int RS_ROWS_LDS = 2048;   // rows whose scan results are kept in LDS (half of it in the chain kernel)
+
+// STAGED: the batch fits the LDS tables (B * (L-1) <= RS_STAGE, B <= RS_ROWS_LDS) — the serial part touches LDS only.
+template <bool STAGED>
 __global__ __launch_bounds__(256) void rs_accept_kernel(const int64_t *draft, int B, int L, const float *p_draft, int eos_id,
                                                          const float *u_stream, int64_t u_len, const int64_t *u_cursor,
                                                          int64_t *committed, jf_rs_row *rows, RsWs w) {
-    __shared__ float s_p[RS_STAGE], s_u[RS_STAGE];          // s_p carries "proposed == EOS" in its sign bit (p >= 0)
-    __shared__ int s_res[RS_ROWS_LDS];                       // nacc | eos << 15 | (rej + 1) << 16 per row
+    __shared__ float s_p[STAGED ? RS_STAGE : 1], s_u[STAGED ? RS_STAGE : 1];   // s_p carries "proposed == EOS" in its sign bit (p >= 0)
+    __shared__ int s_res[STAGED ? RS_ROWS_LDS : 1];                            // nacc | eos << 15 | (rej + 1) << 16 per row
     const int tid = threadIdx.x;
     const int W = L - 1;
     const int n = B * W;
     const int64_t uc0 = *u_cursor;
-    const int ub = (int)(uc0 % u_len);
-    const bool staged = n <= RS_STAGE && u_len < 0x7FFFFFFFll, in_lds = B <= RS_ROWS_LDS;
-    auto p_eos = [&](int i) {
-        const int b = i / W, tt = i - b * W;
-        const uint32_t pb = __float_as_uint(p_draft[i]) & 0x7FFFFFFFu;
-        const bool is_eos = eos_id >= 0 && draft[(int64_t)b * L + tt + 1] == (int64_t)eos_id;
-        return __uint_as_float(pb | (is_eos ? 0x80000000u : 0u));
+    auto tok_at = [&](int i) { const int b = i / W; return draft[(int64_t)b * L + (i - b * W) + 1]; };
+    auto pack_pe = [&](float p, int64_t tok) {
+        return __uint_as_float((__float_as_uint(p) & 0x7FFFFFFFu) | ((eos_id >= 0 && tok == (int64_t)eos_id) ? 0x80000000u : 0u));
     };
-    if (staged) {
-        const int ul = (int)u_len;
-        for (int i = tid; i < n; i += 256) { s_p[i] = p_eos(i); s_u[i] = u_stream[(ub + i) % ul]; }   // at most n uniforms are used
+    if constexpr (STAGED) {
+        const int ul = (int)u_len, ub = (int)(uc0 % u_len);
+        // loads first (eight per lane in flight), arithmetic afterwards; at most n uniforms can be used
+        batched_for<8, float2>(n, tid, 256, [&](int64_t i) { return make_float2(p_draft[i], u_stream[(ub + (int)i) % ul]); },
+                               [&](int64_t i, float2 v) { s_p[i] = v.x; s_u[i] = v.y; });
+        if (eos_id >= 0) {
+            __syncthreads();
+            batched_for<8, int64_t>(n, tid, 256, [&](int64_t i) { return tok_at((int)i); },
+                                    [&](int64_t i, int64_t tk) { s_p[i] = pack_pe(s_p[i], tk); });
+        }
     }
     __syncthreads();
     if (tid < 64) {
         const int lane = tid;
-        int used_total = 0, n_rej = 0;
+        int used_total = 0;
         for (int b = 0; b < B; ++b) {                               // JDN:326-348, rows in order
             int nacc = 0, eos = 0, rej = -1, used = 0;
             for (int t0 = 0; t0 < W; t0 += 64) {
@@ -706,10 +733,10 @@ __global__ __launch_bounds__(256) void rs_accept_kernel(const int64_t *draft, in
                 bool stop = false, rejb = false;
                 if (tt < W) {
                     const int i = b * W + tt;
-                    const float pe = staged ? s_p[i] : p_eos(i);
-                    const float uu = staged ? s_u[used_total + tt] : u_stream[(uc0 + used_total + tt) % u_len];
-                    const bool acc = uu < __uint_as_float(__float_as_uint(pe) & 0x7FFFFFFFu);
-                    rejb = !acc;
+                    float pe, uu;
+                    if constexpr (STAGED) { pe = s_p[i]; uu = s_u[used_total + tt]; }
+                    else { pe = pack_pe(p_draft[i], tok_at(i)); uu = u_stream[(uc0 + used_total + tt) % u_len]; }
+                    rejb = !(uu < __uint_as_float(__float_as_uint(pe) & 0x7FFFFFFFu));
                     stop = rejb || (__float_as_uint(pe) >> 31);     // rejected, or accepted EOS
                 }
                 const unsigned long long bal = __ballot(stop);
@@ -724,73 +751,105 @@ __global__ __launch_bounds__(256) void rs_accept_kernel(const int64_t *draft, in
                 nacc = t0 + wd; used = t0 + wd;
             }
             if (lane == 0) {
-                if (in_lds) s_res[b] = nacc | (eos << 15) | ((rej + 1) << 16);
+                if constexpr (STAGED) s_res[b] = nacc | (eos << 15) | ((rej + 1) << 16);
                 else { rows[b].n_committed = nacc; rows[b].eos = eos; rows[b].reject_pos = rej; }
-                rows[b].n_uniforms = used;
-                rows[b].rsv = n_rej;                                // rejected rows before this one
             }
             used_total += used;
-            if (rej >= 0) n_rej++;
         }
     }
     __syncthreads();
     __threadfence_block();
     // everything else about a row in parallel: row record, the rejected row's work item, the accepted tokens
+    auto res_of = [&](int b, int &nacc, int &eos, int &rej) {
+        if constexpr (STAGED) { const int r = s_res[b]; nacc = r & 0x7FFF; eos = (r >> 15) & 1; rej = (r >> 16) - 1; }
+        else { nacc = rows[b].n_committed; eos = rows[b].eos; rej = rows[b].reject_pos; }
+    };
+    if (tid < 64) {                                                 // rejected rows in front of each row: ballot prefix, 64 rows a pass
+        int before = 0;
+        for (int b0 = 0; b0 < B; b0 += 64) {
+            const int b = b0 + tid;
+            int nacc = 0, eos = 0, rej = -1;
+            if (b < B) res_of(b, nacc, eos, rej);
+            const unsigned long long bal = __ballot(b < B && rej >= 0);
+            if (b < B) rows[b].rsv = before + __builtin_popcountll(bal & ((1ull << tid) - 1ull));
+            before += __builtin_popcountll(bal);
+        }
+    }
     for (int b = tid; b < B; b += 256) {
         int nacc, eos, rej;
-        if (in_lds) { const int r = s_res[b]; nacc = r & 0x7FFF; eos = (r >> 15) & 1; rej = (r >> 16) - 1; }
-        else { nacc = rows[b].n_committed; eos = rows[b].eos; rej = rows[b].reject_pos; }
+        res_of(b, nacc, eos, rej);
+        const int64_t avoid = rej >= 0 ? draft[(int64_t)b * L + rej + 1] : -1;
         jf_rs_row &rw = rows[b];
         rw.n_committed = nacc; rw.eos = eos; rw.reject_pos = rej;
+        rw.n_uniforms = rej >= 0 ? rej + 1 : nacc;                  // one uniform per tested position (JDN:329)
         rw.n_bonus_draws = 0; rw.n_pads = 0; rw.active_next = 0;
         w.sel_row[b] = rej >= 0 ? b * W + rej : -1;
-        w.avoid[b] = rej >= 0 ? (int32_t)draft[(int64_t)b * L + rej + 1] : -1;
+        w.avoid[b] = (int32_t)avoid;
         w.pick_u[b] = -1.f;
     }
-    for (int64_t idx = tid; idx < (int64_t)B * W; idx += 256) {
-        const int b = (int)(idx / W), i = (int)(idx - (int64_t)b * W);
-        const int nacc = in_lds ? (s_res[b] & 0x7FFF) : rows[b].n_committed;
-        if (i < nacc) committed[(int64_t)b * L + i] = draft[(int64_t)b * L + i + 1];
-    }
+    batched_for<8, int64_t>((int64_t)B * W, tid, 256, [&](int64_t idx) { return tok_at((int)idx); },
+                            [&](int64_t idx, int64_t v) {
+                                const int b = (int)(idx / W), i = (int)(idx - (int64_t)b * W);
+                                int nacc, eos, rej;
+                                res_of(b, nacc, eos, rej);
+                                if (i < nacc) committed[(int64_t)b * L + i] = v;
+                            });
 }
 
 // bonus-stream bookkeeping in row order (one workgroup): intervals in parallel, then one wavefront walks the rejected rows
 constexpr int RS_CHAIN_STAGE = 4096;
 __global__ __launch_bounds__(256) void rs_chain_kernel(int B, int64_t V, int epv, const float *b_stream, int64_t b_len,
                                                         const int64_t *b_cursor, jf_rs_row *rows, RsWs w) {
-    __shared__ double s_tot[RS_ROWS_LDS / 2], s_lo[RS_ROWS_LDS / 2], s_hi[RS_ROWS_LDS / 2];
-    __shared__ float s_u[RS_CHAIN_STAGE];
+    constexpr int CAP = RS_ROWS_LDS / 2;
+    __shared__ double s_tot[CAP], s_lo[CAP], s_hi[CAP];      // s_tot < 0: the row was not rejected
+    __shared__ float s_u[RS_CHAIN_STAGE], s_uf[CAP];
+    __shared__ int s_draws[CAP];
     __shared__ int s_nrej;
     const int tid = threadIdx.x, lane = tid & 63;
-    const bool in_lds = B <= RS_ROWS_LDS / 2;
+    const bool in_lds = B <= CAP;
     const int64_t bc0 = *b_cursor;
     if (tid == 0) s_nrej = 0;
     __syncthreads();
     int mine = 0;
     for (int b = tid; b < B; b += 256) {
-        if (rows[b].reject_pos < 0) continue;
-        mine++;
-        if (in_lds) { double t_, lo_, hi_; rs_interval(w, b, V, epv, t_, lo_, hi_); s_tot[b] = t_; s_lo[b] = lo_; s_hi[b] = hi_; }
+        const bool rej = rows[b].reject_pos >= 0;
+        mine += rej ? 1 : 0;
+        if (in_lds) {
+            double t_ = -1.0, lo_ = 0.0, hi_ = 0.0;
+            if (rej) rs_interval(w, b, V, epv, t_, lo_, hi_);
+            s_tot[b] = t_; s_lo[b] = lo_; s_hi[b] = hi_; s_draws[b] = 0; s_uf[b] = -1.f;
+        }
     }
     if (mine) atomicAdd(&s_nrej, mine);
     __syncthreads();
     const int nrej = s_nrej;
     if (nrej == 0) return;
     const int win = (RS_MAX_TRIES * nrej < RS_CHAIN_STAGE && b_len < 0x7FFFFFFFll) ? RS_MAX_TRIES * nrej : 0;   // uniforms that can be touched
-    if (win) { const int bl = (int)b_len, bb = (int)(bc0 % b_len); for (int i = tid; i < win; i += 256) s_u[i] = b_stream[(bb + i) % bl]; }
-    __syncthreads();
-    if (tid >= 64) return;
-    int off = 0;                                            // stream entries consumed by the rows before
-    for (int b = 0; b < B; ++b) {
-        if (rows[b].reject_pos < 0) continue;
-        double t_, lo_, hi_;
-        if (in_lds) { t_ = s_tot[b]; lo_ = s_lo[b]; hi_ = s_hi[b]; } else rs_interval(w, b, V, epv, t_, lo_, hi_);
-        float uf;
-        const int o = off;
-        const int draws = rs_count_draws([&](int tr) { return win ? s_u[o + tr] : b_stream[(bc0 + o + tr) % b_len]; }, t_, lo_, hi_, lane, &uf);
-        if (lane == 0) { rows[b].n_bonus_draws = draws; w.pick_u[b] = uf; }
-        off += draws;
+    if (win) {
+        const int bl = (int)b_len, bb = (int)(bc0 % b_len);
+        batched_for<8, float>(win, tid, 256, [&](int64_t i) { return b_stream[(bb + (int)i) % bl]; }, [&](int64_t i, float v) { s_u[i] = v; });
     }
+    __syncthreads();
+    if (tid < 64) {                                          // the serial part: LDS only when the batch fits the tables
+        int off = 0;                                         // stream entries consumed by the rows before
+        for (int b = 0; b < B; ++b) {
+            double t_, lo_, hi_;
+            if (in_lds) { t_ = s_tot[b]; if (t_ < 0.0) continue; lo_ = s_lo[b]; hi_ = s_hi[b]; }
+            else { if (rows[b].reject_pos < 0) continue; rs_interval(w, b, V, epv, t_, lo_, hi_); }
+            float uf;
+            const int o = off;
+            const int draws = rs_count_draws([&](int tr) { return win ? s_u[o + tr] : b_stream[(bc0 + o + tr) % b_len]; }, t_, lo_, hi_, lane, &uf);
+            if (lane == 0) {
+                if (in_lds) { s_draws[b] = draws; s_uf[b] = uf; }
+                else { rows[b].n_bonus_draws = draws; w.pick_u[b] = uf; }
+            }
+            off += draws;
+        }
+    }
+    __syncthreads();
+    if (in_lds)
+        for (int b = tid; b < B; b += 256)
+            if (s_tot[b] >= 0.0) { rows[b].n_bonus_draws = s_draws[b]; w.pick_u[b] = s_uf[b]; }
 }
 
 template <int DT>
@@ -1055,7 +1114,10 @@ extern "C" int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_
     hipStream_t s = (hipStream_t)stream;
     unsigned long long *pk = (unsigned long long *)packed;
     const RsWs w = rs_ws(workspace, B);
-    rs_accept_kernel<<<1, 256, 0, s>>>(draft, B, L, p_draft, eos_id, u_stream, u_len, u_cursor, committed, rows, w);
+    if ((int64_t)B * (L - 1) <= RS_STAGE && B <= RS_ROWS_LDS && u_len < 0x7FFFFFFFll)
+        rs_accept_kernel<true><<<1, 256, 0, s>>>(draft, B, L, p_draft, eos_id, u_stream, u_len, u_cursor, committed, rows, w);
+    else
+        rs_accept_kernel<false><<<1, 256, 0, s>>>(draft, B, L, p_draft, eos_id, u_stream, u_len, u_cursor, committed, rows, w);
     if (dtype == JF_F32) {
         rs_rowsum_kernel<JF_F32><<<B * RS_SEG, 256, 0, s>>>(logits, V, row_stride, row_max, row_sumexp, t, w);
         rs_chain_kernel<<<1, 256, 0, s>>>(B, V, 4, bonus_stream, bonus_len, bonus_cursor, rows, w);

@@ -52,6 +52,21 @@ def test_plain_c_client(tmp_path):
     assert "rc=-1" in out and "null pointer" in out
 
 
+@GPU
+def test_plain_c_client_launches_kernels(tmp_path):
+    """The same C99 client with -DJF_ABI_GPU: device buffers from the HIP runtime's C API, then jf_argmax_rows,
+    jf_accept_lengths and jf_sb_step called from C and checked there — no Python, no torch between caller and kernels."""
+    import __graft_entry__ as G
+    lib = G.build_hip()
+    exe = tmp_path / "abi_client_gpu"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-DJF_ABI_GPU", f"-I{ROOT / 'include'}", "-I/opt/rocm/include",
+                           str(ROOT / "tests" / "abi" / "abi_client.c"), f"-L{lib.parent}", "-ljacobiforcing", "-L/opt/rocm/lib",
+                           "-lamdhip64", f"-Wl,-rpath,{lib.parent}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "gpu=ok" in out.stdout and "accepted=4" in out.stdout
+
+
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(N.NativeLibraryError):
         N.load(tmp_path / "nope.so")
@@ -546,3 +561,13 @@ def test_rs_step_batch64_block32_planted_mass():
     ndc = nd.cpu().numpy()
     assert (ndc[:, 0] == toks[:, 0]).all()
     assert (ndc[:, 1:L - 1] == lo[:, 1:]).all()
+
+
+@GPU
+@pytest.mark.parametrize("B,L,V", [(100, 65, 64), (1100, 4, 40), (300, 9, 50)], ids=["rows_x_block_over_lds", "batch_over_lds", "many_rejections"])
+def test_rs_step_beyond_the_lds_tables(B, L, V):
+    """Batches whose accept tests / row tables / bonus-stream window do not fit the LDS staging of rs_accept_kernel and
+    rs_chain_kernel take the global-memory variants of the same serial walks: results must not change."""
+    a = _run_rs("hip", B, L, V, 5, 0.5, None, torch.float32, 0.9, eos=3)
+    b = _run_rs("hostsim", B, L, V, 5, 0.5, None, torch.float32, 0.9, eos=3)
+    _assert_rs_equal(a, b, B)

@@ -1,8 +1,8 @@
-"""Turn the two PMC passes of tools/pmc_argmax.sh into profiles/pmc_argmax_latest.json.
+"""Turn the two PMC passes of tools/pmc_verify.sh into profiles/pmc_verify_latest.json.
 
-Per argmax launch:  HBM bytes = 2 * FETCH_SIZE + WRITE_SIZE  (both counters are in KiB; FETCH_SIZE is doubled because
+Per verify launch:  HBM bytes = 2 * FETCH_SIZE + WRITE_SIZE  (both counters are in KiB; FETCH_SIZE is doubled because
 gfx950's rocprofv3 reports half of a wide coalesced streaming read, MI355X_MICROARCH.md "HBM").  The launches of the
-decode loop are the LAST n argmax dispatches of the command (prefill's argmax launches come first); their algorithmic bytes
+decode loop are the mb_verify_kernel dispatches of the command (every one of them belongs to the decode loop); their algorithmic bytes
 are valid_rows * V * element_size as dumped by bench.py (JF_DUMP_LAUNCHES)."""
 import csv
 import glob
@@ -17,7 +17,7 @@ def per_dispatch(dirname: str, counter: str):
         raise SystemExit(f"no counter_collection.csv under {dirname}")
     acc = {}
     for row in csv.DictReader(open(files[0])):
-        if "argmax_" not in row["Kernel_Name"] or "decode" in row["Kernel_Name"] or row["Counter_Name"] != counter:
+        if "mb_verify_kernel" not in row["Kernel_Name"] or row["Counter_Name"] != counter:
             continue
         k = int(row["Dispatch_Id"])
         acc[k] = acc.get(k, 0.0) + float(row["Counter_Value"])
@@ -39,12 +39,12 @@ def main():
     res = dict(traffic_over_algorithmic=sum(hbm) / sum(alg), launches=n, algorithmic_bytes=sum(alg), hbm_bytes=sum(hbm),
                fetch_kib_raw=sum(fetch), write_kib_raw=sum(write),
                rows_valid_mean=sum(la["valid"]) / n, rows_launched_mean=sum(la["rows"]) / n,
-               method="tools/pmc_argmax.sh: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
-                      "`bench.py --steps 12 --warmup 2 --no-scripted --cpu-baseline-seconds 0`; per launch HBM bytes = "
+               method="tools/pmc_verify.sh: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
+                      "`bench.py --steps 12 --warmup 2 --no-scripted --no-shapes --cpu-baseline-seconds 0`; per launch HBM bytes = "
                       "(2*FETCH_SIZE + WRITE_SIZE) KiB (FETCH_SIZE doubled: gfx950 reports half of a wide coalesced stream, "
-                      "MI355X_MICROARCH.md HBM section); the decode loop's launches = the last n argmax dispatches; "
+                      "MI355X_MICROARCH.md HBM section); the decode loop's launches = the mb_verify_kernel dispatches; "
                       "algorithmic bytes = draft-carrying rows * V * 2")
-    (out / "pmc_argmax.json").write_text(json.dumps(res, indent=1))
+    (out / "pmc_verify.json").write_text(json.dumps(res, indent=1))
     print(json.dumps(res, indent=1))
 
 
