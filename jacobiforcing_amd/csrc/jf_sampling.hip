@@ -307,7 +307,7 @@ static int64_t rs_chunk(int dtype, int64_t R, int64_t V, int64_t *cpr_out) {
     double best = 1e30;
     for (int64_t pr = 1; pr <= max_pr; ++pr) {
         const double ms = (double)((R * pr + slots - 1) / slots) / (double)pr;
-        if (ms < best * 0.97) { best = ms; per_row = pr; }
+        if (ms < best * 0.90) { best = ms; per_row = pr; }     // a finer split must buy at least 10 %: short items are all overhead
     }
     int64_t chunk = (V + per_row - 1) / per_row;
     chunk = ((chunk + gran - 1) / gran) * gran;
