@@ -21,6 +21,7 @@ struct ArgmaxArgs {
     int chunks_per_row;
     int64_t chunk_elems;
     const int32_t *out_index;      // nullable: row i -> packed[out_index[i]], negative = skip the row unread
+    int32_t reverse;               // 1: items walk the rows last to first (the producer's most recent lines first)
 };
 
 // One (row, chunk) item by a 256-thread workgroup sharing the chunk.  Returns the result slot (orow, -1 = skipped row) to
@@ -31,12 +32,12 @@ __device__ __forceinline__ int64_t argmax_wg_item(const ArgmaxArgs &a, int64_t i
     using E = Elem<DT>;
     constexpr int EPV = E::EPV;
     constexpr int UNROLL = 8;
-    const int64_t row = item / a.chunks_per_row;
+    const int64_t row = a.reverse ? a.R - 1 - item / a.chunks_per_row : item / a.chunks_per_row;
     // slot of this row's result (jf_argmax_scatter): read up front so its latency hides behind the stream; < 0 = padding row
     const int64_t orow = a.out_index ? (int64_t)a.out_index[row] : row;
     if (orow < 0) return -1;
     if (row_owner) *owner = row_owner[(int)orow / owner_div];      // fused launch: whose row this is (latency hides behind the stream)
-    const int c = (int)(item - row * a.chunks_per_row);
+    const int c = (int)(item % a.chunks_per_row);
     const int64_t begin = (int64_t)c * a.chunk_elems;
     int64_t end = begin + a.chunk_elems;
     if (end > a.V) end = a.V;
@@ -97,11 +98,11 @@ __device__ __forceinline__ int64_t argmax_wave_item(const ArgmaxArgs &a, int64_t
     constexpr int UNROLL = 8;
     const int lane = threadIdx.x & 63;
     if (item >= a.R * a.chunks_per_row) return -1;
-    const int64_t row = item / a.chunks_per_row;
+    const int64_t row = a.reverse ? a.R - 1 - item / a.chunks_per_row : item / a.chunks_per_row;
     const int64_t orow = a.out_index ? (int64_t)a.out_index[row] : row;
     if (orow < 0) return -1;
     if (row_owner) *owner = row_owner[(int)orow / owner_div];
-    const int c = (int)(item - row * a.chunks_per_row);
+    const int c = (int)(item % a.chunks_per_row);
     const int64_t begin = (int64_t)c * a.chunk_elems;
     int64_t end = begin + a.chunk_elems;
     if (end > a.V) end = a.V;
@@ -145,7 +146,7 @@ __device__ __forceinline__ int64_t argmax_wave_item(const ArgmaxArgs &a, int64_t
 
 // ---- launch shape (host) ------------------------------------------------------------------------
 struct ArgmaxPlan {
-    bool vec, wave_mode, nt;
+    bool vec, wave_mode, nt, reverse;
     int64_t chunk, cpr, items, blocks;
 };
 int argmax_plan(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, ArgmaxPlan *plan);   // jf_argmax.hip

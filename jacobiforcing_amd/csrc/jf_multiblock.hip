@@ -296,7 +296,7 @@ extern "C" int jf_mb_verify(const void *logits, int dtype, int64_t R, int64_t V,
     lds_ints = (lds_ints + 3) & ~3ll;
     if (lds_ints * 4 > 16 * 1024) lds_ints = 0;
     VerifyArgs a;
-    a.am = ArgmaxArgs{logits, R, V, row_stride, (unsigned long long *)packed, (int)pl.cpr, pl.chunk, out_index};
+    a.am = ArgmaxArgs{logits, R, V, row_stride, (unsigned long long *)packed, (int)pl.cpr, pl.chunk, out_index, pl.reverse ? 1 : 0};
     a.states = states; a.state_ints = state_ints; a.P = P; a.packed_len = packed_len; a.row_prompt = row_prompt;
     a.arrive = arrive; a.desc = desc; a.Tpad = Tpad; a.compacted = out_index ? 1 : 0; a.lds_ints = (int32_t)lds_ints;
     const int64_t blocks = pl.blocks + P;

@@ -297,3 +297,40 @@ def test_block_list_capacity_is_an_error_not_a_corruption(backend):
         inp, st = found
         res = run_calls(ops.MultiblockBatch(1, ops.MultiblockParams(**kw), dev), [m], [m.prompt()], [inp], dev)[0]
         assert res["ret"] == st.ret and res["iters"] == st.iters and res["kv_tokens"] == st.kv_tokens
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_many_prompts_side_by_side(backend):
+    """150 prompts in one batch: 150 stepper workgroups wait for their own rows inside one jf_mb_verify launch (rows of a
+    prompt are spread over many item workgroups), rolling over three calls each, against the oracle prompt by prompt."""
+    P, n, V = 150, 8, 96
+    eos_id, pad_id = V - 1, V - 2
+    rng = np.random.default_rng(123)
+    with use_backend(backend):
+        dev = device_for(backend)
+        models, kvs = [], []
+        for p in range(P):
+            m = ScriptedModel(V, 7000 + p, int(rng.choice([30, 60, 90])), int(rng.integers(3, 12)), eos_id=eos_id,
+                              eos_pos=None, reserved=(pad_id,), period=int(rng.choice([0, 4])))
+            models.append(m)
+            kvs.append(m.prompt())
+        prm = ops.MultiblockParams(n=n, K=2, r=0.5, n_gram_pool_size=4, eos_token_id=eos_id, pad_token_id=pad_id)
+        batch = ops.MultiblockBatch(P, prm, dev)
+        fwd = [(lambda m: (lambda kv_rows, rows: [m.greedy_rows(kv_rows[b], [rows[b]])[0] for b in range(len(rows))]))(m)
+               for m in models]
+        inputs = [O.mb_prefill(fwd[p], kvs[p], [int(x) for x in rng.choice(kvs[p], size=n)])[0] for p in range(P)]
+        okvs = [list(k) for k in kvs]
+        kw = dict(n=n, K=2, r=0.5, lookahead_start_ratio=0.0, n_gram_pool_size=4, eos_token_id=eos_id, pad_token_id=pad_id,
+                  max_iteration_count=128)
+        for call in range(2):
+            want = [O.mb_generation_call(fwd[p], inputs[p], okvs[p], **kw) for p in range(P)]
+            res = run_calls(batch, models, kvs, inputs, dev)
+            nxt = []
+            for p in range(P):
+                st = want[p]
+                assert res[p]["ret"] == st.ret and res[p]["iters"] == st.iters and res[p]["kv_tokens"] == st.kv_tokens, (call, p)
+                okvs[p] = st.kv_tokens
+                kvs[p] = res[p]["kv_tokens"]
+                nt = st.next_token if st.next_token is not None else 0
+                nxt.append([nt] + [int(x) for x in rng.choice(kvs[p], size=n - 1)])
+            inputs = nxt
