@@ -57,13 +57,15 @@ static int64_t pick_chunk(int64_t gran, int64_t R, int64_t V, int64_t target_ite
 // (1024 items, each a long contiguous range with 8 x 16 B per lane in flight: 6.8 TB/s fp32 at R>=512); below ~140 MB the
 // kernel is launch/ramp bound and 4-wave workgroups sharing a chunk (best vector kept in registers, one item per ~64 KB,
 // 256..1024 items) are 5-20 % faster.  Non-temporal loads from 60 MB up, plain loads below.
-int argmax_plan(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, ArgmaxPlan *pl) {
+// Inside the fused verify launch (jf_mb_verify) the 4-wave workgroups win at every size (340 MB in the bench: 69 us against
+// 72.5 us per-wavefront, flat from 512 to 3072 items, profiles/verify_knobs_r02.txt): one arrival per workgroup, not four.
+int argmax_plan(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, bool fused, ArgmaxPlan *pl) {
     const int esz = dtype == JF_F32 ? 4 : 2;
     const int epv = 16 / esz;
     const ArgmaxTune &tn = argmax_tune();
     pl->vec = (((uintptr_t)logits) % 16 == 0) && ((row_stride * esz) % 16 == 0);
     const int64_t bytes = R * V * esz;
-    pl->wave_mode = pl->vec && (tn.wave >= 0 ? tn.wave != 0 : bytes >= (140ll << 20));
+    pl->wave_mode = pl->vec && (tn.wave >= 0 ? tn.wave != 0 : (!fused && bytes >= (140ll << 20)));
     pl->nt = tn.nt >= 0 ? tn.nt != 0 : bytes >= (60ll << 20);
     pl->reverse = tn.reverse > 0;
     if (pl->wave_mode) {
@@ -112,7 +114,7 @@ static int argmax_launch(const void *logits, int dtype, int64_t R, int64_t V, in
         return fail(JF_E_INVALID, "jf_argmax_partial: bad shape R=%lld V=%lld stride=%lld", (long long)R, (long long)V,
                     (long long)row_stride);
     ArgmaxPlan pl;
-    const int rc = argmax_plan(logits, dtype, R, V, row_stride, &pl);
+    const int rc = argmax_plan(logits, dtype, R, V, row_stride, false, &pl);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const ArgmaxArgs a{logits, R, V, row_stride, (unsigned long long *)packed, (int)pl.cpr, pl.chunk, out_index, pl.reverse ? 1 : 0};

@@ -149,6 +149,6 @@ struct ArgmaxPlan {
     bool vec, wave_mode, nt, reverse;
     int64_t chunk, cpr, items, blocks;
 };
-int argmax_plan(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, ArgmaxPlan *plan);   // jf_argmax.hip
+int argmax_plan(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, bool fused, ArgmaxPlan *plan);   // jf_argmax.hip
 
 #endif  // JF_ARGMAX_DEV_H

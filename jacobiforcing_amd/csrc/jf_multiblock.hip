@@ -134,11 +134,17 @@ struct VerifyArgs {
 // experiment build only (tools/verify_trace.py): wall-clock stamps (100 MHz) of the launch — [0] first item start, [1] last
 // item end, then 8 per stepper: start, image copied, rows arrived, tokens gathered, stepped, written back, end
 __device__ unsigned long long g_vtrace[2 + 8 * 256];
+__device__ unsigned long long g_vitems[2 * 8192];       // (start, end) per item workgroup: plain stores, no atomics in the stream
 #define JF_VSTAMP(p, k) do { if (threadIdx.x == 0 && (p) < 256) g_vtrace[2 + 8 * (p) + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 extern "C" __attribute__((visibility("default"))) int jf_exp_read_vtrace(unsigned long long *out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vtrace), sizeof(unsigned long long) * (size_t)n);
 }
+extern "C" __attribute__((visibility("default"))) int jf_exp_read_vitems(unsigned long long *out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vitems), sizeof(unsigned long long) * (size_t)n);
+}
 extern "C" __attribute__((visibility("default"))) int jf_exp_reset_vtrace(void) {
+    static unsigned long long z[2 * 8192];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_vitems), z, sizeof(z));
     static unsigned long long init[2 + 8 * 256];
     for (int i = 0; i < 2 + 8 * 256; ++i) init[i] = 0ull;
     init[0] = ~0ull;
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(AM_TPB) void mb_verify_kernel(VerifyArgs a) {
     if ((int)blockIdx.x < a.P) { verify_stepper(a, blockIdx.x, smem); return; }
     const int64_t blk = (int64_t)blockIdx.x - a.P;
 #ifdef JF_EXP_VERIFY_TRACE
-    if ((threadIdx.x & 63) == 0) atomicMin(&g_vtrace[0], __builtin_amdgcn_s_memrealtime());
+    if (threadIdx.x == 0 && blk < 8192) g_vitems[2 * blk] = __builtin_amdgcn_s_memrealtime();
 #endif
     int owner = -1;                                              // prompt of this item's row: looked up while the row streams
     if constexpr (WAVE) {
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(AM_TPB) void mb_verify_kernel(VerifyArgs a) {
         if (threadIdx.x == 0 && orow >= 0) verify_arrive(a, owner);
     }
 #ifdef JF_EXP_VERIFY_TRACE
-    if ((threadIdx.x & 63) == 0) atomicMax(&g_vtrace[1], __builtin_amdgcn_s_memrealtime());
+    if (threadIdx.x == 0 && blk < 8192) g_vitems[2 * blk + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
@@ -279,7 +285,7 @@ extern "C" int jf_mb_verify(const void *logits, int dtype, int64_t R, int64_t V,
     if (dtype != JF_F32 && dtype != JF_BF16) return fail(JF_E_INVALID, "jf_mb_verify: dtype %d", dtype);
     if (V <= 0 || row_stride < V || V > 0x7FFFFFFFll) return fail(JF_E_INVALID, "jf_mb_verify: bad shape V=%lld stride=%lld", (long long)V, (long long)row_stride);
     ArgmaxPlan pl;
-    rc = argmax_plan(logits, dtype, R, V, row_stride, &pl);
+    rc = argmax_plan(logits, dtype, R, V, row_stride, true, &pl);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     if (!pl.vec) {                                               // unaligned logits: the two-launch path

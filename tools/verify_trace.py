@@ -55,6 +55,15 @@ def run(P, iters, fused, trace_lib=None):
             buf = (C.c_ulonglong * (2 + 8 * 256))()
             trace_lib.jf_exp_read_vtrace(buf, 2 + 8 * 256)
             stamps = np.array(buf[:], dtype=np.uint64)
+            ib = (C.c_ulonglong * (2 * 8192))()
+            trace_lib.jf_exp_read_vitems(ib, 2 * 8192)
+            it_ = np.array(ib[:], dtype=np.uint64).reshape(-1, 2)
+            it_ = it_[it_[:, 0] > 0]
+            stamps[0], stamps[1] = it_[:, 0].min(), it_[:, 1].max()
+            item_us = (it_[:, 1] - it_[:, 0]).astype(np.float64) / 100.0
+            starts = (it_[:, 0] - it_[:, 0].min()).astype(np.float64) / 100.0
+            print(f"      item workgroups {len(it_)}: duration mean {item_us.mean():.1f} us (min {item_us.min():.1f}, max {item_us.max():.1f}); "
+                  f"starts 0..{starts.max():.1f} us (median {np.median(starts):.1f})")
         done = batch.desc_field(d, "done")
         if done.any():                                            # restart finished calls (rolling, like the decoder)
             kv = np.where(done == 1, batch.desc_field(d, "kv_len"), N.JF_MB_KEEP).astype(np.int32)
@@ -87,6 +96,7 @@ def main():
     if hasattr(lib, "jf_exp_read_vtrace"):
         trace_lib = lib
         lib.jf_exp_read_vtrace.argtypes = [C.c_void_p, C.c_int]
+        lib.jf_exp_read_vitems.argtypes = [C.c_void_p, C.c_int]
     for P in a.prompts:
         run(P, a.iters, False)
         run(P, a.iters, True, trace_lib)
