@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Kernel microbench for jf_argmax_partial: GB/s of algorithmic bytes vs R, dtype, chunk size."""
+"""Kernel microbench for jf_argmax_partial: GB/s of algorithmic bytes vs R and dtype, next to the load-only probe.
+
+The library reads its tuning overrides (JF_ARGMAX_CHUNK / ITEMS / WAVE / NT) ONCE per process: sweep them by running this
+script once per setting, e.g.  `for c in 8192 16384 65536; do JF_ARGMAX_CHUNK=$c python tools/microbench_argmax.py; done`."""
 import os
 import sys
 from pathlib import Path
@@ -26,10 +29,6 @@ def probe_lib():
 
 
 def bench(R, dtype, iters=50, chunk=None, probe=False, batch=1):
-    if chunk:
-        os.environ["JF_ARGMAX_CHUNK"] = str(chunk)
-    else:
-        os.environ.pop("JF_ARGMAX_CHUNK", None)
     nbuf = max(1, min(8, int(600e6 // (R * V * (4 if dtype == torch.float32 else 2)))))
     xs = [torch.randn(R, V, device="cuda", dtype=torch.float32).to(dtype) for _ in range(nbuf)]
     packed = ops.new_packed(R, "cuda")
@@ -59,7 +58,8 @@ def bench(R, dtype, iters=50, chunk=None, probe=False, batch=1):
 
 
 if __name__ == "__main__":
-    chunks = [None] + [int(c) for c in sys.argv[1:]]
+    env_chunk = os.environ.get("JF_ARGMAX_CHUNK")
+    chunks = [int(env_chunk) if env_chunk else None]           # the probe uses the same chunk as the kernel under test
     print(f"{'R':>5} {'dtype':>6} {'chunk':>7} {'MB':>8} {'med_us':>8} {'min_us':>8} {'GB/s(med)':>10} {'GB/s(min)':>10}")
     batch = int(os.environ.get("MB_BATCH", "8"))
     Rs = [int(r) for r in os.environ.get("MB_ROWS", "16,32,64,256,512,2048").split(",")]

@@ -1,3 +1,8 @@
+#!/bin/bash
+# The round-2 evidence session: bench line, rocprofv3 kernel stats + trace of the same command, PMC traffic of the verify
+# launch, batch-1 / batch-8 / strong-scaling lines, the drivers, the engine path.  Results under gpurun_out/prof_r02/;
+# the summaries that matter are copied into profiles/ by hand.
+#   gpurun --timeout 4800 -- 'bash tools/profile_session_r02.sh'
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
