@@ -288,7 +288,9 @@ extern "C" int jf_mb_verify(const void *logits, int dtype, int64_t R, int64_t V,
     rc = argmax_plan(logits, dtype, R, V, row_stride, true, &pl);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    if (!pl.vec) {                                               // unaligned logits: the two-launch path
+    // Steppers wait inside the launch, so they must never be able to fill the chip: above 1024 prompts (a quarter of the
+    // resident workgroups the LDS request allows) the convergence check runs as its two launches.  Same for unaligned logits.
+    if (!pl.vec || P > 1024) {
         rc = out_index ? jf_argmax_scatter(logits, dtype, R, V, row_stride, out_index, packed, stream)
                        : jf_argmax_partial(logits, dtype, R, V, row_stride, packed, stream);
         if (rc) return rc;

@@ -303,8 +303,9 @@ def test_block_manager_matches_reference_traces(case):
 
 
 # ------------------------------------------------------------------------------------- statistical criterion of the reference
+@pytest.mark.parametrize("ldt", ["f32", "bf16"])
 @pytest.mark.parametrize("backend", BACKENDS)
-def test_nongreedy_first_token_follows_the_target_distribution(backend):
+def test_nongreedy_first_token_follows_the_target_distribution(backend, ldt):
     """The reference's own acceptance test for the non-greedy decoder is statistical: mean Jensen-Shannon divergence < 0.1
     between Jacobi and autoregressive sampling (inference_engine/tests/test_jacobi_decoding_nongreedy.py).  Rejection
     sampling with a delta proposal is distribution-preserving, so over many independent draws the FIRST committed token must
@@ -318,7 +319,7 @@ def test_nongreedy_first_token_follows_the_target_distribution(backend):
         trials = 3000 if backend == "hostsim" else 1500
         rng = np.random.default_rng(0)
         counts = np.zeros(V)
-        H = Harness(V, dev, torch.float32)
+        H = Harness(V, dev, TORCH_DTYPES[ldt])
         dec = JacobiDecoderNonGreedy(H.bm, forward_step=lambda s, d: H.forward_step_batch([s], d), forward_step_batch=H.forward_step_batch,
                                      eos_token_id=eos, pad_token_id=pad, vocab_size=V, device=torch.device(dev))
         for _ in range(trials):
@@ -330,7 +331,10 @@ def test_nongreedy_first_token_follows_the_target_distribution(backend):
             H.bm.deallocate(seq)
         # the target: softmax of the logits that follow the prompt (the draft row's position 0 sees only the prompt)
         lg = model.logits_rows(model.prompt()[:-1], [[model.prompt()[-1], 0, 0, 0]])[0][0]
-        p = O.softmax_rows_f32(lg[None, :], T)[0].astype(np.float64)
+        if ldt == "bf16":      # the target is the ROUNDED distribution the reference samples from (bf16 probs need not sum to 1)
+            lg = O.bf16_round(lg)
+        p = O.target_probs(lg[None, :], T, ldt)[0].astype(np.float64)
+        p = p / p.sum()
         q = counts / counts.sum()
         mid = 0.5 * (p + q)
         kl = lambda a, b: float(np.sum(np.where(a > 0, a * np.log(a / b), 0.0)))
