@@ -6,6 +6,12 @@
 __device__ unsigned long long g_mb_trace[32];
 #define JF_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_mb_trace[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #endif
+#ifdef JF_EXP_VERIFY_TRACE
+// experiment build only (tools/verify_trace.py): the state machine's phase stamps per stepper workgroup, 16 per prompt
+#include <hip/hip_runtime.h>
+__device__ unsigned long long g_mtrace[16 * 256];
+#define JF_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 256) g_mtrace[16 * blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#endif
 #include "jf_argmax_dev.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -139,6 +145,9 @@ __device__ unsigned long long g_vitems[2 * 8192];       // (start, end) per item
 extern "C" __attribute__((visibility("default"))) int jf_exp_read_vtrace(unsigned long long *out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vtrace), sizeof(unsigned long long) * (size_t)n);
 }
+extern "C" __attribute__((visibility("default"))) int jf_exp_read_mtrace(unsigned long long *out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mtrace), sizeof(unsigned long long) * (size_t)n);
+}
 extern "C" __attribute__((visibility("default"))) int jf_exp_read_vitems(unsigned long long *out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vitems), sizeof(unsigned long long) * (size_t)n);
 }
@@ -195,60 +204,67 @@ __device__ void verify_stepper(const VerifyArgs &a, int p, int32_t *smem) {
     }
     __syncthreads();
     if (use_lds) use_lds = smem[16] != 0;
-    if (threadIdx.x >= 64) return;                               // wavefront 0 is this prompt's state machine
     JF_VSTAMP(p, 1);
-    const int lane = threadIdx.x;
-    int32_t *gtok = img + LC.total;                              // [B, T] greedy tokens (LDS) when use_lds
-    // ---- wait for this prompt's rows ---------------------------------------------------------------
-    const int expected = (a.compacted ? ng : B * (int)tpad) * a.am.chunks_per_row;
-    bool timed_out = false;
-    if (expected > 0) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        unsigned spins = 0;
-        int32_t *word = a.arrive + (int64_t)p * VERIFY_ARRIVE_STRIDE;
-        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
-            __builtin_amdgcn_s_sleep(20);                        // ~0.6 us between polls: pollers must not load the memory system
-            if ((++spins & 255u) == 0u && __builtin_amdgcn_s_memrealtime() - t0 > VERIFY_WAIT_TICKS) { timed_out = true; break; }
-        }
-        if (lane == 0) __hip_atomic_store(word, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-    }
-    JF_VSTAMP(p, 2);
+    // Wavefront 0 is this prompt's state machine.  The other three park at the barrier below (a parked wavefront issues
+    // nothing) and come back for the write-back, which is store-issue bound: 256 lanes instead of 64.
     jf_mb_desc *dg = a.desc ? a.desc + p : nullptr;
-    if (timed_out) {                                             // item workgroups never arrived: report, do not step
-        if (lane == 0) { G[H_ERR] = JF_E_LAUNCH; G[H_DONE] = 1; if (dg) { dg->error = JF_E_LAUNCH; dg->done = 1; dg->B = 0; dg->T = 0; } }
-        return;
-    }
-    const unsigned long long *pk = a.am.packed;
-    const int64_t plen = a.packed_len;
-    auto Gglobal = [pk, base, tpad, plen](int r, int t) -> int {
-        const int64_t idx = (base + r) * tpad + t;
-        return (idx >= 0 && idx < plen) ? decode_packed(ld_agent_u64(pk + idx)) : -1;
-    };
-    bool stepped = false;
-    if (use_lds) {
-        for (int i = lane; i < ng; i += 64) gtok[i] = Gglobal(i / T, i - (i / T) * T);
-        SoloWaveLanes{}.sync();
-        JF_VSTAMP(p, 3);
-        Machine<SoloWaveLanes> m(img, SoloWaveLanes{}, LC);
-        const int32_t *gt = gtok;
-        m.step([gt, T](int r, int t) -> int { return gt[r * T + t]; }, s_desc);
-        SoloWaveLanes{}.sync();
-        JF_VSTAMP(p, 4);
-        if (!s_desc->error) {
-            compact_to_state(SoloWaveLanes{}, img, LC, G, LG);
-            if (dg && lane < (int)(sizeof(jf_mb_desc) / 4)) ((int32_t *)dg)[lane] = ((const int32_t *)s_desc)[lane];
-            stepped = true;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        int32_t *gtok = img + LC.total;                          // [B, T] greedy tokens (LDS) when use_lds
+        // ---- wait for this prompt's rows -----------------------------------------------------------
+        const int expected = (a.compacted ? ng : B * (int)tpad) * a.am.chunks_per_row;
+        bool timed_out = false;
+        if (expected > 0) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            unsigned spins = 0;
+            int32_t *word = a.arrive + (int64_t)p * VERIFY_ARRIVE_STRIDE;
+            while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
+                __builtin_amdgcn_s_sleep(20);                    // ~0.6 us between polls: pollers must not load the memory system
+                if ((++spins & 255u) == 0u && __builtin_amdgcn_s_memrealtime() - t0 > VERIFY_WAIT_TICKS) { timed_out = true; break; }
+            }
+            if (lane == 0) __hip_atomic_store(word, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
         }
-        JF_VSTAMP(p, 5);
+        JF_VSTAMP(p, 2);
+        int wb = 0;                                              // 1: stepped on the image, all four wavefronts write it back
+        if (timed_out) {                                         // item workgroups never arrived: report, do not step
+            if (lane == 0) { G[H_ERR] = JF_E_LAUNCH; G[H_DONE] = 1; if (dg) { dg->error = JF_E_LAUNCH; dg->done = 1; dg->B = 0; dg->T = 0; } }
+            wb = -1;
+        } else {
+            const unsigned long long *pk = a.am.packed;
+            const int64_t plen = a.packed_len;
+            auto Gglobal = [pk, base, tpad, plen](int r, int t) -> int {
+                const int64_t idx = (base + r) * tpad + t;
+                return (idx >= 0 && idx < plen) ? decode_packed(ld_agent_u64(pk + idx)) : -1;
+            };
+            if (use_lds) {
+                for (int i = lane; i < ng; i += 64) gtok[i] = Gglobal(i / T, i - (i / T) * T);
+                SoloWaveLanes{}.sync();
+                JF_VSTAMP(p, 3);
+                Machine<SoloWaveLanes> m(img, SoloWaveLanes{}, LC);
+                const int32_t *gt = gtok;
+                m.step([gt, T](int r, int t) -> int { return gt[r * T + t]; }, s_desc);
+                SoloWaveLanes{}.sync();
+                JF_VSTAMP(p, 4);
+                if (!s_desc->error) wb = 1;
+            }
+            if (!wb) {                                           // step on the HBM block (capacities the parameters ask for)
+                Machine<SoloWaveLanes> m(G, SoloWaveLanes{}, LG);
+                m.step(Gglobal, dg);
+            }
+        }
+        if (lane == 0) smem[17] = wb;
     }
-    if (!stepped) {                                              // step on the HBM block (capacities the parameters ask for)
-        Machine<SoloWaveLanes> m(G, SoloWaveLanes{}, LG);
-        m.step(Gglobal, dg);
+    __syncthreads();
+    const int wb = smem[17];
+    if (wb < 0) return;
+    if (wb > 0) {
+        compact_to_state(Lanes256{}, img, LC, G, LG);
+        if (dg && threadIdx.x < (int)(sizeof(jf_mb_desc) / 4)) ((int32_t *)dg)[threadIdx.x] = ((const int32_t *)s_desc)[threadIdx.x];
     }
+    JF_VSTAMP(p, 5);
     // re-zero this prompt's slice of the argmax workspace for the next launch
-    SoloWaveLanes{}.sync();
     const int64_t lo = base * tpad, hi = (base + B) * tpad;
-    for (int64_t i = lo + lane; i < hi && i < plen; i += 64) a.am.packed[i] = 0ull;
+    for (int64_t i = lo + threadIdx.x; i < hi && i < a.packed_len; i += AM_TPB) a.am.packed[i] = 0ull;
     JF_VSTAMP(p, 6);
 }
 

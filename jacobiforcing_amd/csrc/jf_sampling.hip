@@ -670,14 +670,16 @@ __device__ int rs_final_pick(const RsRow &row, const double *segsum, int64_t pro
 // ------------------------------------------------------------------------------------------------
 // Accept/reject of every row of a batch (JDN:581-639).  The reference visits the rows in order and draws torch.rand /
 // torch.multinomial / torch.randint as it goes, so the position of every draw in the injected streams depends on the rows
-// before it.  Five launches keep that order exact while everything wide runs in parallel:
+// before it.  Four launches keep that order exact while everything wide runs in parallel:
 //   rs_accept_kernel  (1 workgroup)   p_draft / uniforms staged in LDS by 256 threads, then ONE wavefront walks the rows:
 //                                     a row's L-1 accept tests are one ballot, so the serial chain is B steps of LDS
 //                                     latency, not B*(L-1); results are written out by all threads afterwards
 //   rs_rowsum_kernel  (B * RS_SEG)    float64 segment sums of every rejected row + the proposed token's CDF interval
-//   rs_chain_kernel   (1 workgroup)   bonus-stream positions in row order: per rejected row one ballot over <= 16 staged
-//                                     uniforms against the interval gives its number of draws and the uniform that counts
-//   rs_bonus_kernel   (B workgroups)  ONE inverse-CDF walk per rejected row (or the masked argmax)
+//   rs_bonus_kernel   (B workgroups)  bonus-stream positions in row order — per rejected row one ballot over <= 16 staged
+//                                     uniforms against the interval gives its number of draws and the uniform that counts;
+//                                     every workgroup walks the rows up to its own (LDS only) — then ONE inverse-CDF walk
+//                                     for its row (or the masked argmax).  Batches over 512 rows: rs_chain_kernel does the
+//                                     walk once, in its own launch.
 //   rs_finish_kernel  (1 workgroup)   EOS, next drafts, pads, cursors by parallel scans; packed re-zeroed
 // ------------------------------------------------------------------------------------------------
 // strided loop whose loads are issued UNR at a time before the first value is used: the small single-workgroup kernels of
@@ -852,18 +854,60 @@ __global__ __launch_bounds__(256) void rs_chain_kernel(int B, int64_t V, int epv
             if (s_tot[b] >= 0.0) { rows[b].n_bonus_draws = s_draws[b]; w.pick_u[b] = s_uf[b]; }
 }
 
-template <int DT>
+// CHAIN: the workgroup first walks the bonus stream itself, over the rejected rows up to and including its own (intervals
+// in parallel, then one wavefront, LDS only) — every workgroup repeats the rows before it, which costs less than a separate
+// single-workgroup launch between rs_rowsum and this one (batches up to RS_BONUS_CHAIN_ROWS rows with a staged window;
+// larger ones run rs_chain_kernel first and come here with CHAIN = false).
+constexpr int RS_BONUS_CHAIN_ROWS = 512;
+template <int DT, bool CHAIN>
 __global__ __launch_bounds__(256) void rs_bonus_kernel(const void *logits, int64_t V, int64_t row_stride, const int64_t *draft, int L,
                                                         const float *row_max, const float *row_sumexp, float temp,
+                                                        const float *b_stream, int64_t b_len, const int64_t *b_cursor,
                                                         int64_t *committed, jf_rs_row *rows, RsWs w) {
     __shared__ RsPickShared sh;
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x;
     const int rej = rows[b].reject_pos;
     if (rej < 0) return;
+    float u_final;
+    if constexpr (CHAIN) {
+        __shared__ double s_tot[RS_BONUS_CHAIN_ROWS], s_lo[RS_BONUS_CHAIN_ROWS], s_hi[RS_BONUS_CHAIN_ROWS];   // s_tot < 0: not rejected
+        __shared__ float s_u[RS_MAX_TRIES * RS_BONUS_CHAIN_ROWS / 2];
+        __shared__ float s_uf;
+        __shared__ int s_dr;
+        const int64_t bc0 = *b_cursor;
+        const int win = RS_MAX_TRIES * (rows[b].rsv + 1);                  // rsv = rejected rows in front of this one (rs_accept)
+        const bool staged = win <= RS_MAX_TRIES * RS_BONUS_CHAIN_ROWS / 2 && b_len < 0x7FFFFFFFll;
+        for (int i = tid; i <= b; i += 256) {
+            double t_ = -1.0, lo_ = 0.0, hi_ = 0.0;
+            if (rows[i].reject_pos >= 0) rs_interval(w, i, V, Elem<DT>::EPV, t_, lo_, hi_);
+            s_tot[i] = t_; s_lo[i] = lo_; s_hi[i] = hi_;
+        }
+        if (staged) {
+            const int bl = (int)b_len, bb = (int)(bc0 % b_len);
+            batched_for<8, float>(win, tid, 256, [&](int64_t i) { return b_stream[(bb + (int)i) % bl]; }, [&](int64_t i, float v) { s_u[i] = v; });
+        }
+        __syncthreads();
+        if (tid < 64) {
+            int off = 0, draws = 0;
+            float uf = -1.f;
+            for (int i = 0; i <= b; ++i) {
+                const double t_ = s_tot[i];
+                if (t_ < 0.0) continue;
+                const int o = off;
+                draws = rs_count_draws([&](int tr) { return staged ? s_u[o + tr] : b_stream[(bc0 + o + tr) % b_len]; }, t_, s_lo[i], s_hi[i], tid, &uf);
+                off += draws;
+            }
+            if (tid == 0) { s_uf = uf; s_dr = draws; rows[b].n_bonus_draws = draws; }
+        }
+        __syncthreads();
+        u_final = s_uf;
+    } else {
+        u_final = w.pick_u[b];
+    }
     const int64_t r = (int64_t)b * (L - 1) + rej;
     const RsRow row = rs_make_row<DT>(logits, r, V, row_stride, temp, row_max[r], row_sumexp[r]);
-    const int bonus = rs_final_pick<DT>(row, w.segsum + (int64_t)b * RS_SEG, draft[(int64_t)b * L + rej + 1], w.pick_u[b], sh);
-    if (threadIdx.x == 0) committed[(int64_t)b * L + rows[b].n_committed] = bonus;
+    const int bonus = rs_final_pick<DT>(row, w.segsum + (int64_t)b * RS_SEG, draft[(int64_t)b * L + rej + 1], u_final, sh);
+    if (tid == 0) committed[(int64_t)b * L + rows[b].n_committed] = bonus;
 }
 
 // exclusive prefix sum over consecutive lanes of one wavefront; *total = sum over all 64 lanes
@@ -1118,15 +1162,18 @@ extern "C" int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_
         rs_accept_kernel<true><<<1, 256, 0, s>>>(draft, B, L, p_draft, eos_id, u_stream, u_len, u_cursor, committed, rows, w);
     else
         rs_accept_kernel<false><<<1, 256, 0, s>>>(draft, B, L, p_draft, eos_id, u_stream, u_len, u_cursor, committed, rows, w);
+    const bool chain_in_bonus = B <= RS_BONUS_CHAIN_ROWS;
+#define JF_RS_BONUS(DT, CH) rs_bonus_kernel<DT, CH><<<B, 256, 0, s>>>(logits, V, row_stride, draft, L, row_max, row_sumexp, t, bonus_stream, bonus_len, bonus_cursor, committed, rows, w)
     if (dtype == JF_F32) {
         rs_rowsum_kernel<JF_F32><<<B * RS_SEG, 256, 0, s>>>(logits, V, row_stride, row_max, row_sumexp, t, w);
-        rs_chain_kernel<<<1, 256, 0, s>>>(B, V, 4, bonus_stream, bonus_len, bonus_cursor, rows, w);
-        rs_bonus_kernel<JF_F32><<<B, 256, 0, s>>>(logits, V, row_stride, draft, L, row_max, row_sumexp, t, committed, rows, w);
+        if (chain_in_bonus) JF_RS_BONUS(JF_F32, true);
+        else { rs_chain_kernel<<<1, 256, 0, s>>>(B, V, 4, bonus_stream, bonus_len, bonus_cursor, rows, w); JF_RS_BONUS(JF_F32, false); }
     } else {
         rs_rowsum_kernel<JF_BF16><<<B * RS_SEG, 256, 0, s>>>(logits, V, row_stride, row_max, row_sumexp, t, w);
-        rs_chain_kernel<<<1, 256, 0, s>>>(B, V, 8, bonus_stream, bonus_len, bonus_cursor, rows, w);
-        rs_bonus_kernel<JF_BF16><<<B, 256, 0, s>>>(logits, V, row_stride, draft, L, row_max, row_sumexp, t, committed, rows, w);
+        if (chain_in_bonus) JF_RS_BONUS(JF_BF16, true);
+        else { rs_chain_kernel<<<1, 256, 0, s>>>(B, V, 8, bonus_stream, bonus_len, bonus_cursor, rows, w); JF_RS_BONUS(JF_BF16, false); }
     }
+#undef JF_RS_BONUS
     rs_finish_kernel<<<1, 256, 0, s>>>(B, L, pk, eos_id, remaining, u_cursor, bonus_cursor, pad_stream, pad_len, pad_cursor, committed, next_draft, rows);
     return check_launch("rs_step kernels");
 }

@@ -34,6 +34,7 @@ def run(P, iters, fused, trace_lib=None):
     d = batch.begin(ids, torch.full((P,), 200, dtype=torch.int32))
     times, rows_l = [], []
     stamps = None
+    mstamps = None
     for it in range(iters):
         pk = batch.pack(d, t_align=8, compact=True, valid_align=8 * P)
         if pk is None:
@@ -55,6 +56,10 @@ def run(P, iters, fused, trace_lib=None):
             buf = (C.c_ulonglong * (2 + 8 * 256))()
             trace_lib.jf_exp_read_vtrace(buf, 2 + 8 * 256)
             stamps = np.array(buf[:], dtype=np.uint64)
+            if hasattr(trace_lib, "jf_exp_read_mtrace"):
+                mb_ = (C.c_ulonglong * (16 * 256))()
+                trace_lib.jf_exp_read_mtrace(mb_, 16 * 256)
+                mstamps = np.array(mb_[:], dtype=np.uint64).reshape(256, 16)
             ib = (C.c_ulonglong * (2 * 8192))()
             trace_lib.jf_exp_read_vitems(ib, 2 * 8192)
             it_ = np.array(ib[:], dtype=np.uint64).reshape(-1, 2)
@@ -81,6 +86,13 @@ def run(P, iters, fused, trace_lib=None):
             s = stamps[2 + 8 * p: 2 + 8 * p + 7]
             print(f"      stepper {p:3d}: start {rel(s[0]):6.1f}  image {rel(s[1]):6.1f}  arrived {rel(s[2]):6.1f}  gathered {rel(s[3]):6.1f}  "
                   f"stepped {rel(s[4]):6.1f}  written {rel(s[5]):6.1f}  end {rel(s[6]):6.1f}")
+        if mstamps is not None:                                     # state machine phases of the last stepper (last visit of each stamp)
+            names = {1: "scalars", 2: "accept-scan", 3: "commit", 4: "re-draft", 5: "pool-push", 6: "candidates", 7: "spans-done",
+                     8: "spawn/promote", 9: "early-stop", 10: "build_out", 11: "scalars-stored"}
+            q = P - 1
+            row = [(rel(mstamps[q, k]), names[k]) for k in names if mstamps[q, k] >= stamps[2 + 8 * q + 3]]
+            row.sort()
+            print("      machine of stepper %d: " % q + "  ".join(f"{nm} {t:.2f}" for t, nm in row))
         ends = np.array([rel(stamps[2 + 8 * p + 6]) for p in range(P)])
         arr = np.array([rel(stamps[2 + 8 * p + 2]) for p in range(P)])
         print(f"      all steppers: arrived {arr.min():.1f}..{arr.max():.1f} us, end {ends.min():.1f}..{ends.max():.1f} us")
@@ -97,6 +109,8 @@ def main():
         trace_lib = lib
         lib.jf_exp_read_vtrace.argtypes = [C.c_void_p, C.c_int]
         lib.jf_exp_read_vitems.argtypes = [C.c_void_p, C.c_int]
+        if hasattr(lib, "jf_exp_read_mtrace"):
+            lib.jf_exp_read_mtrace.argtypes = [C.c_void_p, C.c_int]
     for P in a.prompts:
         run(P, a.iters, False)
         run(P, a.iters, True, trace_lib)
