@@ -161,8 +161,10 @@ __device__ __forceinline__ int32_t hmin_i16x2(uint32_t a) {
     return lo < hi ? lo : hi;
 }
 
-template <int DT, bool KEEPV> struct FastTrack;
-template <bool KEEPV> struct FastTrack<JF_F32, KEEPV> {
+// KEEPV: the best vector stays in registers (no end-of-item reload; 4 selects per vector).  MINT: the running minimum that
+// catches negative NaNs — a consumer that also sums exp() of every element sees those in its sum and passes false.
+template <int DT, bool KEEPV, bool MINT = true> struct FastTrack;
+template <bool KEEPV, bool MINT> struct FastTrack<JF_F32, KEEPV, MINT> {
     int32_t best = INT32_MIN, mn = INT32_MAX;
     uint32_t bvec = 0xFFFFFFFFu;
     u32x4 bv = {0u, 0u, 0u, 0u};     // KEEPV: the best vector itself (saves the end-of-item reload, costs 4 selects per vector)
@@ -170,7 +172,7 @@ template <bool KEEPV> struct FastTrack<JF_F32, KEEPV> {
     __device__ __forceinline__ int32_t consume_ret(const u32x4 v, uint32_t i) {
         const int32_t k0 = skey32(v.x), k1 = skey32(v.y), k2 = skey32(v.z), k3 = skey32(v.w);
         int32_t m = max(max(k0, k1), max(k2, k3));
-        mn = min(mn, min(min(k0, k1), min(k2, k3)));
+        if constexpr (MINT) mn = min(mn, min(min(k0, k1), min(k2, k3)));
         m = (m == -1) ? 0 : m;
         if constexpr (KEEPV) { if (m > best) { best = m; bvec = i; bv = v; } }
         else { if (m > best) { best = m; bvec = i; } }
@@ -190,7 +192,7 @@ template <bool KEEPV> struct FastTrack<JF_F32, KEEPV> {
     }
     __device__ __forceinline__ uint32_t ukey() const { return (uint32_t)best ^ 0x80000000u; }   // == order_key()
 };
-template <bool KEEPV> struct FastTrack<JF_BF16, KEEPV> {
+template <bool KEEPV, bool MINT> struct FastTrack<JF_BF16, KEEPV, MINT> {
     int32_t best = INT32_MIN;
     uint32_t mnp = 0x7FFF7FFFu;     // packed running min
     uint32_t bvec = 0xFFFFFFFFu;
@@ -198,7 +200,7 @@ template <bool KEEPV> struct FastTrack<JF_BF16, KEEPV> {
     __device__ __forceinline__ int32_t consume_ret(const u32x4 v, uint32_t i) {
         const uint32_t k0 = skey16x2(v.x), k1 = skey16x2(v.y), k2 = skey16x2(v.z), k3 = skey16x2(v.w);
         const uint32_t pm = pk_max_i16(pk_max_i16(k0, k1), pk_max_i16(k2, k3));
-        mnp = pk_min_i16(mnp, pk_min_i16(pk_min_i16(k0, k1), pk_min_i16(k2, k3)));
+        if constexpr (MINT) mnp = pk_min_i16(mnp, pk_min_i16(pk_min_i16(k0, k1), pk_min_i16(k2, k3)));
         int32_t m = hmax_i16x2(pm);
         m = (m == -1) ? 0 : m;
         if constexpr (KEEPV) { if (m > best) { best = m; bvec = i; bv = v; } }

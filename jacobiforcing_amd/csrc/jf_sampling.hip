@@ -109,6 +109,17 @@ __device__ __forceinline__ float scale_bf16_fast(float x, float inv_t) {
     return __uint_as_float((q + 0x7FFFu + ((q >> 16) & 1u)) & 0xFFFF0000u);   // RNE (inf stays inf; NaN stays NaN-ish)
 }
 
+// two at a time: gfx950's v_cvt_pk_bf16_f32 is the same RNE for every non-NaN fp32 pattern (walked exhaustively,
+// tools/experiments/cvt_bf16_exhaustive.hip) — one multiply (v_pk_mul_f32), one conversion and two unpacks for two elements
+typedef __bf16 rs_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float rs_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void scale_bf16_fast2(float &a, float &b, float inv_t) {
+    const rs_f32x2 v = {a * inv_t, b * inv_t};
+    const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rs_bf16x2));
+    a = __uint_as_float(h << 16);
+    b = __uint_as_float(h & 0xFFFF0000u);
+}
+
 template <int DT> __device__ __forceinline__ float key_max_to_float(int32_t k);
 template <> __device__ __forceinline__ float key_max_to_float<JF_F32>(int32_t k) {
     return __uint_as_float((uint32_t)k ^ (((uint32_t)(k >> 31)) & 0x7FFFFFFFu));
@@ -137,7 +148,7 @@ __device__ __forceinline__ void rs_round(const u32x4 (&vv)[NV], FT &ft, uint32_t
     float xmax = key_max_to_float<DT>(kmax);                 // the round's largest raw value (NaN if the round holds one)
     if constexpr (SCALE == 2) {
 #pragma unroll
-        for (int j = 0; j < NE; ++j) x[j] = scale_bf16_fast(x[j], inv_t);
+        for (int j = 0; j < NE; j += 2) scale_bf16_fast2(x[j], x[j + 1], inv_t);
         xmax = scale_bf16_fast(xmax, inv_t);
     } else if constexpr (SCALE == 3) {
 #pragma unroll
@@ -147,11 +158,26 @@ __device__ __forceinline__ void rs_round(const u32x4 (&vv)[NV], FT &ft, uint32_t
     const float mr = xmax * cs;                              // monotone: the round's largest scaled value
     const float mn = fmaxf(m, mr);
     if (mn == -INFINITY) return;                             // nothing finite yet: keep (m, s) = (-inf, 0), never form inf - inf
-    float acc = (m == -INFINITY) ? 0.f : s * __builtin_amdgcn_exp2f(m - mn);
-    const float nm = -mn;
+    // two elements per v_pk_fma_f32 / v_pk_add_f32 (packed fp32 runs at full rate per element pair): two partial sums
+    // (four independent chains: a dependent v_pk_add_f32 per pair would leave the adder waiting on itself)
+    constexpr int NACC = NE >= 8 ? 4 : (NE >= 4 ? 2 : 1);
+    rs_f32x2 acc[NACC];
 #pragma unroll
-    for (int j = 0; j < NE; ++j) acc += __builtin_amdgcn_exp2f(fmaf(x[j], cs, nm));
-    s = acc;
+    for (int q = 0; q < NACC; ++q) acc[q] = rs_f32x2{0.f, 0.f};
+    acc[0].x = (m == -INFINITY) ? 0.f : s * __builtin_amdgcn_exp2f(m - mn);
+    const rs_f32x2 cs2 = {cs, cs}, nm2 = {-mn, -mn};
+#pragma unroll
+    for (int j = 0; j < NE; j += 2) {
+        const rs_f32x2 xx = {x[j], x[j + 1]};
+        const rs_f32x2 a = __builtin_elementwise_fma(xx, cs2, nm2);
+        const rs_f32x2 e = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+        acc[(j >> 1) % NACC] += e;
+    }
+#pragma unroll
+    for (int q = NACC >> 1; q > 0; q >>= 1)
+#pragma unroll
+        for (int r = 0; r < q; ++r) acc[r] += acc[r + q];
+    s = acc[0].x + acc[0].y;
     m = mn;
 }
 
@@ -182,7 +208,9 @@ __global__ __launch_bounds__(256) void rs_probs_partial_kernel(const void *logit
         const int nvec = (int)((end - begin) / EPV);
         const u32x4 *q = (const u32x4 *)p + (begin / EPV) + tid;
         const uint32_t ebase = (uint32_t)begin;
-        FastTrack<DT, true> ft;                          // same vector-granular argmax tracker as the greedy kernel
+        // the greedy kernel's vector-granular argmax tracker, trimmed for a VALU-bound loop: the best vector is re-read at
+        // the end instead of carried, and negative NaNs are seen by the sum (s turns NaN) instead of a running minimum
+        FastTrack<DT, false, false> ft;
         int k = tid;
         for (; k + 7 * 256 < nvec; k += 8 * 256, q += 8 * 256) {
             const u32x4 va[4] = {JF_LOAD(q), JF_LOAD(q + 256), JF_LOAD(q + 512), JF_LOAD(q + 768)};
@@ -200,8 +228,8 @@ __global__ __launch_bounds__(256) void rs_probs_partial_kernel(const void *logit
             rs_round<DT, SCALE, 1>(vv, ft, ebase + (uint32_t)k * EPV, 0u, cs, t, inv_t, m, s);
         }
         done = begin + (int64_t)nvec * EPV;
-        if (__syncthreads_or(ft.saw_nan() ? 1 : 0)) {
-            scan_exact<DT>(p, begin, done, tid, best, bidx);               // NaN in the chunk: exact key rescan
+        if (__syncthreads_or((ft.saw_nan() || s != s) ? 1 : 0)) {
+            scan_exact<DT>(p, begin, done, tid, best, bidx);               // NaN (or inf - inf) in the chunk: exact key rescan
         } else if (ft.bvec != 0xFFFFFFFFu) {
             best = ft.ukey();
             bidx = ft.resolve(p);

@@ -279,14 +279,9 @@ def test_kv_commit_copies_candidate_rows():
         assert torch.equal(mk[l], ref_k[l]) and torch.equal(mv[l], ref_v[l])
 
 
-@GPU
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-def test_argmax_special_values_vector_path(dtype):
-    """-NaN / +NaN with payloads, -0.0 vs +0.0 ties, all-negative and all -inf rows on the 16-byte vector path
-    (V multiple of 8, several chunks) against torch.argmax on the CPU."""
-    V = 40960
+def _special_value_rows(dtype, V=40960):
+    """Rows with -NaN / +NaN payloads, -0.0 vs +0.0 ties, all-negative and all -inf rows, ties across a chunk edge, +inf."""
     g = torch.Generator().manual_seed(9)
-    rows = []
 
     def base(neg=False):
         x = torch.randn(V, generator=g)
@@ -310,7 +305,16 @@ def test_argmax_special_values_vector_path(dtype):
     x = torch.full((V,), -float("inf")).to(dtype); x[V - 1] = -3.0e38; cases.append(x)                # last element
     x = base().to(dtype); x[8191] = 50.0; x[8192] = 50.0; cases.append(x)                             # tie across chunk edge
     x = base().to(dtype); x[3] = float("inf"); x[V - 3] = float("inf"); cases.append(x)
-    X = torch.stack(cases)
+    return torch.stack(cases)
+
+
+@GPU
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_argmax_special_values_vector_path(dtype):
+    """-NaN / +NaN with payloads, -0.0 vs +0.0 ties, all-negative and all -inf rows on the 16-byte vector path
+    (V multiple of 8, several chunks) against torch.argmax on the CPU."""
+    V = 40960
+    X = _special_value_rows(dtype, V)
     ref = torch.argmax(X.float(), dim=-1)
     got = ops.argmax_rows(X.cuda()).cpu()
     assert got.tolist() == ref.tolist()
@@ -332,6 +336,22 @@ def _run_rs_probs(x, dn, temperature):
                                 ops._ptr(m), ops._ptr(s), ops._ptr(packed), ops._ptr(ws), ws.numel() * 4, ops._stream(xd.device)))
     del st
     return p.cpu(), m.cpu(), s.cpu(), (~packed.cpu()) & 0xFFFFFFFF
+
+
+@GPU
+@pytest.mark.parametrize("temperature", [1.0, 0.7])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_rs_probs_argmax_special_values(dtype, temperature):
+    """The greedy token jf_rs_probs records next to the probabilities follows torch.argmax on the same corner cases as the
+    argmax kernel (its NaN detection is different: a negative NaN is seen by the exp sum, not by a running minimum), and the
+    gathered probability is NaN exactly where torch's softmax is."""
+    X = _special_value_rows(dtype)
+    X[8, -1] = -3.0e4                 # the kernel forms exp2(fma(x, log2(e)/T, -max)): exact up to |x| ~ 5e8, not at 3e38 (DESIGN §7)
+    dn = torch.full((X.shape[0],), 17, dtype=torch.int64)
+    p, m, s, greedy = _run_rs_probs(X, dn, temperature)
+    assert greedy.tolist() == torch.argmax(X.float(), dim=-1).tolist()
+    ref = torch.softmax(X.float() / temperature, dim=-1)[:, 17]
+    assert torch.isnan(p).tolist() == torch.isnan(ref).tolist()
 
 
 @GPU
