@@ -113,6 +113,75 @@ __global__ __launch_bounds__(256) void rope_kv_append_kernel(const T *__restrict
     }
 }
 
+// The same arithmetic with 16-byte accesses: one lane rotates EPV consecutive pairs (x1[i], x2[i]) of one (token, head) —
+// two 16-byte loads from the fused QKV row, the cos/sin entries as float4s, two 16-byte stores per destination.  D = 128 bf16:
+// 8 lanes per head, a wavefront covers 8 heads of a token (2 KB contiguous in, 256-byte rows out).
+template <typename T, int EPV>
+__global__ __launch_bounds__(256) void rope_kv_append_vec_kernel(const T *__restrict__ qkv, int64_t N, int Tlen, int nq, int nkv, int D,
+                                                                  const int32_t *__restrict__ positions,
+                                                                  const float *__restrict__ cos_t, const float *__restrict__ sin_t,
+                                                                  T *__restrict__ q_out, T *__restrict__ k_cache,
+                                                                  T *__restrict__ v_cache, const int64_t *__restrict__ slot_main,
+                                                                  int64_t S_max, T *__restrict__ k_cand, T *__restrict__ v_cand,
+                                                                  const int64_t *__restrict__ slot_cand, int64_t T_max) {
+    const int half = D >> 1;
+    const int lph = half / EPV;                               // lanes per head
+    const int heads = nq + 2 * nkv;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= N * heads * lph) return;
+    const int i0 = (int)(gid % lph) * EPV;
+    const int64_t th = gid / lph;
+    const int h = (int)(th % heads);
+    const int64_t tok = th / heads;
+    const T *src = qkv + (tok * heads + h) * D;
+    T a[EPV], b[EPV], oa[EPV], ob[EPV];
+    *reinterpret_cast<uint4 *>(a) = *reinterpret_cast<const uint4 *>(src + i0);
+    *reinterpret_cast<uint4 *>(b) = *reinterpret_cast<const uint4 *>(src + half + i0);
+    if (h < nq + nkv) {                                       // rotate q and k heads, v passes through
+        const int64_t pos = positions[tok];
+        float c[EPV], sn[EPV];
+#pragma unroll
+        for (int j = 0; j < EPV; j += 4) {
+            *reinterpret_cast<float4 *>(c + j) = *reinterpret_cast<const float4 *>(cos_t + pos * half + i0 + j);
+            *reinterpret_cast<float4 *>(sn + j) = *reinterpret_cast<const float4 *>(sin_t + pos * half + i0 + j);
+        }
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+            const float x1 = ld_f(a + j), x2 = ld_f(b + j);
+            st_f(oa + j, x1 * c[j] - x2 * sn[j]);
+            st_f(ob + j, x2 * c[j] + x1 * sn[j]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) { oa[j] = a[j]; ob[j] = b[j]; }
+    }
+    auto put = [&](T *dst) {
+        *reinterpret_cast<uint4 *>(dst + i0) = *reinterpret_cast<const uint4 *>(oa);
+        *reinterpret_cast<uint4 *>(dst + half + i0) = *reinterpret_cast<const uint4 *>(ob);
+    };
+    if (h < nq) {
+        const int G = nq / nkv;
+        const int kvh = h / G, g = h - kvh * G;
+        const int64_t r = tok / Tlen, t = tok - r * Tlen;
+        put(q_out + (((r * nkv + kvh) * (int64_t)G * Tlen) + (int64_t)g * Tlen + t) * D);
+        return;
+    }
+    const bool is_v = h >= nq + nkv;
+    const int kvh = is_v ? h - nq - nkv : h - nq;
+    const int64_t sm = slot_main[tok];
+    if (sm >= 0) {
+        const int64_t brow = sm / S_max, pos = sm - brow * S_max;
+        put((is_v ? v_cache : k_cache) + ((brow * nkv + kvh) * S_max + pos) * D);
+    }
+    if (slot_cand) {
+        const int64_t sc = slot_cand[tok];
+        if (sc >= 0) {
+            const int64_t brow = sc / T_max, pos = sc - brow * T_max;
+            put((is_v ? v_cand : k_cand) + ((brow * nkv + kvh) * T_max + pos) * D);
+        }
+    }
+}
+
 extern "C" int jf_rope_kv_append(const void *qkv, int dtype, int64_t N, int32_t T, int32_t nq, int32_t nkv, int32_t D,
                                  const int32_t *positions, const float *cos_table, const float *sin_table, void *q_out,
                                  void *k_cache, void *v_cache, const int64_t *slot_main, int64_t S_max, void *k_cand,
@@ -123,9 +192,29 @@ extern "C" int jf_rope_kv_append(const void *qkv, int dtype, int64_t N, int32_t 
     if (T <= 0 || N % T != 0 || nq <= 0 || nkv <= 0 || nq % nkv != 0 || D <= 0 || (D & 1) || S_max <= 0)
         return fail(JF_E_INVALID, "jf_rope_kv_append: bad shape N=%lld T=%d nq=%d nkv=%d D=%d", (long long)N, T, nq, nkv, D);
     if (slot_cand && (!k_cand || !v_cand || T_max <= 0)) return fail(JF_E_INVALID, "jf_rope_kv_append: candidate cache missing");
+    hipStream_t s = (hipStream_t)stream;
+    // 16-byte path: every row start (QKV rows, q_out, caches) and the table rows are 16-byte aligned
+    const int esz = dtype == JF_F32 ? 4 : 2, epv = 16 / esz;
+    auto al16 = [](const void *p) { return ((uintptr_t)p) % 16 == 0; };
+    static const bool force_scalar = [] { const char *e = getenv("JF_ROPE_SCALAR"); return e && *e == '1'; }();   // A/B in tools/
+    const bool vec = !force_scalar && (dtype == JF_F32 || dtype == JF_BF16) && (D / 2) % epv == 0 && (D / 2) % 4 == 0 && al16(qkv) && al16(q_out) &&
+                     al16(k_cache) && al16(v_cache) && al16(cos_table) && al16(sin_table) && (!slot_cand || (al16(k_cand) && al16(v_cand)));
+    if (vec) {
+        const int64_t total = N * (nq + 2 * nkv) * ((D / 2) / epv);
+        const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+        if (dtype == JF_F32)
+            rope_kv_append_vec_kernel<float, 4><<<grid, block, 0, s>>>((const float *)qkv, N, T, nq, nkv, D, positions, cos_table, sin_table,
+                                                                      (float *)q_out, (float *)k_cache, (float *)v_cache, slot_main, S_max,
+                                                                      (float *)k_cand, (float *)v_cand, slot_cand, T_max);
+        else
+            rope_kv_append_vec_kernel<uint16_t, 8><<<grid, block, 0, s>>>((const uint16_t *)qkv, N, T, nq, nkv, D, positions, cos_table,
+                                                                         sin_table, (uint16_t *)q_out, (uint16_t *)k_cache,
+                                                                         (uint16_t *)v_cache, slot_main, S_max, (uint16_t *)k_cand,
+                                                                         (uint16_t *)v_cand, slot_cand, T_max);
+        return check_launch("rope_kv_append_vec_kernel");
+    }
     const int64_t total = N * (nq + 2 * nkv) * (D / 2);
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
-    hipStream_t s = (hipStream_t)stream;
     if (dtype == JF_F32)
         rope_kv_append_kernel<float><<<grid, block, 0, s>>>((const float *)qkv, N, T, nq, nkv, D, positions, cos_table, sin_table,
                                                          (float *)q_out, (float *)k_cache, (float *)v_cache, slot_main, S_max,

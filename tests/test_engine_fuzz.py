@@ -1,5 +1,7 @@
 """Randomised engine-path sweep: JacobiDecoder / JacobiDecoderNonGreedy (HIP jf_engine_step / jf_rs_*) against the oracle's
 restatement of JD / JDN over random batch sizes, block lengths, max_tokens, EOS positions and robustness."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -50,10 +52,13 @@ def _as_dtype(logits, ldt):
     return O.bf16_round(logits) if ldt == "bf16" else logits
 
 
+FUZZ_SCALE = max(int(os.environ.get("JF_FUZZ_SCALE", "1")), 1)      # soak runs on a GPU box: k times the kernel-only seeds
+
+
 def _cases(n_both, n_total):
     """seeds below n_both run on both backends; the rest only through the real kernels (the CPU suite stays short)"""
     return [pytest.param(seed, b, id=f"{b}-{seed}", marks=[pytest.mark.gpu] if b == "hip" else [])
-            for seed in range(n_total) for b in (("hostsim", "hip") if seed < n_both else ("hip",))]
+            for seed in range(n_total * FUZZ_SCALE) for b in (("hostsim", "hip") if seed < n_both else ("hip",))]
 
 
 @pytest.mark.parametrize("seed,backend", _cases(40, 120))

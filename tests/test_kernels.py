@@ -404,9 +404,10 @@ def test_rs_probs_bf16_follows_torch_rounding_points(temperature):
 
 # ------------------------------------------------------------------------------------- fused RoPE + Q layout + KV append
 @GPU
+@pytest.mark.parametrize("D", [32, 128, 24])          # 24: half a head is 12 elements — bf16 takes the element-wise kernel
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-def test_rope_kv_append_matches_torch(dtype):
-    R, T, nq, nkv, D, S_max, T_max = 3, 5, 8, 2, 32, 40, 8
+def test_rope_kv_append_matches_torch(dtype, D):
+    R, T, nq, nkv, S_max, T_max = 3, 5, 8, 2, 40, 8
     g = torch.Generator().manual_seed(6)
     qkv = torch.randn(R * T, (nq + 2 * nkv) * D, generator=g).to(dtype).cuda()
     pos = torch.randint(0, 30, (R * T,), generator=g, dtype=torch.int32)

@@ -1,5 +1,7 @@
 """Randomised sweep: the device state-machine source (hostsim on CPU, real kernels with -m gpu) vs the CPU oracle over
 many (n, K, r, pool, lookahead, max_iter, vocab, robustness, periodicity, EOS) combinations, several calls each."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -14,9 +16,11 @@ from .test_multiblock import run_calls
 BACKENDS = [pytest.param("hostsim", id="hostsim"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
 
 
-# seeds 0..119 run on both backends; 120..359 only through the real kernels (the CPU suite stays short)
+# seeds 0..119 run on both backends; 120..359 only through the real kernels (the CPU suite stays short).  JF_FUZZ_SCALE=k
+# multiplies the kernel-only range for a soak run on a GPU box (profiles/soak_r02.txt).
+FUZZ_SCALE = max(int(os.environ.get("JF_FUZZ_SCALE", "1")), 1)
 CASES = [pytest.param(seed, b, id=f"{b}-{seed}", marks=[pytest.mark.gpu] if b == "hip" else [])
-         for seed in range(360) for b in (("hostsim", "hip") if seed < 120 else ("hip",))]
+         for seed in range(360 * FUZZ_SCALE) for b in (("hostsim", "hip") if seed < 120 else ("hip",))]
 
 
 @pytest.mark.parametrize("seed,backend", CASES)
