@@ -203,8 +203,9 @@ class Qwen2Model:
         return torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], dim=-1)
 
     def _mlp_residual(self, L, x2d, h2d):
-        """x + down(silu(gate(h)) * up(h)) with the gate in one HIP launch and the residual in the GEMM epilogue."""
-        return torch.addmm(x2d, ops.swiglu(F.linear(h2d, L["wgu"])), L["wd"].t())
+        """x += down(silu(gate(h)) * up(h)) with the gate in one HIP launch and the residual in the GEMM epilogue (in place:
+        an out-of-place addmm first copies x into its result, one more launch per GEMM)."""
+        return x2d.addmm_(ops.swiglu(F.linear(h2d, L["wgu"])), L["wd"].t())
 
     # -- forward over a static cache -------------------------------------------------------------
     @torch.inference_mode()
@@ -276,7 +277,7 @@ class Qwen2Model:
                 Kf, Vf = cache.k[li][rp, :, :S_cur], cache.v[li][rp, :, :S_cur]
             o = F.scaled_dot_product_attention(qh, Kf, Vf, attn_mask=bias)
             o = o.view(R, nkv, G, T, hd).permute(0, 3, 1, 2, 4).reshape(R * T, nq * hd)
-            x = torch.addmm(x, o, L["wo"].t())                                        # residual in the GEMM epilogue
+            x.addmm_(o, L["wo"].t())                                                  # residual in the GEMM epilogue, in place
             x = self._mlp_residual(L, x, self._norm(x, L["ln2"]))
         flat = self._norm(x, w.norm)
         if logits_rows is not None:
