@@ -172,8 +172,8 @@ JF_API int jf_mb_step(int32_t *states, int64_t state_ints, int P, uint64_t *pack
  *   arrive [P * 64] int32 (one 256-byte line per prompt): zero on entry (one torch.zeros at start-up); the call
  *   leaves it zero,
  *   params: the jf_mb_params the states were begun with.
- * Rows that are not 16-byte aligned, or more than 1024 prompts (waiting steppers must never be able to fill the chip), fall
- * back to the two launches.  A stepper that waits longer than 2 s for its rows
+ * Rows that are not 16-byte aligned, or more prompts than half of the workgroups the device keeps resident of this kernel
+ * (waiting steppers must never be able to fill the chip; 640 on an MI355X), fall back to the two launches.  A stepper that waits longer than 2 s for its rows
  * reports JF_E_LAUNCH in its descriptor instead of hanging the GPU. */
 JF_API int jf_mb_verify(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, const int32_t *out_index,
                  int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len, int32_t Tpad,

@@ -13,6 +13,7 @@ __device__ unsigned long long g_mtrace[16 * 256];
 #define JF_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 256) g_mtrace[16 * blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #endif
 #include "jf_argmax_dev.h"
+#include <mutex>
 
 // ------------------------------------------------------------------------------------------------
 // multiblock state machine: one wavefront per prompt
@@ -289,6 +290,26 @@ __global__ __launch_bounds__(AM_TPB) void mb_verify_kernel(VerifyArgs a) {
 #endif
 }
 
+// Largest number of stepper workgroups a fused launch may carry: half of what the device keeps resident of this kernel
+// variant at this LDS request (cached per variant; 0 if the runtime cannot tell, which selects the two-launch path).
+static int verify_stepper_cap(const void *kern, int variant, size_t shm) {
+    static std::mutex mu;
+    static size_t seen_shm[8];
+    static int seen_cap[8];
+    static bool seen[8];
+    std::lock_guard<std::mutex> g(mu);
+    if (seen[variant] && seen_shm[variant] == shm) return seen_cap[variant];
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, AM_TPB, shm) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        per_cu = 0;
+    }
+    const long long cap = (long long)per_cu * cus / 2;
+    seen[variant] = true; seen_shm[variant] = shm; seen_cap[variant] = (int)(cap > 0x7FFFFFFF ? 0x7FFFFFFF : cap);
+    return seen_cap[variant];
+}
+
 extern "C" int jf_mb_verify(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, const int32_t *out_index,
                             int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len, int32_t Tpad,
                             const int32_t *row_prompt, int32_t *arrive, jf_mb_desc *desc, const jf_mb_params *params,
@@ -304,30 +325,17 @@ extern "C" int jf_mb_verify(const void *logits, int dtype, int64_t R, int64_t V,
     rc = argmax_plan(logits, dtype, R, V, row_stride, true, &pl);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    // Steppers wait inside the launch, so they must never be able to fill the chip: above 1024 prompts (a quarter of the
-    // resident workgroups the LDS request allows) the convergence check runs as its two launches.  Same for unaligned logits.
-    if (!pl.vec || P > 1024) {
-        rc = out_index ? jf_argmax_scatter(logits, dtype, R, V, row_stride, out_index, packed, stream)
-                       : jf_argmax_partial(logits, dtype, R, V, row_stride, packed, stream);
-        if (rc) return rc;
-        return jf_mb_step(states, state_ints, P, packed, packed_len, desc, stream);
-    }
-    // compact image + greedy tokens of one prompt in LDS; a configuration that needs more than 20 KB steps on HBM instead
+    // compact image + greedy tokens of one prompt in LDS; a configuration that needs more than 16 KB steps on HBM instead
     // (the LDS request applies to every workgroup of the launch and must not cut the streaming workgroups' residency)
     const jfmb::Layout LG = jfmb::make_layout(params->n, params->K, params->pool_size, params->max_blocks);
     const jfmb::Layout LC = jfmb::compact_layout(LG, params->K);
     int64_t lds_ints = VERIFY_LDS_HDR + (int64_t)LC.total + (int64_t)LC.RMAX * LC.TMAX;
     lds_ints = (lds_ints + 3) & ~3ll;
     if (lds_ints * 4 > 16 * 1024) lds_ints = 0;
-    VerifyArgs a;
-    a.am = ArgmaxArgs{logits, R, V, row_stride, (unsigned long long *)packed, (int)pl.cpr, pl.chunk, out_index, pl.reverse ? 1 : 0};
-    a.states = states; a.state_ints = state_ints; a.P = P; a.packed_len = packed_len; a.row_prompt = row_prompt;
-    a.arrive = arrive; a.desc = desc; a.Tpad = Tpad; a.compacted = out_index ? 1 : 0; a.lds_ints = (int32_t)lds_ints;
-    const int64_t blocks = pl.blocks + P;
-    if (blocks > 0x7FFFFFFFll) return fail(JF_E_CAPACITY, "jf_mb_verify: grid too large");
-    const dim3 grid((unsigned)blocks), block(AM_TPB);
     const size_t shm = (size_t)lds_ints * 4;
-#define JF_V(DT, WV, NTF) mb_verify_kernel<DT, WV, NTF><<<grid, block, shm, s>>>(a)
+    void (*kern)(VerifyArgs) = nullptr;
+    int variant = 0;
+#define JF_V(DT, WV, NTF) kern = mb_verify_kernel<DT, WV, NTF>
     if (dtype == JF_F32) {
         if (pl.wave_mode) { if (pl.nt) JF_V(JF_F32, true, true); else JF_V(JF_F32, true, false); }
         else { if (pl.nt) JF_V(JF_F32, false, true); else JF_V(JF_F32, false, false); }
@@ -336,5 +344,24 @@ extern "C" int jf_mb_verify(const void *logits, int dtype, int64_t R, int64_t V,
         else { if (pl.nt) JF_V(JF_BF16, false, true); else JF_V(JF_BF16, false, false); }
     }
 #undef JF_V
+    variant = (dtype == JF_BF16 ? 4 : 0) + (pl.wave_mode ? 2 : 0) + (pl.nt ? 1 : 0);
+    // Steppers wait inside the launch, so they must never be able to fill the chip: they may hold at most half of the
+    // workgroups this kernel can keep resident (registers, LDS request, 256 threads: asked of the runtime, not assumed).
+    // More prompts than that, or unaligned logits, run the convergence check as its two launches.
+    const int cap = pl.vec ? verify_stepper_cap((const void *)kern, variant, shm) : 0;
+    if (!pl.vec || P > cap) {
+        rc = out_index ? jf_argmax_scatter(logits, dtype, R, V, row_stride, out_index, packed, stream)
+                       : jf_argmax_partial(logits, dtype, R, V, row_stride, packed, stream);
+        if (rc) return rc;
+        return jf_mb_step(states, state_ints, P, packed, packed_len, desc, stream);
+    }
+    VerifyArgs a;
+    a.am = ArgmaxArgs{logits, R, V, row_stride, (unsigned long long *)packed, (int)pl.cpr, pl.chunk, out_index, pl.reverse ? 1 : 0};
+    a.states = states; a.state_ints = state_ints; a.P = P; a.packed_len = packed_len; a.row_prompt = row_prompt;
+    a.arrive = arrive; a.desc = desc; a.Tpad = Tpad; a.compacted = out_index ? 1 : 0; a.lds_ints = (int32_t)lds_ints;
+    const int64_t blocks = pl.blocks + P;
+    if (blocks > 0x7FFFFFFFll) return fail(JF_E_CAPACITY, "jf_mb_verify: grid too large");
+    const dim3 grid((unsigned)blocks), block(AM_TPB);
+    kern<<<grid, block, shm, s>>>(a);
     return check_launch("mb_verify_kernel");
 }

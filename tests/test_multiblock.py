@@ -299,11 +299,15 @@ def test_block_list_capacity_is_an_error_not_a_corruption(backend):
         assert res["ret"] == st.ret and res["iters"] == st.iters and res["kv_tokens"] == st.kv_tokens
 
 
-@pytest.mark.parametrize("backend", BACKENDS)
-def test_many_prompts_side_by_side(backend):
+@pytest.mark.parametrize("backend,P", [pytest.param("hostsim", 150, id="hostsim-150"),
+                                       pytest.param("hip", 150, id="hip-150", marks=pytest.mark.gpu),
+                                       pytest.param("hip", 700, id="hip-700", marks=pytest.mark.gpu)])
+def test_many_prompts_side_by_side(backend, P):
     """150 prompts in one batch: 150 stepper workgroups wait for their own rows inside one jf_mb_verify launch (rows of a
-    prompt are spread over many item workgroups), rolling over three calls each, against the oracle prompt by prompt."""
-    P, n, V = 150, 8, 96
+    prompt are spread over many item workgroups), rolling over two calls each, against the oracle prompt by prompt.  700
+    prompts are more steppers than the launch may carry (half of the resident workgroups: 640 on an MI355X): the same call
+    runs as its two launches."""
+    n, V = 8, 96
     eos_id, pad_id = V - 1, V - 2
     rng = np.random.default_rng(123)
     with use_backend(backend):
