@@ -39,6 +39,13 @@ def _dtype_code(t: torch.Tensor) -> int:
     raise ValueError(f"logits dtype must be float32 or bfloat16, got {t.dtype}")
 
 
+def _grown(buf: torch.Tensor, need_bytes: int) -> torch.Tensor:
+    """``buf`` if it holds ``need_bytes``, else a zeroed buffer of the same dtype that does (workspaces sized by the library)."""
+    if buf.numel() * buf.element_size() >= need_bytes:
+        return buf
+    return torch.zeros((-(-need_bytes // buf.element_size()),), dtype=buf.dtype, device=buf.device)
+
+
 # --------------------------------------------------------------------------------------------
 # (a2) argmax
 # --------------------------------------------------------------------------------------------
@@ -538,7 +545,7 @@ class RsStepper:
         self.packed = new_packed(n, dev)
         f32 = lambda k: torch.zeros((k,), dtype=torch.float32, device=dev)
         self.p_draft, self.row_max, self.row_sumexp = f32(n), f32(n), f32(n)
-        self.ws = torch.zeros((n * 64 * 2,), dtype=torch.float32, device=dev)     # jf_rs_workspace_bytes(n, V)
+        self.ws = torch.zeros((n * 16 * 2,), dtype=torch.float32, device=dev)     # grown to jf_rs_workspace_bytes(R, V) on demand
         self.step_ws = torch.zeros((int(N.lib().jf_rs_step_workspace_bytes(self.max_rows)) // 8 + 2,), dtype=torch.float64, device=dev)
         self.committed = torch.zeros((self.max_rows, self.max_L), dtype=torch.int64, device=dev)
         self.next_draft = torch.zeros((self.max_rows, self.max_L), dtype=torch.int64, device=dev)
@@ -570,6 +577,7 @@ class RsStepper:
         R = B * (L - 1)
         draft_next = draft[:, 1:].reshape(-1).contiguous()
         lib = N.lib()
+        self.ws = _grown(self.ws, int(lib.jf_rs_workspace_bytes(R, V)))
         N.check(lib.jf_rs_probs(_ptr(flat), _dtype_code(flat), R, V, flat.stride(0), _ptr(draft_next), float(temperature),
                                 _ptr(self.p_draft), _ptr(self.row_max), _ptr(self.row_sumexp), _ptr(self.packed),
                                 _ptr(self.ws), self.ws.numel() * 4, _stream(dev)), "jf_rs_probs")
@@ -608,7 +616,7 @@ class OnPolicyStepper:
         self.packed = new_packed(n, dev)
         f32 = lambda k: torch.zeros((k,), dtype=torch.float32, device=dev)
         self.p_draft, self.row_max, self.row_sumexp = f32(n), f32(n), f32(n)
-        self.ws = torch.zeros((n * 64 * 2,), dtype=torch.float32, device=dev)
+        self.ws = torch.zeros((n * 16 * 2,), dtype=torch.float32, device=dev)     # grown to jf_rs_workspace_bytes(R, V) on demand
         self.step_ws = torch.zeros((int(N.lib().jf_rs_step_workspace_bytes(n)) // 8 + 2,), dtype=torch.float64, device=dev)
         self.out = torch.zeros((2, n), dtype=torch.int64, device=dev)              # committed, redraft
         self.row_dev = torch.zeros((N.OP_ROW_INTS,), dtype=torch.int32, device=dev)
@@ -632,6 +640,7 @@ class OnPolicyStepper:
         flat = logits if logits.stride(1) == 1 else logits.contiguous()
         prop = proposed.to(device=dev, dtype=torch.int64).contiguous()
         lib = N.lib()
+        self.ws = _grown(self.ws, int(lib.jf_rs_workspace_bytes(R, V)))
         N.check(lib.jf_rs_probs(_ptr(flat), _dtype_code(flat), R, V, flat.stride(0) if R > 1 else V, _ptr(prop),
                                 float(temperature), _ptr(self.p_draft), _ptr(self.row_max), _ptr(self.row_sumexp),
                                 _ptr(self.packed), _ptr(self.ws), self.ws.numel() * 4, _stream(dev)), "jf_rs_probs")

@@ -278,6 +278,9 @@ class HostSimLib:
     def _ldt(dtype):
         return "bf16" if dtype == N.JF_BF16 else "f32"
 
+    def jf_rs_workspace_bytes(self, R, V):
+        return max(int(R), 0) * 8                       # the CPU stand-in keeps no per-chunk partials
+
     def jf_rs_step_workspace_bytes(self, rows):
         return max(int(rows), 0) * (16 * 8 + 16)
 
