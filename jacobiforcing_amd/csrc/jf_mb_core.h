@@ -37,6 +37,7 @@ enum : int {
     H_NUM_BLOCKS, H_ACTIVE, H_RA, H_LEN_LISTS, H_LNT, H_HAS_LNT, H_ITERS, H_DONE, // MB:249-262
     H_RET_EARLY, H_ERR, H_PROMPT_LEN, H_KV_LEN, H_POOL_COUNT, H_POOL_HEAD,
     H_RET_LEN, H_NEXT_TOK, H_B, H_T, H_NSPANS, H_ROW_BASE, H_TPAD,
+    H_LOOK_THR,              // smallest block total t with (double)t / n >= lookahead_start_ratio (MB:577), INT32_MAX if none
     H_SPANS = 40             // 3 ints per span (block, start, L), NB spans follow the fixed header
 };
 constexpr int MAX_NB = 4096; // sanity bound only; the block lists can grow by one entry per iteration (Q3/Q4 with K >= 3)
@@ -51,6 +52,7 @@ struct Layout {
 };
 
 JF_HD int imax(int a, int b) { return a > b ? a : b; }
+JF_HD int wrap(int x, int m) { return x >= m ? x - m : x; }   // x mod m for 0 <= x < 2m (ring indices: no integer division)
 JF_HD int imin(int a, int b) { return a < b ? a : b; }
 
 // every offset follows from (n, NB, RMAX, TMAX, LPOOL, pool_size): the state block in HBM uses the capacities the
@@ -114,7 +116,7 @@ struct Machine {
     JF_HD int32_t *acc(int b) const { return blk(b) + B_HDR; }
     JF_HD int32_t *draft(int b, int r) const { return blk(b) + B_HDR + (L.n + 1) + r * L.n; }
     JF_HD int32_t *pool_entry(int i) const {   // i-th oldest, 0 <= i < pool_count
-        int slot = (pool_head + i) % L.pool_size;
+        int slot = wrap(pool_head + i, L.pool_size);
         return S + L.off_pool + slot * (1 + L.LPOOL);
     }
     JF_HD int32_t *out_row(int r) const { return S + L.off_out + r * L.TMAX; }
@@ -167,8 +169,8 @@ struct Machine {
     // reserve the slot for a new newest entry; returns its storage (caller fills tokens, then sync)
     JF_HD int32_t *pool_push_slot(int len) {
         if (L.pool_size <= 0) return nullptr;
-        if (pool_count == L.pool_size) { pool_head = (pool_head + 1) % L.pool_size; pool_count--; }
-        int slot = (pool_head + pool_count) % L.pool_size;
+        if (pool_count == L.pool_size) { pool_head = wrap(pool_head + 1, L.pool_size); pool_count--; }
+        int slot = wrap(pool_head + pool_count, L.pool_size);
         pool_count++;
         int32_t *e = S + L.off_pool + slot * (1 + L.LPOOL);
         if (lanes.lane() == 0) e[0] = len;
@@ -251,6 +253,10 @@ struct Machine {
             S[H_RMAX] = L.RMAX; S[H_TMAX] = L.TMAX; S[H_LPOOL] = L.LPOOL;
             union { double d; int32_t i[2]; } u; u.d = p.lookahead_start_ratio;
             S[H_LOOK_LO] = u.i[0]; S[H_LOOK_HI] = u.i[1];
+            // MB:577 compares total_accepted / n >= ratio in double: monotone in the total, so the step compares integers
+            int thr = INT32_MAX;
+            for (int t = 2 * p.n + 2; t >= 0; --t) if ((double)t / (double)p.n >= p.lookahead_start_ratio) thr = t;
+            S[H_LOOK_THR] = thr;
             S[H_NUM_BLOCKS] = 1; S[H_ACTIVE] = 1; S[H_RA] = 0; S[H_LEN_LISTS] = 1;
             S[H_LNT] = -1; S[H_HAS_LNT] = 0; S[H_PROMPT_LEN] = kv0; S[H_KV_LEN] = kv0; S[H_NEXT_TOK] = -1;
             int32_t *b0 = blk(0);
@@ -303,7 +309,7 @@ struct Machine {
         int kv_cur = kv_before + T;          // DynamicCache.update appended every forwarded token
         int best_row = 0;                    // physical candidate row the logical cache was narrowed to
         bool returned = false;
-        union { double dd; int32_t i[2]; } lk; lk.i[0] = S[H_LOOK_LO]; lk.i[1] = S[H_LOOK_HI];
+        const int look_thr = S[H_LOOK_THR];
 
         for (int s = 0; s < nspans && !returned; ++s) {
             const int b = S[H_SPANS + 3 * s], start = S[H_SPANS + 3 * s + 1], Ls = S[H_SPANS + 3 * s + 2];
@@ -389,7 +395,7 @@ JF_UNROLL
                         // PAD-stripped concat (MB:405-407) compacted straight into the slot the push will take (the oldest
                         // entry's storage when the deque is full); the push is committed only if something was kept
                         if (L.pool_size > 0) {
-                            const int slot = (pool_count == L.pool_size) ? pool_head : (pool_head + pool_count) % L.pool_size;
+                            const int slot = (pool_count == L.pool_size) ? pool_head : wrap(pool_head + pool_count, L.pool_size);
                             int32_t *e = S + L.off_pool + slot * (1 + L.LPOOL);
                             int clen = 0;
                             for (int q = 0; q < num_blocks && !err; ++q) {
@@ -422,7 +428,7 @@ JF_UNROLL
                         JF_STAMP(5);
                     }
                     // MB:577-585 candidates
-                    if ((double)new_total / (double)n >= lk.dd) {
+                    if (new_total >= look_thr) {
                         int C = 0;
                         // reversed(list(pool)[:-1]), four entries per pass so that their length reads, then their token
                         // reads, are independent round trips instead of a chain
@@ -679,7 +685,7 @@ JF_HD bool state_to_compact(Lanes lanes, const int32_t *G, const Layout &LG, int
     lanes.sync();
     bool fits = true;
     for (int i = 0; i < pool_count; ++i) {
-        const int slot = (pool_head + i) % LG.pool_size;
+        const int slot = wrap(pool_head + i, LG.pool_size);
         if (C[LC.off_pool + slot * per_slot] > LC.LPOOL) fits = false;
     }
     return fits;
@@ -694,7 +700,7 @@ JF_HD void compact_to_state(Lanes lanes, const int32_t *C, const Layout &LC, int
     for (int i = lanes.lane(); i < H_SPANS + 3 * nsp; i += lanes.count()) G[i] = C[i];
     for (int i = lanes.lane(); i < len_lists * LG.blk_stride; i += lanes.count()) G[LG.off_blocks + i] = C[LC.off_blocks + i];
     for (int k = 0; k < pool_count; ++k) {
-        const int slot = (pool_head + k) % LG.pool_size;
+        const int slot = wrap(pool_head + k, LG.pool_size);
         const int32_t *c = C + LC.off_pool + slot * (1 + LC.LPOOL);
         int32_t *e = G + LG.off_pool + slot * (1 + LG.LPOOL);
         const int len = c[0];
