@@ -35,7 +35,7 @@ static const ArgmaxTune &argmax_tune() {
         r.items = rd("JF_ARGMAX_ITEMS", 1, 1ll << 24, 0);
         r.wave = (int)rd("JF_ARGMAX_WAVE", 0, 1, -1);
         r.nt = (int)rd("JF_ARGMAX_NT", 0, 1, -1);
-        r.reverse = (int)rd("JF_ARGMAX_REVERSE", 0, 1, -1);
+        r.reverse = (int)rd("JF_ARGMAX_REVERSE", 0, 2, -1);
         return r;
     }();
     return t;
@@ -67,7 +67,7 @@ int argmax_plan(const void *logits, int dtype, int64_t R, int64_t V, int64_t row
     const int64_t bytes = R * V * esz;
     pl->wave_mode = pl->vec && (tn.wave >= 0 ? tn.wave != 0 : (!fused && bytes >= (140ll << 20)));
     pl->nt = tn.nt >= 0 ? tn.nt != 0 : bytes >= (60ll << 20);
-    pl->reverse = tn.reverse > 0;
+    pl->reverse = tn.reverse > 0 ? tn.reverse : 0;
     if (pl->wave_mode) {
         // one item per wavefront, ~one wavefront per SIMD (256 CUs x 4 SIMDs = 1024 slots).  Split each row into the
         // smallest number of chunks whose makespan ceil(items / 1024) * (V / per_row) is within 10 % of the best
@@ -117,7 +117,7 @@ static int argmax_launch(const void *logits, int dtype, int64_t R, int64_t V, in
     const int rc = argmax_plan(logits, dtype, R, V, row_stride, false, &pl);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const ArgmaxArgs a{logits, R, V, row_stride, (unsigned long long *)packed, (int)pl.cpr, pl.chunk, out_index, pl.reverse ? 1 : 0};
+    const ArgmaxArgs a{logits, R, V, row_stride, (unsigned long long *)packed, (int)pl.cpr, pl.chunk, out_index, pl.reverse};
     const dim3 grid((unsigned)pl.blocks), block(AM_TPB);
     if (pl.wave_mode) {
         if (dtype == JF_F32) { if (pl.nt) argmax_wave_kernel<JF_F32, true><<<grid, block, 0, s>>>(a); else argmax_wave_kernel<JF_F32, false><<<grid, block, 0, s>>>(a); }

@@ -32,12 +32,14 @@ __device__ __forceinline__ int64_t argmax_wg_item(const ArgmaxArgs &a, int64_t i
     using E = Elem<DT>;
     constexpr int EPV = E::EPV;
     constexpr int UNROLL = 8;
-    const int64_t row = a.reverse ? a.R - 1 - item / a.chunks_per_row : item / a.chunks_per_row;
+    // item -> (row, chunk): rows first to last (0), last to first (1), or chunk-major = the same column range of every row
+    // before the next range (2: the order a column-tiled producer wrote the logits in)
+    const int64_t row = a.reverse == 2 ? item % a.R : (a.reverse ? a.R - 1 - item / a.chunks_per_row : item / a.chunks_per_row);
     // slot of this row's result (jf_argmax_scatter): read up front so its latency hides behind the stream; < 0 = padding row
     const int64_t orow = a.out_index ? (int64_t)a.out_index[row] : row;
     if (orow < 0) return -1;
     if (row_owner) *owner = row_owner[(int)orow / owner_div];      // fused launch: whose row this is (latency hides behind the stream)
-    const int c = (int)(item % a.chunks_per_row);
+    const int c = (int)(a.reverse == 2 ? item / a.R : item % a.chunks_per_row);
     const int64_t begin = (int64_t)c * a.chunk_elems;
     int64_t end = begin + a.chunk_elems;
     if (end > a.V) end = a.V;
@@ -146,7 +148,8 @@ __device__ __forceinline__ int64_t argmax_wave_item(const ArgmaxArgs &a, int64_t
 
 // ---- launch shape (host) ------------------------------------------------------------------------
 struct ArgmaxPlan {
-    bool vec, wave_mode, nt, reverse;
+    bool vec, wave_mode, nt;
+    int reverse;                   // item order: 0 rows first to last, 1 last to first, 2 chunk-major (JF_ARGMAX_REVERSE)
     int64_t chunk, cpr, items, blocks;
 };
 int argmax_plan(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, bool fused, ArgmaxPlan *plan);   // jf_argmax.hip

@@ -356,7 +356,7 @@ extern "C" int jf_mb_verify(const void *logits, int dtype, int64_t R, int64_t V,
         return jf_mb_step(states, state_ints, P, packed, packed_len, desc, stream);
     }
     VerifyArgs a;
-    a.am = ArgmaxArgs{logits, R, V, row_stride, (unsigned long long *)packed, (int)pl.cpr, pl.chunk, out_index, pl.reverse ? 1 : 0};
+    a.am = ArgmaxArgs{logits, R, V, row_stride, (unsigned long long *)packed, (int)pl.cpr, pl.chunk, out_index, pl.reverse};
     a.states = states; a.state_ints = state_ints; a.P = P; a.packed_len = packed_len; a.row_prompt = row_prompt;
     a.arrive = arrive; a.desc = desc; a.Tpad = Tpad; a.compacted = out_index ? 1 : 0; a.lds_ints = (int32_t)lds_ints;
     const int64_t blocks = pl.blocks + P;
