@@ -187,6 +187,7 @@ class MultiblockBatch:
         d = self.desc_host.numpy()
         err = d[:, N.DESC_FIELDS.index("error")]
         if err.any():
+            self.arrive.zero_()                         # a launch that reported an error may have left arrival counts behind
             p = int(np.nonzero(err)[0][0])
             N.raise_state_error(int(err[p]), f"multiblock prompt {p} (state-machine line {int(d[p, N.DESC_FIELDS.index('rsv0')])})",
                                 aux=int(d[p, N.DESC_FIELDS.index("rsv1")]))
