@@ -262,3 +262,42 @@ def test_from_hf_builds_equivalent_forward():
         with torch.no_grad():
             ref = hf(input_ids=ids).logits[0]
         assert torch.allclose(got, ref, atol=2e-4, rtol=2e-4)
+
+
+def test_checkpoint_directory_loads_and_decodes_like_hf(tmp_path):
+    """A HF Qwen2 checkpoint directory (config.json + *.safetensors, as `save_pretrained` writes it) through the two loaders a
+    user of the reference meets — `Qwen2Weights.load_safetensors` and `LLM(model_dir)` — gives HF's logits and HF's greedy
+    continuation; Jacobi decoding of the same request returns the same tokens (the reference's own criterion)."""
+    tr = pytest.importorskip("transformers")
+    pytest.importorskip("safetensors")
+    from jacobiforcing_amd import LLM, SamplingParams
+    hf_cfg = tr.Qwen2Config(vocab_size=131, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                            num_key_value_heads=2, max_position_embeddings=512, rms_norm_eps=1e-6, rope_theta=10000.0,
+                            tie_word_embeddings=False, attention_dropout=0.0, use_sliding_window=False, eos_token_id=130,
+                            pad_token_id=129)
+    torch.manual_seed(5)
+    hf = tr.Qwen2ForCausalLM(hf_cfg).eval().float()
+    hf.save_pretrained(str(tmp_path), safe_serialization=True)
+    assert list(tmp_path.glob("*.safetensors"))
+    with use_backend("hostsim"):
+        cfg = Qwen2Config.from_json(tmp_path / "config.json")
+        w = Qwen2Weights(cfg, "cpu", dtype=torch.float32, seed=9)
+        w.load_safetensors(tmp_path, cfg)
+        model = Qwen2Model(cfg, w)
+        ids = torch.randint(0, 128, (1, 19))
+        with torch.no_grad():
+            ref = hf(input_ids=ids).logits[0]
+        cache = StaticKVCache(cfg, 1, 64, 0, 1, "cpu", dtype=torch.float32)
+        z = torch.zeros(1, dtype=torch.int32)
+        got = model.forward(ids, torch.arange(19, dtype=torch.int32).view(1, 19), cache, z, z - 1, z + 19, z, False)
+        assert torch.allclose(got, ref, atol=2e-4, rtol=2e-4), float((got - ref).abs().max())
+        # engine path on the same directory: greedy AR == HF greedy; Jacobi == AR
+        prompt = [int(x) for x in ids[0]]
+        with torch.no_grad():
+            want = hf.generate(ids, max_new_tokens=12, do_sample=False, eos_token_id=None, pad_token_id=129)[0, 19:].tolist()
+        llm = LLM(str(tmp_path), tokenizer_path="none", device="cpu", max_model_len=128, max_num_batched_tokens=128, max_num_seqs=2)
+        ar = llm.generate([prompt], SamplingParams(temperature=0.0, max_tokens=12, ignore_eos=True), use_tqdm=False)[0]["token_ids"]
+        assert ar == want
+        jac = llm.generate([prompt], SamplingParams(temperature=0.0, max_tokens=12, ignore_eos=True, decode_strategy="jacobi",
+                                                    jacobi_block_len=4), use_tqdm=False)[0]["token_ids"]
+        assert jac == want
