@@ -62,15 +62,20 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--csv", default="diffusion_profile_humaneval.csv")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="library-default GEMM selection instead of the committed table")
+    ap.add_argument("--device", default=None, help="default: cuda:<local rank>")
     args = ap.parse_args(argv)
 
     info = jd.init_from_env()
-    dev = torch.device("cuda", info.local_rank)
-    torch.cuda.set_device(dev)
+    dev = torch.device(args.device) if args.device else torch.device("cuda", info.local_rank)
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)
     if args.model:
         cfg = Qwen2Config.from_json(Path(args.model) / "config.json")
-        w = Qwen2Weights(cfg, dev)
-        w.load_safetensors(args.model, cfg)
+        w = Qwen2Weights(cfg, dev) if dev.type == "cuda" else Qwen2Weights(cfg, dev, dtype=torch.float32)
+        if list(Path(args.model).glob("*.safetensors")):
+            w.load_safetensors(args.model, cfg)
+        else:
+            print(f"[mr_humaneval] no *.safetensors under {args.model}: random-init weights", flush=True)
     else:
         cfg = Qwen2Config.qwen2_5_coder_7b()
         w = Qwen2Weights(cfg, dev)

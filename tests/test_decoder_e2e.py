@@ -301,3 +301,30 @@ def test_checkpoint_directory_loads_and_decodes_like_hf(tmp_path):
         jac = llm.generate([prompt], SamplingParams(temperature=0.0, max_tokens=12, ignore_eos=True, decode_strategy="jacobi",
                                                     jacobi_block_len=4), use_tqdm=False)[0]["token_ids"]
         assert jac == want
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_mr_humaneval_driver_writes_the_reference_csv(backend, tmp_path, capsys):
+    """drivers/mr_humaneval (counterpart of the reference's timing driver): one row per prompt with the reference's columns
+    (DRV-MR:259-273), derived columns consistent with the counted ones, and the EOS-only summary block (DRV-MR:329-349)."""
+    import csv as _csv
+    import json as _json
+    from jacobiforcing_amd.drivers import mr_humaneval
+    cfgd = dict(vocab_size=211, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=2, max_position_embeddings=2048, rms_norm_eps=1e-6, rope_theta=10000.0,
+                tie_word_embeddings=False, eos_token_id=210, pad_token_id=209, model_type="qwen2")
+    (tmp_path / "config.json").write_text(_json.dumps(cfgd))
+    out = tmp_path / "profile.csv"
+    with use_backend(backend):
+        mr_humaneval.main(["--model", str(tmp_path), "--synthetic", "3", "--batch", "2", "--n", "8", "--max-new-tokens", "24",
+                           "--csv", str(out), "--no-tuned-gemms", "--device", device_for(backend)])
+    rows = list(_csv.DictReader(open(out)))
+    assert list(rows[0].keys()) == mr_humaneval.COLUMNS and len(rows) == 3
+    for r in rows:
+        nt, calls, its = int(r["new_tokens"]), int(r["calls"]), int(r["total_iterations"])
+        # new_tokens = generated - 1 (DRV-MR:243)
+        assert nt >= 23 and calls >= 1 and its >= calls and r["stop_reason"] in ("eos", "max_new_tokens", "max_calls")
+        assert abs(float(r["avg_iter_per_call"]) - its / calls) < 1e-9 and abs(float(r["avg_iter_per_token"]) - its / nt) < 1e-9
+        assert 110 <= int(r["prompt_tokens"]) <= 620                      # the HumanEval-shaped synthetic prompts (SURVEY §8d)
+    text = capsys.readouterr().out
+    assert "EOS-only:" in text and "Avg iterations / token" in text and '"tokens_per_forward"' in text
