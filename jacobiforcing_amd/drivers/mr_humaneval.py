@@ -19,7 +19,7 @@ import torch
 from .. import distributed as jd
 from .. import ops
 from ..engine.multiblock_decoder import MultiblockJacobiDecoder
-from ..modeling.qwen2 import Qwen2Config, Qwen2Model, Qwen2Weights
+from ..modeling.qwen2 import load_model_directory, Qwen2Config, Qwen2Model, Qwen2Weights
 from ..synthetic import humaneval_shaped_prompts
 
 COLUMNS = ["index", "task_id", "prompt_tokens", "new_tokens", "calls", "total_iterations", "avg_iter_per_call",
@@ -70,12 +70,7 @@ def main(argv=None):
     if dev.type == "cuda":
         torch.cuda.set_device(dev)
     if args.model:
-        cfg = Qwen2Config.from_json(Path(args.model) / "config.json")
-        w = Qwen2Weights(cfg, dev) if dev.type == "cuda" else Qwen2Weights(cfg, dev, dtype=torch.float32)
-        if list(Path(args.model).glob("*.safetensors")):
-            w.load_safetensors(args.model, cfg)
-        else:
-            print(f"[mr_humaneval] no *.safetensors under {args.model}: random-init weights", flush=True)
+        cfg, w = load_model_directory(args.model, dev)
     else:
         cfg = Qwen2Config.qwen2_5_coder_7b()
         w = Qwen2Weights(cfg, dev)

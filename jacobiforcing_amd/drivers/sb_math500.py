@@ -20,7 +20,7 @@ from pathlib import Path
 import torch
 
 from ..hf_seam import Qwen2Backend, jacobi_forward_greedy
-from ..modeling.qwen2 import Qwen2Config, Qwen2Model, Qwen2Weights
+from ..modeling.qwen2 import load_model_directory, Qwen2Config, Qwen2Model, Qwen2Weights
 from .mr_humaneval import COLUMNS
 
 SYSTEM = "You are Qwen, created by Alibaba Cloud. You are a helpful assistant."        # DRV-SB:84
@@ -108,9 +108,7 @@ def main(argv=None):
     args = ap.parse_args(argv)
     dev = torch.device(args.device)
     if args.model:
-        cfg = Qwen2Config.from_json(Path(args.model) / "config.json")
-        w = Qwen2Weights(cfg, dev)
-        w.load_safetensors(args.model, cfg)
+        cfg, w = load_model_directory(args.model, dev)
     else:
         cfg = Qwen2Config.qwen2_5_coder_7b()
         w = Qwen2Weights(cfg, dev)

@@ -115,6 +115,8 @@ class Qwen2Weights:
         from safetensors import safe_open
         nq, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         tensors = {}
+        if not list(Path(model_dir).glob("*.safetensors")):
+            raise FileNotFoundError(f"no *.safetensors under {model_dir}")
         for f in sorted(Path(model_dir).glob("*.safetensors")):
             with safe_open(str(f), "pt", "cpu") as sf:
                 for k in sf.keys():
@@ -133,6 +135,19 @@ class Qwen2Weights:
             L["wd"] = get(pre + "mlp.down_proj.weight")
         self.norm = get("model.norm.weight")
         self.lm_head = self.embed if cfg.tie_word_embeddings else get("lm_head.weight")
+
+
+def load_model_directory(model_dir, device, dtype=None):
+    """(config, weights) of a HF Qwen2 directory: ``config.json`` and, when present, its ``*.safetensors``; a directory that
+    only holds the config gets random-init weights (said on stdout), like the engine's ModelRunner does."""
+    device = torch.device(device)
+    cfg = Qwen2Config.from_json(Path(model_dir) / "config.json")
+    w = Qwen2Weights(cfg, device, dtype=dtype or (torch.bfloat16 if device.type == "cuda" else torch.float32))
+    if list(Path(model_dir).glob("*.safetensors")):
+        w.load_safetensors(model_dir, cfg)
+    else:
+        print(f"[qwen2] no *.safetensors under {model_dir}: random-init weights", flush=True)
+    return cfg, w
 
 
 class StaticKVCache:
