@@ -160,3 +160,31 @@ def test_on_policy_rollout_records(model_dir, backend, monkeypatch):
             # the last vector of block k is what was committed for that block
             first = r[0]
             assert first["answer_trajectory_ids"][-1][:min(8, total)] == done[len(prompts[i]):len(prompts[i]) + min(8, total)]
+
+
+def test_string_prompts_go_through_the_directory_tokenizer(model_dir, tmp_path, monkeypatch):
+    """`LLM(model, tokenizer_path)` with text prompts (ENG:59-63, 188-200): the tokenizer found in the directory encodes the
+    prompt, supplies EOS / PAD ids and decodes the result; without one, a text prompt is refused."""
+    pytest.importorskip("transformers")
+    tk = pytest.importorskip("tokenizers")
+    vocab = {f"w{i}": i for i in range(300)}
+    vocab.update({"<pad>": 300, "<eos>": 301, "<unk>": 302})
+    tok = tk.Tokenizer(tk.models.WordLevel(vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = tk.pre_tokenizers.Whitespace()
+    tdir = tmp_path / "tok"                        # its own directory: config.json's model_type would pick Qwen2's tokenizer class
+    tdir.mkdir()
+    tok.save(str(tdir / "tokenizer.json"))
+    (tdir / "tokenizer_config.json").write_text(json.dumps({"tokenizer_class": "PreTrainedTokenizerFast", "eos_token": "<eos>",
+                                                                "pad_token": "<pad>", "unk_token": "<unk>"}))
+    monkeypatch.setenv("JF_DTYPE", "float32")
+    with use_backend("hostsim"):
+        llm = LLM(model_dir, tokenizer_path=str(tdir), device="cpu", max_model_len=256, max_num_batched_tokens=256, max_num_seqs=2)
+        assert (llm.config.eos, llm.config.pad) == (301, 300)
+        sp = SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True)
+        by_text = llm.generate(["w5 w9 w200 w31"], sp, use_tqdm=False)[0]
+        by_ids = llm.generate([[5, 9, 200, 31]], sp, use_tqdm=False)[0]
+        assert by_text["token_ids"] == by_ids["token_ids"] and len(by_text["token_ids"]) == 6
+        assert by_text["text"] == llm.tokenizer.decode(by_text["token_ids"])
+        bare = LLM(model_dir, tokenizer_path="none", device="cpu", max_model_len=256, max_num_batched_tokens=256, max_num_seqs=2)
+        with pytest.raises(ValueError):
+            bare.generate(["w5 w9"], sp, use_tqdm=False)
