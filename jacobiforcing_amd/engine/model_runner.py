@@ -119,10 +119,12 @@ class ModelRunner:
         B, T = ids.shape
         st = torch.tensor(starts, dtype=torch.int32, device=dev)
         pos = st.view(B, 1) + torch.arange(T, dtype=torch.int32, device=dev).view(1, T)
-        rp = torch.tensor([self._row(s) for s in seqs], dtype=torch.int32, device=dev)
+        rows = [self._row(s) for s in seqs]
+        rp = torch.tensor(rows, dtype=torch.int32, device=dev)
         return self.model.forward(ids.to(dev), pos, self.kv_cache, row_prompt=rp, row_cand=torch.full((B,), -1, dtype=torch.int32, device=dev),
                                   row_len=torch.tensor(lens, dtype=torch.int32, device=dev), kv_len_rows=st,
-                                  any_candidates=False, logits_rows=logits_rows, s_cur=max(starts) + T, logit_index=logit_index)
+                                  any_candidates=False, logits_rows=logits_rows, s_cur=max(starts) + T, logit_index=logit_index,
+                                  rows_in_place=rows == list(range(B)))     # freed rows are reused in any order
 
     def _prompt_forward(self, seqs: List[Sequence], rows: List[List[int]], want: List[range]) -> List[torch.Tensor]:
         """Forward whole token rows from position 0 (prefill), several ragged rows per launch: rows are padded to the longest

@@ -20,9 +20,13 @@ class Scheduler:
         self.block_manager = BlockManager(config.num_kvcache_blocks, config.kvcache_block_size)
         self.waiting: deque = deque()
         self.running: deque = deque()
+        self.row_capacity = None
 
     def set_kv_cache(self, kv_cache) -> None:
         self.block_manager.kv_cache = kv_cache
+        # a running request owns one row of the static cache: admission stops when the rows are taken (the reference's
+        # limit is its paged block pool, SCH:36-37; the rest of the queue waits exactly as it does there)
+        self.row_capacity = int(getattr(kv_cache, "P", 0)) or None
 
     def add(self, seq: Sequence) -> None:
         self.waiting.append(seq)
@@ -45,6 +49,8 @@ class Scheduler:
         while self.waiting and len(batch) < self.max_num_seqs:
             seq = self.waiting[0]
             if tokens + len(seq) > self.max_num_batched_tokens or not bm.can_allocate(seq):
+                break
+            if self.row_capacity is not None and len(self.running) >= self.row_capacity:
                 break
             bm.allocate(seq)
             tokens += len(seq) - seq.num_cached_tokens

@@ -227,13 +227,15 @@ class Qwen2Model:
     def forward(self, input_ids: torch.Tensor, positions: torch.Tensor, cache: StaticKVCache,
                 row_prompt: torch.Tensor, row_cand: torch.Tensor, row_len: torch.Tensor,
                 kv_len_rows: torch.Tensor, any_candidates: bool, logits_rows: Optional[slice] = None,
-                s_cur: Optional[int] = None, logit_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+                s_cur: Optional[int] = None, logit_index: Optional[torch.Tensor] = None,
+                rows_in_place: Optional[bool] = None) -> torch.Tensor:
         """One forward over R rows of (padded) length T.
 
         input_ids [R,T] int64, positions [R,T] int32 (= kv_len + t), row_prompt [R] (cache row of the prefix),
         row_cand [R] (-1: the row writes into the main cache, else index into the candidate scratch),
         row_len [R] valid tokens per row, kv_len_rows [R] committed prefix length per row, s_cur = max(kv_len)+T when the
-        caller knows it (saves a device read).  Returns logits [R*T, V] in the weight dtype (or ``logits_rows`` of it, or
+        caller knows it (saves a device read), rows_in_place = False when row r is NOT cache row r although R == P (a
+        caller whose rows are a permutation of the cache rows; None: rows of one batch in cache order).  Returns logits [R*T, V] in the weight dtype (or ``logits_rows`` of it, or
         the rows listed in ``logit_index`` — flat positions, negative entries are list padding and yield a junk row)."""
         cfg, w = self.cfg, self.w
         R, T = input_ids.shape
@@ -270,7 +272,7 @@ class Qwen2Model:
                 tail_idx = tail_idx.view(-1, 1, T, 1).expand(-1, nkv, T, hd)
                 crc = row_cand[cr].long()
         pos32 = positions.to(torch.int32).reshape(-1).contiguous()
-        direct = (not any_candidates) and R == cache.P                               # row r is prompt r: attend in place
+        direct = (not any_candidates) and R == cache.P and rows_in_place is not False   # row r is cache row r: attend in place
 
         x = w.embed[input_ids].view(R * T, cfg.hidden_size)                           # [R*T, H]
         for li, L in enumerate(w.layers):

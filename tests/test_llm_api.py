@@ -188,3 +188,23 @@ def test_string_prompts_go_through_the_directory_tokenizer(model_dir, tmp_path, 
         bare = LLM(model_dir, tokenizer_path="none", device="cpu", max_model_len=256, max_num_batched_tokens=256, max_num_seqs=2)
         with pytest.raises(ValueError):
             bare.generate(["w5 w9"], sp, use_tqdm=False)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_more_requests_than_cache_rows_queue_up(model_dir, backend, monkeypatch):
+    """Five requests on an engine with two cache rows (max_num_seqs=2): the rest of the queue waits for a row, as the
+    reference's waits for KV blocks (SCH:27-47); every request decodes exactly as it does alone, in all three strategies."""
+    monkeypatch.setenv("JF_INIT_STD", "0.3")
+    monkeypatch.setenv("JF_DTYPE", "float32")
+    with use_backend(backend):
+        dev = device_for(backend)
+        llm = LLM(model_dir, tokenizer_path="none", device=dev, max_model_len=256, max_num_batched_tokens=256, max_num_seqs=2)
+        prompts = [[5, 9, 200, 31, 7], [100, 101, 102], [250, 3], [7, 7, 7, 8], [1, 2, 3, 4, 5, 6]]
+        N = 10
+        sp = SamplingParams(temperature=0.0, max_tokens=N, ignore_eos=True)
+        alone = [llm.generate([p], sp, use_tqdm=False)[0]["token_ids"] for p in prompts]
+        assert [o["token_ids"] for o in llm.generate(prompts, sp, use_tqdm=False)] == alone
+        for strategy in ("jacobi", "jacobi_multiblock_rejection_recycling"):
+            out = llm.generate(prompts, SamplingParams(temperature=0.0, max_tokens=N, ignore_eos=True, decode_strategy=strategy,
+                                                       jacobi_block_len=4), use_tqdm=False)
+            assert [o["token_ids"][:N] for o in out] == alone, strategy
