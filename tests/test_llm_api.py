@@ -208,3 +208,41 @@ def test_more_requests_than_cache_rows_queue_up(model_dir, backend, monkeypatch)
             out = llm.generate(prompts, SamplingParams(temperature=0.0, max_tokens=N, ignore_eos=True, decode_strategy=strategy,
                                                        jacobi_block_len=4), use_tqdm=False)
             assert [o["token_ids"][:N] for o in out] == alone, strategy
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_engine_queue_stress_with_eos(tmp_path, backend, monkeypatch):
+    """Fourteen requests of mixed prompt lengths and budgets over three cache rows, with an EOS id the random model really
+    emits, so requests finish at different times and freed rows are reused in every order: each request's tokens equal
+    the ones it produces alone (greedy AR), for the AR, Jacobi and multiblock strategies."""
+    from collections import Counter
+    import numpy as np
+    monkeypatch.setenv("JF_INIT_STD", "0.3")
+    monkeypatch.setenv("JF_DTYPE", "float32")
+    base = dict(vocab_size=320, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=2, max_position_embeddings=1024, rms_norm_eps=1e-6, rope_theta=10000.0,
+                tie_word_embeddings=False, eos_token_id=319, pad_token_id=318, model_type="qwen2")
+    rng = np.random.default_rng(11)
+    prompts = [[int(x) for x in rng.integers(0, 300, size=int(rng.integers(2, 40)))] for _ in range(14)]
+    budgets = [int(rng.integers(3, 28)) for _ in prompts]
+    kw = dict(tokenizer_path="none", max_model_len=256, max_num_batched_tokens=256, max_num_seqs=3)
+    with use_backend(backend):
+        dev = device_for(backend)
+        d0 = tmp_path / "a"; d0.mkdir(); (d0 / "config.json").write_text(json.dumps(base))
+        free = LLM(str(d0), device=dev, **kw).generate(prompts, [SamplingParams(temperature=0.0, max_tokens=b, ignore_eos=True)
+                                                                for b in budgets], use_tqdm=False)
+        eos = Counter(t for o in free for t in o["token_ids"][2:]).most_common(1)[0][0]      # an id that shows up mid-stream
+        d1 = tmp_path / "b"; d1.mkdir(); (d1 / "config.json").write_text(json.dumps(dict(base, eos_token_id=int(eos))))
+        llm = LLM(str(d1), device=dev, **kw)
+        sps = lambda **extra: [SamplingParams(temperature=0.0, max_tokens=b, **extra) for b in budgets]
+        alone = [llm.generate([p], sp, use_tqdm=False)[0]["token_ids"] for p, sp in zip(prompts, sps())]
+        assert any(a and a[-1] == eos and len(a) < b for a, b in zip(alone, budgets))          # some requests do stop early
+        assert [o["token_ids"] for o in llm.generate(prompts, sps(), use_tqdm=False)] == alone
+        for strategy in ("jacobi", "jacobi_multiblock_rejection_recycling"):
+            out = llm.generate(prompts, sps(decode_strategy=strategy, jacobi_block_len=4), use_tqdm=False)
+            for o, a, b in zip(out, alone, budgets):
+                got = o["token_ids"]
+                if a[-1] == eos and len(a) < b:
+                    assert got == a, strategy                           # stops on the same EOS, nothing after it
+                else:
+                    assert got[:b] == a, strategy
