@@ -289,6 +289,8 @@ def main():
     scripted = None
     if not args.no_scripted:
         dec.logits_hook = ScriptedAcceptance(cfg.vocab_size, robust_pct=args.robust, vocab_hi=vocab_hi)
+        if not args.no_prewarm:
+            run_steps(dec, prompts, args.warmup, args.steps, seed=4321 + info.rank)
         with VerifyTimer() as tm2:
             tm2.valid_rows = lambda: dec.last_valid_rows
             r2 = run_steps(dec, prompts, args.warmup, args.steps, seed=4321 + info.rank, timer=tm2)
