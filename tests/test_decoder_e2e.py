@@ -328,3 +328,37 @@ def test_mr_humaneval_driver_writes_the_reference_csv(backend, tmp_path, capsys)
         assert 110 <= int(r["prompt_tokens"]) <= 620                      # the HumanEval-shaped synthetic prompts
     text = capsys.readouterr().out
     assert "EOS-only:" in text and "Avg iterations / token" in text and '"tokens_per_forward"' in text
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_batch_of_uneven_prompts_decodes_like_each_prompt_alone(backend):
+    """Seven prompts of very different lengths and budgets, an EOS id the model really emits, candidate rows on: every prompt's
+    tokens in the shared batch (rolling restarts, prompts going inactive at different times) equal its tokens when it is
+    decoded alone, and both are the greedy AR continuation."""
+    from collections import Counter
+    from jacobiforcing_amd.drivers.ar_baseline import generate_greedy
+    with use_backend(backend):
+        dev = device_for(backend)
+        model = tiny_model(dev, seed=21)
+        V = model.cfg.vocab_size
+        rng = np.random.default_rng(5)
+        prompts = [[int(x) for x in rng.integers(0, V - 2, size=int(k))] for k in (3, 61, 12, 40, 7, 25, 90)]
+        budgets = [int(b) for b in (30, 9, 44, 17, 25, 60, 12)]
+        pad = V - 2
+        ar = [generate_greedy(model, p, 70, eos_id=None)[0] for p in prompts]
+        eos = Counter(t for a in ar for t in a[4:40]).most_common(1)[0][0]              # shows up mid-stream in several prompts
+        prm = ops.MultiblockParams(n=8, K=2, r=0.5, n_gram_pool_size=4, eos_token_id=int(eos), pad_token_id=pad)
+        dec = MultiblockJacobiDecoder(model, len(prompts), prm, max_seq_len=512)
+        stats, _, _ = dec.generate(prompts, max_new_tokens=budgets, max_calls=64, seed=77)
+        stops = set()
+        for p, (st, a, b) in enumerate(zip(stats, ar, budgets)):
+            one = MultiblockJacobiDecoder(model, 1, prm, max_seq_len=512)
+            alone, _, _ = one.generate([prompts[p]], max_new_tokens=b, max_calls=64, seed=77 + p)
+            assert st.token_ids == alone[0].token_ids and st.stop_reason == alone[0].stop_reason, p
+            assert st.token_ids == a[:len(st.token_ids)], p                              # greedy Jacobi == greedy AR
+            if st.stop_reason == "eos":
+                assert eos in st.token_ids
+            else:
+                assert len(st.token_ids) >= b and eos not in st.token_ids[:b]
+            stops.add(st.stop_reason)
+        assert stops == {"eos", "max_new_tokens"}
