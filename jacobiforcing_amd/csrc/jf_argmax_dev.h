@@ -21,7 +21,7 @@ struct ArgmaxArgs {
     int chunks_per_row;
     int64_t chunk_elems;
     const int32_t *out_index;      // nullable: row i -> packed[out_index[i]], negative = skip the row unread
-    int32_t reverse;               // 1: items walk the rows last to first (the producer's most recent lines first)
+    int32_t reverse;               // item order: 0 rows first to last, 1 last to first, 2 chunk-major (see argmax_wg_item)
 };
 
 // One (row, chunk) item by a 256-thread workgroup sharing the chunk.  Returns the result slot (orow, -1 = skipped row) to
@@ -100,11 +100,11 @@ __device__ __forceinline__ int64_t argmax_wave_item(const ArgmaxArgs &a, int64_t
     constexpr int UNROLL = 8;
     const int lane = threadIdx.x & 63;
     if (item >= a.R * a.chunks_per_row) return -1;
-    const int64_t row = a.reverse ? a.R - 1 - item / a.chunks_per_row : item / a.chunks_per_row;
+    const int64_t row = a.reverse == 2 ? item % a.R : (a.reverse ? a.R - 1 - item / a.chunks_per_row : item / a.chunks_per_row);
     const int64_t orow = a.out_index ? (int64_t)a.out_index[row] : row;
     if (orow < 0) return -1;
     if (row_owner) *owner = row_owner[(int)orow / owner_div];
-    const int c = (int)(item % a.chunks_per_row);
+    const int c = (int)(a.reverse == 2 ? item / a.R : item % a.chunks_per_row);
     const int64_t begin = (int64_t)c * a.chunk_elems;
     int64_t end = begin + a.chunk_elems;
     if (end > a.V) end = a.V;

@@ -592,3 +592,23 @@ def test_rs_step_beyond_the_lds_tables(B, L, V):
     a = _run_rs("hip", B, L, V, 5, 0.5, None, torch.float32, 0.9, eos=3)
     b = _run_rs("hostsim", B, L, V, 5, 0.5, None, torch.float32, 0.9, eos=3)
     _assert_rs_equal(a, b, B)
+
+
+@GPU
+@pytest.mark.parametrize("env", [dict(JF_ARGMAX_REVERSE="1"), dict(JF_ARGMAX_REVERSE="2", JF_ARGMAX_ITEMS="4096"),
+                                 dict(JF_ARGMAX_WAVE="1", JF_ARGMAX_REVERSE="2"), dict(JF_ARGMAX_NT="0", JF_ARGMAX_CHUNK="4096")],
+                         ids=["rows-reversed", "chunk-major", "wave-chunk-major", "plain-small-chunks"])
+def test_argmax_is_invariant_under_the_launch_shape_knobs(env):
+    """The sweep overrides (item order, item count, per-wavefront items, load policy — read once per process) only change how
+    the vocabulary is walked: torch.argmax semantics stay, ties and a NaN row included."""
+    import os
+    import subprocess
+    import sys
+    code = ("import torch; from jacobiforcing_amd import ops; g = torch.Generator().manual_seed(3); "
+            "x = torch.randn(37, 152064, generator=g).to(torch.bfloat16); x[5, 777] = x[5, 151000] = 30.0; x[9, 4242] = float('nan'); "
+            "assert ops.argmax_rows(x.cuda()).cpu().tolist() == torch.argmax(x.float(), -1).tolist(); "
+            "y = torch.randn(700, 152064, generator=g).to(torch.bfloat16).cuda(); "
+            "assert torch.equal(ops.argmax_rows(y), torch.argmax(y.float(), -1)); print('ok')")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300,
+                       cwd=str(ROOT))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
