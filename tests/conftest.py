@@ -28,12 +28,12 @@ def mb_cases():
 
 @pytest.fixture(scope="session")
 def sb_cases():
-    return load_golden("sb_cases.json")
+    return load_golden("sb_cases.json") + load_golden("sb_cases_v2.json")
 
 
 @pytest.fixture(scope="session")
 def jd_cases():
-    return load_golden("jd_cases.json")
+    return load_golden("jd_cases.json") + load_golden("jd_cases_v2.json")
 
 
 @pytest.fixture(scope="session")

@@ -860,6 +860,29 @@ def main():
         run_jdo_case("jdo2_bf16_hot_T2", vocab=48, seeds=[150], robust=100, prompt_lens=[6], block_len=8, max_tokens=16,
                      temperature=2.0, logits_dtype="bf16", rng_seed=36),
     ]
+    # round 2: seeded sweeps of the single-block function and the engine decoder (the first sets are hand-picked and small)
+    sbs2 = []
+    for sd in range(200, 216):
+        rr = random.Random(sd)
+        n = rr.choice([4, 8, 16, 16, 32, 64])
+        pl = rr.randint(3, 30)
+        sbs2.append(run_sb_case(f"sb2_rand_{sd}", vocab=rr.choice([32, 64, 500]), seed=sd, robust=rr.choice([20, 50, 80, 100]),
+                                prompt_len=pl, n=n, eos_pos=rr.choice([None, None, pl + rr.randint(0, 3 * n)]), max_calls=4))
+    jds2 = []
+    for sd in range(300, 312):
+        rr = random.Random(sd)
+        B = rr.choice([1, 2, 3, 5, 8])
+        same = rr.random() < 0.5
+        L0 = rr.choice([4, 8, 16, 32, 64])
+        bls = [L0 if same else rr.choice([4, 8, 16, 32]) for _ in range(B)]
+        pls = [rr.choice([rr.randint(3, 40), rr.randint(250, 262)]) if rr.random() < 0.25 else rr.randint(3, 40) for _ in range(B)]
+        mts = [rr.randint(6, 90) for _ in range(B)]
+        eps = [(pl + rr.randint(0, 40)) if rr.random() < 0.35 else None for pl in pls]
+        jds2.append(run_jd_case(f"jd2_rand_{sd}", vocab=rr.choice([48, 64, 300]), seeds=[1000 + 10 * sd + i for i in range(B)],
+                                robust=rr.choice([0, 30, 60, 85, 100]), prompt_lens=pls, block_lens=bls, max_tokens=mts,
+                                eos_pos=eps if any(e is not None for e in eps) else None,
+                                use_prefill_draft=rr.random() < 0.7, pad_seed=500 + sd, batch=(B > 1) or rr.random() < 0.5,
+                                max_iters=rr.choice([128, 128, 128, 3])))
     smx = run_softmax_vectors()
     kv = run_argmax_vectors()
     slots = run_slot_pattern_vectors()
@@ -877,6 +900,8 @@ def main():
     dump("jd_cases.json", jds)
     dump("jdn_cases.json", jdns)
     dump("jdo_cases.json", jdos)
+    dump("sb_cases_v2.json", sbs2)
+    dump("jd_cases_v2.json", jds2)
     dump("jdn_cases_v2.json", jdns2)
     dump("jdo_cases_v2.json", jdos2)
     dump("softmax_vectors.json", smx)

@@ -16,7 +16,7 @@ from oracle.scripted_model import ScriptedModel
 from .backends import device_for, use_backend
 from .conftest import load_golden
 
-JD = load_golden("jd_cases.json")
+JD = load_golden("jd_cases.json") + load_golden("jd_cases_v2.json")
 BACKENDS = [pytest.param("hostsim", id="hostsim"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
 
 

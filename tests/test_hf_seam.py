@@ -15,7 +15,7 @@ from .conftest import load_golden
 from .test_decoder_e2e import scratch_forward, tiny_model
 
 MB = load_golden("mb_cases.json")
-SB = load_golden("sb_cases.json")
+SB = load_golden("sb_cases.json") + load_golden("sb_cases_v2.json")
 BACKENDS = [pytest.param("hostsim", id="hostsim"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
 
 

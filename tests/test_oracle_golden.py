@@ -9,8 +9,8 @@ from oracle.scripted_model import ScriptedModel
 from .conftest import load_golden
 
 MB = load_golden("mb_cases.json")
-SB = load_golden("sb_cases.json")
-JD = load_golden("jd_cases.json")
+SB = load_golden("sb_cases.json") + load_golden("sb_cases_v2.json")
+JD = load_golden("jd_cases.json") + load_golden("jd_cases_v2.json")
 JDN = load_golden("jdn_cases.json") + load_golden("jdn_cases_v2.json")
 MBR = load_golden("mb_raises.json")
 SLOTS = load_golden("slot_cases.json")
