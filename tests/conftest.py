@@ -23,7 +23,7 @@ def load_golden(name: str):
 
 @pytest.fixture(scope="session")
 def mb_cases():
-    return load_golden("mb_cases.json")
+    return load_golden("mb_cases.json") + load_golden("mb_cases_v2.json")
 
 
 @pytest.fixture(scope="session")

@@ -860,6 +860,24 @@ def main():
         run_jdo_case("jdo2_bf16_hot_T2", vocab=48, seeds=[150], robust=100, prompt_lens=[6], block_len=8, max_tokens=16,
                      temperature=2.0, logits_dtype="bf16", rng_seed=36),
     ]
+    # round 2: the multiblock function at BASELINE's knobs (n = 32, K = 2, r = 0.85, pool = 4) over seeded acceptance
+    # patterns, plus a seeded sweep of the other knobs
+    mbs2 = []
+    for sd in range(400, 408):
+        rr = random.Random(sd)
+        pl = rr.randint(6, 28)
+        mbs2.append(run_mb_case(f"mb2_baseline_{sd}", vocab=rr.choice([48, 200, 1000]), seed=sd, robust=rr.choice([35, 55, 75, 90]),
+                                prompt_len=pl, n=32, K=2, r=0.85, pool=4, period=rr.choice([0, 5, 9, 13]),
+                                eos_pos=rr.choice([None, None, pl + rr.randint(20, 90)]), max_calls=3))
+    for sd in range(408, 416):
+        rr = random.Random(sd)
+        n = rr.choice([8, 16, 24, 48])
+        pl = rr.randint(4, 20)
+        mbs2.append(run_mb_case(f"mb2_rand_{sd}", vocab=rr.choice([24, 64, 300]), seed=sd, robust=rr.choice([25, 50, 70, 95]),
+                                prompt_len=pl, n=n, K=rr.choice([1, 2, 2]), r=rr.choice([0.25, 0.6, 0.85, 1.0]),
+                                pool=rr.choice([0, 1, 2, 4, 8]), period=rr.choice([0, 0, 3, 7]),
+                                lookahead=rr.choice([0.0, 0.0, 0.4]),
+                                eos_pos=rr.choice([None, None, pl + rr.randint(0, 3 * n)]), max_calls=3))
     # round 2: seeded sweeps of the single-block function and the engine decoder (the first sets are hand-picked and small)
     sbs2 = []
     for sd in range(200, 216):
@@ -900,6 +918,7 @@ def main():
     dump("jd_cases.json", jds)
     dump("jdn_cases.json", jdns)
     dump("jdo_cases.json", jdos)
+    dump("mb_cases_v2.json", mbs2)
     dump("sb_cases_v2.json", sbs2)
     dump("jd_cases_v2.json", jds2)
     dump("jdn_cases_v2.json", jdns2)

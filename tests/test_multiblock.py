@@ -16,7 +16,7 @@ from oracle.scripted_model import ScriptedModel
 from .backends import device_for, use_backend
 from .conftest import load_golden
 
-MB = load_golden("mb_cases.json")
+MB = load_golden("mb_cases.json") + load_golden("mb_cases_v2.json")
 MBR = load_golden("mb_raises.json")
 
 BACKENDS = [pytest.param("hostsim", id="hostsim"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]

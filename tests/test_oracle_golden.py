@@ -8,7 +8,7 @@ from oracle.scripted_model import ScriptedModel
 
 from .conftest import load_golden
 
-MB = load_golden("mb_cases.json")
+MB = load_golden("mb_cases.json") + load_golden("mb_cases_v2.json")
 SB = load_golden("sb_cases.json") + load_golden("sb_cases_v2.json")
 JD = load_golden("jd_cases.json") + load_golden("jd_cases_v2.json")
 JDN = load_golden("jdn_cases.json") + load_golden("jdn_cases_v2.json")
