@@ -27,6 +27,8 @@ def main():
     from jacobiforcing_amd.modeling.qwen2 import Qwen2Config, Qwen2Model, Qwen2Weights
     from jacobiforcing_amd.synthetic import ScriptedAcceptance, humaneval_shaped_prompts
     lib = _native.load()
+    if not hasattr(lib, "jf_exp_read_trace"):
+        raise SystemExit("this tool needs the experiment build (-DJF_EXP_MB_TRACE, see the header of this file) selected with JF_LIB=...")
     lib.jf_exp_read_trace.argtypes = [ctypes.c_void_p]
     dev = torch.device("cuda:0")
     cfg = Qwen2Config.qwen2_5_coder_7b()
