@@ -78,6 +78,7 @@ class MultiblockJacobiDecoder:
         self.compact_logits = bool(compact_logits)   # lm_head + argmax on draft-carrying positions only (no padding rows)
         self.logit_align = int(logit_align) if logit_align else self.t_align   # lm_head M rounded up to this multiple
         self.kv_len_host = np.zeros(self.P, dtype=np.int64)
+        self._kv_len_pin = torch.zeros((self.P,), dtype=torch.int32, pin_memory=self.device.type == "cuda")
         self.forwards = 0
         self.last_logits_rows = 0
         self.last_valid_rows = 0             # sum_p B_p * T_p of the last forward (algorithmic rows, without padding)
@@ -122,7 +123,7 @@ class MultiblockJacobiDecoder:
                 ngrams[r] = ops.argmax_rows(lg).cpu().tolist()
                 self.kv_len_host[r] = len(prompts[r])
             i = j
-        self.cache.kv_len.copy_(torch.from_numpy(self.kv_len_host.astype(np.int32)))
+        self._push_kv_len()
         return ngrams
 
     # ------------------------------------------------------------------------------ one Jacobi iteration
@@ -176,8 +177,14 @@ class MultiblockJacobiDecoder:
             prof.tokens += int(d[:, self._f["accepted"]].sum())
         act = B > 0
         self.kv_len_host[act] = d[act, self._f["kv_len"]]
-        self.cache.kv_len.copy_(torch.from_numpy(self.kv_len_host.astype(np.int32)), non_blocking=True)
+        self._push_kv_len()
         return d
+
+    def _push_kv_len(self) -> None:
+        """Committed lengths to the device through a pinned staging buffer (asynchronous: every caller sits behind the
+        descriptor read-back's stream sync, so the buffer is never rewritten under a copy in flight)."""
+        self._kv_len_pin.copy_(torch.from_numpy(self.kv_len_host.astype(np.int32)))
+        self.cache.kv_len.copy_(self._kv_len_pin, non_blocking=True)
 
     # ------------------------------------------------------------------------------ streaming (applications/)
     def generate_stream(self, prompts, **kw):
@@ -262,7 +269,7 @@ class MultiblockJacobiDecoder:
                         restart[p] = r["kv_len"]
                 if active.any():
                     d = self.batch.begin(torch.from_numpy(inputs), torch.from_numpy(restart))
-                    self.cache.kv_len.copy_(torch.from_numpy(self.kv_len_host.astype(np.int32)), non_blocking=True)
+                    self._push_kv_len()
             if max_iterations is not None and iters_total >= max_iterations:
                 break
         if self.device.type == "cuda":
