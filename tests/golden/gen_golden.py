@@ -901,6 +901,29 @@ def main():
                                 eos_pos=eps if any(e is not None for e in eps) else None,
                                 use_prefill_draft=rr.random() < 0.7, pad_seed=500 + sd, batch=(B > 1) or rr.random() < 0.5,
                                 max_iters=rr.choice([128, 128, 128, 3])))
+    # round 2: seeded sweeps of the two sampling decoders, alternating float32 / bfloat16 logits
+    jdns3, jdos3 = [], []
+    for sd in range(500, 510):
+        rr = random.Random(sd)
+        B = rr.choice([1, 2, 4, 6])
+        pls = [rr.randint(4, 24) for _ in range(B)]
+        L = rr.choice([8, 16, 32])
+        jdns3.append(run_jdn_case(f"jdn3_rand_{sd}", vocab=rr.choice([64, 300, 1000]), seeds=[2000 + 10 * sd + i for i in range(B)],
+                                  robust=rr.choice([50, 70, 90]), prompt_lens=pls, block_len=L, max_tokens=rr.randint(12, 3 * L),
+                                  temperature=rr.choice([0.5, 0.8, 1.0, 1.0, 1.4]),
+                                  eos_pos=[(pl + rr.randint(2, 40)) if rr.random() < 0.3 else None for pl in pls] if rr.random() < 0.5 else None,
+                                  rng_seed=100 + sd, batch=B > 1, logits_dtype="bf16" if sd % 2 else "f32",
+                                  peak=rr.choice([3.0, 5.0, 8.0])))
+    for sd in range(520, 526):
+        rr = random.Random(sd)
+        B = rr.choice([1, 2, 3])
+        pls = [rr.randint(4, 16) for _ in range(B)]
+        L = rr.choice([8, 16, 32])
+        jdos3.append(run_jdo_case(f"jdo3_rand_{sd}", vocab=rr.choice([64, 200, 1000]), seeds=[3000 + 10 * sd + i for i in range(B)],
+                                  robust=rr.choice([60, 80, 95]), prompt_lens=pls, block_len=L, max_tokens=rr.randint(10, 2 * L + 8),
+                                  temperature=rr.choice([0.6, 1.0, 1.3]), max_blocks=rr.choice([128, 128, 2]),
+                                  eos_pos=[(pl + rr.randint(2, 30)) if rr.random() < 0.4 else None for pl in pls],
+                                  rng_seed=200 + sd, logits_dtype="bf16" if sd % 2 else "f32", peak=rr.choice([4.0, 6.0, 8.0])))
     smx = run_softmax_vectors()
     kv = run_argmax_vectors()
     slots = run_slot_pattern_vectors()
@@ -921,6 +944,8 @@ def main():
     dump("mb_cases_v2.json", mbs2)
     dump("sb_cases_v2.json", sbs2)
     dump("jd_cases_v2.json", jds2)
+    dump("jdn_cases_v3.json", jdns3)
+    dump("jdo_cases_v3.json", jdos3)
     dump("jdn_cases_v2.json", jdns2)
     dump("jdo_cases_v2.json", jdos2)
     dump("softmax_vectors.json", smx)

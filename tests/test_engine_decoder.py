@@ -111,8 +111,8 @@ def test_constructor_errors():
 # ----------------------------------------------------------------------------- non-greedy (rejection sampling)
 from jacobiforcing_amd.engine.jacobi_decoding_nongreedy import JacobiDecoderNonGreedy  # noqa: E402
 
-JDN = load_golden("jdn_cases.json") + load_golden("jdn_cases_v2.json")
-JDO = load_golden("jdo_cases.json") + load_golden("jdo_cases_v2.json")
+JDN = load_golden("jdn_cases.json") + load_golden("jdn_cases_v2.json") + load_golden("jdn_cases_v3.json")
+JDO = load_golden("jdo_cases.json") + load_golden("jdo_cases_v2.json") + load_golden("jdo_cases_v3.json")
 BMC = load_golden("bm_cases.json")
 TORCH_DTYPES = {"f32": torch.float32, "bf16": torch.bfloat16}
 

@@ -11,10 +11,10 @@ from .conftest import load_golden
 MB = load_golden("mb_cases.json") + load_golden("mb_cases_v2.json")
 SB = load_golden("sb_cases.json") + load_golden("sb_cases_v2.json")
 JD = load_golden("jd_cases.json") + load_golden("jd_cases_v2.json")
-JDN = load_golden("jdn_cases.json") + load_golden("jdn_cases_v2.json")
+JDN = load_golden("jdn_cases.json") + load_golden("jdn_cases_v2.json") + load_golden("jdn_cases_v3.json")
 MBR = load_golden("mb_raises.json")
 SLOTS = load_golden("slot_cases.json")
-JDO = load_golden("jdo_cases.json") + load_golden("jdo_cases_v2.json")
+JDO = load_golden("jdo_cases.json") + load_golden("jdo_cases_v2.json") + load_golden("jdo_cases_v3.json")
 SMX = load_golden("softmax_vectors.json")
 
 
