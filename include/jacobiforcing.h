@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define JF_VERSION 200
+#define JF_VERSION 300
 
 enum {
     JF_OK = 0,
@@ -179,6 +179,94 @@ JF_API int jf_mb_verify(const void *logits, int dtype, int64_t R, int64_t V, int
                  int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len, int32_t Tpad,
                  const int32_t *row_prompt, int32_t *arrive, jf_mb_desc *desc, const jf_mb_params *params,
                  void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The loop around the step (jf_mb_loop_*): everything between two forwards without a host round trip on the critical
+ * path.  The reference's driver (JacobiForcing/jacobi_forcing_inference_MR_humaneval.py:152-273 = DRV) and its function
+ * (MB:413-721) go back to Python after every iteration (6-10 host syncs) and after every call (DRV:206-250).
+ * Here one launch (jf_mb_verify's, or jf_mb_step's when the fused launch does not apply)
+ *   - runs the loop body of every prompt,
+ *   - writes each prompt's committed KV length where the forward reads it (kv_len, replaces MB:36-59's trims),
+ *   - with a resident driver block per prompt: ends the call (DRV:232-250: text += ret, stop on EOS / max_new_tokens /
+ *     max_calls), and begins the next one with [first_correct_token] + n-1 tokens drawn from the text (DRV:209-215),
+ *   - and the LAST prompt to finish publishes a summary of the next forward + the descriptor table to a mailbox in mapped
+ *     pinned host memory, stamped with a sequence number (system-scope release): the host polls that word instead of
+ *     copying descriptors and synchronising the stream.
+ * A pack launch queued right behind it (row length chosen on the device) writes the next forward's inputs while the host is
+ * still waking up.
+ */
+enum {  /* mailbox layout (int32): header, then P descriptors (16 ints each), then P driver records (JF_MB_FIN_INTS each) */
+    JF_MB_SEQ = 0,        /* written last: the sequence number passed to the call                            */
+    JF_MB_RTOT = 1,       /* rows of the next forward (sum of B)                                             */
+    JF_MB_RMAIN = 2,      /* prompts with rows (= rows that use the main cache; they come first, order 1)    */
+    JF_MB_TPAD = 3,       /* padded row length the pack step uses                                            */
+    JF_MB_TMAX = 4,       /* longest row                                                                     */
+    JF_MB_NVALID = 5,     /* positions that carry a draft token (sum of B*T)                                 */
+    JF_MB_NVALID_PAD = 6, /* ... rounded up to valid_align: rows of the compacted logits                     */
+    JF_MB_NDONE = 7,      /* prompts whose descriptor says done                                              */
+    JF_MB_MAXKV = 8,      /* largest committed length among prompts with rows                                */
+    JF_MB_ERROR = 9,      /* 0, or 1 + the first prompt whose descriptor carries an error                    */
+    JF_MB_ACCEPTED = 10,  /* sum of desc.accepted                                                            */
+    JF_MB_NCALL_END = 11, /* prompts whose call ended in this launch (resident driver)                       */
+    JF_MB_MAILBOX_HDR = 16,
+    JF_MB_FIN_INTS = 8    /* per prompt: stop, calls, total iterations, new tokens, last ret_len, last next_token, last iters, text offset of last ret */
+};
+#define JF_MB_MAILBOX_INTS(P) (JF_MB_MAILBOX_HDR + (P) * (16 + JF_MB_FIN_INTS))
+
+enum {  /* resident driver block of one prompt (int32): header, then the text (prompt + generated tokens) */
+    JF_DRV_ACTIVE = 0,    /* 1 while the prompt keeps starting calls                                         */
+    JF_DRV_STOP = 1,      /* JF_STOP_* once it stopped                                                       */
+    JF_DRV_CALLS = 2,     /* calls so far (the prefill counts as one, DRV:234)                               */
+    JF_DRV_ITERS = 3,     /* total Jacobi iterations of the finished calls                                   */
+    JF_DRV_NEW = 4,       /* generated tokens (len(generated) - prompt)                                      */
+    JF_DRV_BUDGET = 5,    /* max_new_tokens                                                                  */
+    JF_DRV_MAX_CALLS = 6,
+    JF_DRV_TEXT_LEN = 7,  /* tokens in the text                                                              */
+    JF_DRV_CURSOR = 8,    /* next word of this prompt's draw stream                                          */
+    JF_DRV_FIN_RET_LEN = 9, JF_DRV_FIN_NEXT = 10, JF_DRV_FIN_ITERS = 11, JF_DRV_FIN_OFF = 12,   /* the last finished call */
+    JF_DRV_HDR_INTS = 16
+};
+enum { JF_STOP_NONE = 0, JF_STOP_EOS = 1, JF_STOP_MAX_NEW_TOKENS = 2, JF_STOP_MAX_CALLS = 3, JF_STOP_MAX_SEQ_LEN = 4,
+       JF_STOP_TEXT_FULL = 5 };
+
+typedef struct jf_mb_loop {
+    /* the state machines (same objects as jf_mb_begin / jf_mb_step / jf_mb_verify take) */
+    int32_t *states; int64_t state_ints; int32_t P; int32_t order;   /* order: row order of the pack step, 0 prompt-major, 1 row 0 of every prompt first */
+    uint64_t *packed; int64_t packed_cap;        /* argmax workspace, zero; capacity in entries                  */
+    int32_t *arrive;                              /* [P * 64] zero (jf_mb_verify)                                 */
+    jf_mb_desc *desc;                             /* [P]                                                          */
+    /* forward inputs, written by the pack step: capacity rows_cap x t_cap tokens                                  */
+    int64_t *input_ids; int32_t *positions; int32_t *row_prompt; int32_t *row_len;
+    int32_t *row_cand;                            /* [rows] -1 = the row writes the main cache, else p * cand_rows + b - 1 */
+    int32_t *row_kv_len;                          /* [rows] committed prefix length of the row's prompt           */
+    int32_t *valid_index;                         /* nullable: compacted position list (see jf_mb_pack)           */
+    int32_t rows_cap, t_cap, t_align, valid_align, cand_rows, rsv0;
+    int64_t pad_fill;
+    int32_t *kv_len;                              /* nullable [P]: committed length per prompt (the cache's)      */
+    int32_t *mailbox;                             /* JF_MB_MAILBOX_INTS(P) ints of MAPPED PINNED HOST memory (jf_host_alloc) */
+    int32_t *sync;                                /* [4] device ints, zero                                        */
+    /* resident driver (all nullable / 0: the caller restarts calls itself with jf_mb_loop_begin)                  */
+    int32_t *drv; int64_t drv_ints;               /* [P, drv_ints]: JF_DRV_HDR_INTS + text capacity               */
+    const uint32_t *draws; int32_t draw_len;      /* [P, draw_len] pre-drawn 32-bit words                         */
+    int32_t max_seq_len;                          /* positions a cache row holds (JF_STOP_MAX_SEQ_LEN)            */
+} jf_mb_loop;
+
+/* Mapped, coherent pinned host memory for the mailbox (the one allocation of this library; done once at start-up). */
+JF_API int jf_host_alloc(size_t bytes, void **out);
+JF_API int jf_host_free(void *p);
+/* Host side of the hand-off: spin until mailbox[JF_MB_SEQ] == seq (acquire).  Gives up with JF_E_LAUNCH after timeout_us, or
+ * when `stream` has drained and the word still has not arrived (a launch that failed). */
+JF_API int jf_mailbox_wait(const int32_t *mailbox, int32_t seq, int64_t timeout_us, void *stream);
+
+/* jf_mb_begin for the loop: begin / keep / retire the prompts (kv_len as in jf_mb_begin), write loop->kv_len, publish
+ * (sequence number seq), then the pack step. */
+JF_API int jf_mb_loop_begin(const jf_mb_loop *loop, int32_t seq, const jf_mb_params *params, const int64_t *input_ids,
+                     const int32_t *kv_len, void *stream);
+/* One iteration after the forward: the convergence check + loop body of every prompt (jf_mb_verify's launch, same logits
+ * contract: rows follow valid_index when `compacted`, else the Rtot x Tpad rectangle; Rtot / Tpad are the mailbox's),
+ * then the pack step of the next forward.  jf_kv_commit (when candidate rows ran) may follow on the same stream. */
+JF_API int jf_mb_loop_iterate(const jf_mb_loop *loop, int32_t seq, const void *logits, int dtype, int64_t R, int64_t V,
+                       int64_t row_stride, int compacted, int32_t Rtot, int32_t Tpad, const jf_mb_params *params, void *stream);
 
 /* Copy results of finished calls: ret [P, ret_cap] int64 (ret_len in desc). */
 JF_API int jf_mb_read_ret(const int32_t *states, int64_t state_ints, int P, int64_t *ret, int32_t ret_cap,

@@ -35,6 +35,34 @@ DESC_INTS = C.sizeof(MbDesc) // 4
 DESC_FIELDS = [f[0] for f in MbDesc._fields_]
 
 
+class MbLoop(C.Structure):
+    """jf_mb_loop (include/jacobiforcing.h): the pointers of the loop around the step, filled once."""
+    _fields_ = [("states", C.c_void_p), ("state_ints", C.c_int64), ("P", C.c_int32), ("order", C.c_int32),
+                ("packed", C.c_void_p), ("packed_cap", C.c_int64), ("arrive", C.c_void_p), ("desc", C.c_void_p),
+                ("input_ids", C.c_void_p), ("positions", C.c_void_p), ("row_prompt", C.c_void_p), ("row_len", C.c_void_p),
+                ("row_cand", C.c_void_p), ("row_kv_len", C.c_void_p), ("valid_index", C.c_void_p),
+                ("rows_cap", C.c_int32), ("t_cap", C.c_int32), ("t_align", C.c_int32), ("valid_align", C.c_int32),
+                ("cand_rows", C.c_int32), ("rsv0", C.c_int32), ("pad_fill", C.c_int64),
+                ("kv_len", C.c_void_p), ("mailbox", C.c_void_p), ("sync", C.c_void_p),
+                ("drv", C.c_void_p), ("drv_ints", C.c_int64), ("draws", C.c_void_p), ("draw_len", C.c_int32),
+                ("max_seq_len", C.c_int32)]
+
+
+# mailbox header slots / per-prompt driver record / driver block header (include/jacobiforcing.h)
+MB_SEQ, MB_RTOT, MB_RMAIN, MB_TPAD, MB_TMAX, MB_NVALID, MB_NVALID_PAD, MB_NDONE, MB_MAXKV, MB_ERROR, MB_ACCEPTED, MB_NCALL_END = range(12)
+MB_MAILBOX_HDR, MB_FIN_INTS = 16, 8
+FIN_FIELDS = ["stop", "calls", "iters_total", "new_tokens", "ret_len", "next_token", "iters", "text_off"]
+DRV_FIELDS = ["active", "stop", "calls", "iters_total", "new_tokens", "budget", "max_calls", "text_len", "cursor", "fin_ret_len",
+              "fin_next", "fin_iters", "fin_off"]
+DRV_HDR_INTS = 16
+STOP_REASONS = {0: None, 1: "eos", 2: "max_new_tokens", 3: "max_calls", 4: "max_seq_len", 5: "max_seq_len"}
+EVT_SPAWN, EVT_SWITCH, EVT_EARLY, EVT_CALL_END, EVT_STOPPED = 1, 2, 4, 8, 16
+
+
+def mailbox_ints(P: int) -> int:
+    return MB_MAILBOX_HDR + int(P) * (DESC_INTS + MB_FIN_INTS)
+
+
 class EngineRow(C.Structure):
     _fields_ = [("acc_len", C.c_int32), ("n_new", C.c_int32), ("eos", C.c_int32), ("active_next", C.c_int32),
                 ("n_pads", C.c_int32), ("rsv", C.c_int32 * 3)]
@@ -84,6 +112,12 @@ _SIGNATURES = {
     "jf_mb_verify": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _vp, _vp, _i64, C.c_int, _vp, _i64, _i32, _vp, _vp, _vp,
                                C.POINTER(MbParams), _vp]),
     "jf_mb_read_ret": (C.c_int, [_vp, _i64, C.c_int, _vp, _i32, _vp]),
+    "jf_host_alloc": (C.c_int, [_sz, C.POINTER(C.c_void_p)]),
+    "jf_host_free": (C.c_int, [_vp]),
+    "jf_mailbox_wait": (C.c_int, [_vp, _i32, _i64, _vp]),
+    "jf_mb_loop_begin": (C.c_int, [C.POINTER(MbLoop), _i32, C.POINTER(MbParams), _vp, _vp, _vp]),
+    "jf_mb_loop_iterate": (C.c_int, [C.POINTER(MbLoop), _i32, _vp, C.c_int, _i64, _i64, _i64, C.c_int, _i32, _i32,
+                                     C.POINTER(MbParams), _vp]),
     "jf_kv_append": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i32, _vp]),
     "jf_rope_kv_append": (C.c_int, [_vp, C.c_int, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
                                     _vp, _i64, _vp]),

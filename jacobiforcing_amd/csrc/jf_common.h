@@ -67,6 +67,13 @@ struct DevLanes {
         const unsigned long long m = __ballot(pred);
         return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
     }
+    // every lane's earlier stores become visible to the HOST, then one word is released (mailbox hand-off; the word may
+    // live in mapped pinned host memory).  The lanes are ONE wavefront: its stores are issued in program order, the
+    // system-scope release fence drains them, no barrier is involved.
+    __device__ __forceinline__ void publish(int32_t *word, int32_t v) const {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        if (lane() == 0) __hip_atomic_store(word, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 };
 
 // one wavefront that is the only live wavefront of a larger workgroup (the steppers of jf_mb_verify): a phase boundary is a

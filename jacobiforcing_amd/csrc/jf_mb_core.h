@@ -38,11 +38,14 @@ enum : int {
     H_RET_EARLY, H_ERR, H_PROMPT_LEN, H_KV_LEN, H_POOL_COUNT, H_POOL_HEAD,
     H_RET_LEN, H_NEXT_TOK, H_B, H_T, H_NSPANS, H_ROW_BASE, H_TPAD,
     H_LOOK_THR,              // smallest block total t with (double)t / n >= lookahead_start_ratio (MB:577), INT32_MAX if none
+    H_CAND_BASE,             // forward row of this prompt's candidate row 1 (row 0 sits at H_ROW_BASE); set by the pack step
     H_SPANS = 40             // 3 ints per span (block, start, L), NB spans follow the fixed header
 };
 constexpr int MAX_NB = 4096; // sanity bound only; the block lists can grow by one entry per iteration (Q3/Q4 with K >= 3)
 
-enum : int { EVT_SPAWN = 1, EVT_SWITCH = 2, EVT_EARLY = 4 };
+enum : int { EVT_SPAWN = 1, EVT_SWITCH = 2, EVT_EARLY = 4,
+             EVT_CALL_END = 8,     // resident driver: a generation call ended in this step (its results are in the driver block)
+             EVT_STOPPED = 16 };   // resident driver: ... and the prompt stopped (EOS / budget / calls / cache row full)
 
 struct Layout {
     int n, NB, RMAX, TMAX, LPOOL, pool_size;
@@ -243,8 +246,9 @@ struct Machine {
     }
 
     // ---- start of a call: MB:230-262 ------------------------------------------------------------
+    // look_thr_known: H_LOOK_THR of an earlier call with the same parameters (rolling restarts skip the search below)
     template <class TokFn>
-    JF_HD void begin(const jf_mb_params &p, TokFn input_tok, int kv0, jf_mb_desc *d) {
+    JF_HD void begin(const jf_mb_params &p, TokFn input_tok, int kv0, jf_mb_desc *d, int look_thr_known = -1) {
         fill(S, 0, L.hdr_ints);                              // header + span table (3 ints per possible block), lanes in parallel
         lanes.sync();
         if (lanes.lane() == 0) {
@@ -254,8 +258,11 @@ struct Machine {
             union { double d; int32_t i[2]; } u; u.d = p.lookahead_start_ratio;
             S[H_LOOK_LO] = u.i[0]; S[H_LOOK_HI] = u.i[1];
             // MB:577 compares total_accepted / n >= ratio in double: monotone in the total, so the step compares integers
-            int thr = INT32_MAX;
-            for (int t = 2 * p.n + 2; t >= 0; --t) if ((double)t / (double)p.n >= p.lookahead_start_ratio) thr = t;
+            int thr = look_thr_known;
+            if (thr < 0) {
+                thr = INT32_MAX;
+                for (int t = 2 * p.n + 2; t >= 0; --t) if ((double)t / (double)p.n >= p.lookahead_start_ratio) thr = t;
+            }
             S[H_LOOK_THR] = thr;
             S[H_NUM_BLOCKS] = 1; S[H_ACTIVE] = 1; S[H_RA] = 0; S[H_LEN_LISTS] = 1;
             S[H_LNT] = -1; S[H_HAS_LNT] = 0; S[H_PROMPT_LEN] = kv0; S[H_KV_LEN] = kv0; S[H_NEXT_TOK] = -1;
@@ -584,73 +591,261 @@ namespace jfmb {
 
 JF_HD int decode_packed(uint64_t v) { return (int)(~(uint32_t)(v & 0xFFFFFFFFull)); }
 
+// ---- the loop around a step (jf_mb_loop_*): device-side views ----------------------------------------
+// Resident driver block of one prompt (int32, caller-allocated, layout part of the ABI: include/jacobiforcing.h JF_DRV_*):
+// the reference driver's per-prompt bookkeeping (JacobiForcing/jacobi_forcing_inference_MR_humaneval.py:152-273 = DRV) kept
+// next to the state machine so that a finished call restarts without a host round trip.
+enum : int { D_ACTIVE = JF_DRV_ACTIVE, D_STOP = JF_DRV_STOP, D_CALLS = JF_DRV_CALLS, D_ITERS = JF_DRV_ITERS, D_NEW = JF_DRV_NEW,
+             D_BUDGET = JF_DRV_BUDGET, D_MAX_CALLS = JF_DRV_MAX_CALLS, D_TEXT_LEN = JF_DRV_TEXT_LEN, D_CURSOR = JF_DRV_CURSOR,
+             D_FIN_RET_LEN = JF_DRV_FIN_RET_LEN, D_FIN_NEXT = JF_DRV_FIN_NEXT, D_FIN_ITERS = JF_DRV_FIN_ITERS,
+             D_FIN_OFF = JF_DRV_FIN_OFF, D_HDR = JF_DRV_HDR_INTS };
+
+struct LoopDev {                   // what a step needs beyond the state block (all nullable / zero = classic jf_mb_step)
+    int32_t *kv_len;               // [P] committed length per prompt, written by every begin / step
+    int32_t *mailbox;              // host-visible summary + descriptor table (JF_MB_MAILBOX_*), written by the last prompt to finish
+    int32_t *sync;                 // [0] prompts finished in this launch (returns to zero)
+    int32_t seq;                   // sequence number the mailbox is stamped with
+    int32_t t_align, t_cap, valid_align;
+    int32_t *drv;                  // [P, drv_ints] resident driver blocks (nullable)
+    int64_t drv_ints;
+    const uint32_t *draws;         // [P, draw_len] pre-drawn 32-bit words for the restart drafts (DRV:209-215's random.choice)
+    int32_t draw_len, text_cap, max_seq_len;
+    jf_mb_params prm;              // parameters of the calls (restarts begin with them)
+};
+
+JF_HD int32_t align_up(int32_t v, int32_t a) { return a > 1 ? (v + a - 1) / a * a : v; }
+
+inline LoopDev make_loop_dev(const jf_mb_loop *lp, int32_t seq, const jf_mb_params *params) {
+    LoopDev d{};
+    d.kv_len = lp->kv_len; d.mailbox = lp->mailbox; d.sync = lp->sync; d.seq = seq;
+    d.t_align = lp->t_align < 1 ? 1 : lp->t_align; d.t_cap = lp->t_cap; d.valid_align = lp->valid_align < 1 ? 1 : lp->valid_align;
+    d.drv = lp->drv; d.drv_ints = lp->drv_ints; d.draws = lp->draws; d.draw_len = lp->draw_len;
+    d.text_cap = lp->drv ? (int32_t)(lp->drv_ints - JF_DRV_HDR_INTS) : 0; d.max_seq_len = lp->max_seq_len;
+    d.prm = *params;
+    return d;
+}
+
+// DRV:152-160, 232-250 at the end of a call + DRV:206-215 the next call's input, for one prompt whose machine `m` has just
+// finished a call (m.done, no error).  Results of the finished call go to the driver block; the state machine is begun
+// again in place unless the prompt stops.  `d` keeps this step's KV-copy triple / accepted count (the forward it describes
+// has already happened) and carries the new call's B and T.
+template <class M>
+JF_HD void drv_call_end(M &m, const LoopDev &lp, int p, jf_mb_desc *d) {
+    int32_t *D = lp.drv + (int64_t)p * lp.drv_ints;
+    int32_t *text = D + D_HDR;
+    int32_t *S = m.S;
+    const int n = lp.prm.n;
+    const int ret_len = S[H_RET_LEN], next_tok = S[H_NEXT_TOK], iters = m.iters, kv = m.kv_len;
+    const int ev = m.events, acc = m.ra_accepted, ksr = m.kv_src_row, kcd = m.kv_copy_dst, kcl = m.kv_copy_len;
+    const int old_len = D[D_TEXT_LEN], cursor = D[D_CURSOR];
+    const int calls = D[D_CALLS] + 1, it_total = D[D_ITERS] + iters, new_total = D[D_NEW] + ret_len;
+    const int budget = D[D_BUDGET], max_calls = D[D_MAX_CALLS];
+    const int32_t *ret = m.ret();
+    const bool fits = old_len + ret_len <= lp.text_cap;
+    if (fits) m.copy(text + old_len, ret, ret_len);                              // generated_ids += ret (DRV:236)
+    const bool has_eos = m.eos >= 0 && m.find_first_eq(ret, ret_len, m.eos) < ret_len;   // DRV:154-160
+    int stop = 0;
+    if (!fits) stop = JF_STOP_TEXT_FULL;
+    else if (has_eos) stop = JF_STOP_EOS;
+    else if (new_total >= budget) stop = JF_STOP_MAX_NEW_TOKENS;
+    else if (calls >= max_calls) stop = JF_STOP_MAX_CALLS;
+    else if (kv + n * (lp.prm.K + 1) + lp.t_cap > lp.max_seq_len) stop = JF_STOP_MAX_SEQ_LEN;   // the next call could outgrow the cache row
+    const int new_len = fits ? old_len + ret_len : old_len;
+    m.lanes.sync();
+    if (m.lanes.lane() == 0) {
+        D[D_CALLS] = calls; D[D_ITERS] = it_total; D[D_NEW] = new_total; D[D_TEXT_LEN] = new_len;
+        D[D_FIN_RET_LEN] = ret_len; D[D_FIN_NEXT] = next_tok; D[D_FIN_ITERS] = iters; D[D_FIN_OFF] = old_len;
+        D[D_STOP] = stop; D[D_ACTIVE] = stop ? 0 : 1;
+        if (!stop) D[D_CURSOR] = (cursor + n - 1) % lp.draw_len;
+    }
+    int new_events = 0;
+    if (!stop) {
+        // next input = [first_correct_token] + n-1 tokens drawn from the text so far (DRV:209-215); draw k of this prompt
+        // is text[(u_k * len) >> 32] with u_k the k-th word of its pre-drawn stream
+        const uint32_t *u = lp.draws + (int64_t)p * lp.draw_len;
+        const int dl = lp.draw_len;
+        auto tok = [=](int i) -> int64_t {
+            if (i == 0) return next_tok;
+            const uint32_t w = u[(cursor + i - 1) % dl];
+            const int idx = (int)(((uint64_t)w * (uint64_t)(uint32_t)new_len) >> 32);
+            return idx < old_len ? text[idx] : ret[idx - old_len];
+        };
+        const int c_nb = S[H_NB], c_rmax = S[H_RMAX], c_tmax = S[H_TMAX], c_lpool = S[H_LPOOL], thr = S[H_LOOK_THR];
+        m.begin(lp.prm, tok, kv, d, thr);
+        new_events = m.events;
+        m.lanes.sync();
+        if (m.lanes.lane() == 0) {        // the block keeps the capacities it was allocated with (m may run on a compact image)
+            S[H_NB] = c_nb; S[H_RMAX] = c_rmax; S[H_TMAX] = c_tmax; S[H_LPOOL] = c_lpool;
+        }
+    }
+    m.lanes.sync();
+    if (d && m.lanes.lane() == 0) {
+        d->kv_src_row = ksr; d->kv_copy_dst = kcd; d->kv_copy_len = kcl; d->accepted = acc;
+        d->events = ev | new_events | EVT_CALL_END | (stop ? EVT_STOPPED : 0);
+        d->ret_len = ret_len; d->next_token = next_tok;
+    }
+    m.lanes.sync();
+}
+
+// Summary of the next forward + the descriptor table, written where the host polls for it (mapped pinned memory).  Run by
+// ONE prompt's lanes after every prompt of the launch has written its descriptor (the caller orders that).  The sequence
+// number goes last, behind a system-scope release.
+template <class Lanes>
+JF_HD void mb_publish_body(Lanes lanes, int P, const jf_mb_desc *desc, const LoopDev &lp) {
+    int rtot = 0, rmain = 0, tmax = 0, nvalid = 0, ndone = 0, maxkv = 0, err_p = 0, acc = 0, nend = 0;
+    for (int q = lanes.lane(); q < P; q += lanes.count()) {
+        const jf_mb_desc &d = desc[q];
+        if (d.B > 0) { rtot += d.B; rmain += 1; nvalid += d.B * d.T; tmax = imax(tmax, d.T); maxkv = imax(maxkv, d.kv_len); }
+        ndone += d.done ? 1 : 0;
+        acc += d.accepted;
+        nend += (d.events & EVT_CALL_END) ? 1 : 0;
+        if (d.error && (err_p == 0 || q + 1 < err_p)) err_p = q + 1;
+    }
+    rtot = lanes.reduce_sum(rtot); rmain = lanes.reduce_sum(rmain); nvalid = lanes.reduce_sum(nvalid);
+    ndone = lanes.reduce_sum(ndone); acc = lanes.reduce_sum(acc); nend = lanes.reduce_sum(nend);
+    tmax = -lanes.reduce_min(-tmax); maxkv = -lanes.reduce_min(-maxkv);
+    err_p = lanes.reduce_min(err_p ? err_p : INT32_MAX); if (err_p == INT32_MAX) err_p = 0;
+    int32_t *mb = lp.mailbox;
+    const int32_t *src = (const int32_t *)desc;
+    const int dints = (int)(sizeof(jf_mb_desc) / 4);
+    for (int i = lanes.lane(); i < P * dints; i += lanes.count()) mb[JF_MB_MAILBOX_HDR + i] = src[i];
+    if (lp.drv) {
+        int32_t *fin = mb + JF_MB_MAILBOX_HDR + P * dints;
+        for (int i = lanes.lane(); i < P * JF_MB_FIN_INTS; i += lanes.count()) {
+            const int q = i / JF_MB_FIN_INTS, j = i - q * JF_MB_FIN_INTS;
+            const int32_t *D = lp.drv + (int64_t)q * lp.drv_ints;
+            const int slot[JF_MB_FIN_INTS] = {D_STOP, D_CALLS, D_ITERS, D_NEW, D_FIN_RET_LEN, D_FIN_NEXT, D_FIN_ITERS, D_FIN_OFF};
+            fin[i] = D[slot[j]];
+        }
+    }
+    if (lanes.lane() == 0) {
+        const int tpad = rtot ? imin(align_up(tmax, lp.t_align), imax(lp.t_cap, tmax)) : 0;
+        mb[JF_MB_RTOT] = rtot; mb[JF_MB_RMAIN] = rmain; mb[JF_MB_TPAD] = tpad; mb[JF_MB_TMAX] = tmax;
+        mb[JF_MB_NVALID] = nvalid; mb[JF_MB_NVALID_PAD] = align_up(nvalid, lp.valid_align);
+        mb[JF_MB_NDONE] = ndone; mb[JF_MB_MAXKV] = maxkv; mb[JF_MB_ERROR] = err_p; mb[JF_MB_ACCEPTED] = acc; mb[JF_MB_NCALL_END] = nend;
+    }
+    lanes.publish(mb + JF_MB_SEQ, lp.seq);
+}
+
 template <class Lanes>
 JF_HD void mb_begin_body(Lanes lanes, int p, int32_t *states, int64_t state_ints, const jf_mb_params &prm,
-                         const int64_t *input_ids, const int32_t *kv_len, jf_mb_desc *desc) {
+                         const int64_t *input_ids, const int32_t *kv_len, jf_mb_desc *desc, int32_t *kv_len_out = nullptr) {
     int32_t *S = states + (int64_t)p * state_ints;
     Layout lay = make_layout(prm.n, prm.K, prm.pool_size, prm.max_blocks);
     Machine<Lanes> m(S, lanes, lay);
     const int64_t *in = input_ids + (int64_t)p * prm.n;
-    if (kv_len[p] == JF_MB_KEEP) return;                      // prompt keeps running its current call
+    if (kv_len[p] == JF_MB_KEEP) {                            // prompt keeps running its current call
+        if (desc && lanes.lane() == 0) { desc[p].events = 0; desc[p].accepted = 0; desc[p].kv_copy_len = 0; desc[p].kv_src_row = 0; }
+        return;
+    }
     m.begin(prm, [in](int i) { return in[i]; }, kv_len[p], desc ? desc + p : nullptr);
+    if (kv_len_out && lanes.lane() == 0 && kv_len[p] >= 0) kv_len_out[p] = kv_len[p];
 }
 
+// Forward inputs of the current iteration (MB:417-436).  B and T of every prompt come from the descriptors when given (one
+// contiguous table), else from the state blocks.
+//   order 0  rows prompt by prompt (row 0, then the prompt's candidate rows)
+//   order 1  row 0 of every prompt with rows first, in prompt order — when every prompt is running these ARE the cache rows
+//            in order and attend in place — then the candidate rows prompt by prompt (the only rows whose K/V prefix has
+//            to be gathered, MB:93-127's cost paid for those rows alone)
+//   Tpad_in > 0: row length chosen by the caller; else max T rounded up to t_align (at most t_cap unless a row is longer).
+struct PackOut {
+    int64_t *input_ids; int32_t *positions, *row_prompt, *row_len, *valid_index;
+    int32_t *row_cand, *row_kv;          // nullable: candidate scratch row (-1 = main cache) / committed prefix length of the row
+};
 template <class Lanes>
-JF_HD void mb_pack_body(Lanes lanes, int p, int P, int32_t *states, int64_t state_ints, int32_t Tpad, int64_t pad_fill,
-                        int64_t *input_ids, int32_t *positions, int32_t *row_prompt, int32_t *row_len,
-                        int32_t *valid_index, int32_t valid_align) {
+JF_HD void mb_pack_body(Lanes lanes, int p, int P, int32_t *states, int64_t state_ints, const jf_mb_desc *desc, int32_t Tpad_in,
+                        int32_t t_align, int32_t t_cap, int64_t pad_fill, int order, int32_t cand_rows, const PackOut &o,
+                        int32_t valid_align) {
     int32_t *S = states + (int64_t)p * state_ints;
-    int row_base = 0, valid_base = 0;                 // exclusive prefix over the prompts before this one, lanes in parallel
-    for (int q = lanes.lane(); q < p; q += lanes.count()) {
-        const int32_t *Q = states + (int64_t)q * state_ints;
-        row_base += Q[H_B];
-        valid_base += Q[H_B] * Q[H_T];
+    // exclusive prefixes over the prompts before this one and totals over all of them, lanes in parallel
+    int rows_b = 0, valid_b = 0, act_b = 0, act_t = 0, cand_b = 0, va_b = 0, va_t = 0, vb_b = 0, v_t = 0, tmax = 0;
+    for (int q = lanes.lane(); q < P; q += lanes.count()) {
+        int Bq, Tq;
+        if (desc) { Bq = desc[q].B; Tq = desc[q].T; }
+        else { const int32_t *Q = states + (int64_t)q * state_ints; Bq = Q[H_B]; Tq = Q[H_T]; }
+        if (Bq <= 0) continue;
+        const int before = q < p ? 1 : 0;
+        rows_b += before * Bq; valid_b += before * Bq * Tq;
+        act_b += before; act_t += 1;
+        cand_b += before * (Bq - 1);
+        va_b += before * Tq; va_t += Tq;
+        vb_b += before * (Bq - 1) * Tq;
+        v_t += Bq * Tq;
+        tmax = imax(tmax, Tq);
     }
-    row_base = lanes.reduce_sum(row_base);
-    valid_base = lanes.reduce_sum(valid_base);
+    rows_b = lanes.reduce_sum(rows_b); valid_b = lanes.reduce_sum(valid_b); act_b = lanes.reduce_sum(act_b);
+    act_t = lanes.reduce_sum(act_t); cand_b = lanes.reduce_sum(cand_b); va_b = lanes.reduce_sum(va_b);
+    va_t = lanes.reduce_sum(va_t); vb_b = lanes.reduce_sum(vb_b); v_t = lanes.reduce_sum(v_t);
+    tmax = -lanes.reduce_min(-tmax);
+    const int Tpad = Tpad_in > 0 ? Tpad_in : imin(align_up(tmax, t_align), imax(t_cap, tmax));
     Layout lay = layout_of(S);
-    const int B = S[H_B], T = S[H_T], kv = S[H_KV_LEN];
+    const int B = desc ? desc[p].B : S[H_B], T = desc ? desc[p].T : S[H_T], kv = S[H_KV_LEN];
+    const int base0 = order ? act_b : rows_b;
+    const int cbase = order ? act_t + cand_b : rows_b + 1;
     lanes.sync();
-    if (lanes.lane() == 0) { S[H_ROW_BASE] = row_base; S[H_TPAD] = Tpad; }
+    if (lanes.lane() == 0) { S[H_ROW_BASE] = base0; S[H_CAND_BASE] = cbase; S[H_TPAD] = Tpad; }
     for (int r = 0; r < B; ++r) {
         const int32_t *src = S + lay.off_out + r * lay.TMAX;
-        const int64_t o = (int64_t)(row_base + r) * Tpad;
+        const int row = r == 0 ? base0 : cbase + r - 1;
+        const int64_t ob = (int64_t)row * Tpad;
         for (int t = lanes.lane(); t < Tpad; t += lanes.count()) {
-            input_ids[o + t] = t < T ? (int64_t)src[t] : pad_fill;
-            positions[o + t] = kv + t;
+            o.input_ids[ob + t] = t < T ? (int64_t)src[t] : pad_fill;
+            o.positions[ob + t] = kv + t;
         }
-        if (lanes.lane() == 0) { row_prompt[row_base + r] = p; row_len[row_base + r] = T; }
-        // flat position of every token that carries a draft (lm_head / argmax run on these only)
-        if (valid_index)
-            for (int t = lanes.lane(); t < T; t += lanes.count()) valid_index[valid_base + r * T + t] = (int32_t)(o + t);
+        if (lanes.lane() == 0) {
+            o.row_prompt[row] = p; o.row_len[row] = T;
+            if (o.row_cand) o.row_cand[row] = r == 0 ? -1 : p * imax(cand_rows, 1) + r - 1;
+            if (o.row_kv) o.row_kv[row] = kv;
+        }
+        // flat position of every token that carries a draft, in forward-row order (lm_head / argmax run on these only)
+        if (o.valid_index) {
+            const int vb = order ? (r == 0 ? va_b : va_t + vb_b + (r - 1) * T) : valid_b + r * T;
+            for (int t = lanes.lane(); t < T; t += lanes.count()) o.valid_index[vb + t] = (int32_t)(ob + t);
+        }
     }
-    if (valid_index && p == P - 1 && valid_align > 1) {            // round the list up with "no position" entries
-        const int nv = valid_base + B * T;
-        const int nvp = (nv + valid_align - 1) / valid_align * valid_align;
-        for (int i = nv + lanes.lane(); i < nvp; i += lanes.count()) valid_index[i] = -1;
+    if (o.valid_index && p == P - 1 && valid_align > 1) {            // round the list up with "no position" entries
+        const int nvp = align_up(v_t, valid_align);
+        for (int i = v_t + lanes.lane(); i < nvp; i += lanes.count()) o.valid_index[i] = -1;
     }
     lanes.sync();
+}
+
+// greedy token of (row r, position t) of a prompt whose row 0 is forward row base0 and whose candidate rows start at cbase
+struct PackedRows {
+    const uint64_t *pk; int64_t base0, cbase, tpad, plen;
+    JF_HD int64_t index(int r, int t) const { return (r == 0 ? base0 : cbase + r - 1) * tpad + t; }
+};
+
+// What follows Machine::step in the loop API: the resident driver's call end, then the prompt's committed length.
+template <class M>
+JF_HD void loop_after_step(M &m, const LoopDev *lp, int p, bool was_done, jf_mb_desc *d) {
+    if (!lp) return;
+    if (lp->drv && !was_done && m.done && !m.err && lp->drv[(int64_t)p * lp->drv_ints + D_ACTIVE]) drv_call_end(m, *lp, p, d);
+    if (lp->kv_len && m.lanes.lane() == 0 && !m.err && !was_done) lp->kv_len[p] = m.kv_len;
 }
 
 template <class Lanes>
 JF_HD void mb_step_body(Lanes lanes, int p, int32_t *states, int64_t state_ints, uint64_t *packed,
-                        int64_t packed_len, jf_mb_desc *desc) {
+                        int64_t packed_len, jf_mb_desc *desc, const LoopDev *lp = nullptr) {
     int32_t *S = states + (int64_t)p * state_ints;
     Layout lay = layout_of(S);
     Machine<Lanes> m(S, lanes, lay);
-    const int64_t base = S[H_ROW_BASE];
-    const int64_t tpad = S[H_TPAD];
+    const PackedRows rows{packed, S[H_ROW_BASE], S[H_CAND_BASE], S[H_TPAD], packed_len};
     const int B = S[H_B];
-    const uint64_t *pk = packed;
-    auto G = [pk, base, tpad, packed_len](int r, int t) -> int {
-        const int64_t idx = (base + r) * tpad + t;
-        return (idx >= 0 && idx < packed_len) ? decode_packed(pk[idx]) : -1;
+    const bool was_done = S[H_DONE] != 0;
+    auto G = [rows](int r, int t) -> int {
+        const int64_t idx = rows.index(r, t);
+        return (idx >= 0 && idx < rows.plen) ? decode_packed(rows.pk[idx]) : -1;
     };
     m.step(G, desc ? desc + p : nullptr);
+    loop_after_step(m, lp, p, was_done, desc ? desc + p : nullptr);
     // re-zero this prompt's slice of the argmax workspace for the next jf_argmax_partial
     lanes.sync();
-    const int64_t lo = base * tpad, hi = (base + B) * tpad;
-    for (int64_t i = lo + lanes.lane(); i < hi && i < packed_len; i += lanes.count()) packed[i] = 0;
+    for (int r = 0; r < B; ++r) {
+        const int64_t lo = rows.index(r, 0), hi = lo + rows.tpad;
+        for (int64_t i = lo + lanes.lane(); i < hi && i < packed_len; i += lanes.count()) packed[i] = 0;
+    }
 }
 
 template <class Lanes>

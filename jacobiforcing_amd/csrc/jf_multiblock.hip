@@ -18,21 +18,37 @@ __device__ unsigned long long g_mtrace[16 * 256];
 // ------------------------------------------------------------------------------------------------
 // multiblock state machine: one wavefront per prompt
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void mb_begin_kernel(int32_t *states, int64_t state_ints, jf_mb_params prm,
-                                                       const int64_t *input_ids, const int32_t *kv_len, jf_mb_desc *desc) {
-    jfmb::mb_begin_body(DevLanes{}, blockIdx.x, states, state_ints, prm, input_ids, kv_len, desc);
+// A one-wavefront workgroup reports that its prompt's global writes are done; true for the last of P to do so (which then
+// sees everybody's writes).  The counter returns to zero.
+__device__ __forceinline__ bool loop_arrive_last(int32_t *counter, int P) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    int old = 0;
+    if ((threadIdx.x & 63) == 0) old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != P - 1) return false;
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return true;
 }
-__global__ __launch_bounds__(64) void mb_pack_kernel(int32_t *states, int64_t state_ints, int32_t Tpad, int64_t pad_fill,
-                                                      int64_t *input_ids, int32_t *positions, int32_t *row_prompt,
-                                                      int32_t *row_len, int32_t *valid_index, int32_t valid_align) {
-    jfmb::mb_pack_body(DevLanes{}, blockIdx.x, gridDim.x, states, state_ints, Tpad, pad_fill, input_ids, positions, row_prompt,
-                       row_len, valid_index, valid_align);
+
+__global__ __launch_bounds__(64) void mb_begin_kernel(int32_t *states, int64_t state_ints, jf_mb_params prm,
+                                                       const int64_t *input_ids, const int32_t *kv_len, jf_mb_desc *desc,
+                                                       jfmb::LoopDev lp) {
+    jfmb::mb_begin_body(DevLanes{}, blockIdx.x, states, state_ints, prm, input_ids, kv_len, desc, lp.kv_len);
+    if (lp.mailbox && loop_arrive_last(lp.sync, gridDim.x)) jfmb::mb_publish_body(DevLanes{}, gridDim.x, desc, lp);
+}
+__global__ __launch_bounds__(64) void mb_pack_kernel(int32_t *states, int64_t state_ints, const jf_mb_desc *desc, int32_t Tpad,
+                                                      int32_t t_align, int32_t t_cap, int64_t pad_fill, int32_t order,
+                                                      int32_t cand_rows, jfmb::PackOut o, int32_t valid_align) {
+    jfmb::mb_pack_body(DevLanes{}, blockIdx.x, gridDim.x, states, state_ints, desc, Tpad, t_align, t_cap, pad_fill, order,
+                       cand_rows, o, valid_align);
 }
 __global__ __launch_bounds__(64) void mb_step_kernel(int32_t *states, int64_t state_ints, unsigned long long *packed,
-                                                      int64_t packed_len, jf_mb_desc *desc) {
+                                                      int64_t packed_len, jf_mb_desc *desc, jfmb::LoopDev lp, int has_loop) {
     JF_STAMP(0);
-    jfmb::mb_step_body(DevLanes{}, blockIdx.x, states, state_ints, (uint64_t *)packed, packed_len, desc);
+    jfmb::mb_step_body(DevLanes{}, blockIdx.x, states, state_ints, (uint64_t *)packed, packed_len, desc, has_loop ? &lp : nullptr);
     JF_STAMP(12);
+    if (has_loop && lp.mailbox && loop_arrive_last(lp.sync, gridDim.x)) jfmb::mb_publish_body(DevLanes{}, gridDim.x, desc, lp);
 }
 #ifdef JF_EXP_MB_TRACE
 extern "C" int jf_exp_read_trace(unsigned long long *out32) {
@@ -74,7 +90,7 @@ extern "C" int jf_mb_begin(int32_t *states, int64_t state_ints, int P, const jf_
     if (rc) return rc;
     if (!states || !input_ids || !kv_len) return fail(JF_E_INVALID, "jf_mb_begin: null pointer");
     if (state_ints < jf_mb_state_ints(params)) return fail(JF_E_INVALID, "jf_mb_begin: state block too small");
-    mb_begin_kernel<<<P, 64, 0, (hipStream_t)stream>>>(states, state_ints, *params, input_ids, kv_len, desc);
+    mb_begin_kernel<<<P, 64, 0, (hipStream_t)stream>>>(states, state_ints, *params, input_ids, kv_len, desc, jfmb::LoopDev{});
     return check_launch("mb_begin_kernel");
 }
 
@@ -84,8 +100,9 @@ extern "C" int jf_mb_pack(int32_t *states, int64_t state_ints, int P, int32_t Tp
     if (P <= 0) return JF_OK;
     if (!states || !input_ids || !positions || !row_prompt || !row_len) return fail(JF_E_INVALID, "jf_mb_pack: null pointer");
     if (Tpad <= 0) return fail(JF_E_INVALID, "jf_mb_pack: Tpad=%d", Tpad);
-    mb_pack_kernel<<<P, 64, 0, (hipStream_t)stream>>>(states, state_ints, Tpad, pad_fill, input_ids, positions, row_prompt, row_len,
-                                                      valid_index, valid_align < 1 ? 1 : valid_align);
+    const jfmb::PackOut o{input_ids, positions, row_prompt, row_len, valid_index, nullptr, nullptr};
+    mb_pack_kernel<<<P, 64, 0, (hipStream_t)stream>>>(states, state_ints, nullptr, Tpad, 1, Tpad, pad_fill, 0, 1, o,
+                                                      valid_align < 1 ? 1 : valid_align);
     return check_launch("mb_pack_kernel");
 }
 
@@ -93,7 +110,8 @@ extern "C" int jf_mb_step(int32_t *states, int64_t state_ints, int P, uint64_t *
                           void *stream) {
     if (P <= 0) return JF_OK;
     if (!states || !packed) return fail(JF_E_INVALID, "jf_mb_step: null pointer");
-    mb_step_kernel<<<P, 64, 0, (hipStream_t)stream>>>(states, state_ints, (unsigned long long *)packed, packed_len, desc);
+    mb_step_kernel<<<P, 64, 0, (hipStream_t)stream>>>(states, state_ints, (unsigned long long *)packed, packed_len, desc,
+                                                      jfmb::LoopDev{}, 0);
     return check_launch("mb_step_kernel");
 }
 
@@ -135,6 +153,8 @@ struct VerifyArgs {
     int32_t Tpad;
     int32_t compacted;             // 1: logits rows follow valid_index (B*T per prompt); 0: the Rtot x Tpad rectangle
     int32_t lds_ints;              // ints of dynamic LDS available for (compact image + greedy tokens); 0 = step on HBM
+    int32_t has_loop;              // jf_mb_loop_iterate: kv_len / resident driver / mailbox (lp) apply
+    jfmb::LoopDev lp;
 };
 
 #ifdef JF_EXP_VERIFY_TRACE
@@ -180,8 +200,8 @@ constexpr int VERIFY_LDS_HDR = 32;                               // ints in fron
 constexpr unsigned long long VERIFY_WAIT_TICKS = 200000000ull;   // 2 s of the 100 MHz constant clock: never hang the GPU
 
 __device__ __forceinline__ void verify_arrive(const VerifyArgs &a, int owner) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the atomicMax above is performed before the count moves
-    __hip_atomic_fetch_add(a.arrive + (int64_t)owner * VERIFY_ARRIVE_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // release: the atomicMax above is performed (and visible at agent scope) before the count moves
+    __hip_atomic_fetch_add(a.arrive + (int64_t)owner * VERIFY_ARRIVE_STRIDE, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ void verify_stepper(const VerifyArgs &a, int p, int32_t *smem) {
@@ -190,9 +210,10 @@ __device__ void verify_stepper(const VerifyArgs &a, int p, int32_t *smem) {
     const Layout LG = layout_of(G);
     const Layout LC = compact_layout(LG, G[H_K]);
     const int B = G[H_B], T = G[H_T];
-    const int64_t base = G[H_ROW_BASE];
-    const int64_t tpad = G[H_TPAD];
+    const PackedRows rows{(const uint64_t *)a.am.packed, G[H_ROW_BASE], G[H_CAND_BASE], G[H_TPAD], a.packed_len};
     const int ng = B * T;                                        // greedy tokens this prompt consumes
+    const bool was_done = G[H_DONE] != 0;
+    const LoopDev *lp = a.has_loop ? &a.lp : nullptr;
     JF_VSTAMP(p, 0);
     // dynamic LDS: [0,16) descriptor, [16,32) flags, then the compact image, then the greedy tokens
     jf_mb_desc *s_desc = (jf_mb_desc *)smem;
@@ -213,7 +234,7 @@ __device__ void verify_stepper(const VerifyArgs &a, int p, int32_t *smem) {
         const int lane = threadIdx.x;
         int32_t *gtok = img + LC.total;                          // [B, T] greedy tokens (LDS) when use_lds
         // ---- wait for this prompt's rows -----------------------------------------------------------
-        const int expected = (a.compacted ? ng : B * (int)tpad) * a.am.chunks_per_row;
+        const int expected = (a.compacted ? ng : B * (int)rows.tpad) * a.am.chunks_per_row;
         bool timed_out = false;
         if (expected > 0) {
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -223,6 +244,8 @@ __device__ void verify_stepper(const VerifyArgs &a, int p, int32_t *smem) {
                 __builtin_amdgcn_s_sleep(20);                    // ~0.6 us between polls: pollers must not load the memory system
                 if ((++spins & 255u) == 0u && __builtin_amdgcn_s_memrealtime() - t0 > VERIFY_WAIT_TICKS) { timed_out = true; break; }
             }
+            // the items released their atomicMax before the count moved (verify_arrive); acquire it before reading packed[]
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             if (lane == 0) __hip_atomic_store(word, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
         }
         JF_VSTAMP(p, 2);
@@ -231,11 +254,9 @@ __device__ void verify_stepper(const VerifyArgs &a, int p, int32_t *smem) {
             if (lane == 0) { G[H_ERR] = JF_E_LAUNCH; G[H_DONE] = 1; if (dg) { dg->error = JF_E_LAUNCH; dg->done = 1; dg->B = 0; dg->T = 0; } }
             wb = -1;
         } else {
-            const unsigned long long *pk = a.am.packed;
-            const int64_t plen = a.packed_len;
-            auto Gglobal = [pk, base, tpad, plen](int r, int t) -> int {
-                const int64_t idx = (base + r) * tpad + t;
-                return (idx >= 0 && idx < plen) ? decode_packed(ld_agent_u64(pk + idx)) : -1;
+            auto Gglobal = [rows](int r, int t) -> int {
+                const int64_t idx = rows.index(r, t);
+                return (idx >= 0 && idx < rows.plen) ? decode_packed(ld_agent_u64((const unsigned long long *)rows.pk + idx)) : -1;
             };
             if (use_lds) {
                 for (int i = lane; i < ng; i += 64) gtok[i] = Gglobal(i / T, i - (i / T) * T);
@@ -245,28 +266,42 @@ __device__ void verify_stepper(const VerifyArgs &a, int p, int32_t *smem) {
                 const int32_t *gt = gtok;
                 m.step([gt, T](int r, int t) -> int { return gt[r * T + t]; }, s_desc);
                 SoloWaveLanes{}.sync();
+                if (!s_desc->error) {
+                    wb = 1;
+                    loop_after_step(m, lp, p, was_done, s_desc);
+                    SoloWaveLanes{}.sync();
+                }
                 JF_VSTAMP(p, 4);
-                if (!s_desc->error) wb = 1;
             }
             if (!wb) {                                           // step on the HBM block (capacities the parameters ask for)
                 Machine<SoloWaveLanes> m(G, SoloWaveLanes{}, LG);
                 m.step(Gglobal, dg);
+                loop_after_step(m, lp, p, was_done, dg);
             }
         }
         if (lane == 0) smem[17] = wb;
     }
     __syncthreads();
     const int wb = smem[17];
-    if (wb < 0) return;
     if (wb > 0) {
         compact_to_state(Lanes256{}, img, LC, G, LG);
         if (dg && threadIdx.x < (int)(sizeof(jf_mb_desc) / 4)) ((int32_t *)dg)[threadIdx.x] = ((const int32_t *)s_desc)[threadIdx.x];
     }
     JF_VSTAMP(p, 5);
-    // re-zero this prompt's slice of the argmax workspace for the next launch
-    const int64_t lo = base * tpad, hi = (base + B) * tpad;
-    for (int64_t i = lo + threadIdx.x; i < hi && i < a.packed_len; i += AM_TPB) a.am.packed[i] = 0ull;
+    if (wb >= 0) {
+        // re-zero this prompt's slice of the argmax workspace for the next launch
+        for (int r = 0; r < B; ++r) {
+            const int64_t lo = rows.index(r, 0), hi = lo + rows.tpad;
+            for (int64_t i = lo + threadIdx.x; i < hi && i < a.packed_len; i += AM_TPB) a.am.packed[i] = 0ull;
+        }
+    }
     JF_VSTAMP(p, 6);
+    // ---- loop API: the last prompt to get here publishes the next forward's summary to the host ---------------------
+    if (lp && lp->mailbox) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // every wavefront's write-back, before the count moves
+        __syncthreads();
+        if (threadIdx.x < 64 && loop_arrive_last(lp->sync, a.P)) mb_publish_body(SoloWaveLanes{}, a.P, a.desc, *lp);
+    }
 }
 
 template <int DT, bool WAVE, bool NT>
@@ -310,17 +345,17 @@ static int verify_stepper_cap(const void *kern, int variant, size_t shm) {
     return seen_cap[variant];
 }
 
-extern "C" int jf_mb_verify(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, const int32_t *out_index,
-                            int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len, int32_t Tpad,
-                            const int32_t *row_prompt, int32_t *arrive, jf_mb_desc *desc, const jf_mb_params *params,
-                            void *stream) {
+static int verify_launch(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, const int32_t *out_index,
+                         int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len, int32_t Tpad,
+                         const int32_t *row_prompt, int32_t *arrive, jf_mb_desc *desc, const jf_mb_params *params,
+                         const jfmb::LoopDev *lp, void *stream, const char *who) {
     if (P <= 0) return JF_OK;
-    int rc = check_params(params, "jf_mb_verify");
+    int rc = check_params(params, who);
     if (rc) return rc;
     if (!logits || !states || !packed || !row_prompt || !arrive || R <= 0 || Tpad <= 0)
-        return fail(JF_E_INVALID, "jf_mb_verify: null pointer or empty forward");
-    if (dtype != JF_F32 && dtype != JF_BF16) return fail(JF_E_INVALID, "jf_mb_verify: dtype %d", dtype);
-    if (V <= 0 || row_stride < V || V > 0x7FFFFFFFll) return fail(JF_E_INVALID, "jf_mb_verify: bad shape V=%lld stride=%lld", (long long)V, (long long)row_stride);
+        return fail(JF_E_INVALID, "%s: null pointer or empty forward", who);
+    if (dtype != JF_F32 && dtype != JF_BF16) return fail(JF_E_INVALID, "%s: dtype %d", who, dtype);
+    if (V <= 0 || row_stride < V || V > 0x7FFFFFFFll) return fail(JF_E_INVALID, "%s: bad shape V=%lld stride=%lld", who, (long long)V, (long long)row_stride);
     ArgmaxPlan pl;
     rc = argmax_plan(logits, dtype, R, V, row_stride, true, &pl);
     if (rc) return rc;
@@ -353,15 +388,116 @@ extern "C" int jf_mb_verify(const void *logits, int dtype, int64_t R, int64_t V,
         rc = out_index ? jf_argmax_scatter(logits, dtype, R, V, row_stride, out_index, packed, stream)
                        : jf_argmax_partial(logits, dtype, R, V, row_stride, packed, stream);
         if (rc) return rc;
-        return jf_mb_step(states, state_ints, P, packed, packed_len, desc, stream);
+        mb_step_kernel<<<P, 64, 0, s>>>(states, state_ints, (unsigned long long *)packed, packed_len, desc,
+                                        lp ? *lp : jfmb::LoopDev{}, lp ? 1 : 0);
+        return check_launch("mb_step_kernel");
     }
     VerifyArgs a;
     a.am = ArgmaxArgs{logits, R, V, row_stride, (unsigned long long *)packed, (int)pl.cpr, pl.chunk, out_index, pl.reverse};
     a.states = states; a.state_ints = state_ints; a.P = P; a.packed_len = packed_len; a.row_prompt = row_prompt;
     a.arrive = arrive; a.desc = desc; a.Tpad = Tpad; a.compacted = out_index ? 1 : 0; a.lds_ints = (int32_t)lds_ints;
+    a.has_loop = lp ? 1 : 0;
+    a.lp = lp ? *lp : jfmb::LoopDev{};
     const int64_t blocks = pl.blocks + P;
-    if (blocks > 0x7FFFFFFFll) return fail(JF_E_CAPACITY, "jf_mb_verify: grid too large");
+    if (blocks > 0x7FFFFFFFll) return fail(JF_E_CAPACITY, "%s: grid too large", who);
     const dim3 grid((unsigned)blocks), block(AM_TPB);
     kern<<<grid, block, shm, s>>>(a);
     return check_launch("mb_verify_kernel");
+}
+
+extern "C" int jf_mb_verify(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, const int32_t *out_index,
+                            int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len, int32_t Tpad,
+                            const int32_t *row_prompt, int32_t *arrive, jf_mb_desc *desc, const jf_mb_params *params,
+                            void *stream) {
+    return verify_launch(logits, dtype, R, V, row_stride, out_index, states, state_ints, P, packed, packed_len, Tpad, row_prompt,
+                         arrive, desc, params, nullptr, stream, "jf_mb_verify");
+}
+
+// ------------------------------------------------------------------------------------------------
+// jf_mb_loop_*: the loop around the step (include/jacobiforcing.h)
+// ------------------------------------------------------------------------------------------------
+extern "C" int jf_host_alloc(size_t bytes, void **out) {
+    if (!out || bytes == 0) return fail(JF_E_INVALID, "jf_host_alloc: bad argument");
+    void *p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(JF_E_LAUNCH, "jf_host_alloc: %s", hipGetErrorString(e)); }
+    memset(p, 0, bytes);
+    *out = p;
+    return JF_OK;
+}
+extern "C" int jf_host_free(void *p) {
+    if (p && hipHostFree(p) != hipSuccess) { (void)hipGetLastError(); return fail(JF_E_LAUNCH, "jf_host_free failed"); }
+    return JF_OK;
+}
+
+extern "C" int jf_mailbox_wait(const int32_t *mailbox, int32_t seq, int64_t timeout_us, void *stream) {
+    if (!mailbox) return fail(JF_E_INVALID, "jf_mailbox_wait: null mailbox");
+    const volatile int32_t *w = mailbox + JF_MB_SEQ;
+    struct timespec t0, t;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned spins = 1;; ++spins) {
+        if (__atomic_load_n((const int32_t *)w, __ATOMIC_ACQUIRE) == seq) return JF_OK;
+        __builtin_ia32_pause();
+        if ((spins & 1023u) == 0u) {
+            clock_gettime(CLOCK_MONOTONIC, &t);
+            const int64_t us = (int64_t)(t.tv_sec - t0.tv_sec) * 1000000 + (t.tv_nsec - t0.tv_nsec) / 1000;
+            // a launch that failed never publishes: once the stream has drained the word is final
+            if (us > 2000 && (spins & 0xFFFFFu) == 0u && hipStreamQuery((hipStream_t)stream) == hipSuccess) {
+                if (__atomic_load_n((const int32_t *)w, __ATOMIC_ACQUIRE) == seq) return JF_OK;
+                return fail(JF_E_LAUNCH, "jf_mailbox_wait: the stream drained without publishing sequence %d (mailbox holds %d)", seq, (int)*w);
+            }
+            if (timeout_us > 0 && us > timeout_us)
+                return fail(JF_E_LAUNCH, "jf_mailbox_wait: sequence %d not published within %lld us (mailbox holds %d)", seq, (long long)timeout_us, (int)*w);
+        }
+    }
+}
+
+static int check_loop(const jf_mb_loop *lp, const char *who) {
+    if (!lp) return fail(JF_E_INVALID, "%s: null loop", who);
+    if (lp->P <= 0) return fail(JF_E_INVALID, "%s: P=%d", who, lp->P);
+    if (!lp->states || !lp->packed || !lp->arrive || !lp->desc || !lp->input_ids || !lp->positions || !lp->row_prompt || !lp->row_len ||
+        !lp->row_cand || !lp->row_kv_len || !lp->mailbox || !lp->sync)
+        return fail(JF_E_INVALID, "%s: null pointer in jf_mb_loop", who);
+    if (lp->t_cap <= 0 || lp->rows_cap <= 0) return fail(JF_E_INVALID, "%s: forward buffers have no capacity", who);
+    if (lp->drv && (!lp->draws || lp->draw_len <= 0 || lp->drv_ints <= JF_DRV_HDR_INTS))
+        return fail(JF_E_INVALID, "%s: resident driver without a draw stream / text capacity", who);
+    return JF_OK;
+}
+
+static int loop_pack(const jf_mb_loop *lp, hipStream_t s) {
+    const jfmb::PackOut o{lp->input_ids, lp->positions, lp->row_prompt, lp->row_len, lp->valid_index, lp->row_cand, lp->row_kv_len};
+    mb_pack_kernel<<<lp->P, 64, 0, s>>>(lp->states, lp->state_ints, lp->desc, 0, lp->t_align < 1 ? 1 : lp->t_align, lp->t_cap,
+                                        lp->pad_fill, lp->order ? 1 : 0, lp->cand_rows, o, lp->valid_align < 1 ? 1 : lp->valid_align);
+    return check_launch("mb_pack_kernel");
+}
+
+extern "C" int jf_mb_loop_begin(const jf_mb_loop *loop, int32_t seq, const jf_mb_params *params, const int64_t *input_ids,
+                                const int32_t *kv_len, void *stream) {
+    int rc = check_loop(loop, "jf_mb_loop_begin");
+    if (rc) return rc;
+    rc = check_params(params, "jf_mb_loop_begin");
+    if (rc) return rc;
+    if (!input_ids || !kv_len) return fail(JF_E_INVALID, "jf_mb_loop_begin: null pointer");
+    if (loop->state_ints < jf_mb_state_ints(params)) return fail(JF_E_INVALID, "jf_mb_loop_begin: state block too small");
+    mb_begin_kernel<<<loop->P, 64, 0, (hipStream_t)stream>>>(loop->states, loop->state_ints, *params, input_ids, kv_len, loop->desc,
+                                                             jfmb::make_loop_dev(loop, seq, params));
+    rc = check_launch("mb_begin_kernel");
+    if (rc) return rc;
+    return loop_pack(loop, (hipStream_t)stream);
+}
+
+extern "C" int jf_mb_loop_iterate(const jf_mb_loop *loop, int32_t seq, const void *logits, int dtype, int64_t R, int64_t V,
+                                  int64_t row_stride, int compacted, int32_t Rtot, int32_t Tpad, const jf_mb_params *params,
+                                  void *stream) {
+    int rc = check_loop(loop, "jf_mb_loop_iterate");
+    if (rc) return rc;
+    if (Rtot <= 0 || Rtot > loop->rows_cap || Tpad <= 0 || (int64_t)Rtot * Tpad > loop->packed_cap)
+        return fail(JF_E_INVALID, "jf_mb_loop_iterate: forward of %d x %d positions exceeds the buffers", Rtot, Tpad);
+    if (compacted && !loop->valid_index) return fail(JF_E_INVALID, "jf_mb_loop_iterate: compacted logits without a position list");
+    const jfmb::LoopDev d = jfmb::make_loop_dev(loop, seq, params);
+    rc = verify_launch(logits, dtype, R, V, row_stride, compacted ? loop->valid_index : nullptr, loop->states, loop->state_ints,
+                       loop->P, loop->packed, (int64_t)Rtot * Tpad, Tpad, loop->row_prompt, loop->arrive, loop->desc, params, &d,
+                       stream, "jf_mb_loop_iterate");
+    if (rc) return rc;
+    return loop_pack(loop, (hipStream_t)stream);
 }

@@ -61,7 +61,7 @@ LogitsHook = Callable[[torch.Tensor, "MultiblockJacobiDecoder"], torch.Tensor]
 class MultiblockJacobiDecoder:
     def __init__(self, model: Qwen2Model, num_prompts: int, params: ops.MultiblockParams, max_seq_len: int = 4096,
                  logits_hook: Optional[LogitsHook] = None, t_align: int = 1, compact_logits: bool = True,
-                 logit_align: Optional[int] = None):
+                 logit_align: Optional[int] = None, resident: Optional[bool] = None, draw_len: int = 8192):
         self.model = model
         self.P = int(num_prompts)
         self.params = params
@@ -77,6 +77,18 @@ class MultiblockJacobiDecoder:
         self.t_align = int(t_align)          # pad the per-iteration row length to a multiple (tuned-GEMM shape grid)
         self.compact_logits = bool(compact_logits)   # lm_head + argmax on draft-carrying positions only (no padding rows)
         self.logit_align = int(logit_align) if logit_align else self.t_align   # lm_head M rounded up to this multiple
+        # resident driver (default): finished calls restart on the device (DRV:206-250 inside the convergence launch);
+        # JF_RESIDENT=0 / resident=False keeps the driver loop on the host (one extra round trip per finished call)
+        self.resident = (os.environ.get("JF_RESIDENT", "1") != "0") if resident is None else bool(resident)
+        self.draw_len = int(draw_len)
+        self.text_cap = int(max_seq_len) + self.t_cap + 8
+        dev = self.device
+        self.drv = torch.zeros((self.P, N.DRV_HDR_INTS + self.text_cap), dtype=torch.int32, device=dev)
+        self.draws_dev = torch.zeros((self.P, self.draw_len), dtype=torch.int32, device=dev)
+        self.loop = ops.MultiblockLoop(self.batch, kv_len=self.cache.kv_len, t_cap=self.t_cap, t_align=self.t_align,
+                                       valid_align=self.logit_align, compact=self.compact_logits, cand_rows=self.cand_rows, order=1,
+                                       max_seq_len=max_seq_len, drv=self.drv if self.resident else None,
+                                       draws=self.draws_dev if self.resident else None)
         self.kv_len_host = np.zeros(self.P, dtype=np.int64)
         self._kv_len_pin = torch.zeros((self.P,), dtype=torch.int32, pin_memory=self.device.type == "cuda")
         self.forwards = 0
@@ -128,61 +140,47 @@ class MultiblockJacobiDecoder:
 
     # ------------------------------------------------------------------------------ one Jacobi iteration
     @torch.inference_mode()
-    def iteration(self, d: np.ndarray) -> np.ndarray:
-        """forward -> verify/accept/re-draft (HIP) -> KV commit.  ``d`` is the current descriptor table."""
-        packed_in = self.batch.pack(d, self.t_align, compact=self.compact_logits, valid_align=self.logit_align)
-        if packed_in is None:
-            return d
-        ids, pos, row_prompt, row_len = packed_in
-        if ids.shape[1] > self.t_cap:
-            raise RuntimeError(f"a row of {ids.shape[1]} tokens exceeds the forward capacity {self.t_cap} "
+    def iteration(self, s: ops.LoopSummary) -> ops.LoopSummary:
+        """forward -> convergence check + loop body (+ restarts) + next pack (HIP, one launch + the pack) -> KV commit, then
+        the mailbox.  ``s`` describes the forward to run (the previous launch published it); the forward's inputs were
+        written by the pack launch queued behind that launch."""
+        if s.Rtot == 0:
+            return s
+        if s.Tpad > self.t_cap:
+            raise RuntimeError(f"a row of {s.Tpad} tokens exceeds the forward capacity {self.t_cap} "
                                "(the block counters ran away, see DESIGN.md §3.2)")
-        B = d[:, self._f["B"]]
-        any_cand = bool((B > 1).any())
-        dev = self.device
-        R = ids.shape[0]
-        if any_cand:
-            # candidate index inside a prompt -> scratch row p*cand_rows + (b-1); row 0 writes the main cache
-            bidx = np.concatenate([np.arange(b) for b in B if b > 0])
-            pidx = np.repeat(np.arange(self.P), B)
-            rc = np.where(bidx > 0, pidx * max(self.cand_rows, 1) + bidx - 1, -1).astype(np.int32)
-            row_cand = torch.from_numpy(rc).to(dev, non_blocking=True)
-        else:
-            row_cand = torch.full((R,), -1, dtype=torch.int32, device=dev)
-        self.last_valid_rows = int((B * d[:, self._f["T"]]).sum())
-        if int(self.kv_len_host[B > 0].max()) + ids.shape[1] > self.max_seq_len:
+        if s.max_kv + s.Tpad > self.max_seq_len:
             raise RuntimeError(f"KV cache rows hold {self.max_seq_len} positions; a prompt at "
-                               f"{int(self.kv_len_host[B > 0].max())} cannot take {ids.shape[1]} more (raise max_seq_len)")
+                               f"{s.max_kv} cannot take {s.Tpad} more (raise max_seq_len)")
+        ids, pos, row_prompt, row_len, row_cand, row_kv = self.loop.inputs()
+        any_cand = s.Rtot > s.Rmain
+        self.last_valid_rows = s.Nvalid
         prof = self.profiler
-        kv_rows = self.cache.kv_len[row_prompt.long()]
-        s_cur = int(self.kv_len_host[B > 0].max()) + ids.shape[1]
         if prof: prof.start("jacobi.forward")
         logits = self.model.forward(ids, pos, self.cache, row_prompt=row_prompt, row_cand=row_cand, row_len=row_len,
-                                    kv_len_rows=kv_rows, any_candidates=any_cand, s_cur=s_cur,
-                                    logit_index=self.batch.valid_index)
+                                    kv_len_rows=row_kv, any_candidates=any_cand, s_cur=s.max_kv + s.Tpad,
+                                    logit_index=self.loop.valid_index(), n_main=s.Rmain)
         if self.logits_hook is not None:
             logits = self.logits_hook(logits, self, prefill=None)
         if prof: prof.stop("jacobi.forward")
         self.forwards += 1
         self.last_logits_rows = logits.shape[0]
-        if prof: prof.start("jacobi.verify")          # argmax + accept + re-draft + pool + spawn/promote in two launches
-        d = self.batch.verify(logits)
-        if prof: prof.stop("jacobi.verify")
+        if prof: prof.start("jacobi.verify")          # argmax + accept + re-draft + pool + spawn/promote (+ restart): one launch
+        self.loop.iterate(logits)
         if self.cache.committer is not None and any_cand:
-            if prof: prof.start("jacobi.commit")
             self.cache.committer.commit(self.batch.desc_dev)
-            if prof: prof.stop("jacobi.commit")
+        s2 = self.loop.wait()
         if prof:
+            prof.stop("jacobi.verify")
             prof.iterations += 1
-            prof.tokens += int(d[:, self._f["accepted"]].sum())
-        act = B > 0
-        self.kv_len_host[act] = d[act, self._f["kv_len"]]
-        self._push_kv_len()
-        return d
+            prof.tokens += s2.accepted
+        act = s.d[:, self._f["B"]] > 0
+        self.kv_len_host[act] = s2.d[act, self._f["kv_len"]]
+        return s2
 
     def _push_kv_len(self) -> None:
-        """Committed lengths to the device through a pinned staging buffer (asynchronous: every caller sits behind the
-        descriptor read-back's stream sync, so the buffer is never rewritten under a copy in flight)."""
+        """Committed lengths to the device through a pinned staging buffer (prefill only: inside the loop the step writes
+        them itself)."""
         self._kv_len_pin.copy_(torch.from_numpy(self.kv_len_host.astype(np.int32)))
         self.cache.kv_len.copy_(self._kv_len_pin, non_blocking=True)
 
@@ -191,12 +189,12 @@ class MultiblockJacobiDecoder:
         """Generator counterpart of the reference's streaming driver (applications/jacobi_streaming_driver.py:7-193):
         yields ``(prompt_index, new_token_ids)`` the moment a prompt finishes a block-level call; the generator's return
         value (``StopIteration.value``) is ``generate``'s result."""
-        return self._generate_events(prompts, **kw)
+        return self._generate_events(prompts, chunks=True, **kw)
 
     def generate(self, prompts, **kw):
         """Decode every prompt to EOS / max_new_tokens / max_calls.  Returns (stats per prompt, gen_seconds, iterations);
         ``gen_seconds`` covers the generation phase only (prefill excluded, DRV:217-230)."""
-        it = self._generate_events(prompts, **kw)
+        it = self._generate_events(prompts, chunks=kw.get("on_call_done") is not None, **kw)
         while True:
             try:
                 next(it)
@@ -207,33 +205,109 @@ class MultiblockJacobiDecoder:
     def _generate_events(self, prompts: Sequence[Sequence[int]], max_new_tokens: int = 1024, max_calls: int = 1024,
                  seed: int = 1234, on_iteration: Optional[Callable[[int, np.ndarray], None]] = None,
                  max_iterations: Optional[int] = None, on_generation_start: Optional[Callable[[], None]] = None,
-                 on_call_done: Optional[Callable[[int, List[int]], None]] = None):
+                 on_call_done: Optional[Callable[[int, List[int]], None]] = None, chunks: bool = False,
+                 draws: Optional[ops.DrawStreams] = None):
         assert len(prompts) == self.P
         # one budget per prompt (a scalar applies to all): a prompt stops its calls once it holds that many new tokens
         budgets = ([int(max_new_tokens)] * self.P if np.isscalar(max_new_tokens) else [int(x) for x in max_new_tokens])
         assert len(budgets) == self.P
-        n, eos = self.params.n, self.params.eos_token_id
-        rngs = [random.Random(seed + p) for p in range(self.P)]          # one stream per prompt (order-independent)
+        n = self.params.n
+        # random.choice(generated_ids) of DRV:176-180 / 209-215: one pre-drawn stream per prompt (order-independent)
+        draws = draws if draws is not None else ops.DrawStreams(self.P, seed=seed, length=self.draw_len)
+        rngs = [draws.rng(p) for p in range(self.P)]
         stats = [PromptStats(prompt_tokens=len(p)) for p in prompts]
         text = [list(p) for p in prompts]                              # generated_ids incl. the prompt (DRV:150)
         t0 = time.perf_counter()
         drafts = [[rngs[p].choice(text[p]) for _ in range(n)] for p in range(self.P)]      # DRV:176-180
         ngrams = self.prefill(prompts, drafts)
-        for s in stats:
-            s.calls = 1                                                # the prefill call counts (DRV:234)
-        active = np.ones(self.P, dtype=bool)
         inputs = np.array(ngrams, dtype=np.int64)                      # call 1 reuses the prefill n-gram (DRV:206-208)
         begin_kv = self.kv_len_host.astype(np.int32).copy()
+        if self.resident:
+            self._load_driver(prompts, budgets, max_calls, draws)
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         t_gen = time.perf_counter()
-        d = self.batch.begin(torch.from_numpy(inputs), torch.from_numpy(begin_kv))
+        s = self.loop.begin(torch.from_numpy(inputs), torch.from_numpy(begin_kv))
         if on_generation_start is not None:
             on_generation_start()
+        run = self._run_resident if self.resident else self._run_host_driven
+        iters_total = yield from run(s, stats, text, rngs, inputs, budgets, max_calls, on_iteration, max_iterations, on_call_done, chunks)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        gen_seconds = time.perf_counter() - t_gen
+        if self.resident:
+            self._collect_driver(stats, prompts)
+        for st in stats:
+            st.new_tokens = max(len(st.token_ids) - 1, 0)              # DRV:243 "subtract prefill"
+            st.time_sec = time.perf_counter() - t0
+            if st.stop_reason is None:
+                st.stop_reason = "interrupted"
+        return stats, gen_seconds, iters_total
+
+    # -- resident driver: calls end and restart inside the convergence launch -------------------------------------
+    def _load_driver(self, prompts, budgets, max_calls, draws: ops.DrawStreams) -> None:
+        H = N.DRV_HDR_INTS
+        blk = np.zeros((self.P, H + self.text_cap), dtype=np.int32)
+        f = N.DRV_FIELDS.index
+        for p, prompt in enumerate(prompts):
+            blk[p, f("active")] = 1
+            blk[p, f("calls")] = 1                                     # the prefill call counts (DRV:234)
+            blk[p, f("budget")] = min(int(budgets[p]), (1 << 31) - 1)
+            blk[p, f("max_calls")] = min(int(max_calls), (1 << 31) - 1)
+            blk[p, f("text_len")] = len(prompt)
+            blk[p, f("cursor")] = int(draws.cursor[p] % draws.length)
+            blk[p, H:H + len(prompt)] = prompt
+        self.drv.copy_(torch.from_numpy(blk))
+        self.draws_dev.copy_(torch.from_numpy(draws.words.view(np.int32)))
+
+    def _run_resident(self, s, stats, text, rngs, inputs, budgets, max_calls, on_iteration, max_iterations, on_call_done, chunks):
         iters_total = 0
-        while active.any():
-            d = self.iteration(d)
+        ev = self._f["events"]
+        while s.Rtot > 0:
+            s = self.iteration(s)
             iters_total += 1
+            if on_iteration is not None:
+                on_iteration(iters_total, s.d)
+            if chunks and s.n_call_end:
+                ended = np.nonzero(s.d[:, ev] & N.EVT_CALL_END)[0]
+                fin = s.fin
+                off, ln = fin[:, N.FIN_FIELDS.index("text_off")], fin[:, N.FIN_FIELDS.index("ret_len")]
+                H = N.DRV_HDR_INTS
+                rows = [self.drv[int(p), H + int(off[p]):H + int(off[p]) + int(ln[p])] for p in ended]
+                flat = torch.cat(rows).cpu().tolist() if rows else []
+                at = 0
+                for p in ended:
+                    ret = flat[at:at + int(ln[p])]
+                    at += int(ln[p])
+                    if on_call_done is not None:
+                        on_call_done(int(p), ret)
+                    yield int(p), ret
+            if max_iterations is not None and iters_total >= max_iterations:
+                break
+        return iters_total
+
+    def _collect_driver(self, stats, prompts) -> None:
+        blk = self.drv.cpu().numpy()
+        f = N.DRV_FIELDS.index
+        H = N.DRV_HDR_INTS
+        for p, st in enumerate(stats):
+            tl = int(blk[p, f("text_len")])
+            st.token_ids = blk[p, H + len(prompts[p]):H + tl].tolist()
+            st.calls = int(blk[p, f("calls")])
+            st.total_iterations = int(blk[p, f("iters_total")])
+            st.stop_reason = N.STOP_REASONS.get(int(blk[p, f("stop")]))
+
+    # -- host-driven restarts (JF_RESIDENT=0): the reference driver's loop on the host ------------------------------
+    def _run_host_driven(self, s, stats, text, rngs, inputs, budgets, max_calls, on_iteration, max_iterations, on_call_done, chunks):
+        n, eos = self.params.n, self.params.eos_token_id
+        for st in stats:
+            st.calls = 1                                               # the prefill call counts (DRV:234)
+        active = np.ones(self.P, dtype=bool)
+        iters_total = 0
+        while active.any() and s.Rtot > 0:
+            s = self.iteration(s)
+            iters_total += 1
+            d = s.d
             if on_iteration is not None:
                 on_iteration(iters_total, d)
             done = (d[:, self._f["done"]] == 1) & active
@@ -247,12 +321,13 @@ class MultiblockJacobiDecoder:
                     st.token_ids += r["ret"]
                     if on_call_done is not None:
                         on_call_done(int(p), r["ret"])
-                    yield int(p), list(r["ret"])
+                    if chunks:
+                        yield int(p), list(r["ret"])
                     st.calls += 1
                     st.total_iterations += r["iters"]
                     new_total = len(st.token_ids)
                     self.kv_len_host[p] = r["kv_len"]
-                    if eos is not None and eos in st.token_ids:                      # DRV:154-160
+                    if eos is not None and eos in r["ret"]:                          # DRV:154-160
                         st.stop_reason = "eos"
                     elif new_total >= budgets[p]:
                         st.stop_reason = "max_new_tokens"
@@ -268,16 +343,7 @@ class MultiblockJacobiDecoder:
                         inputs[p] = [nt] + [rngs[p].choice(text[p]) for _ in range(n - 1)]   # DRV:209-215
                         restart[p] = r["kv_len"]
                 if active.any():
-                    d = self.batch.begin(torch.from_numpy(inputs), torch.from_numpy(restart))
-                    self._push_kv_len()
+                    s = self.loop.begin(torch.from_numpy(inputs), torch.from_numpy(restart))
             if max_iterations is not None and iters_total >= max_iterations:
                 break
-        if self.device.type == "cuda":
-            torch.cuda.synchronize(self.device)
-        gen_seconds = time.perf_counter() - t_gen
-        for st in stats:
-            st.new_tokens = max(len(st.token_ids) - 1, 0)              # DRV:243 "subtract prefill"
-            st.time_sec = time.perf_counter() - t0
-            if st.stop_reason is None:
-                st.stop_reason = "interrupted"
-        return stats, gen_seconds, iters_total
+        return iters_total

@@ -228,14 +228,17 @@ class Qwen2Model:
                 row_prompt: torch.Tensor, row_cand: torch.Tensor, row_len: torch.Tensor,
                 kv_len_rows: torch.Tensor, any_candidates: bool, logits_rows: Optional[slice] = None,
                 s_cur: Optional[int] = None, logit_index: Optional[torch.Tensor] = None,
-                rows_in_place: Optional[bool] = None) -> torch.Tensor:
+                rows_in_place: Optional[bool] = None, n_main: Optional[int] = None) -> torch.Tensor:
         """One forward over R rows of (padded) length T.
 
         input_ids [R,T] int64, positions [R,T] int32 (= kv_len + t), row_prompt [R] (cache row of the prefix),
         row_cand [R] (-1: the row writes into the main cache, else index into the candidate scratch),
         row_len [R] valid tokens per row, kv_len_rows [R] committed prefix length per row, s_cur = max(kv_len)+T when the
         caller knows it (saves a device read), rows_in_place = False when row r is NOT cache row r although R == P (a
-        caller whose rows are a permutation of the cache rows; None: rows of one batch in cache order).  Returns logits [R*T, V] in the weight dtype (or ``logits_rows`` of it, or
+        caller whose rows are a permutation of the cache rows; None: rows of one batch in cache order), n_main = the rows come
+        in the loop API's order (jf_mb_loop, order 1): the first n_main rows write the main cache (row 0 of every running
+        prompt, in prompt order), the rest are candidate rows — only THOSE rows' K/V prefixes are gathered, the main rows
+        attend in place when they are the cache rows in order (what is left of MB:93-127).  Returns logits [R*T, V] in the weight dtype (or ``logits_rows`` of it, or
         the rows listed in ``logit_index`` — flat positions, negative entries are list padding and yield a junk row)."""
         cfg, w = self.cfg, self.w
         R, T = input_ids.shape
@@ -263,7 +266,20 @@ class Qwen2Model:
         neg = torch.full_like(pos, -1)
         slot_main = torch.where(valid & main_rows.view(R, 1), row_prompt.long().view(R, 1) * cache.S_max + pos, neg).reshape(-1)
         rp = row_prompt.long()
-        if any_candidates:
+        split = n_main is not None
+        if split:
+            RA = int(n_main)
+            RB = R - RA
+            any_candidates = RB > 0
+            direct_a = RA == cache.P and rows_in_place is not False
+            if RB:
+                slot_cand = torch.where(valid[RA:], row_cand[RA:].long().view(RB, 1) * cache.T_max + ar_t.view(1, T), neg[RA:])
+                slot_cand = torch.cat([neg[:RA].reshape(-1), slot_cand.reshape(-1)])
+                tail_idx = (kvl[RA:].view(-1, 1) + ar_t.view(1, T)).clamp_(max=S_cur - 1).view(-1, 1, T, 1).expand(-1, nkv, T, hd)
+                crc, rp_b = row_cand[RA:].long(), rp[RA:]
+            if not direct_a:
+                rp_a = rp[:RA]
+        elif any_candidates:
             slot_cand = torch.where(valid & (~main_rows).view(R, 1), row_cand.long().view(R, 1) * cache.T_max + ar_t.view(1, T),
                                     neg).reshape(-1)
             cr = (~main_rows).nonzero(as_tuple=True)[0]
@@ -281,6 +297,23 @@ class Qwen2Model:
             qh = ops.rope_kv_append(qkv, T, nq, nkv, hd, pos32, self.cos, self.sin, cache.k[li], cache.v[li], slot_main,
                                     cache.ck[li] if any_candidates else None, cache.cv[li] if any_candidates else None,
                                     slot_cand if any_candidates else None)
+            if split:
+                if direct_a:
+                    Ka, Va = cache.k[li][:, :, :S_cur], cache.v[li][:, :, :S_cur]
+                else:
+                    Ka, Va = cache.k[li][rp_a, :, :S_cur], cache.v[li][rp_a, :, :S_cur]
+                oa = F.scaled_dot_product_attention(qh[:RA], Ka, Va, attn_mask=bias[:RA])
+                o = torch.empty((R * T, nq * hd), dtype=oa.dtype, device=dev)
+                o[:RA * T].view(RA, T, nkv, G, hd).copy_(oa.view(RA, nkv, G, T, hd).permute(0, 3, 1, 2, 4))
+                if RB:
+                    # candidate rows: the prompt's prefix (gathered for these rows only) with their own speculative tail
+                    Kb = cache.k[li][rp_b, :, :S_cur].scatter_(2, tail_idx, cache.ck[li][crc, :, :T])
+                    Vb = cache.v[li][rp_b, :, :S_cur].scatter_(2, tail_idx, cache.cv[li][crc, :, :T])
+                    ob = F.scaled_dot_product_attention(qh[RA:], Kb, Vb, attn_mask=bias[RA:])
+                    o[RA * T:].view(RB, T, nkv, G, hd).copy_(ob.view(RB, nkv, G, T, hd).permute(0, 3, 1, 2, 4))
+                x.addmm_(o, L["wo"].t())
+                x = self._mlp_residual(L, x, self._norm(x, L["ln2"]))
+                continue
             if any_candidates:
                 Kf = cache.k[li][rp, :, :S_cur]                                       # [R,nkv,S,hd] gathered prefix (+ row-0 tail)
                 Vf = cache.v[li][rp, :, :S_cur]

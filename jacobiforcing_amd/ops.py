@@ -187,7 +187,7 @@ class MultiblockBatch:
         d = self.desc_host.numpy()
         err = d[:, N.DESC_FIELDS.index("error")]
         if err.any():
-            self.arrive.zero_()                         # a launch that reported an error may have left arrival counts behind
+            self.arrive.zero_(); self.packed.zero_()    # a launch that reported an error may have left arrival counts / stale keys behind
             p = int(np.nonzero(err)[0][0])
             N.raise_state_error(int(err[p]), f"multiblock prompt {p} (state-machine line {int(d[p, N.DESC_FIELDS.index('rsv0')])})",
                                 aux=int(d[p, N.DESC_FIELDS.index("rsv1")]))
@@ -292,6 +292,173 @@ class MultiblockBatch:
             out.append(dict(ret=ret[p, :ln].tolist(), next_token=int(self.desc_field(d, "next_token")[p]),
                             iters=int(self.desc_field(d, "iters")[p]), kv_len=int(self.desc_field(d, "kv_len")[p])))
         return out
+
+
+# --------------------------------------------------------------------------------------------
+# the loop around the step (jf_mb_loop_*): no host round trip on the critical path
+# --------------------------------------------------------------------------------------------
+class DrawStreams:
+    """Pre-drawn 32-bit words, one stream per prompt, behind the reference driver's ``random.choice(generated_ids)``
+    (DRV:176-180, 209-215): draw k of prompt p is ``text[(u[p, k % len] * len(text)) >> 32]``.  The same streams feed the
+    host-side driver (``rng(p).choice``), the resident driver on the device and — in the tests — the oracle's driver."""
+
+    def __init__(self, P: int, seed: int = 1234, length: int = 8192):
+        self.P, self.length = int(P), int(length)
+        self.words = np.stack([np.random.default_rng(int(seed) + p).integers(0, 1 << 32, size=self.length, dtype=np.uint64)
+                               for p in range(self.P)]).astype(np.uint32) if self.P else np.zeros((0, self.length), np.uint32)
+        self.cursor = np.zeros(self.P, dtype=np.int64)
+
+    class _Rng:
+        def __init__(self, owner, p):
+            self.o, self.p = owner, p
+
+        def choice(self, seq):
+            o, p = self.o, self.p
+            w = int(o.words[p, o.cursor[p] % o.length])
+            o.cursor[p] += 1
+            return seq[(w * len(seq)) >> 32]
+
+    def rng(self, p: int) -> "DrawStreams._Rng":
+        return DrawStreams._Rng(self, int(p))
+
+
+@dataclass
+class LoopSummary:
+    """What the device published about the NEXT forward (mailbox header) + the descriptor table of the launch."""
+    seq: int
+    Rtot: int
+    Rmain: int
+    Tpad: int
+    Tmax: int
+    Nvalid: int
+    Nvalid_pad: int
+    n_done: int
+    max_kv: int
+    accepted: int
+    n_call_end: int
+    d: np.ndarray                    # [P, DESC_INTS] descriptors
+    fin: Optional[np.ndarray]        # [P, MB_FIN_INTS] resident-driver records (None without a driver)
+
+
+class MultiblockLoop:
+    """jf_mb_loop_begin / jf_mb_loop_iterate over a ``MultiblockBatch``: per iteration ONE launch for the convergence check +
+    loop body of every prompt (committed lengths written into the cache's ``kv_len``, finished calls restarted on the
+    device when a resident driver is attached), the pack launch of the next forward queued right behind it, and a mailbox
+    in mapped pinned host memory that the host polls for (Rtot, Tpad, ...) instead of copying descriptors and synchronising
+    the stream.  Row order 1: row 0 of every prompt first (the cache rows in order, attended in place), candidate rows after."""
+
+    def __init__(self, batch: "MultiblockBatch", kv_len: Optional[torch.Tensor], t_cap: int, t_align: int = 1, valid_align: int = 1,
+                 compact: bool = True, cand_rows: int = 1, order: int = 1, max_seq_len: int = 0,
+                 drv: Optional[torch.Tensor] = None, draws: Optional[torch.Tensor] = None, wait_timeout_s: float = 30.0):
+        b = self.batch = batch
+        dev = b.device
+        lib = N.lib()
+        self.compact = bool(compact)
+        self.t_cap = int(min(t_cap, b.max_tokens))
+        rows = b.P * b.max_rows
+        self.row_cand = torch.full((rows,), -1, dtype=torch.int32, device=dev)
+        self.row_kv = torch.zeros((rows,), dtype=torch.int32, device=dev)
+        self.sync = torch.zeros((4,), dtype=torch.int32, device=dev)
+        self.kv_len = kv_len
+        self.drv, self.draws = drv, draws
+        self.n_ints = N.mailbox_ints(b.P)
+        ptr = C.c_void_p()
+        N.check(lib.jf_host_alloc(self.n_ints * 4, C.byref(ptr)), "jf_host_alloc")
+        self._mb_ptr = ptr
+        self.mailbox = np.ctypeslib.as_array((C.c_int32 * self.n_ints).from_address(ptr.value))
+        self.seq = 0
+        self.timeout_us = int(wait_timeout_s * 1e6)
+        fill = b.params.pad_token_id if b.params.pad_token_id is not None else 0
+        self.c_loop = N.MbLoop(
+            states=b.states.data_ptr(), state_ints=b.state_ints, P=b.P, order=int(order),
+            packed=b.packed.data_ptr(), packed_cap=b.packed.numel(), arrive=b.arrive.data_ptr(), desc=b.desc_dev.data_ptr(),
+            input_ids=b.input_ids.data_ptr(), positions=b.positions.data_ptr(), row_prompt=b.row_prompt.data_ptr(),
+            row_len=b.row_len.data_ptr(), row_cand=self.row_cand.data_ptr(), row_kv_len=self.row_kv.data_ptr(),
+            valid_index=b.valid_index_buf.data_ptr() if compact else None,
+            rows_cap=rows, t_cap=self.t_cap, t_align=int(t_align), valid_align=int(valid_align), cand_rows=int(max(cand_rows, 1)),
+            rsv0=0, pad_fill=int(fill), kv_len=None if kv_len is None else kv_len.data_ptr(), mailbox=ptr.value,
+            sync=self.sync.data_ptr(), drv=None if drv is None else drv.data_ptr(),
+            drv_ints=0 if drv is None else int(drv.shape[1]), draws=None if draws is None else draws.data_ptr(),
+            draw_len=0 if draws is None else int(draws.shape[1]), max_seq_len=int(max_seq_len))
+        self.last: Optional[LoopSummary] = None
+
+    def close(self) -> None:
+        if self._mb_ptr is not None:
+            self.mailbox = None
+            N.lib().jf_host_free(self._mb_ptr)
+            self._mb_ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- launches -------------------------------------------------------------------------------------
+    def begin(self, input_ids: torch.Tensor, kv_len: torch.Tensor) -> LoopSummary:
+        """MB:230-262 for every prompt (kv_len: a length, JF_MB_KEEP or JF_MB_INACTIVE) + publish + pack."""
+        b = self.batch
+        n = b.params.n
+        if tuple(input_ids.shape) != (b.P, n):
+            raise ValueError(f"input_ids must be [{b.P}, {n}], got {tuple(input_ids.shape)}")
+        self._in = input_ids.to(device=b.device, dtype=torch.int64).contiguous()
+        self._kv = kv_len.to(device=b.device, dtype=torch.int32).contiguous()
+        self.seq += 1
+        N.check(N.lib().jf_mb_loop_begin(self.c_loop, self.seq, C.byref(b.c_params), _ptr(self._in), _ptr(self._kv),
+                                         _stream(b.device)), "jf_mb_loop_begin")
+        return self.wait()
+
+    def iterate(self, logits: torch.Tensor) -> None:
+        """Queue the convergence check + loop body + next pack behind the forward that produced ``logits`` (rows follow
+        ``valid_index()`` when the loop was built with ``compact``, else the Rtot x Tpad rectangle).  Does not wait."""
+        b, s = self.batch, self.last
+        V = logits.shape[-1]
+        flat = logits.reshape(-1, V)
+        want = s.Nvalid_pad if self.compact else s.Rtot * s.Tpad
+        if flat.shape[0] != want or flat.stride(1) != 1:
+            raise ValueError(f"expected contiguous logits for {want} positions, got {tuple(logits.shape)}")
+        self.seq += 1
+        VERIFY_HOOK and VERIFY_HOOK[0](b, flat)
+        N.check(N.lib().jf_mb_loop_iterate(self.c_loop, self.seq, _ptr(flat), _dtype_code(flat), flat.shape[0], V,
+                                           flat.stride(0) if flat.shape[0] > 1 else V, 1 if self.compact else 0, s.Rtot, s.Tpad,
+                                           C.byref(b.c_params), _stream(b.device)), "jf_mb_loop_iterate")
+        VERIFY_HOOK and VERIFY_HOOK[1](b, flat)
+
+    def wait(self) -> LoopSummary:
+        """Poll the mailbox for the sequence number of the last launch."""
+        b = self.batch
+        N.check(N.lib().jf_mailbox_wait(self._mb_ptr, self.seq, self.timeout_us, _stream(b.device)), "jf_mailbox_wait")
+        m = self.mailbox
+        P = b.P
+        d = m[N.MB_MAILBOX_HDR:N.MB_MAILBOX_HDR + P * N.DESC_INTS].reshape(P, N.DESC_INTS).copy()
+        fin = None
+        if self.drv is not None:
+            o = N.MB_MAILBOX_HDR + P * N.DESC_INTS
+            fin = m[o:o + P * N.MB_FIN_INTS].reshape(P, N.MB_FIN_INTS).copy()
+        if m[N.MB_ERROR]:
+            p = int(m[N.MB_ERROR]) - 1
+            b.arrive.zero_(); b.packed.zero_(); self.sync.zero_()      # a failed launch may have left counts / keys behind
+            f = N.DESC_FIELDS.index
+            N.raise_state_error(int(d[p, f("error")]), f"multiblock prompt {p} (state-machine line {int(d[p, f('rsv0')])})",
+                                aux=int(d[p, f("rsv1")]))
+        s = LoopSummary(seq=int(m[N.MB_SEQ]), Rtot=int(m[N.MB_RTOT]), Rmain=int(m[N.MB_RMAIN]), Tpad=int(m[N.MB_TPAD]),
+                        Tmax=int(m[N.MB_TMAX]), Nvalid=int(m[N.MB_NVALID]), Nvalid_pad=int(m[N.MB_NVALID_PAD]),
+                        n_done=int(m[N.MB_NDONE]), max_kv=int(m[N.MB_MAXKV]), accepted=int(m[N.MB_ACCEPTED]),
+                        n_call_end=int(m[N.MB_NCALL_END]), d=d, fin=fin)
+        self.last = s
+        b.Rtot, b.Tpad, b.Nvalid = s.Rtot, s.Tpad, s.Nvalid
+        b.valid_index = b.valid_index_buf[:s.Nvalid_pad] if self.compact else None
+        return s
+
+    # -- views of the next forward's inputs (written by the pack launch that is already queued) ---------
+    def inputs(self):
+        b, s = self.batch, self.last
+        R, Tp = s.Rtot, s.Tpad
+        return (b.input_ids[:R * Tp].view(R, Tp), b.positions[:R * Tp].view(R, Tp), b.row_prompt[:R], b.row_len[:R],
+                self.row_cand[:R], self.row_kv[:R])
+
+    def valid_index(self) -> Optional[torch.Tensor]:
+        return self.batch.valid_index
 
 
 # --------------------------------------------------------------------------------------------

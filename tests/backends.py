@@ -62,7 +62,10 @@ class HostSimLib:
             "hs_mb_read_ret": (C.c_int, [vp, i64, C.c_int, vp, i32]),
             "hs_engine_step": (C.c_int, [vp, C.c_int, C.c_int, vp, i32, vp, vp, vp, vp, i64, vp, vp]),
             "hs_sb_step": (C.c_int, [vp, C.c_int, vp, i32, i32, i32, vp, i32, vp]),
+            "hs_mb_loop_begin": (C.c_int, [C.POINTER(N.MbLoop), i32, P, vp, vp]),
+            "hs_mb_loop_step": (C.c_int, [C.POINTER(N.MbLoop), i32, P, i32, i32]),
         }
+        self._host_blocks = {}
         for k, (r, a) in sig.items():
             f = getattr(self.hs, k)
             f.restype, f.argtypes = r, a
@@ -105,6 +108,35 @@ class HostSimLib:
 
     def jf_mb_read_ret(self, *a):
         return self.hs.hs_mb_read_ret(*a[:-1])
+
+    # -- the loop API: plain memory for the mailbox, the argmax stand-in, then the same bodies prompt after prompt
+    def jf_host_alloc(self, nbytes, out):
+        buf = (C.c_char * int(nbytes))()
+        addr = C.addressof(buf)
+        self._host_blocks[addr] = buf
+        out._obj.value = addr
+        return 0
+
+    def jf_host_free(self, p):
+        self._host_blocks.pop(_addr(p), None)
+        return 0
+
+    def jf_mailbox_wait(self, mailbox, seq, timeout_us, stream):
+        got = int(_view(mailbox, 1, np.int32)[0])
+        if got != seq:
+            self._err = f"jf_mailbox_wait: sequence {seq} not published (mailbox holds {got})".encode()
+            return N.JF_E_LAUNCH
+        return 0
+
+    def jf_mb_loop_begin(self, loop, seq, params, input_ids, kv_len, stream):
+        return self.hs.hs_mb_loop_begin(loop, seq, params, input_ids, kv_len)
+
+    def jf_mb_loop_iterate(self, loop, seq, logits, dtype, R, V, stride, compacted, Rtot, Tpad, params, stream):
+        if compacted:
+            rc = self.jf_argmax_scatter(logits, dtype, R, V, stride, loop.valid_index, loop.packed, stream)
+        else:
+            rc = self.jf_argmax_partial(logits, dtype, R, V, stride, loop.packed, stream)
+        return rc or self.hs.hs_mb_loop_step(loop, seq, params, Rtot, Tpad)
 
     def jf_engine_step(self, *a):
         return self.hs.hs_engine_step(*a[:-1])

@@ -19,6 +19,7 @@ struct HostLanes {
     int first_true(bool pred) const { return pred ? 0 : 1; }
     int count_true(bool pred) const { return pred ? 1 : 0; }
     int prefix_count(bool) const { return 0; }
+    void publish(int32_t *word, int32_t v) const { *word = v; }
 };
 
 extern "C" {
@@ -34,9 +35,35 @@ int hs_mb_begin(int32_t *states, int64_t state_ints, int P, const jf_mb_params *
 }
 int hs_mb_pack(int32_t *states, int64_t state_ints, int P, int32_t Tpad, int64_t pad_fill, int64_t *input_ids,
                int32_t *positions, int32_t *row_prompt, int32_t *row_len, int32_t *valid_index, int32_t valid_align) {
+    const jfmb::PackOut o{input_ids, positions, row_prompt, row_len, valid_index, nullptr, nullptr};
     for (int p = 0; p < P; ++p)
-        jfmb::mb_pack_body(HostLanes{}, p, P, states, state_ints, Tpad, pad_fill, input_ids, positions, row_prompt, row_len,
-                           valid_index, valid_align < 1 ? 1 : valid_align);
+        jfmb::mb_pack_body(HostLanes{}, p, P, states, state_ints, nullptr, Tpad, 1, Tpad, pad_fill, 0, 1, o,
+                           valid_align < 1 ? 1 : valid_align);
+    return 0;
+}
+
+// ---- the loop API (jf_mb_loop_*): same bodies, prompts one after the other, the "last to finish" is the last of the loop
+static void hs_loop_pack(const jf_mb_loop *lp) {
+    const jfmb::PackOut o{lp->input_ids, lp->positions, lp->row_prompt, lp->row_len, lp->valid_index, lp->row_cand, lp->row_kv_len};
+    for (int p = 0; p < lp->P; ++p)
+        jfmb::mb_pack_body(HostLanes{}, p, lp->P, lp->states, lp->state_ints, lp->desc, 0, lp->t_align < 1 ? 1 : lp->t_align, lp->t_cap,
+                           lp->pad_fill, lp->order ? 1 : 0, lp->cand_rows, o, lp->valid_align < 1 ? 1 : lp->valid_align);
+}
+int hs_mb_loop_begin(const jf_mb_loop *lp, int32_t seq, const jf_mb_params *params, const int64_t *input_ids, const int32_t *kv_len) {
+    const jfmb::LoopDev d = jfmb::make_loop_dev(lp, seq, params);
+    for (int p = 0; p < lp->P; ++p)
+        jfmb::mb_begin_body(HostLanes{}, p, lp->states, lp->state_ints, *params, input_ids, kv_len, lp->desc, d.kv_len);
+    jfmb::mb_publish_body(HostLanes{}, lp->P, lp->desc, d);
+    hs_loop_pack(lp);
+    return 0;
+}
+// the step half of jf_mb_loop_iterate (the caller has filled packed[] with the argmax stand-in)
+int hs_mb_loop_step(const jf_mb_loop *lp, int32_t seq, const jf_mb_params *params, int32_t Rtot, int32_t Tpad) {
+    const jfmb::LoopDev d = jfmb::make_loop_dev(lp, seq, params);
+    for (int p = 0; p < lp->P; ++p)
+        jfmb::mb_step_body(HostLanes{}, p, lp->states, lp->state_ints, lp->packed, (int64_t)Rtot * Tpad, lp->desc, &d);
+    jfmb::mb_publish_body(HostLanes{}, lp->P, lp->desc, d);
+    hs_loop_pack(lp);
     return 0;
 }
 int hs_mb_step(int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len, jf_mb_desc *desc) {

@@ -111,7 +111,10 @@ def test_forward_matches_hf_qwen2():
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("cfg", [dict(n=8, K=2, r=0.5, pool=4), dict(n=16, K=2, r=0.85, pool=4), dict(n=16, K=3, r=0.4, pool=8)],
                          ids=lambda c: f"n{c['n']}K{c['K']}p{c['pool']}")
-def test_decoder_matches_oracle(cfg, backend):
+@pytest.mark.parametrize("resident", [True, False], ids=["resident", "hostdriven"])
+def test_decoder_matches_oracle(cfg, backend, resident):
+    """Both drivers — calls restarted on the device inside the convergence launch (resident) and the reference driver's
+    loop on the host — against the oracle driven by the same pre-drawn draft streams."""
     with use_backend(backend):
         dev = device_for(backend)
         model = tiny_model(dev, seed=3 + cfg["n"])
@@ -121,7 +124,7 @@ def test_decoder_matches_oracle(cfg, backend):
                                    pad_token_id=pad)
         rng = np.random.default_rng(7)
         prompts = [[int(t) for t in rng.integers(0, V - 2, size=int(L))] for L in (9, 17, 5, 30)]
-        dec = MultiblockJacobiDecoder(model, len(prompts), prm, max_seq_len=256)
+        dec = MultiblockJacobiDecoder(model, len(prompts), prm, max_seq_len=256, resident=resident)
         shapes = []
         fwd = scratch_forward(model)
         try:
@@ -135,14 +138,14 @@ def test_decoder_matches_oracle(cfg, backend):
             failed = 0
             for p, prompt in enumerate(prompts):
                 try:
-                    oracle_generate(fwd, prompt, prm, 3 * cfg["n"], 6, random.Random(99 + p))
+                    oracle_generate(fwd, prompt, prm, 3 * cfg["n"], 6, ops.DrawStreams(len(prompts), seed=99).rng(p))
                 except RuntimeError as oe:
                     assert "size of tensor" in str(oe)
                     failed += 1
             assert failed >= 1
             return
         for p, prompt in enumerate(prompts):
-            ref = oracle_generate(fwd, prompt, prm, 3 * cfg["n"], 6, random.Random(99 + p))
+            ref = oracle_generate(fwd, prompt, prm, 3 * cfg["n"], 6, ops.DrawStreams(len(prompts), seed=99).rng(p))
             assert stats[p].token_ids == ref["tokens"], f"prompt {p}"
             assert stats[p].calls == ref["calls"] and stats[p].total_iterations == ref["iters"]
             assert stats[p].stop_reason == ref["stop"]
