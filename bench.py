@@ -74,6 +74,10 @@ class VerifyTimer:
         self.launched_rows = 0
         self.valid_rows = None      # callable -> algorithmic rows of the launch in flight
         self._a = None
+        self._b = None              # end of the last convergence launch
+        self._c = None              # behind the pack launch queued after it
+        self.body = []              # (verify start, pack end): the whole loop body of an iteration
+        self.idle = []              # (pack end, next forward's first kernel): what the GPU waits for the host
 
     def __enter__(self):
         def before(batch, logits):
@@ -93,14 +97,32 @@ class VerifyTimer:
             self.launched_rows += int(logits.shape[0])
             self.all_rows.append(int(logits.shape[0]))
             self.all_valid.append(valid)
+            self._b = b
+
+        def pack_end(batch):
+            c = torch.cuda.Event(enable_timing=True)
+            c.record()
+            self.body.append((self._a, c))
+            self._c = c
+
+        def forward_begin(batch):
+            if self._c is None:
+                return
+            d = torch.cuda.Event(enable_timing=True)
+            d.record()
+            self.idle.append((self._c, d))
+            self._c = None
         ops.VERIFY_HOOK = (before, after)
+        ops.LOOP_HOOKS = {"pack_end": pack_end, "forward_begin": forward_begin}
         return self
 
     def __exit__(self, *exc):
         ops.VERIFY_HOOK = None
+        ops.LOOP_HOOKS = None
 
     def reset(self):
         self.events.clear(); self.bytes = 0; self.rows = 0; self.launched_rows = 0
+        self.body.clear(); self.idle.clear(); self._c = None
 
     def summary(self):
         if not self.events:
@@ -108,8 +130,13 @@ class VerifyTimer:
         us = [a.elapsed_time(b) * 1e3 for a, b in self.events]
         avg_us = sum(us) / len(us)
         avg_bytes = self.bytes / len(us)
+        body = [a.elapsed_time(b) * 1e3 for a, b in self.body]
+        idle = [a.elapsed_time(b) * 1e3 for a, b in self.idle]
+        med = lambda v: float(sorted(v)[len(v) // 2]) if v else None
         return dict(launches=len(us), avg_us=avg_us, avg_bytes=avg_bytes, avg_rows=self.rows / len(us),
-                    avg_launched_rows=self.launched_rows / len(us), gbs=avg_bytes / avg_us / 1e3)
+                    avg_launched_rows=self.launched_rows / len(us), gbs=avg_bytes / avg_us / 1e3,
+                    body_us=(sum(body) / len(body)) if body else None, idle_us=(sum(idle) / len(idle)) if idle else None,
+                    idle_us_median=med(idle), idle_samples=len(idle))
 
 
 def run_steps(dec: MultiblockJacobiDecoder, prompts, warmup: int, steps: int, seed: int, timer=None):
@@ -139,7 +166,8 @@ def run_steps(dec: MultiblockJacobiDecoder, prompts, warmup: int, steps: int, se
             state["t0"] = time.perf_counter()
 
     stats, gen_s, iters = dec.generate(prompts, max_new_tokens=1 << 30, max_calls=1 << 30, seed=seed,
-                                       on_iteration=on_iter, max_iterations=total, on_generation_start=on_start)
+                                       on_iteration=on_iter, max_iterations=total, on_generation_start=on_start,
+                                       fence_iterations=(warmup, total))
     if state["t1"] is None:          # every prompt finished early (EOS): close the window
         jd.barrier(dev)
         state["t1"] = time.perf_counter()
@@ -327,7 +355,8 @@ def main():
             if rs is not None:
                 shapes.append(dict(prompts_per_gpu=Ps, rows_per_launch=rs["avg_rows"], bytes_per_launch=rs["avg_bytes"],
                                    us_per_launch=rs["avg_us"], achieved=rs["gbs"], frac=rs["gbs"] / HBM_PEAK_GBS,
-                                   launches=rs["launches"]))
+                                   launches=rs["launches"], body_us_per_step=rs["body_us"], gpu_idle_us_per_step=rs["idle_us"],
+                                   gpu_idle_us_median=rs["idle_us_median"]))
     out = None
     if info.rank == 0:
         steps_done = max(int(round(agg["iterations"] / info.world_size)), 1)
@@ -363,6 +392,12 @@ def main():
                                "note": "logits rows beyond rows_per_launch are list padding (lm_head M on the tuned grid); the "
                                        "kernel skips them unread",
                                "launches": roof["launches"]}
+            out["loop_body"] = {"body_us_per_step": roof["body_us"], "gpu_idle_us_per_step": roof["idle_us"],
+                                "gpu_idle_us_median": roof["idle_us_median"], "samples": roof["idle_samples"],
+                                "driver": "resident (calls restart inside the convergence launch)" if dec.resident else "host-driven restarts",
+                                "note": "HIP events on the launch stream: body = convergence launch start -> end of the pack launch queued "
+                                        "behind it; gpu_idle = end of that pack launch -> the event recorded in front of the next forward's "
+                                        "first kernel (mailbox poll + host control; the reference's 'overhead %', MR:116-134)"}
         if shapes:
             out["roofline_by_shape"] = {"unit": "GB/s", "peak": HBM_PEAK_GBS, "kernel": VERIFY_KERNEL,
                                         "note": "HIP events around the verify launch inside short decode windows (6 warm-up + 24 "

@@ -266,7 +266,15 @@ JF_API int jf_mb_loop_begin(const jf_mb_loop *loop, int32_t seq, const jf_mb_par
  * contract: rows follow valid_index when `compacted`, else the Rtot x Tpad rectangle; Rtot / Tpad are the mailbox's),
  * then the pack step of the next forward.  jf_kv_commit (when candidate rows ran) may follow on the same stream. */
 JF_API int jf_mb_loop_iterate(const jf_mb_loop *loop, int32_t seq, const void *logits, int dtype, int64_t R, int64_t V,
-                       int64_t row_stride, int compacted, int32_t Rtot, int32_t Tpad, const jf_mb_params *params, void *stream);
+                       int64_t row_stride, int compacted, int32_t Rtot, int32_t Tpad, const jf_mb_params *params,
+                       int queue_pack, void *stream);
+/* The pack step alone (queue_pack = 0 above: a caller that brackets the convergence launch with its own events). */
+JF_API int jf_mb_loop_pack(const jf_mb_loop *loop, void *stream);
+
+/* A/B knob: 0 makes every step run the general state-machine code instead of its straight-line steady-state path
+ * (Machine::step_fast); results are identical (the parity suites run both).  Returns the previous setting.  Default 1, or
+ * the JF_MB_FAST environment variable read once. */
+JF_API int jf_mb_set_fast_path(int on);
 
 /* Copy results of finished calls: ret [P, ret_cap] int64 (ret_len in desc). */
 JF_API int jf_mb_read_ret(const int32_t *states, int64_t state_ints, int P, int64_t *ret, int32_t ret_cap,

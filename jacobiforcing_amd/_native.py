@@ -56,7 +56,7 @@ DRV_FIELDS = ["active", "stop", "calls", "iters_total", "new_tokens", "budget", 
               "fin_next", "fin_iters", "fin_off"]
 DRV_HDR_INTS = 16
 STOP_REASONS = {0: None, 1: "eos", 2: "max_new_tokens", 3: "max_calls", 4: "max_seq_len", 5: "max_seq_len"}
-EVT_SPAWN, EVT_SWITCH, EVT_EARLY, EVT_CALL_END, EVT_STOPPED = 1, 2, 4, 8, 16
+EVT_SPAWN, EVT_SWITCH, EVT_EARLY, EVT_CALL_END, EVT_STOPPED, EVT_FAST = 1, 2, 4, 8, 16, 32
 
 
 def mailbox_ints(P: int) -> int:
@@ -112,12 +112,14 @@ _SIGNATURES = {
     "jf_mb_verify": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _vp, _vp, _i64, C.c_int, _vp, _i64, _i32, _vp, _vp, _vp,
                                C.POINTER(MbParams), _vp]),
     "jf_mb_read_ret": (C.c_int, [_vp, _i64, C.c_int, _vp, _i32, _vp]),
+    "jf_mb_set_fast_path": (C.c_int, [C.c_int]),
     "jf_host_alloc": (C.c_int, [_sz, C.POINTER(C.c_void_p)]),
     "jf_host_free": (C.c_int, [_vp]),
     "jf_mailbox_wait": (C.c_int, [_vp, _i32, _i64, _vp]),
     "jf_mb_loop_begin": (C.c_int, [C.POINTER(MbLoop), _i32, C.POINTER(MbParams), _vp, _vp, _vp]),
     "jf_mb_loop_iterate": (C.c_int, [C.POINTER(MbLoop), _i32, _vp, C.c_int, _i64, _i64, _i64, C.c_int, _i32, _i32,
-                                     C.POINTER(MbParams), _vp]),
+                                     C.POINTER(MbParams), C.c_int, _vp]),
+    "jf_mb_loop_pack": (C.c_int, [C.POINTER(MbLoop), _vp]),
     "jf_kv_append": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i32, _vp]),
     "jf_rope_kv_append": (C.c_int, [_vp, C.c_int, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
                                     _vp, _i64, _vp]),

@@ -70,6 +70,8 @@ struct DevLanes {
     // every lane's earlier stores become visible to the HOST, then one word is released (mailbox hand-off; the word may
     // live in mapped pinned host memory).  The lanes are ONE wavefront: its stores are issued in program order, the
     // system-scope release fence drains them, no barrier is involved.
+    // System-scope release in front of the sequence word.  Measured free (profiles/verify_release_ab_r03.txt: 73.0 vs 74.4 us
+    // per launch without it) — unlike a release on the per-item arrival counts, it runs once per launch.
     __device__ __forceinline__ void publish(int32_t *word, int32_t v) const {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         if (lane() == 0) __hip_atomic_store(word, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

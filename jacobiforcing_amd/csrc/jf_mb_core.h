@@ -45,7 +45,8 @@ constexpr int MAX_NB = 4096; // sanity bound only; the block lists can grow by o
 
 enum : int { EVT_SPAWN = 1, EVT_SWITCH = 2, EVT_EARLY = 4,
              EVT_CALL_END = 8,     // resident driver: a generation call ended in this step (its results are in the driver block)
-             EVT_STOPPED = 16 };   // resident driver: ... and the prompt stopped (EOS / budget / calls / cache row full)
+             EVT_STOPPED = 16,     // resident driver: ... and the prompt stopped (EOS / budget / calls / cache row full)
+             EVT_FAST = 32 };      // this step ran as Machine::step_fast (diagnostic)
 
 struct Layout {
     int n, NB, RMAX, TMAX, LPOOL, pool_size;
@@ -112,6 +113,7 @@ struct Machine {
     int n, K, eos, pad, num_blocks, active, RA, len_lists, lnt, has_lnt, iters, done, ret_early, err;
     int prompt_len, kv_len, pool_count, pool_head;
     int events, ra_accepted, kv_src_row, kv_copy_dst, kv_copy_len, err_line, err_aux;
+    bool allow_fast = true;   // step_fast() for the steady-state iteration (JF_MB_FAST=0 / the tests switch it off for A/B)
 
     JF_HD Machine(int32_t *s, Lanes l, const Layout &lay) : S(s), L(lay), lanes(l) {}
 
@@ -305,12 +307,113 @@ struct Machine {
         lanes.sync();
     }
 
+    // ---- the steady-state iteration of MB:467-721 as straight-line code ----------------------------------------
+    // One block in flight (num_blocks == 1, RA == 0, one span), some tokens accepted and the rest rejected, and none of
+    // the events that change the shape of the state this iteration: no EOS (in the accepted prefix or as next token), no
+    // spawn, no promotion / early stop, no full accept, iteration budget not exhausted.  Everything is decided from
+    // read-only data first; when a condition does not hold NOTHING has been written and step() runs the general code.
+    // What it does is what step() does for that case, line by line (accept scan over the B candidate rows MB:482-489,
+    // commit MB:526-528, re-draft MB:550-558, the two pool pushes MB:564-573, candidates MB:577-585, KV bookkeeping
+    // MB:617-626), in ~1/4 of the instructions: the last prompt's step is the serial tail of the convergence launch.
+    template <class GreedyFn>
+    JF_HD bool step_fast(GreedyFn G, jf_mb_desc *d) {
+        if (num_blocks != 1 || RA != 0 || len_lists != 1) return false;
+        const int B = S[H_B], T = S[H_T];
+        if (S[H_NSPANS] != 1 || S[H_SPANS] != 0 || iters >= S[H_MAX_ITER]) return false;
+        const int start = S[H_SPANS + 1], Ls = S[H_SPANS + 2];
+        int32_t *bb = blk(0);
+        if (Ls < 2 || bb[B_DROWS] != B || B < 1) return false;
+        const int cmp = Ls - 1;
+        int best_idx = 0, acc_len = 0;
+        for (int r = 0; r < B; ++r) {                                   // MB:482-489: first row with the longest accepted prefix
+            const int32_t *dr = draft(0, r);
+            int m = cmp;
+            for (int i0 = 0; i0 < cmp; i0 += lanes.count()) {
+                const int i = i0 + lanes.lane();
+                const int f = lanes.first_true(i < cmp ? dr[i + 1] != G(r, start - 1 + i) : false);
+                if (f < lanes.count()) { m = i0 + f; break; }
+            }
+            if (m + 1 > acc_len) { acc_len = m + 1; best_idx = r; }
+        }
+        if (acc_len >= Ls) return false;                                // everything accepted: the call may end (MB:590-593)
+        const int32_t *drow = draft(0, best_idx);
+        if (eos >= 0 && find_first_eq(drow, acc_len, eos) < acc_len) return false;   // MB:513-521
+        const int nxt = G(best_idx, start - 1 + acc_len - 1);           // MB:550
+        if (eos >= 0 && nxt == eos) return false;                       // MB:599-614
+        const int old_acclen = bb[B_ACCLEN];
+        const int new_acclen = old_acclen + acc_len, new_total = bb[B_TOTAL] + acc_len;
+        const int newL = Ls - acc_len;
+        if (new_acclen > n + 1) return false;                           // capacity error: reported by the general code
+        if (new_total >= S[H_SPAWN_THR] && active < K) return false;    // MB:629-653 spawn
+        if (new_total >= n) return false;                               // MB:656-721 promote / early stop
+        if (L.pool_size > 0 && new_acclen + newL > L.LPOOL) return false;
+        // ---- nothing below can fail -------------------------------------------------------------------------
+        const int kv_before = kv_len;
+        int kv_cur = kv_before + T;
+        copy(acc(0) + old_acclen, drow, acc_len);                        // MB:526-528
+        lanes.sync();                                                   // drow may be d0 itself
+        int32_t *d0 = draft(0, 0);
+        for (int j = lanes.lane(); j < newL; j += lanes.count())        // [nxt] + greedy[acc_len:-1] (MB:553-558)
+            d0[j] = G(best_idx, start - 1 + acc_len - 1 + j);
+        if (lanes.lane() == 0) { bb[B_ACCLEN] = new_acclen; bb[B_TOTAL] = new_total; bb[B_DROWS] = 1; bb[B_DLEN] = newL; }
+        lanes.sync();
+        ra_accepted += acc_len;
+        if (L.pool_size > 0) {                                          // MB:564-573
+            const int slot = (pool_count == L.pool_size) ? pool_head : wrap(pool_head + pool_count, L.pool_size);
+            int32_t *e = S + L.off_pool + slot * (1 + L.LPOOL);
+            int clen = 0;
+            const int tot = new_acclen + newL;
+            for (int i0 = 0; i0 < tot; i0 += lanes.count()) {           // PAD-stripped acc ⧺ draft, order preserved (MB:405-407)
+                const int i = i0 + lanes.lane();
+                int tok = 0; bool keep = false;
+                if (i < tot) { tok = i < new_acclen ? acc(0)[i] : d0[i - new_acclen]; keep = !(pad >= 0 && tok == pad); }
+                const int before = lanes.prefix_count(keep);
+                if (keep) e[1 + clen + before] = tok;
+                clen += lanes.count_true(keep);
+            }
+            if (clen > 0) pool_push_slot(clen);
+            lanes.sync();
+            const int tlen = newL - 1;                                  // the rejected greedy tail
+            if (tlen > 0) {
+                int32_t *t = pool_push_slot(tlen);
+                for (int i = lanes.lane(); i < tlen; i += lanes.count()) t[1 + i] = d0[1 + i];
+            }
+            lanes.sync();
+        }
+        if (new_total >= S[H_LOOK_THR]) {                               // MB:577-585: every pool entry but the newest, newest first
+            int C = 0;
+            for (int i1 = pool_count - 2; i1 >= 0; --i1) {
+                const int32_t *e = pool_entry(i1);
+                const int elen = e[0];
+                const int pos = find_first_eq(e + 1, elen, nxt);
+                if (pos >= elen) continue;
+                if (1 + C >= L.RMAX) { JF_FAIL(JF_E_CAPACITY); break; }
+                int32_t *c = draft(0, 1 + C);
+                const int avail = elen - pos;
+                for (int j = lanes.lane(); j < newL; j += lanes.count()) c[j] = j < avail ? e[1 + pos + j] : d0[j];   // MB:82-86
+                C++;
+            }
+            lanes.sync();
+            if (C > 1 && lanes.lane() == 0) bb[B_DROWS] = 1 + C;        // a single recycled candidate is ignored (Q5)
+            lanes.sync();
+        }
+        lnt = nxt; has_lnt = 1;
+        events |= EVT_FAST;
+        { const int c = prompt_len + new_acclen; if (kv_cur > c) kv_cur = c; }   // MB:617-626 (committed_len with one block)
+        kv_len = kv_cur;
+        if (err) done = 1;
+        if (best_idx != 0 && kv_len > kv_before) { kv_src_row = best_idx; kv_copy_dst = kv_before; kv_copy_len = kv_len - kv_before; }
+        next_iteration(d);
+        return true;
+    }
+
     // ---- MB:467-721 ------------------------------------------------------------------------------
     template <class GreedyFn>
     JF_HD void step(GreedyFn G, jf_mb_desc *d) {
         load_scalars();
         if (done || err) { next_iteration(d); return; }
         JF_STAMP(1);
+        if (allow_fast && step_fast(G, d)) return;
         const int B = S[H_B], T = S[H_T], nspans = S[H_NSPANS];
         const int kv_before = kv_len;
         int kv_cur = kv_before + T;          // DynamicCache.update appended every forwarded token
@@ -689,33 +792,43 @@ JF_HD void drv_call_end(M &m, const LoopDev &lp, int p, jf_mb_desc *d) {
 
 // Summary of the next forward + the descriptor table, written where the host polls for it (mapped pinned memory).  Run by
 // ONE prompt's lanes after every prompt of the launch has written its descriptor (the caller orders that).  The sequence
-// number goes last, behind a system-scope release.
-template <class Lanes>
-JF_HD void mb_publish_body(Lanes lanes, int P, const jf_mb_desc *desc, const LoopDev &lp) {
+// number goes last.  copy_tables = false: every prompt has already put its own descriptor / driver record into the mailbox
+// (the fused launch), only the header is written here; ld reads one int of another prompt's descriptor.
+struct PlainLoad { JF_HD int operator()(const int32_t *p) const { return *p; } };
+JF_HD void mb_fin_record(const int32_t *D, int32_t *fin, int j) {
+    const int slot[JF_MB_FIN_INTS] = {D_STOP, D_CALLS, D_ITERS, D_NEW, D_FIN_RET_LEN, D_FIN_NEXT, D_FIN_ITERS, D_FIN_OFF};
+    fin[j] = D[slot[j]];
+}
+template <class Lanes, class LoadFn = PlainLoad>
+JF_HD void mb_publish_body(Lanes lanes, int P, const jf_mb_desc *desc, const LoopDev &lp, bool copy_tables = true, LoadFn ld = LoadFn{}) {
     int rtot = 0, rmain = 0, tmax = 0, nvalid = 0, ndone = 0, maxkv = 0, err_p = 0, acc = 0, nend = 0;
     for (int q = lanes.lane(); q < P; q += lanes.count()) {
-        const jf_mb_desc &d = desc[q];
-        if (d.B > 0) { rtot += d.B; rmain += 1; nvalid += d.B * d.T; tmax = imax(tmax, d.T); maxkv = imax(maxkv, d.kv_len); }
-        ndone += d.done ? 1 : 0;
-        acc += d.accepted;
-        nend += (d.events & EVT_CALL_END) ? 1 : 0;
-        if (d.error && (err_p == 0 || q + 1 < err_p)) err_p = q + 1;
+        const jf_mb_desc *d = desc + q;
+        const int B = ld(&d->B);
+        if (B > 0) {
+            const int T = ld(&d->T);
+            rtot += B; rmain += 1; nvalid += B * T; tmax = imax(tmax, T); maxkv = imax(maxkv, ld(&d->kv_len));
+        }
+        ndone += ld(&d->done) ? 1 : 0;
+        acc += ld(&d->accepted);
+        nend += (ld(&d->events) & EVT_CALL_END) ? 1 : 0;
+        if (ld(&d->error) && (err_p == 0 || q + 1 < err_p)) err_p = q + 1;
     }
     rtot = lanes.reduce_sum(rtot); rmain = lanes.reduce_sum(rmain); nvalid = lanes.reduce_sum(nvalid);
     ndone = lanes.reduce_sum(ndone); acc = lanes.reduce_sum(acc); nend = lanes.reduce_sum(nend);
     tmax = -lanes.reduce_min(-tmax); maxkv = -lanes.reduce_min(-maxkv);
     err_p = lanes.reduce_min(err_p ? err_p : INT32_MAX); if (err_p == INT32_MAX) err_p = 0;
     int32_t *mb = lp.mailbox;
-    const int32_t *src = (const int32_t *)desc;
     const int dints = (int)(sizeof(jf_mb_desc) / 4);
-    for (int i = lanes.lane(); i < P * dints; i += lanes.count()) mb[JF_MB_MAILBOX_HDR + i] = src[i];
-    if (lp.drv) {
-        int32_t *fin = mb + JF_MB_MAILBOX_HDR + P * dints;
-        for (int i = lanes.lane(); i < P * JF_MB_FIN_INTS; i += lanes.count()) {
-            const int q = i / JF_MB_FIN_INTS, j = i - q * JF_MB_FIN_INTS;
-            const int32_t *D = lp.drv + (int64_t)q * lp.drv_ints;
-            const int slot[JF_MB_FIN_INTS] = {D_STOP, D_CALLS, D_ITERS, D_NEW, D_FIN_RET_LEN, D_FIN_NEXT, D_FIN_ITERS, D_FIN_OFF};
-            fin[i] = D[slot[j]];
+    if (copy_tables) {
+        const int32_t *src = (const int32_t *)desc;
+        for (int i = lanes.lane(); i < P * dints; i += lanes.count()) mb[JF_MB_MAILBOX_HDR + i] = src[i];
+        if (lp.drv) {
+            int32_t *fin = mb + JF_MB_MAILBOX_HDR + P * dints;
+            for (int i = lanes.lane(); i < P * JF_MB_FIN_INTS; i += lanes.count()) {
+                const int q = i / JF_MB_FIN_INTS;
+                mb_fin_record(lp.drv + (int64_t)q * lp.drv_ints, fin + q * JF_MB_FIN_INTS, i - q * JF_MB_FIN_INTS);
+            }
         }
     }
     if (lanes.lane() == 0) {
@@ -827,10 +940,11 @@ JF_HD void loop_after_step(M &m, const LoopDev *lp, int p, bool was_done, jf_mb_
 
 template <class Lanes>
 JF_HD void mb_step_body(Lanes lanes, int p, int32_t *states, int64_t state_ints, uint64_t *packed,
-                        int64_t packed_len, jf_mb_desc *desc, const LoopDev *lp = nullptr) {
+                        int64_t packed_len, jf_mb_desc *desc, const LoopDev *lp = nullptr, bool fast = true) {
     int32_t *S = states + (int64_t)p * state_ints;
     Layout lay = layout_of(S);
     Machine<Lanes> m(S, lanes, lay);
+    m.allow_fast = fast;
     const PackedRows rows{packed, S[H_ROW_BASE], S[H_CAND_BASE], S[H_TPAD], packed_len};
     const int B = S[H_B];
     const bool was_done = S[H_DONE] != 0;

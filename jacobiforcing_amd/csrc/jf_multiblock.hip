@@ -44,9 +44,9 @@ __global__ __launch_bounds__(64) void mb_pack_kernel(int32_t *states, int64_t st
                        cand_rows, o, valid_align);
 }
 __global__ __launch_bounds__(64) void mb_step_kernel(int32_t *states, int64_t state_ints, unsigned long long *packed,
-                                                      int64_t packed_len, jf_mb_desc *desc, jfmb::LoopDev lp, int has_loop) {
+                                                      int64_t packed_len, jf_mb_desc *desc, jfmb::LoopDev lp, int has_loop, int fast) {
     JF_STAMP(0);
-    jfmb::mb_step_body(DevLanes{}, blockIdx.x, states, state_ints, (uint64_t *)packed, packed_len, desc, has_loop ? &lp : nullptr);
+    jfmb::mb_step_body(DevLanes{}, blockIdx.x, states, state_ints, (uint64_t *)packed, packed_len, desc, has_loop ? &lp : nullptr, fast != 0);
     JF_STAMP(12);
     if (has_loop && lp.mailbox && loop_arrive_last(lp.sync, gridDim.x)) jfmb::mb_publish_body(DevLanes{}, gridDim.x, desc, lp);
 }
@@ -59,6 +59,13 @@ __global__ __launch_bounds__(64) void mb_read_ret_kernel(const int32_t *states, 
                                                           int32_t ret_cap) {
     jfmb::mb_read_ret_body(DevLanes{}, blockIdx.x, states, state_ints, ret, ret_cap);
 }
+
+static int g_fast_path = -1;      // -1: not decided yet (JF_MB_FAST, default on)
+static int fast_path() {
+    if (g_fast_path < 0) { const char *e = getenv("JF_MB_FAST"); g_fast_path = (e && e[0] == '0') ? 0 : 1; }
+    return g_fast_path;
+}
+extern "C" int jf_mb_set_fast_path(int on) { const int old = fast_path(); g_fast_path = on ? 1 : 0; return old; }
 
 static int check_params(const jf_mb_params *p, const char *who) {
     if (!p) return fail(JF_E_INVALID, "%s: null params", who);
@@ -111,7 +118,7 @@ extern "C" int jf_mb_step(int32_t *states, int64_t state_ints, int P, uint64_t *
     if (P <= 0) return JF_OK;
     if (!states || !packed) return fail(JF_E_INVALID, "jf_mb_step: null pointer");
     mb_step_kernel<<<P, 64, 0, (hipStream_t)stream>>>(states, state_ints, (unsigned long long *)packed, packed_len, desc,
-                                                      jfmb::LoopDev{}, 0);
+                                                      jfmb::LoopDev{}, 0, fast_path());
     return check_launch("mb_step_kernel");
 }
 
@@ -153,6 +160,7 @@ struct VerifyArgs {
     int32_t Tpad;
     int32_t compacted;             // 1: logits rows follow valid_index (B*T per prompt); 0: the Rtot x Tpad rectangle
     int32_t lds_ints;              // ints of dynamic LDS available for (compact image + greedy tokens); 0 = step on HBM
+    int32_t fast;                  // Machine::step_fast allowed (jf_mb_set_fast_path)
     int32_t has_loop;              // jf_mb_loop_iterate: kv_len / resident driver / mailbox (lp) apply
     jfmb::LoopDev lp;
 };
@@ -184,6 +192,10 @@ extern "C" __attribute__((visibility("default"))) int jf_exp_reset_vtrace(void) 
 #define JF_VSTAMP(p, k) do { } while (0)
 #endif
 
+struct Lanes192 {                  // wavefronts 1-3 of a stepper workgroup (write-back while wavefront 0 publishes)
+    __device__ __forceinline__ int lane() const { return threadIdx.x - 64; }
+    __device__ __forceinline__ int count() const { return 192; }
+};
 struct Lanes256 {                  // all four wavefronts of a stepper workgroup (copy-in only)
     __device__ __forceinline__ int lane() const { return threadIdx.x; }
     __device__ __forceinline__ int count() const { return 256; }
@@ -200,8 +212,16 @@ constexpr int VERIFY_LDS_HDR = 32;                               // ints in fron
 constexpr unsigned long long VERIFY_WAIT_TICKS = 200000000ull;   // 2 s of the 100 MHz constant clock: never hang the GPU
 
 __device__ __forceinline__ void verify_arrive(const VerifyArgs &a, int owner) {
-    // release: the atomicMax above is performed (and visible at agent scope) before the count moves
+    // The payload is itself an agent-scope atomic RMW (atomicMax on packed[]): it is performed at the coherence point, and the
+    // wait below keeps the count from moving before it has been.  A RELEASE on the add instead would have every item write
+    // back its XCD's L2 (buffer_wbl2): 131 us instead of 70 us per launch at 64 prompts (profiles/verify_release_ab_r03.txt).
+    // The consumer side does carry an acquire (one buffer_inv per stepper, free).
+#ifdef JF_EXP_ARRIVE_RELEASE
     __hip_atomic_fetch_add(a.arrive + (int64_t)owner * VERIFY_ARRIVE_STRIDE, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(a.arrive + (int64_t)owner * VERIFY_ARRIVE_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
 
 __device__ void verify_stepper(const VerifyArgs &a, int p, int32_t *smem) {
@@ -263,6 +283,7 @@ __device__ void verify_stepper(const VerifyArgs &a, int p, int32_t *smem) {
                 SoloWaveLanes{}.sync();
                 JF_VSTAMP(p, 3);
                 Machine<SoloWaveLanes> m(img, SoloWaveLanes{}, LC);
+                m.allow_fast = a.fast != 0;
                 const int32_t *gt = gtok;
                 m.step([gt, T](int r, int t) -> int { return gt[r * T + t]; }, s_desc);
                 SoloWaveLanes{}.sync();
@@ -275,6 +296,7 @@ __device__ void verify_stepper(const VerifyArgs &a, int p, int32_t *smem) {
             }
             if (!wb) {                                           // step on the HBM block (capacities the parameters ask for)
                 Machine<SoloWaveLanes> m(G, SoloWaveLanes{}, LG);
+                m.allow_fast = a.fast != 0;
                 m.step(Gglobal, dg);
                 loop_after_step(m, lp, p, was_done, dg);
             }
@@ -283,25 +305,47 @@ __device__ void verify_stepper(const VerifyArgs &a, int p, int32_t *smem) {
     }
     __syncthreads();
     const int wb = smem[17];
-    if (wb > 0) {
-        compact_to_state(Lanes256{}, img, LC, G, LG);
-        if (dg && threadIdx.x < (int)(sizeof(jf_mb_desc) / 4)) ((int32_t *)dg)[threadIdx.x] = ((const int32_t *)s_desc)[threadIdx.x];
-    }
-    JF_VSTAMP(p, 5);
-    if (wb >= 0) {
-        // re-zero this prompt's slice of the argmax workspace for the next launch
-        for (int r = 0; r < B; ++r) {
-            const int64_t lo = rows.index(r, 0), hi = lo + rows.tpad;
-            for (int64_t i = lo + threadIdx.x; i < hi && i < a.packed_len; i += AM_TPB) a.am.packed[i] = 0ull;
+    const bool mail = lp && lp->mailbox;
+    if (threadIdx.x >= 64) {
+        // ---- wavefronts 1-3: the image goes back to the HBM block and the prompt's argmax slots are re-zeroed, while
+        // wavefront 0 hands the descriptor over (nothing below depends on these stores; the kernel boundary orders them
+        // before the pack launch)
+        if (wb > 0) compact_to_state(Lanes192{}, img, LC, G, LG);
+        JF_VSTAMP(p, 5);
+        if (wb >= 0) {
+            for (int r = 0; r < B; ++r) {
+                const int64_t lo = rows.index(r, 0), hi = lo + rows.tpad;
+                for (int64_t i = lo + (threadIdx.x - 64); i < hi && i < a.packed_len; i += AM_TPB - 64) a.am.packed[i] = 0ull;
+            }
         }
+        return;
     }
+    // ---- wavefront 0: the descriptor goes out through agent-scope atomic stores (the last prompt to finish reads
+    // everybody's for the summary — no cache write-back involved) and, loop API, straight into this prompt's slot of the
+    // host mailbox together with its driver record
+    constexpr int DINTS = (int)(sizeof(jf_mb_desc) / 4);
+    if (dg && threadIdx.x < DINTS) {
+        const int v = wb > 0 ? ((const int32_t *)s_desc)[threadIdx.x] : ((const int32_t *)dg)[threadIdx.x];
+        __hip_atomic_store((int32_t *)dg + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (mail) lp->mailbox[JF_MB_MAILBOX_HDR + p * DINTS + threadIdx.x] = v;
+    }
+    if (mail && lp->drv && threadIdx.x >= 32 && threadIdx.x < 32 + JF_MB_FIN_INTS)
+        mb_fin_record(lp->drv + (int64_t)p * lp->drv_ints, lp->mailbox + JF_MB_MAILBOX_HDR + a.P * DINTS + p * JF_MB_FIN_INTS,
+                      threadIdx.x - 32);
     JF_VSTAMP(p, 6);
     // ---- loop API: the last prompt to get here publishes the next forward's summary to the host ---------------------
-    if (lp && lp->mailbox) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // every wavefront's write-back, before the count moves
-        __syncthreads();
-        if (threadIdx.x < 64 && loop_arrive_last(lp->sync, a.P)) mb_publish_body(SoloWaveLanes{}, a.P, a.desc, *lp);
+    if (mail) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this prompt's descriptor / mailbox stores are performed
+        int old = 0;
+        if (threadIdx.x == 0) old = __hip_atomic_fetch_add(lp->sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old == a.P - 1) {
+            if (threadIdx.x == 0) __hip_atomic_store(lp->sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            auto ld = [](const int32_t *q) -> int { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+            mb_publish_body(SoloWaveLanes{}, a.P, a.desc, *lp, false, ld);
+        }
     }
+    JF_VSTAMP(p, 7);
 }
 
 template <int DT, bool WAVE, bool NT>
@@ -389,7 +433,7 @@ static int verify_launch(const void *logits, int dtype, int64_t R, int64_t V, in
                        : jf_argmax_partial(logits, dtype, R, V, row_stride, packed, stream);
         if (rc) return rc;
         mb_step_kernel<<<P, 64, 0, s>>>(states, state_ints, (unsigned long long *)packed, packed_len, desc,
-                                        lp ? *lp : jfmb::LoopDev{}, lp ? 1 : 0);
+                                        lp ? *lp : jfmb::LoopDev{}, lp ? 1 : 0, fast_path());
         return check_launch("mb_step_kernel");
     }
     VerifyArgs a;
@@ -397,6 +441,7 @@ static int verify_launch(const void *logits, int dtype, int64_t R, int64_t V, in
     a.states = states; a.state_ints = state_ints; a.P = P; a.packed_len = packed_len; a.row_prompt = row_prompt;
     a.arrive = arrive; a.desc = desc; a.Tpad = Tpad; a.compacted = out_index ? 1 : 0; a.lds_ints = (int32_t)lds_ints;
     a.has_loop = lp ? 1 : 0;
+    a.fast = fast_path();
     a.lp = lp ? *lp : jfmb::LoopDev{};
     const int64_t blocks = pl.blocks + P;
     if (blocks > 0x7FFFFFFFll) return fail(JF_E_CAPACITY, "%s: grid too large", who);
@@ -488,7 +533,7 @@ extern "C" int jf_mb_loop_begin(const jf_mb_loop *loop, int32_t seq, const jf_mb
 
 extern "C" int jf_mb_loop_iterate(const jf_mb_loop *loop, int32_t seq, const void *logits, int dtype, int64_t R, int64_t V,
                                   int64_t row_stride, int compacted, int32_t Rtot, int32_t Tpad, const jf_mb_params *params,
-                                  void *stream) {
+                                  int queue_pack, void *stream) {
     int rc = check_loop(loop, "jf_mb_loop_iterate");
     if (rc) return rc;
     if (Rtot <= 0 || Rtot > loop->rows_cap || Tpad <= 0 || (int64_t)Rtot * Tpad > loop->packed_cap)
@@ -498,6 +543,11 @@ extern "C" int jf_mb_loop_iterate(const jf_mb_loop *loop, int32_t seq, const voi
     rc = verify_launch(logits, dtype, R, V, row_stride, compacted ? loop->valid_index : nullptr, loop->states, loop->state_ints,
                        loop->P, loop->packed, (int64_t)Rtot * Tpad, Tpad, loop->row_prompt, loop->arrive, loop->desc, params, &d,
                        stream, "jf_mb_loop_iterate");
-    if (rc) return rc;
+    if (rc || !queue_pack) return rc;
     return loop_pack(loop, (hipStream_t)stream);
+}
+
+extern "C" int jf_mb_loop_pack(const jf_mb_loop *loop, void *stream) {
+    const int rc = check_loop(loop, "jf_mb_loop_pack");
+    return rc ? rc : loop_pack(loop, (hipStream_t)stream);
 }

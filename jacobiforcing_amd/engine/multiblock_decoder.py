@@ -140,12 +140,9 @@ class MultiblockJacobiDecoder:
 
     # ------------------------------------------------------------------------------ one Jacobi iteration
     @torch.inference_mode()
-    def iteration(self, s: ops.LoopSummary) -> ops.LoopSummary:
-        """forward -> convergence check + loop body (+ restarts) + next pack (HIP, one launch + the pack) -> KV commit, then
-        the mailbox.  ``s`` describes the forward to run (the previous launch published it); the forward's inputs were
-        written by the pack launch queued behind that launch."""
-        if s.Rtot == 0:
-            return s
+    def _forward(self, s: ops.LoopSummary) -> torch.Tensor:
+        """Queue the forward ``s`` describes (its inputs were written by the pack launch queued behind the launch that
+        published ``s``) and return its logits."""
         if s.Tpad > self.t_cap:
             raise RuntimeError(f"a row of {s.Tpad} tokens exceeds the forward capacity {self.t_cap} "
                                "(the block counters ran away, see DESIGN.md §3.2)")
@@ -153,29 +150,51 @@ class MultiblockJacobiDecoder:
             raise RuntimeError(f"KV cache rows hold {self.max_seq_len} positions; a prompt at "
                                f"{s.max_kv} cannot take {s.Tpad} more (raise max_seq_len)")
         ids, pos, row_prompt, row_len, row_cand, row_kv = self.loop.inputs()
-        any_cand = s.Rtot > s.Rmain
         self.last_valid_rows = s.Nvalid
         prof = self.profiler
         if prof: prof.start("jacobi.forward")
+        if ops.LOOP_HOOKS and "forward_begin" in ops.LOOP_HOOKS:
+            ops.LOOP_HOOKS["forward_begin"](self.batch)
         logits = self.model.forward(ids, pos, self.cache, row_prompt=row_prompt, row_cand=row_cand, row_len=row_len,
-                                    kv_len_rows=row_kv, any_candidates=any_cand, s_cur=s.max_kv + s.Tpad,
+                                    kv_len_rows=row_kv, any_candidates=s.Rtot > s.Rmain, s_cur=s.max_kv + s.Tpad,
                                     logit_index=self.loop.valid_index(), n_main=s.Rmain)
         if self.logits_hook is not None:
             logits = self.logits_hook(logits, self, prefill=None)
         if prof: prof.stop("jacobi.forward")
         self.forwards += 1
         self.last_logits_rows = logits.shape[0]
+        return logits
+
+    @torch.inference_mode()
+    def _verify(self, s: ops.LoopSummary, logits: torch.Tensor) -> ops.LoopSummary:
+        """Queue the convergence check + loop body (+ restarts) + next pack (one launch + the pack) and the KV commit behind
+        the forward, then poll the mailbox: returns the header of the next forward's summary."""
+        prof = self.profiler
         if prof: prof.start("jacobi.verify")          # argmax + accept + re-draft + pool + spawn/promote (+ restart): one launch
         self.loop.iterate(logits)
-        if self.cache.committer is not None and any_cand:
+        if self.cache.committer is not None and s.Rtot > s.Rmain:
             self.cache.committer.commit(self.batch.desc_dev)
-        s2 = self.loop.wait()
+        s2 = self.loop.wait(snapshot=False)
         if prof:
             prof.stop("jacobi.verify")
             prof.iterations += 1
             prof.tokens += s2.accepted
-        act = s.d[:, self._f["B"]] > 0
-        self.kv_len_host[act] = s2.d[act, self._f["kv_len"]]
+        return s2
+
+    def _account(self, s_prev: ops.LoopSummary, s: ops.LoopSummary) -> None:
+        """Host bookkeeping of the iteration that ran forward ``s_prev`` and published ``s`` (off the critical path)."""
+        self.loop.snapshot(s)
+        act = s_prev.d[:, self._f["B"]] > 0
+        self.kv_len_host[act] = s.d[act, self._f["kv_len"]]
+
+    def iteration(self, s: ops.LoopSummary) -> ops.LoopSummary:
+        """forward -> convergence check + loop body -> KV commit -> mailbox, one after the other (the drivers below overlap
+        the host's bookkeeping with the next forward instead)."""
+        if s.Rtot == 0:
+            return s
+        self.loop.snapshot(s)
+        s2 = self._verify(s, self._forward(s))
+        self._account(s, s2)
         return s2
 
     def _push_kv_len(self) -> None:
@@ -206,7 +225,7 @@ class MultiblockJacobiDecoder:
                  seed: int = 1234, on_iteration: Optional[Callable[[int, np.ndarray], None]] = None,
                  max_iterations: Optional[int] = None, on_generation_start: Optional[Callable[[], None]] = None,
                  on_call_done: Optional[Callable[[int, List[int]], None]] = None, chunks: bool = False,
-                 draws: Optional[ops.DrawStreams] = None):
+                 draws: Optional[ops.DrawStreams] = None, fence_iterations=()):
         assert len(prompts) == self.P
         # one budget per prompt (a scalar applies to all): a prompt stops its calls once it holds that many new tokens
         budgets = ([int(max_new_tokens)] * self.P if np.isscalar(max_new_tokens) else [int(x) for x in max_new_tokens])
@@ -231,7 +250,8 @@ class MultiblockJacobiDecoder:
         if on_generation_start is not None:
             on_generation_start()
         run = self._run_resident if self.resident else self._run_host_driven
-        iters_total = yield from run(s, stats, text, rngs, inputs, budgets, max_calls, on_iteration, max_iterations, on_call_done, chunks)
+        iters_total = yield from run(s, stats, text, rngs, inputs, budgets, max_calls, on_iteration, max_iterations, on_call_done, chunks,
+                                     frozenset(fence_iterations))
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         gen_seconds = time.perf_counter() - t_gen
@@ -260,17 +280,22 @@ class MultiblockJacobiDecoder:
         self.drv.copy_(torch.from_numpy(blk))
         self.draws_dev.copy_(torch.from_numpy(draws.words.view(np.int32)))
 
-    def _run_resident(self, s, stats, text, rngs, inputs, budgets, max_calls, on_iteration, max_iterations, on_call_done, chunks):
+    def _run_resident(self, s, stats, text, rngs, inputs, budgets, max_calls, on_iteration, max_iterations, on_call_done, chunks,
+                      fence_iterations=()):
+        """The loop: forward -> one launch -> mailbox.  The host's bookkeeping for iteration i (descriptor copy, callbacks,
+        streamed chunks) runs after the forward of iteration i+1 has been queued, i.e. while the GPU is busy — except at
+        ``fence_iterations`` (and at the end), where the callback runs before any further GPU work is queued (bench.py's
+        timing fences)."""
         iters_total = 0
         ev = self._f["events"]
-        while s.Rtot > 0:
-            s = self.iteration(s)
-            iters_total += 1
+
+        def account(s_prev, s_new, i):
+            self._account(s_prev, s_new)
             if on_iteration is not None:
-                on_iteration(iters_total, s.d)
-            if chunks and s.n_call_end:
-                ended = np.nonzero(s.d[:, ev] & N.EVT_CALL_END)[0]
-                fin = s.fin
+                on_iteration(i, s_new.d)
+            if chunks and s_new.n_call_end:
+                ended = np.nonzero(s_new.d[:, ev] & N.EVT_CALL_END)[0]
+                fin = s_new.fin
                 off, ln = fin[:, N.FIN_FIELDS.index("text_off")], fin[:, N.FIN_FIELDS.index("ret_len")]
                 H = N.DRV_HDR_INTS
                 rows = [self.drv[int(p), H + int(off[p]):H + int(off[p]) + int(ln[p])] for p in ended]
@@ -282,6 +307,21 @@ class MultiblockJacobiDecoder:
                     if on_call_done is not None:
                         on_call_done(int(p), ret)
                     yield int(p), ret
+
+        pending = None                                   # (s_prev, s_new, i): an iteration whose bookkeeping is still due
+        while s.Rtot > 0:
+            logits = self._forward(s)
+            if pending is not None:
+                yield from account(*pending)
+                pending = None
+            s_new = self._verify(s, logits)
+            iters_total += 1
+            last = (max_iterations is not None and iters_total >= max_iterations) or s_new.Rtot == 0
+            if last or iters_total in fence_iterations:
+                yield from account(s, s_new, iters_total)
+            else:
+                pending = (s, s_new, iters_total)
+            s = s_new
             if max_iterations is not None and iters_total >= max_iterations:
                 break
         return iters_total
@@ -298,7 +338,8 @@ class MultiblockJacobiDecoder:
             st.stop_reason = N.STOP_REASONS.get(int(blk[p, f("stop")]))
 
     # -- host-driven restarts (JF_RESIDENT=0): the reference driver's loop on the host ------------------------------
-    def _run_host_driven(self, s, stats, text, rngs, inputs, budgets, max_calls, on_iteration, max_iterations, on_call_done, chunks):
+    def _run_host_driven(self, s, stats, text, rngs, inputs, budgets, max_calls, on_iteration, max_iterations, on_call_done, chunks,
+                         fence_iterations=()):
         n, eos = self.params.n, self.params.eos_token_id
         for st in stats:
             st.calls = 1                                               # the prefill call counts (DRV:234)

@@ -19,6 +19,8 @@ from . import _native as N
 
 EVT_SPAWN, EVT_SWITCH, EVT_EARLY = 1, 2, 4
 VERIFY_HOOK = None      # bench.py: (before, after) callables around the verify launch (HIP events on the launch stream)
+LOOP_HOOKS = None       # bench.py: {"pack_end": f(batch), "forward_begin": f(batch)} — events behind the queued pack launch and in
+                        # front of the next forward's first kernel (GPU idle time between the loop body and the forward)
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -418,36 +420,51 @@ class MultiblockLoop:
         if flat.shape[0] != want or flat.stride(1) != 1:
             raise ValueError(f"expected contiguous logits for {want} positions, got {tuple(logits.shape)}")
         self.seq += 1
-        VERIFY_HOOK and VERIFY_HOOK[0](b, flat)
+        hook = VERIFY_HOOK                      # bench.py: events around the convergence launch alone, the pack queued after
+        hook and hook[0](b, flat)
         N.check(N.lib().jf_mb_loop_iterate(self.c_loop, self.seq, _ptr(flat), _dtype_code(flat), flat.shape[0], V,
                                            flat.stride(0) if flat.shape[0] > 1 else V, 1 if self.compact else 0, s.Rtot, s.Tpad,
-                                           C.byref(b.c_params), _stream(b.device)), "jf_mb_loop_iterate")
-        VERIFY_HOOK and VERIFY_HOOK[1](b, flat)
+                                           C.byref(b.c_params), 0 if hook else 1, _stream(b.device)), "jf_mb_loop_iterate")
+        if hook:
+            hook[1](b, flat)
+            N.check(N.lib().jf_mb_loop_pack(self.c_loop, _stream(b.device)), "jf_mb_loop_pack")
+        if LOOP_HOOKS and "pack_end" in LOOP_HOOKS:
+            LOOP_HOOKS["pack_end"](b)
 
-    def wait(self) -> LoopSummary:
-        """Poll the mailbox for the sequence number of the last launch."""
+    def wait(self, snapshot: bool = True) -> LoopSummary:
+        """Poll the mailbox for the sequence number of the last launch.  ``snapshot=False`` returns the header only (all the
+        next forward needs); call ``snapshot(s)`` for the descriptor table before the next ``iterate``/``begin`` — e.g. after
+        the forward has been queued, so that the copy is off the critical path."""
         b = self.batch
         N.check(N.lib().jf_mailbox_wait(self._mb_ptr, self.seq, self.timeout_us, _stream(b.device)), "jf_mailbox_wait")
-        m = self.mailbox
-        P = b.P
-        d = m[N.MB_MAILBOX_HDR:N.MB_MAILBOX_HDR + P * N.DESC_INTS].reshape(P, N.DESC_INTS).copy()
-        fin = None
-        if self.drv is not None:
-            o = N.MB_MAILBOX_HDR + P * N.DESC_INTS
-            fin = m[o:o + P * N.MB_FIN_INTS].reshape(P, N.MB_FIN_INTS).copy()
-        if m[N.MB_ERROR]:
-            p = int(m[N.MB_ERROR]) - 1
-            b.arrive.zero_(); b.packed.zero_(); self.sync.zero_()      # a failed launch may have left counts / keys behind
-            f = N.DESC_FIELDS.index
-            N.raise_state_error(int(d[p, f("error")]), f"multiblock prompt {p} (state-machine line {int(d[p, f('rsv0')])})",
-                                aux=int(d[p, f("rsv1")]))
-        s = LoopSummary(seq=int(m[N.MB_SEQ]), Rtot=int(m[N.MB_RTOT]), Rmain=int(m[N.MB_RMAIN]), Tpad=int(m[N.MB_TPAD]),
-                        Tmax=int(m[N.MB_TMAX]), Nvalid=int(m[N.MB_NVALID]), Nvalid_pad=int(m[N.MB_NVALID_PAD]),
-                        n_done=int(m[N.MB_NDONE]), max_kv=int(m[N.MB_MAXKV]), accepted=int(m[N.MB_ACCEPTED]),
-                        n_call_end=int(m[N.MB_NCALL_END]), d=d, fin=fin)
+        h = self.mailbox[:N.MB_MAILBOX_HDR].tolist()
+        s = LoopSummary(seq=h[N.MB_SEQ], Rtot=h[N.MB_RTOT], Rmain=h[N.MB_RMAIN], Tpad=h[N.MB_TPAD], Tmax=h[N.MB_TMAX],
+                        Nvalid=h[N.MB_NVALID], Nvalid_pad=h[N.MB_NVALID_PAD], n_done=h[N.MB_NDONE], max_kv=h[N.MB_MAXKV],
+                        accepted=h[N.MB_ACCEPTED], n_call_end=h[N.MB_NCALL_END], d=None, fin=None)
         self.last = s
         b.Rtot, b.Tpad, b.Nvalid = s.Rtot, s.Tpad, s.Nvalid
         b.valid_index = b.valid_index_buf[:s.Nvalid_pad] if self.compact else None
+        if h[N.MB_ERROR]:
+            self.snapshot(s)
+            p = h[N.MB_ERROR] - 1
+            b.arrive.zero_(); b.packed.zero_(); self.sync.zero_()      # a failed launch may have left counts / keys behind
+            f = N.DESC_FIELDS.index
+            N.raise_state_error(int(s.d[p, f("error")]), f"multiblock prompt {p} (state-machine line {int(s.d[p, f('rsv0')])})",
+                                aux=int(s.d[p, f("rsv1")]))
+        if snapshot:
+            self.snapshot(s)
+        return s
+
+    def snapshot(self, s: LoopSummary) -> LoopSummary:
+        """Copy the descriptor table (and the driver records) of summary ``s`` out of the mailbox."""
+        if s.d is None:
+            if s.seq != self.seq:
+                raise RuntimeError("the mailbox has been overwritten by a later launch")
+            m, P = self.mailbox, self.batch.P
+            s.d = m[N.MB_MAILBOX_HDR:N.MB_MAILBOX_HDR + P * N.DESC_INTS].reshape(P, N.DESC_INTS).copy()
+            if self.drv is not None:
+                o = N.MB_MAILBOX_HDR + P * N.DESC_INTS
+                s.fin = m[o:o + P * N.MB_FIN_INTS].reshape(P, N.MB_FIN_INTS).copy()
         return s
 
     # -- views of the next forward's inputs (written by the pack launch that is already queued) ---------

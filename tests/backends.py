@@ -63,7 +63,8 @@ class HostSimLib:
             "hs_engine_step": (C.c_int, [vp, C.c_int, C.c_int, vp, i32, vp, vp, vp, vp, i64, vp, vp]),
             "hs_sb_step": (C.c_int, [vp, C.c_int, vp, i32, i32, i32, vp, i32, vp]),
             "hs_mb_loop_begin": (C.c_int, [C.POINTER(N.MbLoop), i32, P, vp, vp]),
-            "hs_mb_loop_step": (C.c_int, [C.POINTER(N.MbLoop), i32, P, i32, i32]),
+            "hs_mb_loop_step": (C.c_int, [C.POINTER(N.MbLoop), i32, P, i32, i32, C.c_int]),
+            "hs_mb_loop_pack": (C.c_int, [C.POINTER(N.MbLoop)]),
         }
         self._host_blocks = {}
         for k, (r, a) in sig.items():
@@ -109,6 +110,9 @@ class HostSimLib:
     def jf_mb_read_ret(self, *a):
         return self.hs.hs_mb_read_ret(*a[:-1])
 
+    def jf_mb_set_fast_path(self, on):
+        return self.hs.hs_set_fast_path(int(on))
+
     # -- the loop API: plain memory for the mailbox, the argmax stand-in, then the same bodies prompt after prompt
     def jf_host_alloc(self, nbytes, out):
         buf = (C.c_char * int(nbytes))()
@@ -131,12 +135,15 @@ class HostSimLib:
     def jf_mb_loop_begin(self, loop, seq, params, input_ids, kv_len, stream):
         return self.hs.hs_mb_loop_begin(loop, seq, params, input_ids, kv_len)
 
-    def jf_mb_loop_iterate(self, loop, seq, logits, dtype, R, V, stride, compacted, Rtot, Tpad, params, stream):
+    def jf_mb_loop_pack(self, loop, stream):
+        return self.hs.hs_mb_loop_pack(loop)
+
+    def jf_mb_loop_iterate(self, loop, seq, logits, dtype, R, V, stride, compacted, Rtot, Tpad, params, queue_pack, stream):
         if compacted:
             rc = self.jf_argmax_scatter(logits, dtype, R, V, stride, loop.valid_index, loop.packed, stream)
         else:
             rc = self.jf_argmax_partial(logits, dtype, R, V, stride, loop.packed, stream)
-        return rc or self.hs.hs_mb_loop_step(loop, seq, params, Rtot, Tpad)
+        return rc or self.hs.hs_mb_loop_step(loop, seq, params, Rtot, Tpad, queue_pack)
 
     def jf_engine_step(self, *a):
         return self.hs.hs_engine_step(*a[:-1])

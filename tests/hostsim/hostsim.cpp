@@ -22,7 +22,9 @@ struct HostLanes {
     void publish(int32_t *word, int32_t v) const { *word = v; }
 };
 
+static int g_fast = 1;
 extern "C" {
+int hs_set_fast_path(int on) { const int old = g_fast; g_fast = on ? 1 : 0; return old; }
 
 int64_t hs_mb_state_ints(const jf_mb_params *p) { return jfmb::make_layout(p->n, p->K, p->pool_size, p->max_blocks).total; }
 int32_t hs_mb_max_rows(const jf_mb_params *p) { return jfmb::make_layout(p->n, p->K, p->pool_size, p->max_blocks).RMAX; }
@@ -58,16 +60,17 @@ int hs_mb_loop_begin(const jf_mb_loop *lp, int32_t seq, const jf_mb_params *para
     return 0;
 }
 // the step half of jf_mb_loop_iterate (the caller has filled packed[] with the argmax stand-in)
-int hs_mb_loop_step(const jf_mb_loop *lp, int32_t seq, const jf_mb_params *params, int32_t Rtot, int32_t Tpad) {
+int hs_mb_loop_pack(const jf_mb_loop *lp) { hs_loop_pack(lp); return 0; }
+int hs_mb_loop_step(const jf_mb_loop *lp, int32_t seq, const jf_mb_params *params, int32_t Rtot, int32_t Tpad, int queue_pack) {
     const jfmb::LoopDev d = jfmb::make_loop_dev(lp, seq, params);
     for (int p = 0; p < lp->P; ++p)
-        jfmb::mb_step_body(HostLanes{}, p, lp->states, lp->state_ints, lp->packed, (int64_t)Rtot * Tpad, lp->desc, &d);
+        jfmb::mb_step_body(HostLanes{}, p, lp->states, lp->state_ints, lp->packed, (int64_t)Rtot * Tpad, lp->desc, &d, g_fast != 0);
     jfmb::mb_publish_body(HostLanes{}, lp->P, lp->desc, d);
-    hs_loop_pack(lp);
+    if (queue_pack) hs_loop_pack(lp);
     return 0;
 }
 int hs_mb_step(int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len, jf_mb_desc *desc) {
-    for (int p = 0; p < P; ++p) jfmb::mb_step_body(HostLanes{}, p, states, state_ints, packed, packed_len, desc);
+    for (int p = 0; p < P; ++p) jfmb::mb_step_body(HostLanes{}, p, states, state_ints, packed, packed_len, desc, nullptr, g_fast != 0);
     return 0;
 }
 int hs_mb_read_ret(const int32_t *states, int64_t state_ints, int P, int64_t *ret, int32_t ret_cap) {

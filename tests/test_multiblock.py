@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 import torch
 
+from jacobiforcing_amd import _native as N
 from jacobiforcing_amd import ops
 from oracle import jacobi_oracle as O
 from oracle.scripted_model import ScriptedModel
@@ -34,6 +35,7 @@ def run_calls(batch, models, kvs, inputs, dev, dtype=torch.float32, traces=None)
     d = batch.begin(torch.tensor(inputs, dtype=torch.int64), torch.tensor([len(k) for k in kvs], dtype=torch.int32))
     kvs = [list(k) for k in kvs]
     events = [[] for _ in range(P)]
+    fast, steps = [0] * P, [0] * P
     while True:
         packed_in = batch.pack(d)
         if packed_in is None:
@@ -72,12 +74,15 @@ def run_calls(batch, models, kvs, inputs, dev, dtype=torch.float32, traces=None)
             kvs[p] = kvs[p] + rows_of[p][src][:keep]
             ev = int(batch.desc_field(d, "events")[p])
             events[p] += [nm for bit, nm in ((1, "spawn"), (2, "switch"), (4, "early_stop")) if ev & bit]
+            fast[p] += 1 if ev & N.EVT_FAST else 0
+            steps[p] += 1
         if batch.desc_field(d, "done").all():
             break
     res = batch.results(d)
     for p in range(P):
         res[p]["kv_tokens"] = kvs[p]
         res[p]["banners"] = events[p]
+        res[p]["fast_steps"], res[p]["steps"] = fast[p], steps[p]
     return res
 
 
@@ -338,3 +343,41 @@ def test_many_prompts_side_by_side(backend, P):
                 nt = st.next_token if st.next_token is not None else 0
                 nxt.append([nt] + [int(x) for x in rng.choice(kvs[p], size=n - 1)])
             inputs = nxt
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_fast_path_is_taken_and_changes_nothing(backend):
+    """Machine::step_fast (the steady-state iteration as straight-line code) against the general state-machine code on
+    the same calls: identical results, and the fast path really is the common case at BASELINE's knobs."""
+    with use_backend(backend) as lib:
+        dev = device_for(backend)
+        n, V, P = 32, 300, 5
+        eos_id, pad_id = V - 1, V - 2
+        out = {}
+        for fast_on in (1, 0):
+            old = lib.jf_mb_set_fast_path(fast_on)
+            try:
+                rng = np.random.default_rng(77)
+                models = [ScriptedModel(V, 4000 + p, [0, 40, 70, 82, 95][p], 20 + 7 * p, eos_id=eos_id, eos_pos=None,
+                                        reserved=(pad_id,), period=0) for p in range(P)]
+                kvs = [m.prompt() for m in models]
+                prm = ops.MultiblockParams(n=n, K=2, r=0.85, n_gram_pool_size=4, eos_token_id=eos_id, pad_token_id=pad_id)
+                batch = ops.MultiblockBatch(P, prm, dev)
+                fwd = [(lambda m: (lambda kv_rows, rows: [m.greedy_rows(kv_rows[b], [rows[b]])[0] for b in range(len(rows))]))(m)
+                       for m in models]
+                inputs = [O.mb_prefill(fwd[p], kvs[p], [int(x) for x in rng.choice(kvs[p], size=n)])[0] for p in range(P)]
+                got = []
+                for call in range(3):
+                    res = run_calls(batch, models, kvs, inputs, dev)
+                    got.append([(r["ret"], r["next_token"], r["iters"], r["kv_tokens"], r["banners"]) for r in res])
+                    kvs = [r["kv_tokens"] for r in res]
+                    inputs = [[max(r["next_token"], 0)] + [int(x) for x in rng.choice(kvs[p], size=n - 1)] for p, r in enumerate(res)]
+                    if fast_on:
+                        frac = sum(r["fast_steps"] for r in res) / max(sum(r["steps"] for r in res), 1)
+                        assert frac > 0.5, frac
+                    else:
+                        assert sum(r["fast_steps"] for r in res) == 0
+                out[fast_on] = got
+            finally:
+                lib.jf_mb_set_fast_path(old)
+        assert out[1] == out[0]
