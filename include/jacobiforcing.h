@@ -189,11 +189,10 @@ JF_API int jf_mb_verify(const void *logits, int dtype, int64_t R, int64_t V, int
  *   - writes each prompt's committed KV length where the forward reads it (kv_len, replaces MB:36-59's trims),
  *   - with a resident driver block per prompt: ends the call (DRV:232-250: text += ret, stop on EOS / max_new_tokens /
  *     max_calls), and begins the next one with [first_correct_token] + n-1 tokens drawn from the text (DRV:209-215),
- *   - and the LAST prompt to finish publishes a summary of the next forward + the descriptor table to a mailbox in mapped
- *     pinned host memory, stamped with a sequence number (system-scope release): the host polls that word instead of
- *     copying descriptors and synchronising the stream.
- * A pack launch queued right behind it (row length chosen on the device) writes the next forward's inputs while the host is
- * still waking up.
+ *   - and mails every prompt's descriptor to a mailbox in mapped pinned host memory.
+ * The pack launch queued right behind it (row length chosen on the device) first stamps the mailbox with a summary of the
+ * next forward and a sequence number (system-scope release) — the host polls that word instead of copying descriptors and
+ * synchronising the stream — and then writes the next forward's inputs while the host is still waking up.
  */
 enum {  /* mailbox layout (int32): header, then P descriptors (16 ints each), then P driver records (JF_MB_FIN_INTS each) */
     JF_MB_SEQ = 0,        /* written last: the sequence number passed to the call                            */
@@ -244,7 +243,6 @@ typedef struct jf_mb_loop {
     int64_t pad_fill;
     int32_t *kv_len;                              /* nullable [P]: committed length per prompt (the cache's)      */
     int32_t *mailbox;                             /* JF_MB_MAILBOX_INTS(P) ints of MAPPED PINNED HOST memory (jf_host_alloc) */
-    int32_t *sync;                                /* [4] device ints, zero                                        */
     /* resident driver (all nullable / 0: the caller restarts calls itself with jf_mb_loop_begin)                  */
     int32_t *drv; int64_t drv_ints;               /* [P, drv_ints]: JF_DRV_HDR_INTS + text capacity               */
     const uint32_t *draws; int32_t draw_len;      /* [P, draw_len] pre-drawn 32-bit words                         */
@@ -268,8 +266,9 @@ JF_API int jf_mb_loop_begin(const jf_mb_loop *loop, int32_t seq, const jf_mb_par
 JF_API int jf_mb_loop_iterate(const jf_mb_loop *loop, int32_t seq, const void *logits, int dtype, int64_t R, int64_t V,
                        int64_t row_stride, int compacted, int32_t Rtot, int32_t Tpad, const jf_mb_params *params,
                        int queue_pack, void *stream);
-/* The pack step alone (queue_pack = 0 above: a caller that brackets the convergence launch with its own events). */
-JF_API int jf_mb_loop_pack(const jf_mb_loop *loop, void *stream);
+/* The pack step alone (queue_pack = 0 above: a caller that brackets the convergence launch with its own events); it is the
+ * launch that stamps the mailbox with `seq`. */
+JF_API int jf_mb_loop_pack(const jf_mb_loop *loop, int32_t seq, const jf_mb_params *params, void *stream);
 
 /* A/B knob: 0 makes every step run the general state-machine code instead of its straight-line steady-state path
  * (Machine::step_fast); results are identical (the parity suites run both).  Returns the previous setting.  Default 1, or

@@ -43,7 +43,7 @@ class MbLoop(C.Structure):
                 ("row_cand", C.c_void_p), ("row_kv_len", C.c_void_p), ("valid_index", C.c_void_p),
                 ("rows_cap", C.c_int32), ("t_cap", C.c_int32), ("t_align", C.c_int32), ("valid_align", C.c_int32),
                 ("cand_rows", C.c_int32), ("rsv0", C.c_int32), ("pad_fill", C.c_int64),
-                ("kv_len", C.c_void_p), ("mailbox", C.c_void_p), ("sync", C.c_void_p),
+                ("kv_len", C.c_void_p), ("mailbox", C.c_void_p),
                 ("drv", C.c_void_p), ("drv_ints", C.c_int64), ("draws", C.c_void_p), ("draw_len", C.c_int32),
                 ("max_seq_len", C.c_int32)]
 
@@ -119,7 +119,7 @@ _SIGNATURES = {
     "jf_mb_loop_begin": (C.c_int, [C.POINTER(MbLoop), _i32, C.POINTER(MbParams), _vp, _vp, _vp]),
     "jf_mb_loop_iterate": (C.c_int, [C.POINTER(MbLoop), _i32, _vp, C.c_int, _i64, _i64, _i64, C.c_int, _i32, _i32,
                                      C.POINTER(MbParams), C.c_int, _vp]),
-    "jf_mb_loop_pack": (C.c_int, [C.POINTER(MbLoop), _vp]),
+    "jf_mb_loop_pack": (C.c_int, [C.POINTER(MbLoop), _i32, C.POINTER(MbParams), _vp]),
     "jf_kv_append": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i32, _vp]),
     "jf_rope_kv_append": (C.c_int, [_vp, C.c_int, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
                                     _vp, _i64, _vp]),

@@ -429,31 +429,16 @@ struct Machine {
             int best_idx = 0, acc_raw = 0;
             const int nrows = (b == RA) ? B : 1;
             const int cmp = Ls - 1;          // comparisons per row; m == cmp <=> no mismatch found (yet)
-            // four rows per pass: their loads are independent and issue together, then one ballot per row
-            for (int r0 = 0; r0 < nrows; r0 += 4) {
-                int m[4] = {cmp, cmp, cmp, cmp};
+            // (the steady-state iteration never gets here — step_fast; this loop favours code size over overlapped loads)
+            for (int r = 0; r < nrows; ++r) {
+                const int32_t *dr = draft(b, rows_d == 1 ? 0 : r);
+                int m = cmp;
                 for (int i0 = 0; i0 < cmp; i0 += lanes.count()) {
                     const int i = i0 + lanes.lane();
-                    bool mm[4];
-JF_UNROLL
-                    for (int k = 0; k < 4; ++k) {
-                        const int r = r0 + k;
-                        mm[k] = (r < nrows && i < cmp && m[k] == cmp)
-                                    ? draft(b, rows_d == 1 ? 0 : r)[i + 1] != G(r, start - 1 + i) : false;
-                    }
-                    bool open = false;
-JF_UNROLL
-                    for (int k = 0; k < 4; ++k) {
-                        if (r0 + k < nrows && m[k] == cmp) {
-                            const int f = lanes.first_true(mm[k]);
-                            if (f < lanes.count()) m[k] = i0 + f; else open = true;
-                        }
-                    }
-                    if (!open) break;
+                    const int f = lanes.first_true(i < cmp ? dr[i + 1] != G(r, start - 1 + i) : false);
+                    if (f < lanes.count()) { m = i0 + f; break; }
                 }
-JF_UNROLL
-                for (int k = 0; k < 4; ++k)
-                    if (r0 + k < nrows && m[k] + 1 > acc_raw) { acc_raw = m[k] + 1; best_idx = r0 + k; }
+                if (m + 1 > acc_raw) { acc_raw = m + 1; best_idx = r; }
             }
             JF_STAMP(2);
             if (rows_d != 1 && B != 1 && rows_d != B) {                                   // torch broadcast raises (MB:482)
@@ -540,41 +525,18 @@ JF_UNROLL
                     // MB:577-585 candidates
                     if (new_total >= look_thr) {
                         int C = 0;
-                        // reversed(list(pool)[:-1]), four entries per pass so that their length reads, then their token
-                        // reads, are independent round trips instead of a chain
-                        for (int i1 = pool_count - 2; i1 >= 0 && !err; i1 -= 4) {
-                            const int32_t *e[4];
-                            int elen[4], pos[4];
-JF_UNROLL
-                            for (int k = 0; k < 4; ++k) e[k] = (i1 - k >= 0) ? pool_entry(i1 - k) : nullptr;
-                            int maxlen = 0;
-JF_UNROLL
-                            for (int k = 0; k < 4; ++k) { elen[k] = e[k] ? e[k][0] : 0; pos[k] = elen[k]; maxlen = imax(maxlen, elen[k]); }
-                            for (int i0 = 0; i0 < maxlen; i0 += lanes.count()) {
-                                const int i = i0 + lanes.lane();
-                                bool hit[4];
-JF_UNROLL
-                                for (int k = 0; k < 4; ++k) hit[k] = (pos[k] == elen[k] && i < elen[k]) ? e[k][1 + i] == nxt : false;
-                                bool open = false;
-JF_UNROLL
-                                for (int k = 0; k < 4; ++k) {
-                                    if (pos[k] == elen[k] && i0 < elen[k]) {
-                                        const int f = lanes.first_true(hit[k]);
-                                        if (f < lanes.count()) pos[k] = i0 + f; else if (i0 + lanes.count() < elen[k]) open = true;
-                                    }
-                                }
-                                if (!open) break;
-                            }
-JF_UNROLL
-                            for (int k = 0; k < 4; ++k) {
-                                if (!e[k] || pos[k] >= elen[k] || err) continue;
-                                if (1 + C >= L.RMAX) { JF_FAIL(JF_E_CAPACITY); continue; }
-                                int32_t *c = draft(b, 1 + C);
-                                const int avail = elen[k] - pos[k];
-                                for (int j = lanes.lane(); j < newL; j += lanes.count())
-                                    c[j] = j < avail ? e[k][1 + pos[k] + j] : d0[j];   // MB:82-86
-                                C++;
-                            }
+                        // reversed(list(pool)[:-1]): every entry but the newest, newest first
+                        for (int i1 = pool_count - 2; i1 >= 0 && !err; --i1) {
+                            const int32_t *e = pool_entry(i1);
+                            const int elen = e[0];
+                            const int pos = find_first_eq(e + 1, elen, nxt);
+                            if (pos >= elen) continue;
+                            if (1 + C >= L.RMAX) { JF_FAIL(JF_E_CAPACITY); continue; }
+                            int32_t *c = draft(b, 1 + C);
+                            const int avail = elen - pos;
+                            for (int j = lanes.lane(); j < newL; j += lanes.count())
+                                c[j] = j < avail ? e[1 + pos + j] : d0[j];   // MB:82-86
+                            C++;
                         }
                         if (err) break;
                         lanes.sync();
@@ -705,8 +667,7 @@ enum : int { D_ACTIVE = JF_DRV_ACTIVE, D_STOP = JF_DRV_STOP, D_CALLS = JF_DRV_CA
 
 struct LoopDev {                   // what a step needs beyond the state block (all nullable / zero = classic jf_mb_step)
     int32_t *kv_len;               // [P] committed length per prompt, written by every begin / step
-    int32_t *mailbox;              // host-visible summary + descriptor table (JF_MB_MAILBOX_*), written by the last prompt to finish
-    int32_t *sync;                 // [0] prompts finished in this launch (returns to zero)
+    int32_t *mailbox;              // host-visible summary + descriptor table (JF_MB_MAILBOX_*); the pack launch stamps it
     int32_t seq;                   // sequence number the mailbox is stamped with
     int32_t t_align, t_cap, valid_align;
     int32_t *drv;                  // [P, drv_ints] resident driver blocks (nullable)
@@ -720,7 +681,7 @@ JF_HD int32_t align_up(int32_t v, int32_t a) { return a > 1 ? (v + a - 1) / a * 
 
 inline LoopDev make_loop_dev(const jf_mb_loop *lp, int32_t seq, const jf_mb_params *params) {
     LoopDev d{};
-    d.kv_len = lp->kv_len; d.mailbox = lp->mailbox; d.sync = lp->sync; d.seq = seq;
+    d.kv_len = lp->kv_len; d.mailbox = lp->mailbox; d.seq = seq;
     d.t_align = lp->t_align < 1 ? 1 : lp->t_align; d.t_cap = lp->t_cap; d.valid_align = lp->valid_align < 1 ? 1 : lp->valid_align;
     d.drv = lp->drv; d.drv_ints = lp->drv_ints; d.draws = lp->draws; d.draw_len = lp->draw_len;
     d.text_cap = lp->drv ? (int32_t)(lp->drv_ints - JF_DRV_HDR_INTS) : 0; d.max_seq_len = lp->max_seq_len;
@@ -790,29 +751,26 @@ JF_HD void drv_call_end(M &m, const LoopDev &lp, int p, jf_mb_desc *d) {
     m.lanes.sync();
 }
 
-// Summary of the next forward + the descriptor table, written where the host polls for it (mapped pinned memory).  Run by
-// ONE prompt's lanes after every prompt of the launch has written its descriptor (the caller orders that).  The sequence
-// number goes last.  copy_tables = false: every prompt has already put its own descriptor / driver record into the mailbox
-// (the fused launch), only the header is written here; ld reads one int of another prompt's descriptor.
-struct PlainLoad { JF_HD int operator()(const int32_t *p) const { return *p; } };
+// Summary of the next forward, written where the host polls for it (the mailbox: mapped pinned host memory).  Run by the
+// lanes of ONE prompt at the start of the pack step — the launch queued behind the convergence launch, so every prompt's
+// descriptor is final — while the other prompts' lanes are already writing the forward's inputs.  copy_tables = false: every
+// prompt's stepper has put its own descriptor / driver record into the mailbox (the fused launch), only the header is
+// written here.  The sequence number goes last, behind a system-scope release.
 JF_HD void mb_fin_record(const int32_t *D, int32_t *fin, int j) {
-    const int slot[JF_MB_FIN_INTS] = {D_STOP, D_CALLS, D_ITERS, D_NEW, D_FIN_RET_LEN, D_FIN_NEXT, D_FIN_ITERS, D_FIN_OFF};
-    fin[j] = D[slot[j]];
+    const int slot = j == 0 ? D_STOP : j == 1 ? D_CALLS : j == 2 ? D_ITERS : j == 3 ? D_NEW : j == 4 ? D_FIN_RET_LEN
+                   : j == 5 ? D_FIN_NEXT : j == 6 ? D_FIN_ITERS : D_FIN_OFF;
+    fin[j] = D[slot];
 }
-template <class Lanes, class LoadFn = PlainLoad>
-JF_HD void mb_publish_body(Lanes lanes, int P, const jf_mb_desc *desc, const LoopDev &lp, bool copy_tables = true, LoadFn ld = LoadFn{}) {
+template <class Lanes>
+JF_HD void mb_publish_body(Lanes lanes, int P, const jf_mb_desc *desc, const LoopDev &lp, bool copy_tables) {
     int rtot = 0, rmain = 0, tmax = 0, nvalid = 0, ndone = 0, maxkv = 0, err_p = 0, acc = 0, nend = 0;
     for (int q = lanes.lane(); q < P; q += lanes.count()) {
-        const jf_mb_desc *d = desc + q;
-        const int B = ld(&d->B);
-        if (B > 0) {
-            const int T = ld(&d->T);
-            rtot += B; rmain += 1; nvalid += B * T; tmax = imax(tmax, T); maxkv = imax(maxkv, ld(&d->kv_len));
-        }
-        ndone += ld(&d->done) ? 1 : 0;
-        acc += ld(&d->accepted);
-        nend += (ld(&d->events) & EVT_CALL_END) ? 1 : 0;
-        if (ld(&d->error) && (err_p == 0 || q + 1 < err_p)) err_p = q + 1;
+        const jf_mb_desc d = desc[q];
+        if (d.B > 0) { rtot += d.B; rmain += 1; nvalid += d.B * d.T; tmax = imax(tmax, d.T); maxkv = imax(maxkv, d.kv_len); }
+        ndone += d.done ? 1 : 0;
+        acc += d.accepted;
+        nend += (d.events & EVT_CALL_END) ? 1 : 0;
+        if (d.error && (err_p == 0 || q + 1 < err_p)) err_p = q + 1;
     }
     rtot = lanes.reduce_sum(rtot); rmain = lanes.reduce_sum(rmain); nvalid = lanes.reduce_sum(nvalid);
     ndone = lanes.reduce_sum(ndone); acc = lanes.reduce_sum(acc); nend = lanes.reduce_sum(nend);
@@ -869,7 +827,8 @@ struct PackOut {
 template <class Lanes>
 JF_HD void mb_pack_body(Lanes lanes, int p, int P, int32_t *states, int64_t state_ints, const jf_mb_desc *desc, int32_t Tpad_in,
                         int32_t t_align, int32_t t_cap, int64_t pad_fill, int order, int32_t cand_rows, const PackOut &o,
-                        int32_t valid_align) {
+                        int32_t valid_align, const LoopDev &lp, int publish /* 0 no, 1 header only, 2 header + tables */) {
+    if (publish && p == 0) mb_publish_body(lanes, P, desc, lp, publish == 2);
     int32_t *S = states + (int64_t)p * state_ints;
     // exclusive prefixes over the prompts before this one and totals over all of them, lanes in parallel
     int rows_b = 0, valid_b = 0, act_b = 0, act_t = 0, cand_b = 0, va_b = 0, va_t = 0, vb_b = 0, v_t = 0, tmax = 0;
@@ -931,16 +890,18 @@ struct PackedRows {
 };
 
 // What follows Machine::step in the loop API: the resident driver's call end, then the prompt's committed length.
+// (the loop's view is passed by reference + a flag, never as a nullable pointer: a select between an address and null keeps
+// the whole kernel-argument struct in scratch memory)
 template <class M>
-JF_HD void loop_after_step(M &m, const LoopDev *lp, int p, bool was_done, jf_mb_desc *d) {
-    if (!lp) return;
-    if (lp->drv && !was_done && m.done && !m.err && lp->drv[(int64_t)p * lp->drv_ints + D_ACTIVE]) drv_call_end(m, *lp, p, d);
-    if (lp->kv_len && m.lanes.lane() == 0 && !m.err && !was_done) lp->kv_len[p] = m.kv_len;
+JF_HD void loop_after_step(M &m, const LoopDev &lp, bool has_loop, int p, bool was_done, jf_mb_desc *d) {
+    if (!has_loop) return;
+    if (lp.drv && !was_done && m.done && !m.err && lp.drv[(int64_t)p * lp.drv_ints + D_ACTIVE]) drv_call_end(m, lp, p, d);
+    if (lp.kv_len && m.lanes.lane() == 0 && !m.err && !was_done) lp.kv_len[p] = m.kv_len;
 }
 
 template <class Lanes>
 JF_HD void mb_step_body(Lanes lanes, int p, int32_t *states, int64_t state_ints, uint64_t *packed,
-                        int64_t packed_len, jf_mb_desc *desc, const LoopDev *lp = nullptr, bool fast = true) {
+                        int64_t packed_len, jf_mb_desc *desc, const LoopDev &lp, bool has_loop, bool fast = true) {
     int32_t *S = states + (int64_t)p * state_ints;
     Layout lay = layout_of(S);
     Machine<Lanes> m(S, lanes, lay);
@@ -953,7 +914,7 @@ JF_HD void mb_step_body(Lanes lanes, int p, int32_t *states, int64_t state_ints,
         return (idx >= 0 && idx < rows.plen) ? decode_packed(rows.pk[idx]) : -1;
     };
     m.step(G, desc ? desc + p : nullptr);
-    loop_after_step(m, lp, p, was_done, desc ? desc + p : nullptr);
+    loop_after_step(m, lp, has_loop, p, was_done, desc ? desc + p : nullptr);
     // re-zero this prompt's slice of the argmax workspace for the next jf_argmax_partial
     lanes.sync();
     for (int r = 0; r < B; ++r) {

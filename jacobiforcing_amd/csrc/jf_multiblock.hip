@@ -18,37 +18,26 @@ __device__ unsigned long long g_mtrace[16 * 256];
 // ------------------------------------------------------------------------------------------------
 // multiblock state machine: one wavefront per prompt
 // ------------------------------------------------------------------------------------------------
-// A one-wavefront workgroup reports that its prompt's global writes are done; true for the last of P to do so (which then
-// sees everybody's writes).  The counter returns to zero.
-__device__ __forceinline__ bool loop_arrive_last(int32_t *counter, int P) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    int old = 0;
-    if ((threadIdx.x & 63) == 0) old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    old = __builtin_amdgcn_readfirstlane(old);
-    if (old != P - 1) return false;
-    if ((threadIdx.x & 63) == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    return true;
-}
-
 __global__ __launch_bounds__(64) void mb_begin_kernel(int32_t *states, int64_t state_ints, jf_mb_params prm,
                                                        const int64_t *input_ids, const int32_t *kv_len, jf_mb_desc *desc,
-                                                       jfmb::LoopDev lp) {
-    jfmb::mb_begin_body(DevLanes{}, blockIdx.x, states, state_ints, prm, input_ids, kv_len, desc, lp.kv_len);
-    if (lp.mailbox && loop_arrive_last(lp.sync, gridDim.x)) jfmb::mb_publish_body(DevLanes{}, gridDim.x, desc, lp);
+                                                       int32_t *kv_len_out) {
+    jfmb::mb_begin_body(DevLanes{}, blockIdx.x, states, state_ints, prm, input_ids, kv_len, desc, kv_len_out);
 }
+// publish: the loop API's summary for the host goes out at the START of this launch (prompt 0's wavefront), while the other
+// wavefronts write the forward's inputs: 1 = header only (the steppers of the fused launch mailed their own descriptors),
+// 2 = header + descriptor table + driver records
 __global__ __launch_bounds__(64) void mb_pack_kernel(int32_t *states, int64_t state_ints, const jf_mb_desc *desc, int32_t Tpad,
                                                       int32_t t_align, int32_t t_cap, int64_t pad_fill, int32_t order,
-                                                      int32_t cand_rows, jfmb::PackOut o, int32_t valid_align) {
+                                                      int32_t cand_rows, jfmb::PackOut o, int32_t valid_align, jfmb::LoopDev lp,
+                                                      int32_t publish) {
     jfmb::mb_pack_body(DevLanes{}, blockIdx.x, gridDim.x, states, state_ints, desc, Tpad, t_align, t_cap, pad_fill, order,
-                       cand_rows, o, valid_align);
+                       cand_rows, o, valid_align, lp, publish);
 }
 __global__ __launch_bounds__(64) void mb_step_kernel(int32_t *states, int64_t state_ints, unsigned long long *packed,
                                                       int64_t packed_len, jf_mb_desc *desc, jfmb::LoopDev lp, int has_loop, int fast) {
     JF_STAMP(0);
-    jfmb::mb_step_body(DevLanes{}, blockIdx.x, states, state_ints, (uint64_t *)packed, packed_len, desc, has_loop ? &lp : nullptr, fast != 0);
+    jfmb::mb_step_body(DevLanes{}, blockIdx.x, states, state_ints, (uint64_t *)packed, packed_len, desc, lp, has_loop != 0, fast != 0);
     JF_STAMP(12);
-    if (has_loop && lp.mailbox && loop_arrive_last(lp.sync, gridDim.x)) jfmb::mb_publish_body(DevLanes{}, gridDim.x, desc, lp);
 }
 #ifdef JF_EXP_MB_TRACE
 extern "C" int jf_exp_read_trace(unsigned long long *out32) {
@@ -97,7 +86,7 @@ extern "C" int jf_mb_begin(int32_t *states, int64_t state_ints, int P, const jf_
     if (rc) return rc;
     if (!states || !input_ids || !kv_len) return fail(JF_E_INVALID, "jf_mb_begin: null pointer");
     if (state_ints < jf_mb_state_ints(params)) return fail(JF_E_INVALID, "jf_mb_begin: state block too small");
-    mb_begin_kernel<<<P, 64, 0, (hipStream_t)stream>>>(states, state_ints, *params, input_ids, kv_len, desc, jfmb::LoopDev{});
+    mb_begin_kernel<<<P, 64, 0, (hipStream_t)stream>>>(states, state_ints, *params, input_ids, kv_len, desc, nullptr);
     return check_launch("mb_begin_kernel");
 }
 
@@ -109,7 +98,7 @@ extern "C" int jf_mb_pack(int32_t *states, int64_t state_ints, int P, int32_t Tp
     if (Tpad <= 0) return fail(JF_E_INVALID, "jf_mb_pack: Tpad=%d", Tpad);
     const jfmb::PackOut o{input_ids, positions, row_prompt, row_len, valid_index, nullptr, nullptr};
     mb_pack_kernel<<<P, 64, 0, (hipStream_t)stream>>>(states, state_ints, nullptr, Tpad, 1, Tpad, pad_fill, 0, 1, o,
-                                                      valid_align < 1 ? 1 : valid_align);
+                                                      valid_align < 1 ? 1 : valid_align, jfmb::LoopDev{}, 0);
     return check_launch("mb_pack_kernel");
 }
 
@@ -167,10 +156,11 @@ struct VerifyArgs {
 
 #ifdef JF_EXP_VERIFY_TRACE
 // experiment build only (tools/verify_trace.py): wall-clock stamps (100 MHz) of the launch — [0] first item start, [1] last
-// item end, then 8 per stepper: start, image copied, rows arrived, tokens gathered, stepped, written back, end
+// item end, then 8 per stepper: start, image copied, rows arrived, tokens gathered, stepped, written back (wavefronts 1-3),
+// descriptor out, end (summary published when this was the last prompt)
 __device__ unsigned long long g_vtrace[2 + 8 * 256];
 __device__ unsigned long long g_vitems[2 * 8192];       // (start, end) per item workgroup: plain stores, no atomics in the stream
-#define JF_VSTAMP(p, k) do { if (threadIdx.x == 0 && (p) < 256) g_vtrace[2 + 8 * (p) + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define JF_VSTAMP(p, k) do { if (threadIdx.x == ((k) == 5 ? 64 : 0) && (p) < 256) g_vtrace[2 + 8 * (p) + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 extern "C" __attribute__((visibility("default"))) int jf_exp_read_vtrace(unsigned long long *out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vtrace), sizeof(unsigned long long) * (size_t)n);
 }
@@ -224,7 +214,7 @@ __device__ __forceinline__ void verify_arrive(const VerifyArgs &a, int owner) {
 #endif
 }
 
-__device__ void verify_stepper(const VerifyArgs &a, int p, int32_t *smem) {
+__device__ __forceinline__ void verify_stepper(const VerifyArgs &a, int p, int32_t *smem) {   // one call site; as a real call the whole launch pays its register budget
     using namespace jfmb;
     int32_t *G = a.states + (int64_t)p * a.state_ints;
     const Layout LG = layout_of(G);
@@ -233,7 +223,8 @@ __device__ void verify_stepper(const VerifyArgs &a, int p, int32_t *smem) {
     const PackedRows rows{(const uint64_t *)a.am.packed, G[H_ROW_BASE], G[H_CAND_BASE], G[H_TPAD], a.packed_len};
     const int ng = B * T;                                        // greedy tokens this prompt consumes
     const bool was_done = G[H_DONE] != 0;
-    const LoopDev *lp = a.has_loop ? &a.lp : nullptr;
+    const LoopDev &lp = a.lp;
+    const bool has_loop = a.has_loop != 0;
     JF_VSTAMP(p, 0);
     // dynamic LDS: [0,16) descriptor, [16,32) flags, then the compact image, then the greedy tokens
     jf_mb_desc *s_desc = (jf_mb_desc *)smem;
@@ -289,7 +280,7 @@ __device__ void verify_stepper(const VerifyArgs &a, int p, int32_t *smem) {
                 SoloWaveLanes{}.sync();
                 if (!s_desc->error) {
                     wb = 1;
-                    loop_after_step(m, lp, p, was_done, s_desc);
+                    loop_after_step(m, lp, has_loop, p, was_done, s_desc);
                     SoloWaveLanes{}.sync();
                 }
                 JF_VSTAMP(p, 4);
@@ -298,14 +289,14 @@ __device__ void verify_stepper(const VerifyArgs &a, int p, int32_t *smem) {
                 Machine<SoloWaveLanes> m(G, SoloWaveLanes{}, LG);
                 m.allow_fast = a.fast != 0;
                 m.step(Gglobal, dg);
-                loop_after_step(m, lp, p, was_done, dg);
+                loop_after_step(m, lp, has_loop, p, was_done, dg);
             }
         }
         if (lane == 0) smem[17] = wb;
     }
     __syncthreads();
     const int wb = smem[17];
-    const bool mail = lp && lp->mailbox;
+    const bool mail = has_loop && lp.mailbox;
     if (threadIdx.x >= 64) {
         // ---- wavefronts 1-3: the image goes back to the HBM block and the prompt's argmax slots are re-zeroed, while
         // wavefront 0 hands the descriptor over (nothing below depends on these stores; the kernel boundary orders them
@@ -320,31 +311,18 @@ __device__ void verify_stepper(const VerifyArgs &a, int p, int32_t *smem) {
         }
         return;
     }
-    // ---- wavefront 0: the descriptor goes out through agent-scope atomic stores (the last prompt to finish reads
-    // everybody's for the summary — no cache write-back involved) and, loop API, straight into this prompt's slot of the
-    // host mailbox together with its driver record
+    // ---- wavefront 0: the descriptor goes to the descriptor table and, loop API, straight into this prompt's slot of the
+    // host mailbox together with its driver record (the summary over all prompts is the pack launch's first action)
     constexpr int DINTS = (int)(sizeof(jf_mb_desc) / 4);
     if (dg && threadIdx.x < DINTS) {
         const int v = wb > 0 ? ((const int32_t *)s_desc)[threadIdx.x] : ((const int32_t *)dg)[threadIdx.x];
-        __hip_atomic_store((int32_t *)dg + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (mail) lp->mailbox[JF_MB_MAILBOX_HDR + p * DINTS + threadIdx.x] = v;
+        if (wb > 0) ((int32_t *)dg)[threadIdx.x] = v;
+        if (mail) lp.mailbox[JF_MB_MAILBOX_HDR + p * DINTS + threadIdx.x] = v;
     }
-    if (mail && lp->drv && threadIdx.x >= 32 && threadIdx.x < 32 + JF_MB_FIN_INTS)
-        mb_fin_record(lp->drv + (int64_t)p * lp->drv_ints, lp->mailbox + JF_MB_MAILBOX_HDR + a.P * DINTS + p * JF_MB_FIN_INTS,
+    if (mail && lp.drv && threadIdx.x >= 32 && threadIdx.x < 32 + JF_MB_FIN_INTS)
+        mb_fin_record(lp.drv + (int64_t)p * lp.drv_ints, lp.mailbox + JF_MB_MAILBOX_HDR + a.P * DINTS + p * JF_MB_FIN_INTS,
                       threadIdx.x - 32);
     JF_VSTAMP(p, 6);
-    // ---- loop API: the last prompt to get here publishes the next forward's summary to the host ---------------------
-    if (mail) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this prompt's descriptor / mailbox stores are performed
-        int old = 0;
-        if (threadIdx.x == 0) old = __hip_atomic_fetch_add(lp->sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        old = __builtin_amdgcn_readfirstlane(old);
-        if (old == a.P - 1) {
-            if (threadIdx.x == 0) __hip_atomic_store(lp->sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            auto ld = [](const int32_t *q) -> int { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-            mb_publish_body(SoloWaveLanes{}, a.P, a.desc, *lp, false, ld);
-        }
-    }
     JF_VSTAMP(p, 7);
 }
 
@@ -392,7 +370,8 @@ static int verify_stepper_cap(const void *kern, int variant, size_t shm) {
 static int verify_launch(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, const int32_t *out_index,
                          int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len, int32_t Tpad,
                          const int32_t *row_prompt, int32_t *arrive, jf_mb_desc *desc, const jf_mb_params *params,
-                         const jfmb::LoopDev *lp, void *stream, const char *who) {
+                         const jfmb::LoopDev *lp, void *stream, const char *who, int *fused_out = nullptr) {
+    if (fused_out) *fused_out = 0;
     if (P <= 0) return JF_OK;
     int rc = check_params(params, who);
     if (rc) return rc;
@@ -447,6 +426,7 @@ static int verify_launch(const void *logits, int dtype, int64_t R, int64_t V, in
     if (blocks > 0x7FFFFFFFll) return fail(JF_E_CAPACITY, "%s: grid too large", who);
     const dim3 grid((unsigned)blocks), block(AM_TPB);
     kern<<<grid, block, shm, s>>>(a);
+    if (fused_out) *fused_out = 1;
     return check_launch("mb_verify_kernel");
 }
 
@@ -501,7 +481,7 @@ static int check_loop(const jf_mb_loop *lp, const char *who) {
     if (!lp) return fail(JF_E_INVALID, "%s: null loop", who);
     if (lp->P <= 0) return fail(JF_E_INVALID, "%s: P=%d", who, lp->P);
     if (!lp->states || !lp->packed || !lp->arrive || !lp->desc || !lp->input_ids || !lp->positions || !lp->row_prompt || !lp->row_len ||
-        !lp->row_cand || !lp->row_kv_len || !lp->mailbox || !lp->sync)
+        !lp->row_cand || !lp->row_kv_len || !lp->mailbox)
         return fail(JF_E_INVALID, "%s: null pointer in jf_mb_loop", who);
     if (lp->t_cap <= 0 || lp->rows_cap <= 0) return fail(JF_E_INVALID, "%s: forward buffers have no capacity", who);
     if (lp->drv && (!lp->draws || lp->draw_len <= 0 || lp->drv_ints <= JF_DRV_HDR_INTS))
@@ -509,10 +489,12 @@ static int check_loop(const jf_mb_loop *lp, const char *who) {
     return JF_OK;
 }
 
-static int loop_pack(const jf_mb_loop *lp, hipStream_t s) {
+// publish: 1 = the launch in front mailed the per-prompt tables itself (fused verify), 2 = this launch copies them
+static int loop_pack(const jf_mb_loop *lp, const jfmb::LoopDev &d, int publish, hipStream_t s) {
     const jfmb::PackOut o{lp->input_ids, lp->positions, lp->row_prompt, lp->row_len, lp->valid_index, lp->row_cand, lp->row_kv_len};
     mb_pack_kernel<<<lp->P, 64, 0, s>>>(lp->states, lp->state_ints, lp->desc, 0, lp->t_align < 1 ? 1 : lp->t_align, lp->t_cap,
-                                        lp->pad_fill, lp->order ? 1 : 0, lp->cand_rows, o, lp->valid_align < 1 ? 1 : lp->valid_align);
+                                        lp->pad_fill, lp->order ? 1 : 0, lp->cand_rows, o, lp->valid_align < 1 ? 1 : lp->valid_align,
+                                        d, publish);
     return check_launch("mb_pack_kernel");
 }
 
@@ -525,10 +507,10 @@ extern "C" int jf_mb_loop_begin(const jf_mb_loop *loop, int32_t seq, const jf_mb
     if (!input_ids || !kv_len) return fail(JF_E_INVALID, "jf_mb_loop_begin: null pointer");
     if (loop->state_ints < jf_mb_state_ints(params)) return fail(JF_E_INVALID, "jf_mb_loop_begin: state block too small");
     mb_begin_kernel<<<loop->P, 64, 0, (hipStream_t)stream>>>(loop->states, loop->state_ints, *params, input_ids, kv_len, loop->desc,
-                                                             jfmb::make_loop_dev(loop, seq, params));
+                                                             loop->kv_len);
     rc = check_launch("mb_begin_kernel");
     if (rc) return rc;
-    return loop_pack(loop, (hipStream_t)stream);
+    return loop_pack(loop, jfmb::make_loop_dev(loop, seq, params), 2, (hipStream_t)stream);
 }
 
 extern "C" int jf_mb_loop_iterate(const jf_mb_loop *loop, int32_t seq, const void *logits, int dtype, int64_t R, int64_t V,
@@ -540,14 +522,17 @@ extern "C" int jf_mb_loop_iterate(const jf_mb_loop *loop, int32_t seq, const voi
         return fail(JF_E_INVALID, "jf_mb_loop_iterate: forward of %d x %d positions exceeds the buffers", Rtot, Tpad);
     if (compacted && !loop->valid_index) return fail(JF_E_INVALID, "jf_mb_loop_iterate: compacted logits without a position list");
     const jfmb::LoopDev d = jfmb::make_loop_dev(loop, seq, params);
+    int fused = 0;
     rc = verify_launch(logits, dtype, R, V, row_stride, compacted ? loop->valid_index : nullptr, loop->states, loop->state_ints,
                        loop->P, loop->packed, (int64_t)Rtot * Tpad, Tpad, loop->row_prompt, loop->arrive, loop->desc, params, &d,
-                       stream, "jf_mb_loop_iterate");
+                       stream, "jf_mb_loop_iterate", &fused);
     if (rc || !queue_pack) return rc;
-    return loop_pack(loop, (hipStream_t)stream);
+    return loop_pack(loop, d, fused ? 1 : 2, (hipStream_t)stream);     // the fused launch's steppers mailed their own descriptors
 }
 
-extern "C" int jf_mb_loop_pack(const jf_mb_loop *loop, void *stream) {
-    const int rc = check_loop(loop, "jf_mb_loop_pack");
-    return rc ? rc : loop_pack(loop, (hipStream_t)stream);
+extern "C" int jf_mb_loop_pack(const jf_mb_loop *loop, int32_t seq, const jf_mb_params *params, void *stream) {
+    int rc = check_loop(loop, "jf_mb_loop_pack");
+    if (rc) return rc;
+    rc = check_params(params, "jf_mb_loop_pack");
+    return rc ? rc : loop_pack(loop, jfmb::make_loop_dev(loop, seq, params), 2, (hipStream_t)stream);
 }

@@ -360,7 +360,6 @@ class MultiblockLoop:
         rows = b.P * b.max_rows
         self.row_cand = torch.full((rows,), -1, dtype=torch.int32, device=dev)
         self.row_kv = torch.zeros((rows,), dtype=torch.int32, device=dev)
-        self.sync = torch.zeros((4,), dtype=torch.int32, device=dev)
         self.kv_len = kv_len
         self.drv, self.draws = drv, draws
         self.n_ints = N.mailbox_ints(b.P)
@@ -379,7 +378,7 @@ class MultiblockLoop:
             valid_index=b.valid_index_buf.data_ptr() if compact else None,
             rows_cap=rows, t_cap=self.t_cap, t_align=int(t_align), valid_align=int(valid_align), cand_rows=int(max(cand_rows, 1)),
             rsv0=0, pad_fill=int(fill), kv_len=None if kv_len is None else kv_len.data_ptr(), mailbox=ptr.value,
-            sync=self.sync.data_ptr(), drv=None if drv is None else drv.data_ptr(),
+            drv=None if drv is None else drv.data_ptr(),
             drv_ints=0 if drv is None else int(drv.shape[1]), draws=None if draws is None else draws.data_ptr(),
             draw_len=0 if draws is None else int(draws.shape[1]), max_seq_len=int(max_seq_len))
         self.last: Optional[LoopSummary] = None
@@ -427,7 +426,7 @@ class MultiblockLoop:
                                            C.byref(b.c_params), 0 if hook else 1, _stream(b.device)), "jf_mb_loop_iterate")
         if hook:
             hook[1](b, flat)
-            N.check(N.lib().jf_mb_loop_pack(self.c_loop, _stream(b.device)), "jf_mb_loop_pack")
+            N.check(N.lib().jf_mb_loop_pack(self.c_loop, self.seq, C.byref(b.c_params), _stream(b.device)), "jf_mb_loop_pack")
         if LOOP_HOOKS and "pack_end" in LOOP_HOOKS:
             LOOP_HOOKS["pack_end"](b)
 
@@ -447,7 +446,7 @@ class MultiblockLoop:
         if h[N.MB_ERROR]:
             self.snapshot(s)
             p = h[N.MB_ERROR] - 1
-            b.arrive.zero_(); b.packed.zero_(); self.sync.zero_()      # a failed launch may have left counts / keys behind
+            b.arrive.zero_(); b.packed.zero_()      # a failed launch may have left counts / keys behind
             f = N.DESC_FIELDS.index
             N.raise_state_error(int(s.d[p, f("error")]), f"multiblock prompt {p} (state-machine line {int(s.d[p, f('rsv0')])})",
                                 aux=int(s.d[p, f("rsv1")]))

@@ -64,7 +64,7 @@ class HostSimLib:
             "hs_sb_step": (C.c_int, [vp, C.c_int, vp, i32, i32, i32, vp, i32, vp]),
             "hs_mb_loop_begin": (C.c_int, [C.POINTER(N.MbLoop), i32, P, vp, vp]),
             "hs_mb_loop_step": (C.c_int, [C.POINTER(N.MbLoop), i32, P, i32, i32, C.c_int]),
-            "hs_mb_loop_pack": (C.c_int, [C.POINTER(N.MbLoop)]),
+            "hs_mb_loop_pack": (C.c_int, [C.POINTER(N.MbLoop), i32, P]),
         }
         self._host_blocks = {}
         for k, (r, a) in sig.items():
@@ -135,8 +135,8 @@ class HostSimLib:
     def jf_mb_loop_begin(self, loop, seq, params, input_ids, kv_len, stream):
         return self.hs.hs_mb_loop_begin(loop, seq, params, input_ids, kv_len)
 
-    def jf_mb_loop_pack(self, loop, stream):
-        return self.hs.hs_mb_loop_pack(loop)
+    def jf_mb_loop_pack(self, loop, seq, params, stream):
+        return self.hs.hs_mb_loop_pack(loop, seq, params)
 
     def jf_mb_loop_iterate(self, loop, seq, logits, dtype, R, V, stride, compacted, Rtot, Tpad, params, queue_pack, stream):
         if compacted:

@@ -40,37 +40,35 @@ int hs_mb_pack(int32_t *states, int64_t state_ints, int P, int32_t Tpad, int64_t
     const jfmb::PackOut o{input_ids, positions, row_prompt, row_len, valid_index, nullptr, nullptr};
     for (int p = 0; p < P; ++p)
         jfmb::mb_pack_body(HostLanes{}, p, P, states, state_ints, nullptr, Tpad, 1, Tpad, pad_fill, 0, 1, o,
-                           valid_align < 1 ? 1 : valid_align);
+                           valid_align < 1 ? 1 : valid_align, jfmb::LoopDev{}, 0);
     return 0;
 }
 
 // ---- the loop API (jf_mb_loop_*): same bodies, prompts one after the other, the "last to finish" is the last of the loop
-static void hs_loop_pack(const jf_mb_loop *lp) {
+static void hs_loop_pack(const jf_mb_loop *lp, const jfmb::LoopDev &d) {
     const jfmb::PackOut o{lp->input_ids, lp->positions, lp->row_prompt, lp->row_len, lp->valid_index, lp->row_cand, lp->row_kv_len};
     for (int p = 0; p < lp->P; ++p)
         jfmb::mb_pack_body(HostLanes{}, p, lp->P, lp->states, lp->state_ints, lp->desc, 0, lp->t_align < 1 ? 1 : lp->t_align, lp->t_cap,
-                           lp->pad_fill, lp->order ? 1 : 0, lp->cand_rows, o, lp->valid_align < 1 ? 1 : lp->valid_align);
+                           lp->pad_fill, lp->order ? 1 : 0, lp->cand_rows, o, lp->valid_align < 1 ? 1 : lp->valid_align, d, 2);
 }
 int hs_mb_loop_begin(const jf_mb_loop *lp, int32_t seq, const jf_mb_params *params, const int64_t *input_ids, const int32_t *kv_len) {
     const jfmb::LoopDev d = jfmb::make_loop_dev(lp, seq, params);
     for (int p = 0; p < lp->P; ++p)
         jfmb::mb_begin_body(HostLanes{}, p, lp->states, lp->state_ints, *params, input_ids, kv_len, lp->desc, d.kv_len);
-    jfmb::mb_publish_body(HostLanes{}, lp->P, lp->desc, d);
-    hs_loop_pack(lp);
+    hs_loop_pack(lp, d);
     return 0;
 }
 // the step half of jf_mb_loop_iterate (the caller has filled packed[] with the argmax stand-in)
-int hs_mb_loop_pack(const jf_mb_loop *lp) { hs_loop_pack(lp); return 0; }
+int hs_mb_loop_pack(const jf_mb_loop *lp, int32_t seq, const jf_mb_params *params) { hs_loop_pack(lp, jfmb::make_loop_dev(lp, seq, params)); return 0; }
 int hs_mb_loop_step(const jf_mb_loop *lp, int32_t seq, const jf_mb_params *params, int32_t Rtot, int32_t Tpad, int queue_pack) {
     const jfmb::LoopDev d = jfmb::make_loop_dev(lp, seq, params);
     for (int p = 0; p < lp->P; ++p)
-        jfmb::mb_step_body(HostLanes{}, p, lp->states, lp->state_ints, lp->packed, (int64_t)Rtot * Tpad, lp->desc, &d, g_fast != 0);
-    jfmb::mb_publish_body(HostLanes{}, lp->P, lp->desc, d);
-    if (queue_pack) hs_loop_pack(lp);
+        jfmb::mb_step_body(HostLanes{}, p, lp->states, lp->state_ints, lp->packed, (int64_t)Rtot * Tpad, lp->desc, d, true, g_fast != 0);
+    if (queue_pack) hs_loop_pack(lp, d);
     return 0;
 }
 int hs_mb_step(int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len, jf_mb_desc *desc) {
-    for (int p = 0; p < P; ++p) jfmb::mb_step_body(HostLanes{}, p, states, state_ints, packed, packed_len, desc, nullptr, g_fast != 0);
+    for (int p = 0; p < P; ++p) jfmb::mb_step_body(HostLanes{}, p, states, state_ints, packed, packed_len, desc, jfmb::LoopDev{}, false, g_fast != 0);
     return 0;
 }
 int hs_mb_read_ret(const int32_t *states, int64_t state_ints, int P, int64_t *ret, int32_t ret_cap) {

@@ -1,6 +1,7 @@
 """Kernel-level parity through the C ABI: argmax (a2), accepted-prefix scan (a3), engine step (a15),
 KV append/commit (a9/a10/a18) vs the CPU oracle and the golden vectors.  GPU tests are marked."""
 import ctypes
+import os
 import re
 import subprocess
 from pathlib import Path
@@ -612,3 +613,28 @@ def test_argmax_is_invariant_under_the_launch_shape_knobs(env):
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300,
                        cwd=str(ROOT))
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+def test_convergence_launch_keeps_its_register_budget():
+    """The fused convergence launch shares one kernel between the streaming argmax items and the per-prompt steppers: the
+    steppers' code must not cost the items their occupancy (round 3 met both ways this breaks silently: a stepper that is no
+    longer inlined — 248 VGPRs + scratch, 2 waves per SIMD, the stream 35 % slower — and a kernel-argument struct kept in
+    scratch because its address was selected against null).  Cross-compiles jf_multiblock.hip with the resource remarks."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    csrc = ROOT / "jacobiforcing_amd" / "csrc"
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", f"-I{ROOT / 'include'}", f"-I{csrc}",
+                          str(csrc / "jf_multiblock.hip"), "-Rpass-analysis=kernel-resource-usage", "-o", os.devnull],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    blocks = re.split(r"remark: Function Name: ", out.stderr)[1:]
+    seen = 0
+    for b in blocks:
+        name = b.split()[0]
+        if "mb_verify_kernel" not in name:
+            continue
+        vgprs = int(re.search(r"VGPRs: (\d+)", b).group(1))
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        assert vgprs <= 96 and scratch == 0, (name, vgprs, scratch)
+        seen += 1
+    assert seen == 8

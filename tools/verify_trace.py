@@ -25,20 +25,31 @@ from jacobiforcing_amd import _native as N, ops  # noqa: E402
 V = 152064
 
 
-def run(P, iters, fused, trace_lib=None):
+def run(P, iters, fused, trace_lib=None, loop=False):
     prm = ops.MultiblockParams(n=32, K=2, r=0.85, n_gram_pool_size=4, eos_token_id=None, pad_token_id=151643)
     batch = ops.MultiblockBatch(P, prm, "cuda")
     batch.fused = fused
     g = torch.Generator(device="cuda").manual_seed(7)
     ids = torch.randint(0, 151000, (P, 32), generator=g, device="cuda")
-    d = batch.begin(ids, torch.full((P,), 200, dtype=torch.int32))
+    lp = None
+    if loop:                                                      # the loop API: kv_len on the device, mailbox, pack queued behind
+        kvl = torch.zeros(P, dtype=torch.int32, device="cuda")
+        lp = ops.MultiblockLoop(batch, kv_len=kvl, t_cap=128, t_align=8, valid_align=8 * P, compact=True, cand_rows=3, order=1,
+                                max_seq_len=1 << 20)
+        sm = lp.begin(ids, torch.full((P,), 200, dtype=torch.int32))
+    else:
+        d = batch.begin(ids, torch.full((P,), 200, dtype=torch.int32))
     times, rows_l = [], []
     stamps = None
     mstamps = None
     for it in range(iters):
-        pk = batch.pack(d, t_align=8, compact=True, valid_align=8 * P)
-        if pk is None:
-            break
+        if loop:
+            if sm.Rtot == 0:
+                break
+        else:
+            pk = batch.pack(d, t_align=8, compact=True, valid_align=8 * P)
+            if pk is None:
+                break
         nv = batch.valid_index.numel()
         logits = torch.randn(nv, V, generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
         _ = torch.zeros(64 << 20, device="cuda").sum()          # push the fresh logits out of the caches a little
@@ -47,7 +58,12 @@ def run(P, iters, fused, trace_lib=None):
             trace_lib.jf_exp_reset_vtrace()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ops.VERIFY_HOOK = (lambda *_: a.record(), lambda *_: b.record())
-        d = batch.verify(logits, compacted=True)
+        if loop:
+            lp.iterate(logits)
+            sm = lp.wait()
+            d = sm.d
+        else:
+            d = batch.verify(logits, compacted=True)
         ops.VERIFY_HOOK = None
         torch.cuda.synchronize()
         times.append(a.elapsed_time(b) * 1e3)
@@ -72,20 +88,23 @@ def run(P, iters, fused, trace_lib=None):
         done = batch.desc_field(d, "done")
         if done.any():                                            # restart finished calls (rolling, like the decoder)
             kv = np.where(done == 1, batch.desc_field(d, "kv_len"), N.JF_MB_KEEP).astype(np.int32)
-            d = batch.begin(ids, torch.from_numpy(kv))
+            if loop:
+                sm = lp.begin(ids, torch.from_numpy(kv))
+            else:
+                d = batch.begin(ids, torch.from_numpy(kv))
     t = np.array(times[2:])
     r = np.array(rows_l[2:])
     mb = r.mean() * V * 2 / 1e6
-    print(f"P={P:3d} {'fused  ' if fused else 'unfused'} rows/launch {r.mean():7.1f} ({mb:6.1f} MB)  {t.mean():6.1f} us (min {t.min():6.1f})  "
+    print(f"P={P:3d} {'loop   ' if loop else 'fused  ' if fused else 'unfused'} rows/launch {r.mean():7.1f} ({mb:6.1f} MB)  {t.mean():6.1f} us (min {t.min():6.1f})  "
           f"{mb / t.mean() * 1e3 / 1e3:6.2f} TB/s = {mb / t.mean() / 8:5.3f} of 8 TB/s", flush=True)
     if stamps is not None:
         t0 = int(stamps[0])
         rel = lambda x: (int(x) - t0) / 100.0                     # 100 MHz ticks -> us
         print(f"      items: first start 0.0 us, last end {rel(stamps[1]):.1f} us")
         for p in list(range(min(P, 3))) + ([P - 1] if P > 3 else []):
-            s = stamps[2 + 8 * p: 2 + 8 * p + 7]
+            s = stamps[2 + 8 * p: 2 + 8 * p + 8]
             print(f"      stepper {p:3d}: start {rel(s[0]):6.1f}  image {rel(s[1]):6.1f}  arrived {rel(s[2]):6.1f}  gathered {rel(s[3]):6.1f}  "
-                  f"stepped {rel(s[4]):6.1f}  written {rel(s[5]):6.1f}  end {rel(s[6]):6.1f}")
+                  f"stepped {rel(s[4]):6.1f}  written(w1-3) {rel(s[5]):6.1f}  desc-out {rel(s[6]):6.1f}  end {rel(s[7]):6.1f}")
         if mstamps is not None:                                     # state machine phases of the last stepper (last visit of each stamp)
             names = {1: "scalars", 2: "accept-scan", 3: "commit", 4: "re-draft", 5: "pool-push", 6: "candidates", 7: "spans-done",
                      8: "spawn/promote", 9: "early-stop", 10: "build_out", 11: "scalars-stored"}
@@ -93,7 +112,7 @@ def run(P, iters, fused, trace_lib=None):
             row = [(rel(mstamps[q, k]), names[k]) for k in names if mstamps[q, k] >= stamps[2 + 8 * q + 3]]
             row.sort()
             print("      machine of stepper %d: " % q + "  ".join(f"{nm} {t:.2f}" for t, nm in row))
-        ends = np.array([rel(stamps[2 + 8 * p + 6]) for p in range(P)])
+        ends = np.array([max(rel(stamps[2 + 8 * p + 7]), rel(stamps[2 + 8 * p + 5])) for p in range(P)])
         arr = np.array([rel(stamps[2 + 8 * p + 2]) for p in range(P)])
         print(f"      all steppers: arrived {arr.min():.1f}..{arr.max():.1f} us, end {ends.min():.1f}..{ends.max():.1f} us")
 
@@ -114,6 +133,7 @@ def main():
     for P in a.prompts:
         run(P, a.iters, False)
         run(P, a.iters, True, trace_lib)
+        run(P, a.iters, True, trace_lib, loop=True)
 
 
 if __name__ == "__main__":
