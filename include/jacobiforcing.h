@@ -265,7 +265,9 @@ JF_API int jf_mb_loop_begin(const jf_mb_loop *loop, int32_t seq, const jf_mb_par
  * then the pack step of the next forward.  jf_kv_commit (when candidate rows ran) may follow on the same stream. */
 JF_API int jf_mb_loop_iterate(const jf_mb_loop *loop, int32_t seq, const void *logits, int dtype, int64_t R, int64_t V,
                        int64_t row_stride, int compacted, int32_t Rtot, int32_t Tpad, const jf_mb_params *params,
-                       int queue_pack, void *stream);
+                       int queue_pack, void *ev_begin, void *ev_end, void *stream);
+/* ev_begin / ev_end (nullable hipEvent_t): recorded on `stream` immediately before and after the convergence launch — a
+ * caller's timing of that launch alone without splitting the call (the pack launch still follows at once). */
 /* The pack step alone (queue_pack = 0 above: a caller that brackets the convergence launch with its own events); it is the
  * launch that stamps the mailbox with `seq`. */
 JF_API int jf_mb_loop_pack(const jf_mb_loop *loop, int32_t seq, const jf_mb_params *params, void *stream);

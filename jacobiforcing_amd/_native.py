@@ -118,7 +118,7 @@ _SIGNATURES = {
     "jf_mailbox_wait": (C.c_int, [_vp, _i32, _i64, _vp]),
     "jf_mb_loop_begin": (C.c_int, [C.POINTER(MbLoop), _i32, C.POINTER(MbParams), _vp, _vp, _vp]),
     "jf_mb_loop_iterate": (C.c_int, [C.POINTER(MbLoop), _i32, _vp, C.c_int, _i64, _i64, _i64, C.c_int, _i32, _i32,
-                                     C.POINTER(MbParams), C.c_int, _vp]),
+                                     C.POINTER(MbParams), C.c_int, _vp, _vp, _vp]),
     "jf_mb_loop_pack": (C.c_int, [C.POINTER(MbLoop), _i32, C.POINTER(MbParams), _vp]),
     "jf_kv_append": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i32, _vp]),
     "jf_rope_kv_append": (C.c_int, [_vp, C.c_int, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,

@@ -67,14 +67,19 @@ struct DevLanes {
         const unsigned long long m = __ballot(pred);
         return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
     }
-    // every lane's earlier stores become visible to the HOST, then one word is released (mailbox hand-off; the word may
-    // live in mapped pinned host memory).  The lanes are ONE wavefront: its stores are issued in program order, the
-    // system-scope release fence drains them, no barrier is involved.
-    // System-scope release in front of the sequence word.  Measured free (profiles/verify_release_ab_r03.txt: 73.0 vs 74.4 us
-    // per launch without it) — unlike a release on the per-item arrival counts, it runs once per launch.
+    // Mailbox hand-off: every lane's earlier stores, then one word the host polls.  The mailbox is coherent (uncached)
+    // host memory — its stores go straight to the fabric — so draining this wavefront's memory counter orders them in
+    // front of the sequence word.  A system-scope RELEASE fence instead also writes back the L2 (the state blocks the
+    // convergence launch has just stored, the forward inputs being packed): +7 us on the pack launch and on the host's
+    // wake-up (profiles/verify_release_ab_r03.txt); -DJF_EXP_PUBLISH_FENCE builds that variant.
     __device__ __forceinline__ void publish(int32_t *word, int32_t v) const {
+#ifdef JF_EXP_PUBLISH_FENCE
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         if (lane() == 0) __hip_atomic_store(word, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane() == 0) __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
     }
 };
 

@@ -134,12 +134,12 @@ __global__ __launch_bounds__(256) void rope_kv_append_vec_kernel(const T *__rest
     const int h = (int)(th % heads);
     const int64_t tok = th / heads;
     const T *src = qkv + (tok * heads + h) * D;
-    T a[EPV], b[EPV], oa[EPV], ob[EPV];
+    alignas(16) T a[EPV], b[EPV], oa[EPV], ob[EPV];
     *reinterpret_cast<uint4 *>(a) = *reinterpret_cast<const uint4 *>(src + i0);
     *reinterpret_cast<uint4 *>(b) = *reinterpret_cast<const uint4 *>(src + half + i0);
     if (h < nq + nkv) {                                       // rotate q and k heads, v passes through
         const int64_t pos = positions[tok];
-        float c[EPV], sn[EPV];
+        alignas(16) float c[EPV], sn[EPV];
 #pragma unroll
         for (int j = 0; j < EPV; j += 4) {
             *reinterpret_cast<float4 *>(c + j) = *reinterpret_cast<const float4 *>(cos_t + pos * half + i0 + j);
@@ -227,25 +227,40 @@ extern "C" int jf_rope_kv_append(const void *qkv, int dtype, int64_t N, int32_t 
     return check_launch("rope_kv_append_kernel");
 }
 
-// ---- SwiGLU gate: 8 bf16 (or 4 fp32) per lane per load on both halves -------------------------------------------
+// ---- SwiGLU gate: two 16-byte vectors of gate and of up per lane (four independent loads in flight), silu through the
+// hardware exp2 / rcp (x * rcp(1 + exp2(-x * log2 e)): ~6 VALU operations per element; the exact expf + IEEE division it
+// replaces cost ~35 and made the kernel VALU-bound at 2.6 TB/s, profiles/kernel_classes_r02.txt)
 template <typename T, int EPV>
 __global__ __launch_bounds__(256) void swiglu_kernel(const T *__restrict__ gu, int64_t M, int64_t I, T *__restrict__ out) {
+    constexpr int VPT = 2;                                     // vectors per thread, 256 * EPV elements apart
     const int64_t vec_per_row = I / EPV;
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= M * vec_per_row) return;
-    const int64_t m = gid / vec_per_row, v = gid - m * vec_per_row;
-    const T *g = gu + m * 2 * I + v * EPV;
+    const int64_t chunks_per_row = (vec_per_row + 256 * VPT - 1) / (256 * VPT);
+    const int64_t m = blockIdx.x / chunks_per_row;
+    const int64_t v0 = (blockIdx.x - m * chunks_per_row) * (256 * VPT) + threadIdx.x;
+    const T *g = gu + m * 2 * I;
     const T *u = g + I;
-    T *o = out + m * I + v * EPV;
-    T gv[EPV], uv[EPV], ov[EPV];
-    *reinterpret_cast<uint4 *>(gv) = *reinterpret_cast<const uint4 *>(g);
-    *reinterpret_cast<uint4 *>(uv) = *reinterpret_cast<const uint4 *>(u);
+    T *o = out + m * I;
+    alignas(16) T gv[VPT][EPV], uv[VPT][EPV], ov[EPV];
 #pragma unroll
-    for (int j = 0; j < EPV; ++j) {
-        const float x = ld_f(gv + j), y = ld_f(uv + j);
-        st_f(ov + j, (x / (1.f + expf(-x))) * y);
+    for (int k = 0; k < VPT; ++k) {
+        const int64_t v = v0 + k * 256;
+        if (v < vec_per_row) {
+            *reinterpret_cast<u32x4 *>(gv[k]) = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(g + v * EPV));
+            *reinterpret_cast<u32x4 *>(uv[k]) = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(u + v * EPV));
+        }
     }
-    *reinterpret_cast<uint4 *>(o) = *reinterpret_cast<const uint4 *>(ov);
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+        const int64_t v = v0 + k * 256;
+        if (v >= vec_per_row) continue;
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+            const float x = ld_f(gv[k] + j), y = ld_f(uv[k] + j);
+            const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
+            st_f(ov + j, x * sg * y);
+        }
+        *reinterpret_cast<uint4 *>(o + v * EPV) = *reinterpret_cast<const uint4 *>(ov);
+    }
 }
 
 extern "C" int jf_swiglu(const void *gu, int dtype, int64_t M, int64_t I, void *out, void *stream) {
@@ -254,8 +269,9 @@ extern "C" int jf_swiglu(const void *gu, int dtype, int64_t M, int64_t I, void *
     const int epv = dtype == JF_F32 ? 4 : 8;
     if ((dtype != JF_F32 && dtype != JF_BF16) || I % epv != 0 || ((uintptr_t)gu) % 16 || ((uintptr_t)out) % 16)
         return fail(JF_E_INVALID, "jf_swiglu: dtype/alignment (I must be a multiple of %d)", epv);
-    const int64_t total = M * (I / epv);
-    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    const int64_t chunks = ((I / epv) + 511) / 512;            // 256 threads x 2 vectors per workgroup, one row per workgroup
+    if (M * chunks > 0x7FFFFFFFll) return fail(JF_E_CAPACITY, "jf_swiglu: grid too large");
+    const dim3 grid((unsigned)(M * chunks)), block(256);
     if (dtype == JF_F32) swiglu_kernel<float, 4><<<grid, block, 0, (hipStream_t)stream>>>((const float *)gu, M, I, (float *)out);
     else swiglu_kernel<uint16_t, 8><<<grid, block, 0, (hipStream_t)stream>>>((const uint16_t *)gu, M, I, (uint16_t *)out);
     return check_launch("swiglu_kernel");

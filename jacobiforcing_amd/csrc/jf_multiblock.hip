@@ -515,7 +515,7 @@ extern "C" int jf_mb_loop_begin(const jf_mb_loop *loop, int32_t seq, const jf_mb
 
 extern "C" int jf_mb_loop_iterate(const jf_mb_loop *loop, int32_t seq, const void *logits, int dtype, int64_t R, int64_t V,
                                   int64_t row_stride, int compacted, int32_t Rtot, int32_t Tpad, const jf_mb_params *params,
-                                  int queue_pack, void *stream) {
+                                  int queue_pack, void *ev_begin, void *ev_end, void *stream) {
     int rc = check_loop(loop, "jf_mb_loop_iterate");
     if (rc) return rc;
     if (Rtot <= 0 || Rtot > loop->rows_cap || Tpad <= 0 || (int64_t)Rtot * Tpad > loop->packed_cap)
@@ -523,9 +523,11 @@ extern "C" int jf_mb_loop_iterate(const jf_mb_loop *loop, int32_t seq, const voi
     if (compacted && !loop->valid_index) return fail(JF_E_INVALID, "jf_mb_loop_iterate: compacted logits without a position list");
     const jfmb::LoopDev d = jfmb::make_loop_dev(loop, seq, params);
     int fused = 0;
+    if (ev_begin) (void)hipEventRecord((hipEvent_t)ev_begin, (hipStream_t)stream);
     rc = verify_launch(logits, dtype, R, V, row_stride, compacted ? loop->valid_index : nullptr, loop->states, loop->state_ints,
                        loop->P, loop->packed, (int64_t)Rtot * Tpad, Tpad, loop->row_prompt, loop->arrive, loop->desc, params, &d,
                        stream, "jf_mb_loop_iterate", &fused);
+    if (ev_end) (void)hipEventRecord((hipEvent_t)ev_end, (hipStream_t)stream);
     if (rc || !queue_pack) return rc;
     return loop_pack(loop, d, fused ? 1 : 2, (hipStream_t)stream);     // the fused launch's steppers mailed their own descriptors
 }

@@ -62,6 +62,10 @@ class ProfileTimer:
 
 
 class ModelRunner:
+    # bench.py: weights of the architecture `config` names that are already on the device (the engine sections of the bench
+    # line run on the same random-init model as the headline instead of drawing 15 GB again)
+    shared_weights: Optional[Qwen2Weights] = None
+
     def __init__(self, config: Config, rank: int = 0, event=None, device: Optional[str] = None):
         self.config = config
         self.rank, self.world_size = 0, 1
@@ -73,12 +77,19 @@ class ModelRunner:
         dtype = torch.bfloat16 if self.device.type == "cuda" else torch.float32
         if os.environ.get("JF_DTYPE"):
             dtype = getattr(torch, os.environ["JF_DTYPE"])
-        self.weights = Qwen2Weights(hf, self.device, dtype=dtype, seed=int(os.environ.get("JF_WEIGHT_SEED", "0")),
-                                    init_std=float(os.environ.get("JF_INIT_STD", "0.02")))
-        if list(Path(config.model_path).glob("*.safetensors")):
-            self.weights.load_safetensors(config.model_path, hf)
+        sw = ModelRunner.shared_weights
+        if sw is not None and sw.embed.device == self.device and tuple(sw.embed.shape) == (hf.vocab_size, hf.hidden_size) \
+                and len(sw.layers) == hf.num_hidden_layers:
+            self.weights = sw
+            dtype = sw.embed.dtype
         else:
-            print(f"[ModelRunner] no *.safetensors under {config.model_path}: using random-init weights", flush=True)
+            self.weights = Qwen2Weights(hf, self.device, dtype=dtype, seed=int(os.environ.get("JF_WEIGHT_SEED", "0")),
+                                        init_std=float(os.environ.get("JF_INIT_STD", "0.02")))
+            if list(Path(config.model_path).glob("*.safetensors")):
+                self.weights.load_safetensors(config.model_path, hf)
+            else:
+                import sys
+                print(f"[ModelRunner] no *.safetensors under {config.model_path}: using random-init weights", file=sys.stderr, flush=True)
         self.model = Qwen2Model(hf, self.weights)
         self.block_size = config.kvcache_block_size
         self.max_rows = int(min(config.max_num_seqs, int(os.environ.get("JF_MAX_ROWS", "64"))))

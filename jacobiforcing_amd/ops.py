@@ -19,6 +19,8 @@ from . import _native as N
 
 EVT_SPAWN, EVT_SWITCH, EVT_EARLY = 1, 2, 4
 VERIFY_HOOK = None      # bench.py: (before, after) callables around the verify launch (HIP events on the launch stream)
+VERIFY_EVENTS = None    # bench.py: callable -> (begin, end) torch.cuda.Event pair (already recorded once, so their handles exist)
+STAGE_HOOK = None       # bench.py: f(name, phase) with phase "begin"/"end" around jf_rs_probs / jf_rs_step / jf_argmax+jf_sb_step
 LOOP_HOOKS = None       # bench.py: {"pack_end": f(batch), "forward_begin": f(batch)} — events behind the queued pack launch and in
                         # front of the next forward's first kernel (GPU idle time between the loop body and the forward)
 
@@ -324,22 +326,17 @@ class DrawStreams:
         return DrawStreams._Rng(self, int(p))
 
 
-@dataclass
 class LoopSummary:
-    """What the device published about the NEXT forward (mailbox header) + the descriptor table of the launch."""
-    seq: int
-    Rtot: int
-    Rmain: int
-    Tpad: int
-    Tmax: int
-    Nvalid: int
-    Nvalid_pad: int
-    n_done: int
-    max_kv: int
-    accepted: int
-    n_call_end: int
-    d: np.ndarray                    # [P, DESC_INTS] descriptors
-    fin: Optional[np.ndarray]        # [P, MB_FIN_INTS] resident-driver records (None without a driver)
+    """What the device published about the NEXT forward (mailbox header) + the descriptor table of the launch
+    (``d`` [P, DESC_INTS], ``fin`` [P, MB_FIN_INTS] resident-driver records or None; both filled by ``snapshot``)."""
+    __slots__ = ("seq", "Rtot", "Rmain", "Tpad", "Tmax", "Nvalid", "Nvalid_pad", "n_done", "max_kv", "error", "accepted",
+                 "n_call_end", "d", "fin")
+
+    def __init__(self, h):
+        (self.seq, self.Rtot, self.Rmain, self.Tpad, self.Tmax, self.Nvalid, self.Nvalid_pad, self.n_done, self.max_kv,
+         self.error, self.accepted, self.n_call_end) = h
+        self.d = None
+        self.fin = None
 
 
 class MultiblockLoop:
@@ -367,6 +364,9 @@ class MultiblockLoop:
         N.check(lib.jf_host_alloc(self.n_ints * 4, C.byref(ptr)), "jf_host_alloc")
         self._mb_ptr = ptr
         self.mailbox = np.ctypeslib.as_array((C.c_int32 * self.n_ints).from_address(ptr.value))
+        self._hdr = self.mailbox[:N.MB_MAILBOX_HDR]
+        self._wait = lib.jf_mailbox_wait
+        self._views, self._vi = {}, {}
         self.seq = 0
         self.timeout_us = int(wait_timeout_s * 1e6)
         fill = b.params.pad_token_id if b.params.pad_token_id is not None else 0
@@ -419,14 +419,16 @@ class MultiblockLoop:
         if flat.shape[0] != want or flat.stride(1) != 1:
             raise ValueError(f"expected contiguous logits for {want} positions, got {tuple(logits.shape)}")
         self.seq += 1
-        hook = VERIFY_HOOK                      # bench.py: events around the convergence launch alone, the pack queued after
+        # bench.py: VERIFY_EVENTS() -> (begin, end) torch events recorded by the library around the convergence launch alone
+        # (the pack launch is queued in the same call either way); VERIFY_HOOK (before, after) callables are told about it
+        ev = VERIFY_EVENTS() if VERIFY_EVENTS else None
+        hook = VERIFY_HOOK
         hook and hook[0](b, flat)
         N.check(N.lib().jf_mb_loop_iterate(self.c_loop, self.seq, _ptr(flat), _dtype_code(flat), flat.shape[0], V,
                                            flat.stride(0) if flat.shape[0] > 1 else V, 1 if self.compact else 0, s.Rtot, s.Tpad,
-                                           C.byref(b.c_params), 0 if hook else 1, _stream(b.device)), "jf_mb_loop_iterate")
-        if hook:
-            hook[1](b, flat)
-            N.check(N.lib().jf_mb_loop_pack(self.c_loop, self.seq, C.byref(b.c_params), _stream(b.device)), "jf_mb_loop_pack")
+                                           C.byref(b.c_params), 1, C.c_void_p(ev[0].cuda_event) if ev else None,
+                                           C.c_void_p(ev[1].cuda_event) if ev else None, _stream(b.device)), "jf_mb_loop_iterate")
+        hook and hook[1](b, flat)
         if LOOP_HOOKS and "pack_end" in LOOP_HOOKS:
             LOOP_HOOKS["pack_end"](b)
 
@@ -435,17 +437,16 @@ class MultiblockLoop:
         next forward needs); call ``snapshot(s)`` for the descriptor table before the next ``iterate``/``begin`` — e.g. after
         the forward has been queued, so that the copy is off the critical path."""
         b = self.batch
-        N.check(N.lib().jf_mailbox_wait(self._mb_ptr, self.seq, self.timeout_us, _stream(b.device)), "jf_mailbox_wait")
-        h = self.mailbox[:N.MB_MAILBOX_HDR].tolist()
-        s = LoopSummary(seq=h[N.MB_SEQ], Rtot=h[N.MB_RTOT], Rmain=h[N.MB_RMAIN], Tpad=h[N.MB_TPAD], Tmax=h[N.MB_TMAX],
-                        Nvalid=h[N.MB_NVALID], Nvalid_pad=h[N.MB_NVALID_PAD], n_done=h[N.MB_NDONE], max_kv=h[N.MB_MAXKV],
-                        accepted=h[N.MB_ACCEPTED], n_call_end=h[N.MB_NCALL_END], d=None, fin=None)
+        rc = self._wait(self._mb_ptr, self.seq, self.timeout_us, _stream(b.device))
+        if rc:
+            N.check(rc, "jf_mailbox_wait")
+        s = LoopSummary(self._hdr[:12].tolist())
         self.last = s
         b.Rtot, b.Tpad, b.Nvalid = s.Rtot, s.Tpad, s.Nvalid
-        b.valid_index = b.valid_index_buf[:s.Nvalid_pad] if self.compact else None
-        if h[N.MB_ERROR]:
+        b.valid_index = None                   # valid_index() sets it for the forward that uses it
+        if s.error:
             self.snapshot(s)
-            p = h[N.MB_ERROR] - 1
+            p = s.error - 1
             b.arrive.zero_(); b.packed.zero_()      # a failed launch may have left counts / keys behind
             f = N.DESC_FIELDS.index
             N.raise_state_error(int(s.d[p, f("error")]), f"multiblock prompt {p} (state-machine line {int(s.d[p, f('rsv0')])})",
@@ -468,13 +469,29 @@ class MultiblockLoop:
 
     # -- views of the next forward's inputs (written by the pack launch that is already queued) ---------
     def inputs(self):
+        """(input_ids [R,Tpad], positions [R,Tpad], row_prompt, row_len, row_cand, row_kv [R]) of the next forward; the views
+        are kept per shape (making six tensor views costs the host ~10 us, on the critical path behind the mailbox)."""
         b, s = self.batch, self.last
-        R, Tp = s.Rtot, s.Tpad
-        return (b.input_ids[:R * Tp].view(R, Tp), b.positions[:R * Tp].view(R, Tp), b.row_prompt[:R], b.row_len[:R],
-                self.row_cand[:R], self.row_kv[:R])
+        key = (s.Rtot, s.Tpad)
+        v = self._views.get(key)
+        if v is None:
+            R, Tp = key
+            v = (b.input_ids[:R * Tp].view(R, Tp), b.positions[:R * Tp].view(R, Tp), b.row_prompt[:R], b.row_len[:R],
+                 self.row_cand[:R], self.row_kv[:R])
+            if len(self._views) > 4096:
+                self._views.clear()
+            self._views[key] = v
+        return v
 
     def valid_index(self) -> Optional[torch.Tensor]:
-        return self.batch.valid_index
+        if not self.compact:
+            return None
+        n = self.last.Nvalid_pad
+        v = self._vi.get(n)
+        if v is None:
+            v = self._vi[n] = self.batch.valid_index_buf[:n]
+        self.batch.valid_index = v
+        return v
 
 
 # --------------------------------------------------------------------------------------------
@@ -631,10 +648,13 @@ class SingleBlockStepper:
         flat = logits.reshape(-1, logits.shape[-1])
         if flat.shape[0] != L:
             raise ValueError(f"expected logits for {L} positions, got {tuple(logits.shape)}")
+        hk = STAGE_HOOK
+        hk and hk("sb_body", "begin", flat.shape[0] * flat.shape[1] * flat.element_size())
         argmax_partial(flat, self.packed)
         N.check(N.lib().jf_sb_step(_ptr(self.out), L, _ptr(self.packed), -1 if eos_id is None else int(eos_id), self.total,
                                    self.cap, _ptr(self.acc), int(kv_before), _ptr(self.desc_dev), _stream(self.device)),
                 "jf_sb_step")
+        hk and hk("sb_body", "end", 0)
         self.desc_host.copy_(self.desc_dev, non_blocking=True)
         if self.device.type == "cuda":
             torch.cuda.current_stream(self.device).synchronize()
@@ -762,15 +782,19 @@ class RsStepper:
         draft_next = draft[:, 1:].reshape(-1).contiguous()
         lib = N.lib()
         self.ws = _grown(self.ws, int(lib.jf_rs_workspace_bytes(R, V)))
+        hk = STAGE_HOOK
+        hk and hk("rs_probs", "begin", R * V * flat.element_size())
         N.check(lib.jf_rs_probs(_ptr(flat), _dtype_code(flat), R, V, flat.stride(0), _ptr(draft_next), float(temperature),
                                 _ptr(self.p_draft), _ptr(self.row_max), _ptr(self.row_sumexp), _ptr(self.packed),
                                 _ptr(self.ws), self.ws.numel() * 4, _stream(dev)), "jf_rs_probs")
+        hk and hk("rs_probs", "end", 0)
         self.remaining[:B].copy_(torch.tensor(list(remaining), dtype=torch.int32), non_blocking=True)
         self.cursors.copy_(torch.tensor(list(cursors), dtype=torch.int64), non_blocking=True)
         cm = self.committed.view(-1)[:B * L].view(B, L)
         nd = self.next_draft.view(-1)[:B * L].view(B, L)
         cur = self.cursors
         c_ptr = lambda i: C.c_void_p(cur.data_ptr() + 8 * i)
+        hk and hk("rs_step", "begin", B * V * flat.element_size())          # <= one rejected row per draft row
         N.check(lib.jf_rs_step(_ptr(flat), _dtype_code(flat), V, flat.stride(0), _ptr(draft), B, L, _ptr(self.p_draft),
                                _ptr(self.row_max), _ptr(self.row_sumexp), _ptr(self.packed), float(temperature),
                                -1 if eos_id is None else int(eos_id), _ptr(self.remaining),
@@ -779,6 +803,7 @@ class RsStepper:
                                _ptr(self.pad_stream), self.pad_stream.numel(), c_ptr(2),
                                _ptr(cm), _ptr(nd), _ptr(self.rows_dev), _ptr(self.step_ws), self.step_ws.numel() * 8,
                                _stream(dev)), "jf_rs_step")
+        hk and hk("rs_step", "end", 0)
         self.rows_host[:B].copy_(self.rows_dev[:B], non_blocking=True)
         th = self.tok_host.view(-1)[:B * L].view(B, L)
         th.copy_(cm, non_blocking=True)

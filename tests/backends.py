@@ -138,7 +138,7 @@ class HostSimLib:
     def jf_mb_loop_pack(self, loop, seq, params, stream):
         return self.hs.hs_mb_loop_pack(loop, seq, params)
 
-    def jf_mb_loop_iterate(self, loop, seq, logits, dtype, R, V, stride, compacted, Rtot, Tpad, params, queue_pack, stream):
+    def jf_mb_loop_iterate(self, loop, seq, logits, dtype, R, V, stride, compacted, Rtot, Tpad, params, queue_pack, ev_begin, ev_end, stream):
         if compacted:
             rc = self.jf_argmax_scatter(logits, dtype, R, V, stride, loop.valid_index, loop.packed, stream)
         else:

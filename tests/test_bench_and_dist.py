@@ -87,6 +87,34 @@ def test_full_vocabulary_batch_decodes_the_planted_sequence():
     assert tpf > 2.5 and max(rows) * V * 2 >= (140 << 20)            # at least one launch took the wavefront shape
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("resident", [True, False], ids=["resident", "hostdriven"])
+def test_bench_batch_decodes_the_planted_sequence(resident):
+    """The bench's own shape: 64 prompts side by side at BASELINE knobs, the full vocabulary in bf16, rolling restarts on the
+    device (resident) or on the host — every token returned is the planted target sequence, and both drivers return the
+    same tokens, calls and iteration counts."""
+    from jacobiforcing_amd.modeling.qwen2 import Qwen2Config, Qwen2Model, Qwen2Weights
+    dev = torch.device("cuda")
+    V = 152064
+    cfg = Qwen2Config.tiny(vocab_size=V, hidden_size=128, layers=2, heads=4, kv_heads=2, head_dim=32, inter=256)
+    model = Qwen2Model(cfg, Qwen2Weights(cfg, dev, dtype=torch.bfloat16, seed=1, init_std=0.05))
+    prm = ops.MultiblockParams(n=32, K=2, r=0.85, n_gram_pool_size=4, eos_token_id=None, pad_token_id=151643)
+    prompts = humaneval_shaped_prompts(64, seed=1234, vocab_hi=151643)
+    hook = ScriptedAcceptance(V, robust_pct=82, vocab_hi=151643)
+    dec = MultiblockJacobiDecoder(model, len(prompts), prm, max_seq_len=1024, logits_hook=hook, t_align=8, logit_align=512,
+                                  resident=resident)
+    stats, _, iters = dec.generate(prompts, max_new_tokens=80, max_calls=6, seed=1234)
+    for p, st in enumerate(stats):
+        pos = torch.arange(len(prompts[p]), len(prompts[p]) + len(st.token_ids))
+        assert st.token_ids == hook.target(pos, torch.full_like(pos, p)).tolist(), p
+        assert len(st.token_ids) >= 80 and st.stop_reason in ("max_new_tokens", "max_calls")
+    key = [(s.token_ids, s.calls, s.total_iterations, s.stop_reason) for s in stats]
+    other = getattr(test_bench_batch_decodes_the_planted_sequence, "_seen", None)
+    if other is not None:
+        assert key == other                                   # resident == host-driven
+    test_bench_batch_decodes_the_planted_sequence._seen = key
+
+
 _WORKER = textwrap.dedent("""
     import os, sys, json
     sys.path.insert(0, {root!r})

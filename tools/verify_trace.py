@@ -50,7 +50,7 @@ def run(P, iters, fused, trace_lib=None, loop=False):
             pk = batch.pack(d, t_align=8, compact=True, valid_align=8 * P)
             if pk is None:
                 break
-        nv = batch.valid_index.numel()
+        nv = lp.valid_index().numel() if loop else batch.valid_index.numel()
         logits = torch.randn(nv, V, generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
         _ = torch.zeros(64 << 20, device="cuda").sum()          # push the fresh logits out of the caches a little
         torch.cuda.synchronize()
