@@ -409,6 +409,7 @@ __host__ __device__ inline int64_t rs_seg_elems(int64_t V, int epv) {
     return ((per + tile - 1) / tile) * tile;
 }
 
+constexpr int RS_FLAG_STRIDE = 16;                // 8-byte words between two rows' accept flags (one 128-byte line each)
 struct RsWs {                                     // carve-up of the step workspace for `rows` items
     double *segsum;                               // [rows, RS_SEG] float64 mass of each vocabulary segment
     double *lo_part;                              // [rows] mass in front of the avoided token inside its segment
@@ -416,10 +417,19 @@ struct RsWs {                                     // carve-up of the step worksp
     int32_t *sel_row;                             // [rows] logits row to sum for item i, -1 = none
     int32_t *avoid;                               // [rows] token a draw must not return (the rejected proposal), -1 = none
     float *pick_u;                                // [rows] the uniform of the draw that counts; < 0: masked argmax instead
+    // hand-off words of the one-launch step (rs_step_fused_kernel), all tagged with the call's generation number, so nothing
+    // has to be re-zeroed and a late poller can never see a recycled word
+    unsigned long long *flag;                     // [rows * RS_FLAG_STRIDE] (gen << 32) | (reject_pos + 2): the accept walk has decided the
+                                                  // row; one 128-byte line per row (its 17 pollers must not share lines with other rows)
+    unsigned long long *pick;                     // [rows] (gen << 32) | bits of the uniform that counts (chain workgroup -> bonus workgroup)
+    uint32_t *segdone;                            // [rows, RS_SEG] gen: this segment's sum is stored
+    uint32_t *bonusdone;                          // [rows] gen: the row's bonus token is stored
+    uint32_t *acceptdone;                         // [4]   gen: the accept workgroup has written every row record
 };
 static inline size_t rs_ws_bytes(int64_t rows) {
     const size_t r = (size_t)((rows + 3) / 4 * 4);
-    return r * RS_SEG * sizeof(double) + 2 * r * sizeof(double) + 3 * r * sizeof(int32_t);
+    return r * RS_SEG * sizeof(double) + 2 * r * sizeof(double) + 3 * r * sizeof(int32_t) +
+           r * (RS_FLAG_STRIDE + 1) * sizeof(unsigned long long) + r * RS_SEG * sizeof(uint32_t) + r * sizeof(uint32_t) + 4 * sizeof(uint32_t);
 }
 __host__ __device__ inline RsWs rs_ws(void *ws, int64_t rows) {
     const size_t r = (size_t)((rows + 3) / 4 * 4);
@@ -430,6 +440,11 @@ __host__ __device__ inline RsWs rs_ws(void *ws, int64_t rows) {
     w.sel_row = (int32_t *)(w.p_avoid + r);
     w.avoid = w.sel_row + r;
     w.pick_u = (float *)(w.avoid + r);
+    w.flag = (unsigned long long *)(w.pick_u + r);
+    w.pick = w.flag + r * RS_FLAG_STRIDE;
+    w.segdone = (uint32_t *)(w.pick + r);
+    w.bonusdone = w.segdone + r * RS_SEG;
+    w.acceptdone = w.bonusdone + r;
     return w;
 }
 extern "C" size_t jf_rs_step_workspace_bytes(int64_t rows) { return rows > 0 ? rs_ws_bytes(rows) : 0; }
@@ -459,19 +474,21 @@ __device__ __forceinline__ RsRow rs_make_row(const void *logits, int64_t r, int6
     return rr;
 }
 
-template <int DT>
-__global__ __launch_bounds__(256) void rs_rowsum_kernel(const void *logits, int64_t V, int64_t row_stride, const float *row_max,
-                                                         const float *row_sumexp, float t, RsWs w) {
+__device__ __forceinline__ void st_agent_f64(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent_f64(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// One vocabulary segment of one selected row (r = logits row, av = the token its draws must avoid).  SIG: results go out as
+// agent-scope atomic stores followed by the segment's generation word (the consumers are other workgroups of the SAME launch).
+template <int DT, bool SIG>
+__device__ __forceinline__ void rs_rowsum_body(const void *logits, int64_t V, int64_t row_stride, const float *row_max,
+                                               const float *row_sumexp, float t, const RsWs &w, int item, int seg, int r,
+                                               int64_t av, uint32_t gen) {
     constexpr int EPV = Elem<DT>::EPV;
-    const int item = blockIdx.x / RS_SEG, seg = blockIdx.x % RS_SEG;
-    const int r = w.sel_row[item];
-    if (r < 0) return;
     const RsRow row = rs_make_row<DT>(logits, r, V, row_stride, t, row_max[r], row_sumexp[r]);
     const int64_t segE = rs_seg_elems(V, EPV);
     const int64_t lo = (int64_t)seg * segE;
     int64_t hi = lo + segE;
     if (hi > V) hi = V;
-    const int64_t av = w.avoid[item];
     const bool mine = av >= lo && av < hi;                   // workgroup-uniform: this segment holds the avoided token
     double acc = 0.0, front = 0.0, pav = 0.0;
     for (int64_t b0 = lo + (int64_t)threadIdx.x * EPV; b0 < hi; b0 += (int64_t)RS_TILES * 256 * EPV) {
@@ -509,16 +526,39 @@ __global__ __launch_bounds__(256) void rs_rowsum_kernel(const void *logits, int6
     if ((threadIdx.x & 63) == 0) { sw[threadIdx.x >> 6] = acc; sf[threadIdx.x >> 6] = front; sp[threadIdx.x >> 6] = pav; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        w.segsum[(int64_t)item * RS_SEG + seg] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
-        if (mine) { w.lo_part[item] = (sf[0] + sf[1]) + (sf[2] + sf[3]); w.p_avoid[item] = (sp[0] + sp[1]) + (sp[2] + sp[3]); }
+        const double sum = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+        if constexpr (SIG) {
+            st_agent_f64(w.segsum + (int64_t)item * RS_SEG + seg, sum);
+            if (mine) { st_agent_f64(w.lo_part + item, (sf[0] + sf[1]) + (sf[2] + sf[3])); st_agent_f64(w.p_avoid + item, (sp[0] + sp[1]) + (sp[2] + sp[3])); }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the sums are performed before the word that announces them
+            __hip_atomic_store(w.segdone + (int64_t)item * RS_SEG + seg, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            w.segsum[(int64_t)item * RS_SEG + seg] = sum;
+            if (mine) { w.lo_part[item] = (sf[0] + sf[1]) + (sf[2] + sf[3]); w.p_avoid[item] = (sp[0] + sp[1]) + (sp[2] + sp[3]); }
+        }
     }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void rs_rowsum_kernel(const void *logits, int64_t V, int64_t row_stride, const float *row_max,
+                                                         const float *row_sumexp, float t, RsWs w) {
+    const int item = blockIdx.x / RS_SEG, seg = blockIdx.x % RS_SEG;
+    const int r = w.sel_row[item];
+    if (r < 0) return;
+    rs_rowsum_body<DT, false>(logits, V, row_stride, row_max, row_sumexp, t, w, item, seg, r, (int64_t)w.avoid[item], 0u);
 }
 
 // total mass of a row and the CDF interval [c_lo, c_hi) of its avoided token, from the segment sums.  `total` is formed
 // exactly as rs_pick forms it (segments in order), so both compare u * total with the same number.
-__device__ __forceinline__ void rs_interval(const RsWs &w, int item, int64_t V, int epv, double &total, double &c_lo, double &c_hi) {
-    const double *sg = w.segsum + (int64_t)item * RS_SEG;
-    const int64_t av = w.avoid[item];
+// AGENT: the sums were stored by other workgroups of the same launch (agent-scope atomics on both sides); av then comes from
+// the caller (the accept workgroup's w.avoid may not be visible yet)
+template <bool AGENT = false>
+__device__ __forceinline__ void rs_interval(const RsWs &w, int item, int64_t V, int epv, double &total, double &c_lo, double &c_hi,
+                                            int64_t av_in = -2) {
+    double sg[RS_SEG];
+#pragma unroll
+    for (int s = 0; s < RS_SEG; ++s) sg[s] = AGENT ? ld_agent_f64(w.segsum + (int64_t)item * RS_SEG + s) : w.segsum[(int64_t)item * RS_SEG + s];
+    const int64_t av = AGENT ? av_in : (int64_t)w.avoid[item];
     const int sstar = (av >= 0 && av < V) ? (int)(av / rs_seg_elems(V, epv)) : -1;   // an id outside the vocabulary is never drawn
     double run = 0.0, before = 0.0;
 #pragma unroll
@@ -527,8 +567,10 @@ __device__ __forceinline__ void rs_interval(const RsWs &w, int item, int64_t V, 
         run += sg[s];
     }
     total = run;
-    c_lo = sstar >= 0 ? before + w.lo_part[item] : 0.0;
-    c_hi = sstar >= 0 ? c_lo + w.p_avoid[item] : 0.0;
+    const double lo_p = sstar >= 0 ? (AGENT ? ld_agent_f64(w.lo_part + item) : w.lo_part[item]) : 0.0;
+    const double p_av = sstar >= 0 ? (AGENT ? ld_agent_f64(w.p_avoid + item) : w.p_avoid[item]) : 0.0;
+    c_lo = sstar >= 0 ? before + lo_p : 0.0;
+    c_hi = sstar >= 0 ? c_lo + p_av : 0.0;
 }
 
 // Up to RS_MAX_TRIES draws from stream[(pos + tr) % len] by lanes 0..15 of one wavefront: the first one that does not
@@ -560,7 +602,7 @@ __device__ int rs_pick(const RsRow &row, const double *segsum /* global, RS_SEG 
     constexpr int EPV = Elem<DT>::EPV;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __syncthreads();                                        // sh may still be read by a previous draw
-    if (tid < RS_SEG) sh.seg[tid] = segsum[tid];
+    if (tid < RS_SEG) sh.seg[tid] = ld_agent_f64(segsum + tid);   // may have been stored by another workgroup of this launch
     if (tid == 0) sh.pick = 0x7FFFFFFF;
     __syncthreads();
     double total = 0.0;
@@ -727,12 +769,14 @@ constexpr int RS_STAGE = 6144;      // floats of p_draft / uniforms staged in LD
 constexpr int RS_ROWS_LDS = 2048;   // rows whose scan results are kept in LDS (half of it in the chain kernel)
 
 // STAGED: the batch fits the LDS tables (B * (L-1) <= RS_STAGE, B <= RS_ROWS_LDS) — the serial part touches LDS only.
-template <bool STAGED>
-__global__ __launch_bounds__(256) void rs_accept_kernel(const int64_t *draft, int B, int L, const float *p_draft, int eos_id,
-                                                         const float *u_stream, int64_t u_len, const int64_t *u_cursor,
-                                                         int64_t *committed, jf_rs_row *rows, RsWs w) {
-    __shared__ float s_p[STAGED ? RS_STAGE : 1], s_u[STAGED ? RS_STAGE : 1];   // s_p carries "proposed == EOS" in its sign bit (p >= 0)
-    __shared__ int s_res[STAGED ? RS_ROWS_LDS : 1];                            // nacc | eos << 15 | (rej + 1) << 16 per row
+// SIG (one-launch step): the walker announces every row the moment it is decided — flag[b] = (gen << 32) | (reject_pos + 2),
+// one self-contained 8-byte agent-scope store — and the workgroup ends with a release + the accept-done word.
+template <bool STAGED, bool SIG, int STAGE_N = RS_STAGE, int ROWS_N = RS_ROWS_LDS>
+__device__ __forceinline__ void rs_accept_body(const int64_t *draft, int B, int L, const float *p_draft, int eos_id,
+                                               const float *u_stream, int64_t u_len, const int64_t *u_cursor,
+                                               int64_t *committed, jf_rs_row *rows, const RsWs &w, uint32_t gen) {
+    __shared__ float s_p[STAGED ? STAGE_N : 1], s_u[STAGED ? STAGE_N : 1];     // s_p carries "proposed == EOS" in its sign bit (p >= 0)
+    __shared__ int s_res[STAGED ? ROWS_N : 1];                                 // nacc | eos << 15 | (rej + 1) << 16 per row
     const int tid = threadIdx.x;
     const int W = L - 1;
     const int n = B * W;
@@ -783,6 +827,9 @@ __global__ __launch_bounds__(256) void rs_accept_kernel(const int64_t *draft, in
             if (lane == 0) {
                 if constexpr (STAGED) s_res[b] = nacc | (eos << 15) | ((rej + 1) << 16);
                 else { rows[b].n_committed = nacc; rows[b].eos = eos; rows[b].reject_pos = rej; }
+                if constexpr (SIG)
+                    __hip_atomic_store(w.flag + (int64_t)b * RS_FLAG_STRIDE, ((unsigned long long)gen << 32) | (unsigned long long)(rej + 2), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
             }
             used_total += used;
         }
@@ -824,6 +871,18 @@ __global__ __launch_bounds__(256) void rs_accept_kernel(const int64_t *draft, in
                                 res_of(b, nacc, eos, rej);
                                 if (i < nacc) committed[(int64_t)b * L + i] = v;
                             });
+    if constexpr (SIG) {                                            // row records + accepted tokens, for the finishing workgroup
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(w.acceptdone, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <bool STAGED>
+__global__ __launch_bounds__(256) void rs_accept_kernel(const int64_t *draft, int B, int L, const float *p_draft, int eos_id,
+                                                         const float *u_stream, int64_t u_len, const int64_t *u_cursor,
+                                                         int64_t *committed, jf_rs_row *rows, RsWs w) {
+    rs_accept_body<STAGED, false>(draft, B, L, p_draft, eos_id, u_stream, u_len, u_cursor, committed, rows, w, 0u);
 }
 
 // bonus-stream bookkeeping in row order (one workgroup): intervals in parallel, then one wavefront walks the rejected rows
@@ -950,10 +1009,10 @@ __device__ __forceinline__ int wave_excl_scan_i32(int v, int lane, int *total) {
     return x - v;
 }
 
-__global__ __launch_bounds__(256) void rs_finish_kernel(int B, int L, unsigned long long *packed, int eos_id,
-                                                         const int32_t *remaining, int64_t *u_cursor, int64_t *b_cursor,
-                                                         const int64_t *pad_stream, int64_t pad_len, int64_t *pad_cursor,
-                                                         int64_t *committed, int64_t *next_draft, jf_rs_row *rows) {
+__device__ __forceinline__ void rs_finish_body(int B, int L, unsigned long long *packed, int eos_id,
+                                               const int32_t *remaining, int64_t *u_cursor, int64_t *b_cursor,
+                                               const int64_t *pad_stream, int64_t pad_len, int64_t *pad_cursor,
+                                               int64_t *committed, int64_t *next_draft, jf_rs_row *rows) {
     __shared__ int s_total_pads;
     const int tid = threadIdx.x, lane = tid & 63;
     // rows in parallel: bonus joins the committed tokens, EOS, next-draft shape (JDN:444-466 / 619-638)
@@ -1025,6 +1084,160 @@ __global__ __launch_bounds__(256) void rs_finish_kernel(int B, int L, unsigned l
     for (int64_t i = tid; i < (int64_t)B * (L - 1); i += 256) packed[i] = 0ull;
     for (int b = tid; b < B; b += 256) rows[b].rsv = 0;
     if (tid == 0) *pad_cursor = pc0 + s_total_pads;
+}
+
+__global__ __launch_bounds__(256) void rs_finish_kernel(int B, int L, unsigned long long *packed, int eos_id,
+                                                         const int32_t *remaining, int64_t *u_cursor, int64_t *b_cursor,
+                                                         const int64_t *pad_stream, int64_t pad_len, int64_t *pad_cursor,
+                                                         int64_t *committed, int64_t *next_draft, jf_rs_row *rows) {
+    rs_finish_body(B, L, packed, eos_id, remaining, u_cursor, b_cursor, pad_stream, pad_len, pad_cursor, committed, next_draft, rows);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The whole step as ONE launch (batches of at most RS_FUSED_ROWS rows whose accept tests fit RS_FUSED_STAGE):
+//   block 0                    the accept walk (rs_accept_body): announces every row the moment it is decided
+//   blocks 1 .. B*RS_SEG       the segment sums of row (blk-1)/RS_SEG: wait for that row's flag, sum if it was rejected
+//   block  B*RS_SEG + 1        the chain: waits for every flag and every rejected row's sums, turns them into CDF intervals in
+//                              parallel, counts the draws of all rows in stream order on LDS (one wavefront), hands every
+//                              rejected row the uniform that counts
+//   blocks .. + B              the bonus draw of row b: ONE inverse-CDF walk (or the masked argmax) for the uniform it was handed
+//   last block                 waits for the accept workgroup and every bonus word, then rs_finish_body
+// A workgroup only ever waits for workgroups with LOWER block ids (dispatched before it), so every wait ends whatever the
+// residency; all hand-off words carry the call's generation number (nothing to re-zero, no stale reads); payloads cross
+// workgroups as agent-scope atomics (a release fence per producer would write back an L2 full of freshly written logits —
+// profiles/verify_release_ab_r03.txt).  Replaces four dependent launches (accept 19 + rowsum 21 + bonus 34 + finish 14 us
+// at 64 rejected rows, profiles/rs_step_r03.txt).
+// ------------------------------------------------------------------------------------------------
+constexpr int RS_FUSED_ROWS = 128;      // rows of a one-launch step
+constexpr int RS_FUSED_STAGE = 4096;    // B * (L-1) accept tests staged in LDS by its accept workgroup
+struct RsFusedArgs {
+    const void *logits; int64_t V, row_stride; const int64_t *draft; int B, L;
+    const float *p_draft, *row_max, *row_sumexp; unsigned long long *packed; float t; int eos_id; const int32_t *remaining;
+    const float *u_stream; int64_t u_len; int64_t *u_cursor;
+    const float *b_stream; int64_t b_len; int64_t *b_cursor;
+    const int64_t *pad_stream; int64_t pad_len; int64_t *pad_cursor;
+    int64_t *committed, *next_draft; jf_rs_row *rows; RsWs w; uint32_t gen;
+};
+
+__device__ __forceinline__ unsigned long long rs_wait_flag(const unsigned long long *word, uint32_t gen) {
+    unsigned long long v;
+    while ((uint32_t)((v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != gen) __builtin_amdgcn_s_sleep(16);
+    return v;
+}
+__device__ __forceinline__ void rs_wait_word(const uint32_t *word, uint32_t gen) {
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen) __builtin_amdgcn_s_sleep(16);
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void rs_step_fused_kernel(RsFusedArgs a) {
+    const int blk = blockIdx.x, tid = threadIdx.x;
+    const int B = a.B, L = a.L, W = a.L - 1;
+    const RsWs &w = a.w;
+    if (blk == 0) {
+        rs_accept_body<true, true, RS_FUSED_STAGE, RS_FUSED_ROWS>(a.draft, B, L, a.p_draft, a.eos_id, a.u_stream, a.u_len, a.u_cursor,
+                                                                  a.committed, a.rows, w, a.gen);
+        return;
+    }
+    if (blk <= B * RS_SEG) {                                        // ---- segment sums
+        const int item = (blk - 1) / RS_SEG, seg = (blk - 1) % RS_SEG;
+        __shared__ int s_rej;
+        if (tid == 0) s_rej = (int)(uint32_t)rs_wait_flag(w.flag + (int64_t)item * RS_FLAG_STRIDE, a.gen) - 2;
+        __syncthreads();
+        const int rej = s_rej;
+        if (rej < 0) return;
+        rs_rowsum_body<DT, true>(a.logits, a.V, a.row_stride, a.row_max, a.row_sumexp, a.t, w, item, seg, item * W + rej,
+                                 a.draft[(int64_t)item * L + rej + 1], a.gen);
+        return;
+    }
+    if (blk == B * RS_SEG + 1) {                                    // ---- the chain: draws of all rows in stream order
+        __shared__ double s_tot[RS_FUSED_ROWS], s_lo[RS_FUSED_ROWS], s_hi[RS_FUSED_ROWS];   // s_tot < 0: not rejected
+        __shared__ int s_rejpos[RS_FUSED_ROWS], s_draws[RS_FUSED_ROWS];
+        __shared__ float s_u[RS_MAX_TRIES * RS_FUSED_ROWS], s_ufv[RS_FUSED_ROWS];
+        __shared__ int s_nrej;
+        if (tid == 0) s_nrej = 0;
+        __syncthreads();
+        int mine = 0;
+        for (int i = tid; i < B; i += 256) {
+            const int rp = (int)(uint32_t)rs_wait_flag(w.flag + (int64_t)i * RS_FLAG_STRIDE, a.gen) - 2;
+            s_rejpos[i] = rp; s_draws[i] = 0; s_ufv[i] = -1.f;
+            mine += rp >= 0 ? 1 : 0;
+        }
+        if (mine) atomicAdd(&s_nrej, mine);
+        __syncthreads();
+        const int nrej = s_nrej;
+        if (nrej > 0) {
+            for (int k = tid; k < B * RS_SEG; k += 256)
+                if (s_rejpos[k / RS_SEG] >= 0) rs_wait_word(w.segdone + k, a.gen);
+            __syncthreads();
+            for (int i = tid; i < B; i += 256) {
+                double t_ = -1.0, lo_ = 0.0, hi_ = 0.0;
+                if (s_rejpos[i] >= 0) rs_interval<true>(w, i, a.V, Elem<DT>::EPV, t_, lo_, hi_, a.draft[(int64_t)i * L + s_rejpos[i] + 1]);
+                s_tot[i] = t_; s_lo[i] = lo_; s_hi[i] = hi_;
+            }
+            const int64_t bc0 = *a.b_cursor;
+            const int win = RS_MAX_TRIES * nrej;                     // stream entries the walk can touch
+            const bool staged = a.b_len < 0x7FFFFFFFll;
+            if (staged) {
+                const int bl = (int)a.b_len, bb = (int)(bc0 % a.b_len);
+                batched_for<8, float>(win, tid, 256, [&](int64_t i) { return a.b_stream[(bb + (int)i) % bl]; }, [&](int64_t i, float v) { s_u[i] = v; });
+            }
+            __syncthreads();
+            if (tid < 64) {
+                int off = 0;
+                for (int i = 0; i < B; ++i) {
+                    const double t_ = s_tot[i];
+                    if (t_ < 0.0) continue;
+                    float uf;
+                    const int o = off;
+                    const int draws = rs_count_draws([&](int tr) { return staged ? s_u[o + tr] : a.b_stream[(bc0 + o + tr) % a.b_len]; }, t_, s_lo[i], s_hi[i], tid, &uf);
+                    if (tid == 0) { s_draws[i] = draws; s_ufv[i] = uf; }
+                    off += draws;
+                }
+            }
+        }
+        if (tid == 0) rs_wait_word(w.acceptdone, a.gen);             // the accept workgroup's row records are final: ours go on top
+        __syncthreads();
+        for (int i = tid; i < B; i += 256)
+            if (s_rejpos[i] >= 0) __hip_atomic_store(&a.rows[i].n_bonus_draws, s_draws[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the draw counts are performed before the words that release the rows
+        for (int i = tid; i < B; i += 256)
+            if (s_rejpos[i] >= 0)
+                __hip_atomic_store(w.pick + i, ((unsigned long long)a.gen << 32) | (unsigned long long)__float_as_uint(s_ufv[i]), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (blk <= B * RS_SEG + 1 + B) {                                // ---- bonus draw of row b
+        const int b = blk - 2 - B * RS_SEG;
+        __shared__ RsPickShared sh;
+        __shared__ int s_rej;
+        __shared__ float s_uf;
+        if (tid == 0) {
+            const int rp = (int)(uint32_t)rs_wait_flag(w.flag + (int64_t)b * RS_FLAG_STRIDE, a.gen) - 2;
+            s_rej = rp;
+            if (rp >= 0) s_uf = __uint_as_float((uint32_t)rs_wait_flag(w.pick + b, a.gen));
+        }
+        __syncthreads();
+        const int rej = s_rej;
+        if (rej >= 0) {
+            const int64_t r = (int64_t)b * W + rej;
+            const RsRow row = rs_make_row<DT>(a.logits, r, a.V, a.row_stride, a.t, a.row_max[r], a.row_sumexp[r]);
+            const int bonus = rs_final_pick<DT>(row, w.segsum + (int64_t)b * RS_SEG, a.draft[(int64_t)b * L + rej + 1], s_uf, sh);
+            // n_committed of a rejected row == reject_pos (rs_accept_body)
+            if (tid == 0) __hip_atomic_store((long long *)a.committed + (int64_t)b * L + rej, (long long)bonus, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(w.bonusdone + b, a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    // ---- last block: everything is in, finish (JDN:444-466 / 619-638)
+    if (tid == 0) rs_wait_word(w.acceptdone, a.gen);
+    for (int i = tid; i < B; i += 256) rs_wait_word(w.bonusdone + i, a.gen);
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    rs_finish_body(B, L, a.packed, a.eos_id, a.remaining, a.u_cursor, a.b_cursor, a.pad_stream, a.pad_len, a.pad_cursor, a.committed,
+                   a.next_draft, a.rows);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1146,7 +1359,7 @@ extern "C" int jf_rs_onpolicy_step(const void *logits, int dtype, int64_t V, int
         !m_cursor || !committed || !redraft || !row || !workspace || (n_stop > 0 && !stop_ids))
         return fail(JF_E_INVALID, "jf_rs_onpolicy_step: null pointer");
     if (u_len <= 0 || m_len <= 0 || n_stop < 0) return fail(JF_E_INVALID, "jf_rs_onpolicy_step: empty random stream");
-    if (workspace_bytes < rs_ws_bytes(R) || ((uintptr_t)workspace % 8) != 0) return fail(JF_E_INVALID, "jf_rs_onpolicy_step: workspace too small or misaligned");
+    if (workspace_bytes < rs_ws_bytes(R) || ((uintptr_t)workspace % 16) != 0) return fail(JF_E_INVALID, "jf_rs_onpolicy_step: workspace too small or not 16-byte aligned");
     if (dtype != JF_F32 && dtype != JF_BF16) return fail(JF_E_INVALID, "jf_rs_onpolicy_step: dtype %d", dtype);
     if (V <= 0 || V > 0x7FFFFFFFll) return fail(JF_E_INVALID, "jf_rs_onpolicy_step: V=%lld", (long long)V);
     const float t = (temperature <= 0.f) ? 1.f : temperature;
@@ -1179,13 +1392,24 @@ extern "C" int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_
         !bonus_stream || !bonus_cursor || !pad_stream || !pad_cursor || !committed || !next_draft || !rows || !workspace)
         return fail(JF_E_INVALID, "jf_rs_step: null pointer");
     if (u_len <= 0 || bonus_len <= 0 || pad_len <= 0) return fail(JF_E_INVALID, "jf_rs_step: empty random stream");
-    if (workspace_bytes < rs_ws_bytes(B) || ((uintptr_t)workspace % 8) != 0) return fail(JF_E_INVALID, "jf_rs_step: workspace too small or misaligned");
+    if (workspace_bytes < rs_ws_bytes(B) || ((uintptr_t)workspace % 16) != 0) return fail(JF_E_INVALID, "jf_rs_step: workspace too small or not 16-byte aligned");
     if (V <= 0 || V > 0x7FFFFFFFll) return fail(JF_E_INVALID, "jf_rs_step: V=%lld", (long long)V);
     const float t = (temperature <= 0.f) ? 1.f : temperature;
     if (dtype != JF_F32 && dtype != JF_BF16) return fail(JF_E_INVALID, "jf_rs_step: dtype %d", dtype);
     hipStream_t s = (hipStream_t)stream;
     unsigned long long *pk = (unsigned long long *)packed;
     const RsWs w = rs_ws(workspace, B);
+    static const bool fused_ok = !(getenv("JF_RS_FUSED") && getenv("JF_RS_FUSED")[0] == '0');   // A/B knob, read once
+    if (fused_ok && (int64_t)B * (L - 1) <= RS_FUSED_STAGE && B <= RS_FUSED_ROWS && u_len < 0x7FFFFFFFll) {
+        static uint32_t g_gen = 0;                                  // generation of the hand-off words (0 never used: a zeroed workspace)
+        if (++g_gen == 0) ++g_gen;
+        RsFusedArgs a{logits, V, row_stride, draft, B, L, p_draft, row_max, row_sumexp, pk, t, eos_id, remaining, u_stream, u_len, u_cursor,
+                      bonus_stream, bonus_len, bonus_cursor, pad_stream, pad_len, pad_cursor, committed, next_draft, rows, w, g_gen};
+        const unsigned grid = (unsigned)(1 + B * RS_SEG + 1 + B + 1);
+        if (dtype == JF_F32) rs_step_fused_kernel<JF_F32><<<grid, 256, 0, s>>>(a);
+        else rs_step_fused_kernel<JF_BF16><<<grid, 256, 0, s>>>(a);
+        return check_launch("rs_step_fused_kernel");
+    }
     if ((int64_t)B * (L - 1) <= RS_STAGE && B <= RS_ROWS_LDS && u_len < 0x7FFFFFFFll)
         rs_accept_kernel<true><<<1, 256, 0, s>>>(draft, B, L, p_draft, eos_id, u_stream, u_len, u_cursor, committed, rows, w);
     else
