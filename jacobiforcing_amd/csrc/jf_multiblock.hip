@@ -352,18 +352,20 @@ __global__ __launch_bounds__(AM_TPB) void mb_verify_kernel(VerifyArgs a) {
 static int verify_stepper_cap(const void *kern, int variant, size_t shm) {
     static std::mutex mu;
     static size_t seen_shm[8];
-    static int seen_cap[8];
+    static int seen_cap[8], seen_dev[8];
     static bool seen[8];
     std::lock_guard<std::mutex> g(mu);
-    if (seen[variant] && seen_shm[variant] == shm) return seen_cap[variant];
-    int per_cu = 0, dev = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, AM_TPB, shm) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (seen[variant] && seen_shm[variant] == shm && seen_dev[variant] == dev) return seen_cap[variant];   // per variant, LDS request AND device
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, AM_TPB, shm) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
         (void)hipGetLastError();
         per_cu = 0;
     }
     const long long cap = (long long)per_cu * cus / 2;
-    seen[variant] = true; seen_shm[variant] = shm; seen_cap[variant] = (int)(cap > 0x7FFFFFFF ? 0x7FFFFFFF : cap);
+    seen[variant] = true; seen_shm[variant] = shm; seen_dev[variant] = dev; seen_cap[variant] = (int)(cap > 0x7FFFFFFF ? 0x7FFFFFFF : cap);
     return seen_cap[variant];
 }
 

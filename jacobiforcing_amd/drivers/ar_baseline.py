@@ -48,6 +48,7 @@ def generate_greedy(model: Qwen2Model, prompt, max_new_tokens: int, eos_id=None)
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default=None)
+    ap.add_argument("--allow-random-init", action="store_true", help="a --model directory without *.safetensors runs random-init")
     ap.add_argument("--synthetic", type=int, default=4)
     ap.add_argument("--max-new-tokens", type=int, default=1024)      # ar_inference_baseline.py:141
     ap.add_argument("--seed", type=int, default=1234)                # ar_inference_baseline.py:35
@@ -55,7 +56,7 @@ def main(argv=None):
     args = ap.parse_args(argv)
     dev = torch.device(args.device)
     if args.model:
-        cfg, w = load_model_directory(args.model, dev)
+        cfg, w = load_model_directory(args.model, dev, allow_random_init=args.allow_random_init)
     else:
         cfg = Qwen2Config.qwen2_5_coder_7b()
         w = Qwen2Weights(cfg, dev)

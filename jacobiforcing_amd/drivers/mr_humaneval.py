@@ -48,6 +48,7 @@ def load_prompts(args, cfg):
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default=None)
+    ap.add_argument("--allow-random-init", action="store_true", help="a --model directory without *.safetensors runs random-init")
     ap.add_argument("--tokenizer", default=None)
     ap.add_argument("--prompts", default=None, help="HumanEval parquet (column 'prompt')")
     ap.add_argument("--synthetic", type=int, default=0)
@@ -70,7 +71,7 @@ def main(argv=None):
     if dev.type == "cuda":
         torch.cuda.set_device(dev)
     if args.model:
-        cfg, w = load_model_directory(args.model, dev)
+        cfg, w = load_model_directory(args.model, dev, allow_random_init=args.allow_random_init)
     else:
         cfg = Qwen2Config.qwen2_5_coder_7b()
         w = Qwen2Weights(cfg, dev)

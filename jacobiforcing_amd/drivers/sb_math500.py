@@ -95,6 +95,7 @@ def decode_one(me, prompt, n, eos_id, alt_eos_id, max_new_tokens, max_calls, rng
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default=None)
+    ap.add_argument("--allow-random-init", action="store_true", help="a --model directory without *.safetensors runs random-init")
     ap.add_argument("--tokenizer", default=None)
     ap.add_argument("--prompts", default=None, help="jsonl with a 'problem' field (MATH500)")
     ap.add_argument("--synthetic", type=int, default=0)
@@ -108,7 +109,7 @@ def main(argv=None):
     args = ap.parse_args(argv)
     dev = torch.device(args.device)
     if args.model:
-        cfg, w = load_model_directory(args.model, dev)
+        cfg, w = load_model_directory(args.model, dev, allow_random_init=args.allow_random_init)
     else:
         cfg = Qwen2Config.qwen2_5_coder_7b()
         w = Qwen2Weights(cfg, dev)

@@ -36,6 +36,7 @@ class LLMEngine:
         self.scheduler = Scheduler(config)
         self.model_runner.block_manager = self.scheduler.block_manager
         self.scheduler.set_kv_cache(self.model_runner.kv_cache)
+        self.scheduler.release_row = self.model_runner.release
         atexit.register(self.exit)
 
     def exit(self):

@@ -21,6 +21,7 @@ class Scheduler:
         self.waiting: deque = deque()
         self.running: deque = deque()
         self.row_capacity = None
+        self.release_row = None     # callable(seq): hands a request's static cache row back (ModelRunner.release), set by the engine
 
     def set_kv_cache(self, kv_cache) -> None:
         self.block_manager.kv_cache = kv_cache
@@ -81,8 +82,12 @@ class Scheduler:
         return batch
 
     def preempt(self, seq: Sequence) -> None:
+        """Back to the queue (SCH:70-73).  The request also gives its cache row back — it is re-prefilled from scratch when it
+        is admitted again — so that the admission limit above counts rows that are really free."""
         seq.status = SequenceStatus.WAITING
         self.block_manager.deallocate(seq)
+        if self.release_row is not None:
+            self.release_row(seq)
         self.waiting.appendleft(seq)
 
     def _finish(self, seq: Sequence) -> None:

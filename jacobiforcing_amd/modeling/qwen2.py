@@ -137,16 +137,27 @@ class Qwen2Weights:
         self.lm_head = self.embed if cfg.tie_word_embeddings else get("lm_head.weight")
 
 
-def load_model_directory(model_dir, device, dtype=None):
-    """(config, weights) of a HF Qwen2 directory: ``config.json`` and, when present, its ``*.safetensors``; a directory that
-    only holds the config gets random-init weights (said on stdout), like the engine's ModelRunner does."""
+def load_model_directory(model_dir, device, dtype=None, allow_random_init: bool = False):
+    """(config, weights) of a HF Qwen2 directory: ``config.json`` + its ``*.safetensors``.  A directory without safetensors is an
+    error (a checkpoint shipped as ``pytorch_model.bin``, or a path one level off, must not turn into numbers from random
+    weights) unless ``allow_random_init`` is given; the notice then goes to stderr (the drivers' stdout is their data)."""
+    import sys
     device = torch.device(device)
     cfg = Qwen2Config.from_json(Path(model_dir) / "config.json")
+    has = bool(list(Path(model_dir).glob("*.safetensors")))
+    if not has:
+        other = [f.name for pat in ("*.bin", "*.pt", "*.pth") for f in Path(model_dir).glob(pat)]
+        if other:
+            raise FileNotFoundError(f"{model_dir} holds {other[:3]} but no *.safetensors: convert the checkpoint "
+                                    "(save_pretrained(..., safe_serialization=True)); refusing to decode with random weights")
+        if not allow_random_init:
+            raise FileNotFoundError(f"no *.safetensors under {model_dir} (pass allow_random_init=True / --allow-random-init to "
+                                    "run this architecture with random-init weights)")
     w = Qwen2Weights(cfg, device, dtype=dtype or (torch.bfloat16 if device.type == "cuda" else torch.float32))
-    if list(Path(model_dir).glob("*.safetensors")):
+    if has:
         w.load_safetensors(model_dir, cfg)
     else:
-        print(f"[qwen2] no *.safetensors under {model_dir}: random-init weights", flush=True)
+        print(f"[qwen2] no *.safetensors under {model_dir}: random-init weights (allow_random_init)", file=sys.stderr, flush=True)
     return cfg, w
 
 

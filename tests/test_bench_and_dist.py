@@ -187,3 +187,49 @@ def test_bench_starts_its_own_ranks():
         assert d["n_gpus"] == 2 and d["scaling"] == mode and d["config"]["prompts_per_gpu"] == per_gpu
         assert d["config"]["total_prompts"] == 2 * per_gpu and d["value"] > 0 and d["steps"] == 3
         assert d["tokens_per_forward"] >= 1.0
+
+
+def test_eight_ranks_without_gpus_fail_with_the_ranks_message():
+    """The 8-rank launch path on a machine without GPUs: bench.py starts its eight ranks (JF_FORCE_DEVICE + gloo, the plumbing
+    mode), every rank refuses to measure without an MI355X, and the launcher's non-zero exit code and the ranks' own message
+    reach the caller — a failing rank is never a silent success."""
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the 8-rank run itself is test_eight_ranks_share_one_gpu")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(JF_DIST_BACKEND="gloo", JF_FORCE_DEVICE="0", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--model", "tiny",
+                        "--total-prompts", "64"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "needs an MI355X" in (r.stderr + r.stdout)
+    assert '"n_gpus"' not in r.stdout
+
+
+@pytest.mark.gpu
+def test_eight_ranks_share_one_gpu():
+    """BASELINE config 4 as stated — 64 prompts sharded 8-way, prompt i on rank i mod 8 — through the real `python bench.py
+    --gpus 8` (it starts the ranks itself); on the one-GPU box all eight ranks share the GPU and the final gather runs over
+    gloo, so everything but RCCL itself is exercised: n_gpus = 8, 8 prompts per rank, the tokens of all ranks in the line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(JF_DIST_BACKEND="gloo", JF_FORCE_DEVICE="0", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1", "--model", "tiny",
+                        "--total-prompts", "64", "--no-scripted", "--no-prewarm", "--cpu-baseline-seconds", "0"], env=env,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["config"]["prompts_per_gpu"] == 8 and d["config"]["total_prompts"] == 64
+    # every prompt accepts at least one token per step: the line carries all 8 ranks' tokens
+    assert d["value"] * d["ms_per_step"] * 1e-3 * d["steps"] >= 64 * 4 * 0.99
+    assert d["tokens_per_forward"] >= 1.0
+
+
+def test_shard_is_i_mod_world_for_eight_ranks():
+    from jacobiforcing_amd import distributed as jd
+    prompts = list(range(64))
+    seen = []
+    for rank in range(8):
+        mine = jd.shard_prompts(prompts, jd.RankInfo(rank, 8, rank))
+        assert mine == [i for i in prompts if i % 8 == rank] and len(mine) == 8
+        seen += mine
+    assert sorted(seen) == prompts

@@ -319,8 +319,11 @@ def test_mr_humaneval_driver_writes_the_reference_csv(backend, tmp_path, capsys)
     (tmp_path / "config.json").write_text(_json.dumps(cfgd))
     out = tmp_path / "profile.csv"
     with use_backend(backend):
-        mr_humaneval.main(["--model", str(tmp_path), "--synthetic", "3", "--batch", "2", "--n", "8", "--max-new-tokens", "24",
-                           "--csv", str(out), "--no-tuned-gemms", "--device", device_for(backend)])
+        with pytest.raises(FileNotFoundError):                    # a directory without weights is refused unless asked for
+            mr_humaneval.main(["--model", str(tmp_path), "--synthetic", "1", "--csv", str(out), "--no-tuned-gemms",
+                               "--device", device_for(backend)])
+        mr_humaneval.main(["--model", str(tmp_path), "--allow-random-init", "--synthetic", "3", "--batch", "2", "--n", "8",
+                           "--max-new-tokens", "24", "--csv", str(out), "--no-tuned-gemms", "--device", device_for(backend)])
     rows = list(_csv.DictReader(open(out)))
     assert list(rows[0].keys()) == mr_humaneval.COLUMNS and len(rows) == 3
     for r in rows:

@@ -53,19 +53,47 @@ def test_plain_c_client(tmp_path):
     assert "rc=-1" in out and "null pointer" in out
 
 
+def _c_case_file(case, path):
+    """One golden multiblock record (tests/golden/mb_cases*.json: calls of the unmodified reference) as the flat integer file the
+    C client reads."""
+    import math
+    p = case["params"]
+    V = case["model"]["vocab"] if "vocab" in case["model"] else case["model"]["V"]
+    out = [p["n"], p["K"], int(math.ceil(p["r"] * p["n"])), p["pool"], -1 if p["eos_id"] is None else p["eos_id"],
+           -1 if p["pad_id"] is None else p["pad_id"], p["max_iter"], 1 + p["max_iter"], V, len(case["calls"])]
+    for call in case["calls"]:
+        out += [call["kv_len_before"]] + list(call["input"]) + [len(call["forwards"])]
+        for fw in call["forwards"]:
+            B, T = len(fw["out"]), len(fw["out"][0])
+            out += [B, T] + [t for row in fw["out"] for t in row] + [t for row in fw["greedy"] for t in row]
+        nt = call["next_token"][0] if call["next_token"] else -1
+        out += [len(call["ret"])] + list(call["ret"]) + [-1 if nt is None else nt, call["iters"], call["kv_len"]]
+    path.write_text(" ".join(str(int(x)) for x in out))
+
+
 @GPU
-def test_plain_c_client_launches_kernels(tmp_path):
+def test_plain_c_client_launches_kernels(tmp_path, mb_cases):
     """The same C99 client with -DJF_ABI_GPU: device buffers from the HIP runtime's C API, then jf_argmax_rows,
-    jf_accept_lengths and jf_sb_step called from C and checked there — no Python, no torch between caller and kernels."""
+    jf_accept_lengths and jf_sb_step called from C and checked there — and the HOT PATH itself: golden records of the
+    reference (BASELINE's knobs, a candidate-row case, a K = 3 case) driven through jf_mb_begin -> jf_mb_pack -> jf_mb_verify
+    -> jf_mb_read_ret from C, every forward's rows and every call's ret / next_token / iters / kv_len compared in C.
+    No Python, no torch between caller and kernels."""
     import __graft_entry__ as G
     lib = G.build_hip()
     exe = tmp_path / "abi_client_gpu"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-DJF_ABI_GPU", f"-I{ROOT / 'include'}", "-I/opt/rocm/include",
                            str(ROOT / "tests" / "abi" / "abi_client.c"), f"-L{lib.parent}", "-ljacobiforcing", "-L/opt/rocm/lib",
                            "-lamdhip64", f"-Wl,-rpath,{lib.parent}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
-    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    files = []
+    for name in ("n32_K2_r85_default", "n32_period_candidates_pool8", "n16_K3_r50"):
+        case = next(c for c in mb_cases if c["name"] == name)
+        f = tmp_path / f"{name}.txt"
+        _c_case_file(case, f)
+        files.append(str(f))
+    out = subprocess.run([str(exe)] + files, capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "gpu=ok" in out.stdout and "accepted=4" in out.stdout
+    assert out.stdout.count("hot_path=ok") == 3, out.stdout
 
 
 def test_missing_library_fails_loudly(tmp_path):

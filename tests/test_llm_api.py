@@ -246,3 +246,39 @@ def test_engine_queue_stress_with_eos(tmp_path, backend, monkeypatch):
                     assert got == a, strategy                           # stops on the same EOS, nothing after it
                 else:
                     assert got[:b] == a, strategy
+
+
+def test_preempted_request_gives_its_cache_row_back():
+    """A tiny KV block pool forces the scheduler to preempt (SCH:63-73): the preempted request's static cache row returns to the
+    free list, so the admission limit counts rows that are really free and a later admission never meets 'no free KV cache
+    row'; everything still decodes to the greedy continuation."""
+    import json, tempfile
+    from pathlib import Path
+    from jacobiforcing_amd import LLM, SamplingParams
+    from tests.backends import use_backend
+    cfgd = dict(vocab_size=97, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=2, max_position_embeddings=2048, rms_norm_eps=1e-6, rope_theta=10000.0,
+                tie_word_embeddings=False, eos_token_id=96, pad_token_id=95, model_type="qwen2")
+    d = tempfile.mkdtemp()
+    (Path(d) / "config.json").write_text(json.dumps(cfgd))
+    prompts = [[(7 * i + j) % 90 for j in range(200 + 40 * i)] for i in range(4)]
+    sp = SamplingParams(temperature=0.0, max_tokens=150, ignore_eos=True)
+    with use_backend("hostsim"):
+        ref = LLM(d, tokenizer_path="none", device="cpu", max_model_len=1024, max_num_batched_tokens=4096, max_num_seqs=4)
+        want = [r["token_ids"] for r in ref.generate(prompts, sp, use_tqdm=False)]
+        # 256-token blocks: 6 blocks cannot hold four requests that each cross a block edge while decoding
+        llm = LLM(d, tokenizer_path="none", device="cpu", max_model_len=1024, max_num_batched_tokens=4096, max_num_seqs=4,
+                  num_kvcache_blocks=6)
+        sched = llm.scheduler
+        n_pre = [0]
+        orig = sched.preempt
+
+        def counting(seq):
+            n_pre[0] += 1
+            orig(seq)
+            assert seq.cache_row < 0                       # the row went back with the blocks
+        sched.preempt = counting
+        got = [r["token_ids"] for r in llm.generate(prompts, sp, use_tqdm=False)]
+        assert n_pre[0] >= 1, "the pool was meant to force a preemption"
+        assert got == want
+        assert sorted(llm.model_runner.free_rows) == list(range(llm.model_runner.max_rows))
