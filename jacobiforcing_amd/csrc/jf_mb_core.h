@@ -751,9 +751,9 @@ JF_HD void drv_call_end(M &m, const LoopDev &lp, int p, jf_mb_desc *d) {
     m.lanes.sync();
 }
 
-// Summary of the next forward, written where the host polls for it (the mailbox: mapped pinned host memory).  Run by the
-// lanes of ONE prompt at the start of the pack step — the launch queued behind the convergence launch, so every prompt's
-// descriptor is final — while the other prompts' lanes are already writing the forward's inputs.  copy_tables = false: every
+// Summary of the next forward, written where the host polls for it (the mailbox: mapped pinned host memory).  Run by ONE extra
+// group of lanes of the pack step (index P) — the launch queued behind the convergence launch, so every prompt's descriptor is
+// final — while the prompts' own lanes write the forward's inputs.  copy_tables = false: every
 // prompt's stepper has put its own descriptor / driver record into the mailbox (the fused launch), only the header is
 // written here.  The sequence number goes last, behind a system-scope release.
 JF_HD void mb_fin_record(const int32_t *D, int32_t *fin, int j) {
@@ -828,7 +828,10 @@ template <class Lanes>
 JF_HD void mb_pack_body(Lanes lanes, int p, int P, int32_t *states, int64_t state_ints, const jf_mb_desc *desc, int32_t Tpad_in,
                         int32_t t_align, int32_t t_cap, int64_t pad_fill, int order, int32_t cand_rows, const PackOut &o,
                         int32_t valid_align, const LoopDev &lp, int publish /* 0 no, 1 header only, 2 header + tables */) {
-    if (publish && p == 0) mb_publish_body(lanes, P, desc, lp, publish == 2);
+    if (p >= P) {                        // the extra lane group of the loop API's pack launch: the host's summary, nothing to pack
+        if (publish) mb_publish_body(lanes, P, desc, lp, publish == 2);
+        return;
+    }
     int32_t *S = states + (int64_t)p * state_ints;
     // exclusive prefixes over the prompts before this one and totals over all of them, lanes in parallel
     int rows_b = 0, valid_b = 0, act_b = 0, act_t = 0, cand_b = 0, va_b = 0, va_t = 0, vb_b = 0, v_t = 0, tmax = 0;

@@ -30,7 +30,8 @@ __global__ __launch_bounds__(64) void mb_pack_kernel(int32_t *states, int64_t st
                                                       int32_t t_align, int32_t t_cap, int64_t pad_fill, int32_t order,
                                                       int32_t cand_rows, jfmb::PackOut o, int32_t valid_align, jfmb::LoopDev lp,
                                                       int32_t publish) {
-    jfmb::mb_pack_body(DevLanes{}, blockIdx.x, gridDim.x, states, state_ints, desc, Tpad, t_align, t_cap, pad_fill, order,
+    const int P = publish ? (int)gridDim.x - 1 : (int)gridDim.x;            // a publishing launch carries one extra workgroup for it
+    jfmb::mb_pack_body(DevLanes{}, blockIdx.x, P, states, state_ints, desc, Tpad, t_align, t_cap, pad_fill, order,
                        cand_rows, o, valid_align, lp, publish);
 }
 __global__ __launch_bounds__(64) void mb_step_kernel(int32_t *states, int64_t state_ints, unsigned long long *packed,
@@ -494,7 +495,7 @@ static int check_loop(const jf_mb_loop *lp, const char *who) {
 // publish: 1 = the launch in front mailed the per-prompt tables itself (fused verify), 2 = this launch copies them
 static int loop_pack(const jf_mb_loop *lp, const jfmb::LoopDev &d, int publish, hipStream_t s) {
     const jfmb::PackOut o{lp->input_ids, lp->positions, lp->row_prompt, lp->row_len, lp->valid_index, lp->row_cand, lp->row_kv_len};
-    mb_pack_kernel<<<lp->P, 64, 0, s>>>(lp->states, lp->state_ints, lp->desc, 0, lp->t_align < 1 ? 1 : lp->t_align, lp->t_cap,
+    mb_pack_kernel<<<lp->P + (publish ? 1 : 0), 64, 0, s>>>(lp->states, lp->state_ints, lp->desc, 0, lp->t_align < 1 ? 1 : lp->t_align, lp->t_cap,
                                         lp->pad_fill, lp->order ? 1 : 0, lp->cand_rows, o, lp->valid_align < 1 ? 1 : lp->valid_align,
                                         d, publish);
     return check_launch("mb_pack_kernel");

@@ -102,6 +102,7 @@ class ModelRunner:
         self._mb_decoders = {}
         self.profiler = ProfileTimer(self.device)
         self._kv_host = [0] * self.max_rows
+        self._logit_idx = {}
 
     # ------------------------------------------------------------------------------------------
     def call(self, method_name, *args):
@@ -214,12 +215,18 @@ class ModelRunner:
             seq.num_permanent_spec_blocks = max(seq.num_permanent_spec_blocks, need - committed)
         prof.stop("jacobi.block_alloc")
         prof.start("jacobi.forward")
-        logits = self._forward_rows(seqs, draft_tokens_batch, [len(s) - 1 for s in seqs], [L] * B)   # seed re-forwarded at S-1
+        # lm_head on the L-1 positions per row that verify a speculative token (the reference computes all L and slices,
+        # MR:1413-1416; slicing afterwards would make the verify kernels' [B*(L-1), V] view a 600 MB copy at batch 64)
+        key = (B, L)
+        idx = self._logit_idx.get(key)
+        if idx is None:
+            idx = self._logit_idx[key] = (torch.arange(B, dtype=torch.int32, device=self.device).view(B, 1) * L +
+                                          torch.arange(L - 1, dtype=torch.int32, device=self.device).view(1, L - 1)).reshape(-1)
+        logits = self._forward_rows(seqs, draft_tokens_batch, [len(s) - 1 for s in seqs], [L] * B, logit_index=idx)   # seed re-forwarded at S-1
         prof.stop("jacobi.forward")
         for seq in seqs:
             seq.num_cached_tokens = (len(seq) - 1) + L                                         # MR:1407-1408
-        V = logits.shape[-1]
-        return logits.view(B, L, V)[:, :-1, :]                                                  # MR:1413-1416
+        return logits.view(B, L - 1, logits.shape[-1])
 
     def _jacobi_forward_step(self, seq: Sequence, draft_tokens: torch.Tensor) -> torch.Tensor:
         return self._jacobi_forward_step_batch([seq], draft_tokens)

@@ -47,7 +47,7 @@ int hs_mb_pack(int32_t *states, int64_t state_ints, int P, int32_t Tpad, int64_t
 // ---- the loop API (jf_mb_loop_*): same bodies, prompts one after the other, the "last to finish" is the last of the loop
 static void hs_loop_pack(const jf_mb_loop *lp, const jfmb::LoopDev &d) {
     const jfmb::PackOut o{lp->input_ids, lp->positions, lp->row_prompt, lp->row_len, lp->valid_index, lp->row_cand, lp->row_kv_len};
-    for (int p = 0; p < lp->P; ++p)
+    for (int p = 0; p <= lp->P; ++p)                       // index P: the summary for the host
         jfmb::mb_pack_body(HostLanes{}, p, lp->P, lp->states, lp->state_ints, lp->desc, 0, lp->t_align < 1 ? 1 : lp->t_align, lp->t_cap,
                            lp->pad_fill, lp->order ? 1 : 0, lp->cand_rows, o, lp->valid_align < 1 ? 1 : lp->valid_align, d, 2);
 }

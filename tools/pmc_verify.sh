@@ -9,7 +9,7 @@ OUT=gpurun_out/pmc
 mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
     JF_DUMP_LAUNCHES=$OUT/launches_$c.json timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv \
-        -d $OUT/$c -o run -- python bench.py --steps 12 --warmup 2 --no-scripted --no-shapes --cpu-baseline-seconds 0 > $OUT/bench_$c.log 2>&1
+        -d $OUT/$c -o run -- python bench.py --steps 12 --warmup 2 --no-scripted --no-shapes --no-sections --cpu-baseline-seconds 0 > $OUT/bench_$c.log 2>&1
 done
 python tools/pmc_verify_parse.py $OUT
 rm -rf $OUT/FETCH_SIZE $OUT/WRITE_SIZE

@@ -40,7 +40,7 @@ def main():
                fetch_kib_raw=sum(fetch), write_kib_raw=sum(write),
                rows_valid_mean=sum(la["valid"]) / n, rows_launched_mean=sum(la["rows"]) / n,
                method="tools/pmc_verify.sh: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
-                      "`bench.py --steps 12 --warmup 2 --no-scripted --no-shapes --cpu-baseline-seconds 0`; per launch HBM bytes = "
+                      "`bench.py --steps 12 --warmup 2 --no-scripted --no-shapes --no-sections --cpu-baseline-seconds 0`; per launch HBM bytes = "
                       "(2*FETCH_SIZE + WRITE_SIZE) KiB (FETCH_SIZE doubled: gfx950 reports half of a wide coalesced stream, "
                       "MI355X_MICROARCH.md HBM section); the decode loop's launches = the mb_verify_kernel dispatches; "
                       "algorithmic bytes = draft-carrying rows * V * 2")
