@@ -1,8 +1,9 @@
 """Multiblock Jacobi decoding with rejection recycling for a batch of prompts.
 
 Host orchestration of the hot path the north star names: per Jacobi iteration one PyTorch forward
-over every prompt's rows, then ``jf_argmax_partial`` + ``jf_mb_step`` (verify, accept, re-draft,
-pool/candidates, spawn/promote) + ``jf_kv_commit`` in HIP, and ONE small descriptor read-back.
+over every prompt's rows, then ``jf_mb_loop_iterate`` (argmax + verify, accept, re-draft, pool /
+candidates, spawn/promote, committed lengths, call restarts, next forward's inputs: two launches) +
+``jf_kv_commit`` in HIP, and a poll of the mailbox the device stamps (ops.MultiblockLoop).
 
 The per-prompt semantics are those of the reference's ``jacobi_forward_greedy_multiblock``
 (MB:140-740) and its driver loop (JacobiForcing/jacobi_forcing_inference_MR_humaneval.py:152-273 =
