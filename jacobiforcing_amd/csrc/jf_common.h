@@ -53,6 +53,8 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 
 // one wavefront per workgroup
 struct DevLanes {
+    static constexpr bool WAVE64 = true;                               // one token per lane code paths (Machine::step_fast64)
+    __device__ __forceinline__ int shfl(int v, int src) const { return __shfl(v, src, 64); }
     __device__ __forceinline__ int lane() const { return threadIdx.x; }
     __device__ __forceinline__ int count() const { return 64; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }

@@ -407,12 +407,124 @@ struct Machine {
         return true;
     }
 
+    // ---- step_fast for a 64-lane wavefront, one token per lane ---------------------------------------------------
+    // Same case, same conditions, same effects as step_fast (rows of at most 64 tokens, n <= 63), but the rows live in
+    // registers: the accepted prefix, the re-draft and the pool entries come out of lane shuffles of the draft / greedy row
+    // instead of strided loops over the image, the next forward's rows are written while the drafts are, and only the header
+    // words that change are stored.  The step is the serial tail of the convergence launch: ~1 020 instructions as step_fast.
+    template <class GreedyFn>
+    JF_HD bool step_fast64(GreedyFn G, jf_mb_desc *d) {
+        if (num_blocks != 1 || RA != 0 || len_lists != 1) return false;
+        const int B = S[H_B], T = S[H_T];
+        if (S[H_NSPANS] != 1 || S[H_SPANS] != 0 || iters >= S[H_MAX_ITER]) return false;
+        const int start = S[H_SPANS + 1], Ls = S[H_SPANS + 2];
+        int32_t *bb = blk(0);
+        if (Ls < 2 || Ls > 64 || n > 63 || bb[B_DROWS] != B || B < 1 || B > L.RMAX) return false;
+        const int l = lanes.lane();
+        const int cmp = Ls - 1;
+        int best_idx = 0, acc_len = 0;
+        for (int r = 0; r < B; ++r) {                                   // MB:482-489
+            const int f = lanes.first_true(l < cmp ? draft(0, r)[l + 1] != G(r, start - 1 + l) : false);
+            const int m = f < 64 ? f : cmp;
+            if (m + 1 > acc_len) { acc_len = m + 1; best_idx = r; }
+        }
+        if (acc_len >= Ls) return false;
+        const int dtok = l < Ls ? draft(0, best_idx)[l] : 0;            // the winning draft row and its greedy row, a token per lane
+        const int gtok = l < Ls ? G(best_idx, start - 1 + l) : 0;
+        if (eos >= 0 && lanes.first_true(l < acc_len && dtok == eos) < 64) return false;    // MB:513-521
+        const int nxt = lanes.shfl(gtok, acc_len - 1);                  // MB:550
+        if (eos >= 0 && nxt == eos) return false;                       // MB:599-614
+        const int old_acclen = bb[B_ACCLEN];
+        const int new_acclen = old_acclen + acc_len, new_total = bb[B_TOTAL] + acc_len;
+        const int newL = Ls - acc_len;
+        if (new_acclen > n + 1) return false;
+        if (new_total >= S[H_SPAWN_THR] && active < K) return false;    // MB:629-653
+        if (new_total >= n) return false;                               // MB:656-721
+        if (L.pool_size > 0 && new_acclen + newL > L.LPOOL) return false;
+        // ---- nothing below can fail; no store above ---------------------------------------------------------
+        const int kv_before = kv_len;
+        const int nd = lanes.shfl(gtok, l + acc_len - 1 < 64 ? l + acc_len - 1 : 63);   // re-draft [nxt] + greedy[acc_len:-1], lane j < newL
+        int32_t *d0 = draft(0, 0), *o0 = out_row(0);
+        if (l < acc_len) acc(0)[old_acclen + l] = dtok;                  // MB:526-528 (from registers: no hazard with d0 below)
+        if (l < newL) { d0[l] = nd; o0[l] = nd; }                       // MB:553-558 and the next forward's row 0 (MB:317-340)
+        ra_accepted += acc_len;
+        int C = 0;
+        if (L.pool_size > 0) {                                          // MB:564-573
+            const int slot = (pool_count == L.pool_size) ? pool_head : wrap(pool_head + pool_count, L.pool_size);
+            int32_t *e = S + L.off_pool + slot * (1 + L.LPOOL);
+            const int tot = new_acclen + newL;                          // <= 2n + 1 <= 127: two passes of 64
+            int clen = 0;
+            for (int i0 = 0; i0 < tot; i0 += 64) {
+                const int i = i0 + l;
+                // position i of acc_old ⧺ accepted prefix ⧺ re-draft: image, or a shuffle out of the rows in registers
+                const int from_d = lanes.shfl(dtok, (i - old_acclen) & 63);
+                const int from_n = lanes.shfl(nd, (i - new_acclen) & 63);
+                int tok = 0; bool keep = false;
+                if (i < tot) {
+                    tok = i < old_acclen ? acc(0)[i] : (i < new_acclen ? from_d : from_n);
+                    keep = !(pad >= 0 && tok == pad);
+                }
+                const int before = lanes.prefix_count(keep);
+                if (keep) e[1 + clen + before] = tok;
+                clen += lanes.count_true(keep);
+            }
+            if (clen > 0) pool_push_slot(clen);
+            const int tlen = newL - 1;                                  // the rejected greedy tail
+            if (tlen > 0) {
+                int32_t *t = pool_push_slot(tlen);
+                if (l >= 1 && l < newL) t[l] = nd;
+            }
+            lanes.sync();                                               // the entries are searched below
+        }
+        if (new_total >= S[H_LOOK_THR]) {                               // MB:577-585
+            for (int i1 = pool_count - 2; i1 >= 0; --i1) {
+                const int32_t *e = pool_entry(i1);
+                const int elen = e[0];
+                const int pos = find_first_eq(e + 1, elen, nxt);
+                if (pos >= elen) continue;
+                if (1 + C >= L.RMAX) { JF_FAIL(JF_E_CAPACITY); break; }
+                const int avail = elen - pos;
+                if (l < newL) {
+                    const int v = l < avail ? e[1 + pos + l] : nd;      // MB:82-86
+                    draft(0, 1 + C)[l] = v;
+                    out_row(1 + C)[l] = v;
+                }
+                C++;
+            }
+        }
+        if (err) { lanes.sync(); done = 1; if (lanes.lane() == 0) { bb[B_ACCLEN] = new_acclen; bb[B_TOTAL] = new_total; bb[B_DROWS] = 1; bb[B_DLEN] = newL; } next_iteration(d); return true; }
+        const int rows = C > 1 ? 1 + C : 1;                             // a single recycled candidate is ignored (Q5)
+        lnt = nxt; has_lnt = 1;
+        events |= EVT_FAST;
+        int kv_cur = kv_before + T;
+        { const int c = prompt_len + new_acclen; if (kv_cur > c) kv_cur = c; }   // MB:617-626
+        kv_len = kv_cur;
+        if (best_idx != 0 && kv_len > kv_before) { kv_src_row = best_idx; kv_copy_dst = kv_before; kv_copy_len = kv_len - kv_before; }
+        iters++;
+        if (l == 0) {                                                   // the block entry, the header words that change, the descriptor
+            bb[B_ACCLEN] = new_acclen; bb[B_TOTAL] = new_total; bb[B_DROWS] = rows; bb[B_DLEN] = newL;
+            S[H_SPANS + 2] = newL;
+            S[H_LNT] = lnt; S[H_HAS_LNT] = 1; S[H_ITERS] = iters; S[H_KV_LEN] = kv_len;
+            S[H_POOL_COUNT] = pool_count; S[H_POOL_HEAD] = pool_head;
+            S[H_B] = rows; S[H_T] = newL;
+            if (d) {
+                d->B = rows; d->T = newL; d->done = 0; d->error = 0; d->iters = iters;
+                d->kv_len = kv_len; d->ret_len = S[H_RET_LEN]; d->next_token = S[H_NEXT_TOK];
+                d->kv_src_row = kv_src_row; d->kv_copy_dst = kv_copy_dst; d->kv_copy_len = kv_copy_len;
+                d->events = events; d->accepted = ra_accepted; d->nspans = 1; d->rsv0 = 0; d->rsv1 = 0;
+            }
+        }
+        lanes.sync();
+        return true;
+    }
+
     // ---- MB:467-721 ------------------------------------------------------------------------------
     template <class GreedyFn>
     JF_HD void step(GreedyFn G, jf_mb_desc *d) {
         load_scalars();
         if (done || err) { next_iteration(d); return; }
         JF_STAMP(1);
+        if constexpr (Lanes::WAVE64) { if (allow_fast && step_fast64(G, d)) return; }
         if (allow_fast && step_fast(G, d)) return;
         const int B = S[H_B], T = S[H_T], nspans = S[H_NSPANS];
         const int kv_before = kv_len;

@@ -11,6 +11,8 @@
 #include "jf_mb_core.h"
 
 struct HostLanes {
+    static constexpr bool WAVE64 = false;
+    int shfl(int v, int) const { return v; }
     int lane() const { return 0; }
     int count() const { return 1; }
     void sync() const {}
