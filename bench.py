@@ -380,6 +380,8 @@ def cpu_verify_kernel(rows: int, V: int, budget_s: float = 3.0):
         reps += 1
     dt = (time.perf_counter() - t0) / reps
     return dict(us_per_call=dt * 1e6, gbs=rows * V * 2 / dt / 1e9, rows=rows, threads=int(lib.ref_num_threads()), reps=reps,
+                seconds=budget_s, placement="no explicit NUMA binding: the rows are first-touched by the OpenMP threads that scan them "
+                                            "(static schedule), one warm-up call before the timed repetitions",
                 what="oracle/verify_ref.c ref_argmax_rows (C + OpenMP) over bf16 logits of the bench's launch shape")
 
 

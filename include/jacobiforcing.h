@@ -416,8 +416,11 @@ typedef struct jf_rs_row {
  *   u_stream / bonus_stream (floats in [0,1)) and pad_stream (token ids) are consumed cyclically from *cursor in row
  *   order, exactly where the reference calls torch.rand / torch.multinomial / torch.randint.
  *   committed [B, L], next_draft [B, L] (JDN:444-466), rows [B].  packed is re-zeroed.
- *   workspace: jf_rs_step_workspace_bytes(B) bytes (float64 segment sums of the rejected rows + a row list), 16-byte
- *   aligned; contents need not be preserved between calls.
+ *   workspace: jf_rs_step_workspace_bytes(B) bytes (float64 segment sums of the rejected rows, a row list and the hand-off
+ *   words of the one-launch step), 16-byte aligned, ZERO before its first use (one torch.zeros at start-up); the calls
+ *   themselves never need it re-zeroed (the hand-off words carry a per-call generation number).
+ *   Batches of at most 128 rows (B * (L-1) <= 4096) run as ONE launch: accept walk, segment sums, draw counting, bonus walks
+ *   and the finish are roles of one kernel (JF_RS_FUSED=0 selects the four launches that larger batches use).
  */
 JF_API size_t jf_rs_step_workspace_bytes(int64_t rows);   /* rows = B (jf_rs_step) or R (jf_rs_onpolicy_step) */
 JF_API int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_stride, const int64_t *draft, int B, int L,

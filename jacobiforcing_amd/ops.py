@@ -385,7 +385,10 @@ class MultiblockLoop:
 
     def close(self) -> None:
         if self._mb_ptr is not None:
+            if self.batch.device.type == "cuda":             # a queued launch may still be mailing descriptors
+                torch.cuda.synchronize(self.batch.device)
             self.mailbox = None
+            self._hdr = None
             N.lib().jf_host_free(self._mb_ptr)
             self._mb_ptr = None
 
