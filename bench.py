@@ -231,13 +231,15 @@ def roof(su, kernel, note=None):
     return r
 
 
-def single_block_section(model, cfg, n: int = 16, prompt_len: int = 256, new_tokens: int = 96):
+def single_block_section(model, cfg, tuned: bool = True, n: int = 16, prompt_len: int = 256, new_tokens: int = 96):
     """BASELINE config 2: single-block Jacobi n=16, greedy, batch 1 (SB:140-276 through hf_seam.jacobi_forward_greedy and the
     reference driver's loop, drivers/sb_math500.decode_one)."""
     import types
     from jacobiforcing_amd.drivers.sb_math500 import decode_one
     from jacobiforcing_amd.hf_seam import Qwen2Backend
-    me = types.SimpleNamespace(jf_backend=Qwen2Backend(model, max_seq_len=prompt_len + new_tokens + 8 * n, max_rows=1, max_tokens=n))
+    from jacobiforcing_amd.tuning import grid_alignment
+    me = types.SimpleNamespace(jf_backend=Qwen2Backend(model, max_seq_len=prompt_len + new_tokens + 8 * n + 64, max_rows=1, max_tokens=n,
+                                                        t_align=grid_alignment(1, tuned)[0]))
     rng = random.Random(1234)
     prompt = [rng.randrange(min(151643, cfg.vocab_size - 2)) for _ in range(prompt_len)]
     eos = cfg.vocab_size - 1                               # an id the synthetic prompts never contain
@@ -306,8 +308,9 @@ def vs_ar_section(model, cfg, prm, tuned, vocab_hi, robust, warmup: int = 8, ste
     from jacobiforcing_amd.drivers.ar_baseline import generate_greedy
     prompt = humaneval_shaped_prompts(1, seed=1234, vocab_hi=vocab_hi)
     hook = ScriptedAcceptance(cfg.vocab_size, robust_pct=robust, vocab_hi=vocab_hi)
-    dec = MultiblockJacobiDecoder(model, 1, prm, max_seq_len=4096, t_align=8 if tuned else 1, logit_align=8 if tuned else 1,
-                                  logits_hook=hook)
+    from jacobiforcing_amd.tuning import grid_alignment
+    ta, la = grid_alignment(1, tuned)
+    dec = MultiblockJacobiDecoder(model, 1, prm, max_seq_len=4096, t_align=ta, logit_align=la, logits_hook=hook)
     run_steps(dec, prompt, warmup, steps, seed=77)
     with VerifyTimer() as tm:
         tm.valid_rows = lambda: dec.last_valid_rows
@@ -422,6 +425,7 @@ def main():
     ap.add_argument("--robust", type=int, default=82)
     ap.add_argument("--no-tuned-gemms", action="store_true")
     ap.add_argument("--logit-align", type=int, default=0, help="lm_head row count rounded up to this multiple (0 = default)")
+    ap.add_argument("--t-align", type=int, default=0, help="forward row length rounded up to this multiple (0 = default: 8 with tuned GEMMs)")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -440,7 +444,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     _native.lib()                                   # fail loudly if the HIP extension is missing
-    from jacobiforcing_amd.tuning import enable_tuned_gemms
+    from jacobiforcing_amd.tuning import enable_tuned_gemms, grid_alignment
     tuned = (not args.no_tuned_gemms) and enable_tuned_gemms()
 
     if args.model == "tiny":
@@ -466,8 +470,8 @@ def main():
     vocab_hi = min(151643, cfg.vocab_size - 2)
     all_prompts = humaneval_shaped_prompts(P * info.world_size, seed=1234, vocab_hi=vocab_hi)
     prompts = jd.shard_prompts(all_prompts, info)
-    dec = MultiblockJacobiDecoder(model, P, prm, max_seq_len=4096, t_align=8 if tuned else 1,
-                                  logit_align=args.logit_align or (8 * P if tuned else 1))   # lm_head M stays on the tuned grid (multiples of 8*P)
+    ta, la = grid_alignment(P, tuned)
+    dec = MultiblockJacobiDecoder(model, P, prm, max_seq_len=4096, t_align=args.t_align or ta, logit_align=args.logit_align or la)   # lm_head M stays on the tuned grid (multiples of 8*P)
 
     # ---- untimed: one pass over the same W + K iterations, so that every library kernel the window launches (the GEMM
     # shapes change with the rows per step) is loaded before the clock starts; the measured pass below starts again from
@@ -516,8 +520,8 @@ def main():
                 rs = roof
             else:
                 torch.cuda.empty_cache()
-                ds = MultiblockJacobiDecoder(model, Ps, prm, max_seq_len=4096, t_align=8 if tuned else 1,
-                                             logit_align=(8 * Ps if tuned else 1))
+                tas, las = grid_alignment(Ps, tuned)
+                ds = MultiblockJacobiDecoder(model, Ps, prm, max_seq_len=4096, t_align=tas, logit_align=las)
                 with VerifyTimer() as tms:
                     tms.valid_rows = lambda: ds.last_valid_rows
                     run_steps(ds, all_prompts[:Ps] if len(all_prompts) >= Ps else humaneval_shaped_prompts(Ps, seed=1234, vocab_hi=vocab_hi),
@@ -551,7 +555,7 @@ def main():
                        "steps_measured": steps_done, "logits_dtype": "bf16",
                        "weights": "random-init (no network for checkpoints); acceptance is what these weights give",
                        "gemm_selection": "TunableOp table jacobiforcing_amd/tunableop_mi355x.csv (hipBLASLt/rocBLAS picks for "
-                                         "M=64..4096; row length padded to a multiple of 8)" if tuned else "library default",
+                                         "M=64..4096; rows kept on that grid: tuning.grid_alignment)" if tuned else "library default",
                        "prewarm": "none" if args.no_prewarm else "one untimed pass over the same W + K iterations before the measured "
                                                                  "pass (loads the library kernels of every GEMM shape the window uses)"},
         }
@@ -580,7 +584,7 @@ def main():
     if out is not None and info.world_size == 1 and not args.no_sections:
         del dec
         torch.cuda.empty_cache()
-        for key, fn in (("single_block", lambda: single_block_section(model, cfg)),
+        for key, fn in (("single_block", lambda: single_block_section(model, cfg, tuned)),
                         ("nongreedy", lambda: nongreedy_section(model, cfg, weights, tuned)),
                         ("vs_ar", lambda: vs_ar_section(model, cfg, prm, tuned, vocab_hi, args.robust))):
             try:

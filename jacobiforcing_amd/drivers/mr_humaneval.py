@@ -76,7 +76,7 @@ def main(argv=None):
         cfg = Qwen2Config.qwen2_5_coder_7b()
         w = Qwen2Weights(cfg, dev)
     model = Qwen2Model(cfg, w)
-    from ..tuning import enable_tuned_gemms
+    from ..tuning import enable_tuned_gemms, grid_alignment
     tuned = (not args.no_tuned_gemms) and enable_tuned_gemms()       # rows then stay on the tuned M grid (t_align)
     prm = ops.MultiblockParams(n=args.n, K=args.K, r=args.r, lookahead_start_ratio=args.lookahead, n_gram_pool_size=args.pool,
                                eos_token_id=cfg.eos_token_id, pad_token_id=cfg.pad_token_id)
@@ -85,7 +85,7 @@ def main(argv=None):
     for b0 in range(0, len(items), args.batch):
         chunk = items[b0:b0 + args.batch]
         dec = MultiblockJacobiDecoder(model, len(chunk), prm, max_seq_len=max(len(p) for _, (_, p) in chunk) + args.max_new_tokens + 6 * args.n + 128,
-                                      t_align=8 if tuned else 1, logit_align=8 * len(chunk) if tuned else 1)
+                                      t_align=grid_alignment(len(chunk), tuned)[0], logit_align=grid_alignment(len(chunk), tuned)[1])
         stats, gen_s, iters = dec.generate([p for _, (_, p) in chunk], max_new_tokens=args.max_new_tokens, max_calls=args.max_calls,
                                            seed=args.seed + b0)
         for (idx, (task, _)), st in zip(chunk, stats):

@@ -106,6 +106,7 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--device", default="cuda")
     ap.add_argument("--csv", default="diffusion_profile_math500.csv")
+    ap.add_argument("--no-tuned-gemms", action="store_true")
     args = ap.parse_args(argv)
     dev = torch.device(args.device)
     if args.model:
@@ -114,11 +115,14 @@ def main(argv=None):
         cfg = Qwen2Config.qwen2_5_coder_7b()
         w = Qwen2Weights(cfg, dev)
     model = Qwen2Model(cfg, w)
+    from ..tuning import enable_tuned_gemms, grid_alignment
+    tuned = dev.type == "cuda" and not args.no_tuned_gemms and enable_tuned_gemms()   # rows then stay on the tuned M grid
     rng = random.Random(args.seed)
     rows = []
     for idx, (task, prompt) in enumerate(load_prompts(args, cfg)):
-        me = types.SimpleNamespace(jf_backend=Qwen2Backend(model, max_seq_len=len(prompt) + args.max_new_tokens + 4 * args.n + 8,
-                                                           max_rows=1, max_tokens=len(prompt) + args.n + 8))
+        me = types.SimpleNamespace(jf_backend=Qwen2Backend(model, max_seq_len=len(prompt) + args.max_new_tokens + 4 * args.n + 72,
+                                                           max_rows=1, max_tokens=len(prompt) + args.n + 8,
+                                                           t_align=grid_alignment(1, tuned)[0]))
         r, _ = decode_one(me, prompt, args.n, cfg.eos_token_id, getattr(cfg, "alt_eos_token_id", None), args.max_new_tokens,
                           args.max_calls, rng)
         rows.append(dict(index=idx, task_id=task, **r))

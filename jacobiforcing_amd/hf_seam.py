@@ -29,12 +29,17 @@ from .modeling.qwen2 import Qwen2Model, StaticKVCache
 class Qwen2Backend:
     """One prompt (batch 1, like the reference's HF functions) over a static cache with candidate scratch rows."""
 
-    def __init__(self, model: Qwen2Model, max_seq_len: int = 8192, max_rows: int = 8, max_tokens: int = 512):
+    def __init__(self, model: Qwen2Model, max_seq_len: int = 8192, max_rows: int = 8, max_tokens: int = 512, t_align: int = 1):
         self.model, self.max_seq_len, self.max_rows, self.max_tokens = model, max_seq_len, max_rows, max_tokens
         self.device = model.device
+        # rows are padded to a multiple of t_align tokens inside the forward (masked, no logits for them): keeps the GEMM row
+        # count on the tuned grid (tuning.grid_alignment: 64 for one prompt) — off it the library's kernels are 1.1-1.3x slower
+        self.t_align = max(int(t_align), 1)
+        self._idx = {}
 
     def new_cache(self):
-        c = StaticKVCache(self.model.cfg, 1, self.max_seq_len, self.max_rows - 1, self.max_tokens, self.device, dtype=self.model.dtype)
+        tpad = -(-self.max_tokens // self.t_align) * self.t_align
+        c = StaticKVCache(self.model.cfg, 1, self.max_seq_len, self.max_rows - 1, tpad, self.device, dtype=self.model.dtype)
         c.length = 0
         c.get_seq_length = lambda: c.length
         return c
@@ -48,11 +53,22 @@ class Qwen2Backend:
         if kv + T > self.max_seq_len or B > self.max_rows or (B > 1 and T > self.max_tokens):
             raise RuntimeError(f"forward of {B}x{T} tokens at position {kv} exceeds the static cache "
                                f"(max_seq_len={self.max_seq_len}, max_rows={self.max_rows}, max_tokens={self.max_tokens})")
-        pos = (kv + torch.arange(T, dtype=torch.int32, device=dev)).view(1, T).expand(B, T).contiguous()
+        Tp = -(-T // self.t_align) * self.t_align
+        if Tp != T and kv + Tp > self.max_seq_len:
+            Tp = T
+        rows = rows.to(dev)
+        idx = None
+        if Tp != T:
+            rows = torch.nn.functional.pad(rows, (0, Tp - T))
+            idx = self._idx.get((B, T, Tp))
+            if idx is None:
+                idx = self._idx[(B, T, Tp)] = (torch.arange(B, dtype=torch.int32, device=dev).view(B, 1) * Tp +
+                                               torch.arange(T, dtype=torch.int32, device=dev).view(1, T)).reshape(-1)
+        pos = (kv + torch.arange(Tp, dtype=torch.int32, device=dev)).view(1, Tp).expand(B, Tp).contiguous()
         z = torch.zeros(B, dtype=torch.int32, device=dev)
         cand = torch.arange(-1, B - 1, dtype=torch.int32, device=dev)
-        return self.model.forward(rows.to(dev), pos, cache, row_prompt=z, row_cand=cand, row_len=z + T, kv_len_rows=z + kv,
-                                  any_candidates=B > 1, s_cur=kv + T)
+        return self.model.forward(rows, pos, cache, row_prompt=z, row_cand=cand, row_len=z + T, kv_len_rows=z + kv,
+                                  any_candidates=B > 1, s_cur=kv + Tp, logit_index=idx)
 
     def commit(self, cache, src_row: int, dst: int, length: int) -> None:
         d = torch.zeros((1, N.DESC_INTS), dtype=torch.int32)

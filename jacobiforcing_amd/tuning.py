@@ -36,3 +36,14 @@ def enable_tuned_gemms(csv: Path = CSV) -> bool:
         except Exception:
             pass
         return False
+
+
+def grid_alignment(num_prompts: int, tuned: bool = True):
+    """(t_align, logit_align) that keep the GEMM row counts of a P-prompt Jacobi forward on the tuned grid (multiples of 64):
+    the forward has Rtot x Tpad rows with Rtot >= P, lm_head one row per draft-carrying position.  Off the grid the library's
+    default heuristics are 1.1-1.3x slower — at ONE prompt a forward of 32-56 rows takes 6.4 ms against 5.7 ms at 64 rows
+    (profiles/batch1_r03.txt)."""
+    if not tuned:
+        return 1, 1
+    P = max(int(num_prompts), 1)
+    return max(8, 64 // P), max(64, 8 * P)

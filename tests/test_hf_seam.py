@@ -123,6 +123,40 @@ def test_seam_on_qwen2_backend_equals_autoregressive(backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+def test_seam_row_padding_changes_nothing(backend):
+    """Qwen2Backend(t_align=...) pads every forward's rows to the tuned GEMM grid (masked tokens, no logits for them): the
+    multiblock and the single-block function return exactly what they return without padding."""
+    import random
+    with use_backend(backend):
+        dev = device_for(backend)
+        model = tiny_model(dev, seed=23)
+        V = model.cfg.vocab_size
+        out = {}
+        for ta in (1, 24):
+            me = types.SimpleNamespace(jf_backend=hf_seam.Qwen2Backend(model, max_seq_len=320, max_rows=4, max_tokens=64, t_align=ta))
+            n, rng = 16, random.Random(9)
+            prompt = [int(t) for t in np.random.default_rng(4).integers(0, V - 2, size=13)]
+            text = list(prompt)
+            kw = dict(n_token_seq_len=n, K=2, r=0.5, n_gram_pool_size=4, eos_token_id=V - 1, pad_token_id=V - 2, use_cache=True)
+            draft = [rng.choice(text) for _ in range(n)]
+            cache, _, ngram, _ = hf_seam.jacobi_forward_greedy_multiblock(me, torch.tensor([prompt + draft], device=dev),
+                                                                          past_key_values=None, prefill_phase=True, **kw)
+            inp, got = ngram, []
+            for _ in range(3):
+                cache, first, acc, iters = hf_seam.jacobi_forward_greedy_multiblock(me, inp, past_key_values=cache, prefill_phase=False, **kw)
+                got.append((acc[0].cpu().tolist(), int(iters), cache.get_seq_length()))
+                text += acc[0].cpu().tolist()
+                inp = torch.cat([first.view(1, 1), torch.tensor([[rng.choice(text) for _ in range(n - 1)]], device=dev)], dim=-1)
+            cache2, _, ng2, _ = hf_seam.jacobi_forward_greedy(me, input_ids=torch.tensor([prompt + draft], device=dev), past_key_values=None,
+                                                              use_cache=True, prefill_phase=True, n_token_seq_len=n, eos_token_id=V - 1)
+            c2, f2, a2, it2 = hf_seam.jacobi_forward_greedy(me, input_ids=ng2, past_key_values=cache2, use_cache=True, prefill_phase=False,
+                                                            n_token_seq_len=n, eos_token_id=V - 1)
+            got.append((a2[0].cpu().tolist(), int(it2), c2.get_seq_length()))
+            out[ta] = got
+        assert out[1] == out[24]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_seam_prefill_longer_than_the_candidate_scratch(backend):
     """max_tokens sizes the candidate scratch rows only: a one-row forward (the prefill of prompt + draft, every single-block
     forward) may be as long as the cache row.  A 70-token prompt with max_tokens = 32 must prefill and decode."""
