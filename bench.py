@@ -237,9 +237,9 @@ def single_block_section(model, cfg, tuned: bool = True, n: int = 16, prompt_len
     import types
     from jacobiforcing_amd.drivers.sb_math500 import decode_one
     from jacobiforcing_amd.hf_seam import Qwen2Backend
-    from jacobiforcing_amd.tuning import grid_alignment
+    from jacobiforcing_amd.tuning import SMALL_ROW_ALIGN
     me = types.SimpleNamespace(jf_backend=Qwen2Backend(model, max_seq_len=prompt_len + new_tokens + 8 * n + 64, max_rows=1, max_tokens=n,
-                                                        t_align=grid_alignment(1, tuned)[0]))
+                                                        t_align=SMALL_ROW_ALIGN if tuned else 1))
     rng = random.Random(1234)
     prompt = [rng.randrange(min(151643, cfg.vocab_size - 2)) for _ in range(prompt_len)]
     eos = cfg.vocab_size - 1                               # an id the synthetic prompts never contain

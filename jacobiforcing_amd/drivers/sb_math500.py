@@ -115,14 +115,14 @@ def main(argv=None):
         cfg = Qwen2Config.qwen2_5_coder_7b()
         w = Qwen2Weights(cfg, dev)
     model = Qwen2Model(cfg, w)
-    from ..tuning import enable_tuned_gemms, grid_alignment
+    from ..tuning import enable_tuned_gemms, SMALL_ROW_ALIGN
     tuned = dev.type == "cuda" and not args.no_tuned_gemms and enable_tuned_gemms()   # rows then stay on the tuned M grid
     rng = random.Random(args.seed)
     rows = []
     for idx, (task, prompt) in enumerate(load_prompts(args, cfg)):
         me = types.SimpleNamespace(jf_backend=Qwen2Backend(model, max_seq_len=len(prompt) + args.max_new_tokens + 4 * args.n + 72,
                                                            max_rows=1, max_tokens=len(prompt) + args.n + 8,
-                                                           t_align=grid_alignment(1, tuned)[0]))
+                                                           t_align=SMALL_ROW_ALIGN if tuned else 1))
         r, _ = decode_one(me, prompt, args.n, cfg.eos_token_id, getattr(cfg, "alt_eos_token_id", None), args.max_new_tokens,
                           args.max_calls, rng)
         rows.append(dict(index=idx, task_id=task, **r))

@@ -60,15 +60,17 @@ class Qwen2Backend:
         idx = None
         if Tp != T:
             rows = torch.nn.functional.pad(rows, (0, Tp - T))
-            idx = self._idx.get((B, T, Tp))
-            if idx is None:
-                idx = self._idx[(B, T, Tp)] = (torch.arange(B, dtype=torch.int32, device=dev).view(B, 1) * Tp +
-                                               torch.arange(T, dtype=torch.int32, device=dev).view(1, T)).reshape(-1)
+            if B > 1:                                   # one row: lm_head runs on all Tp rows (on the grid) and the prefix is returned
+                idx = self._idx.get((B, T, Tp))
+                if idx is None:
+                    idx = self._idx[(B, T, Tp)] = (torch.arange(B, dtype=torch.int32, device=dev).view(B, 1) * Tp +
+                                                   torch.arange(T, dtype=torch.int32, device=dev).view(1, T)).reshape(-1)
         pos = (kv + torch.arange(Tp, dtype=torch.int32, device=dev)).view(1, Tp).expand(B, Tp).contiguous()
         z = torch.zeros(B, dtype=torch.int32, device=dev)
         cand = torch.arange(-1, B - 1, dtype=torch.int32, device=dev)
-        return self.model.forward(rows, pos, cache, row_prompt=z, row_cand=cand, row_len=z + T, kv_len_rows=z + kv,
-                                  any_candidates=B > 1, s_cur=kv + Tp, logit_index=idx)
+        logits = self.model.forward(rows, pos, cache, row_prompt=z, row_cand=cand, row_len=z + T, kv_len_rows=z + kv,
+                                    any_candidates=B > 1, s_cur=kv + Tp, logit_index=idx)
+        return logits[:T] if (Tp != T and B == 1) else logits
 
     def commit(self, cache, src_row: int, dst: int, length: int) -> None:
         d = torch.zeros((1, N.DESC_INTS), dtype=torch.int32)

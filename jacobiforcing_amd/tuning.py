@@ -1,6 +1,7 @@
 """GEMM solution selection for the decode shapes (stock PyTorch-ROCm TunableOp).
 
-``tunableop_mi355x.csv`` holds, for Qwen2.5-7B's five projection shapes at M = 64..512 rows (multiples of 64), which
+``tunableop_mi355x.csv`` holds, for Qwen2.5-7B's five projection shapes at M = 8..56 (multiples of 8, round 3: the single-block
+and batch-1 shapes), 64..512 (multiples of 64) and 1024..4096 rows, which
 hipBLASLt / rocBLAS solution was fastest on an MI355X (produced by ``tools/tune_gemms.py``).  At the skinny M of Jacobi
 decoding the default heuristics run these weight-streaming GEMMs at ~30 % of HBM bandwidth; the tuned picks are ~1.4x faster.
 Nothing here touches the loop body; it only tells PyTorch which library kernel to call."""
@@ -47,3 +48,6 @@ def grid_alignment(num_prompts: int, tuned: bool = True):
         return 1, 1
     P = max(int(num_prompts), 1)
     return max(8, 64 // P), max(64, 8 * P)
+
+
+SMALL_ROW_ALIGN = 8      # forwards of fewer than 64 rows (single-block drafts, L <= 16): the table has every multiple of 8
