@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define JF_VERSION 300
+#define JF_VERSION 310
 
 enum {
     JF_OK = 0,
@@ -165,20 +165,23 @@ JF_API int jf_mb_step(int32_t *states, int64_t state_ints, int P, uint64_t *pack
 
 /* jf_argmax_scatter / jf_argmax_partial + jf_mb_step as ONE launch: the argmax items of the whole forward and one
  * "stepper" workgroup per prompt that pre-loads the prompt's live state into LDS while the logits stream, waits for its
- * own rows only (per-prompt arrival counter) and runs the loop body on LDS — a prompt's state machine overlaps the
- * other prompts' streaming and there is no dependent launch.  Same results as the two calls.
+ * own rows only and runs the loop body on LDS — a prompt's state machine overlaps the other prompts' streaming and there
+ * is no dependent launch.  Same results as the two calls.
  *   logits [R, V] (rows follow valid_index when out_index is given, else the Rtot x Tpad rectangle of jf_mb_pack),
- *   row_prompt [Rtot] as written by jf_mb_pack, Tpad as passed to jf_mb_pack,
- *   arrive [P * 64] int32 (one 256-byte line per prompt): zero on entry (one torch.zeros at start-up); the call
- *   leaves it zero,
+ *   Tpad as passed to jf_mb_pack,
+ *   packed: zero on entry, left zero.  packed_len = Rtot * Tpad (positions of the forward), packed_cap = entries the
+ *   buffer holds (>= packed_len).  Inside this launch every (position, chunk of the vocabulary) item owns the slot
+ *   packed[chunk * packed_len + position] and its non-zero result word is its own arrival flag (no counters, nothing to
+ *   order); rows are split into at most packed_cap / packed_len chunks, so give small forwards room for ~16 chunks
+ *   (JF_MB_PACKED_ENTRIES) — with packed_cap == packed_len a row is one item,
  *   params: the jf_mb_params the states were begun with.
  * Rows that are not 16-byte aligned, or more prompts than half of the workgroups the device keeps resident of this kernel
  * (waiting steppers must never be able to fill the chip; 640 on an MI355X), fall back to the two launches.  A stepper that waits longer than 2 s for its rows
  * reports JF_E_LAUNCH in its descriptor instead of hanging the GPU. */
+#define JF_MB_PACKED_ENTRIES(positions) ((int64_t)(positions) + 65536)   /* a capacity that never limits the chunking of small forwards much */
 JF_API int jf_mb_verify(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, const int32_t *out_index,
-                 int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len, int32_t Tpad,
-                 const int32_t *row_prompt, int32_t *arrive, jf_mb_desc *desc, const jf_mb_params *params,
-                 void *stream);
+                 int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len, int64_t packed_cap,
+                 int32_t Tpad, jf_mb_desc *desc, const jf_mb_params *params, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The loop around the step (jf_mb_loop_*): everything between two forwards without a host round trip on the critical
@@ -231,8 +234,7 @@ enum { JF_STOP_NONE = 0, JF_STOP_EOS = 1, JF_STOP_MAX_NEW_TOKENS = 2, JF_STOP_MA
 typedef struct jf_mb_loop {
     /* the state machines (same objects as jf_mb_begin / jf_mb_step / jf_mb_verify take) */
     int32_t *states; int64_t state_ints; int32_t P; int32_t order;   /* order: row order of the pack step, 0 prompt-major, 1 row 0 of every prompt first */
-    uint64_t *packed; int64_t packed_cap;        /* argmax workspace, zero; capacity in entries                  */
-    int32_t *arrive;                              /* [P * 64] zero (jf_mb_verify)                                 */
+    uint64_t *packed; int64_t packed_cap;        /* argmax workspace, zero; capacity in entries (jf_mb_verify: room for chunk slots) */
     jf_mb_desc *desc;                             /* [P]                                                          */
     /* forward inputs, written by the pack step: capacity rows_cap x t_cap tokens                                  */
     int64_t *input_ids; int32_t *positions; int32_t *row_prompt; int32_t *row_len;

@@ -38,7 +38,7 @@ DESC_FIELDS = [f[0] for f in MbDesc._fields_]
 class MbLoop(C.Structure):
     """jf_mb_loop (include/jacobiforcing.h): the pointers of the loop around the step, filled once."""
     _fields_ = [("states", C.c_void_p), ("state_ints", C.c_int64), ("P", C.c_int32), ("order", C.c_int32),
-                ("packed", C.c_void_p), ("packed_cap", C.c_int64), ("arrive", C.c_void_p), ("desc", C.c_void_p),
+                ("packed", C.c_void_p), ("packed_cap", C.c_int64), ("desc", C.c_void_p),
                 ("input_ids", C.c_void_p), ("positions", C.c_void_p), ("row_prompt", C.c_void_p), ("row_len", C.c_void_p),
                 ("row_cand", C.c_void_p), ("row_kv_len", C.c_void_p), ("valid_index", C.c_void_p),
                 ("rows_cap", C.c_int32), ("t_cap", C.c_int32), ("t_align", C.c_int32), ("valid_align", C.c_int32),
@@ -51,6 +51,7 @@ class MbLoop(C.Structure):
 # mailbox header slots / per-prompt driver record / driver block header (include/jacobiforcing.h)
 MB_SEQ, MB_RTOT, MB_RMAIN, MB_TPAD, MB_TMAX, MB_NVALID, MB_NVALID_PAD, MB_NDONE, MB_MAXKV, MB_ERROR, MB_ACCEPTED, MB_NCALL_END = range(12)
 MB_MAILBOX_HDR, MB_FIN_INTS = 16, 8
+MB_PACKED_EXTRA = 65536            # JF_MB_PACKED_ENTRIES(positions) - positions: room for jf_mb_verify's per-chunk result slots
 FIN_FIELDS = ["stop", "calls", "iters_total", "new_tokens", "ret_len", "next_token", "iters", "text_off"]
 DRV_FIELDS = ["active", "stop", "calls", "iters_total", "new_tokens", "budget", "max_calls", "text_len", "cursor", "fin_ret_len",
               "fin_next", "fin_iters", "fin_off"]
@@ -109,7 +110,7 @@ _SIGNATURES = {
     "jf_mb_begin": (C.c_int, [_vp, _i64, C.c_int, C.POINTER(MbParams), _vp, _vp, _vp, _vp]),
     "jf_mb_pack": (C.c_int, [_vp, _i64, C.c_int, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "jf_mb_step": (C.c_int, [_vp, _i64, C.c_int, _vp, _i64, _vp, _vp]),
-    "jf_mb_verify": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _vp, _vp, _i64, C.c_int, _vp, _i64, _i32, _vp, _vp, _vp,
+    "jf_mb_verify": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _vp, _vp, _i64, C.c_int, _vp, _i64, _i64, _i32, _vp,
                                C.POINTER(MbParams), _vp]),
     "jf_mb_read_ret": (C.c_int, [_vp, _i64, C.c_int, _vp, _i32, _vp]),
     "jf_mb_set_fast_path": (C.c_int, [C.c_int]),

@@ -59,7 +59,7 @@ static int64_t pick_chunk(int64_t gran, int64_t R, int64_t V, int64_t target_ite
 // 256..1024 items) are 5-20 % faster.  Non-temporal loads from 60 MB up, plain loads below.
 // Inside the fused verify launch (jf_mb_verify) the 4-wave workgroups win at every size (340 MB in the bench: 69 us against
 // 72.5 us per-wavefront, flat from 512 to 3072 items, profiles/verify_knobs_r02.txt): one arrival per workgroup, not four.
-int argmax_plan(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, bool fused, ArgmaxPlan *pl) {
+int argmax_plan(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, bool fused, ArgmaxPlan *pl, int64_t max_cpr) {
     const int esz = dtype == JF_F32 ? 4 : 2;
     const int epv = 16 / esz;
     const ArgmaxTune &tn = argmax_tune();
@@ -90,6 +90,7 @@ int argmax_plan(const void *logits, int dtype, int64_t R, int64_t V, int64_t row
         }
         pl->chunk = pick_chunk(64 * epv, R, V, items_target);
         pl->cpr = (V + pl->chunk - 1) / pl->chunk;
+        if (max_cpr > 0 && pl->cpr > max_cpr) { pl->chunk = pick_chunk(64 * epv, R, V, R * max_cpr); pl->cpr = (V + pl->chunk - 1) / pl->chunk; }
         pl->items = R * pl->cpr;
         pl->blocks = (pl->items + (AM_TPB / 64) - 1) / (AM_TPB / 64);
     } else {
@@ -98,6 +99,7 @@ int argmax_plan(const void *logits, int dtype, int64_t R, int64_t V, int64_t row
         if (wg_items > 1024) wg_items = 1024;
         pl->chunk = pick_chunk((int64_t)AM_TPB * epv, R, V, tn.items > 0 ? tn.items : wg_items);
         pl->cpr = (V + pl->chunk - 1) / pl->chunk;
+        if (max_cpr > 0 && pl->cpr > max_cpr) { pl->chunk = pick_chunk((int64_t)AM_TPB * epv, R, V, R * max_cpr); pl->cpr = (V + pl->chunk - 1) / pl->chunk; }
         pl->items = R * pl->cpr;
         pl->blocks = pl->items;
     }
@@ -117,7 +119,7 @@ static int argmax_launch(const void *logits, int dtype, int64_t R, int64_t V, in
     const int rc = argmax_plan(logits, dtype, R, V, row_stride, false, &pl);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const ArgmaxArgs a{logits, R, V, row_stride, (unsigned long long *)packed, (int)pl.cpr, pl.chunk, out_index, pl.reverse};
+    const ArgmaxArgs a{logits, R, V, row_stride, (unsigned long long *)packed, (int)pl.cpr, pl.chunk, out_index, pl.reverse, 0};
     const dim3 grid((unsigned)pl.blocks), block(AM_TPB);
     if (pl.wave_mode) {
         if (dtype == JF_F32) { if (pl.nt) argmax_wave_kernel<JF_F32, true><<<grid, block, 0, s>>>(a); else argmax_wave_kernel<JF_F32, false><<<grid, block, 0, s>>>(a); }

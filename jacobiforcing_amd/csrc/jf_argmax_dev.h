@@ -22,13 +22,20 @@ struct ArgmaxArgs {
     int64_t chunk_elems;
     const int32_t *out_index;      // nullable: row i -> packed[out_index[i]], negative = skip the row unread
     int32_t reverse;               // item order: 0 rows first to last, 1 last to first, 2 chunk-major (see argmax_wg_item)
+    int64_t slot_stride;           // 0: chunks of a row meet in packed[orow] (atomicMax).  > 0 (fused verify launch): every
+                                   // (row, chunk) item owns packed[chunk * slot_stride + orow] and stores its result there —
+                                   // a non-zero slot IS the arrival (every real key is >= 0x007FFFFF), nothing to wait for
 };
+
+__device__ __forceinline__ void am_publish(const ArgmaxArgs &a, int64_t orow, int c, unsigned long long m) {
+    if (a.slot_stride > 0) __hip_atomic_store(a.packed + (int64_t)c * a.slot_stride + orow, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else atomicMax(a.packed + orow, m);
+}
 
 // One (row, chunk) item by a 256-thread workgroup sharing the chunk.  Returns the result slot (orow, -1 = skipped row) to
 // every thread; thread 0 has published the item with atomicMax when the function returns.
 template <int DT, bool VEC, bool NT>
-__device__ __forceinline__ int64_t argmax_wg_item(const ArgmaxArgs &a, int64_t item, const int32_t *row_owner = nullptr,
-                                                  int32_t owner_div = 1, int *owner = nullptr) {
+__device__ __forceinline__ int64_t argmax_wg_item(const ArgmaxArgs &a, int64_t item) {
     using E = Elem<DT>;
     constexpr int EPV = E::EPV;
     constexpr int UNROLL = 8;
@@ -38,7 +45,6 @@ __device__ __forceinline__ int64_t argmax_wg_item(const ArgmaxArgs &a, int64_t i
     // slot of this row's result (jf_argmax_scatter): read up front so its latency hides behind the stream; < 0 = padding row
     const int64_t orow = a.out_index ? (int64_t)a.out_index[row] : row;
     if (orow < 0) return -1;
-    if (row_owner) *owner = row_owner[(int)orow / owner_div];      // fused launch: whose row this is (latency hides behind the stream)
     const int c = (int)(a.reverse == 2 ? item / a.R : item % a.chunks_per_row);
     const int64_t begin = (int64_t)c * a.chunk_elems;
     int64_t end = begin + a.chunk_elems;
@@ -85,7 +91,7 @@ __device__ __forceinline__ int64_t argmax_wg_item(const ArgmaxArgs &a, int64_t i
         uint64_t m = s_part[0];
 #pragma unroll
         for (int w = 1; w < AM_TPB / 64; ++w) m = s_part[w] > m ? s_part[w] : m;
-        atomicMax(a.packed + orow, (unsigned long long)m);
+        am_publish(a, orow, c, (unsigned long long)m);
     }
     return orow;
 }
@@ -93,8 +99,7 @@ __device__ __forceinline__ int64_t argmax_wg_item(const ArgmaxArgs &a, int64_t i
 // Wave-independent variant: every wavefront owns one (row, chunk) item end to end — no LDS, no workgroup barrier; the NaN
 // vote is a ballot, the reduction six shuffles, the publish one atomicMax per wavefront (lane 0).  Returns orow or -1.
 template <int DT, bool NT>
-__device__ __forceinline__ int64_t argmax_wave_item(const ArgmaxArgs &a, int64_t item, const int32_t *row_owner = nullptr,
-                                                    int32_t owner_div = 1, int *owner = nullptr) {
+__device__ __forceinline__ int64_t argmax_wave_item(const ArgmaxArgs &a, int64_t item) {
     using E = Elem<DT>;
     constexpr int EPV = E::EPV;
     constexpr int UNROLL = 8;
@@ -103,7 +108,6 @@ __device__ __forceinline__ int64_t argmax_wave_item(const ArgmaxArgs &a, int64_t
     const int64_t row = a.reverse == 2 ? item % a.R : (a.reverse ? a.R - 1 - item / a.chunks_per_row : item / a.chunks_per_row);
     const int64_t orow = a.out_index ? (int64_t)a.out_index[row] : row;
     if (orow < 0) return -1;
-    if (row_owner) *owner = row_owner[(int)orow / owner_div];
     const int c = (int)(a.reverse == 2 ? item / a.R : item % a.chunks_per_row);
     const int64_t begin = (int64_t)c * a.chunk_elems;
     int64_t end = begin + a.chunk_elems;
@@ -142,7 +146,7 @@ __device__ __forceinline__ int64_t argmax_wave_item(const ArgmaxArgs &a, int64_t
         if (kk > best) { best = kk; bidx = (uint32_t)j; }
     }
     uint64_t pk = wave_max_u64(((uint64_t)best << 32) | (uint64_t)(~bidx));
-    if (lane == 0) atomicMax(a.packed + orow, (unsigned long long)pk);
+    if (lane == 0) am_publish(a, orow, c, (unsigned long long)pk);
     return orow;
 }
 
@@ -152,6 +156,7 @@ struct ArgmaxPlan {
     int reverse;                   // item order: 0 rows first to last, 1 last to first, 2 chunk-major (JF_ARGMAX_REVERSE)
     int64_t chunk, cpr, items, blocks;
 };
-int argmax_plan(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, bool fused, ArgmaxPlan *plan);   // jf_argmax.hip
+int argmax_plan(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, bool fused, ArgmaxPlan *plan,
+                int64_t max_cpr = 0);   // jf_argmax.hip; max_cpr > 0: at most that many chunks per row
 
 #endif  // JF_ARGMAX_DEV_H

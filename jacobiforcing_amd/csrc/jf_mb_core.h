@@ -1077,25 +1077,34 @@ JF_HD bool state_to_compact(Lanes lanes, const int32_t *G, const Layout &LG, int
 }
 
 // Write a stepped compact image back: header + spans, every listed block, the live pool entries, the next forward's rows,
-// and ret when the call ended.
+// and ret when the call ended.  ONE flat loop over all of it: the regions are a handful of short copies, and as separate
+// loops each costs a dependent LDS-load -> store round per trip (1.6 us for ~1 100 ints on 192 lanes); flat, a lane has
+// five or six independent element copies in flight (profiles/verify_trace_r03.txt).
 template <class Lanes>
 JF_HD void compact_to_state(Lanes lanes, const int32_t *C, const Layout &LC, int32_t *G, const Layout &LG) {
     const int len_lists = C[H_LEN_LISTS], nsp = C[H_NSPANS], pool_count = C[H_POOL_COUNT], pool_head = C[H_POOL_HEAD];
     const int B = C[H_B], T = C[H_T];
-    for (int i = lanes.lane(); i < H_SPANS + 3 * nsp; i += lanes.count()) G[i] = C[i];
-    for (int i = lanes.lane(); i < len_lists * LG.blk_stride; i += lanes.count()) G[LG.off_blocks + i] = C[LC.off_blocks + i];
-    for (int k = 0; k < pool_count; ++k) {
-        const int slot = wrap(pool_head + k, LG.pool_size);
-        const int32_t *c = C + LC.off_pool + slot * (1 + LC.LPOOL);
-        int32_t *e = G + LG.off_pool + slot * (1 + LG.LPOOL);
-        const int len = c[0];
-        for (int i = lanes.lane(); i < 1 + len; i += lanes.count()) e[i] = c[i];
-    }
-    for (int r = 0; r < B; ++r)
-        for (int i = lanes.lane(); i < T; i += lanes.count()) G[LG.off_out + r * LG.TMAX + i] = C[LC.off_out + r * LC.TMAX + i];
-    if (C[H_DONE]) {
-        const int rl = C[H_RET_LEN];
-        for (int i = lanes.lane(); i < rl; i += lanes.count()) G[LG.off_ret + i] = C[LC.off_ret + i];
+    int pool_w = 0;                                              // widest live pool entry (its length word included)
+    for (int k = 0; k < pool_count; ++k) pool_w = imax(pool_w, 1 + C[LC.off_pool + wrap(pool_head + k, LG.pool_size) * (1 + LC.LPOOL)]);
+    const int n0 = H_SPANS + 3 * nsp;                            // header + spans: same offsets in both layouts
+    const int n1 = n0 + len_lists * LG.blk_stride;               // listed blocks (blk_stride depends on n and RMAX only)
+    const int n2 = n1 + pool_count * pool_w;                     // live pool entries, pool_w columns each
+    const int n3 = n2 + B * T;                                   // rows of the next forward
+    const int n4 = n3 + (C[H_DONE] ? C[H_RET_LEN] : 0);          // ret of a call that ended
+    for (int i = lanes.lane(); i < n4; i += lanes.count()) {
+        int src, dst;
+        if (i < n0) { src = i; dst = i; }
+        else if (i < n1) { src = LC.off_blocks + (i - n0); dst = LG.off_blocks + (i - n0); }
+        else if (i < n2) {
+            const int j = i - n1, k = j / pool_w, e = j - k * pool_w, slot = wrap(pool_head + k, LG.pool_size);
+            src = LC.off_pool + slot * (1 + LC.LPOOL) + e;
+            if (e > C[LC.off_pool + slot * (1 + LC.LPOOL)]) continue;          // beyond this entry's tokens
+            dst = LG.off_pool + slot * (1 + LG.LPOOL) + e;
+        } else if (i < n3) {
+            const int j = i - n2, r = j / T, t = j - r * T;
+            src = LC.off_out + r * LC.TMAX + t; dst = LG.off_out + r * LG.TMAX + t;
+        } else { src = LC.off_ret + (i - n3); dst = LG.off_ret + (i - n3); }
+        G[dst] = C[src];
     }
 }
 

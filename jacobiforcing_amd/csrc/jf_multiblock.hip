@@ -124,17 +124,20 @@ extern "C" int jf_mb_read_ret(const int32_t *states, int64_t state_ints, int P, 
 //
 //   workgroups [0, P)        one STEPPER per prompt.  While the logits stream, its 256 threads copy the live part of the
 //                            prompt's state block into a compact LDS image (same Machine, smaller Layout); then wavefront 0
-//                            waits for the prompt's arrival count, pulls the prompt's argmax results (8-byte agent-scope
-//                            loads) into LDS, runs Machine::step entirely on LDS, and writes the image + descriptor back.
+//                            polls the prompt's argmax result slots (8-byte agent-scope loads) into LDS until all have
+//                            arrived, runs Machine::step entirely on LDS, and writes the image + descriptor back.
 //                            A step that does not fit the compact capacities (runaway block lists, Q3/Q4) is redone on
 //                            the HBM block: nothing was written before that, so the result is the same.
-//   workgroups [P, ...)      the argmax items of jf_argmax_scatter / _partial (jf_argmax_dev.h).  After its atomicMax a
-//                            publishing lane drains its memory counter and adds 1 to arrive[prompt of the row].
+//   workgroups [P, ...)      the argmax items of jf_argmax_scatter / _partial (jf_argmax_dev.h).  Every (row, chunk) item owns
+//                            one result slot, packed[chunk * Rtot*Tpad + position], and stores its (key, ~index) word there.
 //
-// Hand-off (cdna_hip_programming.md, Guideline 16, "8-byte agent atomics both sides"): payload = device-scope atomicMax
-// on packed[], s_waitcnt vmcnt(0), relaxed agent-scope add on the counter; the stepper polls the counter with relaxed
-// agent-scope loads (s_sleep between polls, bounded by a wall-clock limit) and reads packed[] with agent-scope loads.
-// arrive[] must be zero on entry; every stepper resets its word, so the call leaves it zero.
+// Hand-off: the result word is its own arrival flag.  The slots are zero on entry, every real key is >= 0x007FFFFF, so a
+// non-zero slot has arrived; payload and flag being ONE 8-byte agent-scope store there is nothing to order — the item does
+// not drain its memory counter, adds to no counter and ends with the store in flight (round 2/3a: atomicMax, s_waitcnt
+// vmcnt(0), add on a per-prompt counter, and a gather after the count was seen: ~3 us more behind the last row,
+// profiles/verify_slots_ab_r03.txt).  The stepper's wavefront 0 polls the slots of its own positions (agent-scope loads,
+// s_sleep between rounds, bounded by a wall-clock limit), keeps the maximum over a position's chunks — the poll is the
+// gather — and wavefronts 1-3 re-zero the slots after the step, so the call leaves packed[] zero.
 // Steppers only WAIT for item workgroups and never the other way round, and they are the lowest block ids (dispatched
 // first), so an item workgroup can always be scheduled: no residency assumption, no deadlock.
 // ------------------------------------------------------------------------------------------------
@@ -143,9 +146,7 @@ struct VerifyArgs {
     int32_t *states;
     int64_t state_ints;
     int P;
-    int64_t packed_len;
-    const int32_t *row_prompt;     // [Rtot] prompt of every forward row (jf_mb_pack)
-    int32_t *arrive;               // [P]
+    int64_t packed_len;            // Rtot * Tpad: positions of the forward = slots per chunk
     jf_mb_desc *desc;
     int32_t Tpad;
     int32_t compacted;             // 1: logits rows follow valid_index (B*T per prompt); 0: the Rtot x Tpad rectangle
@@ -197,23 +198,8 @@ __device__ __forceinline__ unsigned long long ld_agent_u64(const unsigned long l
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-constexpr int VERIFY_ARRIVE_STRIDE = 64;                         // ints between two prompts' arrival words: one 256-byte line each,
-                                                                 // so polls and arrivals of different prompts use different channels
 constexpr int VERIFY_LDS_HDR = 32;                               // ints in front of the compact image (descriptor + flags)
 constexpr unsigned long long VERIFY_WAIT_TICKS = 200000000ull;   // 2 s of the 100 MHz constant clock: never hang the GPU
-
-__device__ __forceinline__ void verify_arrive(const VerifyArgs &a, int owner) {
-    // The payload is itself an agent-scope atomic RMW (atomicMax on packed[]): it is performed at the coherence point, and the
-    // wait below keeps the count from moving before it has been.  A RELEASE on the add instead would have every item write
-    // back its XCD's L2 (buffer_wbl2): 131 us instead of 70 us per launch at 64 prompts (profiles/verify_release_ab_r03.txt).
-    // The consumer side does carry an acquire (one buffer_inv per stepper, free).
-#ifdef JF_EXP_ARRIVE_RELEASE
-    __hip_atomic_fetch_add(a.arrive + (int64_t)owner * VERIFY_ARRIVE_STRIDE, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_fetch_add(a.arrive + (int64_t)owner * VERIFY_ARRIVE_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-}
 
 __device__ __forceinline__ void verify_stepper(const VerifyArgs &a, int p, int32_t *smem) {   // one call site; as a real call the whole launch pays its register budget
     using namespace jfmb;
@@ -245,20 +231,38 @@ __device__ __forceinline__ void verify_stepper(const VerifyArgs &a, int p, int32
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         int32_t *gtok = img + LC.total;                          // [B, T] greedy tokens (LDS) when use_lds
-        // ---- wait for this prompt's rows -----------------------------------------------------------
-        const int expected = (a.compacted ? ng : B * (int)rows.tpad) * a.am.chunks_per_row;
+        // ---- wait for this prompt's rows: poll their result slots; the poll is the gather -------------------------
+        // compacted logits: the B*T draft-carrying positions have items; the rectangle: all B*Tpad (their slots must all
+        // have been written before the re-zero below, also the ones nobody reads)
+        const int tw = a.compacted ? T : (int)rows.tpad, nw = B * tw, cpr = a.am.chunks_per_row;
+        const unsigned long long *pk = (const unsigned long long *)rows.pk;
         bool timed_out = false;
-        if (expected > 0) {
+        if (nw > 0) {
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             unsigned spins = 0;
-            int32_t *word = a.arrive + (int64_t)p * VERIFY_ARRIVE_STRIDE;
-            while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
-                __builtin_amdgcn_s_sleep(20);                    // ~0.6 us between polls: pollers must not load the memory system
+            for (;;) {
+                bool miss = false;
+                for (int i = lane; i < nw; i += 64) {
+                    const int r = i / tw, t = i - r * tw;
+                    const int64_t idx = rows.index(r, t);
+                    int tok = -1;
+                    if (idx >= 0 && idx < rows.plen) {
+                        unsigned long long mx = 0ull;
+                        bool zero = false;
+                        for (int c = 0; c < cpr; ++c) {
+                            const unsigned long long v = ld_agent_u64(pk + (int64_t)c * a.am.slot_stride + idx);
+                            zero |= v == 0ull;
+                            mx = v > mx ? v : mx;
+                        }
+                        if (zero) { miss = true; continue; }
+                        tok = decode_packed(mx);
+                    }
+                    if (use_lds && t < T) gtok[r * T + t] = tok;
+                }
+                if (__ballot(miss) == 0ull) break;
+                __builtin_amdgcn_s_sleep(8);                     // ~0.2 us between rounds: pollers must not load the memory system
                 if ((++spins & 255u) == 0u && __builtin_amdgcn_s_memrealtime() - t0 > VERIFY_WAIT_TICKS) { timed_out = true; break; }
             }
-            // the items released their atomicMax before the count moved (verify_arrive); acquire it before reading packed[]
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if (lane == 0) __hip_atomic_store(word, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
         }
         JF_VSTAMP(p, 2);
         int wb = 0;                                              // 1: stepped on the image, all four wavefronts write it back
@@ -266,12 +270,18 @@ __device__ __forceinline__ void verify_stepper(const VerifyArgs &a, int p, int32
             if (lane == 0) { G[H_ERR] = JF_E_LAUNCH; G[H_DONE] = 1; if (dg) { dg->error = JF_E_LAUNCH; dg->done = 1; dg->B = 0; dg->T = 0; } }
             wb = -1;
         } else {
-            auto Gglobal = [rows](int r, int t) -> int {
+            const int64_t cstride = a.am.slot_stride;
+            auto Gglobal = [rows, cpr, cstride](int r, int t) -> int {
                 const int64_t idx = rows.index(r, t);
-                return (idx >= 0 && idx < rows.plen) ? decode_packed(ld_agent_u64((const unsigned long long *)rows.pk + idx)) : -1;
+                if (idx < 0 || idx >= rows.plen) return -1;
+                unsigned long long mx = 0ull;
+                for (int c = 0; c < cpr; ++c) {
+                    const unsigned long long v = ld_agent_u64((const unsigned long long *)rows.pk + (int64_t)c * cstride + idx);
+                    mx = v > mx ? v : mx;
+                }
+                return decode_packed(mx);
             };
             if (use_lds) {
-                for (int i = lane; i < ng; i += 64) gtok[i] = Gglobal(i / T, i - (i / T) * T);
                 SoloWaveLanes{}.sync();
                 JF_VSTAMP(p, 3);
                 Machine<SoloWaveLanes> m(img, SoloWaveLanes{}, LC);
@@ -305,10 +315,12 @@ __device__ __forceinline__ void verify_stepper(const VerifyArgs &a, int p, int32
         if (wb > 0) compact_to_state(Lanes192{}, img, LC, G, LG);
         JF_VSTAMP(p, 5);
         if (wb >= 0) {
-            for (int r = 0; r < B; ++r) {
-                const int64_t lo = rows.index(r, 0), hi = lo + rows.tpad;
-                for (int64_t i = lo + (threadIdx.x - 64); i < hi && i < a.packed_len; i += AM_TPB - 64) a.am.packed[i] = 0ull;
-            }
+            for (int c = 0; c < a.am.chunks_per_row; ++c)
+                for (int r = 0; r < B; ++r) {
+                    const int64_t lo = rows.index(r, 0), hi = lo + rows.tpad;
+                    for (int64_t i = lo + (threadIdx.x - 64); i < hi && i < a.packed_len; i += AM_TPB - 64)
+                        a.am.packed[(int64_t)c * a.am.slot_stride + i] = 0ull;
+                }
         }
         return;
     }
@@ -335,14 +347,8 @@ __global__ __launch_bounds__(AM_TPB) void mb_verify_kernel(VerifyArgs a) {
 #ifdef JF_EXP_VERIFY_TRACE
     if (threadIdx.x == 0 && blk < 8192) g_vitems[2 * blk] = __builtin_amdgcn_s_memrealtime();
 #endif
-    int owner = -1;                                              // prompt of this item's row: looked up while the row streams
-    if constexpr (WAVE) {
-        const int64_t orow = argmax_wave_item<DT, NT>(a.am, blk * (AM_TPB / 64) + (threadIdx.x >> 6), a.row_prompt, a.Tpad, &owner);
-        if ((threadIdx.x & 63) == 0 && orow >= 0) verify_arrive(a, owner);
-    } else {
-        const int64_t orow = argmax_wg_item<DT, true, NT>(a.am, blk, a.row_prompt, a.Tpad, &owner);
-        if (threadIdx.x == 0 && orow >= 0) verify_arrive(a, owner);
-    }
+    if constexpr (WAVE) (void)argmax_wave_item<DT, NT>(a.am, blk * (AM_TPB / 64) + (threadIdx.x >> 6));
+    else (void)argmax_wg_item<DT, true, NT>(a.am, blk);
 #ifdef JF_EXP_VERIFY_TRACE
     if (threadIdx.x == 0 && blk < 8192) g_vitems[2 * blk + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -371,19 +377,21 @@ static int verify_stepper_cap(const void *kern, int variant, size_t shm) {
 }
 
 static int verify_launch(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, const int32_t *out_index,
-                         int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len, int32_t Tpad,
-                         const int32_t *row_prompt, int32_t *arrive, jf_mb_desc *desc, const jf_mb_params *params,
+                         int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len, int64_t packed_cap,
+                         int32_t Tpad, jf_mb_desc *desc, const jf_mb_params *params,
                          const jfmb::LoopDev *lp, void *stream, const char *who, int *fused_out = nullptr) {
     if (fused_out) *fused_out = 0;
     if (P <= 0) return JF_OK;
     int rc = check_params(params, who);
     if (rc) return rc;
-    if (!logits || !states || !packed || !row_prompt || !arrive || R <= 0 || Tpad <= 0)
+    if (!logits || !states || !packed || R <= 0 || Tpad <= 0)
         return fail(JF_E_INVALID, "%s: null pointer or empty forward", who);
+    if (packed_len <= 0 || packed_cap < packed_len)
+        return fail(JF_E_INVALID, "%s: packed holds %lld entries, the forward has %lld positions", who, (long long)packed_cap, (long long)packed_len);
     if (dtype != JF_F32 && dtype != JF_BF16) return fail(JF_E_INVALID, "%s: dtype %d", who, dtype);
     if (V <= 0 || row_stride < V || V > 0x7FFFFFFFll) return fail(JF_E_INVALID, "%s: bad shape V=%lld stride=%lld", who, (long long)V, (long long)row_stride);
     ArgmaxPlan pl;
-    rc = argmax_plan(logits, dtype, R, V, row_stride, true, &pl);
+    rc = argmax_plan(logits, dtype, R, V, row_stride, true, &pl, packed_cap / packed_len);   // one result slot per (position, chunk)
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     // compact image + greedy tokens of one prompt in LDS; a configuration that needs more than 16 KB steps on HBM instead
@@ -410,7 +418,7 @@ static int verify_launch(const void *logits, int dtype, int64_t R, int64_t V, in
     // workgroups this kernel can keep resident (registers, LDS request, 256 threads: asked of the runtime, not assumed).
     // More prompts than that, or unaligned logits, run the convergence check as its two launches.
     const int cap = pl.vec ? verify_stepper_cap((const void *)kern, variant, shm) : 0;
-    if (!pl.vec || P > cap) {
+    if (!pl.vec || P > cap || pl.cpr * packed_len > packed_cap) {
         rc = out_index ? jf_argmax_scatter(logits, dtype, R, V, row_stride, out_index, packed, stream)
                        : jf_argmax_partial(logits, dtype, R, V, row_stride, packed, stream);
         if (rc) return rc;
@@ -419,9 +427,9 @@ static int verify_launch(const void *logits, int dtype, int64_t R, int64_t V, in
         return check_launch("mb_step_kernel");
     }
     VerifyArgs a;
-    a.am = ArgmaxArgs{logits, R, V, row_stride, (unsigned long long *)packed, (int)pl.cpr, pl.chunk, out_index, pl.reverse};
-    a.states = states; a.state_ints = state_ints; a.P = P; a.packed_len = packed_len; a.row_prompt = row_prompt;
-    a.arrive = arrive; a.desc = desc; a.Tpad = Tpad; a.compacted = out_index ? 1 : 0; a.lds_ints = (int32_t)lds_ints;
+    a.am = ArgmaxArgs{logits, R, V, row_stride, (unsigned long long *)packed, (int)pl.cpr, pl.chunk, out_index, pl.reverse, packed_len};
+    a.states = states; a.state_ints = state_ints; a.P = P; a.packed_len = packed_len;
+    a.desc = desc; a.Tpad = Tpad; a.compacted = out_index ? 1 : 0; a.lds_ints = (int32_t)lds_ints;
     a.has_loop = lp ? 1 : 0;
     a.fast = fast_path();
     a.lp = lp ? *lp : jfmb::LoopDev{};
@@ -434,11 +442,10 @@ static int verify_launch(const void *logits, int dtype, int64_t R, int64_t V, in
 }
 
 extern "C" int jf_mb_verify(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, const int32_t *out_index,
-                            int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len, int32_t Tpad,
-                            const int32_t *row_prompt, int32_t *arrive, jf_mb_desc *desc, const jf_mb_params *params,
-                            void *stream) {
-    return verify_launch(logits, dtype, R, V, row_stride, out_index, states, state_ints, P, packed, packed_len, Tpad, row_prompt,
-                         arrive, desc, params, nullptr, stream, "jf_mb_verify");
+                            int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len, int64_t packed_cap,
+                            int32_t Tpad, jf_mb_desc *desc, const jf_mb_params *params, void *stream) {
+    return verify_launch(logits, dtype, R, V, row_stride, out_index, states, state_ints, P, packed, packed_len, packed_cap, Tpad,
+                         desc, params, nullptr, stream, "jf_mb_verify");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -483,7 +490,7 @@ extern "C" int jf_mailbox_wait(const int32_t *mailbox, int32_t seq, int64_t time
 static int check_loop(const jf_mb_loop *lp, const char *who) {
     if (!lp) return fail(JF_E_INVALID, "%s: null loop", who);
     if (lp->P <= 0) return fail(JF_E_INVALID, "%s: P=%d", who, lp->P);
-    if (!lp->states || !lp->packed || !lp->arrive || !lp->desc || !lp->input_ids || !lp->positions || !lp->row_prompt || !lp->row_len ||
+    if (!lp->states || !lp->packed || !lp->desc || !lp->input_ids || !lp->positions || !lp->row_prompt || !lp->row_len ||
         !lp->row_cand || !lp->row_kv_len || !lp->mailbox)
         return fail(JF_E_INVALID, "%s: null pointer in jf_mb_loop", who);
     if (lp->t_cap <= 0 || lp->rows_cap <= 0) return fail(JF_E_INVALID, "%s: forward buffers have no capacity", who);
@@ -528,7 +535,7 @@ extern "C" int jf_mb_loop_iterate(const jf_mb_loop *loop, int32_t seq, const voi
     int fused = 0;
     if (ev_begin) (void)hipEventRecord((hipEvent_t)ev_begin, (hipStream_t)stream);
     rc = verify_launch(logits, dtype, R, V, row_stride, compacted ? loop->valid_index : nullptr, loop->states, loop->state_ints,
-                       loop->P, loop->packed, (int64_t)Rtot * Tpad, Tpad, loop->row_prompt, loop->arrive, loop->desc, params, &d,
+                       loop->P, loop->packed, (int64_t)Rtot * Tpad, loop->packed_cap, Tpad, loop->desc, params, &d,
                        stream, "jf_mb_loop_iterate", &fused);
     if (ev_end) (void)hipEventRecord((hipEvent_t)ev_end, (hipStream_t)stream);
     if (rc || !queue_pack) return rc;

@@ -167,7 +167,8 @@ class MultiblockBatch:
         pin = dev.type == "cuda"
         self.desc_host = torch.zeros((self.P, N.DESC_INTS), dtype=torch.int32, pin_memory=pin)
         rows = self.P * self.max_rows
-        self.packed = new_packed(rows * self.max_tokens, dev)
+        # one slot per position, plus room for the fused launch's per-chunk slots (JF_MB_PACKED_ENTRIES)
+        self.packed = new_packed(rows * self.max_tokens + N.MB_PACKED_EXTRA, dev)
         self.input_ids = torch.zeros((rows * self.max_tokens,), dtype=torch.int64, device=dev)
         self.positions = torch.zeros((rows * self.max_tokens,), dtype=torch.int32, device=dev)
         self.row_prompt = torch.zeros((rows,), dtype=torch.int32, device=dev)
@@ -179,7 +180,6 @@ class MultiblockBatch:
         self.ret_buf = torch.zeros((self.P, self.ret_cap), dtype=torch.int64, device=dev)
         self.Rtot = 0
         self.Tpad = 0
-        self.arrive = torch.zeros((self.P * 64,), dtype=torch.int32, device=dev)   # jf_mb_verify: one 256-byte counter line per prompt
         # JF_FUSED_VERIFY=0: argmax and state machine as two launches (A/B measurements in tools/)
         self.fused = os.environ.get("JF_FUSED_VERIFY", "1") != "0"
 
@@ -191,7 +191,7 @@ class MultiblockBatch:
         d = self.desc_host.numpy()
         err = d[:, N.DESC_FIELDS.index("error")]
         if err.any():
-            self.arrive.zero_(); self.packed.zero_()    # a launch that reported an error may have left arrival counts / stale keys behind
+            self.packed.zero_()    # a launch that reported an error may have left stale keys behind
             p = int(np.nonzero(err)[0][0])
             N.raise_state_error(int(err[p]), f"multiblock prompt {p} (state-machine line {int(d[p, N.DESC_FIELDS.index('rsv0')])})",
                                 aux=int(d[p, N.DESC_FIELDS.index("rsv1")]))
@@ -273,7 +273,7 @@ class MultiblockBatch:
         VERIFY_HOOK and VERIFY_HOOK[0](self, flat)
         N.check(N.lib().jf_mb_verify(_ptr(flat), _dtype_code(flat), R, V, flat.stride(0) if R > 1 else V, _ptr(out_index),
                                      _ptr(self.states), self.state_ints, self.P, _ptr(self.packed), self.Rtot * self.Tpad,
-                                     self.Tpad, _ptr(self.row_prompt), _ptr(self.arrive), _ptr(self.desc_dev),
+                                     self.packed.numel(), self.Tpad, _ptr(self.desc_dev),
                                      C.byref(self.c_params), _stream(self.device)), "jf_mb_verify")
         VERIFY_HOOK and VERIFY_HOOK[1](self, flat)
         return self._read_desc()
@@ -372,7 +372,7 @@ class MultiblockLoop:
         fill = b.params.pad_token_id if b.params.pad_token_id is not None else 0
         self.c_loop = N.MbLoop(
             states=b.states.data_ptr(), state_ints=b.state_ints, P=b.P, order=int(order),
-            packed=b.packed.data_ptr(), packed_cap=b.packed.numel(), arrive=b.arrive.data_ptr(), desc=b.desc_dev.data_ptr(),
+            packed=b.packed.data_ptr(), packed_cap=b.packed.numel(), desc=b.desc_dev.data_ptr(),
             input_ids=b.input_ids.data_ptr(), positions=b.positions.data_ptr(), row_prompt=b.row_prompt.data_ptr(),
             row_len=b.row_len.data_ptr(), row_cand=self.row_cand.data_ptr(), row_kv_len=self.row_kv.data_ptr(),
             valid_index=b.valid_index_buf.data_ptr() if compact else None,
@@ -450,7 +450,7 @@ class MultiblockLoop:
         if s.error:
             self.snapshot(s)
             p = s.error - 1
-            b.arrive.zero_(); b.packed.zero_()      # a failed launch may have left counts / keys behind
+            b.packed.zero_()      # a failed launch may have left keys behind
             f = N.DESC_FIELDS.index
             N.raise_state_error(int(s.d[p, f("error")]), f"multiblock prompt {p} (state-machine line {int(s.d[p, f('rsv0')])})",
                                 aux=int(s.d[p, f("rsv1")]))

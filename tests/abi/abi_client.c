@@ -83,13 +83,13 @@ static int hot_path(const char *path) {
     const int64_t state_ints = jf_mb_state_ints(&p);
     const int RMAX = jf_mb_max_rows(&p), TMAX = jf_mb_max_tokens(&p), n = p.n;
     if (state_ints <= 0 || RMAX <= 0 || TMAX <= 0) { printf("bad params: %s\n", jf_last_error()); return 11; }
-    int32_t *d_states, *d_pos, *d_rp, *d_rl, *d_arrive, *d_kv; int64_t *d_ids, *d_in, *d_ret; uint64_t *d_packed; jf_mb_desc *d_desc; float *d_logits;
+    int32_t *d_states, *d_pos, *d_rp, *d_rl, *d_kv; int64_t *d_ids, *d_in, *d_ret; uint64_t *d_packed; jf_mb_desc *d_desc; float *d_logits;
     const size_t cells = (size_t)RMAX * TMAX;
     CK(hipMalloc((void **)&d_states, sizeof(int32_t) * state_ints)); CK(hipMemset(d_states, 0, sizeof(int32_t) * state_ints));
     CK(hipMalloc((void **)&d_ids, sizeof(int64_t) * cells)); CK(hipMalloc((void **)&d_pos, sizeof(int32_t) * cells));
     CK(hipMalloc((void **)&d_rp, sizeof(int32_t) * RMAX)); CK(hipMalloc((void **)&d_rl, sizeof(int32_t) * RMAX));
-    CK(hipMalloc((void **)&d_packed, sizeof(uint64_t) * cells)); CK(hipMemset(d_packed, 0, sizeof(uint64_t) * cells));
-    CK(hipMalloc((void **)&d_arrive, sizeof(int32_t) * 64)); CK(hipMemset(d_arrive, 0, sizeof(int32_t) * 64));
+    const size_t pcap = (size_t)JF_MB_PACKED_ENTRIES(cells);        /* positions + room for the launch's per-chunk slots */
+    CK(hipMalloc((void **)&d_packed, sizeof(uint64_t) * pcap)); CK(hipMemset(d_packed, 0, sizeof(uint64_t) * pcap));
     CK(hipMalloc((void **)&d_desc, sizeof(jf_mb_desc))); CK(hipMalloc((void **)&d_kv, sizeof(int32_t)));
     CK(hipMalloc((void **)&d_in, sizeof(int64_t) * n)); CK(hipMalloc((void **)&d_ret, sizeof(int64_t) * (TMAX + 2)));
     const size_t lcap = (size_t)8 * 4 * n * V;                     /* logits of one forward: at most 8 rows x 4n tokens here */
@@ -120,7 +120,7 @@ static int hot_path(const char *path) {
             memset(h_logits, 0, sizeof(float) * B * T * V);
             for (long long i = 0; i < B * T; ++i) { rd(f, &v); h_logits[i * V + v] = 1.0f; }     /* the recorded greedy token wins its row */
             CK(hipMemcpy(d_logits, h_logits, sizeof(float) * B * T * V, hipMemcpyHostToDevice));
-            JF(jf_mb_verify(d_logits, JF_F32, B * T, V, V, NULL, d_states, state_ints, 1, d_packed, B * T, (int32_t)T, d_rp, d_arrive, d_desc, &p, NULL));
+            JF(jf_mb_verify(d_logits, JF_F32, B * T, V, V, NULL, d_states, state_ints, 1, d_packed, B * T, (int64_t)pcap, (int32_t)T, d_desc, &p, NULL));
             CK(hipMemcpy(&ds, d_desc, sizeof(ds), hipMemcpyDeviceToHost));
             ++forwards;
         }

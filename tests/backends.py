@@ -98,8 +98,8 @@ class HostSimLib:
     def jf_mb_step(self, *a):
         return self.hs.hs_mb_step(*a[:-1])
 
-    def jf_mb_verify(self, logits, dtype, R, V, stride, out_index, states, state_ints, P, packed, packed_len, Tpad,
-                     row_prompt, arrive, desc, params, stream):
+    def jf_mb_verify(self, logits, dtype, R, V, stride, out_index, states, state_ints, P, packed, packed_len, packed_cap, Tpad,
+                     desc, params, stream):
         """the two stand-ins back to back (the fused launch computes the same thing)"""
         if _addr(out_index):
             rc = self.jf_argmax_scatter(logits, dtype, R, V, stride, out_index, packed, stream)

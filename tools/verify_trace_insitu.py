@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""In-kernel stamps of the convergence launch INSIDE the decode step of bench.py's model (logits just written by the lm_head
+GEMM), next to tools/verify_trace.py (synthetic logits nobody has just written).  Needs the experiment build:
+
+    tools/build_exp.sh vtrace -DJF_EXP_VERIFY_TRACE
+    JF_LIB=tools/libjf_exp_vtrace.so python tools/verify_trace_insitu.py [--prompts 64] [--iters 24]
+
+Every traced iteration resets the stamp buffers before the launch (a blocking copy: the launch then starts from an idle
+queue, the memory system is as the forward left it) and reads them after it."""
+import argparse
+import ctypes as C
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import bench  # noqa: E402
+from jacobiforcing_amd import _native, ops  # noqa: E402
+from jacobiforcing_amd.engine.multiblock_decoder import MultiblockJacobiDecoder  # noqa: E402
+from jacobiforcing_amd.modeling.qwen2 import Qwen2Config, Qwen2Model, Qwen2Weights  # noqa: E402
+from jacobiforcing_amd.synthetic import ScriptedAcceptance, humaneval_shaped_prompts  # noqa: E402
+from jacobiforcing_amd.tuning import enable_tuned_gemms, grid_alignment  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--prompts", type=int, default=64)
+    ap.add_argument("--iters", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--scripted", action="store_true")
+    a = ap.parse_args()
+    lib = _native.lib()
+    if not hasattr(lib, "jf_exp_read_vtrace"):
+        raise SystemExit("needs JF_LIB=tools/libjf_exp_vtrace.so (tools/build_exp.sh vtrace -DJF_EXP_VERIFY_TRACE)")
+    dev = torch.device("cuda", 0)
+    tuned = enable_tuned_gemms()
+    cfg = Qwen2Config.qwen2_5_coder_7b()
+    model = Qwen2Model(cfg, Qwen2Weights(cfg, dev, dtype=torch.bfloat16, seed=0))
+    prm = ops.MultiblockParams(n=32, K=2, r=0.85, lookahead_start_ratio=0.0, n_gram_pool_size=4, eos_token_id=None,
+                               pad_token_id=cfg.pad_token_id)
+    P = a.prompts
+    vocab_hi = min(151643, cfg.vocab_size - 2)
+    prompts = humaneval_shaped_prompts(P, seed=1234, vocab_hi=vocab_hi)
+    ta, la = grid_alignment(P, tuned)
+    dec = MultiblockJacobiDecoder(model, P, prm, max_seq_len=4096, t_align=ta, logit_align=la)
+    if a.scripted:
+        dec.logits_hook = ScriptedAcceptance(cfg.vocab_size, robust_pct=82, vocab_hi=vocab_hi)
+    rows, steps = [], []
+    state = dict(i=0)
+
+    def before(b, flat):
+        state["i"] += 1
+        if state["i"] > a.warmup:
+            torch.cuda.synchronize()
+            lib.jf_exp_reset_vtrace()
+
+    def after(b, flat):
+        if state["i"] <= a.warmup:
+            return
+        torch.cuda.synchronize()
+        buf = (C.c_ulonglong * (2 + 8 * 256))()
+        lib.jf_exp_read_vtrace(buf, 2 + 8 * 256)
+        st = np.array(buf[:], dtype=np.uint64)
+        ib = (C.c_ulonglong * (2 * 8192))()
+        lib.jf_exp_read_vitems(ib, 2 * 8192)
+        it = np.array(ib[:], dtype=np.uint64).reshape(-1, 2)
+        it = it[it[:, 0] > 0]
+        t0 = int(it[:, 0].min())
+        dur = (it[:, 1] - it[:, 0]).astype(np.float64) / 100.0
+        real = it[dur > 1.0]                                      # list-padding rows leave at once
+        ends = [max(int(st[2 + 8 * p + 7]), int(st[2 + 8 * p + 5])) for p in range(P)]
+        arrived = [int(st[2 + 8 * p + 2]) for p in range(P)]
+        ev = b.desc_dev.cpu().numpy().reshape(P, -1)[:, _native.DESC_FIELDS.index("events")]
+        for p in range(P):
+            if arrived[p] > 0:
+                cls = ("call end" if ev[p] & _native.EVT_CALL_END else "fast" if ev[p] & _native.EVT_FAST else "general")
+                steps.append((cls, (int(st[2 + 8 * p + 4]) - int(st[2 + 8 * p + 3])) / 100.0, (ends[p] - arrived[p]) / 100.0,
+                              (ends[p] - t0) / 100.0 > (max(ends) - t0) / 100.0 - 0.05))
+        rows.append(dict(valid=dec.last_valid_rows, launched=flat.shape[0], items=len(it), real=len(real),
+                         items_end=(int(it[:, 1].max()) - t0) / 100.0, last_start=(int(it[:, 0].max()) - t0) / 100.0,
+                         arrived=(max(arrived) - t0) / 100.0, end=(max(ends) - t0) / 100.0))
+
+    ops.VERIFY_HOOK = (before, after)
+    bench.run_steps(dec, prompts, 0, a.warmup + a.iters, seed=1234)
+    ops.VERIFY_HOOK = None
+    V = cfg.vocab_size
+    print(f"# in situ, {P} prompts per GPU{' (scripted acceptance)' if a.scripted else ''}: us after the first item start")
+    print("# valid rows  logits rows   MB    items end   last stepper saw its rows   launch end    stream TB/s   whole TB/s")
+    for r in rows:
+        mb = r["valid"] * V * 2 / 1e6
+        print(f"  {r['valid']:7d}   {r['launched']:7d}   {mb:6.1f}   {r['items_end']:7.1f}   {r['arrived']:10.1f}   {r['end']:14.1f}   "
+              f"{mb / r['items_end']:10.2f}   {mb / r['end']:8.2f}")
+    mbs = np.array([r["valid"] * V * 2 / 1e6 for r in rows]); ie = np.array([r["items_end"] for r in rows]); en = np.array([r["end"] for r in rows])
+    print(f"# mean: {mbs.mean():.1f} MB, items end {ie.mean():.1f} us ({mbs.mean() / ie.mean():.2f} TB/s), launch end {en.mean():.1f} us "
+          f"({mbs.mean() / en.mean():.2f} TB/s = {mbs.mean() / en.mean() / 8:.3f} of 8 TB/s); tail {np.mean(en - ie):.1f} us")
+    print("# steppers by what their step was: count, gathered -> stepped us (mean / max), rows seen -> end us (mean / max), times it was the launch's last")
+    for cls in ("fast", "general", "call end"):
+        sel = [x for x in steps if x[0] == cls]
+        if sel:
+            st_ = np.array([x[1] for x in sel]); tl = np.array([x[2] for x in sel])
+            print(f"#   {cls:9s} {len(sel):5d}   step {st_.mean():5.1f} / {st_.max():5.1f}   tail {tl.mean():5.1f} / {tl.max():5.1f}   last {sum(x[3] for x in sel)}")
+
+
+if __name__ == "__main__":
+    main()
+
