@@ -118,7 +118,11 @@ typedef struct jf_mb_desc {
     int32_t kv_src_row; /* candidate row whose K/V for [kv_copy_dst, +kv_copy_len) must be     */
     int32_t kv_copy_dst;/*   copied onto row 0 (0 when nothing to copy, MB:500-502)            */
     int32_t kv_copy_len;
-    int32_t events;     /* bit0 spawn, bit1 switch, bit2 early-stop (banners MB:634/660/720)   */
+    int32_t events;     /* bit0 spawn, bit1 switch, bit2 early-stop (banners MB:634/660/720);
+                           bit3 call ended, bit4 prompt stopped (resident driver); bit5 the step ran as the
+                           straight-line fast path (diagnostic); bit6 the NEXT step will not (more than one
+                           block in flight / spawn or block end within reach): jf_mb_loop_* list such prompts'
+                           positions first, so their steps run under the logits stream                    */
     int32_t accepted;   /* tokens the real-active block accepted in this step                  */
     int32_t nspans;
     int32_t rsv0, rsv1;   /* on error: rsv0 = state-machine source line, rsv1 = (draft rows << 16) | candidate rows for JF_E_SHAPE */

@@ -57,7 +57,7 @@ DRV_FIELDS = ["active", "stop", "calls", "iters_total", "new_tokens", "budget", 
               "fin_next", "fin_iters", "fin_off"]
 DRV_HDR_INTS = 16
 STOP_REASONS = {0: None, 1: "eos", 2: "max_new_tokens", 3: "max_calls", 4: "max_seq_len", 5: "max_seq_len"}
-EVT_SPAWN, EVT_SWITCH, EVT_EARLY, EVT_CALL_END, EVT_STOPPED, EVT_FAST = 1, 2, 4, 8, 16, 32
+EVT_SPAWN, EVT_SWITCH, EVT_EARLY, EVT_CALL_END, EVT_STOPPED, EVT_FAST, EVT_SLOW_NEXT = 1, 2, 4, 8, 16, 32, 64
 
 
 def mailbox_ints(P: int) -> int:

@@ -46,7 +46,10 @@ constexpr int MAX_NB = 4096; // sanity bound only; the block lists can grow by o
 enum : int { EVT_SPAWN = 1, EVT_SWITCH = 2, EVT_EARLY = 4,
              EVT_CALL_END = 8,     // resident driver: a generation call ended in this step (its results are in the driver block)
              EVT_STOPPED = 16,     // resident driver: ... and the prompt stopped (EOS / budget / calls / cache row full)
-             EVT_FAST = 32 };      // this step ran as Machine::step_fast (diagnostic)
+             EVT_FAST = 32,        // this step ran as Machine::step_fast (diagnostic)
+             EVT_SLOW_NEXT = 64 }; // the prompt's NEXT step cannot be the straight-line one (more than one block in flight, a spawn
+                                   // or the block's end within reach): the loop's pack step lists such prompts first, so that
+                                   // their steps run under the logits stream and the launch ends behind a short one
 
 struct Layout {
     int n, NB, RMAX, TMAX, LPOOL, pool_size;
@@ -279,6 +282,16 @@ struct Machine {
         next_iteration(d);
     }
 
+    // step_fast()'s conditions as far as they can be told before the next forward: more than one block in flight, or the
+    // spawn threshold / the end of the block within n/4 accepted tokens (a guess that may be wrong either way: it only
+    // orders the position list)
+    JF_HD int slow_next(int nsp, int total0) const {
+        if (done || err) return 0;
+        if (num_blocks != 1 || RA != 0 || len_lists != 1 || nsp != 1) return EVT_SLOW_NEXT;
+        const int reach = total0 + imax(1, (n + 3) / 4);
+        return ((reach >= S[H_SPAWN_THR] && active < K) || reach >= n) ? EVT_SLOW_NEXT : 0;
+    }
+
     // ---- MB:414-419 loop head + the descriptor --------------------------------------------------
     JF_HD void next_iteration(jf_mb_desc *d) {
         int B = 0, T = 0, nsp = 0;
@@ -294,6 +307,7 @@ struct Machine {
             }
         }
         store_scalars();
+        events |= slow_next(nsp, blk(0)[B_TOTAL]);
         if (lanes.lane() == 0) {
             JF_STAMP(11);
             S[H_B] = done ? 0 : B; S[H_T] = done ? 0 : T; S[H_NSPANS] = done ? 0 : nsp;
@@ -495,7 +509,7 @@ struct Machine {
         if (err) { lanes.sync(); done = 1; if (lanes.lane() == 0) { bb[B_ACCLEN] = new_acclen; bb[B_TOTAL] = new_total; bb[B_DROWS] = 1; bb[B_DLEN] = newL; } next_iteration(d); return true; }
         const int rows = C > 1 ? 1 + C : 1;                             // a single recycled candidate is ignored (Q5)
         lnt = nxt; has_lnt = 1;
-        events |= EVT_FAST;
+        events |= EVT_FAST | slow_next(1, new_total);
         int kv_cur = kv_before + T;
         { const int c = prompt_len + new_acclen; if (kv_cur > c) kv_cur = c; }   // MB:617-626
         kv_len = kv_cur;
@@ -947,17 +961,22 @@ JF_HD void mb_pack_body(Lanes lanes, int p, int P, int32_t *states, int64_t stat
     int32_t *S = states + (int64_t)p * state_ints;
     // exclusive prefixes over the prompts before this one and totals over all of them, lanes in parallel
     int rows_b = 0, valid_b = 0, act_b = 0, act_t = 0, cand_b = 0, va_b = 0, va_t = 0, vb_b = 0, v_t = 0, tmax = 0;
+    const int slow_p = desc ? (desc[p].events & EVT_SLOW_NEXT) : 0;
     for (int q = lanes.lane(); q < P; q += lanes.count()) {
         int Bq, Tq;
         if (desc) { Bq = desc[q].B; Tq = desc[q].T; }
         else { const int32_t *Q = states + (int64_t)q * state_ints; Bq = Q[H_B]; Tq = Q[H_T]; }
         if (Bq <= 0) continue;
         const int before = q < p ? 1 : 0;
-        rows_b += before * Bq; valid_b += before * Bq * Tq;
+        // order of the position list (= of the logits rows, = of the convergence launch's stream): prompts whose step
+        // will be a long one first (EVT_SLOW_NEXT), the forward's own row order is untouched
+        const int sq = desc ? (desc[q].events & EVT_SLOW_NEXT) : 0;
+        const int vbefore = desc ? ((sq > slow_p || (sq == slow_p && q < p)) ? 1 : 0) : before;
+        rows_b += before * Bq; valid_b += vbefore * Bq * Tq;
         act_b += before; act_t += 1;
         cand_b += before * (Bq - 1);
-        va_b += before * Tq; va_t += Tq;
-        vb_b += before * (Bq - 1) * Tq;
+        va_b += vbefore * Tq; va_t += Tq;
+        vb_b += vbefore * (Bq - 1) * Tq;
         v_t += Bq * Tq;
         tmax = imax(tmax, Tq);
     }

@@ -153,6 +153,7 @@ struct VerifyArgs {
     int32_t lds_ints;              // ints of dynamic LDS available for (compact image + greedy tokens); 0 = step on HBM
     int32_t fast;                  // Machine::step_fast allowed (jf_mb_set_fast_path)
     int32_t has_loop;              // jf_mb_loop_iterate: kv_len / resident driver / mailbox (lp) apply
+    int64_t items;                 // (row, chunk) items of the launch (wave items in wave mode)
     jfmb::LoopDev lp;
 };
 
@@ -347,8 +348,17 @@ __global__ __launch_bounds__(AM_TPB) void mb_verify_kernel(VerifyArgs a) {
 #ifdef JF_EXP_VERIFY_TRACE
     if (threadIdx.x == 0 && blk < 8192) g_vitems[2 * blk] = __builtin_amdgcn_s_memrealtime();
 #endif
-    if constexpr (WAVE) (void)argmax_wave_item<DT, NT>(a.am, blk * (AM_TPB / 64) + (threadIdx.x >> 6));
-    else (void)argmax_wg_item<DT, true, NT>(a.am, blk);
+    // the item workgroups walk the items in order, workgroup k taking k, k + G, k + 2G, ...: rows near the head of the list are
+    // finished early in the stream instead of every row sharing the bandwidth until the end (verify_launch picks G)
+    const int64_t G = (int64_t)gridDim.x - a.P;
+    if constexpr (WAVE) {
+        for (int64_t it = blk; it * (AM_TPB / 64) < a.items; it += G) (void)argmax_wave_item<DT, NT>(a.am, it * (AM_TPB / 64) + (threadIdx.x >> 6));
+    } else {
+        for (int64_t it = blk; it < a.items; it += G) {
+            (void)argmax_wg_item<DT, true, NT>(a.am, it);
+            __syncthreads();                                     // the item's LDS partials are reused by the next one
+        }
+    }
 #ifdef JF_EXP_VERIFY_TRACE
     if (threadIdx.x == 0 && blk < 8192) g_vitems[2 * blk + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -433,7 +443,15 @@ static int verify_launch(const void *logits, int dtype, int64_t R, int64_t V, in
     a.has_loop = lp ? 1 : 0;
     a.fast = fast_path();
     a.lp = lp ? *lp : jfmb::LoopDev{};
-    const int64_t blocks = pl.blocks + P;
+    a.items = pl.items;
+    // item workgroups: 1024 (four per CU) keep the memory system as full as one per item does — 768 already lose 1-2 %,
+    // 512 4 %, 256 19 % in situ — and work the list through in order, so that the prompts listed first (EVT_SLOW_NEXT)
+    // see their rows ~20 us before the others (profiles/verify_item_wgs_r03.txt).  JF_VERIFY_ITEM_WGS overrides
+    // (0 = one workgroup per item, the round-2 shape)
+    static const long long wgs_env = [] { const char *e = getenv("JF_VERIFY_ITEM_WGS"); return e && *e ? atoll(e) : -1ll; }();
+    int64_t item_wgs = wgs_env > 0 ? wgs_env : (wgs_env == 0 ? pl.blocks : 1024);
+    if (item_wgs > pl.blocks) item_wgs = pl.blocks;
+    const int64_t blocks = item_wgs + P;
     if (blocks > 0x7FFFFFFFll) return fail(JF_E_CAPACITY, "%s: grid too large", who);
     const dim3 grid((unsigned)blocks), block(AM_TPB);
     kern<<<grid, block, shm, s>>>(a);

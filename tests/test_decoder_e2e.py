@@ -188,6 +188,55 @@ def test_compacted_logits_equal_rectangular(backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+def test_position_list_puts_long_steps_first(backend):
+    """The loop's pack step orders the position list (= the logits rows, = the stream of the convergence launch) with the
+    prompts whose next step cannot be the straight-line one first (EVT_SLOW_NEXT in their descriptor): every listed position
+    is still listed exactly once, row 0 of every prompt before the candidate rows, and within each part the flagged prompts
+    come first, prompt order otherwise."""
+    with use_backend(backend):
+        dev = device_for(backend)
+        model = tiny_model(dev, seed=33)
+        V = model.cfg.vocab_size
+        prm = ops.MultiblockParams(n=16, K=2, r=0.5, n_gram_pool_size=4, eos_token_id=V - 1, pad_token_id=V - 2)
+        rng = np.random.default_rng(3)
+        prompts = [[int(t) for t in rng.integers(0, V - 2, size=int(L))] for L in (6, 23, 11, 40, 3, 17)]
+        dec = MultiblockJacobiDecoder(model, len(prompts), prm, max_seq_len=256, t_align=4)
+        ev_col, b_col, t_col = (N.DESC_FIELDS.index(k) for k in ("events", "B", "T"))
+        seen = dict(mixed=0, reordered=0, checked=0)
+
+        def on_it(i, d):
+            lp = dec.loop
+            vi = lp.valid_index()
+            if vi is None or lp.last.Rtot == 0:
+                return
+            vi = vi.cpu().numpy()
+            Tpad, nv = lp.last.Tpad, lp.last.Nvalid
+            assert (vi[nv:] == -1).all() and (vi[:nv] >= 0).all() and len(set(vi[:nv].tolist())) == nv
+            rp = lp.inputs()[2].cpu().numpy()
+            rows = vi[:nv] // Tpad
+            main = dec.loop.last.Rmain
+            slow = (d[:, ev_col] & N.EVT_SLOW_NEXT) != 0
+            live = [p for p in range(len(prompts)) if d[p, b_col] > 0]
+            want_main = [p for p in live if slow[p]] + [p for p in live if not slow[p]]
+            got_main, got_cand = [], []
+            for r in rows:
+                (got_main if r < main else got_cand).append(int(rp[r]))
+            dedup = lambda xs: [x for k, x in enumerate(xs) if k == 0 or xs[k - 1] != x]
+            assert dedup(got_main) == want_main
+            assert dedup(got_cand) == [p for p in want_main if d[p, b_col] > 1]
+            assert all(r < main for r in rows[:len(got_main)])                   # row 0 of every prompt first
+            for p in live:                                                        # every draft-carrying position of the prompt
+                assert (np.array(got_main) == p).sum() == d[p, t_col]
+                assert (np.array(got_cand) == p).sum() == (d[p, b_col] - 1) * d[p, t_col]
+            seen["checked"] += 1
+            seen["mixed"] += bool(slow[live].any() and not slow[live].all())
+            seen["reordered"] += want_main != live
+
+        dec.generate(prompts, max_new_tokens=48, max_calls=6, seed=9, on_iteration=on_it)
+        assert seen["checked"] > 10 and seen["mixed"] > 0 and seen["reordered"] > 0, seen
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_decoder_equals_autoregressive(backend):
     """The reference's greedy criterion (inference_engine/tests/test_jacobi_decoding_greedy.py:180-206): the Jacobi
     output equals plain greedy AR decoding of the same model."""

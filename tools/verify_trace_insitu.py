@@ -47,13 +47,14 @@ def main():
     dec = MultiblockJacobiDecoder(model, P, prm, max_seq_len=4096, t_align=ta, logit_align=la)
     if a.scripted:
         dec.logits_hook = ScriptedAcceptance(cfg.vocab_size, robust_pct=82, vocab_hi=vocab_hi)
-    rows, steps = [], []
+    rows, steps, flagged, pred = [], [], [], {}
     state = dict(i=0)
 
     def before(b, flat):
         state["i"] += 1
         if state["i"] > a.warmup:
             torch.cuda.synchronize()
+            state["flag"] = (b.desc_dev.cpu().numpy().reshape(P, -1)[:, _native.DESC_FIELDS.index("events")] & _native.EVT_SLOW_NEXT) != 0
             lib.jf_exp_reset_vtrace()
 
     def after(b, flat):
@@ -73,8 +74,14 @@ def main():
         ends = [max(int(st[2 + 8 * p + 7]), int(st[2 + 8 * p + 5])) for p in range(P)]
         arrived = [int(st[2 + 8 * p + 2]) for p in range(P)]
         ev = b.desc_dev.cpu().numpy().reshape(P, -1)[:, _native.DESC_FIELDS.index("events")]
+        fl = state["flag"]
+        arr_us = np.array([(x - t0) / 100.0 for x in arrived])
+        live = np.array([x > 0 for x in arrived])
+        if (fl & live).any() and (~fl & live).any():
+            flagged.append((arr_us[fl & live].mean(), arr_us[~fl & live].mean(), int((fl & live).sum())))
         for p in range(P):
             if arrived[p] > 0:
+                pred[(bool(fl[p]), "fast" if ev[p] & _native.EVT_FAST else "other")] = pred.get((bool(fl[p]), "fast" if ev[p] & _native.EVT_FAST else "other"), 0) + 1
                 cls = ("call end" if ev[p] & _native.EVT_CALL_END else "fast" if ev[p] & _native.EVT_FAST else "general")
                 steps.append((cls, (int(st[2 + 8 * p + 4]) - int(st[2 + 8 * p + 3])) / 100.0, (ends[p] - arrived[p]) / 100.0,
                               (ends[p] - t0) / 100.0 > (max(ends) - t0) / 100.0 - 0.05))
@@ -101,6 +108,10 @@ def main():
         if sel:
             st_ = np.array([x[1] for x in sel]); tl = np.array([x[2] for x in sel])
             print(f"#   {cls:9s} {len(sel):5d}   step {st_.mean():5.1f} / {st_.max():5.1f}   tail {tl.mean():5.1f} / {tl.max():5.1f}   last {sum(x[3] for x in sel)}")
+    if flagged:
+        f = np.array(flagged)
+        print(f"# prompts listed first (EVT_SLOW_NEXT): {f[:, 2].mean():.1f} per launch; they saw their rows at {f[:, 0].mean():.1f} us, the others at {f[:, 1].mean():.1f} us")
+        print("# prediction: " + "  ".join(f"flagged={k[0]} step={k[1]}: {v}" for k, v in sorted(pred.items())))
 
 
 if __name__ == "__main__":
