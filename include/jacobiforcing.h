@@ -175,7 +175,7 @@ JF_API int jf_mb_step(int32_t *states, int64_t state_ints, int P, uint64_t *pack
  *   Tpad as passed to jf_mb_pack,
  *   packed: zero on entry, left zero.  packed_len = Rtot * Tpad (positions of the forward), packed_cap = entries the
  *   buffer holds (>= packed_len).  Inside this launch every (position, chunk of the vocabulary) item owns the slot
- *   packed[chunk * packed_len + position] and its non-zero result word is its own arrival flag (no counters, nothing to
+ *   packed[position * chunks + chunk] and its non-zero result word is its own arrival flag (no counters, nothing to
  *   order); rows are split into at most packed_cap / packed_len chunks, so give small forwards room for ~16 chunks
  *   (JF_MB_PACKED_ENTRIES) — with packed_cap == packed_len a row is one item,
  *   params: the jf_mb_params the states were begun with.

@@ -22,18 +22,18 @@ struct ArgmaxArgs {
     int64_t chunk_elems;
     const int32_t *out_index;      // nullable: row i -> packed[out_index[i]], negative = skip the row unread
     int32_t reverse;               // item order: 0 rows first to last, 1 last to first, 2 chunk-major (see argmax_wg_item)
-    int64_t slot_stride;           // 0: chunks of a row meet in packed[orow] (atomicMax).  > 0 (fused verify launch): every
-                                   // (row, chunk) item owns packed[chunk * slot_stride + orow] and stores its result there —
+    int32_t slots;                 // 0: chunks of a row meet in packed[orow] (atomicMax).  1 (fused verify launch): every
+                                   // (row, chunk) item owns packed[orow * chunks_per_row + chunk] and stores its result there —
                                    // a non-zero slot IS the arrival (every real key is >= 0x007FFFFF), nothing to wait for
 };
 
 __device__ __forceinline__ void am_publish(const ArgmaxArgs &a, int64_t orow, int c, unsigned long long m) {
-    if (a.slot_stride > 0) __hip_atomic_store(a.packed + (int64_t)c * a.slot_stride + orow, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.slots) __hip_atomic_store(a.packed + orow * a.chunks_per_row + c, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else atomicMax(a.packed + orow, m);
 }
 
 // One (row, chunk) item by a 256-thread workgroup sharing the chunk.  Returns the result slot (orow, -1 = skipped row) to
-// every thread; thread 0 has published the item with atomicMax when the function returns.
+// every thread; thread 0 has published the item (am_publish) when the function returns.
 template <int DT, bool VEC, bool NT>
 __device__ __forceinline__ int64_t argmax_wg_item(const ArgmaxArgs &a, int64_t item) {
     using E = Elem<DT>;

@@ -129,7 +129,7 @@ extern "C" int jf_mb_read_ret(const int32_t *states, int64_t state_ints, int P, 
 //                            A step that does not fit the compact capacities (runaway block lists, Q3/Q4) is redone on
 //                            the HBM block: nothing was written before that, so the result is the same.
 //   workgroups [P, ...)      the argmax items of jf_argmax_scatter / _partial (jf_argmax_dev.h).  Every (row, chunk) item owns
-//                            one result slot, packed[chunk * Rtot*Tpad + position], and stores its (key, ~index) word there.
+//                            one result slot, packed[position * chunks + chunk], and stores its (key, ~index) word there.
 //
 // Hand-off: the result word is its own arrival flag.  The slots are zero on entry, every real key is >= 0x007FFFFF, so a
 // non-zero slot has arrived; payload and flag being ONE 8-byte agent-scope store there is nothing to order — the item does
@@ -202,6 +202,23 @@ __device__ __forceinline__ unsigned long long ld_agent_u64(const unsigned long l
 constexpr int VERIFY_LDS_HDR = 32;                               // ints in front of the compact image (descriptor + flags)
 constexpr unsigned long long VERIFY_WAIT_TICKS = 200000000ull;   // 2 s of the 100 MHz constant clock: never hang the GPU
 
+// Maximum over the chunk slots of one position (adjacent words); false while one of them is still zero.  Eight loads are
+// issued before the first is looked at: a position of a small forward has up to ~16 chunks, and one dependent round trip
+// per chunk was 3 us between the last item and the step at one prompt.
+__device__ __forceinline__ bool slots_max(const unsigned long long *q, int cpr, unsigned long long &mx) {
+    mx = 0ull;
+    bool zero = false;
+    for (int c0 = 0; c0 < cpr; c0 += 8) {
+        unsigned long long v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = c0 + u < cpr ? ld_agent_u64(q + c0 + u) : ~0ull;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (c0 + u < cpr) { zero |= v[u] == 0ull; mx = v[u] > mx ? v[u] : mx; }
+    }
+    return !zero;
+}
+
 __device__ __forceinline__ void verify_stepper(const VerifyArgs &a, int p, int32_t *smem) {   // one call site; as a real call the whole launch pays its register budget
     using namespace jfmb;
     int32_t *G = a.states + (int64_t)p * a.state_ints;
@@ -248,14 +265,8 @@ __device__ __forceinline__ void verify_stepper(const VerifyArgs &a, int p, int32
                     const int64_t idx = rows.index(r, t);
                     int tok = -1;
                     if (idx >= 0 && idx < rows.plen) {
-                        unsigned long long mx = 0ull;
-                        bool zero = false;
-                        for (int c = 0; c < cpr; ++c) {
-                            const unsigned long long v = ld_agent_u64(pk + (int64_t)c * a.am.slot_stride + idx);
-                            zero |= v == 0ull;
-                            mx = v > mx ? v : mx;
-                        }
-                        if (zero) { miss = true; continue; }
+                        unsigned long long mx;
+                        if (!slots_max(pk + idx * cpr, cpr, mx)) { miss = true; continue; }
                         tok = decode_packed(mx);
                     }
                     if (use_lds && t < T) gtok[r * T + t] = tok;
@@ -271,15 +282,11 @@ __device__ __forceinline__ void verify_stepper(const VerifyArgs &a, int p, int32
             if (lane == 0) { G[H_ERR] = JF_E_LAUNCH; G[H_DONE] = 1; if (dg) { dg->error = JF_E_LAUNCH; dg->done = 1; dg->B = 0; dg->T = 0; } }
             wb = -1;
         } else {
-            const int64_t cstride = a.am.slot_stride;
-            auto Gglobal = [rows, cpr, cstride](int r, int t) -> int {
+            auto Gglobal = [rows, cpr](int r, int t) -> int {
                 const int64_t idx = rows.index(r, t);
                 if (idx < 0 || idx >= rows.plen) return -1;
-                unsigned long long mx = 0ull;
-                for (int c = 0; c < cpr; ++c) {
-                    const unsigned long long v = ld_agent_u64((const unsigned long long *)rows.pk + (int64_t)c * cstride + idx);
-                    mx = v > mx ? v : mx;
-                }
+                unsigned long long mx;
+                (void)slots_max((const unsigned long long *)rows.pk + idx * cpr, cpr, mx);
                 return decode_packed(mx);
             };
             if (use_lds) {
@@ -316,12 +323,11 @@ __device__ __forceinline__ void verify_stepper(const VerifyArgs &a, int p, int32
         if (wb > 0) compact_to_state(Lanes192{}, img, LC, G, LG);
         JF_VSTAMP(p, 5);
         if (wb >= 0) {
-            for (int c = 0; c < a.am.chunks_per_row; ++c)
-                for (int r = 0; r < B; ++r) {
-                    const int64_t lo = rows.index(r, 0), hi = lo + rows.tpad;
-                    for (int64_t i = lo + (threadIdx.x - 64); i < hi && i < a.packed_len; i += AM_TPB - 64)
-                        a.am.packed[(int64_t)c * a.am.slot_stride + i] = 0ull;
-                }
+            const int64_t cpr = a.am.chunks_per_row;
+            for (int r = 0; r < B; ++r) {                         // a position's slots are adjacent: one contiguous range per row
+                const int64_t lo = rows.index(r, 0), hi = lo + rows.tpad < a.packed_len ? lo + rows.tpad : a.packed_len;
+                for (int64_t i = lo * cpr + (threadIdx.x - 64); i < hi * cpr; i += AM_TPB - 64) a.am.packed[i] = 0ull;
+            }
         }
         return;
     }
@@ -437,7 +443,7 @@ static int verify_launch(const void *logits, int dtype, int64_t R, int64_t V, in
         return check_launch("mb_step_kernel");
     }
     VerifyArgs a;
-    a.am = ArgmaxArgs{logits, R, V, row_stride, (unsigned long long *)packed, (int)pl.cpr, pl.chunk, out_index, pl.reverse, packed_len};
+    a.am = ArgmaxArgs{logits, R, V, row_stride, (unsigned long long *)packed, (int)pl.cpr, pl.chunk, out_index, pl.reverse, 1};
     a.states = states; a.state_ints = state_ints; a.P = P; a.packed_len = packed_len;
     a.desc = desc; a.Tpad = Tpad; a.compacted = out_index ? 1 : 0; a.lds_ints = (int32_t)lds_ints;
     a.has_loop = lp ? 1 : 0;
