@@ -163,6 +163,8 @@ class JacobiDecoder:
         n_iter_call = 0
         prev_len = [0] * B
         dev = self.device
+        prof = getattr(self, "profiler", None)        # ModelRunner's PROFILE=1 section timer (reference names, MR:116-134)
+        tick = (lambda name, on: (prof.start(name) if on else prof.stop(name))) if prof is not None else (lambda name, on: None)
         while True:
             active = [i for i in range(B) if not eos_reached[i] and len(accepted[i]) < max_tokens[i] and iters[i] < max_iters[i]]
             if not active:
@@ -188,10 +190,13 @@ class JacobiDecoder:
                 if single:
                     sub[0].draft_tokens = draft_batch[0].tolist()                              # JD:351
                 logits = self._forward_batched(sub, draft_batch)
+                tick("jacobi.verify", True)
                 st = self._ensure(len(idxs), L)
                 st.pad_cursor.fill_(self._pad_cursor)
                 rows, new_tokens, next_draft = st.step(draft_batch, logits, self.eos_token_id,
                                                        [max_tokens[i] - len(accepted[i]) for i in idxs])
+                tick("jacobi.verify", False)
+                tick("jacobi.commit", True)
                 for row, i in enumerate(idxs):
                     seq = sub[row]
                     acc_len, n_new, eos, active_next, n_pads = (int(x) for x in rows[row][:5])
@@ -219,6 +224,9 @@ class JacobiDecoder:
                         raise RuntimeError(f"Invariant violated: len(token_ids)={len(seq)} != num_cached_tokens={seq.num_cached_tokens}")
                     self._pad_cursor += n_pads
                     q_draft[i] = next_draft[row].clone() if active_next else None
+                tick("jacobi.commit", False)
+                if prof is not None:
+                    prof.iterations += 1; prof.tokens += tokens_this_iter
             if not single:
                 self.stats["tokens_per_iteration"].append(tokens_this_iter)
         total = sum(len(a) for a in accepted)

@@ -128,6 +128,8 @@ class JacobiDecoderNonGreedy:
             ops.reject_unsupported_filters(getattr(seq, "sampling_params", None), self.vocab_size)
         n_iter_call = 0
         dev = self.device
+        prof = getattr(self, "profiler", None)        # ModelRunner's PROFILE=1 section timer (reference names, MR:116-134)
+        tick = (lambda name, on: (prof.start(name) if on else prof.stop(name))) if prof is not None else (lambda name, on: None)
         while True:
             active = [i for i in range(B) if not eos_reached[i] and len(accepted[i]) < max_tokens[i] and iters[i] < max_iters[i]]
             if not active:
@@ -157,9 +159,12 @@ class JacobiDecoderNonGreedy:
                 logits = self._forward_batched(sub, draft_batch)
                 for i in idxs:
                     forwards[i] += 1
+                tick("jacobi.verify", True)
                 st = self._ensure(len(idxs), L)
                 rows, committed, next_draft = st.step(draft_batch, logits, temperature, self.eos_token_id,
                                                       [max_tokens[i] - len(accepted[i]) for i in idxs], self._cur)
+                tick("jacobi.verify", False)
+                tick("jacobi.commit", True)
                 for row, i in enumerate(idxs):
                     seq = sub[row]
                     n_c, eos, _rej, n_b, n_u, n_p, act, _ = (int(x) for x in rows[row])
@@ -182,6 +187,9 @@ class JacobiDecoderNonGreedy:
                     self._cur[1] += n_b
                     self._cur[2] += n_p
                     q_draft[i] = next_draft[row].clone() if act else None
+                tick("jacobi.commit", False)
+                if prof is not None:
+                    prof.iterations += 1; prof.tokens += tokens_this_iter
             if not single:
                 self.stats["tokens_per_iteration"].append(tokens_this_iter)
         total = sum(len(a) for a in accepted)

@@ -253,6 +253,7 @@ class ModelRunner:
                                        forward_step_batch=self._jacobi_forward_step_batch, eos_token_id=self.config.eos,
                                        pad_token_id=self.config.pad, vocab_size=self.config.hf_config.vocab_size,
                                        device=self.device)
+        self.jacobi_decoder.profiler = self.profiler
 
     # ------------------------------------------------------------------------------------------ multiblock (new)
     @torch.inference_mode()
