@@ -66,9 +66,14 @@ __device__ __forceinline__ int64_t argmax_wg_item(const ArgmaxArgs &a, int64_t i
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) ft.consume(v[u], ebase + (uint32_t)(k + u * AM_TPB) * EPV);
         }
-        for (; k < nvec; k += AM_TPB, q += AM_TPB) {
-            const u32x4 v0 = am_load<NT>(q);
-            ft.consume(v0, ebase + (uint32_t)k * EPV);
+        if (k < nvec) {                                               // up to UNROLL - 1 vectors left for this thread: issue them
+            u32x4 v[UNROLL - 1];                                      // together (one latency, not one per vector — the last
+#pragma unroll                                                        // items of a launch have nobody to hide it behind)
+            for (int u = 0; u < UNROLL - 1; ++u)
+                if (k + u * AM_TPB < nvec) v[u] = am_load<NT>(q + u * AM_TPB);
+#pragma unroll
+            for (int u = 0; u < UNROLL - 1; ++u)
+                if (k + u * AM_TPB < nvec) ft.consume(v[u], ebase + (uint32_t)(k + u * AM_TPB) * EPV);
         }
         const int64_t vec_end = begin + ((end - begin) / EPV) * EPV;
         if (__syncthreads_or(ft.saw_nan() ? 1 : 0)) {
@@ -126,9 +131,14 @@ __device__ __forceinline__ int64_t argmax_wave_item(const ArgmaxArgs &a, int64_t
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) ft.consume(v[u], ebase + (uint32_t)(k + u * 64) * EPV);
     }
-    for (; k < nvec; k += 64, q += 64) {
-        const u32x4 v0 = am_load<NT>(q);
-        ft.consume(v0, ebase + (uint32_t)k * EPV);
+    if (k < nvec) {                                                   // the remaining < UNROLL vectors in one round of loads
+        u32x4 v[UNROLL - 1];
+#pragma unroll
+        for (int u = 0; u < UNROLL - 1; ++u)
+            if (k + u * 64 < nvec) v[u] = am_load<NT>(q + u * 64);
+#pragma unroll
+        for (int u = 0; u < UNROLL - 1; ++u)
+            if (k + u * 64 < nvec) ft.consume(v[u], ebase + (uint32_t)(k + u * 64) * EPV);
     }
     uint32_t best = 0u, bidx = 0xFFFFFFFFu;
     const int64_t vec_end = begin + (int64_t)nvec * EPV;

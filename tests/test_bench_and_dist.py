@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from jacobiforcing_amd import ops
+from jacobiforcing_amd import _native, ops
 from jacobiforcing_amd.engine.multiblock_decoder import MultiblockJacobiDecoder
 from jacobiforcing_amd.synthetic import ScriptedAcceptance, humaneval_shaped_prompts
 
@@ -62,13 +62,16 @@ def test_scripted_acceptance_raises_tokens_per_forward():
 
 
 @pytest.mark.gpu
-def test_full_vocabulary_batch_decodes_the_planted_sequence():
+@pytest.mark.parametrize("extra", [65536, 0], ids=["roomy", "tight"])
+def test_full_vocabulary_batch_decodes_the_planted_sequence(extra, monkeypatch):
     """BASELINE sizes end to end through the real kernels: 16 prompts side by side, n=32 K=2 r=0.85 pool=4, the full
     152 064-entry vocabulary in bf16 (hundreds of logits rows per launch: the wavefront launch shape of the argmax), candidate
     rows, KV commits.  Size-independent property instead of a CPU pass: with the planted acceptance model the decoded tokens
     of every prompt ARE the planted target sequence (greedy Jacobi == greedy AR of the same logits) and several tokens are
-    accepted per forward."""
+    accepted per forward.  "tight": the argmax workspace has no room beyond one slot per position of the largest forward, so
+    the convergence launch may split a row into fewer chunks than it would like (packed_cap / packed_len)."""
     from jacobiforcing_amd.modeling.qwen2 import Qwen2Config, Qwen2Model, Qwen2Weights
+    monkeypatch.setattr(_native, "MB_PACKED_EXTRA", extra)
     dev = torch.device("cuda")
     V = 152064
     cfg = Qwen2Config.tiny(vocab_size=V, hidden_size=128, layers=2, heads=4, kv_heads=2, head_dim=32, inter=256)
@@ -113,6 +116,31 @@ def test_bench_batch_decodes_the_planted_sequence(resident):
     if other is not None:
         assert key == other                                   # resident == host-driven
     test_bench_batch_decodes_the_planted_sequence._seen = key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [1, 3, 8])
+def test_small_batches_decode_the_planted_sequence(P):
+    """The literal config-3 / config-4 per-GPU shapes: one, three and eight prompts at the full vocabulary.  A row is split into
+    many chunks there (16 at one prompt, 7 at eight), so every position has that many result slots in the convergence launch;
+    the decoded tokens are the planted sequence, with the pack step's alignment of the bench (tuning.grid_alignment)."""
+    from jacobiforcing_amd.modeling.qwen2 import Qwen2Config, Qwen2Model, Qwen2Weights
+    from jacobiforcing_amd.tuning import grid_alignment
+    dev = torch.device("cuda")
+    V = 152064
+    cfg = Qwen2Config.tiny(vocab_size=V, hidden_size=128, layers=2, heads=4, kv_heads=2, head_dim=32, inter=256)
+    model = Qwen2Model(cfg, Qwen2Weights(cfg, dev, dtype=torch.bfloat16, seed=1, init_std=0.05))
+    prm = ops.MultiblockParams(n=32, K=2, r=0.85, n_gram_pool_size=4, eos_token_id=None, pad_token_id=151643)
+    prompts = humaneval_shaped_prompts(P, seed=99, vocab_hi=151643)
+    hook = ScriptedAcceptance(V, robust_pct=82, vocab_hi=151643)
+    ta, la = grid_alignment(P, True)
+    dec = MultiblockJacobiDecoder(model, P, prm, max_seq_len=1024, logits_hook=hook, t_align=ta, logit_align=la)
+    stats, _, iters = dec.generate(prompts, max_new_tokens=96, max_calls=8, seed=7)
+    for p, st in enumerate(stats):
+        pos = torch.arange(len(prompts[p]), len(prompts[p]) + len(st.token_ids))
+        assert st.token_ids == hook.target(pos, torch.full_like(pos, p)).tolist(), p
+        assert len(st.token_ids) >= 96 or st.stop_reason == "max_calls"
+    assert sum(len(s.token_ids) for s in stats) / max(sum(s.total_iterations for s in stats), 1) > 2.0
 
 
 _WORKER = textwrap.dedent("""
