@@ -53,6 +53,35 @@ def test_plain_c_client(tmp_path):
     assert "rc=-1" in out and "null pointer" in out
 
 
+def test_python_constants_are_the_headers(tmp_path):
+    """The mailbox / driver-block / event constants of _native.py are the values a C compiler reads out of the header."""
+    names = ["JF_MB_SEQ", "JF_MB_RTOT", "JF_MB_RMAIN", "JF_MB_TPAD", "JF_MB_TMAX", "JF_MB_NVALID", "JF_MB_NVALID_PAD", "JF_MB_NDONE",
+             "JF_MB_MAXKV", "JF_MB_ERROR", "JF_MB_ACCEPTED", "JF_MB_NCALL_END", "JF_MB_MAILBOX_HDR", "JF_MB_FIN_INTS",
+             "JF_DRV_HDR_INTS", "JF_DRV_ACTIVE", "JF_DRV_STOP", "JF_DRV_CALLS", "JF_DRV_ITERS", "JF_DRV_NEW", "JF_DRV_BUDGET",
+             "JF_DRV_MAX_CALLS", "JF_DRV_TEXT_LEN", "JF_DRV_CURSOR", "JF_DRV_FIN_RET_LEN", "JF_DRV_FIN_NEXT", "JF_DRV_FIN_ITERS",
+             "JF_DRV_FIN_OFF", "JF_STOP_NONE", "JF_STOP_EOS", "JF_STOP_MAX_NEW_TOKENS", "JF_STOP_MAX_CALLS", "JF_STOP_MAX_SEQ_LEN",
+             "JF_STOP_TEXT_FULL", "JF_MB_INACTIVE", "JF_MB_KEEP", "JF_E_INVALID", "JF_E_CAPACITY", "JF_E_LAUNCH", "JF_E_SHAPE"]
+    src = tmp_path / "consts.c"
+    src.write_text('#include <stdio.h>\n#include "jacobiforcing.h"\nint main(void) {\n' +
+                   "".join(f'  printf("{n} %lld\\n", (long long)({n}));\n' for n in names) +
+                   '  printf("MAILBOX_INTS_7 %lld\\n", (long long)JF_MB_MAILBOX_INTS(7));\n'
+                   '  printf("PACKED_ENTRIES_100 %lld\\n", (long long)JF_MB_PACKED_ENTRIES(100));\n'
+                   '  printf("LOOP_BYTES %lld\\n", (long long)sizeof(jf_mb_loop));\n  return 0;\n}\n')
+    exe = tmp_path / "consts"
+    subprocess.check_call(["gcc", "-std=c99", f"-I{ROOT / 'include'}", str(src), "-o", str(exe)])
+    c = {k: int(v) for k, v in (line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())}
+    mb = ["SEQ", "RTOT", "RMAIN", "TPAD", "TMAX", "NVALID", "NVALID_PAD", "NDONE", "MAXKV", "ERROR", "ACCEPTED", "NCALL_END"]
+    assert [c["JF_MB_" + k] for k in mb] == [getattr(N, "MB_" + k) for k in mb]
+    assert (c["JF_MB_MAILBOX_HDR"], c["JF_MB_FIN_INTS"], c["JF_DRV_HDR_INTS"]) == (N.MB_MAILBOX_HDR, N.MB_FIN_INTS, N.DRV_HDR_INTS)
+    assert c["MAILBOX_INTS_7"] == N.mailbox_ints(7) and c["PACKED_ENTRIES_100"] == 100 + N.MB_PACKED_EXTRA
+    drv = ["ACTIVE", "STOP", "CALLS", "ITERS", "NEW", "BUDGET", "MAX_CALLS", "TEXT_LEN", "CURSOR", "FIN_RET_LEN", "FIN_NEXT", "FIN_ITERS",
+           "FIN_OFF"]
+    assert [c["JF_DRV_" + k] for k in drv] == list(range(len(N.DRV_FIELDS))) and len(drv) == len(N.DRV_FIELDS)
+    assert sorted(c[k] for k in c if k.startswith("JF_STOP_")) == sorted(N.STOP_REASONS)
+    assert (c["JF_MB_INACTIVE"], c["JF_MB_KEEP"]) == (N.JF_MB_INACTIVE, N.JF_MB_KEEP)
+    assert c["LOOP_BYTES"] == ctypes.sizeof(N.MbLoop)
+
+
 def _c_case_file(case, path):
     """One golden multiblock record (tests/golden/mb_cases*.json: calls of the unmodified reference) as the flat integer file the
     C client reads."""

@@ -27,9 +27,12 @@ done
 timeout 1500 bash tools/pmc_verify.sh > $O/r3e_pmc_verify.log 2>&1; cp $O/pmc/pmc_verify.json $O/r3e_pmc_verify.json
 # in-kernel timeline
 JF_LIB=tools/libjf_exp_vtrace.so timeout 600 python tools/verify_trace.py > $O/r3e_vtrace.txt 2>&1
+for M in "--warmup 30" "--scripted --iters 40"; do echo "## tools/verify_trace_insitu.py $M"; JF_LIB=tools/libjf_exp_vtrace.so timeout 400 python tools/verify_trace_insitu.py $M 2>&1 | grep -v amdgpu.ids; done > $O/r3e_vtrace_insitu.txt
 # batch-1 drivers
 timeout 600 python -m jacobiforcing_amd.drivers.ar_baseline --synthetic 2 --max-new-tokens 256 > $O/r3e_ar.txt 2>&1
 timeout 600 python -m jacobiforcing_amd.drivers.sb_math500 --synthetic 4 --n 16 --max-new-tokens 256 --csv /tmp/sb.csv > $O/r3e_sb.txt 2>&1
 timeout 600 python -m jacobiforcing_amd.drivers.mr_humaneval --synthetic 8 --batch 1 --max-new-tokens 256 --csv /tmp/mr.csv > $O/r3e_mr.txt 2>&1
 timeout 900 python tools/engine_throughput.py --batch 64 --block-len 32 --max-tokens 96 > $O/r3e_engine.txt 2>&1
+for M in "jacobi greedy" "T=0.8"; do PROFILE=1 timeout 600 python tools/engine_throughput.py --batch 64 --block-len 32 --max-tokens 96 --only "$M" 2>&1 | grep -v amdgpu.ids; done > $O/r3e_engine_profile.txt
+JF_FUZZ_SCALE=100 timeout 1500 python -m pytest tests/test_engine_fuzz.py tests/test_multiblock_fuzz.py -m gpu -n 12 -q -p no:cacheprovider > $O/r3e_soak100.log 2>&1; tail -4 $O/r3e_soak100.log
 tail -3 $O/r3e_gputest.log; tail -1 $O/r3e_smoke.log; ls -la $O | grep r3e_
