@@ -672,6 +672,22 @@ def test_argmax_is_invariant_under_the_launch_shape_knobs(env):
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
 
 
+@GPU
+@pytest.mark.parametrize("env", [dict(JF_VERIFY_ITEM_WGS="7"), dict(JF_VERIFY_ITEM_WGS="0", JF_ARGMAX_ITEMS="4096"),
+                                 dict(JF_ARGMAX_WAVE="1", JF_VERIFY_ITEM_WGS="33"), dict(JF_ARGMAX_CHUNK="4096")],
+                         ids=["seven-item-workgroups", "one-per-item-many-chunks", "wave-items", "small-chunks"])
+def test_convergence_launch_is_invariant_under_its_knobs(env):
+    """How many item workgroups walk the list, how many chunk slots a position has and whether an item is a workgroup or a
+    wavefront (overrides read once per process) change nothing about what the convergence launch computes: the golden records
+    of the reference and the small full-vocabulary batches decode as before."""
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        str(ROOT / "tests" / "test_multiblock.py"), str(ROOT / "tests" / "test_bench_and_dist.py"),
+                        "-k", "golden_calls or small_batches or many_prompts"],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
 def test_convergence_launch_keeps_its_register_budget():
     """The fused convergence launch shares one kernel between the streaming argmax items and the per-prompt steppers: the
     steppers' code must not cost the items their occupancy (round 3 met both ways this breaks silently: a stepper that is no
