@@ -119,7 +119,7 @@ static int argmax_launch(const void *logits, int dtype, int64_t R, int64_t V, in
     const int rc = argmax_plan(logits, dtype, R, V, row_stride, false, &pl);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const ArgmaxArgs a{logits, R, V, row_stride, (unsigned long long *)packed, (int)pl.cpr, pl.chunk, out_index, pl.reverse, 0};
+    const ArgmaxArgs a{logits, R, V, row_stride, (unsigned long long *)packed, (int)pl.cpr, pl.chunk, out_index, pl.reverse, -1, 0};
     const dim3 grid((unsigned)pl.blocks), block(AM_TPB);
     if (pl.wave_mode) {
         if (dtype == JF_F32) { if (pl.nt) argmax_wave_kernel<JF_F32, true><<<grid, block, 0, s>>>(a); else argmax_wave_kernel<JF_F32, false><<<grid, block, 0, s>>>(a); }

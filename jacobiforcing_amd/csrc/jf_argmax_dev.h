@@ -22,6 +22,10 @@ struct ArgmaxArgs {
     int64_t chunk_elems;
     const int32_t *out_index;      // nullable: row i -> packed[out_index[i]], negative = skip the row unread
     int32_t reverse;               // item order: 0 rows first to last, 1 last to first, 2 chunk-major (see argmax_wg_item)
+    int64_t valid_rows;            // < 0: a negative out_index entry is looked at BEFORE the row is read (skip it unread).
+                                   // >= 0: rows [valid_rows, R) are list padding and skipped without a look; the others start
+                                   // streaming at once and out_index is only consulted when the result is published (one
+                                   // dependent load less in front of every item)
     int32_t slots;                 // 0: chunks of a row meet in packed[orow] (atomicMax).  1 (fused verify launch): every
                                    // (row, chunk) item owns packed[orow * chunks_per_row + chunk] and stores its result there —
                                    // a non-zero slot IS the arrival (every real key is >= 0x007FFFFF), nothing to wait for
@@ -43,8 +47,9 @@ __device__ __forceinline__ int64_t argmax_wg_item(const ArgmaxArgs &a, int64_t i
     // before the next range (2: the order a column-tiled producer wrote the logits in)
     const int64_t row = a.reverse == 2 ? item % a.R : (a.reverse ? a.R - 1 - item / a.chunks_per_row : item / a.chunks_per_row);
     // slot of this row's result (jf_argmax_scatter): read up front so its latency hides behind the stream; < 0 = padding row
+    if (a.valid_rows >= 0 && row >= a.valid_rows) return -1;
     const int64_t orow = a.out_index ? (int64_t)a.out_index[row] : row;
-    if (orow < 0) return -1;
+    if (a.valid_rows < 0 && orow < 0) return -1;
     const int c = (int)(a.reverse == 2 ? item / a.R : item % a.chunks_per_row);
     const int64_t begin = (int64_t)c * a.chunk_elems;
     int64_t end = begin + a.chunk_elems;
@@ -66,14 +71,9 @@ __device__ __forceinline__ int64_t argmax_wg_item(const ArgmaxArgs &a, int64_t i
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) ft.consume(v[u], ebase + (uint32_t)(k + u * AM_TPB) * EPV);
         }
-        if (k < nvec) {                                               // up to UNROLL - 1 vectors left for this thread: issue them
-            u32x4 v[UNROLL - 1];                                      // together (one latency, not one per vector — the last
-#pragma unroll                                                        // items of a launch have nobody to hide it behind)
-            for (int u = 0; u < UNROLL - 1; ++u)
-                if (k + u * AM_TPB < nvec) v[u] = am_load<NT>(q + u * AM_TPB);
-#pragma unroll
-            for (int u = 0; u < UNROLL - 1; ++u)
-                if (k + u * AM_TPB < nvec) ft.consume(v[u], ebase + (uint32_t)(k + u * AM_TPB) * EPV);
+        for (; k < nvec; k += AM_TPB, q += AM_TPB) {                  // (issuing these < 8 vectors as one round of loads was
+            const u32x4 v0 = am_load<NT>(q);                           //  measured: no gain at any shape, +12 VGPRs)
+            ft.consume(v0, ebase + (uint32_t)k * EPV);
         }
         const int64_t vec_end = begin + ((end - begin) / EPV) * EPV;
         if (__syncthreads_or(ft.saw_nan() ? 1 : 0)) {
@@ -92,7 +92,7 @@ __device__ __forceinline__ int64_t argmax_wg_item(const ArgmaxArgs &a, int64_t i
     __shared__ uint64_t s_part[AM_TPB / 64];
     if ((tid & 63) == 0) s_part[tid >> 6] = pk;
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0 && orow >= 0) {
         uint64_t m = s_part[0];
 #pragma unroll
         for (int w = 1; w < AM_TPB / 64; ++w) m = s_part[w] > m ? s_part[w] : m;
@@ -111,8 +111,9 @@ __device__ __forceinline__ int64_t argmax_wave_item(const ArgmaxArgs &a, int64_t
     const int lane = threadIdx.x & 63;
     if (item >= a.R * a.chunks_per_row) return -1;
     const int64_t row = a.reverse == 2 ? item % a.R : (a.reverse ? a.R - 1 - item / a.chunks_per_row : item / a.chunks_per_row);
+    if (a.valid_rows >= 0 && row >= a.valid_rows) return -1;
     const int64_t orow = a.out_index ? (int64_t)a.out_index[row] : row;
-    if (orow < 0) return -1;
+    if (a.valid_rows < 0 && orow < 0) return -1;
     const int c = (int)(a.reverse == 2 ? item / a.R : item % a.chunks_per_row);
     const int64_t begin = (int64_t)c * a.chunk_elems;
     int64_t end = begin + a.chunk_elems;
@@ -131,14 +132,9 @@ __device__ __forceinline__ int64_t argmax_wave_item(const ArgmaxArgs &a, int64_t
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) ft.consume(v[u], ebase + (uint32_t)(k + u * 64) * EPV);
     }
-    if (k < nvec) {                                                   // the remaining < UNROLL vectors in one round of loads
-        u32x4 v[UNROLL - 1];
-#pragma unroll
-        for (int u = 0; u < UNROLL - 1; ++u)
-            if (k + u * 64 < nvec) v[u] = am_load<NT>(q + u * 64);
-#pragma unroll
-        for (int u = 0; u < UNROLL - 1; ++u)
-            if (k + u * 64 < nvec) ft.consume(v[u], ebase + (uint32_t)(k + u * 64) * EPV);
+    for (; k < nvec; k += 64, q += 64) {
+        const u32x4 v0 = am_load<NT>(q);
+        ft.consume(v0, ebase + (uint32_t)k * EPV);
     }
     uint32_t best = 0u, bidx = 0xFFFFFFFFu;
     const int64_t vec_end = begin + (int64_t)nvec * EPV;
@@ -156,7 +152,7 @@ __device__ __forceinline__ int64_t argmax_wave_item(const ArgmaxArgs &a, int64_t
         if (kk > best) { best = kk; bidx = (uint32_t)j; }
     }
     uint64_t pk = wave_max_u64(((uint64_t)best << 32) | (uint64_t)(~bidx));
-    if (lane == 0) am_publish(a, orow, c, (unsigned long long)pk);
+    if (lane == 0 && orow >= 0) am_publish(a, orow, c, (unsigned long long)pk);
     return orow;
 }
 

@@ -347,7 +347,7 @@ __device__ __forceinline__ void verify_stepper(const VerifyArgs &a, int p, int32
 }
 
 template <int DT, bool WAVE, bool NT>
-__global__ __launch_bounds__(AM_TPB) void mb_verify_kernel(VerifyArgs a) {
+__global__ __launch_bounds__(AM_TPB, 5) void mb_verify_kernel(VerifyArgs a) {   // five workgroups per CU: 1 280 resident >= 64 steppers + 1 024 items
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     if ((int)blockIdx.x < a.P) { verify_stepper(a, blockIdx.x, smem); return; }
     const int64_t blk = (int64_t)blockIdx.x - a.P;
@@ -395,7 +395,7 @@ static int verify_stepper_cap(const void *kern, int variant, size_t shm) {
 static int verify_launch(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, const int32_t *out_index,
                          int32_t *states, int64_t state_ints, int P, uint64_t *packed, int64_t packed_len, int64_t packed_cap,
                          int32_t Tpad, jf_mb_desc *desc, const jf_mb_params *params,
-                         const jfmb::LoopDev *lp, void *stream, const char *who, int *fused_out = nullptr) {
+                         const jfmb::LoopDev *lp, void *stream, const char *who, int *fused_out = nullptr, int64_t valid_rows = -1) {
     if (fused_out) *fused_out = 0;
     if (P <= 0) return JF_OK;
     int rc = check_params(params, who);
@@ -443,7 +443,7 @@ static int verify_launch(const void *logits, int dtype, int64_t R, int64_t V, in
         return check_launch("mb_step_kernel");
     }
     VerifyArgs a;
-    a.am = ArgmaxArgs{logits, R, V, row_stride, (unsigned long long *)packed, (int)pl.cpr, pl.chunk, out_index, pl.reverse, 1};
+    a.am = ArgmaxArgs{logits, R, V, row_stride, (unsigned long long *)packed, (int)pl.cpr, pl.chunk, out_index, pl.reverse, valid_rows, 1};
     a.states = states; a.state_ints = state_ints; a.P = P; a.packed_len = packed_len;
     a.desc = desc; a.Tpad = Tpad; a.compacted = out_index ? 1 : 0; a.lds_ints = (int32_t)lds_ints;
     a.has_loop = lp ? 1 : 0;
@@ -557,10 +557,17 @@ extern "C" int jf_mb_loop_iterate(const jf_mb_loop *loop, int32_t seq, const voi
     if (compacted && !loop->valid_index) return fail(JF_E_INVALID, "jf_mb_loop_iterate: compacted logits without a position list");
     const jfmb::LoopDev d = jfmb::make_loop_dev(loop, seq, params);
     int fused = 0;
+    // rows of the compacted logits beyond the position list's entries are list padding: the mailbox the caller has just waited
+    // on says how many entries there are, so the items need not look at the list before they start to stream
+    int64_t nvalid = -1;
+    if (compacted) {
+        nvalid = loop->mailbox[JF_MB_NVALID];
+        if (nvalid < 0 || nvalid > R) return fail(JF_E_INVALID, "jf_mb_loop_iterate: the mailbox lists %lld positions, the logits have %lld rows", (long long)nvalid, (long long)R);
+    }
     if (ev_begin) (void)hipEventRecord((hipEvent_t)ev_begin, (hipStream_t)stream);
     rc = verify_launch(logits, dtype, R, V, row_stride, compacted ? loop->valid_index : nullptr, loop->states, loop->state_ints,
                        loop->P, loop->packed, (int64_t)Rtot * Tpad, loop->packed_cap, Tpad, loop->desc, params, &d,
-                       stream, "jf_mb_loop_iterate", &fused);
+                       stream, "jf_mb_loop_iterate", &fused, nvalid);
     if (ev_end) (void)hipEventRecord((hipEvent_t)ev_end, (hipStream_t)stream);
     if (rc || !queue_pack) return rc;
     return loop_pack(loop, d, fused ? 1 : 2, (hipStream_t)stream);     // the fused launch's steppers mailed their own descriptors
