@@ -336,7 +336,7 @@ typedef struct jf_engine_row {
     int32_t eos;         /* EOS committed                                   */
     int32_t active_next; /* row keeps decoding (not eos, below max_tokens)  */
     int32_t n_pads;      /* pads consumed for the next draft                */
-    int32_t rsv[3];
+    int32_t rsv[3];      /* scratch: [0] copied tokens, [1..2] the row's hand-off word inside the launch (zero the records once) */
 } jf_engine_row;
 
 JF_API int jf_engine_step(const int64_t *draft, int B, int L, uint64_t *packed, int32_t eos_id,

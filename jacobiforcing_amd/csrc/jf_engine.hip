@@ -1,5 +1,7 @@
 // jf_engine.hip — (a15) the engine decoder's single-block step and (a16) the paged-KV index fill of its caller.
 #include "jf_common.h"
+#include <atomic>
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------------
 // engine single-block step (JD:567-710): one wavefront per row, then one small launch hands out the pads
@@ -7,7 +9,8 @@
 // Rows are independent except for the pad stream, which the reference consumes in row order (JD:705-707 calls
 // torch.randint per row): launch 1 runs every row on its own wavefront (accept scan = one ballot per 64 tokens), launch 2
 // turns the rows' pad counts into stream offsets with a wavefront scan and fills all pads in parallel.  A dependent
-// launch boundary (~1.5 us) is cheaper than an in-kernel agent-scope fence + arrival counter (~3.5 us per workgroup).
+// launch boundary (~1.5 us) is cheaper than an in-kernel agent-scope fence + arrival counter (~3.5 us per workgroup) — round 1's
+// measurement; the one-word hand-off of engine_step_kernel below needs neither fence nor counter and replaces the pair.
 __global__ __launch_bounds__(64) void engine_rows_kernel(const int64_t *draft, int L, const unsigned long long *packed, int eos_id,
                                                           const int32_t *remaining, int64_t *new_tokens, int64_t *next_draft,
                                                           jf_engine_row *rows) {
@@ -60,6 +63,77 @@ __global__ __launch_bounds__(256) void engine_pads_kernel(int B, int L, unsigned
     if (tid == 0) *pad_cursor = base + s_total;
 }
 
+// The two launches as ONE (rows up to ENGINE_ONE_LAUNCH_ROWS): workgroups [0, B) are the rows (wavefront 0 of each), workgroup B
+// hands out the pads.  A row's hand-off is one 8-byte word — (generation << 32) | n_pads << 16 | copy_len — stored into its
+// own record (rsv[1..2]): the word is payload and arrival flag at once, so there is nothing to order (the same hand-off as the
+// convergence launch's result slots, jf_multiblock.hip).  The pad workgroup has the highest block id and only waits for lower
+// ones: they are dispatched before it, no residency assumption.  It re-zeroes packed[] after every row has published, i.e.
+// after every row has read its greedy tokens.
+constexpr int ENGINE_ONE_LAUNCH_ROWS = 2048;
+__global__ __launch_bounds__(256) void engine_step_kernel(const int64_t *draft, int B, int L, unsigned long long *packed, int eos_id,
+                                                           const int32_t *remaining, int64_t *new_tokens, int64_t *next_draft,
+                                                           const int64_t *pad_stream, int64_t pad_len, int64_t *pad_cursor,
+                                                           jf_engine_row *rows, uint32_t gen) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (b < B) {
+        if (tid >= 64) return;
+        const unsigned long long *pk = packed + (int64_t)b * (L - 1);
+        auto G = [pk](int i) { return jfmb::decode_packed(pk[i]); };
+        jfmb::EngineRowOut o = jfmb::engine_row_body(SoloWaveLanes{}, draft + (int64_t)b * L, L, G, eos_id, remaining[b],
+                                                     new_tokens + (int64_t)b * L, next_draft + (int64_t)b * L);
+        if (tid == 0) {
+            const int np = o.active_next ? (L - 1 - o.copy_len) : 0;
+            rows[b].acc_len = o.acc_len; rows[b].n_new = o.n_new; rows[b].eos = o.eos; rows[b].active_next = o.active_next;
+            rows[b].n_pads = np; rows[b].rsv[0] = o.copy_len;
+            __hip_atomic_store((unsigned long long *)__builtin_assume_aligned(&rows[b].rsv[1], 8),
+                               ((unsigned long long)gen << 32) | ((unsigned long long)np << 16) | (unsigned long long)o.copy_len,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    __shared__ int s_np[ENGINE_ONE_LAUNCH_ROWS], s_cl[ENGINE_ONE_LAUNCH_ROWS], s_off[ENGINE_ONE_LAUNCH_ROWS];
+    __shared__ int s_total;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (int r = tid; r < B; r += 256) {                      // wait for every row's word (bounded: 2 s of the 100 MHz clock)
+        unsigned long long w;
+        unsigned spins = 0;
+        while (((w = __hip_atomic_load((const unsigned long long *)__builtin_assume_aligned(&rows[r].rsv[1], 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != gen) {
+            __builtin_amdgcn_s_sleep(4);
+            if ((++spins & 255u) == 0u && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { w = 0ull; break; }
+        }
+        s_np[r] = (int)((w >> 16) & 0xFFFFu);
+        s_cl[r] = (int)(w & 0xFFFFu);
+    }
+    __syncthreads();
+    if (tid < 64) {                                           // exclusive scan of n_pads in row order, 64 rows per pass
+        int run = 0;
+        for (int b0 = 0; b0 < B; b0 += 64) {
+            const int r = b0 + tid;
+            const int np = r < B ? s_np[r] : 0;
+            int x = np;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(x, off, 64);
+                if (tid >= off) x += o;
+            }
+            if (r < B) s_off[r] = run + x - np;
+            run += __shfl(x, 63, 64);
+        }
+        if (tid == 0) s_total = run;
+    }
+    __syncthreads();
+    const int64_t base = *pad_cursor;
+    for (int64_t idx = tid; idx < (int64_t)B * (L - 1); idx += 256) {
+        const int r = (int)(idx / (L - 1)), i = (int)(idx - (int64_t)r * (L - 1));
+        if (i < s_np[r]) {
+            const int64_t k = base + s_off[r] + i;
+            next_draft[(int64_t)r * L + 1 + s_cl[r] + i] = pad_stream[pad_len > 0 ? (k % pad_len) : 0];
+        }
+        packed[idx] = 0ull;                                  // every row has read its slice: ready for the next argmax
+    }
+    if (tid == 0) *pad_cursor = base + s_total;
+}
+
 extern "C" int jf_engine_step(const int64_t *draft, int B, int L, uint64_t *packed, int32_t eos_id, const int32_t *remaining_tokens,
                               int64_t *new_tokens, int64_t *next_draft, const int64_t *pad_stream, int64_t pad_stream_len,
                               int64_t *pad_cursor, jf_engine_row *rows, void *stream) {
@@ -68,6 +142,15 @@ extern "C" int jf_engine_step(const int64_t *draft, int B, int L, uint64_t *pack
     if (!draft || !packed || !remaining_tokens || !new_tokens || !next_draft || !pad_cursor || !rows || (!pad_stream && pad_stream_len > 0))
         return fail(JF_E_INVALID, "jf_engine_step: null pointer");
     hipStream_t s = (hipStream_t)stream;
+    static const bool one_launch = [] { const char *e = getenv("JF_ENGINE_ONE_LAUNCH"); return !(e && e[0] == '0'); }();
+    if (one_launch && B <= ENGINE_ONE_LAUNCH_ROWS && L <= 0xFFFF && ((uintptr_t)rows % 8) == 0) {   // 32-byte records: rsv[1..2] is an aligned 8-byte word
+        static std::atomic<uint32_t> generation{0};
+        uint32_t gen = ++generation;
+        if (gen == 0) gen = ++generation;                       // 0 is what a fresh record holds
+        engine_step_kernel<<<B + 1, 256, 0, s>>>(draft, B, L, (unsigned long long *)packed, eos_id, remaining_tokens, new_tokens, next_draft,
+                                                 pad_stream, pad_stream_len, pad_cursor, rows, gen);
+        return check_launch("engine_step_kernel");
+    }
     engine_rows_kernel<<<B, 64, 0, s>>>(draft, L, (const unsigned long long *)packed, eos_id, remaining_tokens, new_tokens, next_draft, rows);
     engine_pads_kernel<<<1, 256, 0, s>>>(B, L, (unsigned long long *)packed, next_draft, pad_stream, pad_stream_len, pad_cursor, rows);
     return check_launch("engine_step kernels");

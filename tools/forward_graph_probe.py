@@ -9,6 +9,9 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from jacobiforcing_amd.modeling.qwen2 import Qwen2Config, Qwen2Model, Qwen2Weights, StaticKVCache  # noqa: E402
 
+if __import__("os").environ.get("PROBE_TUNED", "1") != "0":
+    from jacobiforcing_amd.tuning import enable_tuned_gemms
+    print("tuned GEMM table:", enable_tuned_gemms(), flush=True)
 dev = torch.device("cuda")
 cfg = Qwen2Config.qwen2_5_coder_7b()
 model = Qwen2Model(cfg, Qwen2Weights(cfg, dev, seed=0))
