@@ -304,6 +304,40 @@ def test_block_list_capacity_is_an_error_not_a_corruption(backend):
         assert res["ret"] == st.ret and res["iters"] == st.iters and res["kv_tokens"] == st.kv_tokens
 
 
+@pytest.mark.gpu
+def test_a_missing_row_is_reported_not_waited_for_forever():
+    """The steppers of the convergence launch wait for their rows inside the launch.  A position whose item never runs (here: its
+    entry of the position list is struck out, so no workgroup writes its slot) must end in JF_E_LAUNCH in that prompt's
+    descriptor after the 2 s wall-clock bound — not in a hung GPU — and the batch must be usable again afterwards."""
+    import time
+    with use_backend("hip"):
+        dev = device_for("hip")
+        V, n = 64, 8
+        prm = ops.MultiblockParams(n=n, K=2, r=0.5, n_gram_pool_size=4, eos_token_id=None, pad_token_id=0)
+        batch = ops.MultiblockBatch(2, prm, dev)
+        rng = np.random.default_rng(5)
+        ids = torch.tensor(rng.integers(1, V, size=(2, n)), dtype=torch.int64)
+        kv = torch.tensor([11, 17], dtype=torch.int32)
+
+        def one_iteration(strike):
+            d = batch.begin(ids, kv)
+            batch.pack(d, compact=True, valid_align=8)
+            logits = torch.randn(batch.valid_index.numel(), V, device=dev)
+            if strike:
+                batch.valid_index[batch.Nvalid - 1] = -1              # the last position of the second prompt gets no item
+            return batch.verify(logits, compacted=True)
+
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with pytest.raises(RuntimeError, match="state machine error"):
+            one_iteration(True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert 1.5 < dt < 10.0, dt
+        d = one_iteration(False)                                      # packed[] was cleared on the error path: a clean step
+        assert not batch.desc_field(d, "error").any() and (batch.desc_field(d, "iters") == 2).all()   # stepped once: the second iteration is next
+
+
 @pytest.mark.parametrize("backend,P", [pytest.param("hostsim", 150, id="hostsim-150"),
                                        pytest.param("hip", 150, id="hip-150", marks=pytest.mark.gpu),
                                        pytest.param("hip", 700, id="hip-700", marks=pytest.mark.gpu)])
