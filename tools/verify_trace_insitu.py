@@ -30,6 +30,11 @@ def main():
     ap.add_argument("--iters", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--scripted", action="store_true")
+    ap.add_argument("--before", choices=["none", "touch-pages", "sweep-other", "reread"], default="none",
+                    help="what runs between the forward and the traced launch: touch-pages = one element per 4 KB of the logits "
+                         "(address translations warm, caches as the forward left them); sweep-other = a read-only pass over an "
+                         "unrelated 1 GB buffer (the producer's dirty lines are written back before the launch); reread = a "
+                         "read-only pass over the logits themselves")
     a = ap.parse_args()
     lib = _native.lib()
     if not hasattr(lib, "jf_exp_read_vtrace"):
@@ -48,11 +53,19 @@ def main():
     if a.scripted:
         dec.logits_hook = ScriptedAcceptance(cfg.vocab_size, robust_pct=82, vocab_hi=vocab_hi)
     rows, steps, flagged, pred = [], [], [], {}
+    other = torch.zeros(1 << 29, dtype=torch.bfloat16, device=dev) if a.before == "sweep-other" else None
     state = dict(i=0)
 
     def before(b, flat):
         state["i"] += 1
         if state["i"] > a.warmup:
+            torch.cuda.synchronize()
+            if a.before == "touch-pages":
+                state["sink"] = flat.view(-1)[::2048].float().sum()
+            elif a.before == "sweep-other":
+                state["sink"] = other.sum()
+            elif a.before == "reread":
+                state["sink"] = flat.float().amax()
             torch.cuda.synchronize()
             state["flag"] = (b.desc_dev.cpu().numpy().reshape(P, -1)[:, _native.DESC_FIELDS.index("events")] & _native.EVT_SLOW_NEXT) != 0
             lib.jf_exp_reset_vtrace()
@@ -93,7 +106,7 @@ def main():
     bench.run_steps(dec, prompts, 0, a.warmup + a.iters, seed=1234)
     ops.VERIFY_HOOK = None
     V = cfg.vocab_size
-    print(f"# in situ, {P} prompts per GPU{' (scripted acceptance)' if a.scripted else ''}: us after the first item start")
+    print(f"# in situ, {P} prompts per GPU{' (scripted acceptance)' if a.scripted else ''}, before the launch: {a.before}: us after the first item start")
     print("# valid rows  logits rows   MB    items end   last stepper saw its rows   launch end    stream TB/s   whole TB/s")
     for r in rows:
         mb = r["valid"] * V * 2 / 1e6
