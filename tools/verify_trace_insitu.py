@@ -30,11 +30,11 @@ def main():
     ap.add_argument("--iters", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--scripted", action="store_true")
-    ap.add_argument("--before", choices=["none", "touch-pages", "sweep-other", "reread"], default="none",
+    ap.add_argument("--before", choices=["none", "touch-pages", "sweep-other", "reread", "idle-5ms", "idle-50ms"], default="none",
                     help="what runs between the forward and the traced launch: touch-pages = one element per 4 KB of the logits "
                          "(address translations warm, caches as the forward left them); sweep-other = a read-only pass over an "
                          "unrelated 1 GB buffer (the producer's dirty lines are written back before the launch); reread = a "
-                         "read-only pass over the logits themselves")
+                         "read-only pass over the logits themselves; idle-N = the GPU idles that long before the launch")
     a = ap.parse_args()
     lib = _native.lib()
     if not hasattr(lib, "jf_exp_read_vtrace"):
@@ -66,6 +66,8 @@ def main():
                 state["sink"] = other.sum()
             elif a.before == "reread":
                 state["sink"] = flat.float().amax()
+            elif a.before.startswith("idle"):
+                __import__("time").sleep(0.005 if a.before == "idle-5ms" else 0.05)
             torch.cuda.synchronize()
             state["flag"] = (b.desc_dev.cpu().numpy().reshape(P, -1)[:, _native.DESC_FIELDS.index("events")] & _native.EVT_SLOW_NEXT) != 0
             lib.jf_exp_reset_vtrace()
