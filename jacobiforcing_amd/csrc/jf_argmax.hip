@@ -58,7 +58,7 @@ static int64_t pick_chunk(int64_t gran, int64_t R, int64_t V, int64_t target_ite
 // kernel is launch/ramp bound and 4-wave workgroups sharing a chunk (best vector kept in registers, one item per ~64 KB,
 // 256..1024 items) are 5-20 % faster.  Non-temporal loads from 60 MB up, plain loads below.
 // Inside the fused verify launch (jf_mb_verify) the 4-wave workgroups win at every size (340 MB in the bench: 69 us against
-// 72.5 us per-wavefront, flat from 512 to 3072 items, profiles/verify_knobs_r02.txt): one arrival per workgroup, not four.
+// 72.5 us per-wavefront, flat from 512 to 3072 items, profiles/verify_knobs_r02.txt): one result per workgroup, not four.
 int argmax_plan(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, bool fused, ArgmaxPlan *pl, int64_t max_cpr) {
     const int esz = dtype == JF_F32 ? 4 : 2;
     const int epv = 16 / esz;

@@ -1,8 +1,8 @@
 // jf_argmax_dev.h — device bodies of the vocabulary argmax (a2), shared by the stand-alone launches (jf_argmax.hip) and
-// the fused verify launch (jf_multiblock.hip: the same items followed by a per-prompt arrival count).
+// the fused verify launch (jf_multiblock.hip: the same items, each storing its result into a slot of its own).
 //
 // 16 B per lane per load, eight independent loads in flight per lane, one compare chain per 16-byte vector (FastTrack,
-// jf_common.h), wave shuffles, one 64-bit atomicMax per (row, chunk).  NT selects non-temporal loads: better for streams
+// jf_common.h), wave shuffles, one 64-bit atomicMax (stand-alone launches) or store (fused launch) per (row, chunk).  NT selects non-temporal loads: better for streams
 // that do not fit the Infinity Cache, 3 % worse below ~60 MB (profiles/argmax_nt_keepv_ab_r01.txt) — chosen per launch.
 #ifndef JF_ARGMAX_DEV_H
 #define JF_ARGMAX_DEV_H
