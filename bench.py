@@ -325,6 +325,9 @@ def vs_ar_section(model, cfg, prm, tuned, vocab_hi, robust, warmup: int = 8, ste
     return dict(vs_ar=j_tps / ar_tps, jacobi_tokens_per_s=j_tps, ar_tokens_per_s=ar_tps,
                 tokens_per_forward=r["tokens"] / max(r["iterations"], 1), verified=verify_scripted(hook, r["stats"], prompt),
                 jacobi_ms_per_step=ms, ar_ms_per_token=1e3 / ar_tps,
+                # the checkpoint-independent part of the ratio: what one Jacobi iteration costs in AR steps; the speed-up at any
+                # acceptance rate is tokens_per_forward / this (derived, e.g. at the reference's 4.1 tokens/forward)
+                iteration_cost_in_ar_steps=ms * ar_tps / 1e3, implied_vs_ar_at_4_1_tokens_per_forward=4.1 / (ms * ar_tps / 1e3),
                 split_us={"forward": ms * 1e3 - body - idle, "loop_body": body, "gpu_idle_behind_body": idle},
                 note="batch 1, scripted acceptance (a trained Jacobi-Forcing checkpoint's regime; the reference reports 3.9-4.0x at "
                      "4.0-4.1 tokens/forward); forward = step minus the HIP-event loop body and the idle gap behind it")
