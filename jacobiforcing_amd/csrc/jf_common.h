@@ -69,11 +69,17 @@ struct DevLanes {
         const unsigned long long m = __ballot(pred);
         return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
     }
-    // Mailbox hand-off: every lane's earlier stores, then one word the host polls.  The mailbox is coherent (uncached)
-    // host memory — its stores go straight to the fabric — so draining this wavefront's memory counter orders them in
-    // front of the sequence word.  A system-scope RELEASE fence instead also writes back the L2 (the state blocks the
-    // convergence launch has just stored, the forward inputs being packed): +7 us on the pack launch and on the host's
-    // wake-up (profiles/verify_release_ab_r03.txt); -DJF_EXP_PUBLISH_FENCE builds that variant.
+    // Mailbox hand-off: stores the host will read (mail), then one word the host polls (publish).  The mailbox is coherent host
+    // memory, but a PLAIN store to it may sit in this XCD's L2 until the kernel ends: with plain stores and a drained memory
+    // counter the host saw the sequence word before the tables in front of it in 9 of 10 rounds of tools/mailbox_stress.py
+    // (the tables of a launch that also stamps the mailbox: jf_mb_loop_begin and the non-fused pack).  mail() therefore writes
+    // THROUGH (system-scope store); the drained counter then does order them in front of the sequence word (0 stale reads in
+    // 780 000 rounds, profiles/mailbox_order_r03.txt).  A system-scope RELEASE fence instead would also write back everything
+    // else this L2 holds (the state blocks the convergence launch has just stored, the forward inputs being packed):
+    // +7 us on the pack launch and on the host's wake-up (profiles/verify_release_ab_r03.txt); -DJF_EXP_PUBLISH_FENCE builds it.
+    __device__ __forceinline__ void mail(int32_t *word, int32_t v) const {
+        __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __device__ __forceinline__ void publish(int32_t *word, int32_t v) const {
 #ifdef JF_EXP_PUBLISH_FENCE
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");

@@ -882,10 +882,10 @@ JF_HD void drv_call_end(M &m, const LoopDev &lp, int p, jf_mb_desc *d) {
 // final — while the prompts' own lanes write the forward's inputs.  copy_tables = false: every
 // prompt's stepper has put its own descriptor / driver record into the mailbox (the fused launch), only the header is
 // written here.  The sequence number goes last, behind a system-scope release.
-JF_HD void mb_fin_record(const int32_t *D, int32_t *fin, int j) {
+JF_HD int32_t mb_fin_value(const int32_t *D, int j) {        // word j of a prompt's driver record in the mailbox
     const int slot = j == 0 ? D_STOP : j == 1 ? D_CALLS : j == 2 ? D_ITERS : j == 3 ? D_NEW : j == 4 ? D_FIN_RET_LEN
                    : j == 5 ? D_FIN_NEXT : j == 6 ? D_FIN_ITERS : D_FIN_OFF;
-    fin[j] = D[slot];
+    return D[slot];
 }
 template <class Lanes>
 JF_HD void mb_publish_body(Lanes lanes, int P, const jf_mb_desc *desc, const LoopDev &lp, bool copy_tables) {
@@ -906,20 +906,22 @@ JF_HD void mb_publish_body(Lanes lanes, int P, const jf_mb_desc *desc, const Loo
     const int dints = (int)(sizeof(jf_mb_desc) / 4);
     if (copy_tables) {
         const int32_t *src = (const int32_t *)desc;
-        for (int i = lanes.lane(); i < P * dints; i += lanes.count()) mb[JF_MB_MAILBOX_HDR + i] = src[i];
+        for (int i = lanes.lane(); i < P * dints; i += lanes.count()) lanes.mail(mb + JF_MB_MAILBOX_HDR + i, src[i]);
         if (lp.drv) {
             int32_t *fin = mb + JF_MB_MAILBOX_HDR + P * dints;
             for (int i = lanes.lane(); i < P * JF_MB_FIN_INTS; i += lanes.count()) {
                 const int q = i / JF_MB_FIN_INTS;
-                mb_fin_record(lp.drv + (int64_t)q * lp.drv_ints, fin + q * JF_MB_FIN_INTS, i - q * JF_MB_FIN_INTS);
+                lanes.mail(fin + i, mb_fin_value(lp.drv + (int64_t)q * lp.drv_ints, i - q * JF_MB_FIN_INTS));
             }
         }
     }
     if (lanes.lane() == 0) {
         const int tpad = rtot ? imin(align_up(tmax, lp.t_align), imax(lp.t_cap, tmax)) : 0;
-        mb[JF_MB_RTOT] = rtot; mb[JF_MB_RMAIN] = rmain; mb[JF_MB_TPAD] = tpad; mb[JF_MB_TMAX] = tmax;
-        mb[JF_MB_NVALID] = nvalid; mb[JF_MB_NVALID_PAD] = align_up(nvalid, lp.valid_align);
-        mb[JF_MB_NDONE] = ndone; mb[JF_MB_MAXKV] = maxkv; mb[JF_MB_ERROR] = err_p; mb[JF_MB_ACCEPTED] = acc; mb[JF_MB_NCALL_END] = nend;
+        lanes.mail(mb + JF_MB_RTOT, rtot); lanes.mail(mb + JF_MB_RMAIN, rmain); lanes.mail(mb + JF_MB_TPAD, tpad);
+        lanes.mail(mb + JF_MB_TMAX, tmax); lanes.mail(mb + JF_MB_NVALID, nvalid);
+        lanes.mail(mb + JF_MB_NVALID_PAD, align_up(nvalid, lp.valid_align)); lanes.mail(mb + JF_MB_NDONE, ndone);
+        lanes.mail(mb + JF_MB_MAXKV, maxkv); lanes.mail(mb + JF_MB_ERROR, err_p); lanes.mail(mb + JF_MB_ACCEPTED, acc);
+        lanes.mail(mb + JF_MB_NCALL_END, nend);
     }
     lanes.publish(mb + JF_MB_SEQ, lp.seq);
 }

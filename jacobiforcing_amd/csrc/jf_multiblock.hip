@@ -337,11 +337,11 @@ __device__ __forceinline__ void verify_stepper(const VerifyArgs &a, int p, int32
     if (dg && threadIdx.x < DINTS) {
         const int v = wb > 0 ? ((const int32_t *)s_desc)[threadIdx.x] : ((const int32_t *)dg)[threadIdx.x];
         if (wb > 0) ((int32_t *)dg)[threadIdx.x] = v;
-        if (mail) lp.mailbox[JF_MB_MAILBOX_HDR + p * DINTS + threadIdx.x] = v;
+        if (mail) DevLanes{}.mail(lp.mailbox + JF_MB_MAILBOX_HDR + p * DINTS + threadIdx.x, v);   // written through: see DevLanes::mail
     }
     if (mail && lp.drv && threadIdx.x >= 32 && threadIdx.x < 32 + JF_MB_FIN_INTS)
-        mb_fin_record(lp.drv + (int64_t)p * lp.drv_ints, lp.mailbox + JF_MB_MAILBOX_HDR + a.P * DINTS + p * JF_MB_FIN_INTS,
-                      threadIdx.x - 32);
+        DevLanes{}.mail(lp.mailbox + JF_MB_MAILBOX_HDR + a.P * DINTS + p * JF_MB_FIN_INTS + (threadIdx.x - 32),
+                        mb_fin_value(lp.drv + (int64_t)p * lp.drv_ints, threadIdx.x - 32));
     JF_VSTAMP(p, 6);
     JF_VSTAMP(p, 7);
 }

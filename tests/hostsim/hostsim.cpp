@@ -21,6 +21,7 @@ struct HostLanes {
     int first_true(bool pred) const { return pred ? 0 : 1; }
     int count_true(bool pred) const { return pred ? 1 : 0; }
     int prefix_count(bool) const { return 0; }
+    void mail(int32_t *word, int32_t v) const { *word = v; }
     void publish(int32_t *word, int32_t v) const { *word = v; }
 };
 

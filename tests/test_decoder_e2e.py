@@ -187,6 +187,36 @@ def test_compacted_logits_equal_rectangular(backend):
         assert sum(r[0] for r in out[True][2]) < sum(r[0] for r in out[False][2])
 
 
+@pytest.mark.gpu
+def test_mailbox_tables_are_visible_when_the_sequence_word_is():
+    """jf_mb_loop_begin copies every prompt's descriptor into the mailbox and stamps it in ONE launch: when the host sees the
+    stamp, the table must be there.  (Plain stores to the coherent mailbox were overtaken by the stamp in 9 of 10 rounds:
+    they may sit in the L2 until the kernel ends; profiles/mailbox_order_r03.txt.)  The slots are pre-filled with a value no
+    descriptor holds, so a table that has not landed cannot look right."""
+    import time
+    with use_backend("hip"):
+        P, n = 48, 16
+        prm = ops.MultiblockParams(n=n, K=2, r=0.85, n_gram_pool_size=4, eos_token_id=None, pad_token_id=0)
+        batch = ops.MultiblockBatch(P, prm, "cuda")
+        kvl = torch.zeros(P, dtype=torch.int32, device="cuda")
+        lp = ops.MultiblockLoop(batch, kv_len=kvl, t_cap=64, t_align=1, valid_align=8, compact=True, cand_rows=3, order=1,
+                                max_seq_len=1 << 20)
+        fB, fT, fkv = (N.DESC_FIELDS.index(k) for k in ("B", "T", "kv_len"))
+        g = np.random.default_rng(1)
+        stale = rounds = 0
+        t0 = time.time()
+        while time.time() - t0 < 2.0:
+            ids = torch.from_numpy(g.integers(1, 1000, size=(P, n))).cuda()
+            kv = g.integers(5, 500, size=P).astype(np.int32)
+            lp.mailbox[N.MB_MAILBOX_HDR:N.MB_MAILBOX_HDR + P * N.DESC_INTS] = -7
+            s = lp.begin(ids, torch.from_numpy(kv))
+            ok = (s.d[:, fB] == 1).all() and (s.d[:, fT] == n).all() and (s.d[:, fkv] == kv).all() and s.Rtot == P
+            stale += 0 if ok else 1
+            rounds += 1
+        lp.close()
+        assert rounds > 500 and stale == 0, (rounds, stale)
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_position_list_puts_long_steps_first(backend):
     """The loop's pack step orders the position list (= the logits rows, = the stream of the convergence launch) with the
