@@ -89,8 +89,20 @@ def test_loop_fuzz_vs_oracle(seed, backend):
         dec = MultiblockJacobiDecoder(model, P, prm, max_seq_len=512, resident=resident, t_align=t_align, logits_hook=hook)
         draw_seed = int(rng.integers(1, 1 << 20))
         failed = None
+        stream = seed % 3 == 0              # every third seed through the streaming generator (chunks per finished call)
+        chunks = {p: [] for p in range(P)}
         try:
-            stats, _, iters = dec.generate(prompts, max_new_tokens=max_new, max_calls=max_calls, seed=draw_seed)
+            if stream:
+                it = dec.generate_stream(prompts, max_new_tokens=max_new, max_calls=max_calls, seed=draw_seed)
+                while True:
+                    try:
+                        p_, toks = next(it)
+                        chunks[p_] += toks
+                    except StopIteration as stop:
+                        stats, _, iters = stop.value
+                        break
+            else:
+                stats, _, iters = dec.generate(prompts, max_new_tokens=max_new, max_calls=max_calls, seed=draw_seed)
         except RuntimeError as e:
             # K >= 3 only: the reference's own crash at MB:482, or its block counters running away (Q3/Q4) until a row outgrows
             # the forward's capacity — a fixed capacity here, an ever longer row there: nothing to compare
@@ -124,5 +136,6 @@ def test_loop_fuzz_vs_oracle(seed, backend):
             assert stats[p].token_ids == ref["tokens"], f"prompt {p}"
             assert (stats[p].calls, stats[p].total_iterations, stats[p].stop_reason) == (ref["calls"], ref["iters"], ref["stop"]), p
             assert int(dec.kv_len_host[p]) == ref["kv_len"]
+            assert not stream or chunks[p] == ref["tokens"], f"streamed chunks of prompt {p}"
         tpf = sum(len(s.token_ids) for s in stats) / max(sum(s.total_iterations for s in stats), 1)
         assert tpf > 1.2 or robust < 70, tpf                        # the sweep runs where several tokens are accepted per forward
