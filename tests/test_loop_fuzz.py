@@ -84,7 +84,9 @@ def test_loop_fuzz_vs_oracle(seed, backend):
     use_eos = bool(rng.integers(0, 3) == 0)                       # one in three with an EOS id the planted sequence can hit
     with use_backend(backend):
         dev = device_for(backend)
-        model = tiny_model(dev, seed=seed)
+        # a vocabulary whose rows are not 16-byte multiples takes the convergence check as its two launches (and the pack
+        # launch behind them copies the descriptor tables into the mailbox itself): one seed in four
+        model = tiny_model(dev, seed=seed, vocab=381 if seed % 4 == 1 else 384)
         V = model.cfg.vocab_size
         eos = int(rng.integers(0, 40)) if use_eos else None        # one id of the 382 the planted sequence draws from: a prompt in five meets it
         prm = ops.MultiblockParams(n=n, K=K, r=r, lookahead_start_ratio=look, n_gram_pool_size=pool, eos_token_id=eos,
