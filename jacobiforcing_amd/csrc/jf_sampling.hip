@@ -424,7 +424,7 @@ struct RsWs {                                     // carve-up of the step worksp
     unsigned long long *pick;                     // [rows] (gen << 32) | bits of the uniform that counts (chain workgroup -> bonus workgroup)
     uint32_t *segdone;                            // [rows, RS_SEG] gen: this segment's sum is stored
     uint32_t *bonusdone;                          // [rows] gen: the row's bonus token is stored
-    uint32_t *acceptdone;                         // [4]   gen: the accept workgroup has written every row record
+    uint32_t *acceptdone;                         // [4]   gen: [0] the accept workgroup has written every row record, [1] the chain workgroup every draw count
 };
 static inline size_t rs_ws_bytes(int64_t rows) {
     const size_t r = (size_t)((rows + 3) / 4 * 4);
@@ -765,6 +765,30 @@ __device__ __forceinline__ void batched_for(int64_t n, int tid, int nthreads, Lo
     }
 }
 
+#ifdef JF_EXP_RS_TRACE
+// experiment build (tools/microbench_rs_step.py --trace): wall-clock stamps (100 MHz) of the one-launch step, min / max per role
+__device__ unsigned long long g_rstrace[32];
+__device__ unsigned long long g_rsrow[8 * 128];   // per row: flag stored, first segment sum saw it, its sums ready in the chain, uniform handed out
+#define RS_ROWSTAMP(k, b) do { if ((b) < 128) g_rsrow[(k) * 128 + (b)] = (unsigned long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define RS_STAMP_MIN(k) do { if (threadIdx.x == 0) atomicMin(&g_rstrace[k], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
+#define RS_STAMP_MAX(k) do { if (threadIdx.x == 0) atomicMax(&g_rstrace[k], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
+extern "C" __attribute__((visibility("default"))) int jf_exp_rs_trace(unsigned long long *out, int reset) {
+    if (reset) {
+        unsigned long long init[32];
+        for (int i = 0; i < 32; ++i) init[i] = (i & 1) ? 0ull : ~0ull;      // even slots take minima, odd slots maxima
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_rstrace), init, sizeof(init));
+    }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rstrace), sizeof(unsigned long long) * 32);
+}
+extern "C" __attribute__((visibility("default"))) int jf_exp_rs_rows(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rsrow), sizeof(unsigned long long) * 8 * 128);
+}
+#else
+#define RS_STAMP_MIN(k) do { } while (0)
+#define RS_STAMP_MAX(k) do { } while (0)
+#define RS_ROWSTAMP(k, b) do { } while (0)
+#endif
+
 constexpr int RS_STAGE = 6144;      // floats of p_draft / uniforms staged in LDS by the accept scan (B * (L-1) <= this, else global)
 constexpr int RS_ROWS_LDS = 2048;   // rows whose scan results are kept in LDS (half of it in the chain kernel)
 
@@ -827,12 +851,15 @@ __device__ __forceinline__ void rs_accept_body(const int64_t *draft, int B, int 
             if (lane == 0) {
                 if constexpr (STAGED) s_res[b] = nacc | (eos << 15) | ((rej + 1) << 16);
                 else { rows[b].n_committed = nacc; rows[b].eos = eos; rows[b].reject_pos = rej; }
-                if constexpr (SIG)
+                if constexpr (SIG) {
                     __hip_atomic_store(w.flag + (int64_t)b * RS_FLAG_STRIDE, ((unsigned long long)gen << 32) | (unsigned long long)(rej + 2), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
+                    RS_ROWSTAMP(0, b);
+                }
             }
             used_total += used;
         }
+        if constexpr (SIG) RS_STAMP_MAX(15);                        // 15: the accept walk has decided the last row
     }
     __syncthreads();
     __threadfence_block();
@@ -859,7 +886,8 @@ __device__ __forceinline__ void rs_accept_body(const int64_t *draft, int B, int 
         jf_rs_row &rw = rows[b];
         rw.n_committed = nacc; rw.eos = eos; rw.reject_pos = rej;
         rw.n_uniforms = rej >= 0 ? rej + 1 : nacc;                  // one uniform per tested position (JDN:329)
-        rw.n_bonus_draws = 0; rw.n_pads = 0; rw.active_next = 0;
+        if (!SIG || rej < 0) rw.n_bonus_draws = 0;                  // one-launch step: the chain workgroup owns a rejected row's count
+        rw.n_pads = 0; rw.active_next = 0;
         w.sel_row[b] = rej >= 0 ? b * W + rej : -1;
         w.avoid[b] = (int32_t)avoid;
         w.pick_u[b] = -1.f;
@@ -1096,19 +1124,23 @@ __global__ __launch_bounds__(256) void rs_finish_kernel(int B, int L, unsigned l
 // ------------------------------------------------------------------------------------------------
 // The whole step as ONE launch (batches of at most RS_FUSED_ROWS rows whose accept tests fit RS_FUSED_STAGE):
 //   block 0                    the accept walk (rs_accept_body): announces every row the moment it is decided
-//   blocks 1 .. B*RS_SEG       the segment sums of row (blk-1)/RS_SEG: wait for that row's flag, sum if it was rejected
-//   block  B*RS_SEG + 1        the chain: waits for every flag and every rejected row's sums, turns them into CDF intervals in
-//                              parallel, counts the draws of all rows in stream order on LDS (one wavefront), hands every
-//                              rejected row the uniform that counts
-//   blocks .. + B              the bonus draw of row b: ONE inverse-CDF walk (or the masked argmax) for the uniform it was handed
-//   last block                 waits for the accept workgroup and every bonus word, then rs_finish_body
-// A workgroup only ever waits for workgroups with LOWER block ids (dispatched before it), so every wait ends whatever the
-// residency; all hand-off words carry the call's generation number (nothing to re-zero, no stale reads); payloads cross
+//   block 1                    the chain: rows become CDF intervals as their flags and sums arrive (wavefronts 1-3, a thread per
+//                              row), wavefront 0 counts the draws in stream order on LDS and hands every rejected row the
+//                              uniform that counts as soon as the rows before it are counted
+//   block 2                    waits for the accept workgroup, the chain and every bonus word, then rs_finish_body
+//   blocks 3 .. B+2            the bonus draw of row b: ONE inverse-CDF walk (or the masked argmax) for the uniform it was handed
+//   blocks B+3 ..              the segment sums of row (blk-B-3)/RS_SEG: wait for that row's flag, sum if it was rejected
+// The B + 3 workgroups that wait for others come FIRST, the 16 B short ones last: with the roles in pipeline order the device
+// filled up with segment-sum workgroups spinning on the flags of late rows, and the chain / bonus workgroups were not even
+// dispatched before those had left (in-kernel stamps: first uniform handed out at 56 us of a launch whose accept walk ends at
+// 17 us).  The waiting workgroups number at most RS_FUSED_ROWS + 3 — far fewer than the device keeps resident (at least one
+// per CU) — and the segment sums only wait for block 0, so they always find a slot and everything they are waited for by
+// comes to pass; all hand-off words carry the call's generation number (nothing to re-zero, no stale reads); payloads cross
 // workgroups as agent-scope atomics (a release fence per producer would write back an L2 full of freshly written logits —
 // profiles/verify_release_ab_r03.txt).  Replaces four dependent launches (accept 19 + rowsum 21 + bonus 34 + finish 14 us
 // at 64 rejected rows, profiles/rs_step_r03.txt).
 // ------------------------------------------------------------------------------------------------
-constexpr int RS_FUSED_ROWS = 128;      // rows of a one-launch step
+constexpr int RS_FUSED_ROWS = 128;      // rows of a one-launch step (<= 192: the chain workgroup gives every row a thread of wavefronts 1-3)
 constexpr int RS_FUSED_STAGE = 4096;    // B * (L-1) accept tests staged in LDS by its accept workgroup
 struct RsFusedArgs {
     const void *logits; int64_t V, row_stride; const int64_t *draft; int B, L;
@@ -1134,80 +1166,106 @@ __global__ __launch_bounds__(256) void rs_step_fused_kernel(RsFusedArgs a) {
     const int B = a.B, L = a.L, W = a.L - 1;
     const RsWs &w = a.w;
     if (blk == 0) {
+        RS_STAMP_MIN(0);                                             // 0: launch start (accept workgroup)
         rs_accept_body<true, true, RS_FUSED_STAGE, RS_FUSED_ROWS>(a.draft, B, L, a.p_draft, a.eos_id, a.u_stream, a.u_len, a.u_cursor,
                                                                   a.committed, a.rows, w, a.gen);
+        RS_STAMP_MAX(1);                                             // 1: accept workgroup done (records + accept-done word)
         return;
     }
-    if (blk <= B * RS_SEG) {                                        // ---- segment sums
-        const int item = (blk - 1) / RS_SEG, seg = (blk - 1) % RS_SEG;
+    if (blk >= B + 3) {                                             // ---- segment sums (the many short workgroups come last)
+        const int item = (blk - B - 3) / RS_SEG, seg = (blk - B - 3) % RS_SEG;
         __shared__ int s_rej;
         if (tid == 0) s_rej = (int)(uint32_t)rs_wait_flag(w.flag + (int64_t)item * RS_FLAG_STRIDE, a.gen) - 2;
         __syncthreads();
         const int rej = s_rej;
         if (rej < 0) return;
+        if (tid == 0 && seg == 0) RS_ROWSTAMP(1, item);
         rs_rowsum_body<DT, true>(a.logits, a.V, a.row_stride, a.row_max, a.row_sumexp, a.t, w, item, seg, item * W + rej,
                                  a.draft[(int64_t)item * L + rej + 1], a.gen);
+        if (tid == 0 && seg == 0) RS_ROWSTAMP(4, item);
         return;
     }
-    if (blk == B * RS_SEG + 1) {                                    // ---- the chain: draws of all rows in stream order
+    if (blk == 1) {                                                 // ---- the chain: draws of all rows in stream order
+        // Wavefronts 1-3 turn rows into CDF intervals as their flags and segment sums come in (a thread per row); wavefront 0
+        // counts the draws in row order on LDS and hands every rejected row its uniform the moment the rows before it are
+        // counted — the walk of row i starts ~7 us after row i was decided, not after the last row's sums.
         __shared__ double s_tot[RS_FUSED_ROWS], s_lo[RS_FUSED_ROWS], s_hi[RS_FUSED_ROWS];   // s_tot < 0: not rejected
-        __shared__ int s_rejpos[RS_FUSED_ROWS], s_draws[RS_FUSED_ROWS];
-        __shared__ float s_u[RS_MAX_TRIES * RS_FUSED_ROWS], s_ufv[RS_FUSED_ROWS];
-        __shared__ int s_nrej;
-        if (tid == 0) s_nrej = 0;
-        __syncthreads();
-        int mine = 0;
-        for (int i = tid; i < B; i += 256) {
-            const int rp = (int)(uint32_t)rs_wait_flag(w.flag + (int64_t)i * RS_FLAG_STRIDE, a.gen) - 2;
-            s_rejpos[i] = rp; s_draws[i] = 0; s_ufv[i] = -1.f;
-            mine += rp >= 0 ? 1 : 0;
+        __shared__ int s_ready[RS_FUSED_ROWS];
+        __shared__ float s_u[RS_MAX_TRIES * RS_FUSED_ROWS];
+        const int64_t bc0 = *a.b_cursor;
+        const bool staged = a.b_len < 0x7FFFFFFFll;
+        for (int i = tid; i < B; i += 256) s_ready[i] = 0;
+        if (staged) {                                                // every entry the walk can touch: RS_MAX_TRIES per row
+            const int bl = (int)a.b_len, bb = (int)(bc0 % a.b_len);
+            batched_for<8, float>(RS_MAX_TRIES * B, tid, 256, [&](int64_t i) { return a.b_stream[(bb + (int)i) % bl]; }, [&](int64_t i, float v) { s_u[i] = v; });
         }
-        if (mine) atomicAdd(&s_nrej, mine);
         __syncthreads();
-        const int nrej = s_nrej;
-        if (nrej > 0) {
-            for (int k = tid; k < B * RS_SEG; k += 256)
-                if (s_rejpos[k / RS_SEG] >= 0) rs_wait_word(w.segdone + k, a.gen);
-            __syncthreads();
-            for (int i = tid; i < B; i += 256) {
-                double t_ = -1.0, lo_ = 0.0, hi_ = 0.0;
-                if (s_rejpos[i] >= 0) rs_interval<true>(w, i, a.V, Elem<DT>::EPV, t_, lo_, hi_, a.draft[(int64_t)i * L + s_rejpos[i] + 1]);
-                s_tot[i] = t_; s_lo[i] = lo_; s_hi[i] = hi_;
-            }
-            const int64_t bc0 = *a.b_cursor;
-            const int win = RS_MAX_TRIES * nrej;                     // stream entries the walk can touch
-            const bool staged = a.b_len < 0x7FFFFFFFll;
-            if (staged) {
-                const int bl = (int)a.b_len, bb = (int)(bc0 % a.b_len);
-                batched_for<8, float>(win, tid, 256, [&](int64_t i) { return a.b_stream[(bb + (int)i) % bl]; }, [&](int64_t i, float v) { s_u[i] = v; });
-            }
-            __syncthreads();
-            if (tid < 64) {
-                int off = 0;
-                for (int i = 0; i < B; ++i) {
-                    const double t_ = s_tot[i];
-                    if (t_ < 0.0) continue;
-                    float uf;
-                    const int o = off;
-                    const int draws = rs_count_draws([&](int tr) { return staged ? s_u[o + tr] : a.b_stream[(bc0 + o + tr) % a.b_len]; }, t_, s_lo[i], s_hi[i], tid, &uf);
-                    if (tid == 0) { s_draws[i] = draws; s_ufv[i] = uf; }
-                    off += draws;
+        if (tid >= 64) {
+            // a thread per row (B <= RS_FUSED_ROWS <= 192), every lane polling for ITS row without blocking the others of its
+            // wavefront: a lane that waited in a loop of its own would hold all 64 rows back until the last of them is in
+            const int i = tid - 64;
+            bool fin = i >= B;
+            int rp = -3;                                             // -3: the row's flag has not been seen yet
+            for (;;) {                                               // wave-uniform exit (the ballot below): with a per-lane `while (!fin)` the
+                if (!fin) {                                          // compiler sinks a lane's publishing behind the loop, i.e. behind ALL 64 rows
+                if (rp == -3) {
+                    const unsigned long long v = __hip_atomic_load(w.flag + (int64_t)i * RS_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint32_t)(v >> 32) == a.gen) rp = (int)(uint32_t)v - 2;
                 }
+                if (rp != -3) {
+                    bool sums_in = true;
+                    if (rp >= 0)
+                        for (int sg = 0; sg < RS_SEG; ++sg)
+                            sums_in &= __hip_atomic_load(w.segdone + (int64_t)i * RS_SEG + sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.gen;
+                    if (sums_in) {
+                        double t_ = -1.0, lo_ = 0.0, hi_ = 0.0;
+                        if (rp >= 0) rs_interval<true>(w, i, a.V, Elem<DT>::EPV, t_, lo_, hi_, a.draft[(int64_t)i * L + rp + 1]);
+                        s_tot[i] = t_; s_lo[i] = lo_; s_hi[i] = hi_;
+                        __hip_atomic_store(&s_ready[i], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        RS_ROWSTAMP(2, i);
+                        fin = true;
+                    }
+                }
+                }
+                if (__ballot(!fin) == 0ull) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            return;
+        }
+        // wavefront 0: one look at the ready words of the next 64 rows (a lane each), then every row of the leading run of ready
+        // ones without polling again — a poll per row (an acquire on LDS each) was 0.7 us per row, 46 us for 64 rows
+        int off = 0, i = 0;
+        while (i < B) {
+            const int r = i + tid;
+            const bool rdy = r < B && __hip_atomic_load(&s_ready[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+            const unsigned long long nr = ~__ballot(rdy);
+            const int run = nr ? __builtin_ctzll(nr) : 64;           // rows i .. i + run - 1 are ready
+            if (run == 0) { __builtin_amdgcn_s_sleep(1); continue; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // their intervals were stored before their ready words
+            for (const int end = i + run; i < end; ++i) {
+                const double t_ = s_tot[i];
+                if (t_ < 0.0) continue;
+                float uf;
+                const int o = off;
+                const int draws = rs_count_draws([&](int tr) { return staged ? s_u[o + tr] : a.b_stream[(bc0 + o + tr) % a.b_len]; }, t_, s_lo[i], s_hi[i], tid, &uf);
+                if (tid == 0) {                                      // the count for the finishing workgroup (ordered by chain-done below),
+                    __hip_atomic_store(&a.rows[i].n_bonus_draws, draws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(w.pick + i, ((unsigned long long)a.gen << 32) | (unsigned long long)__float_as_uint(uf), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);   // the uniform for the row's bonus workgroup: a self-contained word
+                    RS_ROWSTAMP(3, i);
+                }
+                off += draws;
             }
         }
-        if (tid == 0) rs_wait_word(w.acceptdone, a.gen);             // the accept workgroup's row records are final: ours go on top
-        __syncthreads();
-        for (int i = tid; i < B; i += 256)
-            if (s_rejpos[i] >= 0) __hip_atomic_store(&a.rows[i].n_bonus_draws, s_draws[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the draw counts are performed before the words that release the rows
-        for (int i = tid; i < B; i += 256)
-            if (s_rejpos[i] >= 0)
-                __hip_atomic_store(w.pick + i, ((unsigned long long)a.gen << 32) | (unsigned long long)__float_as_uint(s_ufv[i]), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+        RS_STAMP_MAX(7);                                             // 7: last row handed its uniform
+        if (tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every count is performed before the word that says so
+            __hip_atomic_store(w.acceptdone + 1, a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         return;
     }
-    if (blk <= B * RS_SEG + 1 + B) {                                // ---- bonus draw of row b
-        const int b = blk - 2 - B * RS_SEG;
+    if (blk >= 3) {                                                 // ---- bonus draw of row b (3 <= blk < B + 3 here)
+        const int b = blk - 3;
         __shared__ RsPickShared sh;
         __shared__ int s_rej;
         __shared__ float s_uf;
@@ -1218,6 +1276,7 @@ __global__ __launch_bounds__(256) void rs_step_fused_kernel(RsFusedArgs a) {
         }
         __syncthreads();
         const int rej = s_rej;
+        if (tid == 0) RS_ROWSTAMP(5, b);
         if (rej >= 0) {
             const int64_t r = (int64_t)b * W + rej;
             const RsRow row = rs_make_row<DT>(a.logits, r, a.V, a.row_stride, a.t, a.row_max[r], a.row_sumexp[r]);
@@ -1229,15 +1288,18 @@ __global__ __launch_bounds__(256) void rs_step_fused_kernel(RsFusedArgs a) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(w.bonusdone + b, a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (tid == 0) RS_ROWSTAMP(6, b);
         return;
     }
-    // ---- last block: everything is in, finish (JDN:444-466 / 619-638)
-    if (tid == 0) rs_wait_word(w.acceptdone, a.gen);
+    // ---- block 2: waits until everything is in, then finishes (JDN:444-466 / 619-638)
+    if (tid == 0) { rs_wait_word(w.acceptdone, a.gen); rs_wait_word(w.acceptdone + 1, a.gen); }   // accept records, the chain's draw counts
     for (int i = tid; i < B; i += 256) rs_wait_word(w.bonusdone + i, a.gen);
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    RS_STAMP_MIN(12);                                                // 12: finishing workgroup starts
     rs_finish_body(B, L, a.packed, a.eos_id, a.remaining, a.u_cursor, a.b_cursor, a.pad_stream, a.pad_len, a.pad_cursor, a.committed,
                    a.next_draft, a.rows);
+    RS_STAMP_MAX(13);                                                // 13: finished
 }
 
 // ------------------------------------------------------------------------------------------------

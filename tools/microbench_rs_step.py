@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--block", type=int, default=32)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--p-hit", type=float, default=0.6)
+    ap.add_argument("--trace", action="store_true", help="in-kernel stamps of the one-launch step (JF_LIB=tools/libjf_exp_rstrace.so)")
     a = ap.parse_args()
     B, L, V = a.batch, a.block, 152064
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -47,6 +48,30 @@ def main():
     torch.cuda.synchronize()
     import numpy as np
     from jacobiforcing_amd import _native as N
+    if a.trace:
+        import ctypes as C
+        lib = N.lib()
+        names = {1: "accept workgroup done", 15: "accept walk decided the last row", 6: "first row handed its uniform", 7: "last row handed its uniform",
+                 12: "finishing workgroup starts", 13: "finished"}
+        acc = {k: [] for k in names}
+        for i in range(8):
+            lib.jf_exp_rs_trace(None, 1)
+            st.step(draft, logits, a.temperature, None, [L] * B, [i * 7, i * 3, 0])
+            torch.cuda.synchronize()
+            buf = (C.c_ulonglong * 32)()
+            lib.jf_exp_rs_trace(buf, 0)
+            t0 = buf[0]
+            for k in names:
+                acc[k].append((buf[k] - t0) / 100.0)
+        rb = (C.c_ulonglong * 1024)()
+        lib.jf_exp_rs_rows(rb)
+        r = np.array(rb[:], dtype=np.float64).reshape(8, 128)
+        print("# last launch, per row: flag stored by the accept walk / segment 0 saw it / segment 0 stored / sums ready in the chain / uniform handed out / bonus workgroup has it / bonus token stored (us)")
+        for b_ in list(range(0, B, 8)) + [B - 1]:
+            print(f"#   row {b_:3d}: " + "  ".join(f"{(r[k, b_] - t0) / 100.0:7.1f}" for k in (0, 1, 4, 2, 3, 5, 6)))
+        print("# in-kernel stamps of rs_step_fused_kernel, us after the accept workgroup started (mean of 8 launches):")
+        for k in sorted(names, key=lambda k: np.mean(acc[k])):
+            print(f"#   {np.mean(acc[k]):7.1f}  {names[k]}")
     f = N.RS_FIELDS.index
     rej = int((rows[:, f("reject_pos")] >= 0).sum())
     print(f"B={B} L={L} V={V} {a.dtype} T={a.temperature}: {ev[0].elapsed_time(ev[1]) / a.iters * 1e3:.1f} us per probs+step+readback "
