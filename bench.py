@@ -269,7 +269,9 @@ def nongreedy_section(model, cfg, weights, tuned, P: int = 64, L: int = 32, temp
         num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
         num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim, max_position_embeddings=cfg.max_position_embeddings,
         rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta, tie_word_embeddings=cfg.tie_word_embeddings,
-        eos_token_id=cfg.eos_token_id, pad_token_id=cfg.pad_token_id, model_type="qwen2")))
+        # EOS handling off, as in the headline window: random weights emit any id, and a request that emits the EOS id is
+        # decoded ALONE afterwards (reference behaviour under ignore_eos, JD:597-602) — 33 extra one-row iterations in one run
+        eos_token_id=-1, pad_token_id=cfg.pad_token_id, model_type="qwen2")))
     ModelRunner.shared_weights = weights
     try:
         llm = LLM(d, tokenizer_path="none", max_model_len=2048, max_num_batched_tokens=65536, max_num_seqs=P)

@@ -27,10 +27,13 @@ def main():
     ap.add_argument("--block-len", type=int, default=32)
     ap.add_argument("--max-tokens", type=int, default=128)
     ap.add_argument("--only", default="", help="substring of the mode name to run")
+    ap.add_argument("--keep-eos", action="store_true", help="keep the EOS id (a request that emits it by chance is decoded alone afterwards)")
     args = ap.parse_args()
     cfg = dict(vocab_size=152064, hidden_size=3584, intermediate_size=18944, num_hidden_layers=28, num_attention_heads=28,
                num_key_value_heads=4, max_position_embeddings=32768, rms_norm_eps=1e-6, rope_theta=1000000.0,
                tie_word_embeddings=False, eos_token_id=151645, pad_token_id=151643, model_type="qwen2")
+    if not args.keep_eos:
+        cfg["eos_token_id"] = -1        # random weights emit any id: without this a run may or may not contain an EOS straggler
     d = tempfile.mkdtemp()
     (Path(d) / "config.json").write_text(json.dumps(cfg))
     enable_tuned_gemms()

@@ -35,4 +35,6 @@ timeout 600 python -m jacobiforcing_amd.drivers.mr_humaneval --synthetic 8 --bat
 timeout 900 python tools/engine_throughput.py --batch 64 --block-len 32 --max-tokens 96 > $O/r3e_engine.txt 2>&1
 for M in "jacobi greedy" "T=0.8"; do PROFILE=1 timeout 600 python tools/engine_throughput.py --batch 64 --block-len 32 --max-tokens 96 --only "$M" 2>&1 | grep -v amdgpu.ids; done > $O/r3e_engine_profile.txt
 JF_FUZZ_SCALE=100 timeout 1500 python -m pytest tests/test_engine_fuzz.py tests/test_multiblock_fuzz.py -m gpu -n 12 -q -p no:cacheprovider > $O/r3e_soak100.log 2>&1; tail -4 $O/r3e_soak100.log
+JF_FUZZ_SCALE=100 timeout 900 python -m pytest tests/test_loop_fuzz.py -m gpu -n 12 -q -p no:cacheprovider > $O/r3e_loopsoak.log 2>&1; tail -2 $O/r3e_loopsoak.log
+for DT in bf16 f32; do for F in 1 0; do JF_RS_FUSED=$F timeout 300 python tools/microbench_rs_step.py --dtype $DT --temperature 0.8 2>&1 | grep -v amdgpu.ids | head -1 | sed "s/^/fused=$F /"; done; done > $O/r3e_rs_step.txt
 tail -3 $O/r3e_gputest.log; tail -1 $O/r3e_smoke.log; ls -la $O | grep r3e_
