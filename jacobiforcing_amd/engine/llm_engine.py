@@ -3,6 +3,7 @@
 from __future__ import annotations
 
 import atexit
+import sys
 from dataclasses import fields
 from time import perf_counter
 
@@ -27,7 +28,7 @@ class LLMEngine:
                 from transformers import AutoTokenizer
                 self.tokenizer = AutoTokenizer.from_pretrained(tok_path, use_fast=True)
             except Exception as e:  # no tokenizer files: token-id prompts still work
-                print(f"[LLMEngine] tokenizer not loaded from {tok_path} ({type(e).__name__}); prompts must be token ids", flush=True)
+                print(f"[LLMEngine] tokenizer not loaded from {tok_path} ({type(e).__name__}); prompts must be token ids", file=sys.stderr, flush=True)
         if self.tokenizer is not None:
             config.eos = self.tokenizer.eos_token_id
             config.pad = self.tokenizer.pad_token_id if self.tokenizer.pad_token_id is not None else self.tokenizer.eos_token_id
