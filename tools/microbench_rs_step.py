@@ -52,7 +52,8 @@ def main():
         import ctypes as C
         lib = N.lib()
         names = {1: "accept workgroup done", 15: "accept walk decided the last row", 6: "first row handed its uniform", 7: "last row handed its uniform",
-                 12: "finishing workgroup starts", 13: "finished"}
+                 12: "finishing workgroup starts", 13: "finished", 17: "last row's bonus workgroup has its uniform", 19: "... has walked",
+                 21: "... has stored its token", 23: "finish: row records done", 25: "finish: scans done", 27: "finish: next drafts written"}
         acc = {k: [] for k in names}
         for i in range(8):
             lib.jf_exp_rs_trace(None, 1)
