@@ -1090,49 +1090,27 @@ __device__ __forceinline__ void rs_finish_body(int B, int L, unsigned long long 
     __syncthreads();
     RS_STAMP_MAX(25);                                                 // 25: finish: scans done
     const int64_t pc0 = *pad_cursor;
-    // every next-draft element independently, eight per thread: the rows' records first, then the one word each element copies.
-    // All index arithmetic in 32 bits and (row, column) advanced incrementally — as 64-bit divisions and a 64-bit modulo per
-    // element this loop was 11 of the 14 us the workgroup took at 64 rows x 32 tokens.
-    constexpr int ND = 8;
-    const int n_el = B * L;                                            // <= RS_ROWS_LDS * L: far below 2^31
-    const int stepb = 256 / L, stepi = 256 - stepb * L;                // one 256-element stride in (row, column) terms
-    const bool pad32 = pad_len > 0 && pad_len < 0x7FFFFFFFll;
-    const uint32_t pl32 = pad32 ? (uint32_t)pad_len : 1u, pb32 = pad32 ? (uint32_t)(pc0 % pad_len) : 0u;
-    for (int i0 = tid; i0 < n_el; i0 += 256 * ND) {
-        int nC[ND], act[ND], rsv[ND], bb[ND], ii[ND];
-        int b = i0 / L, i = i0 - b * L;
-#pragma unroll
-        for (int k = 0; k < ND; ++k) {
-            bb[k] = b; ii[k] = i; act[k] = 0;
-            if (i0 + k * 256 < n_el) { const jf_rs_row *rw = rows + b; nC[k] = rw->n_committed; act[k] = rw->active_next; rsv[k] = rw->rsv; }
-            b += stepb; i += stepi;
-            if (i >= L) { i -= L; b += 1; }
+    // (this loop takes ~10 of the workgroup's 14 us at 64 rows x 32 tokens; batching its loads eight per thread, one load per
+    //  element from a selected address and 32-bit index arithmetic were each measured and changed nothing: profiles/rs_step_r03.txt)
+    for (int64_t idx = tid; idx < (int64_t)B * L; idx += 256) {        // every next-draft element independently
+        const int b = (int)(idx / L), i = (int)(idx - (int64_t)b * L);
+        const jf_rs_row rw = rows[b];
+        if (!rw.active_next) continue;
+        const int64_t r0 = (int64_t)b * (L - 1);
+        const int n = rw.n_committed, acc_len = 1 + n;
+        int off = 0, copy_len = 1;
+        if (acc_len < L) {
+            off = acc_len > 1 ? acc_len - 1 : 1;
+            const int rem = (L - 1) - off;
+            copy_len = rem < L - 1 ? rem : L - 1;
+        } else {
+            off = L - 2;
         }
-        int64_t v[ND];
-#pragma unroll
-        for (int k = 0; k < ND; ++k) {
-            if (!act[k]) continue;
-            const int bk = bb[k], ik = ii[k];
-            const int64_t r0 = (int64_t)bk * (L - 1);
-            const int n = nC[k], acc_len = 1 + n;
-            int off = 0, copy_len = 1;
-            if (acc_len < L) {
-                off = acc_len > 1 ? acc_len - 1 : 1;
-                const int rem = (L - 1) - off;
-                copy_len = rem < L - 1 ? rem : L - 1;
-            } else {
-                off = L - 2;
-            }
-            if (ik == 0) v[k] = committed[(int64_t)bk * L + n - 1];
-            else if (ik - 1 < copy_len) v[k] = jfmb::decode_packed(packed[r0 + off + (ik - 1)]);
-            else {
-                const int e = rsv[k] + (ik - 1 - copy_len);
-                v[k] = pad32 ? pad_stream[(pb32 + (uint32_t)e) % pl32] : pad_stream[(pc0 + e) % pad_len];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < ND; ++k)
-            if (act[k]) next_draft[i0 + k * 256] = v[k];
+        int64_t v;
+        if (i == 0) v = committed[(int64_t)b * L + n - 1];
+        else if (i - 1 < copy_len) v = jfmb::decode_packed(packed[r0 + off + (i - 1)]);
+        else v = pad_stream[(pc0 + rw.rsv + (i - 1 - copy_len)) % pad_len];
+        next_draft[idx] = v;
     }
     __syncthreads();
     RS_STAMP_MAX(27);                                                 // 27: finish: next drafts written
