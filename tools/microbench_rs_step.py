@@ -36,7 +36,8 @@ def main():
     others = V * math.exp(0.5 * (2.0 / a.temperature) ** 2)            # E[sum exp(x / T)] for x ~ N(0, 2^2)
     logits.scatter_(2, draft[:, 1:].unsqueeze(-1), a.temperature * math.log(a.p_hit / (1 - a.p_hit) * others))
     n = 1 << 16
-    st = ops.RsStepper(B, L, "cuda", torch.randint(0, V, (n,)), torch.rand(n), torch.rand(n))
+    gc = torch.Generator().manual_seed(2)                               # the same streams in every process: runs are comparable
+    st = ops.RsStepper(B, L, "cuda", torch.randint(0, V, (n,), generator=gc), torch.rand(n, generator=gc), torch.rand(n, generator=gc))
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     for _ in range(3):
         rows, toks, nd = st.step(draft, logits, a.temperature, None, [L] * B, [0, 0, 0])
