@@ -97,6 +97,9 @@ int argmax_plan(const void *logits, int dtype, int64_t R, int64_t V, int64_t row
         int64_t wg_items = bytes >> 16;
         if (wg_items < 256) wg_items = 256;
         if (wg_items > 1024) wg_items = 1024;
+        // inside the convergence launch small forwards do better with twice the items (one prompt: 20.8 us at 512 items against
+        // 22.8 at 256: every item is one result slot and the stepper polls them in batches of eight)
+        if (fused && wg_items < 512) wg_items = 512;
         pl->chunk = pick_chunk((int64_t)AM_TPB * epv, R, V, tn.items > 0 ? tn.items : wg_items);
         pl->cpr = (V + pl->chunk - 1) / pl->chunk;
         if (max_cpr > 0 && pl->cpr > max_cpr) { pl->chunk = pick_chunk((int64_t)AM_TPB * epv, R, V, R * max_cpr); pl->cpr = (V + pl->chunk - 1) / pl->chunk; }
