@@ -449,6 +449,35 @@ __host__ __device__ inline RsWs rs_ws(void *ws, int64_t rows) {
 }
 extern "C" size_t jf_rs_step_workspace_bytes(int64_t rows) { return rows > 0 ? rs_ws_bytes(rows) : 0; }
 
+#ifdef JF_EXP_RS_TRACE
+// experiment build (tools/microbench_rs_step.py --trace): wall-clock stamps (100 MHz) of the one-launch step, min / max per role
+__device__ unsigned long long g_rstrace[32];
+__device__ unsigned long long g_rsrow[8 * 128];   // per row: flag stored, first segment sum saw it, its sums ready in the chain, uniform handed out
+#define RS_ROWSTAMP(k, b) do { if ((b) < 128) g_rsrow[(k) * 128 + (b)] = (unsigned long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define RS_STAMP_MIN(k) do { if (threadIdx.x == 0) atomicMin(&g_rstrace[k], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
+#define RS_STAMP_MAX(k) do { if (threadIdx.x == 0) atomicMax(&g_rstrace[k], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
+extern "C" __attribute__((visibility("default"))) int jf_exp_rs_trace(unsigned long long *out, int reset) {
+    if (reset) {
+        unsigned long long init[32];
+        for (int i = 0; i < 32; ++i) init[i] = (i & 1) ? 0ull : ~0ull;      // even slots take minima, odd slots maxima
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_rstrace), init, sizeof(init));
+    }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rstrace), sizeof(unsigned long long) * 32);
+}
+extern "C" __attribute__((visibility("default"))) int jf_exp_rs_rows(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rsrow), sizeof(unsigned long long) * 8 * 128);
+}
+#else
+#define RS_STAMP_MIN(k) do { } while (0)
+#define RS_STAMP_MAX(k) do { } while (0)
+#define RS_ROWSTAMP(k, b) do { } while (0)
+#endif
+#ifdef JF_EXP_RS_TRACE
+#define RS_PICKSTAMP(k) do { if (blockIdx.x == 66 && threadIdx.x == 0) g_rstrace[k] = (unsigned long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define RS_PICKSTAMP(k) do { } while (0)
+#endif
+
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -601,6 +630,7 @@ template <int DT>
 __device__ int rs_pick(const RsRow &row, const double *segsum /* global, RS_SEG */, float u, RsPickShared &sh) {
     constexpr int EPV = Elem<DT>::EPV;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    RS_PICKSTAMP(16);                                       // 16: pick starts
     __syncthreads();                                        // sh may still be read by a previous draw
     if (tid < RS_SEG) sh.seg[tid] = ld_agent_f64(segsum + tid);   // may have been stored by another workgroup of this launch
     if (tid == 0) sh.pick = 0x7FFFFFFF;
@@ -624,6 +654,7 @@ __device__ int rs_pick(const RsRow &row, const double *segsum /* global, RS_SEG 
     int64_t hi = lo + segE;
     if (hi > row.V) hi = row.V;
     const int ntiles = (int)((hi - lo + 256 * EPV - 1) / (256 * EPV));
+    RS_PICKSTAMP(18);                                       // 18: segment known
     // per-lane sums of the first RS_TILES tiles (independent loads), wavefront inclusive scans, wave totals to LDS
     double incl[RS_TILES], lex[RS_TILES];                    // inclusive / exclusive running sums inside the wavefront
     u32x4 tv[RS_TILES];
@@ -644,6 +675,7 @@ __device__ int rs_pick(const RsRow &row, const double *segsum /* global, RS_SEG 
         lex[k] = lane == 0 ? 0.0 : up;
         if (lane == 63) sh.wt[k][wave] = incl[k];
     }
+    RS_PICKSTAMP(20);                                       // 20: tiles loaded, probabilities and wave scans done
     __syncthreads();
     double base = 0.0;                                      // running sum of everything before tile k
     bool found = false;
@@ -691,6 +723,7 @@ __device__ int rs_pick(const RsRow &row, const double *segsum /* global, RS_SEG 
         if (!found && wb + in > thr_s) { cand = resolve(k, wb + (lane == 0 ? 0.0 : up)); found = true; }
         base += (sh.wtx[0] + sh.wtx[1]) + (sh.wtx[2] + sh.wtx[3]);
     }
+    RS_PICKSTAMP(22);                                       // 22: resolved
     if (found) atomicMin(&sh.pick, cand);
     __syncthreads();
     int pick = sh.pick;
@@ -765,29 +798,6 @@ __device__ __forceinline__ void batched_for(int64_t n, int tid, int nthreads, Lo
     }
 }
 
-#ifdef JF_EXP_RS_TRACE
-// experiment build (tools/microbench_rs_step.py --trace): wall-clock stamps (100 MHz) of the one-launch step, min / max per role
-__device__ unsigned long long g_rstrace[32];
-__device__ unsigned long long g_rsrow[8 * 128];   // per row: flag stored, first segment sum saw it, its sums ready in the chain, uniform handed out
-#define RS_ROWSTAMP(k, b) do { if ((b) < 128) g_rsrow[(k) * 128 + (b)] = (unsigned long long)__builtin_amdgcn_s_memrealtime(); } while (0)
-#define RS_STAMP_MIN(k) do { if (threadIdx.x == 0) atomicMin(&g_rstrace[k], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
-#define RS_STAMP_MAX(k) do { if (threadIdx.x == 0) atomicMax(&g_rstrace[k], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
-extern "C" __attribute__((visibility("default"))) int jf_exp_rs_trace(unsigned long long *out, int reset) {
-    if (reset) {
-        unsigned long long init[32];
-        for (int i = 0; i < 32; ++i) init[i] = (i & 1) ? 0ull : ~0ull;      // even slots take minima, odd slots maxima
-        return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_rstrace), init, sizeof(init));
-    }
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rstrace), sizeof(unsigned long long) * 32);
-}
-extern "C" __attribute__((visibility("default"))) int jf_exp_rs_rows(unsigned long long *out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rsrow), sizeof(unsigned long long) * 8 * 128);
-}
-#else
-#define RS_STAMP_MIN(k) do { } while (0)
-#define RS_STAMP_MAX(k) do { } while (0)
-#define RS_ROWSTAMP(k, b) do { } while (0)
-#endif
 
 constexpr int RS_STAGE = 6144;      // floats of p_draft / uniforms staged in LDS by the accept scan (B * (L-1) <= this, else global)
 constexpr int RS_ROWS_LDS = 2048;   // rows whose scan results are kept in LDS (half of it in the chain kernel)
