@@ -147,3 +147,39 @@ def test_loop_fuzz_vs_oracle(seed, backend):
             assert not stream or chunks[p] == ref["tokens"], f"streamed chunks of prompt {p}"
         tpf = sum(len(s.token_ids) for s in stats) / max(sum(s.total_iterations for s in stats), 1)
         assert tpf > 1.2 or robust < 70 or max_iter < 10 or eos is not None, tpf   # the sweep runs where several tokens are accepted per forward
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("resident", [True, False], ids=["resident", "hostdriven"])
+def test_more_prompts_than_a_launch_may_carry_steppers(resident):
+    """700 prompts through the loop API: more steppers than the fused convergence launch may carry (half of the resident
+    workgroups, 640 on an MI355X), so every iteration runs as argmax + step launches and the pack launch behind them copies
+    all 700 descriptors into the mailbox and stamps it.  Every prompt decodes the planted sequence; every seventh is also
+    compared with the oracle's driver (tokens, calls, iterations, committed length)."""
+    with use_backend("hip"):
+        dev = device_for("hip")
+        model = tiny_model(dev, seed=5)
+        V = model.cfg.vocab_size
+        P, n = 700, 8
+        rng = np.random.default_rng(77)
+        prm = ops.MultiblockParams(n=n, K=2, r=0.85, n_gram_pool_size=4, eos_token_id=None, pad_token_id=V - 2)
+        prompts = [[int(t) for t in rng.integers(0, V - 2, size=int(L))] for L in rng.integers(3, 20, size=P)]
+        hook = ScriptedAcceptance(V, robust_pct=82, seed=11, vocab_hi=V - 2)
+        dec = MultiblockJacobiDecoder(model, P, prm, max_seq_len=512, resident=resident, t_align=4, logits_hook=hook)
+        stats, _, iters = dec.generate(prompts, max_new_tokens=2 * n, max_calls=6, seed=31)
+        for p, st in enumerate(stats):
+            pos = torch.arange(len(prompts[p]), len(prompts[p]) + len(st.token_ids))
+            assert st.token_ids == hook.target(pos, torch.full_like(pos, p)).tolist(), p
+        for p in range(0, P, 7):
+            pf = PlantedForward(hook, p, len(prompts[p]))
+
+            class _Fwd:
+                calls = 0
+
+                def __call__(self, kv_rows, out_rows):
+                    self.calls += 1
+                    return pf.prefill(kv_rows, out_rows) if self.calls == 1 else pf.decode(kv_rows, out_rows)
+            ref = oracle_generate(_Fwd(), prompts[p], prm, 2 * n, 6, ops.DrawStreams(P, seed=31).rng(p))
+            assert stats[p].token_ids == ref["tokens"], p
+            assert (stats[p].calls, stats[p].total_iterations, stats[p].stop_reason) == (ref["calls"], ref["iters"], ref["stop"]), p
+            assert int(dec.kv_len_host[p]) == ref["kv_len"], p
