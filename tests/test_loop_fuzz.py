@@ -150,17 +150,19 @@ def test_loop_fuzz_vs_oracle(seed, backend):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("P", [300, 700])
 @pytest.mark.parametrize("resident", [True, False], ids=["resident", "hostdriven"])
-def test_more_prompts_than_a_launch_may_carry_steppers(resident):
-    """700 prompts through the loop API: more steppers than the fused convergence launch may carry (half of the resident
-    workgroups, 640 on an MI355X), so every iteration runs as argmax + step launches and the pack launch behind them copies
-    all 700 descriptors into the mailbox and stamps it.  Every prompt decodes the planted sequence; every seventh is also
-    compared with the oracle's driver (tokens, calls, iterations, committed length)."""
+def test_hundreds_of_prompts_through_the_loop(resident, P):
+    """300 prompts: one fused convergence launch with 300 steppers, the position list ordered over 300 descriptors.  700 prompts:
+    more steppers than the fused launch may carry (half of the resident workgroups, 640 on an MI355X), so every iteration runs
+    as argmax + step launches and the pack launch behind them copies all 700 descriptors into the mailbox and stamps it.
+    Every prompt decodes the planted sequence; every seventh is also compared with the oracle's driver (tokens, calls,
+    iterations, committed length)."""
     with use_backend("hip"):
         dev = device_for("hip")
         model = tiny_model(dev, seed=5)
         V = model.cfg.vocab_size
-        P, n = 700, 8
+        n = 8
         rng = np.random.default_rng(77)
         prm = ops.MultiblockParams(n=n, K=2, r=0.85, n_gram_pool_size=4, eos_token_id=None, pad_token_id=V - 2)
         prompts = [[int(t) for t in rng.integers(0, V - 2, size=int(L))] for L in rng.integers(3, 20, size=P)]
