@@ -69,8 +69,9 @@ class MultiblockJacobiDecoder:
         self.device = model.device
         self.batch = ops.MultiblockBatch(self.P, params, self.device)
         self.cand_rows = self.batch.max_rows - 1
-        # rows longer than (K+2)*n only occur when the reference's block counters run away; the forward buffers are sized
-        # for the realistic case and a longer row is a capacity error rather than gigabytes of idle scratch
+        # rows longer than (K+2)*n only occur when the reference's block counters run away (K >= 3 with a small spawn ratio:
+        # up to ~77 n tokens, tests/golden/mb_cases_v3.json); the candidate scratch is sized for the realistic case and
+        # grows on demand (_forward) instead of reserving gigabytes up front
         self.t_cap = min(self.batch.max_tokens, max(128, (params.K + 2) * params.n))
         self.cache = StaticKVCache(model.cfg, self.P, max_seq_len, self.cand_rows, self.t_cap, self.device, dtype=model.dtype)
         self.max_seq_len = max_seq_len
@@ -144,9 +145,9 @@ class MultiblockJacobiDecoder:
     def _forward(self, s: ops.LoopSummary) -> torch.Tensor:
         """Queue the forward ``s`` describes (its inputs were written by the pack launch queued behind the launch that
         published ``s``) and return its logits."""
-        if s.Tpad > self.t_cap:
-            raise RuntimeError(f"a row of {s.Tpad} tokens exceeds the forward capacity {self.t_cap} "
-                               "(the block counters ran away, see DESIGN.md §3.2)")
+        if s.Tpad > self.cache.T_max and s.Rtot > s.Rmain:
+            # a runaway row WITH candidate rows: the scratch doubles (the state machine itself holds rows of max_tokens)
+            self.cache.grow_candidates(min(self.batch.max_tokens, max(2 * self.cache.T_max, -(-s.Tpad // 64) * 64)))
         if s.max_kv + s.Tpad > self.max_seq_len:
             raise RuntimeError(f"KV cache rows hold {self.max_seq_len} positions; a prompt at "
                                f"{s.max_kv} cannot take {s.Tpad} more (raise max_seq_len)")

@@ -50,12 +50,14 @@ class Qwen2Backend:
         kv = cache.length
         # max_tokens sizes the candidate scratch rows only: a single row (prefill of prompt + draft, any B == 1 forward)
         # writes the main cache and may be as long as the cache itself
-        if kv + T > self.max_seq_len or B > self.max_rows or (B > 1 and T > self.max_tokens):
+        if kv + T > self.max_seq_len or B > self.max_rows:
             raise RuntimeError(f"forward of {B}x{T} tokens at position {kv} exceeds the static cache "
-                               f"(max_seq_len={self.max_seq_len}, max_rows={self.max_rows}, max_tokens={self.max_tokens})")
+                               f"(max_seq_len={self.max_seq_len}, max_rows={self.max_rows})")
         Tp = -(-T // self.t_align) * self.t_align
         if Tp != T and kv + Tp > self.max_seq_len:
             Tp = T
+        if B > 1 and Tp > cache.T_max:                  # runaway block lists (K >= 3, small r) with candidate rows: grow the scratch
+            cache.grow_candidates(max(2 * cache.T_max, -(-Tp // 64) * 64))
         rows = rows.to(dev)
         idx = None
         if Tp != T:

@@ -176,6 +176,25 @@ class StaticKVCache:
         self.kv_len = torch.zeros(P, dtype=torch.int32, device=device)     # committed length per prompt
         self.committer = ops.KVCommitter(self.k, self.v, self.ck, self.cv, cr) if self.cand_rows > 0 else None
 
+    def grow_candidates(self, T_new: int) -> None:
+        """Re-allocate the candidate scratch for rows of up to ``T_new`` tokens.  The scratch only lives from a forward to the
+        KV commit behind its convergence launch, so between two iterations there is nothing to carry over.  Needed when the
+        reference's block lists run away (K >= 3 with a small spawn ratio: rows of up to ~77 n tokens,
+        tests/golden/mb_cases_v3.json) and such a row carries candidates; the usual rows fit the initial (K + 2) n."""
+        if T_new <= self.T_max:
+            return
+        like = self.ck[0]
+        shape = (like.shape[0], like.shape[1], int(T_new), like.shape[3])
+        n_layers, dev, dt = len(self.ck), like.device, like.dtype
+        del like
+        self.ck = self.cv = self.committer = None                          # free before allocating the larger scratch
+        z = lambda: torch.zeros(shape, device=dev, dtype=dt)
+        self.ck = [z() for _ in range(n_layers)]
+        self.cv = [z() for _ in range(n_layers)]
+        self.T_max = int(T_new)
+        if self.cand_rows > 0:
+            self.committer = ops.KVCommitter(self.k, self.v, self.ck, self.cv, max(self.cand_rows, 1))
+
     def get_seq_length(self, p: int = 0) -> int:
         return int(self.kv_len[p])
 

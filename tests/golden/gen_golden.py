@@ -30,6 +30,7 @@ import os
 import random
 import sys
 import types
+import zlib
 from pathlib import Path
 
 os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
@@ -196,6 +197,25 @@ def banners_of(text: str):
 # --------------------------------------------------------------------------------------
 # HF multiblock (MB) cases — driver mirrors DRV-MR:152-240
 # --------------------------------------------------------------------------------------
+def rows_crc(rows) -> int:
+    """Digest of a list of token rows (or one token list): crc32 over the little-endian int64 image, shape included."""
+    a = np.asarray(rows, dtype="<i8")
+    return zlib.crc32(a.tobytes(), zlib.crc32(np.asarray(a.shape, dtype="<i8").tobytes()))
+
+
+def digest_mb_case(case):
+    """Runaway cases (K >= 3 with a small spawn ratio: rows of 1000+ tokens over hundreds of forwards) are stored as digests:
+    per forward (kv_len, B, T, crc of the rows, crc of the greedy tokens), per call the crc of the cache content; ret /
+    next_token / iters / kv_len / banners stay in full."""
+    for cl in case["calls"]:
+        cl["forwards"] = [dict(kv_len=f["kv_len"], B=len(f["out"]), T=len(f["out"][0]), out_crc=rows_crc(f["out"]),
+                               greedy_crc=rows_crc(f["greedy"])) for f in cl["forwards"]]
+        if "kv_tokens" in cl:
+            cl["kv_tokens_crc"] = rows_crc(cl.pop("kv_tokens"))
+    case["digest"] = True
+    return case
+
+
 def run_mb_case(name, *, vocab, seed, robust, prompt_len, n, K, r, pool, lookahead=0.0,
                 eos_pos=None, period=0, max_iter=128, max_calls=6, max_new_tokens=10 ** 9, allow_raise=False):
     eos_id, pad_id = vocab - 1, vocab - 2
@@ -878,6 +898,23 @@ def main():
                                 pool=rr.choice([0, 1, 2, 4, 8]), period=rr.choice([0, 0, 3, 7]),
                                 lookahead=rr.choice([0.0, 0.0, 0.4]),
                                 eos_pos=rr.choice([None, None, pl + rr.randint(0, 3 * n)]), max_calls=3))
+    # round 4: K >= 3 with a small spawn ratio — the reference's block lists run away (promotion decrements num_blocks without
+    # removing list entries, active_blocks goes negative, MB:629-716 / SURVEY Q3, Q4): a spawn per iteration, rows of up to
+    # ~77 n tokens, a ret of several hundred tokens per call.  These pin the LARGEST rows the reference really produces
+    # (every configuration below runs to the end without the MB:482 crash; all have pool = 2, i.e. never a stacked candidate).
+    mbs3 = [run_mb_case("mb3_runaway_n4_K3_r005_full", vocab=48, seed=2172, robust=30, prompt_len=14, n=4, K=3, r=0.05, pool=2,
+                        period=3, max_calls=2)]
+    for nm, kw in [
+        ("n8_K3_r005", dict(vocab=48, seed=2311, robust=30, prompt_len=20, n=8, K=3, r=0.05, pool=2, period=5)),
+        ("n16_K3_r005", dict(vocab=64, seed=2195, robust=60, prompt_len=5, n=16, K=3, r=0.05, pool=2, period=3)),
+        ("n32_K3_r005", dict(vocab=24, seed=2196, robust=75, prompt_len=15, n=32, K=3, r=0.05, pool=2, period=0)),
+        ("n32_K3_r025", dict(vocab=64, seed=2276, robust=75, prompt_len=14, n=32, K=3, r=0.25, pool=2, period=0)),
+        ("n8_K4_r025", dict(vocab=24, seed=2233, robust=30, prompt_len=6, n=8, K=4, r=0.25, pool=2, period=0)),
+        ("n16_K4_r005", dict(vocab=200, seed=2179, robust=60, prompt_len=20, n=16, K=4, r=0.05, pool=2, period=7)),
+        ("n32_K4_r005", dict(vocab=64, seed=2117, robust=75, prompt_len=5, n=32, K=4, r=0.05, pool=2, period=3)),
+        ("n16_K5_r005", dict(vocab=24, seed=1160, robust=45, prompt_len=19, n=16, K=5, r=0.05, pool=2, period=7)),
+    ]:
+        mbs3.append(digest_mb_case(run_mb_case(f"mb3_runaway_{nm}", **kw)))
     # round 2: seeded sweeps of the single-block function and the engine decoder (the first sets are hand-picked and small)
     sbs2 = []
     for sd in range(200, 216):
@@ -942,6 +979,7 @@ def main():
     dump("jdn_cases.json", jdns)
     dump("jdo_cases.json", jdos)
     dump("mb_cases_v2.json", mbs2)
+    dump("mb_cases_v3.json", mbs3)
     dump("sb_cases_v2.json", sbs2)
     dump("jd_cases_v2.json", jds2)
     dump("jdn_cases_v3.json", jdns3)
@@ -953,10 +991,10 @@ def main():
     dump("slot_cases.json", slots)
     dump("bm_cases.json", bms)
     # quick human summary
-    for c in mbs:
+    for c in mbs + mbs3:
         fw = [f for cl in c["calls"] for f in cl["forwards"]]
-        maxB = max((len(f["out"]) for f in fw), default=0)
-        maxT = max((len(f["out"][0]) for f in fw), default=0)
+        maxB = max((f["B"] if "B" in f else len(f["out"]) for f in fw), default=0)
+        maxT = max((f["T"] if "T" in f else len(f["out"][0]) for f in fw), default=0)
         s = c["summary"]
         tpf = (s["new_tokens"] / s["total_iterations"]) if s["total_iterations"] else 0
         ban = sum((cl["banners"] for cl in c["calls"]), [])

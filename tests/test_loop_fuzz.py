@@ -82,6 +82,10 @@ def test_loop_fuzz_vs_oracle(seed, backend):
     logit_align = int(rng.choice([1, 8, 64]))
     max_iter = int(rng.choice([128, 128, 128, 6]))
     use_eos = bool(rng.integers(0, 3) == 0)                       # one in three with an EOS id the planted sequence can hit
+    if K >= 3 and rng.integers(0, 2) == 0:
+        # K >= 3 with a small spawn ratio: the reference's block lists run away (tests/golden/mb_cases_v3.json pins
+        # rows of up to ~77 n tokens) — the decoder follows (its candidate scratch grows on demand), nothing is cut off
+        r = float(rng.choice([0.05, 0.25]))
     with use_backend(backend):
         dev = device_for(backend)
         # a vocabulary whose rows are not 16-byte multiples takes the convergence check as its two launches (and the pack
@@ -93,8 +97,8 @@ def test_loop_fuzz_vs_oracle(seed, backend):
                                    pad_token_id=V - 2, max_iteration_count=max_iter)
         prompts = [[int(t) for t in rng.integers(0, V - 2, size=int(L))] for L in rng.integers(3, 40, size=P)]
         hook = ScriptedAcceptance(V, robust_pct=robust, seed=int(rng.integers(1, 1000)), vocab_hi=V - 2)
-        dec = MultiblockJacobiDecoder(model, P, prm, max_seq_len=512, resident=resident, t_align=t_align, logits_hook=hook,
-                                      compact_logits=compact, logit_align=logit_align)
+        dec = MultiblockJacobiDecoder(model, P, prm, max_seq_len=512 if K < 3 else 6144, resident=resident, t_align=t_align,
+                                      logits_hook=hook, compact_logits=compact, logit_align=logit_align)
         draw_seed = int(rng.integers(1, 1 << 20))
         failed = None
         stream = seed % 3 == 0              # every third seed through the streaming generator (chunks per finished call)
@@ -112,12 +116,8 @@ def test_loop_fuzz_vs_oracle(seed, backend):
             else:
                 stats, _, iters = dec.generate(prompts, max_new_tokens=max_new, max_calls=max_calls, seed=draw_seed)
         except RuntimeError as e:
-            # K >= 3 only: the reference's own crash at MB:482, or its block counters running away (Q3/Q4) until a row outgrows
-            # the forward's capacity — a fixed capacity here, an ever longer row there: nothing to compare
-            runaway = "capacity" in str(e) or "raise max_seq_len" in str(e)
-            assert K >= 3 and ("size of tensor" in str(e) or runaway), e
-            if runaway:
-                return
+            # K >= 3 only: the reference's own crash at MB:482 (the oracle must fail on the same decode, below)
+            assert K >= 3 and "size of tensor" in str(e), e
             failed = e
         refs, ref_failed = [], 0
         for p, prompt in enumerate(prompts):
@@ -182,6 +182,57 @@ def test_hundreds_of_prompts_through_the_loop(resident, P):
                     self.calls += 1
                     return pf.prefill(kv_rows, out_rows) if self.calls == 1 else pf.decode(kv_rows, out_rows)
             ref = oracle_generate(_Fwd(), prompts[p], prm, 2 * n, 6, ops.DrawStreams(P, seed=31).rng(p))
+            assert stats[p].token_ids == ref["tokens"], p
+            assert (stats[p].calls, stats[p].total_iterations, stats[p].stop_reason) == (ref["calls"], ref["iters"], ref["stop"]), p
+            assert int(dec.kv_len_host[p]) == ref["kv_len"], p
+
+
+BACKENDS = [pytest.param("hostsim", id="hostsim"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("cfg", [dict(seed=5, n=8, K=3, r=0.05, pool=2, robust=30),       # one row per prompt, 551 tokens long
+                                 dict(seed=16, n=8, K=3, r=0.05, pool=4, robust=45),      # candidate rows of 577 tokens: scratch grows x3
+                                 dict(seed=11, n=8, K=3, r=0.25, pool=4, robust=30),
+                                 dict(seed=0, n=8, K=4, r=0.05, pool=2, robust=30)],
+                         ids=lambda c: f"n{c['n']}K{c['K']}r{c['r']}p{c['pool']}")
+def test_runaway_block_lists_are_followed_not_cut(cfg, backend):
+    """K >= 3 with a small spawn ratio: the reference's block lists run away (promotion decrements num_blocks without removing
+    list entries, MB:711-716; tests/golden/mb_cases_v3.json pins rows of up to ~77 n tokens on the reference itself).  The
+    decoder follows — rows far beyond (K + 2) n, the candidate scratch growing on demand — and decodes what the oracle's
+    driver decodes: tokens, calls, iterations, committed lengths."""
+    rng = np.random.default_rng(cfg["seed"])
+    n, K, P, max_new, max_calls = cfg["n"], cfg["K"], 2, 64, 4
+    with use_backend(backend):
+        dev = device_for(backend)
+        model = tiny_model(dev, seed=cfg["seed"], vocab=384)
+        V = model.cfg.vocab_size
+        prm = ops.MultiblockParams(n=n, K=K, r=cfg["r"], n_gram_pool_size=cfg["pool"], eos_token_id=None, pad_token_id=V - 2)
+        prompts = [[int(t) for t in rng.integers(0, V - 2, size=int(L))] for L in rng.integers(3, 20, size=P)]
+        hook = ScriptedAcceptance(V, robust_pct=cfg["robust"], seed=int(rng.integers(1, 1000)), vocab_hi=V - 2)
+        dec = MultiblockJacobiDecoder(model, P, prm, max_seq_len=4096, logits_hook=hook)
+        t_first = dec.cache.T_max
+        longest = [0]
+        fwd = dec._forward
+
+        def counting(s):
+            longest[0] = max(longest[0], s.Tpad)
+            return fwd(s)
+        dec._forward = counting
+        stats, _, iters = dec.generate(prompts, max_new_tokens=max_new, max_calls=max_calls, seed=7)
+        assert longest[0] > (K + 2) * n, longest                   # the lists did run away
+        if cfg["pool"] > 2 and cfg["seed"] == 16:
+            assert dec.cache.T_max > t_first                       # ... with candidate rows: the scratch grew
+        for p, prompt in enumerate(prompts):
+            pf = PlantedForward(hook, p, len(prompt))
+
+            class _Fwd:
+                calls = 0
+
+                def __call__(self, kv_rows, out_rows):
+                    self.calls += 1
+                    return pf.prefill(kv_rows, out_rows) if self.calls == 1 else pf.decode(kv_rows, out_rows)
+            ref = oracle_generate(_Fwd(), prompt, prm, max_new, max_calls, ops.DrawStreams(P, seed=7).rng(p))
             assert stats[p].token_ids == ref["tokens"], p
             assert (stats[p].calls, stats[p].total_iterations, stats[p].stop_reason) == (ref["calls"], ref["iters"], ref["stop"]), p
             assert int(dec.kv_len_host[p]) == ref["kv_len"], p

@@ -15,9 +15,9 @@ from oracle import jacobi_oracle as O
 from oracle.scripted_model import ScriptedModel
 
 from .backends import device_for, use_backend
-from .conftest import load_golden
+from .conftest import forward_matches, kv_matches, load_golden
 
-MB = load_golden("mb_cases.json") + load_golden("mb_cases_v2.json")
+MB = load_golden("mb_cases.json") + load_golden("mb_cases_v2.json") + load_golden("mb_cases_v3.json")
 MBR = load_golden("mb_raises.json")
 
 BACKENDS = [pytest.param("hostsim", id="hostsim"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
@@ -103,12 +103,11 @@ def test_golden_calls(case, backend):
             assert [r["next_token"]] == call["next_token"], ctx
             assert r["iters"] == call["iters"], ctx
             assert r["kv_len"] == call["kv_len"], ctx
-            assert r["kv_tokens"] == call["kv_tokens"], ctx
+            assert kv_matches(r["kv_tokens"], call), ctx
             assert r["banners"] == call["banners"], ctx
             assert len(traces[0]) == len(call["forwards"]), ctx
-            for it, (a, b) in enumerate(zip(traces[0], call["forwards"])):
-                assert a["out"] == b["out"], f"{ctx} iter {it}"
-                assert a["kv_len"] == b["kv_len"], f"{ctx} iter {it}"
+            for it, (a, b) in enumerate(zip(traces[0], call["forwards"])):        # mb_cases_v3.json: digests of the rows
+                assert forward_matches(a, b, greedy=False), f"{ctx} iter {it}"
             kv = r["kv_tokens"]
 
 

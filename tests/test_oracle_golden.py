@@ -6,9 +6,9 @@ import pytest
 from oracle import jacobi_oracle as O
 from oracle.scripted_model import ScriptedModel
 
-from .conftest import load_golden
+from .conftest import forward_matches, kv_matches, load_golden
 
-MB = load_golden("mb_cases.json") + load_golden("mb_cases_v2.json")
+MB = load_golden("mb_cases.json") + load_golden("mb_cases_v2.json") + load_golden("mb_cases_v3.json")
 SB = load_golden("sb_cases.json") + load_golden("sb_cases_v2.json")
 JD = load_golden("jd_cases.json") + load_golden("jd_cases_v2.json")
 JDN = load_golden("jdn_cases.json") + load_golden("jdn_cases_v2.json") + load_golden("jdn_cases_v3.json")
@@ -73,15 +73,14 @@ def test_multiblock_calls(case):
         assert st.ret == call["ret"], ctx
         assert [st.next_token] == call["next_token"], ctx
         assert st.iters == call["iters"], ctx
-        assert st.kv_tokens == call["kv_tokens"], ctx
+        assert st.kv_len() == call["kv_len"], ctx
+        assert kv_matches(st.kv_tokens, call), ctx
         assert len(st.kv_rows) == call["kv_batch"], ctx
         assert st.banners == call["banners"], ctx
-        # per-iteration forward inputs/outputs
+        # per-iteration forward inputs/outputs (the runaway cases of mb_cases_v3.json hold them as digests)
         assert len(st.trace) == len(call["forwards"]), ctx
         for it, (a, b) in enumerate(zip(st.trace, call["forwards"])):
-            assert a["out"] == b["out"], f"{ctx} iter {it}"
-            assert a["greedy"] == b["greedy"], f"{ctx} iter {it}"
-            assert a["kv_len"] == b["kv_len"], f"{ctx} iter {it}"
+            assert forward_matches(a, b), f"{ctx} iter {it}"
         kv = st.kv_tokens
 
 
