@@ -349,48 +349,61 @@ def verify_scripted(hook, stats, prompts) -> bool:
     return bool(ok)
 
 
-def cpu_baseline(model, prompt, prm, budget_s: float):
+def cpu_baseline(model, prompt, prm, budget_s: float, min_tokens: int = 30):
     """The reference's HF path restated for the CPU (oracle state machine + DynamicCache-style torch-CPU forward of the
-    same weights), timed on the host cores for a bounded sample.  Only this leg imports oracle/."""
+    same weights), timed on the host cores for a bounded sample of at least ``min_tokens`` accepted tokens.  Only this leg
+    imports oracle/.  Both weight dtypes are timed — bf16 (what the GPU path computes in) over the full sample, fp32 over a
+    short one — and the FASTER one is the reported value; both are named (DRV-MR:217-230 timing rule: generation calls
+    only, prefill excluded)."""
     from oracle import cpu_reference as CR
-    t0 = time.perf_counter()
-    # bf16 like the GPU path by default; JF_CPU_DTYPE=float32 uses fp32 weights (twice the memory, often the faster CPU GEMM)
-    cpu_dtype = getattr(torch, os.environ.get("JF_CPU_DTYPE", "bfloat16"))
-    cpu = CR.CpuQwen2(model.cfg, model.w, dtype=cpu_dtype)
-    load_s = time.perf_counter() - t0
-    r = CR.timed_tokens_per_second(cpu, prompt, random.Random(1234), n=prm.n, K=prm.K, r=prm.r,
-                                   pool=prm.n_gram_pool_size, eos=prm.eos_token_id, pad=prm.pad_token_id, budget_s=budget_s)
-    return dict(value=r["tokens_per_sec"], unit="tokens/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"1 prompt ({len(prompt)} tokens), {r['calls']} generation calls, {r['iterations']} Jacobi "
-                       f"iterations, {r['tokens']} tokens in {r['seconds']:.1f}s; oracle loop + torch-CPU {str(cpu_dtype)[6:]} forward "
-                       f"with DynamicCache-style cat/expand/narrow (weights copied from the GPU in {load_s:.1f}s, untimed)",
+    kw = dict(n=prm.n, K=prm.K, r=prm.r, pool=prm.n_gram_pool_size, eos=prm.eos_token_id, pad=prm.pad_token_id)
+    legs = {}
+    order = [os.environ["JF_CPU_DTYPE"]] if os.environ.get("JF_CPU_DTYPE") else ["bfloat16", "float32"]
+    for name in order:
+        t0 = time.perf_counter()
+        cpu = CR.CpuQwen2(model.cfg, model.w, dtype=getattr(torch, name))
+        load_s = time.perf_counter() - t0
+        full = name == order[0]
+        # the first dtype carries the sample the line quotes (>= min_tokens tokens, at most 4.5 x the budget); the other is a
+        # short rate check (a quarter of the budget, no token floor)
+        r = CR.timed_tokens_per_second(cpu, prompt, random.Random(1234), budget_s=budget_s if full else budget_s / 2,
+                                       min_tokens=min_tokens if full else 3, hard_cap_s=4.5 * budget_s if full else budget_s, **kw)
+        if not full and r["tokens_per_sec"] > legs[order[0]]["tokens_per_sec"] and r["tokens"] < min_tokens:
+            # the short leg looks faster: it becomes the quoted value, so it gets the full sample too
+            r = CR.timed_tokens_per_second(cpu, prompt, random.Random(1234), budget_s=budget_s, min_tokens=min_tokens,
+                                           hard_cap_s=4.5 * budget_s, **kw)
+        r["load_s"] = load_s
+        legs[name] = r
+        del cpu
+    best = max(legs, key=lambda k: legs[k]["tokens_per_sec"])
+    r = legs[best]
+    desc = lambda k, v: (f"{k}: {v['tokens']} tokens / {v['iterations']} iterations / {v['calls']} calls in {v['seconds']:.1f}s = "
+                         f"{v['tokens_per_sec']:.3f} tokens/s")
+    return dict(value=r["tokens_per_sec"], unit="tokens/s", cores=torch.get_num_threads(), kind="port", dtype=best,
+                sample=f"1 prompt ({len(prompt)} tokens); oracle loop + torch-CPU forward with DynamicCache-style cat/expand/narrow, "
+                       f"generation calls only (prefill untimed, DRV-MR:217-230); faster dtype reported ({best}); "
+                       + "; ".join(desc(k, v) for k, v in legs.items())
+                       + " (weights copied from the GPU untimed: " + ", ".join(f"{k} {v['load_s']:.1f}s" for k, v in legs.items()) + ")",
+                tokens=r["tokens"], calls=r["calls"], iterations=r["iterations"], seconds=r["seconds"],
+                by_dtype={k: dict(tokens_per_sec=v["tokens_per_sec"], tokens=v["tokens"], iterations=v["iterations"], calls=v["calls"],
+                                  seconds=v["seconds"]) for k, v in legs.items()},
                 tokens_per_forward=(r["tokens"] / r["iterations"]) if r["iterations"] else 0.0)
 
 
 def cpu_verify_kernel(rows: int, V: int, budget_s: float = 3.0):
     """Kernel-level CPU figure beside the roofline: the C/OpenMP restatement of the verify body's HBM-heavy op (argmax over the
-    vocabulary, oracle/verify_ref.c) over a logits tensor of the bench's launch shape, on all host cores."""
-    import ctypes as C
-    lib_path = ROOT / "oracle" / "_build" / "libjf_oracle.so"
-    if not lib_path.exists():
+    vocabulary, oracle/verify_ref.c) over a logits tensor of the bench's launch shape, on all host cores — run as its own
+    process (oracle/verify_bench.py) so that the OpenMP threads are bound core by core before the runtime starts: the static
+    row partition then places every row on the NUMA node of the core that scans it."""
+    if not (ROOT / "oracle" / "_build" / "libjf_oracle.so").exists():
         return None
-    lib = C.CDLL(str(lib_path))
-    lib.ref_argmax_rows.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]
-    lib.ref_num_threads.restype = C.c_int
-    lib.ref_fill_rows_bf16.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_uint32]
-    x = torch.empty(rows, V, dtype=torch.bfloat16)                             # pages placed by the threads that will scan them
-    lib.ref_fill_rows_bf16(x.data_ptr(), rows, V, V, 1234)
-    out = torch.zeros(rows, dtype=torch.int64)
-    lib.ref_argmax_rows(x.data_ptr(), 1, rows, V, V, out.data_ptr())          # warm-up
-    reps, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
-        lib.ref_argmax_rows(x.data_ptr(), 1, rows, V, V, out.data_ptr())
-        reps += 1
-    dt = (time.perf_counter() - t0) / reps
-    return dict(us_per_call=dt * 1e6, gbs=rows * V * 2 / dt / 1e9, rows=rows, threads=int(lib.ref_num_threads()), reps=reps,
-                seconds=budget_s, placement="no explicit NUMA binding: the rows are first-touched by the OpenMP threads that scan them "
-                                            "(static schedule), one warm-up call before the timed repetitions",
-                what="oracle/verify_ref.c ref_argmax_rows (C + OpenMP) over bf16 logits of the bench's launch shape")
+    env = {k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS",)}
+    env.update(OMP_PROC_BIND="close", OMP_PLACES="cores")
+    r = subprocess.run([sys.executable, str(ROOT / "oracle" / "verify_bench.py"), str(rows), str(V), str(budget_s)], env=env,
+                       capture_output=True, text=True, timeout=120 + 10 * budget_s)
+    if r.returncode != 0:
+        return dict(error=r.stderr[-400:])
+    return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 def launch_command(n_gpus: int, argv, port: int):
@@ -558,15 +571,19 @@ def main():
                        "scaling_mode": "strong" if strong else "weak", "total_prompts": P * info.world_size,
                        "model": name, "n": 32, "K": 2, "r": 0.85, "pool": 4, "prompts_per_gpu": P,
                        "steps_measured": steps_done, "logits_dtype": "bf16",
-                       "weights": "random-init (no network for checkpoints); acceptance is what these weights give",
+                       "weights": ("random-init (no network for checkpoints); acceptance is what these weights give"
+                                   if args.model in ("tiny", "qwen2.5-coder-7b") else
+                                   f"checkpoint directory {args.model} (*.safetensors): tokens_per_forward is this checkpoint's own"),
                        "gemm_selection": "TunableOp table jacobiforcing_amd/tunableop_mi355x.csv (hipBLASLt/rocBLAS picks for "
                                          "M=64..4096; rows kept on that grid: tuning.grid_alignment)" if tuned else "library default",
+                       "dist_backend": jd.backend_name() or "none (single process, no process group)",
                        "prewarm": "none" if args.no_prewarm else "one untimed pass over the same W + K iterations before the measured "
                                                                  "pass (loads the library kernels of every GEMM shape the window uses)"},
         }
         if roof is not None:
             out["roofline"] = {"bound": "hbm", "achieved": roof["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": roof["gbs"] / HBM_PEAK_GBS, "traffic": _pmc_traffic(roof),
+                               "traffic_source": _pmc_source(),
                                "kernel": VERIFY_KERNEL,
                                "bytes_per_launch": roof["avg_bytes"], "us_per_launch": roof["avg_us"],
                                "rows_per_launch": roof["avg_rows"], "logits_rows_per_launch": roof["avg_launched_rows"],
@@ -620,6 +637,17 @@ def _pmc_traffic(roof):
     try:
         d = json.loads(f.read_text())
         return float(d["traffic_over_algorithmic"]) * roof["avg_bytes"]
+    except Exception:
+        return None
+
+
+def _pmc_source():
+    """Where roofline.traffic comes from: NOT measured in this run (PMC passes need rocprofv3 around the command)."""
+    f = ROOT / "profiles" / "pmc_verify_latest.json"
+    try:
+        d = json.loads(f.read_text())
+        return (f"derived, not measured in this run: bytes_per_launch x traffic_over_algorithmic ({float(d['traffic_over_algorithmic']):.3f}) "
+                f"of the committed rocprofv3 PMC passes of this command (profiles/pmc_verify_latest.json, tools/pmc_verify.sh)")
     except Exception:
         return None
 

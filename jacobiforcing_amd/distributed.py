@@ -17,19 +17,53 @@ class RankInfo:
     local_rank: int = 0
 
 
-def init_from_env(backend: Optional[str] = None) -> RankInfo:
+def pin_rank_cpus(info: RankInfo, local_world: Optional[int] = None) -> Optional[int]:
+    """Give every rank of a node its own contiguous slice of the host cores (and an OMP/torch thread count to match), so
+    that eight ranks' host threads — the mailbox poll, the tokenizer-free driver loop, torch's intra-op pool — do not all
+    land on the same cores.  JF_PIN_CPUS=0 switches it off.  Returns the number of cores of the slice (None: untouched)."""
+    if os.environ.get("JF_PIN_CPUS", "1") == "0" or not hasattr(os, "sched_getaffinity"):
+        return None
+    lw = int(local_world or os.environ.get("LOCAL_WORLD_SIZE", info.world_size) or 1)
+    if lw <= 1:
+        return None
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        per = len(cpus) // lw
+        if per < 1:
+            return None
+        mine = cpus[(info.local_rank % lw) * per:(info.local_rank % lw + 1) * per]
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(per, int(os.environ.get("OMP_NUM_THREADS", per)))))
+        return per
+    except OSError:
+        return None
+
+
+def init_from_env(backend: Optional[str] = None, force: Optional[bool] = None) -> RankInfo:
+    """Read RANK / LOCAL_RANK / WORLD_SIZE and create the process group when there is more than one rank — or when
+    ``force`` (env JF_DIST_FORCE_INIT=1) asks for a single-rank group: a one-rank "nccl" group still loads RCCL, creates
+    the communicator and launches its reduce kernels, which is how the collective path is exercised on a one-GPU box."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if ws > 1 and not dist.is_initialized():
+    if force is None:
+        force = os.environ.get("JF_DIST_FORCE_INIT", "0") == "1"
+    info = RankInfo(rank, ws, local)
+    if (ws > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver only supports dmabuf IPC (RCCL's P2P setup)
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(int(os.environ.get("JF_FORCE_DEVICE", local)))
+        pin_rank_cpus(info)
         dist.init_process_group(backend=backend, rank=rank, world_size=ws)
-    return RankInfo(rank, ws, local)
+    return info
+
+
+def backend_name() -> Optional[str]:
+    return dist.get_backend() if dist.is_initialized() else None
 
 
 def barrier(device: Optional[torch.device] = None) -> None:

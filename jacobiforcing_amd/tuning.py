@@ -24,7 +24,8 @@ def enable_tuned_gemms(csv: Path = CSV) -> bool:
         return False
     try:
         # TunableOp may rewrite its file at exit: give every process a private copy so the repo file is never touched
-        tmp = Path(tempfile.gettempdir()) / f"jf_tunableop_{os.getpid()}.csv"
+        # (keyed on the rank as well as the pid: eight ranks of one node start within the same millisecond)
+        tmp = Path(tempfile.gettempdir()) / f"jf_tunableop_r{os.environ.get('RANK', '0')}_{os.getpid()}.csv"
         shutil.copyfile(csv, tmp)
         torch.cuda.tunable.enable(True)
         torch.cuda.tunable.tuning_enable(False)
@@ -46,7 +47,15 @@ def grid_alignment(num_prompts: int, tuned: bool = True):
     (profiles/batch1_r03.txt)."""
     if not tuned:
         return 1, 1
+    ov = os.environ.get("JF_GRID_ALIGN")                     # "t_align,logit_align": A/B runs (profiles/batch1_align_ab_r04.txt)
+    if ov:
+        t, l = (int(x) for x in ov.split(","))
+        return max(t, 1), max(l, 1)
     P = max(int(num_prompts), 1)
+    if P <= 2:
+        # one or two prompts: rows on the M = 8..56 part of the table (round 4; padding a 17-24-token row to 64 cost a
+        # forward 5.9 ms against 4.9 ms at 16 rows, profiles/batch1_forward_split_r03.txt)
+        return 8, 8
     return max(8, 64 // P), max(64, 8 * P)
 
 

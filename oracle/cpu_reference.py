@@ -139,14 +139,17 @@ class _Hooked(O.MultiblockOracle):
 
 def cpu_multiblock_call(model: CpuQwen2, cache: CpuCache, input_ids, kv_tokens, deadline: Optional[float] = None, **kw):
     """One generation call (MB:227-740) on the CPU.  Returns the oracle state (ret, next_token, iters).  With a
-    ``deadline`` (perf_counter seconds) the call is abandoned between iterations once it is passed; ``st.partial``
-    then holds the tokens the real-active block had accepted so far (bounded CPU sample for bench.py)."""
+    ``deadline`` (perf_counter seconds, or a callable taking the tokens accepted so far in this call) the call is abandoned
+    between iterations once it is passed / returns True; ``st.partial`` then holds the tokens the real-active block had
+    accepted so far (bounded CPU sample for bench.py)."""
     st = _Hooked(input_ids, kv_tokens, cache=cache, **kw)
     st.partial = None
     while True:
-        if deadline is not None and time.perf_counter() > deadline:
-            st.partial = sum(len(a) for b, a in enumerate(st.out_acc) if not st.need_reverify[b])
-            return st
+        if deadline is not None:
+            acc = sum(len(a) for b, a in enumerate(st.out_acc) if not st.need_reverify[b])
+            if deadline(acc) if callable(deadline) else time.perf_counter() > deadline:
+                st.partial = acc
+                return st
         step = st.begin_iteration()
         if step is None:
             break
@@ -171,17 +174,26 @@ def cpu_prefill(model: CpuQwen2, prompt: List[int], draft: List[int]):
 
 
 def timed_tokens_per_second(model: CpuQwen2, prompt: List[int], rng, *, n, K, r, pool, eos, pad, budget_s=20.0,
-                            max_calls=64):
-    """Bounded CPU sample of the same workload: prefill (untimed) then generation calls until ``budget_s``."""
+                            max_calls=64, min_tokens=0, hard_cap_s=None):
+    """Bounded CPU sample of the same workload: prefill (untimed) then generation calls until ``budget_s`` has passed AND at
+    least ``min_tokens`` tokens were accepted (never beyond ``hard_cap_s``)."""
     text = list(prompt)
     ngram, cache = cpu_prefill(model, prompt, [rng.choice(text) for _ in range(n)])
     kv = list(prompt)
     inp = ngram
     t0 = time.perf_counter()
     tokens = iters = calls = 0
-    while time.perf_counter() - t0 < budget_s and calls < max_calls:
-        st = cpu_multiblock_call(model, cache, inp, kv, deadline=t0 + budget_s, n=n, K=K, r=r, n_gram_pool_size=pool,
-                                 eos_token_id=eos, pad_token_id=pad)
+    cap = budget_s if hard_cap_s is None else max(hard_cap_s, budget_s)
+    while calls < max_calls:
+        el = time.perf_counter() - t0
+        if el >= cap or (el >= budget_s and tokens >= min_tokens):
+            break
+        # a call is abandoned between iterations once the budget has passed and the token floor is met, or at the hard cap
+        def stop(acc_in_call, _done=tokens):
+            e = time.perf_counter() - t0
+            return e >= cap or (e >= budget_s and _done + acc_in_call >= min_tokens)
+        st = cpu_multiblock_call(model, cache, inp, kv, deadline=stop, n=n, K=K, r=r,
+                                 n_gram_pool_size=pool, eos_token_id=eos, pad_token_id=pad)
         if st.partial is not None:                 # budget hit inside a call: count what was accepted so far
             tokens += st.partial
             iters += st.iters

@@ -261,3 +261,120 @@ def test_shard_is_i_mod_world_for_eight_ranks():
         assert mine == [i for i in prompts if i % 8 == rank] and len(mine) == 8
         seen += mine
     assert sorted(seen) == prompts
+
+
+_RCCL_WORKER = textwrap.dedent("""
+    import json, os, sys
+    sys.path.insert(0, {root!r})
+    import torch
+    from jacobiforcing_amd import distributed as jd
+    info = jd.init_from_env("nccl", force=True)
+    assert torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device())
+    jd.barrier(dev)                                      # RCCL barrier (an all_reduce on the device) + synchronize
+    agg = jd.gather_throughput(tokens=123.0, iterations=7.0, seconds=0.5, device=dev)   # two all_reduces of device tensors
+    x = torch.arange(1 << 20, dtype=torch.float32, device=dev)
+    torch.distributed.all_reduce(x)                      # a payload large enough for RCCL's ring kernels
+    jd.barrier(dev)
+    print(json.dumps(dict(agg=agg, ws=info.world_size, backend=jd.backend_name(), sum=float(x.sum()))))
+    torch.distributed.destroy_process_group()
+""")
+
+
+@pytest.mark.gpu
+def test_rccl_single_rank_group_runs_the_collectives(tmp_path):
+    """RCCL itself on the one GPU of the box: a one-rank "nccl" process group still loads librccl, creates the communicator
+    and launches the reduce kernels — `distributed.init_from_env(force=True)`, `barrier(device)` and `gather_throughput` on
+    device tensors are exactly the calls the 8-GPU run makes (the only exchange is the final throughput gather)."""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(_RCCL_WORKER.format(root=str(ROOT)))
+    with __import__("socket").socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("JF_FORCE_DEVICE",)}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["backend"] == "nccl" and d["ws"] == 1
+    assert d["agg"] == dict(tokens=123.0, iterations=7.0, seconds=0.5, world_size=1)
+    assert d["sum"] == float((1 << 20) * ((1 << 20) - 1) // 2)
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_through_rccl():
+    """`bench.py --gpus 1` with the process group forced through init_process_group("nccl"): the barriers around the timed
+    region and the final gather run on RCCL, and the line says which backend carried them."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "JF_FORCE_DEVICE")}
+    with __import__("socket").socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env.update(JF_DIST_BACKEND="nccl", JF_DIST_FORCE_INIT="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--model", "tiny",
+                        "--prompts-per-gpu", "4", "--no-scripted", "--no-shapes", "--no-sections", "--cpu-baseline-seconds", "0"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["dist_backend"] == "nccl" and d["value"] > 0 and d["steps"] == 3
+
+
+def test_forced_single_rank_group_over_gloo(tmp_path):
+    """The same forced one-rank group on the CPU (gloo): init_from_env(force=True) creates it, the gather returns its input."""
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent(f"""
+        import json, sys
+        sys.path.insert(0, {str(ROOT)!r})
+        import torch
+        from jacobiforcing_amd import distributed as jd
+        info = jd.init_from_env("gloo", force=True)
+        jd.barrier()
+        print(json.dumps(dict(agg=jd.gather_throughput(5.0, 2.0, 1.5), backend=jd.backend_name())))
+        torch.distributed.destroy_process_group()
+    """))
+    with __import__("socket").socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d == dict(agg=dict(tokens=5.0, iterations=2.0, seconds=1.5, world_size=1), backend="gloo")
+
+
+def test_bench_line_labels_derived_evidence():
+    """roofline.traffic is derived from the committed PMC passes, not measured in the run: the line says so."""
+    import bench
+    src = bench._pmc_source()
+    assert src is not None and "derived, not measured in this run" in src and "profiles/pmc_verify_latest.json" in src
+    t = bench._pmc_traffic(dict(avg_bytes=1000.0))
+    assert t is not None and 900.0 < t < 1200.0
+
+
+@pytest.mark.gpu
+def test_bench_headline_runs_a_checkpoint_directory(tmp_path):
+    """JF_MODEL=<hf dir> (config.json + *.safetensors) makes that checkpoint the headline: the line names it, says the
+    weights are the checkpoint's, and reports the tokens per forward those weights give — the first box that holds
+    JacobiForcing_Coder_7B_v1 produces north_star's number without a code change."""
+    tr = pytest.importorskip("transformers")
+    pytest.importorskip("safetensors")
+    hf_cfg = tr.Qwen2Config(vocab_size=512, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                            num_key_value_heads=2, max_position_embeddings=4096, rms_norm_eps=1e-6, rope_theta=10000.0,
+                            tie_word_embeddings=False, attention_dropout=0.0, use_sliding_window=False, eos_token_id=511,
+                            pad_token_id=510)
+    torch.manual_seed(5)
+    d = tmp_path / "TinyJacobi_v1"
+    tr.Qwen2ForCausalLM(hf_cfg).eval().to(torch.bfloat16).save_pretrained(str(d), safe_serialization=True)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["JF_MODEL"] = str(d)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "4", "--warmup", "1", "--prompts-per-gpu", "4",
+                        "--no-scripted", "--no-shapes", "--no-sections", "--cpu-baseline-seconds", "0"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["config"]["model"] == "TinyJacobi_v1 (checkpoint)"
+    assert "checkpoint directory" in line["config"]["weights"] and line["tokens_per_forward"] >= 1.0
+    assert "traffic_source" in line["roofline"]
