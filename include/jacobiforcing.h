@@ -388,15 +388,22 @@ JF_API int jf_engine_fill(const int64_t *draft, int B, int L, const int32_t *seq
  *
  * The reference builds its target distribution IN THE DTYPE OF THE LOGITS (JDN:64-70 has no .float(); the engine's
  * logits are bf16, MR:1382), so dtype selects the arithmetic of every jf_rs_* call:
- *   JF_F32   p = softmax(logits / T) in float32.
+ *   JF_F32   xs = fl32(x / T), p = softmax(xs) rounded once to float32.
  *   JF_BF16  xs = bf16(float(x) / float(T)) (one rounding of the float32 quotient; T == 1 leaves x as it is),
- *            p = bf16(exp(xs - max xs) / sum exp(xs - max xs)) with float32 inside: torch's rounding points.
+ *            p = softmax(xs) rounded once to bf16: torch's rounding points.
  *            `u < p`, the inverse-CDF draws and the masked argmax all use the ROUNDED p.
+ *   "softmax" is the EXACT quotient exp(xs - max xs) / sum exp(xs - max xs) (torch's float32 kernels approximate it to an
+ *   ulp of float32, which after the bf16 rounding is one ulp on ~1 % of the entries): jf_rs_step / jf_rs_onpolicy_step
+ *   evaluate every probability a decision depends on in float64 (accept tests against the float32 row sum with a proven
+ *   error band, the row's float64 sum where that cannot decide; rejected rows entirely in float64), so token ids, draw counts
+ *   and stream cursors equal the definition bit for bit (oracle/jacobi_oracle.py: exact_softmax_rows).  Rows holding NaN /
+ *   +inf keep the plain float32 formula (NaN where torch's softmax is NaN).
  *
  * jf_rs_probs: fused softmax-gather + argmax over logits [R, V] read once.  For row r:
- *   p_draft[r] = p[draft_next[r]] (JDN:65-70, 328; a float holding a bf16 value for JF_BF16), row_max[r] = max xs,
- *   row_sumexp[r] = sum exp(xs - max) (both for the residual sampling) and the packed argmax of the RAW logits (next
- *   draft, JDN:446/619).  packed must be zero on entry.
+ *   p_draft[r] = p[draft_next[r]] (JDN:65-70, 328; a float holding a bf16 value for JF_BF16; the float32 approximation —
+ *   informational: the steps re-derive it), row_max[r] = max xs (exact), row_sumexp[r] = sum exp(xs - max) in float32 (relative
+ *   error < 2^-14: the steps' error band) and the packed argmax of the RAW logits (next draft, JDN:446/619).  packed must
+ *   be zero on entry.
  */
 JF_API int jf_rs_probs(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride,
                 const int64_t *draft_next, float temperature, float *p_draft, float *row_max,
@@ -422,11 +429,14 @@ typedef struct jf_rs_row {
  *   u_stream / bonus_stream (floats in [0,1)) and pad_stream (token ids) are consumed cyclically from *cursor in row
  *   order, exactly where the reference calls torch.rand / torch.multinomial / torch.randint.
  *   committed [B, L], next_draft [B, L] (JDN:444-466), rows [B].  packed is re-zeroed.
- *   workspace: jf_rs_step_workspace_bytes(B) bytes (float64 segment sums of the rejected rows, a row list and the hand-off
- *   words of the one-launch step), 16-byte aligned, ZERO before its first use (one torch.zeros at start-up); the calls
- *   themselves never need it re-zeroed (the hand-off words carry a per-call generation number).
- *   Batches of at most 128 rows (B * (L-1) <= 4096) run as ONE launch: accept walk, segment sums, draw counting, bonus walks
- *   and the finish are roles of one kernel (JF_RS_FUSED=0 selects the four launches that larger batches use).
+ *   workspace: jf_rs_step_workspace_bytes(B) bytes (float64 sums of the rejected rows per segment and per wave-tile, a row
+ *   list and the hand-off words of the one-launch step: ~9 KB per row), 16-byte aligned, ZERO before its first use (one
+ *   torch.zeros at start-up); the calls themselves never need it re-zeroed (the hand-off words carry a per-call generation
+ *   number).
+ *   Batches of at most 128 rows (B * (L-1) <= 4096) run as ONE launch when the device keeps enough workgroups of it resident
+ *   (asked of the runtime): accept walk, row sums, draw counting, bonus walks and the finish are roles of one kernel whose
+ *   in-kernel waits are bounded (2 s; a timeout is reported as JF_E_LAUNCH in rows[0].rsv, which the caller clears).
+ *   JF_RS_FUSED=0 selects the six launches that larger batches use.
  */
 JF_API size_t jf_rs_step_workspace_bytes(int64_t rows);   /* rows = B (jf_rs_step) or R (jf_rs_onpolicy_step) */
 JF_API int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_stride, const int64_t *draft, int B, int L,

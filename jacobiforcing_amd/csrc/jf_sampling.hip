@@ -2,13 +2,19 @@
 // step (jf_rs_step) and the on-policy rollout step (jf_rs_onpolicy_step).
 //
 // dtype is part of the semantics (JDN = inference_engine/engine/jacobi_decoding_nongreedy.py):
-//   JF_F32   probabilities are a float32 softmax of logits * (1/T): p = expf(x/T - M) / S.
+//   JF_F32   xs = fl32(x / T), probabilities are the softmax of xs rounded ONCE to float32.
 //   JF_BF16  the reference never widens the engine's bf16 logits (MR:1382, JDN:64-70), so torch rounds after every op:
 //            xs = bf16(float(x) / float(T))  (skipped when T == 1, JDN:68; ATen div_true_kernel: correctly rounded
-//            float32 quotient, then one rounding to bf16), p = bf16(expf(xs - M) / S) with M = max xs, S = sum expf(xs - M)
-//            in float32.  `u < p`, the inverse-CDF walk of the bonus / re-draft draws and the masked argmax all work on the
-//            ROUNDED probabilities, exactly like the reference's `probs` tensor.
+//            float32 quotient, then one rounding to bf16), p = the softmax of xs rounded ONCE to bf16.  `u < p`, the
+//            inverse-CDF walk of the bonus / re-draft draws and the masked argmax all work on the ROUNDED probabilities,
+//            exactly like the reference's `probs` tensor.
+//   "The softmax" is the exact quotient exp(xs - M) / sum exp(xs - M) (see "Exact probabilities" below): torch's float32
+//   kernel approximates it to an ulp; jf_rs_probs' p_draft / row_sumexp are such float32 approximations too (one pass over
+//   the logits), and every DECISION of the steps is made on the exact value.
 #include "jf_common.h"
+
+#include <atomic>
+#include <mutex>
 
 // ------------------------------------------------------------------------------------------------
 // numeric helpers
@@ -23,7 +29,7 @@ __device__ __forceinline__ float bf16_rne(float x) {         // nearest bfloat16
 // temperature-scaled logit, exactly as torch forms it for this dtype
 template <int DT>
 __device__ __forceinline__ float rs_scaled(float x, float t, float inv_t, bool unit_t) {
-    if constexpr (DT == JF_F32) return x * inv_t;
+    if constexpr (DT == JF_F32) return unit_t ? x : __fdiv_rn(x, t);      // torch: logits / T is a true division (round 4; x * (1/T) before)
     else return unit_t ? x : bf16_rne(__fdiv_rn(x, t));
 }
 // probability of one element given the row statistics
@@ -384,34 +390,110 @@ extern "C" int jf_rs_probs(const void *logits, int dtype, int64_t R, int64_t V, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Inverse-CDF draws (the injected stand-in for torch.multinomial, JDN:126-153 / JDO:150-168): the smallest index whose
-// float64 running sum of probabilities, in vocabulary order, exceeds u * total.
+// Exact probabilities (round 4).
 //
-// Two levels, both streaming the row with lane-contiguous 16-byte loads:
-//   rs_rowsum_kernel   RS_SEG workgroups per selected row; each sums one contiguous vocabulary segment in float64
-//                      (per-lane partials, one tree) -> segsum[row][seg].  The row is read ONCE however many draws follow.
-//                      The workgroup whose segment holds the row's PROPOSED token also records the mass in front of it
-//                      inside the segment and its own probability: with the segment sums that is the token's interval
-//                      [c_lo, c_hi) of the CDF, so "this draw returns the proposed token again" (JDN:140-146: draw until
-//                      the sample differs, at most 16 times) is a comparison of u * total with two numbers — the serial
-//                      part of the reference's draw order costs a few cycles per draw and every row needs ONE real pick.
-//   rs_pick (device)   one workgroup per draw: prefix over the RS_SEG segment sums -> the segment the threshold falls
-//                      into -> re-read that one segment (V / RS_SEG elements, L2-resident) with a wavefront scan per
-//                      2048/1024-element tile -> the crossing lane resolves inside its 8/4 elements.
+// Rounds 1-3 formed  p = bf16(expf(xs - M) / S)  with a float32 row sum S: two float32 softmax implementations differ in the
+// last place, after the bf16 rounding that is one ulp on ~1 % of the entries, and one inverse-CDF draw in ~10^6 then lands
+// on the other side of a token boundary (profiles/soak_r02.txt, seed 4555).  The probability tensor is now DEFINED as the
+// exact quotient rounded once (oracle/jacobi_oracle.py, exact_softmax_rows):
+//
+//     p_i = RN_dtype( exp(xs_i - M) / sum_j exp(xs_j - M) )          dtype = bf16 for bf16 logits, float32 for float32 logits
+//
+// and everything a decision depends on is evaluated to that definition:
+//   * accept tests  u < p[proposed]  (every row): p from a float64 exp of the gathered logit over the streaming kernel's
+//     float32 row sum, whose relative error is bounded by RS_EPS-ish (rs_eps_row); the test is decided when u lies outside
+//     the two candidate roundings — else (~1e-4 p of the tests) the accept workgroup forms the row's float64 sum itself;
+//   * the CDF of a rejected row: its 16 segment workgroups first sum float64 exps (partials exchanged inside the launch:
+//     every one of them needs the whole row's S), then round every element exactly: bf16 logits take a float32 product
+//     whose error band (2^-21) is tested against the rounding boundaries (1 element in ~8 000 falls back to the float64
+//     quotient), float32 logits always the float64 quotient;
+//   * the inverse-CDF walk and the masked argmax re-derive the few probabilities they touch with the same float64 S.
+// float64 evaluation errs by ~5e-16; the oracle re-decides elements that close to a rounding boundary in 60-digit decimal
+// arithmetic, the kernels do not (1 element in ~10^13).
 // ------------------------------------------------------------------------------------------------
+__device__ const double RS_EXP2_TAB[64] = {   // 2^(j/64), correctly rounded
+    1.0, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284, 1.0442737824274138, 1.0556451783605572, 1.0671404006768237,
+    1.0787607977571199, 1.0905077326652577, 1.102382583307841, 1.1143867425958924, 1.1265216186082418, 1.1387886347566916,
+    1.1511892299529827, 1.1637248587775775, 1.1763969916502812, 1.189207115002721, 1.202156731452703, 1.215247359980469,
+    1.22848053610687, 1.241857812073484, 1.255380757024691, 1.2690509571917332, 1.2828700160787783, 1.2968395546510096,
+    1.3109612115247644, 1.3252366431597413, 1.339667524053303, 1.3542555469368927, 1.3690024229745905, 1.383909881963832,
+    1.3989796725383112, 1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647, 1.4768261459394993,
+    1.4929077282912648, 1.5091644275934228, 1.5255981507445384, 1.5422108254079407, 1.559004400237837, 1.5759808451078865,
+    1.593142151342267, 1.6104903319492543, 1.6280274218573478, 1.645755478153965, 1.6636765803267364, 1.681792830507429,
+    1.7001063537185235, 1.718619298122478, 1.7373338352737062, 1.7562521603732995, 1.7753764925265212, 1.7947090750031072,
+    1.8142521755003989, 1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656, 1.9152065613971474,
+    1.9360617934922943, 1.9571441241754002, 1.978456026387951};
+constexpr double RS_EXP_CUT = -104.0;             // exp(d) < 2^-150: the quotient (S >= 1) rounds to 0 in bf16 and in float32
+__device__ __forceinline__ void rs_load_tab(double *tab) {   // 64-entry table into LDS (callers follow with a barrier)
+    if (threadIdx.x < 64) tab[threadIdx.x] = RS_EXP2_TAB[threadIdx.x];
+}
+// exp(d) for RS_EXP_CUT <= d <= 0, relative error <= 2.3e-16 (checked against 50-digit decimals over 20 000 arguments):
+// d = k ln2/64 + r, |r| <= ln2/128, exp(r) by a degree-5 polynomial, 2^(k/64) = 2^(k >> 6) * tab[k & 63].  14 float64 ops.
+__device__ __forceinline__ double rs_exp64(double d, const double *tab) {
+    const double kf = __builtin_rint(d * 92.33248261689366);                               // 64 / ln 2
+    const double r = __builtin_fma(-kf, 2.9815858269852933e-12, __builtin_fma(-kf, 0.01083042469326756, d));   // ln2/64 = hi (33 bits) + lo
+    double p = 8.333333333333333e-3;
+    p = __builtin_fma(p, r, 4.1666666666666664e-2);
+    p = __builtin_fma(p, r, 1.6666666666666666e-1);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = p * r;                                                                              // exp(r) - 1
+    const int k = (int)kf;
+    const double tj = tab[k & 63];
+    return __builtin_ldexp(__builtin_fma(tj, p, tj), k >> 6);
+}
+// nearest-even bf16 of a non-negative float64 (subnormals included), as a float: float32 by round-to-odd, then RNE
+__device__ __forceinline__ float rs_bf16_of_f64(double q) {
+    const float f = (float)q;
+    const double back = (double)f;
+    uint32_t u = __float_as_uint(f);
+    if (back > q) u -= 1u;                          // toward zero
+    if (back != q) u |= 1u;                         // sticky
+    u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+    return __uint_as_float(u);
+}
+template <int DT>
+__device__ __forceinline__ float rs_round_prob(double q) {
+    if constexpr (DT == JF_BF16) return rs_bf16_of_f64(q);
+    else return (float)q;
+}
+// a row statistic pair the exact path can work with (else: NaN / inf rows keep the plain float32 formula, like torch)
+__device__ __forceinline__ bool rs_row_is_exact(float M, float S) {
+    return (__float_as_uint(M) & 0x7F800000u) != 0x7F800000u && S > 0.f && (__float_as_uint(S) & 0x7F800000u) != 0x7F800000u;
+}
+// relative error bound of the streaming kernel's float32 row sum against the exact sum relative to M: float32 accumulation
+// and v_exp_f32 (2^-15, three times what the sweeps show), plus the scaled maximum's rounding residual and the float32
+// x * (1/T) of its exponent arguments, both proportional to |M|
+__device__ __forceinline__ double rs_eps_row(float M) {
+    return 3.0517578125e-5 + 2.384185791015625e-7 * (1.45 * (double)fabsf(M) + 32.0);
+}
+// exp(xs - M) in float64 for a scaled logit; 0 for anything below the cut (and for -inf)
+__device__ __forceinline__ double rs_e64(float xs, double M, const double *tab) {
+    const double d = (double)xs - M;
+    return d >= RS_EXP_CUT ? rs_exp64(d, tab) : 0.0;
+}
+
 constexpr int RS_SEG = 16;
-constexpr int RS_TILES = 8;                       // tiles of a segment whose per-lane sums are kept in registers
+constexpr int RS_TILES = 8;                       // tiles of a segment whose vectors are kept in registers by the whole-workgroup walk
 constexpr int RS_MAX_TRIES = 16;                  // JDN:135 max_tries
+constexpr int RS_WT = 64;                         // wave-tile sums kept per segment (16 tiles x 4 wavefronts): V <= 16 * 16 * 256 * EPV
+template <int DT> struct RsKeep { static constexpr int NV = DT == JF_BF16 ? 5 : 10; };   // vectors per lane of a Qwen-sized segment
 
 __host__ __device__ inline int64_t rs_seg_elems(int64_t V, int epv) {
     const int64_t tile = 256 * (int64_t)epv;
     const int64_t per = (V + RS_SEG - 1) / RS_SEG;
     return ((per + tile - 1) / tile) * tile;
 }
+__host__ __device__ inline bool rs_hier_ok(int64_t V, int epv) {       // the wave-tile sums of a segment fit RS_WT entries
+    return rs_seg_elems(V, epv) / (256 * (int64_t)epv) * 4 <= RS_WT;
+}
 
 constexpr int RS_FLAG_STRIDE = 16;                // 8-byte words between two rows' accept flags (one 128-byte line each)
 struct RsWs {                                     // carve-up of the step workspace for `rows` items
-    double *segsum;                               // [rows, RS_SEG] float64 mass of each vocabulary segment
+    double *segsum;                               // [rows, RS_SEG] float64 mass of each vocabulary segment (rounded probabilities)
+    double *wtsum;                                // [rows, RS_SEG, RS_WT] the same per (tile, wavefront) of a segment, tile-major
+    double *s64part;                              // [rows, RS_SEG] float64 sum of exp(xs - M) over the segment (phase A)
+    double *s64;                                  // [rows] the row's float64 sum (all segments, in order)
     double *lo_part;                              // [rows] mass in front of the avoided token inside its segment
     double *p_avoid;                              // [rows] probability of the avoided token
     int32_t *sel_row;                             // [rows] logits row to sum for item i, -1 = none
@@ -419,32 +501,37 @@ struct RsWs {                                     // carve-up of the step worksp
     float *pick_u;                                // [rows] the uniform of the draw that counts; < 0: masked argmax instead
     // hand-off words of the one-launch step (rs_step_fused_kernel), all tagged with the call's generation number, so nothing
     // has to be re-zeroed and a late poller can never see a recycled word
-    unsigned long long *flag;                     // [rows * RS_FLAG_STRIDE] (gen << 32) | (reject_pos + 2): the accept walk has decided the
-                                                  // row; one 128-byte line per row (its 17 pollers must not share lines with other rows)
+    unsigned long long *flag;                     // [rows * RS_FLAG_STRIDE] (gen << 32) | eos << 30 | n_accepted << 16 | (reject_pos + 2):
+                                                  // the accept walk has decided the row; one 128-byte line per row
     unsigned long long *pick;                     // [rows] (gen << 32) | bits of the uniform that counts (chain workgroup -> bonus workgroup)
-    uint32_t *segdone;                            // [rows, RS_SEG] gen: this segment's sum is stored
-    uint32_t *bonusdone;                          // [rows] gen: the row's bonus token is stored
+    unsigned long long *fin;                      // [rows] (gen << 32) | n_pads: the row's bonus workgroup has finished the row
+    uint32_t *s64done;                            // [rows, RS_SEG] gen: this segment's float64 partial is stored
+    uint32_t *segdone;                            // [rows, RS_SEG] gen: this segment's sums are stored
     uint32_t *acceptdone;                         // [4]   gen: [0] the accept workgroup has written every row record, [1] the chain workgroup every draw count
 };
 static inline size_t rs_ws_bytes(int64_t rows) {
     const size_t r = (size_t)((rows + 3) / 4 * 4);
-    return r * RS_SEG * sizeof(double) + 2 * r * sizeof(double) + 3 * r * sizeof(int32_t) +
-           r * (RS_FLAG_STRIDE + 1) * sizeof(unsigned long long) + r * RS_SEG * sizeof(uint32_t) + r * sizeof(uint32_t) + 4 * sizeof(uint32_t);
+    return r * RS_SEG * sizeof(double) * 2 + r * RS_SEG * RS_WT * sizeof(double) + 3 * r * sizeof(double) + 3 * r * sizeof(int32_t) +
+           r * (RS_FLAG_STRIDE + 2) * sizeof(unsigned long long) + 2 * r * RS_SEG * sizeof(uint32_t) + 4 * sizeof(uint32_t);
 }
 __host__ __device__ inline RsWs rs_ws(void *ws, int64_t rows) {
     const size_t r = (size_t)((rows + 3) / 4 * 4);
     RsWs w;
     w.segsum = (double *)ws;
-    w.lo_part = w.segsum + r * RS_SEG;
+    w.wtsum = w.segsum + r * RS_SEG;
+    w.s64part = w.wtsum + r * RS_SEG * RS_WT;
+    w.s64 = w.s64part + r * RS_SEG;
+    w.lo_part = w.s64 + r;
     w.p_avoid = w.lo_part + r;
-    w.sel_row = (int32_t *)(w.p_avoid + r);
+    w.flag = (unsigned long long *)(w.p_avoid + r);
+    w.pick = w.flag + r * RS_FLAG_STRIDE;
+    w.fin = w.pick + r;
+    w.sel_row = (int32_t *)(w.fin + r);
     w.avoid = w.sel_row + r;
     w.pick_u = (float *)(w.avoid + r);
-    w.flag = (unsigned long long *)(w.pick_u + r);
-    w.pick = w.flag + r * RS_FLAG_STRIDE;
-    w.segdone = (uint32_t *)(w.pick + r);
-    w.bonusdone = w.segdone + r * RS_SEG;
-    w.acceptdone = w.bonusdone + r;
+    w.s64done = (uint32_t *)(w.pick_u + r);
+    w.segdone = w.s64done + r * RS_SEG;
+    w.acceptdone = w.segdone + r * RS_SEG;
     return w;
 }
 extern "C" size_t jf_rs_step_workspace_bytes(int64_t rows) { return rows > 0 ? rs_ws_bytes(rows) : 0; }
@@ -471,11 +558,6 @@ extern "C" __attribute__((visibility("default"))) int jf_exp_rs_rows(unsigned lo
 #define RS_STAMP_MIN(k) do { } while (0)
 #define RS_STAMP_MAX(k) do { } while (0)
 #define RS_ROWSTAMP(k, b) do { } while (0)
-#endif
-#ifdef JF_EXP_RS_TRACE
-#define RS_PICKSTAMP(k) do { if (blockIdx.x == 66 && threadIdx.x == 0) g_rstrace[k] = (unsigned long long)__builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define RS_PICKSTAMP(k) do { } while (0)
 #endif
 
 __device__ __forceinline__ double wave_sum_f64(double v) {
@@ -506,79 +588,371 @@ __device__ __forceinline__ RsRow rs_make_row(const void *logits, int64_t r, int6
 __device__ __forceinline__ void st_agent_f64(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ld_agent_f64(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// One vocabulary segment of one selected row (r = logits row, av = the token its draws must avoid).  SIG: results go out as
-// agent-scope atomic stores followed by the segment's generation word (the consumers are other workgroups of the SAME launch).
-template <int DT, bool SIG>
-__device__ __forceinline__ void rs_rowsum_body(const void *logits, int64_t V, int64_t row_stride, const float *row_max,
-                                               const float *row_sumexp, float t, const RsWs &w, int item, int seg, int r,
-                                               int64_t av, uint32_t gen) {
+// bounded in-kernel waits: a wait that lasts 2 s of the 100 MHz constant clock gives up; the caller reports
+// JF_E_LAUNCH through rows[0].rsv instead of hanging the GPU
+constexpr unsigned long long RS_WAIT_TICKS = 200000000ull;
+__device__ __forceinline__ bool rs_wait_flag(const unsigned long long *word, uint32_t gen, unsigned long long *out, int sleep = 16) {
+    unsigned long long v;
+    unsigned spins = 0;
+    unsigned long long t0 = 0;
+    while ((uint32_t)((v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != gen) {
+        __builtin_amdgcn_s_sleep(16);
+        if ((++spins & 1023u) == 0u) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > RS_WAIT_TICKS) { *out = 0ull; return false; }
+        }
+    }
+    (void)sleep;
+    *out = v;
+    return true;
+}
+__device__ __forceinline__ bool rs_wait_word(const uint32_t *word, uint32_t gen) {
+    unsigned spins = 0;
+    unsigned long long t0 = 0;
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen) {
+        __builtin_amdgcn_s_sleep(8);
+        if ((++spins & 1023u) == 0u) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > RS_WAIT_TICKS) return false;
+        }
+    }
+    return true;
+}
+
+// scaled logits of one 16-byte vector, as torch forms them for this dtype
+template <int DT>
+__device__ __forceinline__ void rs_scaled_from_vec(const RsRow &r, const u32x4 v, float (&xs)[Elem<DT>::EPV]) {
+    rs_unpack<DT>(v, xs);
+#pragma unroll
+    for (int j = 0; j < Elem<DT>::EPV; ++j) xs[j] = rs_scaled<DT>(xs[j], r.t, r.inv_t, r.unit_t);
+}
+// exact probabilities of one vector (elements >= V hold -inf: probability 0), given the row's float64 1 / S
+template <int DT>
+__device__ __forceinline__ void rs_exact_probs_from_vec(const RsRow &r, const u32x4 v, double invS, const double *tab, float (&p)[Elem<DT>::EPV]) {
+    float xs[Elem<DT>::EPV];
+    rs_scaled_from_vec<DT>(r, v, xs);
+#pragma unroll
+    for (int j = 0; j < Elem<DT>::EPV; ++j) p[j] = rs_round_prob<DT>(rs_e64(xs[j], (double)r.M, tab) * invS);
+}
+// probabilities of one vector by whichever definition the row takes: exact (invS > 0) or the plain float32 formula
+template <int DT>
+__device__ __forceinline__ void rs_any_probs_from_vec(const RsRow &r, const u32x4 v, double invS, const double *tab, float (&p)[Elem<DT>::EPV]) {
+    if (invS > 0.0) rs_exact_probs_from_vec<DT>(r, v, invS, tab, p);
+    else rs_probs_from_vec<DT>(r, v, p);
+}
+
+// float64 sum of exp(xs - M) over a whole row by one workgroup (every thread gets the result).  Used where ONE row's exact
+// sum is needed on the spot: an accept test that the float32 sum cannot decide, and the rows of the on-policy accept.
+template <int DT>
+__device__ double rs_row_s64_wg(const RsRow &row, const double *tab, double *s_red /* LDS, 4 */) {
     constexpr int EPV = Elem<DT>::EPV;
+    double acc = 0.0;
+    for (int64_t b0 = (int64_t)threadIdx.x * EPV; b0 < row.V; b0 += (int64_t)4 * 256 * EPV) {
+        u32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int64_t e0 = b0 + (int64_t)k * 256 * EPV; if (e0 < row.V) v[k] = rs_load_vec<DT>(row, e0); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t e0 = b0 + (int64_t)k * 256 * EPV;
+            if (e0 >= row.V) continue;
+            float xs[EPV];
+            rs_scaled_from_vec<DT>(row, v[k], xs);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) acc += rs_e64(xs[j], (double)row.M, tab);
+        }
+    }
+    acc = wave_sum_f64(acc);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+// exact probability of one element, by the whole workgroup (uniform control flow)
+template <int DT>
+__device__ float rs_exact_prob_wg(const void *logits, int64_t r, int64_t V, int64_t row_stride, float t, float M, int64_t tok,
+                                  const double *tab, double *s_red) {
+    const RsRow row = rs_make_row<DT>(logits, r, V, row_stride, t, M, 1.f);
+    const double S = rs_row_s64_wg<DT>(row, tab, s_red);
+    if (tok < 0 || tok >= V) return 0.f;
+    const float xs = rs_scaled<DT>(load_f<DT>(row.p, tok), row.t, row.inv_t, row.unit_t);
+    return rs_round_prob<DT>(rs_e64(xs, (double)M, tab) / S);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Inverse-CDF draws (the injected stand-in for torch.multinomial, JDN:126-153 / JDO:150-168): the smallest index whose
+// float64 running sum of (exactly rounded) probabilities, in vocabulary order, exceeds u * total.
+//
+// The row is summed ONCE, hierarchically, by RS_SEG workgroups (one vocabulary segment each):
+//   phase A   float64 sum of exp(xs - M) over the segment -> s64part; the row's S is the sum of the RS_SEG partials in
+//             segment order (every workgroup forms the same S).  One launch: the partials are exchanged through agent-scope
+//             words inside it (the 16 workgroups of a row have consecutive block ids); several launches: rs_rowsum_a_kernel.
+//   phase B   every element's exact probability, summed in float64 per lane vector, wavefront scans per tile: the mass of
+//             every (tile, wavefront) of the segment -> wtsum, their sum in order -> segsum.  The workgroup whose segment
+//             holds the row's PROPOSED token also records the running sum in front of it (lo_part, relative to the segment)
+//             and its probability: with the segment sums that is the token's interval [c_lo, c_hi) of the CDF, so "this draw
+//             returns the proposed token again" (JDN:140-146) is a comparison of u * total with two numbers.
+// A draw then needs ONE wavefront (rs_pick_wave): segment prefix -> wave-tile prefix -> the 64 vectors of that wavefront's
+// tile slice (one 16-byte load per lane, L2-resident) -> scan -> the crossing lane resolves inside its vector.  All running
+// sums are formed the same way on both sides (sequential prefixes, one scan), so the interval test and the walk agree except
+// at float64 rounding of lane boundaries; should the walk return the proposed token after all, the masked argmax decides.
+// Vocabularies whose segments have more than RS_WT wave-tiles (V > 524 288 bf16 / 262 144 fp32) walk the segment with the
+// whole workgroup instead (rs_pick_wg).
+// ------------------------------------------------------------------------------------------------
+struct RsSumShared {
+    double tab[64];
+    double red[4];
+    double wt[RS_WT];               // wave-tile sums of this segment (phase B), tile-major
+    double part[RS_SEG];
+    double pv[8];                   // the avoided token's vector, its lane's exclusive prefix in front
+    double excl;
+    int ok;
+};
+
+// phase A of one (row, segment): float64 sum of exp(xs - M); KEEP: the float32 images of the exps stay in e32 for phase B
+template <int DT, bool KEEP>
+__device__ __forceinline__ double rs_seg_exp_sum(const RsRow &row, int64_t lo, int64_t hi, const double *tab,
+                                                 float (&e32)[RsKeep<DT>::NV][Elem<DT>::EPV], u32x4 (&v)[RsKeep<DT>::NV]) {
+    constexpr int EPV = Elem<DT>::EPV, NV = RsKeep<DT>::NV;
+    double acc = 0.0;
+    for (int64_t b0 = lo + (int64_t)threadIdx.x * EPV; b0 < hi; b0 += (int64_t)NV * 256 * EPV) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) { const int64_t e0 = b0 + (int64_t)k * 256 * EPV; if (e0 < hi) v[k] = rs_load_vec<DT>(row, e0); }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int64_t e0 = b0 + (int64_t)k * 256 * EPV;
+            if (e0 >= hi) { if constexpr (KEEP) { for (int j = 0; j < EPV; ++j) e32[k][j] = 0.f; } continue; }
+            float xs[EPV];
+            rs_scaled_from_vec<DT>(row, v[k], xs);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) {
+                const double e = rs_e64(xs[j], (double)row.M, tab);
+                acc += e;
+                if constexpr (KEEP) e32[k][j] = (float)e;
+            }
+        }
+    }
+    return acc;
+}
+
+// exact probabilities of one vector from the kept float32 exps (bf16 logits): the float32 product errs by < 2^-22, so the
+// rounding is certain unless a bf16 boundary lies inside the 2^-21 band around it (1 element in ~8 000: float64 quotient)
+template <int DT>
+__device__ __forceinline__ void rs_probs_from_kept(const RsRow &row, const u32x4 v, const float (&e)[Elem<DT>::EPV], double invS, float invS32,
+                                                   const double *tab, float (&p)[Elem<DT>::EPV]) {
+    constexpr int EPV = Elem<DT>::EPV;
+    bool slow = false;
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+        const float q = e[j] * invS32;
+        const float a = bf16_rne(q * 0.99999952316284179688f), b = bf16_rne(q * 1.00000047683715820312f);   // 1 -+ 2^-21
+        p[j] = a;
+        slow |= (a != b) || (q < 1e-36f && e[j] != 0.f);     // near float32's subnormal range the product itself is inexact
+    }
+    if (slow) rs_exact_probs_from_vec<DT>(row, v, invS, tab, p);
+}
+
+// phase B of one (row, segment): exact probabilities, float64 sums per lane vector, one scan per tile.  SIG: results go out
+// as agent-scope atomic stores followed by the segment's generation word (the consumers are other workgroups of the SAME
+// launch).  S <= 0: the row keeps the plain float32 formula (NaN / inf rows).  HIER: the segment's wave-tile sums fit the
+// table (every real vocabulary); else the sums are formed tile by tile as rs_pick_wg re-forms them.
+template <int DT, bool SIG, bool KEEP>
+__device__ __forceinline__ void rs_seg_prob_sums(const RsRow &row, int64_t lo, int64_t hi, double S, const RsWs &w, int item, int seg,
+                                                 int64_t av, uint32_t gen, RsSumShared &sh, const float (&e32)[RsKeep<DT>::NV][Elem<DT>::EPV],
+                                                 u32x4 (&v)[RsKeep<DT>::NV]) {
+    constexpr int EPV = Elem<DT>::EPV, NV = RsKeep<DT>::NV;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool mine = av >= lo && av < hi;                   // workgroup-uniform: this segment holds the avoided token
+    const int64_t avo = av - lo;
+    const int kstar = mine ? (int)(avo / (256 * EPV)) : -1;  // its tile, and its thread inside the tile
+    const int tstar = mine ? (int)((avo % (256 * EPV)) / EPV) : -1;
+    const double invS = S > 0.0 ? 1.0 / S : 0.0;
+    const float invS32 = (float)invS;
+    const int ntiles = (int)((hi - lo + 256 * EPV - 1) / (256 * EPV));
+    const bool hier = ntiles * 4 <= RS_WT;
+    double base = 0.0, front = 0.0;                          // !hier: running sum of the tiles before / in front of the token's wavefront
+    for (int k0 = 0; k0 < ntiles; k0 += NV) {
+        if constexpr (!KEEP) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) { const int64_t e0 = lo + ((int64_t)(k0 + k) * 256 + tid) * EPV; if (k0 + k < ntiles && e0 < hi) v[k] = rs_load_vec<DT>(row, e0); }
+        }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            if (k0 + k >= ntiles) continue;                  // workgroup-uniform
+            const int64_t e0 = lo + ((int64_t)(k0 + k) * 256 + tid) * EPV;
+            float p[EPV];
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) p[j] = 0.f;
+            if (e0 < hi) {
+                if constexpr (KEEP && DT == JF_BF16) {
+                    if (invS > 0.0) rs_probs_from_kept<DT>(row, v[k], e32[k], invS, invS32, sh.tab, p);
+                    else rs_probs_from_vec<DT>(row, v[k], p);
+                } else {
+                    rs_any_probs_from_vec<DT>(row, v[k], invS, sh.tab, p);
+                }
+            }
+            double a = 0.0;
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) a += (double)p[j];
+            const double incl = wave_incl_scan_f64(a, lane);  // all lanes: the wavefront's total is the scan's last value
+            const double up = __shfl_up(incl, 1, 64);         // all lanes active: never shuffle under the lane test
+            const double wt = __shfl(incl, 63, 64);
+            if (mine && k0 + k == kstar && tid == tstar) {    // the avoided token's lane: exclusive prefix inside its wavefront, its vector
+                sh.excl = lane == 0 ? 0.0 : up;
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) sh.pv[j] = (double)p[j];
+            }
+            if (hier) {
+                if (lane == 0) sh.wt[(k0 + k) * 4 + wave] = wt;
+            } else {                                          // tile by tile, as rs_pick_wg walks: (w0 + w1) + (w2 + w3) per tile
+                __syncthreads();
+                if (lane == 0) sh.red[wave] = wt;
+                __syncthreads();
+                if (mine && k0 + k == kstar) { double wb = base; for (int q = 0; q < (tstar >> 6); ++q) wb += sh.red[q]; front = wb; }
+                base += (sh.red[0] + sh.red[1]) + (sh.red[2] + sh.red[3]);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double sum = base;
+        if (hier) {
+            sum = 0.0;
+            const int istar = mine ? kstar * 4 + (tstar >> 6) : -1;
+            for (int i = 0; i < ntiles * 4; ++i) { if (i == istar) front = sum; sum += sh.wt[i]; }
+        }
+        double lo_p = 0.0, p_av = 0.0;
+        if (mine) {                                          // the running sum in front of the token, formed as the walk forms it
+            double rr = front + sh.excl;
+            const int jstar = (int)(avo % EPV);
+            for (int j = 0; j < jstar; ++j) rr += sh.pv[j];
+            lo_p = rr; p_av = sh.pv[jstar];
+        }
+        if constexpr (SIG) {
+            st_agent_f64(w.segsum + (int64_t)item * RS_SEG + seg, sum);
+            if (mine) { st_agent_f64(w.lo_part + item, lo_p); st_agent_f64(w.p_avoid + item, p_av); }
+            if (seg == 0) st_agent_f64(w.s64 + item, S);
+        } else {
+            w.segsum[(int64_t)item * RS_SEG + seg] = sum;
+            if (mine) { w.lo_part[item] = lo_p; w.p_avoid[item] = p_av; }
+            if (seg == 0) w.s64[item] = S;
+        }
+    }
+    if (hier && tid < ntiles * 4) {                          // the wave-tile table of this segment, for the one-wavefront walk
+        double *dst = w.wtsum + ((int64_t)item * RS_SEG + seg) * RS_WT;
+        if constexpr (SIG) st_agent_f64(dst + tid, sh.wt[tid]); else dst[tid] = sh.wt[tid];
+    }
+    if constexpr (SIG) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the sums are performed before the word that announces them
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(w.segdone + (int64_t)item * RS_SEG + seg, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Both phases of one (row, segment) inside ONE launch (rs_step_fused_kernel): the 16 workgroups of a row exchange their
+// float64 partials through agent-scope words.  Returns false when a peer's partial did not arrive within the wait bound.
+template <int DT>
+__device__ __forceinline__ bool rs_rowsum_fused(const void *logits, int64_t V, int64_t row_stride, const float *row_max, const float *row_sumexp,
+                                                float t, const RsWs &w, int item, int seg, int r, int64_t av, uint32_t gen, RsSumShared &sh) {
+    constexpr int EPV = Elem<DT>::EPV, NV = RsKeep<DT>::NV;
+    const int tid = threadIdx.x;
     const RsRow row = rs_make_row<DT>(logits, r, V, row_stride, t, row_max[r], row_sumexp[r]);
     const int64_t segE = rs_seg_elems(V, EPV);
     const int64_t lo = (int64_t)seg * segE;
     int64_t hi = lo + segE;
     if (hi > V) hi = V;
-    const bool mine = av >= lo && av < hi;                   // workgroup-uniform: this segment holds the avoided token
-    double acc = 0.0, front = 0.0, pav = 0.0;
-    for (int64_t b0 = lo + (int64_t)threadIdx.x * EPV; b0 < hi; b0 += (int64_t)RS_TILES * 256 * EPV) {
-        u32x4 v[RS_TILES];                                   // up to RS_TILES independent 16-byte loads in flight per lane
-#pragma unroll
-        for (int k = 0; k < RS_TILES; ++k) {
-            const int64_t e0 = b0 + (int64_t)k * 256 * EPV;
-            if (e0 < hi) v[k] = rs_load_vec<DT>(row, e0);
-        }
-#pragma unroll
-        for (int k = 0; k < RS_TILES; ++k) {
-            const int64_t e0 = b0 + (int64_t)k * 256 * EPV;
-            if (e0 >= hi) continue;
-            float p[EPV];
-            rs_probs_from_vec<DT>(row, v[k], p);
-            double a = 0.0;
-#pragma unroll
-            for (int j = 0; j < EPV; ++j) a += (double)p[j];
-            acc += a;
-            if (mine) {
-                if (e0 + EPV <= av) front += a;
-                else if (e0 <= av) {
-#pragma unroll
-                    for (int j = 0; j < EPV; ++j) {
-                        if (e0 + j < av) front += (double)p[j];
-                        if (e0 + j == av) pav = (double)p[j];
-                    }
-                }
-            }
-        }
-    }
-    acc = wave_sum_f64(acc);
-    __shared__ double sw[4], sf[4], sp[4];
-    if (mine) { front = wave_sum_f64(front); pav = wave_sum_f64(pav); }
-    if ((threadIdx.x & 63) == 0) { sw[threadIdx.x >> 6] = acc; sf[threadIdx.x >> 6] = front; sp[threadIdx.x >> 6] = pav; }
+    if (lo > V) hi = lo;                                       // (tiny vocabularies: empty trailing segments)
+    const bool exact = rs_row_is_exact(row.M, row.S);
+    const int ntiles = (int)((hi - lo + 256 * EPV - 1) / (256 * EPV));
+    rs_load_tab(sh.tab);
+    if (tid == 0) sh.ok = 1;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const double sum = (sw[0] + sw[1]) + (sw[2] + sw[3]);
-        if constexpr (SIG) {
-            st_agent_f64(w.segsum + (int64_t)item * RS_SEG + seg, sum);
-            if (mine) { st_agent_f64(w.lo_part + item, (sf[0] + sf[1]) + (sf[2] + sf[3])); st_agent_f64(w.p_avoid + item, (sp[0] + sp[1]) + (sp[2] + sp[3])); }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the sums are performed before the word that announces them
-            __hip_atomic_store(w.segdone + (int64_t)item * RS_SEG + seg, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            w.segsum[(int64_t)item * RS_SEG + seg] = sum;
-            if (mine) { w.lo_part[item] = (sf[0] + sf[1]) + (sf[2] + sf[3]); w.p_avoid[item] = (sp[0] + sp[1]) + (sp[2] + sp[3]); }
+    float e32[NV][EPV];
+    u32x4 v[NV];
+    double S = 0.0;
+    const bool keep = ntiles <= NV;                           // workgroup-uniform (true for every vocabulary up to 163 840)
+    if (exact) {
+        double acc = keep ? rs_seg_exp_sum<DT, true>(row, lo, hi, sh.tab, e32, v) : rs_seg_exp_sum<DT, false>(row, lo, hi, sh.tab, e32, v);
+        acc = wave_sum_f64(acc);
+        if ((tid & 63) == 0) sh.red[tid >> 6] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            st_agent_f64(w.s64part + (int64_t)item * RS_SEG + seg, (sh.red[0] + sh.red[1]) + (sh.red[2] + sh.red[3]));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(w.s64done + (int64_t)item * RS_SEG + seg, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (tid < RS_SEG) {                                   // the 15 peers: consecutive block ids, dispatched together
+            if (!rs_wait_word(w.s64done + (int64_t)item * RS_SEG + tid, gen)) sh.ok = 0;
+            sh.part[tid] = ld_agent_f64(w.s64part + (int64_t)item * RS_SEG + tid);
+        }
+        __syncthreads();
+        if (!sh.ok) return false;
+#pragma unroll
+        for (int s = 0; s < RS_SEG; ++s) S += sh.part[s];    // segment order: every workgroup of the row forms the same S
+    } else if (keep) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) { const int64_t e0 = lo + ((int64_t)k * 256 + tid) * EPV; if (k < ntiles && e0 < hi) v[k] = rs_load_vec<DT>(row, e0); }
     }
+    if (keep) rs_seg_prob_sums<DT, true, true>(row, lo, hi, S, w, item, seg, av, gen, sh, e32, v);
+    else rs_seg_prob_sums<DT, true, false>(row, lo, hi, S, w, item, seg, av, gen, sh, e32, v);
+    return true;
 }
 
+// The same as two launches (batches the one-launch step does not take, and the on-policy step)
 template <int DT>
-__global__ __launch_bounds__(256) void rs_rowsum_kernel(const void *logits, int64_t V, int64_t row_stride, const float *row_max,
-                                                         const float *row_sumexp, float t, RsWs w) {
+__global__ __launch_bounds__(256) void rs_rowsum_a_kernel(const void *logits, int64_t V, int64_t row_stride, const float *row_max,
+                                                           const float *row_sumexp, float t, RsWs w) {
+    constexpr int EPV = Elem<DT>::EPV, NV = RsKeep<DT>::NV;
+    __shared__ RsSumShared sh;
+    const int item = blockIdx.x / RS_SEG, seg = blockIdx.x % RS_SEG, tid = threadIdx.x;
+    const int r = w.sel_row[item];
+    if (r < 0) return;
+    const RsRow row = rs_make_row<DT>(logits, r, V, row_stride, t, row_max[r], row_sumexp[r]);
+    if (!rs_row_is_exact(row.M, row.S)) { if (tid == 0) w.s64part[(int64_t)item * RS_SEG + seg] = 0.0; return; }
+    const int64_t segE = rs_seg_elems(V, EPV);
+    const int64_t lo = (int64_t)seg * segE;
+    int64_t hi = lo + segE;
+    if (hi > V) hi = V;
+    if (lo > V) hi = lo;
+    rs_load_tab(sh.tab);
+    __syncthreads();
+    float e32[NV][EPV];
+    u32x4 v[NV];
+    double acc = rs_seg_exp_sum<DT, false>(row, lo, hi, sh.tab, e32, v);
+    acc = wave_sum_f64(acc);
+    if ((tid & 63) == 0) sh.red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) w.s64part[(int64_t)item * RS_SEG + seg] = (sh.red[0] + sh.red[1]) + (sh.red[2] + sh.red[3]);
+}
+template <int DT>
+__global__ __launch_bounds__(256) void rs_rowsum_b_kernel(const void *logits, int64_t V, int64_t row_stride, const float *row_max,
+                                                           const float *row_sumexp, float t, RsWs w) {
+    constexpr int EPV = Elem<DT>::EPV, NV = RsKeep<DT>::NV;
+    __shared__ RsSumShared sh;
     const int item = blockIdx.x / RS_SEG, seg = blockIdx.x % RS_SEG;
     const int r = w.sel_row[item];
     if (r < 0) return;
-    rs_rowsum_body<DT, false>(logits, V, row_stride, row_max, row_sumexp, t, w, item, seg, r, (int64_t)w.avoid[item], 0u);
+    const RsRow row = rs_make_row<DT>(logits, r, V, row_stride, t, row_max[r], row_sumexp[r]);
+    const int64_t segE = rs_seg_elems(V, EPV);
+    const int64_t lo = (int64_t)seg * segE;
+    int64_t hi = lo + segE;
+    if (hi > V) hi = V;
+    if (lo > V) hi = lo;
+    rs_load_tab(sh.tab);
+    double S = 0.0;
+    if (rs_row_is_exact(row.M, row.S)) {
+#pragma unroll
+        for (int s = 0; s < RS_SEG; ++s) S += w.s64part[(int64_t)item * RS_SEG + s];
+    }
+    __syncthreads();
+    float e32[NV][EPV];
+    u32x4 v[NV];
+    rs_seg_prob_sums<DT, false, false>(row, lo, hi, S, w, item, seg, (int64_t)w.avoid[item], 0u, sh, e32, v);
 }
 
-// total mass of a row and the CDF interval [c_lo, c_hi) of its avoided token, from the segment sums.  `total` is formed
-// exactly as rs_pick forms it (segments in order), so both compare u * total with the same number.
+// total mass of a row and the CDF interval [c_lo, c_hi) of its avoided token, from the segment sums.  `total` and the prefix
+// in front of the token's segment are formed exactly as the walks form them (segments in order).
 // AGENT: the sums were stored by other workgroups of the same launch (agent-scope atomics on both sides); av then comes from
 // the caller (the accept workgroup's w.avoid may not be visible yet)
 template <bool AGENT = false>
@@ -599,7 +973,7 @@ __device__ __forceinline__ void rs_interval(const RsWs &w, int item, int64_t V, 
     const double lo_p = sstar >= 0 ? (AGENT ? ld_agent_f64(w.lo_part + item) : w.lo_part[item]) : 0.0;
     const double p_av = sstar >= 0 ? (AGENT ? ld_agent_f64(w.p_avoid + item) : w.p_avoid[item]) : 0.0;
     c_lo = sstar >= 0 ? before + lo_p : 0.0;
-    c_hi = sstar >= 0 ? c_lo + p_av : 0.0;
+    c_hi = sstar >= 0 ? before + (lo_p + p_av) : 0.0;         // the walk's running sum behind the token: prefix + (relative sum + p)
 }
 
 // Up to RS_MAX_TRIES draws from stream[(pos + tr) % len] by lanes 0..15 of one wavefront: the first one that does not
@@ -617,22 +991,104 @@ __device__ __forceinline__ int rs_count_draws(UFn u_at, double total, double c_l
     return f + 1;
 }
 
+// One inverse-CDF draw by ONE wavefront (all 64 lanes, uniform control flow) over the hierarchical sums of a row:
+// segment prefix -> wave-tile prefix -> the 64 vectors of that wavefront's slice -> scan -> element.  S: the row's float64
+// sum (<= 0: plain float32 formula).  AGENT: the sums were stored by other workgroups of this launch.
+template <int DT, bool AGENT>
+__device__ __forceinline__ int rs_pick_wave(const RsRow &row, const RsWs &w, int item, double S, float u, const double *tab, int lane) {
+    constexpr int EPV = Elem<DT>::EPV;
+    auto ld = [](const double *p) { return AGENT ? ld_agent_f64(p) : *p; };
+    const double *segsum = w.segsum + (int64_t)item * RS_SEG;
+    double sg[RS_SEG];
+#pragma unroll
+    for (int s = 0; s < RS_SEG; ++s) sg[s] = ld(segsum + s);
+    double total = 0.0;
+#pragma unroll
+    for (int s = 0; s < RS_SEG; ++s) total += sg[s];
+    const double thr = (double)u * total;
+    int sstar = -1;
+    double before = 0.0, run = 0.0;
+#pragma unroll
+    for (int s = 0; s < RS_SEG; ++s) {
+        const double nx = run + sg[s];
+        if (sstar < 0 && nx > thr) { sstar = s; before = run; }
+        run = nx;
+    }
+    if (sstar < 0) return (int)(row.V - 1);                 // thr >= total: clamp like min(idx, V - 1)
+    const int64_t segE = rs_seg_elems(row.V, EPV);
+    const int64_t lo = (int64_t)sstar * segE;
+    int64_t hi = lo + segE;
+    if (hi > row.V) hi = row.V;
+    const int nwt = (int)((hi - lo + 256 * EPV - 1) / (256 * EPV)) * 4;
+    // wave-tile prefix, sequential in table order (as the segment sum was formed): every lane holds one entry, the running
+    // sum is walked with broadcasts
+    const double *wtp = w.wtsum + ((int64_t)item * RS_SEG + sstar) * RS_WT;
+    const double mywt = lane < nwt ? ld(wtp + lane) : 0.0;
+    int istar = -1;
+    double rel = 0.0;                                       // relative running sum in front of wave-tile istar
+    {
+        double r2 = 0.0;
+        for (int i = 0; i < nwt; ++i) {
+            const double nx = r2 + __shfl(mywt, i, 64);
+            if (before + nx > thr) { istar = i; rel = r2; break; }
+            r2 = nx;
+        }
+        if (istar < 0) {                                    // rounding only: the segment sum said it crosses here -> last wave-tile with mass
+            double r3 = 0.0;
+            for (int i = 0; i < nwt; ++i) { const double wv = __shfl(mywt, i, 64); if (wv > 0.0) { istar = i; rel = r3; } r3 += wv; }
+            if (istar < 0) return (int)(hi - 1);
+        }
+    }
+    const int64_t e0 = lo + ((int64_t)(istar >> 2) * 256 + (istar & 3) * 64 + lane) * EPV;
+    float p[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) p[j] = 0.f;
+    if (e0 < hi) rs_any_probs_from_vec<DT>(row, rs_load_vec<DT>(row, e0), S > 0.0 ? 1.0 / S : 0.0, tab, p);
+    double a = 0.0;
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) a += (double)p[j];
+    const double incl = wave_incl_scan_f64(a, lane);
+    const double up = __shfl_up(incl, 1, 64);
+    const double ex = rel + (lane == 0 ? 0.0 : up);          // relative running sum in front of this lane's vector
+    const unsigned long long crossing = __ballot(before + (rel + incl) > thr);
+    int src = crossing ? __builtin_ctzll(crossing) : -1;
+    if (src < 0) {                                           // rounding only: last lane with mass
+        const unsigned long long pos = __ballot(a > 0.0);
+        src = pos ? 63 - __builtin_clzll(pos) : 63;
+    }
+    int hit = -1, lastpos = -1;
+    {
+        double rr = ex;
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+            rr += (double)p[j];
+            if (p[j] > 0.f) lastpos = j;
+            if (hit < 0 && before + rr > thr) hit = j;
+        }
+        if (hit < 0) hit = lastpos >= 0 ? lastpos : EPV - 1;
+    }
+    int64_t e = e0 + hit;
+    if (e >= row.V) e = row.V - 1;
+    return __shfl((int)e, src, 64);
+}
+
 struct RsPickShared {
+    double tab[64];
+    double red[4];
     double seg[RS_SEG];
-    double wt[RS_TILES][4];
     double wtx[4];
     unsigned long long best[4];
     int pick;
 };
 
-// One inverse-CDF draw by the whole workgroup (uniform control flow).  Returns the index for every thread.
+// The same draw by the whole workgroup walking the crossing segment tile by tile (vocabularies whose segments do not fit
+// the wave-tile table).  Forms its sums as rs_seg_prob_sums' flat branch does.
 template <int DT>
-__device__ int rs_pick(const RsRow &row, const double *segsum /* global, RS_SEG */, float u, RsPickShared &sh) {
+__device__ int rs_pick_wg(const RsRow &row, const double *segsum, double S, float u, RsPickShared &sh) {
     constexpr int EPV = Elem<DT>::EPV;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    RS_PICKSTAMP(16);                                       // 16: pick starts
-    __syncthreads();                                        // sh may still be read by a previous draw
-    if (tid < RS_SEG) sh.seg[tid] = ld_agent_f64(segsum + tid);   // may have been stored by another workgroup of this launch
+    __syncthreads();
+    if (tid < RS_SEG) sh.seg[tid] = ld_agent_f64(segsum + tid);
     if (tid == 0) sh.pick = 0x7FFFFFFF;
     __syncthreads();
     double total = 0.0;
@@ -640,76 +1096,29 @@ __device__ int rs_pick(const RsRow &row, const double *segsum /* global, RS_SEG 
     for (int s = 0; s < RS_SEG; ++s) total += sh.seg[s];
     const double thr = (double)u * total;
     int sstar = -1;
-    double excl = 0.0, run = 0.0;
+    double before = 0.0, run = 0.0;
 #pragma unroll
     for (int s = 0; s < RS_SEG; ++s) {
         const double nx = run + sh.seg[s];
-        if (sstar < 0 && nx > thr) { sstar = s; excl = run; }
+        if (sstar < 0 && nx > thr) { sstar = s; before = run; }
         run = nx;
     }
-    if (sstar < 0) return (int)(row.V - 1);                 // thr >= total: clamp like min(idx, V - 1)
-    const double thr_s = thr - excl;                        // threshold inside the segment
+    if (sstar < 0) return (int)(row.V - 1);
     const int64_t segE = rs_seg_elems(row.V, EPV);
     const int64_t lo = (int64_t)sstar * segE;
     int64_t hi = lo + segE;
     if (hi > row.V) hi = row.V;
     const int ntiles = (int)((hi - lo + 256 * EPV - 1) / (256 * EPV));
-    RS_PICKSTAMP(18);                                       // 18: segment known
-    // per-lane sums of the first RS_TILES tiles (independent loads), wavefront inclusive scans, wave totals to LDS
-    double incl[RS_TILES], lex[RS_TILES];                    // inclusive / exclusive running sums inside the wavefront
-    u32x4 tv[RS_TILES];
-#pragma unroll
-    for (int k = 0; k < RS_TILES; ++k)
-        if (k < ntiles) tv[k] = rs_load_vec<DT>(row, lo + ((int64_t)k * 256 + tid) * EPV);   // independent loads first
-#pragma unroll
-    for (int k = 0; k < RS_TILES; ++k) {
-        double a = 0.0;
-        if (k < ntiles) {
-            float p[EPV];
-            rs_probs_from_vec<DT>(row, tv[k], p);
-#pragma unroll
-            for (int j = 0; j < EPV; ++j) a += (double)p[j];
-        }
-        incl[k] = wave_incl_scan_f64(a, lane);
-        const double up = __shfl_up(incl[k], 1, 64);        // all lanes active here: never shuffle under the crossing test
-        lex[k] = lane == 0 ? 0.0 : up;
-        if (lane == 63) sh.wt[k][wave] = incl[k];
-    }
-    RS_PICKSTAMP(20);                                       // 20: tiles loaded, probabilities and wave scans done
-    __syncthreads();
-    double base = 0.0;                                      // running sum of everything before tile k
+    const double invS = S > 0.0 ? 1.0 / S : 0.0;
+    double base = 0.0;
     bool found = false;
     int cand = 0x7FFFFFFF;
-    auto resolve = [&](int k, double ex) {                  // first element of this lane's vector in tile k whose running sum crosses
-        float p[EPV];
+    for (int k = 0; k < ntiles; ++k) {
         const int64_t e0 = lo + ((int64_t)k * 256 + tid) * EPV;
-        rs_probs_of_vec<DT>(row, e0, p);
-        double rr = ex;
-        int lastpos = -1, hit = -1;
-#pragma unroll
-        for (int j = 0; j < EPV; ++j) {
-            rr += (double)p[j];
-            if (p[j] > 0.f) lastpos = j;
-            if (hit < 0 && rr > thr_s) hit = j;
-        }
-        if (hit < 0) hit = lastpos >= 0 ? lastpos : EPV - 1;   // rounding only: the scan said this lane crosses
-        int64_t e = e0 + hit;
-        if (e >= row.V) e = row.V - 1;
-        return (int)e;
-    };
-#pragma unroll
-    for (int k = 0; k < RS_TILES; ++k) {
-        if (k < ntiles) {
-            double wb = base;
-            for (int w = 0; w < wave; ++w) wb += sh.wt[k][w];
-            if (!found && wb + incl[k] > thr_s) { cand = resolve(k, wb + lex[k]); found = true; }
-            base += (sh.wt[k][0] + sh.wt[k][1]) + (sh.wt[k][2] + sh.wt[k][3]);
-        }
-    }
-    // segments longer than RS_TILES tiles (V > 16 * 8 * 2048 bf16 elements): remaining tiles one at a time
-    for (int k = RS_TILES; k < ntiles; ++k) {
         float p[EPV];
-        rs_probs_of_vec<DT>(row, lo + ((int64_t)k * 256 + tid) * EPV, p);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) p[j] = 0.f;
+        if (e0 < hi) rs_any_probs_from_vec<DT>(row, rs_load_vec<DT>(row, e0), invS, sh.tab, p);
         double a = 0.0;
 #pragma unroll
         for (int j = 0; j < EPV; ++j) a += (double)p[j];
@@ -719,11 +1128,24 @@ __device__ int rs_pick(const RsRow &row, const double *segsum /* global, RS_SEG 
         if (lane == 63) sh.wtx[wave] = in;
         __syncthreads();
         double wb = base;
-        for (int w = 0; w < wave; ++w) wb += sh.wtx[w];
-        if (!found && wb + in > thr_s) { cand = resolve(k, wb + (lane == 0 ? 0.0 : up)); found = true; }
+        for (int q = 0; q < wave; ++q) wb += sh.wtx[q];
+        if (!found && before + (wb + in) > thr) {
+            double rr = wb + (lane == 0 ? 0.0 : up);
+            int hit = -1, lastpos = -1;
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) {
+                rr += (double)p[j];
+                if (p[j] > 0.f) lastpos = j;
+                if (hit < 0 && before + rr > thr) hit = j;
+            }
+            if (hit < 0) hit = lastpos >= 0 ? lastpos : EPV - 1;
+            int64_t e = e0 + hit;
+            if (e >= row.V) e = row.V - 1;
+            cand = (int)e;
+            found = true;
+        }
         base += (sh.wtx[0] + sh.wtx[1]) + (sh.wtx[2] + sh.wtx[3]);
     }
-    RS_PICKSTAMP(22);                                       // 22: resolved
     if (found) atomicMin(&sh.pick, cand);
     __syncthreads();
     int pick = sh.pick;
@@ -734,13 +1156,14 @@ __device__ int rs_pick(const RsRow &row, const double *segsum /* global, RS_SEG 
 // argmax of the distribution with `proposed` masked (JDN:147-153 / JDO:164-168): first index of the largest probability —
 // for bf16 logits that is a tie among every id whose ROUNDED probability equals the maximum; all mass on it -> keep it.
 template <int DT>
-__device__ int rs_masked_argmax(const RsRow &row, int64_t proposed, RsPickShared &sh) {
+__device__ int rs_masked_argmax(const RsRow &row, int64_t proposed, double S, RsPickShared &sh) {
     constexpr int EPV = Elem<DT>::EPV;
     const int tid = threadIdx.x;
+    const double invS = S > 0.0 ? 1.0 / S : 0.0;
     unsigned long long best = 0ull;
     for (int64_t e0 = (int64_t)tid * EPV; e0 < row.V; e0 += 256 * EPV) {
         float p[EPV];
-        rs_probs_of_vec<DT>(row, e0, p);
+        rs_any_probs_from_vec<DT>(row, rs_load_vec<DT>(row, e0), invS, sh.tab, p);
 #pragma unroll
         for (int j = 0; j < EPV; ++j) {
             const int64_t i = e0 + j;
@@ -759,25 +1182,36 @@ __device__ int rs_masked_argmax(const RsRow &row, int64_t proposed, RsPickShared
     return mm ? jfmb::decode_packed(mm) : (int)proposed;
 }
 
-// the draw that counts for one row: the pick at u (u >= 0), or the masked argmax after RS_MAX_TRIES collisions (u < 0).
-// The interval test and the walk agree except when u * total lies within float64 rounding of the proposed token's CDF
-// boundary; should the walk return the proposed token after all, the masked argmax is the answer (never the proposal).
-template <int DT>
-__device__ int rs_final_pick(const RsRow &row, const double *segsum, int64_t proposed, float u, RsPickShared &sh) {
+// the draw that counts for one row, by a whole workgroup (sh.tab loaded): wavefront 0 walks at u (u >= 0); the masked argmax
+// after RS_MAX_TRIES collisions (u < 0), or should the walk return the proposed token after all (float64 rounding of the
+// interval test against the walk: never the proposal).
+template <int DT, bool AGENT>
+__device__ __forceinline__ int rs_final_pick(const RsRow &row, const RsWs &w, int item, double S, int64_t proposed, float u, RsPickShared &sh) {
     int y = -1;
-    if (u >= 0.f) y = rs_pick<DT>(row, segsum, u, sh);
-    if (y < 0 || (int64_t)y == proposed) y = rs_masked_argmax<DT>(row, proposed, sh);
+    if (u >= 0.f) {
+        if (rs_hier_ok(row.V, Elem<DT>::EPV)) {
+            if (threadIdx.x < 64) { const int yy = rs_pick_wave<DT, AGENT>(row, w, item, S, u, sh.tab, threadIdx.x); if (threadIdx.x == 0) sh.pick = yy; }
+            __syncthreads();
+            y = sh.pick;
+        } else {
+            y = rs_pick_wg<DT>(row, w.segsum + (int64_t)item * RS_SEG, S, u, sh);
+        }
+    }
+    if (y < 0 || (int64_t)y == proposed) y = rs_masked_argmax<DT>(row, proposed, S, sh);
     return y;
 }
 
 // ------------------------------------------------------------------------------------------------
 // Accept/reject of every row of a batch (JDN:581-639).  The reference visits the rows in order and draws torch.rand /
 // torch.multinomial / torch.randint as it goes, so the position of every draw in the injected streams depends on the rows
-// before it.  Four launches keep that order exact while everything wide runs in parallel:
-//   rs_accept_kernel  (1 workgroup)   p_draft / uniforms staged in LDS by 256 threads, then ONE wavefront walks the rows:
-//                                     a row's L-1 accept tests are one ballot, so the serial chain is B steps of LDS
-//                                     latency, not B*(L-1); results are written out by all threads afterwards
-//   rs_rowsum_kernel  (B * RS_SEG)    float64 segment sums of every rejected row + the proposed token's CDF interval
+// before it.  Everything wide runs in parallel around one short serial walk:
+//   rs_accept_kernel  (1 workgroup)   every accept test's probability (float64 exp of the gathered logit over the float32
+//                                     row sum: two candidate roundings, see "Exact probabilities") and the uniforms staged
+//                                     in LDS by 256 threads, then ONE wavefront walks the rows: a row's L-1 accept tests are
+//                                     one ballot, so the serial chain is B steps of LDS latency, not B*(L-1).  A test whose
+//                                     uniform falls between the two candidates stops the walk: the workgroup forms that
+//                                     row's float64 sum, patches the entry and the walk resumes at that row.
+//   rs_rowsum_a/b     (B * RS_SEG)    the rejected rows' float64 sums and exact CDF sums (above)
 //   rs_bonus_kernel   (B workgroups)  bonus-stream positions in row order — per rejected row one ballot over <= 16 staged
 //                                     uniforms against the interval gives its number of draws and the uniform that counts;
 //                                     every workgroup walks the rows up to its own (LDS only) — then ONE inverse-CDF walk
@@ -798,87 +1232,147 @@ __device__ __forceinline__ void batched_for(int64_t n, int tid, int nthreads, Lo
     }
 }
 
-
-constexpr int RS_STAGE = 6144;      // floats of p_draft / uniforms staged in LDS by the accept scan (B * (L-1) <= this, else global)
+constexpr int RS_STAGE = 6144;      // accept tests / uniforms staged in LDS by the accept scan (B * (L-1) <= this, else global)
 constexpr int RS_ROWS_LDS = 2048;   // rows whose scan results are kept in LDS (half of it in the chain kernel)
+constexpr uint32_t RS_PE_EOS = 0x80000000u, RS_PE_AMB = 0x40000000u, RS_PE_VAL = 0x3FFFFFFFu;
+
+struct RsAcceptIn {                 // what an accept test's probability is made of
+    const void *logits; int64_t V, row_stride; float t; const float *row_max, *row_sumexp, *p_draft;
+};
+// One accept test as an LDS word: the LOWER candidate probability (a float <= 1: bits 31 / 30 are free), RS_PE_AMB when the
+// float32 row sum cannot decide the rounding (bf16: the upper candidate is the next bf16; float32: lo * (1 + 2^-12) bounds
+// it), RS_PE_EOS when the proposed token is the EOS id.  Rows without finite statistics keep jf_rs_probs' plain float32 value.
+template <int DT>
+__device__ __forceinline__ uint32_t rs_accept_entry(const RsAcceptIn &in, int64_t i, int64_t tok, int eos_id, const double *tab) {
+    const uint32_t eos = (eos_id >= 0 && tok == (int64_t)eos_id) ? RS_PE_EOS : 0u;
+    const float M = in.row_max[i], S = in.row_sumexp[i];
+    if (!rs_row_is_exact(M, S)) {                            // NaN / inf rows: jf_rs_probs' plain float32 value (a NaN never accepts)
+        const float pd = in.p_draft[i];
+        return ((pd > 0.f) ? (__float_as_uint(pd > 1.f ? 1.f : pd) & RS_PE_VAL) : 0u) | eos;
+    }
+    if (tok < 0 || tok >= in.V) return eos;
+    const float inv_t = 1.f / in.t;
+    const float xs = rs_scaled<DT>(load_f<DT>((const char *)in.logits + i * in.row_stride * (DT == JF_F32 ? 4 : 2), tok), in.t, inv_t, in.t == 1.f);
+    const double e = rs_e64(xs, (double)M, tab);
+    if (e == 0.0) return eos;                                 // exactly 0 under every candidate sum
+    const double ph = e / (double)S, eps = rs_eps_row(M);
+    const float lo = rs_round_prob<DT>(ph * (1.0 - eps)), hi = rs_round_prob<DT>(ph * (1.0 + eps));
+    uint32_t bits = __float_as_uint(lo > 1.f ? 1.f : lo) & RS_PE_VAL;
+    if (DT == JF_F32 || lo != hi) bits |= RS_PE_AMB;
+    return bits | eos;
+}
+template <int DT>
+__device__ __forceinline__ float rs_accept_hi(uint32_t pe) {   // upper candidate of an ambiguous entry
+    const uint32_t b = pe & RS_PE_VAL;
+    if constexpr (DT == JF_BF16) return __uint_as_float(b + 0x00010000u);
+    else return fmaxf(__uint_as_float(b) * 1.000244140625f, 1e-44f);
+}
 
 // STAGED: the batch fits the LDS tables (B * (L-1) <= RS_STAGE, B <= RS_ROWS_LDS) — the serial part touches LDS only.
-// SIG (one-launch step): the walker announces every row the moment it is decided — flag[b] = (gen << 32) | (reject_pos + 2),
-// one self-contained 8-byte agent-scope store — and the workgroup ends with a release + the accept-done word.
-template <bool STAGED, bool SIG, int STAGE_N = RS_STAGE, int ROWS_N = RS_ROWS_LDS>
-__device__ __forceinline__ void rs_accept_body(const int64_t *draft, int B, int L, const float *p_draft, int eos_id,
+// SIG (one-launch step): the walker announces every row the moment it is decided — flag[b] = (gen << 32) | eos << 30 |
+// n_accepted << 16 | (reject_pos + 2), one self-contained 8-byte agent-scope store — and the workgroup ends with a release +
+// the accept-done word; the row records' n_committed / eos / n_pads / active_next then belong to the row's bonus workgroup.
+template <int DT, bool STAGED, bool SIG, int STAGE_N = RS_STAGE, int ROWS_N = RS_ROWS_LDS>
+__device__ __forceinline__ void rs_accept_body(const RsAcceptIn &in, const int64_t *draft, int B, int L, int eos_id,
                                                const float *u_stream, int64_t u_len, const int64_t *u_cursor,
                                                int64_t *committed, jf_rs_row *rows, const RsWs &w, uint32_t gen) {
-    __shared__ float s_p[STAGED ? STAGE_N : 1], s_u[STAGED ? STAGE_N : 1];     // s_p carries "proposed == EOS" in its sign bit (p >= 0)
+    __shared__ uint32_t s_p[STAGED ? STAGE_N : 1];
+    __shared__ float s_u[STAGED ? STAGE_N : 1];
     __shared__ int s_res[STAGED ? ROWS_N : 1];                                 // nacc | eos << 15 | (rej + 1) << 16 per row
+    __shared__ double s_tab[64], s_red[4];
+    __shared__ int s_unc, s_resume, s_used;
+    __shared__ uint32_t s_patch_i[8], s_patch_v[8];                            // !STAGED: resolved entries (index, word)
+    __shared__ int s_npatch;
     const int tid = threadIdx.x;
     const int W = L - 1;
     const int n = B * W;
     const int64_t uc0 = *u_cursor;
     auto tok_at = [&](int i) { const int b = i / W; return draft[(int64_t)b * L + (i - b * W) + 1]; };
-    auto pack_pe = [&](float p, int64_t tok) {
-        return __uint_as_float((__float_as_uint(p) & 0x7FFFFFFFu) | ((eos_id >= 0 && tok == (int64_t)eos_id) ? 0x80000000u : 0u));
-    };
+    rs_load_tab(s_tab);
+    if (tid == 0) s_npatch = 0;
+    __syncthreads();
     if constexpr (STAGED) {
         const int ul = (int)u_len, ub = (int)(uc0 % u_len);
         // loads first (eight per lane in flight), arithmetic afterwards; at most n uniforms can be used
-        batched_for<8, float2>(n, tid, 256, [&](int64_t i) { return make_float2(p_draft[i], u_stream[(ub + (int)i) % ul]); },
-                               [&](int64_t i, float2 v) { s_p[i] = v.x; s_u[i] = v.y; });
-        if (eos_id >= 0) {
-            __syncthreads();
-            batched_for<8, int64_t>(n, tid, 256, [&](int64_t i) { return tok_at((int)i); },
-                                    [&](int64_t i, int64_t tk) { s_p[i] = pack_pe(s_p[i], tk); });
-        }
+        batched_for<8, float>(n, tid, 256, [&](int64_t i) { return u_stream[(ub + (int)i) % ul]; }, [&](int64_t i, float v) { s_u[i] = v; });
+        batched_for<4, int64_t>(n, tid, 256, [&](int64_t i) { return tok_at((int)i); },
+                                [&](int64_t i, int64_t tk) { s_p[i] = rs_accept_entry<DT>(in, i, tk, eos_id, s_tab); });
     }
     __syncthreads();
-    if (tid < 64) {
-        const int lane = tid;
-        int used_total = 0;
-        for (int b = 0; b < B; ++b) {                               // JDN:326-348, rows in order
-            int nacc = 0, eos = 0, rej = -1, used = 0;
-            for (int t0 = 0; t0 < W; t0 += 64) {
-                const int tt = t0 + lane;
-                bool stop = false, rejb = false;
-                if (tt < W) {
-                    const int i = b * W + tt;
-                    float pe, uu;
-                    if constexpr (STAGED) { pe = s_p[i]; uu = s_u[used_total + tt]; }
-                    else { pe = pack_pe(p_draft[i], tok_at(i)); uu = u_stream[(uc0 + used_total + tt) % u_len]; }
-                    rejb = !(uu < __uint_as_float(__float_as_uint(pe) & 0x7FFFFFFFu));
-                    stop = rejb || (__float_as_uint(pe) >> 31);     // rejected, or accepted EOS
+    int b_start = 0, used_start = 0;
+    for (;;) {                                                      // the walk; re-entered after an undecided test was resolved
+        if (tid < 64) {
+            const int lane = tid;
+            int used_total = used_start, unc_at = -1, b = b_start;
+            for (; b < B; ++b) {                                    // JDN:326-348, rows in order
+                int nacc = 0, eos = 0, rej = -1, used = 0;
+                for (int t0 = 0; t0 < W; t0 += 64) {
+                    const int tt = t0 + lane;
+                    bool stop = false, rejb = false, unc = false;
+                    if (tt < W) {
+                        const int i = b * W + tt;
+                        uint32_t pe;
+                        float uu;
+                        if constexpr (STAGED) { pe = s_p[i]; uu = s_u[used_total + tt]; }
+                        else {
+                            pe = rs_accept_entry<DT>(in, i, tok_at(i), eos_id, s_tab);
+                            for (int q = 0; q < s_npatch; ++q) if (s_patch_i[q] == (uint32_t)i) pe = s_patch_v[q];
+                            uu = u_stream[(uc0 + used_total + tt) % u_len];
+                        }
+                        const bool sure = uu < __uint_as_float(pe & RS_PE_VAL);
+                        rejb = !sure;
+                        unc = rejb && (pe & RS_PE_AMB) && uu < rs_accept_hi<DT>(pe);
+                        stop = rejb || (pe & RS_PE_EOS);            // rejected, or accepted EOS
+                    }
+                    const unsigned long long bal = __ballot(stop);
+                    if (bal) {
+                        const int f = __builtin_ctzll(bal);
+                        if ((__ballot(unc) >> f) & 1ull) { unc_at = b * W + t0 + f; break; }   // the first stop is undecided: resolve it
+                        const bool is_rej = (__ballot(rejb) >> f) & 1ull;
+                        if (is_rej) { rej = t0 + f; nacc = t0 + f; } else { eos = 1; nacc = t0 + f + 1; }
+                        used = t0 + f + 1;
+                        break;
+                    }
+                    const int wd = (W - t0) < 64 ? (W - t0) : 64;
+                    nacc = t0 + wd; used = t0 + wd;
                 }
-                const unsigned long long bal = __ballot(stop);
-                if (bal) {
-                    const int f = __builtin_ctzll(bal);
-                    const bool is_rej = (__ballot(rejb) >> f) & 1ull;
-                    if (is_rej) { rej = t0 + f; nacc = t0 + f; } else { eos = 1; nacc = t0 + f + 1; }
-                    used = t0 + f + 1;
-                    break;
+                if (unc_at >= 0) break;
+                if (lane == 0) {
+                    if constexpr (STAGED) s_res[b] = nacc | (eos << 15) | ((rej + 1) << 16);
+                    else { rows[b].n_committed = nacc; rows[b].eos = eos; rows[b].reject_pos = rej; }
+                    if constexpr (SIG) {
+                        __hip_atomic_store(w.flag + (int64_t)b * RS_FLAG_STRIDE,
+                                           ((unsigned long long)gen << 32) | ((unsigned long long)eos << 30) | ((unsigned long long)nacc << 16) |
+                                               (unsigned long long)(rej + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        RS_ROWSTAMP(0, b);
+                    }
                 }
-                const int wd = (W - t0) < 64 ? (W - t0) : 64;
-                nacc = t0 + wd; used = t0 + wd;
+                used_total += used;
             }
-            if (lane == 0) {
-                if constexpr (STAGED) s_res[b] = nacc | (eos << 15) | ((rej + 1) << 16);
-                else { rows[b].n_committed = nacc; rows[b].eos = eos; rows[b].reject_pos = rej; }
-                if constexpr (SIG) {
-                    __hip_atomic_store(w.flag + (int64_t)b * RS_FLAG_STRIDE, ((unsigned long long)gen << 32) | (unsigned long long)(rej + 2), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                    RS_ROWSTAMP(0, b);
-                }
-            }
-            used_total += used;
+            if (lane == 0) { s_unc = unc_at; s_resume = b; s_used = used_total; }
+            if constexpr (SIG) { if (unc_at < 0) RS_STAMP_MAX(15); }   // 15: the accept walk has decided the last row
         }
-        if constexpr (SIG) RS_STAMP_MAX(15);                        // 15: the accept walk has decided the last row
+        __syncthreads();
+        const int ui = s_unc;
+        if (ui < 0) break;
+        // ---- the float32 row sum cannot decide this test: the row's float64 sum, by the whole workgroup (~1e-4 p of the tests)
+        const int64_t tk = tok_at(ui);
+        const float pex = rs_exact_prob_wg<DT>(in.logits, ui, in.V, in.row_stride, in.t, in.row_max[ui], tk, s_tab, s_red);
+        if (tid == 0) {
+            const uint32_t word = (__float_as_uint(pex > 1.f ? 1.f : pex) & RS_PE_VAL) | ((eos_id >= 0 && tk == (int64_t)eos_id) ? RS_PE_EOS : 0u);
+            if constexpr (STAGED) s_p[ui] = word;
+            else { const int q = s_npatch < 8 ? s_npatch : 7; s_patch_i[q] = (uint32_t)ui; s_patch_v[q] = word; s_npatch = q + 1; }
+        }
+        b_start = s_resume; used_start = s_used;
+        __syncthreads();
     }
-    __syncthreads();
     __threadfence_block();
     // everything else about a row in parallel: row record, the rejected row's work item, the accepted tokens
     auto res_of = [&](int b, int &nacc, int &eos, int &rej) {
         if constexpr (STAGED) { const int r = s_res[b]; nacc = r & 0x7FFF; eos = (r >> 15) & 1; rej = (r >> 16) - 1; }
         else { nacc = rows[b].n_committed; eos = rows[b].eos; rej = rows[b].reject_pos; }
     };
-    if (tid < 64) {                                                 // rejected rows in front of each row: ballot prefix, 64 rows a pass
+    if (tid < 64 && !SIG) {                                         // rejected rows in front of each row: ballot prefix, 64 rows a pass
         int before = 0;
         for (int b0 = 0; b0 < B; b0 += 64) {
             const int b = b0 + tid;
@@ -894,10 +1388,9 @@ __device__ __forceinline__ void rs_accept_body(const int64_t *draft, int B, int 
         res_of(b, nacc, eos, rej);
         const int64_t avoid = rej >= 0 ? draft[(int64_t)b * L + rej + 1] : -1;
         jf_rs_row &rw = rows[b];
-        rw.n_committed = nacc; rw.eos = eos; rw.reject_pos = rej;
+        rw.reject_pos = rej;
         rw.n_uniforms = rej >= 0 ? rej + 1 : nacc;                  // one uniform per tested position (JDN:329)
-        if (!SIG || rej < 0) rw.n_bonus_draws = 0;                  // one-launch step: the chain workgroup owns a rejected row's count
-        rw.n_pads = 0; rw.active_next = 0;
+        if constexpr (!SIG) { rw.n_committed = nacc; rw.eos = eos; rw.n_bonus_draws = 0; rw.n_pads = 0; rw.active_next = 0; }
         w.sel_row[b] = rej >= 0 ? b * W + rej : -1;
         w.avoid[b] = (int32_t)avoid;
         w.pick_u[b] = -1.f;
@@ -916,11 +1409,11 @@ __device__ __forceinline__ void rs_accept_body(const int64_t *draft, int B, int 
     }
 }
 
-template <bool STAGED>
-__global__ __launch_bounds__(256) void rs_accept_kernel(const int64_t *draft, int B, int L, const float *p_draft, int eos_id,
+template <int DT, bool STAGED>
+__global__ __launch_bounds__(256) void rs_accept_kernel(RsAcceptIn in, const int64_t *draft, int B, int L, int eos_id,
                                                          const float *u_stream, int64_t u_len, const int64_t *u_cursor,
                                                          int64_t *committed, jf_rs_row *rows, RsWs w) {
-    rs_accept_body<STAGED, false>(draft, B, L, p_draft, eos_id, u_stream, u_len, u_cursor, committed, rows, w, 0u);
+    rs_accept_body<DT, STAGED, false>(in, draft, B, L, eos_id, u_stream, u_len, u_cursor, committed, rows, w, 0u);
 }
 
 // bonus-stream bookkeeping in row order (one workgroup): intervals in parallel, then one wavefront walks the rejected rows
@@ -981,7 +1474,7 @@ __global__ __launch_bounds__(256) void rs_chain_kernel(int B, int64_t V, int epv
 
 // CHAIN: the workgroup first walks the bonus stream itself, over the rejected rows up to and including its own (intervals
 // in parallel, then one wavefront, LDS only) — every workgroup repeats the rows before it, which costs less than a separate
-// single-workgroup launch between rs_rowsum and this one (batches up to RS_BONUS_CHAIN_ROWS rows with a staged window;
+// single-workgroup launch between the row sums and this one (batches up to RS_BONUS_CHAIN_ROWS rows with a staged window;
 // larger ones run rs_chain_kernel first and come here with CHAIN = false).
 constexpr int RS_BONUS_CHAIN_ROWS = 512;
 template <int DT, bool CHAIN>
@@ -993,6 +1486,7 @@ __global__ __launch_bounds__(256) void rs_bonus_kernel(const void *logits, int64
     const int b = blockIdx.x, tid = threadIdx.x;
     const int rej = rows[b].reject_pos;
     if (rej < 0) return;
+    rs_load_tab(sh.tab);
     float u_final;
     if constexpr (CHAIN) {
         __shared__ double s_tot[RS_BONUS_CHAIN_ROWS], s_lo[RS_BONUS_CHAIN_ROWS], s_hi[RS_BONUS_CHAIN_ROWS];   // s_tot < 0: not rejected
@@ -1027,11 +1521,12 @@ __global__ __launch_bounds__(256) void rs_bonus_kernel(const void *logits, int64
         __syncthreads();
         u_final = s_uf;
     } else {
+        __syncthreads();
         u_final = w.pick_u[b];
     }
     const int64_t r = (int64_t)b * (L - 1) + rej;
     const RsRow row = rs_make_row<DT>(logits, r, V, row_stride, temp, row_max[r], row_sumexp[r]);
-    const int bonus = rs_final_pick<DT>(row, w.segsum + (int64_t)b * RS_SEG, draft[(int64_t)b * L + rej + 1], u_final, sh);
+    const int bonus = rs_final_pick<DT, false>(row, w, b, w.s64[b], draft[(int64_t)b * L + rej + 1], u_final, sh);
     if (tid == 0) committed[(int64_t)b * L + rows[b].n_committed] = bonus;
 }
 
@@ -1045,6 +1540,19 @@ __device__ __forceinline__ int wave_excl_scan_i32(int v, int lane, int *total) {
     }
     *total = __shfl(x, 63, 64);
     return x - v;
+}
+
+// next-draft shape of a row that keeps decoding with n committed tokens (JDN:444-466 / 619-638)
+__device__ __forceinline__ void rs_next_shape(int n, int L, int &off, int &copy_len) {
+    const int acc_len = 1 + n;
+    off = 0; copy_len = 1;
+    if (acc_len < L) {
+        off = acc_len > 1 ? acc_len - 1 : 1;
+        const int rem = (L - 1) - off;
+        copy_len = rem < L - 1 ? rem : L - 1;
+    } else {
+        off = L - 2;
+    }
 }
 
 __device__ __forceinline__ void rs_finish_body(int B, int L, unsigned long long *packed, int eos_id,
@@ -1065,20 +1573,14 @@ __device__ __forceinline__ void rs_finish_body(int B, int L, unsigned long long 
         rw.active_next = (!rw.eos && n < remaining[b]) ? 1 : 0;
         int n_pads = 0;
         if (rw.active_next) {
-            const int acc_len = 1 + n;
-            int copy_len = 1;
-            if (acc_len < L) {
-                const int off = acc_len > 1 ? acc_len - 1 : 1;
-                const int rem = (L - 1) - off;
-                copy_len = rem < L - 1 ? rem : L - 1;
-            }
+            int off, copy_len;
+            rs_next_shape(n, L, off, copy_len);
             n_pads = L - 1 - copy_len;
         }
         rw.n_pads = n_pads;
     }
     __threadfence_block();
     __syncthreads();
-    RS_STAMP_MAX(23);                                                 // 23: finish: rows done
     // stream cursors and every row's offset into the pad stream: exclusive scans in row order by one wavefront
     if (tid < 64) {
         int uc = 0, bc = 0, pc = 0;
@@ -1098,24 +1600,15 @@ __device__ __forceinline__ void rs_finish_body(int B, int L, unsigned long long 
     }
     __threadfence_block();
     __syncthreads();
-    RS_STAMP_MAX(25);                                                 // 25: finish: scans done
     const int64_t pc0 = *pad_cursor;
-    // (this loop takes ~10 of the workgroup's 14 us at 64 rows x 32 tokens; batching its loads eight per thread, one load per
-    //  element from a selected address and 32-bit index arithmetic were each measured and changed nothing: profiles/rs_step_r03.txt)
     for (int64_t idx = tid; idx < (int64_t)B * L; idx += 256) {        // every next-draft element independently
         const int b = (int)(idx / L), i = (int)(idx - (int64_t)b * L);
         const jf_rs_row rw = rows[b];
         if (!rw.active_next) continue;
         const int64_t r0 = (int64_t)b * (L - 1);
-        const int n = rw.n_committed, acc_len = 1 + n;
-        int off = 0, copy_len = 1;
-        if (acc_len < L) {
-            off = acc_len > 1 ? acc_len - 1 : 1;
-            const int rem = (L - 1) - off;
-            copy_len = rem < L - 1 ? rem : L - 1;
-        } else {
-            off = L - 2;
-        }
+        const int n = rw.n_committed;
+        int off, copy_len;
+        rs_next_shape(n, L, off, copy_len);
         int64_t v;
         if (i == 0) v = committed[(int64_t)b * L + n - 1];
         else if (i - 1 < copy_len) v = jfmb::decode_packed(packed[r0 + off + (i - 1)]);
@@ -1123,7 +1616,6 @@ __device__ __forceinline__ void rs_finish_body(int B, int L, unsigned long long 
         next_draft[idx] = v;
     }
     __syncthreads();
-    RS_STAMP_MAX(27);                                                 // 27: finish: next drafts written
     for (int64_t i = tid; i < (int64_t)B * (L - 1); i += 256) packed[i] = 0ull;
     for (int b = tid; b < B; b += 256) rows[b].rsv = 0;
     if (tid == 0) *pad_cursor = pc0 + s_total_pads;
@@ -1142,18 +1634,21 @@ __global__ __launch_bounds__(256) void rs_finish_kernel(int B, int L, unsigned l
 //   block 1                    the chain: rows become CDF intervals as their flags and sums arrive (wavefronts 1-3, a thread per
 //                              row), wavefront 0 counts the draws in stream order on LDS and hands every rejected row the
 //                              uniform that counts as soon as the rows before it are counted
-//   block 2                    waits for the accept workgroup, the chain and every bonus word, then rs_finish_body
-//   blocks 3 .. B+2            the bonus draw of row b: ONE inverse-CDF walk (or the masked argmax) for the uniform it was handed
-//   blocks B+3 ..              the segment sums of row (blk-B-3)/RS_SEG: wait for that row's flag, sum if it was rejected
+//   block 2                    the end: waits for every row's finish word, then the pad offsets (one scan), the pads themselves
+//                              and the stream cursors — all that depends on more than one row
+//   blocks 3 .. B+2            row b: the bonus draw (ONE wavefront walks the hierarchical sums for the uniform it was handed,
+//                              or the masked argmax), then everything about the row that depends on this row alone — EOS,
+//                              row record, the next draft's seed and greedy tail, its argmax slots re-zeroed
+//   blocks B+3 ..              the sums of row (blk-B-3)/RS_SEG: wait for that row's flag; if it was rejected, phase A, the
+//                              exchange of the float64 partials with the row's 15 other workgroups, phase B
 // The B + 3 workgroups that wait for others come FIRST, the 16 B short ones last: with the roles in pipeline order the device
 // filled up with segment-sum workgroups spinning on the flags of late rows, and the chain / bonus workgroups were not even
-// dispatched before those had left (in-kernel stamps: first uniform handed out at 56 us of a launch whose accept walk ends at
-// 17 us).  The waiting workgroups number at most RS_FUSED_ROWS + 3 — far fewer than the device keeps resident (at least one
-// per CU) — and the segment sums only wait for block 0, so they always find a slot and everything they are waited for by
-// comes to pass; all hand-off words carry the call's generation number (nothing to re-zero, no stale reads); payloads cross
-// workgroups as agent-scope atomics (a release fence per producer would write back an L2 full of freshly written logits —
-// profiles/verify_release_ab_r03.txt).  Replaces four dependent launches (accept 19 + rowsum 21 + bonus 34 + finish 14 us
-// at 64 rejected rows, profiles/rs_step_r03.txt).
+// dispatched before those had left.  A segment workgroup waits for block 0 and for its row's 15 peers (consecutive block
+// ids: dispatched together); jf_rs_step takes this path only when the device keeps at least 2 x (B + 3 + RS_SEG) workgroups
+// of the kernel resident (asked of the runtime), so the waiters can never fill it.  Every wait is bounded (2 s): a row that
+// times out reports JF_E_LAUNCH through rows[0].rsv.  All hand-off words carry the call's generation number (nothing to
+// re-zero, no stale reads); payloads cross workgroups as agent-scope atomics (a release fence per producer would write back
+// an L2 full of freshly written logits — profiles/verify_release_ab_r03.txt).
 // ------------------------------------------------------------------------------------------------
 constexpr int RS_FUSED_ROWS = 128;      // rows of a one-launch step (<= 192: the chain workgroup gives every row a thread of wavefronts 1-3)
 constexpr int RS_FUSED_STAGE = 4096;    // B * (L-1) accept tests staged in LDS by its accept workgroup
@@ -1165,14 +1660,8 @@ struct RsFusedArgs {
     const int64_t *pad_stream; int64_t pad_len; int64_t *pad_cursor;
     int64_t *committed, *next_draft; jf_rs_row *rows; RsWs w; uint32_t gen;
 };
-
-__device__ __forceinline__ unsigned long long rs_wait_flag(const unsigned long long *word, uint32_t gen) {
-    unsigned long long v;
-    while ((uint32_t)((v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != gen) __builtin_amdgcn_s_sleep(16);
-    return v;
-}
-__device__ __forceinline__ void rs_wait_word(const uint32_t *word, uint32_t gen) {
-    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen) __builtin_amdgcn_s_sleep(16);
+__device__ __forceinline__ void rs_report_timeout(jf_rs_row *rows) {
+    __hip_atomic_store(&rows[0].rsv, (int32_t)JF_E_LAUNCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int DT>
@@ -1182,28 +1671,37 @@ __global__ __launch_bounds__(256) void rs_step_fused_kernel(RsFusedArgs a) {
     const RsWs &w = a.w;
     if (blk == 0) {
         RS_STAMP_MIN(0);                                             // 0: launch start (accept workgroup)
-        rs_accept_body<true, true, RS_FUSED_STAGE, RS_FUSED_ROWS>(a.draft, B, L, a.p_draft, a.eos_id, a.u_stream, a.u_len, a.u_cursor,
-                                                                  a.committed, a.rows, w, a.gen);
+        const RsAcceptIn in{a.logits, a.V, a.row_stride, a.t, a.row_max, a.row_sumexp, a.p_draft};
+        rs_accept_body<DT, true, true, RS_FUSED_STAGE, RS_FUSED_ROWS>(in, a.draft, B, L, a.eos_id, a.u_stream, a.u_len, a.u_cursor,
+                                                                      a.committed, a.rows, w, a.gen);
         RS_STAMP_MAX(1);                                             // 1: accept workgroup done (records + accept-done word)
         return;
     }
     if (blk >= B + 3) {                                             // ---- segment sums (the many short workgroups come last)
         const int item = (blk - B - 3) / RS_SEG, seg = (blk - B - 3) % RS_SEG;
+        __shared__ RsSumShared shs;
         __shared__ int s_rej;
-        if (tid == 0) s_rej = (int)(uint32_t)rs_wait_flag(w.flag + (int64_t)item * RS_FLAG_STRIDE, a.gen) - 2;
+        if (tid == 0) {
+            unsigned long long f;
+            s_rej = rs_wait_flag(w.flag + (int64_t)item * RS_FLAG_STRIDE, a.gen, &f) ? (int)(f & 0xFFFFull) - 2 : -3;
+        }
         __syncthreads();
         const int rej = s_rej;
+        if (rej == -3) { if (tid == 0) rs_report_timeout(a.rows); return; }
         if (rej < 0) return;
         if (tid == 0 && seg == 0) RS_ROWSTAMP(1, item);
-        rs_rowsum_body<DT, true>(a.logits, a.V, a.row_stride, a.row_max, a.row_sumexp, a.t, w, item, seg, item * W + rej,
-                                 a.draft[(int64_t)item * L + rej + 1], a.gen);
+        if (!rs_rowsum_fused<DT>(a.logits, a.V, a.row_stride, a.row_max, a.row_sumexp, a.t, w, item, seg, item * W + rej,
+                                 a.draft[(int64_t)item * L + rej + 1], a.gen, shs)) {
+            if (tid == 0) rs_report_timeout(a.rows);
+            return;
+        }
         if (tid == 0 && seg == 0) RS_ROWSTAMP(4, item);
         return;
     }
     if (blk == 1) {                                                 // ---- the chain: draws of all rows in stream order
         // Wavefronts 1-3 turn rows into CDF intervals as their flags and segment sums come in (a thread per row); wavefront 0
         // counts the draws in row order on LDS and hands every rejected row its uniform the moment the rows before it are
-        // counted — the walk of row i starts ~7 us after row i was decided, not after the last row's sums.
+        // counted — the walk of row i starts a few us after row i was decided, not after the last row's sums.
         __shared__ double s_tot[RS_FUSED_ROWS], s_lo[RS_FUSED_ROWS], s_hi[RS_FUSED_ROWS];   // s_tot < 0: not rejected
         __shared__ int s_ready[RS_FUSED_ROWS];
         __shared__ float s_u[RS_MAX_TRIES * RS_FUSED_ROWS];
@@ -1221,11 +1719,13 @@ __global__ __launch_bounds__(256) void rs_step_fused_kernel(RsFusedArgs a) {
             const int i = tid - 64;
             bool fin = i >= B;
             int rp = -3;                                             // -3: the row's flag has not been seen yet
+            unsigned spins = 0;
+            unsigned long long t0 = 0;
             for (;;) {                                               // wave-uniform exit (the ballot below): with a per-lane `while (!fin)` the
                 if (!fin) {                                          // compiler sinks a lane's publishing behind the loop, i.e. behind ALL 64 rows
                 if (rp == -3) {
                     const unsigned long long v = __hip_atomic_load(w.flag + (int64_t)i * RS_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((uint32_t)(v >> 32) == a.gen) rp = (int)(uint32_t)v - 2;
+                    if ((uint32_t)(v >> 32) == a.gen) rp = (int)(v & 0xFFFFull) - 2;
                 }
                 if (rp != -3) {
                     bool sums_in = true;
@@ -1244,6 +1744,13 @@ __global__ __launch_bounds__(256) void rs_step_fused_kernel(RsFusedArgs a) {
                 }
                 if (__ballot(!fin) == 0ull) break;
                 __builtin_amdgcn_s_sleep(4);
+                if ((++spins & 4095u) == 0u) {                       // bounded: a row whose sums never arrive is reported, not waited for
+                    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                    if (t0 == 0) t0 = now;
+                    else if (now - t0 > RS_WAIT_TICKS) {
+                        if (!fin) { s_tot[i] = -1.0; rs_report_timeout(a.rows); __hip_atomic_store(&s_ready[i], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); fin = true; }
+                    }
+                }
             }
             return;
         }
@@ -1263,7 +1770,7 @@ __global__ __launch_bounds__(256) void rs_step_fused_kernel(RsFusedArgs a) {
                 float uf;
                 const int o = off;
                 const int draws = rs_count_draws([&](int tr) { return staged ? s_u[o + tr] : a.b_stream[(bc0 + o + tr) % a.b_len]; }, t_, s_lo[i], s_hi[i], tid, &uf);
-                if (tid == 0) {                                      // the count for the finishing workgroup (ordered by chain-done below),
+                if (tid == 0) {                                      // the count for the end workgroup (ordered by chain-done below),
                     __hip_atomic_store(&a.rows[i].n_bonus_draws, draws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(w.pick + i, ((unsigned long long)a.gen << 32) | (unsigned long long)__float_as_uint(uf), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);   // the uniform for the row's bonus workgroup: a self-contained word
@@ -1279,44 +1786,109 @@ __global__ __launch_bounds__(256) void rs_step_fused_kernel(RsFusedArgs a) {
         }
         return;
     }
-    if (blk >= 3) {                                                 // ---- bonus draw of row b (3 <= blk < B + 3 here)
+    if (blk >= 3) {                                                 // ---- row b (3 <= blk < B + 3 here): bonus draw, then the row's own finish
         const int b = blk - 3;
         __shared__ RsPickShared sh;
-        __shared__ int s_rej;
+        __shared__ int s_rej, s_nacc, s_eos;
         __shared__ float s_uf;
+        __shared__ double s_S;
+        rs_load_tab(sh.tab);
         if (tid == 0) {
-            const int rp = (int)(uint32_t)rs_wait_flag(w.flag + (int64_t)b * RS_FLAG_STRIDE, a.gen) - 2;
-            s_rej = rp;
-            if (rp >= 0) s_uf = __uint_as_float((uint32_t)rs_wait_flag(w.pick + b, a.gen));
+            unsigned long long f, pk = 0ull;
+            if (!rs_wait_flag(w.flag + (int64_t)b * RS_FLAG_STRIDE, a.gen, &f)) { s_rej = -3; }
+            else {
+                const int rp = (int)(f & 0xFFFFull) - 2;
+                s_rej = rp; s_nacc = (int)((f >> 16) & 0x3FFFull); s_eos = (int)((f >> 30) & 1ull);
+                if (rp >= 0) {
+                    if (!rs_wait_flag(w.pick + b, a.gen, &pk)) s_rej = -3;
+                    s_uf = __uint_as_float((uint32_t)pk);
+                    s_S = ld_agent_f64(w.s64 + b);                   // stored before the row's segment-done words the chain has seen
+                }
+            }
         }
         __syncthreads();
         const int rej = s_rej;
+        if (rej == -3) { if (tid == 0) { rs_report_timeout(a.rows); __hip_atomic_store(w.fin + b, (unsigned long long)a.gen << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } return; }
         if (tid == 0) RS_ROWSTAMP(5, b);
+        int n = s_nacc, eos = s_eos, bonus = -1;
         if (rej >= 0) {
             const int64_t r = (int64_t)b * W + rej;
             if (b == B - 1) RS_STAMP_MAX(17);                        // 17: last row's bonus workgroup has its uniform
             const RsRow row = rs_make_row<DT>(a.logits, r, a.V, a.row_stride, a.t, a.row_max[r], a.row_sumexp[r]);
-            const int bonus = rs_final_pick<DT>(row, w.segsum + (int64_t)b * RS_SEG, a.draft[(int64_t)b * L + rej + 1], s_uf, sh);
+            bonus = rs_final_pick<DT, true>(row, w, b, s_S, a.draft[(int64_t)b * L + rej + 1], s_uf, sh);
             if (b == B - 1) RS_STAMP_MAX(19);                        // 19: ... has walked
-            // n_committed of a rejected row == reject_pos (rs_accept_body)
-            if (tid == 0) __hip_atomic_store((long long *)a.committed + (int64_t)b * L + rej, (long long)bonus, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.eos_id >= 0 && bonus == a.eos_id) eos = 1;
+            n += 1;                                                  // n_accepted of a rejected row == reject_pos (rs_accept_body)
         }
+        // everything that depends on this row alone (JDN:444-466 / 619-638): the next draft's seed and greedy tail
+        const int active = (!eos && n < a.remaining[b]) ? 1 : 0;
+        int off = 0, copy_len = 0, n_pads = 0;
+        if (active) { rs_next_shape(n, L, off, copy_len); n_pads = L - 1 - copy_len; }
+        const int64_t r0 = (int64_t)b * W;
+        if (active) {
+            for (int i = tid; i < 1 + copy_len; i += 256) {
+                int64_t v;
+                if (i == 0) v = rej >= 0 ? (int64_t)bonus : a.draft[(int64_t)b * L + n];     // the last committed token
+                else v = jfmb::decode_packed(a.packed[r0 + off + (i - 1)]);
+                a.next_draft[(int64_t)b * L + i] = v;
+            }
+        }
+        __syncthreads();                                             // the greedy tokens are read: the row's argmax slots go back to zero
+        for (int i = tid; i < W; i += 256) a.packed[r0 + i] = 0ull;
         if (tid == 0) {
+            if (rej >= 0) a.committed[(int64_t)b * L + rej] = bonus;
+            jf_rs_row &rw = a.rows[b];
+            rw.n_committed = n; rw.eos = eos; rw.active_next = active; rw.n_pads = n_pads;
+            if (rej < 0) rw.n_bonus_draws = 0;
+            if (b != 0) rw.rsv = 0;                                  // rows[0].rsv carries a timeout report (cleared by the host before the call)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(w.bonusdone + b, a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(w.fin + b, ((unsigned long long)a.gen << 32) | (unsigned long long)n_pads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            RS_ROWSTAMP(6, b);
         }
-        if (tid == 0) RS_ROWSTAMP(6, b);
-        if (b == B - 1) RS_STAMP_MAX(21);                            // 21: ... has stored its token and its done word
+        if (b == B - 1) RS_STAMP_MAX(21);                            // 21: ... has stored its token and its finish word
         return;
     }
-    // ---- block 2: waits until everything is in, then finishes (JDN:444-466 / 619-638)
-    if (tid == 0) { rs_wait_word(w.acceptdone, a.gen); rs_wait_word(w.acceptdone + 1, a.gen); }   // accept records, the chain's draw counts
-    for (int i = tid; i < B; i += 256) rs_wait_word(w.bonusdone + i, a.gen);
+    // ---- block 2: what depends on more than one row — pad offsets, the pads, the stream cursors
+    __shared__ int s_np[RS_FUSED_ROWS], s_off[RS_FUSED_ROWS];
+    __shared__ int s_bad, s_pads;
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    if (tid == 0) { if (!rs_wait_word(w.acceptdone, a.gen) || !rs_wait_word(w.acceptdone + 1, a.gen)) s_bad = 1; }   // n_uniforms, the draw counts
+    for (int i = tid; i < B; i += 256) {
+        unsigned long long f;
+        if (!rs_wait_flag(w.fin + i, a.gen, &f)) s_bad = 1;
+        s_np[i] = (int)(f & 0xFFFFull);
+    }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    RS_STAMP_MIN(12);                                                // 12: finishing workgroup starts
-    rs_finish_body(B, L, a.packed, a.eos_id, a.remaining, a.u_cursor, a.b_cursor, a.pad_stream, a.pad_len, a.pad_cursor, a.committed,
-                   a.next_draft, a.rows);
+    RS_STAMP_MIN(12);                                                // 12: end workgroup has everything
+    if (s_bad) { if (tid == 0) rs_report_timeout(a.rows); return; }
+    if (tid < 64) {
+        int uc = 0, bc = 0, pc = 0;
+        for (int b0 = 0; b0 < B; b0 += 64) {
+            const int b = b0 + tid;
+            const int nu = b < B ? a.rows[b].n_uniforms : 0;
+            const int nb = (b < B && a.rows[b].reject_pos >= 0) ? __hip_atomic_load(&a.rows[b].n_bonus_draws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            const int np = b < B ? s_np[b] : 0;
+            int tu, tb, tp;
+            (void)wave_excl_scan_i32(nu, tid, &tu);
+            (void)wave_excl_scan_i32(nb, tid, &tb);
+            const int ep = wave_excl_scan_i32(np, tid, &tp);
+            if (b < B) s_off[b] = pc + ep;                            // this row's offset into the pad stream
+            uc += tu; bc += tb; pc += tp;
+        }
+        if (tid == 0) { *a.u_cursor += uc; *a.b_cursor += bc; s_pads = pc; }
+    }
+    __syncthreads();
+    RS_STAMP_MAX(25);                                                // 25: end: scans done
+    const int64_t pc0 = *a.pad_cursor;
+    for (int idx = tid; idx < B * W; idx += 256) {                   // the pads of every row that keeps decoding
+        const int b = idx / W, j = idx - b * W;
+        const int np = s_np[b];
+        if (j < np) a.next_draft[(int64_t)b * L + (L - np) + j] = a.pad_stream[(pc0 + s_off[b] + j) % a.pad_len];
+    }
+    __syncthreads();
+    if (tid == 0) *a.pad_cursor = pc0 + s_pads;
     RS_STAMP_MAX(13);                                                // 13: finished
 }
 
@@ -1324,8 +1896,9 @@ __global__ __launch_bounds__(256) void rs_step_fused_kernel(RsFusedArgs a) {
 // On-policy rollout step (JDO = inference_engine/engine/jacobi_decoding_nongreedy_on_policy.py): sequential accept /
 // reject of ONE sequence's proposed tokens with a stop-token SET (JDO:270-327), then a fresh sample of every not yet
 // accepted position from this forward's distribution (JDO:465-477).
-//   rs_op_accept_kernel   one wavefront: the R accept tests are one ballot
-//   rs_rowsum_kernel      float64 segment sums of the rejected row (+ its proposed token's CDF interval) and of every
+//   rs_op_accept_kernel   one workgroup: the R accept tests are one ballot of its first wavefront (probabilities as in
+//                         rs_accept_entry; an undecided test is resolved with the row's float64 sum by the workgroup)
+//   rs_rowsum_a/b         float64 sums and exact CDF sums of the rejected row (+ its proposed token's interval) and of every
 //                         row after it (the re-draft candidates)
 //   rs_op_bonus_kernel    one workgroup: draws counted against the interval, ONE walk, stop flag, stream cursors
 //   rs_op_redraft_kernel  one workgroup per re-drafted row: one draw each; re-zeroes packed
@@ -1335,40 +1908,75 @@ __device__ __forceinline__ bool op_is_stop(const int32_t *stop_ids, int n_stop, 
     return false;
 }
 
-__global__ __launch_bounds__(64) void rs_op_accept_kernel(const int64_t *proposed, int R, const float *p_draft,
-                                                           const int32_t *stop_ids, int n_stop, const float *u_stream,
-                                                           int64_t u_len, const int64_t *u_cursor, int64_t *committed,
-                                                           jf_op_row *out, RsWs w) {
-    const int lane = threadIdx.x;
+constexpr int RS_OP_STAGE = 2048;
+template <int DT>
+__global__ __launch_bounds__(256) void rs_op_accept_kernel(RsAcceptIn in, const int64_t *proposed, int R,
+                                                            const int32_t *stop_ids, int n_stop, const float *u_stream,
+                                                            int64_t u_len, const int64_t *u_cursor, int64_t *committed,
+                                                            jf_op_row *out, RsWs w) {
+    __shared__ uint32_t s_p[RS_OP_STAGE];
+    __shared__ double s_tab[64], s_red[4];
+    __shared__ int s_unc, s_n, s_stop, s_rej, s_used;
+    __shared__ uint32_t s_patch_i[8], s_patch_v[8];
+    __shared__ int s_npatch;
+    const int tid = threadIdx.x;
     const int64_t uc = *u_cursor;
-    int n = 0, stop = 0, rej = -1, used = 0;
-    for (int t0 = 0; t0 < R; t0 += 64) {                              // JDO:293-320
-        const int t = t0 + lane;
-        bool st = false, rejb = false;
-        if (t < R) {
-            const bool acc = u_stream[(uc + t) % u_len] < p_draft[t];
-            rejb = !acc;
-            st = rejb || op_is_stop(stop_ids, n_stop, proposed[t]);
+    const bool staged = R <= RS_OP_STAGE;
+    rs_load_tab(s_tab);
+    if (tid == 0) s_npatch = 0;
+    __syncthreads();
+    if (staged) for (int i = tid; i < R; i += 256) s_p[i] = rs_accept_entry<DT>(in, i, proposed[i], -1, s_tab);
+    __syncthreads();
+    for (;;) {
+        if (tid < 64) {
+            const int lane = tid;
+            int n = 0, stop = 0, rej = -1, used = 0, unc_at = -1;
+            for (int t0 = 0; t0 < R; t0 += 64) {                              // JDO:293-320
+                const int t = t0 + lane;
+                bool st = false, rejb = false, unc = false;
+                if (t < R) {
+                    uint32_t pe;
+                    if (staged) pe = s_p[t];
+                    else { pe = rs_accept_entry<DT>(in, t, proposed[t], -1, s_tab); for (int q = 0; q < s_npatch; ++q) if (s_patch_i[q] == (uint32_t)t) pe = s_patch_v[q]; }
+                    const float uu = u_stream[(uc + t) % u_len];
+                    rejb = !(uu < __uint_as_float(pe & RS_PE_VAL));
+                    unc = rejb && (pe & RS_PE_AMB) && uu < rs_accept_hi<DT>(pe);
+                    st = rejb || op_is_stop(stop_ids, n_stop, proposed[t]);
+                }
+                const unsigned long long bal = __ballot(st);
+                if (bal) {
+                    const int f = __builtin_ctzll(bal);
+                    if ((__ballot(unc) >> f) & 1ull) { unc_at = t0 + f; break; }
+                    const bool is_rej = (__ballot(rejb) >> f) & 1ull;
+                    if (is_rej) { rej = t0 + f; n = t0 + f; } else { stop = 1; n = t0 + f + 1; }
+                    used = t0 + f + 1;
+                    break;
+                }
+                const int wd = (R - t0) < 64 ? (R - t0) : 64;
+                n = t0 + wd; used = t0 + wd;
+            }
+            if (lane == 0) { s_unc = unc_at; s_n = n; s_stop = stop; s_rej = rej; s_used = used; }
         }
-        const unsigned long long bal = __ballot(st);
-        if (bal) {
-            const int f = __builtin_ctzll(bal);
-            const bool is_rej = (__ballot(rejb) >> f) & 1ull;
-            if (is_rej) { rej = t0 + f; n = t0 + f; } else { stop = 1; n = t0 + f + 1; }
-            used = t0 + f + 1;
-            break;
+        __syncthreads();
+        const int ui = s_unc;
+        if (ui < 0) break;
+        const float pex = rs_exact_prob_wg<DT>(in.logits, ui, in.V, in.row_stride, in.t, in.row_max[ui], proposed[ui], s_tab, s_red);
+        if (tid == 0) {
+            const uint32_t word = __float_as_uint(pex > 1.f ? 1.f : pex) & RS_PE_VAL;
+            if (staged) s_p[ui] = word;
+            else { const int q = s_npatch < 8 ? s_npatch : 7; s_patch_i[q] = (uint32_t)ui; s_patch_v[q] = word; s_npatch = q + 1; }
         }
-        const int wd = (R - t0) < 64 ? (R - t0) : 64;
-        n = t0 + wd; used = t0 + wd;
+        __syncthreads();
     }
-    for (int i = lane; i < n; i += 64) committed[i] = proposed[i];
-    for (int i = lane; i < R; i += 64) {
+    const int n = s_n, rej = s_rej;
+    for (int i = tid; i < n; i += 256) committed[i] = proposed[i];
+    for (int i = tid; i < R; i += 256) {
         w.sel_row[i] = (rej >= 0 && i >= rej) ? i : -1;
         w.avoid[i] = (i == rej) ? (int32_t)proposed[i] : -1;
     }
-    if (lane == 0) {
-        out->n_committed = n; out->stop_hit = stop; out->reject_pos = rej; out->n_bonus_draws = 0;
-        out->n_uniforms = used; out->n_redraft = 0; out->redraft_base_lo = 0; out->redraft_base_hi = 0;
+    if (tid == 0) {
+        out->n_committed = n; out->stop_hit = s_stop; out->reject_pos = rej; out->n_bonus_draws = 0;
+        out->n_uniforms = s_used; out->n_redraft = 0; out->redraft_base_lo = 0; out->redraft_base_hi = 0;
     }
 }
 
@@ -1385,6 +1993,7 @@ __global__ __launch_bounds__(256) void rs_op_bonus_kernel(const void *logits, in
     const int rej = out->reject_pos;
     const int64_t mc = *m_cursor;
     int n = out->n_committed, stop = out->stop_hit, draws = 0;
+    rs_load_tab(sh.tab);
     if (rej >= 0) {                                                    // JDO:157-168 (bonus != proposed)
         if (tid < 64) {
             double t_, lo_, hi_;
@@ -1396,7 +2005,7 @@ __global__ __launch_bounds__(256) void rs_op_bonus_kernel(const void *logits, in
         __syncthreads();
         draws = s_draws;
         const RsRow row = rs_make_row<DT>(logits, rej, V, row_stride, temp, row_max[rej], row_sumexp[rej]);
-        const int bonus = rs_final_pick<DT>(row, w.segsum + (int64_t)rej * RS_SEG, proposed[rej], s_uf, sh);
+        const int bonus = rs_final_pick<DT, false>(row, w, rej, w.s64[rej], proposed[rej], s_uf, sh);
         if (tid == 0) committed[n] = bonus;
         n += 1;
         if (op_is_stop(stop_ids, n_stop, bonus)) stop = 1;
@@ -1416,15 +2025,25 @@ template <int DT>
 __global__ __launch_bounds__(256) void rs_op_redraft_kernel(const void *logits, int64_t V, int64_t row_stride, int R,
                                                              const float *row_max, const float *row_sumexp, float temp,
                                                              const float *m_stream, int64_t m_len, const jf_op_row *res,
-                                                             const double *segsum, int64_t *redraft, unsigned long long *packed) {
+                                                             RsWs w, int64_t *redraft, unsigned long long *packed) {
     __shared__ RsPickShared sh;
     const int li = blockIdx.x, tid = threadIdx.x;
     if (tid == 0) packed[li] = 0ull;
     const int n = res->n_committed;
     if (res->n_redraft <= 0 || li < n) return;
+    rs_load_tab(sh.tab);
+    __syncthreads();
     const int64_t base = ((int64_t)res->redraft_base_hi << 32) | (int64_t)(uint32_t)res->redraft_base_lo;
     const RsRow row = rs_make_row<DT>(logits, li, V, row_stride, temp, row_max[li], row_sumexp[li]);
-    const int y = rs_pick<DT>(row, segsum + (int64_t)li * RS_SEG, m_stream[(base + (li - n)) % m_len], sh);
+    const float u = m_stream[(base + (li - n)) % m_len];
+    int y;
+    if (rs_hier_ok(V, Elem<DT>::EPV)) {
+        if (tid < 64) { const int yy = rs_pick_wave<DT, false>(row, w, li, w.s64[li], u, sh.tab, tid); if (tid == 0) sh.pick = yy; }
+        __syncthreads();
+        y = sh.pick;
+    } else {
+        y = rs_pick_wg<DT>(row, w.segsum + (int64_t)li * RS_SEG, w.s64[li], u, sh);
+    }
     if (tid == 0) redraft[li] = y;
 }
 
@@ -1446,17 +2065,39 @@ extern "C" int jf_rs_onpolicy_step(const void *logits, int dtype, int64_t V, int
     hipStream_t s = (hipStream_t)stream;
     const RsWs w = rs_ws(workspace, R);
     unsigned long long *pk = (unsigned long long *)packed;
-    rs_op_accept_kernel<<<1, 64, 0, s>>>(proposed, R, p_draft, stop_ids, n_stop, u_stream, u_len, u_cursor, committed, row, w);
-    if (dtype == JF_F32) {
-        rs_rowsum_kernel<JF_F32><<<R * RS_SEG, 256, 0, s>>>(logits, V, row_stride, row_max, row_sumexp, t, w);
-        rs_op_bonus_kernel<JF_F32><<<1, 256, 0, s>>>(logits, V, row_stride, proposed, R, row_max, row_sumexp, t, stop_ids, n_stop, u_cursor, m_stream, m_len, m_cursor, committed, row, w);
-        rs_op_redraft_kernel<JF_F32><<<R, 256, 0, s>>>(logits, V, row_stride, R, row_max, row_sumexp, t, m_stream, m_len, row, w.segsum, redraft, pk);
-    } else {
-        rs_rowsum_kernel<JF_BF16><<<R * RS_SEG, 256, 0, s>>>(logits, V, row_stride, row_max, row_sumexp, t, w);
-        rs_op_bonus_kernel<JF_BF16><<<1, 256, 0, s>>>(logits, V, row_stride, proposed, R, row_max, row_sumexp, t, stop_ids, n_stop, u_cursor, m_stream, m_len, m_cursor, committed, row, w);
-        rs_op_redraft_kernel<JF_BF16><<<R, 256, 0, s>>>(logits, V, row_stride, R, row_max, row_sumexp, t, m_stream, m_len, row, w.segsum, redraft, pk);
-    }
+    const RsAcceptIn in{logits, V, row_stride, t, row_max, row_sumexp, p_draft};
+#define JF_OP(DT)                                                                                                                              \
+    rs_op_accept_kernel<DT><<<1, 256, 0, s>>>(in, proposed, R, stop_ids, n_stop, u_stream, u_len, u_cursor, committed, row, w);                 \
+    rs_rowsum_a_kernel<DT><<<R * RS_SEG, 256, 0, s>>>(logits, V, row_stride, row_max, row_sumexp, t, w);                                        \
+    rs_rowsum_b_kernel<DT><<<R * RS_SEG, 256, 0, s>>>(logits, V, row_stride, row_max, row_sumexp, t, w);                                        \
+    rs_op_bonus_kernel<DT><<<1, 256, 0, s>>>(logits, V, row_stride, proposed, R, row_max, row_sumexp, t, stop_ids, n_stop, u_cursor, m_stream,  \
+                                             m_len, m_cursor, committed, row, w);                                                               \
+    rs_op_redraft_kernel<DT><<<R, 256, 0, s>>>(logits, V, row_stride, R, row_max, row_sumexp, t, m_stream, m_len, row, w, redraft, pk)
+    if (dtype == JF_F32) { JF_OP(JF_F32); } else { JF_OP(JF_BF16); }
+#undef JF_OP
     return check_launch("rs_onpolicy kernels");
+}
+
+// May the one-launch step carry B rows on this device?  Its B + 3 waiting workgroups and the 16 workgroups of a row that wait
+// for each other must never be able to fill the chip: at most half of what the runtime says it keeps resident.
+static bool rs_fused_fits(const void *kern, int variant, int B) {
+    static std::mutex mu;
+    static int cap[2] = {-1, -1}, capdev[2] = {-1, -1};
+    std::lock_guard<std::mutex> g(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (cap[variant] < 0 || capdev[variant] != dev) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+            (void)hipGetLastError();
+            per_cu = 0;
+        }
+        const long long c = (long long)per_cu * cus / 2;
+        cap[variant] = (int)(c > 0x7FFFFFFF ? 0x7FFFFFFF : c);
+        capdev[variant] = dev;
+    }
+    return B + 3 + RS_SEG <= cap[variant];
 }
 
 extern "C" int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_stride, const int64_t *draft, int B, int L,
@@ -1467,7 +2108,7 @@ extern "C" int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_
                           int64_t *next_draft, jf_rs_row *rows, void *workspace, size_t workspace_bytes, void *stream) {
     if (B <= 0) return JF_OK;
     if (L < 2) return fail(JF_E_INVALID, "Draft must have at least 2 tokens (seed + 1 speculative)");
-    if (L > 0x7FFF) return fail(JF_E_INVALID, "jf_rs_step: L=%d too large", L);
+    if (L > 0x3FFF) return fail(JF_E_INVALID, "jf_rs_step: L=%d too large", L);
     if (!logits || !draft || !p_draft || !row_max || !row_sumexp || !packed || !remaining || !u_stream || !u_cursor ||
         !bonus_stream || !bonus_cursor || !pad_stream || !pad_cursor || !committed || !next_draft || !rows || !workspace)
         return fail(JF_E_INVALID, "jf_rs_step: null pointer");
@@ -1480,32 +2121,36 @@ extern "C" int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_
     unsigned long long *pk = (unsigned long long *)packed;
     const RsWs w = rs_ws(workspace, B);
     static const bool fused_ok = !(getenv("JF_RS_FUSED") && getenv("JF_RS_FUSED")[0] == '0');   // A/B knob, read once
-    if (fused_ok && (int64_t)B * (L - 1) <= RS_FUSED_STAGE && B <= RS_FUSED_ROWS && u_len < 0x7FFFFFFFll) {
-        static uint32_t g_gen = 0;                                  // generation of the hand-off words (0 never used: a zeroed workspace)
-        if (++g_gen == 0) ++g_gen;
+    const void *fk = dtype == JF_F32 ? (const void *)rs_step_fused_kernel<JF_F32> : (const void *)rs_step_fused_kernel<JF_BF16>;
+    if (fused_ok && (int64_t)B * (L - 1) <= RS_FUSED_STAGE && B <= RS_FUSED_ROWS && u_len < 0x7FFFFFFFll &&
+        rs_hier_ok(V, dtype == JF_F32 ? 4 : 8) && rs_fused_fits(fk, dtype == JF_F32 ? 0 : 1, B)) {
+        static std::atomic<uint32_t> g_gen{0};                      // generation of the hand-off words (0 never used: a zeroed workspace)
+        uint32_t gen = ++g_gen;
+        if (gen == 0) gen = ++g_gen;
         RsFusedArgs a{logits, V, row_stride, draft, B, L, p_draft, row_max, row_sumexp, pk, t, eos_id, remaining, u_stream, u_len, u_cursor,
-                      bonus_stream, bonus_len, bonus_cursor, pad_stream, pad_len, pad_cursor, committed, next_draft, rows, w, g_gen};
+                      bonus_stream, bonus_len, bonus_cursor, pad_stream, pad_len, pad_cursor, committed, next_draft, rows, w, gen};
         const unsigned grid = (unsigned)(1 + B * RS_SEG + 1 + B + 1);
         if (dtype == JF_F32) rs_step_fused_kernel<JF_F32><<<grid, 256, 0, s>>>(a);
         else rs_step_fused_kernel<JF_BF16><<<grid, 256, 0, s>>>(a);
         return check_launch("rs_step_fused_kernel");
     }
-    if ((int64_t)B * (L - 1) <= RS_STAGE && B <= RS_ROWS_LDS && u_len < 0x7FFFFFFFll)
-        rs_accept_kernel<true><<<1, 256, 0, s>>>(draft, B, L, p_draft, eos_id, u_stream, u_len, u_cursor, committed, rows, w);
-    else
-        rs_accept_kernel<false><<<1, 256, 0, s>>>(draft, B, L, p_draft, eos_id, u_stream, u_len, u_cursor, committed, rows, w);
+    const RsAcceptIn in{logits, V, row_stride, t, row_max, row_sumexp, p_draft};
+    const bool staged = (int64_t)B * (L - 1) <= RS_STAGE && B <= RS_ROWS_LDS && u_len < 0x7FFFFFFFll;
     const bool chain_in_bonus = B <= RS_BONUS_CHAIN_ROWS;
-#define JF_RS_BONUS(DT, CH) rs_bonus_kernel<DT, CH><<<B, 256, 0, s>>>(logits, V, row_stride, draft, L, row_max, row_sumexp, t, bonus_stream, bonus_len, bonus_cursor, committed, rows, w)
-    if (dtype == JF_F32) {
-        rs_rowsum_kernel<JF_F32><<<B * RS_SEG, 256, 0, s>>>(logits, V, row_stride, row_max, row_sumexp, t, w);
-        if (chain_in_bonus) JF_RS_BONUS(JF_F32, true);
-        else { rs_chain_kernel<<<1, 256, 0, s>>>(B, V, 4, bonus_stream, bonus_len, bonus_cursor, rows, w); JF_RS_BONUS(JF_F32, false); }
-    } else {
-        rs_rowsum_kernel<JF_BF16><<<B * RS_SEG, 256, 0, s>>>(logits, V, row_stride, row_max, row_sumexp, t, w);
-        if (chain_in_bonus) JF_RS_BONUS(JF_BF16, true);
-        else { rs_chain_kernel<<<1, 256, 0, s>>>(B, V, 8, bonus_stream, bonus_len, bonus_cursor, rows, w); JF_RS_BONUS(JF_BF16, false); }
+#define JF_RS_MULTI(DT)                                                                                                                        \
+    if (staged) rs_accept_kernel<DT, true><<<1, 256, 0, s>>>(in, draft, B, L, eos_id, u_stream, u_len, u_cursor, committed, rows, w);           \
+    else rs_accept_kernel<DT, false><<<1, 256, 0, s>>>(in, draft, B, L, eos_id, u_stream, u_len, u_cursor, committed, rows, w);                 \
+    rs_rowsum_a_kernel<DT><<<B * RS_SEG, 256, 0, s>>>(logits, V, row_stride, row_max, row_sumexp, t, w);                                        \
+    rs_rowsum_b_kernel<DT><<<B * RS_SEG, 256, 0, s>>>(logits, V, row_stride, row_max, row_sumexp, t, w);                                        \
+    if (chain_in_bonus) rs_bonus_kernel<DT, true><<<B, 256, 0, s>>>(logits, V, row_stride, draft, L, row_max, row_sumexp, t, bonus_stream,      \
+                                                                    bonus_len, bonus_cursor, committed, rows, w);                               \
+    else {                                                                                                                                      \
+        rs_chain_kernel<<<1, 256, 0, s>>>(B, V, Elem<DT>::EPV, bonus_stream, bonus_len, bonus_cursor, rows, w);                                 \
+        rs_bonus_kernel<DT, false><<<B, 256, 0, s>>>(logits, V, row_stride, draft, L, row_max, row_sumexp, t, bonus_stream, bonus_len,          \
+                                                     bonus_cursor, committed, rows, w);                                                         \
     }
-#undef JF_RS_BONUS
+    if (dtype == JF_F32) { JF_RS_MULTI(JF_F32) } else { JF_RS_MULTI(JF_BF16) }
+#undef JF_RS_MULTI
     rs_finish_kernel<<<1, 256, 0, s>>>(B, L, pk, eos_id, remaining, u_cursor, bonus_cursor, pad_stream, pad_len, pad_cursor, committed, next_draft, rows);
     return check_launch("rs_step kernels");
 }

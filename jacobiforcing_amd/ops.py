@@ -812,7 +812,11 @@ class RsStepper:
         th.copy_(cm, non_blocking=True)
         if dev.type == "cuda":
             torch.cuda.current_stream(dev).synchronize()
-        return self.rows_host[:B].numpy(), th.numpy(), nd
+        rows = self.rows_host[:B].numpy()
+        if int(rows[0, N.RS_FIELDS.index("rsv")]) != 0:       # the one-launch step gave up on an in-kernel wait (2 s bound) instead of hanging
+            self.rows_dev[0, N.RS_FIELDS.index("rsv")] = 0
+            N.check(N.JF_E_LAUNCH, "jf_rs_step (a workgroup of the one-launch step waited 2 s for another: launch incomplete)")
+        return rows, th.numpy(), nd
 
 
 # --------------------------------------------------------------------------------------------

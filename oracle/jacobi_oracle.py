@@ -732,15 +732,95 @@ def engine_generate_batch(forward: EngineForward, seqs: List[OracleSeq], eos_id:
 # ======================================================================================
 # a19 — non-greedy rejection-sampling verify (JDN:299-354) with injected randomness
 # ======================================================================================
+# ---- The probability tensor, defined EXACTLY (round 4) -------------------------------------------------------------------
+# torch forms  probs = softmax(xs)  in float32 and (bf16 logits) rounds once to bf16; its float32 internals (vectorised exp,
+# summation order) are not a specification — torch's CPU and GPU kernels, numpy and any HIP kernel differ from each other in the
+# last place, and after the bf16 rounding that is one bf16 ulp on ~0.1-1 % of the entries: enough to move an inverse-CDF draw
+# across a token boundary once in ~10^6 draws (profiles/soak_r02.txt, seed 4555).  What every one of them approximates is
+#
+#     p_i = RN_dtype( exp(xs_i - M) / sum_j exp(xs_j - M) ),   M = max xs,
+#
+# the exact real quotient rounded ONCE (nearest, ties to even; subnormals included) to the dtype of the logits — bf16 for the
+# engine's logits (MR:1382, JDN:64-70 never widens them), float32 for float32 logits.  That IS the definition here, and the HIP
+# kernels implement the same definition (float64 evaluation where a decision depends on it, jf_sampling.hip), so token ids are
+# bit-exact by construction instead of "equal unless a draw lands within an ulp of a boundary".  It stays within one ulp of the
+# dtype of torch's own tensor (tests/golden/softmax_vectors.json, recorded from the reference).
+# float64 evaluation errs by ~5e-16 relative; an element whose exact quotient lies that close to a rounding boundary cannot be
+# decided in float64.  Elements within 1e-12 (relative) of a boundary are therefore re-decided in 60-digit decimal arithmetic.
+NEAR_TIE_REL = 1e-12
+NEAR_TIES_RESOLVED = [0]          # how many elements took the decimal path (diagnostics for the tests)
+
+
+def _round_to_grid(q: np.ndarray, mant_bits: int, row_ctx=None) -> np.ndarray:
+    """Nearest-even rounding of non-negative float64 values onto the grid of a binary format with ``mant_bits`` explicit
+    mantissa bits and float32's exponent range (bf16: 7, float32: 23), subnormals included.  Returned as float64 (exact)."""
+    q = np.asarray(q, dtype=np.float64)
+    _, ex = np.frexp(q)                                   # q = f * 2^ex, f in [0.5, 1)
+    g = np.maximum(ex - 1, -126) - mant_bits              # exponent of the grid spacing at q
+    k = np.ldexp(q, -g)                                   # exact (power-of-two scaling, no underflow: q * 2^149 at most)
+    r = np.rint(k)                                        # nearest even on the exact value
+    if row_ctx is not None:
+        frac = np.abs(k - np.floor(k) - 0.5)
+        near = (frac < NEAR_TIE_REL * np.maximum(k, 1.0)) & (q > 0)
+        if near.any():
+            for i in np.nonzero(near)[0]:
+                r[i] = row_ctx(int(i), int(g[i]))
+                NEAR_TIES_RESOLVED[0] += 1
+    return np.ldexp(r, g)
+
+
+def _decimal_rounder(d_row: np.ndarray):
+    """Returns f(i, g) -> the correctly rounded integer k = RN(exp(d_i) / sum_j exp(d_j) / 2^g) decided in 60-digit decimal."""
+    import decimal
+    ctx = decimal.Context(prec=60)
+    state = {}
+
+    def decide(i: int, g: int):
+        if "S" not in state:
+            uniq, cnt = np.unique(d_row[np.isfinite(d_row)], return_counts=True)
+            state["S"] = sum((ctx.multiply(ctx.exp(decimal.Decimal(float(v))), decimal.Decimal(int(c))) for v, c in zip(uniq, cnt)),
+                             decimal.Decimal(0))
+        q = ctx.divide(ctx.exp(decimal.Decimal(float(d_row[i]))), state["S"])
+        k = ctx.multiply(q, ctx.power(decimal.Decimal(2), decimal.Decimal(-g)))
+        fl = k.to_integral_value(rounding=decimal.ROUND_FLOOR)
+        diff = ctx.subtract(k, fl)
+        half = decimal.Decimal("0.5")
+        if diff > half or (diff == half and int(fl) % 2 == 1):
+            return float(int(fl) + 1)
+        return float(int(fl))
+    return decide
+
+
+def exact_softmax_rows(xs: np.ndarray, mant_bits: int) -> np.ndarray:
+    """Rows of already temperature-scaled logits (float32 values) -> probabilities per the definition above, as float32.
+    Rows without a finite maximum, or holding NaN / +inf, keep the plain float32 formula (NaN where torch's softmax is NaN)."""
+    xs = np.asarray(xs, dtype=np.float32)
+    out = np.empty(xs.shape, dtype=np.float32)
+    flat_in, flat_out = xs.reshape(-1, xs.shape[-1]), out.reshape(-1, xs.shape[-1])
+    for r in range(flat_in.shape[0]):
+        x = flat_in[r]
+        m = x.max() if x.size else np.float32(0)
+        if not np.isfinite(m) or np.isnan(x).any():
+            with np.errstate(invalid="ignore", over="ignore"):
+                e = np.exp(x - m, dtype=np.float32)
+                p = (e / e.sum(dtype=np.float32)).astype(np.float32)
+            flat_out[r] = p if mant_bits == 23 else bf16_round(p)
+            continue
+        d = x.astype(np.float64) - np.float64(m)          # exact: both are float32 values
+        e = np.exp(d)
+        S = float(np.sum(e, dtype=np.float64))
+        flat_out[r] = _round_to_grid(e / S, mant_bits, row_ctx=_decimal_rounder(d)).astype(np.float32)
+    return out
+
+
 def softmax_rows_f32(logits: np.ndarray, temperature: float) -> np.ndarray:
-    """JDN:65-70 in fp32: p = softmax(logits / T) (T<=0 treated as 1)."""
+    """JDN:65-70 on float32 logits: xs = fl32(logits / T) (torch's true division; T<=0 treated as 1), p = the exact softmax of
+    xs rounded once to float32."""
     x = np.asarray(logits, dtype=np.float32)
     t = np.float32(1.0 if (temperature is None or temperature <= 0) else temperature)
     if t != np.float32(1.0):
-        x = x / t
-    m = x.max(axis=-1, keepdims=True)
-    e = np.exp(x - m, dtype=np.float32)
-    return (e / e.sum(axis=-1, keepdims=True, dtype=np.float32)).astype(np.float32)
+        x = (x / t).astype(np.float32)
+    return exact_softmax_rows(x, 23)
 
 
 def bf16_round(x: np.ndarray) -> np.ndarray:
@@ -750,24 +830,20 @@ def bf16_round(x: np.ndarray) -> np.ndarray:
 
 def softmax_rows_bf16(logits: np.ndarray, temperature: float) -> np.ndarray:
     """JDN:64-70 on a bfloat16 logits tensor, which is what the engine hands the verifier (MR:1382 has no cast and
-    JDN never calls ``.float()``).  torch keeps the tensor dtype through both ops and rounds after each one:
+    JDN never calls ``.float()``).  torch keeps the tensor dtype through both ops:
       * ``logits / float(T)``: float32 quotient of the widened operand by float32(T), rounded to bf16
-        (ATen div_true_kernel for reduced floating types; skipped when T == 1, JDN:68);
-      * ``torch.softmax``: max / exp(x - max) / sum in float32, result rounded to bf16.
-    Returned as float32 values that are exactly bf16-representable.  The float32 internals of torch's CPU softmax
-    (vectorised exp, summation order) are not reproduced bit for bit - torch's own result differs from an exactly
-    rounded softmax in ~0.1 % of the entries by one bf16 ulp - so entries may differ from torch by one bf16 ulp at
-    that rate; every consumer of the result (``u < p``, the float64 inverse-CDF walk, the masked argmax) works on
-    the rounded values, as the reference does."""
+        (ATen div_true_kernel for reduced floating types; skipped when T == 1, JDN:68) — reproduced bit for bit;
+      * ``torch.softmax``: a float32 softmax rounded to bf16 — DEFINED here as the exact softmax rounded once to bf16 (see
+        the block comment above); torch's tensor lies within one bf16 ulp of it.
+    Returned as float32 values that are exactly bf16-representable; every consumer (``u < p``, the float64 inverse-CDF
+    walk, the masked argmax) works on these rounded values, as the reference does."""
     x = np.asarray(logits, dtype=np.float32)
     if not np.array_equal(bf16_round(x), x, equal_nan=True):
         raise ValueError("softmax_rows_bf16 expects bf16-representable logits")
     t = np.float32(1.0 if (temperature is None or temperature <= 0) else temperature)
     if t != np.float32(1.0):
         x = bf16_round((x / t).astype(np.float32))
-    m = x.max(axis=-1, keepdims=True)
-    e = np.exp(x - m, dtype=np.float32)
-    return bf16_round((e / e.sum(axis=-1, keepdims=True, dtype=np.float32)).astype(np.float32))
+    return exact_softmax_rows(x, 7)
 
 
 def target_probs(logits: np.ndarray, temperature: float, logits_dtype: str = "f32") -> np.ndarray:

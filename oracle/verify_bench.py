@@ -37,9 +37,11 @@ def main():
     nodes = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node")]) if os.path.isdir("/sys/devices/system/node") else None
     print(json.dumps(dict(us_per_call=dt * 1e6, gbs=rows * V * 2 / dt / 1e9, rows=rows, threads=int(lib.ref_num_threads()), reps=reps,
                           seconds=budget_s, numa_nodes=nodes,
-                          placement=f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND', 'unset')} OMP_PLACES={os.environ.get('OMP_PLACES', 'unset')}: "
-                                    "threads pinned core by core, rows first-touched by the thread that scans them (static schedule in fill "
-                                    "and scan), one warm-up call before the timed repetitions",
+                          placement=f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND', 'unset')} OMP_PLACES={os.environ.get('OMP_PLACES', 'unset')} "
+                                    f"OMP_NUM_THREADS={os.environ.get('OMP_NUM_THREADS', 'unset')}: "
+                                    + ("threads pinned in order, " if os.environ.get("OMP_PROC_BIND") else "the runtime's default placement, ")
+                                    + "rows first-touched by the thread that scans them (static schedule in fill and scan), one warm-up call "
+                                      "before the timed repetitions",
                           what="oracle/verify_ref.c ref_argmax_rows (C + OpenMP) over bf16 logits of the bench's launch shape")))
 
 

@@ -296,7 +296,7 @@ def test_rccl_single_rank_group_runs_the_collectives(tmp_path):
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
-    d = json.loads(r.stdout.strip().splitlines()[-1])
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])      # RCCL prints its library path on stdout
     assert d["backend"] == "nccl" and d["ws"] == 1
     assert d["agg"] == dict(tokens=123.0, iterations=7.0, seconds=0.5, world_size=1)
     assert d["sum"] == float((1 << 20) * ((1 << 20) - 1) // 2)

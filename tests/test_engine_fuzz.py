@@ -206,3 +206,12 @@ def test_engine_onpolicy_fuzz(seed, backend):
         assert dec._cur == [cur["u"], cur["m"]] and a.k == b.k
         for s, o in zip(seqs, oseqs):
             assert s.token_ids == o.token_ids and s.num_cached_tokens == o.num_cached_tokens
+
+
+@pytest.mark.gpu
+def test_onpolicy_seed_4555_the_draw_next_to_a_cdf_boundary():
+    """Permanent regression for the one mismatch of the round-2 / round-3 soaks (profiles/soak_r02.txt, soak_r03.txt): an
+    inverse-CDF draw whose target lies 4.3e-8 above a token boundary of a bf16 row (V = 200, T = 0.4) — decided by a single
+    bf16 ulp of one probability, i.e. by whose float32 softmax it was.  Kernels and oracle now share ONE definition of the
+    probability tensor (the exact softmax rounded once), so the records agree."""
+    test_engine_onpolicy_fuzz(4555, "hip")

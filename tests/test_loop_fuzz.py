@@ -86,6 +86,10 @@ def test_loop_fuzz_vs_oracle(seed, backend):
         # K >= 3 with a small spawn ratio: the reference's block lists run away (tests/golden/mb_cases_v3.json pins
         # rows of up to ~77 n tokens) — the decoder follows (its candidate scratch grows on demand), nothing is cut off
         r = float(rng.choice([0.05, 0.25]))
+        # (hundreds of forwards with rows of hundreds of tokens, restated token by token in Python on the oracle's side: two
+        #  prompts, three calls and a small block keep such a seed at a few seconds)
+        P, max_calls, n = min(P, 2), min(max_calls, 3), min(n, 16)
+        max_new = min(max_new, 4 * n)
     with use_backend(backend):
         dev = device_for(backend)
         # a vocabulary whose rows are not 16-byte multiples takes the convergence check as its two launches (and the pack
