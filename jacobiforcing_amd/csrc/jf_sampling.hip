@@ -1242,24 +1242,28 @@ struct RsAcceptIn {                 // what an accept test's probability is made
 // One accept test as an LDS word: the LOWER candidate probability (a float <= 1: bits 31 / 30 are free), RS_PE_AMB when the
 // float32 row sum cannot decide the rounding (bf16: the upper candidate is the next bf16; float32: lo * (1 + 2^-12) bounds
 // it), RS_PE_EOS when the proposed token is the EOS id.  Rows without finite statistics keep jf_rs_probs' plain float32 value.
+// the word of one test from its loaded ingredients (M, S: the row's statistics; x: the raw logit of the proposed token;
+// pd: jf_rs_probs' float32 value, used only for rows without finite statistics)
 template <int DT>
-__device__ __forceinline__ uint32_t rs_accept_entry(const RsAcceptIn &in, int64_t i, int64_t tok, int eos_id, const double *tab) {
-    const uint32_t eos = (eos_id >= 0 && tok == (int64_t)eos_id) ? RS_PE_EOS : 0u;
-    const float M = in.row_max[i], S = in.row_sumexp[i];
-    if (!rs_row_is_exact(M, S)) {                            // NaN / inf rows: jf_rs_probs' plain float32 value (a NaN never accepts)
-        const float pd = in.p_draft[i];
+__device__ __forceinline__ uint32_t rs_accept_word(float M, float S, float x, float pd, bool tok_ok, bool is_eos, float t, const double *tab) {
+    const uint32_t eos = is_eos ? RS_PE_EOS : 0u;
+    if (!rs_row_is_exact(M, S))                              // NaN / inf rows: the plain float32 value (a NaN never accepts)
         return ((pd > 0.f) ? (__float_as_uint(pd > 1.f ? 1.f : pd) & RS_PE_VAL) : 0u) | eos;
-    }
-    if (tok < 0 || tok >= in.V) return eos;
-    const float inv_t = 1.f / in.t;
-    const float xs = rs_scaled<DT>(load_f<DT>((const char *)in.logits + i * in.row_stride * (DT == JF_F32 ? 4 : 2), tok), in.t, inv_t, in.t == 1.f);
+    if (!tok_ok) return eos;
+    const float xs = rs_scaled<DT>(x, t, 1.f / t, t == 1.f);
     const double e = rs_e64(xs, (double)M, tab);
     if (e == 0.0) return eos;                                 // exactly 0 under every candidate sum
-    const double ph = e / (double)S, eps = rs_eps_row(M);
+    const double ph = e * (1.0 / (double)S), eps = rs_eps_row(M) + 2.3e-16;
     const float lo = rs_round_prob<DT>(ph * (1.0 - eps)), hi = rs_round_prob<DT>(ph * (1.0 + eps));
     uint32_t bits = __float_as_uint(lo > 1.f ? 1.f : lo) & RS_PE_VAL;
     if (DT == JF_F32 || lo != hi) bits |= RS_PE_AMB;
     return bits | eos;
+}
+template <int DT>
+__device__ __forceinline__ uint32_t rs_accept_entry(const RsAcceptIn &in, int64_t i, int64_t tok, int eos_id, const double *tab) {
+    const bool ok = tok >= 0 && tok < in.V;
+    const float x = ok ? load_f<DT>((const char *)in.logits + i * in.row_stride * (DT == JF_F32 ? 4 : 2), tok) : 0.f;
+    return rs_accept_word<DT>(in.row_max[i], in.row_sumexp[i], x, in.p_draft[i], ok, eos_id >= 0 && tok == (int64_t)eos_id, in.t, tab);
 }
 template <int DT>
 __device__ __forceinline__ float rs_accept_hi(uint32_t pe) {   // upper candidate of an ambiguous entry
@@ -1295,13 +1299,71 @@ __device__ __forceinline__ void rs_accept_body(const RsAcceptIn &in, const int64
         const int ul = (int)u_len, ub = (int)(uc0 % u_len);
         // loads first (eight per lane in flight), arithmetic afterwards; at most n uniforms can be used
         batched_for<8, float>(n, tid, 256, [&](int64_t i) { return u_stream[(ub + (int)i) % ul]; }, [&](int64_t i, float v) { s_u[i] = v; });
-        batched_for<4, int64_t>(n, tid, 256, [&](int64_t i) { return tok_at((int)i); },
-                                [&](int64_t i, int64_t tk) { s_p[i] = rs_accept_entry<DT>(in, i, tk, eos_id, s_tab); });
+        // every test's word: (token, M, S, p_draft) in one round of loads, the gathered logits in a second, then the arithmetic
+        for (int i0 = tid; i0 < n; i0 += 8 * 256) {
+            int64_t tk[8];
+            float M[8], S[8], pd[8], x[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + k * 256;
+                if (i < n) { tk[k] = tok_at(i); M[k] = in.row_max[i]; S[k] = in.row_sumexp[i]; pd[k] = in.p_draft[i]; }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + k * 256;
+                x[k] = 0.f;
+                if (i < n && tk[k] >= 0 && tk[k] < in.V) x[k] = load_f<DT>((const char *)in.logits + (int64_t)i * in.row_stride * (DT == JF_F32 ? 4 : 2), tk[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + k * 256;
+                if (i < n) s_p[i] = rs_accept_word<DT>(M[k], S[k], x[k], pd[k], tk[k] >= 0 && tk[k] < in.V, eos_id >= 0 && tk[k] == (int64_t)eos_id, in.t, s_tab);
+            }
+        }
     }
     __syncthreads();
     int b_start = 0, used_start = 0;
     for (;;) {                                                      // the walk; re-entered after an undecided test was resolved
-        if (tid < 64) {
+        if (tid < 64 && STAGED && W <= 64) {
+            // one ballot per row; the row's words were loaded while the row before it was decided, so the only dependent
+            // access of a step is the uniform at this row's stream offset (~0.1 us per row)
+            const int lane = tid;
+            const bool inrow = lane < W;
+            int used_total = used_start, unc_at = -1, b = b_start;
+            uint32_t pe = (inrow && b < B) ? s_p[b * W + lane] : 0u;
+            unsigned long long fa = (unsigned long long)(w.flag + (int64_t)b * RS_FLAG_STRIDE);
+            asm volatile("" : "+v"(fa));                            // the flag line's address lives in vector registers: no scalar reloads per row
+            for (; b < B; ++b) {                                    // JDN:326-348, rows in order
+                const float uu = inrow ? s_u[used_total + lane] : 0.f;
+                const uint32_t pe_next = (inrow && b + 1 < B) ? s_p[(b + 1) * W + lane] : 0u;
+                const bool rejb = inrow && !(uu < __uint_as_float(pe & RS_PE_VAL));
+                const unsigned long long rejmask = __ballot(rejb);
+                const unsigned long long stopmask = rejmask | __ballot(inrow && (pe & RS_PE_EOS));
+                int nacc = W, eos = 0, rej = -1, used = W;
+                if (stopmask) {
+                    const int f = __builtin_ctzll(stopmask);
+                    if ((rejmask >> f) & 1ull) {
+                        const bool unc = rejb && (pe & RS_PE_AMB) && uu < rs_accept_hi<DT>(pe);
+                        if ((__ballot(unc) >> f) & 1ull) { unc_at = b * W + f; break; }   // the first stop is undecided: resolve it
+                        rej = f; nacc = f;
+                    } else { eos = 1; nacc = f + 1; }
+                    used = f + 1;
+                }
+                if (lane == 0) {
+                    s_res[b] = nacc | (eos << 15) | ((rej + 1) << 16);
+                    if constexpr (SIG) {
+                        __hip_atomic_store((unsigned long long *)fa, ((unsigned long long)gen << 32) | ((unsigned long long)eos << 30) |
+                                           ((unsigned long long)nacc << 16) | (unsigned long long)(rej + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        RS_ROWSTAMP(0, b);
+                    }
+                }
+                fa += RS_FLAG_STRIDE * sizeof(unsigned long long);
+                used_total += used;
+                pe = pe_next;
+            }
+            if (lane == 0) { s_unc = unc_at; s_resume = b; s_used = used_total; }
+            if constexpr (SIG) { if (unc_at < 0) RS_STAMP_MAX(15); }   // 15: the accept walk has decided the last row
+        } else if (tid < 64) {
             const int lane = tid;
             int used_total = used_start, unc_at = -1, b = b_start;
             for (; b < B; ++b) {                                    // JDN:326-348, rows in order
@@ -1755,7 +1817,8 @@ __global__ __launch_bounds__(256) void rs_step_fused_kernel(RsFusedArgs a) {
             return;
         }
         // wavefront 0: one look at the ready words of the next 64 rows (a lane each), then every row of the leading run of ready
-        // ones without polling again — a poll per row (an acquire on LDS each) was 0.7 us per row, 46 us for 64 rows
+        // ones without polling again — a poll per row (an acquire on LDS each) was 0.7 us per row.  The run's intervals are
+        // loaded a lane per row and broadcast from registers: the one dependent access of a row's step is its uniforms.
         int off = 0, i = 0;
         while (i < B) {
             const int r = i + tid;
@@ -1764,12 +1827,14 @@ __global__ __launch_bounds__(256) void rs_step_fused_kernel(RsFusedArgs a) {
             const int run = nr ? __builtin_ctzll(nr) : 64;           // rows i .. i + run - 1 are ready
             if (run == 0) { __builtin_amdgcn_s_sleep(1); continue; }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // their intervals were stored before their ready words
-            for (const int end = i + run; i < end; ++i) {
-                const double t_ = s_tot[i];
+            const double my_tot = tid < run ? s_tot[r] : -1.0, my_lo = tid < run ? s_lo[r] : 0.0, my_hi = tid < run ? s_hi[r] : 0.0;
+            for (int k = 0; k < run; ++k, ++i) {
+                const double t_ = __shfl(my_tot, k, 64);
                 if (t_ < 0.0) continue;
                 float uf;
                 const int o = off;
-                const int draws = rs_count_draws([&](int tr) { return staged ? s_u[o + tr] : a.b_stream[(bc0 + o + tr) % a.b_len]; }, t_, s_lo[i], s_hi[i], tid, &uf);
+                const int draws = rs_count_draws([&](int tr) { return staged ? s_u[o + tr] : a.b_stream[(bc0 + o + tr) % a.b_len]; }, t_,
+                                                 __shfl(my_lo, k, 64), __shfl(my_hi, k, 64), tid, &uf);
                 if (tid == 0) {                                      // the count for the end workgroup (ordered by chain-done below),
                     __hip_atomic_store(&a.rows[i].n_bonus_draws, draws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(w.pick + i, ((unsigned long long)a.gen << 32) | (unsigned long long)__float_as_uint(uf), __ATOMIC_RELAXED,
@@ -1851,6 +1916,7 @@ __global__ __launch_bounds__(256) void rs_step_fused_kernel(RsFusedArgs a) {
     // ---- block 2: what depends on more than one row — pad offsets, the pads, the stream cursors
     __shared__ int s_np[RS_FUSED_ROWS], s_off[RS_FUSED_ROWS];
     __shared__ int s_bad, s_pads;
+    const int64_t pc0 = *a.pad_cursor;                               // (nobody else writes it: loaded while the rows are still at work)
     if (tid == 0) s_bad = 0;
     __syncthreads();
     if (tid == 0) { if (!rs_wait_word(w.acceptdone, a.gen) || !rs_wait_word(w.acceptdone + 1, a.gen)) s_bad = 1; }   // n_uniforms, the draw counts
@@ -1881,11 +1947,10 @@ __global__ __launch_bounds__(256) void rs_step_fused_kernel(RsFusedArgs a) {
     }
     __syncthreads();
     RS_STAMP_MAX(25);                                                // 25: end: scans done
-    const int64_t pc0 = *a.pad_cursor;
-    for (int idx = tid; idx < B * W; idx += 256) {                   // the pads of every row that keeps decoding
-        const int b = idx / W, j = idx - b * W;
+    for (int idx = tid; idx < B * 32; idx += 256) {                  // the pads of every row that keeps decoding: 32 lanes per row
+        const int b = idx >> 5;
         const int np = s_np[b];
-        if (j < np) a.next_draft[(int64_t)b * L + (L - np) + j] = a.pad_stream[(pc0 + s_off[b] + j) % a.pad_len];
+        for (int j = idx & 31; j < np; j += 32) a.next_draft[(int64_t)b * L + (L - np) + j] = a.pad_stream[(pc0 + s_off[b] + j) % a.pad_len];
     }
     __syncthreads();
     if (tid == 0) *a.pad_cursor = pc0 + s_pads;

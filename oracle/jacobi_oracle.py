@@ -745,10 +745,13 @@ def engine_generate_batch(forward: EngineForward, seqs: List[OracleSeq], eos_id:
 # kernels implement the same definition (float64 evaluation where a decision depends on it, jf_sampling.hip), so token ids are
 # bit-exact by construction instead of "equal unless a draw lands within an ulp of a boundary".  It stays within one ulp of the
 # dtype of torch's own tensor (tests/golden/softmax_vectors.json, recorded from the reference).
-# float64 evaluation errs by ~5e-16 relative; an element whose exact quotient lies that close to a rounding boundary cannot be
-# decided in float64.  Elements within 1e-12 (relative) of a boundary are therefore re-decided in 60-digit decimal arithmetic.
-NEAR_TIE_REL = 1e-12
-NEAR_TIES_RESOLVED = [0]          # how many elements took the decimal path (diagnostics for the tests)
+# float64 evaluation errs by a few 1e-16 relative (exp and division one ulp each, a pairwise sum of non-negative terms); an
+# element whose exact quotient lies that close to a rounding boundary cannot be decided in float64.  Elements within 1e-14
+# (relative) of a boundary are therefore re-decided in 80-bit extended precision, and those within 1e-18 of it in 60-digit
+# decimal arithmetic.
+NEAR_TIE_REL = 1e-14
+NEAR_TIE_REL_LD = 1e-18
+NEAR_TIES_RESOLVED = [0, 0]       # how many elements took the extended / the decimal path (diagnostics for the tests)
 
 
 def _round_to_grid(q: np.ndarray, mant_bits: int, row_ctx=None) -> np.ndarray:
@@ -765,17 +768,29 @@ def _round_to_grid(q: np.ndarray, mant_bits: int, row_ctx=None) -> np.ndarray:
         if near.any():
             for i in np.nonzero(near)[0]:
                 r[i] = row_ctx(int(i), int(g[i]))
-                NEAR_TIES_RESOLVED[0] += 1
     return np.ldexp(r, g)
 
 
 def _decimal_rounder(d_row: np.ndarray):
-    """Returns f(i, g) -> the correctly rounded integer k = RN(exp(d_i) / sum_j exp(d_j) / 2^g) decided in 60-digit decimal."""
+    """Returns f(i, g) -> the correctly rounded integer k = RN(exp(d_i) / sum_j exp(d_j) / 2^g): first in 80-bit extended
+    precision (x86 long double: 64-bit mantissa), and when the quotient lies within NEAR_TIE_REL_LD of the boundary even
+    there, in 60-digit decimal arithmetic."""
     import decimal
     ctx = decimal.Context(prec=60)
     state = {}
+    ld = np.longdouble
+    have_ld = np.finfo(ld).nmant >= 63
 
     def decide(i: int, g: int):
+        if have_ld:
+            if "Sld" not in state:
+                state["Sld"] = np.exp(d_row.astype(ld)).sum()
+            k = np.ldexp(np.exp(ld(d_row[i])) / state["Sld"], -g)
+            fl = np.floor(k)
+            if abs(k - fl - ld(0.5)) >= ld(NEAR_TIE_REL_LD) * max(k, ld(1.0)):
+                NEAR_TIES_RESOLVED[0] += 1
+                return float(fl + 1) if k - fl > ld(0.5) else float(fl)
+        NEAR_TIES_RESOLVED[1] += 1
         if "S" not in state:
             uniq, cnt = np.unique(d_row[np.isfinite(d_row)], return_counts=True)
             state["S"] = sum((ctx.multiply(ctx.exp(decimal.Decimal(float(v))), decimal.Decimal(int(c))) for v, c in zip(uniq, cnt)),

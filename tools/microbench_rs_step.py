@@ -52,9 +52,9 @@ def main():
     if a.trace:
         import ctypes as C
         lib = N.lib()
-        names = {1: "accept workgroup done", 15: "accept walk decided the last row", 6: "first row handed its uniform", 7: "last row handed its uniform",
-                 12: "finishing workgroup starts", 13: "finished", 17: "last row's bonus workgroup has its uniform", 19: "... has walked",
-                 21: "... has stored its token", 16: "    pick: starts (row constants loaded)", 18: "    pick: segment known", 20: "    pick: tiles loaded, probabilities + wave scans", 22: "    pick: resolved", 23: "finish: row records done", 25: "finish: scans done", 27: "finish: next drafts written"}
+        names = {1: "accept workgroup done", 15: "accept walk decided the last row", 7: "last row handed its uniform",
+                 12: "end workgroup has every row's finish word", 25: "end: scans done", 13: "finished", 17: "last row's bonus workgroup has its uniform",
+                 19: "... has walked", 21: "... has finished its row (token, record, next draft's seed and tail)"}
         acc = {k: [] for k in names}
         for i in range(8):
             lib.jf_exp_rs_trace(None, 1)
