@@ -400,10 +400,14 @@ JF_API int jf_engine_fill(const int64_t *draft, int B, int L, const int32_t *seq
  *   +inf keep the plain float32 formula (NaN where torch's softmax is NaN).
  *
  * jf_rs_probs: fused softmax-gather + argmax over logits [R, V] read once.  For row r:
- *   p_draft[r] = p[draft_next[r]] (JDN:65-70, 328; a float holding a bf16 value for JF_BF16; the float32 approximation —
- *   informational: the steps re-derive it), row_max[r] = max xs (exact), row_sumexp[r] = sum exp(xs - max) in float32 (relative
- *   error < 2^-14: the steps' error band) and the packed argmax of the RAW logits (next draft, JDN:446/619).  packed must
- *   be zero on entry.
+ *   p_draft[r] = p[draft_next[r]] (JDN:65-70, 328) as far as one pass over the logits can know it: the float64 exp of the
+ *   gathered logit over the float32 row sum, whose relative error is below ~4e-5 (+ 3.5e-7 |max xs|).  JF_F32: that value;
+ *   the steps test u against the band around it.  JF_BF16: a float holding a bf16 value — the LOWER of the two roundings the
+ *   band allows; when they differ (the float32 sum cannot decide the rounding, ~1 % of the rows) the SIGN BIT is set and the
+ *   upper candidate is the next bf16 (|p_draft| is the probability either way).  An accept test whose uniform falls between
+ *   the candidates is re-decided by the step with the row's float64 sum.
+ *   row_max[r] = max xs (exact), row_sumexp[r] = sum exp(xs - max) in float32 and the packed argmax of the RAW logits (next
+ *   draft, JDN:446/619).  packed must be zero on entry.
  */
 JF_API int jf_rs_probs(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride,
                 const int64_t *draft_next, float temperature, float *p_draft, float *row_max,

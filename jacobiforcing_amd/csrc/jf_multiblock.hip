@@ -202,18 +202,18 @@ __device__ __forceinline__ unsigned long long ld_agent_u64(const unsigned long l
 constexpr int VERIFY_LDS_HDR = 32;                               // ints in front of the compact image (descriptor + flags)
 constexpr unsigned long long VERIFY_WAIT_TICKS = 200000000ull;   // 2 s of the 100 MHz constant clock: never hang the GPU
 
-// Maximum over the chunk slots of one position (adjacent words); false while one of them is still zero.  Eight loads are
-// issued before the first is looked at: a position of a small forward has up to ~16 chunks, and one dependent round trip
-// per chunk was 3 us between the last item and the step at one prompt.
+// Maximum over the chunk slots of one position (adjacent words); false while one of them is still zero.  Sixteen loads are
+// issued before the first is looked at: a position of a small forward has up to 16 chunks, and one dependent round trip
+// per chunk was 3 us between the last item and the step at one prompt (round 3: batches of eight, two round trips at 16 chunks).
 __device__ __forceinline__ bool slots_max(const unsigned long long *q, int cpr, unsigned long long &mx) {
     mx = 0ull;
     bool zero = false;
-    for (int c0 = 0; c0 < cpr; c0 += 8) {
-        unsigned long long v[8];
+    for (int c0 = 0; c0 < cpr; c0 += 16) {
+        unsigned long long v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = c0 + u < cpr ? ld_agent_u64(q + c0 + u) : ~0ull;
+        for (int u = 0; u < 16; ++u) v[u] = c0 + u < cpr ? ld_agent_u64(q + c0 + u) : ~0ull;
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 16; ++u)
             if (c0 + u < cpr) { zero |= v[u] == 0ull; mx = v[u] > mx ? v[u] : mx; }
     }
     return !zero;

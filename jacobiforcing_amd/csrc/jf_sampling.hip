@@ -277,11 +277,83 @@ __global__ __launch_bounds__(256) void rs_probs_partial_kernel(const void *logit
     }
 }
 
+// ---- float64 helpers of the exact probability definition (see "Exact probabilities" below) ----
+__device__ const double RS_EXP2_TAB[64] = {   // 2^(j/64), correctly rounded
+    1.0, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284, 1.0442737824274138, 1.0556451783605572, 1.0671404006768237,
+    1.0787607977571199, 1.0905077326652577, 1.102382583307841, 1.1143867425958924, 1.1265216186082418, 1.1387886347566916,
+    1.1511892299529827, 1.1637248587775775, 1.1763969916502812, 1.189207115002721, 1.202156731452703, 1.215247359980469,
+    1.22848053610687, 1.241857812073484, 1.255380757024691, 1.2690509571917332, 1.2828700160787783, 1.2968395546510096,
+    1.3109612115247644, 1.3252366431597413, 1.339667524053303, 1.3542555469368927, 1.3690024229745905, 1.383909881963832,
+    1.3989796725383112, 1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647, 1.4768261459394993,
+    1.4929077282912648, 1.5091644275934228, 1.5255981507445384, 1.5422108254079407, 1.559004400237837, 1.5759808451078865,
+    1.593142151342267, 1.6104903319492543, 1.6280274218573478, 1.645755478153965, 1.6636765803267364, 1.681792830507429,
+    1.7001063537185235, 1.718619298122478, 1.7373338352737062, 1.7562521603732995, 1.7753764925265212, 1.7947090750031072,
+    1.8142521755003989, 1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656, 1.9152065613971474,
+    1.9360617934922943, 1.9571441241754002, 1.978456026387951};
+constexpr double RS_EXP_CUT = -104.0;             // exp(d) < 2^-150: the quotient (S >= 1) rounds to 0 in bf16 and in float32
+__device__ __forceinline__ void rs_load_tab(double *tab) {   // 64-entry table into LDS (callers follow with a barrier)
+    if (threadIdx.x < 64) tab[threadIdx.x] = RS_EXP2_TAB[threadIdx.x];
+}
+// exp(d) for RS_EXP_CUT <= d <= 0, relative error <= 2.3e-16 (checked against 50-digit decimals over 20 000 arguments):
+// d = k ln2/64 + r, |r| <= ln2/128, exp(r) by a degree-5 polynomial, 2^(k/64) = 2^(k >> 6) * tab[k & 63].  14 float64 ops.
+__device__ __forceinline__ double rs_exp64(double d, const double *tab) {
+    const double kf = __builtin_rint(d * 92.33248261689366);                               // 64 / ln 2
+    const double r = __builtin_fma(-kf, 2.9815858269852933e-12, __builtin_fma(-kf, 0.01083042469326756, d));   // ln2/64 = hi (33 bits) + lo
+    double p = 8.333333333333333e-3;
+    p = __builtin_fma(p, r, 4.1666666666666664e-2);
+    p = __builtin_fma(p, r, 1.6666666666666666e-1);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = p * r;                                                                              // exp(r) - 1
+    const int k = (int)kf;
+    const double tj = tab[k & 63];
+    return __builtin_ldexp(__builtin_fma(tj, p, tj), k >> 6);
+}
+// nearest-even bf16 of a non-negative float64 (subnormals included), as a float: float32 by round-to-odd, then RNE
+__device__ __forceinline__ float rs_bf16_of_f64(double q) {
+    const float f = (float)q;
+    const double back = (double)f;
+    uint32_t u = __float_as_uint(f);
+    if (back > q) u -= 1u;                          // toward zero
+    if (back != q) u |= 1u;                         // sticky
+    u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+    return __uint_as_float(u);
+}
+template <int DT>
+__device__ __forceinline__ float rs_round_prob(double q) {
+    if constexpr (DT == JF_BF16) return rs_bf16_of_f64(q);
+    else return (float)q;
+}
+// a row statistic pair the exact path can work with (else: NaN / inf rows keep the plain float32 formula, like torch)
+__device__ __forceinline__ bool rs_row_is_exact(float M, float S) {
+    return (__float_as_uint(M) & 0x7F800000u) != 0x7F800000u && S > 0.f && (__float_as_uint(S) & 0x7F800000u) != 0x7F800000u;
+}
+// relative error bound of the streaming kernel's float32 row sum against the exact sum relative to M: float32 accumulation
+// and v_exp_f32 (2^-15, three times what the sweeps show), plus the scaled maximum's rounding residual and the float32
+// x * (1/T) of its exponent arguments, both proportional to |M| (DESIGN.md §7)
+__device__ __forceinline__ double rs_eps_row(float M) {
+    return 3.0517578125e-5 + 2.384185791015625e-7 * (1.45 * (double)fabsf(M) + 32.0);
+}
+// exp(xs - M) in float64 for a scaled logit; 0 for anything below the cut (and for -inf)
+__device__ __forceinline__ double rs_e64(float xs, double M, const double *tab) {
+    const double d = (double)xs - M;
+    return d >= RS_EXP_CUT ? rs_exp64(d, tab) : 0.0;
+}
+
 // Stage 2 — one thread per row: merge the chunk partials, then the gathered probability of the drafted id.
+// p_draft is what the steps' accept tests start from: the float64 exp of the gathered logit over the float32 row sum S, whose
+// relative error against the exact sum is below rs_eps_row(M).
+//   JF_BF16  the LOWER of the two candidate roundings bf16(p (1 - eps)) <= bf16(p (1 + eps)); when they differ (the float32
+//            sum cannot decide the rounding: ~1 % of the rows) the SIGN BIT is set — the upper candidate is the next bf16.
+//   JF_F32   the centre value fl32(p); the steps test against [p (1 - eps), p (1 + eps)].
+// Rows without finite statistics (NaN / +inf logits) keep the plain float32 formula (NaN where torch's softmax is NaN).
 template <int DT>
 __global__ __launch_bounds__(256) void rs_probs_finish_kernel(const void *logits, int64_t R, int64_t V, int64_t row_stride,
                                                                const int64_t *draft_next, float t, float inv_t, const float2 *partial,
                                                                int cpr, float *p_draft, float *row_max, float *row_sumexp) {
+    __shared__ double s_tab[64];
+    rs_load_tab(s_tab);
+    __syncthreads();
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= R) return;
     const bool unit_t = (t == 1.f);
@@ -296,12 +368,26 @@ __global__ __launch_bounds__(256) void rs_probs_finish_kernel(const void *logits
         const float2 ps = partial[row * cpr + c];
         S += (ps.x == -INFINITY) ? 0.f : ps.y * exp2f(mdom(ps.x) - mM);
     }
-    const float M = rs_scaled<DT>(Mraw, t, inv_t, unit_t);    // consumers form expf(xs - M): exactly 1 at the maximum
+    const float M = rs_scaled<DT>(Mraw, t, inv_t, unit_t);    // consumers form exp(xs - M): exactly 1 at the maximum
     row_max[row] = M;
     row_sumexp[row] = S;
     const int64_t tok = draft_next[row];
     const void *p = (const char *)logits + row * row_stride * (DT == JF_F32 ? 4 : 2);
-    p_draft[row] = (tok >= 0 && tok < V) ? rs_prob<DT>(rs_scaled<DT>(load_f<DT>(p, tok), t, inv_t, unit_t), M, S) : 0.f;
+    float pd = 0.f;
+    if (tok >= 0 && tok < V) {
+        const float xs = rs_scaled<DT>(load_f<DT>(p, tok), t, inv_t, unit_t);
+        if (!rs_row_is_exact(M, S)) pd = rs_prob<DT>(xs, M, S);
+        else {
+            const double ph = rs_e64(xs, (double)M, s_tab) / (double)S;
+            if constexpr (DT == JF_F32) pd = (float)ph;
+            else {
+                const double eps = rs_eps_row(M);
+                const float lo = rs_bf16_of_f64(ph * (1.0 - eps)), hi = rs_bf16_of_f64(ph * (1.0 + eps));
+                pd = lo != hi ? -lo : lo;                         // (lo > 0 whenever the candidates differ)
+            }
+        }
+    }
+    p_draft[row] = pd;
 }
 
 struct RsTune { int64_t items; };
@@ -411,68 +497,6 @@ extern "C" int jf_rs_probs(const void *logits, int dtype, int64_t R, int64_t V, 
 // float64 evaluation errs by ~5e-16; the oracle re-decides elements that close to a rounding boundary in 60-digit decimal
 // arithmetic, the kernels do not (1 element in ~10^13).
 // ------------------------------------------------------------------------------------------------
-__device__ const double RS_EXP2_TAB[64] = {   // 2^(j/64), correctly rounded
-    1.0, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284, 1.0442737824274138, 1.0556451783605572, 1.0671404006768237,
-    1.0787607977571199, 1.0905077326652577, 1.102382583307841, 1.1143867425958924, 1.1265216186082418, 1.1387886347566916,
-    1.1511892299529827, 1.1637248587775775, 1.1763969916502812, 1.189207115002721, 1.202156731452703, 1.215247359980469,
-    1.22848053610687, 1.241857812073484, 1.255380757024691, 1.2690509571917332, 1.2828700160787783, 1.2968395546510096,
-    1.3109612115247644, 1.3252366431597413, 1.339667524053303, 1.3542555469368927, 1.3690024229745905, 1.383909881963832,
-    1.3989796725383112, 1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647, 1.4768261459394993,
-    1.4929077282912648, 1.5091644275934228, 1.5255981507445384, 1.5422108254079407, 1.559004400237837, 1.5759808451078865,
-    1.593142151342267, 1.6104903319492543, 1.6280274218573478, 1.645755478153965, 1.6636765803267364, 1.681792830507429,
-    1.7001063537185235, 1.718619298122478, 1.7373338352737062, 1.7562521603732995, 1.7753764925265212, 1.7947090750031072,
-    1.8142521755003989, 1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656, 1.9152065613971474,
-    1.9360617934922943, 1.9571441241754002, 1.978456026387951};
-constexpr double RS_EXP_CUT = -104.0;             // exp(d) < 2^-150: the quotient (S >= 1) rounds to 0 in bf16 and in float32
-__device__ __forceinline__ void rs_load_tab(double *tab) {   // 64-entry table into LDS (callers follow with a barrier)
-    if (threadIdx.x < 64) tab[threadIdx.x] = RS_EXP2_TAB[threadIdx.x];
-}
-// exp(d) for RS_EXP_CUT <= d <= 0, relative error <= 2.3e-16 (checked against 50-digit decimals over 20 000 arguments):
-// d = k ln2/64 + r, |r| <= ln2/128, exp(r) by a degree-5 polynomial, 2^(k/64) = 2^(k >> 6) * tab[k & 63].  14 float64 ops.
-__device__ __forceinline__ double rs_exp64(double d, const double *tab) {
-    const double kf = __builtin_rint(d * 92.33248261689366);                               // 64 / ln 2
-    const double r = __builtin_fma(-kf, 2.9815858269852933e-12, __builtin_fma(-kf, 0.01083042469326756, d));   // ln2/64 = hi (33 bits) + lo
-    double p = 8.333333333333333e-3;
-    p = __builtin_fma(p, r, 4.1666666666666664e-2);
-    p = __builtin_fma(p, r, 1.6666666666666666e-1);
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
-    p = p * r;                                                                              // exp(r) - 1
-    const int k = (int)kf;
-    const double tj = tab[k & 63];
-    return __builtin_ldexp(__builtin_fma(tj, p, tj), k >> 6);
-}
-// nearest-even bf16 of a non-negative float64 (subnormals included), as a float: float32 by round-to-odd, then RNE
-__device__ __forceinline__ float rs_bf16_of_f64(double q) {
-    const float f = (float)q;
-    const double back = (double)f;
-    uint32_t u = __float_as_uint(f);
-    if (back > q) u -= 1u;                          // toward zero
-    if (back != q) u |= 1u;                         // sticky
-    u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
-    return __uint_as_float(u);
-}
-template <int DT>
-__device__ __forceinline__ float rs_round_prob(double q) {
-    if constexpr (DT == JF_BF16) return rs_bf16_of_f64(q);
-    else return (float)q;
-}
-// a row statistic pair the exact path can work with (else: NaN / inf rows keep the plain float32 formula, like torch)
-__device__ __forceinline__ bool rs_row_is_exact(float M, float S) {
-    return (__float_as_uint(M) & 0x7F800000u) != 0x7F800000u && S > 0.f && (__float_as_uint(S) & 0x7F800000u) != 0x7F800000u;
-}
-// relative error bound of the streaming kernel's float32 row sum against the exact sum relative to M: float32 accumulation
-// and v_exp_f32 (2^-15, three times what the sweeps show), plus the scaled maximum's rounding residual and the float32
-// x * (1/T) of its exponent arguments, both proportional to |M| (DESIGN.md §7)
-__device__ __forceinline__ double rs_eps_row(float M) {
-    return 3.0517578125e-5 + 2.384185791015625e-7 * (1.45 * (double)fabsf(M) + 32.0);
-}
-// exp(xs - M) in float64 for a scaled logit; 0 for anything below the cut (and for -inf)
-__device__ __forceinline__ double rs_e64(float xs, double M, const double *tab) {
-    const double d = (double)xs - M;
-    return d >= RS_EXP_CUT ? rs_exp64(d, tab) : 0.0;
-}
-
 constexpr int RS_SEG = 16;
 constexpr int RS_TILES = 8;                       // tiles of a segment whose vectors are kept in registers by the whole-workgroup walk
 constexpr int RS_MAX_TRIES = 16;                  // JDN:135 max_tries
@@ -554,7 +578,13 @@ extern "C" __attribute__((visibility("default"))) int jf_exp_rs_trace(unsigned l
 extern "C" __attribute__((visibility("default"))) int jf_exp_rs_rows(unsigned long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rsrow), sizeof(unsigned long long) * 8 * 128);
 }
+__device__ unsigned long long g_rsphase[16];      // phases of ONE segment workgroup (row 0, segment 0)
+#define RS_PHASE(item, seg, k) do { if ((item) == 0 && (seg) == 0 && threadIdx.x == 0) g_rsphase[k] = (unsigned long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" __attribute__((visibility("default"))) int jf_exp_rs_phases(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rsphase), sizeof(unsigned long long) * 16);
+}
 #else
+#define RS_PHASE(item, seg, k) do { } while (0)
 #define RS_STAMP_MIN(k) do { } while (0)
 #define RS_STAMP_MAX(k) do { } while (0)
 #define RS_ROWSTAMP(k, b) do { } while (0)
@@ -565,13 +595,44 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+// Inclusive scan over the 64 lanes with DPP moves (the data-parallel-primitive lanes of the VALU: ~8 cycles a step; the
+// ds_bpermute shuffles of rounds 1-3 cost ~60 cycles each, and a segment workgroup scans every tile): Hillis-Steele inside the
+// rows of 16 lanes (row_shr 1, 2, 4, 8), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3.  Lanes without
+// a source add 0.  The order of the additions is fixed, and every running sum of the CDF is formed by this one function
+// (rs_seg_prob_sums, rs_pick_wave, rs_pick_wg), so the sums agree wherever they are re-formed.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double rs_dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_incl_scan_f64(double v, int lane) {
+#ifdef JF_RS_SHFL_SCAN
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const double o = __shfl_up(v, off, 64);
         if (lane >= off) v += o;
     }
+#else
+    (void)lane;
+    v += rs_dpp_f64<0x111, 0xf>(v);      // row_shr:1
+    v += rs_dpp_f64<0x112, 0xf>(v);      // row_shr:2
+    v += rs_dpp_f64<0x114, 0xf>(v);      // row_shr:4
+    v += rs_dpp_f64<0x118, 0xf>(v);      // row_shr:8
+    v += rs_dpp_f64<0x142, 0xa>(v);      // row_bcast:15 -> rows 1, 3
+    v += rs_dpp_f64<0x143, 0xc>(v);      // row_bcast:31 -> rows 2, 3
+#endif
     return v;
+}
+// the value of the lane below (0 for lane 0): the exclusive prefix from an inclusive scan
+__device__ __forceinline__ double wave_shift_up_f64(double v, int lane) {
+#ifdef JF_RS_SHFL_SCAN
+    const double up = __shfl_up(v, 1, 64);
+    return lane == 0 ? 0.0 : up;
+#else
+    (void)lane;
+    return rs_dpp_f64<0x138, 0xf>(v);    // wave_shr:1
+#endif
 }
 
 template <int DT>
@@ -796,10 +857,10 @@ __device__ __forceinline__ void rs_seg_prob_sums(const RsRow &row, int64_t lo, i
 #pragma unroll
             for (int j = 0; j < EPV; ++j) a += (double)p[j];
             const double incl = wave_incl_scan_f64(a, lane);  // all lanes: the wavefront's total is the scan's last value
-            const double up = __shfl_up(incl, 1, 64);         // all lanes active: never shuffle under the lane test
+            const double up = wave_shift_up_f64(incl, lane);  // all lanes active: never shift under the lane test
             const double wt = __shfl(incl, 63, 64);
             if (mine && k0 + k == kstar && tid == tstar) {    // the avoided token's lane: exclusive prefix inside its wavefront, its vector
-                sh.excl = lane == 0 ? 0.0 : up;
+                sh.excl = up;
 #pragma unroll
                 for (int j = 0; j < EPV; ++j) sh.pv[j] = (double)p[j];
             }
@@ -814,6 +875,7 @@ __device__ __forceinline__ void rs_seg_prob_sums(const RsRow &row, int64_t lo, i
             }
         }
     }
+    RS_PHASE(item, seg, 4);                                   // 4: phase B probabilities + scans done
     __syncthreads();
     if (tid == 0) {
         double sum = base;
@@ -843,11 +905,13 @@ __device__ __forceinline__ void rs_seg_prob_sums(const RsRow &row, int64_t lo, i
         double *dst = w.wtsum + ((int64_t)item * RS_SEG + seg) * RS_WT;
         if constexpr (SIG) st_agent_f64(dst + tid, sh.wt[tid]); else dst[tid] = sh.wt[tid];
     }
+    RS_PHASE(item, seg, 5);                                   // 5: sums formed, stores issued
     if constexpr (SIG) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the sums are performed before the word that announces them
         __syncthreads();
         if (tid == 0) __hip_atomic_store(w.segdone + (int64_t)item * RS_SEG + seg, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    RS_PHASE(item, seg, 6);                                   // 6: announced
 }
 
 // Both phases of one (row, segment) inside ONE launch (rs_step_fused_kernel): the 16 workgroups of a row exchange their
@@ -868,15 +932,18 @@ __device__ __forceinline__ bool rs_rowsum_fused(const void *logits, int64_t V, i
     rs_load_tab(sh.tab);
     if (tid == 0) sh.ok = 1;
     __syncthreads();
+    RS_PHASE(item, seg, 0);                                   // 0: table in LDS
     float e32[NV][EPV];
     u32x4 v[NV];
     double S = 0.0;
     const bool keep = ntiles <= NV;                           // workgroup-uniform (true for every vocabulary up to 163 840)
     if (exact) {
         double acc = keep ? rs_seg_exp_sum<DT, true>(row, lo, hi, sh.tab, e32, v) : rs_seg_exp_sum<DT, false>(row, lo, hi, sh.tab, e32, v);
+        RS_PHASE(item, seg, 1);                               // 1: phase A loads + exps done
         acc = wave_sum_f64(acc);
         if ((tid & 63) == 0) sh.red[tid >> 6] = acc;
         __syncthreads();
+        RS_PHASE(item, seg, 2);                               // 2: reduced
         if (tid == 0) {
             st_agent_f64(w.s64part + (int64_t)item * RS_SEG + seg, (sh.red[0] + sh.red[1]) + (sh.red[2] + sh.red[3]));
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -887,6 +954,7 @@ __device__ __forceinline__ bool rs_rowsum_fused(const void *logits, int64_t V, i
             sh.part[tid] = ld_agent_f64(w.s64part + (int64_t)item * RS_SEG + tid);
         }
         __syncthreads();
+        RS_PHASE(item, seg, 3);                               // 3: all 16 partials in
         if (!sh.ok) return false;
 #pragma unroll
         for (int s = 0; s < RS_SEG; ++s) S += sh.part[s];    // segment order: every workgroup of the row forms the same S
@@ -987,7 +1055,7 @@ __device__ __forceinline__ int rs_count_draws(UFn u_at, double total, double c_l
     const unsigned free_mask = (unsigned)(~__ballot(coll)) & ((1u << RS_MAX_TRIES) - 1u);
     if (free_mask == 0u) { *u_final = -1.f; return RS_MAX_TRIES; }
     const int f = __builtin_ctz(free_mask);
-    *u_final = __shfl(u, f, 64);
+    *u_final = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(u), f));   // f is wave-uniform: v_readlane, not a shuffle
     return f + 1;
 }
 
@@ -1048,8 +1116,7 @@ __device__ __forceinline__ int rs_pick_wave(const RsRow &row, const RsWs &w, int
 #pragma unroll
     for (int j = 0; j < EPV; ++j) a += (double)p[j];
     const double incl = wave_incl_scan_f64(a, lane);
-    const double up = __shfl_up(incl, 1, 64);
-    const double ex = rel + (lane == 0 ? 0.0 : up);          // relative running sum in front of this lane's vector
+    const double ex = rel + wave_shift_up_f64(incl, lane);   // relative running sum in front of this lane's vector
     const unsigned long long crossing = __ballot(before + (rel + incl) > thr);
     int src = crossing ? __builtin_ctzll(crossing) : -1;
     if (src < 0) {                                           // rounding only: last lane with mass
@@ -1123,14 +1190,14 @@ __device__ int rs_pick_wg(const RsRow &row, const double *segsum, double S, floa
 #pragma unroll
         for (int j = 0; j < EPV; ++j) a += (double)p[j];
         const double in = wave_incl_scan_f64(a, lane);
-        const double up = __shfl_up(in, 1, 64);
+        const double up = wave_shift_up_f64(in, lane);
         __syncthreads();
         if (lane == 63) sh.wtx[wave] = in;
         __syncthreads();
         double wb = base;
         for (int q = 0; q < wave; ++q) wb += sh.wtx[q];
         if (!found && before + (wb + in) > thr) {
-            double rr = wb + (lane == 0 ? 0.0 : up);
+            double rr = wb + up;
             int hit = -1, lastpos = -1;
 #pragma unroll
             for (int j = 0; j < EPV; ++j) {
@@ -1235,6 +1302,7 @@ __device__ __forceinline__ void batched_for(int64_t n, int tid, int nthreads, Lo
 constexpr int RS_STAGE = 6144;      // accept tests / uniforms staged in LDS by the accept scan (B * (L-1) <= this, else global)
 constexpr int RS_ROWS_LDS = 2048;   // rows whose scan results are kept in LDS (half of it in the chain kernel)
 constexpr uint32_t RS_PE_EOS = 0x80000000u, RS_PE_AMB = 0x40000000u, RS_PE_VAL = 0x3FFFFFFFu;
+constexpr int RS_RES_NONE = -1, RS_RES_ABORT = -2;   // s_res words of rows the walk has not decided / stopped at
 
 struct RsAcceptIn {                 // what an accept test's probability is made of
     const void *logits; int64_t V, row_stride; float t; const float *row_max, *row_sumexp, *p_draft;
@@ -1242,46 +1310,44 @@ struct RsAcceptIn {                 // what an accept test's probability is made
 // One accept test as an LDS word: the LOWER candidate probability (a float <= 1: bits 31 / 30 are free), RS_PE_AMB when the
 // float32 row sum cannot decide the rounding (bf16: the upper candidate is the next bf16; float32: lo * (1 + 2^-12) bounds
 // it), RS_PE_EOS when the proposed token is the EOS id.  Rows without finite statistics keep jf_rs_probs' plain float32 value.
-// the word of one test from its loaded ingredients (M, S: the row's statistics; x: the raw logit of the proposed token;
-// pd: jf_rs_probs' float32 value, used only for rows without finite statistics)
+// the word of one test from jf_rs_probs' p_draft (see rs_probs_finish_kernel) and, float32 logits, the row maximum
 template <int DT>
-__device__ __forceinline__ uint32_t rs_accept_word(float M, float S, float x, float pd, bool tok_ok, bool is_eos, float t, const double *tab) {
+__device__ __forceinline__ uint32_t rs_accept_word(float pd, float M, bool is_eos) {
     const uint32_t eos = is_eos ? RS_PE_EOS : 0u;
-    if (!rs_row_is_exact(M, S))                              // NaN / inf rows: the plain float32 value (a NaN never accepts)
-        return ((pd > 0.f) ? (__float_as_uint(pd > 1.f ? 1.f : pd) & RS_PE_VAL) : 0u) | eos;
-    if (!tok_ok) return eos;
-    const float xs = rs_scaled<DT>(x, t, 1.f / t, t == 1.f);
-    const double e = rs_e64(xs, (double)M, tab);
-    if (e == 0.0) return eos;                                 // exactly 0 under every candidate sum
-    const double ph = e * (1.0 / (double)S), eps = rs_eps_row(M) + 2.3e-16;
-    const float lo = rs_round_prob<DT>(ph * (1.0 - eps)), hi = rs_round_prob<DT>(ph * (1.0 + eps));
-    uint32_t bits = __float_as_uint(lo > 1.f ? 1.f : lo) & RS_PE_VAL;
-    if (DT == JF_F32 || lo != hi) bits |= RS_PE_AMB;
-    return bits | eos;
+    if constexpr (DT == JF_BF16) {
+        const float a = fabsf(pd);
+        if (a != a) return eos;                              // NaN never accepts
+        return (__float_as_uint(a > 1.f ? 1.f : a) & RS_PE_VAL) | ((__float_as_uint(pd) >> 31) ? RS_PE_AMB : 0u) | eos;
+    } else {
+        if (!(pd > 0.f)) return eos;
+        if ((__float_as_uint(M) & 0x7F800000u) == 0x7F800000u) return (__float_as_uint(pd > 1.f ? 1.f : pd) & RS_PE_VAL) | eos;   // plain formula row
+        const float eps = (float)rs_eps_row(M);
+        if (eps > 1.0e-4f) return RS_PE_AMB | eos;            // (|max / T| > 170) beyond the fixed band of rs_accept_hi: every rejection is resolved exactly
+        const float lo = pd * (1.f - eps - 1.2e-7f);
+        return (__float_as_uint(lo > 1.f ? 1.f : lo) & RS_PE_VAL) | RS_PE_AMB | eos;
+    }
 }
 template <int DT>
 __device__ __forceinline__ uint32_t rs_accept_entry(const RsAcceptIn &in, int64_t i, int64_t tok, int eos_id, const double *tab) {
-    const bool ok = tok >= 0 && tok < in.V;
-    const float x = ok ? load_f<DT>((const char *)in.logits + i * in.row_stride * (DT == JF_F32 ? 4 : 2), tok) : 0.f;
-    return rs_accept_word<DT>(in.row_max[i], in.row_sumexp[i], x, in.p_draft[i], ok, eos_id >= 0 && tok == (int64_t)eos_id, in.t, tab);
+    (void)tab;
+    return rs_accept_word<DT>(in.p_draft[i], in.row_max[i], eos_id >= 0 && tok == (int64_t)eos_id);
 }
 template <int DT>
 __device__ __forceinline__ float rs_accept_hi(uint32_t pe) {   // upper candidate of an ambiguous entry
     const uint32_t b = pe & RS_PE_VAL;
     if constexpr (DT == JF_BF16) return __uint_as_float(b + 0x00010000u);
-    else return fmaxf(__uint_as_float(b) * 1.000244140625f, 1e-44f);
+    else return b ? __uint_as_float(b) * 1.000244140625f : INFINITY;   // (1 + 2^-12) lo >= p (1 + eps) while eps <= 1e-4; 0: no band known
 }
 
 // STAGED: the batch fits the LDS tables (B * (L-1) <= RS_STAGE, B <= RS_ROWS_LDS) — the serial part touches LDS only.
 // SIG (one-launch step): the walker announces every row the moment it is decided — flag[b] = (gen << 32) | eos << 30 |
 // n_accepted << 16 | (reject_pos + 2), one self-contained 8-byte agent-scope store — and the workgroup ends with a release +
 // the accept-done word; the row records' n_committed / eos / n_pads / active_next then belong to the row's bonus workgroup.
-template <int DT, bool STAGED, bool SIG, int STAGE_N = RS_STAGE, int ROWS_N = RS_ROWS_LDS>
+template <int DT, bool STAGED, bool SIG, int ROWS_N = RS_ROWS_LDS>
 __device__ __forceinline__ void rs_accept_body(const RsAcceptIn &in, const int64_t *draft, int B, int L, int eos_id,
                                                const float *u_stream, int64_t u_len, const int64_t *u_cursor,
-                                               int64_t *committed, jf_rs_row *rows, const RsWs &w, uint32_t gen) {
-    __shared__ uint32_t s_p[STAGED ? STAGE_N : 1];
-    __shared__ float s_u[STAGED ? STAGE_N : 1];
+                                               int64_t *committed, jf_rs_row *rows, const RsWs &w, uint32_t gen,
+                                               uint32_t *s_p, float *s_u /* LDS, B * (L-1) entries each when STAGED */) {
     __shared__ int s_res[STAGED ? ROWS_N : 1];                                 // nacc | eos << 15 | (rej + 1) << 16 per row
     __shared__ double s_tab[64], s_red[4];
     __shared__ int s_unc, s_resume, s_used;
@@ -1297,42 +1363,42 @@ __device__ __forceinline__ void rs_accept_body(const RsAcceptIn &in, const int64
     __syncthreads();
     if constexpr (STAGED) {
         const int ul = (int)u_len, ub = (int)(uc0 % u_len);
-        // loads first (eight per lane in flight), arithmetic afterwards; at most n uniforms can be used
-        batched_for<8, float>(n, tid, 256, [&](int64_t i) { return u_stream[(ub + (int)i) % ul]; }, [&](int64_t i, float v) { s_u[i] = v; });
-        // every test's word: (token, M, S, p_draft) in one round of loads, the gathered logits in a second, then the arithmetic
+        // every test's word and uniform in ONE round of loads (at most n uniforms can be used)
         for (int i0 = tid; i0 < n; i0 += 8 * 256) {
             int64_t tk[8];
-            float M[8], S[8], pd[8], x[8];
+            float M[8], pd[8], uu[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int i = i0 + k * 256;
-                if (i < n) { tk[k] = tok_at(i); M[k] = in.row_max[i]; S[k] = in.row_sumexp[i]; pd[k] = in.p_draft[i]; }
+                tk[k] = -1; M[k] = 0.f;
+                if (i < n) {
+                    uu[k] = u_stream[(ub + i) % ul]; pd[k] = in.p_draft[i];
+                    if (eos_id >= 0) tk[k] = tok_at(i);
+                    if constexpr (DT == JF_F32) M[k] = in.row_max[i];
+                }
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int i = i0 + k * 256;
-                x[k] = 0.f;
-                if (i < n && tk[k] >= 0 && tk[k] < in.V) x[k] = load_f<DT>((const char *)in.logits + (int64_t)i * in.row_stride * (DT == JF_F32 ? 4 : 2), tk[k]);
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int i = i0 + k * 256;
-                if (i < n) s_p[i] = rs_accept_word<DT>(M[k], S[k], x[k], pd[k], tk[k] >= 0 && tk[k] < in.V, eos_id >= 0 && tk[k] == (int64_t)eos_id, in.t, s_tab);
+                if (i < n) { s_u[i] = uu[k]; s_p[i] = rs_accept_word<DT>(pd[k], M[k], eos_id >= 0 && tk[k] == (int64_t)eos_id); }
             }
         }
     }
     __syncthreads();
     int b_start = 0, used_start = 0;
     for (;;) {                                                      // the walk; re-entered after an undecided test was resolved
+        if constexpr (STAGED && SIG) {                              // (the announcing wavefront polls these words)
+            for (int b = b_start + tid; b < B; b += 256) s_res[b] = RS_RES_NONE;
+            __syncthreads();
+        }
         if (tid < 64 && STAGED && W <= 64) {
             // one ballot per row; the row's words were loaded while the row before it was decided, so the only dependent
-            // access of a step is the uniform at this row's stream offset (~0.1 us per row)
+            // access of a step is the uniform at this row's stream offset.  SIG: the row's result goes to LDS only — wavefront 1
+            // announces it (below): composing and storing the flag word is off this wavefront's instruction stream (~0.1 us per row)
             const int lane = tid;
             const bool inrow = lane < W;
             int used_total = used_start, unc_at = -1, b = b_start;
             uint32_t pe = (inrow && b < B) ? s_p[b * W + lane] : 0u;
-            unsigned long long fa = (unsigned long long)(w.flag + (int64_t)b * RS_FLAG_STRIDE);
-            asm volatile("" : "+v"(fa));                            // the flag line's address lives in vector registers: no scalar reloads per row
             for (; b < B; ++b) {                                    // JDN:326-348, rows in order
                 const float uu = inrow ? s_u[used_total + lane] : 0.f;
                 const uint32_t pe_next = (inrow && b + 1 < B) ? s_p[(b + 1) * W + lane] : 0u;
@@ -1349,20 +1415,34 @@ __device__ __forceinline__ void rs_accept_body(const RsAcceptIn &in, const int64
                     } else { eos = 1; nacc = f + 1; }
                     used = f + 1;
                 }
-                if (lane == 0) {
-                    s_res[b] = nacc | (eos << 15) | ((rej + 1) << 16);
-                    if constexpr (SIG) {
-                        __hip_atomic_store((unsigned long long *)fa, ((unsigned long long)gen << 32) | ((unsigned long long)eos << 30) |
-                                           ((unsigned long long)nacc << 16) | (unsigned long long)(rej + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        RS_ROWSTAMP(0, b);
-                    }
-                }
-                fa += RS_FLAG_STRIDE * sizeof(unsigned long long);
+                if (lane == 0) __hip_atomic_store(&s_res[b], nacc | (eos << 15) | ((rej + 1) << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 used_total += used;
                 pe = pe_next;
             }
-            if (lane == 0) { s_unc = unc_at; s_resume = b; s_used = used_total; }
+            if (lane == 0) {
+                if (SIG && unc_at >= 0) __hip_atomic_store(&s_res[b], RS_RES_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                s_unc = unc_at; s_resume = b; s_used = used_total;
+            }
             if constexpr (SIG) { if (unc_at < 0) RS_STAMP_MAX(15); }   // 15: the accept walk has decided the last row
+        } else if (SIG && STAGED && W <= 64 && tid >= 64 && tid < 128) {
+            // wavefront 1: announces the rows as wavefront 0 decides them — a lane per row of the leading run of decided rows
+            const int lane = tid - 64;
+            int base = b_start;
+            while (base < B) {
+                const int r = base + lane;
+                const int v = r < B ? __hip_atomic_load(&s_res[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : RS_RES_NONE;
+                const unsigned long long nr = ~__ballot(v >= 0);
+                const int run = nr ? __builtin_ctzll(nr) : 64;
+                if (lane < run) {
+                    const int nacc = v & 0x7FFF, eos = (v >> 15) & 1, rej = (v >> 16) - 1;
+                    __hip_atomic_store(w.flag + (int64_t)r * RS_FLAG_STRIDE, ((unsigned long long)gen << 32) | ((unsigned long long)eos << 30) |
+                                       ((unsigned long long)nacc << 16) | (unsigned long long)(rej + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    RS_ROWSTAMP(0, r);
+                }
+                base += run;
+                if (run < 64 && __shfl(v, run, 64) == RS_RES_ABORT) break;      // wavefront 0 stopped at an undecided test
+                if (run == 0) __builtin_amdgcn_s_sleep(1);
+            }
         } else if (tid < 64) {
             const int lane = tid;
             int used_total = used_start, unc_at = -1, b = b_start;
@@ -1475,7 +1555,9 @@ template <int DT, bool STAGED>
 __global__ __launch_bounds__(256) void rs_accept_kernel(RsAcceptIn in, const int64_t *draft, int B, int L, int eos_id,
                                                          const float *u_stream, int64_t u_len, const int64_t *u_cursor,
                                                          int64_t *committed, jf_rs_row *rows, RsWs w) {
-    rs_accept_body<DT, STAGED, false>(in, draft, B, L, eos_id, u_stream, u_len, u_cursor, committed, rows, w, 0u);
+    __shared__ uint32_t s_p[STAGED ? RS_STAGE : 1];
+    __shared__ float s_u[STAGED ? RS_STAGE : 1];
+    rs_accept_body<DT, STAGED, false>(in, draft, B, L, eos_id, u_stream, u_len, u_cursor, committed, rows, w, 0u, s_p, s_u);
 }
 
 // bonus-stream bookkeeping in row order (one workgroup): intervals in parallel, then one wavefront walks the rejected rows
@@ -1731,11 +1813,14 @@ __global__ __launch_bounds__(256) void rs_step_fused_kernel(RsFusedArgs a) {
     const int blk = blockIdx.x, tid = threadIdx.x;
     const int B = a.B, L = a.L, W = a.L - 1;
     const RsWs &w = a.w;
+    // the roles' large LDS tables share one buffer (a workgroup has one role): accept words + uniforms (32 KB), the chain's
+    // staged uniforms (8 KB), the end's pad window (8 KB) — a sum of them would cost the short roles their residency
+    __shared__ __attribute__((aligned(16))) unsigned char s_big[2 * RS_FUSED_STAGE * 4];
     if (blk == 0) {
         RS_STAMP_MIN(0);                                             // 0: launch start (accept workgroup)
         const RsAcceptIn in{a.logits, a.V, a.row_stride, a.t, a.row_max, a.row_sumexp, a.p_draft};
-        rs_accept_body<DT, true, true, RS_FUSED_STAGE, RS_FUSED_ROWS>(in, a.draft, B, L, a.eos_id, a.u_stream, a.u_len, a.u_cursor,
-                                                                      a.committed, a.rows, w, a.gen);
+        rs_accept_body<DT, true, true, RS_FUSED_ROWS>(in, a.draft, B, L, a.eos_id, a.u_stream, a.u_len, a.u_cursor,
+                                                      a.committed, a.rows, w, a.gen, (uint32_t *)s_big, (float *)(s_big + RS_FUSED_STAGE * 4));
         RS_STAMP_MAX(1);                                             // 1: accept workgroup done (records + accept-done word)
         return;
     }
@@ -1766,7 +1851,8 @@ __global__ __launch_bounds__(256) void rs_step_fused_kernel(RsFusedArgs a) {
         // counted — the walk of row i starts a few us after row i was decided, not after the last row's sums.
         __shared__ double s_tot[RS_FUSED_ROWS], s_lo[RS_FUSED_ROWS], s_hi[RS_FUSED_ROWS];   // s_tot < 0: not rejected
         __shared__ int s_ready[RS_FUSED_ROWS];
-        __shared__ float s_u[RS_MAX_TRIES * RS_FUSED_ROWS];
+        float *s_u = (float *)s_big;                                 // [RS_MAX_TRIES * RS_FUSED_ROWS]
+        static_assert(RS_MAX_TRIES * RS_FUSED_ROWS * 4 <= 2 * RS_FUSED_STAGE * 4, "chain window");
         const int64_t bc0 = *a.b_cursor;
         const bool staged = a.b_len < 0x7FFFFFFFll;
         for (int i = tid; i < B; i += 256) s_ready[i] = 0;
@@ -1828,13 +1914,16 @@ __global__ __launch_bounds__(256) void rs_step_fused_kernel(RsFusedArgs a) {
             if (run == 0) { __builtin_amdgcn_s_sleep(1); continue; }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // their intervals were stored before their ready words
             const double my_tot = tid < run ? s_tot[r] : -1.0, my_lo = tid < run ? s_lo[r] : 0.0, my_hi = tid < run ? s_hi[r] : 0.0;
+            auto lane_f64 = [](double v, int k) {               // k is wave-uniform: two v_readlane (a shuffle goes through the LDS crossbar)
+                return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), k), __builtin_amdgcn_readlane(__double2loint(v), k));
+            };
             for (int k = 0; k < run; ++k, ++i) {
-                const double t_ = __shfl(my_tot, k, 64);
+                const double t_ = lane_f64(my_tot, k);
                 if (t_ < 0.0) continue;
                 float uf;
                 const int o = off;
                 const int draws = rs_count_draws([&](int tr) { return staged ? s_u[o + tr] : a.b_stream[(bc0 + o + tr) % a.b_len]; }, t_,
-                                                 __shfl(my_lo, k, 64), __shfl(my_hi, k, 64), tid, &uf);
+                                                 lane_f64(my_lo, k), lane_f64(my_hi, k), tid, &uf);
                 if (tid == 0) {                                      // the count for the end workgroup (ordered by chain-done below),
                     __hip_atomic_store(&a.rows[i].n_bonus_draws, draws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(w.pick + i, ((unsigned long long)a.gen << 32) | (unsigned long long)__float_as_uint(uf), __ATOMIC_RELAXED,
@@ -1915,8 +2004,12 @@ __global__ __launch_bounds__(256) void rs_step_fused_kernel(RsFusedArgs a) {
     }
     // ---- block 2: what depends on more than one row — pad offsets, the pads, the stream cursors
     __shared__ int s_np[RS_FUSED_ROWS], s_off[RS_FUSED_ROWS];
+    int32_t *s_pad = (int32_t *)s_big;                                // [2048]
     __shared__ int s_bad, s_pads;
     const int64_t pc0 = *a.pad_cursor;                               // (nobody else writes it: loaded while the rows are still at work)
+    // the pad stream's window this call can touch (at most L - 2 per row), staged while the rows are still at work
+    const int padwin = B * (L - 2) < 2048 ? B * (L - 2) : 2048;
+    batched_for<8, int64_t>(padwin, tid, 256, [&](int64_t i) { return a.pad_stream[(pc0 + i) % a.pad_len]; }, [&](int64_t i, int64_t v) { s_pad[i] = (int32_t)v; });
     if (tid == 0) s_bad = 0;
     __syncthreads();
     if (tid == 0) { if (!rs_wait_word(w.acceptdone, a.gen) || !rs_wait_word(w.acceptdone + 1, a.gen)) s_bad = 1; }   // n_uniforms, the draw counts
@@ -1950,7 +2043,10 @@ __global__ __launch_bounds__(256) void rs_step_fused_kernel(RsFusedArgs a) {
     for (int idx = tid; idx < B * 32; idx += 256) {                  // the pads of every row that keeps decoding: 32 lanes per row
         const int b = idx >> 5;
         const int np = s_np[b];
-        for (int j = idx & 31; j < np; j += 32) a.next_draft[(int64_t)b * L + (L - np) + j] = a.pad_stream[(pc0 + s_off[b] + j) % a.pad_len];
+        for (int j = idx & 31; j < np; j += 32) {
+            const int o = s_off[b] + j;
+            a.next_draft[(int64_t)b * L + (L - np) + j] = o < padwin ? (int64_t)s_pad[o] : a.pad_stream[(pc0 + o) % a.pad_len];
+        }
     }
     __syncthreads();
     if (tid == 0) *a.pad_cursor = pc0 + s_pads;

@@ -393,7 +393,9 @@ def _run_rs_probs(x, dn, temperature):
     N.check(N.lib().jf_rs_probs(ops._ptr(xd), ops._dtype_code(xd), R, V, xd.stride(0), ops._ptr(dn.cuda()), temperature, ops._ptr(p),
                                 ops._ptr(m), ops._ptr(s), ops._ptr(packed), ops._ptr(ws), ws.numel() * 4, ops._stream(xd.device)))
     del st
-    return p.cpu(), m.cpu(), s.cpu(), (~packed.cpu()) & 0xFFFFFFFF
+    # bf16 logits: the sign bit of p_draft marks "the float32 row sum cannot decide the rounding" (the value is then the lower
+    # candidate): the probability itself is the magnitude
+    return p.cpu().abs(), m.cpu(), s.cpu(), (~packed.cpu()) & 0xFFFFFFFF
 
 
 @GPU

@@ -71,6 +71,12 @@ def main():
         print("# last launch, per row: flag stored by the accept walk / segment 0 saw it / segment 0 stored / sums ready in the chain / uniform handed out / bonus workgroup has it / bonus token stored (us)")
         for b_ in list(range(0, B, 8)) + [B - 1]:
             print(f"#   row {b_:3d}: " + "  ".join(f"{(r[k, b_] - t0) / 100.0:7.1f}" for k in (0, 1, 4, 2, 3, 5, 6)))
+        if hasattr(lib, "jf_exp_rs_phases"):
+            pb = (C.c_ulonglong * 16)()
+            lib.jf_exp_rs_phases(pb)
+            nm = ["table in LDS", "phase A: loads + float64 exps", "reduced over the workgroup", "all 16 partials of the row in", "phase B: probabilities + scans",
+                  "sums formed, stores issued", "announced"]
+            print("# row 0, segment 0 of the last launch (us): " + ";  ".join(f"{nm[k]} {(pb[k] - t0) / 100.0:.1f}" for k in range(7)))
         print("# in-kernel stamps of rs_step_fused_kernel, us after the accept workgroup started (mean of 8 launches):")
         for k in sorted(names, key=lambda k: np.mean(acc[k])):
             print(f"#   {np.mean(acc[k]):7.1f}  {names[k]}")

@@ -52,7 +52,7 @@ def main():
     dec = MultiblockJacobiDecoder(model, P, prm, max_seq_len=4096, t_align=ta, logit_align=la)
     if a.scripted:
         dec.logits_hook = ScriptedAcceptance(cfg.vocab_size, robust_pct=82, vocab_hi=vocab_hi)
-    rows, steps, flagged, pred = [], [], [], {}
+    rows, steps, flagged, pred, anat = [], [], [], {}, []
     other = torch.zeros(1 << 29, dtype=torch.bfloat16, device=dev) if a.before == "sweep-other" else None
     state = dict(i=0)
 
@@ -100,6 +100,13 @@ def main():
                 cls = ("call end" if ev[p] & _native.EVT_CALL_END else "fast" if ev[p] & _native.EVT_FAST else "general")
                 steps.append((cls, (int(st[2 + 8 * p + 4]) - int(st[2 + 8 * p + 3])) / 100.0, (ends[p] - arrived[p]) / 100.0,
                               (ends[p] - t0) / 100.0 > (max(ends) - t0) / 100.0 - 0.05))
+        # launch anatomy (small shapes): when the item workgroups start, how long one lasts, and the last stepper's phases
+        last = int(np.argmax(ends))
+        ph = [int(st[2 + 8 * last + k]) for k in range(8)]
+        anat.append(dict(start_med=float(np.median(it[:, 0] - t0)) / 100.0, start_max=float((it[:, 0] - t0).max()) / 100.0,
+                         dur_med=float(np.median(dur[dur > 1.0])) if (dur > 1.0).any() else 0.0, dur_max=float(dur.max()),
+                         stepper_start=(ph[0] - t0) / 100.0, image=(ph[1] - t0) / 100.0, seen=(ph[2] - t0) / 100.0, gathered=(ph[3] - t0) / 100.0,
+                         stepped=(ph[4] - t0) / 100.0, written=(max(ph[5], ph[6]) - t0) / 100.0, end=(ends[last] - t0) / 100.0))
         rows.append(dict(valid=dec.last_valid_rows, launched=flat.shape[0], items=len(it), real=len(real),
                          items_end=(int(it[:, 1].max()) - t0) / 100.0, last_start=(int(it[:, 0].max()) - t0) / 100.0,
                          arrived=(max(arrived) - t0) / 100.0, end=(max(ends) - t0) / 100.0))
@@ -117,6 +124,12 @@ def main():
     mbs = np.array([r["valid"] * V * 2 / 1e6 for r in rows]); ie = np.array([r["items_end"] for r in rows]); en = np.array([r["end"] for r in rows])
     print(f"# mean: {mbs.mean():.1f} MB, items end {ie.mean():.1f} us ({mbs.mean() / ie.mean():.2f} TB/s), launch end {en.mean():.1f} us "
           f"({mbs.mean() / en.mean():.2f} TB/s = {mbs.mean() / en.mean() / 8:.3f} of 8 TB/s); tail {np.mean(en - ie):.1f} us")
+    if anat:
+        m = lambda k: float(np.mean([x[k] for x in anat]))
+        print(f"# anatomy (means over the launches, us after the first item start): item workgroups start  median {m('start_med'):.1f} / last {m('start_max'):.1f}; "
+              f"one item lasts  median {m('dur_med'):.1f} / longest {m('dur_max'):.1f}")
+        print(f"#   the launch's last stepper: starts {m('stepper_start'):.1f}, image in LDS {m('image'):.1f}, sees its last row {m('seen'):.1f}, tokens gathered {m('gathered'):.1f}, "
+              f"stepped {m('stepped'):.1f}, written back / descriptor out {m('written'):.1f}, end {m('end'):.1f}")
     print("# steppers by what their step was: count, gathered -> stepped us (mean / max), rows seen -> end us (mean / max), times it was the launch's last")
     for cls in ("fast", "general", "call end"):
         sel = [x for x in steps if x[0] == cls]
