@@ -70,6 +70,7 @@ class EngineRow(C.Structure):
 
 
 ENGINE_ROW_INTS = C.sizeof(EngineRow) // 4
+ENGINE_FIELDS = ["acc_len", "n_new", "eos", "active_next", "n_pads", "rsv0", "rsv1", "rsv2"]   # int32 columns of a row record
 
 
 class RsRow(C.Structure):

@@ -91,25 +91,35 @@ __global__ __launch_bounds__(256) void engine_step_kernel(const int64_t *draft, 
         }
         return;
     }
-    __shared__ int s_np[ENGINE_ONE_LAUNCH_ROWS], s_cl[ENGINE_ONE_LAUNCH_ROWS], s_off[ENGINE_ONE_LAUNCH_ROWS];
-    __shared__ int s_total;
+    // (dynamic LDS sized by B — 2 B ints: the launch's LDS request applies to the row workgroups too)
+    extern __shared__ int s_dyn[];
+    int *s_w = s_dyn, *s_off = s_dyn + B;                     // n_pads << 16 | copy_len per row; pad-stream offset per row
+    __shared__ int s_total, s_bad;
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (int r = tid; r < B; r += 256) {                      // wait for every row's word (bounded: 2 s of the 100 MHz clock)
         unsigned long long w;
         unsigned spins = 0;
+        bool ok = true;
         while (((w = __hip_atomic_load((const unsigned long long *)__builtin_assume_aligned(&rows[r].rsv[1], 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != gen) {
             __builtin_amdgcn_s_sleep(4);
-            if ((++spins & 255u) == 0u && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { w = 0ull; break; }
+            if ((++spins & 255u) == 0u && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { ok = false; break; }
         }
-        s_np[r] = (int)((w >> 16) & 0xFFFFu);
-        s_cl[r] = (int)(w & 0xFFFFu);
+        if (!ok) {                                            // the row never published: report it, touch nothing it may still be reading
+            w = 0ull;
+            s_bad = 1;
+            __hip_atomic_store(&rows[r].active_next, (int32_t)JF_E_LAUNCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_w[r] = (int)(w & 0xFFFFFFFFull);
     }
     __syncthreads();
+    if (s_bad) return;                                        // no pads, no re-zeroing, no cursor: the host raises on the marker
     if (tid < 64) {                                           // exclusive scan of n_pads in row order, 64 rows per pass
         int run = 0;
         for (int b0 = 0; b0 < B; b0 += 64) {
             const int r = b0 + tid;
-            const int np = r < B ? s_np[r] : 0;
+            const int np = r < B ? (s_w[r] >> 16) & 0xFFFF : 0;
             int x = np;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -125,9 +135,10 @@ __global__ __launch_bounds__(256) void engine_step_kernel(const int64_t *draft, 
     const int64_t base = *pad_cursor;
     for (int64_t idx = tid; idx < (int64_t)B * (L - 1); idx += 256) {
         const int r = (int)(idx / (L - 1)), i = (int)(idx - (int64_t)r * (L - 1));
-        if (i < s_np[r]) {
+        const int wv = s_w[r];
+        if (i < ((wv >> 16) & 0xFFFF)) {
             const int64_t k = base + s_off[r] + i;
-            next_draft[(int64_t)r * L + 1 + s_cl[r] + i] = pad_stream[pad_len > 0 ? (k % pad_len) : 0];
+            next_draft[(int64_t)r * L + 1 + (wv & 0xFFFF) + i] = pad_stream[pad_len > 0 ? (k % pad_len) : 0];
         }
         packed[idx] = 0ull;                                  // every row has read its slice: ready for the next argmax
     }
@@ -147,7 +158,7 @@ extern "C" int jf_engine_step(const int64_t *draft, int B, int L, uint64_t *pack
         static std::atomic<uint32_t> generation{0};
         uint32_t gen = ++generation;
         if (gen == 0) gen = ++generation;                       // 0 is what a fresh record holds
-        engine_step_kernel<<<B + 1, 256, 0, s>>>(draft, B, L, (unsigned long long *)packed, eos_id, remaining_tokens, new_tokens, next_draft,
+        engine_step_kernel<<<B + 1, 256, (size_t)B * 2 * sizeof(int), s>>>(draft, B, L, (unsigned long long *)packed, eos_id, remaining_tokens, new_tokens, next_draft,
                                                  pad_stream, pad_stream_len, pad_cursor, rows, gen);
         return check_launch("engine_step_kernel");
     }

@@ -26,11 +26,13 @@ __device__ __forceinline__ float bf16_rne(float x) {         // nearest bfloat16
     return __uint_as_float(u);
 }
 
-// temperature-scaled logit, exactly as torch forms it for this dtype
+__device__ __forceinline__ float scale_bf16_fast(float x, float inv_t);
+// temperature-scaled logit, exactly as torch forms it for this dtype.  fast (bf16 only): the host has checked that
+// bf16(x * fl(1/T)) reproduces torch's bf16(fl32(x / T)) for every bf16 x (rs_scale_is_exact: all but ~0.2 % of temperatures)
 template <int DT>
-__device__ __forceinline__ float rs_scaled(float x, float t, float inv_t, bool unit_t) {
+__device__ __forceinline__ float rs_scaled(float x, float t, float inv_t, bool unit_t, bool fast = false) {
     if constexpr (DT == JF_F32) return unit_t ? x : __fdiv_rn(x, t);      // torch: logits / T is a true division (round 4; x * (1/T) before)
-    else return unit_t ? x : bf16_rne(__fdiv_rn(x, t));
+    else return unit_t ? x : (fast ? scale_bf16_fast(x, inv_t) : bf16_rne(__fdiv_rn(x, t)));
 }
 // probability of one element given the row statistics
 template <int DT>
@@ -45,10 +47,11 @@ struct RsRow {                 // one logits row + what is needed to turn an ele
     int64_t V;
     float t, inv_t, M, S;
     bool unit_t, vec;          // vec: 16-byte aligned row -> vector loads
+    bool fast;                 // bf16 temperature scaling as a product (see rs_scaled)
 };
 template <int DT>
 __device__ __forceinline__ float rs_prob_at(const RsRow &r, int64_t i) {
-    return rs_prob<DT>(rs_scaled<DT>(load_f<DT>(r.p, i), r.t, r.inv_t, r.unit_t), r.M, r.S);
+    return rs_prob<DT>(rs_scaled<DT>(load_f<DT>(r.p, i), r.t, r.inv_t, r.unit_t, r.fast), r.M, r.S);
 }
 template <int DT>
 __device__ __forceinline__ void rs_unpack(const u32x4 v, float (&x)[Elem<DT>::EPV]) {
@@ -85,7 +88,7 @@ __device__ __forceinline__ void rs_probs_from_vec(const RsRow &r, const u32x4 v,
     float x[EPV];
     rs_unpack<DT>(v, x);
 #pragma unroll
-    for (int j = 0; j < EPV; ++j) p[j] = rs_prob<DT>(rs_scaled<DT>(x[j], r.t, r.inv_t, r.unit_t), r.M, r.S);
+    for (int j = 0; j < EPV; ++j) p[j] = rs_prob<DT>(rs_scaled<DT>(x[j], r.t, r.inv_t, r.unit_t, r.fast), r.M, r.S);
 }
 // probabilities of the EPV elements starting at element e0 (a multiple of EPV); elements >= V give 0
 template <int DT>
@@ -297,7 +300,11 @@ __device__ __forceinline__ void rs_load_tab(double *tab) {   // 64-entry table i
 // exp(d) for RS_EXP_CUT <= d <= 0, relative error <= 2.3e-16 (checked against 50-digit decimals over 20 000 arguments):
 // d = k ln2/64 + r, |r| <= ln2/128, exp(r) by a degree-5 polynomial, 2^(k/64) = 2^(k >> 6) * tab[k & 63].  14 float64 ops.
 __device__ __forceinline__ double rs_exp64(double d, const double *tab) {
-    const double kf = __builtin_rint(d * 92.33248261689366);                               // 64 / ln 2
+    // k = rint(d * 64 / ln 2) by the 1.5 * 2^52 shift (the integer lands in the low mantissa bits: no v_rndne / v_cvt), and
+    // 2^(k >> 6) by an integer add on the exponent field (the result stays far inside the normal range: no v_ldexp)
+    const double t = __builtin_fma(d, 92.33248261689366, 6755399441055744.0);
+    const int k = __double2loint(t);
+    const double kf = t - 6755399441055744.0;
     const double r = __builtin_fma(-kf, 2.9815858269852933e-12, __builtin_fma(-kf, 0.01083042469326756, d));   // ln2/64 = hi (33 bits) + lo
     double p = 8.333333333333333e-3;
     p = __builtin_fma(p, r, 4.1666666666666664e-2);
@@ -305,9 +312,9 @@ __device__ __forceinline__ double rs_exp64(double d, const double *tab) {
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = p * r;                                                                              // exp(r) - 1
-    const int k = (int)kf;
     const double tj = tab[k & 63];
-    return __builtin_ldexp(__builtin_fma(tj, p, tj), k >> 6);
+    const double v = __builtin_fma(tj, p, tj);                                              // in [1, 2.02)
+    return __hiloint2double(__double2hiint(v) + ((k >> 6) << 20), __double2loint(v));
 }
 // nearest-even bf16 of a non-negative float64 (subnormals included), as a float: float32 by round-to-odd, then RNE
 __device__ __forceinline__ float rs_bf16_of_f64(double q) {
@@ -337,7 +344,8 @@ __device__ __forceinline__ double rs_eps_row(float M) {
 // exp(xs - M) in float64 for a scaled logit; 0 for anything below the cut (and for -inf)
 __device__ __forceinline__ double rs_e64(float xs, double M, const double *tab) {
     const double d = (double)xs - M;
-    return d >= RS_EXP_CUT ? rs_exp64(d, tab) : 0.0;
+    const double e = rs_exp64(fmax(d, RS_EXP_CUT), tab);      // branch-free: a select, not 40 divergent branches per lane
+    return d >= RS_EXP_CUT ? e : 0.0;
 }
 
 // Stage 2 — one thread per row: merge the chunk partials, then the gathered probability of the drafted id.
@@ -640,6 +648,9 @@ __device__ __forceinline__ RsRow rs_make_row(const void *logits, int64_t r, int6
     RsRow rr;
     const int esz = DT == JF_F32 ? 4 : 2;
     rr.p = (const char *)logits + r * row_stride * esz;
+    // the steps pass -T when the host found the product form of the bf16 scaling exact for this T (jf_rs_step / _onpolicy_step)
+    rr.fast = t < 0.f;
+    t = fabsf(t);
     rr.V = V; rr.t = t; rr.inv_t = 1.f / t; rr.M = M; rr.S = S;
     rr.unit_t = (t == 1.f);
     rr.vec = (((uintptr_t)rr.p) % 16) == 0;
@@ -686,8 +697,14 @@ __device__ __forceinline__ bool rs_wait_word(const uint32_t *word, uint32_t gen)
 template <int DT>
 __device__ __forceinline__ void rs_scaled_from_vec(const RsRow &r, const u32x4 v, float (&xs)[Elem<DT>::EPV]) {
     rs_unpack<DT>(v, xs);
+    if (r.unit_t) return;                                      // wave-uniform branches OUTSIDE the element loop: the IEEE division
+    if (DT == JF_BF16 && r.fast) {                             // (12 instructions per element) must not be if-converted into the product's path
 #pragma unroll
-    for (int j = 0; j < Elem<DT>::EPV; ++j) xs[j] = rs_scaled<DT>(xs[j], r.t, r.inv_t, r.unit_t);
+        for (int j = 0; j < Elem<DT>::EPV; ++j) xs[j] = scale_bf16_fast(xs[j], r.inv_t);
+    } else {
+#pragma unroll
+        for (int j = 0; j < Elem<DT>::EPV; ++j) xs[j] = rs_scaled<DT>(xs[j], r.t, r.inv_t, false, false);
+    }
 }
 // exact probabilities of one vector (elements >= V hold -inf: probability 0), given the row's float64 1 / S
 template <int DT>
@@ -737,7 +754,7 @@ __device__ float rs_exact_prob_wg(const void *logits, int64_t r, int64_t V, int6
     const RsRow row = rs_make_row<DT>(logits, r, V, row_stride, t, M, 1.f);
     const double S = rs_row_s64_wg<DT>(row, tab, s_red);
     if (tok < 0 || tok >= V) return 0.f;
-    const float xs = rs_scaled<DT>(load_f<DT>(row.p, tok), row.t, row.inv_t, row.unit_t);
+    const float xs = rs_scaled<DT>(load_f<DT>(row.p, tok), row.t, row.inv_t, row.unit_t, row.fast);
     return rs_round_prob<DT>(rs_e64(xs, (double)M, tab) / S);
 }
 
@@ -811,7 +828,7 @@ __device__ __forceinline__ void rs_probs_from_kept(const RsRow &row, const u32x4
         p[j] = a;
         slow |= (a != b) || (q < 1e-36f && e[j] != 0.f);     // near float32's subnormal range the product itself is inexact
     }
-    if (slow) rs_exact_probs_from_vec<DT>(row, v, invS, tab, p);
+    if (__builtin_expect(slow, 0)) rs_exact_probs_from_vec<DT>(row, v, invS, tab, p);   // out of the straight-line path
 }
 
 // phase B of one (row, segment): exact probabilities, float64 sums per lane vector, one scan per tile.  SIG: results go out
@@ -847,7 +864,7 @@ __device__ __forceinline__ void rs_seg_prob_sums(const RsRow &row, int64_t lo, i
             for (int j = 0; j < EPV; ++j) p[j] = 0.f;
             if (e0 < hi) {
                 if constexpr (KEEP && DT == JF_BF16) {
-                    if (invS > 0.0) rs_probs_from_kept<DT>(row, v[k], e32[k], invS, invS32, sh.tab, p);
+                    if (__builtin_expect(invS > 0.0, 1)) rs_probs_from_kept<DT>(row, v[k], e32[k], invS, invS32, sh.tab, p);
                     else rs_probs_from_vec<DT>(row, v[k], p);
                 } else {
                     rs_any_probs_from_vec<DT>(row, v[k], invS, sh.tab, p);
@@ -1917,21 +1934,39 @@ __global__ __launch_bounds__(256) void rs_step_fused_kernel(RsFusedArgs a) {
             auto lane_f64 = [](double v, int k) {               // k is wave-uniform: two v_readlane (a shuffle goes through the LDS crossbar)
                 return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), k), __builtin_amdgcn_readlane(__double2loint(v), k));
             };
-            for (int k = 0; k < run; ++k, ++i) {
-                const double t_ = lane_f64(my_tot, k);
-                if (t_ < 0.0) continue;
-                float uf;
-                const int o = off;
-                const int draws = rs_count_draws([&](int tr) { return staged ? s_u[o + tr] : a.b_stream[(bc0 + o + tr) % a.b_len]; }, t_,
-                                                 lane_f64(my_lo, k), lane_f64(my_hi, k), tid, &uf);
-                if (tid == 0) {                                      // the count for the end workgroup (ordered by chain-done below),
-                    __hip_atomic_store(&a.rows[i].n_bonus_draws, draws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(w.pick + i, ((unsigned long long)a.gen << 32) | (unsigned long long)__float_as_uint(uf), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);   // the uniform for the row's bonus workgroup: a self-contained word
-                    RS_ROWSTAMP(3, i);
+            auto u_at = [&](int x) { return staged ? s_u[x] : a.b_stream[(bc0 + x) % a.b_len]; };
+            auto hand = [&](int row, int draws, float uf) {      // the count for the end workgroup (ordered by chain-done below) and the
+                __hip_atomic_store(&a.rows[row].n_bonus_draws, draws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // uniform for the row's
+                __hip_atomic_store(w.pick + row, ((unsigned long long)a.gen << 32) | (unsigned long long)__float_as_uint(uf), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);   // bonus workgroup: a self-contained word
+                RS_ROWSTAMP(3, row);
+            };
+            // The run in parallel first, a lane per row, on the assumption that every rejected row in front takes ONE draw (no
+            // collision with its proposed token: the usual case — a rejected proposal rarely holds much mass): the rows up to the
+            // first lane whose first draw collides are final at once.  From that row on the run is counted row by row (<= 16
+            // draws each, all lanes): where collisions are frequent a second parallel attempt would only cost its own pass.
+            {
+                const bool act = tid < run && !(my_tot < 0.0);      // (a NaN total is still a rejected row)
+                const unsigned long long actm = __ballot(act);
+                const int before = __builtin_popcountll(actm & ((1ull << tid) - 1ull));
+                float u1 = 0.f;
+                bool coll = false;
+                if (act) { u1 = u_at(off + before); const double thr = (double)u1 * my_tot; coll = thr >= my_lo && thr < my_hi; }
+                const unsigned long long cm = __ballot(coll);
+                const int f = cm ? __builtin_ctzll(cm) : 64;
+                if (act && tid < f) hand(i + tid, 1, u1);
+                off += __builtin_popcountll(f < 64 ? (actm & ((1ull << f) - 1ull)) : actm);
+                for (int k = f; k < run; ++k) {
+                    const double t_ = lane_f64(my_tot, k);
+                    if (t_ < 0.0) continue;
+                    float uf;
+                    const int o = off;
+                    const int draws = rs_count_draws([&](int tr) { return u_at(o + tr); }, t_, lane_f64(my_lo, k), lane_f64(my_hi, k), tid, &uf);
+                    if (tid == 0) hand(i + k, draws, uf);
+                    off += draws;
                 }
-                off += draws;
             }
+            i += run;
         }
         RS_STAMP_MAX(7);                                             // 7: last row handed its uniform
         if (tid == 0) {
@@ -2222,7 +2257,8 @@ extern "C" int jf_rs_onpolicy_step(const void *logits, int dtype, int64_t V, int
     if (workspace_bytes < rs_ws_bytes(R) || ((uintptr_t)workspace % 16) != 0) return fail(JF_E_INVALID, "jf_rs_onpolicy_step: workspace too small or not 16-byte aligned");
     if (dtype != JF_F32 && dtype != JF_BF16) return fail(JF_E_INVALID, "jf_rs_onpolicy_step: dtype %d", dtype);
     if (V <= 0 || V > 0x7FFFFFFFll) return fail(JF_E_INVALID, "jf_rs_onpolicy_step: V=%lld", (long long)V);
-    const float t = (temperature <= 0.f) ? 1.f : temperature;
+    float t = (temperature <= 0.f) ? 1.f : temperature;
+    if (dtype == JF_BF16 && t != 1.f && rs_scale_is_exact(t)) t = -t;    // the kernels' rows take the product form of the scaling (rs_make_row)
     hipStream_t s = (hipStream_t)stream;
     const RsWs w = rs_ws(workspace, R);
     unsigned long long *pk = (unsigned long long *)packed;
@@ -2276,8 +2312,9 @@ extern "C" int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_
     if (u_len <= 0 || bonus_len <= 0 || pad_len <= 0) return fail(JF_E_INVALID, "jf_rs_step: empty random stream");
     if (workspace_bytes < rs_ws_bytes(B) || ((uintptr_t)workspace % 16) != 0) return fail(JF_E_INVALID, "jf_rs_step: workspace too small or not 16-byte aligned");
     if (V <= 0 || V > 0x7FFFFFFFll) return fail(JF_E_INVALID, "jf_rs_step: V=%lld", (long long)V);
-    const float t = (temperature <= 0.f) ? 1.f : temperature;
+    float t = (temperature <= 0.f) ? 1.f : temperature;
     if (dtype != JF_F32 && dtype != JF_BF16) return fail(JF_E_INVALID, "jf_rs_step: dtype %d", dtype);
+    if (dtype == JF_BF16 && t != 1.f && rs_scale_is_exact(t)) t = -t;    // the kernels' rows take the product form of the scaling (rs_make_row)
     hipStream_t s = (hipStream_t)stream;
     unsigned long long *pk = (unsigned long long *)packed;
     const RsWs w = rs_ws(workspace, B);

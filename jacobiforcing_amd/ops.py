@@ -618,6 +618,10 @@ class EngineStepper:
         th.copy_(nt, non_blocking=True)
         if self.device.type == "cuda":
             torch.cuda.current_stream(self.device).synchronize()
+        if (self.rows_host[:B, N.ENGINE_FIELDS.index("active_next")] < 0).any():     # the pad workgroup gave up waiting for a row (2 s bound)
+            self.rows_dev[:B, N.ENGINE_FIELDS.index("active_next")] = 0
+            self.packed.zero_()
+            N.check(N.JF_E_LAUNCH, "jf_engine_step (a row never published its hand-off word: launch incomplete)")
         return self.rows_host[:B].numpy(), th.numpy(), nd
 
 
