@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define JF_VERSION 310
+#define JF_VERSION 400
 
 enum {
     JF_OK = 0,

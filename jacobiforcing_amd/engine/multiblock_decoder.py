@@ -301,7 +301,7 @@ class MultiblockJacobiDecoder:
                 off, ln = fin[:, N.FIN_FIELDS.index("text_off")], fin[:, N.FIN_FIELDS.index("ret_len")]
                 H = N.DRV_HDR_INTS
                 rows = [self.drv[int(p), H + int(off[p]):H + int(off[p]) + int(ln[p])] for p in ended]
-                flat = torch.cat(rows).cpu().tolist() if rows else []
+                flat = self._fetch_rows(rows) if rows else []
                 at = 0
                 for p in ended:
                     ret = flat[at:at + int(ln[p])]
@@ -327,6 +327,20 @@ class MultiblockJacobiDecoder:
             if max_iterations is not None and iters_total >= max_iterations:
                 break
         return iters_total
+
+    def _fetch_rows(self, rows) -> list:
+        """Token slices of the driver blocks to the host WITHOUT waiting for the forward that has been queued since: the
+        launch that wrote them has finished (its mailbox stamp has been seen), so a copy on a side stream only waits for
+        itself — `torch.cat(rows).cpu()` on the decoding stream waited for the whole next forward."""
+        if self.device.type != "cuda":
+            return torch.cat(rows).tolist()
+        side = getattr(self, "_side_stream", None)
+        if side is None:
+            side = self._side_stream = torch.cuda.Stream(self.device)
+        with torch.cuda.stream(side):
+            host = torch.cat(rows).to("cpu", non_blocking=True)
+        side.synchronize()
+        return host.tolist()
 
     def _collect_driver(self, stats, prompts) -> None:
         blk = self.drv.cpu().numpy()
