@@ -817,7 +817,7 @@ __device__ __forceinline__ double rs_seg_exp_sum(const RsRow &row, int64_t lo, i
 // exact probabilities of one vector from the kept float32 exps (bf16 logits): the float32 product errs by < 2^-22, so the
 // rounding is certain unless a bf16 boundary lies inside the 2^-21 band around it (1 element in ~8 000: float64 quotient)
 template <int DT>
-__device__ __forceinline__ void rs_probs_from_kept(const RsRow &row, const u32x4 v, const float (&e)[Elem<DT>::EPV], double invS, float invS32,
+__device__ __forceinline__ void rs_probs_from_kept(const RsRow &row, int64_t e0, const float (&e)[Elem<DT>::EPV], double invS, float invS32,
                                                    const double *tab, float (&p)[Elem<DT>::EPV]) {
     constexpr int EPV = Elem<DT>::EPV;
     bool slow = false;
@@ -828,7 +828,8 @@ __device__ __forceinline__ void rs_probs_from_kept(const RsRow &row, const u32x4
         p[j] = a;
         slow |= (a != b) || (q < 1e-36f && e[j] != 0.f);     // near float32's subnormal range the product itself is inexact
     }
-    if (__builtin_expect(slow, 0)) rs_exact_probs_from_vec<DT>(row, v, invS, tab, p);   // out of the straight-line path
+    // out of the straight-line path; the vector is read again (L2) rather than kept in registers across the exchange of the partials
+    if (__builtin_expect(slow, 0)) rs_exact_probs_from_vec<DT>(row, rs_load_vec<DT>(row, e0), invS, tab, p);
 }
 
 // phase B of one (row, segment): exact probabilities, float64 sums per lane vector, one scan per tile.  SIG: results go out
@@ -864,8 +865,8 @@ __device__ __forceinline__ void rs_seg_prob_sums(const RsRow &row, int64_t lo, i
             for (int j = 0; j < EPV; ++j) p[j] = 0.f;
             if (e0 < hi) {
                 if constexpr (KEEP && DT == JF_BF16) {
-                    if (__builtin_expect(invS > 0.0, 1)) rs_probs_from_kept<DT>(row, v[k], e32[k], invS, invS32, sh.tab, p);
-                    else rs_probs_from_vec<DT>(row, v[k], p);
+                    if (__builtin_expect(invS > 0.0, 1)) rs_probs_from_kept<DT>(row, e0, e32[k], invS, invS32, sh.tab, p);
+                    else rs_probs_from_vec<DT>(row, rs_load_vec<DT>(row, e0), p);
                 } else {
                     rs_any_probs_from_vec<DT>(row, v[k], invS, sh.tab, p);
                 }
@@ -975,9 +976,6 @@ __device__ __forceinline__ bool rs_rowsum_fused(const void *logits, int64_t V, i
         if (!sh.ok) return false;
 #pragma unroll
         for (int s = 0; s < RS_SEG; ++s) S += sh.part[s];    // segment order: every workgroup of the row forms the same S
-    } else if (keep) {
-#pragma unroll
-        for (int k = 0; k < NV; ++k) { const int64_t e0 = lo + ((int64_t)k * 256 + tid) * EPV; if (k < ntiles && e0 < hi) v[k] = rs_load_vec<DT>(row, e0); }
     }
     if (keep) rs_seg_prob_sums<DT, true, true>(row, lo, hi, S, w, item, seg, av, gen, sh, e32, v);
     else rs_seg_prob_sums<DT, true, false>(row, lo, hi, S, w, item, seg, av, gen, sh, e32, v);
@@ -1826,7 +1824,7 @@ __device__ __forceinline__ void rs_report_timeout(jf_rs_row *rows) {
 }
 
 template <int DT>
-__global__ __launch_bounds__(256) void rs_step_fused_kernel(RsFusedArgs a) {
+__global__ __launch_bounds__(256, 4) void rs_step_fused_kernel(RsFusedArgs a) {   // 4 workgroups per CU (<= 128 VGPRs, < 40 KB LDS): 64 rows' 1 024 segment workgroups are resident at once
     const int blk = blockIdx.x, tid = threadIdx.x;
     const int B = a.B, L = a.L, W = a.L - 1;
     const RsWs &w = a.w;
@@ -1866,21 +1864,49 @@ __global__ __launch_bounds__(256) void rs_step_fused_kernel(RsFusedArgs a) {
         // Wavefronts 1-3 turn rows into CDF intervals as their flags and segment sums come in (a thread per row); wavefront 0
         // counts the draws in row order on LDS and hands every rejected row its uniform the moment the rows before it are
         // counted — the walk of row i starts a few us after row i was decided, not after the last row's sums.
-        __shared__ double s_tot[RS_FUSED_ROWS], s_lo[RS_FUSED_ROWS], s_hi[RS_FUSED_ROWS];   // s_tot < 0: not rejected
-        __shared__ int s_ready[RS_FUSED_ROWS];
         float *s_u = (float *)s_big;                                 // [RS_MAX_TRIES * RS_FUSED_ROWS]
-        static_assert(RS_MAX_TRIES * RS_FUSED_ROWS * 4 <= 2 * RS_FUSED_STAGE * 4, "chain window");
+        double *s_tot = (double *)(s_big + RS_MAX_TRIES * RS_FUSED_ROWS * 4), *s_lo = s_tot + RS_FUSED_ROWS, *s_hi = s_lo + RS_FUSED_ROWS;   // s_tot < 0: not rejected
+        unsigned long long *s_hand = (unsigned long long *)(s_hi + RS_FUSED_ROWS);   // per row: 0 = not counted yet, else HAND_* | draws << 32 | uniform bits
+        int *s_ready = (int *)(s_hand + RS_FUSED_ROWS);
+        static_assert(RS_MAX_TRIES * RS_FUSED_ROWS * 4 + 4 * RS_FUSED_ROWS * 8 + RS_FUSED_ROWS * 4 <= 2 * RS_FUSED_STAGE * 4, "chain tables");
+        constexpr unsigned long long HAND_REJ = 1ull << 63, HAND_SKIP = 1ull << 62;
         const int64_t bc0 = *a.b_cursor;
         const bool staged = a.b_len < 0x7FFFFFFFll;
-        for (int i = tid; i < B; i += 256) s_ready[i] = 0;
+        for (int i = tid; i < B; i += 256) { s_ready[i] = 0; s_hand[i] = 0ull; }
         if (staged) {                                                // every entry the walk can touch: RS_MAX_TRIES per row
             const int bl = (int)a.b_len, bb = (int)(bc0 % a.b_len);
             batched_for<8, float>(RS_MAX_TRIES * B, tid, 256, [&](int64_t i) { return a.b_stream[(bb + (int)i) % bl]; }, [&](int64_t i, float v) { s_u[i] = v; });
         }
         __syncthreads();
+        if (tid >= 192) {
+            // wavefront 3: hands the counted rows over — a lane per row of the leading run of rows wavefront 0 has counted: the
+            // two global stores per row (and their address arithmetic) are off the counting wavefront's instruction stream
+            const int lane = tid - 192;
+            int base = 0;
+            while (base < B) {
+                const int r = base + lane;
+                const unsigned long long hw = r < B ? __hip_atomic_load(&s_hand[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
+                const unsigned long long nr = ~__ballot(hw != 0ull);
+                const int run = nr ? __builtin_ctzll(nr) : 64;
+                if (lane < run && (hw & HAND_REJ)) {
+                    __hip_atomic_store(&a.rows[r].n_bonus_draws, (int)((hw >> 32) & 0xFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the end workgroup
+                    __hip_atomic_store(w.pick + r, ((unsigned long long)a.gen << 32) | (hw & 0xFFFFFFFFull), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);   // the uniform for the row's bonus workgroup: a self-contained word
+                    RS_ROWSTAMP(3, r);
+                }
+                base += run;
+                if (run == 0) __builtin_amdgcn_s_sleep(1);
+            }
+#ifdef JF_EXP_RS_TRACE
+            if (lane == 0) atomicMax(&g_rstrace[7], (unsigned long long)__builtin_amdgcn_s_memrealtime());   // 7: last row handed its uniform
+#endif
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every count is performed before the word that says so
+            if (lane == 0) __hip_atomic_store(w.acceptdone + 1, a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
         if (tid >= 64) {
-            // a thread per row (B <= RS_FUSED_ROWS <= 192), every lane polling for ITS row without blocking the others of its
-            // wavefront: a lane that waited in a loop of its own would hold all 64 rows back until the last of them is in
+            // a thread per row (B <= RS_FUSED_ROWS = 128: wavefronts 1 and 2), every lane polling for ITS row without blocking the
+            // others of its wavefront: a lane that waited in a loop of its own would hold all 64 rows back until the last of them is in
             const int i = tid - 64;
             bool fin = i >= B;
             int rp = -3;                                             // -3: the row's flag has not been seen yet
@@ -1935,11 +1961,9 @@ __global__ __launch_bounds__(256) void rs_step_fused_kernel(RsFusedArgs a) {
                 return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), k), __builtin_amdgcn_readlane(__double2loint(v), k));
             };
             auto u_at = [&](int x) { return staged ? s_u[x] : a.b_stream[(bc0 + x) % a.b_len]; };
-            auto hand = [&](int row, int draws, float uf) {      // the count for the end workgroup (ordered by chain-done below) and the
-                __hip_atomic_store(&a.rows[row].n_bonus_draws, draws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // uniform for the row's
-                __hip_atomic_store(w.pick + row, ((unsigned long long)a.gen << 32) | (unsigned long long)__float_as_uint(uf), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);   // bonus workgroup: a self-contained word
-                RS_ROWSTAMP(3, row);
+            auto hand = [&](int row, int draws, float uf) {      // counted: wavefront 3 stores the count and the uniform where they are read
+                __hip_atomic_store(&s_hand[row], HAND_REJ | ((unsigned long long)draws << 32) | (unsigned long long)__float_as_uint(uf), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
             };
             // The run in parallel first, a lane per row, on the assumption that every rejected row in front takes ONE draw (no
             // collision with its proposed token: the usual case — a rejected proposal rarely holds much mass): the rows up to the
@@ -1955,10 +1979,11 @@ __global__ __launch_bounds__(256) void rs_step_fused_kernel(RsFusedArgs a) {
                 const unsigned long long cm = __ballot(coll);
                 const int f = cm ? __builtin_ctzll(cm) : 64;
                 if (act && tid < f) hand(i + tid, 1, u1);
+                if (!act && tid < run && tid < f) __hip_atomic_store(&s_hand[i + tid], HAND_SKIP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // not rejected
                 off += __builtin_popcountll(f < 64 ? (actm & ((1ull << f) - 1ull)) : actm);
                 for (int k = f; k < run; ++k) {
                     const double t_ = lane_f64(my_tot, k);
-                    if (t_ < 0.0) continue;
+                    if (t_ < 0.0) { if (tid == 0) __hip_atomic_store(&s_hand[i + k], HAND_SKIP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); continue; }
                     float uf;
                     const int o = off;
                     const int draws = rs_count_draws([&](int tr) { return u_at(o + tr); }, t_, lane_f64(my_lo, k), lane_f64(my_hi, k), tid, &uf);
@@ -1968,12 +1993,7 @@ __global__ __launch_bounds__(256) void rs_step_fused_kernel(RsFusedArgs a) {
             }
             i += run;
         }
-        RS_STAMP_MAX(7);                                             // 7: last row handed its uniform
-        if (tid == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every count is performed before the word that says so
-            __hip_atomic_store(w.acceptdone + 1, a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        return;
+        return;                                                      // (wavefront 3 announces the end of the chain)
     }
     if (blk >= 3) {                                                 // ---- row b (3 <= blk < B + 3 here): bonus draw, then the row's own finish
         const int b = blk - 3;

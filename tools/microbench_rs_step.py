@@ -52,7 +52,7 @@ def main():
     if a.trace:
         import ctypes as C
         lib = N.lib()
-        names = {1: "accept workgroup done", 15: "accept walk decided the last row", 7: "last row handed its uniform",
+        names = {1: "accept workgroup done", 15: "accept walk decided the last row", 7: "last row handed its uniform (wavefront 3 of the chain)",
                  12: "end workgroup has every row's finish word", 25: "end: scans done", 13: "finished", 17: "last row's bonus workgroup has its uniform",
                  19: "... has walked", 21: "... has finished its row (token, record, next draft's seed and tail)"}
         acc = {k: [] for k in names}
