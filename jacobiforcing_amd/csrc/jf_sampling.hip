@@ -27,6 +27,7 @@ __device__ __forceinline__ float bf16_rne(float x) {         // nearest bfloat16
 }
 
 __device__ __forceinline__ float scale_bf16_fast(float x, float inv_t);
+__device__ __forceinline__ void scale_bf16_fast2(float &a, float &b, float inv_t);
 // temperature-scaled logit, exactly as torch forms it for this dtype.  fast (bf16 only): the host has checked that
 // bf16(x * fl(1/T)) reproduces torch's bf16(fl32(x / T)) for every bf16 x (rs_scale_is_exact: all but ~0.2 % of temperatures)
 template <int DT>
@@ -700,7 +701,7 @@ __device__ __forceinline__ void rs_scaled_from_vec(const RsRow &r, const u32x4 v
     if (r.unit_t) return;                                      // wave-uniform branches OUTSIDE the element loop: the IEEE division
     if (DT == JF_BF16 && r.fast) {                             // (12 instructions per element) must not be if-converted into the product's path
 #pragma unroll
-        for (int j = 0; j < Elem<DT>::EPV; ++j) xs[j] = scale_bf16_fast(xs[j], r.inv_t);
+        for (int j = 0; j + 1 < Elem<DT>::EPV; j += 2) scale_bf16_fast2(xs[j], xs[j + 1], r.inv_t);   // v_pk_mul_f32 + v_cvt_pk_bf16_f32: two elements at once
     } else {
 #pragma unroll
         for (int j = 0; j < Elem<DT>::EPV; ++j) xs[j] = rs_scaled<DT>(xs[j], r.t, r.inv_t, false, false);
@@ -794,6 +795,7 @@ __device__ __forceinline__ double rs_seg_exp_sum(const RsRow &row, int64_t lo, i
                                                  float (&e32)[RsKeep<DT>::NV][Elem<DT>::EPV], u32x4 (&v)[RsKeep<DT>::NV]) {
     constexpr int EPV = Elem<DT>::EPV, NV = RsKeep<DT>::NV;
     double acc = 0.0;
+    const float mcut = row.M + (float)RS_EXP_CUT + 1.f;                // one above the cut (float rounding of the sum): vectors wholly above it skip the clamp
     for (int64_t b0 = lo + (int64_t)threadIdx.x * EPV; b0 < hi; b0 += (int64_t)NV * 256 * EPV) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) { const int64_t e0 = b0 + (int64_t)k * 256 * EPV; if (e0 < hi) v[k] = rs_load_vec<DT>(row, e0); }
@@ -803,11 +805,23 @@ __device__ __forceinline__ double rs_seg_exp_sum(const RsRow &row, int64_t lo, i
             if (e0 >= hi) { if constexpr (KEEP) { for (int j = 0; j < EPV; ++j) e32[k][j] = 0.f; } continue; }
             float xs[EPV];
             rs_scaled_from_vec<DT>(row, v[k], xs);
+            float xmin = xs[0];
 #pragma unroll
-            for (int j = 0; j < EPV; ++j) {
-                const double e = rs_e64(xs[j], (double)row.M, tab);
-                acc += e;
-                if constexpr (KEEP) e32[k][j] = (float)e;
+            for (int j = 1; j < EPV; ++j) xmin = fminf(xmin, xs[j]);
+            if (__ballot(!(xmin >= mcut)) == 0ull) {           // (wave-uniform, the usual case) nothing of this vector is near the cut: no clamp, no select
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) {
+                    const double e = rs_exp64((double)xs[j] - (double)row.M, tab);
+                    acc += e;
+                    if constexpr (KEEP) e32[k][j] = (float)e;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) {
+                    const double e = rs_e64(xs[j], (double)row.M, tab);
+                    acc += e;
+                    if constexpr (KEEP) e32[k][j] = (float)e;
+                }
             }
         }
     }
@@ -1413,10 +1427,31 @@ __device__ __forceinline__ void rs_accept_body(const RsAcceptIn &in, const int64
             const int lane = tid;
             const bool inrow = lane < W;
             int used_total = used_start, unc_at = -1, b = b_start;
-            uint32_t pe = (inrow && b < B) ? s_p[b * W + lane] : 0u;
-            for (; b < B; ++b) {                                    // JDN:326-348, rows in order
+            while (b < B) {                                         // JDN:326-348, rows in order
+                // A run of rows at once, a lane per row, on the assumption that every row of the run STOPS AT ITS FIRST TEST (the
+                // proposal at position 0 is rejected — what a draft that is not yet right gets — or is an accepted EOS): then each of
+                // them consumes exactly one uniform and the offsets of the whole run are known.  The run ends in front of the first
+                // row that accepts its first proposal (or whose first test is undecided); that row is walked the long way below.
+                {
+                    const int rb = b + lane;
+                    bool ok0 = false, rej0 = false;
+                    if (rb < B) {
+                        const uint32_t pe0 = s_p[rb * W];
+                        const float u0 = s_u[used_total + lane];
+                        rej0 = !(u0 < __uint_as_float(pe0 & RS_PE_VAL));
+                        const bool unc0 = rej0 && (pe0 & RS_PE_AMB) && u0 < rs_accept_hi<DT>(pe0);
+                        ok0 = (rej0 || (pe0 & RS_PE_EOS)) && !unc0;
+                    }
+                    const unsigned long long nok = ~__ballot(ok0);
+                    const int run = nok ? __builtin_ctzll(nok) : 64;
+                    if (lane < run)                                 // rejected at position 0: nothing accepted; else the EOS at position 0 was accepted
+                        __hip_atomic_store(&s_res[rb], rej0 ? (1 << 16) : (1 | (1 << 15)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    b += run;
+                    used_total += run;
+                    if (run == 64 || b >= B) continue;
+                }
+                const uint32_t pe = inrow ? s_p[b * W + lane] : 0u;
                 const float uu = inrow ? s_u[used_total + lane] : 0.f;
-                const uint32_t pe_next = (inrow && b + 1 < B) ? s_p[(b + 1) * W + lane] : 0u;
                 const bool rejb = inrow && !(uu < __uint_as_float(pe & RS_PE_VAL));
                 const unsigned long long rejmask = __ballot(rejb);
                 const unsigned long long stopmask = rejmask | __ballot(inrow && (pe & RS_PE_EOS));
@@ -1432,7 +1467,7 @@ __device__ __forceinline__ void rs_accept_body(const RsAcceptIn &in, const int64
                 }
                 if (lane == 0) __hip_atomic_store(&s_res[b], nacc | (eos << 15) | ((rej + 1) << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 used_total += used;
-                pe = pe_next;
+                ++b;
             }
             if (lane == 0) {
                 if (SIG && unc_at >= 0) __hip_atomic_store(&s_res[b], RS_RES_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
