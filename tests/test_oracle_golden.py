@@ -286,3 +286,36 @@ def test_engine_fill_matches_reference_slot_pattern():
         assert ref["slot_mapping"] == want, c
         assert ref["positions"] == [S - 1 + j for j in range(L)]
         assert ref["cu_seqlens_q"] == [0, L] and ref["cu_seqlens_k"] == [0, S - 1 + L] and ref["cache_seqlens"] == [S - 1]
+
+
+def test_exact_softmax_escalation_levels_agree(monkeypatch):
+    """The definition of the probability tensor (exact softmax rounded once): float64 decides, elements near a rounding boundary
+    are re-decided in 80-bit and then in 60-digit decimal arithmetic.  Forcing MANY elements through the two higher levels (absurdly
+    wide near-tie bands) must not change a single probability — float64 was right for them — and the result is the correctly
+    rounded quotient: checked against exact rational arithmetic on a small row."""
+    from fractions import Fraction
+    import decimal
+    rng = np.random.default_rng(3)
+    x = O.bf16_round((rng.standard_normal((3, 300)) * 3).astype(np.float32))
+    base_bf16, base_f32 = O.target_probs(x, 0.7, "bf16"), O.target_probs(x, 0.7, "f32")
+    monkeypatch.setattr(O, "NEAR_TIE_REL", 5e-3)                       # ~every element takes the extended-precision path
+    before = list(O.NEAR_TIES_RESOLVED)
+    assert np.array_equal(O.target_probs(x, 0.7, "bf16"), base_bf16) and np.array_equal(O.target_probs(x, 0.7, "f32"), base_f32)
+    assert O.NEAR_TIES_RESOLVED[0] > before[0]
+    monkeypatch.setattr(O, "NEAR_TIE_REL_LD", 5e-3)                    # ... and the decimal one
+    assert np.array_equal(O.target_probs(x[:1], 0.7, "bf16"), base_bf16[:1]) and np.array_equal(O.target_probs(x[:1], 0.7, "f32"), base_f32[:1])
+    assert O.NEAR_TIES_RESOLVED[1] > before[1]
+    # bf16: the correctly rounded quotient, from 60-digit exponentials and exact rational rounding
+    ctx = decimal.Context(prec=60)
+    xs = O.bf16_round((x[0] / np.float32(0.7)).astype(np.float32))
+    d = xs.astype(np.float64) - np.float64(xs.max())
+    e = [Fraction(ctx.exp(decimal.Decimal(float(v)))) for v in d]
+    S = sum(e)
+    for i in range(0, 300, 7):
+        q = e[i] / S
+        got = Fraction(float(base_bf16[0, i]))
+        # neighbours of `got` on the bf16 grid: the rounded value must be at least as close to q as either of them
+        bits = int(O.f32_to_bf16_bits(np.array([base_bf16[0, i]], dtype=np.float32))[0])
+        lo = Fraction(float(O.bf16_bits_to_f32(np.array([max(bits - 1, 0)], dtype=np.uint16))[0]))
+        hi = Fraction(float(O.bf16_bits_to_f32(np.array([bits + 1], dtype=np.uint16))[0]))
+        assert abs(q - got) <= abs(q - lo) and abs(q - got) <= abs(q - hi), i
