@@ -426,6 +426,9 @@ struct Machine {
     // registers: the accepted prefix, the re-draft and the pool entries come out of lane shuffles of the draft / greedy row
     // instead of strided loops over the image, the next forward's rows are written while the drafts are, and only the header
     // words that change are stored.  The step is the serial tail of the convergence launch: ~1 020 instructions as step_fast.
+    // What it costs (3.2 us warm, profiles/verify_step_stages_r04.txt) is ISSUE time, one wavefront getting one instruction
+    // every four or five cycles, not image round trips: a version that read every stage's words in one batch (header, four
+    // candidate rows, three pool entries per round) measured the same to 0.05 us and was not kept.
     template <class GreedyFn>
     JF_HD bool step_fast64(GreedyFn G, jf_mb_desc *d) {
         if (num_blocks != 1 || RA != 0 || len_lists != 1) return false;
@@ -442,6 +445,7 @@ struct Machine {
             const int m = f < 64 ? f : cmp;
             if (m + 1 > acc_len) { acc_len = m + 1; best_idx = r; }
         }
+        JF_STAMP(12);
         if (acc_len >= Ls) return false;
         const int dtok = l < Ls ? draft(0, best_idx)[l] : 0;            // the winning draft row and its greedy row, a token per lane
         const int gtok = l < Ls ? G(best_idx, start - 1 + l) : 0;
@@ -456,6 +460,7 @@ struct Machine {
         if (new_total >= n) return false;                               // MB:656-721
         if (L.pool_size > 0 && new_acclen + newL > L.LPOOL) return false;
         // ---- nothing below can fail; no store above ---------------------------------------------------------
+        JF_STAMP(13);
         const int kv_before = kv_len;
         const int nd = lanes.shfl(gtok, l + acc_len - 1 < 64 ? l + acc_len - 1 : 63);   // re-draft [nxt] + greedy[acc_len:-1], lane j < newL
         int32_t *d0 = draft(0, 0), *o0 = out_row(0);
@@ -490,6 +495,7 @@ struct Machine {
             }
             lanes.sync();                                               // the entries are searched below
         }
+        JF_STAMP(14);
         if (new_total >= S[H_LOOK_THR]) {                               // MB:577-585
             for (int i1 = pool_count - 2; i1 >= 0; --i1) {
                 const int32_t *e = pool_entry(i1);
@@ -507,6 +513,7 @@ struct Machine {
             }
         }
         if (err) { lanes.sync(); done = 1; if (lanes.lane() == 0) { bb[B_ACCLEN] = new_acclen; bb[B_TOTAL] = new_total; bb[B_DROWS] = 1; bb[B_DLEN] = newL; } next_iteration(d); return true; }
+        JF_STAMP(15);
         const int rows = C > 1 ? 1 + C : 1;                             // a single recycled candidate is ignored (Q5)
         lnt = nxt; has_lnt = 1;
         events |= EVT_FAST | slow_next(1, new_total);

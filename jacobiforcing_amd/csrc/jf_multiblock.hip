@@ -242,6 +242,13 @@ __device__ __forceinline__ void verify_stepper(const VerifyArgs &a, int p, int32
     }
     __syncthreads();
     if (use_lds) use_lds = smem[16] != 0;
+#ifdef JF_EXP_STEP_TWICE
+    // experiment (tools/verify_trace.py --twice): the step runs twice through the SAME instructions, first on a second copy of
+    // the image, to tell instruction-fetch misses from dependent LDS latency in the step's 4-6 us
+    int32_t *img2 = img + ((LC.total + LC.RMAX * LC.TMAX + 3) & ~3);
+    if (use_lds) { for (int i = threadIdx.x; i < LC.total; i += AM_TPB) img2[i] = img[i]; }
+    __syncthreads();
+#endif
     JF_VSTAMP(p, 1);
     // Wavefront 0 is this prompt's state machine.  The other three park at the barrier below (a parked wavefront issues
     // nothing) and come back for the write-back, which is store-issue bound: 256 lanes instead of 64.
@@ -292,11 +299,26 @@ __device__ __forceinline__ void verify_stepper(const VerifyArgs &a, int p, int32
             if (use_lds) {
                 SoloWaveLanes{}.sync();
                 JF_VSTAMP(p, 3);
+#ifdef JF_EXP_STEP_TWICE
+                const int npass = 1 + (a.fast >> 1);
+                Machine<SoloWaveLanes> m(img, SoloWaveLanes{}, LC);
+#pragma nounroll
+                for (int pass = 0; pass < npass; ++pass) {
+                    const bool last = pass == npass - 1;
+                    m = Machine<SoloWaveLanes>(last ? img : img2, SoloWaveLanes{}, LC);
+                    m.allow_fast = (a.fast & 1) != 0;
+                    const int32_t *gt = gtok;
+                    m.step([gt, T](int r, int t) -> int { return gt[r * T + t]; }, last ? s_desc : (jf_mb_desc *)(img2 + LC.total));
+                    SoloWaveLanes{}.sync();
+                    if (!last && threadIdx.x == 0 && blockIdx.x < 256) g_mtrace[16 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+                }
+#else
                 Machine<SoloWaveLanes> m(img, SoloWaveLanes{}, LC);
                 m.allow_fast = a.fast != 0;
                 const int32_t *gt = gtok;
                 m.step([gt, T](int r, int t) -> int { return gt[r * T + t]; }, s_desc);
                 SoloWaveLanes{}.sync();
+#endif
                 if (!s_desc->error) {
                     wb = 1;
                     loop_after_step(m, lp, has_loop, p, was_done, s_desc);
@@ -416,7 +438,14 @@ static int verify_launch(const void *logits, int dtype, int64_t R, int64_t V, in
     const jfmb::Layout LC = jfmb::compact_layout(LG, params->K);
     int64_t lds_ints = VERIFY_LDS_HDR + (int64_t)LC.total + (int64_t)LC.RMAX * LC.TMAX;
     lds_ints = (lds_ints + 3) & ~3ll;
+#ifdef JF_EXP_STEP_TWICE
+    const int64_t lds_step_ints = lds_ints;
+    lds_ints += LC.total + 16 + 4;                              // the second image + its descriptor
+    lds_ints = (lds_ints + 3) & ~3ll;
+    if (lds_ints * 4 > 32 * 1024) lds_ints = 0;
+#else
     if (lds_ints * 4 > 16 * 1024) lds_ints = 0;
+#endif
     const size_t shm = (size_t)lds_ints * 4;
     void (*kern)(VerifyArgs) = nullptr;
     int variant = 0;
@@ -448,6 +477,9 @@ static int verify_launch(const void *logits, int dtype, int64_t R, int64_t V, in
     a.desc = desc; a.Tpad = Tpad; a.compacted = out_index ? 1 : 0; a.lds_ints = (int32_t)lds_ints;
     a.has_loop = lp ? 1 : 0;
     a.fast = fast_path();
+#ifdef JF_EXP_STEP_TWICE
+    { const char *e = getenv("JF_EXP_TWICE"); if (e && e[0] == '1') a.fast |= 2; a.lds_ints = lds_ints ? (int32_t)lds_step_ints : 0; }
+#endif
     a.lp = lp ? *lp : jfmb::LoopDev{};
     a.items = pl.items;
     // item workgroups: 1024 (four per CU) keep the memory system as full as one per item does — 768 already lose 1-2 %,

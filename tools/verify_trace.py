@@ -107,11 +107,30 @@ def run(P, iters, fused, trace_lib=None, loop=False):
                   f"stepped {rel(s[4]):6.1f}  written(w1-3) {rel(s[5]):6.1f}  desc-out {rel(s[6]):6.1f}  end {rel(s[7]):6.1f}")
         if mstamps is not None:                                     # state machine phases of the last stepper (last visit of each stamp)
             names = {1: "scalars", 2: "accept-scan", 3: "commit", 4: "re-draft", 5: "pool-push", 6: "candidates", 7: "spans-done",
-                     8: "spawn/promote", 9: "early-stop", 10: "build_out", 11: "scalars-stored"}
+                     8: "spawn/promote", 9: "early-stop", 10: "build_out", 11: "scalars-stored",
+                     12: "fast64:accept-scan", 13: "fast64:checks", 14: "fast64:pool-push", 15: "fast64:candidates"}
             q = P - 1
             row = [(rel(mstamps[q, k]), names[k]) for k in names if mstamps[q, k] >= stamps[2 + 8 * q + 3]]
             row.sort()
             print("      machine of stepper %d: " % q + "  ".join(f"{nm} {t:.2f}" for t, nm in row))
+        if mstamps is not None:                                     # the straight-line step's stages over all steppers that took it
+            rows_ = []
+            for q in range(P):
+                g_, st_ = stamps[2 + 8 * q + 3], stamps[2 + 8 * q + 4]
+                m_ = mstamps[q]
+                if all(g_ <= m_[k] <= st_ for k in (12, 13, 14, 15)) and m_[12] <= m_[13] <= m_[14] <= m_[15]:
+                    rows_.append([(int(m_[12]) - int(g_)) / 100, (int(m_[13]) - int(m_[12])) / 100, (int(m_[14]) - int(m_[13])) / 100,
+                                  (int(m_[15]) - int(m_[14])) / 100, (int(st_) - int(m_[15])) / 100])
+            tw = [((int(mstamps[q, 0]) - int(stamps[2 + 8 * q + 3])) / 100, (int(stamps[2 + 8 * q + 4]) - int(mstamps[q, 0])) / 100)
+                  for q in range(P) if stamps[2 + 8 * q + 3] <= mstamps[q, 0] <= stamps[2 + 8 * q + 4]]
+            if tw:                                                    # -DJF_EXP_STEP_TWICE with JF_EXP_TWICE=1
+                tw = np.array(tw)
+                print(f"      step run twice through the same instructions ({len(tw)} steppers): first pass {tw[:, 0].mean():.2f} us "
+                      f"(max {tw[:, 0].max():.2f}), second pass {tw[:, 1].mean():.2f} us (max {tw[:, 1].max():.2f})")
+            if rows_:
+                r_ = np.array(rows_).mean(axis=0)
+                print(f"      straight-line step ({len(rows_)} steppers, mean us): gathered->accept-scan {r_[0]:.2f}  checks {r_[1]:.2f}  "
+                      f"commit+re-draft+pool {r_[2]:.2f}  candidates {r_[3]:.2f}  header+descriptor+kv_len {r_[4]:.2f}")
         ends = np.array([max(rel(stamps[2 + 8 * p + 7]), rel(stamps[2 + 8 * p + 5])) for p in range(P)])
         arr = np.array([rel(stamps[2 + 8 * p + 2]) for p in range(P)])
         print(f"      all steppers: arrived {arr.min():.1f}..{arr.max():.1f} us, end {ends.min():.1f}..{ends.max():.1f} us")
