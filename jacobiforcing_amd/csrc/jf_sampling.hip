@@ -517,6 +517,13 @@ __host__ __device__ inline int64_t rs_seg_elems(int64_t V, int epv) {
     const int64_t per = (V + RS_SEG - 1) / RS_SEG;
     return ((per + tile - 1) / tile) * tile;
 }
+// segments that hold any element: Qwen's V = 152 064 fills 14 segments of 10 240 and a part of the 15th; the 16th is empty (the
+// one-launch step gives the empty ones no workgroup: the last active segment's workgroup stores their zeros)
+__host__ __device__ inline int rs_active_segs(int64_t V, int epv) {
+    const int64_t segE = rs_seg_elems(V, epv);
+    const int64_t n = (V + segE - 1) / segE;
+    return (int)(n < 1 ? 1 : (n > RS_SEG ? RS_SEG : n));
+}
 __host__ __device__ inline bool rs_hier_ok(int64_t V, int epv) {       // the wave-tile sums of a segment fit RS_WT entries
     return rs_seg_elems(V, epv) / (256 * (int64_t)epv) * 4 <= RS_WT;
 }
@@ -529,6 +536,7 @@ struct RsWs {                                     // carve-up of the step worksp
     double *s64;                                  // [rows] the row's float64 sum (all segments, in order)
     double *lo_part;                              // [rows] mass in front of the avoided token inside its segment
     double *p_avoid;                              // [rows] probability of the avoided token
+    double *iv;                                   // [rows, 3] one-launch step: the row's (total, c_lo, c_hi) — its proposed token's CDF interval
     int32_t *sel_row;                             // [rows] logits row to sum for item i, -1 = none
     int32_t *avoid;                               // [rows] token a draw must not return (the rejected proposal), -1 = none
     float *pick_u;                                // [rows] the uniform of the draw that counts; < 0: masked argmax instead
@@ -540,12 +548,13 @@ struct RsWs {                                     // carve-up of the step worksp
     unsigned long long *fin;                      // [rows] (gen << 32) | n_pads: the row's bonus workgroup has finished the row
     uint32_t *s64done;                            // [rows, RS_SEG] gen: this segment's float64 partial is stored
     uint32_t *segdone;                            // [rows, RS_SEG] gen: this segment's sums are stored
+    uint32_t *ivdone;                             // [rows] gen: iv is stored (by the workgroup of the row's segment 0, for the chain)
     uint32_t *acceptdone;                         // [4]   gen: [0] the accept workgroup has written every row record, [1] the chain workgroup every draw count
 };
 static inline size_t rs_ws_bytes(int64_t rows) {
     const size_t r = (size_t)((rows + 3) / 4 * 4);
-    return r * RS_SEG * sizeof(double) * 2 + r * RS_SEG * RS_WT * sizeof(double) + 3 * r * sizeof(double) + 3 * r * sizeof(int32_t) +
-           r * (RS_FLAG_STRIDE + 2) * sizeof(unsigned long long) + 2 * r * RS_SEG * sizeof(uint32_t) + 4 * sizeof(uint32_t);
+    return r * RS_SEG * sizeof(double) * 2 + r * RS_SEG * RS_WT * sizeof(double) + 6 * r * sizeof(double) + 3 * r * sizeof(int32_t) +
+           r * (RS_FLAG_STRIDE + 2) * sizeof(unsigned long long) + 2 * r * RS_SEG * sizeof(uint32_t) + r * sizeof(uint32_t) + 4 * sizeof(uint32_t);
 }
 __host__ __device__ inline RsWs rs_ws(void *ws, int64_t rows) {
     const size_t r = (size_t)((rows + 3) / 4 * 4);
@@ -556,7 +565,8 @@ __host__ __device__ inline RsWs rs_ws(void *ws, int64_t rows) {
     w.s64 = w.s64part + r * RS_SEG;
     w.lo_part = w.s64 + r;
     w.p_avoid = w.lo_part + r;
-    w.flag = (unsigned long long *)(w.p_avoid + r);
+    w.iv = w.p_avoid + r;
+    w.flag = (unsigned long long *)(w.iv + 3 * r);
     w.pick = w.flag + r * RS_FLAG_STRIDE;
     w.fin = w.pick + r;
     w.sel_row = (int32_t *)(w.fin + r);
@@ -564,7 +574,8 @@ __host__ __device__ inline RsWs rs_ws(void *ws, int64_t rows) {
     w.pick_u = (float *)(w.avoid + r);
     w.s64done = (uint32_t *)(w.pick_u + r);
     w.segdone = w.s64done + r * RS_SEG;
-    w.acceptdone = w.segdone + r * RS_SEG;
+    w.ivdone = w.segdone + r * RS_SEG;
+    w.acceptdone = w.ivdone + r;
     return w;
 }
 extern "C" size_t jf_rs_step_workspace_bytes(int64_t rows) { return rows > 0 ? rs_ws_bytes(rows) : 0; }
@@ -853,7 +864,7 @@ __device__ __forceinline__ void rs_probs_from_kept(const RsRow &row, int64_t e0,
 template <int DT, bool SIG, bool KEEP>
 __device__ __forceinline__ void rs_seg_prob_sums(const RsRow &row, int64_t lo, int64_t hi, double S, const RsWs &w, int item, int seg,
                                                  int64_t av, uint32_t gen, RsSumShared &sh, const float (&e32)[RsKeep<DT>::NV][Elem<DT>::EPV],
-                                                 u32x4 (&v)[RsKeep<DT>::NV]) {
+                                                 u32x4 (&v)[RsKeep<DT>::NV], int empty_from = RS_SEG /* SIG: this workgroup also stands in for the empty segments [empty_from, RS_SEG) */) {
     constexpr int EPV = Elem<DT>::EPV, NV = RsKeep<DT>::NV;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool mine = av >= lo && av < hi;                   // workgroup-uniform: this segment holds the avoided token
@@ -925,6 +936,7 @@ __device__ __forceinline__ void rs_seg_prob_sums(const RsRow &row, int64_t lo, i
         }
         if constexpr (SIG) {
             st_agent_f64(w.segsum + (int64_t)item * RS_SEG + seg, sum);
+            for (int e = empty_from; e < RS_SEG; ++e) st_agent_f64(w.segsum + (int64_t)item * RS_SEG + e, 0.0);
             if (mine) { st_agent_f64(w.lo_part + item, lo_p); st_agent_f64(w.p_avoid + item, p_av); }
             if (seg == 0) st_agent_f64(w.s64 + item, S);
         } else {
@@ -941,7 +953,10 @@ __device__ __forceinline__ void rs_seg_prob_sums(const RsRow &row, int64_t lo, i
     if constexpr (SIG) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the sums are performed before the word that announces them
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(w.segdone + (int64_t)item * RS_SEG + seg, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            __hip_atomic_store(w.segdone + (int64_t)item * RS_SEG + seg, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int e = empty_from; e < RS_SEG; ++e) __hip_atomic_store(w.segdone + (int64_t)item * RS_SEG + e, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     RS_PHASE(item, seg, 6);                                   // 6: announced
 }
@@ -950,9 +965,10 @@ __device__ __forceinline__ void rs_seg_prob_sums(const RsRow &row, int64_t lo, i
 // float64 partials through agent-scope words.  Returns false when a peer's partial did not arrive within the wait bound.
 template <int DT>
 __device__ __forceinline__ bool rs_rowsum_fused(const void *logits, int64_t V, int64_t row_stride, const float *row_max, const float *row_sumexp,
-                                                float t, const RsWs &w, int item, int seg, int r, int64_t av, uint32_t gen, RsSumShared &sh) {
+                                                float t, const RsWs &w, int item, int seg, int nact, int r, int64_t av, uint32_t gen, RsSumShared &sh) {
     constexpr int EPV = Elem<DT>::EPV, NV = RsKeep<DT>::NV;
     const int tid = threadIdx.x;
+    const int empty_from = seg == nact - 1 ? nact : RS_SEG;    // the row's last active segment stands in for the empty ones (zeros)
     const RsRow row = rs_make_row<DT>(logits, r, V, row_stride, t, row_max[r], row_sumexp[r]);
     const int64_t segE = rs_seg_elems(V, EPV);
     const int64_t lo = (int64_t)seg * segE;
@@ -978,8 +994,10 @@ __device__ __forceinline__ bool rs_rowsum_fused(const void *logits, int64_t V, i
         RS_PHASE(item, seg, 2);                               // 2: reduced
         if (tid == 0) {
             st_agent_f64(w.s64part + (int64_t)item * RS_SEG + seg, (sh.red[0] + sh.red[1]) + (sh.red[2] + sh.red[3]));
+            for (int e = empty_from; e < RS_SEG; ++e) st_agent_f64(w.s64part + (int64_t)item * RS_SEG + e, 0.0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(w.s64done + (int64_t)item * RS_SEG + seg, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int e = empty_from; e < RS_SEG; ++e) __hip_atomic_store(w.s64done + (int64_t)item * RS_SEG + e, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (tid < RS_SEG) {                                   // the 15 peers: consecutive block ids, dispatched together
             if (!rs_wait_word(w.s64done + (int64_t)item * RS_SEG + tid, gen)) sh.ok = 0;
@@ -991,8 +1009,8 @@ __device__ __forceinline__ bool rs_rowsum_fused(const void *logits, int64_t V, i
 #pragma unroll
         for (int s = 0; s < RS_SEG; ++s) S += sh.part[s];    // segment order: every workgroup of the row forms the same S
     }
-    if (keep) rs_seg_prob_sums<DT, true, true>(row, lo, hi, S, w, item, seg, av, gen, sh, e32, v);
-    else rs_seg_prob_sums<DT, true, false>(row, lo, hi, S, w, item, seg, av, gen, sh, e32, v);
+    if (keep) rs_seg_prob_sums<DT, true, true>(row, lo, hi, S, w, item, seg, av, gen, sh, e32, v, empty_from);
+    else rs_seg_prob_sums<DT, true, false>(row, lo, hi, S, w, item, seg, av, gen, sh, e32, v, empty_from);
     return true;
 }
 
@@ -1121,18 +1139,21 @@ __device__ __forceinline__ int rs_pick_wave(const RsRow &row, const RsWs &w, int
     // sum is walked with broadcasts
     const double *wtp = w.wtsum + ((int64_t)item * RS_SEG + sstar) * RS_WT;
     const double mywt = lane < nwt ? ld(wtp + lane) : 0.0;
+    auto wt_at = [&](int i) {                               // i is wave-uniform: two v_readlane (a shuffle is a trip through the LDS crossbar per step)
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mywt), i), __builtin_amdgcn_readlane(__double2loint(mywt), i));
+    };
     int istar = -1;
     double rel = 0.0;                                       // relative running sum in front of wave-tile istar
     {
         double r2 = 0.0;
         for (int i = 0; i < nwt; ++i) {
-            const double nx = r2 + __shfl(mywt, i, 64);
+            const double nx = r2 + wt_at(i);
             if (before + nx > thr) { istar = i; rel = r2; break; }
             r2 = nx;
         }
         if (istar < 0) {                                    // rounding only: the segment sum said it crosses here -> last wave-tile with mass
             double r3 = 0.0;
-            for (int i = 0; i < nwt; ++i) { const double wv = __shfl(mywt, i, 64); if (wv > 0.0) { istar = i; rel = r3; } r3 += wv; }
+            for (int i = 0; i < nwt; ++i) { const double wv = wt_at(i); if (wv > 0.0) { istar = i; rel = r3; } r3 += wv; }
             if (istar < 0) return (int)(hi - 1);
         }
     }
@@ -1425,14 +1446,17 @@ __device__ __forceinline__ void rs_accept_body(const RsAcceptIn &in, const int64
             // access of a step is the uniform at this row's stream offset.  SIG: the row's result goes to LDS only — wavefront 1
             // announces it (below): composing and storing the flag word is off this wavefront's instruction stream (~0.1 us per row)
             const int lane = tid;
-            const bool inrow = lane < W;
+            const unsigned long long rowmask = W >= 64 ? ~0ull : ((1ull << W) - 1ull);
+            const int lw = lane < W ? lane : W - 1;                 // lanes past the row read a valid entry and are masked out of every ballot
             int used_total = used_start, unc_at = -1, b = b_start;
+            bool try_run = true;                                    // at the start, and behind a row that stopped at its first test
             while (b < B) {                                         // JDN:326-348, rows in order
                 // A run of rows at once, a lane per row, on the assumption that every row of the run STOPS AT ITS FIRST TEST (the
                 // proposal at position 0 is rejected — what a draft that is not yet right gets — or is an accepted EOS): then each of
                 // them consumes exactly one uniform and the offsets of the whole run are known.  The run ends in front of the first
                 // row that accepts its first proposal (or whose first test is undecided); that row is walked the long way below.
-                {
+                // Tried only behind a row that stopped at its first test (such rows come in streaks: drafts go wrong together).
+                if (try_run) {
                     const int rb = b + lane;
                     bool ok0 = false, rej0 = false;
                     if (rb < B) {
@@ -1448,24 +1472,32 @@ __device__ __forceinline__ void rs_accept_body(const RsAcceptIn &in, const int64
                         __hip_atomic_store(&s_res[rb], rej0 ? (1 << 16) : (1 | (1 << 15)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     b += run;
                     used_total += run;
+                    try_run = run == 64;
                     if (run == 64 || b >= B) continue;
                 }
-                const uint32_t pe = inrow ? s_p[b * W + lane] : 0u;
-                const float uu = inrow ? s_u[used_total + lane] : 0.f;
-                const bool rejb = inrow && !(uu < __uint_as_float(pe & RS_PE_VAL));
-                const unsigned long long rejmask = __ballot(rejb);
-                const unsigned long long stopmask = rejmask | __ballot(inrow && (pe & RS_PE_EOS));
-                int nacc = W, eos = 0, rej = -1, used = W;
-                if (stopmask) {
-                    const int f = __builtin_ctzll(stopmask);
-                    if ((rejmask >> f) & 1ull) {
-                        const bool unc = rejb && (pe & RS_PE_AMB) && uu < rs_accept_hi<DT>(pe);
-                        if ((__ballot(unc) >> f) & 1ull) { unc_at = b * W + f; break; }   // the first stop is undecided: resolve it
-                        rej = f; nacc = f;
-                    } else { eos = 1; nacc = f + 1; }
+                // the long way: the row's words and the uniforms at its offset (the one dependent access), one ballot each for
+                // "accepted" and "EOS"; the second candidate of a rounding is looked at only when the first stop is a rejection
+                const uint32_t pe = s_p[b * W + lw];
+                const float uu = s_u[used_total + lw];
+                const unsigned long long accm = __ballot(uu < __uint_as_float(pe & RS_PE_VAL));
+                const unsigned long long eosm = __ballot((pe & RS_PE_EOS) != 0u);
+                const unsigned long long rejm = ~accm & rowmask;
+                const unsigned long long stopm = (rejm | eosm) & rowmask;
+                int res = W, used = W;                              // no stop: all W accepted (eos 0, rej -1)
+                if (stopm) {
+                    const int f = __builtin_ctzll(stopm);
+                    if ((rejm >> f) & 1ull) {
+                        const unsigned long long uncm = __ballot((pe & RS_PE_AMB) != 0u && uu < rs_accept_hi<DT>(pe));
+                        if ((uncm >> f) & 1ull) { unc_at = b * W + f; break; }   // the first stop is undecided: resolve it
+                        res = f | ((f + 1) << 16);                  // rejected at f: f accepted
+                        try_run = f == 0;
+                    } else {
+                        res = (f + 1) | (1 << 15);                  // EOS accepted at f
+                        try_run = f == 0;
+                    }
                     used = f + 1;
                 }
-                if (lane == 0) __hip_atomic_store(&s_res[b], nacc | (eos << 15) | ((rej + 1) << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane == 0) __hip_atomic_store(&s_res[b], res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 used_total += used;
                 ++b;
             }
@@ -1830,16 +1862,20 @@ __global__ __launch_bounds__(256) void rs_finish_kernel(int B, int L, unsigned l
 //                              uniform that counts as soon as the rows before it are counted
 //   block 2                    the end: waits for every row's finish word, then the pad offsets (one scan), the pads themselves
 //                              and the stream cursors — all that depends on more than one row
-//   blocks 3 .. B+2            row b: the bonus draw (ONE wavefront walks the hierarchical sums for the uniform it was handed,
-//                              or the masked argmax), then everything about the row that depends on this row alone — EOS,
-//                              row record, the next draft's seed and greedy tail, its argmax slots re-zeroed
-//   blocks B+3 ..              the sums of row (blk-B-3)/RS_SEG: wait for that row's flag; if it was rejected, phase A, the
-//                              exchange of the float64 partials with the row's 15 other workgroups, phase B
-// The B + 3 workgroups that wait for others come FIRST, the 16 B short ones last: with the roles in pipeline order the device
-// filled up with segment-sum workgroups spinning on the flags of late rows, and the chain / bonus workgroups were not even
-// dispatched before those had left.  A segment workgroup waits for block 0 and for its row's 15 peers (consecutive block
-// ids: dispatched together); jf_rs_step takes this path only when the device keeps at least 2 x (B + 3 + RS_SEG) workgroups
-// of the kernel resident (asked of the runtime), so the waiters can never fill it.  Every wait is bounded (2 s): a row that
+//   blocks 3 ..                nact per row (nact = the segments that hold any element: 15 of RS_SEG = 16 at V = 152 064), block
+//                              3 + b * nact + s = segment s of row b: wait for the row's flag; if the row was rejected, phase A,
+//                              the exchange of the float64 partials with the row's other workgroups, phase B (the last active
+//                              segment's workgroup also stores the zeros of the empty segments).  SEGMENT 0's workgroup then
+//                              stays as the row's own: the bonus draw (ONE wavefront walks the hierarchical sums for the
+//                              uniform the chain hands it, or the masked argmax), then everything about the row that depends
+//                              on this row alone — EOS, row record, the next draft's seed and greedy tail, its argmax slots
+//                              re-zeroed, the row's finish word.  (A row that was not rejected: its segment 0 finishes it at once.)
+// 64 rows are 3 + 960 workgroups: all resident at once at four per CU.  (Until round 4 every row had a sixteenth, empty
+// segment workgroup and a separate bonus workgroup, 1 091 in all: the last 67 — rows 60-63 — started when the first
+// ones left, ~17 us late, and the launch ended with them: profiles/rs_step_r04.txt.)  Waits only point backwards in dispatch
+// order — a row's workgroups wait for block 0 and for each other (consecutive ids), segment 0 for the chain, the chain for the
+// rows in order — so the launch cannot starve itself whatever the device keeps resident; jf_rs_step still asks the runtime
+// that 3 + 2 * RS_SEG workgroups of the kernel fit at once.  Every wait is bounded (2 s): a row that
 // times out reports JF_E_LAUNCH through rows[0].rsv.  All hand-off words carry the call's generation number (nothing to
 // re-zero, no stale reads); payloads cross workgroups as agent-scope atomics (a release fence per producer would write back
 // an L2 full of freshly written logits — profiles/verify_release_ab_r03.txt).
@@ -1859,40 +1895,21 @@ __device__ __forceinline__ void rs_report_timeout(jf_rs_row *rows) {
 }
 
 template <int DT>
-__global__ __launch_bounds__(256, 4) void rs_step_fused_kernel(RsFusedArgs a) {   // 4 workgroups per CU (<= 128 VGPRs, < 40 KB LDS): 64 rows' 1 024 segment workgroups are resident at once
+__global__ __launch_bounds__(256, 4) void rs_step_fused_kernel(RsFusedArgs a) {   // 4 workgroups per CU (<= 128 VGPRs, < 40 KB LDS): 64 rows' 963 workgroups are resident at once
     const int blk = blockIdx.x, tid = threadIdx.x;
     const int B = a.B, L = a.L, W = a.L - 1;
     const RsWs &w = a.w;
     // the roles' large LDS tables share one buffer (a workgroup has one role): accept words + uniforms (32 KB), the chain's
     // staged uniforms (8 KB), the end's pad window (8 KB) — a sum of them would cost the short roles their residency
     __shared__ __attribute__((aligned(16))) unsigned char s_big[2 * RS_FUSED_STAGE * 4];
+    // (raised wave priority — s_setprio 3 — for the role workgroups and a row's own workgroup, which share their CUs with three
+    // segment workgroups each, changed nothing: the serial paths are their own scalar bookkeeping and round trips)
     if (blk == 0) {
         RS_STAMP_MIN(0);                                             // 0: launch start (accept workgroup)
         const RsAcceptIn in{a.logits, a.V, a.row_stride, a.t, a.row_max, a.row_sumexp, a.p_draft};
         rs_accept_body<DT, true, true, RS_FUSED_ROWS>(in, a.draft, B, L, a.eos_id, a.u_stream, a.u_len, a.u_cursor,
                                                       a.committed, a.rows, w, a.gen, (uint32_t *)s_big, (float *)(s_big + RS_FUSED_STAGE * 4));
         RS_STAMP_MAX(1);                                             // 1: accept workgroup done (records + accept-done word)
-        return;
-    }
-    if (blk >= B + 3) {                                             // ---- segment sums (the many short workgroups come last)
-        const int item = (blk - B - 3) / RS_SEG, seg = (blk - B - 3) % RS_SEG;
-        __shared__ RsSumShared shs;
-        __shared__ int s_rej;
-        if (tid == 0) {
-            unsigned long long f;
-            s_rej = rs_wait_flag(w.flag + (int64_t)item * RS_FLAG_STRIDE, a.gen, &f) ? (int)(f & 0xFFFFull) - 2 : -3;
-        }
-        __syncthreads();
-        const int rej = s_rej;
-        if (rej == -3) { if (tid == 0) rs_report_timeout(a.rows); return; }
-        if (rej < 0) return;
-        if (tid == 0 && seg == 0) RS_ROWSTAMP(1, item);
-        if (!rs_rowsum_fused<DT>(a.logits, a.V, a.row_stride, a.row_max, a.row_sumexp, a.t, w, item, seg, item * W + rej,
-                                 a.draft[(int64_t)item * L + rej + 1], a.gen, shs)) {
-            if (tid == 0) rs_report_timeout(a.rows);
-            return;
-        }
-        if (tid == 0 && seg == 0) RS_ROWSTAMP(4, item);
         return;
     }
     if (blk == 1) {                                                 // ---- the chain: draws of all rows in stream order
@@ -1954,16 +1971,12 @@ __global__ __launch_bounds__(256, 4) void rs_step_fused_kernel(RsFusedArgs a) { 
                     if ((uint32_t)(v >> 32) == a.gen) rp = (int)(v & 0xFFFFull) - 2;
                 }
                 if (rp != -3) {
-                    bool sums_in = true;
-                    if (rp >= 0)
-                        for (int sg = 0; sg < RS_SEG; ++sg)
-                            sums_in &= __hip_atomic_load(w.segdone + (int64_t)i * RS_SEG + sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.gen;
+                    const bool sums_in = rp < 0 || __hip_atomic_load(w.ivdone + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.gen;
                     if (sums_in) {
                         double t_ = -1.0, lo_ = 0.0, hi_ = 0.0;
-                        if (rp >= 0) rs_interval<true>(w, i, a.V, Elem<DT>::EPV, t_, lo_, hi_, a.draft[(int64_t)i * L + rp + 1]);
+                        if (rp >= 0) { t_ = ld_agent_f64(w.iv + 3 * (int64_t)i); lo_ = ld_agent_f64(w.iv + 3 * (int64_t)i + 1); hi_ = ld_agent_f64(w.iv + 3 * (int64_t)i + 2); }
                         s_tot[i] = t_; s_lo[i] = lo_; s_hi[i] = hi_;
                         __hip_atomic_store(&s_ready[i], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        RS_ROWSTAMP(2, i);
                         fin = true;
                     }
                 }
@@ -2030,28 +2043,61 @@ __global__ __launch_bounds__(256, 4) void rs_step_fused_kernel(RsFusedArgs a) { 
         }
         return;                                                      // (wavefront 3 announces the end of the chain)
     }
-    if (blk >= 3) {                                                 // ---- row b (3 <= blk < B + 3 here): bonus draw, then the row's own finish
-        const int b = blk - 3;
+    if (blk >= 3) {                                                 // ---- row (blk-3)/nact: one segment's sums; segment 0's workgroup then draws the row's bonus token and finishes the row
+        const int nact = rs_active_segs(a.V, Elem<DT>::EPV);
+        const int item = (blk - 3) / nact, seg = (blk - 3) % nact, b = item;
+        __shared__ RsSumShared shs;
         __shared__ RsPickShared sh;
         __shared__ int s_rej, s_nacc, s_eos;
         __shared__ float s_uf;
         __shared__ double s_S;
-        rs_load_tab(sh.tab);
         if (tid == 0) {
-            unsigned long long f, pk = 0ull;
-            if (!rs_wait_flag(w.flag + (int64_t)b * RS_FLAG_STRIDE, a.gen, &f)) { s_rej = -3; }
-            else {
-                const int rp = (int)(f & 0xFFFFull) - 2;
-                s_rej = rp; s_nacc = (int)((f >> 16) & 0x3FFFull); s_eos = (int)((f >> 30) & 1ull);
-                if (rp >= 0) {
-                    if (!rs_wait_flag(w.pick + b, a.gen, &pk)) s_rej = -3;
-                    s_uf = __uint_as_float((uint32_t)pk);
-                    s_S = ld_agent_f64(w.s64 + b);                   // stored before the row's segment-done words the chain has seen
-                }
-            }
+            unsigned long long f;
+            if (!rs_wait_flag(w.flag + (int64_t)item * RS_FLAG_STRIDE, a.gen, &f)) s_rej = -3;
+            else { s_rej = (int)(f & 0xFFFFull) - 2; s_nacc = (int)((f >> 16) & 0x3FFFull); s_eos = (int)((f >> 30) & 1ull); }
         }
         __syncthreads();
-        const int rej = s_rej;
+        int rej = s_rej;
+        bool sums_ok = rej != -3;
+        if (rej >= 0) {
+            if (tid == 0 && seg == 0) RS_ROWSTAMP(1, item);
+            sums_ok = rs_rowsum_fused<DT>(a.logits, a.V, a.row_stride, a.row_max, a.row_sumexp, a.t, w, item, seg, nact, item * W + rej,
+                                          a.draft[(int64_t)item * L + rej + 1], a.gen, shs);
+            if (tid == 0 && seg == 0) RS_ROWSTAMP(4, item);
+        }
+        if (!sums_ok && tid == 0) rs_report_timeout(a.rows);
+        if (seg != 0) return;
+        // ---- segment 0's workgroup stays as the row's own.  First the row's CDF interval for the chain, as soon as the row's
+        // other segments are in (a lane per segment polls its word): the chain's thread of this row then waits for ONE word and
+        // reads three numbers (until round 4 it polled the RS_SEG words and formed the interval itself, in a loop shared with
+        // 63 other rows: a row's sums were noticed up to 6-10 us after they were stored)
+        if (rej >= 0) {
+            bool ok = sums_ok;
+            if (ok && tid < RS_SEG) ok = rs_wait_word(w.segdone + (int64_t)item * RS_SEG + tid, a.gen);
+            sums_ok = __syncthreads_and(ok ? 1 : 0) != 0;
+            if (tid == 0) {
+                double t_ = -1.0, lo_ = 0.0, hi_ = 0.0;
+                if (sums_ok) rs_interval<true>(w, b, a.V, Elem<DT>::EPV, t_, lo_, hi_, a.draft[(int64_t)b * L + rej + 1]);
+                else rs_report_timeout(a.rows);
+                st_agent_f64(w.iv + 3 * (int64_t)b, t_); st_agent_f64(w.iv + 3 * (int64_t)b + 1, lo_); st_agent_f64(w.iv + 3 * (int64_t)b + 2, hi_);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(w.ivdone + b, a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                RS_ROWSTAMP(2, b);
+            }
+        }
+        // ---- then the bonus draw (when the chain hands the uniform over) and the finish.  (Copying the row's sums and wave-tile
+        // tables into LDS while the uniform is on its way did not shorten the walk: its time is the vector loads and the exact
+        // probabilities of the 512 elements it ends in.)
+        rs_load_tab(sh.tab);
+        if (tid == 0 && sums_ok && rej >= 0) {
+            unsigned long long pk = 0ull;
+            if (!rs_wait_flag(w.pick + b, a.gen, &pk)) s_rej = -3;
+            s_uf = __uint_as_float((uint32_t)pk);
+            s_S = ld_agent_f64(w.s64 + b);                           // stored before the row's segment-done words the chain has seen
+        }
+        if (tid == 0 && !sums_ok) s_rej = -3;
+        __syncthreads();
+        rej = s_rej;
         if (rej == -3) { if (tid == 0) { rs_report_timeout(a.rows); __hip_atomic_store(w.fin + b, (unsigned long long)a.gen << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } return; }
         if (tid == 0) RS_ROWSTAMP(5, b);
         int n = s_nacc, eos = s_eos, bonus = -1;
@@ -2102,31 +2148,52 @@ __global__ __launch_bounds__(256, 4) void rs_step_fused_kernel(RsFusedArgs a) { 
     batched_for<8, int64_t>(padwin, tid, 256, [&](int64_t i) { return a.pad_stream[(pc0 + i) % a.pad_len]; }, [&](int64_t i, int64_t v) { s_pad[i] = (int32_t)v; });
     if (tid == 0) s_bad = 0;
     __syncthreads();
-    if (tid == 0) { if (!rs_wait_word(w.acceptdone, a.gen) || !rs_wait_word(w.acceptdone + 1, a.gen)) s_bad = 1; }   // n_uniforms, the draw counts
-    for (int i = tid; i < B; i += 256) {
-        unsigned long long f;
-        if (!rs_wait_flag(w.fin + i, a.gen, &f)) s_bad = 1;
-        s_np[i] = (int)(f & 0xFFFFull);
+    // wavefronts 2 and 3: the two stream cursors' increments as soon as their producers are done — the accept workgroup's row
+    // records (uniforms per row), the chain's draw counts — long before the last row finishes; wavefronts 0 and 1: a thread per
+    // row waits for the row's finish word (its pads).  Every word that crosses workgroups is read as an agent-scope load.
+    __shared__ int s_uc, s_bc;
+    if (tid >= 128) {
+        const int lane = tid & 63, which = (tid >> 6) - 2;           // 0: accept uniforms, 1: bonus draws
+        bool ok = true;
+        if (lane == 0) ok = rs_wait_word(w.acceptdone, a.gen) && (which == 0 || rs_wait_word(w.acceptdone + 1, a.gen));
+        if (__ballot(!ok) != 0ull) { if (lane == 0) s_bad = 1; }
+        else {
+            int tot = 0;
+            for (int b0 = 0; b0 < B; b0 += 64) {
+                const int r = b0 + lane;
+                int v = 0;
+                if (r < B) {
+                    if (which == 0) v = __hip_atomic_load(&a.rows[r].n_uniforms, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else if (__hip_atomic_load(&a.rows[r].reject_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0)
+                        v = __hip_atomic_load(&a.rows[r].n_bonus_draws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                int t_;
+                (void)wave_excl_scan_i32(v, lane, &t_);
+                tot += t_;
+            }
+            if (lane == 0) { if (which == 0) s_uc = tot; else s_bc = tot; }
+        }
+    } else {
+        for (int i = tid; i < B; i += 128) {
+            unsigned long long f;
+            if (!rs_wait_flag(w.fin + i, a.gen, &f)) s_bad = 1;
+            s_np[i] = (int)(f & 0xFFFFull);
+        }
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     RS_STAMP_MIN(12);                                                // 12: end workgroup has everything
     if (s_bad) { if (tid == 0) rs_report_timeout(a.rows); return; }
     if (tid < 64) {
-        int uc = 0, bc = 0, pc = 0;
+        int pc = 0;
         for (int b0 = 0; b0 < B; b0 += 64) {
-            const int b = b0 + tid;
-            const int nu = b < B ? a.rows[b].n_uniforms : 0;
-            const int nb = (b < B && a.rows[b].reject_pos >= 0) ? __hip_atomic_load(&a.rows[b].n_bonus_draws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-            const int np = b < B ? s_np[b] : 0;
-            int tu, tb, tp;
-            (void)wave_excl_scan_i32(nu, tid, &tu);
-            (void)wave_excl_scan_i32(nb, tid, &tb);
+            const int r = b0 + tid;
+            const int np = r < B ? s_np[r] : 0;
+            int tp;
             const int ep = wave_excl_scan_i32(np, tid, &tp);
-            if (b < B) s_off[b] = pc + ep;                            // this row's offset into the pad stream
-            uc += tu; bc += tb; pc += tp;
+            if (r < B) s_off[r] = pc + ep;                            // this row's offset into the pad stream
+            pc += tp;
         }
-        if (tid == 0) { *a.u_cursor += uc; *a.b_cursor += bc; s_pads = pc; }
+        if (tid == 0) { *a.u_cursor += s_uc; *a.b_cursor += s_bc; s_pads = pc; }
     }
     __syncthreads();
     RS_STAMP_MAX(25);                                                // 25: end: scans done
@@ -2330,8 +2397,9 @@ extern "C" int jf_rs_onpolicy_step(const void *logits, int dtype, int64_t V, int
     return check_launch("rs_onpolicy kernels");
 }
 
-// May the one-launch step carry B rows on this device?  Its B + 3 waiting workgroups and the 16 workgroups of a row that wait
-// for each other must never be able to fill the chip: at most half of what the runtime says it keeps resident.
+// May the one-launch step run on this device?  Its three role workgroups and the workgroups of two rows (a row's wait for each
+// other) must fit at once in HALF of what the runtime says it keeps resident; everything else only waits backwards
+// in dispatch order.
 static bool rs_fused_fits(const void *kern, int variant, int B) {
     static std::mutex mu;
     static int cap[2] = {-1, -1}, capdev[2] = {-1, -1};
@@ -2349,7 +2417,8 @@ static bool rs_fused_fits(const void *kern, int variant, int B) {
         cap[variant] = (int)(c > 0x7FFFFFFF ? 0x7FFFFFFF : c);
         capdev[variant] = dev;
     }
-    return B + 3 + RS_SEG <= cap[variant];
+    (void)B;
+    return 3 + 2 * RS_SEG <= cap[variant];
 }
 
 extern "C" int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_stride, const int64_t *draft, int B, int L,
@@ -2382,7 +2451,7 @@ extern "C" int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_
         if (gen == 0) gen = ++g_gen;
         RsFusedArgs a{logits, V, row_stride, draft, B, L, p_draft, row_max, row_sumexp, pk, t, eos_id, remaining, u_stream, u_len, u_cursor,
                       bonus_stream, bonus_len, bonus_cursor, pad_stream, pad_len, pad_cursor, committed, next_draft, rows, w, gen};
-        const unsigned grid = (unsigned)(1 + B * RS_SEG + 1 + B + 1);
+        const unsigned grid = (unsigned)(3 + B * rs_active_segs(V, dtype == JF_F32 ? 4 : 8));
         if (dtype == JF_F32) rs_step_fused_kernel<JF_F32><<<grid, 256, 0, s>>>(a);
         else rs_step_fused_kernel<JF_BF16><<<grid, 256, 0, s>>>(a);
         return check_launch("rs_step_fused_kernel");

@@ -68,7 +68,7 @@ def main():
         rb = (C.c_ulonglong * 1024)()
         lib.jf_exp_rs_rows(rb)
         r = np.array(rb[:], dtype=np.float64).reshape(8, 128)
-        print("# last launch, per row: flag stored by the accept walk / segment 0 saw it / segment 0 stored / sums ready in the chain / uniform handed out / bonus workgroup has it / bonus token stored (us)")
+        print("# last launch, per row: flag stored by the accept walk / segment 0 saw it / segment 0 stored / interval published by segment 0 / uniform handed out / bonus workgroup has it / bonus token stored (us)")
         for b_ in list(range(0, B, 8)) + [B - 1]:
             print(f"#   row {b_:3d}: " + "  ".join(f"{(r[k, b_] - t0) / 100.0:7.1f}" for k in (0, 1, 4, 2, 3, 5, 6)))
         if hasattr(lib, "jf_exp_rs_phases"):
