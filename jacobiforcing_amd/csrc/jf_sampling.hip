@@ -843,16 +843,27 @@ __device__ __forceinline__ double rs_seg_exp_sum(const RsRow &row, int64_t lo, i
 // rounding is certain unless a bf16 boundary lies inside the 2^-21 band around it (1 element in ~8 000: float64 quotient)
 template <int DT>
 __device__ __forceinline__ void rs_probs_from_kept(const RsRow &row, int64_t e0, const float (&e)[Elem<DT>::EPV], double invS, float invS32,
-                                                   const double *tab, float (&p)[Elem<DT>::EPV]) {
+                                                   uint32_t tiny_m1, const double *tab, float (&p)[Elem<DT>::EPV]) {
     constexpr int EPV = Elem<DT>::EPV;
-    bool slow = false;
+    // two elements per instruction: v_pk_mul_f32 for the product and its two band ends, v_cvt_pk_bf16_f32 for the roundings
+    // (gfx950's conversion is RNE for every non-NaN pattern: tools/experiments/cvt_bf16_exhaustive.hip); the pair is certain when
+    // both ends round to the same bf16.  tiny_m1: bits of (1e-36 / invS32) - 1 — a nonzero exp below it has a product near
+    // float32's subnormal range, inexact in itself (unsigned compare of bits - 1: zero wraps to the top)
+    const rs_f32x2 s2 = {invS32, invS32}, lo2 = {0.99999952316284179688f, 0.99999952316284179688f}, hi2 = {1.00000047683715820312f, 1.00000047683715820312f};   // 1 -+ 2^-21
+    uint32_t diff = 0u, emin = 0xFFFFFFFFu;
 #pragma unroll
-    for (int j = 0; j < EPV; ++j) {
-        const float q = e[j] * invS32;
-        const float a = bf16_rne(q * 0.99999952316284179688f), b = bf16_rne(q * 1.00000047683715820312f);   // 1 -+ 2^-21
-        p[j] = a;
-        slow |= (a != b) || (q < 1e-36f && e[j] != 0.f);     // near float32's subnormal range the product itself is inexact
+    for (int j = 0; j < EPV; j += 2) {
+        const rs_f32x2 q = rs_f32x2{e[j], e[j + 1]} * s2;
+        const uint32_t ha = __builtin_bit_cast(uint32_t, __builtin_convertvector(q * lo2, rs_bf16x2));
+        const uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_convertvector(q * hi2, rs_bf16x2));
+        p[j] = __uint_as_float(ha << 16);
+        p[j + 1] = __uint_as_float(ha & 0xFFFF0000u);
+        diff |= ha ^ hb;
+        const uint32_t b0 = __float_as_uint(e[j]) - 1u, b1 = __float_as_uint(e[j + 1]) - 1u;
+        emin = b0 < emin ? b0 : emin;
+        emin = b1 < emin ? b1 : emin;
     }
+    const bool slow = diff != 0u || emin < tiny_m1;
     // out of the straight-line path; the vector is read again (L2) rather than kept in registers across the exchange of the partials
     if (__builtin_expect(slow, 0)) rs_exact_probs_from_vec<DT>(row, rs_load_vec<DT>(row, e0), invS, tab, p);
 }
@@ -873,6 +884,7 @@ __device__ __forceinline__ void rs_seg_prob_sums(const RsRow &row, int64_t lo, i
     const int tstar = mine ? (int)((avo % (256 * EPV)) / EPV) : -1;
     const double invS = S > 0.0 ? 1.0 / S : 0.0;
     const float invS32 = (float)invS;
+    const uint32_t tiny_m1 = __float_as_uint(1.0e-36f / (invS32 > 0.f ? invS32 : 1.f)) - 1u;   // (S >= 1: the quotient is a normal float)
     const int ntiles = (int)((hi - lo + 256 * EPV - 1) / (256 * EPV));
     const bool hier = ntiles * 4 <= RS_WT;
     double base = 0.0, front = 0.0;                          // !hier: running sum of the tiles before / in front of the token's wavefront
@@ -890,7 +902,7 @@ __device__ __forceinline__ void rs_seg_prob_sums(const RsRow &row, int64_t lo, i
             for (int j = 0; j < EPV; ++j) p[j] = 0.f;
             if (e0 < hi) {
                 if constexpr (KEEP && DT == JF_BF16) {
-                    if (__builtin_expect(invS > 0.0, 1)) rs_probs_from_kept<DT>(row, e0, e32[k], invS, invS32, sh.tab, p);
+                    if (__builtin_expect(invS > 0.0, 1)) rs_probs_from_kept<DT>(row, e0, e32[k], invS, invS32, tiny_m1, sh.tab, p);
                     else rs_probs_from_vec<DT>(row, rs_load_vec<DT>(row, e0), p);
                 } else {
                     rs_any_probs_from_vec<DT>(row, v[k], invS, sh.tab, p);
@@ -920,13 +932,17 @@ __device__ __forceinline__ void rs_seg_prob_sums(const RsRow &row, int64_t lo, i
     }
     RS_PHASE(item, seg, 4);                                   // 4: phase B probabilities + scans done
     __syncthreads();
-    if (tid == 0) {
-        double sum = base;
-        if (hier) {
-            sum = 0.0;
-            const int istar = mine ? kstar * 4 + (tstar >> 6) : -1;
-            for (int i = 0; i < ntiles * 4; ++i) { if (i == istar) front = sum; sum += sh.wt[i]; }
+    double sum = base;
+    if (hier && tid < 64) {                                  // the table's running sum in order: one LDS read per lane, then broadcasts
+        const double mywt = tid < ntiles * 4 ? sh.wt[tid] : 0.0;   // (a read per step of the sum was ~1 us of this workgroup's tail)
+        sum = 0.0;
+        const int istar = mine ? kstar * 4 + (tstar >> 6) : -1;
+        for (int i = 0; i < ntiles * 4; ++i) {
+            if (i == istar) front = sum;
+            sum += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mywt), i), __builtin_amdgcn_readlane(__double2loint(mywt), i));
         }
+    }
+    if (tid == 0) {
         double lo_p = 0.0, p_av = 0.0;
         if (mine) {                                          // the running sum in front of the token, formed as the walk forms it
             double rr = front + sh.excl;
