@@ -1429,7 +1429,8 @@ __device__ __forceinline__ void rs_accept_body(const RsAcceptIn &in, const int64
     __syncthreads();
     if constexpr (STAGED) {
         const int ul = (int)u_len, ub = (int)(uc0 % u_len);
-        // every test's word and uniform in ONE round of loads (at most n uniforms can be used)
+        // every test's word and uniform in ONE round of loads (at most n uniforms can be used); the loads that do not wait for
+        // the stream cursor are issued first, and the stream index wraps by subtraction (an integer division is ~40 instructions)
         for (int i0 = tid; i0 < n; i0 += 8 * 256) {
             int64_t tk[8];
             float M[8], pd[8], uu[8];
@@ -1438,9 +1439,19 @@ __device__ __forceinline__ void rs_accept_body(const RsAcceptIn &in, const int64
                 const int i = i0 + k * 256;
                 tk[k] = -1; M[k] = 0.f;
                 if (i < n) {
-                    uu[k] = u_stream[(ub + i) % ul]; pd[k] = in.p_draft[i];
+                    pd[k] = in.p_draft[i];
                     if (eos_id >= 0) tk[k] = tok_at(i);
                     if constexpr (DT == JF_F32) M[k] = in.row_max[i];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + k * 256;
+                if (i < n) {
+                    unsigned x = (unsigned)ub + (unsigned)i;
+                    if (x >= (unsigned)ul) x -= (unsigned)ul;
+                    if (x >= (unsigned)ul) x %= (unsigned)ul;       // streams shorter than the batch's tests (tests only)
+                    uu[k] = u_stream[x];
                 }
             }
 #pragma unroll
@@ -2117,6 +2128,12 @@ __global__ __launch_bounds__(256, 4) void rs_step_fused_kernel(RsFusedArgs a) { 
         if (rej == -3) { if (tid == 0) { rs_report_timeout(a.rows); __hip_atomic_store(w.fin + b, (unsigned long long)a.gen << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } return; }
         if (tid == 0) RS_ROWSTAMP(5, b);
         int n = s_nacc, eos = s_eos, bonus = -1;
+        // the next draft's greedy tail depends on the NUMBER of committed tokens only, which is known before the bonus token is
+        // (a rejected row commits its accepted tokens + 1): its argmax words are loaded ahead of the walk, not behind it
+        int pre_off = 0, pre_len = 0;
+        rs_next_shape(n + (rej >= 0 ? 1 : 0), L, pre_off, pre_len);
+        unsigned long long pre_tail = 0ull;
+        if (tid >= 1 && tid < 1 + pre_len && tid < 256) pre_tail = a.packed[(int64_t)b * W + pre_off + (tid - 1)];
         if (rej >= 0) {
             const int64_t r = (int64_t)b * W + rej;
             if (b == B - 1) RS_STAMP_MAX(17);                        // 17: last row's bonus workgroup has its uniform
@@ -2135,7 +2152,7 @@ __global__ __launch_bounds__(256, 4) void rs_step_fused_kernel(RsFusedArgs a) { 
             for (int i = tid; i < 1 + copy_len; i += 256) {
                 int64_t v;
                 if (i == 0) v = rej >= 0 ? (int64_t)bonus : a.draft[(int64_t)b * L + n];     // the last committed token
-                else v = jfmb::decode_packed(a.packed[r0 + off + (i - 1)]);
+                else v = jfmb::decode_packed(i < 256 ? pre_tail : a.packed[r0 + off + (i - 1)]);   // (off == pre_off, copy_len == pre_len)
                 a.next_draft[(int64_t)b * L + i] = v;
             }
         }
@@ -2158,7 +2175,8 @@ __global__ __launch_bounds__(256, 4) void rs_step_fused_kernel(RsFusedArgs a) { 
     __shared__ int s_np[RS_FUSED_ROWS], s_off[RS_FUSED_ROWS];
     int32_t *s_pad = (int32_t *)s_big;                                // [2048]
     __shared__ int s_bad, s_pads;
-    const int64_t pc0 = *a.pad_cursor;                               // (nobody else writes it: loaded while the rows are still at work)
+    const int64_t pc0 = *a.pad_cursor;                               // (nobody else writes the cursors: loaded while the rows are still at work,
+    const int64_t uc0 = *a.u_cursor, bc0 = *a.b_cursor;              //  not as a read-modify-write at the very end)
     // the pad stream's window this call can touch (at most L - 2 per row), staged while the rows are still at work
     const int padwin = B * (L - 2) < 2048 ? B * (L - 2) : 2048;
     batched_for<8, int64_t>(padwin, tid, 256, [&](int64_t i) { return a.pad_stream[(pc0 + i) % a.pad_len]; }, [&](int64_t i, int64_t v) { s_pad[i] = (int32_t)v; });
@@ -2209,7 +2227,7 @@ __global__ __launch_bounds__(256, 4) void rs_step_fused_kernel(RsFusedArgs a) { 
             if (r < B) s_off[r] = pc + ep;                            // this row's offset into the pad stream
             pc += tp;
         }
-        if (tid == 0) { *a.u_cursor += s_uc; *a.b_cursor += s_bc; s_pads = pc; }
+        if (tid == 0) { *a.u_cursor = uc0 + s_uc; *a.b_cursor = bc0 + s_bc; s_pads = pc; }
     }
     __syncthreads();
     RS_STAMP_MAX(25);                                                // 25: end: scans done
