@@ -26,12 +26,28 @@ timeout 1500 bash tools/pmc_verify.sh > $O/r4z_pmc_verify.log 2>&1; cp $O/pmc/pm
 # in-kernel timeline and anatomy
 for P in 1 8 64; do echo "## tools/verify_trace_insitu.py --prompts $P"; JF_LIB=tools/libjf_exp_vtrace.so timeout 400 python tools/verify_trace_insitu.py --prompts $P --iters 24 2>&1 | grep -v amdgpu.ids | grep "^#"; done > $O/r4z_vtrace_insitu.txt
 echo "## tools/verify_trace_insitu.py --scripted --iters 40" >> $O/r4z_vtrace_insitu.txt; JF_LIB=tools/libjf_exp_vtrace.so timeout 400 python tools/verify_trace_insitu.py --scripted --iters 40 2>&1 | grep "^#" >> $O/r4z_vtrace_insitu.txt
+# the straight-line step's stages, and the step run twice through the same instructions (instruction fetch vs issue time)
+JF_LIB=tools/libjf_exp_vtrace.so timeout 400 python tools/verify_trace.py --prompts 1 8 64 --iters 12 2>&1 | grep -v "amdgpu.ids\|^      stepper\|item workgroups" > $O/r4z_step_stages.txt
+echo "## -DJF_EXP_STEP_TWICE, JF_EXP_TWICE=1" >> $O/r4z_step_stages.txt
+JF_LIB=tools/libjf_exp_vtrace2.so JF_EXP_TWICE=1 timeout 400 python tools/verify_trace.py --prompts 1 8 64 --iters 12 2>&1 | grep -v "amdgpu.ids\|^      stepper\|item workgroups" >> $O/r4z_step_stages.txt
 # sampling step
 for DT in bf16 f32; do for F in 1 0; do JF_RS_FUSED=$F timeout 300 python tools/microbench_rs_step.py --dtype $DT --temperature 0.8 2>&1 | grep -v amdgpu.ids | head -1 | sed "s/^/fused=$F /"; done; done > $O/r4z_rs_step.txt
 JF_LIB=tools/libjf_exp_rstrace.so timeout 300 python tools/microbench_rs_step.py --dtype bf16 --temperature 0.8 --trace 2>&1 | grep -v amdgpu.ids >> $O/r4z_rs_step.txt
 JF_LIB=tools/libjf_exp_rstrace.so timeout 300 python tools/microbench_rs_step.py --dtype bf16 --temperature 0.8 --trace --p-hit 0.001 2>&1 | grep -v amdgpu.ids >> $O/r4z_rs_step.txt
 timeout 300 python tools/microbench_rs.py > $O/r4z_rs_probs.txt 2>&1
 timeout 900 python tools/engine_throughput.py --batch 64 --block-len 32 --max-tokens 96 > $O/r4z_engine.txt 2>&1
+# the non-greedy engine loop under the profiler: the sampling kernels' durations inside the decode step
+rm -rf /tmp/prof_ng
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ng -- python $GRAFT_REPO_ROOT/tools/engine_throughput.py --batch 64 --block-len 32 --max-tokens 64 --only "T=0.8" > /dev/null 2>&1)
+python - > $O/r4z_rs_insitu_rocprof.txt <<'PYEOF'
+import csv, glob
+f = glob.glob("/tmp/prof_ng/**/*kernel_stats.csv", recursive=True)[0]
+print("# rocprofv3 --kernel-trace --stats -- python tools/engine_throughput.py --batch 64 --block-len 32 --max-tokens 64 --only T=0.8")
+print("# (engine non-greedy Jacobi decoding, 64 requests x block 32, V = 152064, bf16): this package's sampling kernels inside the decode step")
+for r in csv.DictReader(open(f)):
+    if "rs_" in r["Name"]:
+        print(f"{r['Name'].split('(')[0][:70]:70s} calls {r['Calls']:>5s}  avg {float(r['AverageNs']) / 1e3:8.1f} us  min {float(r['MinNs']) / 1e3:8.1f}  max {float(r['MaxNs']) / 1e3:8.1f}")
+PYEOF
 # soaks
 JF_FUZZ_SCALE=100 timeout 1500 python -m pytest tests/test_engine_fuzz.py tests/test_multiblock_fuzz.py -m gpu -n 12 -q -p no:cacheprovider > $O/r4z_soak100.log 2>&1; tail -4 $O/r4z_soak100.log
 JF_FUZZ_SCALE=100 timeout 1500 python -m pytest tests/test_loop_fuzz.py -m gpu -n 12 -q -p no:cacheprovider > $O/r4z_loopsoak.log 2>&1; tail -3 $O/r4z_loopsoak.log
