@@ -565,13 +565,15 @@ def test_rs_step_batch_matches_sequential_reference(p_hit, u_value):
 @GPU
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("B,L,V", [(6, 5, 2048), (6, 5, 2049), (5, 9, 5000), (7, 5, 20000), (4, 9, 40000), (3, 5, 32768), (128, 9, 3000),
-                                   (1, 2, 152064)],
-                         ids=["one_segment", "two_segments", "three", "ten_bf16", "sixteen_f32", "sixteen_full", "128_rows", "one_row_one_test"])
+                                   (1, 2, 152064), (100, 5, 152064)],
+                         ids=["one_segment", "two_segments", "three", "ten_bf16", "sixteen_f32", "sixteen_full", "128_rows", "one_row_one_test",
+                              "more_workgroups_than_resident"])
 def test_rs_step_segment_counts_and_batches(B, L, V, dtype):
     """The one-launch step gives a row one workgroup per NON-EMPTY vocabulary segment (1 ... 16 of them, by V and dtype), the
     last one standing in for the empty ones, and segment 0's workgroup draws the row's bonus token: every count of active
-    segments, a batch of the launch's maximum of 128 rows, and the smallest call (one row, one test), against the row-by-row
-    restatement."""
+    segments, a batch of the launch's maximum of 128 rows, the smallest call (one row, one test), and 100 rows at the real
+    vocabulary (3 + 1 500 workgroups for 1 024 resident slots: waits only point backwards in dispatch order), against the
+    row-by-row restatement."""
     a = _run_rs("hip", B, L, V, 31 + V % 7, 0.5, None, dtype, 0.9, eos=3)
     b = _run_rs("hostsim", B, L, V, 31 + V % 7, 0.5, None, dtype, 0.9, eos=3)
     f = N.RS_FIELDS.index
