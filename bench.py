@@ -198,11 +198,29 @@ def run_steps(dec: MultiblockJacobiDecoder, prompts, warmup: int, steps: int, se
 class StageTimer:
     """HIP events around named library stages (ops.STAGE_HOOK: jf_rs_probs, jf_rs_step, the single-block body)."""
 
+    ATTACH = ("rs_probs", "rs_step")     # single library calls: their events ride on the call's own dispatches (jf_timing_arm)
+
     def __init__(self):
-        self.done, self._open = {}, {}
+        self.done, self._open, self._pool = {}, {}, []
+        self.attached = os.environ.get("JF_VERIFY_EVENTS", "")[:1] != "b"
+
+    def _event(self):
+        """An event whose handle exists (recorded once), for the library to attach to a dispatch."""
+        if not self._pool:
+            for _ in range(256):
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                self._pool.append(e)
+        return self._pool.pop()
 
     def __enter__(self):
         def hook(name, phase, nbytes):
+            if phase == "arm":
+                if not (self.attached and name in self.ATTACH):
+                    return None                      # -> "begin" / "end" around the call
+                a, b = self._event(), self._event()
+                self.done.setdefault(name, []).append((a, b, nbytes))
+                return a, b
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             if phase == "begin":
@@ -210,8 +228,14 @@ class StageTimer:
             else:
                 a, nb = self._open.pop(name)
                 self.done.setdefault(name, []).append((a, e, nb))
+            return None
         ops.STAGE_HOOK = hook
         return self
+
+    def timing(self, name):
+        return ("HIP events attached to the call's dispatches (jf_timing_arm -> hipExtLaunchKernel: start of its first launch, stop of "
+                "its last; the kernels' own duration, the figure rocprofv3 reports)" if self.attached and name in self.ATTACH else
+                "HIP events recorded in front of and behind the call (launches + two event packets)")
 
     def __exit__(self, *exc):
         ops.STAGE_HOOK = None
@@ -295,16 +319,23 @@ def nongreedy_section(model, cfg, weights, tuned, P: int = 64, L: int = 32, temp
     toks = sum(len(r["token_ids"]) for r in res)
     its = len(st.done.get("rs_step", [])) or 1
     del llm
+    if probs is not None:
+        probs = dict(probs)
+    out_roof = roof(probs, "rs_probs_partial_kernel + rs_probs_finish_kernel (jf_rs_probs: softmax-gather + argmax, the "
+                           "logits read once)")
+    out_step = roof(step, "jf_rs_step (accept walk, float64 segment sums of the rejected rows, draw counting, one inverse-CDF "
+                          "walk per rejected row, next drafts)",
+                    "bytes = one rejected row (V x 2 B) per draft row per launch: the rows the step re-reads")
+    if out_roof is not None:
+        out_roof["timing"] = st.timing("rs_probs")
+    if out_step is not None:
+        out_step["timing"] = st.timing("rs_step")
     return dict(workload=f"BASELINE config 5 decoding: engine non-greedy Jacobi (rejection-sampling verify), batch {P} x block {L}, "
                          f"temperature {temperature}, bf16 logits, {max_tokens} tokens per request, prefill included "
                          "(LLM.generate on the bench's random-init weights: acceptance ~1 token per forward)",
                 value=toks / dt, unit="tokens/s", tokens=toks, seconds=dt, iterations=its, ms_per_step=dt / its * 1e3,
                 tokens_per_forward=toks / (its * P),
-                roofline=roof(probs, "rs_probs_partial_kernel + rs_probs_finish_kernel (jf_rs_probs: softmax-gather + argmax, the "
-                                     "logits read once)"),
-                rs_step=roof(step, "jf_rs_step (accept walk, float64 segment sums of the rejected rows, draw counting, one inverse-CDF "
-                                   "walk per rejected row, next drafts)",
-                             "bytes = one rejected row (V x 2 B) per draft row per launch: the rows the step re-reads"))
+                roofline=out_roof, rs_step=out_step)
 
 
 def vs_ar_section(model, cfg, prm, tuned, vocab_hi, robust, warmup: int = 8, steps: int = 40, ar_tokens: int = 64):
@@ -608,6 +639,11 @@ def main():
                                "frac": roof["gbs"] / HBM_PEAK_GBS, "traffic": _pmc_traffic(roof),
                                "traffic_source": _pmc_source(),
                                "kernel": VERIFY_KERNEL,
+                               "timing": ("HIP events recorded in front of and behind the launch (JF_VERIFY_EVENTS=bracket: launch + two event "
+                                          "packets)" if os.environ.get("JF_VERIFY_EVENTS", "")[:1] == "b" else
+                                          "HIP events attached to the launch's dispatch (hipExtLaunchKernel start / stop: the kernel's own "
+                                          "duration, the figure rocprofv3 reports; JF_VERIFY_EVENTS=bracket records them around the launch "
+                                          "instead, ~3-4 us more)"),
                                "bytes_per_launch": roof["avg_bytes"], "us_per_launch": roof["avg_us"],
                                "rows_per_launch": roof["avg_rows"], "logits_rows_per_launch": roof["avg_launched_rows"],
                                "note": "logits rows beyond rows_per_launch are list padding (lm_head M on the tuned grid); the "

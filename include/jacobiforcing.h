@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define JF_VERSION 400
+#define JF_VERSION 410
 
 enum {
     JF_OK = 0,
@@ -44,6 +44,13 @@ enum {
 enum { JF_F32 = 0, JF_BF16 = 1 };
 
 JF_API int jf_version(void);
+/* Timing of ONE call from outside (bench.py's per-kernel figures): the events armed here (nullable hipEvent_t, created with
+ * timing enabled) are taken by the NEXT call of jf_rs_probs or jf_rs_step on this thread and carry the START timestamp of that
+ * call's first launch and the STOP timestamp of its last one (hipExtLaunchKernel: the dispatches' own timestamps, what rocprofv3
+ * reports as kernel durations) — not the time of two event packets around them.  JF_VERIFY_EVENTS=bracket, or a call that takes
+ * several launches on its slow path, records them in front of and behind the launches instead.  Other entry points ignore it;
+ * jf_mb_loop_iterate takes its events as arguments. */
+JF_API int jf_timing_arm(void *ev_begin, void *ev_end);
 JF_API const char *jf_last_error(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -272,8 +279,10 @@ JF_API int jf_mb_loop_begin(const jf_mb_loop *loop, int32_t seq, const jf_mb_par
 JF_API int jf_mb_loop_iterate(const jf_mb_loop *loop, int32_t seq, const void *logits, int dtype, int64_t R, int64_t V,
                        int64_t row_stride, int compacted, int32_t Rtot, int32_t Tpad, const jf_mb_params *params,
                        int queue_pack, void *ev_begin, void *ev_end, void *stream);
-/* ev_begin / ev_end (nullable hipEvent_t): recorded on `stream` immediately before and after the convergence launch — a
- * caller's timing of that launch alone without splitting the call (the pack launch still follows at once). */
+/* ev_begin / ev_end (nullable hipEvent_t): a caller's timing of the convergence launch alone without splitting the call (the
+ * pack launch still follows at once).  They carry the START and STOP timestamps of that launch's dispatch (hipExtLaunchKernel:
+ * the kernel's own duration, what rocprofv3 reports); with JF_VERIFY_EVENTS=bracket in the environment, or when the check runs
+ * as its two launches, they are recorded on `stream` immediately before and after it instead (launch + two event packets). */
 /* The pack step alone (queue_pack = 0 above: a caller that brackets the convergence launch with its own events); it is the
  * launch that stamps the mailbox with `seq`. */
 JF_API int jf_mb_loop_pack(const jf_mb_loop *loop, int32_t seq, const jf_mb_params *params, void *stream);

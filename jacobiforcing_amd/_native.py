@@ -99,6 +99,7 @@ _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_si
 
 _SIGNATURES = {
     "jf_version": (C.c_int, []),
+    "jf_timing_arm": (C.c_int, [C.c_void_p, C.c_void_p]),
     "jf_last_error": (C.c_char_p, []),
     "jf_argmax_partial": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _vp, _vp]),
     "jf_argmax_scatter": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _vp, _vp, _vp]),

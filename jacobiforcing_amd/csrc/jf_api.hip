@@ -17,5 +17,17 @@ int check_launch(const char *what) {
     return JF_OK;
 }
 
+static thread_local JfTiming g_timing;
+extern "C" int jf_timing_arm(void *ev_begin, void *ev_end) {
+    g_timing.begin = (hipEvent_t)ev_begin;
+    g_timing.end = (hipEvent_t)ev_end;
+    return JF_OK;
+}
+JfTiming jf_take_timing() { const JfTiming t = g_timing; g_timing = JfTiming{}; return t; }
+bool jf_timing_bracket() {
+    static const bool b = [] { const char *e = getenv("JF_VERIFY_EVENTS"); return e && e[0] == 'b'; }();
+    return b;
+}
+
 extern "C" int jf_version(void) { return JF_VERSION; }
 extern "C" const char *jf_last_error(void) { return g_err; }

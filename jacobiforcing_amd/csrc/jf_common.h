@@ -25,6 +25,10 @@
 // ---- error plumbing (jf_api.hip) ------------------------------------------------------------------
 int fail(int code, const char *fmt, ...);          // records the message for jf_last_error(), returns `code`
 int check_launch(const char *what);                // JF_OK or JF_E_LAUNCH after a kernel launch
+// jf_timing_arm: events the NEXT timed entry point called on this thread attaches to its launch(es) (taken = cleared)
+struct JfTiming { hipEvent_t begin = nullptr, end = nullptr; bool any() const { return begin || end; } };
+JfTiming jf_take_timing();
+bool jf_timing_bracket();                          // JF_VERIFY_EVENTS=bracket: record the events around the launch instead
 
 // ------------------------------------------------------------------------------------------------
 // wave-level helpers (wavefront = 64 lanes)

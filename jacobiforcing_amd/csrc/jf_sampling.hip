@@ -13,6 +13,7 @@
 //   the logits), and every DECISION of the steps is made on the exact value.
 #include "jf_common.h"
 
+#include <hip/hip_ext.h>
 #include <atomic>
 #include <mutex>
 
@@ -452,6 +453,7 @@ extern "C" size_t jf_rs_workspace_bytes(int64_t R, int64_t V) {
 extern "C" int jf_rs_probs(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, const int64_t *draft_next,
                            float temperature, float *p_draft, float *row_max, float *row_sumexp, uint64_t *packed,
                            void *workspace, size_t workspace_bytes, void *stream) {
+    const JfTiming tm = jf_take_timing();                            // events armed for this call (jf_timing_arm): taken whatever happens below
     if (R <= 0) return JF_OK;
     if (!logits || !draft_next || !p_draft || !row_max || !row_sumexp || !packed || !workspace)
         return fail(JF_E_INVALID, "jf_rs_probs: null pointer");
@@ -469,18 +471,36 @@ extern "C" int jf_rs_probs(const void *logits, int dtype, int64_t R, int64_t V, 
     unsigned long long *pk = (unsigned long long *)packed;
     float2 *part = (float2 *)workspace;
     const bool unit = (t == 1.f);
-#define JF_RS_P(DT, VECF, SC) rs_probs_partial_kernel<DT, VECF, SC><<<grid, block, 0, s>>>(logits, R, V, row_stride, t, inv_t, part, pk, (int)cpr, chunk)
+    // timing events armed for this call (jf_timing_arm): the first launch's start and the second launch's stop timestamps
+    const bool attach = tm.any() && !jf_timing_bracket();
+    if (tm.begin && !attach) (void)hipEventRecord(tm.begin, s);
+    const dim3 fgrid((unsigned)((R + 255) / 256));
+#define JF_RS_P(DT, VECF, SC)                                                                                                             \
+    do {                                                                                                                                  \
+        if (attach) hipExtLaunchKernelGGL((rs_probs_partial_kernel<DT, VECF, SC>), grid, block, 0, s, tm.begin, nullptr, 0, logits, R, V, \
+                                          row_stride, t, inv_t, part, pk, (int)cpr, chunk);                                               \
+        else rs_probs_partial_kernel<DT, VECF, SC><<<grid, block, 0, s>>>(logits, R, V, row_stride, t, inv_t, part, pk, (int)cpr, chunk); \
+    } while (0)
+#define JF_RS_F(DT)                                                                                                                       \
+    do {                                                                                                                                  \
+        if (attach) hipExtLaunchKernelGGL((rs_probs_finish_kernel<DT>), fgrid, block, 0, s, nullptr, tm.end, 0, logits, R, V, row_stride, \
+                                          draft_next, t, inv_t, (const float2 *)part, (int)cpr, p_draft, row_max, row_sumexp);            \
+        else rs_probs_finish_kernel<DT><<<fgrid, block, 0, s>>>(logits, R, V, row_stride, draft_next, t, inv_t, part, (int)cpr, p_draft,  \
+                                                                  row_max, row_sumexp);                                                    \
+    } while (0)
     if (dtype == JF_F32) {
         if (vec) { if (unit) JF_RS_P(JF_F32, true, 0); else JF_RS_P(JF_F32, true, 1); }
         else { if (unit) JF_RS_P(JF_F32, false, 0); else JF_RS_P(JF_F32, false, 1); }
-        rs_probs_finish_kernel<JF_F32><<<dim3((unsigned)((R + 255) / 256)), 256, 0, s>>>(logits, R, V, row_stride, draft_next, t, inv_t, part, (int)cpr, p_draft, row_max, row_sumexp);
+        JF_RS_F(JF_F32);
     } else {
         const bool fast = !unit && rs_scale_is_exact(t);
         if (vec) { if (unit) JF_RS_P(JF_BF16, true, 0); else if (fast) JF_RS_P(JF_BF16, true, 2); else JF_RS_P(JF_BF16, true, 3); }
         else { if (unit) JF_RS_P(JF_BF16, false, 0); else JF_RS_P(JF_BF16, false, 3); }
-        rs_probs_finish_kernel<JF_BF16><<<dim3((unsigned)((R + 255) / 256)), 256, 0, s>>>(logits, R, V, row_stride, draft_next, t, inv_t, part, (int)cpr, p_draft, row_max, row_sumexp);
+        JF_RS_F(JF_BF16);
     }
 #undef JF_RS_P
+#undef JF_RS_F
+    if (tm.end && !attach) (void)hipEventRecord(tm.end, s);
     return check_launch("rs_probs kernels");
 }
 
@@ -2461,6 +2481,7 @@ extern "C" int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_
                           int64_t *u_cursor, const float *bonus_stream, int64_t bonus_len, int64_t *bonus_cursor,
                           const int64_t *pad_stream, int64_t pad_len, int64_t *pad_cursor, int64_t *committed,
                           int64_t *next_draft, jf_rs_row *rows, void *workspace, size_t workspace_bytes, void *stream) {
+    const JfTiming tm = jf_take_timing();                            // events armed for this call (jf_timing_arm): taken whatever happens below
     if (B <= 0) return JF_OK;
     if (L < 2) return fail(JF_E_INVALID, "Draft must have at least 2 tokens (seed + 1 speculative)");
     if (L > 0x3FFF) return fail(JF_E_INVALID, "jf_rs_step: L=%d too large", L);
@@ -2486,10 +2507,18 @@ extern "C" int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_
         RsFusedArgs a{logits, V, row_stride, draft, B, L, p_draft, row_max, row_sumexp, pk, t, eos_id, remaining, u_stream, u_len, u_cursor,
                       bonus_stream, bonus_len, bonus_cursor, pad_stream, pad_len, pad_cursor, committed, next_draft, rows, w, gen};
         const unsigned grid = (unsigned)(3 + B * rs_active_segs(V, dtype == JF_F32 ? 4 : 8));
-        if (dtype == JF_F32) rs_step_fused_kernel<JF_F32><<<grid, 256, 0, s>>>(a);
-        else rs_step_fused_kernel<JF_BF16><<<grid, 256, 0, s>>>(a);
+        if (tm.any() && !jf_timing_bracket()) {                      // the launch's own start / stop timestamps
+            if (dtype == JF_F32) hipExtLaunchKernelGGL(rs_step_fused_kernel<JF_F32>, dim3(grid), dim3(256), 0, s, tm.begin, tm.end, 0, a);
+            else hipExtLaunchKernelGGL(rs_step_fused_kernel<JF_BF16>, dim3(grid), dim3(256), 0, s, tm.begin, tm.end, 0, a);
+        } else {
+            if (tm.begin) (void)hipEventRecord(tm.begin, s);
+            if (dtype == JF_F32) rs_step_fused_kernel<JF_F32><<<grid, 256, 0, s>>>(a);
+            else rs_step_fused_kernel<JF_BF16><<<grid, 256, 0, s>>>(a);
+            if (tm.end) (void)hipEventRecord(tm.end, s);
+        }
         return check_launch("rs_step_fused_kernel");
     }
+    if (tm.begin) (void)hipEventRecord(tm.begin, s);                 // several launches: the events bracket them
     const RsAcceptIn in{logits, V, row_stride, t, row_max, row_sumexp, p_draft};
     const bool staged = (int64_t)B * (L - 1) <= RS_STAGE && B <= RS_ROWS_LDS && u_len < 0x7FFFFFFFll;
     const bool chain_in_bonus = B <= RS_BONUS_CHAIN_ROWS;
@@ -2508,5 +2537,6 @@ extern "C" int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_
     if (dtype == JF_F32) { JF_RS_MULTI(JF_F32) } else { JF_RS_MULTI(JF_BF16) }
 #undef JF_RS_MULTI
     rs_finish_kernel<<<1, 256, 0, s>>>(B, L, pk, eos_id, remaining, u_cursor, bonus_cursor, pad_stream, pad_len, pad_cursor, committed, next_draft, rows);
+    if (tm.end) (void)hipEventRecord(tm.end, s);
     return check_launch("rs_step kernels");
 }

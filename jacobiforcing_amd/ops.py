@@ -20,9 +20,24 @@ from . import _native as N
 EVT_SPAWN, EVT_SWITCH, EVT_EARLY = 1, 2, 4
 VERIFY_HOOK = None      # bench.py: (before, after) callables around the verify launch (HIP events on the launch stream)
 VERIFY_EVENTS = None    # bench.py: callable -> (begin, end) torch.cuda.Event pair (already recorded once, so their handles exist)
-STAGE_HOOK = None       # bench.py: f(name, phase) with phase "begin"/"end" around jf_rs_probs / jf_rs_step / jf_argmax+jf_sb_step
+STAGE_HOOK = None       # bench.py: f(name, phase, nbytes) with phase "begin"/"end" around jf_rs_probs / jf_rs_step / jf_argmax+jf_sb_step;
+                        # jf_rs_probs / jf_rs_step first ask f(name, "arm", nbytes): a (begin, end) pair of torch events (recorded once
+                        # before, so their handles exist) is attached to the call's own dispatches (jf_timing_arm) and no "begin"/"end" follows
 LOOP_HOOKS = None       # bench.py: {"pack_end": f(batch), "forward_begin": f(batch)} — events behind the queued pack launch and in
                         # front of the next forward's first kernel (GPU idle time between the loop body and the forward)
+
+
+def _stage(name: str, nbytes: int):
+    """STAGE_HOOK protocol around one timed library call: returns the callable to run behind the call."""
+    hk = STAGE_HOOK
+    if not hk:
+        return lambda: None
+    ev = hk(name, "arm", nbytes)
+    if ev:
+        N.check(N.lib().jf_timing_arm(C.c_void_p(ev[0].cuda_event), C.c_void_p(ev[1].cuda_event)), "jf_timing_arm")
+        return lambda: None
+    hk(name, "begin", nbytes)
+    return lambda: hk(name, "end", 0)
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -789,19 +804,18 @@ class RsStepper:
         draft_next = draft[:, 1:].reshape(-1).contiguous()
         lib = N.lib()
         self.ws = _grown(self.ws, int(lib.jf_rs_workspace_bytes(R, V)))
-        hk = STAGE_HOOK
-        hk and hk("rs_probs", "begin", R * V * flat.element_size())
+        done = _stage("rs_probs", R * V * flat.element_size())
         N.check(lib.jf_rs_probs(_ptr(flat), _dtype_code(flat), R, V, flat.stride(0), _ptr(draft_next), float(temperature),
                                 _ptr(self.p_draft), _ptr(self.row_max), _ptr(self.row_sumexp), _ptr(self.packed),
                                 _ptr(self.ws), self.ws.numel() * 4, _stream(dev)), "jf_rs_probs")
-        hk and hk("rs_probs", "end", 0)
+        done()
         self.remaining[:B].copy_(torch.tensor(list(remaining), dtype=torch.int32), non_blocking=True)
         self.cursors.copy_(torch.tensor(list(cursors), dtype=torch.int64), non_blocking=True)
         cm = self.committed.view(-1)[:B * L].view(B, L)
         nd = self.next_draft.view(-1)[:B * L].view(B, L)
         cur = self.cursors
         c_ptr = lambda i: C.c_void_p(cur.data_ptr() + 8 * i)
-        hk and hk("rs_step", "begin", B * V * flat.element_size())          # <= one rejected row per draft row
+        done = _stage("rs_step", B * V * flat.element_size())               # <= one rejected row per draft row
         N.check(lib.jf_rs_step(_ptr(flat), _dtype_code(flat), V, flat.stride(0), _ptr(draft), B, L, _ptr(self.p_draft),
                                _ptr(self.row_max), _ptr(self.row_sumexp), _ptr(self.packed), float(temperature),
                                -1 if eos_id is None else int(eos_id), _ptr(self.remaining),
@@ -810,7 +824,7 @@ class RsStepper:
                                _ptr(self.pad_stream), self.pad_stream.numel(), c_ptr(2),
                                _ptr(cm), _ptr(nd), _ptr(self.rows_dev), _ptr(self.step_ws), self.step_ws.numel() * 8,
                                _stream(dev)), "jf_rs_step")
-        hk and hk("rs_step", "end", 0)
+        done()
         self.rows_host[:B].copy_(self.rows_dev[:B], non_blocking=True)
         th = self.tok_host.view(-1)[:B * L].view(B, L)
         th.copy_(cm, non_blocking=True)
