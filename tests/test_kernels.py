@@ -674,6 +674,38 @@ def test_rs_step_beyond_the_lds_tables(B, L, V):
 
 
 @GPU
+@pytest.mark.parametrize("B,L,V", [(8, 9, 20000), (300, 9, 50)], ids=["one_launch", "several_launches"])
+def test_timing_events_ride_on_the_calls_dispatches(B, L, V):
+    """jf_timing_arm: the events a caller arms are taken by the next jf_rs_probs / jf_rs_step call and carry the start of its
+    first launch and the stop of its last one (hipExtLaunchKernel), or bracket the launches of a slow path; the call's results do
+    not change, the events read a plausible duration, and nothing stays armed for the call after."""
+    plain = _run_rs("hip", B, L, V, 9, 0.5, None, torch.bfloat16, 0.9, eos=3)
+    pool, seen = [], {}
+
+    def hook(name, phase, nbytes):
+        assert phase == "arm", (name, phase)                 # armed calls get no "begin" / "end"
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); b.record()                               # their handles exist
+        pool.append((a, b))
+        seen.setdefault(name, []).append((a, b))
+        return a, b
+    ops.STAGE_HOOK = hook
+    try:
+        timed = _run_rs("hip", B, L, V, 9, 0.5, None, torch.bfloat16, 0.9, eos=3)
+    finally:
+        ops.STAGE_HOOK = None
+    _assert_rs_equal(timed, plain, B)
+    torch.cuda.synchronize()
+    assert set(seen) == {"rs_probs", "rs_step"}
+    for name, evs in seen.items():
+        for a, b in evs:
+            us = a.elapsed_time(b) * 1e3
+            assert 0.5 < us < 5e4, (name, us)
+    again = _run_rs("hip", B, L, V, 9, 0.5, None, torch.bfloat16, 0.9, eos=3)      # nothing armed any more
+    _assert_rs_equal(again, plain, B)
+
+
+@GPU
 @pytest.mark.parametrize("env", [dict(JF_ARGMAX_REVERSE="1"), dict(JF_ARGMAX_REVERSE="2", JF_ARGMAX_ITEMS="4096"),
                                  dict(JF_ARGMAX_WAVE="1", JF_ARGMAX_REVERSE="2"), dict(JF_ARGMAX_NT="0", JF_ARGMAX_CHUNK="4096")],
                          ids=["rows-reversed", "chunk-major", "wave-chunk-major", "plain-small-chunks"])
