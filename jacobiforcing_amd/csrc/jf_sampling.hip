@@ -1435,6 +1435,9 @@ __device__ __forceinline__ void rs_accept_body(const RsAcceptIn &in, const int64
                                                int64_t *committed, jf_rs_row *rows, const RsWs &w, uint32_t gen,
                                                uint32_t *s_p, float *s_u /* LDS, B * (L-1) entries each when STAGED */) {
     __shared__ int s_res[STAGED ? ROWS_N : 1];                                 // nacc | eos << 15 | (rej + 1) << 16 per row
+    __shared__ int s_off[STAGED ? ROWS_N + 1 : 1];                             // stream offset of every row's first test (-1: not known yet)
+    __shared__ int s_pipe;                                                     // first row the offset chain (not a leading run) handles, -1: not yet
+    __shared__ int s_eunc[2], s_erow[2], s_eoff[2];                            // the evaluating wavefronts' first undecided test (index, row, its offset)
     __shared__ double s_tab[64], s_red[4];
     __shared__ int s_unc, s_resume, s_used;
     __shared__ uint32_t s_patch_i[8], s_patch_v[8];                            // !STAGED: resolved entries (index, word)
@@ -1484,8 +1487,9 @@ __device__ __forceinline__ void rs_accept_body(const RsAcceptIn &in, const int64
     __syncthreads();
     int b_start = 0, used_start = 0;
     for (;;) {                                                      // the walk; re-entered after an undecided test was resolved
-        if constexpr (STAGED && SIG) {                              // (the announcing wavefront polls these words)
-            for (int b = b_start + tid; b < B; b += 256) s_res[b] = RS_RES_NONE;
+        if constexpr (STAGED) {                                     // (the evaluating / announcing wavefronts poll these words)
+            for (int b = b_start + tid; b < B; b += 256) { s_res[b] = RS_RES_NONE; s_off[b + 1] = -1; }
+            if (tid == 0) { s_off[b_start] = -1; s_pipe = -1; s_eunc[0] = s_eunc[1] = -1; s_erow[0] = s_erow[1] = 0x7FFFFFFF; }
             __syncthreads();
         }
         if (tid < 64 && STAGED && W <= 64) {
@@ -1495,64 +1499,89 @@ __device__ __forceinline__ void rs_accept_body(const RsAcceptIn &in, const int64
             const int lane = tid;
             const unsigned long long rowmask = W >= 64 ? ~0ull : ((1ull << W) - 1ull);
             const int lw = lane < W ? lane : W - 1;                 // lanes past the row read a valid entry and are masked out of every ballot
-            int used_total = used_start, unc_at = -1, b = b_start;
-            bool try_run = true;                                    // at the start, and behind a row that stopped at its first test
-            while (b < B) {                                         // JDN:326-348, rows in order
-                // A run of rows at once, a lane per row, on the assumption that every row of the run STOPS AT ITS FIRST TEST (the
-                // proposal at position 0 is rejected — what a draft that is not yet right gets — or is an accepted EOS): then each of
-                // them consumes exactly one uniform and the offsets of the whole run are known.  The run ends in front of the first
-                // row that accepts its first proposal (or whose first test is undecided); that row is walked the long way below.
-                // Tried only behind a row that stopped at its first test (such rows come in streaks: drafts go wrong together).
-                if (try_run) {
-                    const int rb = b + lane;
-                    bool ok0 = false, rej0 = false;
-                    if (rb < B) {
-                        const uint32_t pe0 = s_p[rb * W];
-                        const float u0 = s_u[used_total + lane];
-                        rej0 = !(u0 < __uint_as_float(pe0 & RS_PE_VAL));
-                        const bool unc0 = rej0 && (pe0 & RS_PE_AMB) && u0 < rs_accept_hi<DT>(pe0);
-                        ok0 = (rej0 || (pe0 & RS_PE_EOS)) && !unc0;
-                    }
-                    const unsigned long long nok = ~__ballot(ok0);
-                    const int run = nok ? __builtin_ctzll(nok) : 64;
-                    if (lane < run)                                 // rejected at position 0: nothing accepted; else the EOS at position 0 was accepted
-                        __hip_atomic_store(&s_res[rb], rej0 ? (1 << 16) : (1 | (1 << 15)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    b += run;
-                    used_total += run;
-                    try_run = run == 64;
-                    if (run == 64 || b >= B) continue;
+            int off = used_start, b = b_start;
+            // Leading runs of rows at once, a lane per row, on the assumption that every row of the run STOPS AT ITS FIRST TEST (the
+            // proposal at position 0 is rejected — what a draft that is not yet right gets — or is an accepted EOS): then each of
+            // them consumes exactly one uniform and the offsets of the whole run are known.  A run ends in front of the first
+            // row that accepts its first proposal (or whose first test is undecided).
+            for (;;) {
+                const int rb = b + lane;
+                bool ok0 = false, rej0 = false;
+                if (rb < B) {
+                    const uint32_t pe0 = s_p[rb * W];
+                    const float u0 = s_u[off + lane];
+                    rej0 = !(u0 < __uint_as_float(pe0 & RS_PE_VAL));
+                    const bool unc0 = rej0 && (pe0 & RS_PE_AMB) && u0 < rs_accept_hi<DT>(pe0);
+                    ok0 = (rej0 || (pe0 & RS_PE_EOS)) && !unc0;
                 }
-                // the long way: the row's words and the uniforms at its offset (the one dependent access), one ballot each for
-                // "accepted" and "EOS"; the second candidate of a rounding is looked at only when the first stop is a rejection
-                const uint32_t pe = s_p[b * W + lw];
-                const float uu = s_u[used_total + lw];
+                const unsigned long long nok = ~__ballot(ok0);
+                const int run = nok ? __builtin_ctzll(nok) : 64;
+                if (lane < run)                                     // rejected at position 0: nothing accepted; else the EOS at position 0 was accepted
+                    __hip_atomic_store(&s_res[rb], rej0 ? (1 << 16) : (1 | (1 << 15)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                b += run;
+                off += run;
+                if (run < 64 || b >= B) break;
+            }
+            // From here on this wavefront does NOTHING but the dependent chain — where does the next row's stream of uniforms
+            // start: one LDS read at the row's offset, one ballot against the row's thresholds (the next row's words are read a
+            // row ahead; an EOS word is a negative float, never accepted: "stops here" either way), find-first, add — and drops
+            // the offset into LDS (~0.1 us per row).  Wavefronts 2 and 3 pick the offsets up, alternate rows, and work out what the
+            // row's stop MEANS (rejected / EOS accepted / undecided rounding: s_res), wavefront 1 announces the leading run of
+            // decided rows: the three stages overlap, a walked batch of 64 rows is through in ~8 us instead of 15.  An undecided
+            // first stop is found by the evaluating wavefronts; the offsets behind it were speculation and are formed again
+            // after the test has been resolved.
+            if (lane == 0) {
+                __hip_atomic_store(&s_off[b < B ? b : B], off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&s_pipe, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (b < B) {
+                uint32_t pe = s_p[b * W + lw];
+                while (b < B) {
+                    const float uu = s_u[off + lw];
+                    const int bn = b + 1 < B ? b + 1 : b;
+                    const uint32_t pen = s_p[bn * W + lw];
+                    const unsigned long long stop = ~__ballot(uu < __uint_as_float(pe & ~RS_PE_AMB)) & rowmask;
+                    const int f = stop ? __builtin_ctzll(stop) : W - 1;    // no stop: all W tests consumed
+                    off += f + 1;
+                    ++b;
+                    if (lane == 0) __hip_atomic_store(&s_off[b], off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    pe = pen;
+                }
+            }
+        } else if (STAGED && W <= 64 && tid >= 128) {
+            // wavefronts 2 and 3: what each row's stop means, alternate rows, as soon as the row's offset is known
+            const int lane = tid & 63, e = (tid >> 6) - 2;
+            const unsigned long long rowmask = W >= 64 ? ~0ull : ((1ull << W) - 1ull);
+            const int lw = lane < W ? lane : W - 1;
+            int start;
+            while ((start = __hip_atomic_load(&s_pipe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < 0) __builtin_amdgcn_s_sleep(1);
+            int my_unc = -1, my_row = 0x7FFFFFFF, my_off = 0;
+            for (int r = start + e; r < B; r += 2) {
+                int o;
+                while ((o = __hip_atomic_load(&s_off[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < 0) __builtin_amdgcn_s_sleep(0);
+                const uint32_t pe = s_p[r * W + lw];
+                const float uu = s_u[o + lw];
                 const unsigned long long accm = __ballot(uu < __uint_as_float(pe & RS_PE_VAL));
                 const unsigned long long eosm = __ballot((pe & RS_PE_EOS) != 0u);
                 const unsigned long long rejm = ~accm & rowmask;
                 const unsigned long long stopm = (rejm | eosm) & rowmask;
-                int res = W, used = W;                              // no stop: all W accepted (eos 0, rej -1)
+                int res = W;                                        // no stop: all W accepted (eos 0, rej -1)
                 if (stopm) {
                     const int f = __builtin_ctzll(stopm);
                     if ((rejm >> f) & 1ull) {
                         const unsigned long long uncm = __ballot((pe & RS_PE_AMB) != 0u && uu < rs_accept_hi<DT>(pe));
-                        if ((uncm >> f) & 1ull) { unc_at = b * W + f; break; }   // the first stop is undecided: resolve it
+                        if ((uncm >> f) & 1ull) { my_unc = r * W + f; my_row = r; my_off = o; break; }   // the first stop is undecided: resolve it
                         res = f | ((f + 1) << 16);                  // rejected at f: f accepted
-                        try_run = f == 0;
                     } else {
                         res = (f + 1) | (1 << 15);                  // EOS accepted at f
-                        try_run = f == 0;
                     }
-                    used = f + 1;
                 }
-                if (lane == 0) __hip_atomic_store(&s_res[b], res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                used_total += used;
-                ++b;
+                if (lane == 0) __hip_atomic_store(&s_res[r], res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             if (lane == 0) {
-                if (SIG && unc_at >= 0) __hip_atomic_store(&s_res[b], RS_RES_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                s_unc = unc_at; s_resume = b; s_used = used_total;
+                s_eunc[e] = my_unc; s_erow[e] = my_row; s_eoff[e] = my_off;
+                if (SIG && my_unc >= 0) __hip_atomic_store(&s_res[my_row], RS_RES_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            if constexpr (SIG) { if (unc_at < 0) RS_STAMP_MAX(15); }   // 15: the accept walk has decided the last row
         } else if (SIG && STAGED && W <= 64 && tid >= 64 && tid < 128) {
             // wavefront 1: announces the rows as wavefront 0 decides them — a lane per row of the leading run of decided rows
             const int lane = tid - 64;
@@ -1569,9 +1598,12 @@ __device__ __forceinline__ void rs_accept_body(const RsAcceptIn &in, const int64
                     RS_ROWSTAMP(0, r);
                 }
                 base += run;
-                if (run < 64 && __shfl(v, run, 64) == RS_RES_ABORT) break;      // wavefront 0 stopped at an undecided test
+                if (run < 64 && __shfl(v, run, 64) == RS_RES_ABORT) break;      // an evaluating wavefront stopped at an undecided test
                 if (run == 0) __builtin_amdgcn_s_sleep(1);
             }
+#ifdef JF_EXP_RS_TRACE
+            if (base >= B && lane == 0) atomicMax(&g_rstrace[15], (unsigned long long)__builtin_amdgcn_s_memrealtime());   // 15: the last row is decided and announced
+#endif
         } else if (tid < 64) {
             const int lane = tid;
             int used_total = used_start, unc_at = -1, b = b_start;
@@ -1624,6 +1656,13 @@ __device__ __forceinline__ void rs_accept_body(const RsAcceptIn &in, const int64
             if constexpr (SIG) { if (unc_at < 0) RS_STAMP_MAX(15); }   // 15: the accept walk has decided the last row
         }
         __syncthreads();
+        if (STAGED && W <= 64) {                                    // the evaluating wavefronts' first undecided tests: the earlier row is the one to resolve
+            if (tid == 0) {
+                const int e = s_erow[0] <= s_erow[1] ? 0 : 1;
+                s_unc = s_eunc[e]; s_resume = s_erow[e]; s_used = s_eoff[e];
+            }
+            __syncthreads();
+        }
         const int ui = s_unc;
         if (ui < 0) break;
         // ---- the float32 row sum cannot decide this test: the row's float64 sum, by the whole workgroup (~1e-4 p of the tests)
