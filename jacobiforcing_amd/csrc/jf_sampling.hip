@@ -569,12 +569,13 @@ struct RsWs {                                     // carve-up of the step worksp
     uint32_t *s64done;                            // [rows, RS_SEG] gen: this segment's float64 partial is stored
     uint32_t *segdone;                            // [rows, RS_SEG] gen: this segment's sums are stored
     uint32_t *ivdone;                             // [rows] gen: iv is stored (by the workgroup of the row's segment 0, for the chain)
+    float *segmax;                                // [rows, RS_SEG] largest scaled logit of each segment (phase A; -inf: empty) — the masked argmax starts from these
     uint32_t *acceptdone;                         // [4]   gen: [0] the accept workgroup has written every row record, [1] the chain workgroup every draw count
 };
 static inline size_t rs_ws_bytes(int64_t rows) {
     const size_t r = (size_t)((rows + 3) / 4 * 4);
     return r * RS_SEG * sizeof(double) * 2 + r * RS_SEG * RS_WT * sizeof(double) + 6 * r * sizeof(double) + 3 * r * sizeof(int32_t) +
-           r * (RS_FLAG_STRIDE + 2) * sizeof(unsigned long long) + 2 * r * RS_SEG * sizeof(uint32_t) + r * sizeof(uint32_t) + 4 * sizeof(uint32_t);
+           r * (RS_FLAG_STRIDE + 2) * sizeof(unsigned long long) + 2 * r * RS_SEG * sizeof(uint32_t) + r * sizeof(uint32_t) + r * RS_SEG * sizeof(float) + 4 * sizeof(uint32_t);
 }
 __host__ __device__ inline RsWs rs_ws(void *ws, int64_t rows) {
     const size_t r = (size_t)((rows + 3) / 4 * 4);
@@ -595,7 +596,8 @@ __host__ __device__ inline RsWs rs_ws(void *ws, int64_t rows) {
     w.s64done = (uint32_t *)(w.pick_u + r);
     w.segdone = w.s64done + r * RS_SEG;
     w.ivdone = w.segdone + r * RS_SEG;
-    w.acceptdone = w.ivdone + r;
+    w.segmax = (float *)(w.ivdone + r);
+    w.acceptdone = (uint32_t *)(w.segmax + r * RS_SEG);
     return w;
 }
 extern "C" size_t jf_rs_step_workspace_bytes(int64_t rows) { return rows > 0 ? rs_ws_bytes(rows) : 0; }
@@ -691,6 +693,8 @@ __device__ __forceinline__ RsRow rs_make_row(const void *logits, int64_t r, int6
 
 __device__ __forceinline__ void st_agent_f64(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ld_agent_f64(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent_f32(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent_f32(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // bounded in-kernel waits: a wait that lasts 2 s of the 100 MHz constant clock gives up; the caller reports
 // JF_E_LAUNCH through rows[0].rsv instead of hanging the GPU
@@ -817,15 +821,17 @@ struct RsSumShared {
     double part[RS_SEG];
     double pv[8];                   // the avoided token's vector, its lane's exclusive prefix in front
     double excl;
+    float mx[4];                    // the wavefronts' largest scaled logit (phase A)
     int ok;
 };
 
 // phase A of one (row, segment): float64 sum of exp(xs - M); KEEP: the float32 images of the exps stay in e32 for phase B
 template <int DT, bool KEEP>
 __device__ __forceinline__ double rs_seg_exp_sum(const RsRow &row, int64_t lo, int64_t hi, const double *tab,
-                                                 float (&e32)[RsKeep<DT>::NV][Elem<DT>::EPV], u32x4 (&v)[RsKeep<DT>::NV]) {
+                                                 float (&e32)[RsKeep<DT>::NV][Elem<DT>::EPV], u32x4 (&v)[RsKeep<DT>::NV], float &lmax) {
     constexpr int EPV = Elem<DT>::EPV, NV = RsKeep<DT>::NV;
     double acc = 0.0;
+    lmax = -INFINITY;                                                  // this lane's largest scaled logit (slots beyond V hold -inf)
     const float mcut = row.M + (float)RS_EXP_CUT + 1.f;                // one above the cut (float rounding of the sum): vectors wholly above it skip the clamp
     for (int64_t b0 = lo + (int64_t)threadIdx.x * EPV; b0 < hi; b0 += (int64_t)NV * 256 * EPV) {
 #pragma unroll
@@ -836,9 +842,10 @@ __device__ __forceinline__ double rs_seg_exp_sum(const RsRow &row, int64_t lo, i
             if (e0 >= hi) { if constexpr (KEEP) { for (int j = 0; j < EPV; ++j) e32[k][j] = 0.f; } continue; }
             float xs[EPV];
             rs_scaled_from_vec<DT>(row, v[k], xs);
-            float xmin = xs[0];
+            float xmin = xs[0], xmax = xs[0];
 #pragma unroll
-            for (int j = 1; j < EPV; ++j) xmin = fminf(xmin, xs[j]);
+            for (int j = 1; j < EPV; ++j) { xmin = fminf(xmin, xs[j]); xmax = fmaxf(xmax, xs[j]); }
+            lmax = fmaxf(lmax, xmax);
             if (__ballot(!(xmin >= mcut)) == 0ull) {           // (wave-uniform, the usual case) nothing of this vector is near the cut: no clamp, no select
 #pragma unroll
                 for (int j = 0; j < EPV; ++j) {
@@ -1022,15 +1029,19 @@ __device__ __forceinline__ bool rs_rowsum_fused(const void *logits, int64_t V, i
     double S = 0.0;
     const bool keep = ntiles <= NV;                           // workgroup-uniform (true for every vocabulary up to 163 840)
     if (exact) {
-        double acc = keep ? rs_seg_exp_sum<DT, true>(row, lo, hi, sh.tab, e32, v) : rs_seg_exp_sum<DT, false>(row, lo, hi, sh.tab, e32, v);
+        float lmax;
+        double acc = keep ? rs_seg_exp_sum<DT, true>(row, lo, hi, sh.tab, e32, v, lmax) : rs_seg_exp_sum<DT, false>(row, lo, hi, sh.tab, e32, v, lmax);
         RS_PHASE(item, seg, 1);                               // 1: phase A loads + exps done
         acc = wave_sum_f64(acc);
-        if ((tid & 63) == 0) sh.red[tid >> 6] = acc;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off, 64));
+        if ((tid & 63) == 0) { sh.red[tid >> 6] = acc; sh.mx[tid >> 6] = lmax; }
         __syncthreads();
         RS_PHASE(item, seg, 2);                               // 2: reduced
         if (tid == 0) {
             st_agent_f64(w.s64part + (int64_t)item * RS_SEG + seg, (sh.red[0] + sh.red[1]) + (sh.red[2] + sh.red[3]));
-            for (int e = empty_from; e < RS_SEG; ++e) st_agent_f64(w.s64part + (int64_t)item * RS_SEG + e, 0.0);
+            st_agent_f32(w.segmax + (int64_t)item * RS_SEG + seg, fmaxf(fmaxf(sh.mx[0], sh.mx[1]), fmaxf(sh.mx[2], sh.mx[3])));
+            for (int e = empty_from; e < RS_SEG; ++e) { st_agent_f64(w.s64part + (int64_t)item * RS_SEG + e, 0.0); st_agent_f32(w.segmax + (int64_t)item * RS_SEG + e, -INFINITY); }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(w.s64done + (int64_t)item * RS_SEG + seg, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int e = empty_from; e < RS_SEG; ++e) __hip_atomic_store(w.s64done + (int64_t)item * RS_SEG + e, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1070,11 +1081,17 @@ __global__ __launch_bounds__(256) void rs_rowsum_a_kernel(const void *logits, in
     __syncthreads();
     float e32[NV][EPV];
     u32x4 v[NV];
-    double acc = rs_seg_exp_sum<DT, false>(row, lo, hi, sh.tab, e32, v);
+    float lmax;
+    double acc = rs_seg_exp_sum<DT, false>(row, lo, hi, sh.tab, e32, v, lmax);
     acc = wave_sum_f64(acc);
-    if ((tid & 63) == 0) sh.red[tid >> 6] = acc;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off, 64));
+    if ((tid & 63) == 0) { sh.red[tid >> 6] = acc; sh.mx[tid >> 6] = lmax; }
     __syncthreads();
-    if (tid == 0) w.s64part[(int64_t)item * RS_SEG + seg] = (sh.red[0] + sh.red[1]) + (sh.red[2] + sh.red[3]);
+    if (tid == 0) {
+        w.s64part[(int64_t)item * RS_SEG + seg] = (sh.red[0] + sh.red[1]) + (sh.red[2] + sh.red[3]);
+        w.segmax[(int64_t)item * RS_SEG + seg] = fmaxf(fmaxf(sh.mx[0], sh.mx[1]), fmaxf(sh.mx[2], sh.mx[3]));
+    }
 }
 template <int DT>
 __global__ __launch_bounds__(256) void rs_rowsum_b_kernel(const void *logits, int64_t V, int64_t row_stride, const float *row_max,
@@ -1307,9 +1324,10 @@ __device__ int rs_pick_wg(const RsRow &row, const double *segsum, double S, floa
 }
 
 // argmax of the distribution with `proposed` masked (JDN:147-153 / JDO:164-168): first index of the largest probability —
+// (this version forms EVERY probability: rows on the plain float32 formula; exact rows take rs_masked_argmax below)
 // for bf16 logits that is a tie among every id whose ROUNDED probability equals the maximum; all mass on it -> keep it.
 template <int DT>
-__device__ int rs_masked_argmax(const RsRow &row, int64_t proposed, double S, RsPickShared &sh) {
+__device__ int rs_masked_argmax_full(const RsRow &row, int64_t proposed, double S, RsPickShared &sh) {
     constexpr int EPV = Elem<DT>::EPV;
     const int tid = threadIdx.x;
     const double invS = S > 0.0 ? 1.0 / S : 0.0;
@@ -1335,6 +1353,97 @@ __device__ int rs_masked_argmax(const RsRow &row, int64_t proposed, double S, Rs
     return mm ? jfmb::decode_packed(mm) : (int)proposed;
 }
 
+// The same for a row with an exact sum, without forming 152 064 float64 exps (~100 us for one workgroup — and the case is not
+// rare with a trained model: a proposal that holds 0.97 of the mass and is rejected collides in all 16 draws).  The exactly
+// rounded probability is a non-decreasing function of the scaled logit, so the largest probability belongs to the largest
+// other logit; ids with smaller logits can only TIE with it after rounding, and only within ln 3 of it (the widest ratio two
+// values can have and still round to the same number: 0.5 and 1.5 units of the smallest subnormal).  Phase A left every
+// segment's largest scaled logit in the workspace (segmax): the largest other logit is their maximum — the proposed id's own
+// segment is scanned again without it when it holds that segment's maximum — and only segments whose maximum lies within that
+// distance of it (a unit in the last place for a normal pmax: almost always one segment) can hold the answer: they are scanned in vocabulary order (one round of loads per segment: 20 KB for a workgroup),
+// exact probabilities for the few ids in range, first index that equals the maximum.  3-8 us instead of ~100.
+template <int DT, bool FIND /* false: largest scaled logit without `proposed`; true: first id in [lo_x, inf) whose probability is pmax */>
+__device__ __forceinline__ void rs_scan_segment(const RsRow &row, int seg, int64_t proposed, float lo_x, float pmax, double invS, const double *tab,
+                                                float &best, unsigned long long &cand) {
+    constexpr int EPV = Elem<DT>::EPV, NB = 5;
+    const int64_t segE = rs_seg_elems(row.V, EPV);
+    const int64_t lo = (int64_t)seg * segE;
+    int64_t hi = lo + segE;
+    if (hi > row.V) hi = row.V;
+    for (int64_t b0 = lo + (int64_t)threadIdx.x * EPV; b0 < hi; b0 += (int64_t)NB * 256 * EPV) {
+        u32x4 v[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) { const int64_t e0 = b0 + (int64_t)k * 256 * EPV; if (e0 < hi) v[k] = rs_load_vec<DT>(row, e0); }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int64_t e0 = b0 + (int64_t)k * 256 * EPV;
+            if (e0 >= hi) continue;
+            float xs[EPV];
+            rs_scaled_from_vec<DT>(row, v[k], xs);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) {
+                const int64_t i = e0 + j;
+                if (i >= row.V || i == proposed) continue;
+                if constexpr (!FIND) best = fmaxf(best, xs[j]);
+                else if (xs[j] >= lo_x && (unsigned long long)i < cand) {
+                    const float pj = rs_round_prob<DT>(rs_e64(xs[j], (double)row.M, tab) * invS);
+                    if (pj == pmax) cand = (unsigned long long)i;
+                }
+            }
+        }
+    }
+}
+template <int DT, bool AGENT>
+__device__ int rs_masked_argmax(const RsRow &row, int64_t proposed, double S, RsPickShared &sh, const float *segmax) {
+    if (!(S > 0.0) || !segmax) return rs_masked_argmax_full<DT>(row, proposed, S, sh);
+    constexpr int EPV = Elem<DT>::EPV;
+    const int tid = threadIdx.x;
+    const double invS = 1.0 / S;
+    const int64_t segE = rs_seg_elems(row.V, EPV);
+    __syncthreads();
+    if (tid < RS_SEG) sh.seg[tid] = (double)(AGENT ? ld_agent_f32(segmax + tid) : segmax[tid]);
+    __syncthreads();
+    const int sp = (proposed >= 0 && proposed < row.V) ? (int)(proposed / segE) : -1;
+    if (sp >= 0 && sp < RS_SEG) {
+        // the proposed id's segment: when the id holds the segment's maximum, the segment's largest OTHER logit takes its place
+        const float xa = rs_scaled<DT>(load_f<DT>(row.p, proposed), row.t, row.inv_t, row.unit_t, row.fast);
+        if (xa >= (float)sh.seg[sp]) {                           // (workgroup-uniform)
+            float m = -INFINITY;
+            unsigned long long none = ~0ull;
+            rs_scan_segment<DT, false>(row, sp, proposed, 0.f, 0.f, invS, sh.tab, m, none);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            if ((tid & 63) == 0) sh.red[tid >> 6] = (double)m;
+            __syncthreads();
+            if (tid == 0) sh.seg[sp] = fmax(fmax(sh.red[0], sh.red[1]), fmax(sh.red[2], sh.red[3]));
+            __syncthreads();
+        }
+    }
+    float best = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < RS_SEG; ++q) best = fmaxf(best, (float)sh.seg[q]);
+    if (best == -INFINITY) return (int)proposed;                 // no other id holds any mass
+    const float pmax = rs_round_prob<DT>(rs_e64(best, (double)row.M, sh.tab) * invS);
+    if (!(pmax > 0.f)) return (int)proposed;
+    // how far below `best` a logit can lie and still round to pmax: ln 3 where pmax is (near) subnormal, else the ratio of one
+    // unit in the last place (bf16: < 1 + 2^-7, float32: < 1 + 2^-22), with a margin
+    const float lo_x = best - (pmax >= 7.5e-37f ? (DT == JF_BF16 ? 0.0157f : 1.0e-5f) : 1.125f);
+    for (int q = 0; q < RS_SEG; ++q) {                           // vocabulary order: the first segment with a hit holds the first index
+        if (!((float)sh.seg[q] >= lo_x)) continue;               // (workgroup-uniform)
+        unsigned long long cand = ~0ull;
+        float unused = 0.f;
+        rs_scan_segment<DT, true>(row, q, proposed, lo_x, pmax, invS, sh.tab, unused, cand);
+        cand = ~wave_max_u64(~cand);                             // smallest index
+        __syncthreads();
+        if ((tid & 63) == 0) sh.best[tid >> 6] = cand;
+        __syncthreads();
+        unsigned long long mm = sh.best[0];
+        for (int w = 1; w < 4; ++w) mm = sh.best[w] < mm ? sh.best[w] : mm;
+        if (mm != ~0ull) { __syncthreads(); return (int)mm; }
+    }
+    return (int)proposed;                                        // (cannot happen: the segment that holds `best` holds a hit)
+}
+
 // the draw that counts for one row, by a whole workgroup (sh.tab loaded): wavefront 0 walks at u (u >= 0); the masked argmax
 // after RS_MAX_TRIES collisions (u < 0), or should the walk return the proposed token after all (float64 rounding of the
 // interval test against the walk: never the proposal).
@@ -1350,7 +1459,7 @@ __device__ __forceinline__ int rs_final_pick(const RsRow &row, const RsWs &w, in
             y = rs_pick_wg<DT>(row, w.segsum + (int64_t)item * RS_SEG, S, u, sh);
         }
     }
-    if (y < 0 || (int64_t)y == proposed) y = rs_masked_argmax<DT>(row, proposed, S, sh);
+    if (y < 0 || (int64_t)y == proposed) y = rs_masked_argmax<DT, AGENT>(row, proposed, S, sh, w.segmax + (int64_t)item * RS_SEG);
     return y;
 }
 

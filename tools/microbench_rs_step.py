@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--p-hit", type=float, default=0.6)
     ap.add_argument("--trace", action="store_true", help="in-kernel stamps of the one-launch step (JF_LIB=tools/libjf_exp_rstrace.so)")
+    ap.add_argument("--checkpoint-like", action="store_true",
+                    help="what a trained Jacobi-Forcing checkpoint gives the step: every row's first 1-6 proposals hold ~0.97 of their position's "
+                         "mass (accepted), the next one ~0.02 (rejected; its residual draw almost never collides with it)")
     a = ap.parse_args()
     B, L, V = a.batch, a.block, 152064
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -34,7 +37,14 @@ def main():
     # reject within a few positions and the residual draw collides with the proposed id with probability ~p_hit
     import math
     others = V * math.exp(0.5 * (2.0 / a.temperature) ** 2)            # E[sum exp(x / T)] for x ~ N(0, 2^2)
-    logits.scatter_(2, draft[:, 1:].unsqueeze(-1), a.temperature * math.log(a.p_hit / (1 - a.p_hit) * others))
+    boost = lambda p: a.temperature * math.log(p / (1 - p) * others)
+    if a.checkpoint_like:
+        k = torch.randint(1, 7, (B, 1), generator=g, device="cuda")                # accepted proposals per row
+        pos = torch.arange(L - 1, device="cuda").unsqueeze(0)
+        val = torch.where(pos < k, torch.tensor(boost(0.97), device="cuda"), torch.tensor(boost(0.02), device="cuda")).to(dt)
+        logits.scatter_(2, draft[:, 1:].unsqueeze(-1), val.unsqueeze(-1))
+    else:
+        logits.scatter_(2, draft[:, 1:].unsqueeze(-1), boost(a.p_hit))
     n = 1 << 16
     gc = torch.Generator().manual_seed(2)                               # the same streams in every process: runs are comparable
     st = ops.RsStepper(B, L, "cuda", torch.randint(0, V, (n,), generator=gc), torch.rand(n, generator=gc), torch.rand(n, generator=gc))
