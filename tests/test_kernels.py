@@ -674,6 +674,38 @@ def test_rs_step_beyond_the_lds_tables(B, L, V):
 
 
 @GPU
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("coarse", [False, True], ids=["distinct_logits", "tied_logits"])
+def test_rs_step_masked_argmax_after_sixteen_collisions(dtype, coarse):
+    """A proposal that holds ~0.97 of its position's mass and is rejected collides in (nearly) all 16 residual draws: the bonus
+    token is the masked argmax (JDN:147-153) — first index of the largest ROUNDED probability among the other ids.  The kernels
+    find it from the segments' largest logits instead of forming every probability; logits on a coarse grid make the maximum a
+    many-way tie (first index wins, ids in several segments).  Real vocabulary, against the row-by-row restatement."""
+    B, L, V = 6, 4, 152064
+    g = torch.Generator().manual_seed(77)
+    draft = torch.randint(0, V, (B, L), generator=g)
+    logits = torch.randn(B, L - 1, V, generator=g) * 2
+    if coarse:
+        logits = torch.round(logits)                                   # hundreds of ids share the largest value
+    boost = float(np.log(0.97 / 0.03) + np.log(V) + 2.0)
+    logits.scatter_(2, draft[:, 1:].unsqueeze(-1), boost)
+    n = 4 * B * L * 16
+    unis = torch.full((n,), 0.995)                                      # every first test rejects its 0.97-mass proposal
+    bonus = torch.randint(0, 1 << 24, (n,), generator=g).float() / float(1 << 24)
+    pads = torch.randint(0, V, (n,), generator=g)
+    out = {}
+    for backend in ("hip", "hostsim"):
+        with use_backend(backend):
+            dev = device_for(backend)
+            st = ops.RsStepper(B, L, dev, pads, unis, bonus)
+            rows, toks, nd = st.step(draft.to(dev), logits.to(dtype).to(dev), 1.0, None, [L] * B, [1, 2, 3])
+            out[backend] = (rows.copy(), toks.copy(), nd.cpu().numpy().copy(), st.cursors.cpu().tolist())
+    f = N.RS_FIELDS.index
+    assert (out["hostsim"][0][:, f("n_bonus_draws")] == 16).sum() >= 2      # the masked argmax really decided rows
+    _assert_rs_equal(out["hip"], out["hostsim"], B)
+
+
+@GPU
 @pytest.mark.parametrize("B,L,V", [(8, 9, 20000), (300, 9, 50)], ids=["one_launch", "several_launches"])
 def test_timing_events_ride_on_the_calls_dispatches(B, L, V):
     """jf_timing_arm: the events a caller arms are taken by the next jf_rs_probs / jf_rs_step call and carry the start of its
