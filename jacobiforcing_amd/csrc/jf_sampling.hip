@@ -140,15 +140,61 @@ template <> __device__ __forceinline__ float key_max_to_float<JF_BF16>(int32_t k
     return __uint_as_float(h << 16);
 }
 
-template <int DT, int SCALE, int NV, class FT>
-__device__ __forceinline__ void rs_round(const u32x4 (&vv)[NV], FT &ft, uint32_t idx0, uint32_t idx_step, float cs, float t,
-                                         float inv_t, float &m, float &s) {
-    constexpr int EPV = Elem<DT>::EPV;
-    constexpr int NE = NV * EPV;
-    int32_t kmax = INT32_MIN;
+// Argmax tracker of the softmax stream, in the FLOAT domain and per ROUND (round 5).  The stream unpacks every element to a
+// float for its exp anyway, so the round's maximum is one v_maximum3_f32 per two elements (IEEE-754-2019 maximum: a NaN
+// anywhere in the round comes out as NaN) and the bookkeeping one compare + three selects per ROUND of up to four vectors —
+// the integer-key tracker of the greedy kernel (FastTrack) cost ~15 instructions per vector here and made the bf16 kernel
+// VALU-bound (profiles/pmc_rs_probs_r05.txt).  Strict "greater" in stream order keeps the first of equal maxima, and the
+// float compare makes -0.0 == +0.0 tie (torch.argmax); the lane re-reads the winning round once at the end (resolve).
+__device__ __forceinline__ float rs_max3(float a, float b, float c) {
+    return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c);
+}
+struct RoundTrack {
+    float best = __builtin_nanf("");          // NaN: "nothing yet" — the first round always takes it over
+    float all = -INFINITY;                     // maximum of every round maximum: NaN from the first NaN on (sticky)
+    uint32_t bidx0 = 0xFFFFFFFFu;              // element index of the winning round's first vector
+    static constexpr uint32_t bstep_vec = 256u; // vectors between a lane's vectors of one round (the workgroup's width)
+    __device__ __forceinline__ void note(float rmax, bool live, uint32_t idx0) {   // live: the lane holds the round's first vector
+        const bool upd = live && !(rmax <= best);
+        best = upd ? rmax : best;
+        bidx0 = upd ? idx0 : bidx0;
+        all = __builtin_elementwise_maximum(all, rmax);
+    }
+    __device__ __forceinline__ bool saw_nan() const { return all != all; }
+    __device__ __forceinline__ uint32_t ukey() const { return order_key(__float_as_uint(best)); }
+    // first element (in index order) of the winning round that equals best; the round's vectors beyond the chunk's `nvec`
+    // whole vectors (a partial last round) are not looked at
+    template <int DT>
+    __device__ __forceinline__ uint32_t resolve(const void *p, uint32_t ebase, int nvec) const {
+        constexpr int EPV = Elem<DT>::EPV;
+        constexpr uint32_t bstep = bstep_vec * EPV;
+        u32x4 v[4];
+        bool in[4];
 #pragma unroll
-    for (int u = 0; u < NV; ++u) { const int32_t k = ft.consume_ret(vv[u], idx0 + u * idx_step); kmax = k > kmax ? k : kmax; }
-    float x[NE];
+        for (int u = 0; u < 4; ++u) {
+            in[u] = (bidx0 - ebase + (uint32_t)u * bstep) / EPV < (uint32_t)nvec;
+            v[u] = in[u] ? *((const u32x4 *)p + (bidx0 + (uint32_t)u * bstep) / EPV) : u32x4{0u, 0u, 0u, 0u};
+        }
+        uint32_t idx = bidx0;
+#pragma unroll
+        for (int u = 3; u >= 0; --u) {
+            if (!in[u]) continue;
+            const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int j = EPV - 1; j >= 0; --j) {
+                float x;
+                if constexpr (DT == JF_F32) x = __uint_as_float(w[j]);
+                else x = __uint_as_float((j & 1) ? (w[j >> 1] & 0xFFFF0000u) : (w[j >> 1] << 16));
+                if (x == best) idx = bidx0 + (uint32_t)u * bstep + (uint32_t)j;
+            }
+        }
+        return idx;
+    }
+};
+
+template <int DT, int NV>
+__device__ __forceinline__ void rs_unpack_round(const u32x4 (&vv)[NV], float (&x)[NV * Elem<DT>::EPV]) {
+    constexpr int EPV = Elem<DT>::EPV;
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
         float xv[EPV];
@@ -156,7 +202,16 @@ __device__ __forceinline__ void rs_round(const u32x4 (&vv)[NV], FT &ft, uint32_t
 #pragma unroll
         for (int j = 0; j < EPV; ++j) x[u * EPV + j] = xv[j];
     }
-    float xmax = key_max_to_float<DT>(kmax);                 // the round's largest raw value (NaN if the round holds one)
+}
+// one round on its unpacked values (x is consumed: scaled in place)
+template <int DT, int SCALE, int NE>
+__device__ __forceinline__ void rs_round_x(float (&x)[NE], RoundTrack &ft, bool live, uint32_t idx0, float cs, float t, float inv_t,
+                                           float &m, float &s) {
+    float xmax = rs_max3(x[0], x[1], x[2]);                  // the round's largest raw value (NaN if the round holds one)
+#pragma unroll
+    for (int j = 3; j + 1 < NE; j += 2) xmax = rs_max3(xmax, x[j], x[j + 1]);
+    xmax = __builtin_elementwise_maximum(xmax, x[NE - 1]);
+    ft.note(xmax, live, idx0);
     if constexpr (SCALE == 2) {
 #pragma unroll
         for (int j = 0; j < NE; j += 2) scale_bf16_fast2(x[j], x[j + 1], inv_t);
@@ -191,95 +246,17 @@ __device__ __forceinline__ void rs_round(const u32x4 (&vv)[NV], FT &ft, uint32_t
     s = acc[0].x + acc[0].y;
     m = mn;
 }
+template <int DT, int SCALE, int NV>
+__device__ __forceinline__ void rs_round(const u32x4 (&vv)[NV], RoundTrack &ft, bool live, uint32_t idx0, float cs, float t, float inv_t,
+                                         float &m, float &s) {
+    float x[NV * Elem<DT>::EPV];
+    rs_unpack_round<DT, NV>(vv, x);
+    rs_round_x<DT, SCALE, NV * Elem<DT>::EPV>(x, ft, live, idx0, cs, t, inv_t, m, s);
+}
 
 // raw fp32 value behind an order key (inverse of order_key for non-NaN values)
 __device__ __forceinline__ float key_to_float(uint32_t k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
-}
-
-template <int DT, bool VEC, int SCALE>
-__global__ __launch_bounds__(256) void rs_probs_partial_kernel(const void *logits, int64_t R, int64_t V, int64_t row_stride,
-                                                                float t, float inv_t, float2 *__restrict__ partial,
-                                                                unsigned long long *packed, int cpr, int64_t chunk_elems) {
-    using E = Elem<DT>;
-    constexpr int EPV = E::EPV;
-    const int64_t item = blockIdx.x;
-    const int64_t row = item / cpr;
-    const int c = (int)(item - row * cpr);
-    const int64_t begin = (int64_t)c * chunk_elems;
-    int64_t end = begin + chunk_elems;
-    if (end > V) end = V;
-    const typename E::T *p = (const typename E::T *)logits + row * row_stride;
-    const int tid = threadIdx.x;
-    const float cs = (SCALE == 1 ? inv_t : 1.f) * 1.44269504088896340736f;
-    float m = -INFINITY, s = 0.f;
-    uint32_t best = 0u, bidx = 0xFFFFFFFFu;
-    int64_t done = begin;
-    if constexpr (VEC) {
-        const int nvec = (int)((end - begin) / EPV);
-        const u32x4 *q = (const u32x4 *)p + (begin / EPV) + tid;
-        const uint32_t ebase = (uint32_t)begin;
-        // the greedy kernel's vector-granular argmax tracker, trimmed for a VALU-bound loop: the best vector is re-read at
-        // the end instead of carried, and negative NaNs are seen by the sum (s turns NaN) instead of a running minimum
-        FastTrack<DT, false, false> ft;
-        int k = tid;
-        for (; k + 7 * 256 < nvec; k += 8 * 256, q += 8 * 256) {
-            const u32x4 va[4] = {JF_LOAD(q), JF_LOAD(q + 256), JF_LOAD(q + 512), JF_LOAD(q + 768)};
-            const u32x4 vb[4] = {JF_LOAD(q + 1024), JF_LOAD(q + 1280), JF_LOAD(q + 1536), JF_LOAD(q + 1792)};
-            rs_round<DT, SCALE, 4>(va, ft, ebase + (uint32_t)k * EPV, 256u * EPV, cs, t, inv_t, m, s);
-            rs_round<DT, SCALE, 4>(vb, ft, ebase + (uint32_t)(k + 1024) * EPV, 256u * EPV, cs, t, inv_t, m, s);
-        }
-        if (k + 3 * 256 < nvec) {                        // a remaining half batch
-            const u32x4 va[4] = {JF_LOAD(q), JF_LOAD(q + 256), JF_LOAD(q + 512), JF_LOAD(q + 768)};
-            rs_round<DT, SCALE, 4>(va, ft, ebase + (uint32_t)k * EPV, 256u * EPV, cs, t, inv_t, m, s);
-            k += 4 * 256; q += 4 * 256;
-        }
-        for (; k < nvec; k += 256, q += 256) {          // this lane's remaining vectors, one at a time
-            const u32x4 vv[1] = {JF_LOAD(q)};
-            rs_round<DT, SCALE, 1>(vv, ft, ebase + (uint32_t)k * EPV, 0u, cs, t, inv_t, m, s);
-        }
-        done = begin + (int64_t)nvec * EPV;
-        if (__syncthreads_or((ft.saw_nan() || s != s) ? 1 : 0)) {
-            scan_exact<DT>(p, begin, done, tid, best, bidx);               // NaN (or inf - inf) in the chunk: exact key rescan
-        } else if (ft.bvec != 0xFFFFFFFFu) {
-            best = ft.ukey();
-            bidx = ft.resolve(p);
-        }
-    }
-    for (int64_t i = done + tid; i < end; i += 256) {    // unaligned rows / ragged tail (V % EPV)
-        const uint32_t kk = load_key<DT>(p, i);
-        if (kk > best) { best = kk; bidx = (uint32_t)i; }
-        float xv = load_f<DT>(p, i);
-        if constexpr (SCALE >= 2) xv = bf16_rne(__fdiv_rn(xv, t));
-        xv *= cs;
-        if (xv > m) { s = (m == -INFINITY ? 0.f : s * __builtin_amdgcn_exp2f(m - xv)) + 1.f; m = xv; }
-        else if (xv != -INFINITY) s += __builtin_amdgcn_exp2f(xv - m);
-    }
-    // merge (m, s) pairs: six shuffle steps inside the wavefront, then one LDS hop across the four wavefronts
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float m2 = __shfl_xor(m, off, 64), s2 = __shfl_xor(s, off, 64);
-        const float M = fmaxf(m, m2);
-        s = (M == -INFINITY) ? 0.f : ((m == -INFINITY ? 0.f : s * exp2f(m - M)) + (m2 == -INFINITY ? 0.f : s2 * exp2f(m2 - M)));
-        m = M;
-    }
-    __shared__ float sm[4], ss[4];
-    __shared__ uint64_t sp[4];
-    uint64_t pk = wave_max_u64(((uint64_t)best << 32) | (uint64_t)(~bidx));
-    if ((tid & 63) == 0) { sp[tid >> 6] = pk; sm[tid >> 6] = m; ss[tid >> 6] = s; }
-    __syncthreads();
-    if (tid == 0) {
-        float M = -INFINITY;
-        for (int i = 0; i < 4; ++i) M = sm[i] > M ? sm[i] : M;
-        float Ssum = 0.f;
-        for (int i = 0; i < 4; ++i) Ssum += (sm[i] == -INFINITY) ? 0.f : ss[i] * exp2f(sm[i] - M);
-        uint64_t mm = sp[0];
-        for (int w = 1; w < 4; ++w) mm = sp[w] > mm ? sp[w] : mm;
-        // the chunk's RAW maximum (from the argmax key) and its sum relative to M == fl(scaled(raw max) * cs): scaling and
-        // the multiply are monotone, so the largest scaled value belongs to the largest raw value
-        partial[item] = make_float2(M == -INFINITY ? -INFINITY : key_to_float((uint32_t)(mm >> 32)), Ssum);
-        atomicMax(packed + row, (unsigned long long)mm);
-    }
 }
 
 // ---- float64 helpers of the exact probability definition (see "Exact probabilities" below) ----
@@ -358,34 +335,28 @@ __device__ __forceinline__ double rs_e64(float xs, double M, const double *tab) 
 //   JF_F32   the centre value fl32(p); the steps test against [p (1 - eps), p (1 + eps)].
 // Rows without finite statistics (NaN / +inf logits) keep the plain float32 formula (NaN where torch's softmax is NaN).
 template <int DT>
-__global__ __launch_bounds__(256) void rs_probs_finish_kernel(const void *logits, int64_t R, int64_t V, int64_t row_stride,
-                                                               const int64_t *draft_next, float t, float inv_t, const float2 *partial,
-                                                               int cpr, float *p_draft, float *row_max, float *row_sumexp) {
-    __shared__ double s_tab[64];
-    rs_load_tab(s_tab);
-    __syncthreads();
-    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= R) return;
+__device__ __forceinline__ void rs_finish_row(const void *logits, int64_t row, int64_t V, int64_t row_stride, int64_t tok, bool have_x, float x_tok,
+                                              float t, float inv_t, const float2 *partial, int cpr, float *p_draft, float *row_max,
+                                              float *row_sumexp, const double *s_tab) {
     const bool unit_t = (t == 1.f);
     const float cs = ((DT == JF_F32 && !unit_t) ? inv_t : 1.f) * 1.44269504088896340736f;
     // the same (scale, * cs) composition stage 1 applied to its running maxima
     auto mdom = [&](float raw) { return ((DT == JF_BF16 && !unit_t) ? bf16_rne(__fdiv_rn(raw, t)) : raw) * cs; };
     float Mraw = -INFINITY;
-    for (int c = 0; c < cpr; ++c) Mraw = fmaxf(Mraw, partial[row * cpr + c].x);
+    for (int c = 0; c < cpr; ++c) Mraw = fmaxf(Mraw, partial[c].x);
     const float mM = mdom(Mraw);
     float S = 0.f;
     for (int c = 0; c < cpr; ++c) {
-        const float2 ps = partial[row * cpr + c];
+        const float2 ps = partial[c];
         S += (ps.x == -INFINITY) ? 0.f : ps.y * exp2f(mdom(ps.x) - mM);
     }
     const float M = rs_scaled<DT>(Mraw, t, inv_t, unit_t);    // consumers form exp(xs - M): exactly 1 at the maximum
     row_max[row] = M;
     row_sumexp[row] = S;
-    const int64_t tok = draft_next[row];
     const void *p = (const char *)logits + row * row_stride * (DT == JF_F32 ? 4 : 2);
     float pd = 0.f;
     if (tok >= 0 && tok < V) {
-        const float xs = rs_scaled<DT>(load_f<DT>(p, tok), t, inv_t, unit_t);
+        const float xs = rs_scaled<DT>(have_x ? x_tok : load_f<DT>(p, tok), t, inv_t, unit_t);
         if (!rs_row_is_exact(M, S)) pd = rs_prob<DT>(xs, M, S);
         else {
             const double ph = rs_e64(xs, (double)M, s_tab) / (double)S;
@@ -399,13 +370,192 @@ __global__ __launch_bounds__(256) void rs_probs_finish_kernel(const void *logits
     }
     p_draft[row] = pd;
 }
+template <int DT>
+__global__ __launch_bounds__(256) void rs_probs_finish_kernel(const void *logits, int64_t R, int64_t V, int64_t row_stride,
+                                                               const int64_t *draft_next, float t, float inv_t, const float2 *partial,
+                                                               int cpr, float *p_draft, float *row_max, float *row_sumexp) {
+    __shared__ double s_tab[64];
+    rs_load_tab(s_tab);
+    __syncthreads();
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= R) return;
+    rs_finish_row<DT>(logits, row, V, row_stride, draft_next[row], false, 0.f, t, inv_t, partial + row * cpr, cpr, p_draft, row_max, row_sumexp, s_tab);
+}
 
-struct RsTune { int64_t items; };
+// `fin` (non-null only when a row is ONE chunk, cpr == 1): the workgroup finishes its own row — stage 2 below — instead of a
+// second launch (round 5: the second launch and the gap in front of it were ~6 us of a 115 us call at 64 x 31 rows)
+struct RsFinishArgs { const int64_t *draft_next; float *p_draft, *row_max, *row_sumexp; };
+#ifndef JF_RS_WAVES
+#define JF_RS_WAVES 1                      // no occupancy bound: forcing 64 VGPRs (8 waves per SIMD) spills inside the loop and loses 5-20 %
+#endif
+#ifndef JF_RS_PIPE
+#define JF_RS_PIPE 1
+#endif
+template <int DT, bool VEC, int SCALE>
+__global__ __launch_bounds__(256, JF_RS_WAVES) void rs_probs_partial_kernel(const void *logits, int64_t R, int64_t V, int64_t row_stride,
+                                                                   float t, float inv_t, float2 *__restrict__ partial,
+                                                                   unsigned long long *packed, int cpr, int64_t chunk_elems, RsFinishArgs fin) {
+    using E = Elem<DT>;
+    constexpr int EPV = E::EPV;
+    const int64_t item = blockIdx.x;
+    const int64_t row = item / cpr;
+    const int c = (int)(item - row * cpr);
+    __shared__ double s_tab[64];
+    const bool fuse = fin.draft_next != nullptr;
+    if (fuse) rs_load_tab(s_tab);                            // (the barriers of the reductions below come before its use)
+    const int64_t begin = (int64_t)c * chunk_elems;
+    int64_t end = begin + chunk_elems;
+    if (end > V) end = V;
+    const typename E::T *p = (const typename E::T *)logits + row * row_stride;
+    const int tid = threadIdx.x;
+    const float cs = (SCALE == 1 ? inv_t : 1.f) * 1.44269504088896340736f;
+    float m = -INFINITY, s = 0.f;
+    uint32_t best = 0u, bidx = 0xFFFFFFFFu;
+    int64_t done = begin;
+    if constexpr (VEC) {
+        const int nvec = (int)((end - begin) / EPV);
+        const uint32_t ebase = (uint32_t)begin;
+        // buffer loads: the chunk is a raw buffer (uniform descriptor), the lane offset one constant VGPR and the position in
+        // the chunk the instruction's scalar offset — no VALU address arithmetic (per-lane 64-bit pointers cost two VALU adds
+        // per load), and every trip count below is wave-uniform (scalar branches, no exec-mask loops)
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((const u32x4 *)p + (begin / EPV)), 0, nvec * 16, 0x00020000);
+        const uint32_t voff = (uint32_t)tid * 16u;
+#define RS_LD(kb_, u_) __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, ((kb_) + (u_) * 256) * 16, 2 /* nt */))
+        RoundTrack ft;
+        const int nfull = nvec / (8 * 256);               // iterations in which every lane has all eight vectors
+        int kb = 0;                                       // vectors of the chunk in front of this iteration
+        const u32x4 ninf = Elem<DT>::EPV == 4 ? u32x4{0xFF800000u, 0xFF800000u, 0xFF800000u, 0xFF800000u}
+                                               : u32x4{0xFF80FF80u, 0xFF80FF80u, 0xFF80FF80u, 0xFF80FF80u};
+        if constexpr (DT == JF_BF16 && JF_RS_PIPE) {
+            // bf16: the stream is half compute (27 VALU cycles per element against ~2.3 per byte of load), so a wavefront that
+            // only asks for its next eight vectors after finishing the current ones has nothing in flight for two thirds of an
+            // iteration.  Unpacking frees a round's 16 raw registers: the NEXT iteration's loads of that round are issued right
+            // there, in front of the round's arithmetic — eight vectors per lane in flight at all times.  The loads are
+            // unconditional (a branch around them would make the wait counters conservative): beyond the chunk a raw buffer
+            // load returns zeros without touching memory, and what the last iteration prefetches IS the chunk's ragged rest.
+            u32x4 va[4] = {RS_LD(0, 0), RS_LD(0, 1), RS_LD(0, 2), RS_LD(0, 3)};
+            u32x4 vb[4] = {RS_LD(0, 4), RS_LD(0, 5), RS_LD(0, 6), RS_LD(0, 7)};
+            for (int it = 0; it < nfull; ++it, kb += 8 * 256) {
+                float xa[4 * EPV];
+                rs_unpack_round<DT, 4>(va, xa);
+                __builtin_amdgcn_sched_barrier(0);
+                va[0] = RS_LD(kb + 2048, 0); va[1] = RS_LD(kb + 2048, 1); va[2] = RS_LD(kb + 2048, 2); va[3] = RS_LD(kb + 2048, 3);
+                __builtin_amdgcn_sched_barrier(0);
+                rs_round_x<DT, SCALE, 4 * EPV>(xa, ft, true, ebase + (uint32_t)(kb + tid) * EPV, cs, t, inv_t, m, s);
+                __builtin_amdgcn_sched_barrier(0);
+                float xb[4 * EPV];
+                rs_unpack_round<DT, 4>(vb, xb);
+                __builtin_amdgcn_sched_barrier(0);
+                vb[0] = RS_LD(kb + 2048, 4); vb[1] = RS_LD(kb + 2048, 5); vb[2] = RS_LD(kb + 2048, 6); vb[3] = RS_LD(kb + 2048, 7);
+                __builtin_amdgcn_sched_barrier(0);
+                rs_round_x<DT, SCALE, 4 * EPV>(xb, ft, true, ebase + (uint32_t)(kb + tid + 1024) * EPV, cs, t, inv_t, m, s);
+            }
+            // the rest (< 2048 vectors) is in the registers already: a lane's missing vectors become -inf (no mass, never the
+            // maximum), a lane without any vector of a round does not touch the tracker
+            if (kb < nvec) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    va[u] = kb + tid + u * 256 < nvec ? va[u] : ninf;
+                    vb[u] = kb + tid + (u + 4) * 256 < nvec ? vb[u] : ninf;
+                }
+                rs_round<DT, SCALE, 4>(va, ft, kb + tid < nvec, ebase + (uint32_t)(kb + tid) * EPV, cs, t, inv_t, m, s);
+                if (kb + 4 * 256 < nvec) rs_round<DT, SCALE, 4>(vb, ft, kb + tid + 1024 < nvec, ebase + (uint32_t)(kb + tid + 1024) * EPV, cs, t, inv_t, m, s);
+            }
+        } else {
+            for (int it = 0; it < nfull; ++it, kb += 8 * 256) {
+                const u32x4 va[4] = {RS_LD(kb, 0), RS_LD(kb, 1), RS_LD(kb, 2), RS_LD(kb, 3)};
+                const u32x4 vb[4] = {RS_LD(kb, 4), RS_LD(kb, 5), RS_LD(kb, 6), RS_LD(kb, 7)};
+                rs_round<DT, SCALE, 4>(va, ft, true, ebase + (uint32_t)(kb + tid) * EPV, cs, t, inv_t, m, s);
+                __builtin_amdgcn_sched_barrier(0);       // keep the second round's unpacked values out of the first round's live range
+                rs_round<DT, SCALE, 4>(vb, ft, true, ebase + (uint32_t)(kb + tid + 1024) * EPV, cs, t, inv_t, m, s);
+            }
+            // the rest (< 2048 vectors) as one or two rounds with all of their loads in flight at once; a lane's missing vectors
+            // are -inf (no mass, never the maximum), a lane without any vector of the round does not touch the tracker
+#define RS_LDP(kb_, u_) ((kb_) + tid + (u_) * 256 < nvec ? RS_LD(kb_, u_) : ninf)
+            if (kb < nvec) {
+                const bool two = kb + 4 * 256 < nvec;
+                const u32x4 va[4] = {RS_LDP(kb, 0), RS_LDP(kb, 1), RS_LDP(kb, 2), RS_LDP(kb, 3)};
+                u32x4 vb[4] = {ninf, ninf, ninf, ninf};
+                if (two) { vb[0] = RS_LDP(kb, 4); vb[1] = RS_LDP(kb, 5); vb[2] = RS_LDP(kb, 6); vb[3] = RS_LDP(kb, 7); }
+                rs_round<DT, SCALE, 4>(va, ft, kb + tid < nvec, ebase + (uint32_t)(kb + tid) * EPV, cs, t, inv_t, m, s);
+                if (two) rs_round<DT, SCALE, 4>(vb, ft, kb + tid + 1024 < nvec, ebase + (uint32_t)(kb + tid + 1024) * EPV, cs, t, inv_t, m, s);
+            }
+        }
+#undef RS_LDP
+#undef RS_LD
+        done = begin + (int64_t)nvec * EPV;
+        __shared__ float s_bw[4];
+        // the workgroup's maximum first (six shuffles, one LDS hop): only the lanes that hold it re-read their winning round —
+        // one scattered read per item instead of one per lane (256 scattered 16-byte reads were ~10 % of an item's traffic)
+        float bw = ft.bidx0 != 0xFFFFFFFFu ? ft.best : -INFINITY;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) bw = __builtin_elementwise_maximum(bw, __shfl_xor(bw, off, 64));
+        if ((tid & 63) == 0) s_bw[tid >> 6] = bw;
+        if (__syncthreads_or((ft.saw_nan() || s != s) ? 1 : 0)) {
+            scan_exact<DT>(p, begin, done, tid, best, bidx);               // NaN (or inf - inf) in the chunk: exact key rescan
+        } else {
+            bw = rs_max3(s_bw[0], s_bw[1], __builtin_elementwise_maximum(s_bw[2], s_bw[3]));
+            if (ft.bidx0 != 0xFFFFFFFFu && ft.best == bw) {
+                best = ft.ukey();
+                bidx = ft.template resolve<DT>(p, ebase, nvec);
+            }
+        }
+    }
+    for (int64_t i = done + tid; i < end; i += 256) {    // unaligned rows / ragged tail (V % EPV)
+        const uint32_t kk = load_key<DT>(p, i);
+        if (kk > best) { best = kk; bidx = (uint32_t)i; }
+        float xv = load_f<DT>(p, i);
+        if constexpr (SCALE >= 2) xv = bf16_rne(__fdiv_rn(xv, t));
+        xv *= cs;
+        if (xv > m) { s = (m == -INFINITY ? 0.f : s * __builtin_amdgcn_exp2f(m - xv)) + 1.f; m = xv; }
+        else if (xv != -INFINITY) s += __builtin_amdgcn_exp2f(xv - m);
+    }
+    // the drafted id's logit for the fused finish: requested now, consumed behind the reductions
+    int64_t tok = -1;
+    float x_tok = 0.f;
+    if (fuse && tid == 0) {
+        tok = fin.draft_next[row];
+        if (tok >= 0 && tok < V) x_tok = load_f<DT>(p, tok);
+    }
+    // merge (m, s) pairs: six shuffle steps inside the wavefront, then one LDS hop across the four wavefronts
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float m2 = __shfl_xor(m, off, 64), s2 = __shfl_xor(s, off, 64);
+        const float M = fmaxf(m, m2);
+        s = (M == -INFINITY) ? 0.f : ((m == -INFINITY ? 0.f : s * exp2f(m - M)) + (m2 == -INFINITY ? 0.f : s2 * exp2f(m2 - M)));
+        m = M;
+    }
+    __shared__ float sm[4], ss[4];
+    __shared__ uint64_t sp[4];
+    uint64_t pk = wave_max_u64(((uint64_t)best << 32) | (uint64_t)(~bidx));
+    if ((tid & 63) == 0) { sp[tid >> 6] = pk; sm[tid >> 6] = m; ss[tid >> 6] = s; }
+    __syncthreads();
+    if (tid == 0) {
+        float M = -INFINITY;
+        for (int i = 0; i < 4; ++i) M = sm[i] > M ? sm[i] : M;
+        float Ssum = 0.f;
+        for (int i = 0; i < 4; ++i) Ssum += (sm[i] == -INFINITY) ? 0.f : ss[i] * exp2f(sm[i] - M);
+        uint64_t mm = sp[0];
+        for (int w = 1; w < 4; ++w) mm = sp[w] > mm ? sp[w] : mm;
+        // the chunk's RAW maximum (from the argmax key) and its sum relative to M == fl(scaled(raw max) * cs): scaling and
+        // the multiply are monotone, so the largest scaled value belongs to the largest raw value
+        const float2 part = make_float2(M == -INFINITY ? -INFINITY : key_to_float((uint32_t)(mm >> 32)), Ssum);
+        partial[item] = part;
+        atomicMax(packed + row, (unsigned long long)mm);
+        if (fuse) rs_finish_row<DT>(logits, row, V, row_stride, tok, true, x_tok, t, inv_t, &part, 1, fin.p_draft, fin.row_max, fin.row_sumexp, s_tab);
+    }
+}
+
+struct RsTune { int64_t items; int dyn_lds; bool fuse_finish; };
 static const RsTune &rs_tune() {                            // read once: sweeps in tools/ set it before the first call
     static const RsTune t = [] {
-        RsTune r{1024};                                     // resident workgroups per round: 256 CUs x 4 (122 VGPRs per lane)
+        RsTune r{1024, 0, true};                                  // workgroups per scheduling round of the chunk split; dynamic LDS per workgroup (occupancy knob of the sweeps)
         const char *e = getenv("JF_RS_ITEMS");
         if (e && *e) { const long long v = atoll(e); if (v >= 1 && v <= (1 << 20)) r.items = v; }
+        e = getenv("JF_RS_DYN_LDS");
+        if (e && *e) { const long long v = atoll(e); if (v >= 0 && v <= 65536) r.dyn_lds = (int)v; }
+        e = getenv("JF_RS_FUSE_FINISH");
+        if (e && *e == '0') r.fuse_finish = false;
         return r;
     }();
     return t;
@@ -463,9 +613,10 @@ extern "C" int jf_rs_probs(const void *logits, int dtype, int64_t R, int64_t V, 
     const float t = (temperature <= 0.f) ? 1.f : temperature;    // JDN:66-67
     const float inv_t = 1.f / t;
     const int esz = dtype == JF_F32 ? 4 : 2;
-    const bool vec = (((uintptr_t)logits) % 16 == 0) && ((row_stride * esz) % 16 == 0);
     int64_t cpr = 1;
     const int64_t chunk = rs_chunk(dtype, R, V, &cpr);
+    // vector path: 16-byte aligned rows, and a chunk the 32-bit offsets of its buffer loads can address
+    const bool vec = (((uintptr_t)logits) % 16 == 0) && ((row_stride * esz) % 16 == 0) && chunk * esz < (1ll << 31) - 65536;
     const dim3 grid((unsigned)(R * cpr)), block(256);
     hipStream_t s = (hipStream_t)stream;
     unsigned long long *pk = (unsigned long long *)packed;
@@ -475,14 +626,18 @@ extern "C" int jf_rs_probs(const void *logits, int dtype, int64_t R, int64_t V, 
     const bool attach = tm.any() && !jf_timing_bracket();
     if (tm.begin && !attach) (void)hipEventRecord(tm.begin, s);
     const dim3 fgrid((unsigned)((R + 255) / 256));
+    // one chunk per row: the stream's workgroups finish their rows themselves (JF_RS_FUSE_FINISH=0: always two launches)
+    const bool fused = cpr == 1 && rs_tune().fuse_finish;
+    const RsFinishArgs fin = fused ? RsFinishArgs{draft_next, p_draft, row_max, row_sumexp} : RsFinishArgs{nullptr, nullptr, nullptr, nullptr};
 #define JF_RS_P(DT, VECF, SC)                                                                                                             \
     do {                                                                                                                                  \
-        if (attach) hipExtLaunchKernelGGL((rs_probs_partial_kernel<DT, VECF, SC>), grid, block, 0, s, tm.begin, nullptr, 0, logits, R, V, \
-                                          row_stride, t, inv_t, part, pk, (int)cpr, chunk);                                               \
-        else rs_probs_partial_kernel<DT, VECF, SC><<<grid, block, 0, s>>>(logits, R, V, row_stride, t, inv_t, part, pk, (int)cpr, chunk); \
+        if (attach) hipExtLaunchKernelGGL((rs_probs_partial_kernel<DT, VECF, SC>), grid, block, rs_tune().dyn_lds, s, tm.begin, fused ? tm.end : nullptr, 0, \
+                                          logits, R, V, row_stride, t, inv_t, part, pk, (int)cpr, chunk, fin);                            \
+        else rs_probs_partial_kernel<DT, VECF, SC><<<grid, block, rs_tune().dyn_lds, s>>>(logits, R, V, row_stride, t, inv_t, part, pk, (int)cpr, chunk, fin); \
     } while (0)
 #define JF_RS_F(DT)                                                                                                                       \
     do {                                                                                                                                  \
+        if (fused) break;                                                                                                                 \
         if (attach) hipExtLaunchKernelGGL((rs_probs_finish_kernel<DT>), fgrid, block, 0, s, nullptr, tm.end, 0, logits, R, V, row_stride, \
                                           draft_next, t, inv_t, (const float2 *)part, (int)cpr, p_draft, row_max, row_sumexp);            \
         else rs_probs_finish_kernel<DT><<<fgrid, block, 0, s>>>(logits, R, V, row_stride, draft_next, t, inv_t, part, (int)cpr, p_draft,  \
