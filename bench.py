@@ -82,6 +82,9 @@ class VerifyTimer:
         self._c = None              # behind the pack launch queued after it
         self.body = []              # (verify start, pack end): the whole loop body of an iteration
         self.idle = []              # (pack end, next forward's first kernel): what the GPU waits for the host
+        self.host_gap = []          # host clock, us: mailbox poll returned -> the next forward is about to be queued (pure host control
+                                    # time: unlike `idle` it does not contain other processes' kernels when ranks share a GPU)
+        self._seen = None
 
     def _fill_pool(self, n: int = 512):
         """Events the library will record on (jf_mb_loop_iterate's ev_begin / ev_end): made ahead of the timed window, and
@@ -122,7 +125,13 @@ class VerifyTimer:
             self.body.append((self._a, c))
             self._c = c
 
+        def mailbox_seen(batch):
+            self._seen = time.perf_counter()
+
         def forward_begin(batch):
+            if self._seen is not None:
+                self.host_gap.append((time.perf_counter() - self._seen) * 1e6)
+                self._seen = None
             if self._c is None:
                 return
             d = torch.cuda.Event(enable_timing=True)
@@ -131,7 +140,7 @@ class VerifyTimer:
             self._c = None
         ops.VERIFY_HOOK = (before, after)
         ops.VERIFY_EVENTS = events
-        ops.LOOP_HOOKS = {"pack_end": pack_end, "forward_begin": forward_begin}
+        ops.LOOP_HOOKS = {"pack_end": pack_end, "forward_begin": forward_begin, "mailbox_seen": mailbox_seen}
         return self
 
     def __exit__(self, *exc):
@@ -142,6 +151,7 @@ class VerifyTimer:
     def reset(self):
         self.events.clear(); self.bytes = 0; self.rows = 0; self.launched_rows = 0
         self.body.clear(); self.idle.clear(); self._c = None
+        self.host_gap.clear(); self._seen = None
         self._fill_pool()
 
     def summary(self):
@@ -153,7 +163,10 @@ class VerifyTimer:
         body = [a.elapsed_time(b) * 1e3 for a, b in self.body]
         idle = [a.elapsed_time(b) * 1e3 for a, b in self.idle]
         med = lambda v: float(sorted(v)[len(v) // 2]) if v else None
-        return dict(launches=len(us), avg_us=avg_us, avg_bytes=avg_bytes, avg_rows=self.rows / len(us),
+        pct = lambda v, q: float(sorted(v)[min(len(v) - 1, int(len(v) * q))]) if v else None
+        return dict(host_gap_us=(sum(self.host_gap) / len(self.host_gap)) if self.host_gap else None,
+                    host_gap_us_median=med(self.host_gap), host_gap_us_p95=pct(self.host_gap, 0.95), idle_us_p95=pct(idle, 0.95),
+                    launches=len(us), avg_us=avg_us, avg_bytes=avg_bytes, avg_rows=self.rows / len(us),
                     avg_launched_rows=self.launched_rows / len(us), gbs=avg_bytes / avg_us / 1e3,
                     body_us=(sum(body) / len(body)) if body else None, idle_us=(sum(idle) / len(idle)) if idle else None,
                     idle_us_median=med(idle), idle_samples=len(idle))
@@ -370,6 +383,21 @@ def vs_ar_section(model, cfg, prm, tuned, vocab_hi, robust, warmup: int = 8, ste
                      "4.0-4.1 tokens/forward); forward = step minus the HIP-event loop body and the idle gap behind it")
 
 
+def rank_record(info, dev_index: int, r: dict, roof) -> dict:
+    """One rank's evidence for the line's `per_rank` list: who it is (rank, pid, host, the GPU's PCI bus id / UUID as the HIP
+    library reports it), what it did in the timed window (tokens, iterations, seconds) and how its convergence launch and the
+    host between two iterations behaved."""
+    rec = dict(rank=info.rank, local_rank=info.local_rank, pid=os.getpid(), host=socket.gethostname(), device_index=dev_index,
+               device=jd.device_identity(dev_index), tokens=int(r["tokens"]), iterations=int(r["iterations"]), seconds=float(r["seconds"]),
+               cpus=len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None)
+    if roof is not None:
+        rec.update(verify_us=roof["avg_us"], verify_bytes=roof["avg_bytes"], verify_gbs=roof["gbs"], verify_launches=roof["launches"],
+                   body_us=roof["body_us"], gpu_idle_us=roof["idle_us"], gpu_idle_us_median=roof["idle_us_median"],
+                   gpu_idle_us_p95=roof["idle_us_p95"], host_gap_us=roof["host_gap_us"], host_gap_us_median=roof["host_gap_us_median"],
+                   host_gap_us_p95=roof["host_gap_us_p95"])
+    return rec
+
+
 def verify_scripted(hook, stats, prompts) -> bool:
     """The scripted model plants target(position, prompt) as the greedy continuation: every token the decoder returned must
     be that sequence (greedy Jacobi == greedy AR, the reference's own criterion, on the bench's own window)."""
@@ -556,6 +584,14 @@ def main():
         r = run_steps(dec, prompts, args.warmup, args.steps, seed=1234 + info.rank, timer=tm)
         roof = tm.summary()
     agg = jd.gather_throughput(r["tokens"], r["iterations"] * 1.0, r["seconds"], dev)
+    # ---- what every rank did, from every rank: the N-GPU line must prove N ranks on N devices by itself ------------------
+    record = rank_record(info, dev_index, r, roof)
+    records = jd.gather_rank_records(record)
+    shared_ok = "JF_FORCE_DEVICE" in os.environ                    # the explicit plumbing mode: N ranks on one GPU (gloo)
+    try:
+        devices_distinct = jd.check_distinct_devices(records, jd.backend_name(), allow_shared=shared_ok and jd.backend_name() != "nccl")
+    except jd.DuplicateDeviceError as e:
+        raise SystemExit(f"bench.py: {e}")
     if os.environ.get("JF_DUMP_LAUNCHES") and info.rank == 0:
         Path(os.environ["JF_DUMP_LAUNCHES"]).write_text(json.dumps(dict(rows=tm.all_rows, valid=tm.all_valid, V=cfg.vocab_size, esz=2)))
     # ---- same measurement with the synthetic acceptance model -------------------------------------
@@ -612,7 +648,7 @@ def main():
         tpf = agg["tokens"] / (agg["iterations"] * P) if agg["iterations"] else 0.0   # per prompt, per forward
         out = {
             "metric": "tokens/sec (+ mean tokens/forward), multiblock Jacobi n=32 K=2 r=0.85 pool=4, Qwen2.5-Coder-7B",
-            "value": value, "unit": "tokens/s", "n_gpus": info.world_size, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "tokens/s", "n_gpus": jd.ranks_seen(), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": agg["seconds"] / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "tokens_per_forward": tpf,
@@ -634,6 +670,18 @@ def main():
                        "prewarm": "none" if args.no_prewarm else "one untimed pass over the same W + K iterations before the measured "
                                                                  "pass (loads the library kernels of every GEMM shape the window uses)"},
         }
+        # N ranks, verifiable from the line alone: ranks_seen is the communicator's world size (not the environment's), every
+        # rank's record names its GPU, devices_distinct counts them (over RCCL a duplicate is refused above, never reported)
+        out["ranks_seen"] = jd.ranks_seen()
+        out["devices_distinct"] = devices_distinct
+        out["shared_device"] = devices_distinct != len(records)
+        out["per_rank"] = records
+        out["per_rank_check"] = {"tokens_sum": sum(x["tokens"] for x in records), "seconds_max": max(x["seconds"] for x in records),
+                                 "value_from_records": sum(x["tokens"] for x in records) / max(x["seconds"] for x in records),
+                                 "slowest_rank": max(records, key=lambda x: x["seconds"])["rank"],
+                                 "seconds_spread": jd.spread(x["seconds"] for x in records),
+                                 "note": "value = tokens_sum / seconds_max must equal the line's value (the two all_reduces); a straggler "
+                                         "shows in seconds_spread, a rank that fell back or idled in its tokens / verify_launches"}
         if roof is not None:
             out["roofline"] = {"bound": "hbm", "achieved": roof["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": roof["gbs"] / HBM_PEAK_GBS, "traffic": _pmc_traffic(roof),
@@ -648,13 +696,24 @@ def main():
                                "rows_per_launch": roof["avg_rows"], "logits_rows_per_launch": roof["avg_launched_rows"],
                                "note": "logits rows beyond rows_per_launch are list padding (lm_head M on the tuned grid); the "
                                        "kernel skips them unread",
-                               "launches": roof["launches"]}
+                               "launches": roof["launches"],
+                               "by_rank": {"frac": jd.spread((x["verify_gbs"] / HBM_PEAK_GBS) if x.get("verify_gbs") else None for x in records),
+                                           "us_per_launch": jd.spread(x.get("verify_us") for x in records),
+                                           "note": "min / mean / max over the ranks' own launches (achieved / frac above are rank 0's)"}}
             out["loop_body"] = {"body_us_per_step": roof["body_us"], "gpu_idle_us_per_step": roof["idle_us"],
-                                "gpu_idle_us_median": roof["idle_us_median"], "samples": roof["idle_samples"],
+                                "gpu_idle_us_median": roof["idle_us_median"], "gpu_idle_us_p95": roof["idle_us_p95"],
+                                "host_gap_us_per_step": roof["host_gap_us"], "host_gap_us_median": roof["host_gap_us_median"],
+                                "host_gap_us_p95": roof["host_gap_us_p95"],
+                                "by_rank": {"gpu_idle_us_median": jd.spread(x.get("gpu_idle_us_median") for x in records),
+                                            "host_gap_us_median": jd.spread(x.get("host_gap_us_median") for x in records),
+                                            "host_gap_us_p95": jd.spread(x.get("host_gap_us_p95") for x in records)},
+                                "samples": roof["idle_samples"],
                                 "driver": "resident (calls restart inside the convergence launch)" if dec.resident else "host-driven restarts",
                                 "note": "HIP events on the launch stream: body = convergence launch start -> end of the pack launch queued "
                                         "behind it; gpu_idle = end of that pack launch -> the event recorded in front of the next forward's "
-                                        "first kernel (mailbox poll + host control; the reference's 'overhead %', MR:116-134)"}
+                                        "first kernel (mailbox poll + host control; the reference's 'overhead %', MR:116-134); host_gap = host "
+                                        "clock from the mailbox poll's return to the next forward's first launch call (host control alone: "
+                                        "comparable between 1 and N ranks per host even when the ranks share a GPU)"}
         if shapes:
             out["roofline_by_shape"] = {"unit": "GB/s", "peak": HBM_PEAK_GBS, "kernel": VERIFY_KERNEL,
                                         "note": "HIP events around the verify launch inside short decode windows (6 warm-up + 24 "

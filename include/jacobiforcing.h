@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define JF_VERSION 410
+#define JF_VERSION 500
 
 enum {
     JF_OK = 0,
@@ -52,6 +52,12 @@ JF_API int jf_version(void);
  * jf_mb_loop_iterate takes its events as arguments. */
 JF_API int jf_timing_arm(void *ev_begin, void *ev_end);
 JF_API const char *jf_last_error(void);
+/* Which GPU the library's launches of this process go to: writes "pci=DDDD:BB:DD.F uuid=<32 hex digits> arch=<gcnArchName>
+ * cus=<compute units>" for HIP device `device` (< 0: the calling thread's current device) into buf (NUL-terminated, at most cap
+ * bytes).  bench.py gathers it from every rank so that the N-GPU line proves N distinct devices (one process per
+ * GPU — the reference's only precedent is scripts/inference/scanning_hyperparameter_jacobi_decoding_mr.sh:30-84, which pins a
+ * process per CUDA_VISIBLE_DEVICES entry and never checks). */
+JF_API int jf_device_identity(int device, char *buf, size_t cap);
 
 /* ---------------------------------------------------------------------------------------------
  * (a2) block-local logits argmax.  Replaces torch.argmax(block_logits, dim=-1) at MB:476, SB:197,

@@ -101,6 +101,7 @@ _SIGNATURES = {
     "jf_version": (C.c_int, []),
     "jf_timing_arm": (C.c_int, [C.c_void_p, C.c_void_p]),
     "jf_last_error": (C.c_char_p, []),
+    "jf_device_identity": (C.c_int, [C.c_int, C.c_char_p, _sz]),
     "jf_argmax_partial": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _vp, _vp]),
     "jf_argmax_scatter": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _vp, _vp, _vp]),
     "jf_argmax_decode": (C.c_int, [_vp, _i64, _vp, _vp]),

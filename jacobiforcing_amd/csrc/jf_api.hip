@@ -29,5 +29,17 @@ bool jf_timing_bracket() {
     return b;
 }
 
+extern "C" int jf_device_identity(int device, char *buf, size_t cap) {
+    if (!buf || cap < 8) return fail(JF_E_INVALID, "jf_device_identity: buffer");
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) return fail(JF_E_LAUNCH, "jf_device_identity: no current device");
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, device) != hipSuccess) return fail(JF_E_LAUNCH, "jf_device_identity: device %d has no properties", device);
+    char uuid[33];
+    for (int i = 0; i < 16; ++i) snprintf(uuid + 2 * i, 3, "%02x", (unsigned)(unsigned char)pr.uuid.bytes[i]);
+    snprintf(buf, cap, "pci=%04x:%02x:%02x.0 uuid=%s arch=%s cus=%d", (unsigned)pr.pciDomainID, (unsigned)pr.pciBusID, (unsigned)pr.pciDeviceID,
+             uuid, pr.gcnArchName, pr.multiProcessorCount);
+    return JF_OK;
+}
+
 extern "C" int jf_version(void) { return JF_VERSION; }
 extern "C" const char *jf_last_error(void) { return g_err; }

@@ -6,6 +6,10 @@ import os
 from dataclasses import dataclass
 from typing import Optional
 
+# the host driver only supports dmabuf IPC (RCCL's P2P setup): must be in the environment before the HSA runtime starts, i.e.
+# before the first torch.cuda call of the process — importing this module is early enough, init_from_env would not be
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 import torch.distributed as dist
 
@@ -18,12 +22,22 @@ class RankInfo:
 
 
 def pin_rank_cpus(info: RankInfo, local_world: Optional[int] = None) -> Optional[int]:
-    """Give every rank of a node its own contiguous slice of the host cores (and an OMP/torch thread count to match), so
-    that eight ranks' host threads — the mailbox poll, the tokenizer-free driver loop, torch's intra-op pool — do not all
-    land on the same cores.  JF_PIN_CPUS=0 switches it off.  Returns the number of cores of the slice (None: untouched)."""
-    if os.environ.get("JF_PIN_CPUS", "1") == "0" or not hasattr(os, "sched_getaffinity"):
+    """OPT-IN (JF_PIN_CPUS=1): give every rank of a node its own contiguous slice of the host cores (and an OMP/torch thread
+    count to match).  Off by default since round 5: measured on the MI355X box with eight ranks of the real model on one host
+    (profiles/idle_gap_8ranks_r05.txt) the slices made the host gap between two iterations WORSE — median 21-45 us and p95
+    100-370 us per rank against 8.5-10.8 us / 14-46 us unpinned (one rank alone: 7.9 / 41 us): the kernel's own placement of
+    the ranks' main and runtime threads beats a topology-blind slice.  Returns the number of cores of the slice (None:
+    untouched)."""
+    if os.environ.get("JF_PIN_CPUS", "0") != "1" or not hasattr(os, "sched_getaffinity"):
         return None
-    lw = int(local_world or os.environ.get("LOCAL_WORLD_SIZE", info.world_size) or 1)
+    if local_world is None:
+        local_world = os.environ.get("LOCAL_WORLD_SIZE")          # set by torch.distributed.run
+    if local_world is None:
+        # no launcher variable: one rank per GPU means the node holds as many ranks as it has GPUs (never the GLOBAL world
+        # size: a multi-node job would otherwise give every rank 1 / world of its node's cores)
+        ngpu = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        local_world = min(info.world_size, ngpu) if ngpu > 0 else info.world_size
+    lw = int(local_world or 1)
     if lw <= 1:
         return None
     try:
@@ -52,7 +66,6 @@ def init_from_env(backend: Optional[str] = None, force: Optional[bool] = None) -
     if (ws > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver only supports dmabuf IPC (RCCL's P2P setup)
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -60,6 +73,59 @@ def init_from_env(backend: Optional[str] = None, force: Optional[bool] = None) -
         pin_rank_cpus(info)
         dist.init_process_group(backend=backend, rank=rank, world_size=ws)
     return info
+
+
+def device_identity(index: Optional[int] = None) -> dict:
+    """PCI bus id / UUID / architecture / CU count of the GPU this process launches on, asked of the HIP library that runs the
+    kernels (jf_device_identity) — what a rank puts into its record so that the N-GPU line can be checked for N devices."""
+    import ctypes
+    from . import _native
+    buf = ctypes.create_string_buffer(192)
+    _native.check(_native.lib().jf_device_identity(-1 if index is None else int(index), buf, len(buf)), "jf_device_identity")
+    out = {"raw": buf.value.decode()}
+    for kv in out["raw"].split():
+        k, _, v = kv.partition("=")
+        out[k] = int(v) if k == "cus" else v
+    return out
+
+
+def ranks_seen() -> int:
+    """World size as the COMMUNICATOR reports it (not the environment): 1 without a process group."""
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def gather_rank_records(record: dict) -> list:
+    """Every rank's record on every rank, in rank order (one all_gather of pickled dicts over the job's backend — RCCL on the
+    GPU box).  Without a process group: the one record."""
+    if not dist.is_initialized():
+        return [dict(record)]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, dict(record))
+    return out
+
+
+class DuplicateDeviceError(RuntimeError):
+    pass
+
+
+def check_distinct_devices(records: list, backend: Optional[str], allow_shared: bool = False) -> int:
+    """Number of distinct GPUs behind the ranks' records (their ``device`` PCI bus id, UUID as tie-breaker).  Over RCCL
+    ("nccl") two ranks on one device is never a valid N-GPU measurement: raise instead of reporting.  ``allow_shared`` is the
+    explicit plumbing mode (JF_FORCE_DEVICE + gloo on a one-GPU box): counted, reported, not refused."""
+    ids = [(r.get("device", {}).get("pci"), r.get("device", {}).get("uuid")) for r in records]
+    distinct = len(set(ids))
+    if distinct != len(records) and backend == "nccl" and not allow_shared:
+        dup = sorted({i for i in ids if ids.count(i) > 1})
+        raise DuplicateDeviceError(f"{len(records)} ranks on {distinct} distinct GPU(s): ranks "
+                                   f"{[r.get('rank') for r in records if (r.get('device', {}).get('pci'), r.get('device', {}).get('uuid')) in dup]} "
+                                   f"share {dup} — refusing to report an N-GPU number")
+    return distinct
+
+
+def spread(values) -> Optional[dict]:
+    """min / mean / max of the ranks' values (None entries skipped)."""
+    v = [float(x) for x in values if x is not None]
+    return dict(min=min(v), mean=sum(v) / len(v), max=max(v)) if v else None
 
 
 def backend_name() -> Optional[str]:

@@ -24,7 +24,8 @@ STAGE_HOOK = None       # bench.py: f(name, phase, nbytes) with phase "begin"/"e
                         # jf_rs_probs / jf_rs_step first ask f(name, "arm", nbytes): a (begin, end) pair of torch events (recorded once
                         # before, so their handles exist) is attached to the call's own dispatches (jf_timing_arm) and no "begin"/"end" follows
 LOOP_HOOKS = None       # bench.py: {"pack_end": f(batch), "forward_begin": f(batch)} — events behind the queued pack launch and in
-                        # front of the next forward's first kernel (GPU idle time between the loop body and the forward)
+                        # front of the next forward's first kernel (GPU idle time between the loop body and the forward);
+                        # "mailbox_seen": f(batch) the moment the host's poll returns (host clock: control time to the next forward)
 
 
 def _stage(name: str, nbytes: int):
@@ -458,6 +459,8 @@ class MultiblockLoop:
         rc = self._wait(self._mb_ptr, self.seq, self.timeout_us, _stream(b.device))
         if rc:
             N.check(rc, "jf_mailbox_wait")
+        if LOOP_HOOKS and "mailbox_seen" in LOOP_HOOKS:
+            LOOP_HOOKS["mailbox_seen"](b)
         s = LoopSummary(self._hdr[:12].tolist())
         self.last = s
         b.Rtot, b.Tpad, b.Nvalid = s.Rtot, s.Tpad, s.Nvalid

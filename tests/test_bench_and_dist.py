@@ -1,5 +1,6 @@
 """bench.py plumbing on the CPU (hostsim backend, tiny model) and the N>1 aggregation path over gloo."""
 import json
+import re
 import os
 import subprocess
 import sys
@@ -176,6 +177,80 @@ def test_two_rank_gloo_aggregation(tmp_path):
     assert d["agg"] == dict(tokens=300.0, iterations=20.0, seconds=2.0, world_size=2)
 
 
+_RECORDS_WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, {root!r})
+    import torch
+    from jacobiforcing_amd import distributed as jd
+    info = jd.init_from_env("gloo")
+    rec = dict(rank=info.rank, pid=os.getpid(), tokens=10 * (info.rank + 1), seconds=1.0 + info.rank,
+               device=dict(pci="0000:0%d:00.0" % (5 if {same} else 5 + info.rank), uuid="aa" * 16))
+    recs = jd.gather_rank_records(rec)
+    out = dict(recs=recs, seen=jd.ranks_seen(), distinct_gloo=jd.check_distinct_devices(recs, "gloo", allow_shared=True))
+    try:
+        out["distinct_nccl"] = jd.check_distinct_devices(recs, "nccl")
+    except jd.DuplicateDeviceError as e:
+        out["refused"] = str(e)
+    if info.rank == 1:
+        print(json.dumps(out))
+    torch.distributed.destroy_process_group()
+""")
+
+
+@pytest.mark.parametrize("same", [False, True], ids=["two-devices", "one-device"])
+def test_rank_records_are_gathered_and_duplicate_devices_refused(tmp_path, same):
+    """world_size-2 over gloo: every rank ends up with both records in rank order, the world size comes from the communicator,
+    and two ranks that name the same GPU are counted (plumbing mode) but REFUSED for an RCCL job — bench.py turns that into a
+    non-zero exit without a JSON line."""
+    script = tmp_path / "records.py"
+    script.write_text(_RECORDS_WORKER.format(root=str(ROOT), same=same))
+    with __import__("socket").socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", JF_PIN_CPUS="0")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    d = json.loads(outs[1][0].strip().splitlines()[-1])
+    assert d["seen"] == 2 and [x["rank"] for x in d["recs"]] == [0, 1] and d["recs"][0]["pid"] != d["recs"][1]["pid"]
+    assert [x["tokens"] for x in d["recs"]] == [10, 20]
+    if same:
+        assert d["distinct_gloo"] == 1 and "refused" in d and "share" in d["refused"] and "distinct_nccl" not in d
+    else:
+        assert d["distinct_gloo"] == 2 and d["distinct_nccl"] == 2 and "refused" not in d
+
+
+def test_duplicate_device_check_and_spread():
+    from jacobiforcing_amd import distributed as jd
+    mk = lambda r, pci: dict(rank=r, device=dict(pci=pci, uuid="00" * 16))
+    assert jd.check_distinct_devices([mk(0, "0000:05:00.0"), mk(1, "0000:15:00.0")], "nccl") == 2
+    with pytest.raises(jd.DuplicateDeviceError, match=r"ranks \[0, 2\] share"):
+        jd.check_distinct_devices([mk(0, "0000:05:00.0"), mk(1, "0000:15:00.0"), mk(2, "0000:05:00.0")], "nccl")
+    assert jd.check_distinct_devices([mk(0, "a"), mk(1, "a")], "gloo", allow_shared=True) == 1
+    assert jd.check_distinct_devices([mk(0, "a"), mk(1, "a")], None) == 1            # no RCCL job: counted, not refused
+    assert jd.spread([1.0, None, 3.0]) == dict(min=1.0, mean=2.0, max=3.0) and jd.spread([None]) is None
+    assert jd.ranks_seen() == 1
+
+
+def _assert_rank_evidence(d, ranks, distinct):
+    """The fields that let a reader verify N ranks from the line alone."""
+    assert d["n_gpus"] == d["ranks_seen"] == ranks and d["devices_distinct"] == distinct and d["shared_device"] == (distinct != ranks)
+    pr = d["per_rank"]
+    assert [x["rank"] for x in pr] == list(range(ranks)) and len({x["pid"] for x in pr}) == ranks
+    for x in pr:
+        assert re.fullmatch(r"[0-9a-f]{4}:[0-9a-f]{2}:[0-9a-f]{2}\.0", x["device"]["pci"]) and len(x["device"]["uuid"]) == 32
+        assert x["device"]["arch"].startswith("gfx") and x["device"]["cus"] > 0
+        assert x["tokens"] > 0 and x["seconds"] > 0 and x["iterations"] == d["steps"] and x["verify_launches"] == d["steps"]
+        assert x["verify_us"] > 0 and x["verify_bytes"] > 0 and x["host_gap_us_median"] > 0
+    chk = d["per_rank_check"]
+    assert chk["tokens_sum"] == sum(x["tokens"] for x in pr)
+    assert abs(chk["value_from_records"] - d["value"]) <= 1e-6 * d["value"]
+    br = d["roofline"]["by_rank"]
+    assert br["frac"]["min"] <= br["frac"]["mean"] <= br["frac"]["max"] and br["us_per_launch"]["min"] > 0
+    assert d["loop_body"]["by_rank"]["host_gap_us_median"]["max"] >= d["loop_body"]["by_rank"]["host_gap_us_median"]["min"] > 0
+
+
 def test_bench_launch_command_is_one_rank_per_gpu():
     """Started as a plain command with --gpus N > 1, bench.py re-runs itself under torch.distributed.run with N ranks on the
     loopback rendezvous (never a silent single-GPU run)."""
@@ -215,6 +290,7 @@ def test_bench_starts_its_own_ranks():
         assert d["n_gpus"] == 2 and d["scaling"] == mode and d["config"]["prompts_per_gpu"] == per_gpu
         assert d["config"]["total_prompts"] == 2 * per_gpu and d["value"] > 0 and d["steps"] == 3
         assert d["tokens_per_forward"] >= 1.0
+        _assert_rank_evidence(d, ranks=2, distinct=1)
 
 
 def test_eight_ranks_without_gpus_fail_with_the_ranks_message():
@@ -250,6 +326,8 @@ def test_eight_ranks_share_one_gpu():
     # every prompt accepts at least one token per step: the line carries all 8 ranks' tokens
     assert d["value"] * d["ms_per_step"] * 1e-3 * d["steps"] >= 64 * 4 * 0.99
     assert d["tokens_per_forward"] >= 1.0
+    _assert_rank_evidence(d, ranks=8, distinct=1)
+    assert all(x["cpus"] >= 1 for x in d["per_rank"])
 
 
 def test_shard_is_i_mod_world_for_eight_ranks():
@@ -320,6 +398,7 @@ def test_bench_single_gpu_through_rccl():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["dist_backend"] == "nccl" and d["value"] > 0 and d["steps"] == 3
+    _assert_rank_evidence(d, ranks=1, distinct=1)            # the record went through all_gather_object on RCCL
 
 
 def test_forced_single_rank_group_over_gloo(tmp_path):

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(raw, name)
     raw.jf_version.restype = ctypes.c_int
-    assert raw.jf_version() == 410
+    assert raw.jf_version() == int(re.search(r"#define JF_VERSION (\d+)", hdr).group(1)) == 500
 
 
 def test_plain_c_client(tmp_path):
@@ -49,7 +49,7 @@ def test_plain_c_client(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(ROOT / "tests" / "abi" / "abi_client.c"),
                            f"-L{lib.parent}", "-ljacobiforcing", f"-Wl,-rpath,{lib.parent}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
     out = subprocess.check_output([str(exe)], text=True)
-    assert "version=410" in out and "desc=64" in out and "params=40" in out
+    assert "version=500" in out and "desc=64" in out and "params=40" in out
     assert "rc=-1" in out and "null pointer" in out
 
 

@@ -37,6 +37,16 @@ rs_ab)                # microbenchmark of jf_rs_probs over experiment builds: ba
         echo "== $L"; JF_LIB=tools/libjf_exp_$L.so timeout 600 python tools/microbench_rs.py 1.0 0.8 2>&1 | grep -v amdgpu.ids | grep "R= 1984\|R=  496" | tee $O/microbench_$L.txt
     done
     ;;
+ranks8)               # what eight ranks do to one host: the real model, 8 prompts per rank, 1 rank vs 8 ranks sharing the one GPU (gloo)
+    COMMON="--steps 40 --warmup 8 --no-scripted --no-shapes --no-sections --cpu-baseline-seconds 0"
+    timeout 900 python bench.py --gpus 1 --prompts-per-gpu 8 $COMMON > $O/ranks1.json 2> $O/ranks1.err
+    JF_DIST_BACKEND=gloo JF_FORCE_DEVICE=0 timeout 1500 python bench.py --gpus 8 --total-prompts 64 $COMMON > $O/ranks8.json 2> $O/ranks8.err
+    JF_PIN_CPUS=0 JF_DIST_BACKEND=gloo JF_FORCE_DEVICE=0 timeout 1500 python bench.py --gpus 8 --total-prompts 64 $COMMON > $O/ranks8_unpinned.json 2> $O/ranks8_unpinned.err
+    python tools/idle_gap_table.py $O/ranks1.json $O/ranks8.json $O/ranks8_unpinned.json | tee $O/idle_gap.txt
+    ;;
+dist_tests)           # the N > 1 line's evidence fields on the GPU box
+    timeout 2400 $PYT tests/test_bench_and_dist.py -m gpu -x 2>&1 | tail -5
+    ;;
 *)
-    echo "sessions: rs_probs rs_ab"; exit 2;;
+    echo "sessions: rs_probs rs_ab ranks8 dist_tests"; exit 2;;
 esac
