@@ -248,6 +248,11 @@ enum {  /* resident driver block of one prompt (int32): header, then the text (p
 enum { JF_STOP_NONE = 0, JF_STOP_EOS = 1, JF_STOP_MAX_NEW_TOKENS = 2, JF_STOP_MAX_CALLS = 3, JF_STOP_MAX_SEQ_LEN = 4,
        JF_STOP_TEXT_FULL = 5 };
 
+/* jf_mb_loop.flags: publish the mailbox's sequence word behind a system-scope RELEASE fence instead of the default "write the
+ * tables through, drain the memory counter, store the word" order.  The default is validated on gfx950 (0 stale tables in 780 000
+ * rounds) and ~7 us cheaper per launch; the Python host runs a short self-test of it when it builds its first loop on a device
+ * and sets this bit if the host ever saw the word before the tables (a new driver / firmware), JF_PUBLISH_FENCE=1 forces it. */
+#define JF_MB_LOOP_PUBLISH_FENCE 1
 typedef struct jf_mb_loop {
     /* the state machines (same objects as jf_mb_begin / jf_mb_step / jf_mb_verify take) */
     int32_t *states; int64_t state_ints; int32_t P; int32_t order;   /* order: row order of the pack step, 0 prompt-major, 1 row 0 of every prompt first */
@@ -258,7 +263,8 @@ typedef struct jf_mb_loop {
     int32_t *row_cand;                            /* [rows] -1 = the row writes the main cache, else p * cand_rows + b - 1 */
     int32_t *row_kv_len;                          /* [rows] committed prefix length of the row's prompt           */
     int32_t *valid_index;                         /* nullable: compacted position list (see jf_mb_pack)           */
-    int32_t rows_cap, t_cap, t_align, valid_align, cand_rows, rsv0;
+    int32_t rows_cap, t_cap, t_align, valid_align, cand_rows;
+    int32_t flags;                                /* JF_MB_LOOP_* bits (was rsv0 = 0)                              */
     int64_t pad_fill;
     int32_t *kv_len;                              /* nullable [P]: committed length per prompt (the cache's)      */
     int32_t *mailbox;                             /* JF_MB_MAILBOX_INTS(P) ints of MAPPED PINNED HOST memory (jf_host_alloc) */
@@ -351,7 +357,8 @@ typedef struct jf_engine_row {
     int32_t eos;         /* EOS committed                                   */
     int32_t active_next; /* row keeps decoding (not eos, below max_tokens)  */
     int32_t n_pads;      /* pads consumed for the next draft                */
-    int32_t rsv[3];      /* scratch: [0] copied tokens, [1..2] the row's hand-off word inside the launch (zero the records once) */
+    int32_t rsv[3];      /* scratch: [0] JF_E_LAUNCH when the launch gave up waiting for this row (2 s bound; else what the two-launch
+                            path left: copied tokens), [1..2] the row's hand-off word inside the launch (zero the records once) */
 } jf_engine_row;
 
 JF_API int jf_engine_step(const int64_t *draft, int B, int L, uint64_t *packed, int32_t eos_id,

@@ -42,7 +42,7 @@ class MbLoop(C.Structure):
                 ("input_ids", C.c_void_p), ("positions", C.c_void_p), ("row_prompt", C.c_void_p), ("row_len", C.c_void_p),
                 ("row_cand", C.c_void_p), ("row_kv_len", C.c_void_p), ("valid_index", C.c_void_p),
                 ("rows_cap", C.c_int32), ("t_cap", C.c_int32), ("t_align", C.c_int32), ("valid_align", C.c_int32),
-                ("cand_rows", C.c_int32), ("rsv0", C.c_int32), ("pad_fill", C.c_int64),
+                ("cand_rows", C.c_int32), ("flags", C.c_int32), ("pad_fill", C.c_int64),
                 ("kv_len", C.c_void_p), ("mailbox", C.c_void_p),
                 ("drv", C.c_void_p), ("drv_ints", C.c_int64), ("draws", C.c_void_p), ("draw_len", C.c_int32),
                 ("max_seq_len", C.c_int32)]
@@ -70,6 +70,7 @@ class EngineRow(C.Structure):
 
 
 ENGINE_ROW_INTS = C.sizeof(EngineRow) // 4
+MB_LOOP_PUBLISH_FENCE = 1        # jf_mb_loop.flags (JF_MB_LOOP_PUBLISH_FENCE)
 ENGINE_FIELDS = ["acc_len", "n_new", "eos", "active_next", "n_pads", "rsv0", "rsv1", "rsv2"]   # int32 columns of a row record
 
 

@@ -80,18 +80,19 @@ struct DevLanes {
     // THROUGH (system-scope store); the drained counter then does order them in front of the sequence word (0 stale reads in
     // 780 000 rounds, profiles/mailbox_order_r03.txt).  A system-scope RELEASE fence instead would also write back everything
     // else this L2 holds (the state blocks the convergence launch has just stored, the forward inputs being packed):
-    // +7 us on the pack launch and on the host's wake-up (profiles/verify_release_ab_r03.txt); -DJF_EXP_PUBLISH_FENCE builds it.
+    // +7 us on the pack launch and on the host's wake-up (profiles/verify_release_ab_r03.txt); publish(..., fence = true) is that
+    // variant, chosen per loop at run time (jf_mb_loop.flags: the host's start-up self-test of the cheap order, ops.MultiblockLoop).
     __device__ __forceinline__ void mail(int32_t *word, int32_t v) const {
         __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __device__ __forceinline__ void publish(int32_t *word, int32_t v) const {
-#ifdef JF_EXP_PUBLISH_FENCE
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-        if (lane() == 0) __hip_atomic_store(word, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-#else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane() == 0) __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#endif
+    __device__ __forceinline__ void publish(int32_t *word, int32_t v, bool fence = false) const {
+        if (fence) {                                          // jf_mb_loop.flags & JF_MB_LOOP_PUBLISH_FENCE (wave-uniform): the formal order
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            if (lane() == 0) __hip_atomic_store(word, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane() == 0) __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 };
 

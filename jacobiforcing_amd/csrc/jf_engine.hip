@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void engine_step_kernel(const int64_t *draft, 
         if (tid == 0) {
             const int np = o.active_next ? (L - 1 - o.copy_len) : 0;
             rows[b].acc_len = o.acc_len; rows[b].n_new = o.n_new; rows[b].eos = o.eos; rows[b].active_next = o.active_next;
-            rows[b].n_pads = np; rows[b].rsv[0] = o.copy_len;
+            rows[b].n_pads = np;                              // (rsv[0] stays the pad workgroup's: the timeout marker below)
             __hip_atomic_store((unsigned long long *)__builtin_assume_aligned(&rows[b].rsv[1], 8),
                                ((unsigned long long)gen << 32) | ((unsigned long long)np << 16) | (unsigned long long)o.copy_len,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -109,7 +109,9 @@ __global__ __launch_bounds__(256) void engine_step_kernel(const int64_t *draft, 
         if (!ok) {                                            // the row never published: report it, touch nothing it may still be reading
             w = 0ull;
             s_bad = 1;
-            __hip_atomic_store(&rows[r].active_next, (int32_t)JF_E_LAUNCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // in a word NO row workgroup writes (the record's rsv[0]): a row that was slow, not hung, rewrites all of its own
+            // fields when it does run and would erase a marker kept in one of them
+            __hip_atomic_store(&rows[r].rsv[0], (int32_t)JF_E_LAUNCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         s_w[r] = (int)(w & 0xFFFFFFFFull);
     }

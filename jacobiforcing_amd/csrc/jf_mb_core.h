@@ -807,6 +807,7 @@ struct LoopDev {                   // what a step needs beyond the state block (
     int64_t drv_ints;
     const uint32_t *draws;         // [P, draw_len] pre-drawn 32-bit words for the restart drafts (DRV:209-215's random.choice)
     int32_t draw_len, text_cap, max_seq_len;
+    int32_t publish_fence;         // jf_mb_loop.flags & JF_MB_LOOP_PUBLISH_FENCE
     jf_mb_params prm;              // parameters of the calls (restarts begin with them)
 };
 
@@ -818,6 +819,7 @@ inline LoopDev make_loop_dev(const jf_mb_loop *lp, int32_t seq, const jf_mb_para
     d.t_align = lp->t_align < 1 ? 1 : lp->t_align; d.t_cap = lp->t_cap; d.valid_align = lp->valid_align < 1 ? 1 : lp->valid_align;
     d.drv = lp->drv; d.drv_ints = lp->drv_ints; d.draws = lp->draws; d.draw_len = lp->draw_len;
     d.text_cap = lp->drv ? (int32_t)(lp->drv_ints - JF_DRV_HDR_INTS) : 0; d.max_seq_len = lp->max_seq_len;
+    d.publish_fence = (lp->flags & JF_MB_LOOP_PUBLISH_FENCE) ? 1 : 0;
     d.prm = *params;
     return d;
 }
@@ -930,7 +932,7 @@ JF_HD void mb_publish_body(Lanes lanes, int P, const jf_mb_desc *desc, const Loo
         lanes.mail(mb + JF_MB_MAXKV, maxkv); lanes.mail(mb + JF_MB_ERROR, err_p); lanes.mail(mb + JF_MB_ACCEPTED, acc);
         lanes.mail(mb + JF_MB_NCALL_END, nend);
     }
-    lanes.publish(mb + JF_MB_SEQ, lp.seq);
+    lanes.publish(mb + JF_MB_SEQ, lp.seq, lp.publish_fence != 0);
 }
 
 template <class Lanes>

@@ -1652,6 +1652,7 @@ __device__ __forceinline__ void batched_for(int64_t n, int tid, int nthreads, Lo
 constexpr int RS_STAGE = 6144;      // accept tests / uniforms staged in LDS by the accept scan (B * (L-1) <= this, else global)
 constexpr int RS_ROWS_LDS = 2048;   // rows whose scan results are kept in LDS (half of it in the chain kernel)
 constexpr uint32_t RS_PE_EOS = 0x80000000u, RS_PE_AMB = 0x40000000u, RS_PE_VAL = 0x3FFFFFFFu;
+constexpr uint32_t RS_PATCH_NONE = 0xFFFFFFFFu;    // (no resolved word looks like this: a resolved test never carries RS_PE_AMB)
 constexpr int RS_RES_NONE = -1, RS_RES_ABORT = -2;   // s_res words of rows the walk has not decided / stopped at
 
 struct RsAcceptIn {                 // what an accept test's probability is made of
@@ -1671,10 +1672,18 @@ __device__ __forceinline__ uint32_t rs_accept_word(float pd, float M, bool is_eo
     } else {
         if (!(pd > 0.f)) return eos;
         if ((__float_as_uint(M) & 0x7F800000u) == 0x7F800000u) return (__float_as_uint(pd > 1.f ? 1.f : pd) & RS_PE_VAL) | eos;   // plain formula row
+        // The band [lo, hi] around the centre value that contains the exact probability: hi = lo (1 + 2^-12) while eps <= 1e-4
+        // (|max / T| < ~179), lo (1 + 2^-8) up to eps = 1.9e-3 (|max / T| < ~5 400: e.g. a maximum logit of 20 at T = 0.1 — round 5;
+        // before, such rows marked EVERY test undecided and resolved them one by one with a float64 row sum each).  The width is
+        // the word's lowest mantissa bit (lo is a lower bound: forcing that bit only lowers it by an ulp).
         const float eps = (float)rs_eps_row(M);
-        if (eps > 1.0e-4f) return RS_PE_AMB | eos;            // (|max / T| > 170) beyond the fixed band of rs_accept_hi: every rejection is resolved exactly
+        if (eps > 1.9e-3f) return RS_PE_AMB | eos;            // no band known: every rejection is resolved exactly
+        const bool wide = eps > 1.0e-4f;
         const float lo = pd * (1.f - eps - 1.2e-7f);
-        return (__float_as_uint(lo > 1.f ? 1.f : lo) & RS_PE_VAL) | RS_PE_AMB | eos;
+        uint32_t lb = __float_as_uint(lo > 1.f ? 1.f : lo) & RS_PE_VAL;
+        if (lb < 2u) return RS_PE_AMB | eos;
+        if ((lb & 1u) != (wide ? 1u : 0u)) lb -= 1u;
+        return lb | RS_PE_AMB | eos;
     }
 }
 template <int DT>
@@ -1686,7 +1695,7 @@ template <int DT>
 __device__ __forceinline__ float rs_accept_hi(uint32_t pe) {   // upper candidate of an ambiguous entry
     const uint32_t b = pe & RS_PE_VAL;
     if constexpr (DT == JF_BF16) return __uint_as_float(b + 0x00010000u);
-    else return b ? __uint_as_float(b) * 1.000244140625f : INFINITY;   // (1 + 2^-12) lo >= p (1 + eps) while eps <= 1e-4; 0: no band known
+    else return b ? __uint_as_float(b) * ((b & 1u) ? 1.00390625f : 1.000244140625f) : INFINITY;   // (1 + 2^-12) lo >= p (1 + eps) while eps <= 1e-4, (1 + 2^-8) lo up to 1.9e-3 (flagged in bit 0); 0: no band known
 }
 
 // STAGED: the batch fits the LDS tables (B * (L-1) <= RS_STAGE, B <= RS_ROWS_LDS) — the serial part touches LDS only.
@@ -1704,15 +1713,19 @@ __device__ __forceinline__ void rs_accept_body(const RsAcceptIn &in, const int64
     __shared__ int s_eunc[2], s_erow[2], s_eoff[2];                            // the evaluating wavefronts' first undecided test (index, row, its offset)
     __shared__ double s_tab[64], s_red[4];
     __shared__ int s_unc, s_resume, s_used;
-    __shared__ uint32_t s_patch_i[8], s_patch_v[8];                            // !STAGED: resolved entries (index, word)
-    __shared__ int s_npatch;
+    // !STAGED: the resolved tests of the row the walk stands at, one word per position of the row (RS_PATCH_NONE = not resolved),
+    // in the part of the workspace the later launches overwrite (w.wtsum).  A row can need a patch for every accepted test in
+    // front of its stop, and the rows in front of it never need theirs again: a per-ROW table (round 4 kept eight entries for the
+    // whole batch and overwrote the last one when full — a row with two live patches then never finished: ADVICE r04).
+    uint32_t *g_patch = (uint32_t *)w.wtsum;
+    __shared__ int s_patch_row;
     const int tid = threadIdx.x;
     const int W = L - 1;
     const int n = B * W;
     const int64_t uc0 = *u_cursor;
     auto tok_at = [&](int i) { const int b = i / W; return draft[(int64_t)b * L + (i - b * W) + 1]; };
     rs_load_tab(s_tab);
-    if (tid == 0) s_npatch = 0;
+    if (tid == 0) s_patch_row = -1;
     __syncthreads();
     if constexpr (STAGED) {
         const int ul = (int)u_len, ub = (int)(uc0 % u_len);
@@ -1883,7 +1896,10 @@ __device__ __forceinline__ void rs_accept_body(const RsAcceptIn &in, const int64
                         if constexpr (STAGED) { pe = s_p[i]; uu = s_u[used_total + tt]; }
                         else {
                             pe = rs_accept_entry<DT>(in, i, tok_at(i), eos_id, s_tab);
-                            for (int q = 0; q < s_npatch; ++q) if (s_patch_i[q] == (uint32_t)i) pe = s_patch_v[q];
+                            if (b == s_patch_row) {
+                                const uint32_t q = __hip_atomic_load(g_patch + tt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (q != RS_PATCH_NONE) pe = q;
+                            }
                             uu = u_stream[(uc0 + used_total + tt) % u_len];
                         }
                         const bool sure = uu < __uint_as_float(pe & RS_PE_VAL);
@@ -1935,7 +1951,18 @@ __device__ __forceinline__ void rs_accept_body(const RsAcceptIn &in, const int64
         if (tid == 0) {
             const uint32_t word = (__float_as_uint(pex > 1.f ? 1.f : pex) & RS_PE_VAL) | ((eos_id >= 0 && tk == (int64_t)eos_id) ? RS_PE_EOS : 0u);
             if constexpr (STAGED) s_p[ui] = word;
-            else { const int q = s_npatch < 8 ? s_npatch : 7; s_patch_i[q] = (uint32_t)ui; s_patch_v[q] = word; s_npatch = q + 1; }
+        }
+        if constexpr (!STAGED) {
+            const int prow = ui / W;
+            if (prow != s_patch_row) {                              // the walk has moved on to another row: its table starts empty
+                for (int t = tid; t < W; t += 256) __hip_atomic_store(g_patch + t, RS_PATCH_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                if (tid == 0) s_patch_row = prow;
+            }
+            if (tid == 0) {
+                const uint32_t word = (__float_as_uint(pex > 1.f ? 1.f : pex) & RS_PE_VAL) | ((eos_id >= 0 && tk == (int64_t)eos_id) ? RS_PE_EOS : 0u);
+                __hip_atomic_store(g_patch + (ui - prow * W), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         b_start = s_resume; used_start = s_used;
         __syncthreads();
@@ -2592,15 +2619,13 @@ __global__ __launch_bounds__(256) void rs_op_accept_kernel(RsAcceptIn in, const 
     __shared__ uint32_t s_p[RS_OP_STAGE];
     __shared__ double s_tab[64], s_red[4];
     __shared__ int s_unc, s_n, s_stop, s_rej, s_used;
-    __shared__ uint32_t s_patch_i[8], s_patch_v[8];
-    __shared__ int s_npatch;
+    uint32_t *g_patch = (uint32_t *)w.wtsum;      // !staged: one word per test, RS_PATCH_NONE = not resolved (the later launches overwrite it)
     const int tid = threadIdx.x;
     const int64_t uc = *u_cursor;
     const bool staged = R <= RS_OP_STAGE;
     rs_load_tab(s_tab);
-    if (tid == 0) s_npatch = 0;
-    __syncthreads();
     if (staged) for (int i = tid; i < R; i += 256) s_p[i] = rs_accept_entry<DT>(in, i, proposed[i], -1, s_tab);
+    else for (int i = tid; i < R; i += 256) __hip_atomic_store(g_patch + i, RS_PATCH_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     for (;;) {
         if (tid < 64) {
@@ -2612,7 +2637,11 @@ __global__ __launch_bounds__(256) void rs_op_accept_kernel(RsAcceptIn in, const 
                 if (t < R) {
                     uint32_t pe;
                     if (staged) pe = s_p[t];
-                    else { pe = rs_accept_entry<DT>(in, t, proposed[t], -1, s_tab); for (int q = 0; q < s_npatch; ++q) if (s_patch_i[q] == (uint32_t)t) pe = s_patch_v[q]; }
+                    else {
+                        pe = rs_accept_entry<DT>(in, t, proposed[t], -1, s_tab);
+                        const uint32_t q = __hip_atomic_load(g_patch + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (q != RS_PATCH_NONE) pe = q;
+                    }
                     const float uu = u_stream[(uc + t) % u_len];
                     rejb = !(uu < __uint_as_float(pe & RS_PE_VAL));
                     unc = rejb && (pe & RS_PE_AMB) && uu < rs_accept_hi<DT>(pe);
@@ -2639,7 +2668,7 @@ __global__ __launch_bounds__(256) void rs_op_accept_kernel(RsAcceptIn in, const 
         if (tid == 0) {
             const uint32_t word = __float_as_uint(pex > 1.f ? 1.f : pex) & RS_PE_VAL;
             if (staged) s_p[ui] = word;
-            else { const int q = s_npatch < 8 ? s_npatch : 7; s_patch_i[q] = (uint32_t)ui; s_patch_v[q] = word; s_npatch = q + 1; }
+            else __hip_atomic_store(g_patch + ui, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
     }
@@ -2824,6 +2853,9 @@ extern "C" int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_
     if (tm.begin) (void)hipEventRecord(tm.begin, s);                 // several launches: the events bracket them
     const RsAcceptIn in{logits, V, row_stride, t, row_max, row_sumexp, p_draft};
     const bool staged = (int64_t)B * (L - 1) <= RS_STAGE && B <= RS_ROWS_LDS && u_len < 0x7FFFFFFFll;
+    // the walk outside LDS keeps a row's resolved tests in the workspace's wave-tile block (one word per position of a row)
+    if (!staged && (int64_t)(L - 1) > (int64_t)((B + 3) / 4 * 4) * RS_SEG * RS_WT * 2)
+        return fail(JF_E_CAPACITY, "jf_rs_step: a block of %d tokens with %d rows does not fit the step workspace's patch table", L, B);
     const bool chain_in_bonus = B <= RS_BONUS_CHAIN_ROWS;
 #define JF_RS_MULTI(DT)                                                                                                                        \
     if (staged) rs_accept_kernel<DT, true><<<1, 256, 0, s>>>(in, draft, B, L, eos_id, u_stream, u_len, u_cursor, committed, rows, w);           \

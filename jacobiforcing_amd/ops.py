@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import sys
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -362,12 +363,62 @@ class MultiblockLoop:
     in mapped pinned host memory that the host polls for (Rtot, Tpad, ...) instead of copying descriptors and synchronising
     the stream.  Row order 1: row 0 of every prompt first (the cache rows in order, attended in place), candidate rows after."""
 
+    # jf_mb_loop.flags per device: None = not decided yet.  Decided once per process and device by mailbox_selftest() — or by
+    # JF_PUBLISH_FENCE=0/1 — when the first loop on that device is built.
+    PUBLISH_FENCE: dict = {}
+    SELFTEST_LOG: dict = {}            # device -> (rounds, stale) of the self-test that decided (tests / bench read it)
+
+    @classmethod
+    def publish_flags(cls, dev: torch.device) -> int:
+        key = (dev.type, dev.index)
+        if key not in cls.PUBLISH_FENCE:
+            forced = os.environ.get("JF_PUBLISH_FENCE")
+            if forced in ("0", "1"):
+                cls.PUBLISH_FENCE[key] = int(forced)
+            elif dev.type != "cuda" or os.environ.get("JF_MAILBOX_SELFTEST", "1") == "0":
+                cls.PUBLISH_FENCE[key] = 0
+            else:
+                cls.PUBLISH_FENCE[key] = 0                         # (the self-test's own loop is built with the cheap order)
+                rounds, stale = cls.mailbox_selftest(dev, int(os.environ.get("JF_MAILBOX_SELFTEST_ROUNDS", "1000")))
+                cls.SELFTEST_LOG[key] = (rounds, stale)
+                if stale:
+                    cls.PUBLISH_FENCE[key] = N.MB_LOOP_PUBLISH_FENCE
+                    print(f"jacobiforcing_amd: the mailbox self-test saw the sequence word before the tables in {stale} of {rounds} rounds on "
+                          f"{dev}: publishing behind a release fence from now on (JF_MB_LOOP_PUBLISH_FENCE, ~7 us per launch)", file=sys.stderr)
+        return cls.PUBLISH_FENCE[key]
+
+    @staticmethod
+    def mailbox_selftest(dev: torch.device, rounds: int = 1000, prompts: int = 48) -> tuple:
+        """The check of tools/mailbox_stress.py through the shipped library: jf_mb_loop_begin restarts every prompt, its pack
+        launch copies all descriptors into the mailbox and stamps it, the host waits for the stamp and looks at the table AT ONCE
+        (the slots were overwritten with a marker before).  Returns (rounds, rounds in which the table was not there yet)."""
+        P, n = int(prompts), 16
+        prm = MultiblockParams(n=n, K=2, r=0.85, n_gram_pool_size=4, eos_token_id=None, pad_token_id=0)
+        batch = MultiblockBatch(P, prm, dev)
+        kvl = torch.zeros(P, dtype=torch.int32, device=dev)
+        lp = MultiblockLoop(batch, kv_len=kvl, t_cap=64, t_align=1, valid_align=8, compact=True, cand_rows=3, order=1, max_seq_len=1 << 20)
+        fB, fT, fkv = (N.DESC_FIELDS.index(k) for k in ("B", "T", "kv_len"))
+        g = np.random.default_rng(1)
+        ids = torch.from_numpy(g.integers(1, 1000, size=(P, n))).to(dev)
+        kvs = [g.integers(5, 500, size=P).astype(np.int32) for _ in range(8)]
+        kvd = [torch.from_numpy(k) for k in kvs]
+        stale = 0
+        for i in range(int(rounds)):
+            lp.mailbox[N.MB_MAILBOX_HDR:N.MB_MAILBOX_HDR + P * N.DESC_INTS] = -7
+            s = lp.begin(ids, kvd[i & 7])
+            d = s.d
+            ok = (d[:, fB] == 1).all() and (d[:, fT] == n).all() and (d[:, fkv] == kvs[i & 7]).all() and s.Rtot == P and s.Nvalid == P * n
+            stale += 0 if ok else 1
+        lp.close()
+        return int(rounds), stale
+
     def __init__(self, batch: "MultiblockBatch", kv_len: Optional[torch.Tensor], t_cap: int, t_align: int = 1, valid_align: int = 1,
                  compact: bool = True, cand_rows: int = 1, order: int = 1, max_seq_len: int = 0,
                  drv: Optional[torch.Tensor] = None, draws: Optional[torch.Tensor] = None, wait_timeout_s: float = 30.0):
         b = self.batch = batch
         dev = b.device
         lib = N.lib()
+        self.flags = self.publish_flags(torch.device(dev))
         self.compact = bool(compact)
         self.t_cap = int(min(t_cap, b.max_tokens))
         rows = b.P * b.max_rows
@@ -393,7 +444,7 @@ class MultiblockLoop:
             row_len=b.row_len.data_ptr(), row_cand=self.row_cand.data_ptr(), row_kv_len=self.row_kv.data_ptr(),
             valid_index=b.valid_index_buf.data_ptr() if compact else None,
             rows_cap=rows, t_cap=self.t_cap, t_align=int(t_align), valid_align=int(valid_align), cand_rows=int(max(cand_rows, 1)),
-            rsv0=0, pad_fill=int(fill), kv_len=None if kv_len is None else kv_len.data_ptr(), mailbox=ptr.value,
+            flags=int(self.flags), pad_fill=int(fill), kv_len=None if kv_len is None else kv_len.data_ptr(), mailbox=ptr.value,
             drv=None if drv is None else drv.data_ptr(),
             drv_ints=0 if drv is None else int(drv.shape[1]), draws=None if draws is None else draws.data_ptr(),
             draw_len=0 if draws is None else int(draws.shape[1]), max_seq_len=int(max_seq_len))
@@ -636,8 +687,8 @@ class EngineStepper:
         th.copy_(nt, non_blocking=True)
         if self.device.type == "cuda":
             torch.cuda.current_stream(self.device).synchronize()
-        if (self.rows_host[:B, N.ENGINE_FIELDS.index("active_next")] < 0).any():     # the pad workgroup gave up waiting for a row (2 s bound)
-            self.rows_dev[:B, N.ENGINE_FIELDS.index("active_next")] = 0
+        if (self.rows_host[:B, N.ENGINE_FIELDS.index("rsv0")] < 0).any():            # the pad workgroup gave up waiting for a row (2 s bound):
+            self.rows_dev[:B, N.ENGINE_FIELDS.index("rsv0")] = 0                     # its marker sits in a word the row workgroups never write
             self.packed.zero_()
             N.check(N.JF_E_LAUNCH, "jf_engine_step (a row never published its hand-off word: launch incomplete)")
         return self.rows_host[:B].numpy(), th.numpy(), nd

@@ -22,7 +22,7 @@ struct HostLanes {
     int count_true(bool pred) const { return pred ? 1 : 0; }
     int prefix_count(bool) const { return 0; }
     void mail(int32_t *word, int32_t v) const { *word = v; }
-    void publish(int32_t *word, int32_t v) const { *word = v; }
+    void publish(int32_t *word, int32_t v, bool = false) const { *word = v; }
 };
 
 static int g_fast = 1;

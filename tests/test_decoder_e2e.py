@@ -217,6 +217,42 @@ def test_mailbox_tables_are_visible_when_the_sequence_word_is():
         assert rounds > 500 and stale == 0, (rounds, stale)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("resident", [True, False], ids=["resident", "hostdriven"])
+def test_mailbox_selftest_and_the_release_fence_fallback(resident, monkeypatch):
+    """The first loop a process builds on a device runs the mailbox check through the shipped library (ops.MultiblockLoop.
+    mailbox_selftest: every round restarts 48 prompts and looks at the descriptor table the moment the sequence word is seen); a
+    stale table would switch every later loop to JF_MB_LOOP_PUBLISH_FENCE (the release-fence order, ~7 us per launch).  Here: the
+    cheap order passes, and a decoder FORCED onto the fence decodes the same tokens through the same calls (both drivers)."""
+    with use_backend("hip"):
+        dev = torch.device("cuda", torch.cuda.current_device())
+        rounds, stale = ops.MultiblockLoop.mailbox_selftest(dev, 400)
+        assert (rounds, stale) == (400, 0)
+        model = tiny_model(dev, seed=19)
+        V = model.cfg.vocab_size
+        prm = ops.MultiblockParams(n=16, K=2, r=0.85, n_gram_pool_size=4, eos_token_id=V - 1, pad_token_id=V - 2)
+        rng = np.random.default_rng(11)
+        prompts = [[int(t) for t in rng.integers(0, V - 2, size=int(L))] for L in (9, 17, 5, 30, 12)]
+        got = {}
+        for fence in (0, 1):
+            monkeypatch.setitem(ops.MultiblockLoop.PUBLISH_FENCE, ("cuda", dev.index), fence)
+            dec = MultiblockJacobiDecoder(model, len(prompts), prm, max_seq_len=256, resident=resident)
+            assert dec.loop.c_loop.flags == fence
+            stats, _, iters = dec.generate(prompts, max_new_tokens=48, max_calls=6, seed=5)
+            got[fence] = ([st.token_ids for st in stats], [st.calls for st in stats], [st.total_iterations for st in stats], iters)
+        assert got[0] == got[1]
+        assert sum(len(t) for t in got[0][0]) > 5 * 16
+
+
+def test_publish_fence_is_decided_once_per_device(monkeypatch):
+    """Without a GPU (hostsim) the flag is 0 and no self-test runs; JF_PUBLISH_FENCE=1 forces the fence without a test."""
+    monkeypatch.setattr(ops.MultiblockLoop, "PUBLISH_FENCE", {})
+    assert ops.MultiblockLoop.publish_flags(torch.device("cpu")) == 0
+    monkeypatch.setattr(ops.MultiblockLoop, "PUBLISH_FENCE", {})
+    monkeypatch.setenv("JF_PUBLISH_FENCE", "1")
+    assert ops.MultiblockLoop.publish_flags(torch.device("cpu")) == N.MB_LOOP_PUBLISH_FENCE == 1
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_position_list_puts_long_steps_first(backend):
     """The loop's pack step orders the position list (= the logits rows, = the stream of the convergence launch) with the

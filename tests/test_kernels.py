@@ -673,6 +673,66 @@ def test_rs_step_beyond_the_lds_tables(B, L, V):
     _assert_rs_equal(a, b, B)
 
 
+def _run_rs_given(backend, draft, logits, unis, bonus, pads, temperature, eos=None):
+    with use_backend(backend):
+        dev = device_for(backend)
+        B, L = draft.shape
+        st = ops.RsStepper(B, L, dev, pads, unis, bonus)
+        rows, toks, nd = st.step(draft.to(dev), logits.to(dev), temperature, eos, [L] * B, [3, 5, 7])
+        return rows.copy(), toks.copy(), nd.cpu().numpy().copy(), st.cursors.cpu().tolist()
+
+
+@GPU
+@pytest.mark.parametrize("B,L,V", [(100, 65, 64), (8, 9, 2000)], ids=["outside_lds", "staged"])
+def test_rs_step_every_accepted_test_needs_the_exact_probability(B, L, V):
+    """Uniforms placed 2e-6 (relative) below the EXACT probability of every proposal: each test lies inside the error band of
+    the streaming kernel's float32 row sum, so each one is resolved with the row's float64 sum — and then accepted, so a row of
+    L - 1 tests carries L - 1 resolved words while the walk works through it.  Round 4's eight-entry patch table of the walk
+    outside LDS overwrote its last entry when full and such a row never finished; the table is one word per
+    position of the current row now.  Every proposal must come out accepted, no bonus draw, cursors = B (L - 1)."""
+    g = torch.Generator().manual_seed(77)
+    draft = torch.randint(0, V, (B, L), generator=g)
+    logits = torch.randn(B, L - 1, V, generator=g) * 0.3
+    logits.scatter_(2, draft[:, 1:].unsqueeze(-1), float(np.log(0.9 / 0.1 * (V - 1))))
+    x = logits.double()
+    pex = torch.softmax(x, dim=-1).gather(2, draft[:, 1:].unsqueeze(-1)).squeeze(-1)          # float64: the exact value to 1e-16
+    unis = (pex * (1.0 - 2e-6)).float().reshape(-1)
+    assert (unis.double() < pex.reshape(-1)).all()
+    n = 4 * B * L
+    unis = torch.cat([torch.full((3,), 0.5), unis, torch.full((n,), 0.5)])     # (_run_rs_given starts the stream at cursor 3)
+    bonus = torch.randint(0, 1 << 24, (n,), generator=g).float() / float(1 << 24)
+    pads = torch.randint(0, V, (n,), generator=g)
+    a = _run_rs_given("hip", draft, logits, unis, bonus, pads, 1.0)
+    b = _run_rs_given("hostsim", draft, logits, unis, bonus, pads, 1.0)
+    f = N.RS_FIELDS.index
+    assert (b[0][:, f("n_committed")] == L - 1).all() and (b[0][:, f("reject_pos")] == -1).all()
+    _assert_rs_equal(a, b, B)
+
+
+@GPU
+@pytest.mark.parametrize("B,L,V", [(48, 9, 2000), (300, 33, 64)], ids=["staged", "outside_lds"])
+def test_rs_step_float32_rows_with_a_large_scaled_maximum(B, L, V):
+    """float32 logits around 30 at T = 0.1: the scaled maximum is ~300, the error bound of the streaming sum grows with it
+    (rs_eps_row) and passes the 1e-4 the narrow accept band covers.  Such rows carry the WIDE band (2^-8, flagged in the word's
+    lowest mantissa bit) — round 4 marked every one of their tests undecided and resolved them serially; the results are the
+    oracle's either way."""
+    T = 0.1
+    g = torch.Generator().manual_seed(5)
+    draft = torch.randint(0, V, (B, L), generator=g)
+    logits = torch.randn(B, L - 1, V, generator=g) * 0.3
+    logits.scatter_(2, draft[:, 1:].unsqueeze(-1), float(np.log(0.5 / 0.5 * (V - 1))))
+    logits = logits * T + 30.0
+    n = 4 * B * L
+    unis = torch.randint(0, 1 << 24, (n,), generator=g).float() / float(1 << 24)
+    bonus = torch.randint(0, 1 << 24, (n,), generator=g).float() / float(1 << 24)
+    pads = torch.randint(0, V, (n,), generator=g)
+    a = _run_rs_given("hip", draft, logits, unis, bonus, pads, T, eos=3)
+    b = _run_rs_given("hostsim", draft, logits, unis, bonus, pads, T, eos=3)
+    f = N.RS_FIELDS.index
+    assert (b[0][:, f("reject_pos")] >= 0).sum() >= B // 4 and (b[0][:, f("n_committed")] > 1).sum() >= B // 8
+    _assert_rs_equal(a, b, B)
+
+
 @GPU
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("coarse", [False, True], ids=["distinct_logits", "tied_logits"])
