@@ -40,6 +40,20 @@ def test_library_exports_every_declared_symbol():
     assert raw.jf_version() == int(re.search(r"#define JF_VERSION (\d+)", hdr).group(1)) == 500
 
 
+def test_docs_state_the_headers_entry_point_count_and_version():
+    """INTEGRATION.md and COVERAGE.md name the number of entry points and the ABI version: both must be the header's (they
+    drifted once: "34 entry points, ABI 400" beside a header with 35 at version 410)."""
+    hdr = (ROOT / "include" / "jacobiforcing.h").read_text()
+    n = len(set(re.findall(r"^JF_API\s+[^;(]*?\b(jf_[a-z_0-9]+)\s*\(", hdr, flags=re.M)))
+    ver = int(re.search(r"#define JF_VERSION (\d+)", hdr).group(1))
+    assert n == len(N.EXPORTED_SYMBOLS)
+    integ = (ROOT / "INTEGRATION.md").read_text()
+    cov = (ROOT / "COVERAGE.md").read_text()
+    counts = [int(x) for x in re.findall(r"(\d+) (?:`jf_\*` )?entry points", integ + cov)]
+    assert counts and all(c == n for c in counts), (counts, n)
+    assert f"ABI version {ver}" in integ and f"ABI {ver})" in cov
+
+
 def test_plain_c_client(tmp_path):
     """The boundary is a C ABI: a C99 program including include/jacobiforcing.h compiles with gcc, links against the shared
     library and gets answers (sizes, argument validation with jf_last_error) without a GPU."""

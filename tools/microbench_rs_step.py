@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--block", type=int, default=32)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--p-hit", type=float, default=0.6)
-    ap.add_argument("--trace", action="store_true", help="in-kernel stamps of the one-launch step (JF_LIB=tools/libjf_exp_rstrace.so)")
+    ap.add_argument("--trace", action="store_true", help="in-kernel stamps of the one-launch step (JF_LIB=tools/exp/libjf_exp_rstrace.so)")
     ap.add_argument("--checkpoint-like", action="store_true",
                     help="what a trained Jacobi-Forcing checkpoint gives the step: every row's first 1-6 proposals hold ~0.97 of their position's "
                          "mass (accepted), the next one ~0.02 (rejected; its residual draw almost never collides with it)")

@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Timeline of the fused verify launch (jf_mb_verify) at 1 / 8 / 64 prompts: synthetic bf16 logits at V = 152064, the state
 machines advance with whatever those logits accept.  Prints HIP-event microseconds of the fused launch and of the two
-launches it replaces; with the experiment build (-DJF_EXP_VERIFY_TRACE, JF_LIB=tools/libjf_exp_vtrace.so) also the
+launches it replaces; with the experiment build (-DJF_EXP_VERIFY_TRACE, JF_LIB=tools/exp/libjf_exp_vtrace.so) also the
 in-kernel stamps: when the items ran and what each stepper did after its rows arrived.
 
     python tools/verify_trace.py [--prompts 1 8 64] [--iters 12]
 
 Experiment build (run in the repo root; the .so is git-ignored and travels with gpurun):
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden -DJF_EXP_VERIFY_TRACE -Iinclude \
-          -Ijacobiforcing_amd/csrc jacobiforcing_amd/csrc/*.hip -o tools/libjf_exp_vtrace.so
+          -Ijacobiforcing_amd/csrc jacobiforcing_amd/csrc/*.hip -o tools/exp/libjf_exp_vtrace.so
 """
 import argparse
 import ctypes as C

@@ -3,7 +3,7 @@
 GEMM), next to tools/verify_trace.py (synthetic logits nobody has just written).  Needs the experiment build:
 
     tools/build_exp.sh vtrace -DJF_EXP_VERIFY_TRACE
-    JF_LIB=tools/libjf_exp_vtrace.so python tools/verify_trace_insitu.py [--prompts 64] [--iters 24]
+    JF_LIB=tools/exp/libjf_exp_vtrace.so python tools/verify_trace_insitu.py [--prompts 64] [--iters 24]
 
 Every traced iteration resets the stamp buffers before the launch (a blocking copy: the launch then starts from an idle
 queue, the memory system is as the forward left it) and reads them after it."""
@@ -38,7 +38,7 @@ def main():
     a = ap.parse_args()
     lib = _native.lib()
     if not hasattr(lib, "jf_exp_read_vtrace"):
-        raise SystemExit("needs JF_LIB=tools/libjf_exp_vtrace.so (tools/build_exp.sh vtrace -DJF_EXP_VERIFY_TRACE)")
+        raise SystemExit("needs JF_LIB=tools/exp/libjf_exp_vtrace.so (tools/build_exp.sh vtrace -DJF_EXP_VERIFY_TRACE)")
     dev = torch.device("cuda", 0)
     tuned = enable_tuned_gemms()
     cfg = Qwen2Config.qwen2_5_coder_7b()
