@@ -861,14 +861,104 @@ def softmax_rows_bf16(logits: np.ndarray, temperature: float) -> np.ndarray:
     return exact_softmax_rows(x, 7)
 
 
-def target_probs(logits: np.ndarray, temperature: float, logits_dtype: str = "f32") -> np.ndarray:
-    """_build_target_probs (JDN:110-123 / JDO:128-136) for the dtype the forward callback returned.  top_k / top_p are
-    not SamplingParams fields (sampling_params.py:4-38), so the getattr defaults (None) always apply."""
+def _round_values(x64: np.ndarray, mant_bits: int) -> np.ndarray:
+    """float64 values (sums of a few thousand grid values, or one quotient of two grid values: both far from needing more than
+    float64) rounded ONCE to the probability grid: float32 (23) or bfloat16 (7), nearest-even, as float32."""
+    f = np.asarray(x64, dtype=np.float64)
+    if mant_bits == 23:
+        return f.astype(np.float32)
+    # float64 -> bf16 in one rounding: round-to-odd into float32 first (a plain float32 cast would round twice)
+    shape = f.shape
+    f = np.atleast_1d(f)
+    f32 = f.astype(np.float32)
+    bits = f32.view(np.uint32).copy()
+    back = f32.astype(np.float64)
+    bits = np.where(back > f, bits - np.uint32(1), bits)            # toward zero (values are non-negative)
+    bits = np.where(back != f, bits | np.uint32(1), bits)           # sticky
+    return bf16_round(bits.astype(np.uint32).view(np.float32)).reshape(shape)
+
+
+def _div_in_dtype(num: np.ndarray, den: float, mant_bits: int) -> np.ndarray:
+    """``tensor / scalar-tensor`` as torch forms it in the tensor's dtype: a float32 quotient of the float32 images (ATen's
+    div_true_kernel, correctly rounded), rounded once more to bf16 for bf16 tensors."""
+    q = (np.asarray(num, dtype=np.float32) / np.float32(den)).astype(np.float32)
+    return q if mant_bits == 23 else bf16_round(q)
+
+
+def filter_probs_row(p: np.ndarray, top_k, top_p, mant_bits: int) -> np.ndarray:
+    """_apply_top_k then _apply_top_p (JDN:72-107) on ONE probability row ``p`` (values on the dtype's grid), in the arithmetic of
+    that dtype, with the two things torch leaves to its kernels DEFINED:
+
+    * **ties**: torch.topk / torch.sort do not say which of several EQUAL probabilities come first (the CPU kernels are
+      neither stable nor consistent between sizes: a 7-element row picks [1, 5, 3] of four equal values, a 5 000-element row the
+      lowest indices).  Here equal values are ordered by INDEX, lowest first — the order of a stable descending sort.  A row whose
+      kept set ends INSIDE a group of equal values is therefore "ours": the reference's choice among those ids is its kernel's.
+    * **sums**: ``out.sum()`` and ``cumsum`` accumulate in float32 in a kernel-specific order and round to the dtype.  Here every
+      sum is the EXACT sum rounded once to the dtype (float64 holds sums of <= 2^18 grid values exactly enough: 2^-35 relative).
+      torch's result differs only when the exact sum lies within its accumulation error of a rounding boundary.
+
+    Everything else is torch's arithmetic to the bit: ``sum.clamp_min(1e-12)`` in the dtype, the quotient ``p / sum`` (float32
+    division, rounded again to bf16 for bf16 tensors), ``cdf <= top_p`` with the Python float cast to the tensor's dtype, "at
+    least one kept".  Returns float32 values on the dtype's grid."""
+    r = np.asarray(p, dtype=np.float32).copy()
+    V = r.shape[0]
+    grid = (lambda x: np.float32(x)) if mant_bits == 23 else (lambda x: np.float32(bf16_round(np.array([x], dtype=np.float32))[0]))
+    floor = grid(1e-12)
+    if top_k is not None and 0 < int(top_k) < V:                                    # JDN:73-84
+        order = np.lexsort((np.arange(V), -r.astype(np.float64)))                   # value descending, index ascending
+        keep = np.zeros(V, dtype=bool)
+        keep[order[:int(top_k)]] = True
+        s1 = _round_values(np.sum(r[keep].astype(np.float64)), mant_bits)
+        s1 = max(np.float32(s1), floor)
+        r = np.where(keep, _div_in_dtype(r, s1, mant_bits), np.float32(0)).astype(np.float32)
+    if top_p is not None and 0.0 < float(top_p) < 1.0:                              # JDN:91-107
+        tp = grid(float(top_p))
+        order = np.lexsort((np.arange(V), -r.astype(np.float64)))
+        cdf = _round_values(np.cumsum(r[order].astype(np.float64)), mant_bits)
+        keep_sorted = cdf <= tp
+        keep_sorted[0] = True
+        keep = np.zeros(V, dtype=bool)
+        keep[order[keep_sorted]] = True
+        s2 = _round_values(np.sum(r[keep].astype(np.float64)), mant_bits)
+        s2 = max(np.float32(s2), floor)
+        r = np.where(keep, _div_in_dtype(r, s2, mant_bits), np.float32(0)).astype(np.float32)
+    return r
+
+
+def filter_boundary_is_tied(p: np.ndarray, top_k, top_p, mant_bits: int) -> bool:
+    """True when a kept set of filter_probs_row ends inside a group of equal values (the reference's own choice among the tied
+    ids is then its kernels', not the algorithm's: such rows are 'defined here', not pinned)."""
+    r = np.asarray(p, dtype=np.float32).copy()
+    V = r.shape[0]
+    tied = False
+    if top_k is not None and 0 < int(top_k) < V:
+        srt = np.sort(r.astype(np.float64))[::-1]
+        tied |= bool(srt[int(top_k) - 1] == srt[int(top_k)])
+        r = filter_probs_row(p, top_k, None, mant_bits)
+    if top_p is not None and 0.0 < float(top_p) < 1.0:
+        q = filter_probs_row(r, None, top_p, mant_bits)
+        kept_min = q[q > 0].size and r[q > 0].min()
+        tied |= bool(((q == 0) & (r == kept_min) & (r > 0)).any())
+    return tied
+
+
+def target_probs(logits: np.ndarray, temperature: float, logits_dtype: str = "f32", top_k=None, top_p=None) -> np.ndarray:
+    """_build_target_probs (JDN:110-123 / JDO:128-136) for the dtype the forward callback returned.  top_k / top_p are not
+    SamplingParams fields (sampling_params.py:4-38): the reference reads them with getattr, so they only exist when a caller
+    planted them on the request object (None: the plain softmax)."""
     if logits_dtype == "bf16":
-        return softmax_rows_bf16(logits, temperature)
-    if logits_dtype != "f32":
+        p, mb = softmax_rows_bf16(logits, temperature), 7
+    elif logits_dtype == "f32":
+        p, mb = softmax_rows_f32(logits, temperature), 23
+    else:
         raise ValueError(f"logits_dtype must be 'f32' or 'bf16', got {logits_dtype!r}")
-    return softmax_rows_f32(logits, temperature)
+    k_on = top_k is not None and 0 < int(top_k) < p.shape[-1]
+    p_on = top_p is not None and 0.0 < float(top_p) < 1.0
+    if not (k_on or p_on):
+        return p
+    flat = p.reshape(-1, p.shape[-1])
+    out = np.stack([filter_probs_row(row, top_k, top_p, mb) for row in flat], 0)
+    return out.reshape(p.shape)
 
 
 def inverse_cdf_sample(probs: np.ndarray, u: float) -> int:
@@ -934,7 +1024,7 @@ def _ng_commit(seq: OracleSeq, L: int, committed: List[int], num_keep: int):
 
 def nongreedy_generate_single(forward: NonGreedyForward, seq: OracleSeq, eos_id: Optional[int], temperature: float,
                               pads, next_uniform, next_bonus_uniform, stats: Optional[dict] = None,
-                              logits_dtype: str = "f32"):
+                              logits_dtype: str = "f32", top_k=None, top_p=None):
     """JDN:376-482."""
     L = seq.block_len
     max_tokens = seq.max_tokens - seq.num_completion_tokens
@@ -953,7 +1043,7 @@ def nongreedy_generate_single(forward: NonGreedyForward, seq: OracleSeq, eos_id:
         seq.grow_for_draft(L)
         logits = forward([seq], [q])[0]
         seq.num_cached_tokens = len(seq) - 1 + L
-        probs = target_probs(logits, temperature, logits_dtype)
+        probs = target_probs(logits, temperature, logits_dtype, top_k, top_p)
         committed, keep, eos = rs_verify_row(q, probs, eos_id, next_uniform, next_bonus_uniform)
         eos_reached = eos_reached or eos
         _ng_commit(seq, L, committed, keep)
@@ -973,13 +1063,13 @@ def nongreedy_generate_single(forward: NonGreedyForward, seq: OracleSeq, eos_id:
 
 def nongreedy_generate_batch(forward: NonGreedyForward, seqs: List[OracleSeq], eos_id: Optional[int],
                              temperature: float, pads, next_uniform, next_bonus_uniform,
-                             stats: Optional[dict] = None, logits_dtype: str = "f32"):
+                             stats: Optional[dict] = None, logits_dtype: str = "f32", top_k=None, top_p=None):
     """JDN:485-667."""
     if not seqs:
         return []
     if len(seqs) == 1:
         return [nongreedy_generate_single(forward, seqs[0], eos_id, temperature, pads, next_uniform,
-                                          next_bonus_uniform, stats, logits_dtype)]
+                                          next_bonus_uniform, stats, logits_dtype, top_k, top_p)]
     B = len(seqs)
     accepted: List[List[int]] = [[] for _ in range(B)]
     q: List[Optional[List[int]]] = [None] * B
@@ -1015,7 +1105,7 @@ def nongreedy_generate_batch(forward: NonGreedyForward, seqs: List[OracleSeq], e
             for i in idxs:
                 seqs[i].num_cached_tokens = len(seqs[i]) - 1 + L
             for row, i in enumerate(idxs):
-                probs = target_probs(logits[row], temperature, logits_dtype)
+                probs = target_probs(logits[row], temperature, logits_dtype, top_k, top_p)
                 committed, keep, eos = rs_verify_row(drafts[row], probs, eos_id, next_uniform, next_bonus_uniform)
                 eos_reached[i] = eos_reached[i] or eos
                 _ng_commit(seqs[i], L, committed, keep)

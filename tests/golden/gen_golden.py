@@ -489,7 +489,7 @@ def scripted_multinomial(stream):
 
 
 def run_jdn_case(name, *, vocab, seeds, robust, prompt_lens, block_len, max_tokens, temperature,
-                 eos_pos=None, rng_seed=5, batch=True, logits_dtype="f32", peak=8.0):
+                 eos_pos=None, rng_seed=5, batch=True, logits_dtype="f32", peak=8.0, top_k=None, top_p=None):
     eos_id, pad_id = vocab - 1, vocab - 2
     H = EngineHarness(vocab, logits_dtype=TORCH_DTYPES[logits_dtype])
     dec = JacobiDecoderNonGreedy(H.bm, forward_step=H.forward_step, forward_step_batch=H.forward_step_batch,
@@ -501,6 +501,12 @@ def run_jdn_case(name, *, vocab, seeds, robust, prompt_lens, block_len, max_toke
         m = ScriptedModel(vocab, sd, robust, pl, eos_id=eos_id, eos_pos=ep, reserved=(pad_id,), peak=peak)
         sp = SamplingParams(temperature=temperature, max_tokens=max_tokens, decode_strategy="jacobi",
                             jacobi_block_len=block_len)
+        # top_k / top_p are not SamplingParams fields: _build_target_probs reads them with getattr (JDN:117-118), so a caller
+        # has to plant them on the instance — which is what this does (round 5)
+        if top_k is not None:
+            sp.top_k = top_k
+        if top_p is not None:
+            sp.top_p = top_p
         seqs.append(H.add_seq(m, sp, None))
         descr.append(dict(model=m.describe(), prompt=m.prompt()))
     pads = CounterStream(rng_seed * 3 + 1)
@@ -529,6 +535,10 @@ def run_jdn_case(name, *, vocab, seeds, robust, prompt_lens, block_len, max_toke
                   block_len=block_len, max_tokens=max_tokens, temperature=temperature)
     if logits_dtype != "f32":                 # recorded only when it differs: round-1 files regenerate byte-identical
         params["logits_dtype"] = logits_dtype
+    if top_k is not None:
+        params["top_k"] = top_k
+    if top_p is not None:
+        params["top_p"] = top_p
     return dict(name=name, kind="jdn", params=params,
                 seqs=descr, outputs=out, stats=dec.stats,
                 final=[dict(token_ids=s.token_ids, num_cached_tokens=s.num_cached_tokens) for s in seqs],
@@ -655,6 +665,34 @@ def run_softmax_vectors():
                             scaled_bf16=scaled.view(torch.int16).numpy().astype(np.uint16).reshape(-1).tolist(),
                             probs_bf16=probs.view(torch.int16).numpy().astype(np.uint16).reshape(-1).tolist(),
                             probs_f32_of_f32_logits=pf.view(torch.int32).numpy().astype(np.uint32).reshape(-1).tolist()))
+    return out
+
+
+def run_filter_vectors():
+    """_build_target_probs (JDN:110-123) with top_k / top_p planted on the request object, on bf16 and on float32 logits: the
+    filtered, renormalised distribution as bit patterns.  Peaked rows (a trained model's shape: the kept set ends between
+    clearly different probabilities) and flat rows (bf16: the kept set usually ends inside a group of EQUAL probabilities,
+    where torch.topk / torch.sort choose by kernel, not by rule)."""
+    from inference_engine.engine.jacobi_decoding_nongreedy import _build_target_probs
+    out = []
+    g = torch.Generator().manual_seed(91)
+    for V, scale in ((64, 2.0), (300, 3.0), (2000, 2.5), (2000, 6.0)):
+        for T in (1.0, 0.7):
+            for top_k, top_p in ((None, 0.9), (5, None), (20, 0.8), (3, 0.5), (50, 0.95), (None, 0.3), (1, None), (None, 0.999), (V - 1, 0.05)):
+                x = (torch.randn(3, V, generator=g) * scale).to(torch.bfloat16)
+                x[0, 7] = 9.0
+                sp = SamplingParams(temperature=T, max_tokens=4, decode_strategy="jacobi")
+                if top_k is not None:
+                    sp.top_k = top_k
+                if top_p is not None:
+                    sp.top_p = top_p
+                pb = _build_target_probs(x, sp)
+                pf = _build_target_probs(x.float(), sp)
+                assert pb.dtype == torch.bfloat16 and pf.dtype == torch.float32
+                out.append(dict(V=V, temperature=T, top_k=top_k, top_p=top_p,
+                                logits_bf16=x.view(torch.int16).numpy().astype(np.uint16).reshape(-1).tolist(),
+                                probs_bf16=pb.view(torch.int16).numpy().astype(np.uint16).reshape(-1).tolist(),
+                                probs_f32_of_f32_logits=pf.view(torch.int32).numpy().astype(np.uint32).reshape(-1).tolist()))
     return out
 
 
@@ -961,6 +999,37 @@ def main():
                                   temperature=rr.choice([0.6, 1.0, 1.3]), max_blocks=rr.choice([128, 128, 2]),
                                   eos_pos=[(pl + rr.randint(2, 30)) if rr.random() < 0.4 else None for pl in pls],
                                   rng_seed=200 + sd, logits_dtype="bf16" if sd % 2 else "f32", peak=rr.choice([4.0, 6.0, 8.0])))
+    # round 5: the same decoder with top_k / top_p on the request objects (JDN:72-123)
+    jdns4 = [
+        run_jdn_case("jdn4_f32_topk5_T1", vocab=300, seeds=[700, 701, 702], robust=75, prompt_lens=[8, 5, 11], block_len=16,
+                     max_tokens=40, temperature=1.0, rng_seed=41, peak=4.0, top_k=5),
+        run_jdn_case("jdn4_f32_topp09_T08", vocab=1000, seeds=[703, 704], robust=80, prompt_lens=[9, 14], block_len=32,
+                     max_tokens=64, temperature=0.8, rng_seed=42, peak=5.0, top_p=0.9),
+        run_jdn_case("jdn4_f32_k20_p08_batch4", vocab=2000, seeds=[705, 706, 707, 708], robust=70, prompt_lens=[8, 5, 11, 20],
+                     block_len=32, max_tokens=48, temperature=1.0, rng_seed=43, peak=3.0, top_k=20, top_p=0.8),
+        run_jdn_case("jdn4_f32_single_p05", vocab=64, seeds=[709], robust=60, prompt_lens=[8], block_len=8,
+                     max_tokens=24, temperature=1.3, rng_seed=44, batch=False, peak=3.0, top_p=0.5),
+        run_jdn_case("jdn4_bf16_topk3_T07", vocab=300, seeds=[710, 711, 712], robust=75, prompt_lens=[8, 5, 11], block_len=16,
+                     max_tokens=40, temperature=0.7, rng_seed=45, logits_dtype="bf16", peak=6.0, top_k=3),
+        run_jdn_case("jdn4_bf16_topp09_L32", vocab=2000, seeds=[713, 714, 715], robust=80, prompt_lens=[9, 14, 6], block_len=32,
+                     max_tokens=64, temperature=1.0, rng_seed=46, logits_dtype="bf16", peak=8.0, top_p=0.9),
+        run_jdn_case("jdn4_bf16_k50_p095_eos", vocab=500, seeds=[716, 717], robust=85, prompt_lens=[8, 5], block_len=16,
+                     max_tokens=40, temperature=0.9, eos_pos=[20, None], rng_seed=47, logits_dtype="bf16", peak=8.0, top_k=50, top_p=0.95),
+        run_jdn_case("jdn4_bf16_flat_p08", vocab=1000, seeds=[718, 719], robust=60, prompt_lens=[7, 9], block_len=16,
+                     max_tokens=32, temperature=1.0, rng_seed=48, logits_dtype="bf16", peak=2.0, top_p=0.8),
+        # small vocabularies: the scripted logits' bf16 images hardly collide, the kept sets end between DIFFERENT probabilities
+        run_jdn_case("jdn4_bf16_V64_p09", vocab=64, seeds=[720, 721, 722], robust=70, prompt_lens=[8, 5, 11], block_len=16,
+                     max_tokens=40, temperature=1.0, rng_seed=51, logits_dtype="bf16", peak=3.0, top_p=0.9),
+        run_jdn_case("jdn4_bf16_V64_p07_T12", vocab=64, seeds=[720, 721, 722], robust=70, prompt_lens=[8, 5, 11], block_len=16,
+                     max_tokens=40, temperature=1.2, rng_seed=51, logits_dtype="bf16", peak=2.0, top_p=0.7),
+        run_jdn_case("jdn4_bf16_V128_p09", vocab=128, seeds=[720, 721, 722], robust=70, prompt_lens=[8, 5, 11], block_len=16,
+                     max_tokens=40, temperature=1.0, rng_seed=51, logits_dtype="bf16", peak=4.0, top_p=0.9),
+        run_jdn_case("jdn4_bf16_V64_k7", vocab=64, seeds=[720, 721, 722], robust=70, prompt_lens=[8, 5, 11], block_len=16,
+                     max_tokens=40, temperature=1.0, rng_seed=51, logits_dtype="bf16", peak=2.0, top_k=7),
+        run_jdn_case("jdn4_bf16_V64_k10_p08_T08", vocab=64, seeds=[720, 721, 722], robust=70, prompt_lens=[8, 5, 11], block_len=16,
+                     max_tokens=40, temperature=0.8, rng_seed=51, logits_dtype="bf16", peak=3.0, top_k=10, top_p=0.8),
+    ]
+    flt = run_filter_vectors()
     smx = run_softmax_vectors()
     kv = run_argmax_vectors()
     slots = run_slot_pattern_vectors()
@@ -986,6 +1055,8 @@ def main():
     dump("jdo_cases_v3.json", jdos3)
     dump("jdn_cases_v2.json", jdns2)
     dump("jdo_cases_v2.json", jdos2)
+    dump("jdn_cases_v4.json", jdns4)
+    dump("filter_vectors.json", flt)
     dump("softmax_vectors.json", smx)
     dump("kernel_vectors.json", kv)
     dump("slot_cases.json", slots)

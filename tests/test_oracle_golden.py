@@ -1,5 +1,7 @@
 """Pin the CPU oracle (oracle/jacobi_oracle.py) against golden vectors recorded from the
 unmodified reference (tests/golden/gen_golden.py).  CPU only."""
+import json
+
 import numpy as np
 import pytest
 
@@ -11,7 +13,8 @@ from .conftest import forward_matches, kv_matches, load_golden
 MB = load_golden("mb_cases.json") + load_golden("mb_cases_v2.json") + load_golden("mb_cases_v3.json")
 SB = load_golden("sb_cases.json") + load_golden("sb_cases_v2.json")
 JD = load_golden("jd_cases.json") + load_golden("jd_cases_v2.json")
-JDN = load_golden("jdn_cases.json") + load_golden("jdn_cases_v2.json") + load_golden("jdn_cases_v3.json")
+JDN = load_golden("jdn_cases.json") + load_golden("jdn_cases_v2.json") + load_golden("jdn_cases_v3.json") + load_golden("jdn_cases_v4.json")
+FLT = load_golden("filter_vectors.json")
 MBR = load_golden("mb_raises.json")
 SLOTS = load_golden("slot_cases.json")
 JDO = load_golden("jdo_cases.json") + load_golden("jdo_cases_v2.json") + load_golden("jdo_cases_v3.json")
@@ -205,8 +208,78 @@ def test_target_probs_follow_torch_rounding_points(case):
     assert np.allclose(p.astype(np.float64).sum(-1), 1.0, atol=5e-3)
 
 
-@pytest.mark.parametrize("case", JDN, ids=[c["name"] for c in JDN])
-def test_engine_nongreedy(case):
+@pytest.mark.parametrize("case", FLT, ids=[f"V{c['V']}_T{c['temperature']}_k{c['top_k']}_p{c['top_p']}_{i}" for i, c in enumerate(FLT)])
+def test_filtered_target_probs(case):
+    """_build_target_probs with top_k / top_p (JDN:72-123) recorded from torch on bf16 logits and on their float32 images.
+    bf16: bit for bit wherever the kept set does not end inside a group of equal probabilities (there torch's topk / sort pick
+    by kernel: the SAME number of ids with the SAME values must survive).  float32: the same kept set, values within a few
+    float32 ulps (torch's softmax and its float32 sums differ from the exact ones in the last place)."""
+    V, T, k, tp = case["V"], case["temperature"], case["top_k"], case["top_p"]
+    x = O.bf16_bits_to_f32(np.array(case["logits_bf16"], dtype=np.uint16).reshape(-1, V))
+    want_b = O.bf16_bits_to_f32(np.array(case["probs_bf16"], dtype=np.uint16).reshape(-1, V))
+    want_f = np.array(case["probs_f32_of_f32_logits"], dtype=np.uint32).reshape(-1, V).view(np.float32)
+    got_b = O.target_probs(x, T, "bf16", k, tp)
+    got_f = O.target_probs(x, T, "f32", k, tp)
+    pb, pf = O.target_probs(x, T, "bf16"), O.target_probs(x, T, "f32")
+    for r in range(x.shape[0]):
+        if O.filter_boundary_is_tied(pb[r], k, tp, 7):
+            assert (got_b[r] > 0).sum() == (want_b[r] > 0).sum()
+            assert np.array_equal(np.sort(got_b[r]), np.sort(want_b[r]))
+        else:
+            assert np.array_equal(got_b[r], want_b[r]), r
+        a, b = got_f[r], want_f[r]
+        if O.filter_boundary_is_tied(pf[r], k, tp, 23):                 # (equal LOGITS are equal probabilities in float32 too)
+            assert (a > 0).sum() == (b > 0).sum()
+            a, b = np.sort(a), np.sort(b)
+        else:
+            assert np.array_equal(a > 0, b > 0), r
+        ulp = np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+        assert ulp.max() <= 16, (r, int(ulp.max()))             # (the smallest kept probabilities: torch's float32 softmax is a few ulps off there)
+    assert np.allclose(got_b.astype(np.float64).sum(-1), 1.0, atol=2e-2) and np.allclose(got_f.astype(np.float64).sum(-1), 1.0, atol=1e-5)
+
+
+# Records of the reference in which a top-p kept set ends INSIDE a group of equal bf16 probabilities AND a draw lands on one of
+# the tied ids: which of them survive is torch.sort's kernel choice (not stable, not the same at every size), so the decode
+# cannot be reproduced by any rule — kept in the fixture as evidence of exactly that (tests below), not as parity targets.
+TIE_CHOICE_OBSERVABLE = {"jdn4_bf16_flat_p08", "jdn4_bf16_topp09_L32"}
+
+
+def _tied_rows(case) -> tuple:
+    """(rows the oracle's decode of this record forms filtered probabilities for, rows whose kept set ends inside a tie)."""
+    p = case["params"]
+    log = [0, 0]
+    orig = O.target_probs
+
+    def counting(logits, temperature, dt="f32", top_k=None, top_p=None):
+        base = orig(logits, temperature, dt)
+        for row in base.reshape(-1, base.shape[-1]):
+            log[0] += 1
+            log[1] += bool(O.filter_boundary_is_tied(row, top_k, top_p, 7 if dt == "bf16" else 23))
+        return orig(logits, temperature, dt, top_k, top_p)
+    O.target_probs = counting
+    try:
+        try:
+            test_engine_nongreedy.__wrapped__(case)
+            ok = True
+        except AssertionError:
+            ok = False
+    finally:
+        O.target_probs = orig
+    return log[0], log[1], ok
+
+
+def test_filtered_records_and_tied_boundaries():
+    """Every other jdn4 record is reproduced draw for draw (some of them meet tied cuts too — 62 of 225 rows in the k=50 record —
+    but no draw of theirs lands on a tied id); the two that are not meet a tied cut in most rows."""
+    for case in load_golden("jdn_cases_v4.json"):
+        rows, tied, ok = _tied_rows(json.loads(json.dumps(case)))
+        if case["name"] in TIE_CHOICE_OBSERVABLE:
+            assert not ok and tied > rows // 2, (case["name"], rows, tied)
+        else:
+            assert ok, (case["name"], rows, tied)
+
+
+def _engine_nongreedy(case):
     p = case["params"]
     seqs, models = _mk_seqs(case)
     by_id = {id(s): m for s, m in zip(seqs, models)}
@@ -221,16 +294,26 @@ def test_engine_nongreedy(case):
     bonus = O.CounterStream(p["rng_seed"] * 3 + 3)
     stats = O.new_stats()
     args = (p["eos_id"], p["temperature"], pads.pads(p["vocab"]), unis.uniform, bonus.uniform, stats)
+    flt = dict(top_k=p.get("top_k"), top_p=p.get("top_p"))      # (jdn_cases_v4.json: planted on the reference's SamplingParams instances)
     if p["batch"]:
-        out = O.nongreedy_generate_batch(fwd, seqs, *args, logits_dtype=ldt)
+        out = O.nongreedy_generate_batch(fwd, seqs, *args, logits_dtype=ldt, **flt)
     else:
-        out = [O.nongreedy_generate_single(fwd, s, *args, logits_dtype=ldt) for s in seqs]
+        out = [O.nongreedy_generate_single(fwd, s, *args, logits_dtype=ldt, **flt) for s in seqs]
     assert out == case["outputs"]
     assert stats == case["stats"]
     assert dict(pads=pads.k, uniforms=unis.k, bonus=bonus.k) == case["draws"]
     for s, f in zip(seqs, case["final"]):
         assert s.token_ids == f["token_ids"]
         assert s.num_cached_tokens == f["num_cached_tokens"]
+
+
+@pytest.mark.parametrize("case", [c for c in JDN if c["name"] not in TIE_CHOICE_OBSERVABLE],
+                         ids=[c["name"] for c in JDN if c["name"] not in TIE_CHOICE_OBSERVABLE])
+def test_engine_nongreedy(case):
+    _engine_nongreedy(case)
+
+
+test_engine_nongreedy.__wrapped__ = _engine_nongreedy
 
 
 # ----------------------------------------------------------------------------- on-policy rollout records (JDO)
