@@ -434,6 +434,19 @@ JF_API int jf_engine_fill(const int64_t *draft, int B, int L, const int32_t *seq
 JF_API int jf_rs_probs(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride,
                 const int64_t *draft_next, float temperature, float *p_draft, float *row_max,
                 float *row_sumexp, uint64_t *packed, void *workspace, size_t workspace_bytes, void *stream);
+
+/* (a19) top_k / top_p on the target distribution — _apply_top_k + _apply_top_p of _build_target_probs, JDN:72-123 (the reference
+ * reads both with getattr(sp, ...): they exist only on request objects a caller planted them on).  Call AFTER jf_rs_probs on the
+ * same rows: turns the R logits rows into R rows `probs` [R, V] (row stride V, dtype of the logits) of the filtered,
+ * renormalised probabilities in torch's dtype arithmetic, p_draft[r] = probs[r, draft_next[r]] (final: no rounding candidates),
+ * and marks the rows as PROBABILITY rows (row_max = +inf, row_sumexp = -1): jf_rs_step / jf_rs_onpolicy_step called with
+ * `probs` in place of the logits read an element as its own probability.  top_k <= 0 or >= V, top_p <= 0 or >= 1: that stage
+ * is off (JDN:75, 95-96).  What torch leaves to its kernels is defined: equal probabilities are ordered by token id, sums are
+ * exact sums rounded once (oracle/jacobi_oracle.py filter_probs_row; tests/golden/filter_vectors.json pins it against the
+ * reference's tensors).  packed / the greedy next-draft tail of jf_rs_probs are untouched (argmax of the LOGITS, JDN:446). */
+JF_API int jf_rs_filter(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, const int64_t *draft_next,
+                 float temperature, int32_t top_k, float top_p, void *probs, float *p_draft, float *row_max /* in: jf_rs_probs' */,
+                 float *row_sumexp, void *stream);
 JF_API size_t jf_rs_workspace_bytes(int64_t R, int64_t V);   /* per-chunk (max, sum-exp) partials */
 
 typedef struct jf_rs_row {

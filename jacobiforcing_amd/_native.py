@@ -134,6 +134,7 @@ _SIGNATURES = {
     "jf_sb_step": (C.c_int, [_vp, C.c_int, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "jf_engine_fill": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "jf_rs_probs": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "jf_rs_filter": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _vp, _f32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "jf_rs_workspace_bytes": (_sz, [_i64, _i64]),
     "jf_rs_step": (C.c_int, [_vp, C.c_int, _i64, _i64, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _f32, _i32, _vp,
                              _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

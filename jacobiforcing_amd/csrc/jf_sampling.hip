@@ -50,9 +50,14 @@ struct RsRow {                 // one logits row + what is needed to turn an ele
     float t, inv_t, M, S;
     bool unit_t, vec;          // vec: 16-byte aligned row -> vector loads
     bool fast;                 // bf16 temperature scaling as a product (see rs_scaled)
+    bool prob;                 // the row HOLDS probabilities (jf_rs_filter's output: row_sumexp == RS_PROB_ROW): an element is its own
+                               // probability.  Such a row is never "exact" (rs_row_is_exact), so every consumer takes its plain-formula
+                               // path, and that path ends here
 };
+constexpr float RS_PROB_ROW = -1.f;     // row_sumexp of a probability row (row_max = +inf)
 template <int DT>
 __device__ __forceinline__ float rs_prob_at(const RsRow &r, int64_t i) {
+    if (r.prob) return fmaxf(load_f<DT>(r.p, i), 0.f);
     return rs_prob<DT>(rs_scaled<DT>(load_f<DT>(r.p, i), r.t, r.inv_t, r.unit_t, r.fast), r.M, r.S);
 }
 template <int DT>
@@ -89,6 +94,11 @@ __device__ __forceinline__ void rs_probs_from_vec(const RsRow &r, const u32x4 v,
     constexpr int EPV = Elem<DT>::EPV;
     float x[EPV];
     rs_unpack<DT>(v, x);
+    if (r.prob) {                                              // (slots at or beyond V were loaded as -inf)
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) p[j] = fmaxf(x[j], 0.f);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < EPV; ++j) p[j] = rs_prob<DT>(rs_scaled<DT>(x[j], r.t, r.inv_t, r.unit_t, r.fast), r.M, r.S);
 }
@@ -841,6 +851,7 @@ __device__ __forceinline__ RsRow rs_make_row(const void *logits, int64_t r, int6
     rr.fast = t < 0.f;
     t = fabsf(t);
     rr.V = V; rr.t = t; rr.inv_t = 1.f / t; rr.M = M; rr.S = S;
+    rr.prob = (S == RS_PROB_ROW);
     rr.unit_t = (t == 1.f);
     rr.vec = (((uintptr_t)rr.p) % 16) == 0;
     return rr;
@@ -947,6 +958,234 @@ __device__ float rs_exact_prob_wg(const void *logits, int64_t r, int64_t V, int6
     if (tok < 0 || tok >= V) return 0.f;
     const float xs = rs_scaled<DT>(load_f<DT>(row.p, tok), row.t, row.inv_t, row.unit_t, row.fast);
     return rs_round_prob<DT>(rs_e64(xs, (double)M, tab) / S);
+}
+
+// ------------------------------------------------------------------------------------------------
+// (a19, round 5) top-k / top-p filtering of the target distribution — _apply_top_k + _apply_top_p of _build_target_probs
+// (JDN:72-123; the reference reads both with getattr: they exist only on request objects a caller planted them on).
+//
+// jf_rs_filter turns R logits rows into R rows of the FILTERED, RENORMALISED probabilities in the dtype of the logits — the
+// tensor the reference's `probs` is — and marks the rows as probability rows (row_max = +inf, row_sumexp = RS_PROB_ROW): the
+// steps then read an element as its own probability (RsRow::prob) through the code path rows without finite statistics
+// already take, accept tests included (p_draft is the final value, no rounding candidates).  One workgroup per row:
+//   1. the row's float64 sum and every exactly rounded probability (the definition of "Exact probabilities" above) -> out row;
+//   2. top-k: the k-th largest value by bisection over the value's bit pattern (a count pass per step: the out row is
+//      L2-resident), the ids above it, the first (k - that many) ids AT it in index order; their exact sum rounded once;
+//      q = p / max(sum, 1e-12) in torch's dtype arithmetic (float32 quotient, rounded again for bf16);
+//   3. top-p on the result: values in descending order, equal values by index; the cumulative sum — exact, rounded once to the
+//      dtype per position — is compared with top_p cast to the dtype; bisection finds the lowest value whose whole group is
+//      kept, the group below it keeps the ids whose own cumulative sum still passes (binary search over the count), at least
+//      one id is kept; renormalised like 2.
+// What torch leaves to its kernels is DEFINED (oracle/jacobi_oracle.py filter_probs_row): equal values are
+// ordered by index (torch.topk / torch.sort pick by kernel), sums are exact sums rounded once (torch accumulates in float32
+// in kernel order).  Reproduces the reference's recorded tensors bit for bit in bf16 wherever a cut does not fall inside a
+// group of equal values, and its kept sets (values within a few ulps) in float32 (tests/golden/filter_vectors.json).
+// Every reduction is formed in a fixed order (a thread's elements in index order, 64-lane scans, four wavefront partials
+// in order): the result does not depend on scheduling.
+// ------------------------------------------------------------------------------------------------
+template <int DT> __device__ __forceinline__ uint32_t flt_key(const void *row, int64_t i) {      // non-negative value -> its bits (order-preserving)
+    if constexpr (DT == JF_F32) return ((const uint32_t *)row)[i];
+    else return (uint32_t)((const uint16_t *)row)[i] << 16;
+}
+template <int DT> __device__ __forceinline__ void flt_store(void *row, int64_t i, float v) {
+    if constexpr (DT == JF_F32) ((float *)row)[i] = v;
+    else ((uint16_t *)row)[i] = (uint16_t)(__float_as_uint(v) >> 16);
+}
+template <int DT> __device__ __forceinline__ float flt_div(float a, float b) {                     // torch: tensor / tensor in the dtype
+    const float q = __fdiv_rn(a, b);
+    if constexpr (DT == JF_BF16) return bf16_rne(q); else return q;
+}
+struct FltShared {
+    double tab[64], red[4], dsum[4];
+    unsigned long long cnt[4];
+    uint32_t umax[4];
+    int scan[256];
+};
+// workgroup totals in a fixed order; every thread gets them
+__device__ __forceinline__ void flt_reduce(FltShared &sh, unsigned long long &cnt, double &sum) {
+    const int tid = threadIdx.x;
+    sum = wave_sum_f64(sum);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) { sh.cnt[tid >> 6] = cnt; sh.dsum[tid >> 6] = sum; }
+    __syncthreads();
+    cnt = (sh.cnt[0] + sh.cnt[1]) + (sh.cnt[2] + sh.cnt[3]);
+    sum = (sh.dsum[0] + sh.dsum[1]) + (sh.dsum[2] + sh.dsum[3]);
+}
+// count and exact sum of the row's elements with key >= lo (and, hi_excl != 0, key < hi_excl)
+template <int DT>
+__device__ __forceinline__ void flt_count_sum(FltShared &sh, const void *row, int64_t V, uint32_t lo, uint32_t hi_excl, unsigned long long &cnt, double &sum) {
+    cnt = 0ull; sum = 0.0;
+    for (int64_t i0 = threadIdx.x; i0 < V; i0 += 4 * 256) {
+        uint32_t k[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int64_t i = i0 + u * 256; k[u] = i < V ? flt_key<DT>(row, i) : 0u; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool in = i0 + u * 256 < V && k[u] >= lo && (hi_excl == 0u || k[u] < hi_excl);
+            cnt += in ? 1ull : 0ull;
+            sum += in ? (double)__uint_as_float(k[u]) : 0.0;
+        }
+    }
+    flt_reduce(sh, cnt, sum);
+}
+// largest key strictly below `below` (0 if none)
+template <int DT>
+__device__ __forceinline__ uint32_t flt_max_below(FltShared &sh, const void *row, int64_t V, uint32_t below) {
+    uint32_t m = 0u;
+    for (int64_t i = threadIdx.x; i < V; i += 256) { const uint32_t k = flt_key<DT>(row, i); m = (k < below && k > m) ? k : m; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh.umax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = sh.umax[0];
+    for (int w = 1; w < 4; ++w) m = sh.umax[w] > m ? sh.umax[w] : m;
+    return m;
+}
+// index of the c-th (1-based) element, in index order, whose key equals `key` (V if there are fewer)
+template <int DT>
+__device__ __forceinline__ int64_t flt_nth_equal(FltShared &sh, const void *row, int64_t V, uint32_t key, long long c) {
+    const int tid = threadIdx.x;
+    const int64_t chunk = (V + 255) / 256, a = (int64_t)tid * chunk, b = a + chunk < V ? a + chunk : V;     // a thread's ids are contiguous here
+    int mine = 0;
+    for (int64_t i = a; i < b; ++i) mine += flt_key<DT>(row, i) == key ? 1 : 0;
+    __syncthreads();
+    sh.scan[tid] = mine;
+    __syncthreads();
+    long long before = 0;
+    for (int q = 0; q < tid; ++q) before += sh.scan[q];                  // (256 LDS reads: this pass is rare and short)
+    __shared__ long long s_hit;
+    if (tid == 0) s_hit = V;
+    __syncthreads();
+    if (before < c && c <= before + mine) {
+        long long seen = before;
+        for (int64_t i = a; i < b; ++i) if (flt_key<DT>(row, i) == key && ++seen == c) { s_hit = i; break; }
+    }
+    __syncthreads();
+    return (int64_t)s_hit;
+}
+// renormalise in place: ids with key > thr, and ids AT thr up to index tie_last, keep value / denom; the others become 0
+template <int DT>
+__device__ __forceinline__ void flt_renorm(void *row, int64_t V, uint32_t thr, int64_t tie_last, float denom) {
+    for (int64_t i = threadIdx.x; i < V; i += 256) {
+        const uint32_t k = flt_key<DT>(row, i);
+        const bool keep = k > thr || (k == thr && i <= tie_last);
+        flt_store<DT>(row, i, keep ? flt_div<DT>(__uint_as_float(k), denom) : 0.f);
+    }
+    __syncthreads();
+}
+template <int DT>
+__global__ __launch_bounds__(256) void rs_filter_kernel(const void *logits, int64_t R, int64_t V, int64_t row_stride, const int64_t *draft_next,
+                                                         float t, int top_k, float top_p, void *probs, float *p_draft, float *row_max,
+                                                         float *row_sumexp) {
+    constexpr int EPV = Elem<DT>::EPV;
+    constexpr uint32_t STEP = DT == JF_F32 ? 1u : 0x10000u;                 // distance of two neighbouring values' keys
+    constexpr uint32_t FLT_KEY_TOP = 0x3F800000u + STEP;                    // the key above 1.0: no probability reaches it (on the key grid)
+    __shared__ FltShared sh;
+    const int tid = threadIdx.x;
+    const int64_t r = blockIdx.x;
+    const float M = row_max[r];
+    void *out = (char *)probs + r * V * (DT == JF_F32 ? 4 : 2);
+    rs_load_tab(sh.tab);
+    __syncthreads();
+    const RsRow row = rs_make_row<DT>(logits, r, V, row_stride, t, M, 1.f);
+    // ---- 1. exactly rounded probabilities of the whole row
+    const bool finite = (__float_as_uint(M) & 0x7F800000u) != 0x7F800000u;
+    const double S = finite ? rs_row_s64_wg<DT>(row, sh.tab, sh.red) : 0.0;
+    {
+        RsRow plain = row;
+        plain.S = row_sumexp[r];                                               // (NaN / inf rows: jf_rs_probs' float32 statistics, plain formula)
+        const double invS = S > 0.0 ? 1.0 / S : 0.0;
+        for (int64_t e0 = (int64_t)tid * EPV; e0 < V; e0 += 256 * EPV) {
+            float p[EPV];
+            rs_any_probs_from_vec<DT>(invS > 0.0 ? row : plain, rs_load_vec<DT>(row, e0), invS, sh.tab, p);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) if (e0 + j < V) flt_store<DT>(out, e0 + j, p[j] >= 0.f ? p[j] : 0.f);     // (a NaN row filters to zeros)
+        }
+    }
+    __syncthreads();
+    const float floor_d = rs_round_prob<DT>(1e-12);                           // sum.clamp_min(1e-12) in the dtype
+    unsigned long long cnt;
+    double sum;
+    // ---- 2. top-k (JDN:73-84)
+    if (top_k > 0 && (int64_t)top_k < V) {
+        uint32_t lo = 0u, hi = FLT_KEY_TOP;                                   // count(key >= lo) >= k > count(key >= hi)
+        while (hi - lo > STEP) {
+            const uint32_t mid = (lo + (hi - lo) / 2u) & ~(STEP - 1u);
+            flt_count_sum<DT>(sh, out, V, mid, 0u, cnt, sum);
+            if (cnt >= (unsigned long long)top_k) lo = mid; else hi = mid;
+        }
+        const uint32_t thr = lo;                                              // the k-th largest value
+        flt_count_sum<DT>(sh, out, V, thr + STEP, 0u, cnt, sum);              // the ids above it, and their sum
+        const long long need = (long long)top_k - (long long)cnt;            // ids AT the threshold to keep (>= 1), lowest index first
+        unsigned long long n_at; double s_at;
+        flt_count_sum<DT>(sh, out, V, thr, thr + STEP, n_at, s_at);
+        const int64_t tie_last = (unsigned long long)need >= n_at ? V : flt_nth_equal<DT>(sh, out, V, thr, need);
+        const double kept = sum + (double)need * (double)__uint_as_float(thr);
+        float s1 = rs_round_prob<DT>(kept);
+        s1 = s1 > floor_d ? s1 : floor_d;
+        flt_renorm<DT>(out, V, thr, tie_last, s1);
+    }
+    // ---- 3. top-p (JDN:91-107)
+    if (top_p > 0.f && top_p < 1.f) {
+        const float tp = rs_round_prob<DT>((double)top_p);                    // `cdf <= tp`: the Python float is cast to the tensor's dtype
+        // the lowest value whose group is kept WHOLE: cumulative sum at the group's end (everything >= it), rounded, <= tp
+        uint32_t lo = 0u, hi = FLT_KEY_TOP;                                   // whole(hi) holds (nothing >= hi: 0 <= tp), whole(lo) may not
+        flt_count_sum<DT>(sh, out, V, STEP, 0u, cnt, sum);                    // all positive values
+        const bool all = rs_round_prob<DT>(sum) <= tp;
+        uint32_t thr = 0u;
+        int64_t tie_last = V;
+        float s2;
+        if (all) {                                                            // the nucleus holds every id with mass (and the zeros behind them)
+            s2 = rs_round_prob<DT>(sum);
+        } else {
+            lo = STEP;                                                        // whole(STEP) fails
+            while (hi - lo > STEP) {
+                const uint32_t mid = (lo + (hi - lo) / 2u) & ~(STEP - 1u);
+                flt_count_sum<DT>(sh, out, V, mid, 0u, cnt, sum);
+                if (rs_round_prob<DT>(sum) <= tp) hi = mid; else lo = mid;
+            }
+            unsigned long long n_whole; double c_whole;
+            flt_count_sum<DT>(sh, out, V, hi, 0u, n_whole, c_whole);           // the groups kept whole
+            thr = flt_max_below<DT>(sh, out, V, hi);                          // the group the cut falls into (a present value: whole(STEP) fails)
+            unsigned long long n_at; double s_at;
+            flt_count_sum<DT>(sh, out, V, thr, thr + STEP, n_at, s_at);
+            const double v = (double)__uint_as_float(thr);
+            long long a = 0, b = (long long)n_at;                             // ids of the group whose own cumulative sum passes: pass(a) holds, pass(b) fails
+            while (b - a > 1) { const long long m2 = a + (b - a) / 2; if (rs_round_prob<DT>(c_whole + (double)m2 * v) <= tp) a = m2; else b = m2; }
+            long long c = a;
+            if (n_whole == 0ull && c == 0) c = 1;                             // keep[..., 0] = True
+            tie_last = c == 0 ? -1 : flt_nth_equal<DT>(sh, out, V, thr, c);
+            s2 = rs_round_prob<DT>(c_whole + (double)c * v);
+        }
+        s2 = s2 > floor_d ? s2 : floor_d;
+        flt_renorm<DT>(out, V, thr, tie_last, s2);
+    }
+    if (tid == 0) {
+        const int64_t tok = draft_next[r];
+        p_draft[r] = (tok >= 0 && tok < V) ? __uint_as_float(flt_key<DT>(out, tok)) : 0.f;
+        row_max[r] = INFINITY;
+        row_sumexp[r] = RS_PROB_ROW;
+    }
+}
+
+extern "C" int jf_rs_filter(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, const int64_t *draft_next,
+                            float temperature, int32_t top_k, float top_p, void *probs, float *p_draft, float *row_max,
+                            float *row_sumexp, void *stream) {
+    if (R <= 0) return JF_OK;
+    if (!logits || !draft_next || !probs || !p_draft || !row_max || !row_sumexp) return fail(JF_E_INVALID, "jf_rs_filter: null pointer");
+    if (dtype != JF_F32 && dtype != JF_BF16) return fail(JF_E_INVALID, "jf_rs_filter: dtype %d", dtype);
+    if (V <= 0 || V > 0x7FFFFFFFll || row_stride < V) return fail(JF_E_INVALID, "jf_rs_filter: bad shape V=%lld stride=%lld", (long long)V, (long long)row_stride);
+    if (!(top_p == top_p)) return fail(JF_E_INVALID, "jf_rs_filter: top_p is NaN");
+    const float t = (temperature <= 0.f) ? 1.f : temperature;               // JDN:66-67
+    hipStream_t s = (hipStream_t)stream;
+    // the product form of the bf16 scaling where the host proves it exact for this T (as jf_rs_probs / jf_rs_step: -T says so)
+    const float tt = (dtype == JF_BF16 && t != 1.f && rs_scale_is_exact(t)) ? -t : t;
+    if (dtype == JF_F32) rs_filter_kernel<JF_F32><<<dim3((unsigned)R), dim3(256), 0, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
+    else rs_filter_kernel<JF_BF16><<<dim3((unsigned)R), dim3(256), 0, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
+    return check_launch("rs_filter_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1087,7 +1326,10 @@ __device__ __forceinline__ void rs_seg_prob_sums(const RsRow &row, int64_t lo, i
                     if (__builtin_expect(invS > 0.0, 1)) rs_probs_from_kept<DT>(row, e0, e32[k], invS, invS32, tiny_m1, sh.tab, p);
                     else rs_probs_from_vec<DT>(row, rs_load_vec<DT>(row, e0), p);
                 } else {
-                    rs_any_probs_from_vec<DT>(row, v[k], invS, sh.tab, p);
+                    // (KEEP: v[] is what phase A loaded — and phase A is skipped for rows without an exact sum: NaN / inf rows and
+                    //  probability rows read their vector here.  Round 5: such float32 rows summed whatever the registers held.)
+                    if (KEEP && !(invS > 0.0)) rs_probs_from_vec<DT>(row, rs_load_vec<DT>(row, e0), p);
+                    else rs_any_probs_from_vec<DT>(row, v[k], invS, sh.tab, p);
                 }
             }
             double a = 0.0;

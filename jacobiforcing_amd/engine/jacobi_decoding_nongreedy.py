@@ -124,8 +124,13 @@ class JacobiDecoderNonGreedy:
             else:
                 max_tokens.append(2048)
         temperature = float(getattr(getattr(seqs[0], "sampling_params", None), "temperature", 1.0))
-        for seq in seqs:
-            ops.reject_unsupported_filters(getattr(seq, "sampling_params", None), self.vocab_size)
+        # top_k / top_p planted on the request objects (JDN:117-118 reads them with getattr): one setting per call, like the
+        # temperature above (the reference builds the distribution sequence by sequence; a batch that mixes settings is split
+        # by the caller)
+        filters = {ops.active_filters(getattr(seq, "sampling_params", None), self.vocab_size) for seq in seqs}
+        if len(filters) > 1:
+            raise NotImplementedError(f"one top_k / top_p setting per generate_chunk_batch call, got {sorted(filters)}")
+        top_k, top_p = next(iter(filters))
         n_iter_call = 0
         dev = self.device
         prof = getattr(self, "profiler", None)        # ModelRunner's PROFILE=1 section timer (reference names, MR:116-134)
@@ -162,7 +167,7 @@ class JacobiDecoderNonGreedy:
                 tick("jacobi.verify", True)
                 st = self._ensure(len(idxs), L)
                 rows, committed, next_draft = st.step(draft_batch, logits, temperature, self.eos_token_id,
-                                                      [max_tokens[i] - len(accepted[i]) for i in idxs], self._cur)
+                                                      [max_tokens[i] - len(accepted[i]) for i in idxs], self._cur, top_k, top_p)
                 tick("jacobi.verify", False)
                 tick("jacobi.commit", True)
                 for row, i in enumerate(idxs):

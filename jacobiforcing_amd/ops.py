@@ -797,19 +797,28 @@ class PagedFill:
 # --------------------------------------------------------------------------------------------
 # non-greedy verify (JDN:299-354, 581-639)
 # --------------------------------------------------------------------------------------------
-def reject_unsupported_filters(sp, vocab_size: int) -> None:
-    """The reference's _build_target_probs (JDN:110-123) applies top_k / top_p when the request object carries such
-    attributes (SamplingParams has no such fields, sampling_params.py:4-38, so this only happens when a caller attaches them).
-    The HIP verify samples from the unfiltered softmax: an ACTIVE filter is refused loudly instead of being ignored."""
+def active_filters(sp, vocab_size: int) -> Tuple[int, float]:
+    """(top_k, top_p) a request object asks for, as jf_rs_filter takes them: 0 / 0.0 = that stage is off.  The reference's
+    _build_target_probs (JDN:110-123) reads both with getattr — SamplingParams has no such fields (sampling_params.py:4-38), so
+    they only exist when a caller planted them on the instance — and switches a stage off for top_k None / <= 0 / >= V (JDN:75)
+    and top_p None / <= 0 / >= 1 (JDN:92-96)."""
     if sp is None:
-        return
+        return 0, 0.0
     top_k, top_p = getattr(sp, "top_k", None), getattr(sp, "top_p", None)
-    k_active = top_k is not None and 0 < int(top_k) < int(vocab_size)                           # JDN:73-74
-    p_active = top_p is not None and 0.0 < float(top_p) < 1.0                                   # JDN:91-95
-    if k_active or p_active:
-        raise NotImplementedError(f"top_k={top_k!r} / top_p={top_p!r} filtering of the target distribution is not implemented "
-                                  "by the HIP rejection-sampling verify (DESIGN.md §7); remove the attribute or use temperature only")
+    k = int(top_k) if (top_k is not None and 0 < int(top_k) < int(vocab_size)) else 0
+    pp = float(top_p) if (top_p is not None and 0.0 < float(top_p) < 1.0) else 0.0
+    return k, pp
 
+
+def reject_unsupported_filters(sp, vocab_size: int) -> None:
+    """The on-policy rollout step still samples from the unfiltered softmax (its producer is out of scope): an
+    ACTIVE top_k / top_p on a request is refused loudly there instead of being ignored.  (The engine's non-greedy decoder
+    applies them since round 5: jf_rs_filter.)"""
+    k, pp = active_filters(sp, vocab_size)
+    if k or pp:
+        raise NotImplementedError(f"top_k={getattr(sp, 'top_k', None)!r} / top_p={getattr(sp, 'top_p', None)!r} filtering of the target "
+                                  "distribution is not implemented for the on-policy rollout step (DESIGN.md §7); remove the attribute or "
+                                  "use temperature only")
 
 
 class RsStepper:
@@ -840,7 +849,9 @@ class RsStepper:
         self.remaining = torch.zeros((self.max_rows,), dtype=torch.int32, device=dev)
 
     def step(self, draft: torch.Tensor, logits: torch.Tensor, temperature: float, eos_id: Optional[int],
-             remaining: Sequence[int], cursors: Sequence[int]):
+             remaining: Sequence[int], cursors: Sequence[int], top_k: int = 0, top_p: float = 0.0):
+        """``top_k`` / ``top_p`` (``active_filters``): when one is active the rows go through jf_rs_filter — the filtered,
+        renormalised distribution as a probability tensor in the logits' dtype (JDN:72-123) — and jf_rs_step samples from that."""
         B, L = draft.shape
         if L < 2:
             raise ValueError("Draft must have at least 2 tokens (seed + 1 speculative)")
@@ -863,6 +874,14 @@ class RsStepper:
                                 _ptr(self.p_draft), _ptr(self.row_max), _ptr(self.row_sumexp), _ptr(self.packed),
                                 _ptr(self.ws), self.ws.numel() * 4, _stream(dev)), "jf_rs_probs")
         done()
+        src = flat
+        if int(top_k) > 0 or float(top_p) > 0.0:
+            if getattr(self, "probs", None) is None or self.probs.numel() < R * V or self.probs.dtype != flat.dtype:
+                self.probs = torch.empty((R * V,), dtype=flat.dtype, device=dev)
+            src = self.probs[:R * V].view(R, V)
+            N.check(lib.jf_rs_filter(_ptr(flat), _dtype_code(flat), R, V, flat.stride(0), _ptr(draft_next), float(temperature),
+                                     int(top_k), float(top_p), _ptr(src), _ptr(self.p_draft), _ptr(self.row_max),
+                                     _ptr(self.row_sumexp), _stream(dev)), "jf_rs_filter")
         self.remaining[:B].copy_(torch.tensor(list(remaining), dtype=torch.int32), non_blocking=True)
         self.cursors.copy_(torch.tensor(list(cursors), dtype=torch.int64), non_blocking=True)
         cm = self.committed.view(-1)[:B * L].view(B, L)
@@ -870,7 +889,7 @@ class RsStepper:
         cur = self.cursors
         c_ptr = lambda i: C.c_void_p(cur.data_ptr() + 8 * i)
         done = _stage("rs_step", B * V * flat.element_size())               # <= one rejected row per draft row
-        N.check(lib.jf_rs_step(_ptr(flat), _dtype_code(flat), V, flat.stride(0), _ptr(draft), B, L, _ptr(self.p_draft),
+        N.check(lib.jf_rs_step(_ptr(src), _dtype_code(src), V, src.stride(0), _ptr(draft), B, L, _ptr(self.p_draft),
                                _ptr(self.row_max), _ptr(self.row_sumexp), _ptr(self.packed), float(temperature),
                                -1 if eos_id is None else int(eos_id), _ptr(self.remaining),
                                _ptr(self.u_stream), self.u_stream.numel(), c_ptr(0),

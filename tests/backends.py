@@ -339,12 +339,31 @@ class HostSimLib:
         pk[:] = np.maximum(pk, (np.uint64(1) << np.uint64(32)) | ((~am) & np.uint64(0xFFFFFFFF)))
         return 0
 
+    def jf_rs_filter(self, logits, dtype, R, V, stride, draft_next, temperature, top_k, top_p, probs, p_draft, row_max, row_sumexp, stream):
+        rows = self._rows_f32(logits, dtype, R, V, stride)
+        q = O.target_probs(rows, float(temperature), self._ldt(dtype), int(top_k) or None, float(top_p) or None).astype(np.float32)
+        if dtype == N.JF_BF16:
+            _view(probs, R * V, np.uint16)[:] = O.f32_to_bf16_bits(q).reshape(-1)
+        else:
+            _view(probs, R * V, np.float32)[:] = q.reshape(-1)
+        dn = _view(draft_next, R, np.int64)
+        _view(p_draft, R, np.float32)[:] = q[np.arange(R), dn]
+        _view(row_max, R, np.float32)[:] = np.inf
+        _view(row_sumexp, R, np.float32)[:] = -1.0
+        return 0
+
+    def _probs_of(self, logits, dtype, R, V, stride, temperature, row_sumexp):
+        """The target distribution the step samples from: rows that jf_rs_filter marked as probability rows ARE it."""
+        lg = self._rows_f32(logits, dtype, R, V, stride)
+        if R and float(_view(row_sumexp, R, np.float32)[0]) == -1.0:
+            return lg
+        return O.target_probs(lg, temperature, self._ldt(dtype))
+
     def jf_rs_step(self, logits, dtype, V, stride, draft, B, L, p_draft, row_max, row_sumexp, packed, temperature, eos_id,
                    remaining, u_stream, u_len, u_cursor, b_stream, b_len, b_cursor, pad_stream, pad_len, pad_cursor,
                    committed, next_draft, rows, ws, ws_bytes, stream):
         R = B * (L - 1)
-        lg = self._rows_f32(logits, dtype, R, V, stride)
-        probs = O.target_probs(lg, temperature, self._ldt(dtype))
+        probs = self._probs_of(logits, dtype, R, V, stride, temperature, row_sumexp)
         d = _view(draft, B * L, np.int64).reshape(B, L)
         us, bs, ps = _view(u_stream, u_len, np.float32), _view(b_stream, b_len, np.float32), _view(pad_stream, pad_len, np.int64)
         uc, bc, pc = _view(u_cursor, 1, np.int64), _view(b_cursor, 1, np.int64), _view(pad_cursor, 1, np.int64)

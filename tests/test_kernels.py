@@ -14,6 +14,7 @@ from jacobiforcing_amd import _native as N
 from jacobiforcing_amd import ops
 from oracle import jacobi_oracle as O
 
+from .conftest import load_golden  # noqa: E402
 from .backends import device_for, use_backend
 
 ROOT = Path(__file__).resolve().parents[1]
@@ -685,6 +686,112 @@ def test_rs_step_beyond_the_lds_tables(B, L, V):
     a = _run_rs("hip", B, L, V, 5, 0.5, None, torch.float32, 0.9, eos=3)
     b = _run_rs("hostsim", B, L, V, 5, 0.5, None, torch.float32, 0.9, eos=3)
     _assert_rs_equal(a, b, B)
+
+
+# ------------------------------------------------------------------------------------- top-k / top-p (jf_rs_filter)
+def _filter_rows(x: torch.Tensor, temperature: float, top_k: int, top_p: float) -> np.ndarray:
+    """jf_rs_probs + jf_rs_filter on [R, V] logits -> the probability tensor as float32 values."""
+    R, V = x.shape
+    dev = x.device
+    dn = torch.zeros(R, dtype=torch.int64, device=dev)
+    p = torch.zeros(R, device=dev); m = torch.zeros(R, device=dev); sm = torch.zeros(R, device=dev)
+    packed = ops.new_packed(R, dev)
+    ws = torch.zeros(max(int(N.lib().jf_rs_workspace_bytes(R, V)) // 4, 1), device=dev)
+    N.check(N.lib().jf_rs_probs(ops._ptr(x), ops._dtype_code(x), R, V, V, ops._ptr(dn), temperature, ops._ptr(p), ops._ptr(m), ops._ptr(sm),
+                                ops._ptr(packed), ops._ptr(ws), ws.numel() * 4, ops._stream(dev)))
+    out = torch.empty_like(x)
+    N.check(N.lib().jf_rs_filter(ops._ptr(x), ops._dtype_code(x), R, V, V, ops._ptr(dn), temperature, int(top_k), float(top_p), ops._ptr(out),
+                                 ops._ptr(p), ops._ptr(m), ops._ptr(sm), ops._stream(dev)))
+    q = out.float().cpu().numpy()
+    assert np.array_equal(p.cpu().numpy(), q[:, 0]) and torch.isinf(m).all() and (sm == -1).all()     # p_draft = the final value; rows marked
+    return q
+
+
+FLT = load_golden("filter_vectors.json")
+
+
+@GPU
+@pytest.mark.parametrize("case", FLT[::3], ids=[f"V{c['V']}_T{c['temperature']}_k{c['top_k']}_p{c['top_p']}_{i}" for i, c in enumerate(FLT)][::3])
+def test_rs_filter_reproduces_the_references_tensors(case):
+    """jf_rs_filter against _build_target_probs of the unmodified reference with top_k / top_p planted (tests/golden/
+    filter_vectors.json): bf16 bit for bit in every row whose cuts fall between DIFFERENT probabilities (rows with a cut inside
+    a group of equal values: the same number of survivors with the same values — which ids survive there is torch's kernel's
+    choice, lowest id first here); float32: the same kept set, values within a few ulps; and exactly the oracle's definition."""
+    V, T, k, tp = case["V"], case["temperature"], case["top_k"], case["top_p"]
+    xb = torch.from_numpy(np.array(case["logits_bf16"], dtype=np.uint16).reshape(-1, V).view(np.int16)).view(torch.bfloat16)
+    want_b = O.bf16_bits_to_f32(np.array(case["probs_bf16"], dtype=np.uint16).reshape(-1, V))
+    want_f = np.array(case["probs_f32_of_f32_logits"], dtype=np.uint32).reshape(-1, V).view(np.float32)
+    got_b = _filter_rows(xb.cuda(), T, k or 0, tp or 0.0)
+    got_f = _filter_rows(xb.float().cuda(), T, k or 0, tp or 0.0)
+    x = xb.float().numpy()
+    assert np.array_equal(got_b, O.target_probs(x, T, "bf16", k, tp))
+    assert np.array_equal(got_f, O.target_probs(x, T, "f32", k, tp))
+    pb = O.target_probs(x, T, "bf16")
+    for r in range(x.shape[0]):
+        if O.filter_boundary_is_tied(pb[r], k, tp, 7):
+            assert np.array_equal(np.sort(got_b[r]), np.sort(want_b[r]))
+        else:
+            assert np.array_equal(got_b[r], want_b[r]), r
+        a, b = np.sort(got_f[r]), np.sort(want_f[r])
+        assert (a > 0).sum() == (b > 0).sum()
+        assert np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64)).max() <= 16
+
+
+@GPU
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("V,top_k,top_p,scale", [(152064, 50, 0.0, 3.0), (152064, 0, 0.9, 3.0), (152064, 40, 0.95, 3.0), (152064, 0, 0.9, 0.3),
+                                                 (152064, 1000, 0.5, 0.3), (4099, 1, 0.0, 2.0), (4099, 4098, 0.999, 2.0), (5, 2, 0.6, 1.0)],
+                         ids=["k50", "p09", "k40_p095", "flat_p09", "flat_k1000_p05", "k1", "all_but_one", "tiny"])
+def test_rs_filter_at_the_real_vocabulary(dtype, V, top_k, top_p, scale):
+    """jf_rs_filter at V = 152064 (and a ragged V, and 5 ids) against the oracle's filter_probs_row in both dtypes: peaked rows
+    (N(0, 3^2) logits: cuts between distinct values) and flat rows (N(0, 0.3^2): in bf16 thousands of ids share the value at a
+    cut — the first ones by id survive on both sides), T = 0.8.  Bit for bit."""
+    g = torch.Generator().manual_seed(V + top_k)
+    x = (torch.randn(3, V, generator=g) * scale).to(dtype)
+    x[1, V // 2] = 12.0
+    got = _filter_rows(x.cuda(), 0.8, top_k, top_p)
+    want = O.target_probs(x.float().numpy(), 0.8, "bf16" if dtype == torch.bfloat16 else "f32", top_k or None, top_p or None)
+    assert np.array_equal(got, want), [(int((got[r] != want[r]).sum()), int((got[r] > 0).sum()), int((want[r] > 0).sum())) for r in range(3)]
+    if top_k:
+        assert ((got > 0).sum(-1) <= top_k).all()
+    assert np.allclose(got.astype(np.float64).sum(-1), 1.0, atol=3e-2 if dtype == torch.bfloat16 else 1e-5)
+
+
+@GPU
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("top_k,top_p", [(8, 0.0), (0, 0.7), (20, 0.9)], ids=["k8", "p07", "k20_p09"])
+def test_rs_step_samples_from_the_filtered_distribution(dtype, top_k, top_p):
+    """The whole non-greedy step with filters: jf_rs_probs -> jf_rs_filter -> jf_rs_step on the probability rows, 24 rows x block
+    9 at V = 5 000 and 6 rows at the real vocabulary, against the row-by-row restatement over the oracle's filtered distribution:
+    accepted counts, rejected positions, bonus tokens (never a filtered-out id), draws, next drafts, cursors."""
+    for B, L, V in ((24, 9, 5000), (6, 5, 152064)):
+        g = torch.Generator().manual_seed(77 + top_k + V)
+        logits = torch.randn(B, L - 1, V, generator=g) * 2.5                # a handful of heavy ids per row: the filters cut between real alternatives
+        heavy = logits.argmax(-1)
+        draft = torch.randint(0, V, (B, L), generator=g)
+        pick = torch.rand(B, L - 1, generator=g) < 0.6                       # most proposals are the row's heaviest id (accepted about half the time) ...
+        draft[:, 1:] = torch.where(pick, heavy, draft[:, 1:])               # ... the others are random ids: filtered out, probability 0, rejected
+        n = 4 * B * L
+        unis = torch.randint(0, 1 << 24, (n,), generator=g).float() / float(1 << 24)
+        bonus = torch.randint(0, 1 << 24, (n,), generator=g).float() / float(1 << 24)
+        pads = torch.randint(0, V, (n,), generator=g)
+        res = {}
+        for backend in ("hip", "hostsim"):
+            with use_backend(backend):
+                dev = device_for(backend)
+                st = ops.RsStepper(B, L, dev, pads, unis, bonus)
+                rows, toks, nd = st.step(draft.to(dev), logits.to(dtype).to(dev), 0.9, 3, [L] * B, [3, 5, 7], top_k, top_p)
+                res[backend] = (rows.copy(), toks.copy(), nd.cpu().numpy().copy(), st.cursors.cpu().tolist())
+        f = N.RS_FIELDS.index
+        assert (res["hostsim"][0][:, f("reject_pos")] >= 0).sum() >= B // 3
+        _assert_rs_equal(res["hip"], res["hostsim"], B)
+        q = O.target_probs(logits.to(dtype).float().numpy().reshape(B * (L - 1), V), 0.9, "bf16" if dtype == torch.bfloat16 else "f32",
+                           top_k or None, top_p or None).reshape(B, L - 1, V)
+        rows, toks = res["hip"][0], res["hip"][1]
+        for b in range(B):
+            rej, n = int(rows[b, f("reject_pos")]), int(rows[b, f("n_committed")])
+            if rej >= 0:
+                assert q[b, rej, int(toks[b, n - 1])] > 0          # the bonus token has mass under the filtered distribution
 
 
 def _run_rs_given(backend, draft, logits, unis, bonus, pads, temperature, eos=None):
