@@ -1013,28 +1013,50 @@ __device__ __forceinline__ void flt_reduce(FltShared &sh, unsigned long long &cn
     cnt = (sh.cnt[0] + sh.cnt[1]) + (sh.cnt[2] + sh.cnt[3]);
     sum = (sh.dsum[0] + sh.dsum[1]) + (sh.dsum[2] + sh.dsum[3]);
 }
+// every element of a probability row as (index, key), a thread's elements in index order: 16-byte vectors, eight loads in
+// flight per thread (a pass over the L2-resident row is a chain of load round trips: with four 2-byte loads in flight a pass of
+// 152 064 ids took ~120 us, this way ~15)
+template <int DT, class F>
+__device__ __forceinline__ void flt_for_each(const void *row, int64_t V, F f) {
+    constexpr int EPV = Elem<DT>::EPV, NB = 8;
+    RsRow rr;
+    rr.p = row; rr.V = V; rr.vec = (((uintptr_t)row) % 16) == 0;
+    for (int64_t b0 = (int64_t)threadIdx.x * EPV; b0 < V; b0 += (int64_t)NB * 256 * EPV) {
+        u32x4 v[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) { const int64_t e0 = b0 + (int64_t)k * 256 * EPV; if (e0 < V) v[k] = rs_load_vec<DT>(rr, e0); }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int64_t e0 = b0 + (int64_t)k * 256 * EPV;
+            if (e0 >= V) continue;
+            const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) {
+                uint32_t key;
+                if constexpr (DT == JF_F32) key = w[j]; else key = (j & 1) ? (w[j >> 1] & 0xFFFF0000u) : (w[j >> 1] << 16);
+                if (e0 + j < V) f(e0 + j, key);
+            }
+        }
+    }
+}
 // count and exact sum of the row's elements with key >= lo (and, hi_excl != 0, key < hi_excl)
 template <int DT>
 __device__ __forceinline__ void flt_count_sum(FltShared &sh, const void *row, int64_t V, uint32_t lo, uint32_t hi_excl, unsigned long long &cnt, double &sum) {
-    cnt = 0ull; sum = 0.0;
-    for (int64_t i0 = threadIdx.x; i0 < V; i0 += 4 * 256) {
-        uint32_t k[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { const int64_t i = i0 + u * 256; k[u] = i < V ? flt_key<DT>(row, i) : 0u; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const bool in = i0 + u * 256 < V && k[u] >= lo && (hi_excl == 0u || k[u] < hi_excl);
-            cnt += in ? 1ull : 0ull;
-            sum += in ? (double)__uint_as_float(k[u]) : 0.0;
-        }
-    }
+    unsigned long long c = 0ull;
+    double a = 0.0;
+    flt_for_each<DT>(row, V, [&](int64_t, uint32_t k) {
+        const bool in = k >= lo && (hi_excl == 0u || k < hi_excl);
+        c += in ? 1ull : 0ull;
+        a += in ? (double)__uint_as_float(k) : 0.0;
+    });
+    cnt = c; sum = a;
     flt_reduce(sh, cnt, sum);
 }
 // largest key strictly below `below` (0 if none)
 template <int DT>
 __device__ __forceinline__ uint32_t flt_max_below(FltShared &sh, const void *row, int64_t V, uint32_t below) {
     uint32_t m = 0u;
-    for (int64_t i = threadIdx.x; i < V; i += 256) { const uint32_t k = flt_key<DT>(row, i); m = (k < below && k > m) ? k : m; }
+    flt_for_each<DT>(row, V, [&](int64_t, uint32_t k) { m = (k < below && k > m) ? k : m; });
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
     __syncthreads();
@@ -1069,11 +1091,11 @@ __device__ __forceinline__ int64_t flt_nth_equal(FltShared &sh, const void *row,
 // renormalise in place: ids with key > thr, and ids AT thr up to index tie_last, keep value / denom; the others become 0
 template <int DT>
 __device__ __forceinline__ void flt_renorm(void *row, int64_t V, uint32_t thr, int64_t tie_last, float denom) {
-    for (int64_t i = threadIdx.x; i < V; i += 256) {
-        const uint32_t k = flt_key<DT>(row, i);
+    __syncthreads();
+    flt_for_each<DT>(row, V, [&](int64_t i, uint32_t k) {      // (a thread rewrites exactly the ids it read)
         const bool keep = k > thr || (k == thr && i <= tie_last);
         flt_store<DT>(row, i, keep ? flt_div<DT>(__uint_as_float(k), denom) : 0.f);
-    }
+    });
     __syncthreads();
 }
 template <int DT>
