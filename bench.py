@@ -336,9 +336,14 @@ def nongreedy_section(model, cfg, weights, tuned, P: int = 64, L: int = 32, temp
         probs = dict(probs)
     out_roof = roof(probs, "rs_probs_partial_kernel + rs_probs_finish_kernel (jf_rs_probs: softmax-gather + argmax, the "
                            "logits read once)")
-    out_step = roof(step, "jf_rs_step (accept walk, float64 segment sums of the rejected rows, draw counting, one inverse-CDF "
-                          "walk per rejected row, next drafts)",
-                    "bytes = one rejected row (V x 2 B) per draft row per launch: the rows the step re-reads")
+    # a chain of hand-offs inside one launch, not a stream: reported in microseconds (a fraction of the HBM roofline says nothing
+    # about it: VERDICT r04); bytes kept for scale
+    out_step = None if step is None else {
+        "bound": "latency", "us_per_launch": step["us"], "launches": step["launches"], "bytes_per_launch": step["bytes"],
+        "kernel": "jf_rs_step (accept walk, float64 segment sums of the rejected rows, draw counting, one inverse-CDF walk per rejected row, "
+                  "next drafts: roles of ONE launch)",
+        "note": "bytes = one rejected row (V x 2 B) per draft row per launch: the rows the step re-reads; where the microseconds go, "
+                "stage by stage (in-kernel stamps): profiles/rs_step_r04.txt, DESIGN.md 3.4"}
     if out_roof is not None:
         out_roof["timing"] = st.timing("rs_probs")
     if out_step is not None:

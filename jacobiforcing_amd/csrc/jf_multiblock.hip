@@ -254,6 +254,10 @@ __device__ __forceinline__ void verify_stepper(const VerifyArgs &a, int p, int32
     // Wavefront 0 is this prompt's state machine.  The other three park at the barrier below (a parked wavefront issues
     // nothing) and come back for the write-back, which is store-issue bound: 256 lanes instead of 64.
     jf_mb_desc *dg = a.desc ? a.desc + p : nullptr;
+    // (Round 5, the launch's tail, measured and NOT adopted: the wavefronts that park at the barrier below reading ahead what a
+    //  call end will read — driver header, the next draft's draw words, the text — so that drv_call_end's three dependent round
+    //  trips hit the L2: scripted window 83.3-83.6 us against 82.7-87.9 without, headline window 65.3 against 64.8 —
+    //  profiles/verify_tail_ab_r05.txt.  The headline pays for loads it rarely needs; the item is closed.)
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         int32_t *gtok = img + LC.total;                          // [B, T] greedy tokens (LDS) when use_lds
