@@ -1052,6 +1052,45 @@ __device__ __forceinline__ void flt_count_sum(FltShared &sh, const void *row, in
     cnt = c; sum = a;
     flt_reduce(sh, cnt, sum);
 }
+// ---- bf16 rows: a COUNT histogram of the row's values in LDS (a bf16 probability is one of 16 257 bit patterns; 64 KB of
+// counters) stands in for the row in every count / sum / maximum below: count x value is exact in float64, so the sums are the
+// sums of the elements, formed from <= 16 384 terms instead of 152 064 loads — a bisection step costs ~1 us on LDS instead of a pass
+// over the row (a 0.6 GB tensor at 64 x 31 rows: ~17 passes from HBM took 3.3 ms per call).  The row itself is read four to six
+// times in all: float64 sum, probabilities (+ histogram), one renormalising pass per active stage (+ histogram of its result), and
+// a tie pass where a cut falls inside a group of equal values.
+constexpr int FLT_BINS = 16384;                                            // bins of the 16-bit patterns 0 .. 0x3FFF (1.0 = 0x3F80)
+__device__ __forceinline__ void flt_hist_zero(uint32_t *hist) {
+    for (int b = threadIdx.x; b < FLT_BINS; b += 256) hist[b] = 0u;
+    __syncthreads();
+}
+__device__ __forceinline__ void flt_hist_count_sum(FltShared &sh, const uint32_t *hist, uint32_t lo, uint32_t hi_excl, unsigned long long &cnt, double &sum) {
+    const uint32_t blo = lo >> 16, bhi = hi_excl ? (hi_excl >> 16) : (uint32_t)FLT_BINS;      // keys are multiples of 0x10000
+    unsigned long long c = 0ull;
+    double a = 0.0;
+    const int b0 = (int)threadIdx.x * (FLT_BINS / 256);
+#pragma unroll 4
+    for (int b = b0; b < b0 + FLT_BINS / 256; ++b) {
+        const uint32_t n = ((uint32_t)b >= blo && (uint32_t)b < bhi) ? hist[b] : 0u;
+        c += n;
+        a += (double)n * (double)__uint_as_float((uint32_t)b << 16);
+    }
+    cnt = c; sum = a;
+    flt_reduce(sh, cnt, sum);
+}
+__device__ __forceinline__ uint32_t flt_hist_max_below(FltShared &sh, const uint32_t *hist, uint32_t below) {
+    const uint32_t bb = below >> 16;
+    uint32_t m = 0u;
+    const int b0 = (int)threadIdx.x * (FLT_BINS / 256);
+    for (int b = b0; b < b0 + FLT_BINS / 256; ++b) m = ((uint32_t)b < bb && hist[b] != 0u && (uint32_t)b > m) ? (uint32_t)b : m;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh.umax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = sh.umax[0];
+    for (int w = 1; w < 4; ++w) m = sh.umax[w] > m ? sh.umax[w] : m;
+    return m << 16;
+}
 // largest key strictly below `below` (0 if none)
 template <int DT>
 __device__ __forceinline__ uint32_t flt_max_below(FltShared &sh, const void *row, int64_t V, uint32_t below) {
@@ -1090,15 +1129,18 @@ __device__ __forceinline__ int64_t flt_nth_equal(FltShared &sh, const void *row,
 }
 // renormalise in place: ids with key > thr, and ids AT thr up to index tie_last, keep value / denom; the others become 0
 template <int DT>
-__device__ __forceinline__ void flt_renorm(void *row, int64_t V, uint32_t thr, int64_t tie_last, float denom) {
+__device__ __forceinline__ void flt_renorm(void *row, int64_t V, uint32_t thr, int64_t tie_last, float denom, uint32_t *hist /* nullable: rebuilt from the results */) {
     __syncthreads();
+    if (hist) flt_hist_zero(hist);
     flt_for_each<DT>(row, V, [&](int64_t i, uint32_t k) {      // (a thread rewrites exactly the ids it read)
         const bool keep = k > thr || (k == thr && i <= tie_last);
-        flt_store<DT>(row, i, keep ? flt_div<DT>(__uint_as_float(k), denom) : 0.f);
+        const float q = keep ? flt_div<DT>(__uint_as_float(k), denom) : 0.f;
+        flt_store<DT>(row, i, q);
+        if (hist) atomicAdd(hist + (__float_as_uint(q) >> 16), 1u);
     });
     __syncthreads();
 }
-template <int DT>
+template <int DT, bool HIST>
 __global__ __launch_bounds__(256) void rs_filter_kernel(const void *logits, int64_t R, int64_t V, int64_t row_stride, const int64_t *draft_next,
                                                          float t, int top_k, float top_p, void *probs, float *p_draft, float *row_max,
                                                          float *row_sumexp) {
@@ -1106,11 +1148,17 @@ __global__ __launch_bounds__(256) void rs_filter_kernel(const void *logits, int6
     constexpr uint32_t STEP = DT == JF_F32 ? 1u : 0x10000u;                 // distance of two neighbouring values' keys
     constexpr uint32_t FLT_KEY_TOP = 0x3F800000u + STEP;                    // the key above 1.0: no probability reaches it (on the key grid)
     __shared__ FltShared sh;
+    extern __shared__ uint32_t flt_dyn[];
+    uint32_t *hist = HIST ? flt_dyn : nullptr;                               // bf16: the row's value counts (FLT_BINS words of dynamic LDS)
+    auto count_sum = [&](uint32_t lo_, uint32_t hi_, unsigned long long &c_, double &s_) {
+        if constexpr (HIST) flt_hist_count_sum(sh, hist, lo_, hi_, c_, s_); else flt_count_sum<DT>(sh, (char *)probs + (int64_t)blockIdx.x * V * (DT == JF_F32 ? 4 : 2), V, lo_, hi_, c_, s_);
+    };
     const int tid = threadIdx.x;
     const int64_t r = blockIdx.x;
     const float M = row_max[r];
     void *out = (char *)probs + r * V * (DT == JF_F32 ? 4 : 2);
     rs_load_tab(sh.tab);
+    if constexpr (HIST) flt_hist_zero(hist);
     __syncthreads();
     const RsRow row = rs_make_row<DT>(logits, r, V, row_stride, t, M, 1.f);
     // ---- 1. exactly rounded probabilities of the whole row
@@ -1124,7 +1172,11 @@ __global__ __launch_bounds__(256) void rs_filter_kernel(const void *logits, int6
             float p[EPV];
             rs_any_probs_from_vec<DT>(invS > 0.0 ? row : plain, rs_load_vec<DT>(row, e0), invS, sh.tab, p);
 #pragma unroll
-            for (int j = 0; j < EPV; ++j) if (e0 + j < V) flt_store<DT>(out, e0 + j, p[j] >= 0.f ? p[j] : 0.f);     // (a NaN row filters to zeros)
+            for (int j = 0; j < EPV; ++j) if (e0 + j < V) {
+                const float pj = p[j] >= 0.f ? p[j] : 0.f;                    // (a NaN row filters to zeros)
+                flt_store<DT>(out, e0 + j, pj);
+                if constexpr (HIST) atomicAdd(hist + (__float_as_uint(pj) >> 16), 1u);
+            }
         }
     }
     __syncthreads();
@@ -1136,26 +1188,26 @@ __global__ __launch_bounds__(256) void rs_filter_kernel(const void *logits, int6
         uint32_t lo = 0u, hi = FLT_KEY_TOP;                                   // count(key >= lo) >= k > count(key >= hi)
         while (hi - lo > STEP) {
             const uint32_t mid = (lo + (hi - lo) / 2u) & ~(STEP - 1u);
-            flt_count_sum<DT>(sh, out, V, mid, 0u, cnt, sum);
+            count_sum(mid, 0u, cnt, sum);
             if (cnt >= (unsigned long long)top_k) lo = mid; else hi = mid;
         }
         const uint32_t thr = lo;                                              // the k-th largest value
-        flt_count_sum<DT>(sh, out, V, thr + STEP, 0u, cnt, sum);              // the ids above it, and their sum
+        count_sum(thr + STEP, 0u, cnt, sum);              // the ids above it, and their sum
         const long long need = (long long)top_k - (long long)cnt;            // ids AT the threshold to keep (>= 1), lowest index first
         unsigned long long n_at; double s_at;
-        flt_count_sum<DT>(sh, out, V, thr, thr + STEP, n_at, s_at);
+        count_sum(thr, thr + STEP, n_at, s_at);
         const int64_t tie_last = (unsigned long long)need >= n_at ? V : flt_nth_equal<DT>(sh, out, V, thr, need);
         const double kept = sum + (double)need * (double)__uint_as_float(thr);
         float s1 = rs_round_prob<DT>(kept);
         s1 = s1 > floor_d ? s1 : floor_d;
-        flt_renorm<DT>(out, V, thr, tie_last, s1);
+        flt_renorm<DT>(out, V, thr, tie_last, s1, (top_p > 0.f && top_p < 1.f) ? hist : nullptr);
     }
     // ---- 3. top-p (JDN:91-107)
     if (top_p > 0.f && top_p < 1.f) {
         const float tp = rs_round_prob<DT>((double)top_p);                    // `cdf <= tp`: the Python float is cast to the tensor's dtype
         // the lowest value whose group is kept WHOLE: cumulative sum at the group's end (everything >= it), rounded, <= tp
         uint32_t lo = 0u, hi = FLT_KEY_TOP;                                   // whole(hi) holds (nothing >= hi: 0 <= tp), whole(lo) may not
-        flt_count_sum<DT>(sh, out, V, STEP, 0u, cnt, sum);                    // all positive values
+        count_sum(STEP, 0u, cnt, sum);                    // all positive values
         const bool all = rs_round_prob<DT>(sum) <= tp;
         uint32_t thr = 0u;
         int64_t tie_last = V;
@@ -1166,14 +1218,14 @@ __global__ __launch_bounds__(256) void rs_filter_kernel(const void *logits, int6
             lo = STEP;                                                        // whole(STEP) fails
             while (hi - lo > STEP) {
                 const uint32_t mid = (lo + (hi - lo) / 2u) & ~(STEP - 1u);
-                flt_count_sum<DT>(sh, out, V, mid, 0u, cnt, sum);
+                count_sum(mid, 0u, cnt, sum);
                 if (rs_round_prob<DT>(sum) <= tp) hi = mid; else lo = mid;
             }
             unsigned long long n_whole; double c_whole;
-            flt_count_sum<DT>(sh, out, V, hi, 0u, n_whole, c_whole);           // the groups kept whole
-            thr = flt_max_below<DT>(sh, out, V, hi);                          // the group the cut falls into (a present value: whole(STEP) fails)
+            count_sum(hi, 0u, n_whole, c_whole);           // the groups kept whole
+            thr = HIST ? flt_hist_max_below(sh, hist, hi) : flt_max_below<DT>(sh, out, V, hi);                          // the group the cut falls into (a present value: whole(STEP) fails)
             unsigned long long n_at; double s_at;
-            flt_count_sum<DT>(sh, out, V, thr, thr + STEP, n_at, s_at);
+            count_sum(thr, thr + STEP, n_at, s_at);
             const double v = (double)__uint_as_float(thr);
             long long a = 0, b = (long long)n_at;                             // ids of the group whose own cumulative sum passes: pass(a) holds, pass(b) fails
             while (b - a > 1) { const long long m2 = a + (b - a) / 2; if (rs_round_prob<DT>(c_whole + (double)m2 * v) <= tp) a = m2; else b = m2; }
@@ -1183,7 +1235,7 @@ __global__ __launch_bounds__(256) void rs_filter_kernel(const void *logits, int6
             s2 = rs_round_prob<DT>(c_whole + (double)c * v);
         }
         s2 = s2 > floor_d ? s2 : floor_d;
-        flt_renorm<DT>(out, V, thr, tie_last, s2);
+        flt_renorm<DT>(out, V, thr, tie_last, s2, nullptr);
     }
     if (tid == 0) {
         const int64_t tok = draft_next[r];
@@ -1205,8 +1257,16 @@ extern "C" int jf_rs_filter(const void *logits, int dtype, int64_t R, int64_t V,
     hipStream_t s = (hipStream_t)stream;
     // the product form of the bf16 scaling where the host proves it exact for this T (as jf_rs_probs / jf_rs_step: -T says so)
     const float tt = (dtype == JF_BF16 && t != 1.f && rs_scale_is_exact(t)) ? -t : t;
-    if (dtype == JF_F32) rs_filter_kernel<JF_F32><<<dim3((unsigned)R), dim3(256), 0, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
-    else rs_filter_kernel<JF_BF16><<<dim3((unsigned)R), dim3(256), 0, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
+    if (dtype == JF_F32) {
+        rs_filter_kernel<JF_F32, false><<<dim3((unsigned)R), dim3(256), 0, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
+    } else {
+        // bf16: value counts in 64 KB of dynamic LDS (beyond the default 64 KB per workgroup together with the static part: opt in once);
+        // JF_RS_FILTER_HIST=0 keeps the pass-per-bisection-step variant (the float32 path's structure)
+        static const bool hist = [] { const char *e = getenv("JF_RS_FILTER_HIST"); return !(e && e[0] == '0'); }();
+        static const bool ok = hist && hipFuncSetAttribute((const void *)rs_filter_kernel<JF_BF16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FLT_BINS * 4) == hipSuccess;
+        if (ok) rs_filter_kernel<JF_BF16, true><<<dim3((unsigned)R), dim3(256), FLT_BINS * 4, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
+        else rs_filter_kernel<JF_BF16, false><<<dim3((unsigned)R), dim3(256), 0, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
+    }
     return check_launch("rs_filter_kernel");
 }
 
