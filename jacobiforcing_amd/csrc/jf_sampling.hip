@@ -925,16 +925,16 @@ __device__ __forceinline__ void rs_any_probs_from_vec(const RsRow &r, const u32x
 
 // float64 sum of exp(xs - M) over a whole row by one workgroup (every thread gets the result).  Used where ONE row's exact
 // sum is needed on the spot: an accept test that the float32 sum cannot decide, and the rows of the on-policy accept.
-template <int DT>
+template <int DT, int NB = 4 /* loads in flight per thread: the one-launch step calls this with its register budget in mind; jf_rs_filter takes 8 */>
 __device__ double rs_row_s64_wg(const RsRow &row, const double *tab, double *s_red /* LDS, 4 */) {
     constexpr int EPV = Elem<DT>::EPV;
     double acc = 0.0;
-    for (int64_t b0 = (int64_t)threadIdx.x * EPV; b0 < row.V; b0 += (int64_t)4 * 256 * EPV) {
-        u32x4 v[4];
+    for (int64_t b0 = (int64_t)threadIdx.x * EPV; b0 < row.V; b0 += (int64_t)NB * 256 * EPV) {
+        u32x4 v[NB];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { const int64_t e0 = b0 + (int64_t)k * 256 * EPV; if (e0 < row.V) v[k] = rs_load_vec<DT>(row, e0); }
+        for (int k = 0; k < NB; ++k) { const int64_t e0 = b0 + (int64_t)k * 256 * EPV; if (e0 < row.V) v[k] = rs_load_vec<DT>(row, e0); }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NB; ++k) {
             const int64_t e0 = b0 + (int64_t)k * 256 * EPV;
             if (e0 >= row.V) continue;
             float xs[EPV];
@@ -995,11 +995,14 @@ template <int DT> __device__ __forceinline__ float flt_div(float a, float b) {  
     const float q = __fdiv_rn(a, b);
     if constexpr (DT == JF_BF16) return bf16_rne(q); else return q;
 }
+constexpr int FLT_TPB = 512;                                             // threads of a row's workgroup: 8 wavefronts (with 256 the row's float64 exps
+                                                                         // and load round trips had one wavefront per SIMD to hide behind: 350-450 us per row)
+constexpr int FLT_NW = FLT_TPB / 64;
 struct FltShared {
-    double tab[64], red[4], dsum[4];
-    unsigned long long cnt[4];
-    uint32_t umax[4];
-    int scan[256];
+    double tab[64], dsum[FLT_NW];
+    unsigned long long cnt[FLT_NW];
+    uint32_t umax[FLT_NW];
+    int scan[FLT_TPB];
 };
 // workgroup totals in a fixed order; every thread gets them
 __device__ __forceinline__ void flt_reduce(FltShared &sh, unsigned long long &cnt, double &sum) {
@@ -1010,8 +1013,32 @@ __device__ __forceinline__ void flt_reduce(FltShared &sh, unsigned long long &cn
     __syncthreads();
     if ((tid & 63) == 0) { sh.cnt[tid >> 6] = cnt; sh.dsum[tid >> 6] = sum; }
     __syncthreads();
-    cnt = (sh.cnt[0] + sh.cnt[1]) + (sh.cnt[2] + sh.cnt[3]);
-    sum = (sh.dsum[0] + sh.dsum[1]) + (sh.dsum[2] + sh.dsum[3]);
+    cnt = 0ull; sum = 0.0;
+#pragma unroll
+    for (int w = 0; w < FLT_NW; ++w) { cnt += sh.cnt[w]; sum += sh.dsum[w]; }      // wavefront order: fixed
+}
+// float64 sum of exp(xs - M) over the row by the FLT_TPB threads (rs_row_s64_wg is the 256-thread one of the steps)
+template <int DT>
+__device__ __forceinline__ double flt_row_s64(FltShared &sh, const RsRow &row) {
+    constexpr int EPV = Elem<DT>::EPV, NB = 4;
+    double acc = 0.0;
+    for (int64_t b0 = (int64_t)threadIdx.x * EPV; b0 < row.V; b0 += (int64_t)NB * FLT_TPB * EPV) {
+        u32x4 v[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) { const int64_t e0 = b0 + (int64_t)k * FLT_TPB * EPV; if (e0 < row.V) v[k] = rs_load_vec<DT>(row, e0); }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int64_t e0 = b0 + (int64_t)k * FLT_TPB * EPV;
+            if (e0 >= row.V) continue;
+            float xs[EPV];
+            rs_scaled_from_vec<DT>(row, v[k], xs);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) acc += rs_e64(xs[j], (double)row.M, sh.tab);
+        }
+    }
+    unsigned long long none = 0ull;
+    flt_reduce(sh, none, acc);
+    return acc;
 }
 // every element of a probability row as (index, key), a thread's elements in index order: 16-byte vectors, eight loads in
 // flight per thread (a pass over the L2-resident row is a chain of load round trips: with four 2-byte loads in flight a pass of
@@ -1021,13 +1048,13 @@ __device__ __forceinline__ void flt_for_each(const void *row, int64_t V, F f) {
     constexpr int EPV = Elem<DT>::EPV, NB = 8;
     RsRow rr;
     rr.p = row; rr.V = V; rr.vec = (((uintptr_t)row) % 16) == 0;
-    for (int64_t b0 = (int64_t)threadIdx.x * EPV; b0 < V; b0 += (int64_t)NB * 256 * EPV) {
+    for (int64_t b0 = (int64_t)threadIdx.x * EPV; b0 < V; b0 += (int64_t)NB * FLT_TPB * EPV) {
         u32x4 v[NB];
 #pragma unroll
-        for (int k = 0; k < NB; ++k) { const int64_t e0 = b0 + (int64_t)k * 256 * EPV; if (e0 < V) v[k] = rs_load_vec<DT>(rr, e0); }
+        for (int k = 0; k < NB; ++k) { const int64_t e0 = b0 + (int64_t)k * FLT_TPB * EPV; if (e0 < V) v[k] = rs_load_vec<DT>(rr, e0); }
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            const int64_t e0 = b0 + (int64_t)k * 256 * EPV;
+            const int64_t e0 = b0 + (int64_t)k * FLT_TPB * EPV;
             if (e0 >= V) continue;
             const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
 #pragma unroll
@@ -1060,17 +1087,16 @@ __device__ __forceinline__ void flt_count_sum(FltShared &sh, const void *row, in
 // a tie pass where a cut falls inside a group of equal values.
 constexpr int FLT_BINS = 16384;                                            // bins of the 16-bit patterns 0 .. 0x3FFF (1.0 = 0x3F80)
 __device__ __forceinline__ void flt_hist_zero(uint32_t *hist) {
-    for (int b = threadIdx.x; b < FLT_BINS; b += 256) hist[b] = 0u;
+    for (int b = threadIdx.x; b < FLT_BINS; b += FLT_TPB) hist[b] = 0u;
     __syncthreads();
 }
 __device__ __forceinline__ void flt_hist_count_sum(FltShared &sh, const uint32_t *hist, uint32_t lo, uint32_t hi_excl, unsigned long long &cnt, double &sum) {
     const uint32_t blo = lo >> 16, bhi = hi_excl ? (hi_excl >> 16) : (uint32_t)FLT_BINS;      // keys are multiples of 0x10000
     unsigned long long c = 0ull;
     double a = 0.0;
-    const int b0 = (int)threadIdx.x * (FLT_BINS / 256);
-#pragma unroll 4
-    for (int b = b0; b < b0 + FLT_BINS / 256; ++b) {
-        const uint32_t n = ((uint32_t)b >= blo && (uint32_t)b < bhi) ? hist[b] : 0u;
+#pragma unroll 8
+    for (int b = (int)threadIdx.x; b < FLT_BINS; b += FLT_TPB) {       // lane-interleaved bins: consecutive lanes, consecutive LDS banks (a thread
+        const uint32_t n = ((uint32_t)b >= blo && (uint32_t)b < bhi) ? hist[b] : 0u;   // owning 64 ADJACENT bins puts all 64 lanes on one bank)
         c += n;
         a += (double)n * (double)__uint_as_float((uint32_t)b << 16);
     }
@@ -1080,15 +1106,15 @@ __device__ __forceinline__ void flt_hist_count_sum(FltShared &sh, const uint32_t
 __device__ __forceinline__ uint32_t flt_hist_max_below(FltShared &sh, const uint32_t *hist, uint32_t below) {
     const uint32_t bb = below >> 16;
     uint32_t m = 0u;
-    const int b0 = (int)threadIdx.x * (FLT_BINS / 256);
-    for (int b = b0; b < b0 + FLT_BINS / 256; ++b) m = ((uint32_t)b < bb && hist[b] != 0u && (uint32_t)b > m) ? (uint32_t)b : m;
+#pragma unroll 8
+    for (int b = (int)threadIdx.x; b < FLT_BINS; b += FLT_TPB) m = ((uint32_t)b < bb && hist[b] != 0u && (uint32_t)b > m) ? (uint32_t)b : m;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sh.umax[threadIdx.x >> 6] = m;
     __syncthreads();
     m = sh.umax[0];
-    for (int w = 1; w < 4; ++w) m = sh.umax[w] > m ? sh.umax[w] : m;
+    for (int w = 1; w < FLT_NW; ++w) m = sh.umax[w] > m ? sh.umax[w] : m;
     return m << 16;
 }
 // largest key strictly below `below` (0 if none)
@@ -1102,27 +1128,67 @@ __device__ __forceinline__ uint32_t flt_max_below(FltShared &sh, const void *row
     if ((threadIdx.x & 63) == 0) sh.umax[threadIdx.x >> 6] = m;
     __syncthreads();
     m = sh.umax[0];
-    for (int w = 1; w < 4; ++w) m = sh.umax[w] > m ? sh.umax[w] : m;
+    for (int w = 1; w < FLT_NW; ++w) m = sh.umax[w] > m ? sh.umax[w] : m;
     return m;
 }
-// index of the c-th (1-based) element, in index order, whose key equals `key` (V if there are fewer)
+// index of the c-th (1-based) element, in index order, whose key equals `key` (V if there are fewer).  Two steps: the ties are
+// counted per TILE of 256 vectors (LDS counters, one vectorised pass), the tile that holds the c-th one is ranked thread by thread
+// (a thread's vector of a tile is 16 contiguous bytes).  (The first version walked a contiguous chunk per thread with 2-byte loads:
+// 70-140 us per row, the largest single piece of the kernel.)  Rows of more than 256 tiles take that walk.
 template <int DT>
 __device__ __forceinline__ int64_t flt_nth_equal(FltShared &sh, const void *row, int64_t V, uint32_t key, long long c) {
+    constexpr int EPV = Elem<DT>::EPV;
     const int tid = threadIdx.x;
-    const int64_t chunk = (V + 255) / 256, a = (int64_t)tid * chunk, b = a + chunk < V ? a + chunk : V;     // a thread's ids are contiguous here
+    const int64_t tile_elems = (int64_t)FLT_TPB * EPV, ntiles = (V + tile_elems - 1) / tile_elems;
+    __shared__ long long s_hit, s_rank;
+    __shared__ int s_tile;
+    if (ntiles > FLT_TPB) {
+        const int64_t chunk = (V + FLT_TPB - 1) / FLT_TPB, a0 = (int64_t)tid * chunk, b0 = a0 + chunk < V ? a0 + chunk : V;
+        int mine = 0;
+        for (int64_t i = a0; i < b0; ++i) mine += flt_key<DT>(row, i) == key ? 1 : 0;
+        __syncthreads();
+        sh.scan[tid] = mine;
+        __syncthreads();
+        long long before = 0;
+        for (int q = 0; q < tid; ++q) before += sh.scan[q];
+        if (tid == 0) s_hit = V;
+        __syncthreads();
+        if (before < c && c <= before + mine) {
+            long long seen = before;
+            for (int64_t i = a0; i < b0; ++i) if (flt_key<DT>(row, i) == key && ++seen == c) { s_hit = i; break; }
+        }
+        __syncthreads();
+        return (int64_t)s_hit;
+    }
+    __syncthreads();
+    sh.scan[tid] = 0;
+    if (tid == 0) { s_hit = V; s_tile = -1; s_rank = 0; }
+    __syncthreads();
+    flt_for_each<DT>(row, V, [&](int64_t i, uint32_t k) { if (k == key) atomicAdd(&sh.scan[(int)(i / tile_elems)], 1); });
+    __syncthreads();
+    if (tid == 0) {
+        long long before = 0;
+        for (int t = 0; t < (int)ntiles; ++t) {
+            const long long n = sh.scan[t];
+            if (before < c && c <= before + n) { s_tile = t; s_rank = c - before; break; }
+            before += n;
+        }
+    }
+    __syncthreads();
+    const int tile = s_tile;
+    if (tile < 0) return V;
+    const long long rank = s_rank;
+    const int64_t e0 = (int64_t)tile * tile_elems + (int64_t)tid * EPV;
     int mine = 0;
-    for (int64_t i = a; i < b; ++i) mine += flt_key<DT>(row, i) == key ? 1 : 0;
+    for (int j = 0; j < EPV; ++j) mine += (e0 + j < V && flt_key<DT>(row, e0 + j) == key) ? 1 : 0;
     __syncthreads();
     sh.scan[tid] = mine;
     __syncthreads();
     long long before = 0;
-    for (int q = 0; q < tid; ++q) before += sh.scan[q];                  // (256 LDS reads: this pass is rare and short)
-    __shared__ long long s_hit;
-    if (tid == 0) s_hit = V;
-    __syncthreads();
-    if (before < c && c <= before + mine) {
+    for (int q = 0; q < tid; ++q) before += sh.scan[q];
+    if (before < rank && rank <= before + mine) {
         long long seen = before;
-        for (int64_t i = a; i < b; ++i) if (flt_key<DT>(row, i) == key && ++seen == c) { s_hit = i; break; }
+        for (int j = 0; j < EPV; ++j) if (e0 + j < V && flt_key<DT>(row, e0 + j) == key && ++seen == rank) { s_hit = e0 + j; break; }
     }
     __syncthreads();
     return (int64_t)s_hit;
@@ -1130,18 +1196,59 @@ __device__ __forceinline__ int64_t flt_nth_equal(FltShared &sh, const void *row,
 // renormalise in place: ids with key > thr, and ids AT thr up to index tie_last, keep value / denom; the others become 0
 template <int DT>
 __device__ __forceinline__ void flt_renorm(void *row, int64_t V, uint32_t thr, int64_t tie_last, float denom, uint32_t *hist /* nullable: rebuilt from the results */) {
+    constexpr int EPV = Elem<DT>::EPV, NB = 8;
     __syncthreads();
     if (hist) flt_hist_zero(hist);
-    flt_for_each<DT>(row, V, [&](int64_t i, uint32_t k) {      // (a thread rewrites exactly the ids it read)
-        const bool keep = k > thr || (k == thr && i <= tie_last);
-        const float q = keep ? flt_div<DT>(__uint_as_float(k), denom) : 0.f;
-        flt_store<DT>(row, i, q);
-        if (hist) atomicAdd(hist + (__float_as_uint(q) >> 16), 1u);
-    });
+    RsRow rr;
+    rr.p = row; rr.V = V; rr.vec = (((uintptr_t)row) % 16) == 0;
+    for (int64_t b0 = (int64_t)threadIdx.x * EPV; b0 < V; b0 += (int64_t)NB * FLT_TPB * EPV) {      // (a thread rewrites exactly the ids it read)
+        u32x4 v[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) { const int64_t e0 = b0 + (int64_t)k * FLT_TPB * EPV; if (e0 < V) v[k] = rs_load_vec<DT>(rr, e0); }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int64_t e0 = b0 + (int64_t)k * FLT_TPB * EPV;
+            if (e0 >= V) continue;
+            const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+            float q[EPV];
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) {
+                uint32_t key;
+                if constexpr (DT == JF_F32) key = w[j]; else key = (j & 1) ? (w[j >> 1] & 0xFFFF0000u) : (w[j >> 1] << 16);
+                const int64_t i = e0 + j;
+                const bool keep = i < V && (key > thr || (key == thr && i <= tie_last));
+                q[j] = 0.f;
+                if (keep) {                                               // a BRANCH: the IEEE division is ~12 instructions, and after a top-k
+                    q[j] = flt_div<DT>(__uint_as_float(key), denom);      // hardly any id is kept (as a select the pass was division-bound: 60 us)
+                    // (zeros are not counted: nothing asks for them, and after a top-k nearly every id would hit that one counter)
+                    if (hist && q[j] > 0.f) atomicAdd(hist + (__float_as_uint(q[j]) >> 16), 1u);
+                }
+            }
+            if (rr.vec && e0 + EPV <= V) {                                  // one 16-byte store (2-byte stores made this pass 59 us per row)
+                u32x4 o;
+                if constexpr (DT == JF_F32) o = u32x4{__float_as_uint(q[0]), __float_as_uint(q[1]), __float_as_uint(q[2]), __float_as_uint(q[3])};
+                else o = u32x4{(__float_as_uint(q[0]) >> 16) | (__float_as_uint(q[1]) & 0xFFFF0000u), (__float_as_uint(q[2]) >> 16) | (__float_as_uint(q[3]) & 0xFFFF0000u),
+                               (__float_as_uint(q[4]) >> 16) | (__float_as_uint(q[5]) & 0xFFFF0000u), (__float_as_uint(q[6]) >> 16) | (__float_as_uint(q[7]) & 0xFFFF0000u)};
+                *(u32x4 *)((char *)row + e0 * (DT == JF_F32 ? 4 : 2)) = o;
+            } else {
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) if (e0 + j < V) flt_store<DT>(row, e0 + j, q[j]);
+            }
+        }
+    }
     __syncthreads();
 }
+#ifdef JF_EXP_FLT_TRACE
+__device__ unsigned long long g_flttrace[16];
+extern "C" __attribute__((visibility("default"))) int jf_exp_flt_trace(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_flttrace), sizeof(g_flttrace)) == hipSuccess ? 0 : -1;
+}
+#define FLT_STAMP(k) do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) g_flttrace[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FLT_STAMP(k) do { } while (0)
+#endif
 template <int DT, bool HIST>
-__global__ __launch_bounds__(256) void rs_filter_kernel(const void *logits, int64_t R, int64_t V, int64_t row_stride, const int64_t *draft_next,
+__global__ __launch_bounds__(FLT_TPB) void rs_filter_kernel(const void *logits, int64_t R, int64_t V, int64_t row_stride, const int64_t *draft_next,
                                                          float t, int top_k, float top_p, void *probs, float *p_draft, float *row_max,
                                                          float *row_sumexp) {
     constexpr int EPV = Elem<DT>::EPV;
@@ -1163,23 +1270,44 @@ __global__ __launch_bounds__(256) void rs_filter_kernel(const void *logits, int6
     const RsRow row = rs_make_row<DT>(logits, r, V, row_stride, t, M, 1.f);
     // ---- 1. exactly rounded probabilities of the whole row
     const bool finite = (__float_as_uint(M) & 0x7F800000u) != 0x7F800000u;
-    const double S = finite ? rs_row_s64_wg<DT>(row, sh.tab, sh.red) : 0.0;
+    FLT_STAMP(0);
+    const double S = finite ? flt_row_s64<DT>(sh, row) : 0.0;
+    FLT_STAMP(1);
     {
         RsRow plain = row;
         plain.S = row_sumexp[r];                                               // (NaN / inf rows: jf_rs_probs' float32 statistics, plain formula)
         const double invS = S > 0.0 ? 1.0 / S : 0.0;
-        for (int64_t e0 = (int64_t)tid * EPV; e0 < V; e0 += 256 * EPV) {
-            float p[EPV];
-            rs_any_probs_from_vec<DT>(invS > 0.0 ? row : plain, rs_load_vec<DT>(row, e0), invS, sh.tab, p);
+        constexpr int NB = 8;                                                 // eight loads in flight per thread (one at a time: ~110 us of round trips per row)
+        for (int64_t b0 = (int64_t)tid * EPV; b0 < V; b0 += (int64_t)NB * FLT_TPB * EPV) {
+            u32x4 vv[NB];
 #pragma unroll
-            for (int j = 0; j < EPV; ++j) if (e0 + j < V) {
-                const float pj = p[j] >= 0.f ? p[j] : 0.f;                    // (a NaN row filters to zeros)
-                flt_store<DT>(out, e0 + j, pj);
-                if constexpr (HIST) atomicAdd(hist + (__float_as_uint(pj) >> 16), 1u);
+            for (int k = 0; k < NB; ++k) { const int64_t e0 = b0 + (int64_t)k * FLT_TPB * EPV; if (e0 < V) vv[k] = rs_load_vec<DT>(row, e0); }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int64_t e0 = b0 + (int64_t)k * FLT_TPB * EPV;
+                if (e0 >= V) continue;
+                float p[EPV];
+                rs_any_probs_from_vec<DT>(invS > 0.0 ? row : plain, vv[k], invS, sh.tab, p);
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) {
+                    p[j] = (e0 + j < V && p[j] >= 0.f) ? p[j] : 0.f;          // (a NaN row filters to zeros)
+                    if constexpr (HIST) { if (p[j] > 0.f) atomicAdd(hist + (__float_as_uint(p[j]) >> 16), 1u); }
+                }
+                if (((uintptr_t)out % 16) == 0 && e0 + EPV <= V) {
+                    u32x4 o;
+                    if constexpr (DT == JF_F32) o = u32x4{__float_as_uint(p[0]), __float_as_uint(p[1]), __float_as_uint(p[2]), __float_as_uint(p[3])};
+                    else o = u32x4{(__float_as_uint(p[0]) >> 16) | (__float_as_uint(p[1]) & 0xFFFF0000u), (__float_as_uint(p[2]) >> 16) | (__float_as_uint(p[3]) & 0xFFFF0000u),
+                                   (__float_as_uint(p[4]) >> 16) | (__float_as_uint(p[5]) & 0xFFFF0000u), (__float_as_uint(p[6]) >> 16) | (__float_as_uint(p[7]) & 0xFFFF0000u)};
+                    *(u32x4 *)((char *)out + e0 * (DT == JF_F32 ? 4 : 2)) = o;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j) if (e0 + j < V) flt_store<DT>(out, e0 + j, p[j]);
+                }
             }
         }
     }
     __syncthreads();
+    FLT_STAMP(2);
     const float floor_d = rs_round_prob<DT>(1e-12);                           // sum.clamp_min(1e-12) in the dtype
     unsigned long long cnt;
     double sum;
@@ -1192,6 +1320,7 @@ __global__ __launch_bounds__(256) void rs_filter_kernel(const void *logits, int6
             if (cnt >= (unsigned long long)top_k) lo = mid; else hi = mid;
         }
         const uint32_t thr = lo;                                              // the k-th largest value
+        FLT_STAMP(3);
         count_sum(thr + STEP, 0u, cnt, sum);              // the ids above it, and their sum
         const long long need = (long long)top_k - (long long)cnt;            // ids AT the threshold to keep (>= 1), lowest index first
         unsigned long long n_at; double s_at;
@@ -1200,7 +1329,9 @@ __global__ __launch_bounds__(256) void rs_filter_kernel(const void *logits, int6
         const double kept = sum + (double)need * (double)__uint_as_float(thr);
         float s1 = rs_round_prob<DT>(kept);
         s1 = s1 > floor_d ? s1 : floor_d;
+        FLT_STAMP(4);
         flt_renorm<DT>(out, V, thr, tie_last, s1, (top_p > 0.f && top_p < 1.f) ? hist : nullptr);
+        FLT_STAMP(5);
     }
     // ---- 3. top-p (JDN:91-107)
     if (top_p > 0.f && top_p < 1.f) {
@@ -1235,7 +1366,9 @@ __global__ __launch_bounds__(256) void rs_filter_kernel(const void *logits, int6
             s2 = rs_round_prob<DT>(c_whole + (double)c * v);
         }
         s2 = s2 > floor_d ? s2 : floor_d;
+        FLT_STAMP(6);
         flt_renorm<DT>(out, V, thr, tie_last, s2, nullptr);
+        FLT_STAMP(7);
     }
     if (tid == 0) {
         const int64_t tok = draft_next[r];
@@ -1258,14 +1391,14 @@ extern "C" int jf_rs_filter(const void *logits, int dtype, int64_t R, int64_t V,
     // the product form of the bf16 scaling where the host proves it exact for this T (as jf_rs_probs / jf_rs_step: -T says so)
     const float tt = (dtype == JF_BF16 && t != 1.f && rs_scale_is_exact(t)) ? -t : t;
     if (dtype == JF_F32) {
-        rs_filter_kernel<JF_F32, false><<<dim3((unsigned)R), dim3(256), 0, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
+        rs_filter_kernel<JF_F32, false><<<dim3((unsigned)R), dim3(FLT_TPB), 0, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
     } else {
         // bf16: value counts in 64 KB of dynamic LDS (beyond the default 64 KB per workgroup together with the static part: opt in once);
         // JF_RS_FILTER_HIST=0 keeps the pass-per-bisection-step variant (the float32 path's structure)
         static const bool hist = [] { const char *e = getenv("JF_RS_FILTER_HIST"); return !(e && e[0] == '0'); }();
         static const bool ok = hist && hipFuncSetAttribute((const void *)rs_filter_kernel<JF_BF16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FLT_BINS * 4) == hipSuccess;
-        if (ok) rs_filter_kernel<JF_BF16, true><<<dim3((unsigned)R), dim3(256), FLT_BINS * 4, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
-        else rs_filter_kernel<JF_BF16, false><<<dim3((unsigned)R), dim3(256), 0, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
+        if (ok) rs_filter_kernel<JF_BF16, true><<<dim3((unsigned)R), dim3(FLT_TPB), FLT_BINS * 4, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
+        else rs_filter_kernel<JF_BF16, false><<<dim3((unsigned)R), dim3(FLT_TPB), 0, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
     }
     return check_launch("rs_filter_kernel");
 }
