@@ -191,7 +191,7 @@ class JacobiDecoderNonGreedyOnPolicy:
         blk.start(self._init_block_draft_from_prompt(list(seq.token_ids), blk.gen_len))
         sp = getattr(seq, "sampling_params", None)
         temperature = float(getattr(sp, "temperature", 1.0)) if sp is not None else 1.0
-        ops.reject_unsupported_filters(sp, self.vocab_size)
+        top_k, top_p = ops.active_filters(sp, self.vocab_size)         # planted on the request object (JDO:132-133 reads them with getattr)
         st = self._ensure(blk.full_len + 1)
         bm = self.block_manager
         tick = (lambda name, on: (profiler.start(name) if on else profiler.stop(name))) if profiler else (lambda name, on: None)
@@ -215,7 +215,7 @@ class JacobiDecoderNonGreedyOnPolicy:
                 raise ValueError(f"Token index {bad} out of bounds for vocab size {V}. "
                                  "This may indicate a mismatch between model vocab and tokenizer vocab.")
             tick("jacobi.verify", True)
-            row, committed, redraft = st.step(draft[0, 1:], logits[0], temperature, self._cur)
+            row, committed, redraft = st.step(draft[0, 1:], logits[0], temperature, self._cur, top_k, top_p)
             self._cur[0] += row["n_uniforms"]
             self._cur[1] += row["n_bonus_draws"] + row["n_redraft"]
             stop_hit = bool(row["stop_hit"])

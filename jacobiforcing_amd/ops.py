@@ -810,17 +810,6 @@ def active_filters(sp, vocab_size: int) -> Tuple[int, float]:
     return k, pp
 
 
-def reject_unsupported_filters(sp, vocab_size: int) -> None:
-    """The on-policy rollout step still samples from the unfiltered softmax (its producer is out of scope): an
-    ACTIVE top_k / top_p on a request is refused loudly there instead of being ignored.  (The engine's non-greedy decoder
-    applies them since round 5: jf_rs_filter.)"""
-    k, pp = active_filters(sp, vocab_size)
-    if k or pp:
-        raise NotImplementedError(f"top_k={getattr(sp, 'top_k', None)!r} / top_p={getattr(sp, 'top_p', None)!r} filtering of the target "
-                                  "distribution is not implemented for the on-policy rollout step (DESIGN.md §7); remove the attribute or "
-                                  "use temperature only")
-
-
 class RsStepper:
     """Rejection-sampling verify of a batch of rows: jf_rs_probs (softmax-gather + argmax, logits read once) followed by
     jf_rs_step (accept/reject in stream order, bonus draws, next drafts) and one read-back per iteration.  The logits
@@ -935,8 +924,10 @@ class OnPolicyStepper:
         self.stop_ids = torch.tensor([int(x) for x in stop_ids], dtype=torch.int32, device=dev)
         self.cursors = torch.zeros((2,), dtype=torch.int64, device=dev)             # uniforms, multinomial
 
-    def step(self, proposed: torch.Tensor, logits: torch.Tensor, temperature: float, cursors: Sequence[int]):
-        """proposed [R] int64, logits [R, V] -> (row dict, committed list, redraft list [R] (valid from n_committed))."""
+    def step(self, proposed: torch.Tensor, logits: torch.Tensor, temperature: float, cursors: Sequence[int], top_k: int = 0,
+             top_p: float = 0.0):
+        """proposed [R] int64, logits [R, V] -> (row dict, committed list, redraft list [R] (valid from n_committed)).
+        ``top_k`` / ``top_p`` (``active_filters``): the rows go through jf_rs_filter first (JDO:99-136, the same filters)."""
         R = int(proposed.numel())
         if logits.dim() != 2 or logits.shape[0] != R:
             raise ValueError(f"forward must return logits [1, {R}, vocab], got {tuple(logits.shape)}")     # JDO:392-393
@@ -951,11 +942,19 @@ class OnPolicyStepper:
         N.check(lib.jf_rs_probs(_ptr(flat), _dtype_code(flat), R, V, flat.stride(0) if R > 1 else V, _ptr(prop),
                                 float(temperature), _ptr(self.p_draft), _ptr(self.row_max), _ptr(self.row_sumexp),
                                 _ptr(self.packed), _ptr(self.ws), self.ws.numel() * 4, _stream(dev)), "jf_rs_probs")
+        src, src_stride = flat, (flat.stride(0) if R > 1 else V)
+        if int(top_k) > 0 or float(top_p) > 0.0:
+            if getattr(self, "probs", None) is None or self.probs.numel() < R * V or self.probs.dtype != flat.dtype:
+                self.probs = torch.empty((R * V,), dtype=flat.dtype, device=dev)
+            src, src_stride = self.probs[:R * V].view(R, V), V
+            N.check(lib.jf_rs_filter(_ptr(flat), _dtype_code(flat), R, V, flat.stride(0) if R > 1 else V, _ptr(prop), float(temperature),
+                                     int(top_k), float(top_p), _ptr(src), _ptr(self.p_draft), _ptr(self.row_max), _ptr(self.row_sumexp),
+                                     _stream(dev)), "jf_rs_filter")
         self.cursors.copy_(torch.tensor(list(cursors), dtype=torch.int64), non_blocking=True)
         cur = self.cursors
         c_ptr = lambda i: C.c_void_p(cur.data_ptr() + 8 * i)
         cm, rd = self.out[0], self.out[1]
-        N.check(lib.jf_rs_onpolicy_step(_ptr(flat), _dtype_code(flat), V, flat.stride(0) if R > 1 else V, _ptr(prop), R,
+        N.check(lib.jf_rs_onpolicy_step(_ptr(src), _dtype_code(src), V, src_stride, _ptr(prop), R,
                                         _ptr(self.p_draft), _ptr(self.row_max), _ptr(self.row_sumexp), _ptr(self.packed),
                                         float(temperature), _ptr(self.stop_ids), int(self.stop_ids.numel()),
                                         _ptr(self.u_stream), self.u_stream.numel(), c_ptr(0),

@@ -1211,7 +1211,7 @@ def onpolicy_verify(proposed: List[int], probs: np.ndarray, stop_ids, next_unifo
 
 def onpolicy_run_one_block(forward: NonGreedyForward, seq: OracleSeq, block_len: int, budget: int, completion_start: int,
                            temperature: float, stop_ids, pad_id: int, vocab: int, rnd, next_uniform,
-                           next_multinomial_uniform, logits_dtype: str = "f32"):
+                           next_multinomial_uniform, logits_dtype: str = "f32", top_k=None, top_p=None):
     """JDO:331-488.  Returns (trajectory, appended_total, forwards_used, stopped)."""
     full_len = int(block_len)
     if full_len <= 0 or budget <= 0:
@@ -1233,7 +1233,7 @@ def onpolicy_run_one_block(forward: NonGreedyForward, seq: OracleSeq, block_len:
         logits = forward([seq], [draft])[0]                                      # [remaining, V]
         seq.num_cached_tokens = len(seq) - 1 + (remaining + 1)
         fwd_used += 1
-        probs = target_probs(logits, temperature, logits_dtype)
+        probs = target_probs(logits, temperature, logits_dtype, top_k, top_p)
         committed, stop_hit = onpolicy_verify(proposed, probs, stop_ids, next_uniform, next_multinomial_uniform)
         if not committed:
             committed = [proposed[0]]
@@ -1275,7 +1275,7 @@ def onpolicy_run_one_block(forward: NonGreedyForward, seq: OracleSeq, block_len:
 def onpolicy_rollout_records_batch(forward: NonGreedyForward, seqs: List[OracleSeq], temperature: float, stop_ids,
                                    pad_id: int, vocab: int, rnd, next_uniform, next_multinomial_uniform,
                                    n_token_seq_len: Optional[int] = None, data_ids: Optional[List[str]] = None,
-                                   logits_dtype: str = "f32"):
+                                   logits_dtype: str = "f32", top_k=None, top_p=None):
     """JDO:494-614: (records per sequence {block index -> record}, metrics per sequence).
     ``seq.max_iters`` is the maximum number of BLOCKS (JDO:232-233)."""
     B = len(seqs)
@@ -1300,7 +1300,7 @@ def onpolicy_rollout_records_batch(forward: NonGreedyForward, seqs: List[OracleS
             prompt_trim = trim_left_padding(list(seq.token_ids), pad_id)
             traj, app, fw, hit = onpolicy_run_one_block(forward, seq, block_lens[i], budgets[i], starts[i], temperature,
                                                         stop_ids, pad_id, vocab, rnd, next_uniform, next_multinomial_uniform,
-                                                        logits_dtype)
+                                                        logits_dtype, top_k=top_k, top_p=top_p)
             done_blocks[i] += 1
             forwards[i] += fw
             generated[i] += app

@@ -409,8 +409,7 @@ class HostSimLib:
     def jf_rs_onpolicy_step(self, logits, dtype, V, stride, proposed, R, p_draft, row_max, row_sumexp, packed, temperature,
                             stop_ids, n_stop, u_stream, u_len, u_cursor, m_stream, m_len, m_cursor, committed, redraft, row,
                             ws, ws_bytes, stream):
-        lg = self._rows_f32(logits, dtype, R, V, stride)
-        probs = O.target_probs(lg, temperature, self._ldt(dtype))
+        probs = self._probs_of(logits, dtype, R, V, stride, temperature, row_sumexp)
         prop = _view(proposed, R, np.int64).tolist()
         stops = _view(stop_ids, n_stop, np.int32).tolist() if n_stop else []
         us, ms = _view(u_stream, u_len, np.float32), _view(m_stream, m_len, np.float32)

@@ -562,7 +562,7 @@ class ScriptedRandom:
 
 
 def run_jdo_case(name, *, vocab, seeds, robust, prompt_lens, block_len, max_tokens, temperature, max_blocks=128,
-                 eos_pos=None, extra_stop=None, rng_seed=9, left_pad=0, logits_dtype="f32", peak=8.0):
+                 eos_pos=None, extra_stop=None, rng_seed=9, left_pad=0, logits_dtype="f32", peak=8.0, top_k=None, top_p=None):
     """JacobiDecoderNonGreedyOnPolicy.generate_rollout_records_batch (JDO:494-614) with every random draw injected."""
     eos_id, pad_id = vocab - 1, vocab - 2
     stop_ids = [eos_id] + ([extra_stop] if extra_stop is not None else [])
@@ -577,6 +577,10 @@ def run_jdo_case(name, *, vocab, seeds, robust, prompt_lens, block_len, max_toke
         m = ScriptedModel(vocab, sd, robust, pl, eos_id=eos_id, eos_pos=ep, reserved=reserved, peak=peak)
         sp = SamplingParams(temperature=temperature, max_tokens=max_tokens, decode_strategy="jacobi",
                             jacobi_block_len=block_len, jacobi_max_iterations=max_blocks, jacobi_on_policy=True)
+        if top_k is not None:                   # planted: JDO:132-133 reads them with getattr, like JDN
+            sp.top_k = top_k
+        if top_p is not None:
+            sp.top_p = top_p
         seq = H.add_seq(m, sp, None)
         seqs.append(seq)
         descr.append(dict(model=m.describe(), prompt=m.prompt()))
@@ -594,6 +598,10 @@ def run_jdo_case(name, *, vocab, seeds, robust, prompt_lens, block_len, max_toke
                   block_len=block_len, max_tokens=max_tokens, temperature=temperature, max_blocks=max_blocks)
     if logits_dtype != "f32":
         params["logits_dtype"] = logits_dtype
+    if top_k is not None:
+        params["top_k"] = top_k
+    if top_p is not None:
+        params["top_p"] = top_p
     return dict(name=name, kind="jdo", params=params,
                 seqs=descr, records=[{str(k): v for k, v in r.items()} for r in records], metrics=metrics,
                 final=[dict(token_ids=s.token_ids, num_cached_tokens=s.num_cached_tokens) for s in seqs],
@@ -1029,6 +1037,20 @@ def main():
         run_jdn_case("jdn4_bf16_V64_k10_p08_T08", vocab=64, seeds=[720, 721, 722], robust=70, prompt_lens=[8, 5, 11], block_len=16,
                      max_tokens=40, temperature=0.8, rng_seed=51, logits_dtype="bf16", peak=3.0, top_k=10, top_p=0.8),
     ]
+    jdos4 = [
+        run_jdo_case("jdo4_f32_k5", vocab=300, seeds=[800, 801], robust=80, prompt_lens=[8, 12], block_len=16, max_tokens=40,
+                     temperature=1.0, rng_seed=61, peak=4.0, top_k=5),
+        run_jdo_case("jdo4_f32_p09_T08", vocab=1000, seeds=[802, 803, 804], robust=85, prompt_lens=[9, 6, 14], block_len=32, max_tokens=48,
+                     temperature=0.8, rng_seed=62, peak=5.0, top_p=0.9),
+        run_jdo_case("jdo4_f32_k20_p08_stop", vocab=200, seeds=[805, 806], robust=90, prompt_lens=[8, 5], block_len=8, max_tokens=30,
+                     temperature=1.0, eos_pos=[18, None], rng_seed=63, peak=3.0, top_k=20, top_p=0.8),
+        run_jdo_case("jdo4_bf16_V64_p09", vocab=64, seeds=[807, 808], robust=75, prompt_lens=[8, 11], block_len=16, max_tokens=40,
+                     temperature=1.0, rng_seed=64, logits_dtype="bf16", peak=3.0, top_p=0.9),
+        run_jdo_case("jdo4_bf16_V64_k7_T12", vocab=64, seeds=[809, 810], robust=75, prompt_lens=[7, 9], block_len=8, max_tokens=24,
+                     temperature=1.2, rng_seed=65, logits_dtype="bf16", peak=2.0, top_k=7),
+        run_jdo_case("jdo4_bf16_V64_k10_p08", vocab=64, seeds=[811], robust=80, prompt_lens=[10], block_len=16, max_tokens=40,
+                     temperature=0.8, rng_seed=66, logits_dtype="bf16", peak=3.0, top_k=10, top_p=0.8),
+    ]
     flt = run_filter_vectors()
     smx = run_softmax_vectors()
     kv = run_argmax_vectors()
@@ -1056,6 +1078,7 @@ def main():
     dump("jdn_cases_v2.json", jdns2)
     dump("jdo_cases_v2.json", jdos2)
     dump("jdn_cases_v4.json", jdns4)
+    dump("jdo_cases_v4.json", jdos4)
     dump("filter_vectors.json", flt)
     dump("softmax_vectors.json", smx)
     dump("kernel_vectors.json", kv)

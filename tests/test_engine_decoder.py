@@ -115,7 +115,7 @@ from jacobiforcing_amd.engine.jacobi_decoding_nongreedy import JacobiDecoderNonG
 # which torch's choice among EQUAL probabilities at a cut is observable (tests/test_oracle_golden.py TIE_CHOICE_OBSERVABLE)
 JDN = load_golden("jdn_cases.json") + load_golden("jdn_cases_v2.json") + load_golden("jdn_cases_v3.json") + \
     [c for c in load_golden("jdn_cases_v4.json") if c["name"] not in ("jdn4_bf16_flat_p08", "jdn4_bf16_topp09_L32")]
-JDO = load_golden("jdo_cases.json") + load_golden("jdo_cases_v2.json") + load_golden("jdo_cases_v3.json")
+JDO = load_golden("jdo_cases.json") + load_golden("jdo_cases_v2.json") + load_golden("jdo_cases_v3.json") + load_golden("jdo_cases_v4.json")
 BMC = load_golden("bm_cases.json")
 TORCH_DTYPES = {"f32": torch.float32, "bf16": torch.bfloat16}
 
@@ -180,6 +180,9 @@ def test_engine_onpolicy_records_golden(case, backend):
             m = ScriptedModel.from_dict(d["model"])
             sp = SamplingParams(temperature=p["temperature"], max_tokens=p["max_tokens"], decode_strategy="jacobi",
                                 jacobi_block_len=p["block_len"], jacobi_max_iterations=p["max_blocks"], jacobi_on_policy=True)
+            for k in ("top_k", "top_p"):                     # jdo_cases_v4.json: planted on the instance (JDO:132-133)
+                if k in p:
+                    setattr(sp, k, p[k])
             seqs.append(H.add(m, sp, None))
         records, metrics = dec.generate_rollout_records_batch(seqs, return_metrics=True)
         assert [{str(k): v for k, v in r.items()} for r in records] == case["records"]
@@ -351,8 +354,8 @@ def test_nongreedy_first_token_follows_the_target_distribution(backend, ldt):
 
 def test_top_k_and_top_p_are_read_like_the_reference_reads_them():
     """SamplingParams has no top_k / top_p (sampling_params.py:4-38); the reference honours such attributes when a caller
-    attaches them and switches a stage off for None / out-of-range values (JDN:75, 92-96).  The engine's non-greedy decoder
-    applies them (jf_rs_filter); the on-policy rollout step refuses an active one instead of ignoring it."""
+    attaches them and switches a stage off for None / out-of-range values (JDN:75, 92-96; JDO:100, 112-116).  Both sampling
+    decoders apply them (jf_rs_filter)."""
     import types
     assert ops.active_filters(None, 100) == (0, 0.0)
     assert ops.active_filters(types.SimpleNamespace(temperature=1.0), 100) == (0, 0.0)
@@ -360,10 +363,6 @@ def test_top_k_and_top_p_are_read_like_the_reference_reads_them():
     assert ops.active_filters(types.SimpleNamespace(top_k=0, top_p=1.0), 100) == (0, 0.0)          # inactive values (JDN:75, 96)
     assert ops.active_filters(types.SimpleNamespace(top_k=100, top_p=0.0), 100) == (0, 0.0)
     assert ops.active_filters(types.SimpleNamespace(top_k=5, top_p=0.9), 100) == (5, 0.9)
-    ops.reject_unsupported_filters(types.SimpleNamespace(top_k=100, top_p=0.0), 100)
-    for bad in (dict(top_k=5), dict(top_p=0.9)):
-        with pytest.raises(NotImplementedError):
-            ops.reject_unsupported_filters(types.SimpleNamespace(**bad), 100)
     sp = SamplingParams(temperature=0.8, max_tokens=4, decode_strategy="jacobi")
     sp.top_k, sp.top_p = 7, 0.5                                  # a SamplingParams instance takes the planted attributes
     assert ops.active_filters(sp, 100) == (7, 0.5)

@@ -17,7 +17,7 @@ JDN = load_golden("jdn_cases.json") + load_golden("jdn_cases_v2.json") + load_go
 FLT = load_golden("filter_vectors.json")
 MBR = load_golden("mb_raises.json")
 SLOTS = load_golden("slot_cases.json")
-JDO = load_golden("jdo_cases.json") + load_golden("jdo_cases_v2.json") + load_golden("jdo_cases_v3.json")
+JDO = load_golden("jdo_cases.json") + load_golden("jdo_cases_v2.json") + load_golden("jdo_cases_v3.json") + load_golden("jdo_cases_v4.json")
 SMX = load_golden("softmax_vectors.json")
 
 
@@ -333,7 +333,7 @@ def run_oracle_jdo(case):
     multi = O.CounterStream(p["rng_seed"] * 5 + 3)
     records, metrics = O.onpolicy_rollout_records_batch(fwd, seqs, p["temperature"], p["stop_ids"], p["pad_id"], p["vocab"],
                                                         O.ScriptedRandom(inits), unis.uniform, multi.uniform,
-                                                        logits_dtype=ldt)
+                                                        logits_dtype=ldt, top_k=p.get("top_k"), top_p=p.get("top_p"))
     return seqs, records, metrics, dict(inits=inits.k, uniforms=unis.k, multinomial=multi.k), trace
 
 
