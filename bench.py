@@ -331,6 +331,28 @@ def nongreedy_section(model, cfg, weights, tuned, P: int = 64, L: int = 32, temp
         probs, step = st.summary("rs_probs", skip=1), st.summary("rs_step", skip=1)
     toks = sum(len(r["token_ids"]) for r in res)
     its = len(st.done.get("rs_step", [])) or 1
+    # the same decoding with top_k / top_p planted on the request object, as the reference reads them (JDN:117-118): jf_rs_filter in situ
+    filtered = None
+    try:
+        spf = mk(16)
+        spf.top_k, spf.top_p = 50, 0.9
+        with StageTimer() as stf:
+            t0 = time.perf_counter()
+            resf = llm.generate(prompts, spf, use_tqdm=False)
+            torch.cuda.synchronize()
+            dtf = time.perf_counter() - t0
+            fl = stf.summary("rs_filter", skip=1)
+        itf = len(stf.done.get("rs_step", [])) or 1
+        filtered = dict(top_k=50, top_p=0.9, value=sum(len(r["token_ids"]) for r in resf) / dtf, unit="tokens/s", iterations=itf,
+                        ms_per_step=dtf / itf * 1e3,
+                        rs_filter=None if fl is None else {"us_per_launch": fl["us"], "launches": fl["launches"], "bytes_per_launch": fl["bytes"],
+                                                           "timing": stf.timing("rs_filter"),
+                                                           "kernel": "rs_filter_kernel (jf_rs_filter: exact probabilities -> top-k / top-p by bisection on an "
+                                                                     "LDS count histogram of the bf16 values -> renormalised probability rows)"},
+                        note="prefill included, 16 tokens per request; random-init weights: the kept sets end inside ties of equal bf16 "
+                             "probabilities in most rows (ordered by token id, DESIGN.md 4)")
+    except Exception as e:  # evidence for a new kernel must not cost the section
+        filtered = {"error": f"{type(e).__name__}: {e}"}
     del llm
     if probs is not None:
         probs = dict(probs)
@@ -353,7 +375,7 @@ def nongreedy_section(model, cfg, weights, tuned, P: int = 64, L: int = 32, temp
                          "(LLM.generate on the bench's random-init weights: acceptance ~1 token per forward)",
                 value=toks / dt, unit="tokens/s", tokens=toks, seconds=dt, iterations=its, ms_per_step=dt / its * 1e3,
                 tokens_per_forward=toks / (its * P),
-                roofline=out_roof, rs_step=out_step)
+                roofline=out_roof, rs_step=out_step, filtered=filtered)
 
 
 def vs_ar_section(model, cfg, prm, tuned, vocab_hi, robust, warmup: int = 8, steps: int = 40, ar_tokens: int = 64):

@@ -868,9 +868,11 @@ class RsStepper:
             if getattr(self, "probs", None) is None or self.probs.numel() < R * V or self.probs.dtype != flat.dtype:
                 self.probs = torch.empty((R * V,), dtype=flat.dtype, device=dev)
             src = self.probs[:R * V].view(R, V)
+            done = _stage("rs_filter", 3 * R * V * flat.element_size())        # the logits twice (float64 sum, probabilities), the result once
             N.check(lib.jf_rs_filter(_ptr(flat), _dtype_code(flat), R, V, flat.stride(0), _ptr(draft_next), float(temperature),
                                      int(top_k), float(top_p), _ptr(src), _ptr(self.p_draft), _ptr(self.row_max),
                                      _ptr(self.row_sumexp), _stream(dev)), "jf_rs_filter")
+            done()
         self.remaining[:B].copy_(torch.tensor(list(remaining), dtype=torch.int32), non_blocking=True)
         self.cursors.copy_(torch.tensor(list(cursors), dtype=torch.int64), non_blocking=True)
         cm = self.committed.view(-1)[:B * L].view(B, L)

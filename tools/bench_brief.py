@@ -27,6 +27,11 @@ for path in sys.argv[1:]:
     ng = d.get("nongreedy")
     if ng and "roofline" in ng:
         print(f"   nongreedy: {ng['value']:.0f} tok/s  rs_probs {ng['roofline']['us_per_launch']:.1f} us = {ng['roofline']['frac']:.3f}  rs_step {ng['rs_step']['us_per_launch']:.1f} us")
+        f = ng.get("filtered") or {}
+        if f.get("rs_filter"):
+            print(f"   nongreedy, top_k {f['top_k']} top_p {f['top_p']}: {f['value']:.0f} tok/s  {f['ms_per_step']:.2f} ms/step  rs_filter {f['rs_filter']['us_per_launch']:.0f} us per call")
+        elif f:
+            print("   nongreedy filtered:", f)
     elif ng:
         print("   nongreedy:", ng)
     if "single_block" in d:
