@@ -102,6 +102,24 @@ def test_engine_greedy_fuzz(seed, backend):
             assert len(s.block_table) == o.num_table_blocks
 
 
+# round 5: every third seed of the two sampling sweeps plants top_k / top_p on its requests (chosen from the seed alone, so the
+# other seeds' streams are what they were).  Kernel and oracle share the filters' definition — ties by token id, exact sums — so
+# these seeds are bit-exact too, tied cuts or not.
+_FILTERS = [(5, None), (None, 0.9), (20, 0.8), (None, 0.5), (3, None), (50, 0.95), (1, None), (None, 0.3)]
+
+
+def _filters_of(seed):
+    return _FILTERS[(seed // 3) % len(_FILTERS)] if seed % 3 == 2 else (None, None)
+
+
+def _plant(sp, top_k, top_p):
+    if top_k is not None:
+        sp.top_k = top_k
+    if top_p is not None:
+        sp.top_p = top_p
+    return sp
+
+
 @pytest.mark.parametrize("seed,backend", _cases(24, 72))
 def test_engine_nongreedy_fuzz(seed, backend):
     """Same sweep for rejection sampling.  The oracle and the kernels share the injected streams; probabilities differ only
@@ -112,6 +130,7 @@ def test_engine_nongreedy_fuzz(seed, backend):
     eos, pad = V - 1, V - 2
     temperature = float(rng.choice([1.0, 0.7, 0.4]))
     ldt, peak = _dtype_and_peak(seed, rng)
+    top_k, top_p = _filters_of(seed)
     pads = [int(x) for x in rng.integers(0, V, size=4096)]
     unis = [float(x) for x in (rng.integers(0, 1 << 24, size=8192) / float(1 << 24))]
     bonus = [float(x) for x in (rng.integers(0, 1 << 24, size=8192) / float(1 << 24))]
@@ -126,8 +145,8 @@ def test_engine_nongreedy_fuzz(seed, backend):
         seqs, oseqs, models = [], [], []
         for it in items:
             m = ScriptedModel(V, it["seed"], robust, it["pl"], eos_id=eos, eos_pos=it["eos_pos"], reserved=(pad,), peak=peak)
-            sp = SamplingParams(temperature=temperature, max_tokens=it["mt"], decode_strategy="jacobi", jacobi_block_len=it["L"],
-                                jacobi_max_iterations=max_iters)
+            sp = _plant(SamplingParams(temperature=temperature, max_tokens=it["mt"], decode_strategy="jacobi", jacobi_block_len=it["L"],
+                                       jacobi_max_iterations=max_iters), top_k, top_p)
             seqs.append(H.add(m, sp, None))
             oseqs.append(O.OracleSeq(m.prompt(), it["L"], it["mt"], max_iters=max_iters))
             models.append(m)
@@ -149,7 +168,7 @@ def test_engine_nongreedy_fuzz(seed, backend):
             return [_as_dtype(by[id(s)].logits_rows(s.token_ids[:-1], [d])[0][:-1], ldt) for s, d in zip(ss, drafts)]
         stats = O.new_stats()
         want = O.nongreedy_generate_batch(ofwd, oseqs, eos, temperature, take("p", pads), take("u", unis), take("b", bonus), stats,
-                                          logits_dtype=ldt)
+                                          logits_dtype=ldt, top_k=top_k, top_p=top_p)
         got = dec.generate_chunk_batch(seqs)
         assert got == want
         assert dec.stats == stats
@@ -167,6 +186,7 @@ def test_engine_onpolicy_fuzz(seed, backend):
     temperature = float(rng.choice([1.0, 0.7, 0.4, 1.5]))
     max_blocks = int(rng.choice([128, 128, 2, 1]))
     ldt, peak = _dtype_and_peak(seed, rng)
+    top_k, top_p = _filters_of(seed)
     unis = [float(x) for x in (rng.integers(0, 1 << 24, size=8192) / float(1 << 24))]
     multi = [float(x) for x in (rng.integers(0, 1 << 24, size=8192) / float(1 << 24))]
     L = max(items[0]["L"], 2)
@@ -181,8 +201,8 @@ def test_engine_onpolicy_fuzz(seed, backend):
         seqs, oseqs, models = [], [], []
         for it in items:
             m = ScriptedModel(V, it["seed"], robust, it["pl"], eos_id=eos, eos_pos=it["eos_pos"], reserved=(pad,), peak=peak)
-            sp = SamplingParams(temperature=temperature, max_tokens=it["mt"], decode_strategy="jacobi", jacobi_block_len=L,
-                                jacobi_max_iterations=max_blocks, jacobi_on_policy=True)
+            sp = _plant(SamplingParams(temperature=temperature, max_tokens=it["mt"], decode_strategy="jacobi", jacobi_block_len=L,
+                                       jacobi_max_iterations=max_blocks, jacobi_on_policy=True), top_k, top_p)
             seqs.append(H.add(m, sp, None))
             oseqs.append(O.OracleSeq(m.prompt(), L, it["mt"], max_iters=max_blocks))
             models.append(m)
@@ -199,7 +219,7 @@ def test_engine_onpolicy_fuzz(seed, backend):
         def ofwd(ss, drafts):
             return [_as_dtype(by[id(s)].logits_rows(s.token_ids[:-1], [d])[0][:-1], ldt) for s, d in zip(ss, drafts)]
         want, wmet = O.onpolicy_rollout_records_batch(ofwd, oseqs, temperature, stop_ids, pad, V, O.ScriptedRandom(b),
-                                                      take("u", unis), take("m", multi), logits_dtype=ldt)
+                                                      take("u", unis), take("m", multi), logits_dtype=ldt, top_k=top_k, top_p=top_p)
         got, gmet = dec.generate_rollout_records_batch(seqs, return_metrics=True)
         assert got == want
         assert gmet == wmet
