@@ -1103,33 +1103,93 @@ __device__ __forceinline__ void flt_hist_count_sum(FltShared &sh, const uint32_t
     cnt = c; sum = a;
     flt_reduce(sh, cnt, sum);
 }
-__device__ __forceinline__ uint32_t flt_hist_max_below(FltShared &sh, const uint32_t *hist, uint32_t below) {
-    const uint32_t bb = below >> 16;
-    uint32_t m = 0u;
-#pragma unroll 8
-    for (int b = (int)threadIdx.x; b < FLT_BINS; b += FLT_TPB) m = ((uint32_t)b < bb && hist[b] != 0u && (uint32_t)b > m) ? (uint32_t)b : m;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh.umax[threadIdx.x >> 6] = m;
-    __syncthreads();
-    m = sh.umax[0];
-    for (int w = 1; w < FLT_NW; ++w) m = sh.umax[w] > m ? sh.umax[w] : m;
-    return m << 16;
+// ---- float32 rows: three LEVELS of counters.  The 32-bit pattern of a probability splits into a BIN (its top 15 bits: 8 129 of them)
+// and 17 low bits; a 64-bit LDS word per bin holds (count << 35) | (sum of the low parts), from which the bin's exact float64 sum
+// follows — count x (the bin's first value) + (sum of low parts) x (the bin's spacing): an integer multiple of the spacing below
+// 2^43, exact — so any count / sum whose limits fall on bin edges is ~1 us of LDS work as for bf16.  A limit INSIDE a bin is served
+// by two sub-tables built by one pass over the row each: FOCUS A holds bits 16:8 of the ids of one bin (512 entries), FOCUS B the
+// last 8 bits of the ids under one 24-bit prefix.  The bisections run coarse to fine (bin edges, then 256-aligned keys inside the
+// bin found, then keys), so each builds A once and B once: ~8 passes over the row per call instead of a pass per bisection step
+// (~70).  64 KB of bins + 5 KB of sub-tables: two workgroups per CU, like bf16.  Rows of more than 2^18 ids keep the
+// pass-per-step variant (the low-part sums would carry into the counts).
+constexpr int FLT_F32_SHIFT = 17, FLT_F32_BINS = 8192, FLT_SUBA = 512, FLT_SUBB = 256;
+constexpr unsigned FLT_LDS_F32 = FLT_F32_BINS * 8 + FLT_SUBA * 8 + FLT_SUBB * 4;
+constexpr uint32_t FLT_F32_LOW = (1u << FLT_F32_SHIFT) - 1u;
+constexpr unsigned long long FLT_LOW_MASK = (1ull << 35) - 1ull;
+static_assert(FLT_TPB >= FLT_SUBA && (0x3F800000u >> FLT_F32_SHIFT) < (unsigned)FLT_F32_BINS - 1u, "a thread per sub-table entry; 1.0 has a bin");
+__device__ __forceinline__ double flt_bin_ulp(uint32_t bin) {             // spacing of the float32 values of a bin (subnormals: 2^-149)
+    uint32_t e = bin >> (23 - FLT_F32_SHIFT);
+    e = e ? e : 1u;
+    return __longlong_as_double((long long)(e + 873u) << 52);              // 2^(e - 150)
 }
-// largest key strictly below `below` (0 if none)
-template <int DT>
-__device__ __forceinline__ uint32_t flt_max_below(FltShared &sh, const void *row, int64_t V, uint32_t below) {
-    uint32_t m = 0u;
-    flt_for_each<DT>(row, V, [&](int64_t, uint32_t k) { m = (k < below && k > m) ? k : m; });
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
+struct FltF32 {
+    unsigned long long *hist, *subA;
+    uint32_t *subB;
+    uint32_t focA, focB;                                                   // the bin / the 24-bit prefix the sub-tables hold (0xFFFFFFFF: none)
+    uint32_t l1_from;                                                      // cached: count and sum of the bins >= l1_from
+    unsigned long long l1_cnt;
+    double l1_sum;
+    __device__ __forceinline__ void reset() { focA = focB = l1_from = 0xFFFFFFFFu; }
+};
+__device__ __forceinline__ void flt_hist64_zero(unsigned long long *hist) {
+    for (int b = threadIdx.x; b < FLT_F32_BINS; b += FLT_TPB) hist[b] = 0ull;
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh.umax[threadIdx.x >> 6] = m;
-    __syncthreads();
-    m = sh.umax[0];
-    for (int w = 1; w < FLT_NW; ++w) m = sh.umax[w] > m ? sh.umax[w] : m;
-    return m;
+}
+__device__ __forceinline__ void flt_hist64_add(unsigned long long *hist, uint32_t key) {
+    atomicAdd(hist + (key >> FLT_F32_SHIFT), (1ull << 35) | (unsigned long long)(key & FLT_F32_LOW));
+}
+// count and exact sum of the row's positive elements with key >= `key` (every thread gets them)
+__device__ __forceinline__ void flt_f32_ge(FltShared &sh, FltF32 &f, const void *row, int64_t V, uint32_t key, unsigned long long &cnt, double &sum) {
+    const int tid = threadIdx.x;
+    const uint32_t B = key >> FLT_F32_SHIFT, a = (key & FLT_F32_LOW) >> 8, c = key & 0xFFu;
+    const bool pa = (key & FLT_F32_LOW) != 0u, pb = c != 0u;
+    const uint32_t from = pa ? B + 1u : B;
+    if (pa && f.focA != B) {
+        __syncthreads();
+        if (tid < FLT_SUBA) f.subA[tid] = 0ull;
+        __syncthreads();
+        flt_for_each<JF_F32>(row, V, [&](int64_t, uint32_t k) { if ((k >> FLT_F32_SHIFT) == B && k != 0u) atomicAdd(&f.subA[(k & FLT_F32_LOW) >> 8], (1ull << 35) | (unsigned long long)(k & 0xFFu)); });
+        __syncthreads();
+        f.focA = B;
+    }
+    if (pb && f.focB != (key >> 8)) {
+        const uint32_t P = key >> 8;
+        __syncthreads();
+        if (tid < FLT_SUBB) f.subB[tid] = 0u;
+        __syncthreads();
+        flt_for_each<JF_F32>(row, V, [&](int64_t, uint32_t k) { if ((k >> 8) == P && k != 0u) atomicAdd(&f.subB[k & 0xFFu], 1u); });
+        __syncthreads();
+        f.focB = P;
+    }
+    if (f.l1_from != from) {
+        unsigned long long n = 0ull;
+        double s = 0.0;
+#pragma unroll 8
+        for (int b = tid; b < FLT_F32_BINS; b += FLT_TPB) {
+            const unsigned long long w = (uint32_t)b >= from ? f.hist[b] : 0ull;
+            const unsigned long long cn = w >> 35;
+            n += cn;
+            s += (double)cn * (double)__uint_as_float((uint32_t)b << FLT_F32_SHIFT) + (double)(w & FLT_LOW_MASK) * flt_bin_ulp((uint32_t)b);
+        }
+        flt_reduce(sh, n, s);
+        f.l1_from = from; f.l1_cnt = n; f.l1_sum = s;
+    }
+    cnt = f.l1_cnt; sum = f.l1_sum;
+    if (pa) {
+        unsigned long long n = 0ull;
+        double s = 0.0;
+        if (tid < FLT_SUBA && (uint32_t)tid >= (pb ? a + 1u : a)) {
+            const unsigned long long w = f.subA[tid], cn = w >> 35;
+            n = cn;
+            s = (double)cn * (double)__uint_as_float((B << FLT_F32_SHIFT) | ((uint32_t)tid << 8)) + (double)(w & FLT_LOW_MASK) * flt_bin_ulp(B);
+        }
+        if (pb && tid < FLT_SUBB && (uint32_t)tid >= c) {
+            const unsigned long long nb = f.subB[tid];
+            n += nb; s += (double)nb * (double)__uint_as_float((key & ~0xFFu) | (uint32_t)tid);
+        }
+        flt_reduce(sh, n, s);
+        cnt += n; sum += s;
+    }
 }
 // index of the c-th (1-based) element, in index order, whose key equals `key` (V if there are fewer).  Two steps: the ties are
 // counted per TILE of 256 vectors (LDS counters, one vectorised pass), the tile that holds the c-th one is ranked thread by thread
@@ -1194,11 +1254,11 @@ __device__ __forceinline__ int64_t flt_nth_equal(FltShared &sh, const void *row,
     return (int64_t)s_hit;
 }
 // renormalise in place: ids with key > thr, and ids AT thr up to index tie_last, keep value / denom; the others become 0
-template <int DT>
-__device__ __forceinline__ void flt_renorm(void *row, int64_t V, uint32_t thr, int64_t tie_last, float denom, uint32_t *hist /* nullable: rebuilt from the results */) {
+template <int DT, int HM>
+__device__ __forceinline__ void flt_renorm(void *row, int64_t V, uint32_t thr, int64_t tie_last, float denom, void *hist /* nullable: rebuilt from the results (HM 1: counts, 2: float32 words) */) {
     constexpr int EPV = Elem<DT>::EPV, NB = 8;
     __syncthreads();
-    if (hist) flt_hist_zero(hist);
+    if (hist) { if constexpr (HM == 2) flt_hist64_zero((unsigned long long *)hist); else flt_hist_zero((uint32_t *)hist); }
     RsRow rr;
     rr.p = row; rr.V = V; rr.vec = (((uintptr_t)row) % 16) == 0;
     for (int64_t b0 = (int64_t)threadIdx.x * EPV; b0 < V; b0 += (int64_t)NB * FLT_TPB * EPV) {      // (a thread rewrites exactly the ids it read)
@@ -1221,7 +1281,11 @@ __device__ __forceinline__ void flt_renorm(void *row, int64_t V, uint32_t thr, i
                 if (keep) {                                               // a BRANCH: the IEEE division is ~12 instructions, and after a top-k
                     q[j] = flt_div<DT>(__uint_as_float(key), denom);      // hardly any id is kept (as a select the pass was division-bound: 60 us)
                     // (zeros are not counted: nothing asks for them, and after a top-k nearly every id would hit that one counter)
-                    if (hist && q[j] > 0.f) atomicAdd(hist + (__float_as_uint(q[j]) >> 16), 1u);
+                    if (hist && q[j] > 0.f) {
+                        const uint32_t qb = __float_as_uint(q[j]);
+                        if constexpr (HM == 2) flt_hist64_add((unsigned long long *)hist, qb);
+                        else atomicAdd((uint32_t *)hist + (qb >> 16), 1u);
+                    }
                 }
             }
             if (rr.vec && e0 + EPV <= V) {                                  // one 16-byte store (2-byte stores made this pass 59 us per row)
@@ -1247,25 +1311,53 @@ extern "C" __attribute__((visibility("default"))) int jf_exp_flt_trace(unsigned 
 #else
 #define FLT_STAMP(k) do { } while (0)
 #endif
-template <int DT, bool HIST>
-__global__ __launch_bounds__(FLT_TPB) void rs_filter_kernel(const void *logits, int64_t R, int64_t V, int64_t row_stride, const int64_t *draft_next,
+// HIST: 0 a pass over the row per bisection step, 1 bf16 value counts in LDS, 2 the float32 levels
+template <int DT, int HIST>
+__global__ __launch_bounds__(FLT_TPB, 4) void rs_filter_kernel(const void *logits,   // (4 waves per SIMD = two workgroups per CU — bf16: 2 x 67 KB of LDS —: <= 128 VGPRs)
+                                                          int64_t R, int64_t V, int64_t row_stride, const int64_t *draft_next,
                                                          float t, int top_k, float top_p, void *probs, float *p_draft, float *row_max,
                                                          float *row_sumexp) {
+    static_assert(HIST == 0 || (HIST == 1 && DT == JF_BF16) || (HIST == 2 && DT == JF_F32), "");
     constexpr int EPV = Elem<DT>::EPV;
     constexpr uint32_t STEP = DT == JF_F32 ? 1u : 0x10000u;                 // distance of two neighbouring values' keys
-    constexpr uint32_t FLT_KEY_TOP = 0x3F800000u + STEP;                    // the key above 1.0: no probability reaches it (on the key grid)
+    constexpr uint32_t FLT_KEY_TOP = HIST == 2 ? 0x3F800000u + (1u << FLT_F32_SHIFT) : 0x3F800000u + STEP;   // a key above 1.0 on the (coarsest) key grid: no probability reaches it
     __shared__ FltShared sh;
     extern __shared__ uint32_t flt_dyn[];
-    uint32_t *hist = HIST ? flt_dyn : nullptr;                               // bf16: the row's value counts (FLT_BINS words of dynamic LDS)
-    auto count_sum = [&](uint32_t lo_, uint32_t hi_, unsigned long long &c_, double &s_) {
-        if constexpr (HIST) flt_hist_count_sum(sh, hist, lo_, hi_, c_, s_); else flt_count_sum<DT>(sh, (char *)probs + (int64_t)blockIdx.x * V * (DT == JF_F32 ? 4 : 2), V, lo_, hi_, c_, s_);
-    };
+    uint32_t *hist = HIST == 1 ? flt_dyn : nullptr;                          // bf16: the row's value counts (FLT_BINS words of dynamic LDS)
+    FltF32 f32;
+    f32.hist = (unsigned long long *)flt_dyn; f32.subA = f32.hist + FLT_F32_BINS; f32.subB = (uint32_t *)(f32.subA + FLT_SUBA);
+    f32.reset();
     const int tid = threadIdx.x;
     const int64_t r = blockIdx.x;
     const float M = row_max[r];
     void *out = (char *)probs + r * V * (DT == JF_F32 ? 4 : 2);
+    // count and exact sum of the ids with key >= lo_ (and, hi_ != 0, key < hi_); HIST != 0 leaves the zeros out (they add nothing)
+    auto count_sum = [&](uint32_t lo_, uint32_t hi_, unsigned long long &c_, double &s_) {
+        if constexpr (HIST == 1) flt_hist_count_sum(sh, hist, lo_, hi_, c_, s_);
+        else if constexpr (HIST == 2) {
+            flt_f32_ge(sh, f32, out, V, lo_, c_, s_);
+            if (hi_) { unsigned long long c2; double s2_; flt_f32_ge(sh, f32, out, V, hi_, c2, s2_); c_ -= c2; s_ -= s2_; }
+        } else flt_count_sum<DT>(sh, out, V, lo_, hi_, c_, s_);
+    };
+    // the largest key `lo` (on the key grid) for which pred(count, sum of the ids >= lo) holds — pred is monotone, holds at 0 and fails at
+    // FLT_KEY_TOP.  Coarse to fine for the float32 levels (bin edges, 256-aligned keys, keys): a phase stays inside what the one before found.
+    auto bisect = [&](auto pred) -> uint32_t {
+        uint32_t lo = 0u, hi = FLT_KEY_TOP;
+        unsigned long long c_; double s_;
+#pragma unroll
+        for (int ph = (HIST == 2 ? 0 : 2); ph < 3; ++ph) {
+            const uint32_t G = HIST == 2 ? (ph == 0 ? 1u << FLT_F32_SHIFT : ph == 1 ? 0x100u : 1u) : STEP;
+            while (hi - lo > G) {
+                const uint32_t mid = (lo + (hi - lo) / 2u) & ~(G - 1u);
+                count_sum(mid, 0u, c_, s_);
+                if (pred(c_, s_)) lo = mid; else hi = mid;
+            }
+        }
+        return lo;
+    };
     rs_load_tab(sh.tab);
-    if constexpr (HIST) flt_hist_zero(hist);
+    if constexpr (HIST == 1) flt_hist_zero(hist);
+    if constexpr (HIST == 2) flt_hist64_zero(f32.hist);
     __syncthreads();
     const RsRow row = rs_make_row<DT>(logits, r, V, row_stride, t, M, 1.f);
     // ---- 1. exactly rounded probabilities of the whole row
@@ -1291,7 +1383,8 @@ __global__ __launch_bounds__(FLT_TPB) void rs_filter_kernel(const void *logits, 
 #pragma unroll
                 for (int j = 0; j < EPV; ++j) {
                     p[j] = (e0 + j < V && p[j] >= 0.f) ? p[j] : 0.f;          // (a NaN row filters to zeros)
-                    if constexpr (HIST) { if (p[j] > 0.f) atomicAdd(hist + (__float_as_uint(p[j]) >> 16), 1u); }
+                    if constexpr (HIST == 1) { if (p[j] > 0.f) atomicAdd(hist + (__float_as_uint(p[j]) >> 16), 1u); }
+                    if constexpr (HIST == 2) { if (p[j] > 0.f) flt_hist64_add(f32.hist, __float_as_uint(p[j])); }
                 }
                 if (((uintptr_t)out % 16) == 0 && e0 + EPV <= V) {
                     u32x4 o;
@@ -1311,16 +1404,11 @@ __global__ __launch_bounds__(FLT_TPB) void rs_filter_kernel(const void *logits, 
     const float floor_d = rs_round_prob<DT>(1e-12);                           // sum.clamp_min(1e-12) in the dtype
     unsigned long long cnt;
     double sum;
+    const bool want_p = top_p > 0.f && top_p < 1.f;
     // ---- 2. top-k (JDN:73-84)
     if (top_k > 0 && (int64_t)top_k < V) {
-        uint32_t lo = 0u, hi = FLT_KEY_TOP;                                   // count(key >= lo) >= k > count(key >= hi)
-        while (hi - lo > STEP) {
-            const uint32_t mid = (lo + (hi - lo) / 2u) & ~(STEP - 1u);
-            count_sum(mid, 0u, cnt, sum);
-            if (cnt >= (unsigned long long)top_k) lo = mid; else hi = mid;
-        }
-        const uint32_t thr = lo;                                              // the k-th largest value
-        FLT_STAMP(3);
+        const uint32_t thr = bisect([&](unsigned long long c_, double) { return c_ >= (unsigned long long)top_k; });      // the k-th largest value
+        FLT_STAMP(3);                                                         // (fewer than k positive ids: 0, and every zero is "kept")
         count_sum(thr + STEP, 0u, cnt, sum);              // the ids above it, and their sum
         const long long need = (long long)top_k - (long long)cnt;            // ids AT the threshold to keep (>= 1), lowest index first
         unsigned long long n_at; double s_at;
@@ -1330,15 +1418,14 @@ __global__ __launch_bounds__(FLT_TPB) void rs_filter_kernel(const void *logits, 
         float s1 = rs_round_prob<DT>(kept);
         s1 = s1 > floor_d ? s1 : floor_d;
         FLT_STAMP(4);
-        flt_renorm<DT>(out, V, thr, tie_last, s1, (top_p > 0.f && top_p < 1.f) ? hist : nullptr);
+        flt_renorm<DT, HIST>(out, V, thr, tie_last, s1, !want_p ? nullptr : HIST == 1 ? (void *)hist : HIST == 2 ? (void *)f32.hist : nullptr);
+        f32.reset();
         FLT_STAMP(5);
     }
     // ---- 3. top-p (JDN:91-107)
-    if (top_p > 0.f && top_p < 1.f) {
+    if (want_p) {
         const float tp = rs_round_prob<DT>((double)top_p);                    // `cdf <= tp`: the Python float is cast to the tensor's dtype
-        // the lowest value whose group is kept WHOLE: cumulative sum at the group's end (everything >= it), rounded, <= tp
-        uint32_t lo = 0u, hi = FLT_KEY_TOP;                                   // whole(hi) holds (nothing >= hi: 0 <= tp), whole(lo) may not
-        count_sum(STEP, 0u, cnt, sum);                    // all positive values
+        count_sum(0u, 0u, cnt, sum);                      // everything
         const bool all = rs_round_prob<DT>(sum) <= tp;
         uint32_t thr = 0u;
         int64_t tie_last = V;
@@ -1346,15 +1433,12 @@ __global__ __launch_bounds__(FLT_TPB) void rs_filter_kernel(const void *logits, 
         if (all) {                                                            // the nucleus holds every id with mass (and the zeros behind them)
             s2 = rs_round_prob<DT>(sum);
         } else {
-            lo = STEP;                                                        // whole(STEP) fails
-            while (hi - lo > STEP) {
-                const uint32_t mid = (lo + (hi - lo) / 2u) & ~(STEP - 1u);
-                count_sum(mid, 0u, cnt, sum);
-                if (rs_round_prob<DT>(sum) <= tp) hi = mid; else lo = mid;
-            }
+            // a group of equal values is kept WHOLE when the cumulative sum at its end (everything >= it), rounded, is <= tp.  The group
+            // the cut falls into is the largest value that is NOT: the largest key whose (sum of everything >= key) still exceeds tp — a
+            // present value, since the sum changes there.
+            thr = bisect([&](unsigned long long, double s_) { return !(rs_round_prob<DT>(s_) <= tp); });
             unsigned long long n_whole; double c_whole;
-            count_sum(hi, 0u, n_whole, c_whole);           // the groups kept whole
-            thr = HIST ? flt_hist_max_below(sh, hist, hi) : flt_max_below<DT>(sh, out, V, hi);                          // the group the cut falls into (a present value: whole(STEP) fails)
+            count_sum(thr + STEP, 0u, n_whole, c_whole);   // the groups kept whole
             unsigned long long n_at; double s_at;
             count_sum(thr, thr + STEP, n_at, s_at);
             const double v = (double)__uint_as_float(thr);
@@ -1367,7 +1451,7 @@ __global__ __launch_bounds__(FLT_TPB) void rs_filter_kernel(const void *logits, 
         }
         s2 = s2 > floor_d ? s2 : floor_d;
         FLT_STAMP(6);
-        flt_renorm<DT>(out, V, thr, tie_last, s2, nullptr);
+        flt_renorm<DT, HIST>(out, V, thr, tie_last, s2, nullptr);
         FLT_STAMP(7);
     }
     if (tid == 0) {
@@ -1390,15 +1474,17 @@ extern "C" int jf_rs_filter(const void *logits, int dtype, int64_t R, int64_t V,
     hipStream_t s = (hipStream_t)stream;
     // the product form of the bf16 scaling where the host proves it exact for this T (as jf_rs_probs / jf_rs_step: -T says so)
     const float tt = (dtype == JF_BF16 && t != 1.f && rs_scale_is_exact(t)) ? -t : t;
+    // value counts in dynamic LDS (beyond the default 64 KB per workgroup: opt in once); JF_RS_FILTER_HIST=0 keeps the
+    // pass-per-bisection-step variant (what rows of more than 2^18 float32 ids take)
+    static const bool hist = [] { const char *e = getenv("JF_RS_FILTER_HIST"); return !(e && e[0] == '0'); }();
     if (dtype == JF_F32) {
-        rs_filter_kernel<JF_F32, false><<<dim3((unsigned)R), dim3(FLT_TPB), 0, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
+        static const bool ok = hist && hipFuncSetAttribute((const void *)rs_filter_kernel<JF_F32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FLT_LDS_F32) == hipSuccess;
+        if (ok && V <= (1ll << 18)) rs_filter_kernel<JF_F32, 2><<<dim3((unsigned)R), dim3(FLT_TPB), FLT_LDS_F32, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
+        else rs_filter_kernel<JF_F32, 0><<<dim3((unsigned)R), dim3(FLT_TPB), 0, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
     } else {
-        // bf16: value counts in 64 KB of dynamic LDS (beyond the default 64 KB per workgroup together with the static part: opt in once);
-        // JF_RS_FILTER_HIST=0 keeps the pass-per-bisection-step variant (the float32 path's structure)
-        static const bool hist = [] { const char *e = getenv("JF_RS_FILTER_HIST"); return !(e && e[0] == '0'); }();
-        static const bool ok = hist && hipFuncSetAttribute((const void *)rs_filter_kernel<JF_BF16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FLT_BINS * 4) == hipSuccess;
-        if (ok) rs_filter_kernel<JF_BF16, true><<<dim3((unsigned)R), dim3(FLT_TPB), FLT_BINS * 4, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
-        else rs_filter_kernel<JF_BF16, false><<<dim3((unsigned)R), dim3(FLT_TPB), 0, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
+        static const bool ok = hist && hipFuncSetAttribute((const void *)rs_filter_kernel<JF_BF16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FLT_BINS * 4) == hipSuccess;
+        if (ok) rs_filter_kernel<JF_BF16, 1><<<dim3((unsigned)R), dim3(FLT_TPB), FLT_BINS * 4, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
+        else rs_filter_kernel<JF_BF16, 0><<<dim3((unsigned)R), dim3(FLT_TPB), 0, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
     }
     return check_launch("rs_filter_kernel");
 }

@@ -758,6 +758,30 @@ def test_rs_filter_at_the_real_vocabulary(dtype, V, top_k, top_p, scale):
 
 
 @GPU
+@pytest.mark.parametrize("shape", ["one_bin", "quantised", "subnormal", "beyond_the_levels"])
+@pytest.mark.parametrize("top_k,top_p", [(50, 0.0), (0, 0.9), (3000, 0.35), (0, 0.999)], ids=["k50", "p09", "k3000_p035", "p0999"])
+def test_rs_filter_float32_levels(shape, top_k, top_p):
+    """The float32 path's three levels of counters (15-bit bins with exact sums, bits 16:8 of one bin, the last 8 bits under one
+    prefix) where they are stressed: nearly uniform rows (every probability in ONE or two bins: the whole search happens in the
+    sub-tables), quantised logits (thousands of ids share each float32 value: a cut inside a group, kept by id), rows whose tail is
+    subnormal or zero, and a row of more than 2^18 ids (the pass-per-step variant).  Bit for bit against the oracle."""
+    V = {"one_bin": 152064, "quantised": 70001, "subnormal": 152064, "beyond_the_levels": (1 << 18) + 77}[shape]
+    g = torch.Generator().manual_seed(len(shape) * 1000 + top_k)
+    x = torch.randn(2, V, generator=g)
+    if shape == "one_bin":
+        x = x * 1e-3
+    elif shape == "quantised":
+        x = torch.round(x * 2) / 2
+    elif shape == "subnormal":
+        x = x * 25.0
+    else:
+        x = x * 2.0
+    got = _filter_rows(x.cuda(), 0.8, top_k, top_p)
+    want = O.target_probs(x.numpy(), 0.8, "f32", top_k or None, top_p or None)
+    assert np.array_equal(got, want), [(int((got[r] != want[r]).sum()), int((got[r] > 0).sum()), int((want[r] > 0).sum())) for r in range(2)]
+
+
+@GPU
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("top_k,top_p", [(8, 0.0), (0, 0.7), (20, 0.9)], ids=["k8", "p07", "k20_p09"])
 def test_rs_step_samples_from_the_filtered_distribution(dtype, top_k, top_p):
