@@ -16,7 +16,8 @@ from oracle.scripted_model import ScriptedModel
 from .backends import device_for, use_backend
 from .conftest import load_golden
 
-JD = load_golden("jd_cases.json") + load_golden("jd_cases_v2.json")
+FV = load_golden("fullvocab_cases.json")                 # round 5: the reference at V = 152 064
+JD = load_golden("jd_cases.json") + load_golden("jd_cases_v2.json") + FV["jd"]
 BACKENDS = [pytest.param("hostsim", id="hostsim"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
 
 
@@ -114,8 +115,10 @@ from jacobiforcing_amd.engine.jacobi_decoding_nongreedy import JacobiDecoderNonG
 # jdn_cases_v4.json: the reference with top_k / top_p planted on its SamplingParams instances (round 5); without the two records in
 # which torch's choice among EQUAL probabilities at a cut is observable (tests/test_oracle_golden.py TIE_CHOICE_OBSERVABLE)
 JDN = load_golden("jdn_cases.json") + load_golden("jdn_cases_v2.json") + load_golden("jdn_cases_v3.json") + \
-    [c for c in load_golden("jdn_cases_v4.json") if c["name"] not in ("jdn4_bf16_flat_p08", "jdn4_bf16_topp09_L32")]
-JDO = load_golden("jdo_cases.json") + load_golden("jdo_cases_v2.json") + load_golden("jdo_cases_v3.json") + load_golden("jdo_cases_v4.json")
+    [c for c in load_golden("jdn_cases_v4.json") if c["name"] not in ("jdn4_bf16_flat_p08", "jdn4_bf16_topp09_L32")] + FV["jdn"]
+# (fullvocab_cases.json holds one bf16 rollout whose draws see torch's softmax ulps: tests/test_oracle_golden.py SOFTMAX_ULP_OBSERVABLE)
+JDO = load_golden("jdo_cases.json") + load_golden("jdo_cases_v2.json") + load_golden("jdo_cases_v3.json") + load_golden("jdo_cases_v4.json") + \
+    [c for c in FV["jdo"] if c["name"] != "fv_jdo_bf16_T08_stop"]
 BMC = load_golden("bm_cases.json")
 TORCH_DTYPES = {"f32": torch.float32, "bf16": torch.bfloat16}
 

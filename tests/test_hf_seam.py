@@ -16,7 +16,8 @@ from .test_decoder_e2e import scratch_forward, tiny_model
 
 MB = load_golden("mb_cases.json")
 MB2 = load_golden("mb_cases_v2.json")
-SB = load_golden("sb_cases.json") + load_golden("sb_cases_v2.json")
+FV = load_golden("fullvocab_cases.json")                 # round 5: the reference at V = 152 064
+SB = load_golden("sb_cases.json") + load_golden("sb_cases_v2.json") + FV["sb"]
 BACKENDS = [pytest.param("hostsim", id="hostsim"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
 
 
@@ -47,7 +48,7 @@ class ScriptedBackend:
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("case", MB[:12] + MB[18:24] + MB2[:8], ids=[c["name"] for c in MB[:12] + MB[18:24] + MB2[:8]])
+@pytest.mark.parametrize("case", MB[:12] + MB[18:24] + MB2[:8] + FV["mb"], ids=[c["name"] for c in MB[:12] + MB[18:24] + MB2[:8] + FV["mb"]])
 def test_multiblock_seam_golden(case, backend):
     with use_backend(backend):
         dev = device_for(backend)

@@ -17,7 +17,8 @@ from oracle.scripted_model import ScriptedModel
 from .backends import device_for, use_backend
 from .conftest import forward_matches, kv_matches, load_golden
 
-MB = load_golden("mb_cases.json") + load_golden("mb_cases_v2.json") + load_golden("mb_cases_v3.json")
+MB = load_golden("mb_cases.json") + load_golden("mb_cases_v2.json") + load_golden("mb_cases_v3.json") + \
+    load_golden("fullvocab_cases.json")["mb"]            # round 5: the reference at V = 152 064
 MBR = load_golden("mb_raises.json")
 
 BACKENDS = [pytest.param("hostsim", id="hostsim"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]

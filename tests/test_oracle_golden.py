@@ -10,14 +10,15 @@ from oracle.scripted_model import ScriptedModel
 
 from .conftest import forward_matches, kv_matches, load_golden
 
-MB = load_golden("mb_cases.json") + load_golden("mb_cases_v2.json") + load_golden("mb_cases_v3.json")
-SB = load_golden("sb_cases.json") + load_golden("sb_cases_v2.json")
-JD = load_golden("jd_cases.json") + load_golden("jd_cases_v2.json")
-JDN = load_golden("jdn_cases.json") + load_golden("jdn_cases_v2.json") + load_golden("jdn_cases_v3.json") + load_golden("jdn_cases_v4.json")
+FV = load_golden("fullvocab_cases.json")               # round 5: every entry point at V = 152 064
+MB = load_golden("mb_cases.json") + load_golden("mb_cases_v2.json") + load_golden("mb_cases_v3.json") + FV["mb"]
+SB = load_golden("sb_cases.json") + load_golden("sb_cases_v2.json") + FV["sb"]
+JD = load_golden("jd_cases.json") + load_golden("jd_cases_v2.json") + FV["jd"]
+JDN = load_golden("jdn_cases.json") + load_golden("jdn_cases_v2.json") + load_golden("jdn_cases_v3.json") + load_golden("jdn_cases_v4.json") + FV["jdn"]
 FLT = load_golden("filter_vectors.json")
 MBR = load_golden("mb_raises.json")
 SLOTS = load_golden("slot_cases.json")
-JDO = load_golden("jdo_cases.json") + load_golden("jdo_cases_v2.json") + load_golden("jdo_cases_v3.json") + load_golden("jdo_cases_v4.json")
+JDO = load_golden("jdo_cases.json") + load_golden("jdo_cases_v2.json") + load_golden("jdo_cases_v3.json") + load_golden("jdo_cases_v4.json") + FV["jdo"]
 SMX = load_golden("softmax_vectors.json")
 
 
@@ -349,10 +350,50 @@ def check_jdo(case, seqs, records, metrics, draws, trace=None):
                [dict(draft=t["draft"], seq_lens=t["seq_lens"]) for t in case["forwards"]]
 
 
-@pytest.mark.parametrize("case", JDO, ids=[c["name"] for c in JDO])
+# A full-vocabulary bf16 rollout whose multinomial draws land among the 152 062 noise ids: torch's bf16 softmax is one bf16 ulp off
+# the exactly rounded value on < 1 % of the entries, which moves the running sum of the inverse-CDF draw by more than a noise id's
+# mass — the reference's own draw is then a NEIGHBOURING id.  Kept as evidence of where "bit for bit" ends.
+SOFTMAX_ULP_OBSERVABLE = {"fv_jdo_bf16_T08_stop"}
+
+
+@pytest.mark.parametrize("case", [c for c in JDO if c["name"] not in SOFTMAX_ULP_OBSERVABLE],
+                         ids=[c["name"] for c in JDO if c["name"] not in SOFTMAX_ULP_OBSERVABLE])
 def test_engine_onpolicy_records(case):
     seqs, records, metrics, draws, trace = run_oracle_jdo(case)
     check_jdo(case, seqs, records, metrics, draws, trace)
+
+
+def test_full_vocabulary_bf16_draws_see_torchs_softmax_ulps():
+    """Why the record in SOFTMAX_ULP_OBSERVABLE is not a parity target, shown on one row of its kind (V = 152 064, bf16, T = 0.8,
+    a planted id of logit 13 over noise in (-1, 1)): torch's bf16 softmax and the definition (exact softmax rounded once) differ by
+    exactly one bf16 ulp on ~1 % of the entries (1 364 of 152 064 here); the inverse-CDF draw the goldens inject then picks a
+    different id for most of the uniforms that land among the noise ids — a few places away — while a draw that lands on the
+    planted id is the same under both.  And the record itself: the oracle's first deviation from it is such a neighbouring id."""
+    import torch
+    V = 152064
+    m = ScriptedModel(V, 9042, 90, 8, eos_id=V - 1, reserved=(V - 2,), peak=13.0)
+    x = torch.from_numpy(m.logits_rows(m.prompt()[:-1], [[m.prompt()[-1], 5]])[0][:1]).to(torch.bfloat16)
+    p_torch = torch.softmax(x / 0.8, dim=-1)[0].float().numpy()
+    p_def = O.target_probs(x.float().numpy(), 0.8, "bf16")[0]
+    diff = np.flatnonzero(p_torch != p_def)
+    assert 0 < diff.size < V // 50
+    ulp = np.abs(O.f32_to_bf16_bits(p_torch[diff]).astype(np.int64) - O.f32_to_bf16_bits(p_def[diff]).astype(np.int64))
+    assert (ulp == 1).all()
+    g = int(np.argmax(p_def))
+    us = (np.arange(2000) + 0.5) / 2000.0
+    a = np.array([O.inverse_cdf_sample(p_torch, float(u)) for u in us])
+    b = np.array([O.inverse_cdf_sample(p_def, float(u)) for u in us])
+    moved = a != b
+    noise = (a != g) & (b != g)
+    assert 0.005 < noise.mean() < 0.1                                  # the planted id holds 0.984 of the mass: ~1.6 % of the draws land elsewhere
+    assert moved[noise].mean() > 0.5                                   # ... and MOST of those pick another id under torch's tensor (measured: 85 %)
+    assert not moved[~noise].any()                                     # a draw on the planted id is the same under both
+    assert np.abs(a[moved] - b[moved]).max() < 50                      # the other id is a few places away (measured: <= 9)
+    case = [c for c in JDO if c["name"] in SOFTMAX_ULP_OBSERVABLE][0]
+    _, records, _, _, _ = run_oracle_jdo(json.loads(json.dumps(case)))
+    got, want = records[0][0]["answer_trajectory_ids"], case["records"][0]["0"]["answer_trajectory_ids"]
+    first = next((i, j) for i, (r, w) in enumerate(zip(got, want)) for j, (x1, x2) in enumerate(zip(r, w)) if x1 != x2)
+    assert abs(got[first[0]][first[1]] - want[first[0]][first[1]]) < 50
 
 
 # ----------------------------------------------------------------------------- paged-KV slot mapping (MR:965-986, 1252-1254)
