@@ -543,6 +543,7 @@ def main():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=float(os.environ.get("JF_CPU_BASELINE_S", "20")))
     ap.add_argument("--no-scripted", action="store_true")
     ap.add_argument("--no-sections", action="store_true", help="skip the config 2 / config 5 / vs-AR sections of the line")
+    ap.add_argument("--no-other-timing", action="store_true", help="skip the short extra window that times the launch the other way (roofline.other_timing)")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the untimed pass that loads the window's library kernels")
     ap.add_argument("--robust", type=int, default=82)
     ap.add_argument("--no-tuned-gemms", action="store_true")
@@ -611,6 +612,23 @@ def main():
         r = run_steps(dec, prompts, args.warmup, args.steps, seed=1234 + info.rank, timer=tm)
         roof = tm.summary()
     agg = jd.gather_throughput(r["tokens"], r["iterations"] * 1.0, r["seconds"], dev)
+    # ---- the same launches timed the OTHER way (one more pass over the same W + K iterations, not part of value): rounds 1-3 recorded the events around the launch
+    # (launch + two event packets), round 4 on attaches them to the dispatch (the kernel's own duration, rocprofv3's figure).  Both
+    # figures go on the line so that numbers stay comparable across rounds (the library reads the variable per timed call).
+    other = None
+    if roof is not None and not args.no_other_timing:          # (every rank: the window's barriers are collective)
+        was = os.environ.get("JF_VERIFY_EVENTS")
+        os.environ["JF_VERIFY_EVENTS"] = "attach" if (was or "")[:1] == "b" else "bracket"
+        try:
+            with VerifyTimer() as tmo:
+                tmo.valid_rows = lambda: dec.last_valid_rows
+                run_steps(dec, prompts, args.warmup, args.steps, seed=1234 + info.rank, timer=tmo)      # the SAME launches
+                other = tmo.summary()
+        finally:
+            if was is None:
+                os.environ.pop("JF_VERIFY_EVENTS", None)
+            else:
+                os.environ["JF_VERIFY_EVENTS"] = was
     # ---- what every rank did, from every rank: the N-GPU line must prove N ranks on N devices by itself ------------------
     record = rank_record(info, dev_index, r, roof)
     records = jd.gather_rank_records(record)
@@ -727,6 +745,13 @@ def main():
                                "by_rank": {"frac": jd.spread((x["verify_gbs"] / HBM_PEAK_GBS) if x.get("verify_gbs") else None for x in records),
                                            "us_per_launch": jd.spread(x.get("verify_us") for x in records),
                                            "note": "min / mean / max over the ranks' own launches (achieved / frac above are rank 0's)"}}
+            if other is not None:
+                out["roofline"]["other_timing"] = {
+                    "method": ("HIP events attached to the dispatch" if os.environ.get("JF_VERIFY_EVENTS", "")[:1] == "b" else
+                               "HIP events recorded in front of and behind the launch (launch + two event packets: how rounds 1-3 timed it)"),
+                    "us_per_launch": other["avg_us"], "achieved": other["gbs"], "frac": other["gbs"] / HBM_PEAK_GBS,
+                    "launches": other["launches"],
+                    "note": "the same W + K iterations decoded once more with the launch timed the other way (not part of value / ms_per_step)"}
             out["loop_body"] = {"body_us_per_step": roof["body_us"], "gpu_idle_us_per_step": roof["idle_us"],
                                 "gpu_idle_us_median": roof["idle_us_median"], "gpu_idle_us_p95": roof["idle_us_p95"],
                                 "host_gap_us_per_step": roof["host_gap_us"], "host_gap_us_median": roof["host_gap_us_median"],

@@ -399,6 +399,9 @@ def test_bench_single_gpu_through_rccl():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["dist_backend"] == "nccl" and d["value"] > 0 and d["steps"] == 3
     _assert_rank_evidence(d, ranks=1, distinct=1)            # the record went through all_gather_object on RCCL
+    ot = d["roofline"]["other_timing"]                       # both ways of timing the launch on one line
+    assert "in front of and behind" in ot["method"] and "attached" in d["roofline"]["timing"]
+    assert ot["us_per_launch"] > 0 and ot["launches"] >= 1
 
 
 def test_forced_single_rank_group_over_gloo(tmp_path):

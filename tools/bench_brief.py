@@ -18,6 +18,9 @@ for path in sys.argv[1:]:
     print(f"{d['value']:.0f} tok/s  {d['ms_per_step']:.2f} ms/step  n_gpus {d['n_gpus']} (ranks_seen {d.get('ranks_seen')}, devices {d.get('devices_distinct')})  "
           f"verify {r.get('us_per_launch', 0):.1f} us = {r.get('frac', 0):.3f}  body {lb.get('body_us_per_step') or 0:.1f} us  "
           f"idle median {lb.get('gpu_idle_us_median') or 0:.1f} us  host gap median {lb.get('host_gap_us_median') or 0:.1f} us")
+    ot = r.get("other_timing")
+    if ot:
+        print(f"   timed the other way ({ot['method'][:44]}...): {ot['us_per_launch']:.1f} us = {ot['frac']:.3f}")
     s = d.get("scripted_acceptance")
     if s:
         sr = s.get("roofline") or {}
