@@ -1135,8 +1135,13 @@ __device__ __forceinline__ void flt_hist64_zero(unsigned long long *hist) {
     for (int b = threadIdx.x; b < FLT_F32_BINS; b += FLT_TPB) hist[b] = 0ull;
     __syncthreads();
 }
-__device__ __forceinline__ void flt_hist64_add(unsigned long long *hist, uint32_t key) {
-    atomicAdd(hist + (key >> FLT_F32_SHIFT), (1ull << 35) | (unsigned long long)(key & FLT_F32_LOW));
+__device__ __forceinline__ void flt_hist64_add(unsigned long long *hist, uint32_t key) {       // (a probability is <= 1.0: the clamp only keeps a
+    const uint32_t b = key >> FLT_F32_SHIFT;                                                     // value that cannot occur from indexing outside LDS)
+    atomicAdd(hist + (b < (uint32_t)FLT_F32_BINS ? b : (uint32_t)FLT_F32_BINS - 1u), (1ull << 35) | (unsigned long long)(key & FLT_F32_LOW));
+}
+__device__ __forceinline__ void flt_hist_add(uint32_t *hist, uint32_t key) {                    // bf16: one counter per 16-bit pattern
+    const uint32_t b = key >> 16;
+    atomicAdd(hist + (b < (uint32_t)FLT_BINS ? b : (uint32_t)FLT_BINS - 1u), 1u);
 }
 // count and exact sum of the row's positive elements with key >= `key` (every thread gets them)
 __device__ __forceinline__ void flt_f32_ge(FltShared &sh, FltF32 &f, const void *row, int64_t V, uint32_t key, unsigned long long &cnt, double &sum) {
@@ -1284,7 +1289,7 @@ __device__ __forceinline__ void flt_renorm(void *row, int64_t V, uint32_t thr, i
                     if (hist && q[j] > 0.f) {
                         const uint32_t qb = __float_as_uint(q[j]);
                         if constexpr (HM == 2) flt_hist64_add((unsigned long long *)hist, qb);
-                        else atomicAdd((uint32_t *)hist + (qb >> 16), 1u);
+                        else flt_hist_add((uint32_t *)hist, qb);
                     }
                 }
             }
@@ -1383,7 +1388,7 @@ __global__ __launch_bounds__(FLT_TPB, 4) void rs_filter_kernel(const void *logit
 #pragma unroll
                 for (int j = 0; j < EPV; ++j) {
                     p[j] = (e0 + j < V && p[j] >= 0.f) ? p[j] : 0.f;          // (a NaN row filters to zeros)
-                    if constexpr (HIST == 1) { if (p[j] > 0.f) atomicAdd(hist + (__float_as_uint(p[j]) >> 16), 1u); }
+                    if constexpr (HIST == 1) { if (p[j] > 0.f) flt_hist_add(hist, __float_as_uint(p[j])); }
                     if constexpr (HIST == 2) { if (p[j] > 0.f) flt_hist64_add(f32.hist, __float_as_uint(p[j])); }
                 }
                 if (((uintptr_t)out % 16) == 0 && e0 + EPV <= V) {
@@ -1474,16 +1479,29 @@ extern "C" int jf_rs_filter(const void *logits, int dtype, int64_t R, int64_t V,
     hipStream_t s = (hipStream_t)stream;
     // the product form of the bf16 scaling where the host proves it exact for this T (as jf_rs_probs / jf_rs_step: -T says so)
     const float tt = (dtype == JF_BF16 && t != 1.f && rs_scale_is_exact(t)) ? -t : t;
-    // value counts in dynamic LDS (beyond the default 64 KB per workgroup: opt in once); JF_RS_FILTER_HIST=0 keeps the
-    // pass-per-bisection-step variant (what rows of more than 2^18 float32 ids take)
+    // value counts in dynamic LDS (beyond the default 64 KB per workgroup: opt in once PER DEVICE — a process may drive several);
+    // JF_RS_FILTER_HIST=0 keeps the pass-per-bisection-step variant (what rows of more than 2^18 float32 ids take)
     static const bool hist = [] { const char *e = getenv("JF_RS_FILTER_HIST"); return !(e && e[0] == '0'); }();
+    static std::atomic<int> opted[64];                                      // per device: 0 not asked, 1 granted, -1 refused
+    auto lds_ok = [&](const void *fn, unsigned bytes, int slot) {
+        int dev = 0;
+        if (!hist || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return false;
+        std::atomic<int> &st = opted[dev * 2 + slot];
+        int v = st.load(std::memory_order_acquire);
+        if (v == 0) {
+            v = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 1 : -1;
+            if (v < 0) (void)hipGetLastError();
+            st.store(v, std::memory_order_release);
+        }
+        return v > 0;
+    };
     if (dtype == JF_F32) {
-        static const bool ok = hist && hipFuncSetAttribute((const void *)rs_filter_kernel<JF_F32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FLT_LDS_F32) == hipSuccess;
-        if (ok && V <= (1ll << 18)) rs_filter_kernel<JF_F32, 2><<<dim3((unsigned)R), dim3(FLT_TPB), FLT_LDS_F32, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
+        if (V <= (1ll << 18) && lds_ok((const void *)rs_filter_kernel<JF_F32, 2>, FLT_LDS_F32, 0))
+            rs_filter_kernel<JF_F32, 2><<<dim3((unsigned)R), dim3(FLT_TPB), FLT_LDS_F32, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
         else rs_filter_kernel<JF_F32, 0><<<dim3((unsigned)R), dim3(FLT_TPB), 0, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
     } else {
-        static const bool ok = hist && hipFuncSetAttribute((const void *)rs_filter_kernel<JF_BF16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FLT_BINS * 4) == hipSuccess;
-        if (ok) rs_filter_kernel<JF_BF16, 1><<<dim3((unsigned)R), dim3(FLT_TPB), FLT_BINS * 4, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
+        if (lds_ok((const void *)rs_filter_kernel<JF_BF16, 1>, FLT_BINS * 4, 1))
+            rs_filter_kernel<JF_BF16, 1><<<dim3((unsigned)R), dim3(FLT_TPB), FLT_BINS * 4, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
         else rs_filter_kernel<JF_BF16, 0><<<dim3((unsigned)R), dim3(FLT_TPB), 0, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
     }
     return check_launch("rs_filter_kernel");
