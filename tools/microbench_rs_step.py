@@ -81,6 +81,12 @@ def main():
         print("# last launch, per row: flag stored by the accept walk / segment 0 saw it / segment 0 stored / interval published by segment 0 / uniform handed out / bonus workgroup has it / bonus token stored (us)")
         for b_ in list(range(0, B, 8)) + [B - 1]:
             print(f"#   row {b_:3d}: " + "  ".join(f"{(r[k, b_] - t0) / 100.0:7.1f}" for k in (0, 1, 4, 2, 3, 5, 6)))
+        pub, hand = (r[2, :B] - t0) / 100.0, (r[3, :B] - t0) / 100.0
+        lag = hand - np.maximum.accumulate(pub)              # a row's uniform against the moment the last interval in front of it (or its own) was published
+        print(f"#   all rows: interval published {pub.min():.1f} .. {pub.max():.1f} (row {int(pub.argmax())}); uniform handed out {hand.min():.1f} .. {hand.max():.1f}; "
+              f"hand-out behind the last interval in front: mean {lag.mean():.1f}, max {lag.max():.1f} us (row {int(lag.argmax())})")
+        print("#   published: " + " ".join(f"{x:.1f}" for x in pub))
+        print("#   handed:    " + " ".join(f"{x:.1f}" for x in hand))
         if hasattr(lib, "jf_exp_rs_phases"):
             pb = (C.c_ulonglong * 16)()
             lib.jf_exp_rs_phases(pb)
