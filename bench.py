@@ -334,7 +334,7 @@ def nongreedy_section(model, cfg, weights, tuned, P: int = 64, L: int = 32, temp
     # the same decoding with top_k / top_p planted on the request object, as the reference reads them (JDN:117-118): jf_rs_filter in situ
     filtered = None
     try:
-        spf = mk(16)
+        spf = mk(max_tokens)                                 # the same budget as the unfiltered run: the two ms_per_step are comparable
         spf.top_k, spf.top_p = 50, 0.9
         with StageTimer() as stf:
             t0 = time.perf_counter()
@@ -349,7 +349,7 @@ def nongreedy_section(model, cfg, weights, tuned, P: int = 64, L: int = 32, temp
                                                            "timing": stf.timing("rs_filter"),
                                                            "kernel": "rs_filter_kernel (jf_rs_filter: exact probabilities -> top-k / top-p by bisection on an "
                                                                      "LDS count histogram of the bf16 values -> renormalised probability rows)"},
-                        note="prefill included, 16 tokens per request (ms_per_step carries 1/16 of the prefill, the unfiltered section's 1/64: compare rs_filter's microseconds, not the two ms_per_step); random-init weights: the kept sets end inside ties of equal bf16 "
+                        note="prefill included, the same prompts and token budget as the unfiltered run above (ms_per_step comparable); random-init weights: the kept sets end inside ties of equal bf16 "
                              "probabilities in most rows (ordered by token id, DESIGN.md 4)")
     except Exception as e:  # evidence for a new kernel must not cost the section
         filtered = {"error": f"{type(e).__name__}: {e}"}
