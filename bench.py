@@ -262,6 +262,58 @@ class StageTimer:
         return dict(launches=len(ev), us=sum(us) / len(us), bytes=sum(nb) / len(nb), gbs=(sum(nb) / len(nb)) / (sum(us) / len(us)) / 1e3)
 
 
+class EngineLoopTimer:
+    """HIP events and the host clock around the engine decoders' iteration body (ops.ENGINE_LOOP_HOOKS, engine/chunk_loop.py):
+    body = first launch of the verify step .. behind the commit launch; gpu_idle = behind the commit launch .. in front of the next
+    forward's first kernel (what the GPU waits for the host: record poll, numpy bookkeeping, the forward's own host code);
+    host_gap = host clock from "the iteration's record has been seen" to "the next forward is about to be queued"."""
+
+    def __init__(self):
+        self.body, self.idle, self.host_gap = [], [], []
+        self._a = self._c = self._seen = None
+
+    def __enter__(self):
+        ev = lambda: (lambda e: (e.record(), e)[1])(torch.cuda.Event(enable_timing=True))
+
+        def body_begin(lp):
+            self._a = ev()
+
+        def body_end(lp):
+            self._c = ev()
+            self.body.append((self._a, self._c))
+
+        def record_seen(lp):
+            self._seen = time.perf_counter()
+
+        def forward_begin(lp):
+            if self._seen is not None:
+                self.host_gap.append((time.perf_counter() - self._seen) * 1e6)
+                self._seen = None
+            if self._c is not None:
+                self.idle.append((self._c, ev()))
+                self._c = None
+        ops.ENGINE_LOOP_HOOKS = dict(body_begin=body_begin, body_end=body_end, record_seen=record_seen, forward_begin=forward_begin)
+        return self
+
+    def __exit__(self, *exc):
+        ops.ENGINE_LOOP_HOOKS = None
+
+    def summary(self, skip: int = 1):
+        body = [a.elapsed_time(b) * 1e3 for a, b in self.body[skip:]]
+        idle = [a.elapsed_time(b) * 1e3 for a, b in self.idle[skip:]]
+        gap = self.host_gap[skip:]
+        if not body:
+            return None
+        med = lambda v: float(sorted(v)[len(v) // 2]) if v else None
+        pct = lambda v, q: float(sorted(v)[min(len(v) - 1, int(len(v) * q))]) if v else None
+        return dict(iterations=len(body), body_us=sum(body) / len(body), body_us_median=med(body),
+                    gpu_idle_us_median=med(idle), gpu_idle_us_mean=(sum(idle) / len(idle)) if idle else None, gpu_idle_us_p95=pct(idle, 0.95),
+                    host_gap_us_median=med(gap), host_gap_us_p95=pct(gap, 0.95),
+                    note="body: HIP events in front of the verify step's first launch and behind the commit launch (jf_engine_loop_commit); "
+                         "gpu_idle: behind the commit launch to in front of the next forward's first kernel; host_gap: host clock, record "
+                         "seen -> next forward about to be queued (no request object is touched in between: engine/chunk_loop.py)")
+
+
 def roof(su, kernel, note=None):
     if su is None:
         return None
@@ -323,12 +375,13 @@ def nongreedy_section(model, cfg, weights, tuned, P: int = 64, L: int = 32, temp
     mk = lambda mt: SamplingParams(temperature=temperature, max_tokens=mt, ignore_eos=True, decode_strategy="jacobi", jacobi_block_len=L)
     llm.generate(prompts, mk(4), use_tqdm=False)                                           # untimed: loads the GEMM shapes
     torch.cuda.synchronize()
-    with StageTimer() as st:
+    with StageTimer() as st, EngineLoopTimer() as lt:
         t0 = time.perf_counter()
         res = llm.generate(prompts, mk(max_tokens), use_tqdm=False)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         probs, step = st.summary("rs_probs", skip=1), st.summary("rs_step", skip=1)
+        loop_body = lt.summary()
     toks = sum(len(r["token_ids"]) for r in res)
     its = len(st.done.get("rs_step", [])) or 1
     # the same decoding with top_k / top_p planted on the request object, as the reference reads them (JDN:117-118): jf_rs_filter in situ
@@ -375,7 +428,49 @@ def nongreedy_section(model, cfg, weights, tuned, P: int = 64, L: int = 32, temp
                          "(LLM.generate on the bench's random-init weights: acceptance ~1 token per forward)",
                 value=toks / dt, unit="tokens/s", tokens=toks, seconds=dt, iterations=its, ms_per_step=dt / its * 1e3,
                 tokens_per_forward=toks / (its * P),
-                roofline=out_roof, rs_step=out_step, filtered=filtered)
+                roofline=out_roof, rs_step=out_step, loop_body=loop_body, filtered=filtered)
+
+
+def engine_greedy_section(model, cfg, weights, tuned, P: int = 64, L: int = 32, max_tokens: int = 64):
+    """The engine's greedy single-block decoder (JacobiDecoder, JD:447-724: jf_argmax_partial + jf_engine_step + the commit launch per
+    iteration) at batch 64 x block 32 through LLM.generate on the bench's own random-init weights — the reference's
+    `inference_engine` scenario (batch decode on one GPU)."""
+    import tempfile
+    from jacobiforcing_amd import LLM, SamplingParams
+    from jacobiforcing_amd.engine.model_runner import ModelRunner
+    d = tempfile.mkdtemp()
+    (Path(d) / "config.json").write_text(json.dumps(dict(
+        vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+        num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+        num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim, max_position_embeddings=cfg.max_position_embeddings,
+        rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta, tie_word_embeddings=cfg.tie_word_embeddings,
+        eos_token_id=-1, pad_token_id=cfg.pad_token_id, model_type="qwen2")))          # (EOS handling off: see nongreedy_section)
+    ModelRunner.shared_weights = weights
+    try:
+        llm = LLM(d, tokenizer_path="none", max_model_len=2048, max_num_batched_tokens=65536, max_num_seqs=P)
+    finally:
+        ModelRunner.shared_weights = None
+    prompts = humaneval_shaped_prompts(P, seed=1234, vocab_hi=min(151643, cfg.vocab_size - 2))
+    mk = lambda mt: SamplingParams(temperature=0.0, max_tokens=mt, ignore_eos=True, decode_strategy="jacobi", jacobi_block_len=L)
+    llm.generate(prompts, mk(4), use_tqdm=False)                                           # untimed: loads the GEMM shapes
+    torch.cuda.synchronize()
+    with StageTimer() as st, EngineLoopTimer() as lt:
+        t0 = time.perf_counter()
+        res = llm.generate(prompts, mk(max_tokens), use_tqdm=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        su = st.summary("engine_verify", skip=1)
+        loop_body = lt.summary()
+    del llm
+    toks = sum(len(r["token_ids"]) for r in res)
+    its = len(st.done.get("engine_verify", [])) or 1
+    return dict(workload=f"engine greedy Jacobi (JacobiDecoder, single block), batch {P} x block {L}, bf16 logits, {max_tokens} tokens per request, "
+                         "prefill included (LLM.generate on the bench's random-init weights: acceptance ~1 token per forward)",
+                value=toks / dt, unit="tokens/s", tokens=toks, seconds=dt, iterations=its, ms_per_step=dt / its * 1e3,
+                tokens_per_forward=toks / (its * P),
+                roofline=roof(su, "jf_argmax_partial + jf_engine_step (block-local argmax over [B (L-1), V] bf16, then accept scan / EOS cap / "
+                                  "commit / next draft per row in one launch)", "HIP events recorded in front of and behind the two calls"),
+                loop_body=loop_body)
 
 
 def vs_ar_section(model, cfg, prm, tuned, vocab_hi, robust, warmup: int = 8, steps: int = 40, ar_tokens: int = 64):
@@ -778,6 +873,7 @@ def main():
         torch.cuda.empty_cache()
         for key, fn in (("single_block", lambda: single_block_section(model, cfg, tuned)),
                         ("nongreedy", lambda: nongreedy_section(model, cfg, weights, tuned)),
+                        ("engine_greedy", lambda: engine_greedy_section(model, cfg, weights, tuned)),
                         ("vs_ar", lambda: vs_ar_section(model, cfg, prm, tuned, vocab_hi, args.robust))):
             try:
                 out[key] = fn()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define JF_VERSION 500
+#define JF_VERSION 600
 
 enum {
     JF_OK = 0,
@@ -366,6 +366,50 @@ JF_API int jf_engine_step(const int64_t *draft, int B, int L, uint64_t *packed, 
                    int64_t *new_tokens /* [B, L] */, int64_t *next_draft /* [B, L] */,
                    const int64_t *pad_stream, int64_t pad_stream_len, int64_t *pad_cursor,
                    jf_engine_row *rows, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The loop around the engine steps (f3): what JD:609-710 / JDN:581-639 do on the host between two forwards of a batch —
+ * append the committed tokens to the request, advance its length, its token budget and the cached length, lay out the
+ * next forward — as ONE small launch behind jf_engine_step / jf_rs_step, on device arrays, with one record per
+ * iteration in mapped host memory (the mailbox of jf_mb_loop: jf_host_alloc / jf_mailbox_wait).  The caller keeps the
+ * draft as one [B, L] device tensor (the step's next_draft IS the next draft) and reads nothing else back.
+ *
+ *   rows / tokens   the records and the committed tokens [B, L] the step in front has written (kind 0: jf_engine_row +
+ *                   new_tokens of jf_engine_step, n = n_new; kind 1: jf_rs_row + committed of jf_rs_step, n = n_committed)
+ *   remaining [B]   in/out: -= n (the steps read it: max_tokens - accepted so far, JD:659-669)
+ *   kv_start  [B]   in/out: += n — position of the row's seed = len(seq) - 1, i.e. the cached length the next forward
+ *                   continues from (the reference trims the cache back to len(seq), BM:534-564, and re-forwards the seed, MR:1221)
+ *   positions [B,L] out: kv_start + j of the NEXT forward (MR:1221-1232)
+ *   slot [B], ring [*, ring_cap], ring_len [*]: row b appends its n tokens to ring row slot[b] (slots stay put when the
+ *                   caller compacts the batch after a request finished); a ring that is full drops the tokens and reports
+ *                   the row in the header's error word
+ *   cursors [n_cursors <= 3]: the steps' device stream cursors (pads | uniforms, bonus draws, pads), reported in the header
+ *   mailbox         JF_EL_HDR + B words: [JF_EL_SEQ] = seq (written last: poll it), [JF_EL_ERROR] = a row + 1 whose ring was full,
+ *                   [JF_EL_STEP_ERROR] = a row + 1 the step in front gave up on (its 2 s in-launch wait: rsv markers of the records),
+ *                   [JF_EL_CURSORS + 2 i ..] = cursor i (low, high word); then per row
+ *                   n | eos << 16 | active_next << 17 | (kind 0: acc_len == 1, the autoregressive fallback JD:619-631) << 18.
+ *   flags           JF_MB_LOOP_PUBLISH_FENCE: publish behind a system-scope release fence (see jf_mb_loop.flags)
+ */
+enum { JF_EL_SEQ = 0, JF_EL_ERROR = 1, JF_EL_STEP_ERROR = 2, JF_EL_CURSORS = 4, JF_EL_HDR = 16 };
+#define JF_EL_MAILBOX_INTS(B) (JF_EL_HDR + (B))
+#define JF_EL_KIND_GREEDY 0
+#define JF_EL_KIND_SAMPLING 1
+typedef struct jf_engine_loop {
+    int32_t B, L, kind, ring_cap;
+    const void *rows;
+    const int64_t *tokens;
+    int32_t *remaining;
+    int32_t *kv_start;
+    int32_t *positions;
+    const int32_t *slot;
+    int64_t *ring;
+    int32_t *ring_len;
+    const int64_t *cursors;
+    int32_t n_cursors;
+    int32_t flags;
+    int32_t *mailbox;
+} jf_engine_loop;
+JF_API int jf_engine_loop_commit(const jf_engine_loop *loop, int32_t seq, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * HF single-block step (a14): one iteration body of jacobi_forward_greedy (SB:197-273) after the forward, one launch.

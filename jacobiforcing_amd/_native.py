@@ -93,6 +93,18 @@ class SbDesc(C.Structure):
 
 
 SB_FIELDS = [f[0] for f in SbDesc._fields_]
+
+
+class EngineLoop(C.Structure):
+    """jf_engine_loop (include/jacobiforcing.h): the device arrays of the loop around jf_engine_step / jf_rs_step."""
+    _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("kind", C.c_int32), ("ring_cap", C.c_int32),
+                ("rows", C.c_void_p), ("tokens", C.c_void_p), ("remaining", C.c_void_p), ("kv_start", C.c_void_p),
+                ("positions", C.c_void_p), ("slot", C.c_void_p), ("ring", C.c_void_p), ("ring_len", C.c_void_p),
+                ("cursors", C.c_void_p), ("n_cursors", C.c_int32), ("flags", C.c_int32), ("mailbox", C.c_void_p)]
+
+
+EL_SEQ, EL_ERROR, EL_STEP_ERROR, EL_CURSORS, EL_HDR = 0, 1, 2, 4, 16
+EL_KIND_GREEDY, EL_KIND_SAMPLING = 0, 1
 OP_ROW_INTS = C.sizeof(OpRow) // 4
 OP_FIELDS = [f[0] for f in OpRow._fields_]
 
@@ -132,6 +144,7 @@ _SIGNATURES = {
     "jf_kv_commit": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, C.c_int, _i32, _i32, _i32, _i64, _i64, _i32, _vp]),
     "jf_engine_step": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "jf_sb_step": (C.c_int, [_vp, C.c_int, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
+    "jf_engine_loop_commit": (C.c_int, [C.POINTER(EngineLoop), _i32, _vp]),
     "jf_engine_fill": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "jf_rs_probs": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "jf_rs_filter": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _vp, _f32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),

@@ -170,6 +170,43 @@ extern "C" int jf_engine_step(const int64_t *draft, int B, int L, uint64_t *pack
 }
 
 // ------------------------------------------------------------------------------------------------
+// (f3) the loop around the engine steps: jf_engine_loop_commit (include/jacobiforcing.h), one workgroup behind the step
+// ------------------------------------------------------------------------------------------------
+struct BlockLanes {                                           // every lane of ONE workgroup (engine_loop_commit_body's policy)
+    __device__ __forceinline__ int lane() const { return threadIdx.x; }
+    __device__ __forceinline__ int count() const { return blockDim.x; }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+    __device__ __forceinline__ void mail(int32_t *word, int32_t v) const { DevLanes{}.mail(word, v); }   // written through (jf_common.h)
+    __device__ __forceinline__ void publish(int32_t *word, int32_t v, bool fence) const {
+        if (fence) {                                          // JF_MB_LOOP_PUBLISH_FENCE: the formal order (DevLanes::publish)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(word, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wavefront's mailed words have left ...
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // ... before the word the host polls
+    }
+};
+
+__global__ __launch_bounds__(256) void engine_loop_commit_kernel(jf_engine_loop lp, int32_t seq) {
+    jfmb::engine_loop_commit_body(BlockLanes{}, lp, seq);
+}
+
+extern "C" int jf_engine_loop_commit(const jf_engine_loop *loop, int32_t seq, void *stream) {
+    if (!loop) return fail(JF_E_INVALID, "jf_engine_loop_commit: null loop");
+    const jf_engine_loop &l = *loop;
+    if (l.B <= 0 || l.L < 2 || l.ring_cap <= 0) return fail(JF_E_INVALID, "jf_engine_loop_commit: B=%d L=%d ring_cap=%d", l.B, l.L, l.ring_cap);
+    if (l.kind != JF_EL_KIND_GREEDY && l.kind != JF_EL_KIND_SAMPLING) return fail(JF_E_INVALID, "jf_engine_loop_commit: kind=%d", l.kind);
+    if (!l.rows || !l.tokens || !l.remaining || !l.kv_start || !l.positions || !l.ring || !l.ring_len || !l.mailbox ||
+        (l.n_cursors > 0 && !l.cursors) || l.n_cursors < 0 || l.n_cursors > 3)
+        return fail(JF_E_INVALID, "jf_engine_loop_commit: null pointer / n_cursors=%d", l.n_cursors);
+    engine_loop_commit_kernel<<<1, 256, 0, (hipStream_t)stream>>>(l, seq);
+    return check_launch("engine_loop_commit_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
 // (a14) HF single-block step (SB = modeling/cllm2_qwen2_modeling_kv_terminate_on_eos_improved.py:197-273): everything
 // between two forwards of jacobi_forward_greedy in one launch, one descriptor for the host to read.
 // ------------------------------------------------------------------------------------------------

@@ -1191,6 +1191,60 @@ JF_HD EngineRowOut engine_row_body(Lanes lanes, const int64_t *d, int L, GreedyF
     return o;
 }
 
+// ---- the loop around the engine steps (jf_engine_loop_commit, include/jacobiforcing.h) ---------------------------------
+// What the reference's decoders do per row on the host after a step (JD:609-654, JDN:581-639: extend_tokens, the cached
+// length back to len(seq), the token budget) on the loop's device arrays, and the record the host polls for.  `lanes` spans
+// the whole launch (one workgroup): phase 1 one lane per row, phase 2 one lane per (row, column).
+struct EngineLoopRow { int n, eos, act, fallback, bad; };
+JF_HD EngineLoopRow engine_loop_row(const jf_engine_loop &lp, int b) {
+    EngineLoopRow o;
+    if (lp.kind == JF_EL_KIND_GREEDY) {
+        const jf_engine_row &r = ((const jf_engine_row *)lp.rows)[b];
+        o.n = r.n_new; o.eos = r.eos; o.act = r.active_next; o.fallback = r.acc_len == 1; o.bad = r.rsv[0] == JF_E_LAUNCH;
+    } else {
+        const jf_rs_row &r = ((const jf_rs_row *)lp.rows)[b];
+        o.n = r.n_committed; o.eos = r.eos; o.act = r.active_next; o.fallback = 0; o.bad = r.rsv != 0;
+    }
+    if (o.n < 0) o.n = 0;
+    if (o.n > lp.L) o.n = lp.L;
+    return o;
+}
+template <class Lanes>
+JF_HD void engine_loop_commit_body(Lanes lanes, const jf_engine_loop &lp, int32_t seq) {
+    int32_t *mb = lp.mailbox;
+    if (lanes.lane() == 0) { lanes.mail(mb + JF_EL_ERROR, 0); lanes.mail(mb + JF_EL_STEP_ERROR, 0); }
+    lanes.sync();
+    for (int b = lanes.lane(); b < lp.B; b += lanes.count()) {
+        const EngineLoopRow r = engine_loop_row(lp, b);
+        const int s = lp.slot ? lp.slot[b] : b;
+        const int have = lp.ring_len[s];
+        if (r.bad) lanes.mail(mb + JF_EL_STEP_ERROR, b + 1);                 // (any such row: the host raises)
+        if (have + r.n > lp.ring_cap) lanes.mail(mb + JF_EL_ERROR, b + 1);
+        else lp.ring_len[s] = have + r.n;
+        lp.remaining[b] -= r.n;
+        lp.kv_start[b] += r.n;
+        lanes.mail(mb + JF_EL_HDR + b, r.n | (r.eos ? 1 << 16 : 0) | (r.act ? 1 << 17 : 0) | (r.fallback ? 1 << 18 : 0));
+    }
+    lanes.sync();
+    const int64_t cells = (int64_t)lp.B * lp.L;
+    for (int64_t i = lanes.lane(); i < cells; i += lanes.count()) {
+        const int b = (int)(i / lp.L), j = (int)(i - (int64_t)b * lp.L);
+        const EngineLoopRow r = engine_loop_row(lp, b);
+        lp.positions[i] = lp.kv_start[b] + j;
+        if (j < r.n) {
+            const int s = lp.slot ? lp.slot[b] : b;
+            const int at = lp.ring_len[s] - r.n + j;                           // (a ring that was full kept its length: the store lands on
+            if (at >= 0) lp.ring[(int64_t)s * lp.ring_cap + at] = lp.tokens[i];   //  older tokens, inside the ring; the host raises on the error word)
+        }
+    }
+    for (int c = lanes.lane(); c < lp.n_cursors && c < 3; c += lanes.count()) {
+        const int64_t v = lp.cursors[c];
+        lanes.mail(mb + JF_EL_CURSORS + 2 * c, (int32_t)(uint32_t)(v & 0xFFFFFFFFll));
+        lanes.mail(mb + JF_EL_CURSORS + 2 * c + 1, (int32_t)(v >> 32));
+    }
+    lanes.publish(mb + JF_EL_SEQ, seq, (lp.flags & JF_MB_LOOP_PUBLISH_FENCE) != 0);
+}
+
 // ---- HF single-block step (SB = modeling/cllm2_qwen2_modeling_kv_terminate_on_eos_improved.py:197-273) -------------
 // Everything between two forwards of jacobi_forward_greedy for one call; greedy[i] = decode(packed[i]) verifies out[i+1].
 template <class Lanes>

@@ -1,8 +1,8 @@
 """Engine single-block greedy Jacobi decoder — same constructor, callbacks, return values and ``stats`` as the
 reference's ``JacobiDecoder`` (inference_engine/engine/jacobi_decoding.py:47-724 = "JD"), with the per-iteration body
 (argmax, accept scan, EOS cap, commit, AR fallback, next draft incl. random pads) in one HIP launch
-(``jf_argmax_partial`` + ``jf_engine_step``) and one read-back per iteration instead of JD's per-row ``.item()`` /
-``.tolist()`` syncs.
+(``jf_argmax_partial`` + ``jf_engine_step``), the loop around it on device arrays (``jf_engine_loop_commit``:
+engine/chunk_loop.py) and one polled record per iteration instead of JD's per-row ``.item()`` / ``.tolist()`` syncs.
 
 Callback contract (JD:30-44, MR:1134-1418): ``forward_step_batch(seqs, draft[B, L]) -> logits[B, L-1, V]`` where
 ``draft[:, 0]`` is the already-cached last token ("seed"); the callback sets ``seq.draft_tokens_gpu`` and
@@ -17,8 +17,10 @@ import numpy as np
 import torch
 from torch import Tensor
 
+from .. import _native as N
 from .. import ops
 from .block_manager import BlockManager
+from .chunk_loop import ChunkLoopMixin
 from .sequence import Sequence
 
 LogitsForwardFn = Callable[[Sequence, Tensor], Tensor]
@@ -27,16 +29,22 @@ LogitsForwardFnBatch = Callable[[List[Sequence], Tensor], Tensor]
 _PAD_STREAM_LEN = 1 << 16
 
 
-class JacobiDecoder:
+class JacobiDecoder(ChunkLoopMixin):
+    KIND = N.EL_KIND_GREEDY
+
     def __init__(self, block_manager: BlockManager, forward_step: Optional[LogitsForwardFn] = None,
                  forward_step_batch: Optional[LogitsForwardFnBatch] = None, eos_token_id: Optional[int] = None,
                  pad_token_id: Optional[int] = None, vocab_size: Optional[int] = None,
-                 device: Optional[torch.device] = None) -> None:
-        if forward_step is None and forward_step_batch is None:
+                 device: Optional[torch.device] = None, forward_step_loop=None) -> None:
+        """``forward_step_loop`` (new, optional): ``f(loop: ops.EngineLoop) -> logits [B, L-1, V]`` — a forward that takes the
+        draft, the positions and the cached lengths from the loop's DEVICE arrays instead of request objects; with it the
+        decoder touches no request object between the first and the last iteration of a chunk (engine/chunk_loop.py)."""
+        if forward_step is None and forward_step_batch is None and forward_step_loop is None:
             raise ValueError("Provide at least one of forward_step or forward_step_batch.")          # JD:78-79
         self.block_manager = block_manager
         self.forward_step = forward_step
         self.forward_step_batch = forward_step_batch
+        self.forward_step_loop = forward_step_loop
         self.eos_token_id = eos_token_id
         self.pad_token_id = pad_token_id
         if vocab_size is None:
@@ -49,7 +57,8 @@ class JacobiDecoder:
         self.stats = {"num_chunk_calls": 0, "num_jacobi_iterations": 0, "tokens_accepted": 0, "tokens_per_call": [],
                       "tokens_per_iteration": [], "iterations_per_call": []}                        # JD:101-108
         self._pad_stream_host: Optional[np.ndarray] = None
-        self._pad_cursor = 0
+        self._pad_cursor = 0                 # host mirror of the stepper's device cursor (the iteration record refreshes it)
+        self._cursor_dirty = True
         self._stepper: Optional[ops.EngineStepper] = None
 
     # ----------------------------------------------------------------------------------- random pads
@@ -58,6 +67,7 @@ class JacobiDecoder:
         is consumed in exactly that order).  By default one is drawn from torch's generator on first use."""
         self._pad_stream_host = np.asarray(stream, dtype=np.int64).copy()
         self._pad_cursor = 0
+        self._cursor_dirty = True
         self._stepper = None
 
     def _ensure(self, B: int, L: int) -> ops.EngineStepper:
@@ -65,10 +75,9 @@ class JacobiDecoder:
             self._pad_stream_host = torch.randint(0, self.vocab_size, (_PAD_STREAM_LEN,)).numpy().astype(np.int64)
         st = self._stepper
         if st is None or st.max_rows < B or st.max_L < L:
-            cur = self._pad_cursor
             st = ops.EngineStepper(max(B, 8 if st is None else st.max_rows), max(L, 64 if st is None else st.max_L),
                                    self.device, torch.from_numpy(self._pad_stream_host))
-            st.pad_cursor.fill_(cur)
+            self._cursor_dirty = True
             self._stepper = st
         return st
 
@@ -76,6 +85,7 @@ class JacobiDecoder:
         s = self._pad_stream_host
         idx = (self._pad_cursor + np.arange(count)) % len(s)
         self._pad_cursor += count
+        self._cursor_dirty = True
         return s[idx].tolist()
 
     # ----------------------------------------------------------------------------------- config helpers
@@ -143,96 +153,46 @@ class JacobiDecoder:
 
     # ----------------------------------------------------------------------------------- core loop (JD:302-724)
     def _run(self, seqs: List[Sequence], single: bool) -> List[List[int]]:
-        B = len(seqs)
-        accepted: List[List[int]] = [[] for _ in range(B)]
-        q_draft: List[Optional[Tensor]] = [None] * B
-        eos_reached = [False] * B
-        iters = [0] * B
-        cfg = [self._get_sampling_cfg(s) for s in seqs]
-        block_lens, max_iters = [c[0] for c in cfg], [c[1] for c in cfg]
-        max_tokens = []
-        for seq in seqs:
-            sp = getattr(seq, "sampling_params", None)
-            if sp is not None:
-                rem = getattr(sp, "max_tokens", 2048) - seq.num_completion_tokens
-                max_tokens.append(rem if single else max(0, rem))
-            else:
-                max_tokens.append(2048)
-        if single and block_lens[0] <= 1:
+        if single and self._get_sampling_cfg(seqs[0])[0] <= 1:
             return [[]]                                                                        # JD:313-314
-        n_iter_call = 0
-        prev_len = [0] * B
-        dev = self.device
-        prof = getattr(self, "profiler", None)        # ModelRunner's PROFILE=1 section timer (reference names, MR:116-134)
-        tick = (lambda name, on: (prof.start(name) if on else prof.stop(name))) if prof is not None else (lambda name, on: None)
-        while True:
-            active = [i for i in range(B) if not eos_reached[i] and len(accepted[i]) < max_tokens[i] and iters[i] < max_iters[i]]
-            if not active:
-                break
-            groups = {}
-            for i in active:
-                if block_lens[i] > 1:
-                    groups.setdefault(block_lens[i], []).append(i)
-            if not groups:
-                break
-            n_iter_call += 1
-            tokens_this_iter = 0
-            for L, idxs in sorted(groups.items(), key=lambda x: len(x[1]), reverse=True):       # JD:513
-                rows_t = []
-                for i in idxs:
-                    iters[i] += 1
-                    if q_draft[i] is None:
-                        q_draft[i] = torch.tensor(self._first_draft(seqs[i], L), dtype=torch.int64, device=dev)
-                    rows_t.append(q_draft[i])
-                    seqs[i].draft_tokens = None
-                draft_batch = torch.stack(rows_t, 0)
-                sub = [seqs[i] for i in idxs]
-                if single:
-                    sub[0].draft_tokens = draft_batch[0].tolist()                              # JD:351
-                logits = self._forward_batched(sub, draft_batch)
-                tick("jacobi.verify", True)
-                st = self._ensure(len(idxs), L)
-                st.pad_cursor.fill_(self._pad_cursor)
-                rows, new_tokens, next_draft = st.step(draft_batch, logits, self.eos_token_id,
-                                                       [max_tokens[i] - len(accepted[i]) for i in idxs])
-                tick("jacobi.verify", False)
-                tick("jacobi.commit", True)
-                for row, i in enumerate(idxs):
-                    seq = sub[row]
-                    acc_len, n_new, eos, active_next, n_pads = (int(x) for x in rows[row][:5])
-                    toks = [int(t) for t in new_tokens[row, :n_new]]
-                    if acc_len > 1:                                                            # JD:609-614
-                        seq.extend_tokens(toks)
-                        if self.block_manager is not None:
-                            self.block_manager.may_append_batch(seq, acc_len - 1)
-                        num_spec = acc_len - 1
-                    else:                                                                      # JD:619-631
-                        seq.append_token(toks[0])
-                        if self.block_manager is not None:
-                            self.block_manager.may_append(seq)
-                        num_spec = 1
-                    accepted[i].extend(toks)
-                    if eos:
-                        eos_reached[i] = True
-                    tokens_this_iter += len(accepted[i]) - prev_len[i]
-                    prev_len[i] = len(accepted[i])
-                    trim = L - 1 - num_spec                                                    # JD:638-646
-                    if trim > 0 and self.block_manager is not None:
-                        self.block_manager.trim_kv_only_fast(seq, trim)
-                    seq.clear_draft()
-                    if len(seq) != seq.num_cached_tokens:                                       # JD:651-654
-                        raise RuntimeError(f"Invariant violated: len(token_ids)={len(seq)} != num_cached_tokens={seq.num_cached_tokens}")
-                    self._pad_cursor += n_pads
-                    q_draft[i] = next_draft[row].clone() if active_next else None
-                tick("jacobi.commit", False)
-                if prof is not None:
-                    prof.iterations += 1; prof.tokens += tokens_this_iter
-            if not single:
-                self.stats["tokens_per_iteration"].append(tokens_this_iter)
+        accepted, iters, _forwards, n_iter_call = self._run_chunk(seqs, single)
         total = sum(len(a) for a in accepted)
         self.stats["num_chunk_calls"] += 1
-        self.stats["num_jacobi_iterations"] += iters[0] if single else n_iter_call
+        self.stats["num_jacobi_iterations"] += int(iters[0]) if single else n_iter_call
         self.stats["tokens_accepted"] += total
         self.stats["tokens_per_call"].append(total)
-        self.stats["iterations_per_call"].append(iters[0] if single else n_iter_call)
+        self.stats["iterations_per_call"].append(int(iters[0]) if single else n_iter_call)
         return accepted
+
+    # ---- chunk-loop hooks (engine/chunk_loop.py): the iteration body is jf_argmax_partial + jf_engine_step + the commit launch
+    def _push_cursors(self, st: ops.EngineStepper) -> None:
+        if self._cursor_dirty:                               # the host drew pads for a first draft (or the stepper is new)
+            st.pad_cursor.fill_(self._pad_cursor)
+            self._cursor_dirty = False
+
+    def _enqueue_step(self, st: ops.EngineStepper, lp: ops.EngineLoop, logits: Tensor, ctx) -> Tensor:
+        st.step_loop(lp, logits, self.eos_token_id)
+        return st.new_tokens.view(-1)[:lp.B * lp.L].view(lp.B, lp.L)
+
+    def _pull_cursors(self, lp: ops.EngineLoop) -> None:
+        self._pad_cursor = lp.cursors_host[0]
+
+    def _commit_row(self, seq: Sequence, toks: List[int], fallback: bool, L: int) -> None:
+        """What JD:609-654 does to one request after a step, for callers whose callbacks read the request objects."""
+        bm = self.block_manager
+        if not fallback:                                                                       # JD:609-614
+            seq.extend_tokens(toks)
+            if bm is not None:
+                bm.may_append_batch(seq, len(toks))
+            num_spec = len(toks)
+        else:                                                                                  # JD:619-631
+            seq.append_token(toks[0])
+            if bm is not None:
+                bm.may_append(seq)
+            num_spec = 1
+        trim = L - 1 - num_spec                                                                # JD:638-646
+        if trim > 0 and bm is not None:
+            bm.trim_kv_only_fast(seq, trim)
+        seq.clear_draft()
+        if len(seq) != seq.num_cached_tokens:                                                   # JD:651-654
+            raise RuntimeError(f"Invariant violated: len(token_ids)={len(seq)} != num_cached_tokens={seq.num_cached_tokens}")

@@ -15,6 +15,7 @@ import time
 from pathlib import Path
 from typing import List, Optional
 
+import numpy as np
 import torch
 
 from .. import _native, ops
@@ -59,6 +60,74 @@ class ProfileTimer:
         if fwd and self.tokens:
             lines.append(f"overhead vs forward-only: {100 * (1 - fwd / tot):.1f}%  TPF={self.tokens / max(self.iterations, 1):.2f}")
         return "\n".join(lines)
+
+
+class LoopForward:
+    """``forward_step_loop`` of the engine decoders (engine/chunk_loop.py): MR:1134-1418 for a batch whose draft, positions and
+    cached lengths are the DEVICE arrays of an ``ops.EngineLoop`` — block tables grow from the loop's host mirror of the lengths
+    (one numpy comparison per iteration; a request is touched only in the iteration it crosses into a new block), the forward
+    reads ``loop.draft`` / ``loop.positions`` / ``loop.kv_start`` where the commit launch left them.  No seed read-back, no
+    per-sequence index tensors, no request object touched between the first and the last iteration of a chunk."""
+
+    def __init__(self, runner: "ModelRunner"):
+        self.r = runner
+
+    def _state(self, lp):
+        r = self.r
+        st = getattr(lp, "_mr", None)
+        if st is None:
+            st = lp._mr = dict(version=-1, bt_len=np.asarray([len(s.block_table) for s in lp.seqs], dtype=np.int64),
+                               perm=np.asarray([s.num_permanent_spec_blocks for s in lp.seqs], dtype=np.int64))
+        if st["version"] != lp.version:
+            rows = [r._row(lp.seqs[s]) for s in lp.members.tolist()]
+            B, dev = len(rows), r.device
+            st.update(version=lp.version, rp=torch.tensor(rows, dtype=torch.int32, device=dev),
+                      row_len=torch.full((B,), lp.L, dtype=torch.int32, device=dev),
+                      row_cand=torch.full((B,), -1, dtype=torch.int32, device=dev), in_place=rows == list(range(B)))
+        return st
+
+    @torch.inference_mode()
+    def __call__(self, lp) -> torch.Tensor:
+        r = self.r
+        B, L, bs = lp.B, lp.L, r.block_size
+        st = self._state(lp)
+        prof = r.profiler
+        prof.start("jacobi.block_alloc")
+        m = lp.members
+        S = lp.seq_len_h[m]
+        s_max = int(S.max())
+        if s_max + L - 1 > r.config.max_model_len:
+            raise RuntimeError(f"Sequence needs {s_max + L - 1} positions but max_model_len={r.config.max_model_len}")
+        need = (S + L - 1 + bs - 1) // bs                                                      # MR:1166-1199
+        committed = (S + bs - 1) // bs
+        cur = st["bt_len"][m]
+        if (need != cur).any():
+            bm = r.block_manager
+            for k in np.flatnonzero(need != cur).tolist():
+                seq = lp.seqs[int(m[k])]
+                r._fit_block_table(seq, int(need[k]), bm)
+                st["bt_len"][m[k]] = len(seq.block_table)
+        st["perm"][m] = np.maximum(st["perm"][m], need - committed)
+        prof.stop("jacobi.block_alloc")
+        prof.start("jacobi.forward")
+        logits = r.model.forward(lp.draft, lp.positions, r.kv_cache, row_prompt=st["rp"], row_cand=st["row_cand"], row_len=st["row_len"],
+                                 kv_len_rows=lp.kv_start, any_candidates=False, s_cur=s_max - 1 + L, logit_index=r._logit_index(B, L),
+                                 rows_in_place=st["in_place"])                                  # seed re-forwarded at S-1
+        prof.stop("jacobi.forward")
+        return logits.view(B, L - 1, logits.shape[-1])
+
+    def finish(self, lp) -> None:
+        """Once per chunk, after the decoder has appended the committed tokens: the counters MR / BM keep per request."""
+        st = getattr(lp, "_mr", None)
+        if st is None:
+            return
+        bm, bs = self.r.block_manager, self.r.block_size
+        for slot, seq in enumerate(lp.seqs):
+            seq.num_permanent_spec_blocks = max(seq.num_permanent_spec_blocks, int(st["perm"][slot]))
+            if bm is not None:                                    # BM:534-564 with the cache already at len(seq): surplus blocks go back
+                keep = -(-len(seq) // bs) + seq.num_permanent_spec_blocks
+                while len(seq.block_table) > keep:
+                    bm._give_back(seq.block_table.pop())
 
 
 class ModelRunner:
@@ -200,33 +269,40 @@ class ModelRunner:
                 raise RuntimeError(f"Sequence needs {S + L - 1} positions but max_model_len={self.config.max_model_len}")
             need = (S + L - 1 + self.block_size - 1) // self.block_size
             committed = (S + self.block_size - 1) // self.block_size
-            cur = len(seq.block_table)
-            if cur > need:
-                seq.block_table = seq.block_table[:need]
-                seq.block_table_version += 1
-            elif bm is not None:
-                for _ in range(need - cur):
-                    if not bm.can_append(seq) or not bm.free_block_ids:
-                        raise RuntimeError("Cannot allocate blocks for draft tokens")
-                    bid = bm.free_block_ids[0]
-                    bm._allocate_block_no_clear(bid)
-                    seq.block_table.append(bid)
-                    seq.block_table_version += 1
+            self._fit_block_table(seq, need, bm)
             seq.num_permanent_spec_blocks = max(seq.num_permanent_spec_blocks, need - committed)
         prof.stop("jacobi.block_alloc")
         prof.start("jacobi.forward")
-        # lm_head on the L-1 positions per row that verify a speculative token (the reference computes all L and slices,
-        # MR:1413-1416; slicing afterwards would make the verify kernels' [B*(L-1), V] view a 600 MB copy at batch 64)
+        logits = self._forward_rows(seqs, draft_tokens_batch, [len(s) - 1 for s in seqs], [L] * B, logit_index=self._logit_index(B, L))   # seed re-forwarded at S-1
+        prof.stop("jacobi.forward")
+        for seq in seqs:
+            seq.num_cached_tokens = (len(seq) - 1) + L                                         # MR:1407-1408
+        return logits.view(B, L - 1, logits.shape[-1])
+
+    def _fit_block_table(self, seq: Sequence, need: int, bm) -> None:
+        """MR:1166-1199 for one request: its block table holds exactly the blocks S + L - 1 positions need."""
+        cur = len(seq.block_table)
+        if cur > need:
+            seq.block_table = seq.block_table[:need]
+            seq.block_table_version += 1
+        elif bm is not None:
+            for _ in range(need - cur):
+                if not bm.can_append(seq) or not bm.free_block_ids:
+                    raise RuntimeError("Cannot allocate blocks for draft tokens")
+                bid = bm.free_block_ids[0]
+                bm._allocate_block_no_clear(bid)
+                seq.block_table.append(bid)
+                seq.block_table_version += 1
+
+    def _logit_index(self, B: int, L: int) -> torch.Tensor:
+        """lm_head on the L-1 positions per row that verify a speculative token (the reference computes all L and slices,
+        MR:1413-1416; slicing afterwards would make the verify kernels' [B*(L-1), V] view a 600 MB copy at batch 64)."""
         key = (B, L)
         idx = self._logit_idx.get(key)
         if idx is None:
             idx = self._logit_idx[key] = (torch.arange(B, dtype=torch.int32, device=self.device).view(B, 1) * L +
                                           torch.arange(L - 1, dtype=torch.int32, device=self.device).view(1, L - 1)).reshape(-1)
-        logits = self._forward_rows(seqs, draft_tokens_batch, [len(s) - 1 for s in seqs], [L] * B, logit_index=idx)   # seed re-forwarded at S-1
-        prof.stop("jacobi.forward")
-        for seq in seqs:
-            seq.num_cached_tokens = (len(seq) - 1) + L                                         # MR:1407-1408
-        return logits.view(B, L - 1, logits.shape[-1])
+        return idx
 
     def _jacobi_forward_step(self, seq: Sequence, draft_tokens: torch.Tensor) -> torch.Tensor:
         return self._jacobi_forward_step_batch([seq], draft_tokens)
@@ -252,7 +328,9 @@ class ModelRunner:
             self.jacobi_decoder = want(block_manager=self.block_manager, forward_step=self._jacobi_forward_step,
                                        forward_step_batch=self._jacobi_forward_step_batch, eos_token_id=self.config.eos,
                                        pad_token_id=self.config.pad, vocab_size=self.config.hf_config.vocab_size,
-                                       device=self.device)
+                                       device=self.device,
+                                       # JF_ENGINE_LOOP=0: the callbacks above per iteration (the reference's contract) instead
+                                       forward_step_loop=LoopForward(self) if os.environ.get("JF_ENGINE_LOOP", "1") != "0" else None)
         self.jacobi_decoder.profiler = self.profiler
 
     # ------------------------------------------------------------------------------------------ multiblock (new)
@@ -311,6 +389,19 @@ class ModelRunner:
                 toks.append(int(ops.argmax_rows(logits[i:i + 1])[0]))
             else:                                               # Gumbel-max sampling like layers/sampler.py:10-24
                 p = torch.softmax(logits[i:i + 1].float() / t, dim=-1)
+                # top_k / top_p planted on the request (the Jacobi decoders read them the same way, JDN:117-118): the same target
+                # distribution for the autoregressive baseline, so that the two decoders can be compared sample for sample
+                k, tp = ops.active_filters(getattr(seqs[i], "sampling_params", None), p.shape[-1])
+                if k:
+                    v, idx = torch.topk(p, k, dim=-1)
+                    p = torch.zeros_like(p).scatter_(-1, idx, v)
+                    p = p / p.sum(dim=-1, keepdim=True).clamp_min(1e-12)
+                if tp:
+                    sp, si = torch.sort(p, dim=-1, descending=True)
+                    keep = torch.cumsum(sp, dim=-1) <= tp
+                    keep[..., 0] = True                         # at least the most likely token
+                    sp = sp * keep
+                    p = torch.zeros_like(p).scatter_(-1, si, sp / sp.sum(dim=-1, keepdim=True).clamp_min(1e-12))
                 toks.append(int(torch.argmax(p / torch.empty_like(p).exponential_(1).clamp_min_(1e-10), dim=-1)[0]))
         return toks
 

@@ -24,6 +24,9 @@ VERIFY_EVENTS = None    # bench.py: callable -> (begin, end) torch.cuda.Event pa
 STAGE_HOOK = None       # bench.py: f(name, phase, nbytes) with phase "begin"/"end" around jf_rs_probs / jf_rs_step / jf_argmax+jf_sb_step;
                         # jf_rs_probs / jf_rs_step first ask f(name, "arm", nbytes): a (begin, end) pair of torch events (recorded once
                         # before, so their handles exist) is attached to the call's own dispatches (jf_timing_arm) and no "begin"/"end" follows
+ENGINE_LOOP_HOOKS = None  # bench.py: {"body_begin", "body_end", "record_seen", "forward_begin"}: f(loop) around the engine decoders' iteration
+                        # body (engine/chunk_loop.py) — events in front of the step and behind the commit launch, the host clock when the
+                        # record has been seen, an event in front of the next forward's first kernel
 LOOP_HOOKS = None       # bench.py: {"pack_end": f(batch), "forward_begin": f(batch)} — events behind the queued pack launch and in
                         # front of the next forward's first kernel (GPU idle time between the loop body and the forward);
                         # "mailbox_seen": f(batch) the moment the host's poll returns (host clock: control time to the next forward)
@@ -693,6 +696,146 @@ class EngineStepper:
             N.check(N.JF_E_LAUNCH, "jf_engine_step (a row never published its hand-off word: launch incomplete)")
         return self.rows_host[:B].numpy(), th.numpy(), nd
 
+    def step_loop(self, loop: "EngineLoop", logits: torch.Tensor, eos_id: Optional[int]) -> None:
+        """The step on ``loop.draft`` with the loop's device arrays (budgets in place, the next draft into the loop's other
+        buffer) and the commit launch behind it.  Nothing is read back: ``loop.wait()`` polls for the iteration's record."""
+        B, L = loop.B, loop.L
+        if logits.ndim != 3 or logits.size(0) != B or logits.size(1) != L - 1:                 # JD:244-248
+            raise ValueError(f"forward must return logits [B, L-1, vocab] for verifying speculative tokens, "
+                             f"expected [{B}, {L - 1}, *], got {tuple(logits.shape)}")
+        if B > self.max_rows or L > self.max_L:
+            raise RuntimeError("EngineStepper capacity exceeded")
+        flat = logits.reshape(B * (L - 1), logits.shape[-1])
+        done = _stage("engine_verify", flat.shape[0] * flat.shape[1] * flat.element_size())
+        argmax_partial(flat, self.packed)
+        nt = self.new_tokens.view(-1)[:B * L].view(B, L)
+        N.check(N.lib().jf_engine_step(_ptr(loop.draft), B, L, _ptr(self.packed), -1 if eos_id is None else int(eos_id),
+                                       _ptr(loop.remaining), _ptr(nt), _ptr(loop.next_buffer()), _ptr(self.pad_stream),
+                                       self.pad_stream.numel(), _ptr(self.pad_cursor), _ptr(self.rows_dev),
+                                       _stream(self.device)), "jf_engine_step")
+        done()
+        loop.commit(self.rows_dev, nt, self.pad_cursor)
+
+
+# --------------------------------------------------------------------------------------------
+# the loop around the engine steps (jf_engine_loop_commit; SURVEY 8 f3)
+# --------------------------------------------------------------------------------------------
+class EngineLoop:
+    """One block-length group of an engine decoder's chunk on the device: the draft as ONE [B, L] tensor that the step's next
+    draft replaces (two buffers, alternating), the rows' token budgets, cached lengths, next positions and committed-token
+    rings as arrays the commit launch maintains, and one record per iteration in mapped host memory (n, eos, active per row +
+    the stream cursors) that the host polls for — no per-row read-back, no stream synchronisation.  When a request leaves the
+    group (``compact``) the arrays are gathered once; ring rows stay where they are (``slot``)."""
+
+    def __init__(self, kind: int, L: int, device, seq_lens: Sequence[int], remaining: Sequence[int], wait_timeout_s: float = 30.0):
+        dev = torch.device(device)
+        self.kind, self.L, self.device = int(kind), int(L), dev
+        n = self.n = len(seq_lens)
+        self.members = np.arange(n, dtype=np.int64)            # ring slot (= row of the group as it started) of each current row
+        self.cap = int(max(max(remaining), 0)) + self.L          # a row commits < remaining + L tokens (the last step may overshoot, JD E3)
+        i32 = lambda a: torch.tensor(np.asarray(a, dtype=np.int32)).to(dev)
+        self.kv_start = i32(np.asarray(seq_lens) - 1)
+        self.remaining = i32(remaining)
+        self.positions = (self.kv_start.view(n, 1) + torch.arange(self.L, dtype=torch.int32, device=dev).view(1, self.L)).contiguous()
+        self.slot = torch.arange(n, dtype=torch.int32, device=dev)
+        self.ring = torch.zeros((n, self.cap), dtype=torch.int64, device=dev)
+        self.ring_len = torch.zeros((n,), dtype=torch.int32, device=dev)
+        self._buf = [torch.empty((n * self.L,), dtype=torch.int64, device=dev) for _ in range(2)]
+        self._cur = -1                                         # which buffer holds ``draft`` (-1: neither)
+        self.draft: Optional[torch.Tensor] = None
+        lib = N.lib()
+        self.n_ints = N.EL_HDR + n
+        ptr = C.c_void_p()
+        N.check(lib.jf_host_alloc(self.n_ints * 4, C.byref(ptr)), "jf_host_alloc")
+        self._mb_ptr = ptr
+        self.mailbox = np.ctypeslib.as_array((C.c_int32 * self.n_ints).from_address(ptr.value))
+        self._wait = lib.jf_mailbox_wait
+        self.seq = 0
+        self.timeout_us = int(wait_timeout_s * 1e6)
+        self.flags = MultiblockLoop.publish_flags(dev)
+        self.version = 0                                       # bumped by compact(): callers cache per-batch tensors against it
+        self._c: Optional[N.EngineLoop] = None
+        self.cursors_host = [0, 0, 0]
+
+    @property
+    def B(self) -> int:
+        return int(self.members.size)
+
+    def close(self) -> None:
+        if self._mb_ptr is not None:
+            if self.device.type == "cuda":                     # a queued commit may still be mailing
+                torch.cuda.synchronize(self.device)
+            self.mailbox = None
+            N.lib().jf_host_free(self._mb_ptr)
+            self._mb_ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_draft(self, draft: torch.Tensor) -> None:
+        self.draft = draft.to(device=self.device, dtype=torch.int64).contiguous()
+        self._cur = -1
+
+    def next_buffer(self) -> torch.Tensor:
+        """Where the step writes the next draft [B, L]; ``advance`` makes it the draft."""
+        k = 1 - self._cur if self._cur >= 0 else 0
+        self._nxt = k
+        return self._buf[k][:self.B * self.L].view(self.B, self.L)
+
+    def commit(self, rows_dev: torch.Tensor, tokens: torch.Tensor, cursors: Optional[torch.Tensor]) -> None:
+        """Queue jf_engine_loop_commit behind the step that wrote ``rows_dev`` / ``tokens`` (and the next draft into
+        ``next_buffer()``, which becomes ``draft``)."""
+        c = self._c
+        if c is None or c.rows != rows_dev.data_ptr() or c.tokens != tokens.data_ptr():
+            c = self._c = N.EngineLoop(
+                B=self.B, L=self.L, kind=self.kind, ring_cap=self.cap, rows=rows_dev.data_ptr(), tokens=tokens.data_ptr(),
+                remaining=self.remaining.data_ptr(), kv_start=self.kv_start.data_ptr(), positions=self.positions.data_ptr(),
+                slot=self.slot.data_ptr(), ring=self.ring.data_ptr(), ring_len=self.ring_len.data_ptr(),
+                cursors=None if cursors is None else cursors.data_ptr(), n_cursors=0 if cursors is None else int(cursors.numel()),
+                flags=int(self.flags), mailbox=self._mb_ptr.value)
+        self.seq += 1
+        N.check(N.lib().jf_engine_loop_commit(C.byref(c), self.seq, _stream(self.device)), "jf_engine_loop_commit")
+        self.draft = self._buf[self._nxt][:self.B * self.L].view(self.B, self.L)
+        self._cur = self._nxt
+
+    def wait(self):
+        """Poll for the record of the last commit: (n, eos, active_next, fallback) int arrays [B]; ``cursors_host`` is refreshed."""
+        rc = self._wait(self._mb_ptr, self.seq, self.timeout_us, _stream(self.device))
+        if rc:
+            N.check(rc, "jf_mailbox_wait")
+        m = self.mailbox
+        hdr = m[:N.EL_HDR].tolist()
+        if hdr[N.EL_STEP_ERROR]:
+            N.check(N.JF_E_LAUNCH, f"engine step (row {hdr[N.EL_STEP_ERROR] - 1}: a workgroup of the step waited 2 s for another: launch incomplete)")
+        if hdr[N.EL_ERROR]:
+            raise RuntimeError(f"engine loop: the committed-token ring of row {hdr[N.EL_ERROR] - 1} is full (capacity {self.cap})")
+        cu = self.cursors_host
+        for i in range(3):
+            cu[i] = (hdr[N.EL_CURSORS + 2 * i] & 0xFFFFFFFF) | (hdr[N.EL_CURSORS + 2 * i + 1] << 32)
+        w = m[N.EL_HDR:N.EL_HDR + self.B].copy()
+        return w & 0xFFFF, (w >> 16) & 1, (w >> 17) & 1, (w >> 18) & 1
+
+    def compact(self, keep_rows: np.ndarray) -> None:
+        """Keep the rows ``keep_rows`` (positions in the current batch, ascending) — once, when a request has left the group."""
+        idx = torch.from_numpy(np.asarray(keep_rows, dtype=np.int64)).to(self.device)
+        self.members = self.members[keep_rows]
+        self.kv_start = self.kv_start[idx].contiguous()
+        self.remaining = self.remaining[idx].contiguous()
+        self.positions = self.positions[idx].contiguous()
+        self.slot = self.slot[idx].contiguous()
+        self.draft = self.draft[idx].contiguous()
+        self._cur = -1
+        self._c = None
+        self.version += 1
+
+    def tokens_host(self):
+        """(ring [n, cap] int64, ring_len [n]) on the host: every token the rows have committed, by slot."""
+        rl = self.ring_len.cpu().numpy()
+        return self.ring.cpu().numpy(), rl
+
 
 # --------------------------------------------------------------------------------------------
 # HF single-block step (SB:197-273)
@@ -837,10 +980,7 @@ class RsStepper:
         self.cursors = torch.zeros((3,), dtype=torch.int64, device=dev)          # uniforms, bonus, pads
         self.remaining = torch.zeros((self.max_rows,), dtype=torch.int32, device=dev)
 
-    def step(self, draft: torch.Tensor, logits: torch.Tensor, temperature: float, eos_id: Optional[int],
-             remaining: Sequence[int], cursors: Sequence[int], top_k: int = 0, top_p: float = 0.0):
-        """``top_k`` / ``top_p`` (``active_filters``): when one is active the rows go through jf_rs_filter — the filtered,
-        renormalised distribution as a probability tensor in the logits' dtype (JDN:72-123) — and jf_rs_step samples from that."""
+    def _check(self, draft: torch.Tensor, logits: torch.Tensor) -> Tuple[int, int]:
         B, L = draft.shape
         if L < 2:
             raise ValueError("Draft must have at least 2 tokens (seed + 1 speculative)")
@@ -848,8 +988,13 @@ class RsStepper:
             raise ValueError(f"forward must return logits [B, L-1, vocab], expected [{B}, {L - 1}, *], got {tuple(logits.shape)}")
         if B > self.max_rows or L > self.max_L:
             raise RuntimeError("RsStepper capacity exceeded")
+        return int(B), int(L)
+
+    def _enqueue(self, draft: torch.Tensor, logits: torch.Tensor, temperature: float, eos_id: Optional[int], remaining: torch.Tensor,
+                 next_draft: torch.Tensor, top_k: int, top_p: float) -> torch.Tensor:
+        """jf_rs_probs [+ jf_rs_filter] + jf_rs_step on draft [B, L] / logits [B, L-1, V]; returns the committed-token view."""
+        B, L = draft.shape
         dev = self.device
-        draft = draft.to(device=dev, dtype=torch.int64).contiguous()
         V = logits.shape[-1]
         flat = logits.reshape(B * (L - 1), V)
         if flat.stride(1) != 1:
@@ -873,22 +1018,32 @@ class RsStepper:
                                      int(top_k), float(top_p), _ptr(src), _ptr(self.p_draft), _ptr(self.row_max),
                                      _ptr(self.row_sumexp), _stream(dev)), "jf_rs_filter")
             done()
-        self.remaining[:B].copy_(torch.tensor(list(remaining), dtype=torch.int32), non_blocking=True)
-        self.cursors.copy_(torch.tensor(list(cursors), dtype=torch.int64), non_blocking=True)
         cm = self.committed.view(-1)[:B * L].view(B, L)
-        nd = self.next_draft.view(-1)[:B * L].view(B, L)
         cur = self.cursors
         c_ptr = lambda i: C.c_void_p(cur.data_ptr() + 8 * i)
         done = _stage("rs_step", B * V * flat.element_size())               # <= one rejected row per draft row
         N.check(lib.jf_rs_step(_ptr(src), _dtype_code(src), V, src.stride(0), _ptr(draft), B, L, _ptr(self.p_draft),
                                _ptr(self.row_max), _ptr(self.row_sumexp), _ptr(self.packed), float(temperature),
-                               -1 if eos_id is None else int(eos_id), _ptr(self.remaining),
+                               -1 if eos_id is None else int(eos_id), _ptr(remaining),
                                _ptr(self.u_stream), self.u_stream.numel(), c_ptr(0),
                                _ptr(self.bonus_stream), self.bonus_stream.numel(), c_ptr(1),
                                _ptr(self.pad_stream), self.pad_stream.numel(), c_ptr(2),
-                               _ptr(cm), _ptr(nd), _ptr(self.rows_dev), _ptr(self.step_ws), self.step_ws.numel() * 8,
+                               _ptr(cm), _ptr(next_draft), _ptr(self.rows_dev), _ptr(self.step_ws), self.step_ws.numel() * 8,
                                _stream(dev)), "jf_rs_step")
         done()
+        return cm
+
+    def step(self, draft: torch.Tensor, logits: torch.Tensor, temperature: float, eos_id: Optional[int],
+             remaining: Sequence[int], cursors: Sequence[int], top_k: int = 0, top_p: float = 0.0):
+        """``top_k`` / ``top_p`` (``active_filters``): when one is active the rows go through jf_rs_filter — the filtered,
+        renormalised distribution as a probability tensor in the logits' dtype (JDN:72-123) — and jf_rs_step samples from that."""
+        B, L = self._check(draft, logits)
+        dev = self.device
+        draft = draft.to(device=dev, dtype=torch.int64).contiguous()
+        self.remaining[:B].copy_(torch.tensor(list(remaining), dtype=torch.int32), non_blocking=True)
+        self.cursors.copy_(torch.tensor(list(cursors), dtype=torch.int64), non_blocking=True)
+        nd = self.next_draft.view(-1)[:B * L].view(B, L)
+        cm = self._enqueue(draft, logits, temperature, eos_id, self.remaining, nd, top_k, top_p)
         self.rows_host[:B].copy_(self.rows_dev[:B], non_blocking=True)
         th = self.tok_host.view(-1)[:B * L].view(B, L)
         th.copy_(cm, non_blocking=True)
@@ -899,6 +1054,14 @@ class RsStepper:
             self.rows_dev[0, N.RS_FIELDS.index("rsv")] = 0
             N.check(N.JF_E_LAUNCH, "jf_rs_step (a workgroup of the one-launch step waited 2 s for another: launch incomplete)")
         return rows, th.numpy(), nd
+
+    def step_loop(self, loop: "EngineLoop", logits: torch.Tensor, temperature: float, eos_id: Optional[int], top_k: int = 0,
+                  top_p: float = 0.0) -> None:
+        """The step on ``loop.draft`` with the loop's device arrays and the commit launch behind it; nothing is read back
+        (``loop.wait()``).  The stream cursors stay on the device (``self.cursors``; the record reports them)."""
+        self._check(loop.draft, logits)
+        cm = self._enqueue(loop.draft, logits, temperature, eos_id, loop.remaining, loop.next_buffer(), top_k, top_p)
+        loop.commit(self.rows_dev, cm, self.cursors)
 
 
 # --------------------------------------------------------------------------------------------

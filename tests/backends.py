@@ -62,6 +62,7 @@ class HostSimLib:
             "hs_mb_read_ret": (C.c_int, [vp, i64, C.c_int, vp, i32]),
             "hs_engine_step": (C.c_int, [vp, C.c_int, C.c_int, vp, i32, vp, vp, vp, vp, i64, vp, vp]),
             "hs_sb_step": (C.c_int, [vp, C.c_int, vp, i32, i32, i32, vp, i32, vp]),
+            "hs_engine_loop_commit": (C.c_int, [C.POINTER(N.EngineLoop), i32]),
             "hs_mb_loop_begin": (C.c_int, [C.POINTER(N.MbLoop), i32, P, vp, vp]),
             "hs_mb_loop_step": (C.c_int, [C.POINTER(N.MbLoop), i32, P, i32, i32, C.c_int]),
             "hs_mb_loop_pack": (C.c_int, [C.POINTER(N.MbLoop), i32, P]),
@@ -150,6 +151,9 @@ class HostSimLib:
 
     def jf_sb_step(self, *a):
         return self.hs.hs_sb_step(*a[:-1])
+
+    def jf_engine_loop_commit(self, loop, seq, stream):
+        return self.hs.hs_engine_loop_commit(loop, seq)
 
     def jf_engine_fill(self, draft, B, L, seq_len, block_tables, max_cols, block_size, input_ids, positions, slot_mapping,
                        cu_q, cu_k, cache_seqlens, err, stream):

@@ -3,7 +3,9 @@
 
 Run (build container only — /root/reference does not exist on the GPU box):
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py            # rewrites all 22 files, byte for byte
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py --check    # regenerates into a temporary directory and compares
+    (--full-vocabulary / --skip-full-vocabulary: only / everything but fullvocab_cases.json; --out DIR: write there)
 
 What it does
 ------------
@@ -48,7 +50,8 @@ sys.path.insert(0, str(REF))
 
 from oracle.scripted_model import ScriptedModel, mix32  # noqa: E402
 
-OUT_DIR = Path(__file__).resolve().parent
+GOLDEN_DIR = Path(__file__).resolve().parent
+OUT_DIR = GOLDEN_DIR
 
 # --------------------------------------------------------------------------------------
 # shims + imports of the reference
@@ -791,6 +794,10 @@ def run_full_vocabulary_cases():
     real width (earlier files stop at V = 2 000; at this width an id needs 18 bits, a row is many chunks of the argmax stream,
     the softmax sum runs over 152 064 terms and the bf16 image of the noise collides everywhere).  The fixtures stay small: the
     scripted model regenerates the logits from its descriptor."""
+    import itertools
+    # the non-greedy records keep the reference's request ids (``seq_ids``), which come from a process-global counter of its
+    # Sequence class: restart it here, so that this file does not depend on what ran before it in the process
+    Sequence.counter = itertools.count()
     V = FULL_V
     mbs = [
         run_mb_case("fv_mb_baseline_knobs", vocab=V, seed=9001, robust=70, prompt_len=24, n=32, K=2, r=0.85, pool=4, max_calls=3),
@@ -833,9 +840,40 @@ def run_full_vocabulary_cases():
     return dict(mb=mbs, sb=sbs, jd=jds, jdn=jdns, jdo=jdos)
 
 
+def check() -> int:
+    """Regenerate every fixture into a temporary directory and compare it with the committed file, byte for byte."""
+    import tempfile
+    global OUT_DIR
+    with tempfile.TemporaryDirectory() as d:
+        OUT_DIR = Path(d)
+        with contextlib.redirect_stdout(io.StringIO()):
+            generate([a for a in sys.argv[1:] if a in ("--full-vocabulary", "--skip-full-vocabulary")])
+        made = sorted(p.name for p in OUT_DIR.glob("*.json"))
+        want = sorted(p.name for p in GOLDEN_DIR.glob("*.json"))
+        if "--full-vocabulary" in sys.argv:
+            want = ["fullvocab_cases.json"]
+        elif "--skip-full-vocabulary" in sys.argv:
+            want = [w for w in want if w != "fullvocab_cases.json"]
+        bad = [n for n in want if n not in made or (OUT_DIR / n).read_bytes() != (GOLDEN_DIR / n).read_bytes()]
+        extra = [n for n in made if n not in want]
+    print(f"gen_golden --check: {len(want) - len(bad)} of {len(want)} fixture files regenerate byte-identical from {REF}"
+          + (f"; DIFFERENT: {bad}" if bad else "") + (f"; not committed: {extra}" if extra else ""))
+    return 1 if bad or extra else 0
+
+
 def main():
+    if "--out" in sys.argv:
+        global OUT_DIR
+        OUT_DIR = Path(sys.argv[sys.argv.index("--out") + 1])
+        OUT_DIR.mkdir(parents=True, exist_ok=True)
+    if "--check" in sys.argv:
+        sys.exit(check())
+    generate(sys.argv[1:])
+
+
+def generate(argv):
     torch.manual_seed(0)
-    if "--full-vocabulary" in sys.argv:          # only that file (the others take ~50 s)
+    if "--full-vocabulary" in argv:              # only that file (the others take ~50 s)
         with open(OUT_DIR / "fullvocab_cases.json", "w") as f:
             json.dump(run_full_vocabulary_cases(), f, separators=(",", ":"))
         print("wrote", OUT_DIR / "fullvocab_cases.json", (OUT_DIR / "fullvocab_cases.json").stat().st_size // 1024, "KiB")
@@ -1139,7 +1177,8 @@ def main():
     dump("kernel_vectors.json", kv)
     dump("slot_cases.json", slots)
     dump("bm_cases.json", bms)
-    dump("fullvocab_cases.json", run_full_vocabulary_cases())
+    if "--skip-full-vocabulary" not in argv:
+        dump("fullvocab_cases.json", run_full_vocabulary_cases())
     # quick human summary
     for c in mbs + mbs3:
         fw = [f for cl in c["calls"] for f in cl["forwards"]]

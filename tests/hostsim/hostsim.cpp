@@ -85,6 +85,12 @@ int hs_sb_step(int64_t *out, int L, uint64_t *packed, int32_t eos_id, int32_t to
     return 0;
 }
 
+// the loop around the engine steps, same contract as jf_engine_loop_commit
+int hs_engine_loop_commit(const jf_engine_loop *lp, int32_t seq) {
+    jfmb::engine_loop_commit_body(HostLanes{}, *lp, seq);
+    return 0;
+}
+
 // engine step for a batch of rows, same contract as jf_engine_step
 int hs_engine_step(const int64_t *draft, int B, int L, uint64_t *packed, int32_t eos_id, const int32_t *remaining,
                    int64_t *new_tokens, int64_t *next_draft, const int64_t *pad_stream, int64_t pad_len,

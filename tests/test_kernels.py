@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(raw, name)
     raw.jf_version.restype = ctypes.c_int
-    assert raw.jf_version() == int(re.search(r"#define JF_VERSION (\d+)", hdr).group(1)) == 500
+    assert raw.jf_version() == int(re.search(r"#define JF_VERSION (\d+)", hdr).group(1)) == 600
 
 
 def test_docs_state_the_headers_entry_point_count_and_version():
@@ -64,7 +64,7 @@ def test_plain_c_client(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(ROOT / "tests" / "abi" / "abi_client.c"),
                            f"-L{lib.parent}", "-ljacobiforcing", f"-Wl,-rpath,{lib.parent}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
     out = subprocess.check_output([str(exe)], text=True)
-    assert "version=500" in out and "desc=64" in out and "params=40" in out
+    assert "version=600" in out and "desc=64" in out and "params=40" in out
     assert "rc=-1" in out and "null pointer" in out
 
 
@@ -75,13 +75,17 @@ def test_python_constants_are_the_headers(tmp_path):
              "JF_DRV_HDR_INTS", "JF_DRV_ACTIVE", "JF_DRV_STOP", "JF_DRV_CALLS", "JF_DRV_ITERS", "JF_DRV_NEW", "JF_DRV_BUDGET",
              "JF_DRV_MAX_CALLS", "JF_DRV_TEXT_LEN", "JF_DRV_CURSOR", "JF_DRV_FIN_RET_LEN", "JF_DRV_FIN_NEXT", "JF_DRV_FIN_ITERS",
              "JF_DRV_FIN_OFF", "JF_STOP_NONE", "JF_STOP_EOS", "JF_STOP_MAX_NEW_TOKENS", "JF_STOP_MAX_CALLS", "JF_STOP_MAX_SEQ_LEN",
-             "JF_STOP_TEXT_FULL", "JF_MB_INACTIVE", "JF_MB_KEEP", "JF_E_INVALID", "JF_E_CAPACITY", "JF_E_LAUNCH", "JF_E_SHAPE"]
+             "JF_STOP_TEXT_FULL", "JF_MB_INACTIVE", "JF_MB_KEEP", "JF_E_INVALID", "JF_E_CAPACITY", "JF_E_LAUNCH", "JF_E_SHAPE",
+             "JF_EL_SEQ", "JF_EL_ERROR", "JF_EL_STEP_ERROR", "JF_EL_CURSORS", "JF_EL_HDR", "JF_EL_KIND_GREEDY", "JF_EL_KIND_SAMPLING",
+             "JF_MB_LOOP_PUBLISH_FENCE"]
     src = tmp_path / "consts.c"
     src.write_text('#include <stdio.h>\n#include "jacobiforcing.h"\nint main(void) {\n' +
                    "".join(f'  printf("{n} %lld\\n", (long long)({n}));\n' for n in names) +
                    '  printf("MAILBOX_INTS_7 %lld\\n", (long long)JF_MB_MAILBOX_INTS(7));\n'
                    '  printf("PACKED_ENTRIES_100 %lld\\n", (long long)JF_MB_PACKED_ENTRIES(100));\n'
-                   '  printf("LOOP_BYTES %lld\\n", (long long)sizeof(jf_mb_loop));\n  return 0;\n}\n')
+                   '  printf("LOOP_BYTES %lld\\n", (long long)sizeof(jf_mb_loop));\n'
+                   '  printf("ENGINE_LOOP_BYTES %lld\\n", (long long)sizeof(jf_engine_loop));\n'
+                   '  printf("EL_MAILBOX_INTS_7 %lld\\n", (long long)JF_EL_MAILBOX_INTS(7));\n  return 0;\n}\n')
     exe = tmp_path / "consts"
     subprocess.check_call(["gcc", "-std=c99", f"-I{ROOT / 'include'}", str(src), "-o", str(exe)])
     c = {k: int(v) for k, v in (line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())}
@@ -95,6 +99,10 @@ def test_python_constants_are_the_headers(tmp_path):
     assert sorted(c[k] for k in c if k.startswith("JF_STOP_")) == sorted(N.STOP_REASONS)
     assert (c["JF_MB_INACTIVE"], c["JF_MB_KEEP"]) == (N.JF_MB_INACTIVE, N.JF_MB_KEEP)
     assert c["LOOP_BYTES"] == ctypes.sizeof(N.MbLoop)
+    assert c["ENGINE_LOOP_BYTES"] == ctypes.sizeof(N.EngineLoop) and c["EL_MAILBOX_INTS_7"] == N.EL_HDR + 7
+    assert [c["JF_EL_" + k] for k in ("SEQ", "ERROR", "STEP_ERROR", "CURSORS", "HDR", "KIND_GREEDY", "KIND_SAMPLING")] == \
+        [N.EL_SEQ, N.EL_ERROR, N.EL_STEP_ERROR, N.EL_CURSORS, N.EL_HDR, N.EL_KIND_GREEDY, N.EL_KIND_SAMPLING]
+    assert c["JF_MB_LOOP_PUBLISH_FENCE"] == N.MB_LOOP_PUBLISH_FENCE
 
 
 def _c_case_file(case, path):
@@ -1001,3 +1009,76 @@ def test_convergence_launch_keeps_its_register_budget():
         assert vgprs <= 96 and scratch == 0, (name, vgprs, scratch)
         seen += 1
     assert seen == 8
+
+
+# ------------------------------------------------------------------------------------- the loop around the engine steps (f3)
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("kind", [N.EL_KIND_GREEDY, N.EL_KIND_SAMPLING], ids=["greedy_rows", "sampling_rows"])
+@pytest.mark.parametrize("B,L", [(1, 2), (7, 5), (64, 32), (300, 9)])
+def test_engine_loop_commit_maintains_the_device_arrays(B, L, kind, backend):
+    """jf_engine_loop_commit against its definition in numpy, several iterations on the same loop (rings fill up, budgets and
+    cached lengths move, positions follow), then once more after a compaction (rings stay in their slots): the arrays on the
+    device, the record in the mailbox (n | eos | active | fallback per row, the stream cursors) and the sequence word."""
+    with use_backend(backend):
+        dev = device_for(backend)
+        g = np.random.default_rng(B * 100 + L + kind)
+        seq_lens = g.integers(1, 500, size=B)
+        remaining = g.integers(1, 3 * L, size=B)
+        lp = ops.EngineLoop(kind, L, dev, seq_lens.tolist(), remaining.tolist())
+        ints = N.ENGINE_ROW_INTS if kind == N.EL_KIND_GREEDY else N.RS_ROW_INTS
+        rows_dev = torch.zeros((B, ints), dtype=torch.int32, device=dev)
+        toks_dev = torch.zeros((B, L), dtype=torch.int64, device=dev)
+        cursors = torch.zeros((1 if kind == N.EL_KIND_GREEDY else 3,), dtype=torch.int64, device=dev)
+        kv, rem = seq_lens - 1, remaining.copy()
+        ring = [[] for _ in range(B)]
+        members = np.arange(B)
+        lp.set_draft(torch.zeros((B, L), dtype=torch.int64))
+        for it in range(4):
+            b = members.size
+            if it == 3 and b > 1:                                   # a request left: the batch is compacted, ring rows stay put
+                keep = np.flatnonzero(g.random(b) < 0.6)
+                keep = keep if keep.size else np.array([0])
+                lp.compact(keep)
+                members, kv, rem = members[keep], kv[keep], rem[keep]
+                b = members.size
+                rows_dev, toks_dev = rows_dev[:b].clone(), toks_dev[:b].clone()
+            room = np.array([lp.cap - len(ring[s]) for s in members])
+            n = np.minimum(g.integers(1, L + 1, size=b), room)      # (a full ring is an error path of its own, below)
+            eos, act = g.integers(0, 2, size=b), g.integers(0, 2, size=b)
+            acc = np.where(g.random(b) < 0.3, 1, n + 1)
+            rec = np.zeros((b, ints), dtype=np.int32)
+            if kind == N.EL_KIND_GREEDY:
+                n = np.where(acc == 1, np.minimum(1, room), n)
+                rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3] = acc, n, eos, act
+            else:
+                rec[:, 0], rec[:, 1], rec[:, 6] = n, eos, act
+            toks = g.integers(0, 152064, size=(b, L))
+            rows_dev[:b].copy_(torch.from_numpy(rec))
+            toks_dev[:b].copy_(torch.from_numpy(toks))
+            cur = g.integers(0, 1 << 40, size=cursors.numel())
+            cursors.copy_(torch.from_numpy(cur))
+            lp.next_buffer()
+            lp.commit(rows_dev, toks_dev, cursors)
+            gn, ge, ga, gf = lp.wait()
+            assert gn.tolist() == n.tolist() and ge.tolist() == eos.tolist() and ga.tolist() == act.tolist()
+            assert gf.tolist() == ((acc == 1).astype(int).tolist() if kind == N.EL_KIND_GREEDY else [0] * b)
+            assert lp.cursors_host[:cursors.numel()] == cur.tolist()
+            kv, rem = kv + n, rem - n
+            for r, s in enumerate(members):
+                ring[s] += toks[r, :n[r]].tolist()
+            assert lp.kv_start.cpu().tolist() == kv.tolist() and lp.remaining.cpu().tolist() == rem.tolist()
+            assert lp.positions.cpu().tolist() == (kv[:, None] + np.arange(L)[None, :]).tolist()
+            rg, rl = lp.tokens_host()
+            assert rl.tolist() == [len(x) for x in ring]
+            assert all(rg[s, :len(ring[s])].tolist() == ring[s] for s in range(B))
+        # a ring without room for the row's tokens: reported, nothing written past the ring
+        rec = np.zeros((members.size, ints), dtype=np.int32)
+        rec[:, 1 if kind == N.EL_KIND_GREEDY else 0] = L
+        rec[:, 0] = L + 1 if kind == N.EL_KIND_GREEDY else L
+        rows_dev[:members.size].copy_(torch.from_numpy(rec))
+        with pytest.raises(RuntimeError, match="ring"):
+            for _ in range(lp.cap // L + 2):
+                lp.next_buffer()
+                lp.commit(rows_dev, toks_dev, cursors)
+                lp.wait()
+        lp.close()

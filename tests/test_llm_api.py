@@ -3,6 +3,7 @@
 (inference_engine/tests/test_jacobi_decoding_greedy.py:180-206): greedy Jacobi output == greedy AR output."""
 import dataclasses
 import json
+import random
 
 import pytest
 import torch
@@ -282,3 +283,130 @@ def test_preempted_request_gives_its_cache_row_back():
         assert n_pre[0] >= 1, "the pool was meant to force a preemption"
         assert got == want
         assert sorted(llm.model_runner.free_rows) == list(range(llm.model_runner.max_rows))
+
+
+# ----------------------------------------------------------------------------- the device-resident chunk loop
+def _engine_state(llm, seqs_log):
+    bm = llm.scheduler.block_manager
+    return dict(free=list(bm.free_block_ids), used=sorted(bm.used_block_ids), seqs=seqs_log)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("temperature", [0.0, 0.8], ids=["greedy", "T08"])
+def test_chunk_loop_on_device_arrays_equals_the_callback_contract(tmp_path, backend, temperature, monkeypatch):
+    """The engine decoders with ModelRunner's ``forward_step_loop`` (draft / positions / cached lengths read from the loop's
+    device arrays, request objects brought up to date once per chunk) against the same decoders driven through the reference's
+    callback contract (``forward_step_batch(seqs, draft)``, request objects current before every forward: JF_ENGINE_LOOP=0):
+    tokens, stats, every request's counters and block table, and the block pool, request by request — with an EOS id the
+    random model emits (requests leave the batch at different iterations: the arrays are compacted), mixed budgets, two block
+    lengths in one batch and a prompt that crosses a KV-block boundary mid-chunk."""
+    from collections import Counter
+    import numpy as np
+    from jacobiforcing_amd.engine import llm_engine
+    monkeypatch.setenv("JF_INIT_STD", "0.3")
+    monkeypatch.setenv("JF_DTYPE", "float32")
+    base = dict(vocab_size=320, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=2, max_position_embeddings=1024, rms_norm_eps=1e-6, rope_theta=10000.0,
+                tie_word_embeddings=False, eos_token_id=319, pad_token_id=318, model_type="qwen2")
+    rng = np.random.default_rng(5)
+    prompts = [[int(x) for x in rng.integers(0, 300, size=int(rng.integers(2, 40)))] for _ in range(9)]
+    prompts[3] = [int(x) for x in rng.integers(0, 300, size=250)]            # 250 + 6 + tokens: crosses position 256 while decoding
+    budgets = [int(rng.integers(3, 40)) for _ in prompts]
+    budgets[3] = 30
+    blocks = [6 if i % 3 else 4 for i in range(len(prompts))]
+    kw = dict(tokenizer_path="none", max_model_len=512, max_num_batched_tokens=2048, max_num_seqs=16)
+    d0 = tmp_path / "a"; d0.mkdir(); (d0 / "config.json").write_text(json.dumps(base))
+
+    def run(model_dir, loop_on):
+        monkeypatch.setenv("JF_ENGINE_LOOP", "1" if loop_on else "0")
+        torch.manual_seed(7)
+        random.seed(7)                                         # (the prefill draft is random.choice of the prompt, MR:797)
+        llm = LLM(str(model_dir), device=dev, **kw)
+        log = []
+        orig = llm.scheduler.postprocess_jacobi
+
+        def spy(seqs, toks):                                   # the request objects as the engine sees them after every chunk
+            for s, t in zip(seqs, toks):
+                log.append((len(log), list(s.token_ids), s.num_cached_tokens, list(s.block_table), s.num_permanent_spec_blocks, list(t)))
+            return orig(seqs, toks)
+        llm.scheduler.postprocess_jacobi = spy
+        sps = [SamplingParams(temperature=temperature, max_tokens=b, decode_strategy="jacobi", jacobi_block_len=L)
+               for b, L in zip(budgets, blocks)]
+        out = llm.generate(prompts, sps, use_tqdm=False)
+        dec = llm.model_runner.jacobi_decoder
+        assert (dec.forward_step_loop is not None) == loop_on
+        return out, dict(dec.stats), _engine_state(llm, log)
+
+    with use_backend(backend):
+        dev = device_for(backend)
+        free, _, _ = run(d0, False)
+        eos = Counter(t for o in free for t in o["token_ids"][2:]).most_common(1)[0][0]
+        d1 = tmp_path / "b"; d1.mkdir(); (d1 / "config.json").write_text(json.dumps(dict(base, eos_token_id=int(eos))))
+        want = run(d1, False)
+        got = run(d1, True)
+    assert any(o["token_ids"] and o["token_ids"][-1] == eos and len(o["token_ids"]) < b for o, b in zip(want[0], budgets))
+    assert any(len(e[3]) == 2 for e in want[2]["seqs"])             # a block table grew inside a chunk
+    assert got[0] == want[0]
+    assert got[1] == want[1]
+    assert got[2] == want[2]
+
+
+# ----------------------------------------------------------------------------- the reference's own acceptance test, in its own shape
+def _per_position_js(a, b, V):
+    """Mean over positions of the Jensen-Shannon divergence (natural log) between the empirical token distributions of two sample
+    sets (lists of token-id lists) at that position — compute_token_distributions + compare_distributions(metric="js") of
+    inference_engine/tests/test_jacobi_decoding_nongreedy.py:204-320."""
+    import numpy as np
+    T = min(min(len(x) for x in a), min(len(x) for x in b))
+    out = []
+    for t in range(T):
+        p = np.bincount([x[t] for x in a], minlength=V).astype(np.float64)
+        q = np.bincount([x[t] for x in b], minlength=V).astype(np.float64)
+        p, q = p / p.sum(), q / q.sum()
+        m = 0.5 * (p + q)
+        kl = lambda u, w: float(np.sum(np.where(u > 0, u * np.log(np.where(u > 0, u, 1.0) / np.where(w > 0, w, 1.0)), 0.0)))
+        out.append(0.5 * kl(p, m) + 0.5 * kl(q, m))
+    return float(np.mean(out)), out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("filters", [None, (50, 0.9)], ids=["plain", "top_k50_top_p09"])
+def test_nongreedy_jacobi_matches_autoregressive_sampling_per_position(tmp_path, filters, monkeypatch):
+    """The reference's acceptance test of the non-greedy decoder (test_jacobi_decoding_nongreedy.py:324-435): sample the same
+    prompt N times with the autoregressive sampler and N times with decode_strategy="jacobi" at the same temperature, compare
+    the empirical token distributions position by position (Jensen-Shannon), pass when the mean is below a threshold (0.1
+    there; 0.05 here, and not above twice what two autoregressive sample sets differ by, i.e. the sampling noise of N draws).
+    Through LLM.generate on the GPU, V = 1 024, 16 positions, N = 512, T = 0.8, with and without top_k = 50 / top_p = 0.9
+    planted on the requests (both samplers read them, JDN:117-118)."""
+    monkeypatch.setenv("JF_INIT_STD", "0.35")               # a random model whose next-token distributions are peaked (entropy ~1-2 nats)
+    monkeypatch.setenv("JF_MAX_ROWS", "256")
+    V, N, T, L, POS = 1024, 512, 0.8, 8, 16
+    cfg = dict(vocab_size=V, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+               num_key_value_heads=2, max_position_embeddings=1024, rms_norm_eps=1e-6, rope_theta=10000.0,
+               tie_word_embeddings=False, eos_token_id=-1, pad_token_id=V - 2, model_type="qwen2")
+    (tmp_path / "config.json").write_text(json.dumps(cfg))
+    with use_backend("hip"):
+        torch.manual_seed(1234)
+        llm = LLM(str(tmp_path), tokenizer_path="none", device="cuda", max_model_len=256, max_num_batched_tokens=65536, max_num_seqs=256)
+        prompt = [5, 9, 200, 31, 7, 640, 77, 3]
+
+        def sample(strategy, n):
+            out = []
+            for _ in range(n // 256):
+                sp = SamplingParams(temperature=T, max_tokens=POS, ignore_eos=True, decode_strategy=strategy, jacobi_block_len=L)
+                if filters:
+                    sp.top_k, sp.top_p = filters
+                out += [o["token_ids"][:POS] for o in llm.generate([prompt] * 256, sp, use_tqdm=False)]
+            return out
+        ar1, ar2, jac = sample("autoregressive", N), sample("autoregressive", N), sample("jacobi", N)
+        stats = dict(llm.model_runner.jacobi_decoder.stats)
+    noise, _ = _per_position_js(ar1, ar2, V)
+    js, per_pos = _per_position_js(ar1, jac, V)
+    js2, _ = _per_position_js(ar2, jac, V)
+    distinct = len({tuple(x) for x in jac})
+    print(f"per-position JS: AR vs AR {noise:.4f}, AR vs Jacobi {js:.4f} / {js2:.4f}; distinct Jacobi samples {distinct} of {N}; "
+          f"tokens per iteration {stats['tokens_accepted'] / max(stats['num_jacobi_iterations'], 1) / 256:.2f}")
+    assert all(len(x) == POS for x in jac)
+    assert distinct > N // 4                                   # a real distribution, not a degenerate one
+    assert js < 0.05 and js2 < 0.05, (js, js2, noise, per_pos)
+    assert max(js, js2) < 2.0 * noise + 0.005, (js, js2, noise)

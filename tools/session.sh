@@ -47,6 +47,16 @@ ranks8)               # what eight ranks do to one host: the real model, 8 promp
 dist_tests)           # the N > 1 line's evidence fields on the GPU box
     timeout 2400 $PYT tests/test_bench_and_dist.py -m gpu -x 2>&1 | tail -5
     ;;
+engine_loop)          # round 6: the engine decoders' chunk loop on device arrays: parity subset, PROFILE=1 sections, A/B against the callback contract
+    timeout 1500 $PYT tests/test_kernels.py tests/test_engine_decoder.py tests/test_engine_fuzz.py tests/test_llm_api.py -m gpu -x -n 6 -s 2>&1 | grep -v "amdgpu.ids" | grep "per-position JS\|passed\|failed\|Error\|error" | tail -12
+    for MODE in "jacobi greedy" "jacobi T=0.8"; do
+        T=$(echo $MODE | tr -d ' =.')
+        timeout 400 python tools/engine_throughput.py --only "$MODE" --max-tokens 96 2>&1 | grep "tok/s" | tee $O/tput_$T.txt
+        JF_ENGINE_LOOP=0 timeout 400 python tools/engine_throughput.py --only "$MODE" --max-tokens 96 2>&1 | grep "tok/s" | sed 's/^/callbacks: /' | tee $O/tput_callbacks_$T.txt
+        PROFILE=1 timeout 400 python tools/engine_throughput.py --only "$MODE" --max-tokens 96 2>&1 | grep "tok/s\|jacobi\.\|overhead" | tee $O/profile_$T.txt
+        JF_ENGINE_LOOP=0 PROFILE=1 timeout 400 python tools/engine_throughput.py --only "$MODE" --max-tokens 96 2>&1 | grep "tok/s\|jacobi\.\|overhead" | sed 's/^/callbacks: /' | tee $O/profile_callbacks_$T.txt
+    done
+    ;;
 gputests)             # the whole GPU suite + smoke
     timeout 2400 $PYT tests -m gpu -n 8 --durations=10 > $O/gputest.log 2>&1; tail -14 $O/gputest.log
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
