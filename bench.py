@@ -383,19 +383,19 @@ def nongreedy_section(model, cfg, weights, tuned, P: int = 64, L: int = 32, temp
         probs, step = st.summary("rs_probs", skip=1), st.summary("rs_step", skip=1)
         loop_body = lt.summary()
     toks = sum(len(r["token_ids"]) for r in res)
-    its = len(st.done.get("rs_step", [])) or 1
+    its = len(lt.body) or len(st.done.get("rs_step", [])) or 1
     # the same decoding with top_k / top_p planted on the request object, as the reference reads them (JDN:117-118): jf_rs_filter in situ
     filtered = None
     try:
         spf = mk(max_tokens)                                 # the same budget as the unfiltered run: the two ms_per_step are comparable
         spf.top_k, spf.top_p = 50, 0.9
-        with StageTimer() as stf:
+        with StageTimer() as stf, EngineLoopTimer() as ltf:
             t0 = time.perf_counter()
             resf = llm.generate(prompts, spf, use_tqdm=False)
             torch.cuda.synchronize()
             dtf = time.perf_counter() - t0
             fl = stf.summary("rs_filter", skip=1)
-        itf = len(stf.done.get("rs_step", [])) or 1
+        itf = len(ltf.body) or len(stf.done.get("rs_step", [])) or 1
         filtered = dict(top_k=50, top_p=0.9, value=sum(len(r["token_ids"]) for r in resf) / dtf, unit="tokens/s", iterations=itf,
                         ms_per_step=dtf / itf * 1e3,
                         rs_filter=None if fl is None else {"us_per_launch": fl["us"], "launches": fl["launches"], "bytes_per_launch": fl["bytes"],
@@ -463,7 +463,7 @@ def engine_greedy_section(model, cfg, weights, tuned, P: int = 64, L: int = 32, 
         loop_body = lt.summary()
     del llm
     toks = sum(len(r["token_ids"]) for r in res)
-    its = len(st.done.get("engine_verify", [])) or 1
+    its = len(lt.body) or len(st.done.get("engine_verify", [])) or 1
     return dict(workload=f"engine greedy Jacobi (JacobiDecoder, single block), batch {P} x block {L}, bf16 logits, {max_tokens} tokens per request, "
                          "prefill included (LLM.generate on the bench's random-init weights: acceptance ~1 token per forward)",
                 value=toks / dt, unit="tokens/s", tokens=toks, seconds=dt, iterations=its, ms_per_step=dt / its * 1e3,

@@ -481,16 +481,52 @@ JF_API int jf_rs_probs(const void *logits, int dtype, int64_t R, int64_t V, int6
 
 /* (a19) top_k / top_p on the target distribution — _apply_top_k + _apply_top_p of _build_target_probs, JDN:72-123 (the reference
  * reads both with getattr(sp, ...): they exist only on request objects a caller planted them on).  Call AFTER jf_rs_probs on the
- * same rows: turns the R logits rows into R rows `probs` [R, V] (row stride V, dtype of the logits) of the filtered,
- * renormalised probabilities in torch's dtype arithmetic, p_draft[r] = probs[r, draft_next[r]] (final: no rounding candidates),
- * and marks the rows as PROBABILITY rows (row_max = +inf, row_sumexp = -1): jf_rs_step / jf_rs_onpolicy_step called with
- * `probs` in place of the logits read an element as its own probability.  top_k <= 0 or >= V, top_p <= 0 or >= 1: that stage
- * is off (JDN:75, 95-96).  What torch leaves to its kernels is defined: equal probabilities are ordered by token id, sums are
- * exact sums rounded once (oracle/jacobi_oracle.py filter_probs_row; tests/golden/filter_vectors.json pins it against the
- * reference's tensors).  packed / the greedy next-draft tail of jf_rs_probs are untouched (argmax of the LOGITS, JDN:446). */
+ * same rows.  The filtered, renormalised distribution of a row is a function of each element's exactly rounded probability and
+ * its id, fixed by ONE small record per row — the tensor itself (the reference's `probs`, 0.6 GB at 64 x 31 rows) is never
+ * written; jf_rs_step / jf_rs_onpolicy_step evaluate the function on the few rows they read again:
+ *
+ *     p    = softmax(xs)[id] rounded once to the dtype, with the float64 row sum `sum` (the definition above)
+ *     y    = top-k on:  (bits(p) > cut1 || (bits(p) == cut1 && id <= tie1)) ? p / s1 : 0        else p
+ *     out  = top-p on:  (bits(y) > cut2 || (bits(y) == cut2 && id <= tie2)) ? y / s2 : 0        else y
+ *
+ * (quotients in the dtype's arithmetic: float32 division, rounded again for bf16).  A cut is the smallest kept value of its stage,
+ * `tie` the last kept id among the ids that hold exactly that value (they are kept in id order: V - 1 = all of them, -1 = none).
+ * What torch leaves to its kernels is defined: equal probabilities are ordered by token id, sums are exact sums rounded once
+ * (oracle/jacobi_oracle.py filter_probs_row; tests/golden/filter_vectors.json pins it against the reference's tensors).
+ *   filt [R]       out: the records.
+ *   p_draft [R]    out: the FINAL filtered probability of draft_next[r] (no rounding candidates).
+ *   row_max / row_sumexp [R]  in: jf_rs_probs'; out: marked (+inf / -1) — the steps then take p_draft as it is; the records carry
+ *                  the rows' statistics from here on (row_max, sum).
+ *   workspace      jf_rs_filter_workspace_bytes(dtype, R, V) bytes, 16-byte aligned: none for bf16 rows of up to 524 288 ids (a
+ *                  workgroup per row keeps the COUNT of every bf16 pattern of the row's scaled logits in LDS — the probability is a
+ *                  monotone function of the pattern, so cuts, sums and tie groups are sums over <= 65 536 counters — and reads the
+ *                  row a second time only to find the last kept id of a tie group); float32 rows use R x V x 4 bytes of scratch.
+ * top_k <= 0 or >= V, top_p <= 0 or >= 1: that stage is off (JDN:75, 95-96); top_p is compared AS GIVEN (a double): a value that
+ * a float would round to 0 or 1 keeps its stage on.  packed / the greedy next-draft tail of jf_rs_probs are untouched (argmax
+ * of the LOGITS, JDN:446).
+ * jf_rs_filter_expand: the dense tensor of the records, probs [R, V] in the dtype of the logits (row stride V) — what the
+ * reference's `probs` holds; for callers that want it, and the parity tests. */
+#define JF_RS_FILT_TOPK 1u
+#define JF_RS_FILT_TOPP 2u
+typedef struct jf_rs_filter_row {
+    double   sum;        /* float64 sum of exp(xs - row_max); 0: the row filters to zeros (NaN / inf logits)                  */
+    float    row_max;    /* max xs                                                                                              */
+    float    x_keep;     /* no id whose scaled logit lies below this is kept (-inf: not known): consumers skip their exps          */
+    uint32_t cut1;       /* top-k: bits (as a float32 value) of the smallest kept probability                                    */
+    int32_t  tie1;       /*        last kept id among the ids AT cut1                                                            */
+    float    s1;         /*        sum of the kept probabilities, rounded once to the dtype, >= 1e-12 in the dtype (JDN:83)      */
+    uint32_t cut2;       /* top-p: the same on y                                                                                 */
+    int32_t  tie2;
+    float    s2;
+    uint32_t flags;      /* JF_RS_FILT_TOPK | JF_RS_FILT_TOPP: the stages that are on                                            */
+    uint32_t rsv;
+} jf_rs_filter_row;
+JF_API size_t jf_rs_filter_workspace_bytes(int dtype, int64_t R, int64_t V);
 JF_API int jf_rs_filter(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, const int64_t *draft_next,
-                 float temperature, int32_t top_k, float top_p, void *probs, float *p_draft, float *row_max /* in: jf_rs_probs' */,
-                 float *row_sumexp, void *stream);
+                 float temperature, int32_t top_k, double top_p, jf_rs_filter_row *filt, float *p_draft, float *row_max,
+                 float *row_sumexp, void *workspace, size_t workspace_bytes, void *stream);
+JF_API int jf_rs_filter_expand(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, float temperature,
+                        const jf_rs_filter_row *filt, void *probs, void *stream);
 JF_API size_t jf_rs_workspace_bytes(int64_t R, int64_t V);   /* per-chunk (max, sum-exp) partials */
 
 typedef struct jf_rs_row {
@@ -529,7 +565,8 @@ JF_API int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_stri
                const float *bonus_stream, int64_t bonus_len, int64_t *bonus_cursor,
                const int64_t *pad_stream, int64_t pad_len, int64_t *pad_cursor,
                int64_t *committed, int64_t *next_draft, jf_rs_row *rows,
-               void *workspace, size_t workspace_bytes, void *stream);
+               void *workspace, size_t workspace_bytes, const jf_rs_filter_row *filt /* nullable: jf_rs_filter's records of the B*(L-1) rows */,
+               void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * On-policy rollout step, JDO = inference_engine/engine/jacobi_decoding_nongreedy_on_policy.py.

@@ -50,10 +50,28 @@ struct RsRow {                 // one logits row + what is needed to turn an ele
     float t, inv_t, M, S;
     bool unit_t, vec;          // vec: 16-byte aligned row -> vector loads
     bool fast;                 // bf16 temperature scaling as a product (see rs_scaled)
-    bool prob;                 // the row HOLDS probabilities (jf_rs_filter's output: row_sumexp == RS_PROB_ROW): an element is its own
-                               // probability.  Such a row is never "exact" (rs_row_is_exact), so every consumer takes its plain-formula
-                               // path, and that path ends here
+    bool prob;                 // the row's statistics are marked (row_sumexp == RS_PROB_ROW, row_max = +inf: jf_rs_filter has been here): its
+                               // p_draft is final, and the steps attach the row's filter record (flt) before they read the row again
+    const jf_rs_filter_row *flt;   // top-k / top-p record of the row (null: the plain distribution): see rs_filter_apply
 };
+template <int DT> __device__ __forceinline__ float flt_div(float a, float b) {                     // torch: tensor / tensor in the dtype
+    const float q = __fdiv_rn(a, b);
+    if constexpr (DT == JF_BF16) return bf16_rne(q); else return q;
+}
+// the filtered, renormalised probability of an id from its exactly rounded probability p (include/jacobiforcing.h: jf_rs_filter)
+template <int DT>
+__device__ __forceinline__ float rs_filter_apply(const jf_rs_filter_row &f, float p, int64_t id) {
+    float y = p;
+    if (f.flags & JF_RS_FILT_TOPK) {
+        const uint32_t b = __float_as_uint(p);
+        y = (b > f.cut1 || (b == f.cut1 && id <= (int64_t)f.tie1)) ? flt_div<DT>(p, f.s1) : 0.f;
+    }
+    if (f.flags & JF_RS_FILT_TOPP) {
+        const uint32_t b = __float_as_uint(y);
+        y = (b > f.cut2 || (b == f.cut2 && id <= (int64_t)f.tie2)) ? flt_div<DT>(y, f.s2) : 0.f;
+    }
+    return y;
+}
 constexpr float RS_PROB_ROW = -1.f;     // row_sumexp of a probability row (row_max = +inf)
 template <int DT>
 __device__ __forceinline__ float rs_prob_at(const RsRow &r, int64_t i) {
@@ -852,6 +870,7 @@ __device__ __forceinline__ RsRow rs_make_row(const void *logits, int64_t r, int6
     t = fabsf(t);
     rr.V = V; rr.t = t; rr.inv_t = 1.f / t; rr.M = M; rr.S = S;
     rr.prob = (S == RS_PROB_ROW);
+    rr.flt = nullptr;
     rr.unit_t = (t == 1.f);
     rr.vec = (((uintptr_t)rr.p) % 16) == 0;
     return rr;
@@ -923,6 +942,34 @@ __device__ __forceinline__ void rs_any_probs_from_vec(const RsRow &r, const u32x
     else rs_probs_from_vec<DT>(r, v, p);
 }
 
+// the same for a row that may carry a filter record (e0 = id of the vector's first element): the exact probability of every id
+// that can be kept (scaled logit >= x_keep: the others are 0 whatever their probability), then the record's map
+template <int DT>
+__device__ __forceinline__ void rs_row_probs_from_vec(const RsRow &r, const u32x4 v, int64_t e0, double invS, const double *tab, float (&p)[Elem<DT>::EPV]) {
+    if (!r.flt) { rs_any_probs_from_vec<DT>(r, v, invS, tab, p); return; }
+    const jf_rs_filter_row &f = *r.flt;
+    float xs[Elem<DT>::EPV];
+    rs_scaled_from_vec<DT>(r, v, xs);
+    const double inv = f.sum > 0.0 ? invS : 0.0;
+#pragma unroll
+    for (int j = 0; j < Elem<DT>::EPV; ++j) {
+        float q = 0.f;
+        if (xs[j] >= f.x_keep && inv > 0.0) q = rs_filter_apply<DT>(f, rs_round_prob<DT>(rs_e64(xs[j], (double)r.M, tab) * inv), e0 + j);
+        p[j] = q;
+    }
+}
+// a row of a step: jf_rs_probs' statistics, or — filt given — the record of jf_rs_filter (which marked the statistics)
+template <int DT>
+__device__ __forceinline__ RsRow rs_step_row(const void *logits, int64_t r, int64_t V, int64_t row_stride, float t, const float *row_max,
+                                             const float *row_sumexp, const jf_rs_filter_row *filt) {
+    if (!filt) return rs_make_row<DT>(logits, r, V, row_stride, t, row_max[r], row_sumexp[r]);
+    RsRow rr = rs_make_row<DT>(logits, r, V, row_stride, t, filt[r].row_max, 1.f);
+    rr.flt = filt + r;
+    return rr;
+}
+// float64 sum of a filtered row's softmax (the record's), as the consumers' S
+__device__ __forceinline__ double rs_flt_sum(const RsRow &row) { return row.flt->sum; }
+
 // float64 sum of exp(xs - M) over a whole row by one workgroup (every thread gets the result).  Used where ONE row's exact
 // sum is needed on the spot: an accept test that the float32 sum cannot decide, and the rows of the on-policy accept.
 template <int DT, int NB = 4 /* loads in flight per thread: the one-launch step calls this with its register budget in mind; jf_rs_filter takes 8 */>
@@ -961,6 +1008,401 @@ __device__ float rs_exact_prob_wg(const void *logits, int64_t r, int64_t V, int6
 }
 
 // ------------------------------------------------------------------------------------------------
+// (a19, round 6) top-k / top-p of a bf16 row WITHOUT its tensor: one workgroup of 1 024 threads per row, the COUNT of every bf16
+// pattern of the row's scaled logits in LDS.  The exactly rounded probability is a non-decreasing function of the scaled logit,
+// and a bf16 scaled logit is one of 65 536 patterns: S = sum count x exp(x - M), the top-k cut, the nucleus, their sums and the
+// groups of equal values are all sums over <= 65 536 counters, formed once the row has been streamed ONCE (integer work per
+// element: scale, key, one LDS atomic; float64 exps only per OCCUPIED pattern).  A cut that falls inside a group of equal values
+// keeps that group's first ids in id order: the id of the last one kept needs the row a second time (matches per tile of 8 192
+// ids, then the tile that holds it).  Out: one jf_rs_filter_row per row (include/jacobiforcing.h) — 48 bytes instead of
+// V x 2 — and the final probability of the drafted id.
+//   counters  two 16-bit counts per LDS word (128 KB): a pattern that occurs more than 65 535 times in a row (at most two can)
+//             wraps; the add returns the old value, a wrap is noticed, and the row is counted again with such patterns in 32-bit
+//             side counters (rows of equal logits; never seen with a model).
+//   ownership thread t owns the 64 patterns [65536 - 64 (t + 1), 65536 - 64 t): thread 0 the largest values.  Prefix sums over
+//             threads are "everything above"; a thread reads its 32 words rotated by t (conflict-free), walks them in order only
+//             where a cut is located.
+//   order     every float64 sum is formed in a fixed order (a thread's words in its rotated order, the DPP wave scan, the 16
+//             wavefronts in order): the record does not depend on scheduling.
+// ------------------------------------------------------------------------------------------------
+constexpr int FH_TPB = 1024, FH_NW = FH_TPB / 64, FH_WORDS = 32768, FH_OVF = 8, FH_TILE = FH_TPB * 8, FH_MAX_TILES = 64;
+constexpr unsigned FH_LDS = FH_WORDS * 4;
+struct FhShared {
+    double tab[64];
+    double dred[FH_NW];
+    long long lred[FH_NW];
+    uint32_t ovf_key[FH_OVF];
+    uint32_t ovf_cnt[FH_OVF];
+    int n_ovf, ovf_seen;
+    int tileA[FH_MAX_TILES], tileB[FH_MAX_TILES];
+    int scan[FH_TPB];
+    double bd[4];                 // broadcast slots
+    long long bl[4];
+    int bi[8];
+};
+__device__ __forceinline__ uint32_t fh_key(uint32_t h16) { return (h16 & 0x8000u) ? (~h16 & 0xFFFFu) : (h16 | 0x8000u); }     // ascending with the value
+__device__ __forceinline__ float fh_value(uint32_t key) { return __uint_as_float(((key & 0x8000u) ? (key & 0x7FFFu) : (~key & 0xFFFFu)) << 16); }
+__device__ __forceinline__ uint32_t fh_count(const FhShared &sh, const uint32_t *hist, uint32_t key) {
+    const uint32_t w = hist[key >> 1];
+    uint32_t c = (key & 1u) ? (w >> 16) : (w & 0xFFFFu);
+    if (sh.n_ovf) for (int i = 0; i < sh.n_ovf; ++i) c += sh.ovf_key[i] == key ? sh.ovf_cnt[i] : 0u;
+    return c;
+}
+// workgroup sums in a fixed order (every thread gets them); `incl` = this thread's inclusive prefix over the thread ids
+__device__ __forceinline__ void fh_scan(FhShared &sh, long long &cnt, double &sum, long long &cnt_incl, double &sum_incl) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double si = wave_incl_scan_f64(sum, lane);
+    long long ci = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const long long o = __shfl_up(ci, off, 64); if (lane >= off) ci += o; }
+    __syncthreads();
+    if (lane == 63) { sh.dred[wave] = si; sh.lred[wave] = ci; }
+    __syncthreads();
+    double sb = 0.0, st = 0.0;
+    long long cb = 0, ct = 0;
+#pragma unroll
+    for (int w = 0; w < FH_NW; ++w) { if (w == wave) { sb = st; cb = ct; } st += sh.dred[w]; ct += sh.lred[w]; }
+    cnt_incl = cb + ci; sum_incl = sb + si;
+    cnt = ct; sum = st;
+}
+__device__ __forceinline__ void fh_reduce(FhShared &sh, long long &cnt, double &sum) {
+    long long ci; double si;
+    fh_scan(sh, cnt, sum, ci, si);
+}
+__device__ __forceinline__ int fh_min_max(FhShared &sh, int v, bool want_max) {          // workgroup min / max of an int (every thread gets it)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off, 64); v = want_max ? (o > v ? o : v) : (o < v ? o : v); }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh.scan[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int r = sh.scan[0];
+#pragma unroll
+    for (int w = 1; w < FH_NW; ++w) { const int o = sh.scan[w]; r = want_max ? (o > r ? o : r) : (o < r ? o : r); }
+    __syncthreads();
+    return r;
+}
+
+// the row streamed once: every scaled logit that can carry mass (>= M + RS_EXP_CUT) counted under its key.  side: count the listed
+// patterns (sh.ovf_key) in 32-bit side counters instead (second attempt of a row whose 16-bit counters wrapped)
+template <bool SIDE>
+__device__ __forceinline__ void fh_count_row(FhShared &sh, uint32_t *hist, const RsRow &row) {
+    constexpr int EPV = 8, NB = 8;
+    const float mcut = row.M + (float)RS_EXP_CUT;
+    for (int64_t b0 = (int64_t)threadIdx.x * EPV; b0 < row.V; b0 += (int64_t)NB * FH_TPB * EPV) {
+        u32x4 v[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) { const int64_t e0 = b0 + (int64_t)k * FH_TPB * EPV; if (e0 < row.V) v[k] = rs_load_vec<JF_BF16>(row, e0); }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int64_t e0 = b0 + (int64_t)k * FH_TPB * EPV;
+            if (e0 >= row.V) continue;
+            float xs[EPV];
+            rs_scaled_from_vec<JF_BF16>(row, v[k], xs);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) {
+                if (!(xs[j] >= mcut)) continue;                            // (slots beyond V hold -inf)
+                const uint32_t key = fh_key(__float_as_uint(xs[j]) >> 16);
+                if constexpr (SIDE) {
+                    bool listed = false;
+                    for (int i = 0; i < sh.n_ovf; ++i) if (sh.ovf_key[i] == key) { atomicAdd(&sh.ovf_cnt[i], 1u); listed = true; }
+                    if (listed) continue;
+                }
+                const uint32_t hi = key & 1u;
+                const uint32_t old = atomicAdd(&hist[key >> 1], hi ? 0x10000u : 1u);
+                if (__builtin_expect(((hi ? (old >> 16) : old) & 0xFFFFu) == 0xFFFFu, 0)) {        // this counter wrapped (or, rarely, its word was seen mid-carry)
+                    const int slot = atomicAdd(&sh.ovf_seen, 1);
+                    if (slot < FH_OVF) sh.ovf_key[slot] = key;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+struct FhStage { uint32_t cut; int32_t tie; float s; };
+__global__ __launch_bounds__(FH_TPB, 1) void rs_filter_hist_kernel(const void *logits, int64_t R, int64_t V, int64_t row_stride, const int64_t *draft_next,
+                                                                    float t, int top_k, double top_p, jf_rs_filter_row *filt, float *p_draft,
+                                                                    float *row_max, float *row_sumexp) {
+    constexpr int EPV = 8;
+    __shared__ FhShared sh;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fh_dyn[];
+    uint32_t *hist = (uint32_t *)fh_dyn;
+    const int tid = threadIdx.x;
+    const int64_t r = blockIdx.x;
+    const float M = row_max[r];
+    jf_rs_filter_row rec;
+    rec.sum = 0.0; rec.row_max = M; rec.x_keep = -INFINITY; rec.cut1 = 0u; rec.tie1 = (int32_t)V - 1; rec.s1 = 1.f; rec.cut2 = 0u; rec.tie2 = (int32_t)V - 1; rec.s2 = 1.f;
+    const bool k_on = top_k > 0 && (int64_t)top_k < V, p_on = top_p > 0.0 && top_p < 1.0;
+    rec.flags = (k_on ? JF_RS_FILT_TOPK : 0u) | (p_on ? JF_RS_FILT_TOPP : 0u); rec.rsv = 0u;
+    const bool finite = (__float_as_uint(M) & 0x7F800000u) != 0x7F800000u;
+    auto finish = [&](float pd) {
+        if (tid == 0) { filt[r] = rec; p_draft[r] = pd; row_max[r] = INFINITY; row_sumexp[r] = RS_PROB_ROW; }
+    };
+    if (!finite) { finish(0.f); return; }                                    // NaN / inf logits: the row filters to zeros (sum = 0)
+    const RsRow row = rs_make_row<JF_BF16>(logits, r, V, row_stride, t, M, 1.f);
+    rs_load_tab(sh.tab);
+    // ---- 1. the counts
+    for (int w = tid; w < FH_WORDS; w += FH_TPB) hist[w] = 0u;
+    if (tid == 0) { sh.n_ovf = 0; sh.ovf_seen = 0; }
+    if (tid < FH_OVF) sh.ovf_cnt[tid] = 0u;
+    __syncthreads();
+    fh_count_row<false>(sh, hist, row);
+    if (sh.ovf_seen) {                                                       // (workgroup-uniform) a counter wrapped: count again with side counters
+        __syncthreads();
+        if (tid == 0) {                                                      // the distinct keys seen wrapping (<= 2 real ones + neighbours seen mid-carry)
+            int n = sh.ovf_seen < FH_OVF ? sh.ovf_seen : FH_OVF, m = 0;
+            for (int i = 0; i < n; ++i) { bool dup = false; for (int q = 0; q < m; ++q) dup |= sh.ovf_key[q] == sh.ovf_key[i]; if (!dup) sh.ovf_key[m++] = sh.ovf_key[i]; }
+            sh.n_ovf = m; sh.ovf_seen = 0;
+        }
+        for (int w = tid; w < FH_WORDS; w += FH_TPB) hist[w] = 0u;
+        __syncthreads();
+        fh_count_row<true>(sh, hist, row);
+    }
+    // a thread's patterns, in its rotated word order (conflict-free): f(key, count) for the occupied ones
+    const uint32_t kbase = 65536u - 64u * (uint32_t)(tid + 1);
+    auto for_mine = [&](auto f) {
+#pragma unroll 4
+        for (int i = 0; i < 32; ++i) {
+            const uint32_t wi = (uint32_t)(i + tid) & 31u;
+            const uint32_t w = hist[(kbase >> 1) + wi];
+            if (w == 0u && sh.n_ovf == 0) continue;
+            const uint32_t k0 = kbase + 2u * wi;
+            const uint32_t c0 = fh_count(sh, hist, k0), c1 = fh_count(sh, hist, k0 + 1u);
+            if (c0) f(k0, c0);
+            if (c1) f(k0 + 1u, c1);
+        }
+    };
+    // ---- 2. the exact sum, then every pattern's probability on demand
+    long long cnt = 0;
+    double sum = 0.0;
+    for_mine([&](uint32_t key, uint32_t c) { sum += (double)c * rs_e64(fh_value(key), (double)M, sh.tab); });
+    fh_reduce(sh, cnt, sum);
+    const double S = sum, invS = 1.0 / S;                                  // (S >= 1: the maximum itself contributes exp(0))
+    rec.sum = S;
+    auto P = [&](uint32_t key) { return rs_bf16_of_f64(rs_e64(fh_value(key), (double)M, sh.tab) * invS); };
+    const float floor_d = rs_round_prob<JF_BF16>(1e-12);                    // sum.clamp_min(1e-12) in the dtype
+    // counts and sums of the patterns whose value f(key) lies above / at a bit pattern: (n above, their sum, n at, key range at)
+    auto query = [&](auto val, uint32_t at_bits, long long &n_gt, double &s_gt, long long &n_eq, int &k_lo, int &k_hi) {
+        long long ng = 0, ne = 0;
+        double sg = 0.0;
+        int lo = 0x7FFFFFFF, hi = -1;
+        for_mine([&](uint32_t key, uint32_t c) {
+            const float v = val(key);
+            const uint32_t b = __float_as_uint(v);
+            if (b > at_bits) { ng += c; sg += (double)c * (double)v; }
+            else if (b == at_bits && b != 0u) { ne += c; lo = (int)key < lo ? (int)key : lo; hi = (int)key > hi ? (int)key : hi; }
+        });
+        double unused = 0.0;
+        fh_reduce(sh, ne, unused);
+        fh_reduce(sh, ng, sg);
+        k_lo = fh_min_max(sh, lo, false); k_hi = fh_min_max(sh, hi, true);
+        n_gt = ng; s_gt = sg; n_eq = ne;
+    };
+    // the first thread (largest values first) at which pred(inclusive count, inclusive sum) holds walks its patterns downwards and
+    // returns the first key at which it holds; -1: nowhere.  pred is monotone along the walk.
+    auto locate = [&](auto val, auto pred) -> int {
+        long long c = 0, ci;
+        double s = 0.0, si;
+        for_mine([&](uint32_t key, uint32_t n) { const float v = val(key); if (v > 0.f) { c += n; s += (double)n * (double)v; } });
+        const long long cm = c;
+        const double sm = s;
+        fh_scan(sh, c, s, ci, si);
+        if (tid == 0) sh.bi[0] = -1;
+        __syncthreads();
+        if (pred(ci, si) && !pred(ci - cm, si - sm)) {                      // the crossing lies in this thread's patterns
+            long long cc = ci - cm;
+            double ss = si - sm;                                            // (the prefix above this thread; the walk below re-forms the thread's own sum in key order)
+            for (int key = (int)kbase + 63; key >= (int)kbase; --key) {
+                const uint32_t n = fh_count(sh, hist, (uint32_t)key);
+                if (!n) continue;
+                const float v = val((uint32_t)key);
+                if (!(v > 0.f)) continue;
+                cc += n; ss += (double)n * (double)v;
+                if (pred(cc, ss)) { sh.bi[0] = key; break; }
+            }
+            if (sh.bi[0] < 0) sh.bi[0] = (int)kbase;                        // (rounding of the re-formed sum only)
+        }
+        __syncthreads();
+        const int k = sh.bi[0];
+        __syncthreads();
+        return k;
+    };
+    // ---- 3. top-k (JDN:73-84): the k-th largest probability, the ids above it, `need1` ids at it
+    uint32_t v1 = 0u;                                                       // bits of the cut value (0: every id is kept)
+    long long need1 = 0, n_eq1 = 0;
+    int ka1 = 0x7FFFFFFF, kb1 = -1;                                         // keys of the cut group
+    float s1 = 1.f;
+    if (k_on) {
+        const int kk = locate(P, [&](long long c, double) { return c >= (long long)top_k; });
+        if (kk >= 0) {
+            v1 = __float_as_uint(P((uint32_t)kk));
+            long long n_gt; double s_gt;
+            query(P, v1, n_gt, s_gt, n_eq1, ka1, kb1);
+            need1 = (long long)top_k - n_gt;
+            if (need1 > n_eq1) need1 = n_eq1;
+            s1 = rs_round_prob<JF_BF16>(s_gt + (double)need1 * (double)__uint_as_float(v1));
+        } else {                                                             // fewer than k ids with mass: all of them (and the zeros) are kept
+            long long n_gt, ne; double s_gt; int a, b;
+            query(P, 0u, n_gt, s_gt, ne, a, b);
+            s1 = rs_round_prob<JF_BF16>(s_gt);
+        }
+        s1 = s1 > floor_d ? s1 : floor_d;
+    }
+    rec.cut1 = v1; rec.s1 = s1;
+    const float yv = v1 ? flt_div<JF_BF16>(__uint_as_float(v1), s1) : 0.f;   // what a kept id of the cut group becomes
+    // y of a pattern: 0 at and below the cut (the cut group's kept ids enter the sums below as need1 x yv)
+    auto Y = [&](uint32_t key) {
+        const float p = P(key);
+        if (!k_on) return p;
+        return __float_as_uint(p) > v1 ? flt_div<JF_BF16>(p, s1) : 0.f;
+    };
+    // ---- 4. top-p (JDN:91-107) on y
+    uint32_t v2 = 0u;
+    long long c2 = 0, n_eq2 = 0;                                            // ids kept of the group at the cut / ids in that group
+    int ka2 = 0x7FFFFFFF, kb2 = -1;
+    bool grp1_in2 = false;                                                  // the top-k cut group's kept ids belong to the top-p cut group (yv == cut2)
+    float s2 = 1.f;
+    bool all2 = true;
+    if (p_on) {
+        const float tp = rs_round_prob<JF_BF16>(top_p);                     // `cdf <= tp`: the Python float is cast to the tensor's dtype
+        long long n_all, ne; double s_all; int a, b;
+        query(Y, 0u, n_all, s_all, ne, a, b);
+        const double total = s_all + (double)need1 * (double)yv;
+        all2 = rs_round_prob<JF_BF16>(total) <= tp;
+        if (all2) s2 = rs_round_prob<JF_BF16>(total);
+        else {
+            // the group the cut falls into: the largest value whose cumulative sum (everything >= it), rounded, exceeds tp
+            const int kk = locate(Y, [&](long long, double s) { return !(rs_round_prob<JF_BF16>(s) <= tp); });
+            const float y2 = kk >= 0 ? Y((uint32_t)kk) : yv;                // nowhere above the top-k cut: the cut group itself
+            v2 = __float_as_uint(y2);
+            long long n_whole; double c_whole;
+            query(Y, v2, n_whole, c_whole, n_eq2, ka2, kb2);
+            grp1_in2 = need1 > 0 && __float_as_uint(yv) == v2;
+            if (grp1_in2) n_eq2 += need1;
+            else if (need1 > 0 && __float_as_uint(yv) > v2) { n_whole += need1; c_whole += (double)need1 * (double)yv; }   // (cannot happen: yv is the smallest y)
+            long long lo = 0, hi = n_eq2;                                   // ids of the group whose own cumulative sum passes: pass(lo) holds, pass(hi) fails
+            while (hi - lo > 1) { const long long m2 = lo + (hi - lo) / 2; if (rs_round_prob<JF_BF16>(c_whole + (double)m2 * (double)y2) <= tp) lo = m2; else hi = m2; }
+            c2 = lo;
+            if (n_whole == 0 && c2 == 0) c2 = 1;                            // keep[..., 0] = True
+            s2 = rs_round_prob<JF_BF16>(c_whole + (double)c2 * (double)y2);
+        }
+        s2 = s2 > floor_d ? s2 : floor_d;
+    }
+    rec.cut2 = v2; rec.s2 = s2;
+    // ---- 5. the last kept id of a cut group that is kept in part: the row a second time
+    const bool tie1_needed = k_on && v1 && need1 < n_eq1;                   // else every id at the cut is kept (tie1 = V - 1)
+    const bool tie2_needed = p_on && !all2 && c2 > 0 && c2 < n_eq2;
+    if (p_on && !all2 && c2 == 0) rec.tie2 = -1;
+    if (tie1_needed && need1 == 0) rec.tie1 = -1;
+    const bool pass2 = (tie1_needed && need1 > 0) || tie2_needed;
+    if (pass2) {
+        const int64_t ntiles = (V + FH_TILE - 1) / FH_TILE;
+        __syncthreads();
+        if (tid < FH_MAX_TILES) { sh.tileA[tid] = 0; sh.tileB[tid] = 0; }
+        __syncthreads();
+        // class A: keys of the top-k cut group; class B: keys above the top-k cut whose y equals the top-p cut (a key range: y is monotone)
+        const int a_lo = ka1, a_hi = kb1, b_lo = ka2, b_hi = kb2;
+        auto classes = [&](const u32x4 vv, int64_t e0, int &na, int &nb, uint32_t &ma, uint32_t &mb) {
+            float xs[EPV];
+            rs_scaled_from_vec<JF_BF16>(row, vv, xs);
+            na = nb = 0; ma = mb = 0u;
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) {
+                if (e0 + j >= V) continue;
+                const int key = (int)fh_key(__float_as_uint(xs[j]) >> 16);
+                const bool ia = key >= a_lo && key <= a_hi, ib = key >= b_lo && key <= b_hi;
+                na += ia; nb += ib; ma |= ia ? 1u << j : 0u; mb |= ib ? 1u << j : 0u;
+            }
+        };
+        {
+            constexpr int NB = 8;
+            for (int64_t t0 = 0; t0 < ntiles; t0 += NB) {
+                u32x4 v[NB];
+#pragma unroll
+                for (int k = 0; k < NB; ++k) { const int64_t e0 = (t0 + k) * FH_TILE + (int64_t)tid * EPV; if (t0 + k < ntiles && e0 < V) v[k] = rs_load_vec<JF_BF16>(row, e0); }
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    const int64_t e0 = (t0 + k) * FH_TILE + (int64_t)tid * EPV;
+                    if (t0 + k >= ntiles || e0 >= V) continue;
+                    int na, nb; uint32_t ma, mb;
+                    classes(v[k], e0, na, nb, ma, mb);
+                    if (na) atomicAdd(&sh.tileA[t0 + k], na);
+                    if (nb) atomicAdd(&sh.tileB[t0 + k], nb);
+                }
+            }
+        }
+        __syncthreads();
+        // the id of the c-th (1-based) member, in id order, of: class A ids (use_a, up to id a_max) and class B ids (use_b)
+        auto nth = [&](long long c, bool use_a, int64_t a_max, bool use_b) -> int64_t {
+            if (tid == 0) {
+                long long before = 0;
+                sh.bi[1] = -1;
+                for (int tl = 0; tl < (int)ntiles; ++tl) {
+                    long long n = use_b ? sh.tileB[tl] : 0;
+                    if (use_a) { const int64_t t_lo = (int64_t)tl * FH_TILE; n += a_max >= t_lo + FH_TILE - 1 ? sh.tileA[tl] : a_max >= t_lo ? sh.bl[2] : 0; }
+                    if (before < c && c <= before + n) { sh.bi[1] = tl; sh.bl[0] = c - before; break; }
+                    before += n;
+                }
+            }
+            __syncthreads();
+            const int tl = sh.bi[1];
+            if (tl < 0) { __syncthreads(); return V - 1; }
+            const long long rank = sh.bl[0];
+            const int64_t e0 = (int64_t)tl * FH_TILE + (int64_t)tid * EPV;
+            int na = 0, nb = 0; uint32_t ma = 0u, mb = 0u;
+            if (e0 < V) classes(rs_load_vec<JF_BF16>(row, e0), e0, na, nb, ma, mb);
+            uint32_t mm = use_b ? mb : 0u;
+            if (use_a) for (int j = 0; j < EPV; ++j) if ((ma >> j & 1u) && e0 + j <= a_max) mm |= 1u << j;
+            long long mine = __popc(mm), ci;
+            double z = 0.0, zi;
+            long long tot = mine;
+            fh_scan(sh, tot, z, ci, zi);
+            if (tid == 0) sh.bl[1] = V - 1;
+            __syncthreads();
+            if (ci - mine < rank && rank <= ci) {
+                long long seen = ci - mine;
+                for (int j = 0; j < EPV; ++j) if ((mm >> j & 1u) && ++seen == rank) { sh.bl[1] = e0 + j; break; }
+            }
+            __syncthreads();
+            const int64_t hit = sh.bl[1];
+            __syncthreads();
+            return hit;
+        };
+        int64_t tie1 = V - 1;
+        if (tie1_needed && need1 > 0) { tie1 = nth(need1, true, V - 1, false); rec.tie1 = (int32_t)tie1; }
+        if (tie2_needed) {
+            if (grp1_in2) {
+                // class A ids up to tie1 are members too: how many of them the tile that holds tie1 has (ids <= tie1), for nth()
+                const int64_t tl = tie1 / FH_TILE, e0 = tl * FH_TILE + (int64_t)tid * EPV;
+                int na = 0, nb = 0; uint32_t ma = 0u, mb = 0u;
+                if (e0 < V) classes(rs_load_vec<JF_BF16>(row, e0), e0, na, nb, ma, mb);
+                long long mine = 0, ci; double z = 0.0, zi;
+                for (int j = 0; j < EPV; ++j) mine += ((ma >> j & 1u) && e0 + j <= tie1) ? 1 : 0;
+                fh_scan(sh, mine, z, ci, zi);
+                if (tid == 0) sh.bl[2] = mine;
+                __syncthreads();
+            }
+            rec.tie2 = (int32_t)nth(c2, grp1_in2, tie1, true);
+        }
+    }
+    // ---- 6. nothing below this scaled logit is kept (the steps skip the exps below it), and the drafted id's final probability
+    {
+        int klow = k_on && v1 ? ka1 : 0;
+        if (p_on && !all2 && kb2 >= 0 && !grp1_in2) klow = ka2 > klow ? ka2 : klow;
+        rec.x_keep = klow > 0 && klow < 0x7FFFFFFF ? fh_value((uint32_t)klow) : -INFINITY;
+    }
+    float pd = 0.f;
+    if (tid == 0) {
+        const int64_t tok = draft_next[r];
+        if (tok >= 0 && tok < V) {
+            const float xs = rs_scaled<JF_BF16>(load_f<JF_BF16>(row.p, tok), row.t, row.inv_t, row.unit_t, row.fast);
+            const float p = xs >= M + (float)RS_EXP_CUT ? P(fh_key(__float_as_uint(xs) >> 16)) : 0.f;
+            pd = rs_filter_apply<JF_BF16>(rec, p, tok);
+        }
+    }
+    finish(pd);
+}
+// ------------------------------------------------------------------------------------------------
 // (a19, round 5) top-k / top-p filtering of the target distribution — _apply_top_k + _apply_top_p of _build_target_probs
 // (JDN:72-123; the reference reads both with getattr: they exist only on request objects a caller planted them on).
 //
@@ -990,10 +1432,6 @@ template <int DT> __device__ __forceinline__ uint32_t flt_key(const void *row, i
 template <int DT> __device__ __forceinline__ void flt_store(void *row, int64_t i, float v) {
     if constexpr (DT == JF_F32) ((float *)row)[i] = v;
     else ((uint16_t *)row)[i] = (uint16_t)(__float_as_uint(v) >> 16);
-}
-template <int DT> __device__ __forceinline__ float flt_div(float a, float b) {                     // torch: tensor / tensor in the dtype
-    const float q = __fdiv_rn(a, b);
-    if constexpr (DT == JF_BF16) return bf16_rne(q); else return q;
 }
 constexpr int FLT_TPB = 512;                                             // threads of a row's workgroup: 8 wavefronts (with 256 the row's float64 exps
                                                                          // and load round trips had one wavefront per SIMD to hide behind: 350-450 us per row)

@@ -979,6 +979,7 @@ class RsStepper:
         self.bonus_stream = torch.as_tensor(bonus_stream).to(device=dev, dtype=torch.float32).contiguous()
         self.cursors = torch.zeros((3,), dtype=torch.int64, device=dev)          # uniforms, bonus, pads
         self.remaining = torch.zeros((self.max_rows,), dtype=torch.int32, device=dev)
+        self._ws_need: dict = {}
 
     def _check(self, draft: torch.Tensor, logits: torch.Tensor) -> Tuple[int, int]:
         B, L = draft.shape
@@ -1002,7 +1003,10 @@ class RsStepper:
         R = B * (L - 1)
         draft_next = draft[:, 1:].reshape(-1).contiguous()
         lib = N.lib()
-        self.ws = _grown(self.ws, int(lib.jf_rs_workspace_bytes(R, V)))
+        need = self._ws_need.get((R, V))
+        if need is None:
+            need = self._ws_need[(R, V)] = int(lib.jf_rs_workspace_bytes(R, V))
+        self.ws = _grown(self.ws, need)
         done = _stage("rs_probs", R * V * flat.element_size())
         N.check(lib.jf_rs_probs(_ptr(flat), _dtype_code(flat), R, V, flat.stride(0), _ptr(draft_next), float(temperature),
                                 _ptr(self.p_draft), _ptr(self.row_max), _ptr(self.row_sumexp), _ptr(self.packed),

@@ -310,7 +310,7 @@ def test_chunk_loop_on_device_arrays_equals_the_callback_contract(tmp_path, back
                 tie_word_embeddings=False, eos_token_id=319, pad_token_id=318, model_type="qwen2")
     rng = np.random.default_rng(5)
     prompts = [[int(x) for x in rng.integers(0, 300, size=int(rng.integers(2, 40)))] for _ in range(9)]
-    prompts[3] = [int(x) for x in rng.integers(0, 300, size=250)]            # 250 + 6 + tokens: crosses position 256 while decoding
+    prompts[3] = [int(x) for x in rng.integers(0, 300, size=254)]            # 254 + 4 - 1 positions: its first forward needs a second KV block
     budgets = [int(rng.integers(3, 40)) for _ in prompts]
     budgets[3] = 30
     blocks = [6 if i % 3 else 4 for i in range(len(prompts))]
@@ -376,11 +376,13 @@ def test_nongreedy_jacobi_matches_autoregressive_sampling_per_position(tmp_path,
     prompt N times with the autoregressive sampler and N times with decode_strategy="jacobi" at the same temperature, compare
     the empirical token distributions position by position (Jensen-Shannon), pass when the mean is below a threshold (0.1
     there; 0.05 here, and not above twice what two autoregressive sample sets differ by, i.e. the sampling noise of N draws).
-    Through LLM.generate on the GPU, V = 1 024, 16 positions, N = 512, T = 0.8, with and without top_k = 50 / top_p = 0.9
-    planted on the requests (both samplers read them, JDN:117-118)."""
-    monkeypatch.setenv("JF_INIT_STD", "0.35")               # a random model whose next-token distributions are peaked (entropy ~1-2 nats)
+    Through LLM.generate on the GPU, V = 1 024, 16 positions, N = 4 096, T = 0.8, with and without top_k = 50 / top_p = 0.9
+    planted on the requests (both samplers read them, JDN:117-118).  A random model's per-position marginals are broad — the
+    contexts diverge — so the sampling noise of N draws is what bounds the statistic: ~0.15 at N = 512 (two autoregressive
+    sets against each other), ~0.02 at N = 4 096."""
+    monkeypatch.setenv("JF_INIT_STD", "1.0")                # next-token distributions with a real choice (most of 512 samples are distinct)
     monkeypatch.setenv("JF_MAX_ROWS", "256")
-    V, N, T, L, POS = 1024, 512, 0.8, 8, 16
+    V, N, T, L, POS = 1024, 4096, 0.8, 8, 16
     cfg = dict(vocab_size=V, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
                num_key_value_heads=2, max_position_embeddings=1024, rms_norm_eps=1e-6, rope_theta=10000.0,
                tie_word_embeddings=False, eos_token_id=-1, pad_token_id=V - 2, model_type="qwen2")
@@ -407,6 +409,8 @@ def test_nongreedy_jacobi_matches_autoregressive_sampling_per_position(tmp_path,
     print(f"per-position JS: AR vs AR {noise:.4f}, AR vs Jacobi {js:.4f} / {js2:.4f}; distinct Jacobi samples {distinct} of {N}; "
           f"tokens per iteration {stats['tokens_accepted'] / max(stats['num_jacobi_iterations'], 1) / 256:.2f}")
     assert all(len(x) == POS for x in jac)
-    assert distinct > N // 4                                   # a real distribution, not a degenerate one
+    assert distinct > N // 16                                  # a real distribution, not a degenerate one
     assert js < 0.05 and js2 < 0.05, (js, js2, noise, per_pos)
-    assert max(js, js2) < 2.0 * noise + 0.005, (js, js2, noise)
+    # (the autoregressive sampler filters float32 probabilities, the decoder the bf16 ones the reference's dtype rule gives it: with
+    #  top-p the two nuclei can differ by a bf16 step of the running sum — a real, small difference on top of the sampling noise)
+    assert max(js, js2) < max(2.0 * noise, 0.01) + 0.005, (js, js2, noise)

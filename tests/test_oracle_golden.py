@@ -443,3 +443,27 @@ def test_exact_softmax_escalation_levels_agree(monkeypatch):
         lo = Fraction(float(O.bf16_bits_to_f32(np.array([max(bits - 1, 0)], dtype=np.uint16))[0]))
         hi = Fraction(float(O.bf16_bits_to_f32(np.array([bits + 1], dtype=np.uint16))[0]))
         assert abs(q - got) <= abs(q - lo) and abs(q - got) <= abs(q - hi), i
+
+
+# ------------------------------------------------------------------------------------- the fixtures ARE the reference's outputs
+def test_fixtures_regenerate_from_the_reference_byte_for_byte():
+    """tests/golden/gen_golden.py --check: import the unmodified reference (build container only: /root/reference), re-run every
+    recorded call into a temporary directory and compare all 22 JSON files with the committed ones, byte for byte.  Skips where the
+    reference is absent (the GPU box).  Two processes side by side (fullvocab_cases.json alone takes as long as the other 21)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    if not Path("/root/reference").is_dir():
+        pytest.skip("the reference tree is not present here")
+    if os.environ.get("JF_SKIP_GOLDEN_CHECK") == "1":
+        pytest.skip("JF_SKIP_GOLDEN_CHECK=1")
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, str(root / "tests" / "golden" / "gen_golden.py"), "--check"]
+    procs = [subprocess.Popen(cmd + [flag], env=env, cwd=str(root), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for flag in ("--skip-full-vocabulary", "--full-vocabulary")]
+    outs = [p.communicate(timeout=1500)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "21 of 21 fixture files regenerate byte-identical" in outs[0] and "1 of 1 fixture files regenerate byte-identical" in outs[1], outs
+    assert not list(Path("/root/reference").rglob("__pycache__")), "the import wrote bytecode into the reference tree"

@@ -57,6 +57,11 @@ engine_loop)          # round 6: the engine decoders' chunk loop on device array
         JF_ENGINE_LOOP=0 PROFILE=1 timeout 400 python tools/engine_throughput.py --only "$MODE" --max-tokens 96 2>&1 | grep "tok/s\|jacobi\.\|overhead" | sed 's/^/callbacks: /' | tee $O/profile_callbacks_$T.txt
     done
     ;;
+engine_ab)            # round 6: the bench's engine sections, chunk loop on device arrays vs the callback contract, with / without the stage timer (same box)
+    timeout 900 python tools/engine_sections.py 2>&1 | grep "JF_ENGINE_LOOP" | tee $O/loop.txt
+    JF_ENGINE_LOOP=0 timeout 900 python tools/engine_sections.py 2>&1 | grep "JF_ENGINE_LOOP" | tee $O/callbacks.txt
+    timeout 900 python tools/engine_sections.py --no-stage-timer 2>&1 | grep "JF_ENGINE_LOOP" | tee $O/loop_nostage.txt
+    ;;
 gputests)             # the whole GPU suite + smoke
     timeout 2400 $PYT tests -m gpu -n 8 --durations=10 > $O/gputest.log 2>&1; tail -14 $O/gputest.log
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
