@@ -17,7 +17,9 @@ visible GPUs than ranks is an error, never a silent single-GPU run.
 
 Scaling modes: default WEAK (every rank decodes --prompts-per-gpu prompts, 64 = BASELINE config 4's batch per replica);
 --total-prompts M is STRONG scaling (M prompts sharded over the ranks: M = 64 is config 4 as BASELINE states it, 8 per
-GPU at N = 8).
+GPU at N = 8).  A weak-scaling run with N > 1 — the driver's plain `--gpus N` — ALSO decodes config 4 as stated (64 prompts
+sharded N-way) in the same process group behind the weak window and reports it as `config4_strong64` (value, ms_per_step,
+tokens_per_forward, roofline, per_rank, per_rank_check); --config4-prompts 0 skips it.
 
 Extra objects on the line:
   roofline      — the argmax launch (the convergence kernel's HBM stream): algorithmic bytes = draft-carrying rows * V * 2
@@ -27,6 +29,8 @@ Extra objects on the line:
   roofline_by_shape — the same launch (and the state-machine step behind it) at 1, 8 and 64 prompts per GPU: rows, bytes,
                   microseconds, fraction of 8 TB/s — the latency regime of the literal config 3 / config 4 shapes, measured
                   in this run with short extra windows on rank 0.
+  nongreedy / engine_greedy — the engine decoders (rejection-sampling verify at T = 0.8; greedy single block) at batch 64 x block 32
+                  through LLM.generate, with loop_body: body / gpu_idle / host_gap of their iteration (engine/chunk_loop.py).
   scripted_acceptance — the same K-step measurement with the synthetic acceptance model switched on (the random
                   weights accept ~1 token per forward; a Jacobi-Forcing checkpoint accepts ~4).
 """
@@ -505,6 +509,52 @@ def vs_ar_section(model, cfg, prm, tuned, vocab_hi, robust, warmup: int = 8, ste
                      "4.0-4.1 tokens/forward); forward = step minus the HIP-event loop body and the idle gap behind it")
 
 
+def config4_window(model, cfg, prm, tuned, args, info, dev, dev_index, total: int, vocab_hi: int):
+    """BASELINE config 4 as BASELINE.json states it — `total` (64) synthetic prompts sharded N-way, total / N per GPU — measured in the
+    SAME process group behind the weak-scaling window (the driver's plain `bench.py --gpus N` passes no --total-prompts): the same
+    prewarm, warm-up, barriers, timed K iterations and final gather as the headline.  Every rank calls this (collectives inside);
+    returns the `config4_strong64` object on rank 0, None elsewhere."""
+    from jacobiforcing_amd.tuning import grid_alignment
+    P4 = total // info.world_size
+    prompts4 = jd.shard_prompts(humaneval_shaped_prompts(total, seed=1234, vocab_hi=vocab_hi), info)
+    ta, la = grid_alignment(P4, tuned)
+    dec4 = MultiblockJacobiDecoder(model, P4, prm, max_seq_len=4096, t_align=args.t_align or ta, logit_align=args.logit_align or la)
+    if not args.no_prewarm:
+        run_steps(dec4, prompts4, args.warmup, args.steps, seed=1234 + info.rank)
+    with VerifyTimer() as tm4:
+        tm4.valid_rows = lambda: dec4.last_valid_rows
+        r4 = run_steps(dec4, prompts4, args.warmup, args.steps, seed=1234 + info.rank, timer=tm4)
+        roof4 = tm4.summary()
+    agg4 = jd.gather_throughput(r4["tokens"], r4["iterations"] * 1.0, r4["seconds"], dev)
+    records4 = jd.gather_rank_records(rank_record(info, dev_index, r4, roof4))
+    del dec4
+    torch.cuda.empty_cache()
+    if info.rank != 0:
+        return None
+    out = dict(workload=f"BASELINE config 4 as stated (STRONG scaling): {total} HumanEval-shaped synthetic prompts sharded {info.world_size}-way = "
+                        f"{P4} per GPU, config 3 decoding (n=32 K=2 r=0.85 pool=4, greedy), no data-path collective; same process group, "
+                        "measured behind the weak-scaling window",
+               value=agg4["tokens"] / agg4["seconds"], unit="tokens/s", scaling="strong", total_prompts=total, prompts_per_gpu=P4,
+               steps=args.steps, warmup=args.warmup, ms_per_step=agg4["seconds"] / args.steps * 1e3,
+               tokens_per_forward=agg4["tokens"] / (agg4["iterations"] * P4) if agg4["iterations"] else 0.0,
+               per_rank=records4,
+               per_rank_check={"tokens_sum": sum(x["tokens"] for x in records4), "seconds_max": max(x["seconds"] for x in records4),
+                               "value_from_records": sum(x["tokens"] for x in records4) / max(x["seconds"] for x in records4),
+                               "slowest_rank": max(records4, key=lambda x: x["seconds"])["rank"],
+                               "seconds_spread": jd.spread(x["seconds"] for x in records4)})
+    if roof4 is not None:
+        out["roofline"] = {"bound": "hbm", "achieved": roof4["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": roof4["gbs"] / HBM_PEAK_GBS,
+                           "kernel": VERIFY_KERNEL, "bytes_per_launch": roof4["avg_bytes"], "us_per_launch": roof4["avg_us"],
+                           "rows_per_launch": roof4["avg_rows"], "launches": roof4["launches"],
+                           "by_rank": {"frac": jd.spread((x["verify_gbs"] / HBM_PEAK_GBS) if x.get("verify_gbs") else None for x in records4),
+                                       "us_per_launch": jd.spread(x.get("verify_us") for x in records4)},
+                           "note": f"rank 0's launches; {P4} prompts per launch: the latency regime of the convergence launch "
+                                   "(roofline_by_shape of a 1-GPU run shows the same shape), not the 64-prompt stream of the headline"}
+        out["loop_body"] = {"body_us_per_step": roof4["body_us"], "gpu_idle_us_median": roof4["idle_us_median"],
+                            "host_gap_us_median": roof4["host_gap_us_median"]}
+    return out
+
+
 def rank_record(info, dev_index: int, r: dict, roof) -> dict:
     """One rank's evidence for the line's `per_rank` list: who it is (rank, pid, host, the GPU's PCI bus id / UUID as the HIP
     library reports it), what it did in the timed window (tokens, iterations, seconds) and how its convergence launch and the
@@ -637,6 +687,8 @@ def main():
     ap.add_argument("--model", default=os.environ.get("JF_MODEL", "qwen2.5-coder-7b"), help="qwen2.5-coder-7b | tiny | <hf dir>")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=float(os.environ.get("JF_CPU_BASELINE_S", "20")))
     ap.add_argument("--no-scripted", action="store_true")
+    ap.add_argument("--config4-prompts", type=int, default=64, help="with --gpus N > 1 and weak scaling: also decode this many prompts sharded "
+                    "N-way in the same process group (BASELINE config 4 as it is stated) -> config4_strong64 on the line; 0 = skip")
     ap.add_argument("--no-sections", action="store_true", help="skip the config 2 / config 5 / vs-AR sections of the line")
     ap.add_argument("--no-other-timing", action="store_true", help="skip the short extra window that times the launch the other way (roofline.other_timing)")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the untimed pass that loads the window's library kernels")
@@ -781,6 +833,10 @@ def main():
                                    us_per_launch=rs["avg_us"], achieved=rs["gbs"], frac=rs["gbs"] / HBM_PEAK_GBS,
                                    launches=rs["launches"], body_us_per_step=rs["body_us"], gpu_idle_us_per_step=rs["idle_us"],
                                    gpu_idle_us_median=rs["idle_us_median"]))
+    # ---- N > 1, weak scaling (the driver's plain invocation): config 4 as BASELINE states it, in the same process group
+    config4 = None
+    if info.world_size > 1 and not strong and args.config4_prompts > 0 and args.config4_prompts % info.world_size == 0:
+        config4 = config4_window(model, cfg, prm, tuned, args, info, dev, dev_index, args.config4_prompts, vocab_hi)
     out = None
     if info.rank == 0:
         steps_done = max(int(round(agg["iterations"] / info.world_size)), 1)
@@ -868,6 +924,8 @@ def main():
                                         "shapes": shapes}
         if scripted is not None:
             out["scripted_acceptance"] = scripted
+        if config4 is not None:
+            out["config4_strong64"] = config4
     if out is not None and info.world_size == 1 and not args.no_sections:
         del dec
         torch.cuda.empty_cache()

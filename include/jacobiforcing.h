@@ -434,7 +434,10 @@ typedef struct jf_sb_desc {
 JF_API int jf_sb_step(int64_t *out, int L, uint64_t *packed, int32_t eos_id, int32_t total, int32_t cap, int64_t *acc_buf,
                int32_t kv_before, jf_sb_desc *desc, void *stream);
 
-/* Caller side of the batched forward when the KV cache is PAGED as in the reference
+/* BOUNDARY-ONLY EXPORT: this package never calls it — its own forward keeps one contiguous cache row per request
+ * (engine/model_runner.py LoopForward reads positions / cached lengths from jf_engine_loop's arrays) — it is here for a
+ * reference-side caller that keeps the PAGED cache and varlen attention of inference_engine (route 1).
+ * Caller side of the batched forward when the KV cache is PAGED as in the reference
  * (MR:1204-1265 "jacobi.buffer_fill" + _get_slot_mapping_pattern MR:965-986): for B sequences of
  * committed length S_i (seq_len, >= 1) and a draft [B, L] (column 0 = the cached seed), fill
  *   input_ids [B*L] int64, positions [B*L] int64 (S_i - 1 + j),
@@ -597,7 +600,8 @@ JF_API int jf_rs_onpolicy_step(const void *logits, int dtype, int64_t V, int64_t
                         const float *u_stream, int64_t u_len, int64_t *u_cursor,
                         const float *m_stream, int64_t m_len, int64_t *m_cursor,
                         int64_t *committed /* [R] */, int64_t *redraft /* [R] */, jf_op_row *row,
-                        void *workspace /* jf_rs_step_workspace_bytes(R) */, size_t workspace_bytes, void *stream);
+                        void *workspace /* jf_rs_step_workspace_bytes(R) */, size_t workspace_bytes,
+                        const jf_rs_filter_row *filt /* nullable: jf_rs_filter's records of the R rows */, void *stream);
 
 #ifdef __cplusplus
 }

@@ -79,6 +79,16 @@ class RsRow(C.Structure):
                                          "active_next", "rsv")]
 
 
+class RsFilterRow(C.Structure):
+    """jf_rs_filter_row (include/jacobiforcing.h): what top-k / top-p make of one row, as a function of (probability, id)."""
+    _fields_ = [("sum", C.c_double), ("row_max", C.c_float), ("x_keep", C.c_float), ("cut1", C.c_uint32), ("tie1", C.c_int32),
+                ("s1", C.c_float), ("cut2", C.c_uint32), ("tie2", C.c_int32), ("s2", C.c_float), ("flags", C.c_uint32),
+                ("rsv", C.c_uint32)]
+
+
+RS_FILTER_ROW_BYTES = C.sizeof(RsFilterRow)
+RS_FILTER_FLAGS_WORD = RsFilterRow.flags.offset // 4
+RS_FILT_TOPK, RS_FILT_TOPP = 1, 2
 RS_ROW_INTS = C.sizeof(RsRow) // 4
 RS_FIELDS = [f[0] for f in RsRow._fields_]
 
@@ -147,13 +157,15 @@ _SIGNATURES = {
     "jf_engine_loop_commit": (C.c_int, [C.POINTER(EngineLoop), _i32, _vp]),
     "jf_engine_fill": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "jf_rs_probs": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "jf_rs_filter": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _vp, _f32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "jf_rs_filter_workspace_bytes": (_sz, [C.c_int, _i64, _i64]),
+    "jf_rs_filter": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _vp, _f32, _i32, C.c_double, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "jf_rs_filter_expand": (C.c_int, [_vp, C.c_int, _i64, _i64, _i64, _f32, _vp, _vp, _vp]),
     "jf_rs_workspace_bytes": (_sz, [_i64, _i64]),
     "jf_rs_step": (C.c_int, [_vp, C.c_int, _i64, _i64, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _f32, _i32, _vp,
-                             _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+                             _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "jf_rs_step_workspace_bytes": (_sz, [_i64]),
     "jf_rs_onpolicy_step": (C.c_int, [_vp, C.c_int, _i64, _i64, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_float, _vp, C.c_int,
-                                      _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+                                      _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -503,7 +503,7 @@ static int verify_launch(const void *logits, int dtype, int64_t R, int64_t V, in
     // Timing events: attached to THIS dispatch (its start / stop timestamps — what rocprofv3 reports as the kernel's duration)
     // unless JF_VERIFY_EVENTS=bracket asks for hipEventRecord in front of and behind the launch (the launch + two event packets:
     // ~3-4 us more, the figure of rounds 1-3 and of this round's earlier sessions)
-    const bool bracket = jf_timing_bracket();
+    const bool bracket = (ev_begin || ev_end) && jf_timing_bracket();      // (the environment is read by TIMED calls only)
     bool launched = false;
     if ((ev_begin || ev_end) && !bracket) {
         void *kargs[] = {(void *)&a};

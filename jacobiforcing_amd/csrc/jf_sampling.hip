@@ -754,6 +754,7 @@ struct RsWs {                                     // carve-up of the step worksp
     uint32_t *ivdone;                             // [rows] gen: iv is stored (by the workgroup of the row's segment 0, for the chain)
     float *segmax;                                // [rows, RS_SEG] largest scaled logit of each segment (phase A; -inf: empty) — the masked argmax starts from these
     uint32_t *acceptdone;                         // [4]   gen: [0] the accept workgroup has written every row record, [1] the chain workgroup every draw count
+    const jf_rs_filter_row *filt;                 // (not in the workspace) jf_rs_filter's records of the rows, null: plain distributions
 };
 static inline size_t rs_ws_bytes(int64_t rows) {
     const size_t r = (size_t)((rows + 3) / 4 * 4);
@@ -781,6 +782,7 @@ __host__ __device__ inline RsWs rs_ws(void *ws, int64_t rows) {
     w.ivdone = w.segdone + r * RS_SEG;
     w.segmax = (float *)(w.ivdone + r);
     w.acceptdone = (uint32_t *)(w.segmax + r * RS_SEG);
+    w.filt = nullptr;
     return w;
 }
 extern "C" size_t jf_rs_step_workspace_bytes(int64_t rows) { return rows > 0 ? rs_ws_bytes(rows) : 0; }
@@ -1025,8 +1027,17 @@ __device__ float rs_exact_prob_wg(const void *logits, int64_t r, int64_t V, int6
 //   order     every float64 sum is formed in a fixed order (a thread's words in its rotated order, the DPP wave scan, the 16
 //             wavefronts in order): the record does not depend on scheduling.
 // ------------------------------------------------------------------------------------------------
-constexpr int FH_TPB = 1024, FH_NW = FH_TPB / 64, FH_WORDS = 32768, FH_OVF = 8, FH_TILE = FH_TPB * 8, FH_MAX_TILES = 64;
-constexpr unsigned FH_LDS = FH_WORDS * 4;
+#ifdef JF_EXP_FLT_TRACE
+__device__ unsigned long long g_fhtrace[16];
+extern "C" __attribute__((visibility("default"))) int jf_exp_fh_trace(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fhtrace), sizeof(g_fhtrace)) == hipSuccess ? 0 : -1;
+}
+#define FH_STAMP(k) do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) g_fhtrace[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FH_STAMP(k) do { } while (0)
+#endif
+constexpr int FH_TPB = 1024, FH_NW = FH_TPB / 64, FH_WORDS = 32768, FH_OVF = 8, FH_TILE = FH_TPB * 8, FH_MAX_TILES = 64, FH_ITEMS = 4096;
+constexpr unsigned FH_LDS = FH_WORDS * 4 + FH_ITEMS * 4 + FH_ITEMS * 2;      // counters + the list of occupied patterns + their probabilities
 struct FhShared {
     double tab[64];
     double dred[FH_NW];
@@ -1049,12 +1060,14 @@ __device__ __forceinline__ uint32_t fh_count(const FhShared &sh, const uint32_t 
     return c;
 }
 // workgroup sums in a fixed order (every thread gets them); `incl` = this thread's inclusive prefix over the thread ids
-__device__ __forceinline__ void fh_scan(FhShared &sh, long long &cnt, double &sum, long long &cnt_incl, double &sum_incl) {
+__device__ __forceinline__ void fh_scan(FhShared &sh, long long &cnt, double &sum, long long &cnt_incl, double &sum_incl, long long &cnt_excl, double &sum_excl) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double si = wave_incl_scan_f64(sum, lane);
+    const double su = wave_shift_up_f64(si, lane);                          // (the exclusive prefix is the neighbour's inclusive one: the two agree bit for bit)
     long long ci = cnt;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const long long o = __shfl_up(ci, off, 64); if (lane >= off) ci += o; }
+    const long long cu = ci - cnt;
     __syncthreads();
     if (lane == 63) { sh.dred[wave] = si; sh.lred[wave] = ci; }
     __syncthreads();
@@ -1063,11 +1076,23 @@ __device__ __forceinline__ void fh_scan(FhShared &sh, long long &cnt, double &su
 #pragma unroll
     for (int w = 0; w < FH_NW; ++w) { if (w == wave) { sb = st; cb = ct; } st += sh.dred[w]; ct += sh.lred[w]; }
     cnt_incl = cb + ci; sum_incl = sb + si;
+    cnt_excl = cb + cu; sum_excl = sb + su;
     cnt = ct; sum = st;
 }
 __device__ __forceinline__ void fh_reduce(FhShared &sh, long long &cnt, double &sum) {
-    long long ci; double si;
-    fh_scan(sh, cnt, sum, ci, si);
+    long long ci, ce; double si, se;
+    fh_scan(sh, cnt, sum, ci, si, ce, se);
+}
+__device__ __forceinline__ void fh_min_max2(FhShared &sh, int &lo, int &hi) {             // workgroup minimum of lo and maximum of hi (every thread gets them)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const int a = __shfl_xor(lo, off, 64), b = __shfl_xor(hi, off, 64); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sh.scan[threadIdx.x >> 6] = lo; sh.scan[FH_NW + (threadIdx.x >> 6)] = hi; }
+    __syncthreads();
+    lo = sh.scan[0]; hi = sh.scan[FH_NW];
+#pragma unroll
+    for (int w = 1; w < FH_NW; ++w) { const int a = sh.scan[w], b = sh.scan[FH_NW + w]; lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+    __syncthreads();
 }
 __device__ __forceinline__ int fh_min_max(FhShared &sh, int v, bool want_max) {          // workgroup min / max of an int (every thread gets it)
 #pragma unroll
@@ -1119,115 +1144,140 @@ __device__ __forceinline__ void fh_count_row(FhShared &sh, uint32_t *hist, const
     __syncthreads();
 }
 
-struct FhStage { uint32_t cut; int32_t tie; float s; };
-__global__ __launch_bounds__(FH_TPB, 1) void rs_filter_hist_kernel(const void *logits, int64_t R, int64_t V, int64_t row_stride, const int64_t *draft_next,
-                                                                    float t, int top_k, double top_p, jf_rs_filter_row *filt, float *p_draft,
-                                                                    float *row_max, float *row_sumexp) {
-    constexpr int EPV = 8;
-    __shared__ FhShared sh;
-    extern __shared__ __attribute__((aligned(16))) unsigned char fh_dyn[];
-    uint32_t *hist = (uint32_t *)fh_dyn;
-    const int tid = threadIdx.x;
-    const int64_t r = blockIdx.x;
-    const float M = row_max[r];
-    jf_rs_filter_row rec;
-    rec.sum = 0.0; rec.row_max = M; rec.x_keep = -INFINITY; rec.cut1 = 0u; rec.tie1 = (int32_t)V - 1; rec.s1 = 1.f; rec.cut2 = 0u; rec.tie2 = (int32_t)V - 1; rec.s2 = 1.f;
-    const bool k_on = top_k > 0 && (int64_t)top_k < V, p_on = top_p > 0.0 && top_p < 1.0;
-    rec.flags = (k_on ? JF_RS_FILT_TOPK : 0u) | (p_on ? JF_RS_FILT_TOPP : 0u); rec.rsv = 0u;
-    const bool finite = (__float_as_uint(M) & 0x7F800000u) != 0x7F800000u;
-    auto finish = [&](float pd) {
-        if (tid == 0) { filt[r] = rec; p_draft[r] = pd; row_max[r] = INFINITY; row_sumexp[r] = RS_PROB_ROW; }
-    };
-    if (!finite) { finish(0.f); return; }                                    // NaN / inf logits: the row filters to zeros (sum = 0)
-    const RsRow row = rs_make_row<JF_BF16>(logits, r, V, row_stride, t, M, 1.f);
-    rs_load_tab(sh.tab);
-    // ---- 1. the counts
-    for (int w = tid; w < FH_WORDS; w += FH_TPB) hist[w] = 0u;
-    if (tid == 0) { sh.n_ovf = 0; sh.ovf_seen = 0; }
-    if (tid < FH_OVF) sh.ovf_cnt[tid] = 0u;
-    __syncthreads();
-    fh_count_row<false>(sh, hist, row);
-    if (sh.ovf_seen) {                                                       // (workgroup-uniform) a counter wrapped: count again with side counters
-        __syncthreads();
-        if (tid == 0) {                                                      // the distinct keys seen wrapping (<= 2 real ones + neighbours seen mid-carry)
-            int n = sh.ovf_seen < FH_OVF ? sh.ovf_seen : FH_OVF, m = 0;
-            for (int i = 0; i < n; ++i) { bool dup = false; for (int q = 0; q < m; ++q) dup |= sh.ovf_key[q] == sh.ovf_key[i]; if (!dup) sh.ovf_key[m++] = sh.ovf_key[i]; }
-            sh.n_ovf = m; sh.ovf_seen = 0;
+// the row streamed once, fast: plain (non-returning) LDS adds; the thread's number of counted elements comes back for the checksum
+// that notices a wrapped counter afterwards (sum of the counters != elements counted)
+__device__ __forceinline__ uint32_t fh_count_row_fast(uint32_t *hist, const RsRow &row) {
+    constexpr int EPV = 8, NB = 8;
+    const float mcut = row.M + (float)RS_EXP_CUT;
+    uint32_t mine = 0u;
+    for (int64_t b0 = (int64_t)threadIdx.x * EPV; b0 < row.V; b0 += (int64_t)NB * FH_TPB * EPV) {
+        u32x4 v[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) { const int64_t e0 = b0 + (int64_t)k * FH_TPB * EPV; if (e0 < row.V) v[k] = rs_load_vec<JF_BF16>(row, e0); }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int64_t e0 = b0 + (int64_t)k * FH_TPB * EPV;
+            if (e0 >= row.V) continue;
+            float xs[EPV];
+            rs_scaled_from_vec<JF_BF16>(row, v[k], xs);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) {
+                if (xs[j] >= mcut) {                                       // (slots beyond V hold -inf)
+                    const uint32_t key = fh_key(__float_as_uint(xs[j]) >> 16);
+                    atomicAdd(&hist[key >> 1], (key & 1u) ? 0x10000u : 1u);
+                    ++mine;
+                }
+            }
         }
-        for (int w = tid; w < FH_WORDS; w += FH_TPB) hist[w] = 0u;
-        __syncthreads();
-        fh_count_row<true>(sh, hist, row);
     }
-    // a thread's patterns, in its rotated word order (conflict-free): f(key, count) for the occupied ones
+    __syncthreads();
+    return mine;
+}
+
+// What top-k / top-p make of the row, from its pattern counts.  FAST: the occupied patterns as a compact list in LDS, largest value
+// first — item i = occ[i] = key << 16 | count, its probability's bf16 bits in pc[i]; a thread owns `ipt` consecutive items.  !FAST:
+// the counters themselves, a thread owns 64 consecutive patterns (rows with more than FH_ITEMS occupied patterns, or a pattern that
+// occurs more than 65 535 times).  The stages are written once over "this thread's items" (any order) and "this thread's items,
+// largest value first".
+template <bool FAST>
+__device__ __forceinline__ float fh_solve(FhShared &sh, const uint32_t *hist, const uint32_t *occ, uint16_t *pc, int n_occ, const RsRow &row, int64_t r,
+                                          int64_t V, const int64_t *draft_next, int top_k, double top_p, bool k_on, bool p_on, jf_rs_filter_row &rec) {
+    constexpr int EPV = 8;
+    const int tid = threadIdx.x;
+    const float M = row.M;
     const uint32_t kbase = 65536u - 64u * (uint32_t)(tid + 1);
+    const int ipt = (n_occ + FH_TPB - 1) / FH_TPB, i0 = tid * ipt, i1 = i0 + ipt < n_occ ? i0 + ipt : n_occ;
+    // f(key, count, item) over this thread's occupied patterns (the counters: in the thread's rotated word order, conflict-free)
     auto for_mine = [&](auto f) {
+        if constexpr (FAST) {
+            for (int i = i0; i < i1; ++i) { const uint32_t w = occ[i]; f(w >> 16, w & 0xFFFFu, i); }
+        } else {
 #pragma unroll 4
-        for (int i = 0; i < 32; ++i) {
-            const uint32_t wi = (uint32_t)(i + tid) & 31u;
-            const uint32_t w = hist[(kbase >> 1) + wi];
-            if (w == 0u && sh.n_ovf == 0) continue;
-            const uint32_t k0 = kbase + 2u * wi;
-            const uint32_t c0 = fh_count(sh, hist, k0), c1 = fh_count(sh, hist, k0 + 1u);
-            if (c0) f(k0, c0);
-            if (c1) f(k0 + 1u, c1);
+            for (int i = 0; i < 32; ++i) {
+                const uint32_t wi = (uint32_t)(i + tid) & 31u;
+                const uint32_t w = hist[(kbase >> 1) + wi];
+                if (w == 0u && sh.n_ovf == 0) continue;
+                const uint32_t k0 = kbase + 2u * wi;
+                const uint32_t c0 = fh_count(sh, hist, k0), c1 = fh_count(sh, hist, k0 + 1u);
+                if (c0) f(k0, c0, 0);
+                if (c1) f(k0 + 1u, c1, 0);
+            }
         }
     };
-    // ---- 2. the exact sum, then every pattern's probability on demand
+    // the same, largest value first, until f returns true
+    auto walk_mine = [&](auto f) {
+        if constexpr (FAST) {
+            for (int i = i0; i < i1; ++i) { const uint32_t w = occ[i]; if (f(w >> 16, w & 0xFFFFu, i)) break; }
+        } else {
+            for (int key = (int)kbase + 63; key >= (int)kbase; --key) {
+                const uint32_t n = fh_count(sh, hist, (uint32_t)key);
+                if (n && f((uint32_t)key, n, 0)) break;
+            }
+        }
+    };
+    // ---- the exact sum, then every pattern's probability (FAST: kept per item)
     long long cnt = 0;
     double sum = 0.0;
-    for_mine([&](uint32_t key, uint32_t c) { sum += (double)c * rs_e64(fh_value(key), (double)M, sh.tab); });
+    for_mine([&](uint32_t key, uint32_t c, int) { sum += (double)c * rs_e64(fh_value(key), (double)M, sh.tab); });
     fh_reduce(sh, cnt, sum);
     const double S = sum, invS = 1.0 / S;                                  // (S >= 1: the maximum itself contributes exp(0))
     rec.sum = S;
-    auto P = [&](uint32_t key) { return rs_bf16_of_f64(rs_e64(fh_value(key), (double)M, sh.tab) * invS); };
+    if constexpr (FAST) {
+        for (int i = i0; i < i1; ++i) pc[i] = (uint16_t)(__float_as_uint(rs_bf16_of_f64(rs_e64(fh_value(occ[i] >> 16), (double)M, sh.tab) * invS)) >> 16);
+        __syncthreads();
+    }
+    FH_STAMP(3);
+    auto P = [&](uint32_t key, int i) {
+        if constexpr (FAST) return __uint_as_float((uint32_t)pc[i] << 16);
+        else return rs_bf16_of_f64(rs_e64(fh_value(key), (double)M, sh.tab) * invS);
+    };
     const float floor_d = rs_round_prob<JF_BF16>(1e-12);                    // sum.clamp_min(1e-12) in the dtype
-    // counts and sums of the patterns whose value f(key) lies above / at a bit pattern: (n above, their sum, n at, key range at)
+    // counts and sums of the patterns whose value val(key, item) lies above / at a bit pattern: (n above, their sum, n at, key range at)
     auto query = [&](auto val, uint32_t at_bits, long long &n_gt, double &s_gt, long long &n_eq, int &k_lo, int &k_hi) {
         long long ng = 0, ne = 0;
         double sg = 0.0;
         int lo = 0x7FFFFFFF, hi = -1;
-        for_mine([&](uint32_t key, uint32_t c) {
-            const float v = val(key);
+        for_mine([&](uint32_t key, uint32_t c, int i) {
+            const float v = val(key, i);
             const uint32_t b = __float_as_uint(v);
             if (b > at_bits) { ng += c; sg += (double)c * (double)v; }
             else if (b == at_bits && b != 0u) { ne += c; lo = (int)key < lo ? (int)key : lo; hi = (int)key > hi ? (int)key : hi; }
         });
-        double unused = 0.0;
-        fh_reduce(sh, ne, unused);
-        fh_reduce(sh, ng, sg);
-        k_lo = fh_min_max(sh, lo, false); k_hi = fh_min_max(sh, hi, true);
+        long long both = ng | (ne << 32);                                    // (each below 2^20: one reduction carries the two counts)
+        fh_reduce(sh, both, sg);
+        ng = both & 0xFFFFFFFFll; ne = both >> 32;
+        fh_min_max2(sh, lo, hi);
+        k_lo = lo; k_hi = hi;
         n_gt = ng; s_gt = sg; n_eq = ne;
     };
     // the first thread (largest values first) at which pred(inclusive count, inclusive sum) holds walks its patterns downwards and
-    // returns the first key at which it holds; -1: nowhere.  pred is monotone along the walk.
+    // returns the first key at which it holds (and that item's value in sh.bd[0]); -1: nowhere.  pred is monotone along the walk.
     auto locate = [&](auto val, auto pred) -> int {
-        long long c = 0, ci;
-        double s = 0.0, si;
-        for_mine([&](uint32_t key, uint32_t n) { const float v = val(key); if (v > 0.f) { c += n; s += (double)n * (double)v; } });
-        const long long cm = c;
-        const double sm = s;
-        fh_scan(sh, c, s, ci, si);
+        long long c = 0, ci, ce;
+        double s = 0.0, si, se;
+        for_mine([&](uint32_t key, uint32_t n, int i) { const float v = val(key, i); if (v > 0.f) { c += n; s += (double)n * (double)v; } });
+        fh_scan(sh, c, s, ci, si, ce, se);
         if (tid == 0) sh.bi[0] = -1;
         __syncthreads();
-        if (pred(ci, si) && !pred(ci - cm, si - sm)) {                      // the crossing lies in this thread's patterns
-            long long cc = ci - cm;
-            double ss = si - sm;                                            // (the prefix above this thread; the walk below re-forms the thread's own sum in key order)
-            for (int key = (int)kbase + 63; key >= (int)kbase; --key) {
-                const uint32_t n = fh_count(sh, hist, (uint32_t)key);
-                if (!n) continue;
-                const float v = val((uint32_t)key);
-                if (!(v > 0.f)) continue;
-                cc += n; ss += (double)n * (double)v;
-                if (pred(cc, ss)) { sh.bi[0] = key; break; }
-            }
-            if (sh.bi[0] < 0) sh.bi[0] = (int)kbase;                        // (rounding of the re-formed sum only)
+        if (pred(ci, si) && !pred(ce, se)) {                                // the crossing lies in this thread's patterns
+            long long cc = ce;
+            double ss = se;                                                 // (the prefix above this thread; the walk re-forms the thread's own sum in key order)
+            int last = -1;
+            float vlast = 0.f;
+            walk_mine([&](uint32_t key, uint32_t n, int i) {
+                const float v = val(key, i);
+                if (!(v > 0.f)) return false;
+                cc += n; ss += (double)n * (double)v; last = (int)key; vlast = v;
+                return pred(cc, ss);
+            });
+            sh.bi[0] = last; sh.bd[0] = (double)vlast;                      // (pred(ci, si) held: the walk ends on a crossing, or — rounding of the re-formed sum only — on its last item)
         }
         __syncthreads();
         const int k = sh.bi[0];
         __syncthreads();
         return k;
     };
-    // ---- 3. top-k (JDN:73-84): the k-th largest probability, the ids above it, `need1` ids at it
+    // ---- top-k (JDN:73-84): the k-th largest probability, the ids above it, `need1` ids at it
     uint32_t v1 = 0u;                                                       // bits of the cut value (0: every id is kept)
     long long need1 = 0, n_eq1 = 0;
     int ka1 = 0x7FFFFFFF, kb1 = -1;                                         // keys of the cut group
@@ -1235,7 +1285,7 @@ __global__ __launch_bounds__(FH_TPB, 1) void rs_filter_hist_kernel(const void *l
     if (k_on) {
         const int kk = locate(P, [&](long long c, double) { return c >= (long long)top_k; });
         if (kk >= 0) {
-            v1 = __float_as_uint(P((uint32_t)kk));
+            v1 = __float_as_uint((float)sh.bd[0]);
             long long n_gt; double s_gt;
             query(P, v1, n_gt, s_gt, n_eq1, ka1, kb1);
             need1 = (long long)top_k - n_gt;
@@ -1249,14 +1299,15 @@ __global__ __launch_bounds__(FH_TPB, 1) void rs_filter_hist_kernel(const void *l
         s1 = s1 > floor_d ? s1 : floor_d;
     }
     rec.cut1 = v1; rec.s1 = s1;
+    FH_STAMP(4);
     const float yv = v1 ? flt_div<JF_BF16>(__uint_as_float(v1), s1) : 0.f;   // what a kept id of the cut group becomes
     // y of a pattern: 0 at and below the cut (the cut group's kept ids enter the sums below as need1 x yv)
-    auto Y = [&](uint32_t key) {
-        const float p = P(key);
+    auto Y = [&](uint32_t key, int i) {
+        const float p = P(key, i);
         if (!k_on) return p;
         return __float_as_uint(p) > v1 ? flt_div<JF_BF16>(p, s1) : 0.f;
     };
-    // ---- 4. top-p (JDN:91-107) on y
+    // ---- top-p (JDN:91-107) on y
     uint32_t v2 = 0u;
     long long c2 = 0, n_eq2 = 0;                                            // ids kept of the group at the cut / ids in that group
     int ka2 = 0x7FFFFFFF, kb2 = -1;
@@ -1264,22 +1315,23 @@ __global__ __launch_bounds__(FH_TPB, 1) void rs_filter_hist_kernel(const void *l
     float s2 = 1.f;
     bool all2 = true;
     if (p_on) {
-        const float tp = rs_round_prob<JF_BF16>(top_p);                     // `cdf <= tp`: the Python float is cast to the tensor's dtype
+        const float tp = rs_round_prob<JF_BF16>((double)(float)top_p);      // `cdf <= tp`: the Python float is cast to the tensor's dtype
         long long n_all, ne; double s_all; int a, b;
         query(Y, 0u, n_all, s_all, ne, a, b);
         const double total = s_all + (double)need1 * (double)yv;
         all2 = rs_round_prob<JF_BF16>(total) <= tp;
+        int kk = -1;
+        // the group the cut falls into: the largest value whose cumulative sum (everything >= it), rounded, exceeds tp
+        if (!all2) kk = locate(Y, [&](long long, double s) { return !(rs_round_prob<JF_BF16>(s) <= tp); });
+        if (!all2 && kk < 0 && need1 == 0) all2 = true;                     // (rounding between the two orders of the same sum only)
         if (all2) s2 = rs_round_prob<JF_BF16>(total);
         else {
-            // the group the cut falls into: the largest value whose cumulative sum (everything >= it), rounded, exceeds tp
-            const int kk = locate(Y, [&](long long, double s) { return !(rs_round_prob<JF_BF16>(s) <= tp); });
-            const float y2 = kk >= 0 ? Y((uint32_t)kk) : yv;                // nowhere above the top-k cut: the cut group itself
+            const float y2 = kk >= 0 ? (float)sh.bd[0] : yv;                // nowhere above the top-k cut: the cut group itself
             v2 = __float_as_uint(y2);
             long long n_whole; double c_whole;
             query(Y, v2, n_whole, c_whole, n_eq2, ka2, kb2);
             grp1_in2 = need1 > 0 && __float_as_uint(yv) == v2;
             if (grp1_in2) n_eq2 += need1;
-            else if (need1 > 0 && __float_as_uint(yv) > v2) { n_whole += need1; c_whole += (double)need1 * (double)yv; }   // (cannot happen: yv is the smallest y)
             long long lo = 0, hi = n_eq2;                                   // ids of the group whose own cumulative sum passes: pass(lo) holds, pass(hi) fails
             while (hi - lo > 1) { const long long m2 = lo + (hi - lo) / 2; if (rs_round_prob<JF_BF16>(c_whole + (double)m2 * (double)y2) <= tp) lo = m2; else hi = m2; }
             c2 = lo;
@@ -1289,7 +1341,8 @@ __global__ __launch_bounds__(FH_TPB, 1) void rs_filter_hist_kernel(const void *l
         s2 = s2 > floor_d ? s2 : floor_d;
     }
     rec.cut2 = v2; rec.s2 = s2;
-    // ---- 5. the last kept id of a cut group that is kept in part: the row a second time
+    FH_STAMP(5);
+    // ---- the last kept id of a cut group that is kept in part: the row a second time
     const bool tie1_needed = k_on && v1 && need1 < n_eq1;                   // else every id at the cut is kept (tie1 = V - 1)
     const bool tie2_needed = p_on && !all2 && c2 > 0 && c2 < n_eq2;
     if (p_on && !all2 && c2 == 0) rec.tie2 = -1;
@@ -1302,16 +1355,16 @@ __global__ __launch_bounds__(FH_TPB, 1) void rs_filter_hist_kernel(const void *l
         __syncthreads();
         // class A: keys of the top-k cut group; class B: keys above the top-k cut whose y equals the top-p cut (a key range: y is monotone)
         const int a_lo = ka1, a_hi = kb1, b_lo = ka2, b_hi = kb2;
-        auto classes = [&](const u32x4 vv, int64_t e0, int &na, int &nb, uint32_t &ma, uint32_t &mb) {
+        auto classes = [&](const u32x4 vv, int64_t e0, uint32_t &ma, uint32_t &mb) {
             float xs[EPV];
             rs_scaled_from_vec<JF_BF16>(row, vv, xs);
-            na = nb = 0; ma = mb = 0u;
+            ma = mb = 0u;
 #pragma unroll
             for (int j = 0; j < EPV; ++j) {
-                if (e0 + j >= V) continue;
                 const int key = (int)fh_key(__float_as_uint(xs[j]) >> 16);
-                const bool ia = key >= a_lo && key <= a_hi, ib = key >= b_lo && key <= b_hi;
-                na += ia; nb += ib; ma |= ia ? 1u << j : 0u; mb |= ib ? 1u << j : 0u;
+                const bool in = e0 + j < V;
+                ma |= (in && key >= a_lo && key <= a_hi) ? 1u << j : 0u;
+                mb |= (in && key >= b_lo && key <= b_hi) ? 1u << j : 0u;
             }
         };
         {
@@ -1322,16 +1375,17 @@ __global__ __launch_bounds__(FH_TPB, 1) void rs_filter_hist_kernel(const void *l
                 for (int k = 0; k < NB; ++k) { const int64_t e0 = (t0 + k) * FH_TILE + (int64_t)tid * EPV; if (t0 + k < ntiles && e0 < V) v[k] = rs_load_vec<JF_BF16>(row, e0); }
 #pragma unroll
                 for (int k = 0; k < NB; ++k) {
+                    if (t0 + k >= ntiles) continue;                          // (workgroup-uniform)
                     const int64_t e0 = (t0 + k) * FH_TILE + (int64_t)tid * EPV;
-                    if (t0 + k >= ntiles || e0 >= V) continue;
-                    int na, nb; uint32_t ma, mb;
-                    classes(v[k], e0, na, nb, ma, mb);
-                    if (na) atomicAdd(&sh.tileA[t0 + k], na);
-                    if (nb) atomicAdd(&sh.tileB[t0 + k], nb);
+                    uint32_t ma = 0u, mb = 0u;
+                    if (e0 < V) classes(v[k], e0, ma, mb);
+                    if (ma) atomicAdd(&sh.tileA[t0 + k], __popc(ma));             // (members of a cut group are few: an add per lane that holds one)
+                    if (mb) atomicAdd(&sh.tileB[t0 + k], __popc(mb));
                 }
             }
         }
         __syncthreads();
+        FH_STAMP(6);
         // the id of the c-th (1-based) member, in id order, of: class A ids (use_a, up to id a_max) and class B ids (use_b)
         auto nth = [&](long long c, bool use_a, int64_t a_max, bool use_b) -> int64_t {
             if (tid == 0) {
@@ -1339,7 +1393,12 @@ __global__ __launch_bounds__(FH_TPB, 1) void rs_filter_hist_kernel(const void *l
                 sh.bi[1] = -1;
                 for (int tl = 0; tl < (int)ntiles; ++tl) {
                     long long n = use_b ? sh.tileB[tl] : 0;
-                    if (use_a) { const int64_t t_lo = (int64_t)tl * FH_TILE; n += a_max >= t_lo + FH_TILE - 1 ? sh.tileA[tl] : a_max >= t_lo ? sh.bl[2] : 0; }
+                    if (use_a) {
+                        const int64_t t_lo = (int64_t)tl * FH_TILE;
+                        int64_t t_hi = t_lo + FH_TILE - 1;
+                        if (t_hi > V - 1) t_hi = V - 1;
+                        n += a_max >= t_hi ? sh.tileA[tl] : a_max >= t_lo ? sh.bl[2] : 0;
+                    }
                     if (before < c && c <= before + n) { sh.bi[1] = tl; sh.bl[0] = c - before; break; }
                     before += n;
                 }
@@ -1349,18 +1408,17 @@ __global__ __launch_bounds__(FH_TPB, 1) void rs_filter_hist_kernel(const void *l
             if (tl < 0) { __syncthreads(); return V - 1; }
             const long long rank = sh.bl[0];
             const int64_t e0 = (int64_t)tl * FH_TILE + (int64_t)tid * EPV;
-            int na = 0, nb = 0; uint32_t ma = 0u, mb = 0u;
-            if (e0 < V) classes(rs_load_vec<JF_BF16>(row, e0), e0, na, nb, ma, mb);
+            uint32_t ma = 0u, mb = 0u;
+            if (e0 < V) classes(rs_load_vec<JF_BF16>(row, e0), e0, ma, mb);
             uint32_t mm = use_b ? mb : 0u;
             if (use_a) for (int j = 0; j < EPV; ++j) if ((ma >> j & 1u) && e0 + j <= a_max) mm |= 1u << j;
-            long long mine = __popc(mm), ci;
-            double z = 0.0, zi;
-            long long tot = mine;
-            fh_scan(sh, tot, z, ci, zi);
+            long long mine = __popc(mm), ci, ce;
+            double z = 0.0, zi, ze;
+            fh_scan(sh, mine, z, ci, zi, ce, ze);
             if (tid == 0) sh.bl[1] = V - 1;
             __syncthreads();
-            if (ci - mine < rank && rank <= ci) {
-                long long seen = ci - mine;
+            if (ce < rank && rank <= ci) {
+                long long seen = ce;
                 for (int j = 0; j < EPV; ++j) if ((mm >> j & 1u) && ++seen == rank) { sh.bl[1] = e0 + j; break; }
             }
             __syncthreads();
@@ -1374,18 +1432,19 @@ __global__ __launch_bounds__(FH_TPB, 1) void rs_filter_hist_kernel(const void *l
             if (grp1_in2) {
                 // class A ids up to tie1 are members too: how many of them the tile that holds tie1 has (ids <= tie1), for nth()
                 const int64_t tl = tie1 / FH_TILE, e0 = tl * FH_TILE + (int64_t)tid * EPV;
-                int na = 0, nb = 0; uint32_t ma = 0u, mb = 0u;
-                if (e0 < V) classes(rs_load_vec<JF_BF16>(row, e0), e0, na, nb, ma, mb);
-                long long mine = 0, ci; double z = 0.0, zi;
+                uint32_t ma = 0u, mb = 0u;
+                if (e0 < V) classes(rs_load_vec<JF_BF16>(row, e0), e0, ma, mb);
+                long long mine = 0, ci, ce; double z = 0.0, zi, ze;
                 for (int j = 0; j < EPV; ++j) mine += ((ma >> j & 1u) && e0 + j <= tie1) ? 1 : 0;
-                fh_scan(sh, mine, z, ci, zi);
+                fh_scan(sh, mine, z, ci, zi, ce, ze);
                 if (tid == 0) sh.bl[2] = mine;
                 __syncthreads();
             }
             rec.tie2 = (int32_t)nth(c2, grp1_in2, tie1, true);
         }
     }
-    // ---- 6. nothing below this scaled logit is kept (the steps skip the exps below it), and the drafted id's final probability
+    FH_STAMP(7);
+    // ---- nothing below this scaled logit is kept (the steps skip the exps below it), and the drafted id's final probability
     {
         int klow = k_on && v1 ? ka1 : 0;
         if (p_on && !all2 && kb2 >= 0 && !grp1_in2) klow = ka2 > klow ? ka2 : klow;
@@ -1396,12 +1455,97 @@ __global__ __launch_bounds__(FH_TPB, 1) void rs_filter_hist_kernel(const void *l
         const int64_t tok = draft_next[r];
         if (tok >= 0 && tok < V) {
             const float xs = rs_scaled<JF_BF16>(load_f<JF_BF16>(row.p, tok), row.t, row.inv_t, row.unit_t, row.fast);
-            const float p = xs >= M + (float)RS_EXP_CUT ? P(fh_key(__float_as_uint(xs) >> 16)) : 0.f;
+            const float p = xs >= M + (float)RS_EXP_CUT ? rs_bf16_of_f64(rs_e64(xs, (double)M, sh.tab) * invS) : 0.f;
             pd = rs_filter_apply<JF_BF16>(rec, p, tok);
         }
     }
+    return pd;
+}
+
+__global__ __launch_bounds__(FH_TPB, 1) void rs_filter_hist_kernel(const void *logits, int64_t R, int64_t V, int64_t row_stride, const int64_t *draft_next,
+                                                                    float t, int top_k, double top_p, jf_rs_filter_row *filt, float *p_draft,
+                                                                    float *row_max, float *row_sumexp) {
+    __shared__ FhShared sh;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fh_dyn[];
+    uint32_t *hist = (uint32_t *)fh_dyn;
+    uint32_t *occ = hist + FH_WORDS;                                        // [FH_ITEMS] the occupied patterns, largest value first
+    uint16_t *pc = (uint16_t *)(occ + FH_ITEMS);                            // [FH_ITEMS] their probabilities (bf16 bits)
+    const int tid = threadIdx.x;
+    const int64_t r = blockIdx.x;
+    const float M = row_max[r];
+    jf_rs_filter_row rec;
+    rec.sum = 0.0; rec.row_max = M; rec.x_keep = -INFINITY; rec.cut1 = 0u; rec.tie1 = (int32_t)V - 1; rec.s1 = 1.f; rec.cut2 = 0u; rec.tie2 = (int32_t)V - 1; rec.s2 = 1.f;
+    const bool k_on = top_k > 0 && (int64_t)top_k < V, p_on = top_p > 0.0 && top_p < 1.0;
+    rec.flags = (k_on ? JF_RS_FILT_TOPK : 0u) | (p_on ? JF_RS_FILT_TOPP : 0u); rec.rsv = 0u;
+    const bool finite = (__float_as_uint(M) & 0x7F800000u) != 0x7F800000u;
+    auto finish = [&](float pd) {
+        if (tid == 0) { filt[r] = rec; p_draft[r] = pd; row_max[r] = INFINITY; row_sumexp[r] = RS_PROB_ROW; }
+    };
+    if (!finite) { finish(0.f); return; }                                    // NaN / inf logits: the row filters to zeros (sum = 0)
+    const RsRow row = rs_make_row<JF_BF16>(logits, r, V, row_stride, t, M, 1.f);
+    FH_STAMP(0);
+    rs_load_tab(sh.tab);
+    // ---- 1. the counts (plain adds)
+    for (int w = tid; w < FH_WORDS; w += FH_TPB) hist[w] = 0u;
+    if (tid == 0) { sh.n_ovf = 0; sh.ovf_seen = 0; }
+    if (tid < FH_OVF) sh.ovf_cnt[tid] = 0u;
+    __syncthreads();
+    FH_STAMP(1);
+    const uint32_t counted = fh_count_row_fast(hist, row);
+    FH_STAMP(2);
+    // ---- 2. the occupied patterns as a list, largest value first; the checksum that notices a wrapped 16-bit counter
+    const uint32_t kbase = 65536u - 64u * (uint32_t)(tid + 1);
+    long long n_mine = 0, in_hist = 0;
+    unsigned long long occ_mask = 0ull;                                      // bit b: this thread's pattern kbase + b is occupied
+#pragma unroll 4
+    for (int i = 0; i < 32; ++i) {
+        const uint32_t wi = (uint32_t)(i + tid) & 31u;                       // (rotated: conflict-free)
+        const uint32_t w = hist[(kbase >> 1) + wi];
+        n_mine += ((w & 0xFFFFu) ? 1 : 0) + ((w >> 16) ? 1 : 0);
+        in_hist += (w & 0xFFFFu) + (w >> 16);
+        occ_mask |= ((w & 0xFFFFu) ? 1ull : 0ull) << (2u * wi) | ((w >> 16) ? 2ull : 0ull) << (2u * wi);
+    }
+    long long tot_counted = counted, ci, ce;
+    double d0 = 0.0, d1 = 0.0, di, de;
+    fh_reduce(sh, tot_counted, d0);
+    fh_reduce(sh, in_hist, d1);
+    long long n_occ = n_mine;
+    fh_scan(sh, n_occ, d0, ci, di, ce, de);
+    const bool wrapped = in_hist != tot_counted;                             // (workgroup-uniform)
+    float pd;
+    if (!wrapped && n_occ <= FH_ITEMS) {
+        // this thread's patterns behind everything above them, largest first: a pattern's place is the number of occupied ones above
+        // it in the thread's block (the mask), so the words can be read in the rotated order again
+#pragma unroll 4
+        for (int i = 0; i < 32; ++i) {
+            const uint32_t wi = (uint32_t)(i + tid) & 31u;
+            const uint32_t w = hist[(kbase >> 1) + wi];
+            if (w == 0u) continue;
+            const uint32_t b0 = 2u * wi;
+            if (w & 0xFFFFu) occ[(int)ce + __popcll(b0 + 1u < 64u ? occ_mask >> (b0 + 1u) : 0ull)] = ((kbase + b0) << 16) | (w & 0xFFFFu);
+            if (w >> 16) occ[(int)ce + __popcll(b0 + 2u < 64u ? occ_mask >> (b0 + 2u) : 0ull)] = ((kbase + b0 + 1u) << 16) | (w >> 16);
+        }
+        __syncthreads();
+        pd = fh_solve<true>(sh, hist, occ, pc, (int)n_occ, row, r, V, draft_next, top_k, top_p, k_on, p_on, rec);
+    } else {
+        if (wrapped) {                                                       // count again, noticing the wraps; then once more with side counters for those patterns
+            for (int w = tid; w < FH_WORDS; w += FH_TPB) hist[w] = 0u;
+            __syncthreads();
+            fh_count_row<false>(sh, hist, row);
+            if (tid == 0) {                                                  // the distinct keys seen wrapping (<= 8 real ones + neighbours seen mid-carry)
+                int n = sh.ovf_seen < FH_OVF ? sh.ovf_seen : FH_OVF, m = 0;
+                for (int i = 0; i < n; ++i) { bool dup = false; for (int q = 0; q < m; ++q) dup |= sh.ovf_key[q] == sh.ovf_key[i]; if (!dup) sh.ovf_key[m++] = sh.ovf_key[i]; }
+                sh.n_ovf = m; sh.ovf_seen = 0;
+            }
+            for (int w = tid; w < FH_WORDS; w += FH_TPB) hist[w] = 0u;
+            __syncthreads();
+            fh_count_row<true>(sh, hist, row);
+        }
+        pd = fh_solve<false>(sh, hist, occ, pc, 0, row, r, V, draft_next, top_k, top_p, k_on, p_on, rec);
+    }
     finish(pd);
 }
+
 // ------------------------------------------------------------------------------------------------
 // (a19, round 5) top-k / top-p filtering of the target distribution — _apply_top_k + _apply_top_p of _build_target_probs
 // (JDN:72-123; the reference reads both with getattr: they exist only on request objects a caller planted them on).
@@ -1756,17 +1900,18 @@ extern "C" __attribute__((visibility("default"))) int jf_exp_flt_trace(unsigned 
 #endif
 // HIST: 0 a pass over the row per bisection step, 1 bf16 value counts in LDS, 2 the float32 levels
 template <int DT, int HIST>
-__global__ __launch_bounds__(FLT_TPB, 4) void rs_filter_kernel(const void *logits,   // (4 waves per SIMD = two workgroups per CU — bf16: 2 x 67 KB of LDS —: <= 128 VGPRs)
+__global__ __launch_bounds__(FLT_TPB, 4) void rs_filter_kernel(const void *logits,   // (4 waves per SIMD = two workgroups per CU: <= 128 VGPRs)
                                                           int64_t R, int64_t V, int64_t row_stride, const int64_t *draft_next,
-                                                         float t, int top_k, float top_p, void *probs, float *p_draft, float *row_max,
-                                                         float *row_sumexp) {
+                                                         float t, int top_k, double top_p_d, void *probs /* scratch [R, V] */, jf_rs_filter_row *filt,
+                                                         float *p_draft, float *row_max, float *row_sumexp) {
+    const float top_p = (top_p_d > 0.0 && top_p_d < 1.0) ? 0.5f : 0.f;          // (only "is the stage on" below; the value is cast where it is compared)
     static_assert(HIST == 0 || (HIST == 1 && DT == JF_BF16) || (HIST == 2 && DT == JF_F32), "");
     constexpr int EPV = Elem<DT>::EPV;
     constexpr uint32_t STEP = DT == JF_F32 ? 1u : 0x10000u;                 // distance of two neighbouring values' keys
     constexpr uint32_t FLT_KEY_TOP = HIST == 2 ? 0x3F800000u + (1u << FLT_F32_SHIFT) : 0x3F800000u + STEP;   // a key above 1.0 on the (coarsest) key grid: no probability reaches it
     __shared__ FltShared sh;
-    extern __shared__ uint32_t flt_dyn[];
-    uint32_t *hist = HIST == 1 ? flt_dyn : nullptr;                          // bf16: the row's value counts (FLT_BINS words of dynamic LDS)
+    extern __shared__ __attribute__((aligned(16))) unsigned char flt_dyn[];   // (64-bit LDS atomics on it: ADVICE r05)
+    uint32_t *hist = HIST == 1 ? (uint32_t *)flt_dyn : nullptr;              // bf16: the row's value counts (FLT_BINS words of dynamic LDS)
     FltF32 f32;
     f32.hist = (unsigned long long *)flt_dyn; f32.subA = f32.hist + FLT_F32_BINS; f32.subB = (uint32_t *)(f32.subA + FLT_SUBA);
     f32.reset();
@@ -1808,6 +1953,9 @@ __global__ __launch_bounds__(FLT_TPB, 4) void rs_filter_kernel(const void *logit
     FLT_STAMP(0);
     const double S = finite ? flt_row_s64<DT>(sh, row) : 0.0;
     FLT_STAMP(1);
+    jf_rs_filter_row rec;
+    rec.sum = S; rec.row_max = M; rec.x_keep = -INFINITY; rec.cut1 = 0u; rec.tie1 = (int32_t)V - 1; rec.s1 = 1.f; rec.cut2 = 0u; rec.tie2 = (int32_t)V - 1; rec.s2 = 1.f;
+    rec.flags = ((top_k > 0 && (int64_t)top_k < V) ? JF_RS_FILT_TOPK : 0u) | (top_p > 0.f ? JF_RS_FILT_TOPP : 0u); rec.rsv = 0u;
     {
         RsRow plain = row;
         plain.S = row_sumexp[r];                                               // (NaN / inf rows: jf_rs_probs' float32 statistics, plain formula)
@@ -1860,6 +2008,7 @@ __global__ __launch_bounds__(FLT_TPB, 4) void rs_filter_kernel(const void *logit
         const double kept = sum + (double)need * (double)__uint_as_float(thr);
         float s1 = rs_round_prob<DT>(kept);
         s1 = s1 > floor_d ? s1 : floor_d;
+        rec.cut1 = thr; rec.tie1 = (int32_t)(tie_last >= V ? V - 1 : tie_last); rec.s1 = s1;
         FLT_STAMP(4);
         flt_renorm<DT, HIST>(out, V, thr, tie_last, s1, !want_p ? nullptr : HIST == 1 ? (void *)hist : HIST == 2 ? (void *)f32.hist : nullptr);
         f32.reset();
@@ -1867,7 +2016,7 @@ __global__ __launch_bounds__(FLT_TPB, 4) void rs_filter_kernel(const void *logit
     }
     // ---- 3. top-p (JDN:91-107)
     if (want_p) {
-        const float tp = rs_round_prob<DT>((double)top_p);                    // `cdf <= tp`: the Python float is cast to the tensor's dtype
+        const float tp = rs_round_prob<DT>((double)(float)top_p_d);           // `cdf <= tp`: the Python float is cast to the tensor's dtype
         count_sum(0u, 0u, cnt, sum);                      // everything
         const bool all = rs_round_prob<DT>(sum) <= tp;
         uint32_t thr = 0u;
@@ -1893,37 +2042,77 @@ __global__ __launch_bounds__(FLT_TPB, 4) void rs_filter_kernel(const void *logit
             s2 = rs_round_prob<DT>(c_whole + (double)c * v);
         }
         s2 = s2 > floor_d ? s2 : floor_d;
-        FLT_STAMP(6);
-        flt_renorm<DT, HIST>(out, V, thr, tie_last, s2, nullptr);
-        FLT_STAMP(7);
+        rec.cut2 = thr; rec.tie2 = (int32_t)(tie_last >= V ? V - 1 : tie_last); rec.s2 = s2;
+        FLT_STAMP(6);                                                          // (no renormalising pass: the record says what an id becomes)
     }
     if (tid == 0) {
         const int64_t tok = draft_next[r];
-        p_draft[r] = (tok >= 0 && tok < V) ? __uint_as_float(flt_key<DT>(out, tok)) : 0.f;
+        float pd = 0.f;
+        if (tok >= 0 && tok < V && S > 0.0) {                                   // the scratch row holds y (p when top-k is off): the top-p stage of the map is left
+            const float y = __uint_as_float(flt_key<DT>(out, tok));
+            const uint32_t b = __float_as_uint(y);
+            pd = !want_p ? y : ((b > rec.cut2 || (b == rec.cut2 && tok <= (int64_t)rec.tie2)) ? flt_div<DT>(y, rec.s2) : 0.f);
+        }
+        filt[r] = rec;
+        p_draft[r] = pd;
         row_max[r] = INFINITY;
         row_sumexp[r] = RS_PROB_ROW;
     }
 }
 
+// the dense tensor of the records (the reference's `probs`): one workgroup per (row, chunk of 8 192 ids)
+template <int DT>
+__global__ __launch_bounds__(256) void rs_filter_expand_kernel(const void *logits, int64_t V, int64_t row_stride, float t, const jf_rs_filter_row *filt,
+                                                                void *probs, int chunks) {
+    constexpr int EPV = Elem<DT>::EPV;
+    __shared__ double s_tab[64];
+    rs_load_tab(s_tab);
+    __syncthreads();
+    const int64_t r = blockIdx.x / chunks, c = blockIdx.x % chunks;
+    const jf_rs_filter_row &f = filt[r];
+    RsRow row = rs_make_row<DT>(logits, r, V, row_stride, t, f.row_max, 1.f);
+    row.flt = &f;
+    const double invS = f.sum > 0.0 ? 1.0 / f.sum : 0.0;
+    void *out = (char *)probs + r * V * (DT == JF_F32 ? 4 : 2);
+    const int64_t per = (V + chunks - 1) / chunks, lo = (c * per + EPV - 1) / EPV * EPV;
+    int64_t hi = ((c + 1) * per + EPV - 1) / EPV * EPV;
+    if (hi > V) hi = V;
+    for (int64_t e0 = lo + (int64_t)threadIdx.x * EPV; e0 < hi; e0 += 256 * EPV) {
+        float p[EPV];
+        rs_row_probs_from_vec<DT>(row, rs_load_vec<DT>(row, e0), e0, invS, s_tab, p);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) if (e0 + j < V) flt_store<DT>(out, e0 + j, p[j]);
+    }
+}
+
+extern "C" size_t jf_rs_filter_workspace_bytes(int dtype, int64_t R, int64_t V) {
+    if (R <= 0 || V <= 0) return 0;
+    if (dtype == JF_BF16 && V <= (int64_t)FH_MAX_TILES * FH_TILE) return 0;      // the pattern counts live in LDS
+    return (size_t)R * (size_t)V * (dtype == JF_F32 ? 4 : 2);                     // a scratch row per row
+}
+
 extern "C" int jf_rs_filter(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, const int64_t *draft_next,
-                            float temperature, int32_t top_k, float top_p, void *probs, float *p_draft, float *row_max,
-                            float *row_sumexp, void *stream) {
+                            float temperature, int32_t top_k, double top_p, jf_rs_filter_row *filt, float *p_draft, float *row_max,
+                            float *row_sumexp, void *workspace, size_t workspace_bytes, void *stream) {
     if (R <= 0) return JF_OK;
-    if (!logits || !draft_next || !probs || !p_draft || !row_max || !row_sumexp) return fail(JF_E_INVALID, "jf_rs_filter: null pointer");
+    if (!logits || !draft_next || !filt || !p_draft || !row_max || !row_sumexp) return fail(JF_E_INVALID, "jf_rs_filter: null pointer");
     if (dtype != JF_F32 && dtype != JF_BF16) return fail(JF_E_INVALID, "jf_rs_filter: dtype %d", dtype);
     if (V <= 0 || V > 0x7FFFFFFFll || row_stride < V) return fail(JF_E_INVALID, "jf_rs_filter: bad shape V=%lld stride=%lld", (long long)V, (long long)row_stride);
     if (!(top_p == top_p)) return fail(JF_E_INVALID, "jf_rs_filter: top_p is NaN");
+    const size_t need = jf_rs_filter_workspace_bytes(dtype, R, V);
+    if (need && (!workspace || workspace_bytes < need || ((uintptr_t)workspace % 16) != 0))
+        return fail(JF_E_INVALID, "jf_rs_filter: workspace of %zu bytes (16-byte aligned) needed, %zu given", need, workspace_bytes);
     const float t = (temperature <= 0.f) ? 1.f : temperature;               // JDN:66-67
     hipStream_t s = (hipStream_t)stream;
     // the product form of the bf16 scaling where the host proves it exact for this T (as jf_rs_probs / jf_rs_step: -T says so)
     const float tt = (dtype == JF_BF16 && t != 1.f && rs_scale_is_exact(t)) ? -t : t;
-    // value counts in dynamic LDS (beyond the default 64 KB per workgroup: opt in once PER DEVICE — a process may drive several);
-    // JF_RS_FILTER_HIST=0 keeps the pass-per-bisection-step variant (what rows of more than 2^18 float32 ids take)
+    // dynamic LDS beyond the default 64 KB per workgroup: opt in once PER DEVICE (a process may drive several);
+    // JF_RS_FILTER_HIST=0 keeps the float32 rows on the pass-per-bisection-step variant (what rows of more than 2^18 ids take)
     static const bool hist = [] { const char *e = getenv("JF_RS_FILTER_HIST"); return !(e && e[0] == '0'); }();
     static std::atomic<int> opted[64];                                      // per device: 0 not asked, 1 granted, -1 refused
     auto lds_ok = [&](const void *fn, unsigned bytes, int slot) {
         int dev = 0;
-        if (!hist || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return false;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return false;
         std::atomic<int> &st = opted[dev * 2 + slot];
         int v = st.load(std::memory_order_acquire);
         if (v == 0) {
@@ -1933,16 +2122,35 @@ extern "C" int jf_rs_filter(const void *logits, int dtype, int64_t R, int64_t V,
         }
         return v > 0;
     };
+    if (dtype == JF_BF16 && need == 0) {
+        if (!lds_ok((const void *)rs_filter_hist_kernel, FH_LDS, 1)) return fail(JF_E_LAUNCH, "jf_rs_filter: the device refuses %u bytes of LDS per workgroup", FH_LDS);
+        rs_filter_hist_kernel<<<dim3((unsigned)R), dim3(FH_TPB), FH_LDS, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, filt, p_draft, row_max, row_sumexp);
+        return check_launch("rs_filter_hist_kernel");
+    }
     if (dtype == JF_F32) {
-        if (V <= (1ll << 18) && lds_ok((const void *)rs_filter_kernel<JF_F32, 2>, FLT_LDS_F32, 0))
-            rs_filter_kernel<JF_F32, 2><<<dim3((unsigned)R), dim3(FLT_TPB), FLT_LDS_F32, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
-        else rs_filter_kernel<JF_F32, 0><<<dim3((unsigned)R), dim3(FLT_TPB), 0, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
-    } else {
-        if (lds_ok((const void *)rs_filter_kernel<JF_BF16, 1>, FLT_BINS * 4, 1))
-            rs_filter_kernel<JF_BF16, 1><<<dim3((unsigned)R), dim3(FLT_TPB), FLT_BINS * 4, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
-        else rs_filter_kernel<JF_BF16, 0><<<dim3((unsigned)R), dim3(FLT_TPB), 0, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, probs, p_draft, row_max, row_sumexp);
+        if (hist && V <= (1ll << 18) && lds_ok((const void *)rs_filter_kernel<JF_F32, 2>, FLT_LDS_F32, 0))
+            rs_filter_kernel<JF_F32, 2><<<dim3((unsigned)R), dim3(FLT_TPB), FLT_LDS_F32, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, workspace, filt, p_draft, row_max, row_sumexp);
+        else rs_filter_kernel<JF_F32, 0><<<dim3((unsigned)R), dim3(FLT_TPB), 0, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, workspace, filt, p_draft, row_max, row_sumexp);
+    } else {                                                                 // bf16 rows of more than 524 288 ids
+        rs_filter_kernel<JF_BF16, 0><<<dim3((unsigned)R), dim3(FLT_TPB), 0, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, workspace, filt, p_draft, row_max, row_sumexp);
     }
     return check_launch("rs_filter_kernel");
+}
+
+extern "C" int jf_rs_filter_expand(const void *logits, int dtype, int64_t R, int64_t V, int64_t row_stride, float temperature,
+                                   const jf_rs_filter_row *filt, void *probs, void *stream) {
+    if (R <= 0) return JF_OK;
+    if (!logits || !filt || !probs) return fail(JF_E_INVALID, "jf_rs_filter_expand: null pointer");
+    if (dtype != JF_F32 && dtype != JF_BF16) return fail(JF_E_INVALID, "jf_rs_filter_expand: dtype %d", dtype);
+    if (V <= 0 || V > 0x7FFFFFFFll || row_stride < V) return fail(JF_E_INVALID, "jf_rs_filter_expand: bad shape V=%lld stride=%lld", (long long)V, (long long)row_stride);
+    const float t = (temperature <= 0.f) ? 1.f : temperature;
+    const float tt = (dtype == JF_BF16 && t != 1.f && rs_scale_is_exact(t)) ? -t : t;
+    const int chunks = (int)((V + 8191) / 8192);
+    if ((int64_t)R * chunks > 0x7FFFFFFFll) return fail(JF_E_CAPACITY, "jf_rs_filter_expand: too many rows");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == JF_F32) rs_filter_expand_kernel<JF_F32><<<dim3((unsigned)(R * chunks)), dim3(256), 0, s>>>(logits, V, row_stride, tt, filt, probs, chunks);
+    else rs_filter_expand_kernel<JF_BF16><<<dim3((unsigned)(R * chunks)), dim3(256), 0, s>>>(logits, V, row_stride, tt, filt, probs, chunks);
+    return check_launch("rs_filter_expand_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2078,7 +2286,9 @@ __device__ __forceinline__ void rs_seg_prob_sums(const RsRow &row, int64_t lo, i
             float p[EPV];
 #pragma unroll
             for (int j = 0; j < EPV; ++j) p[j] = 0.f;
-            if (e0 < hi) {
+            if (e0 < hi && row.flt) {                        // (workgroup-uniform) the record's map of the exact probabilities; phase A did not run
+                rs_row_probs_from_vec<DT>(row, rs_load_vec<DT>(row, e0), e0, invS, sh.tab, p);
+            } else if (e0 < hi) {
                 if constexpr (KEEP && DT == JF_BF16) {
                     if (__builtin_expect(invS > 0.0, 1)) rs_probs_from_kept<DT>(row, e0, e32[k], invS, invS32, tiny_m1, sh.tab, p);
                     else rs_probs_from_vec<DT>(row, rs_load_vec<DT>(row, e0), p);
@@ -2160,19 +2370,19 @@ __device__ __forceinline__ void rs_seg_prob_sums(const RsRow &row, int64_t lo, i
 
 // Both phases of one (row, segment) inside ONE launch (rs_step_fused_kernel): the 16 workgroups of a row exchange their
 // float64 partials through agent-scope words.  Returns false when a peer's partial did not arrive within the wait bound.
-template <int DT>
+template <int DT, bool FLT>
 __device__ __forceinline__ bool rs_rowsum_fused(const void *logits, int64_t V, int64_t row_stride, const float *row_max, const float *row_sumexp,
                                                 float t, const RsWs &w, int item, int seg, int nact, int r, int64_t av, uint32_t gen, RsSumShared &sh) {
     constexpr int EPV = Elem<DT>::EPV, NV = RsKeep<DT>::NV;
     const int tid = threadIdx.x;
     const int empty_from = seg == nact - 1 ? nact : RS_SEG;    // the row's last active segment stands in for the empty ones (zeros)
-    const RsRow row = rs_make_row<DT>(logits, r, V, row_stride, t, row_max[r], row_sumexp[r]);
+    const RsRow row = rs_step_row<DT>(logits, r, V, row_stride, t, row_max, row_sumexp, FLT ? w.filt : nullptr);   // (!FLT: a literal null — the unfiltered kernel compiles without the record paths)
     const int64_t segE = rs_seg_elems(V, EPV);
     const int64_t lo = (int64_t)seg * segE;
     int64_t hi = lo + segE;
     if (hi > V) hi = V;
     if (lo > V) hi = lo;                                       // (tiny vocabularies: empty trailing segments)
-    const bool exact = rs_row_is_exact(row.M, row.S);
+    const bool exact = !row.flt && rs_row_is_exact(row.M, row.S);      // (a filtered row's sum is its record's: no phase A)
     const int ntiles = (int)((hi - lo + 256 * EPV - 1) / (256 * EPV));
     rs_load_tab(sh.tab);
     if (tid == 0) sh.ok = 1;
@@ -2180,7 +2390,7 @@ __device__ __forceinline__ bool rs_rowsum_fused(const void *logits, int64_t V, i
     RS_PHASE(item, seg, 0);                                   // 0: table in LDS
     float e32[NV][EPV];
     u32x4 v[NV];
-    double S = 0.0;
+    double S = row.flt ? rs_flt_sum(row) : 0.0;
     const bool keep = ntiles <= NV;                           // workgroup-uniform (true for every vocabulary up to 163 840)
     if (exact) {
         float lmax;
@@ -2224,8 +2434,8 @@ __global__ __launch_bounds__(256) void rs_rowsum_a_kernel(const void *logits, in
     const int item = blockIdx.x / RS_SEG, seg = blockIdx.x % RS_SEG, tid = threadIdx.x;
     const int r = w.sel_row[item];
     if (r < 0) return;
-    const RsRow row = rs_make_row<DT>(logits, r, V, row_stride, t, row_max[r], row_sumexp[r]);
-    if (!rs_row_is_exact(row.M, row.S)) { if (tid == 0) w.s64part[(int64_t)item * RS_SEG + seg] = 0.0; return; }
+    const RsRow row = rs_step_row<DT>(logits, r, V, row_stride, t, row_max, row_sumexp, w.filt);
+    if (row.flt || !rs_row_is_exact(row.M, row.S)) { if (tid == 0) w.s64part[(int64_t)item * RS_SEG + seg] = 0.0; return; }
     const int64_t segE = rs_seg_elems(V, EPV);
     const int64_t lo = (int64_t)seg * segE;
     int64_t hi = lo + segE;
@@ -2255,7 +2465,7 @@ __global__ __launch_bounds__(256) void rs_rowsum_b_kernel(const void *logits, in
     const int item = blockIdx.x / RS_SEG, seg = blockIdx.x % RS_SEG;
     const int r = w.sel_row[item];
     if (r < 0) return;
-    const RsRow row = rs_make_row<DT>(logits, r, V, row_stride, t, row_max[r], row_sumexp[r]);
+    const RsRow row = rs_step_row<DT>(logits, r, V, row_stride, t, row_max, row_sumexp, w.filt);
     const int64_t segE = rs_seg_elems(V, EPV);
     const int64_t lo = (int64_t)seg * segE;
     int64_t hi = lo + segE;
@@ -2263,7 +2473,8 @@ __global__ __launch_bounds__(256) void rs_rowsum_b_kernel(const void *logits, in
     if (lo > V) hi = lo;
     rs_load_tab(sh.tab);
     double S = 0.0;
-    if (rs_row_is_exact(row.M, row.S)) {
+    if (row.flt) S = rs_flt_sum(row);
+    else if (rs_row_is_exact(row.M, row.S)) {
 #pragma unroll
         for (int s = 0; s < RS_SEG; ++s) S += w.s64part[(int64_t)item * RS_SEG + s];
     }
@@ -2368,7 +2579,7 @@ __device__ __forceinline__ int rs_pick_wave(const RsRow &row, const RsWs &w, int
     float p[EPV];
 #pragma unroll
     for (int j = 0; j < EPV; ++j) p[j] = 0.f;
-    if (e0 < hi) rs_any_probs_from_vec<DT>(row, rs_load_vec<DT>(row, e0), S > 0.0 ? 1.0 / S : 0.0, tab, p);
+    if (e0 < hi) rs_row_probs_from_vec<DT>(row, rs_load_vec<DT>(row, e0), e0, S > 0.0 ? 1.0 / S : 0.0, tab, p);
     double a = 0.0;
 #pragma unroll
     for (int j = 0; j < EPV; ++j) a += (double)p[j];
@@ -2442,7 +2653,7 @@ __device__ int rs_pick_wg(const RsRow &row, const double *segsum, double S, floa
         float p[EPV];
 #pragma unroll
         for (int j = 0; j < EPV; ++j) p[j] = 0.f;
-        if (e0 < hi) rs_any_probs_from_vec<DT>(row, rs_load_vec<DT>(row, e0), invS, sh.tab, p);
+        if (e0 < hi) rs_row_probs_from_vec<DT>(row, rs_load_vec<DT>(row, e0), e0, invS, sh.tab, p);
         double a = 0.0;
 #pragma unroll
         for (int j = 0; j < EPV; ++j) a += (double)p[j];
@@ -2488,7 +2699,7 @@ __device__ int rs_masked_argmax_full(const RsRow &row, int64_t proposed, double 
     unsigned long long best = 0ull;
     for (int64_t e0 = (int64_t)tid * EPV; e0 < row.V; e0 += 256 * EPV) {
         float p[EPV];
-        rs_any_probs_from_vec<DT>(row, rs_load_vec<DT>(row, e0), invS, sh.tab, p);
+        rs_row_probs_from_vec<DT>(row, rs_load_vec<DT>(row, e0), e0, invS, sh.tab, p);
 #pragma unroll
         for (int j = 0; j < EPV; ++j) {
             const int64_t i = e0 + j;
@@ -2549,7 +2760,7 @@ __device__ __forceinline__ void rs_scan_segment(const RsRow &row, int seg, int64
 }
 template <int DT, bool AGENT>
 __device__ int rs_masked_argmax(const RsRow &row, int64_t proposed, double S, RsPickShared &sh, const float *segmax) {
-    if (!(S > 0.0) || !segmax) return rs_masked_argmax_full<DT>(row, proposed, S, sh);
+    if (!(S > 0.0) || !segmax || row.flt) return rs_masked_argmax_full<DT>(row, proposed, S, sh);   // (a filtered row: few ids pass x_keep, few exps)
     constexpr int EPV = Elem<DT>::EPV;
     const int tid = threadIdx.x;
     const double invS = 1.0 / S;
@@ -3127,7 +3338,7 @@ __global__ __launch_bounds__(256) void rs_bonus_kernel(const void *logits, int64
         u_final = w.pick_u[b];
     }
     const int64_t r = (int64_t)b * (L - 1) + rej;
-    const RsRow row = rs_make_row<DT>(logits, r, V, row_stride, temp, row_max[r], row_sumexp[r]);
+    const RsRow row = rs_step_row<DT>(logits, r, V, row_stride, temp, row_max, row_sumexp, w.filt);
     const int bonus = rs_final_pick<DT, false>(row, w, b, w.s64[b], draft[(int64_t)b * L + rej + 1], u_final, sh);
     if (tid == 0) committed[(int64_t)b * L + rows[b].n_committed] = bonus;
 }
@@ -3270,7 +3481,7 @@ __device__ __forceinline__ void rs_report_timeout(jf_rs_row *rows) {
     __hip_atomic_store(&rows[0].rsv, (int32_t)JF_E_LAUNCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int DT>
+template <int DT, bool FLT /* the rows carry jf_rs_filter's records (a.w.filt): the unfiltered kernel compiles without those paths */>
 __global__ __launch_bounds__(256, 4) void rs_step_fused_kernel(RsFusedArgs a) {   // 4 workgroups per CU (<= 128 VGPRs, < 40 KB LDS): 64 rows' 963 workgroups are resident at once
     const int blk = blockIdx.x, tid = threadIdx.x;
     const int B = a.B, L = a.L, W = a.L - 1;
@@ -3437,7 +3648,7 @@ __global__ __launch_bounds__(256, 4) void rs_step_fused_kernel(RsFusedArgs a) { 
         bool sums_ok = rej != -3;
         if (rej >= 0) {
             if (tid == 0 && seg == 0) RS_ROWSTAMP(1, item);
-            sums_ok = rs_rowsum_fused<DT>(a.logits, a.V, a.row_stride, a.row_max, a.row_sumexp, a.t, w, item, seg, nact, item * W + rej,
+            sums_ok = rs_rowsum_fused<DT, FLT>(a.logits, a.V, a.row_stride, a.row_max, a.row_sumexp, a.t, w, item, seg, nact, item * W + rej,
                                           a.draft[(int64_t)item * L + rej + 1], a.gen, shs);
             if (tid == 0 && seg == 0) RS_ROWSTAMP(4, item);
         }
@@ -3486,7 +3697,7 @@ __global__ __launch_bounds__(256, 4) void rs_step_fused_kernel(RsFusedArgs a) { 
         if (rej >= 0) {
             const int64_t r = (int64_t)b * W + rej;
             if (b == B - 1) RS_STAMP_MAX(17);                        // 17: last row's bonus workgroup has its uniform
-            const RsRow row = rs_make_row<DT>(a.logits, r, a.V, a.row_stride, a.t, a.row_max[r], a.row_sumexp[r]);
+            const RsRow row = rs_step_row<DT>(a.logits, r, a.V, a.row_stride, a.t, a.row_max, a.row_sumexp, FLT ? w.filt : nullptr);
             bonus = rs_final_pick<DT, true>(row, w, b, s_S, a.draft[(int64_t)b * L + rej + 1], s_uf, sh);
             if (b == B - 1) RS_STAMP_MAX(19);                        // 19: ... has walked
             if (a.eos_id >= 0 && bonus == a.eos_id) eos = 1;
@@ -3707,7 +3918,7 @@ __global__ __launch_bounds__(256) void rs_op_bonus_kernel(const void *logits, in
         }
         __syncthreads();
         draws = s_draws;
-        const RsRow row = rs_make_row<DT>(logits, rej, V, row_stride, temp, row_max[rej], row_sumexp[rej]);
+        const RsRow row = rs_step_row<DT>(logits, rej, V, row_stride, temp, row_max, row_sumexp, w.filt);
         const int bonus = rs_final_pick<DT, false>(row, w, rej, w.s64[rej], proposed[rej], s_uf, sh);
         if (tid == 0) committed[n] = bonus;
         n += 1;
@@ -3737,7 +3948,7 @@ __global__ __launch_bounds__(256) void rs_op_redraft_kernel(const void *logits, 
     rs_load_tab(sh.tab);
     __syncthreads();
     const int64_t base = ((int64_t)res->redraft_base_hi << 32) | (int64_t)(uint32_t)res->redraft_base_lo;
-    const RsRow row = rs_make_row<DT>(logits, li, V, row_stride, temp, row_max[li], row_sumexp[li]);
+    const RsRow row = rs_step_row<DT>(logits, li, V, row_stride, temp, row_max, row_sumexp, w.filt);
     const float u = m_stream[(base + (li - n)) % m_len];
     int y;
     if (rs_hier_ok(V, Elem<DT>::EPV)) {
@@ -3755,7 +3966,7 @@ extern "C" int jf_rs_onpolicy_step(const void *logits, int dtype, int64_t V, int
                                    float temperature, const int32_t *stop_ids, int n_stop, const float *u_stream, int64_t u_len,
                                    int64_t *u_cursor, const float *m_stream, int64_t m_len, int64_t *m_cursor,
                                    int64_t *committed, int64_t *redraft, jf_op_row *row, void *workspace,
-                                   size_t workspace_bytes, void *stream) {
+                                   size_t workspace_bytes, const jf_rs_filter_row *filt, void *stream) {
     if (R <= 0) return JF_OK;
     if (!logits || !proposed || !p_draft || !row_max || !row_sumexp || !packed || !u_stream || !u_cursor || !m_stream ||
         !m_cursor || !committed || !redraft || !row || !workspace || (n_stop > 0 && !stop_ids))
@@ -3767,7 +3978,8 @@ extern "C" int jf_rs_onpolicy_step(const void *logits, int dtype, int64_t V, int
     float t = (temperature <= 0.f) ? 1.f : temperature;
     if (dtype == JF_BF16 && t != 1.f && rs_scale_is_exact(t)) t = -t;    // the kernels' rows take the product form of the scaling (rs_make_row)
     hipStream_t s = (hipStream_t)stream;
-    const RsWs w = rs_ws(workspace, R);
+    RsWs w = rs_ws(workspace, R);
+    w.filt = filt;
     unsigned long long *pk = (unsigned long long *)packed;
     const RsAcceptIn in{logits, V, row_stride, t, row_max, row_sumexp, p_draft};
 #define JF_OP(DT)                                                                                                                              \
@@ -3787,7 +3999,7 @@ extern "C" int jf_rs_onpolicy_step(const void *logits, int dtype, int64_t V, int
 // in dispatch order.
 static bool rs_fused_fits(const void *kern, int variant, int B) {
     static std::mutex mu;
-    static int cap[2] = {-1, -1}, capdev[2] = {-1, -1};
+    static int cap[4] = {-1, -1, -1, -1}, capdev[4] = {-1, -1, -1, -1};
     std::lock_guard<std::mutex> g(mu);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -3811,7 +4023,8 @@ extern "C" int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_
                           float temperature, int32_t eos_id, const int32_t *remaining, const float *u_stream, int64_t u_len,
                           int64_t *u_cursor, const float *bonus_stream, int64_t bonus_len, int64_t *bonus_cursor,
                           const int64_t *pad_stream, int64_t pad_len, int64_t *pad_cursor, int64_t *committed,
-                          int64_t *next_draft, jf_rs_row *rows, void *workspace, size_t workspace_bytes, void *stream) {
+                          int64_t *next_draft, jf_rs_row *rows, void *workspace, size_t workspace_bytes, const jf_rs_filter_row *filt,
+                          void *stream) {
     const JfTiming tm = jf_take_timing();                            // events armed for this call (jf_timing_arm): taken whatever happens below
     if (B <= 0) return JF_OK;
     if (L < 2) return fail(JF_E_INVALID, "Draft must have at least 2 tokens (seed + 1 speculative)");
@@ -3827,26 +4040,31 @@ extern "C" int jf_rs_step(const void *logits, int dtype, int64_t V, int64_t row_
     if (dtype == JF_BF16 && t != 1.f && rs_scale_is_exact(t)) t = -t;    // the kernels' rows take the product form of the scaling (rs_make_row)
     hipStream_t s = (hipStream_t)stream;
     unsigned long long *pk = (unsigned long long *)packed;
-    const RsWs w = rs_ws(workspace, B);
+    RsWs w = rs_ws(workspace, B);
+    w.filt = filt;
     static const bool fused_ok = !(getenv("JF_RS_FUSED") && getenv("JF_RS_FUSED")[0] == '0');   // A/B knob, read once
-    const void *fk = dtype == JF_F32 ? (const void *)rs_step_fused_kernel<JF_F32> : (const void *)rs_step_fused_kernel<JF_BF16>;
+    const bool flt = filt != nullptr;
+    const void *fk = dtype == JF_F32 ? (flt ? (const void *)rs_step_fused_kernel<JF_F32, true> : (const void *)rs_step_fused_kernel<JF_F32, false>)
+                                     : (flt ? (const void *)rs_step_fused_kernel<JF_BF16, true> : (const void *)rs_step_fused_kernel<JF_BF16, false>);
     if (fused_ok && (int64_t)B * (L - 1) <= RS_FUSED_STAGE && B <= RS_FUSED_ROWS && u_len < 0x7FFFFFFFll &&
-        rs_hier_ok(V, dtype == JF_F32 ? 4 : 8) && rs_fused_fits(fk, dtype == JF_F32 ? 0 : 1, B)) {
+        rs_hier_ok(V, dtype == JF_F32 ? 4 : 8) && rs_fused_fits(fk, (dtype == JF_F32 ? 0 : 1) + (flt ? 2 : 0), B)) {
         static std::atomic<uint32_t> g_gen{0};                      // generation of the hand-off words (0 never used: a zeroed workspace)
         uint32_t gen = ++g_gen;
         if (gen == 0) gen = ++g_gen;
         RsFusedArgs a{logits, V, row_stride, draft, B, L, p_draft, row_max, row_sumexp, pk, t, eos_id, remaining, u_stream, u_len, u_cursor,
                       bonus_stream, bonus_len, bonus_cursor, pad_stream, pad_len, pad_cursor, committed, next_draft, rows, w, gen};
         const unsigned grid = (unsigned)(3 + B * rs_active_segs(V, dtype == JF_F32 ? 4 : 8));
-        if (tm.any() && !jf_timing_bracket()) {                      // the launch's own start / stop timestamps
-            if (dtype == JF_F32) hipExtLaunchKernelGGL(rs_step_fused_kernel<JF_F32>, dim3(grid), dim3(256), 0, s, tm.begin, tm.end, 0, a);
-            else hipExtLaunchKernelGGL(rs_step_fused_kernel<JF_BF16>, dim3(grid), dim3(256), 0, s, tm.begin, tm.end, 0, a);
-        } else {
-            if (tm.begin) (void)hipEventRecord(tm.begin, s);
-            if (dtype == JF_F32) rs_step_fused_kernel<JF_F32><<<grid, 256, 0, s>>>(a);
-            else rs_step_fused_kernel<JF_BF16><<<grid, 256, 0, s>>>(a);
-            if (tm.end) (void)hipEventRecord(tm.end, s);
+#define JF_FUSED(K)                                                                                                     \
+        if (tm.any() && !jf_timing_bracket()) hipExtLaunchKernelGGL(K, dim3(grid), dim3(256), 0, s, tm.begin, tm.end, 0, a);   \
+        else {                                                                                                          \
+            if (tm.begin) (void)hipEventRecord(tm.begin, s);                                                            \
+            K<<<grid, 256, 0, s>>>(a);                                                                                   \
+            if (tm.end) (void)hipEventRecord(tm.end, s);                                                                \
         }
+        // (events attached to the dispatch: the launch's own start / stop timestamps)
+        if (dtype == JF_F32) { if (flt) { JF_FUSED((rs_step_fused_kernel<JF_F32, true>)) } else { JF_FUSED((rs_step_fused_kernel<JF_F32, false>)) } }
+        else { if (flt) { JF_FUSED((rs_step_fused_kernel<JF_BF16, true>)) } else { JF_FUSED((rs_step_fused_kernel<JF_BF16, false>)) } }
+#undef JF_FUSED
         return check_launch("rs_step_fused_kernel");
     }
     if (tm.begin) (void)hipEventRecord(tm.begin, s);                 // several launches: the events bracket them

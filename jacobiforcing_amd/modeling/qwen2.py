@@ -188,23 +188,24 @@ class StaticKVCache:
         like = self.ck[0]
         shape = (like.shape[0], like.shape[1], int(T_new), like.shape[3])
         n_layers, dev, dt = len(self.ck), like.device, like.dtype
-        # a clear capacity error instead of an out-of-memory failure in the middle of generation: the new scratch
-        # must fit the budget — JF_CAND_SCRATCH_MAX_GB, default a quarter of the device's memory — and what is free right now
-        # (the old scratch is released first)
+        # a clear capacity error instead of an out-of-memory failure in the middle of generation.  JF_CAND_SCRATCH_MAX_GB
+        # is a hard cap when set; otherwise the allocation is simply tried (the caching allocator gives back what it holds reserved
+        # but unused before it fails: ADVICE r05) and an out-of-memory error becomes the message below
         need = 2 * n_layers * like.element_size() * shape[0] * shape[1] * shape[2] * shape[3]
-        have = 2 * n_layers * like.element_size() * like.numel()
-        if dev.type == "cuda":
-            free, total = torch.cuda.mem_get_info(dev)
-            budget = float(os.environ.get("JF_CAND_SCRATCH_MAX_GB", total / 4 / 2**30)) * 2**30
-            if need > budget or need > free + have - (1 << 30):
-                raise RuntimeError(f"candidate K/V scratch for rows of {T_new} tokens needs {need / 2**30:.1f} GiB ({shape[0]} candidate rows x "
-                                   f"{n_layers} layers); budget {budget / 2**30:.1f} GiB, free {(free + have) / 2**30:.1f} GiB — a runaway block "
-                                   f"list (K >= 3 with a small spawn ratio) outgrew the cache: lower max_prompts / K or raise JF_CAND_SCRATCH_MAX_GB")
+        msg = (f"candidate K/V scratch for rows of {T_new} tokens needs {need / 2**30:.1f} GiB ({shape[0]} candidate rows x {n_layers} layers) — a "
+               f"runaway block list (K >= 3 with a small spawn ratio) outgrew the cache: lower max_prompts / K")
+        cap = os.environ.get("JF_CAND_SCRATCH_MAX_GB")
+        if cap is not None and need > float(cap) * 2**30:
+            raise RuntimeError(f"{msg} or raise JF_CAND_SCRATCH_MAX_GB (= {cap})")
         del like
         self.ck = self.cv = self.committer = None                          # free before allocating the larger scratch
         z = lambda: torch.zeros(shape, device=dev, dtype=dt)
-        self.ck = [z() for _ in range(n_layers)]
-        self.cv = [z() for _ in range(n_layers)]
+        try:
+            self.ck = [z() for _ in range(n_layers)]
+            self.cv = [z() for _ in range(n_layers)]
+        except torch.OutOfMemoryError as e:
+            self.ck = self.cv = None
+            raise RuntimeError(f"{msg} ({e})") from None
         self.T_max = int(T_new)
         if self.cand_rows > 0:
             self.committer = ops.KVCommitter(self.k, self.v, self.ck, self.cv, max(self.cand_rows, 1))

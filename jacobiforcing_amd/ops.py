@@ -953,6 +953,64 @@ def active_filters(sp, vocab_size: int) -> Tuple[int, float]:
     return k, pp
 
 
+class RowFilter:
+    """jf_rs_filter on the rows jf_rs_probs has just read: one 48-byte record per row (what top-k / top-p make of an id, as a
+    function of its probability and its id) instead of the filtered tensor; the steps take the records (``filt``)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.records = torch.zeros((N.RS_FILTER_ROW_BYTES,), dtype=torch.uint8, device=self.device)
+        self.ws = torch.zeros((16,), dtype=torch.uint8, device=self.device)
+        self._need: dict = {}
+
+    def run(self, flat: torch.Tensor, draft_next: torch.Tensor, temperature: float, top_k: int, top_p: float, p_draft: torch.Tensor,
+            row_max: torch.Tensor, row_sumexp: torch.Tensor) -> torch.Tensor:
+        """flat [R, V] logits (jf_rs_probs has filled p_draft / row_max / row_sumexp for them) -> the record tensor."""
+        R, V = flat.shape
+        lib = N.lib()
+        dt = _dtype_code(flat)
+        need = self._need.get((dt, R, V))
+        if need is None:
+            need = self._need[(dt, R, V)] = int(lib.jf_rs_filter_workspace_bytes(dt, R, V))
+        self.ws = _grown(self.ws, need)
+        self.records = _grown(self.records, R * N.RS_FILTER_ROW_BYTES)
+        done = _stage("rs_filter", 2 * R * V * flat.element_size())          # the logits twice (pattern counts, tie ids): no tensor is written
+        N.check(lib.jf_rs_filter(_ptr(flat), dt, R, V, flat.stride(0) if R > 1 else V, _ptr(draft_next), float(temperature), int(top_k),
+                                 float(top_p), _ptr(self.records), _ptr(p_draft), _ptr(row_max), _ptr(row_sumexp),
+                                 _ptr(self.ws) if need else None, self.ws.numel() if need else 0, _stream(self.device)), "jf_rs_filter")
+        done()
+        return self.records
+
+    def expand(self, flat: torch.Tensor, temperature: float) -> torch.Tensor:
+        """The dense tensor of the last ``run`` on ``flat`` (the reference's ``probs``), in the logits' dtype."""
+        R, V = flat.shape
+        out = torch.empty((R, V), dtype=flat.dtype, device=self.device)
+        N.check(N.lib().jf_rs_filter_expand(_ptr(flat), _dtype_code(flat), R, V, flat.stride(0) if R > 1 else V, float(temperature),
+                                            _ptr(self.records), _ptr(out), _stream(self.device)), "jf_rs_filter_expand")
+        return out
+
+
+def filtered_probs(logits: torch.Tensor, temperature: float, top_k: int, top_p: float, draft_next: Optional[torch.Tensor] = None):
+    """_build_target_probs (JDN:110-123) of logits [R, V] through the library: (probs [R, V] in the logits' dtype, p_draft [R],
+    records [R, 48] uint8).  For callers that want the tensor the reference builds — and the parity tests; the decoders never
+    materialise it."""
+    dev = logits.device
+    flat = logits if logits.stride(-1) == 1 else logits.contiguous()
+    R, V = flat.shape
+    dn = torch.zeros((R,), dtype=torch.int64, device=dev) if draft_next is None else draft_next.to(device=dev, dtype=torch.int64).contiguous()
+    f32 = lambda: torch.zeros((R,), dtype=torch.float32, device=dev)
+    p_draft, row_max, row_sumexp = f32(), f32(), f32()
+    packed = new_packed(R, dev)
+    lib = N.lib()
+    ws = torch.zeros((int(lib.jf_rs_workspace_bytes(R, V)) // 4 + 4,), dtype=torch.float32, device=dev)
+    N.check(lib.jf_rs_probs(_ptr(flat), _dtype_code(flat), R, V, flat.stride(0) if R > 1 else V, _ptr(dn), float(temperature), _ptr(p_draft),
+                            _ptr(row_max), _ptr(row_sumexp), _ptr(packed), _ptr(ws), ws.numel() * 4, _stream(dev)), "jf_rs_probs")
+    rf = RowFilter(dev)
+    rec = rf.run(flat, dn, temperature, top_k, top_p, p_draft, row_max, row_sumexp)
+    probs = rf.expand(flat, temperature)
+    return probs, p_draft, rec[:R * N.RS_FILTER_ROW_BYTES].view(R, N.RS_FILTER_ROW_BYTES).clone()
+
+
 class RsStepper:
     """Rejection-sampling verify of a batch of rows: jf_rs_probs (softmax-gather + argmax, logits read once) followed by
     jf_rs_step (accept/reject in stream order, bonus draws, next drafts) and one read-back per iteration.  The logits
@@ -980,6 +1038,7 @@ class RsStepper:
         self.cursors = torch.zeros((3,), dtype=torch.int64, device=dev)          # uniforms, bonus, pads
         self.remaining = torch.zeros((self.max_rows,), dtype=torch.int32, device=dev)
         self._ws_need: dict = {}
+        self.filter: Optional[RowFilter] = None
 
     def _check(self, draft: torch.Tensor, logits: torch.Tensor) -> Tuple[int, int]:
         B, L = draft.shape
@@ -1012,28 +1071,23 @@ class RsStepper:
                                 _ptr(self.p_draft), _ptr(self.row_max), _ptr(self.row_sumexp), _ptr(self.packed),
                                 _ptr(self.ws), self.ws.numel() * 4, _stream(dev)), "jf_rs_probs")
         done()
-        src = flat
+        filt = None
         if int(top_k) > 0 or float(top_p) > 0.0:
-            if getattr(self, "probs", None) is None or self.probs.numel() < R * V or self.probs.dtype != flat.dtype:
-                self.probs = torch.empty((R * V,), dtype=flat.dtype, device=dev)
-            src = self.probs[:R * V].view(R, V)
-            done = _stage("rs_filter", 3 * R * V * flat.element_size())        # the logits twice (float64 sum, probabilities), the result once
-            N.check(lib.jf_rs_filter(_ptr(flat), _dtype_code(flat), R, V, flat.stride(0), _ptr(draft_next), float(temperature),
-                                     int(top_k), float(top_p), _ptr(src), _ptr(self.p_draft), _ptr(self.row_max),
-                                     _ptr(self.row_sumexp), _stream(dev)), "jf_rs_filter")
-            done()
+            if self.filter is None:
+                self.filter = RowFilter(dev)
+            filt = self.filter.run(flat, draft_next, temperature, top_k, top_p, self.p_draft, self.row_max, self.row_sumexp)
         cm = self.committed.view(-1)[:B * L].view(B, L)
         cur = self.cursors
         c_ptr = lambda i: C.c_void_p(cur.data_ptr() + 8 * i)
         done = _stage("rs_step", B * V * flat.element_size())               # <= one rejected row per draft row
-        N.check(lib.jf_rs_step(_ptr(src), _dtype_code(src), V, src.stride(0), _ptr(draft), B, L, _ptr(self.p_draft),
+        N.check(lib.jf_rs_step(_ptr(flat), _dtype_code(flat), V, flat.stride(0), _ptr(draft), B, L, _ptr(self.p_draft),
                                _ptr(self.row_max), _ptr(self.row_sumexp), _ptr(self.packed), float(temperature),
                                -1 if eos_id is None else int(eos_id), _ptr(remaining),
                                _ptr(self.u_stream), self.u_stream.numel(), c_ptr(0),
                                _ptr(self.bonus_stream), self.bonus_stream.numel(), c_ptr(1),
                                _ptr(self.pad_stream), self.pad_stream.numel(), c_ptr(2),
                                _ptr(cm), _ptr(next_draft), _ptr(self.rows_dev), _ptr(self.step_ws), self.step_ws.numel() * 8,
-                               _stream(dev)), "jf_rs_step")
+                               _ptr(filt), _stream(dev)), "jf_rs_step")
         done()
         return cm
 
@@ -1111,25 +1165,22 @@ class OnPolicyStepper:
         N.check(lib.jf_rs_probs(_ptr(flat), _dtype_code(flat), R, V, flat.stride(0) if R > 1 else V, _ptr(prop),
                                 float(temperature), _ptr(self.p_draft), _ptr(self.row_max), _ptr(self.row_sumexp),
                                 _ptr(self.packed), _ptr(self.ws), self.ws.numel() * 4, _stream(dev)), "jf_rs_probs")
-        src, src_stride = flat, (flat.stride(0) if R > 1 else V)
+        filt = None
         if int(top_k) > 0 or float(top_p) > 0.0:
-            if getattr(self, "probs", None) is None or self.probs.numel() < R * V or self.probs.dtype != flat.dtype:
-                self.probs = torch.empty((R * V,), dtype=flat.dtype, device=dev)
-            src, src_stride = self.probs[:R * V].view(R, V), V
-            N.check(lib.jf_rs_filter(_ptr(flat), _dtype_code(flat), R, V, flat.stride(0) if R > 1 else V, _ptr(prop), float(temperature),
-                                     int(top_k), float(top_p), _ptr(src), _ptr(self.p_draft), _ptr(self.row_max), _ptr(self.row_sumexp),
-                                     _stream(dev)), "jf_rs_filter")
+            if getattr(self, "filter", None) is None:
+                self.filter = RowFilter(dev)
+            filt = self.filter.run(flat, prop, temperature, top_k, top_p, self.p_draft, self.row_max, self.row_sumexp)
         self.cursors.copy_(torch.tensor(list(cursors), dtype=torch.int64), non_blocking=True)
         cur = self.cursors
         c_ptr = lambda i: C.c_void_p(cur.data_ptr() + 8 * i)
         cm, rd = self.out[0], self.out[1]
-        N.check(lib.jf_rs_onpolicy_step(_ptr(src), _dtype_code(src), V, src_stride, _ptr(prop), R,
+        N.check(lib.jf_rs_onpolicy_step(_ptr(flat), _dtype_code(flat), V, flat.stride(0) if R > 1 else V, _ptr(prop), R,
                                         _ptr(self.p_draft), _ptr(self.row_max), _ptr(self.row_sumexp), _ptr(self.packed),
                                         float(temperature), _ptr(self.stop_ids), int(self.stop_ids.numel()),
                                         _ptr(self.u_stream), self.u_stream.numel(), c_ptr(0),
                                         _ptr(self.m_stream), self.m_stream.numel(), c_ptr(1),
                                         _ptr(cm), _ptr(rd), _ptr(self.row_dev), _ptr(self.step_ws),
-                                        self.step_ws.numel() * 8, _stream(dev)), "jf_rs_onpolicy_step")
+                                        self.step_ws.numel() * 8, _ptr(filt), _stream(dev)), "jf_rs_onpolicy_step")
         self.row_host.copy_(self.row_dev, non_blocking=True)
         self.out_host[:, :R].copy_(self.out[:, :R], non_blocking=True)
         if dev.type == "cuda":

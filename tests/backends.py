@@ -68,6 +68,7 @@ class HostSimLib:
             "hs_mb_loop_pack": (C.c_int, [C.POINTER(N.MbLoop), i32, P]),
         }
         self._host_blocks = {}
+        self._filtered = {}                # address of a jf_rs_filter record array -> the dense filtered tensor (oracle)
         for k, (r, a) in sig.items():
             f = getattr(self.hs, k)
             f.restype, f.argtypes = r, a
@@ -343,31 +344,44 @@ class HostSimLib:
         pk[:] = np.maximum(pk, (np.uint64(1) << np.uint64(32)) | ((~am) & np.uint64(0xFFFFFFFF)))
         return 0
 
-    def jf_rs_filter(self, logits, dtype, R, V, stride, draft_next, temperature, top_k, top_p, probs, p_draft, row_max, row_sumexp, stream):
+    def jf_rs_filter_workspace_bytes(self, dtype, R, V):
+        return 0
+
+    def jf_rs_filter(self, logits, dtype, R, V, stride, draft_next, temperature, top_k, top_p, filt, p_draft, row_max, row_sumexp,
+                     workspace, workspace_bytes, stream):
+        """The stand-in keeps the oracle's dense filtered tensor beside the record array (keyed by its address): jf_rs_step /
+        jf_rs_filter_expand called with these records sample from / return it."""
         rows = self._rows_f32(logits, dtype, R, V, stride)
         q = O.target_probs(rows, float(temperature), self._ldt(dtype), int(top_k) or None, float(top_p) or None).astype(np.float32)
-        if dtype == N.JF_BF16:
-            _view(probs, R * V, np.uint16)[:] = O.f32_to_bf16_bits(q).reshape(-1)
-        else:
-            _view(probs, R * V, np.float32)[:] = q.reshape(-1)
+        self._filtered[_addr(filt)] = q
+        rec = _view(filt, R * C.sizeof(N.RsFilterRow) // 4, np.int32).reshape(R, -1)
+        rec[:] = 0
+        rec[:, N.RS_FILTER_FLAGS_WORD] = (1 if int(top_k) > 0 and int(top_k) < V else 0) | (2 if 0.0 < float(top_p) < 1.0 else 0)
         dn = _view(draft_next, R, np.int64)
         _view(p_draft, R, np.float32)[:] = q[np.arange(R), dn]
         _view(row_max, R, np.float32)[:] = np.inf
         _view(row_sumexp, R, np.float32)[:] = -1.0
         return 0
 
-    def _probs_of(self, logits, dtype, R, V, stride, temperature, row_sumexp):
-        """The target distribution the step samples from: rows that jf_rs_filter marked as probability rows ARE it."""
-        lg = self._rows_f32(logits, dtype, R, V, stride)
-        if R and float(_view(row_sumexp, R, np.float32)[0]) == -1.0:
-            return lg
-        return O.target_probs(lg, temperature, self._ldt(dtype))
+    def jf_rs_filter_expand(self, logits, dtype, R, V, stride, temperature, filt, probs, stream):
+        q = self._filtered[_addr(filt)]
+        if dtype == N.JF_BF16:
+            _view(probs, R * V, np.uint16)[:] = O.f32_to_bf16_bits(q).reshape(-1)
+        else:
+            _view(probs, R * V, np.float32)[:] = q.reshape(-1)
+        return 0
+
+    def _probs_of(self, logits, dtype, R, V, stride, temperature, filt):
+        """The target distribution the step samples from: with filter records, the tensor jf_rs_filter stored beside them."""
+        if filt is not None and _addr(filt):
+            return self._filtered[_addr(filt)]
+        return O.target_probs(self._rows_f32(logits, dtype, R, V, stride), temperature, self._ldt(dtype))
 
     def jf_rs_step(self, logits, dtype, V, stride, draft, B, L, p_draft, row_max, row_sumexp, packed, temperature, eos_id,
                    remaining, u_stream, u_len, u_cursor, b_stream, b_len, b_cursor, pad_stream, pad_len, pad_cursor,
-                   committed, next_draft, rows, ws, ws_bytes, stream):
+                   committed, next_draft, rows, ws, ws_bytes, filt, stream):
         R = B * (L - 1)
-        probs = self._probs_of(logits, dtype, R, V, stride, temperature, row_sumexp)
+        probs = self._probs_of(logits, dtype, R, V, stride, temperature, filt)
         d = _view(draft, B * L, np.int64).reshape(B, L)
         us, bs, ps = _view(u_stream, u_len, np.float32), _view(b_stream, b_len, np.float32), _view(pad_stream, pad_len, np.int64)
         uc, bc, pc = _view(u_cursor, 1, np.int64), _view(b_cursor, 1, np.int64), _view(pad_cursor, 1, np.int64)
@@ -412,8 +426,8 @@ class HostSimLib:
 
     def jf_rs_onpolicy_step(self, logits, dtype, V, stride, proposed, R, p_draft, row_max, row_sumexp, packed, temperature,
                             stop_ids, n_stop, u_stream, u_len, u_cursor, m_stream, m_len, m_cursor, committed, redraft, row,
-                            ws, ws_bytes, stream):
-        probs = self._probs_of(logits, dtype, R, V, stride, temperature, row_sumexp)
+                            ws, ws_bytes, filt, stream):
+        probs = self._probs_of(logits, dtype, R, V, stride, temperature, filt)
         prop = _view(proposed, R, np.int64).tolist()
         stops = _view(stop_ids, n_stop, np.int32).tolist() if n_stop else []
         us, ms = _view(u_stream, u_len, np.float32), _view(m_stream, m_len, np.float32)

@@ -328,6 +328,33 @@ def test_eight_ranks_share_one_gpu():
     assert d["tokens_per_forward"] >= 1.0
     _assert_rank_evidence(d, ranks=8, distinct=1)
     assert all(x["cpus"] >= 1 for x in d["per_rank"])
+    assert "config4_strong64" not in d                                  # (the run IS config 4: nothing to add)
+
+
+@pytest.mark.gpu
+def test_weak_run_of_several_ranks_also_reports_config_4_as_stated():
+    """The driver's plain `bench.py --gpus N` is WEAK scaling (a batch per GPU); BASELINE config 4 is 64 prompts sharded 8-way.  One
+    invocation reports both: the weak headline and, measured behind it in the same process group, `config4_strong64` — with its own
+    per-rank records and the same value = tokens_sum / seconds_max check.  Eight ranks on the one GPU of the box, gather over gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(JF_DIST_BACKEND="gloo", JF_FORCE_DEVICE="0", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1", "--model", "tiny",
+                        "--prompts-per-gpu", "4", "--no-scripted", "--no-prewarm", "--cpu-baseline-seconds", "0"], env=env,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["prompts_per_gpu"] == 4 and d["config"]["total_prompts"] == 32
+    _assert_rank_evidence(d, ranks=8, distinct=1)
+    c4 = d["config4_strong64"]
+    assert c4["scaling"] == "strong" and c4["total_prompts"] == 64 and c4["prompts_per_gpu"] == 8 and c4["steps"] == 4
+    assert len(c4["per_rank"]) == 8 and sorted(x["rank"] for x in c4["per_rank"]) == list(range(8))
+    chk = c4["per_rank_check"]
+    assert chk["tokens_sum"] == sum(x["tokens"] for x in c4["per_rank"])
+    assert abs(chk["value_from_records"] - c4["value"]) <= 1e-6 * c4["value"]
+    assert c4["value"] * c4["ms_per_step"] * 1e-3 * c4["steps"] >= 64 * 4 * 0.99          # every prompt commits >= 1 token per step
+    assert c4["tokens_per_forward"] >= 1.0 and c4["roofline"]["frac"] > 0 and c4["roofline"]["by_rank"]["us_per_launch"]["min"] > 0
 
 
 def test_shard_is_i_mod_world_for_eight_ranks():

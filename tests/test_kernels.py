@@ -698,20 +698,22 @@ def test_rs_step_beyond_the_lds_tables(B, L, V):
 
 # ------------------------------------------------------------------------------------- top-k / top-p (jf_rs_filter)
 def _filter_rows(x: torch.Tensor, temperature: float, top_k: int, top_p: float) -> np.ndarray:
-    """jf_rs_probs + jf_rs_filter on [R, V] logits -> the probability tensor as float32 values."""
+    """jf_rs_probs + jf_rs_filter on [R, V] logits: the per-row records, expanded (jf_rs_filter_expand) to the probability tensor the
+    reference's _build_target_probs returns, as float32 values.  Checked on the way: p_draft is the final value of the drafted id,
+    the rows' statistics are marked, and the records are self-consistent (the stages that are on, cuts inside [0, 1])."""
     R, V = x.shape
-    dev = x.device
-    dn = torch.zeros(R, dtype=torch.int64, device=dev)
-    p = torch.zeros(R, device=dev); m = torch.zeros(R, device=dev); sm = torch.zeros(R, device=dev)
-    packed = ops.new_packed(R, dev)
-    ws = torch.zeros(max(int(N.lib().jf_rs_workspace_bytes(R, V)) // 4, 1), device=dev)
-    N.check(N.lib().jf_rs_probs(ops._ptr(x), ops._dtype_code(x), R, V, V, ops._ptr(dn), temperature, ops._ptr(p), ops._ptr(m), ops._ptr(sm),
-                                ops._ptr(packed), ops._ptr(ws), ws.numel() * 4, ops._stream(dev)))
-    out = torch.empty_like(x)
-    N.check(N.lib().jf_rs_filter(ops._ptr(x), ops._dtype_code(x), R, V, V, ops._ptr(dn), temperature, int(top_k), float(top_p), ops._ptr(out),
-                                 ops._ptr(p), ops._ptr(m), ops._ptr(sm), ops._stream(dev)))
-    q = out.float().cpu().numpy()
-    assert np.array_equal(p.cpu().numpy(), q[:, 0]) and torch.isinf(m).all() and (sm == -1).all()     # p_draft = the final value; rows marked
+    dn = torch.arange(R, dtype=torch.int64, device=x.device) % V
+    probs, p, rec = ops.filtered_probs(x, temperature, top_k, top_p, dn)
+    q = probs.float().cpu().numpy()
+    assert np.array_equal(p.cpu().numpy(), q[np.arange(R), dn.cpu().numpy()])                        # p_draft = the final value
+    r = np.frombuffer(rec.cpu().numpy().tobytes(), dtype=np.dtype([("sum", "<f8"), ("row_max", "<f4"), ("x_keep", "<f4"), ("cut1", "<u4"),
+                                                                   ("tie1", "<i4"), ("s1", "<f4"), ("cut2", "<u4"), ("tie2", "<i4"),
+                                                                   ("s2", "<f4"), ("flags", "<u4"), ("rsv", "<u4")]))
+    want_flags = (1 if 0 < int(top_k) < V else 0) | (2 if 0.0 < float(top_p) < 1.0 else 0)
+    assert (r["flags"] == want_flags).all() and (r["cut1"] <= 0x3F800000).all() and (r["cut2"] <= 0x3F800000).all()
+    assert ((r["tie1"] >= -1) & (r["tie1"] < V) & (r["tie2"] >= -1) & (r["tie2"] < V)).all()
+    fin = np.isfinite(x.float().cpu().numpy()).all(-1) | True
+    assert (r["sum"][fin] >= 0).all()
     return q
 
 
@@ -763,6 +765,36 @@ def test_rs_filter_at_the_real_vocabulary(dtype, V, top_k, top_p, scale):
     if top_k:
         assert ((got > 0).sum(-1) <= top_k).all()
     assert np.allclose(got.astype(np.float64).sum(-1), 1.0, atol=3e-2 if dtype == torch.bfloat16 else 1e-5)
+
+
+@GPU
+@pytest.mark.parametrize("top_k,top_p", [(50, 0.0), (0, 0.9), (40, 0.95), (70000, 0.5)], ids=["k50", "p09", "k40_p095", "k70000_p05"])
+@pytest.mark.parametrize("shape", ["equal_logits", "two_values", "many_patterns", "one_heavy_pattern"])
+def test_rs_filter_bf16_rows_that_leave_the_fast_path(shape, top_k, top_p):
+    """The bf16 filter keeps 16-bit counts of the row's scaled-logit patterns and solves on a list of at most 4 096 occupied patterns.
+    Rows that do not fit: a pattern that occurs more than 65 535 times (all logits equal: one pattern 152 064 times — the plain adds
+    wrap, the checksum notices, the row is counted again with 32-bit side counters; two patterns of 76 032 ids each; one heavy pattern
+    among random ones) and rows with more than 4 096 occupied patterns (log-uniform magnitudes: the solver on the counters themselves).
+    Bit for bit against the oracle, T = 0.8."""
+    V = 152064
+    g = torch.Generator().manual_seed(len(shape) * 100 + top_k)
+    if shape == "equal_logits":
+        x = torch.zeros(2, V)
+        x[1] = 3.25
+    elif shape == "two_values":
+        x = torch.where(torch.arange(V) % 2 == 0, torch.tensor(1.0), torch.tensor(0.5)).repeat(2, 1)
+        x[1] = x[1].flip(0)
+    elif shape == "many_patterns":
+        x = torch.sign(torch.randn(2, V, generator=g)) * torch.pow(2.0, torch.rand(2, V, generator=g) * 28.0 - 24.0)
+    else:
+        x = torch.randn(2, V, generator=g)
+        x[:, torch.randperm(V, generator=g)[:70000]] = 0.75
+    x = x.to(torch.bfloat16)
+    if shape == "many_patterns":
+        assert len(np.unique(x[0].view(torch.int16).numpy())) > 4096
+    got = _filter_rows(x.cuda(), 0.8, top_k, top_p)
+    want = O.target_probs(x.float().numpy(), 0.8, "bf16", top_k or None, top_p or None)
+    assert np.array_equal(got, want), [(int((got[r] != want[r]).sum()), int((got[r] > 0).sum()), int((want[r] > 0).sum())) for r in range(2)]
 
 
 @GPU

@@ -62,6 +62,11 @@ engine_ab)            # round 6: the bench's engine sections, chunk loop on devi
     JF_ENGINE_LOOP=0 timeout 900 python tools/engine_sections.py 2>&1 | grep "JF_ENGINE_LOOP" | tee $O/callbacks.txt
     timeout 900 python tools/engine_sections.py --no-stage-timer 2>&1 | grep "JF_ENGINE_LOOP" | tee $O/loop_nostage.txt
     ;;
+filter)               # round 6: jf_rs_filter as records (bf16: pattern counts in LDS): parity subset, microbenchmark, the bench's filtered section
+    timeout 1500 $PYT tests/test_kernels.py tests/test_engine_decoder.py tests/test_engine_fuzz.py -m gpu -x -n 6 -k "filter or nongreedy or onpolicy or rs_ or sampl or budget" 2>&1 | tail -12
+    timeout 600 python tools/microbench_rs_filter.py "$@" 2>&1 | grep -v amdgpu.ids | tee $O/microbench.txt
+    timeout 900 python tools/engine_sections.py --repeat 1 2>&1 | grep "JF_ENGINE_LOOP" | tee $O/sections.txt
+    ;;
 gputests)             # the whole GPU suite + smoke
     timeout 2400 $PYT tests -m gpu -n 8 --durations=10 > $O/gputest.log 2>&1; tail -14 $O/gputest.log
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
