@@ -403,9 +403,12 @@ def nongreedy_section(model, cfg, weights, tuned, P: int = 64, L: int = 32, temp
         filtered = dict(top_k=50, top_p=0.9, value=sum(len(r["token_ids"]) for r in resf) / dtf, unit="tokens/s", iterations=itf,
                         ms_per_step=dtf / itf * 1e3,
                         rs_filter=None if fl is None else {"us_per_launch": fl["us"], "launches": fl["launches"], "bytes_per_launch": fl["bytes"],
+                                                           "bound": "hbm", "achieved": fl["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fl["gbs"] / HBM_PEAK_GBS,
                                                            "timing": stf.timing("rs_filter"),
-                                                           "kernel": "rs_filter_kernel (jf_rs_filter: exact probabilities -> top-k / top-p by bisection on an "
-                                                                     "LDS count histogram of the bf16 values -> renormalised probability rows)"},
+                                                           "kernel": "rs_filter_zone_kernel (+ rs_filter_hist_kernel over the rows it leaves: none here) — jf_rs_filter: one 48-byte "
+                                                                     "record per row instead of the filtered tensor; counts of the row's bf16 scaled-logit patterns in 16 KB of LDS, "
+                                                                     "three rows per CU, exact sum / top-k cut / nucleus / tie groups as sums over the occupied patterns, the row read "
+                                                                     "a second time for the last kept id of a tie group (bytes = the logits twice)"},
                         note="prefill included, the same prompts and token budget as the unfiltered run above (ms_per_step comparable); random-init weights: the kept sets end inside ties of equal bf16 "
                              "probabilities in most rows (ordered by token id, DESIGN.md 4)")
     except Exception as e:  # evidence for a new kernel must not cost the section

@@ -1073,8 +1073,7 @@ __device__ __forceinline__ void fh_scan(FhShared &sh, long long &cnt, double &su
     __syncthreads();
     double sb = 0.0, st = 0.0;
     long long cb = 0, ct = 0;
-#pragma unroll
-    for (int w = 0; w < FH_NW; ++w) { if (w == wave) { sb = st; cb = ct; } st += sh.dred[w]; ct += sh.lred[w]; }
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { if (w == wave) { sb = st; cb = ct; } st += sh.dred[w]; ct += sh.lred[w]; }
     cnt_incl = cb + ci; sum_incl = sb + si;
     cnt_excl = cb + cu; sum_excl = sb + su;
     cnt = ct; sum = st;
@@ -1090,8 +1089,7 @@ __device__ __forceinline__ void fh_min_max2(FhShared &sh, int &lo, int &hi) {   
     if ((threadIdx.x & 63) == 0) { sh.scan[threadIdx.x >> 6] = lo; sh.scan[FH_NW + (threadIdx.x >> 6)] = hi; }
     __syncthreads();
     lo = sh.scan[0]; hi = sh.scan[FH_NW];
-#pragma unroll
-    for (int w = 1; w < FH_NW; ++w) { const int a = sh.scan[w], b = sh.scan[FH_NW + w]; lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { const int a = sh.scan[w], b = sh.scan[FH_NW + w]; lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
     __syncthreads();
 }
 __device__ __forceinline__ int fh_min_max(FhShared &sh, int v, bool want_max) {          // workgroup min / max of an int (every thread gets it)
@@ -1101,8 +1099,7 @@ __device__ __forceinline__ int fh_min_max(FhShared &sh, int v, bool want_max) { 
     if ((threadIdx.x & 63) == 0) sh.scan[threadIdx.x >> 6] = v;
     __syncthreads();
     int r = sh.scan[0];
-#pragma unroll
-    for (int w = 1; w < FH_NW; ++w) { const int o = sh.scan[w]; r = want_max ? (o > r ? o : r) : (o < r ? o : r); }
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { const int o = sh.scan[w]; r = want_max ? (o > r ? o : r) : (o < r ? o : r); }
     __syncthreads();
     return r;
 }
@@ -1113,13 +1110,13 @@ template <bool SIDE>
 __device__ __forceinline__ void fh_count_row(FhShared &sh, uint32_t *hist, const RsRow &row) {
     constexpr int EPV = 8, NB = 8;
     const float mcut = row.M + (float)RS_EXP_CUT;
-    for (int64_t b0 = (int64_t)threadIdx.x * EPV; b0 < row.V; b0 += (int64_t)NB * FH_TPB * EPV) {
+    for (int64_t b0 = (int64_t)threadIdx.x * EPV; b0 < row.V; b0 += (int64_t)NB * blockDim.x * EPV) {
         u32x4 v[NB];
 #pragma unroll
-        for (int k = 0; k < NB; ++k) { const int64_t e0 = b0 + (int64_t)k * FH_TPB * EPV; if (e0 < row.V) v[k] = rs_load_vec<JF_BF16>(row, e0); }
+        for (int k = 0; k < NB; ++k) { const int64_t e0 = b0 + (int64_t)k * blockDim.x * EPV; if (e0 < row.V) v[k] = rs_load_vec<JF_BF16>(row, e0); }
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            const int64_t e0 = b0 + (int64_t)k * FH_TPB * EPV;
+            const int64_t e0 = b0 + (int64_t)k * blockDim.x * EPV;
             if (e0 >= row.V) continue;
             float xs[EPV];
             rs_scaled_from_vec<JF_BF16>(row, v[k], xs);
@@ -1150,13 +1147,13 @@ __device__ __forceinline__ uint32_t fh_count_row_fast(uint32_t *hist, const RsRo
     constexpr int EPV = 8, NB = 8;
     const float mcut = row.M + (float)RS_EXP_CUT;
     uint32_t mine = 0u;
-    for (int64_t b0 = (int64_t)threadIdx.x * EPV; b0 < row.V; b0 += (int64_t)NB * FH_TPB * EPV) {
+    for (int64_t b0 = (int64_t)threadIdx.x * EPV; b0 < row.V; b0 += (int64_t)NB * blockDim.x * EPV) {
         u32x4 v[NB];
 #pragma unroll
-        for (int k = 0; k < NB; ++k) { const int64_t e0 = b0 + (int64_t)k * FH_TPB * EPV; if (e0 < row.V) v[k] = rs_load_vec<JF_BF16>(row, e0); }
+        for (int k = 0; k < NB; ++k) { const int64_t e0 = b0 + (int64_t)k * blockDim.x * EPV; if (e0 < row.V) v[k] = rs_load_vec<JF_BF16>(row, e0); }
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            const int64_t e0 = b0 + (int64_t)k * FH_TPB * EPV;
+            const int64_t e0 = b0 + (int64_t)k * blockDim.x * EPV;
             if (e0 >= row.V) continue;
             float xs[EPV];
             rs_scaled_from_vec<JF_BF16>(row, v[k], xs);
@@ -1186,7 +1183,8 @@ __device__ __forceinline__ float fh_solve(FhShared &sh, const uint32_t *hist, co
     const int tid = threadIdx.x;
     const float M = row.M;
     const uint32_t kbase = 65536u - 64u * (uint32_t)(tid + 1);
-    const int ipt = (n_occ + FH_TPB - 1) / FH_TPB, i0 = tid * ipt, i1 = i0 + ipt < n_occ ? i0 + ipt : n_occ;
+    const int TPB = (int)blockDim.x, TILE = TPB * 8;                       // (1 024 threads over the counters, 512 over the zone table)
+    const int ipt = (n_occ + TPB - 1) / TPB, i0 = tid * ipt, i1 = i0 + ipt < n_occ ? i0 + ipt : n_occ;
     // f(key, count, item) over this thread's occupied patterns (the counters: in the thread's rotated word order, conflict-free)
     auto for_mine = [&](auto f) {
         if constexpr (FAST) {
@@ -1349,7 +1347,7 @@ __device__ __forceinline__ float fh_solve(FhShared &sh, const uint32_t *hist, co
     if (tie1_needed && need1 == 0) rec.tie1 = -1;
     const bool pass2 = (tie1_needed && need1 > 0) || tie2_needed;
     if (pass2) {
-        const int64_t ntiles = (V + FH_TILE - 1) / FH_TILE;
+        const int64_t ntiles = (V + TILE - 1) / TILE;
         __syncthreads();
         if (tid < FH_MAX_TILES) { sh.tileA[tid] = 0; sh.tileB[tid] = 0; }
         __syncthreads();
@@ -1368,15 +1366,15 @@ __device__ __forceinline__ float fh_solve(FhShared &sh, const uint32_t *hist, co
             }
         };
         {
-            constexpr int NB = 8;
+            constexpr int NB = FAST ? 4 : 8;
             for (int64_t t0 = 0; t0 < ntiles; t0 += NB) {
                 u32x4 v[NB];
 #pragma unroll
-                for (int k = 0; k < NB; ++k) { const int64_t e0 = (t0 + k) * FH_TILE + (int64_t)tid * EPV; if (t0 + k < ntiles && e0 < V) v[k] = rs_load_vec<JF_BF16>(row, e0); }
+                for (int k = 0; k < NB; ++k) { const int64_t e0 = (t0 + k) * TILE + (int64_t)tid * EPV; if (t0 + k < ntiles && e0 < V) v[k] = rs_load_vec<JF_BF16>(row, e0); }
 #pragma unroll
                 for (int k = 0; k < NB; ++k) {
                     if (t0 + k >= ntiles) continue;                          // (workgroup-uniform)
-                    const int64_t e0 = (t0 + k) * FH_TILE + (int64_t)tid * EPV;
+                    const int64_t e0 = (t0 + k) * TILE + (int64_t)tid * EPV;
                     uint32_t ma = 0u, mb = 0u;
                     if (e0 < V) classes(v[k], e0, ma, mb);
                     if (ma) atomicAdd(&sh.tileA[t0 + k], __popc(ma));             // (members of a cut group are few: an add per lane that holds one)
@@ -1394,8 +1392,8 @@ __device__ __forceinline__ float fh_solve(FhShared &sh, const uint32_t *hist, co
                 for (int tl = 0; tl < (int)ntiles; ++tl) {
                     long long n = use_b ? sh.tileB[tl] : 0;
                     if (use_a) {
-                        const int64_t t_lo = (int64_t)tl * FH_TILE;
-                        int64_t t_hi = t_lo + FH_TILE - 1;
+                        const int64_t t_lo = (int64_t)tl * TILE;
+                        int64_t t_hi = t_lo + TILE - 1;
                         if (t_hi > V - 1) t_hi = V - 1;
                         n += a_max >= t_hi ? sh.tileA[tl] : a_max >= t_lo ? sh.bl[2] : 0;
                     }
@@ -1407,7 +1405,7 @@ __device__ __forceinline__ float fh_solve(FhShared &sh, const uint32_t *hist, co
             const int tl = sh.bi[1];
             if (tl < 0) { __syncthreads(); return V - 1; }
             const long long rank = sh.bl[0];
-            const int64_t e0 = (int64_t)tl * FH_TILE + (int64_t)tid * EPV;
+            const int64_t e0 = (int64_t)tl * TILE + (int64_t)tid * EPV;
             uint32_t ma = 0u, mb = 0u;
             if (e0 < V) classes(rs_load_vec<JF_BF16>(row, e0), e0, ma, mb);
             uint32_t mm = use_b ? mb : 0u;
@@ -1431,7 +1429,7 @@ __device__ __forceinline__ float fh_solve(FhShared &sh, const uint32_t *hist, co
         if (tie2_needed) {
             if (grp1_in2) {
                 // class A ids up to tie1 are members too: how many of them the tile that holds tie1 has (ids <= tie1), for nth()
-                const int64_t tl = tie1 / FH_TILE, e0 = tl * FH_TILE + (int64_t)tid * EPV;
+                const int64_t tl = tie1 / TILE, e0 = tl * TILE + (int64_t)tid * EPV;
                 uint32_t ma = 0u, mb = 0u;
                 if (e0 < V) classes(rs_load_vec<JF_BF16>(row, e0), e0, ma, mb);
                 long long mine = 0, ci, ce; double z = 0.0, zi, ze;
@@ -1462,16 +1460,14 @@ __device__ __forceinline__ float fh_solve(FhShared &sh, const uint32_t *hist, co
     return pd;
 }
 
-__global__ __launch_bounds__(FH_TPB, 1) void rs_filter_hist_kernel(const void *logits, int64_t R, int64_t V, int64_t row_stride, const int64_t *draft_next,
-                                                                    float t, int top_k, double top_p, jf_rs_filter_row *filt, float *p_draft,
-                                                                    float *row_max, float *row_sumexp) {
-    __shared__ FhShared sh;
-    extern __shared__ __attribute__((aligned(16))) unsigned char fh_dyn[];
+constexpr uint32_t FH_RETRY = 0x80000000u;        // (internal, in jf_rs_filter_row::flags between the two launches) the row is left to rs_filter_hist_kernel
+__device__ __forceinline__ void fh_hist_row(FhShared &sh, unsigned char *fh_dyn, int64_t r, const void *logits, int64_t V, int64_t row_stride,
+                                            const int64_t *draft_next, float t, int top_k, double top_p, jf_rs_filter_row *filt, float *p_draft,
+                                            float *row_max, float *row_sumexp) {
     uint32_t *hist = (uint32_t *)fh_dyn;
     uint32_t *occ = hist + FH_WORDS;                                        // [FH_ITEMS] the occupied patterns, largest value first
     uint16_t *pc = (uint16_t *)(occ + FH_ITEMS);                            // [FH_ITEMS] their probabilities (bf16 bits)
     const int tid = threadIdx.x;
-    const int64_t r = blockIdx.x;
     const float M = row_max[r];
     jf_rs_filter_row rec;
     rec.sum = 0.0; rec.row_max = M; rec.x_keep = -INFINITY; rec.cut1 = 0u; rec.tie1 = (int32_t)V - 1; rec.s1 = 1.f; rec.cut2 = 0u; rec.tie2 = (int32_t)V - 1; rec.s2 = 1.f;
@@ -1544,6 +1540,152 @@ __global__ __launch_bounds__(FH_TPB, 1) void rs_filter_hist_kernel(const void *l
         pd = fh_solve<false>(sh, hist, occ, pc, 0, row, r, V, draft_next, top_k, top_p, k_on, p_on, rec);
     }
     finish(pd);
+}
+
+// retry_only: the rows rs_filter_zone_kernel left (FH_RETRY), a workgroup walks the rows blockIdx.x, + gridDim.x, ...; else every row
+__global__ __launch_bounds__(FH_TPB, 1) void rs_filter_hist_kernel(const void *logits, int64_t R, int64_t V, int64_t row_stride, const int64_t *draft_next,
+                                                                    float t, int top_k, double top_p, jf_rs_filter_row *filt, float *p_draft,
+                                                                    float *row_max, float *row_sumexp, int retry_only) {
+    __shared__ FhShared sh;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fh_dyn[];
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        if (retry_only && !(filt[r].flags & FH_RETRY)) continue;            // (workgroup-uniform)
+        __syncthreads();
+        fh_hist_row(sh, fh_dyn, r, logits, V, row_stride, draft_next, t, top_k, top_p, filt, p_draft, row_max, row_sumexp);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same record from 16 KB of counters instead of 128 KB, so that a CU holds TWO rows at once and one row's solving overlaps the
+// other's streaming.  Between M - 104 and M the scaled logits of a row span ~34 000 bf16 patterns, but nearly all of those are the
+// patterns of magnitudes below 2^-16 on either side of zero, which a row of 152 064 logits visits a handful of times: the table holds
+// the patterns with 2^-16 <= |x| < 2^16 (32 binades x 128 x 2 signs = 8 192, largest value first), a row's smaller magnitudes go
+// to a list of 64 keys (sorted and counted by 64 threads), and a row that does not fit — more than 64 such ids, a magnitude of
+// 2^16 or more, a pattern more than 65 535 times, more than 4 096 occupied patterns — is left to rs_filter_hist_kernel
+// (FH_RETRY), launched behind this one over the flagged rows only.  From the list of occupied patterns on, the two kernels share
+// fh_solve.
+// ------------------------------------------------------------------------------------------------
+#ifndef JF_ZN_WAVES
+#define JF_ZN_WAVES 6                       // waves per SIMD asked of the compiler: 6 = three rows per CU (<= 85 VGPRs), 4 = two
+#endif
+constexpr int ZN_TPB = 512, ZN_SLOTS = 8192, ZN_TINY = 64, ZN_EXP_LO = 111, ZN_EXP_HI = 142;
+constexpr unsigned ZN_LDS = (ZN_SLOTS / 2) * 4 + FH_ITEMS * 4 + FH_ITEMS * 2;
+__global__ __launch_bounds__(ZN_TPB, JF_ZN_WAVES) void rs_filter_zone_kernel(const void *logits, int64_t R, int64_t V, int64_t row_stride, const int64_t *draft_next,
+                                                                    float t, int top_k, double top_p, jf_rs_filter_row *filt, float *p_draft,
+                                                                    float *row_max, float *row_sumexp) {
+    constexpr int EPV = 8, NB = 4;                                          // (four loads in flight per thread x three workgroups per CU)
+    __shared__ FhShared sh;
+    __shared__ uint32_t s_tiny[ZN_TINY];
+    __shared__ int s_ntiny, s_retry, s_ndist;
+    extern __shared__ __attribute__((aligned(16))) unsigned char zn_dyn[];
+    uint32_t *table = (uint32_t *)zn_dyn;                                   // [ZN_SLOTS / 2] two 16-bit counts per word; slot = place in value order
+    uint32_t *occ = table + ZN_SLOTS / 2;
+    uint16_t *pc = (uint16_t *)(occ + FH_ITEMS);
+    const int tid = threadIdx.x;
+    const int64_t r = blockIdx.x;
+    const float M = row_max[r];
+    jf_rs_filter_row rec;
+    rec.sum = 0.0; rec.row_max = M; rec.x_keep = -INFINITY; rec.cut1 = 0u; rec.tie1 = (int32_t)V - 1; rec.s1 = 1.f; rec.cut2 = 0u; rec.tie2 = (int32_t)V - 1; rec.s2 = 1.f;
+    const bool k_on = top_k > 0 && (int64_t)top_k < V, p_on = top_p > 0.0 && top_p < 1.0;
+    rec.flags = (k_on ? JF_RS_FILT_TOPK : 0u) | (p_on ? JF_RS_FILT_TOPP : 0u); rec.rsv = 0u;
+    if ((__float_as_uint(M) & 0x7F800000u) == 0x7F800000u) {               // NaN / inf logits: the row filters to zeros (sum = 0)
+        if (tid == 0) { filt[r] = rec; p_draft[r] = 0.f; row_max[r] = INFINITY; row_sumexp[r] = RS_PROB_ROW; }
+        return;
+    }
+    const RsRow row = rs_make_row<JF_BF16>(logits, r, V, row_stride, t, M, 1.f);
+    rs_load_tab(sh.tab);
+    for (int w = tid; w < ZN_SLOTS / 2; w += ZN_TPB) table[w] = 0u;
+    if (tid == 0) { sh.n_ovf = 0; s_ntiny = 0; s_retry = 0; s_ndist = 0; }
+    __syncthreads();
+    // ---- 1. the counts
+    const float mcut = M + (float)RS_EXP_CUT;
+    uint32_t counted = 0u;
+    for (int64_t b0 = (int64_t)tid * EPV; b0 < V; b0 += (int64_t)NB * ZN_TPB * EPV) {
+        u32x4 v[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) { const int64_t e0 = b0 + (int64_t)k * ZN_TPB * EPV; if (e0 < V) v[k] = rs_load_vec<JF_BF16>(row, e0); }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int64_t e0 = b0 + (int64_t)k * ZN_TPB * EPV;
+            if (e0 >= V) continue;
+            float xs[EPV];
+            rs_scaled_from_vec<JF_BF16>(row, v[k], xs);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) {
+                if (!(xs[j] >= mcut)) continue;                            // (slots beyond V hold -inf)
+                const uint32_t h = __float_as_uint(xs[j]) >> 16, mag = h & 0x7FFFu, off = mag - (uint32_t)(ZN_EXP_LO << 7);
+                ++counted;
+                if (off < (uint32_t)((ZN_EXP_HI - ZN_EXP_LO + 1) << 7)) {
+                    const uint32_t slot = (h & 0x8000u) ? 4096u + off : 4095u - off;
+                    atomicAdd(&table[slot >> 1], (slot & 1u) ? 0x10000u : 1u);
+                } else if (mag < (uint32_t)(ZN_EXP_LO << 7)) {             // a magnitude below 2^-16: the list
+                    const int at = atomicAdd(&s_ntiny, 1);
+                    if (at < ZN_TINY) s_tiny[at] = fh_key(h);
+                } else s_retry = 1;                                          // a magnitude of 2^16 or more
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 2. the list of occupied patterns, largest value first: table slots in order, the small magnitudes between the two signs
+    const int n_tiny = s_ntiny < ZN_TINY ? s_ntiny : ZN_TINY;
+    uint32_t my_tiny = 0u, my_cnt = 0u;
+    int my_pos = -1;
+    if (tid < n_tiny) {                                                      // 64 threads: distinct keys, their counts, their places (largest first)
+        my_tiny = s_tiny[tid];
+        bool first = true;
+        for (int j = 0; j < n_tiny; ++j) { const uint32_t kj = s_tiny[j]; my_cnt += kj == my_tiny ? 1u : 0u; first &= !(kj == my_tiny && j < tid); }
+        if (first) {
+            my_pos = 0;
+            for (int j = 0; j < n_tiny; ++j) {
+                const uint32_t kj = s_tiny[j];
+                bool jfirst = kj > my_tiny;
+                for (int q = 0; q < j && jfirst; ++q) jfirst = s_tiny[q] != kj;
+                my_pos += jfirst ? 1 : 0;
+            }
+            atomicAdd(&s_ndist, 1);
+        }
+    }
+    long long n_mine = 0, in_table = 0;
+    uint32_t w4[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                                            // this thread's 16 slots (8 words; 32 lanes x 8 words: two lanes per bank)
+        w4[i] = table[tid * 8 + i];
+        n_mine += ((w4[i] & 0xFFFFu) ? 1 : 0) + ((w4[i] >> 16) ? 1 : 0);
+        in_table += (w4[i] & 0xFFFFu) + (w4[i] >> 16);
+    }
+    long long packed3 = n_mine | (in_table << 20) | ((long long)counted << 40), ci, ce;   // (each total below 2^20: one scan carries the three)
+    double d0 = 0.0, di, de;
+    fh_scan(sh, packed3, d0, ci, di, ce, de);
+    const long long n_table = packed3 & 0xFFFFF, tot_table = (packed3 >> 20) & 0xFFFFF, tot_counted = packed3 >> 40;
+    const int n_dist = s_ndist;
+    const long long n_occ = n_table + n_dist;
+    if (s_retry || s_ntiny > ZN_TINY || tot_table + s_ntiny != tot_counted || n_occ > FH_ITEMS) {   // (workgroup-uniform) left to the other kernel
+        if (tid == 0) filt[r].flags = FH_RETRY;
+        return;
+    }
+    {
+        int at = (int)(ce & 0xFFFFF) + (tid >= ZN_TPB / 2 ? n_dist : 0);   // (threads of the second half own the negative values: behind the small magnitudes)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const uint32_t c = hh ? (w4[i] >> 16) : (w4[i] & 0xFFFFu);
+                if (!c) continue;
+                const uint32_t slot = (uint32_t)tid * 16u + 2u * i + hh;
+                const uint32_t off = slot < 4096u ? 4095u - slot : slot - 4096u;
+                const uint32_t h = (slot < 4096u ? 0u : 0x8000u) | (off + (uint32_t)(ZN_EXP_LO << 7));
+                occ[at++] = (fh_key(h) << 16) | c;
+            }
+        }
+        // (the scan gave thread 256 the number of occupied slots of the positive half as its exclusive prefix: where the list goes)
+        if (tid == ZN_TPB / 2) sh.bi[2] = (int)(ce & 0xFFFFF);
+    }
+    __syncthreads();
+    if (my_pos >= 0) occ[sh.bi[2] + my_pos] = (my_tiny << 16) | my_cnt;
+    __syncthreads();
+    const float pd = fh_solve<true>(sh, nullptr, occ, pc, (int)n_occ, row, r, V, draft_next, top_k, top_p, k_on, p_on, rec);
+    if (tid == 0) { filt[r] = rec; p_draft[r] = pd; row_max[r] = INFINITY; row_sumexp[r] = RS_PROB_ROW; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2124,7 +2266,15 @@ extern "C" int jf_rs_filter(const void *logits, int dtype, int64_t R, int64_t V,
     };
     if (dtype == JF_BF16 && need == 0) {
         if (!lds_ok((const void *)rs_filter_hist_kernel, FH_LDS, 1)) return fail(JF_E_LAUNCH, "jf_rs_filter: the device refuses %u bytes of LDS per workgroup", FH_LDS);
-        rs_filter_hist_kernel<<<dim3((unsigned)R), dim3(FH_TPB), FH_LDS, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, filt, p_draft, row_max, row_sumexp);
+        static const bool zone = [] { const char *e = getenv("JF_RS_FILTER_ZONE"); return !(e && e[0] == '0'); }();   // A/B knob, read once
+        if (zone && V <= (int64_t)FH_MAX_TILES * ZN_TPB * 8) {
+            // two launches: the rows whose patterns fit the 16 KB zone table (two rows per CU), then the rows that did not (none, with a model's logits)
+            rs_filter_zone_kernel<<<dim3((unsigned)R), dim3(ZN_TPB), ZN_LDS, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, filt, p_draft, row_max, row_sumexp);
+            const unsigned g = (unsigned)(R < 256 ? R : 256);
+            rs_filter_hist_kernel<<<dim3(g), dim3(FH_TPB), FH_LDS, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, filt, p_draft, row_max, row_sumexp, 1);
+            return check_launch("rs_filter_zone_kernel + rs_filter_hist_kernel");
+        }
+        rs_filter_hist_kernel<<<dim3((unsigned)R), dim3(FH_TPB), FH_LDS, s>>>(logits, R, V, row_stride, draft_next, tt, top_k, top_p, filt, p_draft, row_max, row_sumexp, 0);
         return check_launch("rs_filter_hist_kernel");
     }
     if (dtype == JF_F32) {
