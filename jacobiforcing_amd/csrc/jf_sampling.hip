@@ -1171,6 +1171,43 @@ __device__ __forceinline__ uint32_t fh_count_row_fast(uint32_t *hist, const RsRo
     return mine;
 }
 
+// packed bf16 patterns, two ids per register (v_pk_*_u16): what the zone kernel's count pass and the tie pass stream with
+typedef unsigned short zn_u16x2 __attribute__((ext_vector_type(2)));
+typedef short zn_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t zn_pk_sub(uint32_t a, uint32_t b) {      // v_pk_sub_u16 (wraps per half)
+    return __builtin_bit_cast(uint32_t, (zn_u16x2)(__builtin_bit_cast(zn_u16x2, a) - __builtin_bit_cast(zn_u16x2, b)));
+}
+__device__ __forceinline__ uint32_t zn_pk_min(uint32_t a, uint32_t b) {      // v_pk_min_u16
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(zn_u16x2, a), __builtin_bit_cast(zn_u16x2, b)));
+}
+__device__ __forceinline__ uint32_t zn_pk_rotl1(uint32_t a) {                // each half rotated left by one: magnitude << 1 | sign
+    const zn_u16x2 v = __builtin_bit_cast(zn_u16x2, a);
+    return __builtin_bit_cast(uint32_t, (zn_u16x2)((v << (zn_u16x2){1, 1}) | (v >> (zn_u16x2){15, 15})));
+}
+__device__ __forceinline__ uint32_t zn_pk_key(uint32_t a) {                  // fh_key of both halves (ascending with the value)
+    const zn_s16x2 m = __builtin_bit_cast(zn_s16x2, a) >> (zn_s16x2){15, 15};
+    return a ^ (__builtin_bit_cast(uint32_t, m) | 0x80008000u);
+}
+__device__ __forceinline__ uint32_t zn_pk_has_zero(uint32_t e) { return (e - 0x00010001u) & ~e & 0x80008000u; }   // non-zero iff a half of e is zero
+// the scaled logits of one 16-byte vector as bf16 patterns, two per word (the even id in the low half), as torch forms them
+__device__ __forceinline__ void rs_scaled_pk_from_vec(const RsRow &r, const u32x4 v, uint32_t (&pk)[4]) {
+    pk[0] = v.x; pk[1] = v.y; pk[2] = v.z; pk[3] = v.w;
+    if (r.unit_t) return;                                                    // (wave-uniform branches outside the element loop, as rs_scaled_from_vec)
+    if (r.fast) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const rs_f32x2 q = {__uint_as_float(pk[j] << 16) * r.inv_t, __uint_as_float(pk[j] & 0xFFFF0000u) * r.inv_t};
+            pk[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(q, rs_bf16x2));
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = bf16_rne(__fdiv_rn(__uint_as_float(pk[j] << 16), r.t)), b = bf16_rne(__fdiv_rn(__uint_as_float(pk[j] & 0xFFFF0000u), r.t));
+            pk[j] = (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xFFFF0000u);
+        }
+    }
+}
+
 // What top-k / top-p make of the row, from its pattern counts.  FAST: the occupied patterns as a compact list in LDS, largest value
 // first — item i = occ[i] = key << 16 | count, its probability's bf16 bits in pc[i]; a thread owns `ipt` consecutive items.  !FAST:
 // the counters themselves, a thread owns 64 consecutive patterns (rows with more than FH_ITEMS occupied patterns, or a pattern that
@@ -1366,7 +1403,16 @@ __device__ __forceinline__ float fh_solve(FhShared &sh, const uint32_t *hist, co
             }
         };
         {
+            // The pass is a stream with a handful of hits: a vector is first asked, on its packed patterns (two ids per instruction, no
+            // branch), whether ANY of its eight ids belongs to a class; only such vectors are taken apart.  And it ends early: the ids
+            // are wanted in id order, so once the tiles read so far hold the ranks asked for, the rest of the row is not read.
             constexpr int NB = FAST ? 4 : 8;
+            const bool wantA = (tie1_needed && need1 > 0) || (tie2_needed && grp1_in2), wantB = tie2_needed;
+            const bool early = !grp1_in2;                                    // (with the top-k group inside the top-p group the ranks are not per class)
+            const uint32_t aLo2 = (uint32_t)(a_lo & 0xFFFF) * 0x00010001u, aSp2 = (uint32_t)((a_hi - a_lo) & 0xFFFF) * 0x00010001u;
+            const uint32_t bLo2 = (uint32_t)(b_lo & 0xFFFF) * 0x00010001u, bSp2 = (uint32_t)((b_hi - b_lo) & 0xFFFF) * 0x00010001u;
+            const bool rangeA = wantA && a_hi >= a_lo, rangeB = wantB && b_hi >= b_lo;
+            long long cumA = 0, cumB = 0;
             for (int64_t t0 = 0; t0 < ntiles; t0 += NB) {
                 u32x4 v[NB];
 #pragma unroll
@@ -1375,10 +1421,27 @@ __device__ __forceinline__ float fh_solve(FhShared &sh, const uint32_t *hist, co
                 for (int k = 0; k < NB; ++k) {
                     if (t0 + k >= ntiles) continue;                          // (workgroup-uniform)
                     const int64_t e0 = (t0 + k) * TILE + (int64_t)tid * EPV;
-                    uint32_t ma = 0u, mb = 0u;
-                    if (e0 < V) classes(v[k], e0, ma, mb);
-                    if (ma) atomicAdd(&sh.tileA[t0 + k], __popc(ma));             // (members of a cut group are few: an add per lane that holds one)
-                    if (mb) atomicAdd(&sh.tileB[t0 + k], __popc(mb));
+                    if (e0 >= V) continue;
+                    uint32_t pk[4], hit = 0u;
+                    rs_scaled_pk_from_vec(row, v[k], pk);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t key2 = zn_pk_key(pk[j]);
+                        if (rangeA) { const uint32_t d = zn_pk_sub(key2, aLo2); hit |= zn_pk_has_zero(zn_pk_min(d, aSp2) ^ d); }
+                        if (rangeB) { const uint32_t d = zn_pk_sub(key2, bLo2); hit |= zn_pk_has_zero(zn_pk_min(d, bSp2) ^ d); }
+                    }
+                    if (__builtin_expect(hit != 0u, 0)) {
+                        uint32_t ma = 0u, mb = 0u;
+                        classes(v[k], e0, ma, mb);
+                        if (ma && wantA) atomicAdd(&sh.tileA[t0 + k], __popc(ma));     // (members of a cut group are few: an add per lane that holds one)
+                        if (mb && wantB) atomicAdd(&sh.tileB[t0 + k], __popc(mb));
+                    }
+                }
+                if (early) {
+                    __syncthreads();
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) if (t0 + k < ntiles) { cumA += sh.tileA[t0 + k]; cumB += sh.tileB[t0 + k]; }
+                    if ((!wantA || cumA >= need1) && (!wantB || cumB >= c2)) break;   // (workgroup-uniform)
                 }
             }
         }
@@ -1557,20 +1620,30 @@ __global__ __launch_bounds__(FH_TPB, 1) void rs_filter_hist_kernel(const void *l
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same record from 16 KB of counters instead of 128 KB, so that a CU holds TWO rows at once and one row's solving overlaps the
-// other's streaming.  Between M - 104 and M the scaled logits of a row span ~34 000 bf16 patterns, but nearly all of those are the
-// patterns of magnitudes below 2^-16 on either side of zero, which a row of 152 064 logits visits a handful of times: the table holds
-// the patterns with 2^-16 <= |x| < 2^16 (32 binades x 128 x 2 signs = 8 192, largest value first), a row's smaller magnitudes go
-// to a list of 64 keys (sorted and counted by 64 threads), and a row that does not fit — more than 64 such ids, a magnitude of
-// 2^16 or more, a pattern more than 65 535 times, more than 4 096 occupied patterns — is left to rs_filter_hist_kernel
-// (FH_RETRY), launched behind this one over the flagged rows only.  From the list of occupied patterns on, the two kernels share
-// fh_solve.
+// The same record from 32 KB of counters instead of 128 KB, so that a CU holds THREE rows at once and one row's solving overlaps
+// the others' streaming.  Between M - 104 and M the scaled logits of a row span ~34 000 bf16 patterns, but nearly all of those are
+// the patterns of magnitudes below 2^-16 on either side of zero, which a row of 152 064 logits visits a handful of times: the table
+// holds the patterns with 2^-16 <= |x| < 2^16 (32 binades x 128 x 2 signs = 8 192 32-bit counters, the two signs of a magnitude
+// side by side), a row's smaller magnitudes go to a list of 64 keys (sorted and counted by 64 threads), and a row that does not
+// fit — more than 64 such ids, a magnitude of 2^16 or more that carries mass, a pattern more than 65 535 times, more than 4 096
+// occupied patterns — is left to rs_filter_hist_kernel (FH_RETRY), launched behind this one over the flagged rows only.  From the
+// list of occupied patterns on, the two kernels share fh_solve.
+//
+// The count pass is what a row costs (the first version spent ~30 instructions and five branches per element on it: 43 us per row
+// with three rows per CU, all of it VALU issue).  Now it works on the PACKED bf16 patterns, two ids per register, without a branch
+// per element: rotate each half left by one (magnitude << 1 | sign), subtract the table's first magnitude — that IS the counter's
+// index when it is below 8 192 — OR the four words of a 16-byte vector together and look at the top bits once per vector: a vector
+// with an id outside the table (one in ~10^4) takes the slow path per element, every other one is eight plain LDS adds.  Nothing is
+// compared with M - 104 per element: patterns below it are dropped when the list is built (the slot's value says so), and since the
+// counters are 32 bits wide there is no checksum for wrapped counters either.
 // ------------------------------------------------------------------------------------------------
 #ifndef JF_ZN_WAVES
 #define JF_ZN_WAVES 6                       // waves per SIMD asked of the compiler: 6 = three rows per CU (<= 85 VGPRs), 4 = two
 #endif
 constexpr int ZN_TPB = 512, ZN_SLOTS = 8192, ZN_TINY = 64, ZN_EXP_LO = 111, ZN_EXP_HI = 142;
-constexpr unsigned ZN_LDS = (ZN_SLOTS / 2) * 4 + FH_ITEMS * 4 + FH_ITEMS * 2;
+constexpr uint32_t ZN_LO16 = (uint32_t)ZN_EXP_LO << 7;                       // first magnitude pattern of the table
+constexpr unsigned ZN_LDS = (ZN_SLOTS + 4) * 4;                               // the counters; the list of occupied patterns and their probabilities re-use them
+static_assert(FH_ITEMS * 4 + FH_ITEMS * 2 <= ZN_SLOTS * 4, "occ + pc must fit the counters they replace");
 __global__ __launch_bounds__(ZN_TPB, JF_ZN_WAVES) void rs_filter_zone_kernel(const void *logits, int64_t R, int64_t V, int64_t row_stride, const int64_t *draft_next,
                                                                     float t, int top_k, double top_p, jf_rs_filter_row *filt, float *p_draft,
                                                                     float *row_max, float *row_sumexp) {
@@ -1579,10 +1652,10 @@ __global__ __launch_bounds__(ZN_TPB, JF_ZN_WAVES) void rs_filter_zone_kernel(con
     __shared__ uint32_t s_tiny[ZN_TINY];
     __shared__ int s_ntiny, s_retry, s_ndist;
     extern __shared__ __attribute__((aligned(16))) unsigned char zn_dyn[];
-    uint32_t *table = (uint32_t *)zn_dyn;                                   // [ZN_SLOTS / 2] two 16-bit counts per word; slot = place in value order
-    uint32_t *occ = table + ZN_SLOTS / 2;
+    uint32_t *table = (uint32_t *)zn_dyn;                                   // [ZN_SLOTS] counter of magnitude LO16 + (i >> 1), sign i & 1
+    uint32_t *occ = table;                                                   // [FH_ITEMS] the list, once every counter has been read
     uint16_t *pc = (uint16_t *)(occ + FH_ITEMS);
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t r = blockIdx.x;
     const float M = row_max[r];
     jf_rs_filter_row rec;
@@ -1594,40 +1667,55 @@ __global__ __launch_bounds__(ZN_TPB, JF_ZN_WAVES) void rs_filter_zone_kernel(con
         return;
     }
     const RsRow row = rs_make_row<JF_BF16>(logits, r, V, row_stride, t, M, 1.f);
+    FH_STAMP(8);
     rs_load_tab(sh.tab);
-    for (int w = tid; w < ZN_SLOTS / 2; w += ZN_TPB) table[w] = 0u;
+    for (int w = tid; w < ZN_SLOTS; w += ZN_TPB) table[w] = 0u;
     if (tid == 0) { sh.n_ovf = 0; s_ntiny = 0; s_retry = 0; s_ndist = 0; }
     __syncthreads();
+    FH_STAMP(9);
     // ---- 1. the counts
     const float mcut = M + (float)RS_EXP_CUT;
-    uint32_t counted = 0u;
-    for (int64_t b0 = (int64_t)tid * EPV; b0 < V; b0 += (int64_t)NB * ZN_TPB * EPV) {
-        u32x4 v[NB];
+    {
+        const int64_t step = (int64_t)NB * ZN_TPB * EPV;
+        u32x4 v[NB], vn[NB];
 #pragma unroll
-        for (int k = 0; k < NB; ++k) { const int64_t e0 = b0 + (int64_t)k * ZN_TPB * EPV; if (e0 < V) v[k] = rs_load_vec<JF_BF16>(row, e0); }
+        for (int k = 0; k < NB; ++k) { const int64_t e0 = (int64_t)tid * EPV + (int64_t)k * ZN_TPB * EPV; if (e0 < V) v[k] = rs_load_vec<JF_BF16>(row, e0); }
+        for (int64_t b0 = (int64_t)tid * EPV; b0 < V; b0 += step) {
 #pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const int64_t e0 = b0 + (int64_t)k * ZN_TPB * EPV;
-            if (e0 >= V) continue;
-            float xs[EPV];
-            rs_scaled_from_vec<JF_BF16>(row, v[k], xs);
+            for (int k = 0; k < NB; ++k) { const int64_t e0 = b0 + step + (int64_t)k * ZN_TPB * EPV; if (e0 < V) vn[k] = rs_load_vec<JF_BF16>(row, e0); }   // the next round's loads, in front of this round's arithmetic
 #pragma unroll
-            for (int j = 0; j < EPV; ++j) {
-                if (!(xs[j] >= mcut)) continue;                            // (slots beyond V hold -inf)
-                const uint32_t h = __float_as_uint(xs[j]) >> 16, mag = h & 0x7FFFu, off = mag - (uint32_t)(ZN_EXP_LO << 7);
-                ++counted;
-                if (off < (uint32_t)((ZN_EXP_HI - ZN_EXP_LO + 1) << 7)) {
-                    const uint32_t slot = (h & 0x8000u) ? 4096u + off : 4095u - off;
-                    atomicAdd(&table[slot >> 1], (slot & 1u) ? 0x10000u : 1u);
-                } else if (mag < (uint32_t)(ZN_EXP_LO << 7)) {             // a magnitude below 2^-16: the list
-                    const int at = atomicAdd(&s_ntiny, 1);
-                    if (at < ZN_TINY) s_tiny[at] = fh_key(h);
-                } else s_retry = 1;                                          // a magnitude of 2^16 or more
+            for (int k = 0; k < NB; ++k) {
+                const int64_t e0 = b0 + (int64_t)k * ZN_TPB * EPV;
+                if (e0 >= V) continue;
+                uint32_t pk[4], d[4];
+                rs_scaled_pk_from_vec(row, v[k], pk);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[j] = zn_pk_sub(zn_pk_rotl1(pk[j]), (2u * ZN_LO16) * 0x00010001u);
+                if (__builtin_expect(((d[0] | d[1] | d[2] | d[3]) & 0xE000E000u) == 0u, 1)) {      // all eight ids inside the table
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { atomicAdd(&table[d[j] & 0xFFFFu], 1u); atomicAdd(&table[d[j] >> 16], 1u); }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint32_t h = (j & 1) ? (pk[j >> 1] >> 16) : (pk[j >> 1] & 0xFFFFu), idx = (j & 1) ? (d[j >> 1] >> 16) : (d[j >> 1] & 0xFFFFu);
+                        if (idx < (uint32_t)ZN_SLOTS) { atomicAdd(&table[idx], 1u); continue; }
+                        if (!(__uint_as_float(h << 16) >= mcut)) continue;     // no mass (and the slots beyond V, which hold -inf)
+                        if ((h & 0x7FFFu) < ZN_LO16) {                         // a magnitude below 2^-16: the list
+                            const int at = atomicAdd(&s_ntiny, 1);
+                            if (at < ZN_TINY) s_tiny[at] = fh_key(h);
+                        } else s_retry = 1;                                      // a magnitude of 2^16 or more
+                    }
+                }
             }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) v[k] = vn[k];
         }
     }
     __syncthreads();
-    // ---- 2. the list of occupied patterns, largest value first: table slots in order, the small magnitudes between the two signs
+    FH_STAMP(10);
+    // ---- 2. the list of occupied patterns, largest value first: positive magnitudes downwards, the small magnitudes, negative magnitudes upwards.
+    //         List place L < 4096 is the positive magnitude LO16 + 4095 - L, L >= 4096 the negative magnitude LO16 + L - 4096; wavefront w takes
+    //         the places [1024 w, 1024 w + 1024), a lane the places 64 j + lane of them (16 reads, adjacent lanes two words apart).
     const int n_tiny = s_ntiny < ZN_TINY ? s_ntiny : ZN_TINY;
     uint32_t my_tiny = 0u, my_cnt = 0u;
     int my_pos = -1;
@@ -1646,45 +1734,47 @@ __global__ __launch_bounds__(ZN_TPB, JF_ZN_WAVES) void rs_filter_zone_kernel(con
             atomicAdd(&s_ndist, 1);
         }
     }
-    long long n_mine = 0, in_table = 0;
-    uint32_t w4[8];
+    uint32_t cnt16[16];
+    int before[16], mine_n = 0;
+    bool wide = false;
+    const bool neg = wave >= 4;                                              // (wavefront-uniform)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {                                            // this thread's 16 slots (8 words; 32 lanes x 8 words: two lanes per bank)
-        w4[i] = table[tid * 8 + i];
-        n_mine += ((w4[i] & 0xFFFFu) ? 1 : 0) + ((w4[i] >> 16) ? 1 : 0);
-        in_table += (w4[i] & 0xFFFFu) + (w4[i] >> 16);
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t L = (uint32_t)wave * 1024u + 64u * j + lane;
+        const uint32_t off = neg ? L - 4096u : 4095u - L, h = (neg ? 0x8000u : 0u) | (ZN_LO16 + off);
+        uint32_t c = table[2u * off + (neg ? 1u : 0u)];
+        if (!(__uint_as_float(h << 16) >= mcut)) c = 0u;                     // patterns without mass were counted, and are dropped here
+        wide |= c > 0xFFFFu;
+        cnt16[j] = c;
+        const unsigned long long m = __ballot(c != 0u);
+        before[j] = mine_n + __popcll(m & ((1ull << lane) - 1ull));          // (mine_n: the wavefront's occupied places of the rounds in front — uniform)
+        mine_n += __popcll(m);
     }
-    long long packed3 = n_mine | (in_table << 20) | ((long long)counted << 40), ci, ce;   // (each total below 2^20: one scan carries the three)
-    double d0 = 0.0, di, de;
-    fh_scan(sh, packed3, d0, ci, di, ce, de);
-    const long long n_table = packed3 & 0xFFFFF, tot_table = (packed3 >> 20) & 0xFFFFF, tot_counted = packed3 >> 40;
+    if (wide) s_retry = 1;                                                   // a pattern more than 65 535 times: the list's items hold 16-bit counts
+    __syncthreads();                                                         // (every counter has been read: the list may overwrite them)
+    if (lane == 0) sh.scan[wave] = mine_n;
+    __syncthreads();
+    int base = 0, n_pos = 0, n_table = 0;
+#pragma unroll
+    for (int w = 0; w < ZN_TPB / 64; ++w) { const int n = sh.scan[w]; if (w < wave) base += n; if (w < 4) n_pos += n; n_table += n; }
     const int n_dist = s_ndist;
-    const long long n_occ = n_table + n_dist;
-    if (s_retry || s_ntiny > ZN_TINY || tot_table + s_ntiny != tot_counted || n_occ > FH_ITEMS) {   // (workgroup-uniform) left to the other kernel
+    const int n_occ = n_table + n_dist;
+    if (s_retry || s_ntiny > ZN_TINY || n_occ > FH_ITEMS) {                 // (workgroup-uniform) left to the other kernel
         if (tid == 0) filt[r].flags = FH_RETRY;
         return;
     }
-    {
-        int at = (int)(ce & 0xFFFFF) + (tid >= ZN_TPB / 2 ? n_dist : 0);   // (threads of the second half own the negative values: behind the small magnitudes)
+    if (neg) base += n_dist;                                                 // (the negative values: behind the small magnitudes)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const uint32_t c = hh ? (w4[i] >> 16) : (w4[i] & 0xFFFFu);
-                if (!c) continue;
-                const uint32_t slot = (uint32_t)tid * 16u + 2u * i + hh;
-                const uint32_t off = slot < 4096u ? 4095u - slot : slot - 4096u;
-                const uint32_t h = (slot < 4096u ? 0u : 0x8000u) | (off + (uint32_t)(ZN_EXP_LO << 7));
-                occ[at++] = (fh_key(h) << 16) | c;
-            }
-        }
-        // (the scan gave thread 256 the number of occupied slots of the positive half as its exclusive prefix: where the list goes)
-        if (tid == ZN_TPB / 2) sh.bi[2] = (int)(ce & 0xFFFFF);
+    for (int j = 0; j < 16; ++j) {
+        if (!cnt16[j]) continue;
+        const uint32_t L = (uint32_t)wave * 1024u + 64u * j + lane;
+        const uint32_t off = neg ? L - 4096u : 4095u - L, h = (neg ? 0x8000u : 0u) | (ZN_LO16 + off);
+        occ[base + before[j]] = (fh_key(h) << 16) | cnt16[j];
     }
+    if (my_pos >= 0) occ[n_pos + my_pos] = (my_tiny << 16) | my_cnt;
     __syncthreads();
-    if (my_pos >= 0) occ[sh.bi[2] + my_pos] = (my_tiny << 16) | my_cnt;
-    __syncthreads();
-    const float pd = fh_solve<true>(sh, nullptr, occ, pc, (int)n_occ, row, r, V, draft_next, top_k, top_p, k_on, p_on, rec);
+    FH_STAMP(11);
+    const float pd = fh_solve<true>(sh, nullptr, occ, pc, n_occ, row, r, V, draft_next, top_k, top_p, k_on, p_on, rec);
     if (tid == 0) { filt[r] = rec; p_draft[r] = pd; row_max[r] = INFINITY; row_sumexp[r] = RS_PROB_ROW; }
 }
 

@@ -405,11 +405,13 @@ def test_nongreedy_jacobi_matches_autoregressive_sampling_per_position(tmp_path,
     noise, _ = _per_position_js(ar1, ar2, V)
     js, per_pos = _per_position_js(ar1, jac, V)
     js2, _ = _per_position_js(ar2, jac, V)
-    distinct = len({tuple(x) for x in jac})
-    print(f"per-position JS: AR vs AR {noise:.4f}, AR vs Jacobi {js:.4f} / {js2:.4f}; distinct Jacobi samples {distinct} of {N}; "
+    distinct, distinct_ar = len({tuple(x) for x in jac}), len({tuple(x) for x in ar1})
+    print(f"per-position JS: AR vs AR {noise:.4f}, AR vs Jacobi {js:.4f} / {js2:.4f}; distinct Jacobi samples {distinct} of {N} (autoregressive: {distinct_ar}); "
           f"tokens per iteration {stats['tokens_accepted'] / max(stats['num_jacobi_iterations'], 1) / 256:.2f}")
     assert all(len(x) == POS for x in jac)
-    assert distinct > N // 16                                  # a real distribution, not a degenerate one
+    # a real distribution, not a degenerate one: as many different sequences as the autoregressive sampler draws (top_k = 50 / top_p = 0.9
+    # leave this model's peaked rows a nucleus of a few ids: ~10^2 different sequences in 4 096 draws on either side)
+    assert distinct > (32 if filters else N // 16) and distinct_ar // 2 < distinct < 2 * distinct_ar, (distinct, distinct_ar)
     assert js < 0.05 and js2 < 0.05, (js, js2, noise, per_pos)
     # (the autoregressive sampler filters float32 probabilities, the decoder the bf16 ones the reference's dtype rule gives it: with
     #  top-p the two nuclei can differ by a bf16 step of the running sum — a real, small difference on top of the sampling noise)

@@ -9,7 +9,8 @@ V = 152064
 lib = N.lib()
 raw = ctypes.CDLL(os.environ.get("JF_LIB", str(N.LIB_PATH)))
 names = ["zero+tab", "count pass", "S", "top-k", "top-p", "tile counts", "tie ids"]
-for R in (1, 64, 256):
+ZONE = os.environ.get("JF_RS_FILTER_ZONE", "1") != "0"
+for R in ((1, 64, 256, 768, 1984) if ZONE else (1, 64, 256)):
     for scale, shape in ((3.0, "peaked"), (0.3, "flat")):
         for k, tp in ((50, 0.0), (0, 0.9), (50, 0.9)):
             x = (torch.randn(R, V, device="cuda") * scale).to(torch.bfloat16)
@@ -24,5 +25,10 @@ for R in (1, 64, 256):
                 torch.cuda.synchronize()
             buf = (ctypes.c_ulonglong * 16)()
             raw.jf_exp_fh_trace(buf)
+            if ZONE:          # rs_filter_zone_kernel's workgroup 0: stamps 8-11 in front of fh_solve's 3-7 (a stage that did not run keeps an older stamp)
+                z = [buf[i] / 100.0 for i in (8, 9, 10, 11, 3, 4, 5, 6, 7)]
+                zn = ["zero", "count pass", "list", "S + probs", "top-k", "top-p", "tile counts", "tie ids"]
+                print(f"zone R={R:4d} {shape:6s} k={k:2d} p={tp}: " + "  ".join(f"{n} {z[i + 1] - z[i]:6.1f}" for i, n in enumerate(zn)) + f"   total {max(z) - z[0]:6.1f} us", flush=True)
+                continue
             t = [b / 100.0 for b in buf[:8]]
             print(f"R={R:3d} {shape:6s} k={k:2d} p={tp}: " + "  ".join(f"{n} {t[i + 1] - t[i]:6.1f}" for i, n in enumerate(names)) + f"   total {t[7] - t[0]:6.1f} us", flush=True)
