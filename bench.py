@@ -425,7 +425,7 @@ def nongreedy_section(model, cfg, weights, tuned, P: int = 64, L: int = 32, temp
         "kernel": "jf_rs_step (accept walk, float64 segment sums of the rejected rows, draw counting, one inverse-CDF walk per rejected row, "
                   "next drafts: roles of ONE launch)",
         "note": "bytes = one rejected row (V x 2 B) per draft row per launch: the rows the step re-reads; where the microseconds go, "
-                "stage by stage (in-kernel stamps): profiles/rs_step_r04.txt, DESIGN.md 3.4"}
+                "stage by stage (in-kernel stamps): profiles/rs_step_r04.txt, HISTORY.md 3.4"}
     if out_roof is not None:
         out_roof["timing"] = st.timing("rs_probs")
     if out_step is not None:

@@ -159,6 +159,44 @@ def test_engine_nongreedy_golden(case, backend):
             assert s.token_ids == f["token_ids"] and s.num_cached_tokens == f["num_cached_tokens"]
 
 
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_a_batch_that_mixes_settings_is_decoded_setting_by_setting(backend):
+    """The reference builds the target distribution request by request (JDN:110-123), so one batch may mix (temperature, top_k,
+    top_p).  Here a launch takes ONE setting: generate_chunk_batch decodes such a batch part by part, in order of first appearance
+     — the same tokens, cached lengths and stream cursors as decoding the parts as separate batches."""
+    case = next(c for c in JDN if c["name"] == "jdn4_f32_k20_p08_batch4")
+    p = case["params"]
+    settings = [dict(temperature=0.7, top_k=5), dict(temperature=1.3), dict(temperature=0.7, top_k=5), dict(temperature=1.3)]
+
+    def build(order):
+        dev = device_for(backend)
+        H = Harness(p["vocab"], dev, torch.float32)
+        dec = JacobiDecoderNonGreedy(H.bm, forward_step=lambda s, d: H.forward_step_batch([s], d), forward_step_batch=H.forward_step_batch,
+                                     eos_token_id=p["eos_id"], pad_token_id=p["pad_id"], vocab_size=p["vocab"], device=torch.device(dev))
+        pads, unis, bonus = (CounterStream(77 * 3 + k) for k in (1, 2, 3))
+        dec.set_streams([pads.next_u32() % p["vocab"] for _ in range(4096)], [unis.uniform() for _ in range(4096)],
+                        [bonus.uniform() for _ in range(4096)])
+        seqs = {}
+        for i in order:
+            sp = SamplingParams(temperature=settings[i]["temperature"], max_tokens=p["max_tokens"], decode_strategy="jacobi",
+                                jacobi_block_len=p["block_len"])
+            if "top_k" in settings[i]:
+                sp.top_k = settings[i]["top_k"]
+            seqs[i] = H.add(ScriptedModel.from_dict(case["seqs"][i]["model"]), sp, None)
+        return dec, seqs
+
+    with use_backend(backend):
+        dec_a, sa = build([0, 1, 2, 3])
+        out_a = dec_a.generate_chunk_batch([sa[i] for i in range(4)])
+        dec_b, sb = build([0, 2, 1, 3])
+        out_02 = dec_b.generate_chunk_batch([sb[0], sb[2]])
+        out_13 = dec_b.generate_chunk_batch([sb[1], sb[3]])
+        assert out_a == [out_02[0], out_13[0], out_02[1], out_13[1]] and all(len(o) > 0 for o in out_a)
+        assert dec_a._cur == dec_b._cur
+        for i in range(4):
+            assert sa[i].token_ids == sb[i].token_ids and sa[i].num_cached_tokens == sb[i].num_cached_tokens == len(sa[i])
+
+
 # ------------------------------------------------------------------------------------- on-policy rollout records
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("case", JDO, ids=[c["name"] for c in JDO])
