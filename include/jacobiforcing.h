@@ -434,9 +434,11 @@ typedef struct jf_sb_desc {
 JF_API int jf_sb_step(int64_t *out, int L, uint64_t *packed, int32_t eos_id, int32_t total, int32_t cap, int64_t *acc_buf,
                int32_t kv_before, jf_sb_desc *desc, void *stream);
 
-/* BOUNDARY-ONLY EXPORT: this package never calls it — its own forward keeps one contiguous cache row per request
- * (engine/model_runner.py LoopForward reads positions / cached lengths from jf_engine_loop's arrays) — it is here for a
- * reference-side caller that keeps the PAGED cache and varlen attention of inference_engine (route 1).
+/* The PAGED layout's index fill.  This package's default layout keeps one contiguous cache row per request and never calls it;
+ * with Config.kv_cache_layout = "paged" (engine/model_runner.py: the reference's memory model — a pool of blocks, block tables,
+ * slot mappings) every Jacobi step's forward does: from host lists through ops.PagedFill.fill (the callback contract), from the
+ * chunk loop's DEVICE lengths through PagedFill.fill_device (no host copy).  A reference-side caller that keeps inference_engine's
+ * paged cache and varlen attention binds it the same way (route 1).
  * Caller side of the batched forward when the KV cache is PAGED as in the reference
  * (MR:1204-1265 "jacobi.buffer_fill" + _get_slot_mapping_pattern MR:965-986): for B sequences of
  * committed length S_i (seq_len, >= 1) and a draft [B, L] (column 0 = the cached seed), fill

@@ -17,6 +17,9 @@ _FIELDS = [
     ("gpu_memory_utilization", float, 0.9), ("tensor_parallel_size", int, 1), ("enforce_eager", bool, False),
     ("hf_config", Optional[Any], None), ("eos", int, -1), ("pad", int, -1),
     ("kvcache_block_size", int, 256), ("num_kvcache_blocks", int, -1),
+    # "contiguous": one static cache row per request (this package's layout); "paged": the reference's pool of blocks addressed
+    # through block tables and slot mappings (layers/attention.py:10-40, MR:1204-1265) — same decodes, for callers that want its memory model
+    ("kv_cache_layout", str, "contiguous"),
     # Jacobi defaults of the engine (requests override them through SamplingParams)
     ("jacobi_enabled", bool, True), ("jacobi_block_len", int, 64), ("jacobi_max_blocks", int, 2),
     ("jacobi_spawn_ratio", float, 0.8), ("jacobi_lookahead_start_ratio", float, 0.0),
@@ -40,6 +43,8 @@ def _finish_init(self) -> None:
     model_dir = _resolve_model_dir(self.model)
     assert self.kvcache_block_size % 256 == 0
     assert 1 <= self.tensor_parallel_size <= 8
+    if self.kv_cache_layout not in ("contiguous", "paged"):
+        raise ValueError(f"kv_cache_layout must be 'contiguous' or 'paged', got {self.kv_cache_layout!r}")
     if self.tensor_parallel_size != 1:
         raise NotImplementedError("tensor parallelism is not part of this path: prompts replicate across GPUs "
                                   "(one process per GPU); use tensor_parallel_size=1")

@@ -84,7 +84,24 @@ class LoopForward:
             st.update(version=lp.version, rp=torch.tensor(rows, dtype=torch.int32, device=dev),
                       row_len=torch.full((B,), lp.L, dtype=torch.int32, device=dev),
                       row_cand=torch.full((B,), -1, dtype=torch.int32, device=dev), in_place=rows == list(range(B)))
+            if r.paged:                                            # the group's block tables on the device (rows in member order)
+                self._push_tables(lp, st, range(B))
         return st
+
+    def _push_tables(self, lp, st, ks) -> None:
+        """Rows ``ks`` of the group's device block tables from the requests' lists (at the start, after a compaction, and for a
+        request in the iteration it crosses into a new block)."""
+        fill = self.r._fill(lp.L)
+        m = lp.members
+        bt = np.full((len(ks), fill.max_cols), -1, dtype=np.int32)
+        for i, k in enumerate(ks):
+            t = lp.seqs[int(m[k])].block_table
+            bt[i, :len(t)] = t
+        ks = list(ks)
+        if ks == list(range(ks[0], ks[0] + len(ks))):
+            fill.block_tables[ks[0]:ks[0] + len(ks)].copy_(torch.from_numpy(bt), non_blocking=True)
+        else:
+            fill.block_tables[torch.tensor(ks, dtype=torch.int64, device=fill.device)] = torch.from_numpy(bt).to(fill.device)
 
     @torch.inference_mode()
     def __call__(self, lp) -> torch.Tensor:
@@ -103,16 +120,27 @@ class LoopForward:
         cur = st["bt_len"][m]
         if (need != cur).any():
             bm = r.block_manager
-            for k in np.flatnonzero(need != cur).tolist():
+            changed = np.flatnonzero(need != cur).tolist()
+            for k in changed:
                 seq = lp.seqs[int(m[k])]
                 r._fit_block_table(seq, int(need[k]), bm)
                 st["bt_len"][m[k]] = len(seq.block_table)
+            if r.paged:
+                self._push_tables(lp, st, changed)
         st["perm"][m] = np.maximum(st["perm"][m], need - committed)
         prof.stop("jacobi.block_alloc")
         prof.start("jacobi.forward")
-        logits = r.model.forward(lp.draft, lp.positions, r.kv_cache, row_prompt=st["rp"], row_cand=st["row_cand"], row_len=st["row_len"],
-                                 kv_len_rows=lp.kv_start, any_candidates=False, s_cur=s_max - 1 + L, logit_index=r._logit_index(B, L),
-                                 rows_in_place=st["in_place"])                                  # seed re-forwarded at S-1
+        if r.paged:
+            # slot mapping of the whole batch from the loop's device lengths and the device block tables: jf_engine_fill, no host copy
+            fill = r._fill(L)
+            _pos, slots, _cached, bt = fill.fill_device(lp.draft, lp.kv_start + 1, B)
+            logits = r.model.forward(lp.draft, lp.positions, r.kv_cache, row_prompt=st["row_cand"], row_cand=st["row_cand"], row_len=st["row_len"],
+                                     kv_len_rows=lp.kv_start, any_candidates=False, s_cur=s_max - 1 + L, logit_index=r._logit_index(B, L),
+                                     paged_slots=slots, block_tables=bt)
+        else:
+            logits = r.model.forward(lp.draft, lp.positions, r.kv_cache, row_prompt=st["rp"], row_cand=st["row_cand"], row_len=st["row_len"],
+                                     kv_len_rows=lp.kv_start, any_candidates=False, s_cur=s_max - 1 + L, logit_index=r._logit_index(B, L),
+                                     rows_in_place=st["in_place"])                              # seed re-forwarded at S-1
         prof.stop("jacobi.forward")
         return logits.view(B, L - 1, logits.shape[-1])
 
@@ -121,6 +149,11 @@ class LoopForward:
         st = getattr(lp, "_mr", None)
         if st is None:
             return
+        if self.r.paged:                                          # a draft position without a block (MR:1190-1191), reported by the fill launches
+            err = int(self.r._fill(lp.L).err.item())
+            if err:
+                self.r._fill(lp.L).err.zero_()
+                raise RuntimeError(f"Sequence {err - 1}: a draft position has no KV block (Cannot allocate blocks for draft tokens)")
         bm, bs = self.r.block_manager, self.r.block_size
         for slot, seq in enumerate(lp.seqs):
             seq.num_permanent_spec_blocks = max(seq.num_permanent_spec_blocks, int(st["perm"][slot]))
@@ -162,10 +195,19 @@ class ModelRunner:
         self.model = Qwen2Model(hf, self.weights)
         self.block_size = config.kvcache_block_size
         self.max_rows = int(min(config.max_num_seqs, int(os.environ.get("JF_MAX_ROWS", "64"))))
-        self.kv_cache = StaticKVCache(hf, self.max_rows, config.max_model_len, 0, 1, self.device, dtype=dtype)
-        self.free_rows = list(range(self.max_rows))
         if config.num_kvcache_blocks <= 0:
             config.num_kvcache_blocks = self.max_rows * ((config.max_model_len + self.block_size - 1) // self.block_size + 4)
+        # "paged" (Config.kv_cache_layout, or JF_KV_LAYOUT for tools): the reference's memory model — a pool of blocks, K/V of a request
+        # wherever its block table says (MR:1204-1265).  The pool is a StaticKVCache whose rows are BLOCKS ([num_blocks, H_kv, block_size, D]
+        # per layer): the append launch takes the reference's slot mapping as it is, attention gathers a row's blocks in table order.
+        self.paged = (os.environ.get("JF_KV_LAYOUT") or config.kv_cache_layout) == "paged"
+        if self.paged:
+            self.kv_cache = StaticKVCache(hf, config.num_kvcache_blocks, self.block_size, 0, 1, self.device, dtype=dtype)
+            self.max_cols = (config.max_model_len + self.block_size - 1) // self.block_size + 4
+            self._fills = {}                                      # block length -> ops.PagedFill (the reference's jacobi_buffers, MR:650-686)
+        else:
+            self.kv_cache = StaticKVCache(hf, self.max_rows, config.max_model_len, 0, 1, self.device, dtype=dtype)
+        self.free_rows = list(range(self.max_rows))
         self.block_manager = None
         self.jacobi_decoder = None
         self._mb_decoders = {}
@@ -193,6 +235,40 @@ class ModelRunner:
             self.free_rows.append(seq.cache_row)
             seq.cache_row = -1
 
+    # ---- paged layout ---------------------------------------------------------------------------
+    def _grow_block_table(self, seq: Sequence, need: int) -> None:
+        """Blocks for ``need`` * block_size positions (never fewer than the request holds): prefill-with-draft forwards len(seq) +
+        block_len tokens (MR:777-963), which the scheduler's allocation of len(seq) tokens does not cover."""
+        bm = self.block_manager
+        while len(seq.block_table) < need:
+            if bm is None or not bm.free_block_ids:
+                raise RuntimeError("Cannot allocate blocks for draft tokens")
+            seq.block_table.append(bm._allocate_block_no_clear(bm.free_block_ids[0]))
+            seq.block_table_version += 1
+
+    def _paged_slots(self, seqs: List[Sequence], starts: List[int], lens: List[int], T: int):
+        """Slot of every token of rows that continue at ``starts`` (block_table[pos // bs] * bs + pos % bs, -1 = padding) and the rows'
+        block tables — what the reference's prepare_prefill / prepare_decode build on the host (MR:460-560); the Jacobi step's own
+        buffers come from jf_engine_fill instead (``_fill``)."""
+        bs, B = self.block_size, len(seqs)
+        for seq, s0, n in zip(seqs, starts, lens):
+            self._grow_block_table(seq, -(-(s0 + n) // bs))
+        C = max(len(s.block_table) for s in seqs)
+        bt = np.full((B, C), -1, dtype=np.int32)
+        slots = np.full((B, T), -1, dtype=np.int64)
+        for b, (seq, s0, n) in enumerate(zip(seqs, starts, lens)):
+            t = np.asarray(seq.block_table, dtype=np.int64)
+            bt[b, :t.size] = t
+            pos = s0 + np.arange(n, dtype=np.int64)
+            slots[b, :n] = t[pos // bs] * bs + pos % bs
+        return torch.from_numpy(slots).to(self.device), torch.from_numpy(bt).to(self.device)
+
+    def _fill(self, L: int) -> "ops.PagedFill":
+        f = self._fills.get(L)
+        if f is None:
+            f = self._fills[L] = ops.PagedFill(self.max_rows, L, self.max_cols, self.block_size, self.device)
+        return f
+
     def _forward_rows(self, seqs: List[Sequence], ids: torch.Tensor, starts: List[int], lens: List[int],
                       logits_rows=None, logit_index=None) -> torch.Tensor:
         """Forward ``ids`` [B, T] where row b continues cache row seqs[b].cache_row from position starts[b]."""
@@ -200,6 +276,12 @@ class ModelRunner:
         B, T = ids.shape
         st = torch.tensor(starts, dtype=torch.int32, device=dev)
         pos = st.view(B, 1) + torch.arange(T, dtype=torch.int32, device=dev).view(1, T)
+        if self.paged:
+            slots, bt = self._paged_slots(seqs, starts, lens, T)
+            neg = torch.full((B,), -1, dtype=torch.int32, device=dev)
+            return self.model.forward(ids.to(dev), pos, self.kv_cache, row_prompt=neg, row_cand=neg,
+                                      row_len=torch.tensor(lens, dtype=torch.int32, device=dev), kv_len_rows=st, any_candidates=False,
+                                      logits_rows=logits_rows, s_cur=max(starts) + T, logit_index=logit_index, paged_slots=slots, block_tables=bt)
         rows = [self._row(s) for s in seqs]
         rp = torch.tensor(rows, dtype=torch.int32, device=dev)
         return self.model.forward(ids.to(dev), pos, self.kv_cache, row_prompt=rp, row_cand=torch.full((B,), -1, dtype=torch.int32, device=dev),
@@ -272,9 +354,24 @@ class ModelRunner:
             self._fit_block_table(seq, need, bm)
             seq.num_permanent_spec_blocks = max(seq.num_permanent_spec_blocks, need - committed)
         prof.stop("jacobi.block_alloc")
-        prof.start("jacobi.forward")
-        logits = self._forward_rows(seqs, draft_tokens_batch, [len(s) - 1 for s in seqs], [L] * B, logit_index=self._logit_index(B, L))   # seed re-forwarded at S-1
-        prof.stop("jacobi.forward")
+        if self.paged:
+            # MR:1204-1265 ("jacobi.buffer_fill" + _get_slot_mapping_pattern) as ONE launch: ids, positions, slot mapping and cached
+            # lengths of the whole batch from the lengths and block tables (the reference: a Python loop, ~8 launches per sequence)
+            prof.start("jacobi.buffer_fill")
+            dev = self.device
+            _ids, positions, slots, _cq, _ck, cache_seqlens, bt, max_k = self._fill(L).fill(draft_tokens_batch, [len(s) for s in seqs],
+                                                                                             [s.block_table for s in seqs])
+            prof.stop("jacobi.buffer_fill")
+            prof.start("jacobi.forward")
+            neg = torch.full((B,), -1, dtype=torch.int32, device=dev)
+            logits = self.model.forward(draft_tokens_batch.to(dev), positions.view(B, L).to(torch.int32), self.kv_cache, row_prompt=neg, row_cand=neg,
+                                        row_len=torch.full((B,), L, dtype=torch.int32, device=dev), kv_len_rows=cache_seqlens,
+                                        any_candidates=False, s_cur=max_k, logit_index=self._logit_index(B, L), paged_slots=slots, block_tables=bt)
+            prof.stop("jacobi.forward")
+        else:
+            prof.start("jacobi.forward")
+            logits = self._forward_rows(seqs, draft_tokens_batch, [len(s) - 1 for s in seqs], [L] * B, logit_index=self._logit_index(B, L))   # seed re-forwarded at S-1
+            prof.stop("jacobi.forward")
         for seq in seqs:
             seq.num_cached_tokens = (len(seq) - 1) + L                                         # MR:1407-1408
         return logits.view(B, L - 1, logits.shape[-1])

@@ -273,7 +273,8 @@ class Qwen2Model:
                 row_prompt: torch.Tensor, row_cand: torch.Tensor, row_len: torch.Tensor,
                 kv_len_rows: torch.Tensor, any_candidates: bool, logits_rows: Optional[slice] = None,
                 s_cur: Optional[int] = None, logit_index: Optional[torch.Tensor] = None,
-                rows_in_place: Optional[bool] = None, n_main: Optional[int] = None) -> torch.Tensor:
+                rows_in_place: Optional[bool] = None, n_main: Optional[int] = None,
+                paged_slots: Optional[torch.Tensor] = None, block_tables: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One forward over R rows of (padded) length T.
 
         input_ids [R,T] int64, positions [R,T] int32 (= kv_len + t), row_prompt [R] (cache row of the prefix),
@@ -284,7 +285,13 @@ class Qwen2Model:
         in the loop API's order (jf_mb_loop, order 1): the first n_main rows write the main cache (row 0 of every running
         prompt, in prompt order), the rest are candidate rows — only THOSE rows' K/V prefixes are gathered, the main rows
         attend in place when they are the cache rows in order (what is left of MB:93-127).  Returns logits [R*T, V] in the weight dtype (or ``logits_rows`` of it, or
-        the rows listed in ``logit_index`` — flat positions, negative entries are list padding and yield a junk row)."""
+        the rows listed in ``logit_index`` — flat positions, negative entries are list padding and yield a junk row).
+
+        PAGED layout (``Config.kv_cache_layout = "paged"``, the reference's cache: layers/attention.py:10-40, MR:1204-1265): ``cache`` is a
+        pool ``[num_blocks, H_kv, block_size, D]`` per layer (a StaticKVCache whose "rows" are blocks), ``paged_slots`` [R*T] the slot of
+        every new token (block * block_size + offset, -1 = padding: jf_engine_fill's slot_mapping) and ``block_tables`` [R, C] the blocks
+        of each row in order (-1 = none).  The append is the same launch; a row's keys are its blocks gathered in table order (stock
+        SDPA has no block-table argument; flash_attn_with_kvcache is not in this image), so logical key index = position."""
         cfg, w = self.cfg, self.w
         R, T = input_ids.shape
         nq, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
@@ -293,9 +300,11 @@ class Qwen2Model:
         pos = positions.long()
         if s_cur is None:
             s_cur = (int(kv_len_rows.max().item()) + T) if R else T
-        S_cur = min(int(s_cur), cache.S_max)
-        if self.cos.shape[0] < cache.S_max:                  # a cache longer than max_position_embeddings: never read past the table
-            self._rope_tables(cache.S_max)
+        paged = block_tables is not None
+        S_cap = cache.S_max * int(block_tables.shape[1]) if paged else cache.S_max
+        S_cur = min(int(s_cur), S_cap)
+        if self.cos.shape[0] < S_cap:                        # a cache longer than max_position_embeddings: never read past the table
+            self._rope_tables(S_cap)
         ar_t = torch.arange(T, device=dev)
         ar_s = torch.arange(S_cur, device=dev)
         kvl = kv_len_rows.long()
@@ -313,7 +322,14 @@ class Qwen2Model:
         valid = ar_t.view(1, T) < rlen.view(R, 1)
         main_rows = row_cand < 0
         neg = torch.full_like(pos, -1)
-        slot_main = torch.where(valid & main_rows.view(R, 1), row_prompt.long().view(R, 1) * cache.S_max + pos, neg).reshape(-1)
+        if paged:
+            if any_candidates or n_main is not None:
+                raise NotImplementedError("candidate rows over the paged layout (the engine's decoders are single-block: MR:1468-1473)")
+            slot_main = paged_slots.long().reshape(-1)
+            nblk = -(-S_cur // cache.S_max)
+            bt = block_tables[:, :nblk].clamp(min=0).long()                           # (blocks a row does not have: masked keys)
+        else:
+            slot_main = torch.where(valid & main_rows.view(R, 1), row_prompt.long().view(R, 1) * cache.S_max + pos, neg).reshape(-1)
         rp = row_prompt.long()
         split = n_main is not None
         if split:
@@ -337,7 +353,7 @@ class Qwen2Model:
                 tail_idx = tail_idx.view(-1, 1, T, 1).expand(-1, nkv, T, hd)
                 crc = row_cand[cr].long()
         pos32 = positions.to(torch.int32).reshape(-1).contiguous()
-        direct = (not any_candidates) and R == cache.P and rows_in_place is not False   # row r is cache row r: attend in place
+        direct = (not paged) and (not any_candidates) and R == cache.P and rows_in_place is not False   # row r is cache row r: attend in place
 
         x = w.embed[input_ids].view(R * T, cfg.hidden_size)                           # [R*T, H]
         for li, L in enumerate(w.layers):
@@ -370,6 +386,9 @@ class Qwen2Model:
                     # candidate rows see their own speculative tail instead of row 0's
                     Kf[cr] = Kf[cr].scatter(2, tail_idx, cache.ck[li][crc, :, :T])
                     Vf[cr] = Vf[cr].scatter(2, tail_idx, cache.cv[li][crc, :, :T])
+            elif paged:                                                                # [R, nblk, H, bs, D] -> [R, H, nblk * bs, D]
+                Kf = cache.k[li][bt].permute(0, 2, 1, 3, 4).reshape(R, nkv, nblk * cache.S_max, hd)[:, :, :S_cur]
+                Vf = cache.v[li][bt].permute(0, 2, 1, 3, 4).reshape(R, nkv, nblk * cache.S_max, hd)[:, :, :S_cur]
             elif direct:
                 Kf, Vf = cache.k[li][:, :, :S_cur], cache.v[li][:, :, :S_cur]
             else:

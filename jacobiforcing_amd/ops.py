@@ -886,8 +886,9 @@ class SingleBlockStepper:
 # paged-KV index buffers of one batched Jacobi forward (MR:1204-1265, 965-986)
 # --------------------------------------------------------------------------------------------
 class PagedFill:
-    """The reference's ``jacobi_buffers`` (MR:650-686) and their per-forward fill, as one launch.  For callers that keep
-    the reference's paged KV cache + varlen attention; this package's own forward uses a static cache row per request."""
+    """The reference's ``jacobi_buffers`` (MR:650-686) and their per-forward fill, as one launch: for the paged layout
+    (``Config.kv_cache_layout = "paged"``: engine/model_runner.py) and for callers that keep the reference's paged KV cache +
+    varlen attention; the default layout (a static cache row per request) does not need it."""
 
     def __init__(self, max_batch: int, max_block_len: int, max_blocks_per_seq: int, block_size: int, device):
         dev = torch.device(device)
@@ -935,6 +936,20 @@ class PagedFill:
         return (self.input_ids[:n], self.positions[:n], self.slot_mapping[:n], self.cu_seqlens_q[:B + 1],
                 self.cu_seqlens_k[:B + 1], self.cache_seqlens[:B], self.block_tables[:B],
                 max(int(S) - 1 + L for S in seq_lens))
+
+    def fill_device(self, draft: torch.Tensor, seq_len_dev: torch.Tensor, B: int):
+        """The same launch for a caller whose lengths and block tables already live on the device (the engine's chunk loop:
+        ``seq_len_dev`` [B] int32 = len(seq) per row, ``self.block_tables[:B]`` kept current by the caller): no host copy, no
+        read-back — a position without a block is reported in ``self.err`` (checked by the caller once per chunk)."""
+        L = draft.shape[1]
+        if B > self.max_batch or L > self.max_L:
+            raise RuntimeError("PagedFill capacity exceeded")
+        N.check(N.lib().jf_engine_fill(_ptr(draft), B, L, _ptr(seq_len_dev), _ptr(self.block_tables), self.max_cols,
+                                       self.block_size, _ptr(self.input_ids), _ptr(self.positions), _ptr(self.slot_mapping),
+                                       _ptr(self.cu_seqlens_q), _ptr(self.cu_seqlens_k), _ptr(self.cache_seqlens),
+                                       _ptr(self.err), _stream(self.device)), "jf_engine_fill")
+        n = B * L
+        return self.positions[:n], self.slot_mapping[:n], self.cache_seqlens[:B], self.block_tables[:B]
 
 
 # --------------------------------------------------------------------------------------------

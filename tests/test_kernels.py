@@ -798,6 +798,56 @@ def test_rs_filter_bf16_rows_that_leave_the_fast_path(shape, top_k, top_p):
 
 
 @GPU
+@pytest.mark.parametrize("top_k,top_p", [(50, 0.0), (0, 0.9), (40, 0.95)], ids=["k50", "p09", "k40_p095"])
+@pytest.mark.parametrize("shape", ["below_the_exp_cut", "partly_below_the_exp_cut", "tiny_magnitudes", "zeros_of_both_signs", "huge_without_mass",
+                                   "huge_with_mass", "ragged_unaligned"])
+def test_rs_filter_bf16_zone_table_edges(shape, top_k, top_p):
+    """The zone kernel's count pass indexes 8 192 counters by the packed bf16 pattern (2^-16 <= |x| < 2^16) and takes a per-element path
+    only for vectors with an id outside them.  Its edges: patterns INSIDE the table that carry no mass (below max - 104: counted, then
+    dropped when the list is built), magnitudes below 2^-16 (the 64-entry list: duplicates, both signs, +0 and -0), magnitudes of 2^16
+    and more without mass (-1e6, -inf: ignored) and with mass (the maximum itself: the row goes to the other kernel), a ragged row on
+    an odd stride (element loads, -inf padding).  Bit for bit against the oracle, T = 0.8 (T = 1 for the unaligned rows)."""
+    V = 152064
+    g = torch.Generator().manual_seed(len(shape) * 31 + top_k)
+    x = torch.randn(3, V, generator=g) * 2.0
+    T = 0.8
+    if shape == "below_the_exp_cut":
+        x[:, 777] = 120.0                                       # max / T - 104 = 46: every other id is counted and carries nothing
+    elif shape == "partly_below_the_exp_cut":
+        x[:, 5] = 100.0                                         # cut at 21 (scaled): the ids at 30 and 25 stay, the N(0, 4) bulk goes
+        x[:, 1000:1040] = 30.0
+        x[:, 2000:2100:3] = 25.0
+        x[1, 3000:3010] = 16.75                                 # scaled 20.94 / 21.0 either side of the cut after bf16 rounding
+    elif shape == "tiny_magnitudes":
+        idx = torch.randperm(V, generator=g)[:48]
+        x[:, idx] = torch.tensor([1e-6, -1e-6, 3e-7, 1e-6, -2.5e-9, 1.2e-5])[torch.arange(48) % 6]
+    elif shape == "zeros_of_both_signs":
+        x[:, 100:130] = 0.0
+        x[:, 200:220] = -0.0
+        x[2] = torch.where(torch.arange(V) % 3 == 0, torch.tensor(0.0), torch.tensor(-0.0))   # a row of zeros: > 64 small magnitudes
+    elif shape == "huge_without_mass":
+        x[:, 10:20] = -1.0e6
+        x[:, 30:33] = float("-inf")
+        x[1, 40] = -7.0e4
+    elif shape == "huge_with_mass":
+        x[0, 12345] = 70000.0                                   # the maximum itself is outside the table
+        x[1, 5] = 65536.0
+        x[1, 6] = 65536.0 - 256.0                               # 2^16 - 2^8: the largest magnitudes inside (scaled by 1 / 0.8 they are outside)
+    if shape == "ragged_unaligned":
+        V, T = 151999, 1.0
+        buf = (torch.randn(3, V + 3, generator=g) * 2.0).to(torch.bfloat16).cuda()
+        xd = buf[:, 1:V + 1]                                    # rows start 2 bytes off a 16-byte boundary, stride V + 3
+        x = xd.cpu().float()
+        probs, p, rec = ops.filtered_probs(xd, T, top_k, top_p, torch.arange(3, dtype=torch.int64, device="cuda"))
+        got = probs.float().cpu().numpy()
+    else:
+        x = x.to(torch.bfloat16)
+        got = _filter_rows(x.cuda(), T, top_k, top_p)
+    want = O.target_probs(x.float().numpy(), T, "bf16", top_k or None, top_p or None)
+    assert np.array_equal(got, want), [(int((got[r] != want[r]).sum()), int((got[r] > 0).sum()), int((want[r] > 0).sum())) for r in range(3)]
+
+
+@GPU
 @pytest.mark.parametrize("shape", ["one_bin", "quantised", "subnormal", "beyond_the_levels"])
 @pytest.mark.parametrize("top_k,top_p", [(50, 0.0), (0, 0.9), (3000, 0.35), (0, 0.999)], ids=["k50", "p09", "k3000_p035", "p0999"])
 def test_rs_filter_float32_levels(shape, top_k, top_p):

@@ -352,6 +352,55 @@ def test_chunk_loop_on_device_arrays_equals_the_callback_contract(tmp_path, back
 
 
 # ----------------------------------------------------------------------------- the reference's own acceptance test, in its own shape
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("mode", ["autoregressive", "jacobi_loop", "jacobi_callbacks", "jacobi_T08"])
+def test_paged_layout_decodes_like_the_contiguous_cache(tmp_path, backend, mode, monkeypatch):
+    """``Config(kv_cache_layout="paged")``: the reference's memory model (a pool of 256-token blocks, K/V wherever the block
+    table says, slot mapping per forward: layers/attention.py:10-40, MR:965-986, 1204-1265) behind the same decoders — the consumer
+    of jf_engine_fill inside the package.  Same tokens and stats as the contiguous layout request by request:
+    AR, greedy Jacobi through the chunk loop on device arrays (slot mapping from the loop's device lengths: PagedFill.fill_device) and
+    through the callback contract (PagedFill.fill = MR:1204-1265), and T = 0.8 — with prompts that start next to and cross a
+    256-token block edge, more requests than cache rows (blocks are handed back and re-used in another order) and two block lengths."""
+    import numpy as np
+    monkeypatch.setenv("JF_INIT_STD", "0.3")
+    monkeypatch.setenv("JF_DTYPE", "float32")
+    base = dict(vocab_size=320, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=2, max_position_embeddings=1024, rms_norm_eps=1e-6, rope_theta=10000.0,
+                tie_word_embeddings=False, eos_token_id=-1, pad_token_id=318, model_type="qwen2")
+    (tmp_path / "config.json").write_text(json.dumps(base))
+    rng = np.random.default_rng(11)
+    lens = [5, 254, 256, 31, 257, 9, 250, 40, 511 - 60, 3]
+    prompts = [[int(x) for x in rng.integers(0, 300, size=n)] for n in lens]
+    budgets = [int(rng.integers(6, 48)) for _ in prompts]
+    strategy = "autoregressive" if mode == "autoregressive" else "jacobi"
+    T = 0.8 if mode == "jacobi_T08" else 0.0
+    monkeypatch.setenv("JF_ENGINE_LOOP", "0" if mode == "jacobi_callbacks" else "1")
+    sps = [SamplingParams(temperature=T, max_tokens=b, ignore_eos=True, decode_strategy=strategy, jacobi_block_len=8 if i % 2 else 5)
+           for i, b in enumerate(budgets)]
+
+    def run(layout):
+        torch.manual_seed(3)
+        random.seed(3)
+        llm = LLM(str(tmp_path), tokenizer_path="none", device=dev, max_model_len=640, max_num_batched_tokens=4096, max_num_seqs=4,
+                  kv_cache_layout=layout)
+        assert llm.model_runner.paged == (layout == "paged")
+        out = llm.generate(prompts, sps, use_tqdm=False)
+        dec = llm.model_runner.jacobi_decoder
+        bm = llm.scheduler.block_manager
+        assert not bm.used_block_ids                                  # every block came back
+        return [o["token_ids"] for o in out], (dict(dec.stats) if dec is not None else None)
+
+    with use_backend(backend):
+        dev = device_for(backend)
+        want = run("contiguous")
+        got = run("paged")
+    assert all(len(t) >= b for t, b in zip(want[0], budgets)) if strategy == "autoregressive" else all(len(t) > 0 for t in want[0])
+    assert got[0] == want[0]
+    assert got[1] == want[1]
+    with pytest.raises(ValueError):
+        Config(str(tmp_path), kv_cache_layout="rows")
+
+
 def _per_position_js(a, b, V):
     """Mean over positions of the Jensen-Shannon divergence (natural log) between the empirical token distributions of two sample
     sets (lists of token-id lists) at that position — compute_token_distributions + compare_distributions(metric="js") of
