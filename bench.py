@@ -406,7 +406,7 @@ def nongreedy_section(model, cfg, weights, tuned, P: int = 64, L: int = 32, temp
                                                            "bound": "hbm", "achieved": fl["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fl["gbs"] / HBM_PEAK_GBS,
                                                            "timing": stf.timing("rs_filter"),
                                                            "kernel": "rs_filter_zone_kernel (+ rs_filter_hist_kernel over the rows it leaves: none here) — jf_rs_filter: one 48-byte "
-                                                                     "record per row instead of the filtered tensor; counts of the row's bf16 scaled-logit patterns in 16 KB of LDS, "
+                                                                     "record per row instead of the filtered tensor; counts of the row's bf16 scaled-logit patterns in 32 KB of LDS, "
                                                                      "three rows per CU, exact sum / top-k cut / nucleus / tie groups as sums over the occupied patterns, the row read "
                                                                      "a second time for the last kept id of a tie group (bytes = the logits twice)"},
                         note="prefill included, the same prompts and token budget as the unfiltered run above (ms_per_step comparable); random-init weights: the kept sets end inside ties of equal bf16 "

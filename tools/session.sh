@@ -67,6 +67,17 @@ filter)               # round 6: jf_rs_filter as records (bf16: pattern counts i
     timeout 600 python tools/microbench_rs_filter.py "$@" 2>&1 | grep -v amdgpu.ids | tee $O/microbench.txt
     timeout 900 python tools/engine_sections.py --repeat 1 2>&1 | grep "JF_ENGINE_LOOP" | tee $O/sections.txt
     ;;
+filter_trace)         # round 6: in-kernel stamps of rs_filter_zone_kernel's workgroup 0 (tools/build_exp.sh flttrace -DJF_EXP_FLT_TRACE first) + rows-per-CU A/B (zn8 / zn4 builds)
+    JF_LIB=tools/exp/libjf_exp_flttrace.so timeout 300 python tools/rs_filter_trace.py 2>&1 | grep -v amdgpu.ids | tee $O/trace.txt
+    for L in zn8 zn4; do [ -f tools/exp/libjf_exp_$L.so ] && { echo "== $L"; JF_LIB=tools/exp/libjf_exp_$L.so timeout 200 python tools/microbench_rs_filter.py 2>&1 | grep "R= 1984"; }; done | tee $O/waves.txt
+    ;;
+paged)                # round 6: the paged KV layout (Config.kv_cache_layout="paged", the consumer of jf_engine_fill) against the contiguous one: parity tests + engine throughput
+    timeout 900 $PYT tests/test_llm_api.py tests/test_engine_decoder.py -m gpu -x -n 4 -k "paged" 2>&1 | tail -3
+    for MODE in "jacobi greedy" "jacobi T=0.8" "autoregressive"; do
+        timeout 400 python tools/engine_throughput.py --only "$MODE" --max-tokens 96 2>&1 | grep "tok/s" | sed 's/^/contiguous: /'
+        JF_KV_LAYOUT=paged timeout 400 python tools/engine_throughput.py --only "$MODE" --max-tokens 96 2>&1 | grep "tok/s" | sed 's/^/paged:      /'
+    done | tee $O/throughput.txt
+    ;;
 gputests)             # the whole GPU suite + smoke
     timeout 2400 $PYT tests -m gpu -n 8 --durations=10 > $O/gputest.log 2>&1; tail -14 $O/gputest.log
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
