@@ -720,6 +720,38 @@ class EngineStepper:
 # --------------------------------------------------------------------------------------------
 # the loop around the engine steps (jf_engine_loop_commit)
 # --------------------------------------------------------------------------------------------
+class _MailboxPool:
+    """Mapped host memory for the engine loops' records, allocated once and handed from loop to loop.  A loop lives for one chunk;
+    allocating and freeing its mailbox per chunk (hipHostMalloc / hipHostFree: a map and an unmap of GPU-visible host pages each
+    time) lost a record twice in 25 600 cases of the 100 x fuzz soak with twelve processes on one GPU — the commit launch had run, the
+    stream had drained, and the freshly mapped word still read 0 (profiles/soak_r06.txt).  A mailbox that stays mapped has no such
+    window: its sequence numbers simply continue from loop to loop (nothing to re-zero), and a chunk no longer pays two driver calls."""
+    _free: dict = {}                                           # (library, device index, ints) -> [(pointer, last sequence number)]
+
+    @classmethod
+    def take(cls, dev: torch.device, n_ints: int):
+        size = 128
+        while size < n_ints:
+            size *= 2
+        # (the library object is part of the key — and so kept alive: the memory belongs to the library that allocated it; the
+        #  tests' CPU stand-in owns its blocks per instance)
+        key = (N.lib(), dev.index if dev.index is not None else -1, size)
+        lst = cls._free.get(key)
+        if lst:
+            ptr, seq = lst.pop()
+            return key, ptr, seq
+        ptr = C.c_void_p()
+        N.check(key[0].jf_host_alloc(size * 4, C.byref(ptr)), "jf_host_alloc")
+        return key, ptr, 0
+
+    @classmethod
+    def give(cls, key, ptr, seq: int) -> None:
+        if seq > 0x7F000000:                                   # (a mailbox retires long before its 32-bit sequence number wraps)
+            key[0].jf_host_free(ptr)
+            return
+        cls._free.setdefault(key, []).append((ptr, int(seq)))
+
+
 class EngineLoop:
     """One block-length group of an engine decoder's chunk on the device: the draft as ONE [B, L] tensor that the step's next
     draft replaces (two buffers, alternating), the rows' token budgets, cached lengths, next positions and committed-token
@@ -745,12 +777,10 @@ class EngineLoop:
         self.draft: Optional[torch.Tensor] = None
         lib = N.lib()
         self.n_ints = N.EL_HDR + n
-        ptr = C.c_void_p()
-        N.check(lib.jf_host_alloc(self.n_ints * 4, C.byref(ptr)), "jf_host_alloc")
+        self._mb_key, ptr, self.seq = _MailboxPool.take(dev, self.n_ints)      # (a mailbox of an earlier loop: its numbering continues)
         self._mb_ptr = ptr
         self.mailbox = np.ctypeslib.as_array((C.c_int32 * self.n_ints).from_address(ptr.value))
         self._wait = lib.jf_mailbox_wait
-        self.seq = 0
         self.timeout_us = int(wait_timeout_s * 1e6)
         self.flags = MultiblockLoop.publish_flags(dev)
         self.version = 0                                       # bumped by compact(): callers cache per-batch tensors against it
@@ -766,7 +796,7 @@ class EngineLoop:
             if self.device.type == "cuda":                     # a queued commit may still be mailing
                 torch.cuda.synchronize(self.device)
             self.mailbox = None
-            N.lib().jf_host_free(self._mb_ptr)
+            _MailboxPool.give(self._mb_key, self._mb_ptr, self.seq)
             self._mb_ptr = None
 
     def __del__(self):
