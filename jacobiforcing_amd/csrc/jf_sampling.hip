@@ -1382,7 +1382,11 @@ __device__ __forceinline__ float fh_solve(FhShared &sh, const uint32_t *hist, co
     const bool tie2_needed = p_on && !all2 && c2 > 0 && c2 < n_eq2;
     if (p_on && !all2 && c2 == 0) rec.tie2 = -1;
     if (tie1_needed && need1 == 0) rec.tie1 = -1;
+#if defined(JF_EXP_ZN_STOP) && JF_EXP_ZN_STOP == 2                              // (experiment: no tie pass)
+    const bool pass2 = false;
+#else
     const bool pass2 = (tie1_needed && need1 > 0) || tie2_needed;
+#endif
     if (pass2) {
         const int64_t ntiles = (V + TILE - 1) / TILE;
         __syncthreads();
@@ -1713,6 +1717,10 @@ __global__ __launch_bounds__(ZN_TPB, JF_ZN_WAVES) void rs_filter_zone_kernel(con
     }
     __syncthreads();
     FH_STAMP(10);
+#if defined(JF_EXP_ZN_STOP) && JF_EXP_ZN_STOP == 1                              // (experiment: the count pass alone)
+    if (tid == 0) { filt[r] = rec; p_draft[r] = 0.f; row_max[r] = INFINITY; row_sumexp[r] = RS_PROB_ROW; }
+    return;
+#endif
     // ---- 2. the list of occupied patterns, largest value first: positive magnitudes downwards, the small magnitudes, negative magnitudes upwards.
     //         List place L < 4096 is the positive magnitude LO16 + 4095 - L, L >= 4096 the negative magnitude LO16 + L - 4096; wavefront w takes
     //         the places [1024 w, 1024 w + 1024), a lane the places 64 j + lane of them (16 reads, adjacent lanes two words apart).
