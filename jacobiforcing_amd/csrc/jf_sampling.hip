@@ -1417,10 +1417,21 @@ __device__ __forceinline__ float fh_solve(FhShared &sh, const uint32_t *hist, co
             const uint32_t bLo2 = (uint32_t)(b_lo & 0xFFFF) * 0x00010001u, bSp2 = (uint32_t)((b_hi - b_lo) & 0xFFFF) * 0x00010001u;
             const bool rangeA = wantA && a_hi >= a_lo, rangeB = wantB && b_hi >= b_lo;
             long long cumA = 0, cumB = 0;
-            for (int64_t t0 = 0; t0 < ntiles; t0 += NB) {
-                u32x4 v[NB];
+            constexpr int NPRE = FAST ? NB : 1;                             // (the zone kernel prefetches; the 1 024-thread kernel of the rare rows has no registers for it)
+            u32x4 v[NB], vn[NPRE];
+            auto load_batch = [&](int64_t tb, u32x4 (&dst)[NB]) {
 #pragma unroll
-                for (int k = 0; k < NB; ++k) { const int64_t e0 = (t0 + k) * TILE + (int64_t)tid * EPV; if (t0 + k < ntiles && e0 < V) v[k] = rs_load_vec<JF_BF16>(row, e0); }
+                for (int k = 0; k < NB; ++k) { const int64_t e0 = (tb + k) * TILE + (int64_t)tid * EPV; if (tb + k < ntiles && e0 < V) dst[k] = rs_load_vec<JF_BF16>(row, e0); }
+            };
+            if constexpr (FAST) load_batch(0, v);
+            for (int64_t t0 = 0; t0 < ntiles; t0 += NB) {
+                if constexpr (FAST) {                                        // the next batch's loads, in front of this batch's arithmetic and its barrier
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) {
+                        const int64_t e0 = (t0 + NB + k) * TILE + (int64_t)tid * EPV;
+                        if (t0 + NB + k < ntiles && e0 < V) vn[k] = rs_load_vec<JF_BF16>(row, e0);
+                    }
+                } else load_batch(t0, v);
 #pragma unroll
                 for (int k = 0; k < NB; ++k) {
                     if (t0 + k >= ntiles) continue;                          // (workgroup-uniform)
@@ -1446,6 +1457,10 @@ __device__ __forceinline__ float fh_solve(FhShared &sh, const uint32_t *hist, co
 #pragma unroll
                     for (int k = 0; k < NB; ++k) if (t0 + k < ntiles) { cumA += sh.tileA[t0 + k]; cumB += sh.tileB[t0 + k]; }
                     if ((!wantA || cumA >= need1) && (!wantB || cumB >= c2)) break;   // (workgroup-uniform)
+                }
+                if constexpr (FAST) {
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) v[k] = vn[k];
                 }
             }
         }

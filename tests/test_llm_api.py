@@ -369,9 +369,9 @@ def test_paged_layout_decodes_like_the_contiguous_cache(tmp_path, backend, mode,
                 tie_word_embeddings=False, eos_token_id=-1, pad_token_id=318, model_type="qwen2")
     (tmp_path / "config.json").write_text(json.dumps(base))
     rng = np.random.default_rng(11)
-    lens = [5, 254, 256, 31, 257, 9, 250, 40, 511 - 60, 3]
+    lens = [5, 254, 256, 257, 9, 250, 511 - 60]
     prompts = [[int(x) for x in rng.integers(0, 300, size=n)] for n in lens]
-    budgets = [int(rng.integers(6, 48)) for _ in prompts]
+    budgets = [int(rng.integers(6, 22)) for _ in prompts]
     strategy = "autoregressive" if mode == "autoregressive" else "jacobi"
     T = 0.8 if mode == "jacobi_T08" else 0.0
     monkeypatch.setenv("JF_ENGINE_LOOP", "0" if mode == "jacobi_callbacks" else "1")
