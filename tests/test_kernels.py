@@ -1095,6 +1095,34 @@ def test_convergence_launch_keeps_its_register_budget():
 
 # ------------------------------------------------------------------------------------- the loop around the engine steps (f3)
 @pytest.mark.parametrize("backend", BACKENDS)
+def test_engine_loop_mailboxes_are_pooled_and_their_sequence_numbers_continue(backend):
+    """A loop lives for one chunk; its mailbox (mapped host memory the device mails and the host polls) does not: ops._MailboxPool
+    hands the same block from loop to loop and the sequence numbers continue, so nothing is mapped, unmapped or re-zeroed per chunk
+    (profiles/soak_r06.txt: a mailbox allocated per chunk lost its first record twice in 25 600 soak cases)."""
+    with use_backend(backend):
+        dev = device_for(backend)
+        seen = []
+        for it in range(3):
+            B, L = 3 + it, 4                                        # (same size class: 128 words)
+            lp = ops.EngineLoop(N.EL_KIND_GREEDY, L, dev, [10] * B, [8] * B)
+            seen.append((lp._mb_ptr.value, lp.seq))
+            rows = torch.zeros((B, N.ENGINE_ROW_INTS), dtype=torch.int32, device=dev)
+            rows[:, 0], rows[:, 1], rows[:, 3] = 2, 1, 1             # acc_len 2, one new token, still active
+            toks = torch.full((B, L), 7 + it, dtype=torch.int64, device=dev)
+            lp.set_draft(torch.zeros((B, L), dtype=torch.int64))
+            for _ in range(2):
+                lp.next_buffer()
+                lp.commit(rows, toks, torch.zeros((1,), dtype=torch.int64, device=dev))
+                n, e, a, f = lp.wait()
+                assert n.tolist() == [1] * B and a.tolist() == [1] * B
+            ring, rl = lp.tokens_host()
+            assert rl.tolist() == [2] * B and ring[0, :2].tolist() == [7 + it] * 2
+            lp.close()
+        assert seen[0][0] == seen[1][0] == seen[2][0]               # one block, three loops
+        assert [s for _, s in seen] == [seen[0][1], seen[0][1] + 2, seen[0][1] + 4]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("kind", [N.EL_KIND_GREEDY, N.EL_KIND_SAMPLING], ids=["greedy_rows", "sampling_rows"])
 @pytest.mark.parametrize("B,L", [(1, 2), (7, 5), (64, 32), (300, 9)])
 def test_engine_loop_commit_maintains_the_device_arrays(B, L, kind, backend):
