@@ -530,37 +530,19 @@ extern "C" int jf_mb_verify(const void *logits, int dtype, int64_t R, int64_t V,
 // ------------------------------------------------------------------------------------------------
 // jf_mb_loop_*: the loop around the step (include/jacobiforcing.h)
 // ------------------------------------------------------------------------------------------------
-// A mailbox is only as good as its mapping: the device writes it with system-scope stores and the host polls it, nothing else ever
-// checks that the two look at the same memory.  Round 6's soak (twelve processes on one GPU, a mailbox mapped and unmapped around
-// every decoder call) lost the first record of a fresh mailbox twice in 25 600 cases — the launch had run, the word still read 0
-// (profiles/soak_r06.txt).  So a fresh block is PROVEN before it is handed out: a one-lane launch stores a magic word the way
-// the kernels mail, the stream is drained, the host must read it back; a block that fails is kept out of circulation (not freed:
-// freeing is the churn) and another one is tried.  Allocation is rare (ops keeps mailboxes in a pool), the probe costs one launch.
-__global__ void host_probe_kernel(int32_t *word, int32_t v) { __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-
+// (Round 6 tried a probe here — a one-lane launch on a stream of its own that mails a magic word the host must read back before a
+//  fresh block is handed out — after the soak had lost the first record of a freshly mapped mailbox twice in 25 600 cases.  It never
+//  fired in ~140 000 allocations, and with it the GPU suite under `pytest -n 8` stalled twice in a subprocess-spawning test (72 s,
+//  then a 900 s timeout: profiles/soak_r06.txt), so it is gone again.  What fixed the lost record is that mailboxes are no longer
+//  mapped and unmapped per chunk: ops._MailboxPool.)
 extern "C" int jf_host_alloc(size_t bytes, void **out) {
     if (!out || bytes == 0) return fail(JF_E_INVALID, "jf_host_alloc: bad argument");
-    static std::atomic<int> magic{0x5A5A0000};
-    for (int attempt = 0; attempt < 4; ++attempt) {
-        void *p = nullptr;
-        const hipError_t e = hipHostMalloc(&p, bytes < 4 ? 4 : bytes, hipHostMallocMapped | hipHostMallocCoherent);
-        if (e != hipSuccess) { (void)hipGetLastError(); return fail(JF_E_LAUNCH, "jf_host_alloc: %s", hipGetErrorString(e)); }
-        memset(p, 0, bytes);
-        const int32_t want = ++magic;
-        hipStream_t s = nullptr;
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); s = nullptr; }
-        host_probe_kernel<<<1, 1, 0, s>>>((int32_t *)p, want);
-        const hipError_t le = hipGetLastError(), se = hipStreamSynchronize(s);
-        if (s) (void)hipStreamDestroy(s);
-        if (le != hipSuccess || se != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(p); return fail(JF_E_LAUNCH, "jf_host_alloc: the probe launch failed (%s)", hipGetErrorString(le != hipSuccess ? le : se)); }
-        if (__atomic_load_n((const int32_t *)p, __ATOMIC_ACQUIRE) == want) {
-            *(volatile int32_t *)p = 0;
-            *out = p;
-            return JF_OK;
-        }
-        fprintf(stderr, "[jacobiforcing] jf_host_alloc: a store of the device did not arrive in freshly mapped host memory %p (attempt %d): block set aside\n", p, attempt + 1);
-    }
-    return fail(JF_E_LAUNCH, "jf_host_alloc: device stores do not arrive in mapped host memory");
+    void *p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(JF_E_LAUNCH, "jf_host_alloc: %s", hipGetErrorString(e)); }
+    memset(p, 0, bytes);
+    *out = p;
+    return JF_OK;
 }
 extern "C" int jf_host_free(void *p) {
     if (p && hipHostFree(p) != hipSuccess) { (void)hipGetLastError(); return fail(JF_E_LAUNCH, "jf_host_free failed"); }
