@@ -430,14 +430,13 @@ class MultiblockLoop:
         self.kv_len = kv_len
         self.drv, self.draws = drv, draws
         self.n_ints = N.mailbox_ints(b.P)
-        ptr = C.c_void_p()
-        N.check(lib.jf_host_alloc(self.n_ints * 4, C.byref(ptr)), "jf_host_alloc")
+        # (a mailbox of an earlier loop, mapped once: its sequence numbers continue — _MailboxPool below has the reason)
+        self._mb_key, ptr, self.seq = _MailboxPool.take(torch.device(dev), self.n_ints)
         self._mb_ptr = ptr
         self.mailbox = np.ctypeslib.as_array((C.c_int32 * self.n_ints).from_address(ptr.value))
         self._hdr = self.mailbox[:N.MB_MAILBOX_HDR]
         self._wait = lib.jf_mailbox_wait
         self._views, self._vi = {}, {}
-        self.seq = 0
         self.timeout_us = int(wait_timeout_s * 1e6)
         fill = b.params.pad_token_id if b.params.pad_token_id is not None else 0
         self.c_loop = N.MbLoop(
@@ -459,7 +458,7 @@ class MultiblockLoop:
                 torch.cuda.synchronize(self.batch.device)
             self.mailbox = None
             self._hdr = None
-            N.lib().jf_host_free(self._mb_ptr)
+            _MailboxPool.give(self._mb_key, self._mb_ptr, self.seq)
             self._mb_ptr = None
 
     def __del__(self):
@@ -721,11 +720,13 @@ class EngineStepper:
 # the loop around the engine steps (jf_engine_loop_commit)
 # --------------------------------------------------------------------------------------------
 class _MailboxPool:
-    """Mapped host memory for the engine loops' records, allocated once and handed from loop to loop.  A loop lives for one chunk;
-    allocating and freeing its mailbox per chunk (hipHostMalloc / hipHostFree: a map and an unmap of GPU-visible host pages each
-    time) lost a record twice in 25 600 cases of the 100 x fuzz soak with twelve processes on one GPU — the commit launch had run, the
-    stream had drained, and the freshly mapped word still read 0 (profiles/soak_r06.txt).  A mailbox that stays mapped has no such
-    window: its sequence numbers simply continue from loop to loop (nothing to re-zero), and a chunk no longer pays two driver calls."""
+    """Mapped host memory for the loops' records (EngineLoop, MultiblockLoop), allocated once and handed from loop to loop.  An engine
+    loop lives for one chunk; allocating and freeing its mailbox per chunk (hipHostMalloc / hipHostFree: a map and an unmap of
+    GPU-visible host pages each time) lost a record twice in 25 600 cases of the 100 x fuzz soak with twelve processes on one GPU —
+    the commit launch had run, the stream had drained, and the freshly mapped word still read 0; the multiblock loop, which maps one
+    mailbox per decoder, lost its first record once in 4 016 cases of the same soak (profiles/soak_r06.txt).  A mailbox that stays
+    mapped has no such window: its sequence numbers simply continue from loop to loop (nothing to re-zero), and a chunk no longer
+    pays two driver calls."""
     _free: dict = {}                                           # (library, device index, ints) -> [(pointer, last sequence number)]
 
     @classmethod
