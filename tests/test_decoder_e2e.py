@@ -191,6 +191,33 @@ def test_compacted_logits_equal_rectangular(backend):
         assert sum(r[0] for r in out[True][2]) < sum(r[0] for r in out[False][2])
 
 
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_loop_mailboxes_are_pooled_and_their_sequence_numbers_continue(backend):
+    """ops.MultiblockLoop takes its mailbox from ops._MailboxPool like the engine loops do: a second loop of the same size gets the
+    first one's block, still mapped, and numbers its launches on from where the first one stopped — a freshly mapped mailbox lost its
+    first record once in 4 016 cases of the round-6 loop soak (profiles/soak_r06.txt)."""
+    with use_backend(backend):
+        dev = device_for(backend)
+        P, n = 5, 8
+        prm = ops.MultiblockParams(n=n, K=2, r=0.85, n_gram_pool_size=4, eos_token_id=None, pad_token_id=0)
+        fB, fT, fkv = (N.DESC_FIELDS.index(k) for k in ("B", "T", "kv_len"))
+        g = np.random.default_rng(2)
+        seen = []
+        for it in range(3):
+            batch = ops.MultiblockBatch(P, prm, dev)
+            kvl = torch.zeros(P, dtype=torch.int32, device=dev)
+            lp = ops.MultiblockLoop(batch, kv_len=kvl, t_cap=64, t_align=1, valid_align=8, compact=True, cand_rows=3, order=1, max_seq_len=1 << 20)
+            seen.append((lp._mb_ptr.value, lp.seq))
+            for _ in range(2):
+                ids = torch.from_numpy(g.integers(1, 1000, size=(P, n))).to(dev)
+                kv = g.integers(5, 500, size=P).astype(np.int32)
+                s = lp.begin(ids, torch.from_numpy(kv))
+                assert s.seq == lp.seq and (s.d[:, fB] == 1).all() and (s.d[:, fT] == n).all() and (s.d[:, fkv] == kv).all() and s.Rtot == P
+            lp.close()
+        assert seen[0][0] == seen[1][0] == seen[2][0]
+        assert [q for _, q in seen] == [seen[0][1], seen[0][1] + 2, seen[0][1] + 4]
+
+
 @pytest.mark.gpu
 def test_mailbox_tables_are_visible_when_the_sequence_word_is():
     """jf_mb_loop_begin copies every prompt's descriptor into the mailbox and stamps it in ONE launch: when the host sees the
