@@ -84,3 +84,28 @@ def test_sampling_at_a_low_temperature_follows_the_trained_language(backend, mon
             agree = np.mean([np.mean(np.asarray(o) == np.asarray(w)) for o, w in zip(out, want)])
             assert agree > 0.9, (filters, agree)
             assert st["tokens_accepted"] / st["num_jacobi_iterations"] / len(prompts) > 2.0
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_hf_seam_drivers_on_the_trained_checkpoint(backend):
+    """The HF-style entry points on the same checkpoint: the single-block driver (drivers/sb_math500.decode_one over
+    hf_seam.jacobi_forward_greedy = SB:140-276) and the batch-1 multiblock decoder behind jacobi_forward_greedy_multiblock decode
+    exactly what drivers/ar_baseline.generate_greedy decodes token by token, in fewer than half as many forwards."""
+    import types
+    from jacobiforcing_amd import hf_seam, ops
+    from jacobiforcing_amd.drivers import ar_baseline, sb_math500
+    from jacobiforcing_amd.engine.multiblock_decoder import MultiblockJacobiDecoder
+    from jacobiforcing_amd.modeling.qwen2 import Qwen2Model, load_model_directory
+    with use_backend(backend):
+        dev = torch.device(device_for(backend))
+        cfg, w = load_model_directory(str(TOY), dev, dtype=torch.float32)
+        model = Qwen2Model(cfg, w)
+        prompt = _prompts()[2]
+        me = types.SimpleNamespace(jf_backend=hf_seam.Qwen2Backend(model, max_seq_len=512, max_rows=1, max_tokens=64))
+        row, toks = sb_math500.decode_one(me, prompt, n=16, eos_id=None, alt_eos_id=None, max_new_tokens=80, max_calls=64, rng=random.Random(0))
+        ar, _ = ar_baseline.generate_greedy(model, prompt, max_new_tokens=len(toks))
+        assert toks == ar and row["avg_iter_per_token"] < 0.5, row            # more than two tokens per forward
+        prm = ops.MultiblockParams(n=16, K=2, r=0.85, n_gram_pool_size=4, eos_token_id=None, pad_token_id=cfg.pad_token_id)
+        dec = MultiblockJacobiDecoder(model, 1, prm, max_seq_len=512)
+        stats, _, iters = dec.generate([prompt], max_new_tokens=80, max_calls=1 << 20, seed=3)
+        assert stats[0].token_ids[:80] == ar[:80] and len(stats[0].token_ids) / stats[0].total_iterations > 2.0
