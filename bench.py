@@ -33,6 +33,9 @@ Extra objects on the line:
                   through LLM.generate, with loop_body: body / gpu_idle / host_gap of their iteration (engine/chunk_loop.py).
   scripted_acceptance — the same K-step measurement with the synthetic acceptance model switched on (the random
                   weights accept ~1 token per forward; a Jacobi-Forcing checkpoint accepts ~4).
+  trained_toy   — tokens per forward MEASURED on trained weights, of a toy (tests/golden/toy_periodic: 0.3 MB, a periodic language):
+                  the engine's and the multiblock decoder through LLM.generate, greedy outputs checked against greedy AR.  The 7B
+                  checkpoint is not in the image: its tokens per forward stay unmeasured.
 """
 from __future__ import annotations
 
@@ -436,6 +439,51 @@ def nongreedy_section(model, cfg, weights, tuned, P: int = 64, L: int = 32, temp
                 value=toks / dt, unit="tokens/s", tokens=toks, seconds=dt, iterations=its, ms_per_step=dt / its * 1e3,
                 tokens_per_forward=toks / (its * P),
                 roofline=out_roof, rs_step=out_step, loop_body=loop_body, filtered=filtered)
+
+
+def trained_toy_section(n_new: int = 96):
+    """Tokens per forward MEASURED on trained weights — of a toy: tests/golden/toy_periodic (a 0.3 MB two-layer Qwen2 trained by
+    tests/golden/train_toy_checkpoint.py to continue token[i] = PERM[token[i - 6]]), decoded through LLM.generate by the engine's
+    single-block decoder and by the multiblock decoder, every greedy output compared with greedy AR.  The headline model is random-init
+    (1.0 token per forward) and `scripted_acceptance` plants its logits; the 7B checkpoint BASELINE names is not in the image, so its
+    tokens per forward stay unmeasured — this section only shows the decoders accepting several tokens per forward on real logits."""
+    import random
+    import numpy as np
+    from jacobiforcing_amd import LLM, SamplingParams
+    toy = ROOT / "tests" / "golden" / "toy_periodic"
+    sys.path.insert(0, str(toy.parent))
+    from train_toy_checkpoint import corpus
+    old = os.environ.get("JF_DTYPE")
+    os.environ["JF_DTYPE"] = "float32"
+    try:
+        torch.manual_seed(0)
+        random.seed(0)
+        llm = LLM(str(toy), tokenizer_path="none", device="cuda", max_model_len=512, max_num_batched_tokens=8192, max_num_seqs=16)
+        lens = (13, 7, 25, 18, 120, 161, 40, 9, 77, 33, 50, 21)
+        prompts = [row[:n].tolist() for row, n in zip(corpus(np.random.default_rng(5), len(lens), 300), lens)]
+        ar = [o["token_ids"] for o in llm.generate(prompts, SamplingParams(temperature=0.0, max_tokens=n_new, ignore_eos=True), use_tqdm=False)]
+        res = {}
+        for L in (16, 32):
+            llm.model_runner.jacobi_decoder = None
+            out = llm.generate(prompts, SamplingParams(temperature=0.0, max_tokens=n_new, ignore_eos=True, decode_strategy="jacobi", jacobi_block_len=L), use_tqdm=False)
+            st = llm.model_runner.jacobi_decoder.stats
+            res[f"engine_single_block_n{L}"] = {"tokens_per_forward": round(st["tokens_accepted"] / st["num_jacobi_iterations"] / len(prompts), 3),
+                                                "equals_ar": all(o["token_ids"][:n_new] == a for o, a in zip(out, ar))}
+            out = llm.generate(prompts, SamplingParams(temperature=0.0, max_tokens=n_new, ignore_eos=True,
+                                                       decode_strategy="jacobi_multiblock_rejection_recycling", jacobi_block_len=L), use_tqdm=False)
+            lm = llm.model_runner.last_multiblock
+            tk, it = sum(len(s.token_ids) for s in lm["stats"]), sum(s.total_iterations for s in lm["stats"])
+            res[f"multiblock_K2_n{L}"] = {"tokens_per_forward": round(tk / it, 3), "equals_ar": all(o["token_ids"][:n_new] == a for o, a in zip(out, ar))}
+        llm.exit()
+        return {"model": "tests/golden/toy_periodic: a TRAINED toy (2 layers, hidden 64, vocabulary 64; token[i] = PERM[token[i - 6]]), float32 — not the 7B checkpoint",
+                "prompts": len(prompts), "new_tokens_per_prompt": n_new, "autoregressive_tokens_per_forward": 1.0, "decoders": res,
+                "verified": all(v["equals_ar"] for v in res.values()),
+                "note": "measured acceptance on real logits and a real KV cache; up to 6 tokens per forward are possible in this language"}
+    finally:
+        if old is None:
+            os.environ.pop("JF_DTYPE", None)
+        else:
+            os.environ["JF_DTYPE"] = old
 
 
 def engine_greedy_section(model, cfg, weights, tuned, P: int = 64, L: int = 32, max_tokens: int = 64):
@@ -935,7 +983,8 @@ def main():
         for key, fn in (("single_block", lambda: single_block_section(model, cfg, tuned)),
                         ("nongreedy", lambda: nongreedy_section(model, cfg, weights, tuned)),
                         ("engine_greedy", lambda: engine_greedy_section(model, cfg, weights, tuned)),
-                        ("vs_ar", lambda: vs_ar_section(model, cfg, prm, tuned, vocab_hi, args.robust))):
+                        ("vs_ar", lambda: vs_ar_section(model, cfg, prm, tuned, vocab_hi, args.robust)),
+                        ("trained_toy", trained_toy_section)):
             try:
                 out[key] = fn()
             except Exception as e:  # a section must not kill the headline measurement

@@ -39,6 +39,11 @@ for path in sys.argv[1:]:
         print("   nongreedy:", ng)
     if "single_block" in d:
         print(f"   single_block: {d['single_block'].get('value')}   vs_ar: {(d.get('vs_ar') or {}).get('vs_ar')}  iteration cost {(d.get('vs_ar') or {}).get('iteration_cost_in_ar_steps')}")
+    tt = d.get("trained_toy") or {}
+    if tt.get("decoders"):
+        print("   trained toy (measured tokens per forward, == AR " + str(tt.get("verified")) + "): " + "  ".join(f"{k} {v['tokens_per_forward']}" for k, v in tt["decoders"].items()))
+    elif tt:
+        print("   trained toy:", tt)
     cb = d.get("cpu_baseline")
     if cb:
         print(f"   cpu_baseline: {cb.get('value')} {cb.get('unit')} on {cb.get('cores')} cores ({cb.get('kind')})")
